@@ -1,0 +1,8 @@
+"""
+atlite_amd - MI355X (gfx950) implementation of PyPSA/atlite's convert_and_aggregate hot path.
+
+HIP kernels + C ABI: ``atlite_amd/csrc`` -> ``atlite_amd/lib/libatlite_hip.so``
+(``include/atlite_hip.h``).  Host-side mirror of the reference interface: ``atlite_amd.convert``.
+"""
+
+__version__ = "0.1.0"

@@ -1,0 +1,198 @@
+"""
+ctypes binding of ``libatlite_hip.so`` (C ABI: ``include/atlite_hip.h``).
+
+The library is the product path; there is no CPU fallback.  If the shared object is missing
+or a GPU call fails, an exception is raised - nothing silently reroutes to NumPy.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("ATLITE_HIP_LIB", _HERE / "lib" / "libatlite_hip.so"))
+
+ATL_OK, ATL_E_INVALID, ATL_E_HIP, ATL_E_NOMEM, ATL_E_UNSUPPORTED = 0, -1, -2, -3, -4
+TIME_NONE, TIME_SUM, TIME_MEAN = 0, 1, 2
+WIND_NONE, WIND_LOG, WIND_POWER = 0, 1, 2
+SYN_UNIFORM, SYN_RAYLEIGH, SYN_EXPLOG, SYN_NEGLOG = 0, 1, 2, 3
+
+c_double_p = C.POINTER(C.c_double)
+c_int64_p = C.POINTER(C.c_int64)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class PvInputs(C.Structure):
+    _fields_ = [
+        (n, C.c_void_p)
+        for n in (
+            "d_influx_direct",
+            "d_influx_diffuse",
+            "d_influx_toa",
+            "d_albedo",
+            "d_temperature",
+            "d_solar_altitude",
+            "d_solar_azimuth",
+        )
+    ]
+
+
+class PvParams(C.Structure):
+    _fields_ = [
+        ("c_temp_amb", C.c_double),
+        ("c_temp_irrad", C.c_double),
+        ("r_tmod", C.c_double),
+        ("r_irradiance", C.c_double),
+        ("k_1", C.c_double),
+        ("k_2", C.c_double),
+        ("k_3", C.c_double),
+        ("k_4", C.c_double),
+        ("k_5", C.c_double),
+        ("k_6", C.c_double),
+        ("inverter_efficiency", C.c_double),
+        ("slope", C.c_double),
+        ("azimuth", C.c_double),
+        ("d_cell_slope", C.c_void_p),
+        ("d_cell_azimuth", C.c_void_p),
+        ("altitude_threshold", C.c_double),
+    ]
+
+
+class WindInputs(C.Structure):
+    _fields_ = [("d_wnd", C.c_void_p), ("d_aux", C.c_void_p), ("aux_is_static", C.c_int)]
+
+
+class WindParams(C.Structure):
+    _fields_ = [
+        ("method", C.c_int),
+        ("to_height", C.c_double),
+        ("from_height", C.c_double),
+        ("n_knots", C.c_int),
+        ("h_V", c_double_p),
+        ("h_POWn", c_double_p),
+    ]
+
+
+class HeatParams(C.Structure):
+    _fields_ = [
+        ("threshold_K", C.c_double),
+        ("a", C.c_double),
+        ("constant", C.c_double),
+        ("n_days", C.c_int64),
+        ("d_day_ptr", C.c_void_p),
+    ]
+
+
+class SynthSolar(C.Structure):
+    _fields_ = [
+        ("d_sin_dec", C.c_void_p),
+        ("d_cos_dec", C.c_void_p),
+        ("d_h", C.c_void_p),
+        ("d_lat_rad", C.c_void_p),
+        ("d_tseason", C.c_void_p),
+        ("X", C.c_int64),
+        ("Y", C.c_int64),
+        ("seed", C.c_uint64),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/atlite_hip.h declares
+_vp, _i, _i64, _sz, _d = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_double
+SIGNATURES = {
+    "atl_version": (_i, []),
+    "atl_last_error": (C.c_char_p, []),
+    "atl_device_count": (_i, [C.POINTER(_i)]),
+    "atl_create": (_i, [_i, _vp, C.POINTER(_vp)]),
+    "atl_destroy": (_i, [_vp]),
+    "atl_sync": (_i, [_vp]),
+    "atl_device_name": (_i, [_vp, C.c_char_p, _sz]),
+    "atl_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "atl_free": (_i, [_vp, _vp]),
+    "atl_upload": (_i, [_vp, _vp, _vp, _sz]),
+    "atl_download": (_i, [_vp, _vp, _vp, _sz]),
+    "atl_memset": (_i, [_vp, _vp, _i, _sz]),
+    "atl_timer_start": (_i, [_vp]),
+    "atl_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
+    "atl_set_profiling": (_i, [_vp, _i]),
+    "atl_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_float)]),
+    "atl_agg_create": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "atl_agg_destroy": (_i, [_vp]),
+    "atl_agg_info": (_i, [_vp, c_int64_p, c_int64_p, c_int64_p, c_int64_p]),
+    "atl_spmm_csr": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _vp, _i64]),
+    "atl_pv_convert": (_i, [_vp, C.POINTER(PvInputs), C.POINTER(PvParams), _i64, _i64, _i, _vp]),
+    "atl_pv_convert_aggregate": (
+        _i,
+        [_vp, C.POINTER(PvInputs), C.POINTER(PvParams), _i64, _i64, _vp, _i, _vp, _i64],
+    ),
+    "atl_wind_convert": (
+        _i,
+        [_vp, C.POINTER(WindInputs), C.POINTER(WindParams), _i64, _i64, _i, _vp],
+    ),
+    "atl_wind_convert_aggregate": (
+        _i,
+        [_vp, C.POINTER(WindInputs), C.POINTER(WindParams), _i64, _i64, _vp, _i, _vp, _i64],
+    ),
+    "atl_heat_demand_convert": (_i, [_vp, _vp, C.POINTER(HeatParams), _i64, _i64, _i, _vp]),
+    "atl_heat_demand_convert_aggregate": (
+        _i,
+        [_vp, _vp, C.POINTER(HeatParams), _i64, _i64, _vp, _i, _vp, _i64],
+    ),
+    "atl_runoff_convert": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _vp]),
+    "atl_runoff_convert_aggregate": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _i, _vp, _i64]),
+    "atl_synth_field": (
+        _i,
+        [_vp, _i, C.c_uint64, C.c_uint64, _d, _d, _i, _i64, _i64, _vp],
+    ),
+    "atl_synth_pv_inputs": (
+        _i,
+        [_vp, C.POINTER(SynthSolar), _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    ),
+}
+
+_lib = None
+
+
+class AtliteHipError(RuntimeError):
+    """A HIP runtime failure reported by libatlite_hip.so."""
+
+
+def load():
+    """Load (once) and return the ctypes handle; raise loudly if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C atlite_amd/csrc`. There is no CPU fallback."
+        )
+    if os.environ.get("ATLITE_HIP_NO_TORCH", "0") != "1":
+        # torch bundles its own libamdhip64.so.7; importing it first makes this library bind
+        # to the same HIP runtime, so device pointers can be shared with torch tensors.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    """Map an ATL_E_* return code to the Python exception class the reference would raise."""
+    if rc == ATL_OK:
+        return
+    msg = load().atl_last_error().decode("utf-8", "replace")
+    if rc == ATL_E_INVALID:
+        raise ValueError(msg)
+    if rc == ATL_E_NOMEM:
+        raise MemoryError(msg)
+    if rc == ATL_E_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise AtliteHipError(msg)

@@ -1,0 +1,84 @@
+// Internal declarations shared by the runtime (atl_runtime.cpp) and the kernels
+// (atl_kernels.hip).  Not installed; the public surface is include/atlite_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "atlite_hip.h"
+
+namespace atl {
+
+// ---- geometry of the fused segment-reduce kernel -------------------------------------
+constexpr int kLanes = 64;               // gfx950 wavefront
+constexpr int kSegCells = 2 * kLanes;    // one wave covers 128 consecutive cells, 2 per lane
+constexpr int kBatch = 8;                // output slots reduced per butterfly
+constexpr int kWavesPerBlock = 4;        // 256-thread workgroups, waves independent
+constexpr int kMaxKnots = 2048;          // wind power-curve table limit (LDS: 3 x 16 KiB)
+
+void set_error(const char *fmt, ...);
+
+#define ATL_HIP_TRY(expr)                                                                  \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            atl::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),         \
+                           __FILE__, __LINE__);                                            \
+            return e__ == hipErrorOutOfMemory ? ATL_E_NOMEM : ATL_E_HIP;                   \
+        }                                                                                  \
+    } while (0)
+
+#define ATL_REQUIRE(cond, ...)                                                             \
+    do {                                                                                   \
+        if (!(cond)) {                                                                     \
+            atl::set_error(__VA_ARGS__);                                                   \
+            return ATL_E_INVALID;                                                          \
+        }                                                                                  \
+    } while (0)
+
+// Device view of the aggregation plan (all pointers device-resident).
+struct PlanDev {
+    int64_t n_rows;        // N shapes
+    int64_t n_cells;       // S
+    int32_t n_segs;        // ceil(S / kSegCells)
+    int32_t n_prows;       // P partial rows = sum over segments of distinct shapes touching it
+    const int32_t *seg_ptr;     // [n_segs+1] partial rows of segment s: [seg_ptr[s], seg_ptr[s+1])
+    const double *prow_w;       // [P][kSegCells] weight of local cell, NaN = structurally absent
+    const int32_t *shape_ptr;   // [N+1]
+    const int32_t *shape_prow;  // [P] partial rows of each shape in ascending segment order
+    const uint8_t *row_poison;  // [N] 1 = row has a NaN weight -> output row is NaN
+};
+
+}  // namespace atl
+
+struct atl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // scratch arena (grown on demand, stream-ordered reuse)
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    // small table buffer for per-call host tables (wind knots)
+    double *d_table = nullptr;
+    // timing
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // atl_timer_*
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;  // dominant-kernel bracket
+    bool profiling = false;
+    bool have_kernel_time = false;
+    int n_cu = 256;
+};
+
+struct atl_agg {
+    atl_ctx *ctx = nullptr;
+    atl::PlanDev dev{};
+    std::vector<void *> allocs;
+};
+
+namespace atl {
+// scratch: returns a device pointer valid until the next scratch_reserve on this ctx.
+int scratch_reserve(atl_ctx *ctx, size_t bytes, void **out);
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+}  // namespace atl

@@ -1,0 +1,926 @@
+// HIP kernels (gfx950 / CDNA4, wave64) for atlite's convert_and_aggregate hot path and the
+// C-ABI launchers declared in include/atlite_hip.h.
+//
+// One streaming pass over the (time, cell) fp64 cubes.  Three kernel shapes, each a template
+// over a "converter" that turns the input variables of one (slot, cell) into one fp64 value:
+//   k_cells_series   out[slot, cell]               (aggregate_time=None, no matrix)
+//   k_cells_timered  out[cell] = sum_t / mean_t     (no matrix, aggregate_time sum/mean)
+//   k_fused_segred   partial[prow, slot]            (matrix / shapes / layout given)
+// k_fused_segred never materialises the converted cube: a wave owns 128 consecutive cells
+// (2 per lane, 16-byte loads) and walks a chunk of output slots; per batch of 8 slots the
+// per-lane values are multiplied by the segment-local indicator weights and reduced across
+// the wave by a 3+3 stage shuffle butterfly that ends with lane 8g holding slot g, so the
+// partial row is written with one 64-byte store.  k_combine then sums, in a fixed order, the
+// partial rows of each shape: deterministic, no atomics.
+//
+// Reference arithmetic (file:line under /root/reference/atlite):
+//   pv   : convert.py:840-854, pv/orientation.py:114-117,188, pv/irradiation.py:196-226,
+//          247-255, pv/solar_panel_model.py:12-44
+//   wind : convert.py:634-662 (np.interp), wind.py:76-112
+//   heat : convert.py:405-418      runoff : convert.py:1028-1034
+//   agg  : aggregate.py:16-35 (scipy CSR product), convert.py:51-56 (_aggregate_time)
+#include "atl_internal.h"
+
+using namespace atl;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool dnan(double x) { return x != x; }
+__device__ __forceinline__ double fill0(double x) { return dnan(x) ? 0.0 : x; }
+// numpy clip/maximum/minimum semantics: NaN in either operand propagates
+__device__ __forceinline__ double np_max(double a, double b) { return (a > b || dnan(a)) ? a : b; }
+__device__ __forceinline__ double np_min(double a, double b) { return (a < b || dnan(a)) ? a : b; }
+__device__ __forceinline__ double np_clip(double x, double lo, double hi) {
+    return np_min(np_max(x, lo), hi);
+}
+
+template <bool VEC>
+__device__ __forceinline__ double2 ld2(const double *__restrict__ p, int64_t off, bool v0, bool v1) {
+    double2 r;
+    if constexpr (VEC) {
+        // S even and base 16-B aligned: both cells valid or both invalid
+        if (v0) {
+            r = *reinterpret_cast<const double2 *>(p + off);
+        } else {
+            r.x = 0.0;
+            r.y = 0.0;
+        }
+    } else {
+        r.x = v0 ? p[off] : 0.0;
+        r.y = v1 ? p[off + 1] : 0.0;
+    }
+    return r;
+}
+
+template <bool VEC>
+__device__ __forceinline__ void st2(double *__restrict__ p, int64_t off, bool v0, bool v1, double2 v) {
+    if constexpr (VEC) {
+        if (v0) *reinterpret_cast<double2 *>(p + off) = v;
+    } else {
+        if (v0) p[off] = v.x;
+        if (v1) p[off + 1] = v.y;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// converters
+// ---------------------------------------------------------------------------------------
+struct NoCell {};
+
+// generic dense cube (aggregate_matrix on an arbitrary converted DataArray)
+struct IdentityConv {
+    const double *d;
+    int64_t S;
+    using Cell = NoCell;
+    __device__ void block_init(double *) const {}
+    __device__ Cell cell_setup(int64_t, bool, bool) const { return {}; }
+    template <bool VEC>
+    __device__ __forceinline__ double2 eval(int64_t slot, int64_t c0, bool v0, bool v1, const Cell &,
+                                            const double *) const {
+        return ld2<VEC>(d, slot * S + c0, v0, v1);
+    }
+};
+
+// runoff * height  (convert.py:1028-1034)
+struct RunoffConv {
+    const double *runoff;
+    const double *height;  // (S) or nullptr
+    int64_t S;
+    struct Cell {
+        double2 h;
+    };
+    __device__ void block_init(double *) const {}
+    __device__ Cell cell_setup(int64_t c0, bool v0, bool v1) const {
+        Cell c;
+        c.h.x = (height && v0) ? height[c0] : 1.0;
+        c.h.y = (height && v1) ? height[c0 + 1] : 1.0;
+        return c;
+    }
+    template <bool VEC>
+    __device__ __forceinline__ double2 eval(int64_t slot, int64_t c0, bool v0, bool v1, const Cell &c,
+                                            const double *) const {
+        double2 r = ld2<VEC>(runoff, slot * S + c0, v0, v1);
+        if (height) {
+            r.x *= c.h.x;
+            r.y *= c.h.y;
+        }
+        return r;
+    }
+};
+
+// heat demand: nan-skipping daily mean, degree-day transform (convert.py:405-418)
+struct HeatConv {
+    const double *temperature;
+    const int64_t *day_ptr;  // device (D+1)
+    int64_t S;
+    double threshold_K, a, constant;
+    using Cell = NoCell;
+    __device__ void block_init(double *) const {}
+    __device__ Cell cell_setup(int64_t, bool, bool) const { return {}; }
+    template <bool VEC>
+    __device__ __forceinline__ double2 eval(int64_t slot, int64_t c0, bool v0, bool v1, const Cell &,
+                                            const double *) const {
+        const int64_t t0 = day_ptr[slot], t1 = day_ptr[slot + 1];
+        double sx = 0.0, sy = 0.0;
+        int nx = 0, ny = 0;
+#pragma unroll 8
+        for (int64_t t = t0; t < t1; ++t) {
+            double2 v = ld2<VEC>(temperature, t * S + c0, v0, v1);
+            if (!dnan(v.x)) {
+                sx += v.x;
+                ++nx;
+            }
+            if (!dnan(v.y)) {
+                sy += v.y;
+                ++ny;
+            }
+        }
+        // mean over an empty / all-NaN group is NaN (0/0), like xarray's resample().mean()
+        const double mx = sx / double(nx), my = sy / double(ny);
+        double hx = a * (threshold_K - mx), hy = a * (threshold_K - my);
+        hx = np_max(hx, 0.0);
+        hy = np_max(hy, 0.0);
+        double2 r;
+        r.x = constant + hx;
+        r.y = constant + hy;
+        return r;
+    }
+};
+
+// wind: hub-height extrapolation + power curve (wind.py:76-112, convert.py:648-649)
+struct WindConv {
+    const double *wnd;
+    const double *aux;
+    int64_t S;
+    int aux_static;
+    int method;
+    double to_height, from_height;
+    double log_ratio;      // log(to/from)   (power law)
+    const double *table;   // device: V[n] F[n] slope[n]
+    int n_knots;
+    int search_start;      // largest power of two < n_knots
+    struct Cell {
+        double2 aux;
+    };
+    __device__ void block_init(double *lds) const {
+        for (int i = threadIdx.x; i < 3 * n_knots; i += blockDim.x) lds[i] = table[i];
+    }
+    __device__ Cell cell_setup(int64_t c0, bool v0, bool v1) const {
+        Cell c;
+        c.aux.x = 0.0;
+        c.aux.y = 0.0;
+        if (method != ATL_WIND_NONE && aux_static) {
+            c.aux.x = v0 ? aux[c0] : 1.0;
+            c.aux.y = v1 ? aux[c0 + 1] : 1.0;
+        }
+        return c;
+    }
+    __device__ __forceinline__ double hub_speed(double v, double z) const {
+        if (method == ATL_WIND_LOG) {
+            // wind.py:99-101, literally: v * (log(to/z0) / log(from/z0))
+            return v * (log(to_height / z) / log(from_height / z));
+        } else if (method == ATL_WIND_POWER) {
+            // wind.py:111: v * (to/from) ** shear
+            return v * pow(to_height / from_height, z);
+        }
+        return v;
+    }
+    // np.interp(x, V, F) — numpy/_core/src/multiarray/compiled_base.c arr_interp semantics
+    __device__ __forceinline__ double interp(double x, const double *lds) const {
+        const double *V = lds, *F = lds + n_knots, *SL = lds + 2 * n_knots;
+        const int n = n_knots;
+        if (dnan(x)) return x;
+        if (x < V[0]) return F[0];
+        if (x > V[n - 1]) return F[n - 1];
+        int j = 0;  // largest j with V[j] <= x
+        for (int step = search_start; step > 0; step >>= 1) {
+            const int cand = j + step;
+            if (cand < n && V[cand] <= x) j = cand;
+        }
+        if (j == n - 1) return F[j];
+        const double xj = V[j], fj = F[j];
+        if (xj == x) return fj;
+        const double slope = SL[j];
+        double r = slope * (x - xj) + fj;
+        if (dnan(r)) {
+            r = slope * (x - V[j + 1]) + F[j + 1];
+            if (dnan(r) && fj == F[j + 1]) r = fj;
+        }
+        return r;
+    }
+    template <bool VEC>
+    __device__ __forceinline__ double2 eval(int64_t slot, int64_t c0, bool v0, bool v1, const Cell &c,
+                                            const double *lds) const {
+        double2 v = ld2<VEC>(wnd, slot * S + c0, v0, v1);
+        double2 z = c.aux;
+        if (method != ATL_WIND_NONE && !aux_static) z = ld2<VEC>(aux, slot * S + c0, v0, v1);
+        double2 r;
+        r.x = v0 ? interp(hub_speed(v.x, z.x), lds) : 0.0;
+        r.y = v1 ? interp(hub_speed(v.y, z.y), lds) : 0.0;
+        return r;
+    }
+};
+
+// solar PV, ERA5-shaped inputs with stored solar position
+struct PvConst {
+    double c_amb, c_irr, r_tmod, r_irr, k1, k2, k3, k4, k5, k6, inv_eff, alt_thr;
+};
+
+__device__ __forceinline__ double pv_cell(double dir, double dif, double toa, double alb, double tmp,
+                                          double alt, double az, double ss, double cs, double saz,
+                                          const PvConst &k) {
+    // irradiation.py:206-208
+    const double direct = np_clip(dir, 0.0, toa);
+    const double diffuse = np_clip(dif, 0.0, toa - direct);
+    const double influx = direct + diffuse;
+    // irradiation.py:251-252 (NaN compares false: a NaN altitude is not capped)
+    const bool capped = (alt < k.alt_thr) || (influx <= 0.01);
+    if (capped) return 0.0;  // G = 0 -> G_ = 0, eff -> 0 : 0*0*inv
+    double sa, ca;
+    sincos(alt, &sa, &ca);
+    // orientation.py:114-117,188
+    double cosinc = ss * ca * cos(saz - az) + cs * sa;
+    cosinc = np_max(cosinc, 0.0);
+    // irradiation.py:214-226
+    const double kk = cosinc / sa;
+    const double direct_t = kk * direct;
+    const double diffuse_t = (1.0 + cs) / 2.0 * diffuse;
+    const double ground_t = alb * influx * ((1.0 - cs) / 2.0);
+    const double G = fill0(direct_t) + fill0(diffuse_t) + fill0(ground_t);
+    // solar_panel_model.py:22-41
+    const double T_ = (k.c_amb * tmp + k.c_irr * G) - k.r_tmod;
+    const double G_ = G / k.r_irr;
+    double eff = 0.0;
+    if (G_ > 0.0) {
+        const double l = log(G_);
+        const double l2 = l * l;
+        eff = 1.0 + k.k1 * l + k.k2 * l2 + T_ * (k.k3 + k.k4 * l + k.k5 * l2) + k.k6 * (T_ * T_);
+        eff = fill0(eff);
+        eff = eff < 0.0 ? 0.0 : eff;
+    }
+    return G_ * eff * k.inv_eff;
+}
+
+struct PvConv {
+    atl_pv_inputs in;
+    int64_t S;
+    PvConst k;
+    double ss, cs, saz;          // scalar orientation: sin/cos(slope), azimuth
+    const double *cell_slope;    // (S) or nullptr
+    const double *cell_azimuth;  // (S)
+    struct Cell {
+        double2 ss, cs, saz;
+    };
+    __device__ void block_init(double *) const {}
+    __device__ Cell cell_setup(int64_t c0, bool v0, bool v1) const {
+        Cell c;
+        if (cell_slope) {
+            const double s0 = v0 ? cell_slope[c0] : 0.0, s1 = v1 ? cell_slope[c0 + 1] : 0.0;
+            c.ss.x = sin(s0);
+            c.cs.x = cos(s0);
+            c.ss.y = sin(s1);
+            c.cs.y = cos(s1);
+            c.saz.x = v0 ? cell_azimuth[c0] : 0.0;
+            c.saz.y = v1 ? cell_azimuth[c0 + 1] : 0.0;
+        } else {
+            c.ss.x = c.ss.y = ss;
+            c.cs.x = c.cs.y = cs;
+            c.saz.x = c.saz.y = saz;
+        }
+        return c;
+    }
+    template <bool VEC>
+    __device__ __forceinline__ double2 eval(int64_t slot, int64_t c0, bool v0, bool v1, const Cell &c,
+                                            const double *) const {
+        const int64_t off = slot * S + c0;
+        const double2 alt = ld2<VEC>(in.d_solar_altitude, off, v0, v1);
+        const double2 dir = ld2<VEC>(in.d_influx_direct, off, v0, v1);
+        const double2 dif = ld2<VEC>(in.d_influx_diffuse, off, v0, v1);
+        const double2 toa = ld2<VEC>(in.d_influx_toa, off, v0, v1);
+        const double2 alb = ld2<VEC>(in.d_albedo, off, v0, v1);
+        const double2 tmp = ld2<VEC>(in.d_temperature, off, v0, v1);
+        const double2 az = ld2<VEC>(in.d_solar_azimuth, off, v0, v1);
+        double2 r;
+        r.x = v0 ? pv_cell(dir.x, dif.x, toa.x, alb.x, tmp.x, alt.x, az.x, c.ss.x, c.cs.x, c.saz.x, k) : 0.0;
+        r.y = v1 ? pv_cell(dir.y, dif.y, toa.y, alb.y, tmp.y, alt.y, az.y, c.ss.y, c.cs.y, c.saz.y, k) : 0.0;
+        return r;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// kernel 1: per-cell series  out[slot, cell]
+// grid.x over 512-cell blocks, grid.y over slot chunks of kSeriesSlots
+// ---------------------------------------------------------------------------------------
+constexpr int kSeriesSlots = 8;
+
+template <class Conv, bool VEC>
+__global__ __launch_bounds__(256) void k_cells_series(Conv conv, int64_t n_slots, int64_t S,
+                                                      double *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    conv.block_init(lds);
+    __syncthreads();
+    const int64_t c0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * 2;
+    const bool v0 = c0 < S, v1 = c0 + 1 < S;
+    const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1);
+    const int64_t s0 = int64_t(blockIdx.y) * kSeriesSlots;
+#pragma unroll 2
+    for (int i = 0; i < kSeriesSlots; ++i) {
+        const int64_t slot = s0 + i;
+        if (slot >= n_slots) break;
+        const double2 r = conv.template eval<VEC>(slot, c0, v0, v1, cell, lds);
+        st2<VEC>(out, slot * S + c0, v0, v1, r);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// kernel 2: per-cell time reduction.  psum/pcnt[chunk, cell] then k_chunk_reduce.
+// ---------------------------------------------------------------------------------------
+template <class Conv, bool VEC>
+__global__ __launch_bounds__(256) void k_cells_timered(Conv conv, int64_t n_slots, int64_t S,
+                                                       int64_t chunk_len, double *__restrict__ psum,
+                                                       double *__restrict__ pcnt) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    conv.block_init(lds);
+    __syncthreads();
+    const int64_t c0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * 2;
+    const bool v0 = c0 < S, v1 = c0 + 1 < S;
+    const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1);
+    const int64_t s0 = int64_t(blockIdx.y) * chunk_len;
+    const int64_t s1 = min(s0 + chunk_len, n_slots);
+    double2 acc = {0.0, 0.0}, cnt = {0.0, 0.0};
+#pragma unroll 2
+    for (int64_t slot = s0; slot < s1; ++slot) {
+        const double2 r = conv.template eval<VEC>(slot, c0, v0, v1, cell, lds);
+        if (!dnan(r.x)) {
+            acc.x += r.x;
+            cnt.x += 1.0;
+        }
+        if (!dnan(r.y)) {
+            acc.y += r.y;
+            cnt.y += 1.0;
+        }
+    }
+    const int64_t o = int64_t(blockIdx.y) * S + c0;
+    if (v0) {
+        psum[o] = acc.x;
+        pcnt[o] = cnt.x;
+    }
+    if (v1) {
+        psum[o + 1] = acc.y;
+        pcnt[o + 1] = cnt.y;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_chunk_reduce(const double *__restrict__ psum,
+                                                      const double *__restrict__ pcnt, int64_t n_chunks,
+                                                      int64_t S, int mean, double *__restrict__ out) {
+    const int64_t c = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (c >= S) return;
+    double s = 0.0, n = 0.0;
+    for (int64_t k = 0; k < n_chunks; ++k) {
+        s += psum[k * S + c];
+        n += pcnt[k * S + c];
+    }
+    out[c] = mean ? s / n : s;  // nan-skipping mean of nothing is NaN; nan-skipping sum is 0
+}
+
+// ---------------------------------------------------------------------------------------
+// kernel 3: fused convert + segment reduce
+// ---------------------------------------------------------------------------------------
+// wave butterfly: c[i] (i = slot in batch) per lane -> lane 8g holds sum over lanes of c[g]
+__device__ __forceinline__ double butterfly8(const double (&c)[kBatch], int lane) {
+    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+    double d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double keep = h5 ? c[j + 4] : c[j];
+        const double send = h5 ? c[j] : c[j + 4];
+        d[j] = keep + __shfl_xor(send, 32);
+    }
+    double e[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const double keep = h4 ? d[j + 2] : d[j];
+        const double send = h4 ? d[j] : d[j + 2];
+        e[j] = keep + __shfl_xor(send, 16);
+    }
+    const double keep = h3 ? e[1] : e[0];
+    const double send = h3 ? e[0] : e[1];
+    double f = keep + __shfl_xor(send, 8);
+    f += __shfl_xor(f, 4);
+    f += __shfl_xor(f, 2);
+    f += __shfl_xor(f, 1);
+    return f;
+}
+
+template <class Conv, bool VEC>
+__global__ __launch_bounds__(256) void k_fused_segred(Conv conv, PlanDev plan, int64_t n_slots,
+                                                      int64_t S, int32_t chunk_slots, int64_t n_units,
+                                                      double *__restrict__ partials, int64_t ldp) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    conv.block_init(lds);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t unit = int64_t(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+    if (unit >= n_units) return;
+    const int32_t seg = int32_t(unit % plan.n_segs);
+    const int64_t chunk = unit / plan.n_segs;
+    const int64_t c0 = int64_t(seg) * kSegCells + 2 * lane;
+    const bool v0 = c0 < S, v1 = c0 + 1 < S;
+    const int32_t p0 = plan.seg_ptr[seg], p1 = plan.seg_ptr[seg + 1];
+    if (p0 == p1) return;  // no shape touches this segment: nothing to read
+    const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1);
+    const int64_t sbeg = chunk * chunk_slots;
+    const int64_t send = min(sbeg + int64_t(chunk_slots), n_slots);
+    for (int64_t sb = sbeg; sb < send; sb += kBatch) {
+        double2 v[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+            const int64_t slot = sb + i;
+            if (slot < send) {
+                v[i] = conv.template eval<VEC>(slot, c0, v0, v1, cell, lds);
+            } else {
+                v[i].x = 0.0;
+                v[i].y = 0.0;
+            }
+        }
+        for (int32_t p = p0; p < p1; ++p) {
+            const double2 w = *reinterpret_cast<const double2 *>(plan.prow_w + int64_t(p) * kSegCells + 2 * lane);
+            const bool a0 = !dnan(w.x), a1 = !dnan(w.y);  // structurally present
+            double c[kBatch];
+#pragma unroll
+            for (int i = 0; i < kBatch; ++i) {
+                const double t0 = a0 ? w.x * v[i].x : 0.0;
+                const double t1 = a1 ? w.y * v[i].y : 0.0;
+                c[i] = t0 + t1;
+            }
+            const double f = butterfly8(c, lane);
+            const int g = lane >> 3;
+            if ((lane & 7) == 0 && sb + g < send) partials[int64_t(p) * ldp + sb + g] = f;
+        }
+    }
+}
+
+// out[n, t] = sum over the shape's partial rows (ascending segment order)
+__global__ __launch_bounds__(256) void k_combine(PlanDev plan, const double *__restrict__ partials,
+                                                 int64_t ldp, int64_t n_slots, double *__restrict__ out,
+                                                 int64_t ld_out) {
+    const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t n = blockIdx.y;
+    if (t >= n_slots) return;
+    double s = 0.0;
+    const int32_t q0 = plan.shape_ptr[n], q1 = plan.shape_ptr[n + 1];
+    for (int32_t q = q0; q < q1; ++q) s += partials[int64_t(plan.shape_prow[q]) * ldp + t];
+    if (plan.row_poison[n]) s = __builtin_nan("");
+    out[n * ld_out + t] = s;
+}
+
+// nan-skipping sum / mean of each row of a (rows x len) matrix; one block per row
+__global__ __launch_bounds__(256) void k_rows_timered(const double *__restrict__ in, int64_t ld,
+                                                      int64_t len, int mean, double *__restrict__ out) {
+    __shared__ double ss[256], sn[256];
+    const double *row = in + int64_t(blockIdx.x) * ld;
+    double s = 0.0, n = 0.0;
+    for (int64_t t = threadIdx.x; t < len; t += 256) {
+        const double v = row[t];
+        if (!dnan(v)) {
+            s += v;
+            n += 1.0;
+        }
+    }
+    ss[threadIdx.x] = s;
+    sn[threadIdx.x] = n;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (int(threadIdx.x) < w) {
+            ss[threadIdx.x] += ss[threadIdx.x + w];
+            sn[threadIdx.x] += sn[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = mean ? ss[0] / sn[0] : ss[0];
+}
+
+// ---------------------------------------------------------------------------------------
+// synthetic fields
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double hash_u01(uint64_t seed, uint64_t var, uint64_t idx) {
+    uint64_t z = (seed ^ (var * 0xD1B54A32D192ED03ull)) + (idx + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return double(z >> 11) * 0x1.0p-53;
+}
+
+__global__ __launch_bounds__(256) void k_synth_field(int kind, uint64_t seed, uint64_t var, double p0,
+                                                     double p1, int per_cell_static, int64_t T, int64_t S,
+                                                     double *__restrict__ out) {
+    const int64_t n = T * S;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) {
+        const uint64_t idx = per_cell_static ? uint64_t(i % S) : uint64_t(i);
+        const double u = hash_u01(seed, var, idx);
+        double r;
+        switch (kind) {
+            case ATL_SYN_UNIFORM: r = p0 + (p1 - p0) * u; break;
+            case ATL_SYN_RAYLEIGH: r = p0 * sqrt(-log1p(-u)) * 1.1283791670955126; break;
+            case ATL_SYN_EXPLOG: r = exp(log(p0) + u * log(p1)); break;
+            default: r = -p0 * log1p(-u); break;
+        }
+        out[i] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_synth_pv(atl_synth_solar s, int64_t T, int64_t S, double *dir,
+                                                  double *dif, double *toa, double *alb, double *tmp,
+                                                  double *altp, double *azp) {
+    const int64_t n = T * S;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) {
+        const int64_t t = i / S, c = i % S;
+        const int64_t y = c / s.X, x = c % s.X;
+        const double lat = s.d_lat_rad[y];
+        const double sl = sin(lat), cl = cos(lat);
+        const double sd = s.d_sin_dec[t], cd = s.d_cos_dec[t];
+        const double h = s.d_h[t * s.X + x];
+        const double ch = cos(h);
+        // pv/solar_position.py:100-114
+        double sa = sd * sl + cd * cl * ch;
+        sa = fmin(fmax(sa, -1.0), 1.0);
+        const double alt = asin(sa);
+        double caz = (sd * cl - cd * sl * ch) / cos(alt);
+        caz = fmin(fmax(caz, -1.0), 1.0);
+        double az = acos(caz);
+        if (!(h <= 0.0)) az = 2.0 * M_PI - az;
+        const double u1 = hash_u01(s.seed, 1, i), u2 = hash_u01(s.seed, 2, i);
+        const double u3 = hash_u01(s.seed, 3, i), u4 = hash_u01(s.seed, 4, i);
+        const double top = 1361.0 * fmax(sa, 0.0);
+        const double kt = 0.2 + 0.55 * u1, fd = 0.3 + 0.5 * u2;
+        altp[i] = alt;
+        azp[i] = az;
+        toa[i] = top;
+        dir[i] = top * kt * fd;
+        dif[i] = top * kt * (1.0 - fd);
+        alb[i] = 0.05 + 0.30 * u3;
+        tmp[i] = s.d_tseason[t] - 0.4 * (lat * (180.0 / M_PI) - 50.0) + 4.0 * (u4 - 0.5);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host-side launch plumbing
+// ---------------------------------------------------------------------------------------
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+struct KernelBracket {
+    atl_ctx *ctx;
+    explicit KernelBracket(atl_ctx *c) : ctx(c) {
+        if (ctx->profiling) (void)hipEventRecord(ctx->ev_k0, ctx->stream);
+    }
+    ~KernelBracket() {
+        if (ctx->profiling) {
+            (void)hipEventRecord(ctx->ev_k1, ctx->stream);
+            ctx->have_kernel_time = true;
+        }
+    }
+};
+
+int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: kernel launch failed: %s", what, hipGetErrorString(e));
+        return ATL_E_HIP;
+    }
+    return ATL_OK;
+}
+
+// chunk of output slots walked by one wave of the fused kernel
+int32_t pick_chunk_slots(const atl_ctx *ctx, int64_t n_slots, int64_t n_segs) {
+    // aim for >= ~16 waves per CU worth of units, chunks a multiple of kBatch in [8, 64]
+    int64_t chunk = 64;
+    const int64_t want_units = int64_t(ctx->n_cu) * 64;
+    while (chunk > kBatch && n_segs * ((n_slots + chunk - 1) / chunk) < want_units) chunk /= 2;
+    return int32_t(chunk);
+}
+
+template <class Conv>
+int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_t n_slots, int64_t S,
+              int time_agg, double *d_out, const char *what) {
+    ATL_REQUIRE(time_agg == ATL_TIME_NONE || time_agg == ATL_TIME_SUM || time_agg == ATL_TIME_MEAN,
+                "%s: bad time_agg %d", what, time_agg);
+    ATL_REQUIRE(d_out, "%s: d_out is NULL", what);
+    ATL_HIP_TRY(hipSetDevice(ctx->device));
+    if (S == 0 || (n_slots == 0 && time_agg == ATL_TIME_NONE)) return ATL_OK;
+    const unsigned gx = unsigned((S + 511) / 512);
+    vec = vec && aligned16(d_out);
+    if (time_agg == ATL_TIME_NONE) {
+        const dim3 grid(gx, unsigned((n_slots + kSeriesSlots - 1) / kSeriesSlots));
+        KernelBracket kb(ctx);
+        if (vec)
+            hipLaunchKernelGGL((k_cells_series<Conv, true>), grid, dim3(256), lds_bytes, ctx->stream, conv,
+                               n_slots, S, d_out);
+        else
+            hipLaunchKernelGGL((k_cells_series<Conv, false>), grid, dim3(256), lds_bytes, ctx->stream, conv,
+                               n_slots, S, d_out);
+        return check_launch(what);
+    }
+    // time-reduced: split the slot axis so that the grid fills the chip
+    int64_t n_chunks = std::max<int64_t>(1, std::min<int64_t>((n_slots + 15) / 16,
+                                                               (int64_t(ctx->n_cu) * 16 + gx - 1) / gx));
+    const int64_t chunk_len = std::max<int64_t>(1, (n_slots + n_chunks - 1) / n_chunks);
+    n_chunks = std::max<int64_t>(1, (n_slots + chunk_len - 1) / chunk_len);
+    void *scr = nullptr;
+    int rc = scratch_reserve(ctx, size_t(2 * n_chunks * S) * sizeof(double), &scr);
+    if (rc) return rc;
+    double *psum = static_cast<double *>(scr), *pcnt = psum + n_chunks * S;
+    {
+        const dim3 grid(gx, unsigned(n_chunks));
+        KernelBracket kb(ctx);
+        if (vec)
+            hipLaunchKernelGGL((k_cells_timered<Conv, true>), grid, dim3(256), lds_bytes, ctx->stream, conv,
+                               n_slots, S, chunk_len, psum, pcnt);
+        else
+            hipLaunchKernelGGL((k_cells_timered<Conv, false>), grid, dim3(256), lds_bytes, ctx->stream, conv,
+                               n_slots, S, chunk_len, psum, pcnt);
+    }
+    if ((rc = check_launch(what))) return rc;
+    hipLaunchKernelGGL(k_chunk_reduce, dim3(unsigned((S + 255) / 256)), dim3(256), 0, ctx->stream, psum, pcnt,
+                       n_chunks, S, time_agg == ATL_TIME_MEAN ? 1 : 0, d_out);
+    return check_launch(what);
+}
+
+template <class Conv>
+int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_t n_slots, int64_t S,
+              const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out, const char *what) {
+    ATL_REQUIRE(agg, "%s: agg is NULL", what);
+    ATL_REQUIRE(agg->ctx == ctx, "%s: aggregation plan belongs to another context", what);
+    ATL_REQUIRE(agg->dev.n_cells == S, "%s: matrix has %lld columns but the cutout has %lld cells", what,
+                (long long)agg->dev.n_cells, (long long)S);
+    ATL_REQUIRE(time_agg == ATL_TIME_NONE || time_agg == ATL_TIME_SUM || time_agg == ATL_TIME_MEAN,
+                "%s: bad time_agg %d", what, time_agg);
+    ATL_REQUIRE(d_out, "%s: d_out is NULL", what);
+    ATL_REQUIRE(time_agg != ATL_TIME_NONE || ld_out >= n_slots, "%s: ld_out %lld < %lld", what,
+                (long long)ld_out, (long long)n_slots);
+    ATL_HIP_TRY(hipSetDevice(ctx->device));
+    const PlanDev &plan = agg->dev;
+    const int64_t N = plan.n_rows;
+    if (N == 0) return ATL_OK;
+    const int64_t ldp = int64_t(align_up(size_t(std::max<int64_t>(n_slots, 1)), 8));
+    const int64_t P = plan.n_prows;
+    size_t bytes_partials = align_up(size_t(std::max<int64_t>(P, 1) * ldp) * sizeof(double), 256);
+    size_t bytes_series = time_agg == ATL_TIME_NONE ? 0 : align_up(size_t(N * ldp) * sizeof(double), 256);
+    void *scr = nullptr;
+    int rc = scratch_reserve(ctx, bytes_partials + bytes_series, &scr);
+    if (rc) return rc;
+    double *partials = static_cast<double *>(scr);
+    double *series = time_agg == ATL_TIME_NONE
+                         ? d_out
+                         : reinterpret_cast<double *>(static_cast<char *>(scr) + bytes_partials);
+    const int64_t ld_series = time_agg == ATL_TIME_NONE ? ld_out : ldp;
+    if (n_slots > 0 && P > 0) {
+        const int32_t chunk_slots = pick_chunk_slots(ctx, n_slots, plan.n_segs);
+        const int64_t n_chunks = (n_slots + chunk_slots - 1) / chunk_slots;
+        const int64_t n_units = n_chunks * plan.n_segs;
+        const dim3 grid(unsigned((n_units + kWavesPerBlock - 1) / kWavesPerBlock));
+        KernelBracket kb(ctx);
+        if (vec)
+            hipLaunchKernelGGL((k_fused_segred<Conv, true>), grid, dim3(256), lds_bytes, ctx->stream, conv, plan,
+                               n_slots, S, chunk_slots, n_units, partials, ldp);
+        else
+            hipLaunchKernelGGL((k_fused_segred<Conv, false>), grid, dim3(256), lds_bytes, ctx->stream, conv,
+                               plan, n_slots, S, chunk_slots, n_units, partials, ldp);
+        if ((rc = check_launch(what))) return rc;
+    }
+    if (n_slots > 0) {
+        const dim3 grid(unsigned((n_slots + 255) / 256), unsigned(N));
+        hipLaunchKernelGGL(k_combine, grid, dim3(256), 0, ctx->stream, plan, partials, ldp, n_slots, series,
+                           ld_series);
+        if ((rc = check_launch(what))) return rc;
+    }
+    if (time_agg != ATL_TIME_NONE) {
+        hipLaunchKernelGGL(k_rows_timered, dim3(unsigned(N)), dim3(256), 0, ctx->stream, series, ld_series,
+                           n_slots, time_agg == ATL_TIME_MEAN ? 1 : 0, d_out);
+        if ((rc = check_launch(what))) return rc;
+    }
+    return ATL_OK;
+}
+
+bool vec_ok(int64_t S, std::initializer_list<const void *> ptrs) {
+    if (S % 2) return false;
+    for (const void *p : ptrs)
+        if (p && !aligned16(p)) return false;
+    return true;
+}
+
+// ---- converter construction + validation ---------------------------------------------
+int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S, PvConv *c, bool *vec) {
+    ATL_REQUIRE(in && p, "atl_pv: inputs/params is NULL");
+    ATL_REQUIRE(T >= 0 && S >= 0, "atl_pv: negative shape");
+    ATL_REQUIRE(in->d_influx_direct && in->d_influx_diffuse && in->d_influx_toa,
+                "atl_pv: need influx_direct, influx_diffuse and influx_toa (irradiation.py:209-213)");
+    ATL_REQUIRE(in->d_albedo, "atl_pv: need albedo (irradiation.py:128-139)");
+    ATL_REQUIRE(in->d_temperature, "atl_pv: need temperature");
+    ATL_REQUIRE(in->d_solar_altitude && in->d_solar_azimuth, "atl_pv: need solar_altitude and solar_azimuth");
+    ATL_REQUIRE((p->d_cell_slope == nullptr) == (p->d_cell_azimuth == nullptr),
+                "atl_pv: d_cell_slope and d_cell_azimuth must be given together");
+    c->in = *in;
+    c->S = S;
+    c->k = PvConst{p->c_temp_amb, p->c_temp_irrad, p->r_tmod, p->r_irradiance, p->k_1, p->k_2,
+                   p->k_3,        p->k_4,          p->k_5,    p->k_6,          p->inverter_efficiency,
+                   p->altitude_threshold};
+    c->ss = sin(p->slope);
+    c->cs = cos(p->slope);
+    c->saz = p->azimuth;
+    c->cell_slope = p->d_cell_slope;
+    c->cell_azimuth = p->d_cell_azimuth;
+    *vec = vec_ok(S, {in->d_influx_direct, in->d_influx_diffuse, in->d_influx_toa, in->d_albedo,
+                      in->d_temperature, in->d_solar_altitude, in->d_solar_azimuth});
+    return ATL_OK;
+}
+
+int make_wind(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p, int64_t T, int64_t S,
+              WindConv *c, bool *vec, size_t *lds_bytes) {
+    ATL_REQUIRE(in && p, "atl_wind: inputs/params is NULL");
+    ATL_REQUIRE(T >= 0 && S >= 0, "atl_wind: negative shape");
+    ATL_REQUIRE(in->d_wnd, "atl_wind: wind speed is NULL");
+    ATL_REQUIRE(p->method == ATL_WIND_NONE || p->method == ATL_WIND_LOG || p->method == ATL_WIND_POWER,
+                "Interpolation method must be 'logarithmic' or 'power' (got code %d)", p->method);
+    ATL_REQUIRE(p->method == ATL_WIND_NONE || in->d_aux,
+                "atl_wind: method needs roughness / wnd_shear_exp (wind.py:94-98,106-110)");
+    ATL_REQUIRE(p->n_knots >= 1 && p->n_knots <= kMaxKnots && p->h_V && p->h_POWn,
+                "atl_wind: power curve needs 1..%d knots", kMaxKnots);
+    const int n = p->n_knots;
+    std::vector<double> tbl(size_t(3 * n));
+    for (int i = 0; i < n; ++i) {
+        tbl[i] = p->h_V[i];
+        tbl[n + i] = p->h_POWn[i];
+        ATL_REQUIRE(i == 0 || p->h_V[i] >= p->h_V[i - 1],
+                    "wind speed 'V' in the turbine config is expected to be increasing");
+    }
+    for (int i = 0; i + 1 < n; ++i) tbl[2 * n + i] = (tbl[n + i + 1] - tbl[n + i]) / (tbl[i + 1] - tbl[i]);
+    tbl[3 * n - 1] = 0.0;
+    // stream-ordered after any earlier kernel that still reads the table
+    ATL_HIP_TRY(hipMemcpyAsync(ctx->d_table, tbl.data(), tbl.size() * sizeof(double), hipMemcpyHostToDevice,
+                               ctx->stream));
+    c->wnd = in->d_wnd;
+    c->aux = in->d_aux;
+    c->S = S;
+    c->aux_static = in->aux_is_static;
+    c->method = p->method;
+    c->to_height = p->to_height;
+    c->from_height = p->from_height;
+    c->log_ratio = log(p->to_height / p->from_height);
+    c->table = ctx->d_table;
+    c->n_knots = n;
+    int st = 1;
+    while (st * 2 < n) st *= 2;
+    c->search_start = n > 1 ? st : 0;
+    *lds_bytes = size_t(3 * n) * sizeof(double);
+    *vec = vec_ok(S, {in->d_wnd, in->aux_is_static ? nullptr : in->d_aux});
+    return ATL_OK;
+}
+
+int make_heat(const double *d_temperature, const atl_heat_params *p, int64_t T, int64_t S, HeatConv *c,
+              bool *vec) {
+    ATL_REQUIRE(d_temperature && p, "atl_heat_demand: temperature/params is NULL");
+    ATL_REQUIRE(T >= 0 && S >= 0 && p->n_days >= 0, "atl_heat_demand: negative shape");
+    ATL_REQUIRE(p->n_days == 0 || p->d_day_ptr, "atl_heat_demand: d_day_ptr is NULL");
+    c->temperature = d_temperature;
+    c->day_ptr = p->d_day_ptr;
+    c->S = S;
+    c->threshold_K = p->threshold_K;
+    c->a = p->a;
+    c->constant = p->constant;
+    *vec = vec_ok(S, {d_temperature});
+    return ATL_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+int atl_spmm_csr(atl_ctx *ctx, const atl_agg *agg, const double *d_dense, int64_t T, int64_t S,
+                 int time_agg, double *d_out, int64_t ld_out) {
+    ATL_REQUIRE(ctx && d_dense, "atl_spmm_csr: bad argument");
+    ATL_REQUIRE(T >= 0 && S >= 0, "atl_spmm_csr: negative shape");
+    IdentityConv c{d_dense, S};
+    return run_fused(ctx, c, vec_ok(S, {d_dense}), 0, T, S, agg, time_agg, d_out, ld_out, "atl_spmm_csr");
+}
+
+int atl_pv_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S,
+                   int time_agg, double *d_out) {
+    ATL_REQUIRE(ctx, "atl_pv_convert: ctx is NULL");
+    PvConv c;
+    bool vec;
+    int rc = make_pv(in, p, T, S, &c, &vec);
+    if (rc) return rc;
+    return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
+}
+
+int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T,
+                             int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out) {
+    ATL_REQUIRE(ctx, "atl_pv_convert_aggregate: ctx is NULL");
+    PvConv c;
+    bool vec;
+    int rc = make_pv(in, p, T, S, &c, &vec);
+    if (rc) return rc;
+    return run_fused(ctx, c, vec, 0, T, S, agg, time_agg, d_out, ld_out, "atl_pv_convert_aggregate");
+}
+
+int atl_wind_convert(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p, int64_t T,
+                     int64_t S, int time_agg, double *d_out) {
+    ATL_REQUIRE(ctx, "atl_wind_convert: ctx is NULL");
+    WindConv c;
+    bool vec;
+    size_t lds;
+    int rc = make_wind(ctx, in, p, T, S, &c, &vec, &lds);
+    if (rc) return rc;
+    return run_cells(ctx, c, vec, lds, T, S, time_agg, d_out, "atl_wind_convert");
+}
+
+int atl_wind_convert_aggregate(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p,
+                               int64_t T, int64_t S, const atl_agg *agg, int time_agg, double *d_out,
+                               int64_t ld_out) {
+    ATL_REQUIRE(ctx, "atl_wind_convert_aggregate: ctx is NULL");
+    WindConv c;
+    bool vec;
+    size_t lds;
+    int rc = make_wind(ctx, in, p, T, S, &c, &vec, &lds);
+    if (rc) return rc;
+    return run_fused(ctx, c, vec, lds, T, S, agg, time_agg, d_out, ld_out, "atl_wind_convert_aggregate");
+}
+
+int atl_heat_demand_convert(atl_ctx *ctx, const double *d_temperature, const atl_heat_params *p, int64_t T,
+                            int64_t S, int time_agg, double *d_out) {
+    ATL_REQUIRE(ctx, "atl_heat_demand_convert: ctx is NULL");
+    HeatConv c;
+    bool vec;
+    int rc = make_heat(d_temperature, p, T, S, &c, &vec);
+    if (rc) return rc;
+    return run_cells(ctx, c, vec, 0, p->n_days, S, time_agg, d_out, "atl_heat_demand_convert");
+}
+
+int atl_heat_demand_convert_aggregate(atl_ctx *ctx, const double *d_temperature, const atl_heat_params *p,
+                                      int64_t T, int64_t S, const atl_agg *agg, int time_agg,
+                                      double *d_out, int64_t ld_out) {
+    ATL_REQUIRE(ctx, "atl_heat_demand_convert_aggregate: ctx is NULL");
+    HeatConv c;
+    bool vec;
+    int rc = make_heat(d_temperature, p, T, S, &c, &vec);
+    if (rc) return rc;
+    return run_fused(ctx, c, vec, 0, p->n_days, S, agg, time_agg, d_out, ld_out,
+                     "atl_heat_demand_convert_aggregate");
+}
+
+int atl_runoff_convert(atl_ctx *ctx, const double *d_runoff, const double *d_height, int64_t T, int64_t S,
+                       int time_agg, double *d_out) {
+    ATL_REQUIRE(ctx && d_runoff, "atl_runoff_convert: bad argument");
+    ATL_REQUIRE(T >= 0 && S >= 0, "atl_runoff_convert: negative shape");
+    RunoffConv c{d_runoff, d_height, S};
+    return run_cells(ctx, c, vec_ok(S, {d_runoff}), 0, T, S, time_agg, d_out, "atl_runoff_convert");
+}
+
+int atl_runoff_convert_aggregate(atl_ctx *ctx, const double *d_runoff, const double *d_height, int64_t T,
+                                 int64_t S, const atl_agg *agg, int time_agg, double *d_out,
+                                 int64_t ld_out) {
+    ATL_REQUIRE(ctx && d_runoff, "atl_runoff_convert_aggregate: bad argument");
+    ATL_REQUIRE(T >= 0 && S >= 0, "atl_runoff_convert_aggregate: negative shape");
+    RunoffConv c{d_runoff, d_height, S};
+    return run_fused(ctx, c, vec_ok(S, {d_runoff}), 0, T, S, agg, time_agg, d_out, ld_out,
+                     "atl_runoff_convert_aggregate");
+}
+
+int atl_synth_field(atl_ctx *ctx, int kind, uint64_t seed, uint64_t var_id, double p0, double p1,
+                    int per_cell_static, int64_t T, int64_t S, double *d_out) {
+    ATL_REQUIRE(ctx && d_out, "atl_synth_field: bad argument");
+    ATL_REQUIRE(kind >= ATL_SYN_UNIFORM && kind <= ATL_SYN_NEGLOG, "atl_synth_field: bad kind %d", kind);
+    ATL_HIP_TRY(hipSetDevice(ctx->device));
+    if (T * S == 0) return ATL_OK;
+    const unsigned grid = unsigned(std::min<int64_t>((T * S + 255) / 256, int64_t(ctx->n_cu) * 32));
+    hipLaunchKernelGGL(k_synth_field, dim3(grid), dim3(256), 0, ctx->stream, kind, seed, var_id, p0, p1,
+                       per_cell_static, T, S, d_out);
+    return check_launch("atl_synth_field");
+}
+
+int atl_synth_pv_inputs(atl_ctx *ctx, const atl_synth_solar *s, int64_t T, int64_t S,
+                        double *d_influx_direct, double *d_influx_diffuse, double *d_influx_toa,
+                        double *d_albedo, double *d_temperature, double *d_solar_altitude,
+                        double *d_solar_azimuth) {
+    ATL_REQUIRE(ctx && s, "atl_synth_pv_inputs: bad argument");
+    ATL_REQUIRE(s->X > 0 && s->Y > 0 && s->X * s->Y == S, "atl_synth_pv_inputs: X*Y != S");
+    ATL_REQUIRE(d_influx_direct && d_influx_diffuse && d_influx_toa && d_albedo && d_temperature &&
+                    d_solar_altitude && d_solar_azimuth,
+                "atl_synth_pv_inputs: NULL output");
+    ATL_HIP_TRY(hipSetDevice(ctx->device));
+    if (T * S == 0) return ATL_OK;
+    const unsigned grid = unsigned(std::min<int64_t>((T * S + 255) / 256, int64_t(ctx->n_cu) * 32));
+    hipLaunchKernelGGL(k_synth_pv, dim3(grid), dim3(256), 0, ctx->stream, *s, T, S, d_influx_direct,
+                       d_influx_diffuse, d_influx_toa, d_albedo, d_temperature, d_solar_altitude,
+                       d_solar_azimuth);
+    return check_launch("atl_synth_pv_inputs");
+}
+
+}  // extern "C"

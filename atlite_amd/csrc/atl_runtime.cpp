@@ -1,0 +1,342 @@
+// Runtime half of libatlite_hip.so: contexts, device memory, timing, and the host-side
+// construction of the aggregation plan (indicator matrix -> segment-local layout).
+// Boundary: include/atlite_hip.h.  Reference semantics: atlite/convert.py:213-262 (matrix
+// handling), atlite/aggregate.py:16-35 (the product that the plan implements).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+#include "atl_internal.h"
+
+namespace atl {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int scratch_reserve(atl_ctx *ctx, size_t bytes, void **out) {
+    bytes = align_up(bytes ? bytes : 256, 256);
+    if (bytes > ctx->scratch_bytes) {
+        // stream-ordered: earlier kernels may still read the old arena
+        ATL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch) ATL_HIP_TRY(hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        size_t want = bytes + bytes / 4;
+        hipError_t e = hipMalloc(&ctx->scratch, want);
+        if (e != hipSuccess) {
+            want = bytes;
+            ATL_HIP_TRY(hipMalloc(&ctx->scratch, want));
+        }
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->scratch;
+    return ATL_OK;
+}
+
+}  // namespace atl
+
+using namespace atl;
+
+template <class T>
+static int to_device(atl_agg *a, const std::vector<T> &v, const T **out) {
+    void *d = nullptr;
+    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    ATL_HIP_TRY(hipMalloc(&d, bytes));
+    a->allocs.push_back(d);
+    if (!v.empty())
+        ATL_HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T *>(d);
+    return ATL_OK;
+}
+
+extern "C" {
+
+int atl_version(void) { return ATL_VERSION; }
+
+const char *atl_last_error(void) { return g_err; }
+
+int atl_device_count(int *count) {
+    ATL_REQUIRE(count, "atl_device_count: count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return ATL_OK;
+}
+
+int atl_create(int device, void *stream, atl_ctx **out) {
+    ATL_REQUIRE(out, "atl_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    ATL_HIP_TRY(hipGetDeviceCount(&n));
+    ATL_REQUIRE(device >= 0 && device < n, "atl_create: device %d out of range (have %d)",
+                device, n);
+    ATL_HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    ATL_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("atl_create: device %d is %s; this library is built for gfx950 only", device,
+                  prop.gcnArchName);
+        return ATL_E_UNSUPPORTED;
+    }
+    atl_ctx *c = new atl_ctx();
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount;
+    if (stream) {
+        c->stream = reinterpret_cast<hipStream_t>(stream);
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            return ATL_E_HIP;
+        }
+        c->own_stream = true;
+    }
+    hipEventCreate(&c->ev_t0);
+    hipEventCreate(&c->ev_t1);
+    hipEventCreate(&c->ev_k0);
+    hipEventCreate(&c->ev_k1);
+    if (hipMalloc(reinterpret_cast<void **>(&c->d_table), 3 * kMaxKnots * sizeof(double)) !=
+        hipSuccess) {
+        set_error("atl_create: table allocation failed");
+        delete c;
+        return ATL_E_NOMEM;
+    }
+    *out = c;
+    return ATL_OK;
+}
+
+int atl_destroy(atl_ctx *ctx) {
+    if (!ctx) return ATL_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->d_table) (void)hipFree(ctx->d_table);
+    hipEventDestroy(ctx->ev_t0);
+    hipEventDestroy(ctx->ev_t1);
+    hipEventDestroy(ctx->ev_k0);
+    hipEventDestroy(ctx->ev_k1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return ATL_OK;
+}
+
+int atl_sync(atl_ctx *ctx) {
+    ATL_REQUIRE(ctx, "atl_sync: ctx is NULL");
+    ATL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ATL_OK;
+}
+
+int atl_device_name(atl_ctx *ctx, char *buf, size_t buflen) {
+    ATL_REQUIRE(ctx && buf && buflen, "atl_device_name: bad argument");
+    hipDeviceProp_t prop;
+    ATL_HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName,
+             prop.multiProcessorCount);
+    return ATL_OK;
+}
+
+int atl_alloc(atl_ctx *ctx, size_t bytes, void **d_ptr) {
+    ATL_REQUIRE(ctx && d_ptr, "atl_alloc: bad argument");
+    ATL_HIP_TRY(hipSetDevice(ctx->device));
+    *d_ptr = nullptr;
+    ATL_HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 256));
+    return ATL_OK;
+}
+
+int atl_free(atl_ctx *ctx, void *d_ptr) {
+    ATL_REQUIRE(ctx, "atl_free: ctx is NULL");
+    if (!d_ptr) return ATL_OK;
+    ATL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ATL_HIP_TRY(hipFree(d_ptr));
+    return ATL_OK;
+}
+
+int atl_upload(atl_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    ATL_REQUIRE(ctx && (bytes == 0 || (d_dst && h_src)), "atl_upload: bad argument");
+    if (!bytes) return ATL_OK;
+    ATL_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ATL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ATL_OK;
+}
+
+int atl_download(atl_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+    ATL_REQUIRE(ctx && (bytes == 0 || (h_dst && d_src)), "atl_download: bad argument");
+    if (!bytes) return ATL_OK;
+    ATL_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ATL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ATL_OK;
+}
+
+int atl_memset(atl_ctx *ctx, void *d_dst, int byte_value, size_t bytes) {
+    ATL_REQUIRE(ctx && (bytes == 0 || d_dst), "atl_memset: bad argument");
+    if (!bytes) return ATL_OK;
+    ATL_HIP_TRY(hipMemsetAsync(d_dst, byte_value, bytes, ctx->stream));
+    return ATL_OK;
+}
+
+int atl_timer_start(atl_ctx *ctx) {
+    ATL_REQUIRE(ctx, "atl_timer_start: ctx is NULL");
+    ATL_HIP_TRY(hipEventRecord(ctx->ev_t0, ctx->stream));
+    return ATL_OK;
+}
+
+int atl_timer_stop(atl_ctx *ctx, float *ms) {
+    ATL_REQUIRE(ctx && ms, "atl_timer_stop: bad argument");
+    ATL_HIP_TRY(hipEventRecord(ctx->ev_t1, ctx->stream));
+    ATL_HIP_TRY(hipEventSynchronize(ctx->ev_t1));
+    ATL_HIP_TRY(hipEventElapsedTime(ms, ctx->ev_t0, ctx->ev_t1));
+    return ATL_OK;
+}
+
+int atl_set_profiling(atl_ctx *ctx, int enabled) {
+    ATL_REQUIRE(ctx, "atl_set_profiling: ctx is NULL");
+    ctx->profiling = enabled != 0;
+    ctx->have_kernel_time = false;
+    return ATL_OK;
+}
+
+int atl_last_kernel_ms(atl_ctx *ctx, float *ms) {
+    ATL_REQUIRE(ctx && ms, "atl_last_kernel_ms: bad argument");
+    ATL_REQUIRE(ctx->have_kernel_time,
+                "atl_last_kernel_ms: no profiled kernel (call atl_set_profiling(ctx,1) first)");
+    ATL_HIP_TRY(hipEventSynchronize(ctx->ev_k1));
+    ATL_HIP_TRY(hipEventElapsedTime(ms, ctx->ev_k0, ctx->ev_k1));
+    return ATL_OK;
+}
+
+// ---- aggregation plan ------------------------------------------------------------------
+
+int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, const int64_t *h_indptr,
+                   const int32_t *h_indices, const double *h_data, atl_agg **out) {
+    ATL_REQUIRE(ctx && out, "atl_agg_create: bad argument");
+    *out = nullptr;
+    ATL_REQUIRE(n_rows >= 0 && n_cells >= 0, "atl_agg_create: negative shape (%lld, %lld)",
+                (long long)n_rows, (long long)n_cells);
+    ATL_REQUIRE(n_rows < (int64_t(1) << 30) && n_cells < (int64_t(1) << 31),
+                "atl_agg_create: matrix shape too large");
+    ATL_REQUIRE(h_indptr, "atl_agg_create: indptr is NULL");
+    ATL_REQUIRE(h_indptr[0] == 0, "atl_agg_create: indptr[0] must be 0");
+    const int64_t nnz = h_indptr[n_rows];
+    ATL_REQUIRE(nnz >= 0 && (nnz == 0 || (h_indices && h_data)),
+                "atl_agg_create: indices/data missing");
+    const int64_t n_segs = (n_cells + kSegCells - 1) / kSegCells;
+
+    struct Ent {
+        int64_t key;  // seg * n_rows + row
+        int32_t local;
+        double w;
+    };
+    std::vector<Ent> ents;
+    ents.reserve(static_cast<size_t>(nnz));
+    std::vector<uint8_t> poison(static_cast<size_t>(n_rows), 0);
+    for (int64_t r = 0; r < n_rows; ++r) {
+        ATL_REQUIRE(h_indptr[r + 1] >= h_indptr[r], "atl_agg_create: indptr not monotone at row %lld",
+                    (long long)r);
+        for (int64_t k = h_indptr[r]; k < h_indptr[r + 1]; ++k) {
+            const int64_t j = h_indices[k];
+            ATL_REQUIRE(j >= 0 && j < n_cells,
+                        "atl_agg_create: column index %lld out of range [0,%lld)", (long long)j,
+                        (long long)n_cells);
+            const double w = h_data[k];
+            if (std::isnan(w)) {
+                poison[r] = 1;
+                continue;
+            }
+            ents.push_back({(j / kSegCells) * n_rows + r, int32_t(j % kSegCells), w});
+        }
+    }
+    std::stable_sort(ents.begin(), ents.end(),
+                     [](const Ent &a, const Ent &b) { return a.key < b.key; });
+
+    std::vector<int32_t> seg_ptr(static_cast<size_t>(n_segs) + 1, 0);
+    std::vector<int32_t> prow_shape;
+    {
+        int64_t last = -1;
+        for (const Ent &e : ents) {
+            if (e.key != last) {
+                last = e.key;
+                prow_shape.push_back(int32_t(e.key % n_rows));
+                seg_ptr[size_t(e.key / n_rows) + 1]++;
+            }
+        }
+        for (int64_t s = 0; s < n_segs; ++s) seg_ptr[s + 1] += seg_ptr[s];
+    }
+    const int64_t P = int64_t(prow_shape.size());
+    ATL_REQUIRE(P < (int64_t(1) << 31) / 1, "atl_agg_create: too many partial rows");
+    std::vector<double> prow_w(static_cast<size_t>(P) * kSegCells,
+                               std::numeric_limits<double>::quiet_NaN());
+    {
+        int64_t last = -1, p = -1;
+        for (const Ent &e : ents) {
+            if (e.key != last) {
+                last = e.key;
+                ++p;
+            }
+            double &slot = prow_w[size_t(p) * kSegCells + e.local];
+            slot = std::isnan(slot) ? e.w : slot + e.w;  // duplicates are summed (scipy CSR)
+        }
+    }
+    std::vector<int32_t> shape_ptr(static_cast<size_t>(n_rows) + 1, 0);
+    std::vector<int32_t> shape_prow(static_cast<size_t>(P), 0);
+    for (int64_t p = 0; p < P; ++p) shape_ptr[size_t(prow_shape[p]) + 1]++;
+    for (int64_t r = 0; r < n_rows; ++r) shape_ptr[r + 1] += shape_ptr[r];
+    {
+        std::vector<int32_t> fill(shape_ptr.begin(), shape_ptr.end() - 1);
+        for (int64_t p = 0; p < P; ++p) shape_prow[size_t(fill[prow_shape[p]]++)] = int32_t(p);
+    }
+
+    ATL_HIP_TRY(hipSetDevice(ctx->device));
+    atl_agg *a = new atl_agg();
+    a->ctx = ctx;
+    a->dev.n_rows = n_rows;
+    a->dev.n_cells = n_cells;
+    a->dev.n_segs = int32_t(n_segs);
+    a->dev.n_prows = int32_t(P);
+    int rc = ATL_OK;
+    if ((rc = to_device(a, seg_ptr, &a->dev.seg_ptr)) ||
+        (rc = to_device(a, prow_w, &a->dev.prow_w)) ||
+        (rc = to_device(a, shape_ptr, &a->dev.shape_ptr)) ||
+        (rc = to_device(a, shape_prow, &a->dev.shape_prow)) ||
+        (rc = to_device(a, poison, &a->dev.row_poison))) {
+        atl_agg_destroy(a);
+        return rc;
+    }
+    *out = a;
+    return ATL_OK;
+}
+
+int atl_agg_destroy(atl_agg *agg) {
+    if (!agg) return ATL_OK;
+    if (agg->ctx) {
+        (void)hipSetDevice(agg->ctx->device);
+        (void)hipStreamSynchronize(agg->ctx->stream);
+    }
+    for (void *p : agg->allocs) (void)hipFree(p);
+    delete agg;
+    return ATL_OK;
+}
+
+int atl_agg_info(const atl_agg *agg, int64_t *n_rows, int64_t *n_cells, int64_t *n_segments,
+                 int64_t *n_partial_rows) {
+    ATL_REQUIRE(agg, "atl_agg_info: agg is NULL");
+    if (n_rows) *n_rows = agg->dev.n_rows;
+    if (n_cells) *n_cells = agg->dev.n_cells;
+    if (n_segments) *n_segments = agg->dev.n_segs;
+    if (n_partial_rows) *n_partial_rows = agg->dev.n_prows;
+    return ATL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,345 @@
+"""
+Device-side objects: a HIP context, fp64 device arrays, aggregation plans and thin typed
+wrappers of the C-ABI entry points (``include/atlite_hip.h``).  Host logic that mirrors the
+reference's Python interface lives in ``atlite_amd.convert``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib
+from ._lib import TIME_MEAN, TIME_NONE, TIME_SUM, check
+
+_TIME_CODES = {None: TIME_NONE, "sum": TIME_SUM, "mean": TIME_MEAN}
+
+
+class DeviceArray:
+    """A C-contiguous array resident in HBM (fp64 unless stated)."""
+
+    def __init__(self, ctx, ptr, shape, dtype=np.float64, owner=None, owned=True):
+        self.ctx = ctx
+        self.ptr = int(ptr)
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self._owner = owner  # keeps a parent allocation (or a torch tensor) alive
+        self._owned = owned and owner is None
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def numpy(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        if out.size:
+            check(self.ctx.lib.atl_download(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def slab(self, start, stop):
+        """View of rows [start, stop) along the first axis (no copy)."""
+        start, stop = int(start), int(stop)
+        assert 0 <= start <= stop <= self.shape[0]
+        row = int(np.prod(self.shape[1:], dtype=np.int64)) * self.dtype.itemsize
+        return DeviceArray(
+            self.ctx, self.ptr + start * row, (stop - start,) + self.shape[1:], self.dtype, owner=self
+        )
+
+    def reshape(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        assert int(np.prod(shape, dtype=np.int64)) == self.size
+        return DeviceArray(self.ctx, self.ptr, shape, self.dtype, owner=self)
+
+    def free(self):
+        if self._owned and self.ptr:
+            check(self.ctx.lib.atl_free(self.ctx.handle, self.ptr))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def __repr__(self):
+        return f"DeviceArray(shape={self.shape}, dtype={self.dtype}, device={self.ctx.device})"
+
+
+class AggPlan:
+    """Indicator matrix (scipy CSR, N x S) preprocessed into the segment-local device layout."""
+
+    def __init__(self, ctx, matrix):
+        import scipy.sparse as sp
+
+        m = sp.csr_matrix(matrix)
+        self.ctx = ctx
+        self.shape = m.shape
+        indptr = np.ascontiguousarray(m.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(m.indices, dtype=np.int32)
+        data = np.ascontiguousarray(m.data, dtype=np.float64)
+        h = C.c_void_p()
+        check(
+            ctx.lib.atl_agg_create(
+                ctx.handle,
+                m.shape[0],
+                m.shape[1],
+                indptr.ctypes.data,
+                indices.ctypes.data if indices.size else None,
+                data.ctypes.data if data.size else None,
+                C.byref(h),
+            )
+        )
+        self.handle = h
+
+    def info(self):
+        v = [C.c_int64() for _ in range(4)]
+        check(self.ctx.lib.atl_agg_info(self.handle, *[C.byref(x) for x in v]))
+        return dict(zip(("n_rows", "n_cells", "n_segments", "n_partial_rows"), (x.value for x in v)))
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.atl_agg_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One HIP device + stream.  Not thread-safe; use one per thread / per rank."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = _lib.load()
+        n = C.c_int()
+        check(self.lib.atl_device_count(C.byref(n)))
+        if n.value == 0:
+            raise _lib.AtliteHipError(
+                "no HIP device visible: atlite_amd runs on MI355X (gfx950) only; there is no CPU fallback"
+            )
+        h = C.c_void_p()
+        check(self.lib.atl_create(int(device), stream, C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    # -- memory ---------------------------------------------------------------------------
+    def empty(self, shape, dtype=np.float64):
+        shape = (shape,) if np.isscalar(shape) else tuple(shape)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        check(self.lib.atl_alloc(self.handle, nbytes, C.byref(p)))
+        return DeviceArray(self, p.value, shape, dtype)
+
+    def zeros(self, shape, dtype=np.float64):
+        a = self.empty(shape, dtype)
+        check(self.lib.atl_memset(self.handle, a.ptr, 0, a.nbytes))
+        return a
+
+    def upload(self, host, dtype=np.float64):
+        host = np.ascontiguousarray(host, dtype=dtype)
+        a = self.empty(host.shape, dtype)
+        if host.size:
+            check(self.lib.atl_upload(self.handle, a.ptr, host.ctypes.data, host.nbytes))
+        return a
+
+    def asdevice(self, x, dtype=np.float64):
+        """DeviceArray as is; torch CUDA tensor zero-copy; anything else is uploaded."""
+        if isinstance(x, DeviceArray):
+            return x
+        if type(x).__module__.startswith("torch") and hasattr(x, "data_ptr"):
+            if x.is_cuda:
+                assert x.is_contiguous() and x.element_size() == np.dtype(dtype).itemsize
+                return DeviceArray(self, x.data_ptr(), tuple(x.shape), dtype, owner=x)
+            x = x.numpy()
+        return self.upload(np.asarray(x), dtype)
+
+    def sync(self):
+        check(self.lib.atl_sync(self.handle))
+
+    def name(self):
+        buf = C.create_string_buffer(256)
+        check(self.lib.atl_device_name(self.handle, buf, 256))
+        return buf.value.decode()
+
+    # -- timing ---------------------------------------------------------------------------
+    def timer_start(self):
+        check(self.lib.atl_timer_start(self.handle))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(self.lib.atl_timer_stop(self.handle, C.byref(ms)))
+        return ms.value
+
+    def set_profiling(self, on=True):
+        check(self.lib.atl_set_profiling(self.handle, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        check(self.lib.atl_last_kernel_ms(self.handle, C.byref(ms)))
+        return ms.value
+
+    # -- plans ----------------------------------------------------------------------------
+    def plan(self, matrix):
+        return AggPlan(self, matrix)
+
+    # -- conversions (device in, device out) ------------------------------------------------
+    def _out(self, plan, n_slots, S, time_agg):
+        if plan is None:
+            return self.empty((n_slots, S)) if time_agg is None else self.empty((S,))
+        N = plan.shape[0]
+        return self.empty((N, n_slots)) if time_agg is None else self.empty((N,))
+
+    def spmm(self, plan, dense, time_agg=None):
+        T, S = dense.shape
+        out = self._out(plan, T, S, time_agg)
+        check(
+            self.lib.atl_spmm_csr(
+                self.handle, plan.handle, dense.ptr, T, S, _TIME_CODES[time_agg], out.ptr, max(T, 1)
+            )
+        )
+        return out
+
+    def pv(self, inputs: dict, params: dict, T, S, plan=None, time_agg=None):
+        """inputs: name -> DeviceArray (T,S) for the 7 ERA5 variables; params: see PvParams."""
+        keep = []
+        pin = _lib.PvInputs(
+            *[
+                inputs[k].ptr
+                for k in (
+                    "influx_direct",
+                    "influx_diffuse",
+                    "influx_toa",
+                    "albedo",
+                    "temperature",
+                    "solar_altitude",
+                    "solar_azimuth",
+                )
+            ]
+        )
+        pp = _lib.PvParams()
+        for k in ("c_temp_amb", "c_temp_irrad", "r_tmod", "r_irradiance", "k_1", "k_2", "k_3", "k_4",
+                  "k_5", "k_6"):
+            setattr(pp, k, float(params[k]))
+        pp.inverter_efficiency = float(params.get("inverter_efficiency", 1.0))
+        pp.altitude_threshold = float(params.get("altitude_threshold", np.radians(1.0)))
+        slope, azimuth = params["slope"], params["azimuth"]
+        if np.ndim(slope) == 0 and np.ndim(azimuth) == 0:
+            pp.slope, pp.azimuth = float(slope), float(azimuth)
+            pp.d_cell_slope = pp.d_cell_azimuth = None
+        else:
+            ds = self.asdevice(np.broadcast_to(np.asarray(slope, dtype=np.float64), (S,)))
+            da = self.asdevice(np.broadcast_to(np.asarray(azimuth, dtype=np.float64), (S,)))
+            keep += [ds, da]
+            pp.d_cell_slope, pp.d_cell_azimuth = ds.ptr, da.ptr
+        out = self._out(plan, T, S, time_agg)
+        if plan is None:
+            check(self.lib.atl_pv_convert(self.handle, C.byref(pin), C.byref(pp), T, S,
+                                          _TIME_CODES[time_agg], out.ptr))
+        else:
+            check(self.lib.atl_pv_convert_aggregate(self.handle, C.byref(pin), C.byref(pp), T, S,
+                                                    plan.handle, _TIME_CODES[time_agg], out.ptr, max(T, 1)))
+        if keep:
+            self.sync()
+        return out
+
+    def wind(self, wnd, aux, V, POWn, to_height, from_height, method, T, S, plan=None, time_agg=None):
+        V = np.ascontiguousarray(V, dtype=np.float64)
+        POWn = np.ascontiguousarray(POWn, dtype=np.float64)
+        win = _lib.WindInputs(
+            wnd.ptr, aux.ptr if aux is not None else None, 1 if (aux is not None and aux.ndim == 1) else 0
+        )
+        wp = _lib.WindParams(
+            {None: _lib.WIND_NONE, "logarithmic": _lib.WIND_LOG, "power": _lib.WIND_POWER}[method],
+            float(to_height),
+            float(from_height),
+            len(V),
+            V.ctypes.data_as(_lib.c_double_p),
+            POWn.ctypes.data_as(_lib.c_double_p),
+        )
+        out = self._out(plan, T, S, time_agg)
+        if plan is None:
+            check(self.lib.atl_wind_convert(self.handle, C.byref(win), C.byref(wp), T, S,
+                                            _TIME_CODES[time_agg], out.ptr))
+        else:
+            check(self.lib.atl_wind_convert_aggregate(self.handle, C.byref(win), C.byref(wp), T, S,
+                                                      plan.handle, _TIME_CODES[time_agg], out.ptr, max(T, 1)))
+        return out
+
+    def heat_demand(self, temperature, day_ptr, threshold_K, a, constant, T, S, plan=None, time_agg=None):
+        day_ptr = np.ascontiguousarray(day_ptr, dtype=np.int64)
+        D = len(day_ptr) - 1
+        assert D >= 0 and day_ptr[0] >= 0 and day_ptr[-1] <= T and np.all(np.diff(day_ptr) >= 0)
+        d_ptr = self.upload(day_ptr, np.int64)
+        hp = _lib.HeatParams(float(threshold_K), float(a), float(constant), D, d_ptr.ptr)
+        out = self._out(plan, D, S, time_agg)
+        if plan is None:
+            check(self.lib.atl_heat_demand_convert(self.handle, temperature.ptr, C.byref(hp), T, S,
+                                                   _TIME_CODES[time_agg], out.ptr))
+        else:
+            check(self.lib.atl_heat_demand_convert_aggregate(self.handle, temperature.ptr, C.byref(hp), T, S,
+                                                             plan.handle, _TIME_CODES[time_agg], out.ptr,
+                                                             max(D, 1)))
+        self.sync()  # d_ptr must outlive the kernels
+        return out
+
+    def runoff(self, runoff, height, T, S, plan=None, time_agg=None):
+        out = self._out(plan, T, S, time_agg)
+        hptr = height.ptr if height is not None else None
+        if plan is None:
+            check(self.lib.atl_runoff_convert(self.handle, runoff.ptr, hptr, T, S, _TIME_CODES[time_agg],
+                                              out.ptr))
+        else:
+            check(self.lib.atl_runoff_convert_aggregate(self.handle, runoff.ptr, hptr, T, S, plan.handle,
+                                                        _TIME_CODES[time_agg], out.ptr, max(T, 1)))
+        return out
+
+    # -- synthetic fields -------------------------------------------------------------------
+    def synth_field(self, kind, seed, var_id, p0, p1, T, S, per_cell_static=False):
+        out = self.empty((S,) if per_cell_static else (T, S))
+        check(self.lib.atl_synth_field(self.handle, kind, seed, var_id, p0, p1, 1 if per_cell_static else 0,
+                                       1 if per_cell_static else T, S, out.ptr))
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.atl_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = {}
+_default_lock = threading.Lock()
+
+
+def default_context(device=None):
+    """Process-wide context per device (LOCAL_RANK selects the device under torchrun)."""
+    import os
+
+    if device is None:
+        device = int(os.environ.get("ATLITE_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    with _default_lock:
+        if device not in _default:
+            _default[device] = Context(device)
+        return _default[device]

@@ -1,0 +1,228 @@
+/*
+ * atlite_hip.h — C ABI of libatlite_hip.so, the MI355X (gfx950) implementation of
+ * atlite's convert_and_aggregate hot path.
+ *
+ * The reference (PyPSA/atlite) is pure Python and has no FFI for this path; the seam it
+ * offers is the Python callback protocol
+ *     convert_and_aggregate(cutout, convert_func, matrix=..., ...)   atlite/convert.py:59-276
+ *     aggregate_matrix(da, matrix, index)                             atlite/aggregate.py:16-35
+ * Every entry point below therefore cites the reference *function* it replaces; the ctypes
+ * binding a maintainer would add on the reference side is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C, no C++/torch types. All array arguments named d_* are DEVICE pointers
+ *    (hipMalloc'd by atl_alloc, or any other HIP allocation of the same process, e.g. a
+ *    torch tensor's data_ptr()). Arguments named h_* are HOST pointers.
+ *  - cubes are fp64, C-contiguous (time, cell) with cell = y*X + x, x fastest
+ *    (stack(spatial=["y","x"]), atlite/aggregate.py:22, atlite/convert.py:244).
+ *  - every function returns ATL_OK (0) or a negative ATL_E_* code; the message for the
+ *    calling thread's last failure is atl_last_error().
+ *  - all work is enqueued on the context's HIP stream; results are complete after
+ *    atl_sync() or a blocking atl_download().
+ *  - the library never frees caller memory; atl_agg / atl_ctx handles are library-owned.
+ *  - one atl_ctx is not thread-safe; distinct contexts are.
+ */
+#ifndef ATLITE_HIP_H
+#define ATLITE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
+#define ATL_VERSION 100 /* 0.1.0 */
+
+#define ATL_OK 0
+#define ATL_E_INVALID (-1)     /* bad argument (maps to ValueError) */
+#define ATL_E_HIP (-2)         /* HIP runtime failure (RuntimeError) */
+#define ATL_E_NOMEM (-3)       /* allocation failure (MemoryError) */
+#define ATL_E_UNSUPPORTED (-4) /* valid in the reference, not implemented here */
+
+/* time-axis reduction applied after conversion (convert.py:51-56 `_aggregate_time`) */
+#define ATL_TIME_NONE 0 /* keep the series            */
+#define ATL_TIME_SUM 1  /* nan-skipping sum over time */
+#define ATL_TIME_MEAN 2 /* nan-skipping mean over time */
+
+typedef struct atl_ctx atl_ctx; /* device + stream + scratch */
+typedef struct atl_agg atl_agg; /* indicator matrix, preprocessed and resident on device */
+
+/* ---- library / context ------------------------------------------------------------- */
+int atl_version(void);
+const char *atl_last_error(void);
+int atl_device_count(int *count);
+/* stream: a hipStream_t to enqueue on, or NULL to let the context create its own. */
+int atl_create(int device, void *stream, atl_ctx **out);
+int atl_destroy(atl_ctx *ctx);
+int atl_sync(atl_ctx *ctx);
+int atl_device_name(atl_ctx *ctx, char *buf, size_t buflen);
+
+/* ---- device memory (caller owns what it allocates) --------------------------------- */
+int atl_alloc(atl_ctx *ctx, size_t bytes, void **d_ptr);
+int atl_free(atl_ctx *ctx, void *d_ptr);
+int atl_upload(atl_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /* blocking */
+int atl_download(atl_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* blocking */
+int atl_memset(atl_ctx *ctx, void *d_dst, int byte_value, size_t bytes);
+
+/* ---- timing (HIP events on the context's stream) ----------------------------------- */
+/* Bracket any sequence of calls; atl_timer_stop synchronises and returns elapsed ms. */
+int atl_timer_start(atl_ctx *ctx);
+int atl_timer_stop(atl_ctx *ctx, float *ms);
+/* When enabled, every convert call brackets its DOMINANT kernel (the streaming
+ * convert[+segment-reduce] kernel) with events; atl_last_kernel_ms synchronises and
+ * returns the duration of the most recent one. */
+int atl_set_profiling(atl_ctx *ctx, int enabled);
+int atl_last_kernel_ms(atl_ctx *ctx, float *ms);
+
+/* ---- aggregation plan ----------------------------------------------------------------
+ * Replaces: the scipy CSR matrix built in convert_and_aggregate (convert.py:213-251) and
+ * consumed by aggregate_matrix (aggregate.py:16-35).  CSR N x S, rows = shapes/buses,
+ * columns = cells in cutout.grid order.  Host arrays are copied; duplicates are summed.
+ * Rows containing a NaN weight produce an all-NaN output row (what scipy's product gives).
+ */
+int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, const int64_t *h_indptr,
+                   const int32_t *h_indices, const double *h_data, atl_agg **out);
+int atl_agg_destroy(atl_agg *agg);
+int atl_agg_info(const atl_agg *agg, int64_t *n_rows, int64_t *n_cells, int64_t *n_segments,
+                 int64_t *n_partial_rows);
+
+/* ---- generic aggregation: out = M . D^T ----------------------------------------------
+ * Replaces aggregate_matrix(da, matrix, index) (aggregate.py:16-35) for an arbitrary
+ * already-converted cube D (T x S).  time_agg NONE: d_out is (N x T) row-major with row
+ * stride ld_out >= T; SUM/MEAN: d_out is (N).
+ */
+int atl_spmm_csr(atl_ctx *ctx, const atl_agg *agg, const double *d_dense, int64_t T, int64_t S,
+                 int time_agg, double *d_out, int64_t ld_out);
+
+/* ---- solar PV ------------------------------------------------------------------------
+ * Replaces convert_pv (convert.py:840-854) = SolarPosition (pv/solar_position.py:54-60,
+ * getter branch) -> SurfaceOrientation (pv/orientation.py:104-117,188-196, tracking=None)
+ * -> TiltedIrradiation (pv/irradiation.py:196-226,247-255, ERA5 direct/diffuse branch,
+ * trigon_model="simple") -> SolarPanelModel/_power_huld (pv/solar_panel_model.py:12-44).
+ */
+typedef struct {
+    const double *d_influx_direct;  /* (T,S) W m**-2 */
+    const double *d_influx_diffuse; /* (T,S) */
+    const double *d_influx_toa;     /* (T,S) */
+    const double *d_albedo;         /* (T,S) */
+    const double *d_temperature;    /* (T,S) K */
+    const double *d_solar_altitude; /* (T,S) rad */
+    const double *d_solar_azimuth;  /* (T,S) rad */
+} atl_pv_inputs;
+
+typedef struct {
+    /* Huld panel model constants (resources/solarpanel/CSi.yaml keys) */
+    double c_temp_amb, c_temp_irrad, r_tmod, r_irradiance;
+    double k_1, k_2, k_3, k_4, k_5, k_6;
+    double inverter_efficiency;
+    /* orientation in RADIANS: scalar (d_cell_slope == NULL) or one value per cell */
+    double slope, azimuth;
+    const double *d_cell_slope;   /* (S) or NULL */
+    const double *d_cell_azimuth; /* (S) or NULL */
+    double altitude_threshold;    /* radians; reference default radians(1.0) */
+} atl_pv_params;
+
+/* per-cell output: time_agg NONE -> d_out (T x S); SUM/MEAN -> d_out (S) */
+int atl_pv_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T,
+                   int64_t S, int time_agg, double *d_out);
+/* fused convert + aggregate: NONE -> d_out (N x T, stride ld_out); SUM/MEAN -> (N) */
+int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p,
+                             int64_t T, int64_t S, const atl_agg *agg, int time_agg,
+                             double *d_out, int64_t ld_out);
+
+/* ---- wind ----------------------------------------------------------------------------
+ * Replaces convert_wind (convert.py:634-662) = extrapolate_wind_speed (wind.py:76-112)
+ * followed by np.interp(v_hub, V, POW/P) (convert.py:648-649).
+ */
+#define ATL_WIND_NONE 0  /* d_wnd already at hub height (wind.py:76-78 fast lane) */
+#define ATL_WIND_LOG 1   /* logarithmic law with roughness   (wind.py:91-102) */
+#define ATL_WIND_POWER 2 /* power law with wnd_shear_exp     (wind.py:103-112) */
+
+typedef struct {
+    const double *d_wnd; /* (T,S) wind speed at from_height */
+    const double *d_aux; /* roughness or wnd_shear_exp: (T,S), or (S) if aux_is_static */
+    int aux_is_static;
+} atl_wind_inputs;
+
+typedef struct {
+    int method; /* ATL_WIND_* */
+    double to_height, from_height;
+    int n_knots;          /* >= 1 */
+    const double *h_V;    /* HOST (n_knots) ascending (ties allowed, resource.py:346-355) */
+    const double *h_POWn; /* HOST (n_knots) POW / P */
+} atl_wind_params;
+
+int atl_wind_convert(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p,
+                     int64_t T, int64_t S, int time_agg, double *d_out);
+int atl_wind_convert_aggregate(atl_ctx *ctx, const atl_wind_inputs *in,
+                               const atl_wind_params *p, int64_t T, int64_t S,
+                               const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out);
+
+/* ---- heat demand ---------------------------------------------------------------------
+ * Replaces convert_heat_demand (convert.py:405-418): nan-skipping mean of temperature over
+ * calendar-day groups of the (shifted) time axis, then a*(threshold_K - Tmean), clip(min=0),
+ * + constant.  The day grouping is passed as offsets: group g = time steps
+ * [d_day_ptr[g], d_day_ptr[g+1]) ; D groups; threshold_K already includes +273.15.
+ * Output "time" axis is the D days.
+ */
+typedef struct {
+    double threshold_K, a, constant;
+    int64_t n_days;
+    const int64_t *d_day_ptr; /* DEVICE (n_days+1) */
+} atl_heat_params;
+
+int atl_heat_demand_convert(atl_ctx *ctx, const double *d_temperature,
+                            const atl_heat_params *p, int64_t T, int64_t S, int time_agg,
+                            double *d_out /* (D x S) or (S) */);
+int atl_heat_demand_convert_aggregate(atl_ctx *ctx, const double *d_temperature,
+                                      const atl_heat_params *p, int64_t T, int64_t S,
+                                      const atl_agg *agg, int time_agg,
+                                      double *d_out /* (N x D) or (N) */, int64_t ld_out);
+
+/* ---- runoff --------------------------------------------------------------------------
+ * Replaces convert_runoff (convert.py:1028-1034): runoff * height (height static (S)),
+ * or runoff alone when d_height == NULL (weight_with_height=False).
+ */
+int atl_runoff_convert(atl_ctx *ctx, const double *d_runoff, const double *d_height, int64_t T,
+                       int64_t S, int time_agg, double *d_out);
+int atl_runoff_convert_aggregate(atl_ctx *ctx, const double *d_runoff, const double *d_height,
+                                 int64_t T, int64_t S, const atl_agg *agg, int time_agg,
+                                 double *d_out, int64_t ld_out);
+
+/* ---- synthetic ERA5-shaped inputs (bench/test tooling) ----------
+ * Fills device cubes with a stateless splitmix64-hash field so that any (t, cell) slice can
+ * be regenerated or downloaded for the oracle.  Not part of the reference's interface.
+ */
+#define ATL_SYN_UNIFORM 0  /* lo + (hi-lo)*u                          p0=lo p1=hi */
+#define ATL_SYN_RAYLEIGH 1 /* p0*sqrt(-ln(1-u))*(2/sqrt(pi))          p0=mean     */
+#define ATL_SYN_EXPLOG 2   /* exp(ln(p0)+u*ln(p1)) static per cell    p0,p1       */
+#define ATL_SYN_NEGLOG 3   /* -p0*ln(1-u)                             p0=scale    */
+int atl_synth_field(atl_ctx *ctx, int kind, uint64_t seed, uint64_t var_id, double p0, double p1,
+                    int per_cell_static, int64_t T, int64_t S, double *d_out);
+/* solar position + consistent radiation/temperature fields from per-time and per-(time,x)
+ * host-precomputed tables (pv/solar_position.py:86-114 structure). */
+typedef struct {
+    const double *d_sin_dec; /* (T) */
+    const double *d_cos_dec; /* (T) */
+    const double *d_h;       /* (T,X) hour angle rad */
+    const double *d_lat_rad; /* (Y) */
+    const double *d_tseason; /* (T) seasonal+diurnal temperature term, K */
+    int64_t X, Y;
+    uint64_t seed;
+} atl_synth_solar;
+int atl_synth_pv_inputs(atl_ctx *ctx, const atl_synth_solar *s, int64_t T, int64_t S,
+                        double *d_influx_direct, double *d_influx_diffuse, double *d_influx_toa,
+                        double *d_albedo, double *d_temperature, double *d_solar_altitude,
+                        double *d_solar_azimuth);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATLITE_HIP_H */

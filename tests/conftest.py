@@ -1,0 +1,21 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """HIP context on cuda:0; fails loudly if the extension or the GPU is missing."""
+    from atlite_amd.device import Context
+
+    return Context(int(os.environ.get("ATLITE_HIP_DEVICE", "0")))

@@ -1,0 +1,75 @@
+"""Shared builders of small synthetic ERA5-shaped inputs for the tests (host NumPy)."""
+import numpy as np
+import pandas as pd
+import scipy.sparse as sp
+
+from oracle import atlite_oracle as orc
+
+CSI = dict(model="huld", name="CSi", c_temp_amb=1, c_temp_irrad=0.035, r_tamb=293, r_tmod=298,
+           r_irradiance=1000, k_1=-0.017162, k_2=-0.040289, k_3=-0.004681, k_4=0.000148, k_5=0.000169,
+           k_6=0.000005, inverter_efficiency=0.9)
+
+V112 = dict(
+    V=np.array([0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 25, 25], dtype=float),
+    POW=np.array([0.000, 0.000, 0.005, 0.150, 0.300, 0.525, 0.905, 1.375, 1.950, 2.580, 2.960, 3.050, 3.060,
+                  3.060, 0.000]),
+    hub_height=80.0,
+    P=3.06,
+)
+
+
+def grid(Y, X):
+    x = -25.0 + (70.0 / X) * np.arange(X)
+    y = 30.0 + (42.0 / Y) * np.arange(Y)
+    return x, y
+
+
+def times(T, start="2013-01-01"):
+    return pd.date_range(start, periods=T, freq="h")
+
+
+def pv_dataset(T, Y, X, seed=0, start="2013-01-01"):
+    """(T, S) float64 arrays of the 7 ERA5 pv variables, physically consistent."""
+    rng = np.random.default_rng(seed)
+    x, y = grid(Y, X)
+    t = times(T, start)
+    alt, az = orc.solar_position(t, x, y, "-30min")
+    toa = 1361.0 * np.maximum(np.sin(alt), 0.0)
+    kt = 0.2 + 0.55 * rng.random((T, Y, X))
+    fd = 0.3 + 0.5 * rng.random((T, Y, X))
+    ds = dict(
+        influx_direct=toa * kt * fd,
+        influx_diffuse=toa * kt * (1 - fd),
+        influx_toa=toa,
+        albedo=0.05 + 0.3 * rng.random((T, Y, X)),
+        temperature=283.15 + 10 * rng.standard_normal((T, Y, X)),
+        solar_altitude=alt,
+        solar_azimuth=az,
+    )
+    return {k: np.ascontiguousarray(v.reshape(T, Y * X)) for k, v in ds.items()}
+
+
+def wind_dataset(T, Y, X, seed=0):
+    rng = np.random.default_rng(seed)
+    u = rng.random((T, Y * X))
+    wnd = 8.0 * np.sqrt(-np.log1p(-u)) * (2 / np.sqrt(np.pi))
+    rough = np.exp(np.log(1e-3) + rng.random((T, Y * X)) * np.log(1.5e3))
+    shear = 0.05 + 0.3 * rng.random((T, Y * X))
+    return dict(wnd100m=wnd, roughness=rough, wnd_shear_exp=shear)
+
+
+def blob_matrix(N, Y, X, seed=0, overlap=True):
+    """Sparse N x (Y*X) indicator-like matrix: each row a fuzzy disc of cells, weights in (0,1]."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:Y, 0:X]
+    rows, cols, vals = [], [], []
+    for n in range(N):
+        cy, cx = rng.uniform(0, Y), rng.uniform(0, X)
+        r = rng.uniform(0.8, 1.6) * np.sqrt(Y * X / (np.pi * max(N, 1)))
+        d = np.hypot(yy - cy, xx - cx)
+        w = np.clip(r + 0.5 - d, 0.0, 1.0)
+        j = np.flatnonzero(w.ravel() > 0)
+        rows += [n] * len(j)
+        cols += list(j)
+        vals += list(w.ravel()[j])
+    return sp.csr_matrix((vals, (rows, cols)), shape=(N, Y * X))

@@ -1,0 +1,172 @@
+"""
+GPU parity: the HIP path, called through the C ABI (ctypes), against the CPU oracle on the
+same seeded inputs.  Tolerance (BASELINE.json north_star): rtol 1e-10 (+ atol = 1e-12*max to
+absorb denormal-scale differences at sunrise/sunset; heat demand: atol 1e-9*a).
+"""
+import numpy as np
+import pytest
+
+from oracle import atlite_oracle as orc
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+def close(a, b, atol_scale=1e-12):
+    a, b = np.asarray(a), np.asarray(b)
+    atol = atol_scale * max(float(np.nanmax(np.abs(b))) if b.size else 0.0, 1e-300)
+    np.testing.assert_allclose(a, b, rtol=RTOL, atol=atol, equal_nan=True)
+
+
+def up(ctx, ds):
+    return {k: ctx.upload(v) for k, v in ds.items()}
+
+
+PV_PARAMS = dict(H.CSI, slope=np.radians(30.0), azimuth=np.radians(180.0))
+
+
+@pytest.mark.parametrize("T,Y,X", [(48, 7, 9), (30, 8, 16), (24, 1, 1), (9, 3, 129)])
+def test_pv_cells_series(ctx, T, Y, X):
+    ds = H.pv_dataset(T, Y, X, seed=1)
+    ref = orc.convert_pv(ds, H.CSI, dict(slope=np.radians(30.0), azimuth=np.radians(180.0)))
+    out = ctx.pv(up(ctx, ds), PV_PARAMS, T, Y * X).numpy()
+    assert ref.max() > 0.1 and (ref == 0).any()
+    close(out, ref)
+
+
+@pytest.mark.parametrize("T,Y,X,N", [(48, 12, 20, 5), (100, 16, 16, 7), (17, 5, 27, 3), (8, 2, 64, 1)])
+def test_pv_fused_aggregate(ctx, T, Y, X, N):
+    ds = H.pv_dataset(T, Y, X, seed=2)
+    M = H.blob_matrix(N, Y, X, seed=3)
+    ref_cells = orc.convert_pv(ds, H.CSI, dict(slope=np.radians(30.0), azimuth=np.radians(180.0)))
+    ref = orc.aggregate_matrix(ref_cells, M)
+    plan = ctx.plan(M)
+    out = ctx.pv(up(ctx, ds), PV_PARAMS, T, Y * X, plan=plan).numpy()
+    assert out.shape == (N, T)
+    close(out, ref)
+    for agg in ("sum", "mean"):
+        o = ctx.pv(up(ctx, ds), PV_PARAMS, T, Y * X, plan=plan, time_agg=agg).numpy()
+        close(o, orc.aggregate_time(ref, agg, axis=1))
+
+
+def test_pv_per_cell_orientation(ctx):
+    T, Y, X = 36, 6, 10
+    ds = H.pv_dataset(T, Y, X, seed=4)
+    _, y = H.grid(Y, X)
+    ori = orc.orientation_latitude_optimal(np.radians(y))
+    slope = np.repeat(ori["slope"], X)
+    az = np.repeat(ori["azimuth"], X)
+    ref = orc.convert_pv(ds, H.CSI, dict(slope=slope[None, :], azimuth=az[None, :]))
+    out = ctx.pv(up(ctx, ds), dict(H.CSI, slope=slope, azimuth=az), T, Y * X).numpy()
+    close(out, ref)
+
+
+def test_pv_time_reduced_cells(ctx):
+    T, Y, X = 50, 6, 11
+    ds = H.pv_dataset(T, Y, X, seed=5)
+    ref = orc.convert_pv(ds, H.CSI, dict(slope=np.radians(30.0), azimuth=np.radians(180.0)))
+    for agg in ("sum", "mean"):
+        out = ctx.pv(up(ctx, ds), PV_PARAMS, T, Y * X, time_agg=agg).numpy()
+        close(out, orc.aggregate_time(ref, agg, axis=0))
+
+
+@pytest.mark.parametrize("method,aux", [("logarithmic", "roughness"), ("power", "wnd_shear_exp"), (None, None)])
+def test_wind_cells_and_fused(ctx, method, aux):
+    T, Y, X, N = 40, 9, 14, 4
+    ds = H.wind_dataset(T, Y, X, seed=6)
+    # exercise knots, cut-out, NaN, inf, below/above range
+    ds["wnd100m"][0, :8] = [0.0, 2.0, 25.0, 24.999999, 30.0, np.nan, np.inf, 13.0]
+    tb = H.V112
+    a = ds[aux] if aux else None
+    ref = orc.convert_wind(ds["wnd100m"], a, tb["V"], tb["POW"], tb["P"], 80.0, 100.0, method)
+    d_w = ctx.upload(ds["wnd100m"])
+    d_a = ctx.upload(a) if aux else None
+    out = ctx.wind(d_w, d_a, tb["V"], tb["POW"] / tb["P"], 80.0, 100.0, method, T, Y * X).numpy()
+    close(out, ref)
+    M = H.blob_matrix(N, Y, X, seed=7)
+    plan = ctx.plan(M)
+    ds["wnd100m"][0, :8] = 5.0  # NaN/inf would poison whole rows; covered separately
+    ref = orc.convert_wind(ds["wnd100m"], a, tb["V"], tb["POW"], tb["P"], 80.0, 100.0, method)
+    d_w = ctx.upload(ds["wnd100m"])
+    out = ctx.wind(d_w, d_a, tb["V"], tb["POW"] / tb["P"], 80.0, 100.0, method, T, Y * X, plan=plan).numpy()
+    close(out, orc.aggregate_matrix(ref, M))
+
+
+def test_wind_knot_exact(ctx):
+    tb = H.V112
+    x = np.array([[-1, 0, 1.9, 2, 2.5, 12.99, 13, 24.999999, 25, 25.0000001, 30, np.nan, np.inf, 7.0]])
+    ref = np.interp(x, tb["V"], tb["POW"] / tb["P"])
+    out = ctx.wind(ctx.upload(x), None, tb["V"], tb["POW"] / tb["P"], 80.0, 80.0, None, 1, x.shape[1]).numpy()
+    np.testing.assert_array_equal(out, ref)
+
+
+def test_heat_demand(ctx):
+    T, Y, X, N = 24 * 5 + 7, 6, 9, 3
+    rng = np.random.default_rng(8)
+    temp = 283.15 + 8 * rng.standard_normal((T, Y * X))
+    temp[5, 3] = np.nan
+    t = H.times(T)
+    for shift in (0.0, 4.0, -5.0):
+        ptr, _ = orc.day_groups(t, shift)
+        ref = orc.convert_heat_demand(temp, ptr, threshold=15.0, a=1.3, constant=0.2)
+        d_t = ctx.upload(temp)
+        out = ctx.heat_demand(d_t, ptr, 15.0 + 273.15, 1.3, 0.2, T, Y * X).numpy()
+        close(out, ref, atol_scale=1e-9)
+        tfin = np.where(np.isnan(temp), 280.0, temp)
+        ref = orc.convert_heat_demand(tfin, ptr, threshold=15.0, a=1.3, constant=0.2)
+        M = H.blob_matrix(N, Y, X, seed=9)
+        out = ctx.heat_demand(ctx.upload(tfin), ptr, 15.0 + 273.15, 1.3, 0.2, T, Y * X, plan=ctx.plan(M)).numpy()
+        close(out, orc.aggregate_matrix(ref, M), atol_scale=1e-9)
+
+
+def test_runoff(ctx):
+    T, Y, X, N = 33, 7, 13, 4
+    rng = np.random.default_rng(10)
+    ro = -1e-4 * np.log1p(-rng.random((T, Y * X)))
+    h = 2000 * rng.random(Y * X)
+    M = H.blob_matrix(N, Y, X, seed=11)
+    plan = ctx.plan(M)
+    for height in (h, None):
+        ref = orc.convert_runoff(ro, height[None, :] if height is not None else None)
+        d_h = ctx.upload(height) if height is not None else None
+        close(ctx.runoff(ctx.upload(ro), d_h, T, Y * X).numpy(), ref)
+        close(ctx.runoff(ctx.upload(ro), d_h, T, Y * X, plan=plan).numpy(), orc.aggregate_matrix(ref, M))
+
+
+@pytest.mark.parametrize("S", [1, 2, 127, 128, 129, 255, 1000])
+def test_spmm_shapes(ctx, S):
+    """generic CSR product incl. odd S (scalar path), duplicates, empty rows, explicit zeros."""
+    import scipy.sparse as sp
+
+    T, N = 19, 6
+    rng = np.random.default_rng(S)
+    D = rng.standard_normal((T, S))
+    M = sp.random(N, S, density=min(1.0, 8.0 / S + 0.05), random_state=S, format="csr")
+    M = sp.csr_matrix(M)
+    M[2, :] = 0  # becomes structurally empty after eliminate_zeros
+    M.eliminate_zeros()
+    ref = M @ D.T
+    out = ctx.spmm(ctx.plan(M), ctx.upload(D)).numpy()
+    close(out, ref, atol_scale=1e-13)
+
+
+def test_spmm_nan_semantics(ctx):
+    """CSR skips structural zeros: NaN cells outside a shape must not leak into it
+    (atlite/convert.py:313-316 relies on this); explicit zero weights do propagate NaN."""
+    import scipy.sparse as sp
+
+    T, S = 8, 300
+    rng = np.random.default_rng(0)
+    D = rng.random((T, S))
+    D[:, 10] = np.nan
+    D[3, 200] = np.nan
+    rows = [0, 0, 1, 1, 2]
+    cols = [5, 6, 10, 11, 200]
+    vals = [1.0, 0.5, 0.0, 1.0, 2.0]  # row 1 holds an EXPLICIT zero on the NaN cell
+    M = sp.csr_matrix((vals, (rows, cols)), shape=(3, S))
+    ref = M @ D.T
+    out = ctx.spmm(ctx.plan(M), ctx.upload(D)).numpy()
+    np.testing.assert_allclose(out, ref, rtol=1e-13, equal_nan=True)
+    assert np.isfinite(out[0]).all() and np.isnan(out[1]).all() and np.isnan(out[2, 3])
