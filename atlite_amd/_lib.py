@@ -141,6 +141,12 @@ SIGNATURES = {
     ),
     "atl_runoff_convert": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _vp]),
     "atl_runoff_convert_aggregate": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _i, _vp, _i64]),
+    "atl_indicator_polygons": (
+        _i,
+        [_i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _d, _d, _d, _d, C.POINTER(_vp), C.POINTER(_vp),
+         C.POINTER(_vp)],
+    ),
+    "atl_host_free": (_i, [_vp]),
     "atl_synth_field": (
         _i,
         [_vp, _i, C.c_uint64, C.c_uint64, _d, _d, _i, _i64, _i64, _vp],

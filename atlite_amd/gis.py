@@ -1,0 +1,160 @@
+"""
+GIS helpers on the path's input side: the indicator matrix of shapes against the cutout grid
+(reference: ``compute_indicatormatrix``, atlite/gis.py:104-145, called through
+``Cutout.indicatormatrix``, atlite/cutout.py:492-515) and ``spdiag`` (atlite/gis.py:78-84).
+
+The area computation runs in the library's host C++ (``atl_indicator_polygons``), not through
+shapely: exact polygon-box clipping, one entry per (shape, cell) with positive overlap.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+
+
+def spdiag(v):
+    """Sparse diagonal matrix from a 1-d array (atlite/gis.py:78-84)."""
+    v = np.asarray(v)
+    N = len(v)
+    inds = np.arange(N + 1, dtype=np.int32)
+    return sp.csr_matrix((v, inds[:-1], inds), (N, N))
+
+
+def _rings_of(shape):
+    """-> list of (ndarray (n,2), is_hole) for one shape in any accepted representation."""
+    if hasattr(shape, "geom_type"):  # shapely geometry, when shapely is installed
+        polys = list(shape.geoms) if shape.geom_type.startswith("Multi") else [shape]
+        out = []
+        for p in polys:
+            out.append((np.asarray(p.exterior.coords, dtype=np.float64)[:, :2], False))
+            out += [(np.asarray(h.coords, dtype=np.float64)[:, :2], True) for h in p.interiors]
+        return out
+    if isinstance(shape, dict):
+        out = [(np.asarray(shape["exterior"], dtype=np.float64), False)]
+        out += [(np.asarray(h, dtype=np.float64), True) for h in shape.get("holes", ())]
+        return out
+    if isinstance(shape, (list, tuple)) and len(shape) and not np.isscalar(shape[0][0]):
+        arr0 = np.asarray(shape[0])
+        if arr0.ndim == 2:  # multi-part: list of rings / dicts
+            out = []
+            for part in shape:
+                out += _rings_of(part)
+            return out
+    a = np.asarray(shape, dtype=np.float64)
+    if a.ndim != 2 or a.shape[1] != 2:
+        raise ValueError("a shape must be an (n, 2) vertex array, a dict(exterior=, holes=), "
+                         "a list of those, or a shapely polygon")
+    return [(a, False)]
+
+
+def compute_indicatormatrix(x, y, shapes):
+    """
+    Indicator matrix ``I[i, j]`` = share of grid cell ``j`` (``j = iy * X + ix``, cell = box of
+    centre +- half spacing) lying in ``shapes[i]``; returns ``scipy.sparse.csr_matrix (N, Y*X)``.
+
+    x, y : 1-d ascending, evenly spaced cell-centre coordinates (cutout.coords['x'/'y']).
+    shapes : sequence (or pandas Series) of polygons, see ``_rings_of``.
+    """
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    X, Y = len(x), len(y)
+    dx = float(x[1] - x[0]) if X > 1 else 1.0
+    dy = float(y[1] - y[0]) if Y > 1 else 1.0
+    if dx <= 0 or dy <= 0:
+        raise ValueError("grid coordinates must be ascending")
+    shapes = list(shapes.values) if hasattr(shapes, "values") and not isinstance(shapes, np.ndarray) else list(shapes)
+    shape_ptr, ring_ptr, holes, xy = [0], [0], [], []
+    for s in shapes:
+        for ring, is_hole in _rings_of(s):
+            xy.append(np.ascontiguousarray(ring, dtype=np.float64))
+            ring_ptr.append(ring_ptr[-1] + len(ring))
+            holes.append(1 if is_hole else 0)
+        shape_ptr.append(len(holes))
+    shape_ptr = np.asarray(shape_ptr, dtype=np.int64)
+    ring_ptr = np.asarray(ring_ptr, dtype=np.int64)
+    holes = np.asarray(holes, dtype=np.uint8)
+    xy = np.concatenate(xy) if xy else np.zeros((0, 2))
+    lib = _lib.load()
+    p_ip, p_ix, p_d = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _lib.check(
+        lib.atl_indicator_polygons(
+            len(shapes), shape_ptr.ctypes.data, len(holes), ring_ptr.ctypes.data,
+            holes.ctypes.data if len(holes) else None, xy.ctypes.data if len(xy) else None,
+            X, Y, float(x[0]), dx, float(y[0]), dy, C.byref(p_ip), C.byref(p_ix), C.byref(p_d),
+        )
+    )
+    try:
+        N = len(shapes)
+        indptr = np.ctypeslib.as_array(C.cast(p_ip, C.POINTER(C.c_int64)), (N + 1,)).copy()
+        nnz = int(indptr[-1])
+        indices = np.ctypeslib.as_array(C.cast(p_ix, C.POINTER(C.c_int32)), (max(nnz, 1),))[:nnz].copy()
+        data = np.ctypeslib.as_array(C.cast(p_d, C.POINTER(C.c_double)), (max(nnz, 1),))[:nnz].copy()
+    finally:
+        for p in (p_ip, p_ix, p_d):
+            lib.atl_host_free(p)
+    return sp.csr_matrix((data, indices, indptr), shape=(N, Y * X))
+
+
+def random_star_polygons(n, bounds, seed=42, n_vertices=8):
+    """
+    ``n`` star-convex polygons (``n_vertices`` each) with centres uniform in ``bounds`` =
+    (xmin, ymin, xmax, ymax) and mean area ~ domain / n; overlaps allowed.
+    """
+    rng = np.random.default_rng(seed)
+    xmin, ymin, xmax, ymax = bounds
+    w, h = xmax - xmin, ymax - ymin
+    r0 = np.sqrt(w * h / (np.pi * max(n, 1)))
+    polys = []
+    for _ in range(n):
+        cx, cy = rng.uniform(xmin, xmax), rng.uniform(ymin, ymax)
+        # jittered, evenly spread angles: consecutive gaps stay < pi, so the ring is simple
+        ang = (np.arange(n_vertices) + rng.uniform(0.1, 0.9, n_vertices)) * (2 * np.pi / n_vertices)
+        rad = r0 * rng.uniform(0.6, 1.4, n_vertices)
+        polys.append(np.column_stack([cx + rad * np.cos(ang), cy + rad * np.sin(ang)]))
+    return polys
+
+
+def random_tessellation(n, bounds, seed=42):
+    """
+    ``n`` convex polygons that tile ``bounds`` = (xmin, ymin, xmax, ymax) without gaps or
+    overlaps: the Voronoi cells of ``n`` random sites clipped to the domain (bus regions in
+    PyPSA-Eur style workflows are such a tessellation).  Every grid cell belongs to >= 1 shape.
+    """
+    rng = np.random.default_rng(seed)
+    xmin, ymin, xmax, ymax = bounds
+    sites = np.column_stack([rng.uniform(xmin, xmax, n), rng.uniform(ymin, ymax, n)])
+    box = np.array([[xmin, ymin], [xmax, ymin], [xmax, ymax], [xmin, ymax]], dtype=np.float64)
+    polys = []
+    for i in range(n):
+        poly = box
+        order = np.argsort(np.sum((sites - sites[i]) ** 2, axis=1))
+        for j in order[1:]:
+            if len(poly) == 0:
+                break
+            # half-plane of points closer to site i than to site j: a.p <= b
+            a = sites[j] - sites[i]
+            b = 0.5 * (np.dot(sites[j], sites[j]) - np.dot(sites[i], sites[i]))
+            if np.all(poly @ a <= b):
+                # sites are visited by increasing distance: once the bisector is farther than
+                # twice the cell's circumradius it cannot cut any more
+                if np.dot(a, a) > 4 * np.max(np.sum((poly - sites[i]) ** 2, axis=1)):
+                    break
+                continue
+            d = poly @ a - b
+            out = []
+            m = len(poly)
+            for k in range(m):
+                p, q = poly[k], poly[(k + 1) % m]
+                dp, dq = d[k], d[(k + 1) % m]
+                if dp <= 0:
+                    out.append(p)
+                if (dp < 0 < dq) or (dq < 0 < dp):
+                    out.append(p + (q - p) * (dp / (dp - dq)))
+            poly = np.asarray(out, dtype=np.float64).reshape(-1, 2)
+        polys.append(poly)
+    return polys

@@ -193,6 +193,22 @@ int atl_runoff_convert_aggregate(atl_ctx *ctx, const double *d_runoff, const dou
                                  int64_t T, int64_t S, const atl_agg *agg, int time_agg,
                                  double *d_out, int64_t ld_out);
 
+/* ---- indicator matrix (host code, no GPU) -----------------------------------------------
+ * Replaces compute_indicatormatrix (atlite/gis.py:104-145) for polygon shapes against the
+ * cutout grid (cells = boxes centre +- (dx/2, dy/2), atlite/cutout.py:369-376; x, y ascending):
+ * I[i,j] = area(shape_i n cell_j) / area(cell_j), cell j = y*X + x.  Shape i owns rings
+ * [h_shape_ring_ptr[i], h_shape_ring_ptr[i+1]); ring r owns vertices
+ * [h_ring_ptr[r], h_ring_ptr[r+1]) of h_xy (x0,y0,x1,y1,...); rings flagged in h_ring_is_hole
+ * (may be NULL) subtract.  The three CSR arrays are malloc'd by the library; release each with
+ * atl_host_free.
+ */
+int atl_indicator_polygons(int64_t n_shapes, const int64_t *h_shape_ring_ptr, int64_t n_rings,
+                           const int64_t *h_ring_ptr, const uint8_t *h_ring_is_hole,
+                           const double *h_xy, int64_t X, int64_t Y, double x0, double dx, double y0,
+                           double dy, int64_t **out_indptr, int32_t **out_indices,
+                           double **out_data);
+int atl_host_free(void *p);
+
 /* ---- synthetic ERA5-shaped inputs (bench/test tooling) ----------
  * Fills device cubes with a stateless splitmix64-hash field so that any (t, cell) slice can
  * be regenerated or downloaded for the oracle.  Not part of the reference's interface.
