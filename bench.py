@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=800, help="time steps of the CPU baseline sample")
+    ap.add_argument("--cpu-steps", type=int, default=3200, help="time steps of the CPU baseline sample")
     return ap.parse_args()
 
 
@@ -225,8 +225,16 @@ def main():
         Tc = min(a.cpu_steps, T_loc)
         t_a = 4000 if T_loc >= 4000 + Tc else 0  # daytime-rich slab in summer
         host = {k: inputs[k].slab(t_a, t_a + Tc).numpy() for k in synthetic.PV_VARS}
-        cores = os.cpu_count() or 1
-        cdt, _ = cpu_baseline(host, M, cores)
+        # one thread per 100-step chunk (dask's granularity), bounded by the host's cores and by RAM
+        # (each worker holds ~25 chunk-sized temporaries)
+        n_chunks = (Tc + 99) // 100
+        try:
+            avail = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) * 1024
+        except Exception:
+            avail = 16 << 30
+        by_mem = max(1, int(0.4 * avail / (25 * 100 * S * 8)))
+        cores = max(1, min(os.cpu_count() or 1, n_chunks, by_mem))
+        cdt = min(cpu_baseline(host, M, cores)[0] for _ in range(2))
         result["cpu_baseline"] = {
             "value": Tc * S / cdt,
             "unit": "cell-timesteps/s",
