@@ -1,0 +1,613 @@
+"""
+Host-side mirror of atlite's conversion interface for the hot path:
+
+* ``convert_and_aggregate``  - the gateway, atlite/convert.py:59-276
+* ``pv`` / ``wind`` / ``heat_demand`` / ``runoff`` - technology wrappers, convert.py:857-936,
+  665-744, 421-471, 1037-1084 (same signatures, defaults, warnings and exception classes)
+* ``convert_pv`` / ``convert_wind`` / ``convert_heat_demand`` / ``convert_runoff`` - the
+  ``convert_func`` callables the wrappers hand to the gateway.
+
+Where the reference builds a lazy dask graph and executes it with ``.load()``, this module
+resolves the configuration on the host and issues ONE fused call into ``libatlite_hip.so``
+(convert + indicator-matrix aggregation + optional time reduction, on the GPU).  Known
+converters are recognised by identity and never materialise the converted cube; an unknown
+``convert_func`` is called on the host dataset and its result is aggregated on the device with
+``atl_spmm_csr``.  There is no CPU fallback.
+"""
+
+from __future__ import annotations
+
+import datetime as dt
+import logging
+import re
+import warnings
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import scipy.sparse as sp
+
+from . import labeled
+from .device import DeviceArray, default_context
+from .gis import spdiag
+from .labeled import Dataset, LabeledArray
+from .pv.orientation import get_orientation
+from .resource import get_solarpanelconfig, get_windturbineconfig, windturbine_smooth
+
+logger = logging.getLogger(__name__)
+
+
+# --------------------------------------------------------------------------------------
+# converter descriptors
+# --------------------------------------------------------------------------------------
+class _Spec:
+    """A resolved conversion: knows its output time axis and how to launch itself."""
+
+    name = None
+    attrs = {}
+
+    def time_coord(self, ds):
+        return ds.coords["time"]
+
+    def run(self, ctx, ds, plan, time_agg):  # -> DeviceArray
+        raise NotImplementedError
+
+
+def _need(ds, names, exc, msg):
+    for n in names:
+        if n not in ds:
+            raise exc(msg)
+
+
+class _PvSpec(_Spec):
+    name = "specific generation"
+    attrs = {"units": "kWh/kWp"}
+
+    def __init__(self, ds, panel, orientation, tracking, trigon_model, clearsky_model):
+        if tracking is not None:
+            if tracking not in ("horizontal", "tilted_horizontal", "vertical", "dual"):
+                raise AssertionError(
+                    "Values describing tracking system must be None for no tracking,"
+                    + "'horizontal' for 1-axis horizontal tracking,"
+                    + "tilted_horizontal' for 1-axis horizontal tracking of tilted panle,"
+                    + "vertical' for 1-axis vertical tracking, or 'dual' for 2-axis tracking"
+                )
+            raise NotImplementedError(f"tracking={tracking!r} is not implemented on the GPU path yet")
+        if trigon_model != "simple":
+            raise NotImplementedError("only trigon_model='simple' is implemented on the GPU path")
+        if "influx" in ds:
+            if clearsky_model not in (None, "simple", "enhanced"):
+                raise KeyError("`clearsky model` must be chosen from 'simple' and 'enhanced'")
+            raise NotImplementedError("datasets with total 'influx' only (Reindl split) are not implemented yet")
+        if not ("influx_direct" in ds and "influx_diffuse" in ds):
+            raise AssertionError(
+                "Need either influx or influx_direct and influx_diffuse in the "
+                "dataset. Check your cutout and dataset module."
+            )
+        if "albedo" not in ds:
+            if "outflux" in ds:
+                raise NotImplementedError("albedo from outflux/influx is not implemented on the GPU path yet")
+            raise AssertionError(
+                "Need either albedo or outflux as a variable in the dataset. "
+                "Check your cutout and dataset module."
+            )
+        if not ("solar_altitude" in ds and "solar_azimuth" in ds):
+            raise NotImplementedError(
+                "datasets without solar_altitude/solar_azimuth need the in-kernel solar position variant "
+                "(not implemented yet); recreate the cutout so that it stores the solar position"
+            )
+        model = panel.get("model", "huld")
+        if model != "huld":
+            raise NotImplementedError(f"panel model {model!r} is not implemented on the GPU path yet")
+        self.panel = panel
+        # orientation callback evaluated on the host with radian lon / lat (orientation.py:104-107)
+        x, y = ds.coords["x"], ds.coords["y"]
+        lon = LabeledArray(np.radians(ds.coords["lon"]), ("x",), {"x": x}, name="lon")
+        lat = LabeledArray(np.radians(ds.coords["lat"]), ("y",), {"y": y}, name="lat")
+        o = orientation(lon, lat, None)
+        self.slope = self._cellwise(o["slope"], len(y), len(x))
+        self.azimuth = self._cellwise(o["azimuth"], len(y), len(x))
+
+    @staticmethod
+    def _cellwise(v, Y, X):
+        if isinstance(v, LabeledArray):
+            if "time" in v.dims:
+                raise NotImplementedError("time-dependent orientation is not implemented on the GPU path")
+            a = v.values
+            if v.dims == ("y",):
+                a = np.broadcast_to(a[:, None], (Y, X))
+            elif v.dims == ("x",):
+                a = np.broadcast_to(a[None, :], (Y, X))
+            elif v.dims == ("x", "y"):
+                a = a.T
+            return np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+        a = np.asarray(v, dtype=np.float64)
+        if a.ndim == 0:
+            return float(a)
+        return np.ascontiguousarray(np.broadcast_to(a, (Y, X))).reshape(-1)
+
+    def run(self, ctx, ds, plan, time_agg):
+        T, S = len(ds.coords["time"]), len(ds.coords["y"]) * len(ds.coords["x"])
+        names = ("influx_direct", "influx_diffuse", "influx_toa", "albedo", "temperature", "solar_altitude",
+                 "solar_azimuth")
+        inputs = {n: ds.device(ctx, n) for n in names}
+        slope, azimuth = self.slope, self.azimuth
+        if np.ndim(slope) != np.ndim(azimuth):  # mixed scalar / per-cell -> per-cell
+            slope = np.broadcast_to(slope, (S,))
+            azimuth = np.broadcast_to(azimuth, (S,))
+        params = dict(self.panel, slope=slope, azimuth=azimuth)
+        return ctx.pv(inputs, params, T, S, plan=plan, time_agg=time_agg)
+
+
+class _WindSpec(_Spec):
+    name = "specific generation"
+    attrs = {"units": "MWh/MWp"}
+
+    def __init__(self, ds, turbine, interpolation_method):
+        self.V = np.asarray(turbine["V"], dtype=np.float64)
+        self.POWn = np.asarray(turbine["POW"] / turbine["P"], dtype=np.float64)  # convert.py:649
+        to_height = turbine["hub_height"]
+        # extrapolate_wind_speed, atlite/wind.py:75-117
+        to_name = f"wnd{int(to_height):0d}m"
+        if to_name in ds:
+            self.method, self.wnd, self.aux, self.from_height = None, to_name, None, to_height
+        else:
+            heights = np.asarray([int(s[3:-1]) for s in ds if re.match(r"wnd\d+m", s)])
+            if len(heights) == 0:
+                raise AssertionError("Wind speed is not in dataset")
+            from_height = heights[np.argmin(np.abs(heights - to_height))]
+            self.wnd = f"wnd{int(from_height):0d}m"
+            self.from_height = float(from_height)
+            if interpolation_method == "logarithmic":
+                if "roughness" not in ds:
+                    raise RuntimeError(
+                        "The logarithmic interpolation method requires surface roughness (roughness);\n"
+                        "make sure you choose a compatible dataset like ERA5"
+                    )
+                self.method, self.aux = "logarithmic", "roughness"
+            elif interpolation_method == "power":
+                if "wnd_shear_exp" not in ds:
+                    raise RuntimeError(
+                        "The power law interpolation method requires a wind shear exponent (wnd_shear_exp);\n"
+                        "make sure you choose a compatible dataset like ERA5 and update your cutout"
+                    )
+                self.method, self.aux = "power", "wnd_shear_exp"
+            else:
+                raise ValueError(
+                    f"Interpolation method must be 'logarithmic' or 'power',  but is: {interpolation_method}"
+                )
+        self.to_height = float(to_height)
+
+    def run(self, ctx, ds, plan, time_agg):
+        T, S = len(ds.coords["time"]), len(ds.coords["y"]) * len(ds.coords["x"])
+        wnd = ds.device(ctx, self.wnd)
+        aux = ds.device(ctx, self.aux) if self.aux else None
+        return ctx.wind(wnd, aux, self.V, self.POWn, self.to_height, self.from_height, self.method, T, S,
+                        plan=plan, time_agg=time_agg)
+
+
+class _HeatSpec(_Spec):
+    name = "heat_demand"
+    attrs = {}
+
+    def __init__(self, ds, threshold, a, constant, hour_shift):
+        _need(ds, ["temperature"], KeyError, "temperature")
+        self.threshold_K = threshold + 273.15  # convert.py:413
+        self.a, self.constant = a, constant
+        # T.resample(time="1D") on the shifted axis: calendar-day bins, label = day start
+        t = ds.coords["time"] + pd.Timedelta(np.timedelta64(dt.timedelta(hours=hour_shift)))
+        if len(t) == 0:
+            self.day_ptr, self.days = np.zeros(1, dtype=np.int64), pd.DatetimeIndex([])
+        else:
+            day = t.floor("D")
+            self.days = pd.date_range(day[0], day[-1], freq="D")
+            edges = np.append(self.days.values, self.days.values[-1] + np.timedelta64(1, "D"))
+            self.day_ptr = np.searchsorted(day.values, edges).astype(np.int64)
+
+    def time_coord(self, ds):
+        return self.days
+
+    def run(self, ctx, ds, plan, time_agg):
+        T, S = len(ds.coords["time"]), len(ds.coords["y"]) * len(ds.coords["x"])
+        return ctx.heat_demand(ds.device(ctx, "temperature"), self.day_ptr, self.threshold_K, self.a,
+                               self.constant, T, S, plan=plan, time_agg=time_agg)
+
+
+class _RunoffSpec(_Spec):
+    name = "runoff"
+    attrs = {}
+
+    def __init__(self, ds, weight_with_height=True):
+        _need(ds, ["runoff"], KeyError, "runoff")
+        if weight_with_height:
+            _need(ds, ["height"], KeyError, "height")
+        self.weight_with_height = weight_with_height
+
+    def run(self, ctx, ds, plan, time_agg):
+        T, S = len(ds.coords["time"]), len(ds.coords["y"]) * len(ds.coords["x"])
+        h = ds.device(ctx, "height") if self.weight_with_height else None
+        return ctx.runoff(ds.device(ctx, "runoff"), h, T, S, plan=plan, time_agg=time_agg)
+
+
+def _per_cell(spec, ds):
+    """Run a spec without aggregation and wrap the (time, y, x) result (device-resident)."""
+    ctx = default_context()
+    out = spec.run(ctx, ds, None, None)
+    Y, X = len(ds.coords["y"]), len(ds.coords["x"])
+    tc = spec.time_coord(ds)
+    return LabeledArray(out.reshape(len(tc), Y, X), ("time", "y", "x"),
+                        {"time": tc, "y": ds.coords["y"], "x": ds.coords["x"]}, dict(spec.attrs), spec.name)
+
+
+def convert_pv(ds, panel, orientation, tracking, trigon_model="simple", clearsky_model="simple"):
+    """convert.py:840-854; returns the per-cell 'specific generation' cube (kWh/kWp)."""
+    return _per_cell(_PvSpec(ds, panel, orientation, tracking, trigon_model, clearsky_model), ds)
+
+
+def convert_wind(ds, turbine, interpolation_method):
+    """convert.py:634-662; per-cell 'specific generation' (MWh/MWp)."""
+    return _per_cell(_WindSpec(ds, turbine, interpolation_method), ds)
+
+
+def convert_heat_demand(ds, threshold, a, constant, hour_shift):
+    """convert.py:405-418; per-cell daily 'heat_demand'."""
+    return _per_cell(_HeatSpec(ds, threshold, a, constant, hour_shift), ds)
+
+
+def convert_runoff(ds, weight_with_height=True):
+    """convert.py:1028-1034."""
+    return _per_cell(_RunoffSpec(ds, weight_with_height), ds)
+
+
+_KNOWN = {convert_pv: _PvSpec, convert_wind: _WindSpec, convert_heat_demand: _HeatSpec,
+          convert_runoff: _RunoffSpec}
+
+
+class _CubeSpec(_Spec):
+    """Result of an arbitrary user ``convert_func``: an already converted (time, y, x) cube."""
+
+    def __init__(self, da, ds):
+        if labeled.xr is not None and isinstance(da, labeled.xr.DataArray):
+            da = LabeledArray(da.transpose("time", "y", "x").values, ("time", "y", "x"),
+                              {"time": da.coords["time"].values}, dict(da.attrs), da.name)
+        if not isinstance(da, LabeledArray):
+            da = LabeledArray(np.asarray(da), ("time", "y", "x"), {"time": ds.coords["time"]})
+        if da.dims != ("time", "y", "x"):
+            vals = da.data if isinstance(da.data, DeviceArray) else None
+            if vals is None:
+                da = da.transpose("time", "y", "x")
+            else:
+                raise ValueError("device-resident results must have dims (time, y, x)")
+        self.da = da
+        self.name, self.attrs = da.name, dict(da.attrs)
+
+    def time_coord(self, ds):
+        return pd.DatetimeIndex(self.da.coords["time"]) if "time" in self.da.coords else ds.coords["time"]
+
+    def run(self, ctx, ds, plan, time_agg):
+        d = ctx.asdevice(self.da.data)
+        T = d.shape[0]
+        d = d.reshape(T, -1)
+        if plan is None:
+            if time_agg is None:
+                return d
+            # identity conversion + time reduction on the device (runoff kernel without height)
+            return ctx.runoff(d, None, T, d.shape[1], plan=None, time_agg=time_agg)
+        return ctx.spmm(plan, d, time_agg=time_agg)
+
+
+# --------------------------------------------------------------------------------------
+# gateway
+# --------------------------------------------------------------------------------------
+def _aggregate_time(da, method):
+    """convert.py:51-56."""
+    if method == "sum":
+        return da.sum("time", keep_attrs=True)
+    elif method == "mean":
+        return da.mean("time", keep_attrs=True)
+    return da
+
+
+def _index_coords(index):
+    """utils.ensure_coords (atlite/utils.py:22-36): -> (dim name, coordinate values)."""
+    if labeled.xr is not None and isinstance(index, labeled.xr.Coordinates):
+        dims = list(index.dims)
+        if len(dims) > 1:
+            raise ValueError(f"index must have a single dimension, not: {tuple(dims)}")
+        return dims[0], index[dims[0]].values
+    if isinstance(index, pd.Index):
+        return index.name or "dim_0", index
+    raise ValueError(f"index must be a pandas index or xarray coordinates, not: {index}")
+
+
+def _as_dataset(data):
+    if isinstance(data, Dataset):
+        return data
+    if labeled.xr is not None and isinstance(data, labeled.xr.Dataset):
+        return Dataset.from_xarray(data)
+    raise TypeError(f"cutout.data must be an atlite_amd.Dataset (or an xarray.Dataset), not {type(data)}")
+
+
+def _finish(la):
+    """Return a real xarray.DataArray when xarray is available, else the LabeledArray."""
+    if labeled.xr is not None:
+        return la.to_xarray()
+    return la
+
+
+def convert_and_aggregate(
+    cutout,
+    convert_func,
+    matrix=None,
+    index=None,
+    layout=None,
+    shapes=None,
+    shapes_crs=4326,
+    per_unit=False,
+    return_capacity=False,
+    aggregate_time="legacy",
+    capacity_factor=False,
+    capacity_factor_timeseries=False,
+    show_progress=False,
+    dask_kwargs={},
+    **convert_kwds,
+):
+    """
+    Convert and aggregate a weather-based renewable generation time-series on the GPU.
+
+    Same parameters and return values as atlite's gateway (convert.py:59-159):
+    ``matrix`` (N x S sparse / dense / labelled), ``index``, ``layout`` ((y, x) labelled array),
+    ``shapes`` (+ ``shapes_crs``), ``per_unit``, ``return_capacity``, ``aggregate_time`` in
+    {"sum", "mean", "legacy", None}, deprecated ``capacity_factor`` /
+    ``capacity_factor_timeseries``; ``show_progress`` and ``dask_kwargs`` are accepted and
+    ignored (there is no dask graph to execute).  ``**convert_kwds`` go to ``convert_func``.
+    """
+    if aggregate_time not in ("sum", "mean", "legacy", None):
+        raise ValueError(f"aggregate_time must be 'sum', 'mean', 'legacy', or None, got {aggregate_time!r}")
+
+    if aggregate_time == "legacy":
+        warnings.warn(
+            "aggregate_time='legacy' is deprecated and will be removed in a "
+            "future release. Pass 'sum', 'mean', or None explicitly.",
+            FutureWarning,
+            stacklevel=2,
+        )
+
+    if capacity_factor or capacity_factor_timeseries:
+        if aggregate_time != "legacy":
+            raise ValueError(
+                "Cannot use 'aggregate_time' together with deprecated "
+                "'capacity_factor' or 'capacity_factor_timeseries'."
+            )
+        if capacity_factor:
+            warnings.warn("capacity_factor is deprecated. Use aggregate_time='mean' instead.", FutureWarning,
+                          stacklevel=2)
+            aggregate_time = "mean"
+        if capacity_factor_timeseries:
+            warnings.warn("capacity_factor_timeseries is deprecated. Use aggregate_time=None instead.",
+                          FutureWarning, stacklevel=2)
+            aggregate_time = None
+
+    func_name = convert_func.__name__.replace("convert_", "")
+    logger.info(f"Convert and aggregate '{func_name}'.")
+    ds = _as_dataset(cutout.data)
+    if convert_func in _KNOWN:
+        spec = _KNOWN[convert_func](ds, **convert_kwds)
+    else:
+        spec = _CubeSpec(convert_func(cutout.data, **convert_kwds), ds)
+
+    ctx = default_context()
+    Y, X = len(ds.coords["y"]), len(ds.coords["x"])
+    no_args = all(v is None for v in [layout, shapes, matrix])
+
+    if no_args:
+        if per_unit or return_capacity:
+            raise ValueError("One of `matrix`, `shapes` and `layout` must be given for `per_unit` or `return_capacity`")
+        agg = "sum" if aggregate_time == "legacy" else aggregate_time
+        out = spec.run(ctx, ds, None, agg)
+        if agg is None:
+            tc = spec.time_coord(ds)
+            res = LabeledArray(out.reshape(len(tc), Y, X), ("time", "y", "x"),
+                               {"time": tc, "y": ds.coords["y"], "x": ds.coords["x"]}, dict(spec.attrs), spec.name)
+        else:
+            res = LabeledArray(out.numpy().reshape(Y, X), ("y", "x"), {"y": ds.coords["y"], "x": ds.coords["x"]},
+                               dict(spec.attrs), spec.name)
+        return _finish(res) if agg is not None else res
+
+    if matrix is not None:
+        if shapes is not None:
+            raise ValueError("Passing matrix and shapes is ambiguous. Pass only one of them.")
+        is_xr = labeled.xr is not None and isinstance(matrix, labeled.xr.DataArray)
+        if isinstance(matrix, LabeledArray) or is_xr:
+            sdim = matrix.dims[1]
+            mx, my = np.asarray(matrix.coords["x"]), np.asarray(matrix.coords["y"])
+            if is_xr:
+                mx, my = matrix.coords["x"].values, matrix.coords["y"].values
+            g = cutout.grid
+            if not (np.array_equal(mx, g["x"].values) and np.array_equal(my, g["y"].values)):
+                raise ValueError("Matrix spatial coordinates not aligned with cutout spatial coordinates.")
+            if index is None:
+                d0 = matrix.dims[0]
+                c0 = matrix.coords[d0].values if is_xr else matrix.coords.get(d0, np.arange(matrix.shape[0]))
+                index = pd.Index(np.asarray(c0), name=d0)
+            del sdim
+            matrix = np.asarray(matrix.values)
+        if not matrix.ndim == 2:
+            raise ValueError("Matrix not 2-dimensional.")
+        matrix = sp.csr_matrix(matrix)
+
+    if shapes is not None:
+        if isinstance(shapes, pd.Series) and index is None:
+            index = shapes.index
+        matrix = sp.csr_matrix(cutout.indicatormatrix(shapes, shapes_crs))
+
+    if layout is not None:
+        is_xr = labeled.xr is not None and isinstance(layout, labeled.xr.DataArray)
+        assert isinstance(layout, LabeledArray) or is_xr
+        lay = _reindex_layout(layout, ds)
+        if matrix is None:
+            matrix = sp.csr_matrix(lay[None, :])
+        else:
+            matrix = sp.csr_matrix(matrix) * spdiag(lay)
+
+    assert isinstance(matrix, sp.csr_matrix)
+    if matrix.shape[1] != Y * X:
+        raise ValueError(f"matrix has {matrix.shape[1]} columns but the cutout has {Y * X} grid cells")
+
+    dim, index_vals = _index_coords(pd.RangeIndex(matrix.shape[0]) if index is None else index)
+
+    # per-unit needs the series on the host anyway (fillna(0) precedes the time reduction)
+    on_device_time = aggregate_time if (aggregate_time in ("sum", "mean") and not per_unit) else None
+    plan = ctx.plan(matrix, row_len=X)
+    out = spec.run(ctx, ds, plan, on_device_time).numpy()
+    plan.close()
+    tc = spec.time_coord(ds)
+    attrs = {}
+
+    if per_unit or return_capacity:
+        caps = np.asarray(matrix.sum(-1)).flatten()
+        capacity = LabeledArray(caps, (dim,), {dim: index_vals}, {"units": "MW"})
+
+    if on_device_time is not None:
+        results = LabeledArray(out, (dim,), {dim: index_vals}, attrs)
+    else:
+        results = LabeledArray(out, (dim, "time"), {dim: index_vals, "time": tc}, attrs)
+        if ds.chunked:  # dask branch of aggregate_matrix returns (time, dim)
+            results = results.transpose("time", dim)
+
+    if per_unit:
+        with np.errstate(invalid="ignore", divide="ignore"):
+            cap = np.where(caps != 0, caps, np.nan)
+            shape = [1] * results.ndim
+            shape[results.dims.index(dim)] = -1
+            vals = results.values / cap.reshape(shape)
+        results = LabeledArray(np.where(np.isnan(vals), 0.0, vals), results.dims, results.coords)
+        results.attrs["units"] = "p.u."
+    else:
+        results.attrs["units"] = "MW"
+
+    if aggregate_time != "legacy" and on_device_time is None:
+        results = _aggregate_time(results, aggregate_time)
+
+    if return_capacity:
+        return _finish(results), _finish(capacity)
+    return _finish(results)
+
+
+def _reindex_layout(layout, ds):
+    """layout.reindex_like(cutout.data).stack(spatial=["y","x"]) (convert.py:244) -> (S,) array."""
+    if labeled.xr is not None and isinstance(layout, labeled.xr.DataArray):
+        layout = LabeledArray(layout.values, layout.dims, {d: layout.coords[d].values for d in layout.dims})
+    la = layout if layout.dims == ("y", "x") else layout.transpose("y", "x")
+    vals = np.asarray(la.values, dtype=np.float64)
+    for ax, d in enumerate(("y", "x")):
+        have = pd.Index(np.asarray(la.coords[d])) if d in la.coords else pd.Index(ds.coords[d])
+        want = pd.Index(ds.coords[d])
+        if not have.equals(want):
+            idx = have.get_indexer(want)
+            taken = np.take(vals, np.where(idx < 0, 0, idx), axis=ax)
+            mask = (idx < 0).reshape([-1 if i == ax else 1 for i in range(2)])
+            vals = np.where(mask, np.nan, taken)
+    return np.ascontiguousarray(vals).reshape(-1)
+
+
+# --------------------------------------------------------------------------------------
+# technology wrappers (signatures as in atlite/convert.py)
+# --------------------------------------------------------------------------------------
+def pv(cutout, panel, orientation, tracking=None, clearsky_model=None, **params):
+    """Solar PV generation time-series (convert.py:857-936)."""
+    if isinstance(panel, (str, Path)):
+        panel = get_solarpanelconfig(panel)
+    if not callable(orientation):
+        orientation = get_orientation(orientation)
+    return cutout.convert_and_aggregate(
+        convert_func=convert_pv,
+        panel=panel,
+        orientation=orientation,
+        tracking=tracking,
+        clearsky_model=clearsky_model,
+        **params,
+    )
+
+
+def wind(cutout, turbine, smooth=False, add_cutout_windspeed=False, interpolation_method="logarithmic", **params):
+    """Wind generation time-series (convert.py:665-744)."""
+    turbine = get_windturbineconfig(turbine, add_cutout_windspeed=add_cutout_windspeed)
+    if smooth:
+        turbine = windturbine_smooth(turbine, params=smooth)
+    return cutout.convert_and_aggregate(
+        convert_func=convert_wind,
+        turbine=turbine,
+        interpolation_method=interpolation_method,
+        **params,
+    )
+
+
+def heat_demand(cutout, threshold=15.0, a=1.0, constant=0.0, hour_shift=0.0, **params):
+    """Daily heat demand by the degree-day approximation (convert.py:421-471)."""
+    return cutout.convert_and_aggregate(
+        convert_func=convert_heat_demand,
+        threshold=threshold,
+        a=a,
+        constant=constant,
+        hour_shift=hour_shift,
+        **params,
+    )
+
+
+def _values_of(r):
+    return np.asarray(r.values)
+
+
+def runoff(cutout, smooth=None, lower_threshold_quantile=None, normalize_using_yearly=None, **params):
+    """
+    Runoff (optionally height-weighted) aggregated to shapes, with the reference's
+    post-processing of the small (shapes x time) result on the host (convert.py:1037-1084).
+    """
+    result = cutout.convert_and_aggregate(convert_func=convert_runoff, **params)
+    cap = None
+    if "return_capacity" in params.keys() and isinstance(result, tuple):
+        result, cap = result
+    is_xr = labeled.xr is not None and isinstance(result, labeled.xr.DataArray)
+    la = result if not is_xr else LabeledArray(result.values, result.dims,
+                                               {d: result.coords[d].values for d in result.dims},
+                                               dict(result.attrs), result.name)
+
+    if smooth is not None:
+        if smooth is True:
+            smooth = 24 * 7
+        ax = la.get_axis_num("time")
+        df = pd.DataFrame(np.moveaxis(la.values, ax, 0))
+        sm = df.rolling(smooth, min_periods=1).mean().values
+        la = LabeledArray(np.moveaxis(sm, 0, ax), la.dims, la.coords, la.attrs, la.name)
+
+    if lower_threshold_quantile is not None:
+        if lower_threshold_quantile is True:
+            lower_threshold_quantile = 5e-3
+        lower_threshold = pd.Series(la.values.ravel()).quantile(lower_threshold_quantile)
+        la = LabeledArray(np.where(la.values >= lower_threshold, la.values, 0.0), la.dims, la.coords, la.attrs,
+                          la.name)
+
+    if normalize_using_yearly is not None:
+        nidx = normalize_using_yearly.index
+        nidx = nidx.year if isinstance(nidx, pd.DatetimeIndex) else nidx.astype(int)
+        tyear = pd.Series(pd.to_datetime(la.coords["time"]).year)
+        years = tyear.value_counts().loc[lambda x: x > 8700].index.intersection(nidx)
+        assert len(years), "Need at least a full year of data (more is better)"
+        lo, hi = min(years), max(years)
+        tmask = ((tyear >= lo) & (tyear <= hi)).values
+        ax = la.get_axis_num("time")
+        dim = la.dims[1 - ax]
+        ref = normalize_using_yearly.copy()
+        ref.index = nidx
+        ref = ref.loc[lo:hi].sum()
+        ref = ref.reindex(pd.Index(la.coords[dim])).values
+        tot = np.nansum(np.compress(tmask, la.values, axis=ax), axis=ax)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            fac = ref / tot
+        shape = [1, 1]
+        shape[1 - ax] = -1
+        la = LabeledArray(la.values * fac.reshape(shape), la.dims, la.coords, la.attrs, la.name)
+
+    out = _finish(la) if is_xr or labeled.xr is not None else la
+    return (out, cap) if cap is not None else out

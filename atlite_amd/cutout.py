@@ -1,0 +1,88 @@
+"""
+A duck-typed cutout: exactly what the hot path touches on ``atlite.Cutout`` - ``.data``,
+``.grid``, ``.indicatormatrix`` and the conversion methods bound as attributes
+(atlite/cutout.py:355-376, 492-515, 653-689).  Creating / preparing / reading cutouts
+(NetCDF, CDS downloads, GIS reprojection) is outside the hot path and not provided; build a
+``Dataset`` from arrays you already hold (host NumPy, torch CUDA tensors or DeviceArrays), or
+pass an ``xarray.Dataset`` where xarray is installed.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+
+from . import convert as _convert
+from . import gis, labeled
+from .labeled import Dataset
+
+
+class Cutout:
+    def __init__(self, data, crs=4326):
+        if labeled.xr is not None and isinstance(data, labeled.xr.Dataset):
+            data = Dataset.from_xarray(data)
+        if not isinstance(data, Dataset):
+            raise TypeError("Cutout needs an atlite_amd.Dataset (or an xarray.Dataset)")
+        self.data = data
+        self.crs = crs
+
+    # -- geometry (atlite/cutout.py:250-376) ------------------------------------------------
+    @property
+    def coords(self):
+        return self.data.coords
+
+    @property
+    def shape(self):
+        return len(self.coords["y"]), len(self.coords["x"])
+
+    @property
+    def dx(self):
+        x = self.coords["x"]
+        return float((x[-1] - x[0]) / (len(x) - 1)) if len(x) > 1 else 1.0
+
+    @property
+    def dy(self):
+        y = self.coords["y"]
+        return float((y[-1] - y[0]) / (len(y) - 1)) if len(y) > 1 else 1.0
+
+    @property
+    def extent(self):
+        x, y = self.coords["x"], self.coords["y"]
+        return np.array([x[0] - self.dx / 2, x[-1] + self.dx / 2, y[0] - self.dy / 2, y[-1] + self.dy / 2])
+
+    @property
+    def bounds(self):
+        e = self.extent
+        return np.array([e[0], e[2], e[1], e[3]])
+
+    @property
+    def grid(self):
+        """Frame with cell-centre columns 'x' and 'y', cells in y-major order (cutout.py:369-376)."""
+        xs, ys = np.meshgrid(self.coords["x"], self.coords["y"])
+        return pd.DataFrame({"x": np.ravel(xs), "y": np.ravel(ys)})
+
+    def indicatormatrix(self, shapes, shapes_crs=4326):
+        """Share of every grid cell lying in every shape, sparse (N x Y*X) (cutout.py:492-515)."""
+        if shapes_crs != self.crs:
+            raise NotImplementedError("reprojection of shapes needs pyproj; pass shapes in the cutout's crs")
+        return gis.compute_indicatormatrix(self.coords["x"], self.coords["y"], shapes)
+
+    def uniform_layout(self):
+        from .labeled import LabeledArray
+
+        Y, X = self.shape
+        return LabeledArray(np.ones((Y, X)), ("y", "x"), {"y": self.coords["y"], "x": self.coords["x"]},
+                            name="Capacity")
+
+    # -- conversion methods bound like the reference does (cutout.py:653-689) -----------------
+    convert_and_aggregate = _convert.convert_and_aggregate
+    pv = _convert.pv
+    wind = _convert.wind
+    heat_demand = _convert.heat_demand
+    runoff = _convert.runoff
+
+    def __repr__(self):
+        t = self.coords["time"]
+        return (f"<Cutout (amd) x={self.coords['x'][0]:.2f}-{self.coords['x'][-1]:.2f} "
+                f"y={self.coords['y'][0]:.2f}-{self.coords['y'][-1]:.2f} time={t[0]}..{t[-1]} "
+                f"vars={list(self.data.data_vars)}>")

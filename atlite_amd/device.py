@@ -83,7 +83,7 @@ class DeviceArray:
 class AggPlan:
     """Indicator matrix (scipy CSR, N x S) preprocessed into the segment-local device layout."""
 
-    def __init__(self, ctx, matrix):
+    def __init__(self, ctx, matrix, row_len=None):
         import scipy.sparse as sp
 
         m = sp.csr_matrix(matrix)
@@ -196,8 +196,9 @@ class Context:
         return ms.value
 
     # -- plans ----------------------------------------------------------------------------
-    def plan(self, matrix):
-        return AggPlan(self, matrix)
+    def plan(self, matrix, row_len=None):
+        """row_len = X of the (Y, X) grid lets the plan use compact 2-d cell tiles."""
+        return AggPlan(self, matrix, row_len=row_len)
 
     # -- conversions (device in, device out) ------------------------------------------------
     def _out(self, plan, n_slots, S, time_agg):

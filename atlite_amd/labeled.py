@@ -1,0 +1,251 @@
+"""
+Minimal labelled-array containers.
+
+The reference passes ``xarray`` objects across the hot-path boundary (``cutout.data`` is an
+``xr.Dataset``, results are ``xr.DataArray``; atlite/convert.py:59-276).  xarray is not part
+of this image, so the host layer works on two small stand-ins that carry exactly what the
+path needs - values (host ``numpy`` or device ``DeviceArray``), dimension names, coordinates,
+attrs, name - and converts to / from real xarray objects when xarray is importable
+(``LabeledArray.to_xarray``, ``Dataset.from_xarray``).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+
+try:  # optional
+    import xarray as xr
+except Exception:  # pragma: no cover - xarray is absent from the build image
+    xr = None
+
+
+def _is_device(x):
+    return type(x).__name__ == "DeviceArray"
+
+
+class LabeledArray:
+    """``values`` + ``dims`` + ``coords`` + ``attrs`` + ``name`` (a tiny DataArray stand-in)."""
+
+    def __init__(self, values, dims, coords=None, attrs=None, name=None):
+        self._values = values if _is_device(values) else np.asarray(values)
+        self.dims = tuple(dims)
+        if len(self.dims) != len(self._values.shape):
+            raise ValueError(f"dims {self.dims} do not match shape {self._values.shape}")
+        self.coords = {}
+        for k, v in (coords or {}).items():
+            self.coords[k] = v if isinstance(v, pd.Index) else np.asarray(v)
+        self.attrs = dict(attrs or {})
+        self.name = name
+
+    # -- data access ----------------------------------------------------------------------
+    @property
+    def data(self):
+        """Underlying storage: numpy array or DeviceArray."""
+        return self._values
+
+    @property
+    def values(self):
+        if _is_device(self._values):
+            return self._values.numpy()
+        return self._values
+
+    def __array__(self, dtype=None, copy=None):
+        v = self.values
+        return v if dtype is None else v.astype(dtype)
+
+    @property
+    def shape(self):
+        return tuple(self._values.shape)
+
+    @property
+    def ndim(self):
+        return len(self.dims)
+
+    @property
+    def sizes(self):
+        return dict(zip(self.dims, self.shape))
+
+    @property
+    def dtype(self):
+        return self._values.dtype
+
+    def get_axis_num(self, dim):
+        return self.dims.index(dim)
+
+    # -- light algebra (host, small results only) -------------------------------------------
+    def _like(self, values, dims=None, drop=()):
+        dims = self.dims if dims is None else tuple(dims)
+        coords = {k: v for k, v in self.coords.items() if k in dims and k not in drop}
+        return LabeledArray(values, dims, coords, self.attrs, self.name)
+
+    def transpose(self, *dims):
+        if not dims:
+            dims = self.dims[::-1]
+        order = [self.dims.index(d) for d in dims]
+        return self._like(np.transpose(self.values, order), dims)
+
+    def _reduce(self, fn, dim):
+        ax = self.dims.index(dim)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            vals = fn(self.values, ax)
+        return self._like(vals, [d for d in self.dims if d != dim], drop=(dim,))
+
+    def sum(self, dim, keep_attrs=True):
+        return self._reduce(lambda v, ax: np.nansum(v, axis=ax), dim)
+
+    def mean(self, dim, keep_attrs=True):
+        def f(v, ax):
+            cnt = np.sum(~np.isnan(v), axis=ax)
+            return np.nansum(v, axis=ax) / cnt
+
+        return self._reduce(f, dim)
+
+    def isel(self, **idx):
+        vals, dims, coords = self.values, list(self.dims), dict(self.coords)
+        for d, i in idx.items():
+            ax = dims.index(d)
+            vals = np.take(vals, i, axis=ax)
+            if np.ndim(i) == 0:
+                dims.pop(ax)
+                coords.pop(d, None)
+            elif d in coords:
+                coords[d] = np.asarray(coords[d])[i]
+        return LabeledArray(vals, dims, coords, self.attrs, self.name)
+
+    def rename(self, name):
+        out = self._like(self._values)
+        out.name = name
+        return out
+
+    def to_pandas(self):
+        v = self.values
+        if self.ndim == 1:
+            return pd.Series(v, index=pd.Index(self.coords.get(self.dims[0], np.arange(len(v))), name=self.dims[0]),
+                             name=self.name)
+        if self.ndim == 2:
+            return pd.DataFrame(
+                v,
+                index=pd.Index(self.coords.get(self.dims[0], np.arange(v.shape[0])), name=self.dims[0]),
+                columns=pd.Index(self.coords.get(self.dims[1], np.arange(v.shape[1])), name=self.dims[1]),
+            )
+        raise ValueError("to_pandas supports 1-d and 2-d arrays")
+
+    def to_xarray(self):
+        if xr is None:
+            raise ImportError("xarray is not installed")
+        return xr.DataArray(self.values, dims=self.dims, coords={k: (k, np.asarray(v)) for k, v in self.coords.items()},
+                            attrs=self.attrs, name=self.name)
+
+    def __repr__(self):
+        where = "device" if _is_device(self._values) else "host"
+        return f"<LabeledArray {self.name!r} {self.sizes} [{where}] attrs={self.attrs}>"
+
+
+class Dataset:
+    """
+    Dict of (time, y, x) / (y, x) variables sharing coordinates - what the hot path reads from
+    ``cutout.data`` (variable names as in atlite/datasets/era5.py:47-60).
+
+    ``chunked=True`` marks a dataset that plays the role of a dask-backed cutout (file-loaded
+    cutouts always are, atlite/cutout.py:143,151-153): aggregated results then come back as
+    ``(time, <index>)`` like the reference's dask branch, otherwise ``(<index>, time)``
+    (atlite/aggregate.py:21-35).
+    """
+
+    def __init__(self, data_vars, coords, attrs=None, chunked=False):
+        self.coords = {}
+        for k, v in coords.items():
+            self.coords[k] = pd.DatetimeIndex(v) if k == "time" else np.asarray(v, dtype=np.float64)
+        if "lon" not in self.coords and "x" in self.coords:
+            self.coords["lon"] = self.coords["x"]  # atlite/gis.py:73
+        if "lat" not in self.coords and "y" in self.coords:
+            self.coords["lat"] = self.coords["y"]
+        self.attrs = dict(attrs or {})
+        self.chunked = bool(chunked)
+        self._vars = {}
+        for k, v in data_vars.items():
+            self[k] = v
+        self._device_cache = {}
+
+    @classmethod
+    def from_xarray(cls, ds, chunked=None):
+        coords = {k: ds.coords[k].values for k in ("time", "y", "x") if k in ds.coords}
+        if chunked is None:
+            chunked = bool(getattr(ds, "chunks", None))
+        dv = {}
+        for k in ds.data_vars:
+            da = ds[k]
+            dims = tuple(d for d in ("time", "y", "x") if d in da.dims)
+            dv[k] = LabeledArray(da.transpose(*dims).values, dims)
+        return cls(dv, coords, dict(ds.attrs), chunked=chunked)
+
+    def __setitem__(self, name, value):
+        if isinstance(value, LabeledArray):
+            la = value
+        else:
+            shape = tuple(value.shape)
+            T, Y, X = (len(self.coords.get(k, ())) for k in ("time", "y", "x"))
+            if len(shape) == 3:
+                dims = ("time", "y", "x")
+            elif len(shape) == 2 and shape == (Y, X):
+                dims = ("y", "x")
+            elif len(shape) == 2 and shape == (T, Y * X):
+                value = value.reshape(T, Y, X)
+                dims = ("time", "y", "x")
+            elif len(shape) == 1 and shape == (Y * X,):
+                value = value.reshape(Y, X)
+                dims = ("y", "x")
+            else:
+                raise ValueError(f"cannot infer dims of variable {name!r} with shape {shape}")
+            la = LabeledArray(value, dims)
+        la.coords = {d: self.coords[d] for d in la.dims if d in self.coords}
+        if la.name is None:
+            la.name = name
+        self._vars[name] = la
+        if hasattr(self, "_device_cache"):
+            self._device_cache.pop(name, None)
+
+    def __getitem__(self, name):
+        if name in self._vars:
+            return self._vars[name]
+        if name in self.coords:
+            c = self.coords[name]
+            dim = {"lon": "x", "lat": "y"}.get(name, name)
+            return LabeledArray(np.asarray(c), (dim,), {dim: self.coords[dim]}, name=name)
+        raise KeyError(name)
+
+    def __contains__(self, name):
+        return name in self._vars
+
+    def __iter__(self):
+        return iter(self._vars)
+
+    def keys(self):
+        return self._vars.keys()
+
+    @property
+    def data_vars(self):
+        return self._vars
+
+    @property
+    def sizes(self):
+        return {k: len(self.coords[k]) for k in ("time", "y", "x") if k in self.coords}
+
+    @property
+    def indexes(self):
+        return {k: pd.Index(v) for k, v in self.coords.items() if k in ("time", "y", "x")}
+
+    def device(self, ctx, name):
+        """DeviceArray of variable ``name`` flattened to (T, S) or (S,); uploads host data once."""
+        la = self._vars[name]
+        if name not in self._device_cache or self._device_cache[name].ctx is not ctx:
+            d = ctx.asdevice(la.data)
+            self._device_cache[name] = d
+        d = self._device_cache[name]
+        if la.dims == ("time", "y", "x"):
+            return d.reshape(d.shape[0], -1) if d.ndim == 3 else d
+        return d.reshape(-1)
+
+    def __repr__(self):
+        return f"<Dataset {self.sizes} vars={list(self._vars)} chunked={self.chunked}>"

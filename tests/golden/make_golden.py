@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""
+Freeze golden input/output vectors by executing the REFERENCE's own source files
+(/root/reference/atlite/convert.py, aggregate.py, wind.py, resource.py, pv/*.py) under the
+xarray/dask stand-in of ``refshim.py``.  Run in the build container only:
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+
+The .npz files are small (T<=77, 6x8 grid) and committed; tests never need /root/reference.
+"""
+
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import scipy.sparse as sp
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+import refshim  # noqa: E402
+
+refshim.install()
+import xarray as xr  # noqa: E402  (the stand-in)
+
+conv = refshim.reference("atlite.convert")
+res = refshim.reference("atlite.resource")
+solpos = refshim.reference("atlite.pv.solar_position")
+orient = refshim.reference("atlite.pv.orientation")
+
+Y, X = 6, 8
+x = -25.0 + (70.0 / X) * np.arange(X)
+y = 30.0 + (42.0 / Y) * np.arange(Y)
+
+
+def dataset(variables, time):
+    coords = {"time": time, "y": y, "x": x}
+    ds = xr.Dataset(
+        {k: xr.DataArray(v, dims=["time", "y", "x"][-v.ndim:], coords={d: coords[d] for d in ["time", "y", "x"][-v.ndim:]})
+         for k, v in variables.items()},
+        coords={"time": time, "y": y, "x": x, "lon": ("x", x), "lat": ("y", y)},
+    )
+    return ds
+
+
+class MockCutout:  # as in the reference's test/test_aggregate_time.py:13-17
+    def __init__(self, data):
+        self.data = data
+        grid_coords = np.array([(xx, yy) for yy in data["y"].values for xx in data["x"].values])
+        self.grid = pd.DataFrame(grid_coords, columns=["x", "y"])
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        v = v.values if hasattr(v, "values") and not isinstance(v, np.ndarray) else v
+        out[k] = np.asarray(v)
+    np.savez_compressed(HERE / f"{name}.npz", **out)
+    print(f"  wrote {name}.npz: " + ", ".join(f"{k}{tuple(v.shape)}" for k, v in out.items()))
+
+
+def main():
+    rng = np.random.default_rng(20260925)
+    # ---------------------------------------------------------------- solar position ------
+    t = pd.date_range("2013-03-19 18:00", periods=77, freq="h")
+    ds0 = dataset({"dummy": np.zeros((len(t), Y, X))}, t)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        sp_ = solpos.SolarPosition(ds0, time_shift="-30min")  # era5.py:185-186
+        sp0 = solpos.SolarPosition(ds0)
+    alt, az = sp_["altitude"].values, sp_["azimuth"].values
+    save("solar_position", time=t.values.astype("datetime64[ns]").astype(np.int64), x=x, y=y,
+         altitude_shift30=alt, azimuth_shift30=az, altitude_noshift=sp0["altitude"].values,
+         azimuth_noshift=sp0["azimuth"].values)
+
+    # ---------------------------------------------------------------- pv --------------------
+    T = len(t)
+    toa = 1361.0 * np.maximum(np.sin(alt), 0.0)
+    kt = 0.2 + 0.55 * rng.random((T, Y, X))
+    fd = 0.3 + 0.5 * rng.random((T, Y, X))
+    v = dict(
+        influx_direct=toa * kt * fd,
+        influx_diffuse=toa * kt * (1 - fd),
+        influx_toa=toa,
+        albedo=0.05 + 0.3 * rng.random((T, Y, X)),
+        temperature=283.15 + 10 * rng.standard_normal((T, Y, X)),
+        solar_altitude=alt,
+        solar_azimuth=az,
+    )
+    # edge cases the reference's clip / fillna / mask logic must handle
+    day = np.argwhere(toa > 300.0)
+    e = [tuple(i) for i in day[:: max(1, len(day) // 12)][:12]]
+    v["influx_direct"][e[0]] = -5.0  # clipped to 0
+    v["influx_direct"][e[1]] = 5000.0  # clipped to toa -> diffuse clipped to 0
+    v["influx_diffuse"][e[2]] = 5000.0  # clipped to toa - direct
+    v["temperature"][e[3]] = np.nan  # eff NaN -> 0
+    v["albedo"][e[4]] = np.nan  # ground_t NaN -> fillna 0
+    v["influx_diffuse"][e[5]] = -1.0
+    v["solar_altitude"][e[6]] = np.radians(1.0)  # exactly at the threshold: not capped
+    v["solar_altitude"][e[7]] = np.nextafter(np.radians(1.0), 0)  # just below: capped
+    v["influx_direct"][e[8]] = 0.004
+    v["influx_diffuse"][e[8]] = 0.006  # direct + diffuse <= 0.01 (exactly 0.01): capped
+    v["solar_altitude"][e[9]] = np.nan  # NaN altitude: not capped, k NaN -> direct_t 0
+    v["temperature"][e[10]] = 400.0  # eff negative -> clipped at 0
+    v["influx_toa"][e[11]] = np.nan
+    ds = dataset(v, t)
+    pv_out = {}
+    for panel_name in ("CSi", "CdTe"):
+        panel = res.get_solarpanelconfig(panel_name)
+        for oname, ospec in (("const30_180", {"slope": 30.0, "azimuth": 180.0}),
+                             ("const0_0", {"slope": 0.0, "azimuth": 0.0}),
+                             ("latopt", "latitude_optimal"),
+                             ("latitude", {"name": "latitude", "azimuth": 170.0})):
+            o = orient.get_orientation(dict(ospec) if isinstance(ospec, dict) else ospec)
+            da = conv.convert_pv(ds, panel, o, tracking=None)
+            pv_out[f"out_{panel_name}_{oname}"] = da.transpose("time", "y", "x").values
+    save("pv", time=t.values.astype("datetime64[ns]").astype(np.int64), x=x, y=y, **v, **pv_out)
+
+    # ---------------------------------------------------------------- wind ------------------
+    Tw = 40
+    tw = pd.date_range("2013-01-01", periods=Tw, freq="h")
+    u = rng.random((Tw, Y, X))
+    w = dict(
+        wnd100m=8.0 * np.sqrt(-np.log1p(-u)) * (2 / np.sqrt(np.pi)),
+        roughness=np.exp(np.log(1e-3) + rng.random((Tw, Y, X)) * np.log(1.5e3)),
+        wnd_shear_exp=0.05 + 0.3 * rng.random((Tw, Y, X)),
+    )
+    w["wnd100m"][0, 0, :8] = [0.0, 2.0, 25.0, 24.999999, 30.0, np.nan, np.inf, 13.0]
+    w["wnd100m"][1, 0, :4] = [1e-300, 3.0, 12.0, 25.0000001]
+    w["roughness"][2, 0, :3] = [2e-4, 0.0, 100.0]  # sanitized floor / degenerate / == from_height
+    dsw = dataset(w, tw)
+    wout = {}
+    for tname in ("Vestas_V112_3MW", "Enercon_E101_3000kW", "NREL_ReferenceTurbine_5MW_offshore"):
+        turb = res.get_windturbineconfig(tname, add_cutout_windspeed=False)
+        wout[f"{tname}_V"] = np.asarray(turb["V"], dtype=float)
+        wout[f"{tname}_POW"] = np.asarray(turb["POW"], dtype=float)
+        wout[f"{tname}_P_hub"] = np.array([turb["P"], turb["hub_height"]], dtype=float)
+        for m in ("logarithmic", "power"):
+            wout[f"out_{tname}_{m}"] = conv.convert_wind(dsw, turb, m).values
+    turb = res.get_windturbineconfig("Vestas_V112_3MW", add_cutout_windspeed=False)
+    sm = res.windturbine_smooth(turb, params=True)
+    wout["smooth_V"], wout["smooth_POW"], wout["smooth_P"] = sm["V"], sm["POW"], np.array([sm["P"]])
+    wout["out_smooth_logarithmic"] = conv.convert_wind(dsw, sm, "logarithmic").values
+    # fast lane: hub-height wind speed present in the dataset (wind.py:76-78)
+    ds80 = dataset({"wnd80m": w["wnd100m"], "wnd100m": 2 * w["wnd100m"], "roughness": w["roughness"]}, tw)
+    wout["out_fastlane"] = conv.convert_wind(ds80, turb, "logarithmic").values
+    # padding rule of add_cutout_windspeed (test/test_resource.py:28-34)
+    padded = res.get_windturbineconfig(dict(V=[0, 10, 20], POW=[0, 1.0, 1.0], P=1.0, hub_height=90.0),
+                                       add_cutout_windspeed=True)
+    wout["padded_V"], wout["padded_POW"] = np.asarray(padded["V"], float), np.asarray(padded["POW"], float)
+    save("wind", time=tw.values.astype("datetime64[ns]").astype(np.int64), x=x, y=y, **w, **wout)
+
+    # ---------------------------------------------------------------- heat demand / runoff ---
+    Th = 24 * 3 + 5
+    th = pd.date_range("2013-01-01", periods=Th, freq="h")
+    temp = 283.15 + 8 * rng.standard_normal((Th, Y, X))
+    temp[5, 3, 3] = np.nan
+    temp[30:54, 1, 1] = np.nan  # a whole day missing for one cell
+    dsh = dataset({"temperature": temp}, th)
+    hout = {}
+    for shift in (0.0, 4.0, -5.0):
+        da = conv.convert_heat_demand(dsh, threshold=15.0, a=1.3, constant=0.2, hour_shift=shift)
+        hout[f"out_shift{shift:+.0f}"] = da.values
+        hout[f"days_shift{shift:+.0f}"] = da.coords["time"].values.astype("datetime64[ns]").astype(np.int64)
+    save("heat_demand", time=th.values.astype("datetime64[ns]").astype(np.int64), x=x, y=y, temperature=temp, **hout)
+
+    ro = -1e-4 * np.log1p(-rng.random((Th, Y, X)))
+    height = 2000 * rng.random((Y, X))
+    dsr = dataset({"runoff": ro, "height": height}, th)
+    save("runoff", time=th.values.astype("datetime64[ns]").astype(np.int64), x=x, y=y, runoff=ro, height=height,
+         out_weighted=conv.convert_runoff(dsr).values, out_plain=conv.convert_runoff(dsr, weight_with_height=False).values)
+
+    # ---------------------------------------------------------------- gateway ---------------
+    cut = MockCutout(ds)
+    N = 5
+    M = sp.random(N, Y * X, density=0.3, random_state=7, format="csr")
+    M.data[:] = rng.random(M.nnz)
+    lay = 3.0 * rng.random((Y, X))
+    lay[0, 0] = 0.0
+    layout = xr.DataArray(lay, dims=["y", "x"], coords={"y": y, "x": x})
+    panel = res.get_solarpanelconfig("CSi")
+    kw = dict(panel=panel, orientation={"slope": 30.0, "azimuth": 180.0})
+    g = dict(matrix_indptr=M.indptr, matrix_indices=M.indices, matrix_data=M.data, layout=lay)
+    import warnings
+
+    def run(**k):
+        r = conv.pv(cut_bound, **kw, **k)
+        return r
+
+    # convert.pv calls cutout.convert_and_aggregate: bind the reference gateway on the mock
+    MockCutout.convert_and_aggregate = conv.convert_and_aggregate
+    cut_bound = cut
+    g["series_matrix"] = run(matrix=M, aggregate_time=None).values  # (N, T)
+    g["mean_matrix"] = run(matrix=M, aggregate_time="mean").values
+    g["sum_matrix"] = run(matrix=M, aggregate_time="sum").values
+    g["series_layout"] = run(layout=layout, aggregate_time=None).values  # (1, T)
+    g["series_matrix_layout"] = run(matrix=M, layout=layout, aggregate_time=None).values
+    r, cap = run(matrix=M, layout=layout, per_unit=True, return_capacity=True, aggregate_time=None)
+    g["pu_matrix_layout"], g["capacity_matrix_layout"] = r.values, cap.values
+    g["pu_mean_matrix"] = run(matrix=M, per_unit=True, aggregate_time="mean").values
+    g["cells_mean"] = run(aggregate_time="mean").values  # (y, x)
+    g["cells_sum"] = run(aggregate_time="sum").values
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", FutureWarning)
+        g["legacy_nomatrix"] = run().values  # legacy = time sum
+        g["legacy_matrix"] = run(matrix=M).values  # legacy = series
+        g["capfactor"] = run(capacity_factor=True).values
+    save("gateway_pv", **g)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

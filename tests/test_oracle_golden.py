@@ -1,0 +1,131 @@
+"""
+CPU: the NumPy oracle against the golden vectors frozen from the reference's own source files
+(tests/golden/make_golden.py).  This is what pins the oracle: same inputs, the reference's
+arithmetic executed verbatim under an xarray/dask stand-in, outputs compared here.
+The oracle uses the same NumPy ufuncs in the same order, so agreement is expected to the last
+bit; the assertion allows 2 ulp-ish slack (rtol 1e-15) only where summation order can differ.
+"""
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.sparse as sp
+
+from oracle import atlite_oracle as orc
+from tests import helpers as H
+
+G = Path(__file__).parent / "golden"
+
+
+def load(name):
+    return dict(np.load(G / f"{name}.npz"))
+
+
+def times(ns):
+    return pd.DatetimeIndex(ns.astype("datetime64[ns]"))
+
+
+def exact(a, b):
+    np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_solar_position():
+    g = load("solar_position")
+    t = times(g["time"])
+    alt, az = orc.solar_position(t, g["x"], g["y"], "-30min")
+    exact(alt, g["altitude_shift30"])
+    exact(az, g["azimuth_shift30"])
+    alt, az = orc.solar_position(t, g["x"], g["y"])
+    exact(alt, g["altitude_noshift"])
+    exact(az, g["azimuth_noshift"])
+
+
+PANELS = {"CSi": H.CSI, "CdTe": dict(H.CSI, k_1=-0.103251, k_2=-0.040446, k_3=-0.001667, k_4=-0.002075,
+                                     k_5=-0.001445, k_6=-0.000023)}
+
+
+def pv_orientations(y):
+    lat = np.radians(y)
+    lo = orc.orientation_latitude_optimal(lat)
+    la = orc.orientation_latitude(lat, 170.0)
+    return {
+        "const30_180": orc.orientation_constant(30.0, 180.0),
+        "const0_0": orc.orientation_constant(0.0, 0.0),
+        "latopt": dict(slope=lo["slope"][None, :, None], azimuth=lo["azimuth"][None, :, None]),
+        "latitude": dict(slope=la["slope"][None, :, None], azimuth=la["azimuth"]),
+    }
+
+
+@pytest.mark.parametrize("panel", ["CSi", "CdTe"])
+@pytest.mark.parametrize("oname", ["const30_180", "const0_0", "latopt", "latitude"])
+def test_pv(panel, oname):
+    g = load("pv")
+    ds = {k: g[k] for k in ("influx_direct", "influx_diffuse", "influx_toa", "albedo", "temperature",
+                            "solar_altitude", "solar_azimuth")}
+    out = orc.convert_pv(ds, PANELS[panel], pv_orientations(g["y"])[oname])
+    ref = g[f"out_{panel}_{oname}"]
+    assert np.isfinite(ref).all() and ref.max() > 0.3
+    np.testing.assert_allclose(out, ref, rtol=2e-15, atol=0)
+
+
+@pytest.mark.parametrize("turbine", ["Vestas_V112_3MW", "Enercon_E101_3000kW", "NREL_ReferenceTurbine_5MW_offshore"])
+@pytest.mark.parametrize("method,aux", [("logarithmic", "roughness"), ("power", "wnd_shear_exp")])
+def test_wind(turbine, method, aux):
+    g = load("wind")
+    P, hub = g[f"{turbine}_P_hub"]
+    out = orc.convert_wind(g["wnd100m"], g[aux], g[f"{turbine}_V"], g[f"{turbine}_POW"], P, hub, 100, method)
+    exact(out, g[f"out_{turbine}_{method}"])
+
+
+def test_wind_smooth_and_fastlane():
+    g = load("wind")
+    out = orc.convert_wind(g["wnd100m"], g["roughness"], g["smooth_V"], g["smooth_POW"], g["smooth_P"][0], 80.0,
+                           100, "logarithmic")
+    exact(out, g["out_smooth_logarithmic"])
+    P, hub = g["Vestas_V112_3MW_P_hub"]
+    out = orc.convert_wind(g["wnd100m"], None, g["Vestas_V112_3MW_V"], g["Vestas_V112_3MW_POW"], P, hub, hub, None)
+    exact(out, g["out_fastlane"])
+
+
+@pytest.mark.parametrize("shift", [0.0, 4.0, -5.0])
+def test_heat_demand(shift):
+    g = load("heat_demand")
+    ptr, days = orc.day_groups(times(g["time"]), shift)
+    out = orc.convert_heat_demand(g["temperature"], ptr, threshold=15.0, a=1.3, constant=0.2)
+    exact(days.values.astype("datetime64[ns]").astype(np.int64), g[f"days_shift{shift:+.0f}"])
+    np.testing.assert_allclose(out, g[f"out_shift{shift:+.0f}"], rtol=1e-15, equal_nan=True)
+
+
+def test_runoff():
+    g = load("runoff")
+    exact(orc.convert_runoff(g["runoff"], g["height"][None]), g["out_weighted"])
+    exact(orc.convert_runoff(g["runoff"]), g["out_plain"])
+
+
+def test_gateway():
+    g, p = load("gateway_pv"), load("pv")
+    T = p["influx_toa"].shape[0]
+    ds = {k: p[k].reshape(T, -1) for k in ("influx_direct", "influx_diffuse", "influx_toa", "albedo", "temperature",
+                                           "solar_altitude", "solar_azimuth")}
+    da = orc.convert_pv(ds, H.CSI, orc.orientation_constant(30.0, 180.0))
+    S = da.shape[1]
+    M = sp.csr_matrix((g["matrix_data"], g["matrix_indices"], g["matrix_indptr"]), shape=(5, S))
+    lay = g["layout"]
+    rt = 1e-14
+    np.testing.assert_allclose(orc.gateway(da, M)[0], g["series_matrix"], rtol=rt)
+    np.testing.assert_allclose(orc.gateway(da, M, aggregate_time_method="mean")[0], g["mean_matrix"], rtol=rt)
+    np.testing.assert_allclose(orc.gateway(da, M, aggregate_time_method="sum")[0], g["sum_matrix"], rtol=rt)
+    np.testing.assert_allclose(orc.gateway(da, layout=lay)[0], g["series_layout"], rtol=rt)
+    np.testing.assert_allclose(orc.gateway(da, M, layout=lay)[0], g["series_matrix_layout"], rtol=rt)
+    r, cap = orc.gateway(da, M, layout=lay, per_unit=True)
+    np.testing.assert_allclose(r, g["pu_matrix_layout"], rtol=rt)
+    np.testing.assert_allclose(cap, g["capacity_matrix_layout"], rtol=rt)
+    np.testing.assert_allclose(orc.gateway(da, M, per_unit=True, aggregate_time_method="mean")[0],
+                               g["pu_mean_matrix"], rtol=rt)
+    Y, X = lay.shape
+    np.testing.assert_allclose(orc.gateway(da, aggregate_time_method="mean")[0].reshape(Y, X), g["cells_mean"], rtol=rt)
+    np.testing.assert_allclose(orc.gateway(da, aggregate_time_method="sum")[0].reshape(Y, X), g["cells_sum"], rtol=rt)
+    exact(g["legacy_nomatrix"], g["cells_sum"])  # legacy without aggregation = time sum (convert.py:209)
+    exact(g["legacy_matrix"], g["series_matrix"])  # legacy with aggregation = series (convert.py:270)
+    exact(g["capfactor"], g["cells_mean"])  # capacity_factor=True == aggregate_time="mean"
