@@ -63,7 +63,7 @@ class _PvSpec(_Spec):
     name = "specific generation"
     attrs = {"units": "kWh/kWp"}
 
-    def __init__(self, ds, panel, orientation, tracking, trigon_model, clearsky_model):
+    def __init__(self, ds, panel, orientation, tracking, trigon_model="simple", clearsky_model="simple"):
         if tracking is not None:
             if tracking not in ("horizontal", "tilted_horizontal", "vertical", "dual"):
                 raise AssertionError(

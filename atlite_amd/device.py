@@ -62,7 +62,11 @@ class DeviceArray:
     def reshape(self, *shape):
         if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
             shape = tuple(shape[0])
-        assert int(np.prod(shape, dtype=np.int64)) == self.size
+        shape = [int(v) for v in shape]
+        if -1 in shape:
+            known = int(np.prod([v for v in shape if v != -1], dtype=np.int64))
+            shape[shape.index(-1)] = self.size // known if known else 0
+        assert int(np.prod(shape, dtype=np.int64)) == self.size, (shape, self.shape)
         return DeviceArray(self.ctx, self.ptr, shape, self.dtype, owner=self)
 
     def free(self):
