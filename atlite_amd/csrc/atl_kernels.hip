@@ -20,6 +20,7 @@
 //   heat : convert.py:405-418      runoff : convert.py:1028-1034
 //   agg  : aggregate.py:16-35 (scipy CSR product), convert.py:51-56 (_aggregate_time)
 #include "atl_internal.h"
+#include "atl_math.h"
 
 using namespace atl;
 
@@ -180,11 +181,14 @@ struct WindConv {
     }
     __device__ __forceinline__ double hub_speed(double v, double z) const {
         if (method == ATL_WIND_LOG) {
-            // wind.py:99-101, literally: v * (log(to/z0) / log(from/z0))
-            return v * (log(to_height / z) / log(from_height / z));
+            // wind.py:99-101: v * (log(to/z0) / log(from/z0)), with log(a/z0) = log a - log z0.
+            // All three logs go through the same lean_log, so z0 == from_height gives an exact
+            // zero denominator like the reference's log(1).
+            const double lz = lean_log(z);
+            return v * ((lean_log(to_height) - lz) / (lean_log(from_height) - lz));  // IEEE divide: den may be 0
         } else if (method == ATL_WIND_POWER) {
-            // wind.py:111: v * (to/from) ** shear
-            return v * pow(to_height / from_height, z);
+            // wind.py:111: v * (to/from) ** shear = v * exp(shear * log(to/from))
+            return v * exp(z * log_ratio);
         }
         return v;
     }
@@ -226,12 +230,16 @@ struct WindConv {
 
 // solar PV, ERA5-shaped inputs with stored solar position
 struct PvConst {
-    double c_amb, c_irr, r_tmod, r_irr, k1, k2, k3, k4, k5, k6, inv_eff, alt_thr;
+    double c_amb, c_irr, r_tmod, inv_r_irr, k1, k2, k3, k4, k5, k6, inv_eff, alt_thr;
+};
+
+// per-cell orientation factors: sin/cos(slope), (1 +- cos(slope))/2, panel azimuth
+struct PvOri {
+    double ss, cs, hp, hm, saz;
 };
 
 __device__ __forceinline__ double pv_cell(double dir, double dif, double toa, double alb, double tmp,
-                                          double alt, double az, double ss, double cs, double saz,
-                                          const PvConst &k) {
+                                          double alt, double az, const PvOri &o, const PvConst &k) {
     // irradiation.py:206-208
     const double direct = np_clip(dir, 0.0, toa);
     const double diffuse = np_clip(dif, 0.0, toa - direct);
@@ -240,22 +248,22 @@ __device__ __forceinline__ double pv_cell(double dir, double dif, double toa, do
     const bool capped = (alt < k.alt_thr) || (influx <= 0.01);
     if (capped) return 0.0;  // G = 0 -> G_ = 0, eff -> 0 : 0*0*inv
     double sa, ca;
-    sincos(alt, &sa, &ca);
+    lean_sincos(alt, &sa, &ca);
     // orientation.py:114-117,188
-    double cosinc = ss * ca * cos(saz - az) + cs * sa;
+    double cosinc = o.ss * ca * lean_cos(o.saz - az) + o.cs * sa;
     cosinc = np_max(cosinc, 0.0);
     // irradiation.py:214-226
-    const double kk = cosinc / sa;
+    const double kk = fast_div(cosinc, sa);
     const double direct_t = kk * direct;
-    const double diffuse_t = (1.0 + cs) / 2.0 * diffuse;
-    const double ground_t = alb * influx * ((1.0 - cs) / 2.0);
+    const double diffuse_t = o.hp * diffuse;
+    const double ground_t = alb * influx * o.hm;
     const double G = fill0(direct_t) + fill0(diffuse_t) + fill0(ground_t);
     // solar_panel_model.py:22-41
     const double T_ = (k.c_amb * tmp + k.c_irr * G) - k.r_tmod;
-    const double G_ = G / k.r_irr;
+    const double G_ = G * k.inv_r_irr;
     double eff = 0.0;
     if (G_ > 0.0) {
-        const double l = log(G_);
+        const double l = lean_log(G_);
         const double l2 = l * l;
         eff = 1.0 + k.k1 * l + k.k2 * l2 + T_ * (k.k3 + k.k4 * l + k.k5 * l2) + k.k6 * (T_ * T_);
         eff = fill0(eff);
@@ -268,27 +276,29 @@ struct PvConv {
     atl_pv_inputs in;
     int64_t S;
     PvConst k;
-    double ss, cs, saz;          // scalar orientation: sin/cos(slope), azimuth
+    PvOri o;                     // scalar orientation
     const double *cell_slope;    // (S) or nullptr
     const double *cell_azimuth;  // (S)
     struct Cell {
-        double2 ss, cs, saz;
+        PvOri o0, o1;
     };
     __device__ void block_init(double *) const {}
+    __device__ static PvOri make_ori(double slope, double azimuth) {
+        PvOri r;
+        lean_sincos(slope, &r.ss, &r.cs);
+        r.hp = (1.0 + r.cs) / 2.0;
+        r.hm = (1.0 - r.cs) / 2.0;
+        r.saz = azimuth;
+        return r;
+    }
     __device__ Cell cell_setup(int64_t c0, bool v0, bool v1) const {
         Cell c;
         if (cell_slope) {
-            const double s0 = v0 ? cell_slope[c0] : 0.0, s1 = v1 ? cell_slope[c0 + 1] : 0.0;
-            c.ss.x = sin(s0);
-            c.cs.x = cos(s0);
-            c.ss.y = sin(s1);
-            c.cs.y = cos(s1);
-            c.saz.x = v0 ? cell_azimuth[c0] : 0.0;
-            c.saz.y = v1 ? cell_azimuth[c0 + 1] : 0.0;
+            c.o0 = make_ori(v0 ? cell_slope[c0] : 0.0, v0 ? cell_azimuth[c0] : 0.0);
+            c.o1 = make_ori(v1 ? cell_slope[c0 + 1] : 0.0, v1 ? cell_azimuth[c0 + 1] : 0.0);
         } else {
-            c.ss.x = c.ss.y = ss;
-            c.cs.x = c.cs.y = cs;
-            c.saz.x = c.saz.y = saz;
+            c.o0 = o;
+            c.o1 = o;
         }
         return c;
     }
@@ -304,8 +314,8 @@ struct PvConv {
         const double2 tmp = ld2<VEC>(in.d_temperature, off, v0, v1);
         const double2 az = ld2<VEC>(in.d_solar_azimuth, off, v0, v1);
         double2 r;
-        r.x = v0 ? pv_cell(dir.x, dif.x, toa.x, alb.x, tmp.x, alt.x, az.x, c.ss.x, c.cs.x, c.saz.x, k) : 0.0;
-        r.y = v1 ? pv_cell(dir.y, dif.y, toa.y, alb.y, tmp.y, alt.y, az.y, c.ss.y, c.cs.y, c.saz.y, k) : 0.0;
+        r.x = v0 ? pv_cell(dir.x, dif.x, toa.x, alb.x, tmp.x, alt.x, az.x, c.o0, k) : 0.0;
+        r.y = v1 ? pv_cell(dir.y, dif.y, toa.y, alb.y, tmp.y, alt.y, az.y, c.o1, k) : 0.0;
         return r;
     }
 };
@@ -725,12 +735,14 @@ int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t 
                 "atl_pv: d_cell_slope and d_cell_azimuth must be given together");
     c->in = *in;
     c->S = S;
-    c->k = PvConst{p->c_temp_amb, p->c_temp_irrad, p->r_tmod, p->r_irradiance, p->k_1, p->k_2,
-                   p->k_3,        p->k_4,          p->k_5,    p->k_6,          p->inverter_efficiency,
+    c->k = PvConst{p->c_temp_amb, p->c_temp_irrad, p->r_tmod, 1.0 / p->r_irradiance, p->k_1, p->k_2,
+                   p->k_3,        p->k_4,          p->k_5,    p->k_6,                 p->inverter_efficiency,
                    p->altitude_threshold};
-    c->ss = sin(p->slope);
-    c->cs = cos(p->slope);
-    c->saz = p->azimuth;
+    c->o.ss = sin(p->slope);
+    c->o.cs = cos(p->slope);
+    c->o.hp = (1.0 + c->o.cs) / 2.0;
+    c->o.hm = (1.0 - c->o.cs) / 2.0;
+    c->o.saz = p->azimuth;
     c->cell_slope = p->d_cell_slope;
     c->cell_azimuth = p->d_cell_azimuth;
     *vec = vec_ok(S, {in->d_influx_direct, in->d_influx_diffuse, in->d_influx_toa, in->d_albedo,

@@ -1,0 +1,129 @@
+// Lean fp64 elementary functions for the streaming kernels (gfx950).
+//
+// ocml's sin/cos/log carry Payne-Hanek big-argument paths and double-double arithmetic
+// (~600 VALU instructions per pv cell); the kernels only need ~1 ulp on physically ranged
+// arguments, so these are plain Cody-Waite reductions + the classic fdlibm minimax
+// polynomials (constants from FreeBSD msun k_sin.c / k_cos.c / e_log.c, (c) 1993 Sun
+// Microsystems, "Permission to use, copy, modify, and distribute this software is freely
+// granted, provided that this notice is preserved").
+//
+// Accuracy (measured against numpy on the GPU, tests/test_gpu_math.py): <= 2 ulp for
+// sincos on |x| < 2^20, absolute error < 2.3e-16 up to |x| < 2^30; |x| >= 2^30 returns NaN
+// (numpy would still return a value there; solar angles that large are not physical).
+// log: <= 1 ulp on positive normal and subnormal arguments; log(0) = -inf, log(<0) = NaN,
+// log(inf) = inf.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace atl {
+
+__device__ __forceinline__ double fast_rcp(double b) {
+    double y = __builtin_amdgcn_rcp(b);  // v_rcp_f64: ~2^-25 relative
+    y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+    return y;
+}
+
+// a / b to ~1 ulp for normal, well-scaled operands (no denormal / overflow fix-ups)
+__device__ __forceinline__ double fast_div(double a, double b) {
+    const double y = fast_rcp(b);
+    const double q = a * y;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+}
+
+// reduce x to r in [-pi/4, pi/4] (+ tiny slack), quadrant in *q
+__device__ __forceinline__ double reduce_pio2(double x, int *q) {
+    const double k = __builtin_rint(x * 6.36619772367581382433e-01);  // 2/pi
+    // pi/2 split into three doubles; every FMA is exact before its single rounding
+    double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);
+    r = __builtin_fma(-k, 6.12323399573676603587e-17, r);
+    r = __builtin_fma(-k, -1.49738490485916983506e-33, r);
+    *q = int(k) & 3;  // |k| < 2^31 guaranteed by the caller's range check
+    return r;
+}
+
+__device__ __forceinline__ double poly_sin(double r, double z) {
+    double p = 1.58969099521155010221e-10;
+    p = __builtin_fma(p, z, -2.50507602534068634195e-08);
+    p = __builtin_fma(p, z, 2.75573137070700676789e-06);
+    p = __builtin_fma(p, z, -1.98412698298579493134e-04);
+    p = __builtin_fma(p, z, 8.33333333332248946124e-03);
+    p = __builtin_fma(p, z, -1.66666666666666324348e-01);
+    return __builtin_fma(r * z, p, r);
+}
+
+__device__ __forceinline__ double poly_cos(double z) {
+    double p = -1.13596475577881948265e-11;
+    p = __builtin_fma(p, z, 2.08757232129817482790e-09);
+    p = __builtin_fma(p, z, -2.75573143513906633035e-07);
+    p = __builtin_fma(p, z, 2.48015872894767294178e-05);
+    p = __builtin_fma(p, z, -1.38888888888741095749e-03);
+    p = __builtin_fma(p, z, 4.16666666666666019037e-02);
+    // 1 - z/2 + z^2 p, evaluated so that the leading terms stay exact
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    return w + (((1.0 - w) - hz) + z * z * p);
+}
+
+__device__ __forceinline__ void lean_sincos(double x, double *s, double *c) {
+    int q;
+    const double r = reduce_pio2(x, &q);
+    const double z = r * r;
+    const double ps = poly_sin(r, z), pc = poly_cos(z);
+    double ss = (q & 1) ? pc : ps;
+    double cc = (q & 1) ? ps : pc;
+    ss = (q & 2) ? -ss : ss;
+    cc = ((q + 1) & 2) ? -cc : cc;
+    const bool ok = __builtin_fabs(x) < 0x1.0p30;  // false for NaN / inf too
+    *s = ok ? ss : __builtin_nan("");
+    *c = ok ? cc : __builtin_nan("");
+}
+
+__device__ __forceinline__ double lean_cos(double x) {
+    int q;
+    const double r = reduce_pio2(x, &q);
+    const double z = r * r;
+    double cc = (q & 1) ? poly_sin(r, z) : poly_cos(z);
+    cc = ((q + 1) & 2) ? -cc : cc;
+    return __builtin_fabs(x) < 0x1.0p30 ? cc : __builtin_nan("");
+}
+
+__device__ __forceinline__ double lean_sin(double x) {
+    int q;
+    const double r = reduce_pio2(x, &q);
+    const double z = r * r;
+    double ss = (q & 1) ? poly_cos(z) : poly_sin(r, z);
+    ss = (q & 2) ? -ss : ss;
+    return __builtin_fabs(x) < 0x1.0p30 ? ss : __builtin_nan("");
+}
+
+__device__ __forceinline__ double lean_log(double x) {
+    // x = 2^e * m, m in [sqrt(1/2), sqrt(2))
+    double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1), handles subnormals
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 7.07106781186547524401e-01;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double f = m - 1.0;
+    const double s = f * fast_rcp(2.0 + f);
+    const double z = s * s, w = z * z;
+    double t1 = __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01);
+    t1 = __builtin_fma(w, t1, 3.999999999940941908e-01) * w;
+    double t2 = __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01);
+    t2 = __builtin_fma(w, t2, 2.857142874366239149e-01);
+    t2 = __builtin_fma(w, t2, 6.666666666666735130e-01) * z;
+    const double R = t1 + t2;
+    const double hfsq = 0.5 * f * f;
+    const double dk = double(e);
+    double r = dk * 6.93147180369123816490e-01 -
+               ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+    // specials
+    r = (x == 0.0) ? -__builtin_inf() : r;
+    r = (x < 0.0) ? __builtin_nan("") : r;
+    r = (x == __builtin_inf()) ? x : r;
+    r = (x != x) ? x : r;
+    return r;
+}
+
+}  // namespace atl
