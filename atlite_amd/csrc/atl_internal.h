@@ -43,7 +43,12 @@ void set_error(const char *fmt, ...);
 struct PlanDev {
     int64_t n_rows;        // N shapes
     int64_t n_cells;       // S
-    int32_t n_segs;        // ceil(S / kSegCells)
+    // cell tiles: a segment is a w x h tile (w*h = 128) of the (Y, X) grid, lane l owns the two
+    // adjacent cells (y0 + l / (w/2), x0 + 2*(l % (w/2)) + {0,1}).  Unknown grid: Y=1, X=S, 128x1.
+    int64_t X, Y;
+    int32_t ntx;           // tiles per grid row
+    int32_t w2_log2;       // log2(w / 2): lanes per tile row
+    int32_t n_segs;        // number of tiles
     int32_t n_prows;       // P partial rows = sum over segments of distinct shapes touching it
     const int32_t *seg_ptr;     // [n_segs+1] partial rows of segment s: [seg_ptr[s], seg_ptr[s+1])
     const double *prow_w;       // [P][kSegCells] weight of local cell, NaN = structurally absent

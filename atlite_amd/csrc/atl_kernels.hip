@@ -438,8 +438,12 @@ __global__ __launch_bounds__(256) void k_fused_segred(Conv conv, PlanDev plan, i
     if (unit >= n_units) return;
     const int32_t seg = int32_t(unit % plan.n_segs);
     const int64_t chunk = unit / plan.n_segs;
-    const int64_t c0 = int64_t(seg) * kSegCells + 2 * lane;
-    const bool v0 = c0 < S, v1 = c0 + 1 < S;
+    // tile coordinates -> the lane's two adjacent cells
+    const int32_t ty = seg / plan.ntx, tx = seg - ty * plan.ntx;
+    const int64_t gx = (int64_t(tx) << (plan.w2_log2 + 1)) + ((lane & ((1 << plan.w2_log2) - 1)) << 1);
+    const int64_t gy = int64_t(ty) * (kLanes >> plan.w2_log2) + (lane >> plan.w2_log2);
+    const int64_t c0 = gy * plan.X + gx;
+    const bool v0 = gy < plan.Y && gx < plan.X, v1 = gy < plan.Y && gx + 1 < plan.X;
     const int32_t p0 = plan.seg_ptr[seg], p1 = plan.seg_ptr[seg + 1];
     if (p0 == p1) return;  // no shape touches this segment: nothing to read
     const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1);
@@ -675,6 +679,7 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
     const PlanDev &plan = agg->dev;
     const int64_t N = plan.n_rows;
     if (N == 0) return ATL_OK;
+    vec = vec && (plan.X % 2 == 0);  // the lane's cell pair must not straddle a grid row
     const int64_t ldp = int64_t(align_up(size_t(std::max<int64_t>(n_slots, 1)), 8));
     const int64_t P = plan.n_prows;
     size_t bytes_partials = align_up(size_t(std::max<int64_t>(P, 1) * ldp) * sizeof(double), 256);

@@ -4,6 +4,7 @@
 // handling), atlite/aggregate.py:16-35 (the product that the plan implements).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -219,28 +220,31 @@ int atl_last_kernel_ms(atl_ctx *ctx, float *ms) {
 
 // ---- aggregation plan ------------------------------------------------------------------
 
-int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, const int64_t *h_indptr,
-                   const int32_t *h_indices, const double *h_data, atl_agg **out) {
+int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_len,
+                   const int64_t *h_indptr, const int32_t *h_indices, const double *h_data,
+                   atl_agg **out) {
     ATL_REQUIRE(ctx && out, "atl_agg_create: bad argument");
     *out = nullptr;
     ATL_REQUIRE(n_rows >= 0 && n_cells >= 0, "atl_agg_create: negative shape (%lld, %lld)",
                 (long long)n_rows, (long long)n_cells);
-    ATL_REQUIRE(n_rows < (int64_t(1) << 30) && n_cells < (int64_t(1) << 31),
-                "atl_agg_create: matrix shape too large");
+    ATL_REQUIRE(n_rows < 65536, "atl_agg_create: at most 65535 rows (shapes) are supported");
+    ATL_REQUIRE(n_cells < (int64_t(1) << 31), "atl_agg_create: matrix shape too large");
+    ATL_REQUIRE(row_len >= 0 && (row_len == 0 || n_cells % row_len == 0),
+                "atl_agg_create: row_len %lld does not divide the %lld cells", (long long)row_len,
+                (long long)n_cells);
     ATL_REQUIRE(h_indptr, "atl_agg_create: indptr is NULL");
     ATL_REQUIRE(h_indptr[0] == 0, "atl_agg_create: indptr[0] must be 0");
     const int64_t nnz = h_indptr[n_rows];
     ATL_REQUIRE(nnz >= 0 && (nnz == 0 || (h_indices && h_data)),
                 "atl_agg_create: indices/data missing");
-    const int64_t n_segs = (n_cells + kSegCells - 1) / kSegCells;
 
-    struct Ent {
-        int64_t key;  // seg * n_rows + row
-        int32_t local;
+    // ---- validate, collect (row, cell, weight) -------------------------------------------
+    struct Raw {
+        int32_t row, cell;
         double w;
     };
-    std::vector<Ent> ents;
-    ents.reserve(static_cast<size_t>(nnz));
+    std::vector<Raw> raw;
+    raw.reserve(static_cast<size_t>(nnz));
     std::vector<uint8_t> poison(static_cast<size_t>(n_rows), 0);
     for (int64_t r = 0; r < n_rows; ++r) {
         ATL_REQUIRE(h_indptr[r + 1] >= h_indptr[r], "atl_agg_create: indptr not monotone at row %lld",
@@ -255,8 +259,86 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, const int64_t 
                 poison[r] = 1;
                 continue;
             }
-            ents.push_back({(j / kSegCells) * n_rows + r, int32_t(j % kSegCells), w});
+            raw.push_back({int32_t(r), int32_t(j), w});
         }
+    }
+
+    // ---- choose the tile shape --------------------------------------------------------------
+    struct Layout {
+        int64_t X, Y;
+        int w2_log2;  // lanes per tile row
+    };
+    auto tile_of = [](const Layout &L, int64_t cell, int32_t *local) {
+        const int64_t y = cell / L.X, x = cell % L.X;
+        const int w = 2 << L.w2_log2, h = kLanes >> L.w2_log2;
+        const int64_t ntx = (L.X + w - 1) / w;
+        const int64_t tx = x / w, ty = y / h;
+        const int lane = int((y % h) << L.w2_log2) + int((x % w) >> 1);
+        *local = lane * 2 + int(x & 1);
+        return ty * ntx + tx;
+    };
+    std::vector<Layout> cands;
+    cands.push_back({n_cells > 0 ? n_cells : 1, 1, 6});  // flat 128 x 1 over the stacked axis
+    if (row_len > 0 && n_cells / row_len > 1) {
+        const int64_t Yg = n_cells / row_len;
+        for (int l2 : {5, 4, 3}) cands.push_back({row_len, Yg, l2});  // 64x2, 32x4, 16x8
+    }
+    if (const char *env = getenv("ATLITE_HIP_TILE")) {  // experiments: "16x8", "32x4", "64x2", "128x1", "flat"
+        int w = 0, h = 0;
+        if (row_len > 0 && sscanf(env, "%dx%d", &w, &h) == 2 && w * h == kSegCells && w >= 16) {
+            int l2 = 0;
+            while ((2 << l2) < w) ++l2;
+            cands.assign(1, Layout{row_len, n_cells / row_len, l2});
+        } else if (strcmp(env, "flat") == 0) {
+            cands.resize(1);
+        }
+    }
+    size_t best = 0;
+    if (cands.size() > 1) {
+        double best_cost = 0;
+        std::vector<int64_t> keys(raw.size());
+        for (size_t c = 0; c < cands.size(); ++c) {
+            int32_t loc;
+            for (size_t i = 0; i < raw.size(); ++i)
+                keys[i] = tile_of(cands[c], raw[i].cell, &loc) * n_rows + raw[i].row;
+            std::sort(keys.begin(), keys.end());
+            int64_t P = 0, tiles = 0, last = -1, last_tile = -1;
+            for (int64_t k : keys) {
+                if (k != last) {
+                    ++P;
+                    last = k;
+                    if (k / n_rows != last_tile) {
+                        ++tiles;
+                        last_tile = k / n_rows;
+                    }
+                }
+            }
+            // a tile costs its conversion work even for masked lanes, a partial row one wave
+            // reduction; narrow tile rows (128 B per row at 16x8) stream from HBM less
+            // efficiently than 256-B+ rows (measured on C2: 32x4 3.51 ms vs 16x8 3.69 ms)
+            static const double row_eff[7] = {0, 0, 0, 1.25, 1.0, 0.97, 0.95};
+            const double cost = (4.0 * double(tiles) + double(P)) * row_eff[cands[c].w2_log2];
+            if (c == 0 || cost < best_cost) {
+                best_cost = cost;
+                best = c;
+            }
+        }
+    }
+    const Layout L = cands[best];
+    const int tw = 2 << L.w2_log2, th = kLanes >> L.w2_log2;
+    const int64_t ntx = (L.X + tw - 1) / tw, nty = (L.Y + th - 1) / th;
+    const int64_t n_segs = n_cells > 0 ? ntx * nty : 0;
+
+    struct Ent {
+        int64_t key;  // tile * n_rows + row
+        int32_t local;
+        double w;
+    };
+    std::vector<Ent> ents(raw.size());
+    for (size_t i = 0; i < raw.size(); ++i) {
+        int32_t loc;
+        const int64_t t = tile_of(L, raw[i].cell, &loc);
+        ents[i] = {t * n_rows + raw[i].row, loc, raw[i].w};
     }
     std::stable_sort(ents.begin(), ents.end(),
                      [](const Ent &a, const Ent &b) { return a.key < b.key; });
@@ -303,6 +385,10 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, const int64_t 
     a->ctx = ctx;
     a->dev.n_rows = n_rows;
     a->dev.n_cells = n_cells;
+    a->dev.X = L.X;
+    a->dev.Y = L.Y;
+    a->dev.ntx = int32_t(ntx);
+    a->dev.w2_log2 = L.w2_log2;
     a->dev.n_segs = int32_t(n_segs);
     a->dev.n_prows = int32_t(P);
     int rc = ATL_OK;
@@ -330,12 +416,14 @@ int atl_agg_destroy(atl_agg *agg) {
 }
 
 int atl_agg_info(const atl_agg *agg, int64_t *n_rows, int64_t *n_cells, int64_t *n_segments,
-                 int64_t *n_partial_rows) {
+                 int64_t *n_partial_rows, int32_t *tile_w, int32_t *tile_h) {
     ATL_REQUIRE(agg, "atl_agg_info: agg is NULL");
     if (n_rows) *n_rows = agg->dev.n_rows;
     if (n_cells) *n_cells = agg->dev.n_cells;
     if (n_segments) *n_segments = agg->dev.n_segs;
     if (n_partial_rows) *n_partial_rows = agg->dev.n_prows;
+    if (tile_w) *tile_w = 2 << agg->dev.w2_log2;
+    if (tile_h) *tile_h = atl::kLanes >> agg->dev.w2_log2;
     return ATL_OK;
 }
 

@@ -102,6 +102,7 @@ class AggPlan:
                 ctx.handle,
                 m.shape[0],
                 m.shape[1],
+                int(row_len) if row_len and m.shape[1] % int(row_len) == 0 else 0,
                 indptr.ctypes.data,
                 indices.ctypes.data if indices.size else None,
                 data.ctypes.data if data.size else None,
@@ -111,9 +112,10 @@ class AggPlan:
         self.handle = h
 
     def info(self):
-        v = [C.c_int64() for _ in range(4)]
+        v = [C.c_int64() for _ in range(4)] + [C.c_int32(), C.c_int32()]
         check(self.ctx.lib.atl_agg_info(self.handle, *[C.byref(x) for x in v]))
-        return dict(zip(("n_rows", "n_cells", "n_segments", "n_partial_rows"), (x.value for x in v)))
+        return dict(zip(("n_rows", "n_cells", "n_segments", "n_partial_rows", "tile_w", "tile_h"),
+                        (x.value for x in v)))
 
     def close(self):
         if self.handle:

@@ -113,7 +113,8 @@ def main():
     polys = (gis.random_tessellation if a.shape_kind == "tessellation" else gis.random_star_polygons)(
         a.shapes, bounds, seed=42)
     M = gis.compute_indicatormatrix(x, y, polys)
-    plan = ctx.plan(M)
+    plan = ctx.plan(M, row_len=X)
+    plan_info = plan.info()
     N = M.shape[0]
     params = dict(CSI, slope=np.radians(30.0), azimuth=np.radians(180.0))
 
@@ -190,6 +191,8 @@ def main():
                         f"{N} {a.shape_kind} polygon shapes, aggregate_time=None",
             "parallelism": f"time-sharded x{world}" + (" + RCCL all-gather" if world > 1 else ""),
             "time_steps_per_gpu": T_loc,
+            "cell_tile": f"{plan_info['tile_w']}x{plan_info['tile_h']}",
+            "partial_rows": plan_info["n_partial_rows"],
         },
         "roofline": {
             "bound": "hbm",

@@ -83,12 +83,16 @@ int atl_last_kernel_ms(atl_ctx *ctx, float *ms);
  * consumed by aggregate_matrix (aggregate.py:16-35).  CSR N x S, rows = shapes/buses,
  * columns = cells in cutout.grid order.  Host arrays are copied; duplicates are summed.
  * Rows containing a NaN weight produce an all-NaN output row (what scipy's product gives).
+ * row_len = X of the (Y, X) grid (cells per grid row; 0 if unknown): with it the plan groups
+ * cells into compact w x h tiles (w*h = 128) instead of runs of 128 stacked cells, which cuts
+ * the number of (tile, shape) partial rows for compact shapes.
  */
-int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, const int64_t *h_indptr,
-                   const int32_t *h_indices, const double *h_data, atl_agg **out);
+int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_len,
+                   const int64_t *h_indptr, const int32_t *h_indices, const double *h_data,
+                   atl_agg **out);
 int atl_agg_destroy(atl_agg *agg);
 int atl_agg_info(const atl_agg *agg, int64_t *n_rows, int64_t *n_cells, int64_t *n_segments,
-                 int64_t *n_partial_rows);
+                 int64_t *n_partial_rows, int32_t *tile_w, int32_t *tile_h);
 
 /* ---- generic aggregation: out = M . D^T ----------------------------------------------
  * Replaces aggregate_matrix(da, matrix, index) (aggregate.py:16-35) for an arbitrary

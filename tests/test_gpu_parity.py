@@ -170,3 +170,26 @@ def test_spmm_nan_semantics(ctx):
     out = ctx.spmm(ctx.plan(M), ctx.upload(D)).numpy()
     np.testing.assert_allclose(out, ref, rtol=1e-13, equal_nan=True)
     assert np.isfinite(out[0]).all() and np.isnan(out[1]).all() and np.isnan(out[2, 3])
+
+
+@pytest.mark.parametrize("tile", ["flat", "128x1", "64x2", "32x4", "16x8", None])
+@pytest.mark.parametrize("Y,X", [(7, 9), (8, 16), (13, 50), (3, 130), (40, 33)])
+def test_tile_layouts(ctx, monkeypatch, tile, Y, X):
+    """Every cell-tile shape (and the automatic choice) gives the same aggregation; odd X takes
+    the scalar-load path, edge tiles are partially filled."""
+    if tile is None:
+        monkeypatch.delenv("ATLITE_HIP_TILE", raising=False)
+    else:
+        monkeypatch.setenv("ATLITE_HIP_TILE", tile)
+    T, N = 21, 6
+    rng = np.random.default_rng(Y * 1000 + X)
+    D = rng.standard_normal((T, Y * X))
+    M = H.blob_matrix(N, Y, X, seed=X)
+    plan = ctx.plan(M, row_len=X)
+    info = plan.info()
+    if tile not in (None, "flat"):
+        assert f"{info['tile_w']}x{info['tile_h']}" == tile
+    close(ctx.spmm(plan, ctx.upload(D)).numpy(), M @ D.T, atol_scale=1e-13)
+    ds = H.pv_dataset(T, Y, X, seed=3)
+    ref = orc.aggregate_matrix(orc.convert_pv(ds, H.CSI, dict(slope=np.radians(30.0), azimuth=np.radians(180.0))), M)
+    close(ctx.pv(up(ctx, ds), PV_PARAMS, T, Y * X, plan=plan).numpy(), ref)
