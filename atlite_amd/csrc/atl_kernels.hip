@@ -246,6 +246,9 @@ __device__ __forceinline__ double pv_cell(double dir, double dif, double toa, do
     const double influx = direct + diffuse;
     // irradiation.py:251-252 (NaN compares false: a NaN altitude is not capped)
     const bool capped = (alt < k.alt_thr) || (influx <= 0.01);
+#ifdef ATL_ABLATE_NOMATH  // experiment: keep the 7 streams, drop the physics
+    return influx + alb + tmp + alt + az;
+#endif
     if (capped) return 0.0;  // G = 0 -> G_ = 0, eff -> 0 : 0*0*inv
     double sa, ca;
     lean_sincos(alt, &sa, &ca);
@@ -400,31 +403,72 @@ __global__ __launch_bounds__(256) void k_chunk_reduce(const double *__restrict__
 // ---------------------------------------------------------------------------------------
 // kernel 3: fused convert + segment reduce
 // ---------------------------------------------------------------------------------------
-// wave butterfly: c[i] (i = slot in batch) per lane -> lane 8g holds sum over lanes of c[g]
-__device__ __forceinline__ double butterfly8(const double (&c)[kBatch], int lane) {
-    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
-    double d[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const double keep = h5 ? c[j + 4] : c[j];
-        const double send = h5 ? c[j] : c[j + 4];
-        d[j] = keep + __shfl_xor(send, 32);
-    }
-    double e[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const double keep = h4 ? d[j + 2] : d[j];
-        const double send = h4 ? d[j] : d[j + 2];
-        e[j] = keep + __shfl_xor(send, 16);
-    }
-    const double keep = h3 ? e[1] : e[0];
-    const double send = h3 ? e[0] : e[1];
-    double f = keep + __shfl_xor(send, 8);
-    f += __shfl_xor(f, 4);
-    f += __shfl_xor(f, 2);
-    f += __shfl_xor(f, 1);
-    return f;
+// ---- wave butterfly -----------------------------------------------------------------------
+// c[i] (i = slot in batch) per lane -> every lane of the 8-lane group g holds sum over all 64
+// lanes of c[g].  Stage 32 and 16 use the gfx950 lane-swap instructions (v_permlane32_swap /
+// v_permlane16_swap: no selects, no LDS), stages 8..1 are DPP moves inside a row of 16 lanes.
+// Deterministic: a fixed reduction tree.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double swap_add32(double a, double b) {
+    // a kept by lanes 0-31, b kept by lanes 32-63:  lo: a[l] + a[l+32]   hi: b[l-32] + b[l]
+    const u32x2 lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const u32x2 hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi.x, lo.x) + __hiloint2double(hi.y, lo.y);
 }
+
+__device__ __forceinline__ double swap_add16(double a, double b) {
+    // a kept by even rows of 16 lanes, b kept by odd rows
+    const u32x2 lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const u32x2 hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi.x, lo.x) + __hiloint2double(hi.y, lo.y);
+}
+
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ double dpp_mov(double old, double src) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xF, BANK_MASK, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xF, BANK_MASK, false);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int kDppRor8 = 0x128, kDppHalfMirror = 0x141, kDppQuad1032 = 0xB1, kDppQuad2301 = 0x4E;
+
+__device__ __forceinline__ double butterfly8(const double (&c)[kBatch]) {
+    const double d0 = swap_add32(c[0], c[4]), d1 = swap_add32(c[1], c[5]);
+    const double d2 = swap_add32(c[2], c[6]), d3 = swap_add32(c[3], c[7]);
+    const double e0 = swap_add16(d0, d2), e1 = swap_add16(d1, d3);
+    // lanes 0-7 of a row keep e0, lanes 8-15 keep e1 (bank masks select the written lanes)
+    const double u = dpp_mov<kDppRor8, 0x3>(e1, e0);  // lanes 0-7: e0[l+8]   lanes 8-15: e1[l]
+    const double w = dpp_mov<kDppRor8, 0xC>(e0, e1);  // lanes 0-7: e0[l]     lanes 8-15: e1[l-8]
+    double f = u + w;
+    f += dpp_mov<kDppHalfMirror, 0xF>(f, f);
+    f += dpp_mov<kDppQuad1032, 0xF>(f, f);
+    f += dpp_mov<kDppQuad2301, 0xF>(f, f);
+    return f;  // slot index held by lane l: 4*(l>>5) + 2*((l>>4)&1) + ((l>>3)&1) = (l >> 3)
+}
+
+// one partial row: weight the batch, reduce, store 8 consecutive slots
+template <bool GUARD>
+__device__ __forceinline__ void reduce_row(const double2 (&v)[kBatch], double2 w, bool a0, bool a1, int lane,
+                                           int64_t sb, int64_t send, double *__restrict__ prow) {
+    double c[kBatch];
+#pragma unroll
+    for (int i = 0; i < kBatch; ++i) {
+        if constexpr (GUARD) {
+            // structural zeros must not turn NaN/inf cells into NaN (scipy CSR skips them)
+            const double t0 = a0 ? w.x * v[i].x : 0.0;
+            const double t1 = a1 ? w.y * v[i].y : 0.0;
+            c[i] = t0 + t1;
+        } else {
+            c[i] = __builtin_fma(w.y, v[i].y, w.x * v[i].x);  // w = 0 where absent, v finite
+        }
+    }
+    const double f = butterfly8(c);
+    const int g = lane >> 3;
+    if ((lane & 7) == 0 && sb + g < send) prow[sb + g] = f;
+}
+
+constexpr int kRowCache = 4;  // partial rows of a tile whose weights stay in registers
 
 template <class Conv, bool VEC>
 __global__ __launch_bounds__(256) void k_fused_segred(Conv conv, PlanDev plan, int64_t n_slots,
@@ -439,18 +483,37 @@ __global__ __launch_bounds__(256) void k_fused_segred(Conv conv, PlanDev plan, i
     const int32_t seg = int32_t(unit % plan.n_segs);
     const int64_t chunk = unit / plan.n_segs;
     // tile coordinates -> the lane's two adjacent cells
+    // (columns sheared by (gy*X) mod 16 cells: tile rows start on 128-byte lines)
     const int32_t ty = seg / plan.ntx, tx = seg - ty * plan.ntx;
-    const int64_t gx = (int64_t(tx) << (plan.w2_log2 + 1)) + ((lane & ((1 << plan.w2_log2) - 1)) << 1);
     const int64_t gy = int64_t(ty) * (kLanes >> plan.w2_log2) + (lane >> plan.w2_log2);
+    const int64_t gx = (int64_t(tx) << (plan.w2_log2 + 1)) + ((lane & ((1 << plan.w2_log2) - 1)) << 1) -
+                       ((gy * plan.X) & 15);
     const int64_t c0 = gy * plan.X + gx;
-    const bool v0 = gy < plan.Y && gx < plan.X, v1 = gy < plan.Y && gx + 1 < plan.X;
+    const bool v0 = gy < plan.Y && gx >= 0 && gx < plan.X;
+    const bool v1 = gy < plan.Y && gx + 1 >= 0 && gx + 1 < plan.X;
     const int32_t p0 = plan.seg_ptr[seg], p1 = plan.seg_ptr[seg + 1];
-    if (p0 == p1) return;  // no shape touches this segment: nothing to read
+    if (p0 == p1) return;  // no shape touches this tile: nothing to read
     const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1);
+    // weights of the first kRowCache partial rows: registers for the whole chunk
+    double2 wc[kRowCache];
+    unsigned present = 0;  // bit 2r / 2r+1: cell 0 / 1 structurally present in row r
+#pragma unroll
+    for (int r = 0; r < kRowCache; ++r) {
+        wc[r].x = 0.0;
+        wc[r].y = 0.0;
+        if (p0 + r < p1) {
+            const double2 w = *reinterpret_cast<const double2 *>(plan.prow_w + int64_t(p0 + r) * kSegCells + 2 * lane);
+            const bool a0 = !dnan(w.x), a1 = !dnan(w.y);
+            wc[r].x = a0 ? w.x : 0.0;
+            wc[r].y = a1 ? w.y : 0.0;
+            present |= (a0 ? 1u : 0u) << (2 * r) | (a1 ? 1u : 0u) << (2 * r + 1);
+        }
+    }
     const int64_t sbeg = chunk * chunk_slots;
     const int64_t send = min(sbeg + int64_t(chunk_slots), n_slots);
     for (int64_t sb = sbeg; sb < send; sb += kBatch) {
         double2 v[kBatch];
+        bool finite = true;
 #pragma unroll
         for (int i = 0; i < kBatch; ++i) {
             const int64_t slot = sb + i;
@@ -460,20 +523,36 @@ __global__ __launch_bounds__(256) void k_fused_segred(Conv conv, PlanDev plan, i
                 v[i].x = 0.0;
                 v[i].y = 0.0;
             }
+            // |x| < inf is false for NaN and +-inf
+            finite = finite && (__builtin_fabs(v[i].x) < __builtin_inf()) && (__builtin_fabs(v[i].y) < __builtin_inf());
         }
-        for (int32_t p = p0; p < p1; ++p) {
-            const double2 w = *reinterpret_cast<const double2 *>(plan.prow_w + int64_t(p) * kSegCells + 2 * lane);
-            const bool a0 = !dnan(w.x), a1 = !dnan(w.y);  // structurally present
-            double c[kBatch];
+#ifdef ATL_ABLATE_NOREDUCE  // experiment: conversion only, one dummy store per batch
+        {
+            double acc = 0.0;
+            for (int i = 0; i < kBatch; ++i) acc += v[i].x + v[i].y;
+            if (acc == 1.2345e300) partials[sb] = acc;
+            continue;
+        }
+#endif
+        const bool all_finite = __all(finite);  // wave-uniform
 #pragma unroll
-            for (int i = 0; i < kBatch; ++i) {
-                const double t0 = a0 ? w.x * v[i].x : 0.0;
-                const double t1 = a1 ? w.y * v[i].y : 0.0;
-                c[i] = t0 + t1;
+        for (int r = 0; r < kRowCache; ++r) {
+            if (p0 + r < p1) {
+                double *prow = partials + int64_t(p0 + r) * ldp;
+                if (all_finite)
+                    reduce_row<false>(v, wc[r], true, true, lane, sb, send, prow);
+                else
+                    reduce_row<true>(v, wc[r], (present >> (2 * r)) & 1u, (present >> (2 * r + 1)) & 1u, lane, sb,
+                                     send, prow);
             }
-            const double f = butterfly8(c, lane);
-            const int g = lane >> 3;
-            if ((lane & 7) == 0 && sb + g < send) partials[int64_t(p) * ldp + sb + g] = f;
+        }
+        for (int32_t p = p0 + kRowCache; p < p1; ++p) {
+            const double2 w = *reinterpret_cast<const double2 *>(plan.prow_w + int64_t(p) * kSegCells + 2 * lane);
+            const bool a0 = !dnan(w.x), a1 = !dnan(w.y);
+            double2 wz;
+            wz.x = a0 ? w.x : 0.0;
+            wz.y = a1 ? w.y : 0.0;
+            reduce_row<true>(v, wz, a0, a1, lane, sb, send, partials + int64_t(p) * ldp);
         }
     }
 }

@@ -268,14 +268,21 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_le
         int64_t X, Y;
         int w2_log2;  // lanes per tile row
     };
-    auto tile_of = [](const Layout &L, int64_t cell, int32_t *local) {
+    // Tile columns are sheared per grid row by shift(y) = (y*X) mod 16 cells so that every
+    // tile row starts on a 128-byte line of the stacked (time, cell) cube (when S % 16 == 0).
+    auto ntx_of = [](const Layout &L) {
+        const int w = 2 << L.w2_log2;
+        const int64_t max_shift = (L.Y > 1 && L.X % 16 != 0) ? 15 : 0;
+        return (L.X - 1 + max_shift) / w + 1;
+    };
+    auto tile_of = [&ntx_of](const Layout &L, int64_t cell, int32_t *local) {
         const int64_t y = cell / L.X, x = cell % L.X;
         const int w = 2 << L.w2_log2, h = kLanes >> L.w2_log2;
-        const int64_t ntx = (L.X + w - 1) / w;
-        const int64_t tx = x / w, ty = y / h;
-        const int lane = int((y % h) << L.w2_log2) + int((x % w) >> 1);
-        *local = lane * 2 + int(x & 1);
-        return ty * ntx + tx;
+        const int64_t xs = x + ((y * L.X) & 15);
+        const int64_t tx = xs / w, ty = y / h;
+        const int lane = int((y % h) << L.w2_log2) + int((xs % w) >> 1);
+        *local = lane * 2 + int(xs & 1);
+        return ty * ntx_of(L) + tx;
     };
     std::vector<Layout> cands;
     cands.push_back({n_cells > 0 ? n_cells : 1, 1, 6});  // flat 128 x 1 over the stacked axis
@@ -326,7 +333,7 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_le
     }
     const Layout L = cands[best];
     const int tw = 2 << L.w2_log2, th = kLanes >> L.w2_log2;
-    const int64_t ntx = (L.X + tw - 1) / tw, nty = (L.Y + th - 1) / th;
+    const int64_t ntx = ntx_of(L), nty = (L.Y + th - 1) / th;
     const int64_t n_segs = n_cells > 0 ? ntx * nty : 0;
 
     struct Ent {
