@@ -147,6 +147,7 @@ SIGNATURES = {
          C.POINTER(_vp)],
     ),
     "atl_host_free": (_i, [_vp]),
+    "atl_math_probe": (_i, [_vp, _i, _vp, _i64, _vp]),
     "atl_synth_field": (
         _i,
         [_vp, _i, C.c_uint64, C.c_uint64, _d, _d, _i, _i64, _i64, _vp],

@@ -661,6 +661,31 @@ __global__ __launch_bounds__(256) void k_synth_pv(atl_synth_solar s, int64_t T, 
 }
 
 // ---------------------------------------------------------------------------------------
+// math probe (accuracy tests of atl_math.h against numpy)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_math_probe(int fn, const double *__restrict__ in, int64_t n,
+                                                    double *__restrict__ out) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double x = in[i];
+    double r;
+    switch (fn) {
+        case 0: r = lean_sin(x); break;
+        case 1: r = lean_cos(x); break;
+        case 2: r = lean_log(x); break;
+        case 3: {
+            double s, c;
+            lean_sincos(x, &s, &c);
+            r = s;
+            out[n + i] = c;
+            break;
+        }
+        default: r = fast_div(x, in[n + i]); break;
+    }
+    out[i] = r;
+}
+
+// ---------------------------------------------------------------------------------------
 // host-side launch plumbing
 // ---------------------------------------------------------------------------------------
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -987,6 +1012,16 @@ int atl_runoff_convert_aggregate(atl_ctx *ctx, const double *d_runoff, const dou
     RunoffConv c{d_runoff, d_height, S};
     return run_fused(ctx, c, vec_ok(S, {d_runoff}), 0, T, S, agg, time_agg, d_out, ld_out,
                      "atl_runoff_convert_aggregate");
+}
+
+int atl_math_probe(atl_ctx *ctx, int fn, const double *d_in, int64_t n, double *d_out) {
+    ATL_REQUIRE(ctx && d_in && d_out && n >= 0, "atl_math_probe: bad argument");
+    ATL_REQUIRE(fn >= 0 && fn <= 4, "atl_math_probe: fn must be 0..4");
+    ATL_HIP_TRY(hipSetDevice(ctx->device));
+    if (n == 0) return ATL_OK;
+    hipLaunchKernelGGL(k_math_probe, dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, fn, d_in, n,
+                       d_out);
+    return check_launch("atl_math_probe");
 }
 
 int atl_synth_field(atl_ctx *ctx, int kind, uint64_t seed, uint64_t var_id, double p0, double p1,

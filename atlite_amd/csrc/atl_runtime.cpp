@@ -105,10 +105,10 @@ int atl_create(int device, void *stream, atl_ctx **out) {
         }
         c->own_stream = true;
     }
-    hipEventCreate(&c->ev_t0);
-    hipEventCreate(&c->ev_t1);
-    hipEventCreate(&c->ev_k0);
-    hipEventCreate(&c->ev_k1);
+    (void)hipEventCreate(&c->ev_t0);
+    (void)hipEventCreate(&c->ev_t1);
+    (void)hipEventCreate(&c->ev_k0);
+    (void)hipEventCreate(&c->ev_k1);
     if (hipMalloc(reinterpret_cast<void **>(&c->d_table), 3 * kMaxKnots * sizeof(double)) !=
         hipSuccess) {
         set_error("atl_create: table allocation failed");
@@ -125,10 +125,10 @@ int atl_destroy(atl_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->d_table) (void)hipFree(ctx->d_table);
-    hipEventDestroy(ctx->ev_t0);
-    hipEventDestroy(ctx->ev_t1);
-    hipEventDestroy(ctx->ev_k0);
-    hipEventDestroy(ctx->ev_k1);
+    (void)hipEventDestroy(ctx->ev_t0);
+    (void)hipEventDestroy(ctx->ev_t1);
+    (void)hipEventDestroy(ctx->ev_k0);
+    (void)hipEventDestroy(ctx->ev_k1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return ATL_OK;

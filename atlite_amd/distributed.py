@@ -1,0 +1,95 @@
+"""
+Multi-GPU execution of the hot path: one process per GPU, the TIME axis sharded.
+
+Every time step (every calendar day for heat demand) converts and aggregates independently
+(SURVEY.md 8e), so rank r owns a contiguous slab of time steps of every input cube plus the
+whole (small) indicator matrix, runs the fused kernel on its slab, and the (shapes x time)
+result is reassembled with ONE collective over RCCL/xGMI:
+
+* ``aggregate_time=None``  -> all-gather of the (N x T_r) blocks      (``gather_time``)
+* ``"sum"`` / ``"mean"``   -> all-reduce of per-rank (sum, count)      (``reduce_time``)
+
+``torch.distributed`` is the transport ("nccl" = RCCL on ROCm; "gloo" in the CPU tests).
+The reference has no distributed path (its parallelism is dask threads over time chunks,
+atlite/cutout.py:143); this module is the MI355X-native counterpart of that chunking.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def time_partition(n_steps, world_size, align=1, first=0):
+    """
+    Edges ``e[0..world]`` of contiguous time shards, balanced to within ``align`` steps.
+    ``align`` = 24 with ``first`` = number of steps before the first full day keeps calendar
+    days intact for heat demand (shard boundaries fall on day boundaries of the shifted axis).
+    """
+    n_steps, world_size, align = int(n_steps), int(world_size), max(1, int(align))
+    edges = [0]
+    for r in range(1, world_size):
+        e = round(n_steps * r / world_size)
+        if align > 1:
+            e = first + round((e - first) / align) * align
+        edges.append(int(min(max(e, edges[-1]), n_steps)))
+    edges.append(n_steps)
+    return edges
+
+
+def _dist():
+    import torch.distributed as dist
+
+    return dist
+
+
+def gather_time(local, group=None):
+    """
+    All-gather along the LAST axis: ``local`` is this rank's (..., T_r) block (torch tensor on
+    the rank's device, or a NumPy array -> CPU tensor); returns the (..., sum T_r) result on
+    every rank, same kind as the input.  Shards may have different lengths.
+    """
+    import torch
+
+    dist = _dist()
+    world = dist.get_world_size(group)
+    is_np = isinstance(local, np.ndarray)
+    t = torch.from_numpy(np.ascontiguousarray(local)) if is_np else local.contiguous()
+    if world == 1:
+        return local
+    lens = torch.zeros(world, dtype=torch.int64, device=t.device)
+    lens[dist.get_rank(group)] = t.shape[-1]
+    dist.all_reduce(lens, group=group)
+    lens = [int(v) for v in lens.tolist()]
+    lead = t.shape[:-1]
+    if len(set(lens)) == 1:
+        # one collective into a (world, ..., T_r) buffer, then a local transpose-concat
+        buf = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(buf.view(-1), t.view(-1), group=group)
+        out = buf.movedim(0, -2).reshape(*lead, world * lens[0])
+    else:
+        # ragged shards: pad to the longest, gather once, trim
+        tmax = max(lens)
+        pad = torch.zeros(tuple(lead) + (tmax,), dtype=t.dtype, device=t.device)
+        pad[..., : t.shape[-1]] = t
+        buf = torch.empty((world,) + tuple(pad.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(buf.view(-1), pad.view(-1), group=group)
+        out = torch.cat([buf[r][..., : lens[r]] for r in range(world)], dim=-1)
+    return out.numpy() if is_np else out
+
+
+def reduce_time(local_sum, local_count, mean, group=None):
+    """
+    Combine per-rank nan-skipping time sums (and valid counts) of shape (N,) or (S,):
+    returns the global sum, or sum / count for ``mean`` (convert.py:51-56 over the full axis).
+    """
+    import torch
+
+    dist = _dist()
+    is_np = isinstance(local_sum, np.ndarray)
+    s = torch.from_numpy(np.ascontiguousarray(local_sum, dtype=np.float64)) if is_np else local_sum.contiguous()
+    c = torch.from_numpy(np.ascontiguousarray(local_count, dtype=np.float64)) if is_np else local_count.contiguous()
+    both = torch.stack([s, c])
+    if dist.get_world_size(group) > 1:
+        dist.all_reduce(both, group=group)
+    out = both[0] / both[1] if mean else both[0]
+    return out.numpy() if is_np else out

@@ -213,6 +213,13 @@ int atl_indicator_polygons(int64_t n_shapes, const int64_t *h_shape_ring_ptr, in
                            double **out_data);
 int atl_host_free(void *p);
 
+/* ---- diagnostics ------------------------------------------------------------------------
+ * Evaluates the kernels' lean fp64 math (atl_math.h) elementwise, for accuracy tests:
+ * fn 0 sin, 1 cos, 2 log: d_in (n) -> d_out (n);  3 sincos: d_out (2n) = sin | cos;
+ * 4 fast_div: d_in (2n) = a | b -> d_out (n) = a / b.
+ */
+int atl_math_probe(atl_ctx *ctx, int fn, const double *d_in, int64_t n, double *d_out);
+
 /* ---- synthetic ERA5-shaped inputs (bench/test tooling) ----------
  * Fills device cubes with a stateless splitmix64-hash field so that any (t, cell) slice can
  * be regenerated or downloaded for the oracle.  Not part of the reference's interface.
