@@ -332,7 +332,7 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_le
         }
     }
     const Layout L = cands[best];
-    const int tw = 2 << L.w2_log2, th = kLanes >> L.w2_log2;
+    const int th = kLanes >> L.w2_log2;
     const int64_t ntx = ntx_of(L), nty = (L.Y + th - 1) / th;
     const int64_t n_segs = n_cells > 0 ? ntx * nty : 0;
 

@@ -42,11 +42,12 @@ def _dist():
     return dist
 
 
-def gather_time(local, group=None):
+def gather_time(local, group=None, lens=None):
     """
     All-gather along the LAST axis: ``local`` is this rank's (..., T_r) block (torch tensor on
     the rank's device, or a NumPy array -> CPU tensor); returns the (..., sum T_r) result on
-    every rank, same kind as the input.  Shards may have different lengths.
+    every rank, same kind as the input.  Shards may have different lengths; pass the per-rank
+    lengths as ``lens`` when they are known to skip the size exchange.
     """
     import torch
 
@@ -56,10 +57,11 @@ def gather_time(local, group=None):
     t = torch.from_numpy(np.ascontiguousarray(local)) if is_np else local.contiguous()
     if world == 1:
         return local
-    lens = torch.zeros(world, dtype=torch.int64, device=t.device)
-    lens[dist.get_rank(group)] = t.shape[-1]
-    dist.all_reduce(lens, group=group)
-    lens = [int(v) for v in lens.tolist()]
+    if lens is None:
+        lens = torch.zeros(world, dtype=torch.int64, device=t.device)
+        lens[dist.get_rank(group)] = t.shape[-1]
+        dist.all_reduce(lens, group=group)
+        lens = [int(v) for v in lens.tolist()]
     lead = t.shape[:-1]
     if len(set(lens)) == 1:
         # one collective into a (world, ..., T_r) buffer, then a local transpose-concat

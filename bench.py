@@ -119,7 +119,9 @@ def main():
     params = dict(CSI, slope=np.radians(30.0), azimuth=np.radians(180.0))
 
     out_local = torch.empty((N, T_loc), dtype=torch.float64, device=f"cuda:{local}")
-    out_all = torch.empty((world, N, T_loc), dtype=torch.float64, device=f"cuda:{local}") if world > 1 else None
+    from atlite_amd import distributed as D
+
+    shard_lens = [T_loc] * world
     from atlite_amd import _lib
     import ctypes as C
 
@@ -134,7 +136,8 @@ def main():
         _lib.check(ctx.lib.atl_pv_convert_aggregate(ctx.handle, C.byref(pin), C.byref(pp), T_loc, S,
                                                     plan.handle, 0, out_local.data_ptr(), T_loc))
         if world > 1:
-            dist.all_gather_into_tensor(out_all.view(-1), out_local.view(-1))
+            return D.gather_time(out_local, lens=shard_lens)  # (N, world * T_loc) on every rank
+        return out_local
 
     def fence():
         if world > 1:
