@@ -35,8 +35,14 @@ class PvInputs(C.Structure):
             "d_temperature",
             "d_solar_altitude",
             "d_solar_azimuth",
+            "d_sin_dec",
+            "d_cos_dec",
+            "d_hour_angle",
+            "d_cos_hour_angle",
+            "d_sin_lat",
+            "d_cos_lat",
         )
-    ]
+    ] + [("X", C.c_int64)]
 
 
 class PvParams(C.Structure):

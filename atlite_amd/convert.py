@@ -91,11 +91,22 @@ class _PvSpec(_Spec):
                 "Need either albedo or outflux as a variable in the dataset. "
                 "Check your cutout and dataset module."
             )
+        self.solar_tables = None
         if not ("solar_altitude" in ds and "solar_azimuth" in ds):
-            raise NotImplementedError(
-                "datasets without solar_altitude/solar_azimuth need the in-kernel solar position variant "
-                "(not implemented yet); recreate the cutout so that it stores the solar position"
+            # SolarPosition(ds) compute branch (pv/solar_position.py:62-121, no time shift): the (T)-
+            # and (T,X)-sized parts on the host, the cube-sized part inside the kernel
+            warnings.warn(
+                """The calculation method and handling of solar position variables will change.
+    The solar position will in the future be a permanent variables of a cutout.
+    Recreate your cutout to remove this warning and permanently include the solar position variables into your cutout.""",
+                DeprecationWarning,
             )
+            from . import solar
+
+            h, dec = solar.hour_angle(ds.coords["time"], ds.coords["lon"], "0h")
+            lat = np.radians(ds.coords["lat"])
+            self.solar_tables = dict(sin_dec=np.sin(dec), cos_dec=np.cos(dec), h=h, cos_h=np.cos(h),
+                                     sin_lat=np.sin(lat), cos_lat=np.cos(lat))
         model = panel.get("model", "huld")
         if model != "huld":
             raise NotImplementedError(f"panel model {model!r} is not implemented on the GPU path yet")
@@ -128,15 +139,16 @@ class _PvSpec(_Spec):
 
     def run(self, ctx, ds, plan, time_agg):
         T, S = len(ds.coords["time"]), len(ds.coords["y"]) * len(ds.coords["x"])
-        names = ("influx_direct", "influx_diffuse", "influx_toa", "albedo", "temperature", "solar_altitude",
-                 "solar_azimuth")
+        names = ("influx_direct", "influx_diffuse", "influx_toa", "albedo", "temperature")
+        if self.solar_tables is None:
+            names += ("solar_altitude", "solar_azimuth")
         inputs = {n: ds.device(ctx, n) for n in names}
         slope, azimuth = self.slope, self.azimuth
         if np.ndim(slope) != np.ndim(azimuth):  # mixed scalar / per-cell -> per-cell
             slope = np.broadcast_to(slope, (S,))
             azimuth = np.broadcast_to(azimuth, (S,))
         params = dict(self.panel, slope=slope, azimuth=azimuth)
-        return ctx.pv(inputs, params, T, S, plan=plan, time_agg=time_agg)
+        return ctx.pv(inputs, params, T, S, plan=plan, time_agg=time_agg, solar_tables=self.solar_tables)
 
 
 class _WindSpec(_Spec):

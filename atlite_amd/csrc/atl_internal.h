@@ -17,7 +17,7 @@ constexpr int kLanes = 64;               // gfx950 wavefront
 constexpr int kSegCells = 2 * kLanes;    // one wave covers 128 consecutive cells, 2 per lane
 constexpr int kBatch = 8;                // output slots reduced per butterfly
 constexpr int kWavesPerBlock = 4;        // 256-thread workgroups, waves independent
-constexpr int kMaxKnots = 2048;          // wind power-curve table limit (LDS: 3 x 16 KiB)
+constexpr int kMaxKnots = 1023;          // wind power-curve table limit (LDS: 5 x 1024 doubles = 40 KiB)
 
 void set_error(const char *fmt, ...);
 

@@ -19,6 +19,9 @@
 //   wind : convert.py:634-662 (np.interp), wind.py:76-112
 //   heat : convert.py:405-418      runoff : convert.py:1028-1034
 //   agg  : aggregate.py:16-35 (scipy CSR product), convert.py:51-56 (_aggregate_time)
+#include <cmath>
+#include <limits>
+
 #include "atl_internal.h"
 #include "atl_math.h"
 
@@ -152,6 +155,16 @@ struct HeatConv {
 };
 
 // wind: hub-height extrapolation + power curve (wind.py:76-112, convert.py:648-649)
+//
+// LDS table, built on the host (make_wind): n_pad = power of two > n_knots,
+//   V[n_pad]  knots, padded with +inf          (search never needs a bounds check)
+//   K[n_pad]  records {V[j], F[j], slope[j], 0} (slope[n-1] = 0)
+// np.interp(x, V, F) (numpy arr_interp) for a FINITE table reduces to
+//   xc = clamp(x, V[0], V[n-1]);  j = largest index with V[j] <= xc;
+//   r  = fma(slope[j], xc - V[j], F[j])
+// which returns F[j] exactly on knots, F[0] / F[n-1] outside the range (also for +-inf), NaN
+// for NaN, and takes the upper one of repeated knots - all without a branch.  Tables holding
+// non-finite values take interp_generic(), the literal transcription of arr_interp.
 struct WindConv {
     const double *wnd;
     const double *aux;
@@ -160,14 +173,15 @@ struct WindConv {
     int method;
     double to_height, from_height;
     double log_ratio;      // log(to/from)   (power law)
-    const double *table;   // device: V[n] F[n] slope[n]
-    int n_knots;
-    int search_start;      // largest power of two < n_knots
+    const double *table;   // device: V[n_pad] | K[n_pad][4]
+    int n_knots, n_pad;
+    int table_finite;
     struct Cell {
         double2 aux;
+        double lh, lf;  // lean_log(to_height), lean_log(from_height)
     };
     __device__ void block_init(double *lds) const {
-        for (int i = threadIdx.x; i < 3 * n_knots; i += blockDim.x) lds[i] = table[i];
+        for (int i = threadIdx.x; i < 5 * n_pad; i += blockDim.x) lds[i] = table[i];
     }
     __device__ Cell cell_setup(int64_t c0, bool v0, bool v1) const {
         Cell c;
@@ -177,41 +191,64 @@ struct WindConv {
             c.aux.x = v0 ? aux[c0] : 1.0;
             c.aux.y = v1 ? aux[c0 + 1] : 1.0;
         }
+        // through the same lean_log as the per-cell roughness: z0 == from_height gives an exact
+        // zero denominator, like the reference's log(from/z0) = log(1)
+        c.lh = lean_log(to_height);
+        c.lf = lean_log(from_height);
         return c;
     }
-    __device__ __forceinline__ double hub_speed(double v, double z) const {
+    __device__ __forceinline__ double hub_speed(double v, double z, const Cell &c) const {
         if (method == ATL_WIND_LOG) {
-            // wind.py:99-101: v * (log(to/z0) / log(from/z0)), with log(a/z0) = log a - log z0.
-            // All three logs go through the same lean_log, so z0 == from_height gives an exact
-            // zero denominator like the reference's log(1).
+            // wind.py:99-101: v * (log(to/z0) / log(from/z0)), with log(a/z0) = log a - log z0
             const double lz = lean_log(z);
-            return v * ((lean_log(to_height) - lz) / (lean_log(from_height) - lz));  // IEEE divide: den may be 0
+            const double num = c.lh - lz, den = c.lf - lz;
+            double q = fast_div(num, den);
+            const bool tame = __builtin_fabs(den) > 0x1.0p-500 && __builtin_fabs(den) < 0x1.0p500 &&
+                              __builtin_fabs(num) < 0x1.0p500;
+            if (!tame) q = num / den;  // zero / huge / non-finite operands: IEEE division
+            return v * q;
         } else if (method == ATL_WIND_POWER) {
             // wind.py:111: v * (to/from) ** shear = v * exp(shear * log(to/from))
             return v * exp(z * log_ratio);
         }
         return v;
     }
-    // np.interp(x, V, F) — numpy/_core/src/multiarray/compiled_base.c arr_interp semantics
     __device__ __forceinline__ double interp(double x, const double *lds) const {
-        const double *V = lds, *F = lds + n_knots, *SL = lds + 2 * n_knots;
+        const double *V = lds;
+        const double *K = lds + n_pad;
+        const double vmin = V[0], vmax = V[n_knots - 1];
+        double xc = x > vmax ? vmax : x;
+        xc = xc < vmin ? vmin : xc;  // NaN stays NaN
+        int j = 0;
+        for (int step = n_pad >> 1; step > 0; step >>= 1) {
+            const int cand = j + step;
+            j = (V[cand] <= xc) ? cand : j;
+        }
+        const double2 k0 = *reinterpret_cast<const double2 *>(K + 4 * j);
+        const double sl = K[4 * j + 2];
+        return __builtin_fma(sl, xc - k0.x, k0.y);
+    }
+    // literal numpy/_core/src/multiarray/compiled_base.c arr_interp (any table)
+    __device__ double interp_generic(double x, const double *lds) const {
+        const double *V = lds;
+        const double *K = lds + n_pad;
         const int n = n_knots;
         if (dnan(x)) return x;
-        if (x < V[0]) return F[0];
-        if (x > V[n - 1]) return F[n - 1];
-        int j = 0;  // largest j with V[j] <= x
-        for (int step = search_start; step > 0; step >>= 1) {
+        if (x < V[0]) return K[1];
+        if (x > V[n - 1]) return K[4 * (n - 1) + 1];
+        int j = 0;
+        for (int step = n_pad >> 1; step > 0; step >>= 1) {
             const int cand = j + step;
-            if (cand < n && V[cand] <= x) j = cand;
+            if (V[cand] <= x) j = cand;
         }
-        if (j == n - 1) return F[j];
-        const double xj = V[j], fj = F[j];
+        const double xj = K[4 * j], fj = K[4 * j + 1];
+        if (j == n - 1) return fj;
         if (xj == x) return fj;
-        const double slope = SL[j];
+        const double slope = (K[4 * (j + 1) + 1] - fj) / (K[4 * (j + 1)] - xj);
         double r = slope * (x - xj) + fj;
         if (dnan(r)) {
-            r = slope * (x - V[j + 1]) + F[j + 1];
-            if (dnan(r) && fj == F[j + 1]) r = fj;
+            r = slope * (x - K[4 * (j + 1)]) + K[4 * (j + 1) + 1];
+            if (dnan(r) && fj == K[4 * (j + 1) + 1]) r = fj;
         }
         return r;
     }
@@ -221,22 +258,55 @@ struct WindConv {
         double2 v = ld2<VEC>(wnd, slot * S + c0, v0, v1);
         double2 z = c.aux;
         if (method != ATL_WIND_NONE && !aux_static) z = ld2<VEC>(aux, slot * S + c0, v0, v1);
+        const double h0 = hub_speed(v.x, z.x, c), h1 = hub_speed(v.y, z.y, c);
         double2 r;
-        r.x = v0 ? interp(hub_speed(v.x, z.x), lds) : 0.0;
-        r.y = v1 ? interp(hub_speed(v.y, z.y), lds) : 0.0;
+        if (table_finite) {
+            r.x = interp(h0, lds);
+            r.y = interp(h1, lds);
+        } else {
+            r.x = interp_generic(h0, lds);
+            r.y = interp_generic(h1, lds);
+        }
+        r.x = v0 ? r.x : 0.0;
+        r.y = v1 ? r.y : 0.0;
         return r;
     }
 };
 
 // solar PV, ERA5-shaped inputs with stored solar position
 struct PvConst {
-    double c_amb, c_irr, r_tmod, inv_r_irr, k1, k2, k3, k4, k5, k6, inv_eff, alt_thr;
+    double c_amb, c_irr, r_tmod, inv_r_irr, k1, k2, k3, k4, k5, k6, inv_eff, alt_thr, sin_alt_thr;
 };
 
-// per-cell orientation factors: sin/cos(slope), (1 +- cos(slope))/2, panel azimuth
+// per-cell orientation factors: sin/cos(slope), (1 +- cos(slope))/2, panel azimuth (+ its cos/sin)
 struct PvOri {
-    double ss, cs, hp, hm, saz;
+    double ss, cs, hp, hm, saz, csaz, ssaz;
 };
+
+// irradiation on the tilted surface + Huld panel model, from sin/cos of the solar altitude and
+// cos(surface_azimuth - sun_azimuth)   (irradiation.py:214-226, solar_panel_model.py:22-41)
+__device__ __forceinline__ double pv_tail(double direct, double diffuse, double influx, double alb, double tmp,
+                                          double sa, double ca, double cosd, const PvOri &o, const PvConst &k) {
+    // orientation.py:114-117,188
+    double cosinc = o.ss * ca * cosd + o.cs * sa;
+    cosinc = np_max(cosinc, 0.0);
+    const double kk = fast_div(cosinc, sa);
+    const double direct_t = kk * direct;
+    const double diffuse_t = o.hp * diffuse;
+    const double ground_t = alb * influx * o.hm;
+    const double G = fill0(direct_t) + fill0(diffuse_t) + fill0(ground_t);
+    const double T_ = (k.c_amb * tmp + k.c_irr * G) - k.r_tmod;
+    const double G_ = G * k.inv_r_irr;
+    double eff = 0.0;
+    if (G_ > 0.0) {
+        const double l = lean_log(G_);
+        const double l2 = l * l;
+        eff = 1.0 + k.k1 * l + k.k2 * l2 + T_ * (k.k3 + k.k4 * l + k.k5 * l2) + k.k6 * (T_ * T_);
+        eff = fill0(eff);
+        eff = eff < 0.0 ? 0.0 : eff;
+    }
+    return G_ * eff * k.inv_eff;
+}
 
 __device__ __forceinline__ double pv_cell(double dir, double dif, double toa, double alb, double tmp,
                                           double alt, double az, const PvOri &o, const PvConst &k) {
@@ -252,30 +322,34 @@ __device__ __forceinline__ double pv_cell(double dir, double dif, double toa, do
     if (capped) return 0.0;  // G = 0 -> G_ = 0, eff -> 0 : 0*0*inv
     double sa, ca;
     lean_sincos(alt, &sa, &ca);
-    // orientation.py:114-117,188
-    double cosinc = o.ss * ca * lean_cos(o.saz - az) + o.cs * sa;
-    cosinc = np_max(cosinc, 0.0);
-    // irradiation.py:214-226
-    const double kk = fast_div(cosinc, sa);
-    const double direct_t = kk * direct;
-    const double diffuse_t = o.hp * diffuse;
-    const double ground_t = alb * influx * o.hm;
-    const double G = fill0(direct_t) + fill0(diffuse_t) + fill0(ground_t);
-    // solar_panel_model.py:22-41
-    const double T_ = (k.c_amb * tmp + k.c_irr * G) - k.r_tmod;
-    const double G_ = G * k.inv_r_irr;
-    double eff = 0.0;
-    if (G_ > 0.0) {
-        const double l = lean_log(G_);
-        const double l2 = l * l;
-        eff = 1.0 + k.k1 * l + k.k2 * l2 + T_ * (k.k3 + k.k4 * l + k.k5 * l2) + k.k6 * (T_ * T_);
-        eff = fill0(eff);
-        eff = eff < 0.0 ? 0.0 : eff;
-    }
-    return G_ * eff * k.inv_eff;
+    return pv_tail(direct, diffuse, influx, alb, tmp, sa, ca, lean_cos(o.saz - az), o, k);
 }
 
-struct PvConv {
+// same, with the solar position computed from the separable tables instead of read:
+// pv/solar_position.py:100-114.  sin(alt) = s directly, cos(alt) = sqrt(1-s^2),
+// cos(az) = clip(.../cos(alt)), sin(az) = +-sqrt(1-cos^2 az) by the sign of the hour angle, so
+// cos(surface_az - az) needs no inverse trig at all.  The cut alt < thr becomes s < sin(thr).
+__device__ __forceinline__ double pv_cell_sp(double dir, double dif, double toa, double alb, double tmp,
+                                             double sd, double cd, double sl, double cl, double h, double ch,
+                                             const PvOri &o, const PvConst &k) {
+    const double direct = np_clip(dir, 0.0, toa);
+    const double diffuse = np_clip(dif, 0.0, toa - direct);
+    const double influx = direct + diffuse;
+    const double s = np_clip(sd * sl + cd * cl * ch, -1.0, 1.0);  // :103-105
+    const bool capped = (s < k.sin_alt_thr) || (influx <= 0.01);
+    if (capped) return 0.0;
+    const double ca = sqrt((1.0 - s) * (1.0 + s));
+    const double num = sd * cl - cd * sl * ch;
+    double q = fast_div(num, ca);
+    if (!(ca > 0x1.0p-500)) q = num / ca;  // zenith / NaN: IEEE division like the reference
+    const double caz = np_clip(q, -1.0, 1.0);  // :109-113
+    double saz = sqrt((1.0 - caz) * (1.0 + caz));
+    saz = (h <= 0.0) ? saz : -saz;  // :114  az = az if h <= 0 else 2 pi - az
+    return pv_tail(direct, diffuse, influx, alb, tmp, s, ca, o.csaz * caz + o.ssaz * saz, o, k);
+}
+
+template <bool SP>
+struct PvConvT {
     atl_pv_inputs in;
     int64_t S;
     PvConst k;
@@ -284,6 +358,8 @@ struct PvConv {
     const double *cell_azimuth;  // (S)
     struct Cell {
         PvOri o0, o1;
+        double sl0, cl0, sl1, cl1;  // SP: sin/cos(lat) of the two cells
+        int x0, x1;                 // SP: grid column of the two cells
     };
     __device__ void block_init(double *) const {}
     __device__ static PvOri make_ori(double slope, double azimuth) {
@@ -292,6 +368,7 @@ struct PvConv {
         r.hp = (1.0 + r.cs) / 2.0;
         r.hm = (1.0 - r.cs) / 2.0;
         r.saz = azimuth;
+        lean_sincos(azimuth, &r.ssaz, &r.csaz);
         return r;
     }
     __device__ Cell cell_setup(int64_t c0, bool v0, bool v1) const {
@@ -303,25 +380,48 @@ struct PvConv {
             c.o0 = o;
             c.o1 = o;
         }
+        c.sl0 = c.cl0 = c.sl1 = c.cl1 = 0.0;
+        c.x0 = c.x1 = 0;
+        if constexpr (SP) {
+            const int64_t a = v0 ? c0 : 0, b = v1 ? c0 + 1 : 0;
+            const int64_t y0 = a / in.X, y1 = b / in.X;
+            c.x0 = int(a - y0 * in.X);
+            c.x1 = int(b - y1 * in.X);
+            c.sl0 = in.d_sin_lat[y0];
+            c.cl0 = in.d_cos_lat[y0];
+            c.sl1 = in.d_sin_lat[y1];
+            c.cl1 = in.d_cos_lat[y1];
+        }
         return c;
     }
     template <bool VEC>
     __device__ __forceinline__ double2 eval(int64_t slot, int64_t c0, bool v0, bool v1, const Cell &c,
                                             const double *) const {
         const int64_t off = slot * S + c0;
-        const double2 alt = ld2<VEC>(in.d_solar_altitude, off, v0, v1);
         const double2 dir = ld2<VEC>(in.d_influx_direct, off, v0, v1);
         const double2 dif = ld2<VEC>(in.d_influx_diffuse, off, v0, v1);
         const double2 toa = ld2<VEC>(in.d_influx_toa, off, v0, v1);
         const double2 alb = ld2<VEC>(in.d_albedo, off, v0, v1);
         const double2 tmp = ld2<VEC>(in.d_temperature, off, v0, v1);
-        const double2 az = ld2<VEC>(in.d_solar_azimuth, off, v0, v1);
         double2 r;
-        r.x = v0 ? pv_cell(dir.x, dif.x, toa.x, alb.x, tmp.x, alt.x, az.x, c.o0, k) : 0.0;
-        r.y = v1 ? pv_cell(dir.y, dif.y, toa.y, alb.y, tmp.y, alt.y, az.y, c.o1, k) : 0.0;
+        if constexpr (SP) {
+            const double sd = in.d_sin_dec[slot], cd = in.d_cos_dec[slot];
+            const int64_t hb = slot * in.X;
+            const double h0 = in.d_hour_angle[hb + c.x0], h1 = in.d_hour_angle[hb + c.x1];
+            const double ch0 = in.d_cos_hour_angle[hb + c.x0], ch1 = in.d_cos_hour_angle[hb + c.x1];
+            r.x = v0 ? pv_cell_sp(dir.x, dif.x, toa.x, alb.x, tmp.x, sd, cd, c.sl0, c.cl0, h0, ch0, c.o0, k) : 0.0;
+            r.y = v1 ? pv_cell_sp(dir.y, dif.y, toa.y, alb.y, tmp.y, sd, cd, c.sl1, c.cl1, h1, ch1, c.o1, k) : 0.0;
+        } else {
+            const double2 alt = ld2<VEC>(in.d_solar_altitude, off, v0, v1);
+            const double2 az = ld2<VEC>(in.d_solar_azimuth, off, v0, v1);
+            r.x = v0 ? pv_cell(dir.x, dif.x, toa.x, alb.x, tmp.x, alt.x, az.x, c.o0, k) : 0.0;
+            r.y = v1 ? pv_cell(dir.y, dif.y, toa.y, alb.y, tmp.y, alt.y, az.y, c.o1, k) : 0.0;
+        }
         return r;
     }
 };
+using PvConv = PvConvT<false>;
+using PvConvSP = PvConvT<true>;
 
 // ---------------------------------------------------------------------------------------
 // kernel 1: per-cell series  out[slot, cell]
@@ -832,26 +932,38 @@ bool vec_ok(int64_t S, std::initializer_list<const void *> ptrs) {
 }
 
 // ---- converter construction + validation ---------------------------------------------
-int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S, PvConv *c, bool *vec) {
+template <class PV>
+int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S, PV *c, bool *vec) {
     ATL_REQUIRE(in && p, "atl_pv: inputs/params is NULL");
     ATL_REQUIRE(T >= 0 && S >= 0, "atl_pv: negative shape");
     ATL_REQUIRE(in->d_influx_direct && in->d_influx_diffuse && in->d_influx_toa,
                 "atl_pv: need influx_direct, influx_diffuse and influx_toa (irradiation.py:209-213)");
     ATL_REQUIRE(in->d_albedo, "atl_pv: need albedo (irradiation.py:128-139)");
     ATL_REQUIRE(in->d_temperature, "atl_pv: need temperature");
-    ATL_REQUIRE(in->d_solar_altitude && in->d_solar_azimuth, "atl_pv: need solar_altitude and solar_azimuth");
+    if (in->d_solar_altitude || in->d_solar_azimuth) {
+        ATL_REQUIRE(in->d_solar_altitude && in->d_solar_azimuth,
+                    "atl_pv: solar_altitude and solar_azimuth must be given together");
+    } else {
+        ATL_REQUIRE(in->d_sin_dec && in->d_cos_dec && in->d_hour_angle && in->d_cos_hour_angle && in->d_sin_lat &&
+                        in->d_cos_lat,
+                    "atl_pv: need either solar_altitude/solar_azimuth or the solar position tables");
+        ATL_REQUIRE(in->X > 0 && S % in->X == 0, "atl_pv: X (%lld) must divide the number of cells (%lld)",
+                    (long long)in->X, (long long)S);
+    }
     ATL_REQUIRE((p->d_cell_slope == nullptr) == (p->d_cell_azimuth == nullptr),
                 "atl_pv: d_cell_slope and d_cell_azimuth must be given together");
     c->in = *in;
     c->S = S;
     c->k = PvConst{p->c_temp_amb, p->c_temp_irrad, p->r_tmod, 1.0 / p->r_irradiance, p->k_1, p->k_2,
                    p->k_3,        p->k_4,          p->k_5,    p->k_6,                 p->inverter_efficiency,
-                   p->altitude_threshold};
+                   p->altitude_threshold, sin(p->altitude_threshold)};
     c->o.ss = sin(p->slope);
     c->o.cs = cos(p->slope);
     c->o.hp = (1.0 + c->o.cs) / 2.0;
     c->o.hm = (1.0 - c->o.cs) / 2.0;
     c->o.saz = p->azimuth;
+    c->o.csaz = cos(p->azimuth);
+    c->o.ssaz = sin(p->azimuth);
     c->cell_slope = p->d_cell_slope;
     c->cell_azimuth = p->d_cell_azimuth;
     *vec = vec_ok(S, {in->d_influx_direct, in->d_influx_diffuse, in->d_influx_toa, in->d_albedo,
@@ -871,15 +983,23 @@ int make_wind(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p,
     ATL_REQUIRE(p->n_knots >= 1 && p->n_knots <= kMaxKnots && p->h_V && p->h_POWn,
                 "atl_wind: power curve needs 1..%d knots", kMaxKnots);
     const int n = p->n_knots;
-    std::vector<double> tbl(size_t(3 * n));
+    int n_pad = 2;
+    while (n_pad <= n) n_pad *= 2;  // power of two > n: V[n..n_pad) = +inf
+    std::vector<double> tbl(size_t(5 * n_pad), 0.0);
+    bool finite = true;
+    for (int i = 0; i < n_pad; ++i) tbl[i] = std::numeric_limits<double>::infinity();
     for (int i = 0; i < n; ++i) {
-        tbl[i] = p->h_V[i];
-        tbl[n + i] = p->h_POWn[i];
         ATL_REQUIRE(i == 0 || p->h_V[i] >= p->h_V[i - 1],
                     "wind speed 'V' in the turbine config is expected to be increasing");
+        tbl[i] = p->h_V[i];
+        double *k = &tbl[size_t(n_pad) + 4 * size_t(i)];
+        k[0] = p->h_V[i];
+        k[1] = p->h_POWn[i];
+        // slope as numpy precomputes it; only the upper one of repeated knots is ever selected
+        k[2] = (i + 1 < n && p->h_V[i + 1] > p->h_V[i]) ? (p->h_POWn[i + 1] - p->h_POWn[i]) / (p->h_V[i + 1] - p->h_V[i])
+                                                        : 0.0;
+        finite = finite && std::isfinite(k[0]) && std::isfinite(k[1]) && std::isfinite(k[2]);
     }
-    for (int i = 0; i + 1 < n; ++i) tbl[2 * n + i] = (tbl[n + i + 1] - tbl[n + i]) / (tbl[i + 1] - tbl[i]);
-    tbl[3 * n - 1] = 0.0;
     // stream-ordered after any earlier kernel that still reads the table
     ATL_HIP_TRY(hipMemcpyAsync(ctx->d_table, tbl.data(), tbl.size() * sizeof(double), hipMemcpyHostToDevice,
                                ctx->stream));
@@ -893,10 +1013,9 @@ int make_wind(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p,
     c->log_ratio = log(p->to_height / p->from_height);
     c->table = ctx->d_table;
     c->n_knots = n;
-    int st = 1;
-    while (st * 2 < n) st *= 2;
-    c->search_start = n > 1 ? st : 0;
-    *lds_bytes = size_t(3 * n) * sizeof(double);
+    c->n_pad = n_pad;
+    c->table_finite = finite ? 1 : 0;
+    *lds_bytes = size_t(5 * n_pad) * sizeof(double);
     *vec = vec_ok(S, {in->d_wnd, in->aux_is_static ? nullptr : in->d_aux});
     return ATL_OK;
 }
@@ -933,9 +1052,15 @@ int atl_spmm_csr(atl_ctx *ctx, const atl_agg *agg, const double *d_dense, int64_
 
 int atl_pv_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S,
                    int time_agg, double *d_out) {
-    ATL_REQUIRE(ctx, "atl_pv_convert: ctx is NULL");
-    PvConv c;
+    ATL_REQUIRE(ctx && in, "atl_pv_convert: ctx/inputs is NULL");
     bool vec;
+    if (in->d_solar_altitude || in->d_solar_azimuth) {
+        PvConv c;
+        int rc = make_pv(in, p, T, S, &c, &vec);
+        if (rc) return rc;
+        return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
+    }
+    PvConvSP c;
     int rc = make_pv(in, p, T, S, &c, &vec);
     if (rc) return rc;
     return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
@@ -943,9 +1068,15 @@ int atl_pv_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p
 
 int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T,
                              int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out) {
-    ATL_REQUIRE(ctx, "atl_pv_convert_aggregate: ctx is NULL");
-    PvConv c;
+    ATL_REQUIRE(ctx && in, "atl_pv_convert_aggregate: ctx/inputs is NULL");
     bool vec;
+    if (in->d_solar_altitude || in->d_solar_azimuth) {
+        PvConv c;
+        int rc = make_pv(in, p, T, S, &c, &vec);
+        if (rc) return rc;
+        return run_fused(ctx, c, vec, 0, T, S, agg, time_agg, d_out, ld_out, "atl_pv_convert_aggregate");
+    }
+    PvConvSP c;
     int rc = make_pv(in, p, T, S, &c, &vec);
     if (rc) return rc;
     return run_fused(ctx, c, vec, 0, T, S, agg, time_agg, d_out, ld_out, "atl_pv_convert_aggregate");

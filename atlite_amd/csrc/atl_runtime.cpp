@@ -109,7 +109,7 @@ int atl_create(int device, void *stream, atl_ctx **out) {
     (void)hipEventCreate(&c->ev_t1);
     (void)hipEventCreate(&c->ev_k0);
     (void)hipEventCreate(&c->ev_k1);
-    if (hipMalloc(reinterpret_cast<void **>(&c->d_table), 3 * kMaxKnots * sizeof(double)) !=
+    if (hipMalloc(reinterpret_cast<void **>(&c->d_table), 5 * 2 * kMaxKnots * sizeof(double)) !=
         hipSuccess) {
         set_error("atl_create: table allocation failed");
         delete c;

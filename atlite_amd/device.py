@@ -223,23 +223,23 @@ class Context:
         )
         return out
 
-    def pv(self, inputs: dict, params: dict, T, S, plan=None, time_agg=None):
-        """inputs: name -> DeviceArray (T,S) for the 7 ERA5 variables; params: see PvParams."""
+    def pv(self, inputs: dict, params: dict, T, S, plan=None, time_agg=None, solar_tables=None):
+        """
+        inputs: name -> DeviceArray (T,S) for the ERA5 variables (7 with stored solar angles, 5
+        without); params: see PvParams; solar_tables: host arrays ``sin_dec, cos_dec`` (T),
+        ``h, cos_h`` (T,X), ``sin_lat, cos_lat`` (Y) for the in-kernel SolarPosition variant.
+        """
         keep = []
-        pin = _lib.PvInputs(
-            *[
-                inputs[k].ptr
-                for k in (
-                    "influx_direct",
-                    "influx_diffuse",
-                    "influx_toa",
-                    "albedo",
-                    "temperature",
-                    "solar_altitude",
-                    "solar_azimuth",
-                )
-            ]
-        )
+        names = ["influx_direct", "influx_diffuse", "influx_toa", "albedo", "temperature"]
+        ptrs = [inputs[k].ptr for k in names]
+        if solar_tables is None:
+            ptrs += [inputs["solar_altitude"].ptr, inputs["solar_azimuth"].ptr]
+            pin = _lib.PvInputs(*ptrs)
+        else:
+            tabs = [self.asdevice(np.ascontiguousarray(solar_tables[k], dtype=np.float64))
+                    for k in ("sin_dec", "cos_dec", "h", "cos_h", "sin_lat", "cos_lat")]
+            keep += tabs
+            pin = _lib.PvInputs(*ptrs, None, None, *[t.ptr for t in tabs], int(solar_tables["h"].shape[1]))
         pp = _lib.PvParams()
         for k in ("c_temp_amb", "c_temp_irrad", "r_tmod", "r_irradiance", "k_1", "k_2", "k_3", "k_4",
                   "k_5", "k_6"):

@@ -114,8 +114,19 @@ typedef struct {
     const double *d_influx_toa;     /* (T,S) */
     const double *d_albedo;         /* (T,S) */
     const double *d_temperature;    /* (T,S) K */
-    const double *d_solar_altitude; /* (T,S) rad */
-    const double *d_solar_azimuth;  /* (T,S) rad */
+    const double *d_solar_altitude; /* (T,S) rad, or NULL -> computed in the kernel */
+    const double *d_solar_azimuth;  /* (T,S) rad, or NULL                           */
+    /* In-kernel SolarPosition (pv/solar_position.py:71-114) for datasets that do not store
+     * the solar angles: the algorithm is separable, so the caller passes the (T)- and
+     * (T,X)-sized parts (host-computed exactly as the reference writes them) and the kernel
+     * does the cube-sized part.  Used iff d_solar_altitude == NULL. */
+    const double *d_sin_dec;        /* (T)   sin(declination)                  :97     */
+    const double *d_cos_dec;        /* (T)   cos(declination)                          */
+    const double *d_hour_angle;     /* (T,X) h, radians in [-pi, pi)            :95     */
+    const double *d_cos_hour_angle; /* (T,X) cos(h)                                     */
+    const double *d_sin_lat;        /* (Y)   sin(radians(lat))                  :100    */
+    const double *d_cos_lat;        /* (Y)   cos(radians(lat))                          */
+    int64_t X;                      /* cells per grid row (needed for the tables)       */
 } atl_pv_inputs;
 
 typedef struct {

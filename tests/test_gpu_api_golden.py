@@ -242,3 +242,30 @@ def test_config1_wind_tiny_rectangle():
     ref, refcap = orc.gateway(ref_cells, M, per_unit=True)
     close(r.values, ref)
     close(cap.values, refcap)
+
+
+def test_pv_in_kernel_solar_position():
+    """Datasets without stored solar angles: SolarPosition's compute branch
+    (pv/solar_position.py:62-121) runs inside the kernel.  Reference values: the golden
+    altitude/azimuth the reference's SolarPosition produced for this time axis (no shift), fed
+    through the oracle's getter path."""
+    from oracle import atlite_oracle as orc
+    from tests import helpers as H
+
+    p, sp = load("pv"), load("solar_position")
+    names = ("influx_direct", "influx_diffuse", "influx_toa", "albedo", "temperature")
+    c = cutout_from(p, names)
+    ds = {k: p[k] for k in names}
+    ds["solar_altitude"], ds["solar_azimuth"] = sp["altitude_noshift"], sp["azimuth_noshift"]
+    ds["solar_altitude"] = np.where(np.isnan(p["solar_altitude"]), sp["altitude_noshift"], sp["altitude_noshift"])
+    for ospec, ori in (({"slope": 30.0, "azimuth": 180.0}, orc.orientation_constant(30.0, 180.0)),
+                       ({"slope": 25.0, "azimuth": 90.0}, orc.orientation_constant(25.0, 90.0))):
+        ref = orc.convert_pv(ds, H.CSI, ori)
+        with pytest.warns(DeprecationWarning, match="solar position"):
+            r = c.pv(panel="CSi", orientation=ospec, aggregate_time=None)
+        assert ref.max() > 0.3
+        close(r.values, ref)
+        M = H.blob_matrix(4, len(p["y"]), len(p["x"]), seed=2)
+        with pytest.warns(DeprecationWarning):
+            ra = c.pv(panel="CSi", orientation=ospec, matrix=M, aggregate_time=None)
+        close(ra.values, orc.aggregate_matrix(ref.reshape(ref.shape[0], -1), M))
