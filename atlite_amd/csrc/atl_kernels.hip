@@ -165,7 +165,11 @@ struct HeatConv {
 // which returns F[j] exactly on knots, F[0] / F[n-1] outside the range (also for +-inf), NaN
 // for NaN, and takes the upper one of repeated knots - all without a branch.  Tables holding
 // non-finite values take interp_generic(), the literal transcription of arr_interp.
-struct WindConv {
+// METHOD: ATL_WIND_NONE / LOG / POWER fixed at compile time for finite tables (the hot
+// instantiations carry no dead paths); METHOD = -1 is the generic converter: runtime method,
+// any table (interp_generic).
+template <int METHOD>
+struct WindConvT {
     const double *wnd;
     const double *aux;
     int64_t S;
@@ -175,7 +179,6 @@ struct WindConv {
     double log_ratio;      // log(to/from)   (power law)
     const double *table;   // device: V[n_pad] | K[n_pad][4]
     int n_knots, n_pad;
-    int table_finite;
     struct Cell {
         double2 aux;
         double lh, lf;  // lean_log(to_height), lean_log(from_height)
@@ -191,27 +194,35 @@ struct WindConv {
             c.aux.x = v0 ? aux[c0] : 1.0;
             c.aux.y = v1 ? aux[c0 + 1] : 1.0;
         }
-        // through the same lean_log as the per-cell roughness: z0 == from_height gives an exact
-        // zero denominator, like the reference's log(from/z0) = log(1)
-        c.lh = lean_log(to_height);
-        c.lf = lean_log(from_height);
+        // through the same log as the per-cell roughness: z0 == from_height gives an exact zero
+        // denominator, like the reference's log(from/z0) = log(1)
+        c.lh = log_core(to_height);
+        c.lf = log_core(from_height);
         return c;
     }
-    __device__ __forceinline__ double hub_speed(double v, double z, const Cell &c) const {
-        if (method == ATL_WIND_LOG) {
-            // wind.py:99-101: v * (log(to/z0) / log(from/z0)), with log(a/z0) = log a - log z0
-            const double lz = lean_log(z);
-            const double num = c.lh - lz, den = c.lf - lz;
-            double q = fast_div(num, den);
-            const bool tame = __builtin_fabs(den) > 0x1.0p-500 && __builtin_fabs(den) < 0x1.0p500 &&
-                              __builtin_fabs(num) < 0x1.0p500;
-            if (!tame) q = num / den;  // zero / huge / non-finite operands: IEEE division
-            return v * q;
-        } else if (method == ATL_WIND_POWER) {
-            // wind.py:111: v * (to/from) ** shear = v * exp(shear * log(to/from))
-            return v * exp(z * log_ratio);
-        }
+    // wind.py:99-101 / :111, literally; used for the rare arguments the fast path excludes
+    __device__ __noinline__ double hub_speed_literal(double v, double z) const {
+        if (method == ATL_WIND_LOG) return v * (log(to_height / z) / log(from_height / z));
+        if (method == ATL_WIND_POWER) return v * pow(to_height / from_height, z);
         return v;
+    }
+    // fast path: *rare is set when the literal formula must be used instead
+    __device__ __forceinline__ double hub_speed_fast(double v, double z, const Cell &c, bool *rare) const {
+        if constexpr (METHOD == ATL_WIND_LOG) {
+            // v * (log(to/z0) / log(from/z0)) with log(a/z0) = log a - log z0: one log per cell
+            const bool zok = z >= 0x1.0p-1022 && z < __builtin_inf();
+            const double lz = log_core(zok ? z : 1.0);
+            const double num = c.lh - lz, den = c.lf - lz;
+            const bool tame = __builtin_fabs(den) > 0x1.0p-40;  // |num|, |den| < 1500 always
+            *rare = !(zok && tame);
+            return v * fast_div(num, den);
+        } else if constexpr (METHOD == ATL_WIND_POWER) {
+            *rare = false;
+            return v * exp(z * log_ratio);  // v * (to/from) ** shear
+        } else {
+            *rare = false;
+            return v;
+        }
     }
     __device__ __forceinline__ double interp(double x, const double *lds) const {
         const double *V = lds;
@@ -229,7 +240,7 @@ struct WindConv {
         return __builtin_fma(sl, xc - k0.x, k0.y);
     }
     // literal numpy/_core/src/multiarray/compiled_base.c arr_interp (any table)
-    __device__ double interp_generic(double x, const double *lds) const {
+    __device__ __noinline__ double interp_generic(double x, const double *lds) const {
         const double *V = lds;
         const double *K = lds + n_pad;
         const int n = n_knots;
@@ -257,15 +268,20 @@ struct WindConv {
                                             const double *lds) const {
         double2 v = ld2<VEC>(wnd, slot * S + c0, v0, v1);
         double2 z = c.aux;
-        if (method != ATL_WIND_NONE && !aux_static) z = ld2<VEC>(aux, slot * S + c0, v0, v1);
-        const double h0 = hub_speed(v.x, z.x, c), h1 = hub_speed(v.y, z.y, c);
+        if (METHOD != ATL_WIND_NONE && !aux_static) z = ld2<VEC>(aux, slot * S + c0, v0, v1);
         double2 r;
-        if (table_finite) {
+        if constexpr (METHOD < 0) {
+            r.x = interp_generic(hub_speed_literal(v.x, z.x), lds);
+            r.y = interp_generic(hub_speed_literal(v.y, z.y), lds);
+        } else {
+            bool r0, r1;
+            double h0 = hub_speed_fast(v.x, z.x, c, &r0), h1 = hub_speed_fast(v.y, z.y, c, &r1);
+            if ((r0 && v0) || (r1 && v1)) {  // degenerate roughness: literal formula, out of line
+                h0 = hub_speed_literal(v.x, z.x);
+                h1 = hub_speed_literal(v.y, z.y);
+            }
             r.x = interp(h0, lds);
             r.y = interp(h1, lds);
-        } else {
-            r.x = interp_generic(h0, lds);
-            r.y = interp_generic(h1, lds);
         }
         r.x = v0 ? r.x : 0.0;
         r.y = v1 ? r.y : 0.0;
@@ -427,7 +443,7 @@ using PvConvSP = PvConvT<true>;
 // kernel 1: per-cell series  out[slot, cell]
 // grid.x over 512-cell blocks, grid.y over slot chunks of kSeriesSlots
 // ---------------------------------------------------------------------------------------
-constexpr int kSeriesSlots = 8;
+constexpr int kSeriesSlots = 32;
 
 template <class Conv, bool VEC>
 __global__ __launch_bounds__(256) void k_cells_series(Conv conv, int64_t n_slots, int64_t S,
@@ -972,7 +988,7 @@ int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t 
 }
 
 int make_wind(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p, int64_t T, int64_t S,
-              WindConv *c, bool *vec, size_t *lds_bytes) {
+              WindConvT<-1> *c, bool *vec, size_t *lds_bytes, bool *table_finite) {
     ATL_REQUIRE(in && p, "atl_wind: inputs/params is NULL");
     ATL_REQUIRE(T >= 0 && S >= 0, "atl_wind: negative shape");
     ATL_REQUIRE(in->d_wnd, "atl_wind: wind speed is NULL");
@@ -1014,7 +1030,7 @@ int make_wind(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p,
     c->table = ctx->d_table;
     c->n_knots = n;
     c->n_pad = n_pad;
-    c->table_finite = finite ? 1 : 0;
+    *table_finite = finite;
     *lds_bytes = size_t(5 * n_pad) * sizeof(double);
     *vec = vec_ok(S, {in->d_wnd, in->aux_is_static ? nullptr : in->d_aux});
     return ATL_OK;
@@ -1033,6 +1049,37 @@ int make_heat(const double *d_temperature, const atl_heat_params *p, int64_t T, 
     c->constant = p->constant;
     *vec = vec_ok(S, {d_temperature});
     return ATL_OK;
+}
+
+template <int M>
+WindConvT<M> wind_as(const WindConvT<-1> &g) {
+    WindConvT<M> c;
+    c.wnd = g.wnd;
+    c.aux = g.aux;
+    c.S = g.S;
+    c.aux_static = g.aux_static;
+    c.method = g.method;
+    c.to_height = g.to_height;
+    c.from_height = g.from_height;
+    c.log_ratio = g.log_ratio;
+    c.table = g.table;
+    c.n_knots = g.n_knots;
+    c.n_pad = g.n_pad;
+    return c;
+}
+
+// run `f(converter)` with the instantiation matching (method, table finiteness)
+template <class F>
+int wind_dispatch(const WindConvT<-1> &g, bool finite, F &&f) {
+    // the fast log-law path also needs positive, finite heights (their logs are taken once)
+    const bool heights_ok = g.to_height > 0 && g.from_height > 0 && std::isfinite(g.to_height) &&
+                            std::isfinite(g.from_height);
+    if (!finite || (g.method == ATL_WIND_LOG && !heights_ok)) return f(g);
+    switch (g.method) {
+        case ATL_WIND_LOG: return f(wind_as<ATL_WIND_LOG>(g));
+        case ATL_WIND_POWER: return f(wind_as<ATL_WIND_POWER>(g));
+        default: return f(wind_as<ATL_WIND_NONE>(g));
+    }
 }
 
 }  // namespace
@@ -1085,24 +1132,28 @@ int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv
 int atl_wind_convert(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p, int64_t T,
                      int64_t S, int time_agg, double *d_out) {
     ATL_REQUIRE(ctx, "atl_wind_convert: ctx is NULL");
-    WindConv c;
-    bool vec;
+    WindConvT<-1> g;
+    bool vec, finite;
     size_t lds;
-    int rc = make_wind(ctx, in, p, T, S, &c, &vec, &lds);
+    int rc = make_wind(ctx, in, p, T, S, &g, &vec, &lds, &finite);
     if (rc) return rc;
-    return run_cells(ctx, c, vec, lds, T, S, time_agg, d_out, "atl_wind_convert");
+    return wind_dispatch(g, finite, [&](const auto &c) {
+        return run_cells(ctx, c, vec, lds, T, S, time_agg, d_out, "atl_wind_convert");
+    });
 }
 
 int atl_wind_convert_aggregate(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p,
                                int64_t T, int64_t S, const atl_agg *agg, int time_agg, double *d_out,
                                int64_t ld_out) {
     ATL_REQUIRE(ctx, "atl_wind_convert_aggregate: ctx is NULL");
-    WindConv c;
-    bool vec;
+    WindConvT<-1> g;
+    bool vec, finite;
     size_t lds;
-    int rc = make_wind(ctx, in, p, T, S, &c, &vec, &lds);
+    int rc = make_wind(ctx, in, p, T, S, &g, &vec, &lds, &finite);
     if (rc) return rc;
-    return run_fused(ctx, c, vec, lds, T, S, agg, time_agg, d_out, ld_out, "atl_wind_convert_aggregate");
+    return wind_dispatch(g, finite, [&](const auto &c) {
+        return run_fused(ctx, c, vec, lds, T, S, agg, time_agg, d_out, ld_out, "atl_wind_convert_aggregate");
+    });
 }
 
 int atl_heat_demand_convert(atl_ctx *ctx, const double *d_temperature, const atl_heat_params *p, int64_t T,

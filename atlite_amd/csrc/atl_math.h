@@ -98,13 +98,15 @@ __device__ __forceinline__ double lean_sin(double x) {
     return __builtin_fabs(x) < 0x1.0p30 ? ss : __builtin_nan("");
 }
 
-__device__ __forceinline__ double lean_log(double x) {
-    // x = 2^e * m, m in [sqrt(1/2), sqrt(2))
-    double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1), handles subnormals
-    int e = __builtin_amdgcn_frexp_exp(x);
-    const bool lo = m < 7.07106781186547524401e-01;
-    m = lo ? m + m : m;
-    e = lo ? e - 1 : e;
+// log of a positive, normal, finite double: no special cases, integer exponent split
+__device__ __forceinline__ double log_core(double x) {
+    // x = 2^e * m, m in [sqrt(1/2), sqrt(2)): shift the mantissa window by sqrt(2)/2 like fdlibm
+    unsigned hi = unsigned(__double2hiint(x));
+    const unsigned lo = unsigned(__double2loint(x));
+    hi += 0x3ff00000u - 0x3fe6a09eu;
+    const int e = int(hi >> 20) - 0x3ff;
+    hi = (hi & 0x000fffffu) + 0x3fe6a09eu;
+    const double m = __hiloint2double(int(hi), int(lo));
     const double f = m - 1.0;
     const double s = f * fast_rcp(2.0 + f);
     const double z = s * s, w = z * z;
@@ -116,14 +118,19 @@ __device__ __forceinline__ double lean_log(double x) {
     const double R = t1 + t2;
     const double hfsq = 0.5 * f * f;
     const double dk = double(e);
-    double r = dk * 6.93147180369123816490e-01 -
-               ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
-    // specials
-    r = (x == 0.0) ? -__builtin_inf() : r;
-    r = (x < 0.0) ? __builtin_nan("") : r;
-    r = (x == __builtin_inf()) ? x : r;
-    r = (x != x) ? x : r;
-    return r;
+    return dk * 6.93147180369123816490e-01 -
+           ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+
+__device__ __forceinline__ double lean_log(double x) {
+    // ordinary arguments take log_core; zero, subnormal, negative, inf and NaN take the (rare,
+    // exec-masked) slow path
+    if (x >= 0x1.0p-1022 && x < __builtin_inf()) return log_core(x);
+    if (x != x) return x;
+    if (x < 0.0) return __builtin_nan("");
+    if (x == 0.0) return -__builtin_inf();
+    if (x == __builtin_inf()) return x;
+    return log_core(x * 0x1.0p54) - 54.0 * 6.93147180559945286227e-01;  // subnormal
 }
 
 }  // namespace atl
