@@ -42,7 +42,7 @@ class PvInputs(C.Structure):
             "d_sin_lat",
             "d_cos_lat",
         )
-    ] + [("X", C.c_int64)]
+    ] + [("X", C.c_int64)] + [(n, C.c_void_p) for n in ("d_influx", "d_outflux", "d_humidity")]
 
 
 class PvParams(C.Structure):
@@ -63,7 +63,20 @@ class PvParams(C.Structure):
         ("d_cell_slope", C.c_void_p),
         ("d_cell_azimuth", C.c_void_p),
         ("altitude_threshold", C.c_double),
-    ]
+        ("tracking", C.c_int),
+        ("trigon_model", C.c_int),
+        ("clearsky_model", C.c_int),
+        ("irradiation", C.c_int),
+        ("panel_model", C.c_int),
+    ] + [(n, C.c_double) for n in ("bof_A", "bof_B", "bof_C", "bof_D", "bof_NOCT", "bof_Tstd", "bof_Tamb", "bof_Intc",
+                                   "bof_ta", "bof_threshold", "st_c0", "st_c1", "st_t_store_K")]
+
+
+TRACKING = {None: 0, "horizontal": 1, "tilted_horizontal": 2, "vertical": 3, "dual": 4}
+TRIGON = {"simple": 0, "other": 1}
+CLEARSKY = {"simple": 0, "enhanced": 1}
+IRRADIATION = {"total": 0, "direct": 1, "diffuse": 2, "ground": 3}
+PANEL = {"huld": 0, "bofinger": 1, "none": 2, "solar_thermal": 3}
 
 
 class WindInputs(C.Structure):

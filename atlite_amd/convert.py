@@ -60,39 +60,52 @@ def _need(ds, names, exc, msg):
 
 
 class _PvSpec(_Spec):
+    """convert_pv / convert_irradiation / convert_solar_thermal: one kernel family."""
+
     name = "specific generation"
     attrs = {"units": "kWh/kWp"}
 
-    def __init__(self, ds, panel, orientation, tracking, trigon_model="simple", clearsky_model="simple"):
-        if tracking is not None:
-            if tracking not in ("horizontal", "tilted_horizontal", "vertical", "dual"):
-                raise AssertionError(
-                    "Values describing tracking system must be None for no tracking,"
-                    + "'horizontal' for 1-axis horizontal tracking,"
-                    + "tilted_horizontal' for 1-axis horizontal tracking of tilted panle,"
-                    + "vertical' for 1-axis vertical tracking, or 'dual' for 2-axis tracking"
-                )
-            raise NotImplementedError(f"tracking={tracking!r} is not implemented on the GPU path yet")
-        if trigon_model != "simple":
-            raise NotImplementedError("only trigon_model='simple' is implemented on the GPU path")
-        if "influx" in ds:
-            if clearsky_model not in (None, "simple", "enhanced"):
+    def __init__(self, ds, panel, orientation, tracking, trigon_model="simple", clearsky_model="simple",
+                 irradiation="total", panel_model=None, thermal=None):
+        if tracking not in (None, "horizontal", "tilted_horizontal", "vertical", "dual"):
+            raise AssertionError(
+                "Values describing tracking system must be None for no tracking,"
+                + "'horizontal' for 1-axis horizontal tracking,"
+                + "tilted_horizontal' for 1-axis horizontal tracking of tilted panle,"
+                + "vertical' for 1-axis vertical tracking, or 'dual' for 2-axis tracking"
+            )
+        if irradiation not in ("total", "direct", "diffuse", "ground"):
+            raise ValueError(f"irradiation must be 'total', 'direct', 'diffuse' or 'ground', not {irradiation!r}")
+        self.options = dict(tracking=tracking, trigon_model="simple" if trigon_model == "simple" else "other",
+                            irradiation=irradiation)
+        self.vars = ["influx_toa"]
+        if "influx" in ds:  # irradiation.py:202-205: Reindl split of the total influx
+            if clearsky_model is None:
+                clearsky_model = "enhanced" if ("temperature" in ds and "humidity" in ds) else "simple"
+            if clearsky_model not in ("simple", "enhanced"):
                 raise KeyError("`clearsky model` must be chosen from 'simple' and 'enhanced'")
-            raise NotImplementedError("datasets with total 'influx' only (Reindl split) are not implemented yet")
-        if not ("influx_direct" in ds and "influx_diffuse" in ds):
+            self.options["clearsky_model"] = clearsky_model
+            self.vars += ["influx"] + (["humidity"] if clearsky_model == "enhanced" else [])
+        elif "influx_direct" in ds and "influx_diffuse" in ds:
+            self.vars += ["influx_direct", "influx_diffuse"]
+        else:
             raise AssertionError(
                 "Need either influx or influx_direct and influx_diffuse in the "
                 "dataset. Check your cutout and dataset module."
             )
-        if "albedo" not in ds:
-            if "outflux" in ds:
-                raise NotImplementedError("albedo from outflux/influx is not implemented on the GPU path yet")
+        if "albedo" in ds:
+            self.vars.append("albedo")
+        elif "outflux" in ds:
+            self.vars.append("outflux")
+        else:
             raise AssertionError(
                 "Need either albedo or outflux as a variable in the dataset. "
                 "Check your cutout and dataset module."
             )
         self.solar_tables = None
-        if not ("solar_altitude" in ds and "solar_azimuth" in ds):
+        if "solar_altitude" in ds and "solar_azimuth" in ds:
+            self.vars += ["solar_altitude", "solar_azimuth"]
+        else:
             # SolarPosition(ds) compute branch (pv/solar_position.py:62-121, no time shift): the (T)-
             # and (T,X)-sized parts on the host, the cube-sized part inside the kernel
             warnings.warn(
@@ -107,10 +120,24 @@ class _PvSpec(_Spec):
             lat = np.radians(ds.coords["lat"])
             self.solar_tables = dict(sin_dec=np.sin(dec), cos_dec=np.cos(dec), h=h, cos_h=np.cos(h),
                                      sin_lat=np.sin(lat), cos_lat=np.cos(lat))
-        model = panel.get("model", "huld")
-        if model != "huld":
-            raise NotImplementedError(f"panel model {model!r} is not implemented on the GPU path yet")
-        self.panel = panel
+        self.panel = dict(panel or {})
+        if panel_model is None:
+            panel_model = self.panel.get("model", "huld")
+            if panel_model not in ("huld", "bofinger"):
+                raise AssertionError(f"Unknown panel model: {panel_model}")
+        self.options["panel_model"] = panel_model
+        if thermal:
+            self.options.update(thermal)
+        if panel_model != "none" or self.options.get("clearsky_model") == "enhanced":
+            _need(ds, ["temperature"], KeyError, "temperature")
+            self.vars.append("temperature")
+        if panel_model == "none":
+            self.name = f"{irradiation} tilted"
+            self.attrs = {"units": "W m**-2"}
+        elif panel_model == "bofinger":
+            self.name, self.attrs = "AC power", {}
+        elif panel_model == "solar_thermal":
+            self.name, self.attrs = None, {}
         # orientation callback evaluated on the host with radian lon / lat (orientation.py:104-107)
         x, y = ds.coords["x"], ds.coords["y"]
         lon = LabeledArray(np.radians(ds.coords["lon"]), ("x",), {"x": x}, name="lon")
@@ -139,16 +166,26 @@ class _PvSpec(_Spec):
 
     def run(self, ctx, ds, plan, time_agg):
         T, S = len(ds.coords["time"]), len(ds.coords["y"]) * len(ds.coords["x"])
-        names = ("influx_direct", "influx_diffuse", "influx_toa", "albedo", "temperature")
-        if self.solar_tables is None:
-            names += ("solar_altitude", "solar_azimuth")
-        inputs = {n: ds.device(ctx, n) for n in names}
+        inputs = {n: ds.device(ctx, n) for n in dict.fromkeys(self.vars)}
         slope, azimuth = self.slope, self.azimuth
         if np.ndim(slope) != np.ndim(azimuth):  # mixed scalar / per-cell -> per-cell
             slope = np.broadcast_to(slope, (S,))
             azimuth = np.broadcast_to(azimuth, (S,))
         params = dict(self.panel, slope=slope, azimuth=azimuth)
-        return ctx.pv(inputs, params, T, S, plan=plan, time_agg=time_agg, solar_tables=self.solar_tables)
+        return ctx.pv(inputs, params, T, S, plan=plan, time_agg=time_agg, solar_tables=self.solar_tables,
+                      options=self.options)
+
+
+class _IrradiationSpec(_PvSpec):
+    def __init__(self, ds, orientation, tracking=None, irradiation="total", trigon_model="simple",
+                 clearsky_model="simple"):
+        super().__init__(ds, None, orientation, tracking, trigon_model, clearsky_model, irradiation, panel_model="none")
+
+
+class _SolarThermalSpec(_PvSpec):
+    def __init__(self, ds, orientation, trigon_model, clearsky_model, c0, c1, t_store):
+        super().__init__(ds, None, orientation, None, trigon_model, clearsky_model, "total", panel_model="solar_thermal",
+                         thermal=dict(c0=c0, c1=c1, t_store_K=t_store + 273.15))  # convert.py:554
 
 
 class _WindSpec(_Spec):
@@ -256,6 +293,17 @@ def convert_pv(ds, panel, orientation, tracking, trigon_model="simple", clearsky
     return _per_cell(_PvSpec(ds, panel, orientation, tracking, trigon_model, clearsky_model), ds)
 
 
+def convert_irradiation(ds, orientation, tracking=None, irradiation="total", trigon_model="simple",
+                        clearsky_model="simple"):
+    """convert.py:748-767; irradiation on the tilted surface (W m**-2)."""
+    return _per_cell(_IrradiationSpec(ds, orientation, tracking, irradiation, trigon_model, clearsky_model), ds)
+
+
+def convert_solar_thermal(ds, orientation, trigon_model, clearsky_model, c0, c1, t_store):
+    """convert.py:550-574; solar thermal collector output."""
+    return _per_cell(_SolarThermalSpec(ds, orientation, trigon_model, clearsky_model, c0, c1, t_store), ds)
+
+
 def convert_wind(ds, turbine, interpolation_method):
     """convert.py:634-662; per-cell 'specific generation' (MWh/MWp)."""
     return _per_cell(_WindSpec(ds, turbine, interpolation_method), ds)
@@ -272,7 +320,8 @@ def convert_runoff(ds, weight_with_height=True):
 
 
 _KNOWN = {convert_pv: _PvSpec, convert_wind: _WindSpec, convert_heat_demand: _HeatSpec,
-          convert_runoff: _RunoffSpec}
+          convert_runoff: _RunoffSpec, convert_irradiation: _IrradiationSpec,
+          convert_solar_thermal: _SolarThermalSpec}
 
 
 class _CubeSpec(_Spec):
@@ -538,6 +587,37 @@ def pv(cutout, panel, orientation, tracking=None, clearsky_model=None, **params)
         orientation=orientation,
         tracking=tracking,
         clearsky_model=clearsky_model,
+        **params,
+    )
+
+
+def irradiation(cutout, orientation, irradiation="total", tracking=None, clearsky_model=None, **params):
+    """Total / direct / diffuse / ground irradiation on a tilted surface (convert.py:770-836)."""
+    if not callable(orientation):
+        orientation = get_orientation(orientation)
+    return cutout.convert_and_aggregate(
+        convert_func=convert_irradiation,
+        orientation=orientation,
+        tracking=tracking,
+        irradiation=irradiation,
+        clearsky_model=clearsky_model,
+        **params,
+    )
+
+
+def solar_thermal(cutout, orientation={"slope": 45.0, "azimuth": 180.0}, trigon_model="simple",
+                  clearsky_model="simple", c0=0.8, c1=3.0, t_store=80.0, **params):
+    """Solar thermal collector time series (convert.py:577-631)."""
+    if not callable(orientation):
+        orientation = get_orientation(orientation)
+    return cutout.convert_and_aggregate(
+        convert_func=convert_solar_thermal,
+        orientation=orientation,
+        trigon_model=trigon_model,
+        clearsky_model=clearsky_model,
+        c0=c0,
+        c1=c1,
+        t_store=t_store,
         **params,
     )
 

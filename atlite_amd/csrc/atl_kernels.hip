@@ -440,6 +440,208 @@ using PvConv = PvConvT<false>;
 using PvConvSP = PvConvT<true>;
 
 // ---------------------------------------------------------------------------------------
+// general pv converter: every option of convert_pv / convert_irradiation / convert_solar_thermal
+// (tracking modes, Hay-Davies, Reindl split, albedo from outflux, bofinger, irradiation
+// quantities).  A literal transcription of the reference with full-precision libm - selected
+// only when an option differs from the defaults the fast PvConvT path covers.
+// ---------------------------------------------------------------------------------------
+struct PvxOpt {
+    int tracking, trigon, clearsky, irradiation, panel, has_influx, has_albedo;
+    double bA, bB, bC, bD, bNOCT, bTstd, bTamb, bIntc, bta, bthr;
+    double c0, c1, t_store;
+    double r_irr;  // Huld division kept literal here
+};
+
+__device__ double pvx_cell(double dir, double dif, double infl, double toa, double albv, double outf, double tmp,
+                           double rh, double alt, double az, double slope, double sazim, const PvConst &k,
+                           const PvxOpt &o) {
+    const double pi = 3.14159265358979323846;
+    const double nan = __builtin_nan("");
+    const double sa = sin(alt), ca = cos(alt);
+    // ---- SurfaceOrientation (orientation.py:113-188) ---------------------------------------
+    double surface_slope = slope, cosinc;
+    if (o.tracking == ATL_TRACK_NONE) {
+        cosinc = sin(slope) * ca * cos(sazim - az) + cos(slope) * sa;
+    } else if (o.tracking == ATL_TRACK_HORIZONTAL) {
+        const double rotation = atan((ca / sa) * sin(az - sazim));
+        surface_slope = fabs(rotation);
+        const double surface_azimuth = sazim + asin(sin(rotation) / sin(surface_slope));
+        cosinc = cos(surface_slope) * sa + sin(surface_slope) * ca * cos(az - surface_azimuth);
+    } else if (o.tracking == ATL_TRACK_TILTED_HORIZONTAL) {
+        const double tilt = slope;
+        double rotation = atan((ca * sin(az - sazim)) / (ca * cos(az - sazim) * sin(tilt) + sa * cos(tilt)));
+        surface_slope = acos(cos(rotation) * cos(tilt));
+        double ad = az - sazim;
+        ad = ad > pi ? ad - 2 * pi : ad;
+        ad = ad < -pi ? 2 * pi + ad : ad;
+        rotation = (rotation < 0 && ad > 0) ? rotation + pi : rotation;
+        rotation = (rotation > 0 && ad < 0) ? rotation - pi : rotation;
+        cosinc = cos(rotation) * (sin(tilt) * ca * cos(az - sazim) + cos(tilt) * sa) + sin(rotation) * ca * sin(az - sazim);
+    } else if (o.tracking == ATL_TRACK_VERTICAL) {
+        cosinc = sin(slope) * ca + cos(slope) * sa;
+    } else {
+        cosinc = 1.0;
+    }
+    cosinc = np_max(cosinc, 0.0);
+    // ---- direct / diffuse horizontal (irradiation.py:202-208, 13-73) ------------------------
+    double direct, diffuse;
+    if (o.has_influx) {
+        const double influx = np_clip(infl, 0.0, toa);
+        const double kk = influx / toa;
+        double fraction;
+        const double m1 = (kk > 0.0 && kk <= 0.3) ? 1.0 : 0.0, m2 = (kk > 0.3 && kk < 0.78) ? 1.0 : 0.0,
+                     m3 = (kk >= 0.78) ? 1.0 : 0.0;
+        if (o.clearsky == ATL_CLEARSKY_SIMPLE) {
+            fraction = m1 * fmin(1.0, 1.020 - 0.254 * kk + 0.0123 * sa) +
+                       m2 * fmin(0.97, fmax(0.1, 1.400 - 1.749 * kk + 0.177 * sa)) +
+                       m3 * fmax(0.1, 0.486 * kk - 0.182 * sa);
+        } else {
+            fraction = m1 * fmin(1.0, 1.000 - 0.232 * kk + 0.0239 * sa - 0.000682 * tmp + 0.0195 * rh) +
+                       m2 * fmin(0.97, fmax(0.1, 1.329 - 1.716 * kk + 0.267 * sa - 0.00357 * tmp + 0.106 * rh)) +
+                       m3 * fmax(0.1, 0.426 * kk - 0.256 * sa + 0.00349 * tmp + 0.0734 * rh);
+        }
+        diffuse = influx * fraction;
+        direct = influx - diffuse;
+    } else {
+        direct = np_clip(dir, 0.0, toa);
+        diffuse = np_clip(dif, 0.0, toa - direct);
+    }
+    const double influx = direct + diffuse;
+    // ---- albedo (irradiation.py:128-139) ---------------------------------------------------------
+    double alb = albv;
+    if (!o.has_albedo) {
+        alb = fill0(outf / (influx != 0.0 ? influx : nan));
+        alb = np_min(alb, 1.0);
+    }
+    // ---- tilted irradiation ---------------------------------------------------------------------
+    double direct_t, diffuse_t, ground_t, total_t;
+    if (o.trigon == ATL_TRIGON_SIMPLE) {
+        const double kk = cosinc / sa;
+        const double cs = (o.tracking != ATL_TRACK_DUAL) ? cos(surface_slope) : sa;
+        direct_t = kk * direct;
+        diffuse_t = (1.0 + cs) / 2.0 * diffuse;
+        ground_t = alb * influx * ((1.0 - cs) / 2.0);
+        total_t = fill0(direct_t) + fill0(diffuse_t) + fill0(ground_t);
+    } else {
+        const double f = fill0(sqrt(direct / influx));
+        const double A = direct / toa;
+        const double R_b = cosinc / sa;
+        const double sh = sin(surface_slope / 2.0);
+        diffuse_t = ((1.0 - A) * ((1 + cos(surface_slope)) / 2.0) * (1.0 + f * (sh * sh * sh)) + A * R_b) * diffuse;
+        diffuse_t = fill0(np_max(diffuse_t, 0.0));
+        direct_t = R_b * direct;
+        ground_t = influx * alb * (1.0 - cos(surface_slope)) / 2.0;
+        total_t = direct_t + diffuse_t + ground_t;
+    }
+    double G = o.irradiation == ATL_IRR_TOTAL    ? total_t
+               : o.irradiation == ATL_IRR_DIRECT ? direct_t
+               : o.irradiation == ATL_IRR_DIFFUSE ? diffuse_t
+                                                  : ground_t;
+    if ((alt < k.alt_thr) || (influx <= 0.01)) G = 0.0;  // :251-252
+    // ---- panel ------------------------------------------------------------------------------------
+    if (o.panel == ATL_PANEL_NONE) return G;
+    if (o.panel == ATL_PANEL_HULD) {
+        const double T_ = (k.c_amb * tmp + k.c_irr * G) - k.r_tmod;
+        const double G_ = G / o.r_irr;
+        const double l = log(G_ > 0.0 ? G_ : nan);
+        double eff = 1.0 + k.k1 * l + k.k2 * (l * l) + T_ * (k.k3 + k.k4 * l + k.k5 * (l * l)) + k.k6 * (T_ * T_);
+        eff = fill0(eff);
+        eff = eff < 0.0 ? 0.0 : eff;
+        return G_ * eff * k.inv_eff;
+    }
+    if (o.panel == ATL_PANEL_BOFINGER) {
+        const double fraction = (o.bNOCT - o.bTamb) / o.bIntc;
+        const double eta_ref = o.bA + o.bB * G + o.bC * log(G != 0.0 ? G : nan);
+        const double eta = fill0(eta_ref * (1.0 + o.bD * (fraction * G + (tmp - o.bTstd))) /
+                                 (1.0 + o.bD * fraction / o.bta * eta_ref * G));
+        const double capacity = (o.bA + o.bB * 1000.0 + o.bC * log(1000.0)) * 1e3;
+        const double power = G * eta * (k.inv_eff / capacity);
+        return (G >= o.bthr) ? power : 0.0;
+    }
+    // solar thermal (convert.py:565-574)
+    const double eta = o.c0 - o.c1 * fill0((o.t_store - tmp) / (G != 0.0 ? G : nan));
+    const double output = G * eta;
+    return output > 0.0 ? output : 0.0;
+}
+
+struct PvxConv {
+    atl_pv_inputs in;
+    int64_t S;
+    PvConst k;
+    PvxOpt o;
+    double slope, azimuth;       // scalar orientation (radians)
+    const double *cell_slope;    // (S) or nullptr
+    const double *cell_azimuth;  // (S)
+    struct Cell {
+        double sl0, sl1, az0, az1;   // panel slope / azimuth of the two cells
+        double slat0, clat0, slat1, clat1;
+        int x0, x1;
+    };
+    __device__ void block_init(double *) const {}
+    __device__ Cell cell_setup(int64_t c0, bool v0, bool v1) const {
+        Cell c;
+        c.sl0 = c.sl1 = slope;
+        c.az0 = c.az1 = azimuth;
+        if (cell_slope) {
+            c.sl0 = v0 ? cell_slope[c0] : 0.0;
+            c.sl1 = v1 ? cell_slope[c0 + 1] : 0.0;
+            c.az0 = v0 ? cell_azimuth[c0] : 0.0;
+            c.az1 = v1 ? cell_azimuth[c0 + 1] : 0.0;
+        }
+        c.slat0 = c.clat0 = c.slat1 = c.clat1 = 0.0;
+        c.x0 = c.x1 = 0;
+        if (!in.d_solar_altitude) {
+            const int64_t a = v0 ? c0 : 0, b = v1 ? c0 + 1 : 0;
+            const int64_t y0 = a / in.X, y1 = b / in.X;
+            c.x0 = int(a - y0 * in.X);
+            c.x1 = int(b - y1 * in.X);
+            c.slat0 = in.d_sin_lat[y0];
+            c.clat0 = in.d_cos_lat[y0];
+            c.slat1 = in.d_sin_lat[y1];
+            c.clat1 = in.d_cos_lat[y1];
+        }
+        return c;
+    }
+    // pv/solar_position.py:100-114, literally
+    __device__ static void solar(double sd, double cd, double sl, double cl, double h, double ch, double *alt,
+                                 double *az) {
+        const double a = asin(np_clip(sd * sl + cd * cl * ch, -1.0, 1.0));
+        double z = acos(np_clip((sd * cl - cd * sl * ch) / cos(a), -1.0, 1.0));
+        z = (h <= 0.0) ? z : 2.0 * 3.14159265358979323846 - z;
+        *alt = a;
+        *az = z;
+    }
+    template <bool VEC>
+    __device__ __forceinline__ double2 eval(int64_t slot, int64_t c0, bool v0, bool v1, const Cell &c,
+                                            const double *) const {
+        const int64_t off = slot * S + c0;
+        const double2 zero = {0.0, 0.0};
+        const double2 dir = in.d_influx_direct ? ld2<VEC>(in.d_influx_direct, off, v0, v1) : zero;
+        const double2 dif = in.d_influx_diffuse ? ld2<VEC>(in.d_influx_diffuse, off, v0, v1) : zero;
+        const double2 inf = in.d_influx ? ld2<VEC>(in.d_influx, off, v0, v1) : zero;
+        const double2 toa = ld2<VEC>(in.d_influx_toa, off, v0, v1);
+        const double2 alb = in.d_albedo ? ld2<VEC>(in.d_albedo, off, v0, v1) : zero;
+        const double2 ouf = in.d_outflux ? ld2<VEC>(in.d_outflux, off, v0, v1) : zero;
+        const double2 tmp = in.d_temperature ? ld2<VEC>(in.d_temperature, off, v0, v1) : zero;
+        const double2 hum = in.d_humidity ? ld2<VEC>(in.d_humidity, off, v0, v1) : zero;
+        double2 alt, az;
+        if (in.d_solar_altitude) {
+            alt = ld2<VEC>(in.d_solar_altitude, off, v0, v1);
+            az = ld2<VEC>(in.d_solar_azimuth, off, v0, v1);
+        } else {
+            const double sd = in.d_sin_dec[slot], cd = in.d_cos_dec[slot];
+            const int64_t hb = slot * in.X;
+            solar(sd, cd, c.slat0, c.clat0, in.d_hour_angle[hb + c.x0], in.d_cos_hour_angle[hb + c.x0], &alt.x, &az.x);
+            solar(sd, cd, c.slat1, c.clat1, in.d_hour_angle[hb + c.x1], in.d_cos_hour_angle[hb + c.x1], &alt.y, &az.y);
+        }
+        double2 r;
+        r.x = v0 ? pvx_cell(dir.x, dif.x, inf.x, toa.x, alb.x, ouf.x, tmp.x, hum.x, alt.x, az.x, c.sl0, c.az0, k, o) : 0.0;
+        r.y = v1 ? pvx_cell(dir.y, dif.y, inf.y, toa.y, alb.y, ouf.y, tmp.y, hum.y, alt.y, az.y, c.sl1, c.az1, k, o) : 0.0;
+        return r;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
 // kernel 1: per-cell series  out[slot, cell]
 // grid.x over 512-cell blocks, grid.y over slot chunks of kSeriesSlots
 // ---------------------------------------------------------------------------------------
@@ -987,6 +1189,66 @@ int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t 
     return ATL_OK;
 }
 
+bool pv_needs_general(const atl_pv_inputs *in, const atl_pv_params *p) {
+    return p->tracking != ATL_TRACK_NONE || p->trigon_model != ATL_TRIGON_SIMPLE || p->irradiation != ATL_IRR_TOTAL ||
+           p->panel_model != ATL_PANEL_HULD || in->d_influx != nullptr || in->d_albedo == nullptr;
+}
+
+int make_pvx(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S, PvxConv *c, bool *vec) {
+    ATL_REQUIRE(in && p, "atl_pv: inputs/params is NULL");
+    ATL_REQUIRE(T >= 0 && S >= 0, "atl_pv: negative shape");
+    ATL_REQUIRE(p->tracking >= ATL_TRACK_NONE && p->tracking <= ATL_TRACK_DUAL, "atl_pv: bad tracking code %d",
+                p->tracking);
+    ATL_REQUIRE(p->trigon_model == ATL_TRIGON_SIMPLE || p->trigon_model == ATL_TRIGON_OTHER,
+                "atl_pv: bad trigon_model code %d", p->trigon_model);
+    ATL_REQUIRE(p->irradiation >= ATL_IRR_TOTAL && p->irradiation <= ATL_IRR_GROUND, "atl_pv: bad irradiation code %d",
+                p->irradiation);
+    ATL_REQUIRE(p->panel_model >= ATL_PANEL_HULD && p->panel_model <= ATL_PANEL_SOLAR_THERMAL,
+                "atl_pv: bad panel_model code %d", p->panel_model);
+    ATL_REQUIRE(in->d_influx_toa, "atl_pv: need influx_toa");
+    if (in->d_influx) {
+        ATL_REQUIRE(p->clearsky_model == ATL_CLEARSKY_SIMPLE || p->clearsky_model == ATL_CLEARSKY_ENHANCED,
+                    "`clearsky model` must be chosen from 'simple' and 'enhanced'");
+        ATL_REQUIRE(p->clearsky_model == ATL_CLEARSKY_SIMPLE || (in->d_temperature && in->d_humidity),
+                    "atl_pv: the enhanced clearsky model needs temperature and humidity");
+    } else {
+        ATL_REQUIRE(in->d_influx_direct && in->d_influx_diffuse,
+                    "Need either influx or influx_direct and influx_diffuse in the dataset. Check your cutout and "
+                    "dataset module.");
+    }
+    ATL_REQUIRE(in->d_albedo || in->d_outflux,
+                "Need either albedo or outflux as a variable in the dataset. Check your cutout and dataset module.");
+    ATL_REQUIRE(p->panel_model == ATL_PANEL_NONE || in->d_temperature, "atl_pv: need temperature");
+    if (in->d_solar_altitude || in->d_solar_azimuth) {
+        ATL_REQUIRE(in->d_solar_altitude && in->d_solar_azimuth,
+                    "atl_pv: solar_altitude and solar_azimuth must be given together");
+    } else {
+        ATL_REQUIRE(in->d_sin_dec && in->d_cos_dec && in->d_hour_angle && in->d_cos_hour_angle && in->d_sin_lat &&
+                        in->d_cos_lat,
+                    "atl_pv: need either solar_altitude/solar_azimuth or the solar position tables");
+        ATL_REQUIRE(in->X > 0 && S % in->X == 0, "atl_pv: X (%lld) must divide the number of cells (%lld)",
+                    (long long)in->X, (long long)S);
+    }
+    ATL_REQUIRE((p->d_cell_slope == nullptr) == (p->d_cell_azimuth == nullptr),
+                "atl_pv: d_cell_slope and d_cell_azimuth must be given together");
+    c->in = *in;
+    c->S = S;
+    c->k = PvConst{p->c_temp_amb, p->c_temp_irrad, p->r_tmod, 1.0 / p->r_irradiance, p->k_1, p->k_2,
+                   p->k_3,        p->k_4,          p->k_5,    p->k_6,                 p->inverter_efficiency,
+                   p->altitude_threshold, sin(p->altitude_threshold)};
+    c->o = PvxOpt{p->tracking, p->trigon_model, p->clearsky_model, p->irradiation, p->panel_model,
+                  in->d_influx ? 1 : 0, in->d_albedo ? 1 : 0,
+                  p->bof_A, p->bof_B, p->bof_C, p->bof_D, p->bof_NOCT, p->bof_Tstd, p->bof_Tamb, p->bof_Intc, p->bof_ta,
+                  p->bof_threshold, p->st_c0, p->st_c1, p->st_t_store_K, p->r_irradiance};
+    c->slope = p->slope;
+    c->azimuth = p->azimuth;
+    c->cell_slope = p->d_cell_slope;
+    c->cell_azimuth = p->d_cell_azimuth;
+    *vec = vec_ok(S, {in->d_influx_direct, in->d_influx_diffuse, in->d_influx, in->d_influx_toa, in->d_albedo,
+                      in->d_outflux, in->d_temperature, in->d_humidity, in->d_solar_altitude, in->d_solar_azimuth});
+    return ATL_OK;
+}
+
 int make_wind(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p, int64_t T, int64_t S,
               WindConvT<-1> *c, bool *vec, size_t *lds_bytes, bool *table_finite) {
     ATL_REQUIRE(in && p, "atl_wind: inputs/params is NULL");
@@ -1099,8 +1361,14 @@ int atl_spmm_csr(atl_ctx *ctx, const atl_agg *agg, const double *d_dense, int64_
 
 int atl_pv_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S,
                    int time_agg, double *d_out) {
-    ATL_REQUIRE(ctx && in, "atl_pv_convert: ctx/inputs is NULL");
+    ATL_REQUIRE(ctx && in && p, "atl_pv_convert: ctx/inputs/params is NULL");
     bool vec;
+    if (pv_needs_general(in, p)) {
+        PvxConv c;
+        int rc = make_pvx(in, p, T, S, &c, &vec);
+        if (rc) return rc;
+        return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
+    }
     if (in->d_solar_altitude || in->d_solar_azimuth) {
         PvConv c;
         int rc = make_pv(in, p, T, S, &c, &vec);
@@ -1115,8 +1383,14 @@ int atl_pv_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p
 
 int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T,
                              int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out) {
-    ATL_REQUIRE(ctx && in, "atl_pv_convert_aggregate: ctx/inputs is NULL");
+    ATL_REQUIRE(ctx && in && p, "atl_pv_convert_aggregate: ctx/inputs/params is NULL");
     bool vec;
+    if (pv_needs_general(in, p)) {
+        PvxConv c;
+        int rc = make_pvx(in, p, T, S, &c, &vec);
+        if (rc) return rc;
+        return run_fused(ctx, c, vec, 0, T, S, agg, time_agg, d_out, ld_out, "atl_pv_convert_aggregate");
+    }
     if (in->d_solar_altitude || in->d_solar_azimuth) {
         PvConv c;
         int rc = make_pv(in, p, T, S, &c, &vec);

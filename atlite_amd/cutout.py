@@ -77,6 +77,8 @@ class Cutout:
     # -- conversion methods bound like the reference does (cutout.py:653-689) -----------------
     convert_and_aggregate = _convert.convert_and_aggregate
     pv = _convert.pv
+    irradiation = _convert.irradiation
+    solar_thermal = _convert.solar_thermal
     wind = _convert.wind
     heat_demand = _convert.heat_demand
     runoff = _convert.runoff

@@ -223,29 +223,49 @@ class Context:
         )
         return out
 
-    def pv(self, inputs: dict, params: dict, T, S, plan=None, time_agg=None, solar_tables=None):
+    def pv(self, inputs: dict, params: dict, T, S, plan=None, time_agg=None, solar_tables=None, options=None):
         """
-        inputs: name -> DeviceArray (T,S) for the ERA5 variables (7 with stored solar angles, 5
-        without); params: see PvParams; solar_tables: host arrays ``sin_dec, cos_dec`` (T),
-        ``h, cos_h`` (T,X), ``sin_lat, cos_lat`` (Y) for the in-kernel SolarPosition variant.
+        inputs: name -> DeviceArray (T,S): influx_toa plus either influx_direct + influx_diffuse or
+        influx; albedo or outflux; temperature; humidity (enhanced clearsky); solar_altitude +
+        solar_azimuth unless ``solar_tables`` (host arrays ``sin_dec, cos_dec`` (T), ``h, cos_h``
+        (T,X), ``sin_lat, cos_lat`` (Y)) are given.  params: panel constants + slope/azimuth in
+        radians (scalars or per-cell).  options: tracking / trigon_model / clearsky_model /
+        irradiation / panel_model (names as in atlite), solar thermal c0, c1, t_store_K.
         """
         keep = []
-        names = ["influx_direct", "influx_diffuse", "influx_toa", "albedo", "temperature"]
-        ptrs = [inputs[k].ptr for k in names]
-        if solar_tables is None:
-            ptrs += [inputs["solar_altitude"].ptr, inputs["solar_azimuth"].ptr]
-            pin = _lib.PvInputs(*ptrs)
-        else:
-            tabs = [self.asdevice(np.ascontiguousarray(solar_tables[k], dtype=np.float64))
-                    for k in ("sin_dec", "cos_dec", "h", "cos_h", "sin_lat", "cos_lat")]
-            keep += tabs
-            pin = _lib.PvInputs(*ptrs, None, None, *[t.ptr for t in tabs], int(solar_tables["h"].shape[1]))
+        options = dict(options or {})
+        pin = _lib.PvInputs()
+        for name in ("influx_direct", "influx_diffuse", "influx_toa", "albedo", "temperature", "solar_altitude",
+                     "solar_azimuth", "influx", "outflux", "humidity"):
+            if name in inputs and inputs[name] is not None:
+                setattr(pin, "d_" + name, inputs[name].ptr)
+        if solar_tables is not None:
+            pin.d_solar_altitude = pin.d_solar_azimuth = None
+            for field, key in (("d_sin_dec", "sin_dec"), ("d_cos_dec", "cos_dec"), ("d_hour_angle", "h"),
+                               ("d_cos_hour_angle", "cos_h"), ("d_sin_lat", "sin_lat"), ("d_cos_lat", "cos_lat")):
+                t = self.asdevice(np.ascontiguousarray(solar_tables[key], dtype=np.float64))
+                keep.append(t)
+                setattr(pin, field, t.ptr)
+            pin.X = int(np.shape(solar_tables["h"])[1])
         pp = _lib.PvParams()
-        for k in ("c_temp_amb", "c_temp_irrad", "r_tmod", "r_irradiance", "k_1", "k_2", "k_3", "k_4",
-                  "k_5", "k_6"):
-            setattr(pp, k, float(params[k]))
+        model = options.get("panel_model", params.get("model", "huld"))
+        pp.panel_model = _lib.PANEL[model]
+        if model == "huld":
+            for k in ("c_temp_amb", "c_temp_irrad", "r_tmod", "r_irradiance", "k_1", "k_2", "k_3", "k_4", "k_5", "k_6"):
+                setattr(pp, k, float(params[k]))
+        else:
+            pp.r_irradiance = 1.0
+        if model == "bofinger":
+            for k in ("A", "B", "C", "D", "NOCT", "Tstd", "Tamb", "Intc", "ta", "threshold"):
+                setattr(pp, "bof_" + k, float(params[k]))
+        if model == "solar_thermal":
+            pp.st_c0, pp.st_c1, pp.st_t_store_K = (float(options[k]) for k in ("c0", "c1", "t_store_K"))
         pp.inverter_efficiency = float(params.get("inverter_efficiency", 1.0))
         pp.altitude_threshold = float(params.get("altitude_threshold", np.radians(1.0)))
+        pp.tracking = _lib.TRACKING[options.get("tracking")]
+        pp.trigon_model = _lib.TRIGON[options.get("trigon_model", "simple")]
+        pp.clearsky_model = _lib.CLEARSKY[options.get("clearsky_model") or "simple"]
+        pp.irradiation = _lib.IRRADIATION[options.get("irradiation", "total")]
         slope, azimuth = params["slope"], params["azimuth"]
         if np.ndim(slope) == 0 and np.ndim(azimuth) == 0:
             pp.slope, pp.azimuth = float(slope), float(azimuth)

@@ -127,7 +127,30 @@ typedef struct {
     const double *d_sin_lat;        /* (Y)   sin(radians(lat))                  :100    */
     const double *d_cos_lat;        /* (Y)   cos(radians(lat))                          */
     int64_t X;                      /* cells per grid row (needed for the tables)       */
+    /* datasets without a direct/diffuse split or without albedo (irradiation.py:202-205,
+     * 128-139): total influx -> Reindl split in the kernel; albedo = outflux / influx */
+    const double *d_influx;         /* (T,S) or NULL (then influx_direct/diffuse are used) */
+    const double *d_outflux;        /* (T,S), used iff d_albedo == NULL                    */
+    const double *d_humidity;       /* (T,S), "enhanced" clearsky model only               */
 } atl_pv_inputs;
+
+#define ATL_TRACK_NONE 0              /* pv/orientation.py:113-117 */
+#define ATL_TRACK_HORIZONTAL 1        /* :119-131 */
+#define ATL_TRACK_TILTED_HORIZONTAL 2 /* :133-168 */
+#define ATL_TRACK_VERTICAL 3          /* :170-173 */
+#define ATL_TRACK_DUAL 4              /* :174-175 */
+#define ATL_TRIGON_SIMPLE 0           /* pv/irradiation.py:214-226 */
+#define ATL_TRIGON_OTHER 1            /* Hay-Davies, :76-145, 227-236 */
+#define ATL_CLEARSKY_SIMPLE 0         /* Reindl, :33-42 */
+#define ATL_CLEARSKY_ENHANCED 1       /* :43-64 (temperature + humidity) */
+#define ATL_IRR_TOTAL 0
+#define ATL_IRR_DIRECT 1
+#define ATL_IRR_DIFFUSE 2
+#define ATL_IRR_GROUND 3
+#define ATL_PANEL_HULD 0          /* pv/solar_panel_model.py:12-44 */
+#define ATL_PANEL_BOFINGER 1      /* :47-74 */
+#define ATL_PANEL_NONE 2          /* convert_irradiation (convert.py:748-767): W m**-2 */
+#define ATL_PANEL_SOLAR_THERMAL 3 /* convert_solar_thermal (convert.py:550-574) */
 
 typedef struct {
     /* Huld panel model constants (resources/solarpanel/CSi.yaml keys) */
@@ -139,6 +162,13 @@ typedef struct {
     const double *d_cell_slope;   /* (S) or NULL */
     const double *d_cell_azimuth; /* (S) or NULL */
     double altitude_threshold;    /* radians; reference default radians(1.0) */
+    /* options; all-zero = convert_pv defaults (no tracking, "simple", total, Huld).  Any other
+     * combination runs the general kernel (literal transcription, full-precision libm). */
+    int tracking, trigon_model, clearsky_model, irradiation, panel_model;
+    /* bofinger constants (resources/solarpanel/KANENA.yaml keys) */
+    double bof_A, bof_B, bof_C, bof_D, bof_NOCT, bof_Tstd, bof_Tamb, bof_Intc, bof_ta, bof_threshold;
+    /* solar thermal: c0, c1, storage temperature in K (t_store + 273.15) */
+    double st_c0, st_c1, st_t_store_K;
 } atl_pv_params;
 
 /* per-cell output: time_agg NONE -> d_out (T x S); SUM/MEAN -> d_out (S) */

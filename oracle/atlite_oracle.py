@@ -306,3 +306,178 @@ def gateway(da, matrix=None, layout=None, per_unit=False, aggregate_time_method=
             res = _fillna0(res / cap)  # :265
     res = aggregate_time(res, aggregate_time_method, axis=1)
     return res, capacity
+
+
+# --------------------------------------------------------------------------------------
+# remaining pv options: tracking, Hay-Davies, Reindl split, albedo from
+# outflux, bofinger panel, irradiation quantities, solar thermal
+# --------------------------------------------------------------------------------------
+
+
+def surface_orientation_tracking(alt, az, slope, azimuth, tracking=None):
+    """
+    SurfaceOrientation, atlite/pv/orientation.py:104-196, all tracking modes.
+    Returns dict(cosincidence, slope, azimuth); slope/azimuth broadcast against alt/az.
+    """
+    pi = np.pi
+    surface_slope, surface_azimuth = slope, azimuth
+    sun_altitude, sun_azimuth = alt, az
+    sin, cos = np.sin, np.cos
+    with np.errstate(all="ignore"):
+        if tracking is None:
+            cosincidence = sin(surface_slope) * cos(sun_altitude) * cos(surface_azimuth - sun_azimuth) + cos(
+                surface_slope
+            ) * sin(sun_altitude)  # :114-117
+        elif tracking == "horizontal":  # :119-131
+            axis_azimuth = azimuth
+            rotation = np.arctan((cos(sun_altitude) / sin(sun_altitude)) * sin(sun_azimuth - axis_azimuth))
+            surface_slope = abs(rotation)
+            surface_azimuth = axis_azimuth + np.arcsin(sin(rotation) / sin(surface_slope))
+            cosincidence = cos(surface_slope) * sin(sun_altitude) + sin(surface_slope) * cos(sun_altitude) * cos(
+                sun_azimuth - surface_azimuth
+            )
+        elif tracking == "tilted_horizontal":  # :133-168
+            axis_tilt = slope
+            rotation = np.arctan(
+                (cos(sun_altitude) * sin(sun_azimuth - surface_azimuth))
+                / (cos(sun_altitude) * cos(sun_azimuth - surface_azimuth) * sin(axis_tilt) + sin(sun_altitude) * cos(axis_tilt))
+            )
+            surface_slope = np.arccos(cos(rotation) * cos(axis_tilt))
+            azimuth_difference = sun_azimuth - surface_azimuth
+            azimuth_difference = np.where(azimuth_difference > pi, azimuth_difference - 2 * pi, azimuth_difference)
+            azimuth_difference = np.where(azimuth_difference < -pi, 2 * pi + azimuth_difference, azimuth_difference)
+            rotation = np.where(np.logical_and(rotation < 0, azimuth_difference > 0), rotation + pi, rotation)
+            rotation = np.where(np.logical_and(rotation > 0, azimuth_difference < 0), rotation - pi, rotation)
+            cosincidence = cos(rotation) * (
+                sin(axis_tilt) * cos(sun_altitude) * cos(sun_azimuth - surface_azimuth) + cos(axis_tilt) * sin(sun_altitude)
+            ) + sin(rotation) * cos(sun_altitude) * sin(sun_azimuth - surface_azimuth)
+        elif tracking == "vertical":  # :170-173
+            cosincidence = sin(surface_slope) * cos(sun_altitude) + cos(surface_slope) * sin(sun_altitude)
+        elif tracking == "dual":  # :174-175
+            cosincidence = np.float64(1.0)
+        else:
+            raise AssertionError("bad tracking")
+        cosincidence = np.clip(cosincidence, 0, None)  # :188
+    return dict(cosincidence=cosincidence, slope=surface_slope, azimuth=surface_azimuth)
+
+
+def diffuse_horizontal_irrad(influx, influx_toa, alt, clearsky_model, temperature=None, humidity=None):
+    """DiffuseHorizontalIrrad (Reindl 1990), atlite/pv/irradiation.py:13-73."""
+    sinaltitude = np.sin(alt)
+    with np.errstate(all="ignore"):
+        k = influx / influx_toa  # :29
+        if clearsky_model == "simple":  # :36-41
+            fraction = (
+                ((k > 0.0) & (k <= 0.3)) * np.fmin(1.0, 1.020 - 0.254 * k + 0.0123 * sinaltitude)
+                + ((k > 0.3) & (k < 0.78)) * np.fmin(0.97, np.fmax(0.1, 1.400 - 1.749 * k + 0.177 * sinaltitude))
+                + (k >= 0.78) * np.fmax(0.1, 0.486 * k - 0.182 * sinaltitude)
+            )
+        elif clearsky_model == "enhanced":  # :48-63
+            T, rh = temperature, humidity
+            fraction = (
+                ((k > 0.0) & (k <= 0.3)) * np.fmin(1.0, 1.000 - 0.232 * k + 0.0239 * sinaltitude - 0.000682 * T + 0.0195 * rh)
+                + ((k > 0.3) & (k < 0.78))
+                * np.fmin(0.97, np.fmax(0.1, 1.329 - 1.716 * k + 0.267 * sinaltitude - 0.00357 * T + 0.106 * rh))
+                + (k >= 0.78) * np.fmax(0.1, 0.426 * k - 0.256 * sinaltitude + 0.00349 * T + 0.0734 * rh)
+            )
+        else:
+            raise KeyError("`clearsky model` must be chosen from 'simple' and 'enhanced'")
+        return influx * fraction  # :73
+
+
+def _albedo(ds, influx):
+    """irradiation.py:128-139."""
+    if "albedo" in ds:
+        return ds["albedo"]
+    with np.errstate(all="ignore"):
+        a = ds["outflux"] / np.where(influx != 0, influx, np.nan)
+        return np.clip(_fillna0(a), None, 1)
+
+
+def tilted_irradiation_general(ds, alt, so, trigon_model="simple", clearsky_model="simple", tracking=None,
+                               altitude_threshold=1.0, irradiation="total"):
+    """TiltedIrradiation, atlite/pv/irradiation.py:196-255, every branch."""
+    influx_toa = ds["influx_toa"]
+    cosincidence, surface_slope = so["cosincidence"], so["slope"]
+    with np.errstate(all="ignore"):
+        if "influx" in ds:  # :202-205
+            influx = np.clip(ds["influx"], 0, influx_toa)
+            if clearsky_model is None:
+                clearsky_model = "enhanced" if ("temperature" in ds and "humidity" in ds) else "simple"
+            diffuse = diffuse_horizontal_irrad(influx, influx_toa, alt, clearsky_model, ds.get("temperature"),
+                                               ds.get("humidity"))
+            direct = influx - diffuse
+        else:  # :206-208
+            direct = np.clip(ds["influx_direct"], 0, influx_toa)
+            diffuse = np.clip(ds["influx_diffuse"], 0, influx_toa - direct)
+        sinalt = np.sin(alt)
+        if trigon_model == "simple":  # :214-226
+            k = cosincidence / sinalt
+            cos_surface_slope = np.cos(surface_slope) if tracking != "dual" else sinalt
+            influx = direct + diffuse
+            direct_t = k * direct
+            diffuse_t = (1.0 + cos_surface_slope) / 2.0 * diffuse
+            ground_t = _albedo(ds, influx) * influx * ((1.0 - cos_surface_slope) / 2.0)
+            total_t = _fillna0(direct_t) + _fillna0(diffuse_t) + _fillna0(ground_t)
+        else:  # :227-236  Hay-Davies (:76-115), direct (:118-125), ground (:142-145)
+            influx = direct + diffuse
+            f = _fillna0(np.sqrt(direct / influx))
+            A = direct / influx_toa
+            R_b = cosincidence / sinalt
+            diffuse_t = ((1.0 - A) * ((1 + np.cos(surface_slope)) / 2.0) * (1.0 + f * np.sin(surface_slope / 2.0) ** 3)
+                         + A * R_b) * diffuse
+            diffuse_t = _fillna0(np.clip(diffuse_t, 0, None))
+            direct_t = R_b * direct
+            ground_t = influx * _albedo(ds, influx) * (1.0 - np.cos(surface_slope)) / 2.0
+            total_t = direct_t + diffuse_t + ground_t
+        result = dict(total=total_t, direct=direct_t, diffuse=diffuse_t, ground=ground_t)[irradiation]  # :238-245
+        cap_alt = alt < np.radians(altitude_threshold)
+        shape = np.broadcast_shapes(np.shape(result), np.shape(cap_alt), np.shape(direct))
+        result = np.where(~(cap_alt | (direct + diffuse <= 0.01)), np.broadcast_to(result, shape), 0)  # :251-252
+    return result
+
+
+def power_bofinger(irradiance, t_amb, pc):
+    """_power_bofinger, atlite/pv/solar_panel_model.py:47-74."""
+    with np.errstate(all="ignore"):
+        fraction = (pc["NOCT"] - pc["Tamb"]) / pc["Intc"]
+        eta_ref = pc["A"] + pc["B"] * irradiance + pc["C"] * np.log(np.where(irradiance != 0, irradiance, np.nan))
+        eta = _fillna0(
+            eta_ref * (1.0 + pc["D"] * (fraction * irradiance + (t_amb - pc["Tstd"])))
+            / (1.0 + pc["D"] * fraction / pc["ta"] * eta_ref * irradiance)
+        )
+        capacity = (pc["A"] + pc["B"] * 1000.0 + pc["C"] * np.log(1000.0)) * 1e3
+        power = irradiance * eta * (pc.get("inverter_efficiency", 1.0) / capacity)
+        return np.where(irradiance >= pc["threshold"], power, 0)
+
+
+def convert_pv_general(ds, panel, orientation, tracking=None, trigon_model="simple", clearsky_model="simple",
+                       altitude_threshold=1.0):
+    """convert_pv, atlite/convert.py:840-854, any option (stored solar angles)."""
+    alt, az = ds["solar_altitude"], ds["solar_azimuth"]
+    so = surface_orientation_tracking(alt, az, orientation["slope"], orientation["azimuth"], tracking)
+    irr = tilted_irradiation_general(ds, alt, so, trigon_model, clearsky_model, tracking, altitude_threshold)
+    if panel.get("model", "huld") == "huld":
+        return power_huld(irr, ds["temperature"], panel)
+    return power_bofinger(irr, ds["temperature"], panel)
+
+
+def convert_irradiation(ds, orientation, tracking=None, irradiation="total", trigon_model="simple",
+                        clearsky_model="simple"):
+    """convert_irradiation, atlite/convert.py:748-767."""
+    alt, az = ds["solar_altitude"], ds["solar_azimuth"]
+    so = surface_orientation_tracking(alt, az, orientation["slope"], orientation["azimuth"], tracking)
+    return tilted_irradiation_general(ds, alt, so, trigon_model, clearsky_model, tracking, irradiation=irradiation)
+
+
+def convert_solar_thermal(ds, orientation, trigon_model="simple", clearsky_model="simple", c0=0.8, c1=3.0,
+                          t_store=80.0):
+    """convert_solar_thermal, atlite/convert.py:550-574."""
+    t_store = t_store + 273.15
+    alt, az = ds["solar_altitude"], ds["solar_azimuth"]
+    so = surface_orientation_tracking(alt, az, orientation["slope"], orientation["azimuth"], None)
+    irr = tilted_irradiation_general(ds, alt, so, trigon_model, clearsky_model, tracking=0)
+    with np.errstate(all="ignore"):
+        eta = c0 - c1 * _fillna0((t_store - ds["temperature"]) / np.where(irr != 0, irr, np.nan))
+        output = irr * eta
+        return np.where(output > 0.0, output, 0.0)

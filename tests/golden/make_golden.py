@@ -120,6 +120,45 @@ def main():
             pv_out[f"out_{panel_name}_{oname}"] = da.transpose("time", "y", "x").values
     save("pv", time=t.values.astype("datetime64[ns]").astype(np.int64), x=x, y=y, **v, **pv_out)
 
+    # ---------------------------------------------------------------- pv options (8 f-1) -----
+    opt = {}
+    csi = res.get_solarpanelconfig("CSi")
+    kan = res.get_solarpanelconfig("KANENA")
+    o30 = {"slope": 30.0, "azimuth": 180.0}
+    for trk in ("horizontal", "tilted_horizontal", "vertical", "dual"):
+        for tm in ("simple", "other"):
+            da = conv.convert_pv(ds, csi, orient.get_orientation(dict(o30)), tracking=trk, trigon_model=tm)
+            opt[f"pv_{trk}_{tm}"] = da.transpose("time", "y", "x").values
+    opt["pv_none_other"] = conv.convert_pv(ds, csi, orient.get_orientation(dict(o30)), tracking=None,
+                                           trigon_model="other").transpose("time", "y", "x").values
+    opt["pv_kanena_simple"] = conv.convert_pv(ds, kan, orient.get_orientation(dict(o30)), tracking=None
+                                              ).transpose("time", "y", "x").values
+    opt["pv_kanena_latopt_other"] = conv.convert_pv(ds, kan, orient.get_orientation("latitude_optimal"), tracking=None,
+                                                    trigon_model="other").transpose("time", "y", "x").values
+    for q in ("total", "direct", "diffuse", "ground"):
+        for tm in ("simple", "other"):
+            da = conv.convert_irradiation(ds, orient.get_orientation(dict(o30)), irradiation=q, trigon_model=tm)
+            opt[f"irr_{q}_{tm}"] = da.transpose("time", "y", "x").values
+    opt["irr_total_dual"] = conv.convert_irradiation(ds, orient.get_orientation(dict(o30)), tracking="dual"
+                                                     ).transpose("time", "y", "x").values
+    opt["thermal_default"] = conv.convert_solar_thermal(ds, orient.get_orientation({"slope": 45.0, "azimuth": 180.0}),
+                                                        "simple", "simple", 0.8, 3.0, 80.0).transpose("time", "y", "x").values
+    # SARAH-like dataset: total influx + outflux, no direct/diffuse split, no albedo
+    v2 = dict(influx=v["influx_direct"] + v["influx_diffuse"], influx_toa=v["influx_toa"],
+              outflux=(v["influx_direct"] + v["influx_diffuse"]) * np.where(np.isnan(v["albedo"]), 0.2, v["albedo"]),
+              temperature=v["temperature"], humidity=0.3 + 0.5 * rng.random((T, Y, X)),
+              solar_altitude=v["solar_altitude"], solar_azimuth=v["solar_azimuth"])
+    v2["influx"][e[0]] = 0.0          # influx == 0 -> albedo 0/NaN -> fillna 0
+    v2["outflux"][e[1]] = 1e9         # albedo clipped to 1
+    ds2 = dataset(v2, t)
+    for cs in ("simple", "enhanced"):
+        opt[f"pv_influx_{cs}"] = conv.convert_pv(ds2, csi, orient.get_orientation(dict(o30)), tracking=None,
+                                                 clearsky_model=cs).transpose("time", "y", "x").values
+    opt["pv_influx_enhanced_other"] = conv.convert_pv(ds2, csi, orient.get_orientation(dict(o30)), tracking=None,
+                                                      trigon_model="other", clearsky_model="enhanced"
+                                                      ).transpose("time", "y", "x").values
+    save("pv_options", influx=v2["influx"], outflux=v2["outflux"], humidity=v2["humidity"], **opt)
+
     # ---------------------------------------------------------------- wind ------------------
     Tw = 40
     tw = pd.date_range("2013-01-01", periods=Tw, freq="h")

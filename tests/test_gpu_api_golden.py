@@ -269,3 +269,49 @@ def test_pv_in_kernel_solar_position():
         with pytest.warns(DeprecationWarning):
             ra = c.pv(panel="CSi", orientation=ospec, matrix=M, aggregate_time=None)
         close(ra.values, orc.aggregate_matrix(ref.reshape(ref.shape[0], -1), M))
+
+
+# ---- remaining pv options, against reference-generated vectors ------------------
+O30 = {"slope": 30.0, "azimuth": 180.0}
+
+
+@pytest.mark.parametrize("trk", ["horizontal", "tilted_horizontal", "vertical", "dual", None])
+@pytest.mark.parametrize("tm", ["simple", "other"])
+def test_pv_tracking_and_trigon(trk, tm):
+    g, o = load("pv"), load("pv_options")
+    c = cutout_from(g, PV_VARS)
+    r = c.pv(panel="CSi", orientation=dict(O30), tracking=trk, trigon_model=tm, aggregate_time=None)
+    ref = g["out_CSi_const30_180"] if (trk is None and tm == "simple") else o[f"pv_{trk}_{tm}" if trk else "pv_none_other"]
+    close(r.values, ref)
+
+
+def test_pv_bofinger_irradiation_thermal():
+    g, o = load("pv"), load("pv_options")
+    c = cutout_from(g, PV_VARS)
+    r = c.pv(panel="KANENA", orientation=dict(O30), aggregate_time=None)
+    assert r.name == "AC power"
+    close(r.values, o["pv_kanena_simple"])
+    close(c.pv(panel="KANENA", orientation="latitude_optimal", trigon_model="other", aggregate_time=None).values,
+          o["pv_kanena_latopt_other"])
+    for q in ("total", "direct", "diffuse", "ground"):
+        for tm in ("simple", "other"):
+            r = c.irradiation(orientation=dict(O30), irradiation=q, trigon_model=tm, aggregate_time=None)
+            assert r.attrs["units"] == "W m**-2" and r.name == f"{q} tilted"
+            close(r.values, o[f"irr_{q}_{tm}"])
+    close(c.irradiation(orientation=dict(O30), tracking="dual", aggregate_time=None).values, o["irr_total_dual"])
+    close(c.solar_thermal(aggregate_time=None).values, o["thermal_default"])
+    # aggregated through the fused kernel as well
+    S = len(g["y"]) * len(g["x"])
+    M = sp.csr_matrix(np.ones((1, S)))
+    r = c.pv(panel="CSi", orientation=dict(O30), tracking="horizontal", matrix=M, aggregate_time=None)
+    close(r.values[0], o["pv_horizontal_simple"].reshape(len(g["time"]), -1).sum(1))
+
+
+@pytest.mark.parametrize("cs,tm,key", [("simple", "simple", "pv_influx_simple"), ("enhanced", "simple", "pv_influx_enhanced"),
+                                       ("enhanced", "other", "pv_influx_enhanced_other"), (None, "simple", "pv_influx_enhanced")])
+def test_pv_influx_only_dataset(cs, tm, key):
+    g, o = load("pv"), load("pv_options")
+    gg = dict(g, influx=o["influx"], outflux=o["outflux"], humidity=o["humidity"])
+    c = cutout_from(gg, ("influx", "influx_toa", "outflux", "temperature", "humidity", "solar_altitude", "solar_azimuth"))
+    r = c.pv(panel="CSi", orientation=dict(O30), trigon_model=tm, clearsky_model=cs, aggregate_time=None)
+    close(r.values, o[key])

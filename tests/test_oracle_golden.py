@@ -129,3 +129,60 @@ def test_gateway():
     exact(g["legacy_nomatrix"], g["cells_sum"])  # legacy without aggregation = time sum (convert.py:209)
     exact(g["legacy_matrix"], g["series_matrix"])  # legacy with aggregation = series (convert.py:270)
     exact(g["capfactor"], g["cells_mean"])  # capacity_factor=True == aggregate_time="mean"
+
+
+# ---- remaining pv options -------------------------------------------------------
+KANENA = dict(model="bofinger", threshold=1, A=0.0659164166836276, B=-4.44310393547042e-06, C=0.0122044905275824,
+              D=-0.0035, NOCT=318, Tstd=298, Tamb=293, Intc=800, ta=0.9, inverter_efficiency=0.9)
+PV7 = ("influx_direct", "influx_diffuse", "influx_toa", "albedo", "temperature", "solar_altitude", "solar_azimuth")
+
+
+def _opt_ds():
+    g = load("pv")
+    return {k: g[k] for k in PV7}, load("pv_options"), g
+
+
+def tol(a, b, rtol=5e-15):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize("trk", ["horizontal", "tilted_horizontal", "vertical", "dual", None])
+@pytest.mark.parametrize("tm", ["simple", "other"])
+def test_pv_tracking_and_trigon(trk, tm):
+    ds, o, g = _opt_ds()
+    out = orc.convert_pv_general(ds, H.CSI, orc.orientation_constant(30.0, 180.0), tracking=trk, trigon_model=tm)
+    key = f"pv_{trk}_{tm}" if trk else "pv_none_other"
+    ref = o[key] if not (trk is None and tm == "simple") else g["out_CSi_const30_180"]
+    tol(out, ref)
+
+
+def test_pv_bofinger():
+    ds, o, g = _opt_ds()
+    tol(orc.convert_pv_general(ds, KANENA, orc.orientation_constant(30.0, 180.0)), o["pv_kanena_simple"])
+    lo = orc.orientation_latitude_optimal(np.radians(g["y"]))
+    ori = dict(slope=lo["slope"][None, :, None], azimuth=lo["azimuth"][None, :, None])
+    tol(orc.convert_pv_general(ds, KANENA, ori, trigon_model="other"), o["pv_kanena_latopt_other"])
+
+
+@pytest.mark.parametrize("q", ["total", "direct", "diffuse", "ground"])
+@pytest.mark.parametrize("tm", ["simple", "other"])
+def test_irradiation_quantities(q, tm):
+    ds, o, _ = _opt_ds()
+    tol(orc.convert_irradiation(ds, orc.orientation_constant(30.0, 180.0), irradiation=q, trigon_model=tm),
+        o[f"irr_{q}_{tm}"])
+
+
+def test_irradiation_dual_and_solar_thermal():
+    ds, o, _ = _opt_ds()
+    tol(orc.convert_irradiation(ds, orc.orientation_constant(30.0, 180.0), tracking="dual"), o["irr_total_dual"])
+    tol(orc.convert_solar_thermal(ds, orc.orientation_constant(45.0, 180.0)), o["thermal_default"])
+
+
+@pytest.mark.parametrize("cs,tm,key", [("simple", "simple", "pv_influx_simple"), ("enhanced", "simple", "pv_influx_enhanced"),
+                                       ("enhanced", "other", "pv_influx_enhanced_other")])
+def test_pv_influx_only_dataset(cs, tm, key):
+    ds, o, g = _opt_ds()
+    ds2 = dict(influx=o["influx"], influx_toa=ds["influx_toa"], outflux=o["outflux"], temperature=ds["temperature"],
+               humidity=o["humidity"], solar_altitude=ds["solar_altitude"], solar_azimuth=ds["solar_azimuth"])
+    out = orc.convert_pv_general(ds2, H.CSI, orc.orientation_constant(30.0, 180.0), trigon_model=tm, clearsky_model=cs)
+    tol(out, o[key])
