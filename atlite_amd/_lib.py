@@ -101,6 +101,19 @@ class HeatParams(C.Structure):
         ("constant", C.c_double),
         ("n_days", C.c_int64),
         ("d_day_ptr", C.c_void_p),
+        ("cooling", C.c_int),
+    ]
+
+
+class ThermoParams(C.Structure):
+    _fields_ = [
+        ("offset", C.c_double),
+        ("fillna0", C.c_int),
+        ("quadratic", C.c_int),
+        ("sink_T", C.c_double),
+        ("c0", C.c_double),
+        ("c1", C.c_double),
+        ("c2", C.c_double),
     ]
 
 
@@ -158,6 +171,8 @@ SIGNATURES = {
         _i,
         [_vp, _vp, C.POINTER(HeatParams), _i64, _i64, _vp, _i, _vp, _i64],
     ),
+    "atl_thermo_convert": (_i, [_vp, _vp, C.POINTER(ThermoParams), _i64, _i64, _i, _vp]),
+    "atl_thermo_convert_aggregate": (_i, [_vp, _vp, C.POINTER(ThermoParams), _i64, _i64, _vp, _i, _vp, _i64]),
     "atl_runoff_convert": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _vp]),
     "atl_runoff_convert_aggregate": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _i, _vp, _i64]),
     "atl_indicator_polygons": (

@@ -235,9 +235,37 @@ class _WindSpec(_Spec):
                         plan=plan, time_agg=time_agg)
 
 
+class _ThermoSpec(_Spec):
+    """temperature / soil temperature / dewpoint temperature / COP (convert.py:292-401)."""
+
+    attrs = {}
+
+    def __init__(self, ds, var, fillna0=False, cop=None, name=None):
+        _need(ds, [var], KeyError, var)
+        self.var, self.fillna0, self.cop, self.name = var, fillna0, cop, name
+
+    def run(self, ctx, ds, plan, time_agg):
+        T, S = len(ds.coords["time"]), len(ds.coords["y"]) * len(ds.coords["x"])
+        return ctx.thermo(ds.device(ctx, self.var), T, S, fillna0=self.fillna0, cop=self.cop, plan=plan,
+                          time_agg=time_agg)
+
+
+def _cop_spec(ds, source, sink_T, c0, c1, c2):
+    assert source in ["air", "soil"], NotImplementedError("'source' must be one of  ['air', 'soil']")
+    if source == "air":
+        d = (6.81, -0.121, 0.000630)
+        var, fill = "temperature", False
+    else:
+        d = (8.77, -0.150, 0.000734)
+        var, fill = "soil temperature", True
+    c0, c1, c2 = (d[i] if v is None else v for i, v in enumerate((c0, c1, c2)))
+    return _ThermoSpec(ds, var, fill, cop=(sink_T, c0, c1, c2))
+
+
 class _HeatSpec(_Spec):
     name = "heat_demand"
     attrs = {}
+    cooling = False
 
     def __init__(self, ds, threshold, a, constant, hour_shift):
         _need(ds, ["temperature"], KeyError, "temperature")
@@ -259,7 +287,12 @@ class _HeatSpec(_Spec):
     def run(self, ctx, ds, plan, time_agg):
         T, S = len(ds.coords["time"]), len(ds.coords["y"]) * len(ds.coords["x"])
         return ctx.heat_demand(ds.device(ctx, "temperature"), self.day_ptr, self.threshold_K, self.a,
-                               self.constant, T, S, plan=plan, time_agg=time_agg)
+                               self.constant, T, S, plan=plan, time_agg=time_agg, cooling=self.cooling)
+
+
+class _CoolSpec(_HeatSpec):
+    name = "cooling_demand"
+    cooling = True
 
 
 class _RunoffSpec(_Spec):
@@ -314,6 +347,31 @@ def convert_heat_demand(ds, threshold, a, constant, hour_shift):
     return _per_cell(_HeatSpec(ds, threshold, a, constant, hour_shift), ds)
 
 
+def convert_cooling_demand(ds, threshold, a, constant, hour_shift):
+    """convert.py:475-490; per-cell daily 'cooling_demand'."""
+    return _per_cell(_CoolSpec(ds, threshold, a, constant, hour_shift), ds)
+
+
+def convert_temperature(ds):
+    """convert.py:292-299."""
+    return _per_cell(_ThermoSpec(ds, "temperature", name="temperature"), ds)
+
+
+def convert_soil_temperature(ds):
+    """convert.py:307-318 (NaN over sea -> 0 so that it does not contribute to the aggregation)."""
+    return _per_cell(_ThermoSpec(ds, "soil temperature", fillna0=True, name="soil temperature"), ds)
+
+
+def convert_dewpoint_temperature(ds):
+    """convert.py:326-330."""
+    return _per_cell(_ThermoSpec(ds, "dewpoint temperature", name="dewpoint temperature"), ds)
+
+
+def convert_coefficient_of_performance(ds, source, sink_T, c0, c1, c2):
+    """convert.py:338-364."""
+    return _per_cell(_cop_spec(ds, source, sink_T, c0, c1, c2), ds)
+
+
 def convert_runoff(ds, weight_with_height=True):
     """convert.py:1028-1034."""
     return _per_cell(_RunoffSpec(ds, weight_with_height), ds)
@@ -321,7 +379,11 @@ def convert_runoff(ds, weight_with_height=True):
 
 _KNOWN = {convert_pv: _PvSpec, convert_wind: _WindSpec, convert_heat_demand: _HeatSpec,
           convert_runoff: _RunoffSpec, convert_irradiation: _IrradiationSpec,
-          convert_solar_thermal: _SolarThermalSpec}
+          convert_solar_thermal: _SolarThermalSpec, convert_cooling_demand: _CoolSpec,
+          convert_temperature: lambda ds: _ThermoSpec(ds, "temperature", name="temperature"),
+          convert_soil_temperature: lambda ds: _ThermoSpec(ds, "soil temperature", fillna0=True, name="soil temperature"),
+          convert_dewpoint_temperature: lambda ds: _ThermoSpec(ds, "dewpoint temperature", name="dewpoint temperature"),
+          convert_coefficient_of_performance: _cop_spec}
 
 
 class _CubeSpec(_Spec):
@@ -643,6 +705,46 @@ def heat_demand(cutout, threshold=15.0, a=1.0, constant=0.0, hour_shift=0.0, **p
         a=a,
         constant=constant,
         hour_shift=hour_shift,
+        **params,
+    )
+
+
+def cooling_demand(cutout, threshold=23.0, a=1.0, constant=0.0, hour_shift=0.0, **params):
+    """Daily cooling demand by the degree-day approximation (convert.py:493-546)."""
+    return cutout.convert_and_aggregate(
+        convert_func=convert_cooling_demand,
+        threshold=threshold,
+        a=a,
+        constant=constant,
+        hour_shift=hour_shift,
+        **params,
+    )
+
+
+def temperature(cutout, **params):
+    """Outside temperature in deg C (convert.py:302-303)."""
+    return cutout.convert_and_aggregate(convert_func=convert_temperature, **params)
+
+
+def soil_temperature(cutout, **params):
+    """Soil temperature in deg C, NaN (sea) -> 0 (convert.py:321-322)."""
+    return cutout.convert_and_aggregate(convert_func=convert_soil_temperature, **params)
+
+
+def dewpoint_temperature(cutout, **params):
+    """Dewpoint temperature in deg C (convert.py:333-335)."""
+    return cutout.convert_and_aggregate(convert_func=convert_dewpoint_temperature, **params)
+
+
+def coefficient_of_performance(cutout, source="air", sink_T=55.0, c0=None, c1=None, c2=None, **params):
+    """Heat-pump COP from air or soil temperature (convert.py:367-401)."""
+    return cutout.convert_and_aggregate(
+        convert_func=convert_coefficient_of_performance,
+        source=source,
+        sink_T=sink_T,
+        c0=c0,
+        c1=c1,
+        c2=c2,
         **params,
     )
 

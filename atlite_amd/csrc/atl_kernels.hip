@@ -115,12 +115,42 @@ struct RunoffConv {
     }
 };
 
+// temperature family + heat-pump COP (convert.py:292-364)
+struct ThermoConv {
+    const double *var;
+    int64_t S;
+    double offset, sink_T, c0, c1, c2;
+    int fillna0, quadratic;
+    using Cell = NoCell;
+    __device__ void block_init(double *) const {}
+    __device__ Cell cell_setup(int64_t, bool, bool) const { return {}; }
+    __device__ __forceinline__ double f(double v) const {
+        double x = v + offset;
+        if (fillna0) x = fill0(x);
+        if (quadratic) {
+            const double d = sink_T - x;
+            x = c0 + c1 * d + c2 * (d * d);
+        }
+        return x;
+    }
+    template <bool VEC>
+    __device__ __forceinline__ double2 eval(int64_t slot, int64_t c0_, bool v0, bool v1, const Cell &,
+                                            const double *) const {
+        const double2 v = ld2<VEC>(var, slot * S + c0_, v0, v1);
+        double2 r;
+        r.x = v0 ? f(v.x) : 0.0;
+        r.y = v1 ? f(v.y) : 0.0;
+        return r;
+    }
+};
+
 // heat demand: nan-skipping daily mean, degree-day transform (convert.py:405-418)
 struct HeatConv {
     const double *temperature;
     const int64_t *day_ptr;  // device (D+1)
     int64_t S;
     double threshold_K, a, constant;
+    int cooling;
     using Cell = NoCell;
     __device__ void block_init(double *) const {}
     __device__ Cell cell_setup(int64_t, bool, bool) const { return {}; }
@@ -144,7 +174,8 @@ struct HeatConv {
         }
         // mean over an empty / all-NaN group is NaN (0/0), like xarray's resample().mean()
         const double mx = sx / double(nx), my = sy / double(ny);
-        double hx = a * (threshold_K - mx), hy = a * (threshold_K - my);
+        double hx = cooling ? a * (mx - threshold_K) : a * (threshold_K - mx);
+        double hy = cooling ? a * (my - threshold_K) : a * (threshold_K - my);
         hx = np_max(hx, 0.0);
         hy = np_max(hy, 0.0);
         double2 r;
@@ -1309,6 +1340,7 @@ int make_heat(const double *d_temperature, const atl_heat_params *p, int64_t T, 
     c->threshold_K = p->threshold_K;
     c->a = p->a;
     c->constant = p->constant;
+    c->cooling = p->cooling ? 1 : 0;
     *vec = vec_ok(S, {d_temperature});
     return ATL_OK;
 }
@@ -1450,6 +1482,23 @@ int atl_heat_demand_convert_aggregate(atl_ctx *ctx, const double *d_temperature,
     if (rc) return rc;
     return run_fused(ctx, c, vec, 0, p->n_days, S, agg, time_agg, d_out, ld_out,
                      "atl_heat_demand_convert_aggregate");
+}
+
+int atl_thermo_convert(atl_ctx *ctx, const double *d_var, const atl_thermo_params *p, int64_t T, int64_t S,
+                       int time_agg, double *d_out) {
+    ATL_REQUIRE(ctx && d_var && p, "atl_thermo_convert: bad argument");
+    ATL_REQUIRE(T >= 0 && S >= 0, "atl_thermo_convert: negative shape");
+    ThermoConv c{d_var, S, p->offset, p->sink_T, p->c0, p->c1, p->c2, p->fillna0, p->quadratic};
+    return run_cells(ctx, c, vec_ok(S, {d_var}), 0, T, S, time_agg, d_out, "atl_thermo_convert");
+}
+
+int atl_thermo_convert_aggregate(atl_ctx *ctx, const double *d_var, const atl_thermo_params *p, int64_t T,
+                                 int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out) {
+    ATL_REQUIRE(ctx && d_var && p, "atl_thermo_convert_aggregate: bad argument");
+    ATL_REQUIRE(T >= 0 && S >= 0, "atl_thermo_convert_aggregate: negative shape");
+    ThermoConv c{d_var, S, p->offset, p->sink_T, p->c0, p->c1, p->c2, p->fillna0, p->quadratic};
+    return run_fused(ctx, c, vec_ok(S, {d_var}), 0, T, S, agg, time_agg, d_out, ld_out,
+                     "atl_thermo_convert_aggregate");
 }
 
 int atl_runoff_convert(atl_ctx *ctx, const double *d_runoff, const double *d_height, int64_t T, int64_t S,

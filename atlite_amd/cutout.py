@@ -81,6 +81,11 @@ class Cutout:
     solar_thermal = _convert.solar_thermal
     wind = _convert.wind
     heat_demand = _convert.heat_demand
+    cooling_demand = _convert.cooling_demand
+    temperature = _convert.temperature
+    soil_temperature = _convert.soil_temperature
+    dewpoint_temperature = _convert.dewpoint_temperature
+    coefficient_of_performance = _convert.coefficient_of_performance
     runoff = _convert.runoff
 
     def __repr__(self):

@@ -309,12 +309,25 @@ class Context:
                                                       plan.handle, _TIME_CODES[time_agg], out.ptr, max(T, 1)))
         return out
 
-    def heat_demand(self, temperature, day_ptr, threshold_K, a, constant, T, S, plan=None, time_agg=None):
+    def thermo(self, var, T, S, offset=-273.15, fillna0=False, cop=None, plan=None, time_agg=None):
+        """temperature family (var + offset [, fillna 0]) and, with cop=(sink_T, c0, c1, c2), the COP."""
+        tp = _lib.ThermoParams(float(offset), 1 if fillna0 else 0, 0 if cop is None else 1,
+                               *(map(float, cop) if cop is not None else (0.0, 0.0, 0.0, 0.0)))
+        out = self._out(plan, T, S, time_agg)
+        if plan is None:
+            check(self.lib.atl_thermo_convert(self.handle, var.ptr, C.byref(tp), T, S, _TIME_CODES[time_agg], out.ptr))
+        else:
+            check(self.lib.atl_thermo_convert_aggregate(self.handle, var.ptr, C.byref(tp), T, S, plan.handle,
+                                                        _TIME_CODES[time_agg], out.ptr, max(T, 1)))
+        return out
+
+    def heat_demand(self, temperature, day_ptr, threshold_K, a, constant, T, S, plan=None, time_agg=None,
+                    cooling=False):
         day_ptr = np.ascontiguousarray(day_ptr, dtype=np.int64)
         D = len(day_ptr) - 1
         assert D >= 0 and day_ptr[0] >= 0 and day_ptr[-1] <= T and np.all(np.diff(day_ptr) >= 0)
         d_ptr = self.upload(day_ptr, np.int64)
-        hp = _lib.HeatParams(float(threshold_K), float(a), float(constant), D, d_ptr.ptr)
+        hp = _lib.HeatParams(float(threshold_K), float(a), float(constant), D, d_ptr.ptr, 1 if cooling else 0)
         out = self._out(plan, D, S, time_agg)
         if plan is None:
             check(self.lib.atl_heat_demand_convert(self.handle, temperature.ptr, C.byref(hp), T, S,

@@ -218,6 +218,7 @@ typedef struct {
     double threshold_K, a, constant;
     int64_t n_days;
     const int64_t *d_day_ptr; /* DEVICE (n_days+1) */
+    int cooling; /* 0: heat demand a*(threshold - T); 1: convert_cooling_demand (convert.py:475-490) a*(T - threshold) */
 } atl_heat_params;
 
 int atl_heat_demand_convert(atl_ctx *ctx, const double *d_temperature,
@@ -227,6 +228,24 @@ int atl_heat_demand_convert_aggregate(atl_ctx *ctx, const double *d_temperature,
                                       const atl_heat_params *p, int64_t T, int64_t S,
                                       const atl_agg *agg, int time_agg,
                                       double *d_out /* (N x D) or (N) */, int64_t ld_out);
+
+/* ---- temperatures and heat-pump COP ----------------------------------------------------------
+ * Replaces convert_temperature / convert_soil_temperature / convert_dewpoint_temperature
+ * (convert.py:292-335): x = var + offset (offset = -273.15), fillna0 for the soil variant; and
+ * convert_coefficient_of_performance (convert.py:338-364) when quadratic != 0:
+ * d = sink_T - x; out = c0 + c1*d + c2*d*d.
+ */
+typedef struct {
+    double offset;
+    int fillna0;
+    int quadratic;
+    double sink_T, c0, c1, c2;
+} atl_thermo_params;
+
+int atl_thermo_convert(atl_ctx *ctx, const double *d_var, const atl_thermo_params *p, int64_t T, int64_t S,
+                       int time_agg, double *d_out);
+int atl_thermo_convert_aggregate(atl_ctx *ctx, const double *d_var, const atl_thermo_params *p, int64_t T,
+                                 int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out);
 
 /* ---- runoff --------------------------------------------------------------------------
  * Replaces convert_runoff (convert.py:1028-1034): runoff * height (height static (S)),

@@ -481,3 +481,43 @@ def convert_solar_thermal(ds, orientation, trigon_model="simple", clearsky_model
         eta = c0 - c1 * _fillna0((t_store - ds["temperature"]) / np.where(irr != 0, irr, np.nan))
         output = irr * eta
         return np.where(output > 0.0, output, 0.0)
+
+
+# --------------------------------------------------------------------------------------
+# temperatures, COP, cooling demand
+# --------------------------------------------------------------------------------------
+
+
+def convert_temperature(T):
+    """convert_temperature / convert_dewpoint_temperature, atlite/convert.py:292-299, 326-330."""
+    return T - 273.15
+
+
+def convert_soil_temperature(T):
+    """convert_soil_temperature, atlite/convert.py:307-318."""
+    return _fillna0(T - 273.15)
+
+
+def convert_coefficient_of_performance(T, source="air", sink_T=55.0, c0=None, c1=None, c2=None):
+    """convert_coefficient_of_performance, atlite/convert.py:338-364 (T = air or soil temperature, K)."""
+    if source == "air":
+        source_T = convert_temperature(T)
+        d = (6.81, -0.121, 0.000630)
+    else:
+        source_T = convert_soil_temperature(T)
+        d = (8.77, -0.150, 0.000734)
+    c0, c1, c2 = (d[i] if v is None else v for i, v in enumerate((c0, c1, c2)))
+    delta_T = sink_T - source_T
+    return c0 + c1 * delta_T + c2 * delta_T**2
+
+
+def convert_cooling_demand(temperature, day_ptr, threshold=23.0, a=1.0, constant=0.0):
+    """convert_cooling_demand, atlite/convert.py:475-490."""
+    D = len(day_ptr) - 1
+    Tm = np.full((D,) + temperature.shape[1:], np.nan)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for d in range(D):
+            blk = temperature[day_ptr[d] : day_ptr[d + 1]]
+            if blk.shape[0]:
+                Tm[d] = np.nansum(blk, axis=0) / np.sum(~np.isnan(blk), axis=0)
+        return constant + np.clip(a * (Tm - (threshold + 273.15)), 0.0, None)

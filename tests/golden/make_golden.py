@@ -205,6 +205,19 @@ def main():
         da = conv.convert_heat_demand(dsh, threshold=15.0, a=1.3, constant=0.2, hour_shift=shift)
         hout[f"out_shift{shift:+.0f}"] = da.values
         hout[f"days_shift{shift:+.0f}"] = da.coords["time"].values.astype("datetime64[ns]").astype(np.int64)
+    for shift in (0.0, 3.0):
+        da = conv.convert_cooling_demand(dsh, threshold=3.0, a=0.7, constant=0.1, hour_shift=shift)
+        hout[f"cool_shift{shift:+.0f}"] = da.values
+    soil = 278.15 + 5 * rng.standard_normal((Th, Y, X))
+    soil[:, 0, :3] = np.nan  # sea
+    dew = 275.15 + 6 * rng.standard_normal((Th, Y, X))
+    dst = dataset({"temperature": temp, "soil temperature": soil, "dewpoint temperature": dew}, th)
+    hout["soil"], hout["dew"] = soil, dew
+    hout["out_temperature"] = conv.convert_temperature(dst).values
+    hout["out_soil_temperature"] = conv.convert_soil_temperature(dst).values
+    hout["out_dewpoint_temperature"] = conv.convert_dewpoint_temperature(dst).values
+    hout["out_cop_air"] = conv.convert_coefficient_of_performance(dst, "air", 55.0, None, None, None).values
+    hout["out_cop_soil"] = conv.convert_coefficient_of_performance(dst, "soil", 45.0, None, -0.14, None).values
     save("heat_demand", time=th.values.astype("datetime64[ns]").astype(np.int64), x=x, y=y, temperature=temp, **hout)
 
     ro = -1e-4 * np.log1p(-rng.random((Th, Y, X)))

@@ -315,3 +315,24 @@ def test_pv_influx_only_dataset(cs, tm, key):
     c = cutout_from(gg, ("influx", "influx_toa", "outflux", "temperature", "humidity", "solar_altitude", "solar_azimuth"))
     r = c.pv(panel="CSi", orientation=dict(O30), trigon_model=tm, clearsky_model=cs, aggregate_time=None)
     close(r.values, o[key])
+
+
+def test_temperatures_cop_cooling():
+    g = load("heat_demand")
+    t = pd.DatetimeIndex(g["time"].astype("datetime64[ns]"))
+    c = Cutout(Dataset({"temperature": g["temperature"], "soil temperature": g["soil"], "dewpoint temperature": g["dew"]},
+                       dict(time=t, y=g["y"], x=g["x"])))
+    close(c.temperature(aggregate_time=None).values, g["out_temperature"])
+    close(c.soil_temperature(aggregate_time=None).values, g["out_soil_temperature"])
+    close(c.dewpoint_temperature(aggregate_time=None).values, g["out_dewpoint_temperature"])
+    close(c.coefficient_of_performance(aggregate_time=None).values, g["out_cop_air"])
+    close(c.coefficient_of_performance(source="soil", sink_T=45.0, c1=-0.14, aggregate_time=None).values, g["out_cop_soil"])
+    for shift in (0.0, 3.0):
+        r = c.cooling_demand(threshold=3.0, a=0.7, constant=0.1, hour_shift=shift, aggregate_time=None)
+        assert r.name == "cooling_demand"
+        close(r.values, g[f"cool_shift{shift:+.0f}"], atol_scale=1e-9)
+    # soil temperature NaNs (sea) must not poison an aggregation (convert.py:313-316)
+    S = len(g["y"]) * len(g["x"])
+    M = sp.csr_matrix(np.ones((1, S)))
+    r = c.soil_temperature(matrix=M, aggregate_time=None)
+    close(r.values[0], g["out_soil_temperature"].reshape(len(t), -1).sum(1))

@@ -186,3 +186,18 @@ def test_pv_influx_only_dataset(cs, tm, key):
                humidity=o["humidity"], solar_altitude=ds["solar_altitude"], solar_azimuth=ds["solar_azimuth"])
     out = orc.convert_pv_general(ds2, H.CSI, orc.orientation_constant(30.0, 180.0), trigon_model=tm, clearsky_model=cs)
     tol(out, o[key])
+
+
+def test_temperatures_cop_cooling():
+    g = load("heat_demand")
+    exact(orc.convert_temperature(g["temperature"]), g["out_temperature"])
+    exact(orc.convert_soil_temperature(g["soil"]), g["out_soil_temperature"])
+    exact(orc.convert_temperature(g["dew"]), g["out_dewpoint_temperature"])
+    np.testing.assert_allclose(orc.convert_coefficient_of_performance(g["temperature"], "air", 55.0), g["out_cop_air"],
+                               rtol=1e-15, equal_nan=True)
+    np.testing.assert_allclose(orc.convert_coefficient_of_performance(g["soil"], "soil", 45.0, None, -0.14, None),
+                               g["out_cop_soil"], rtol=1e-15)
+    for shift in (0.0, 3.0):
+        ptr, _ = orc.day_groups(times(g["time"]), shift)
+        np.testing.assert_allclose(orc.convert_cooling_demand(g["temperature"], ptr, 3.0, 0.7, 0.1),
+                                   g[f"cool_shift{shift:+.0f}"], rtol=1e-15, equal_nan=True)
