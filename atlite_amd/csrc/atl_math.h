@@ -10,8 +10,8 @@
 // Accuracy (measured against numpy on the GPU, tests/test_gpu_math.py): <= 2 ulp for
 // sincos on |x| < 2^20, absolute error < 2.3e-16 up to |x| < 2^30; |x| >= 2^30 returns NaN
 // (numpy would still return a value there; solar angles that large are not physical).
-// log: <= 1 ulp on positive normal and subnormal arguments; log(0) = -inf, log(<0) = NaN,
-// log(inf) = inf.
+// log: <= 1 ulp on positive normal arguments; zero / subnormal / negative / inf / NaN go to
+// libm's log (log_rare).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -122,15 +122,15 @@ __device__ __forceinline__ double log_core(double x) {
            ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
 }
 
+// zero, subnormal, negative, inf, NaN: full libm, kept out of line so that the hot loops carry
+// only a never-taken branch
+__device__ __noinline__ double log_rare(double x) { return log(x); }
+
 __device__ __forceinline__ double lean_log(double x) {
-    // ordinary arguments take log_core; zero, subnormal, negative, inf and NaN take the (rare,
-    // exec-masked) slow path
-    if (x >= 0x1.0p-1022 && x < __builtin_inf()) return log_core(x);
-    if (x != x) return x;
-    if (x < 0.0) return __builtin_nan("");
-    if (x == 0.0) return -__builtin_inf();
-    if (x == __builtin_inf()) return x;
-    return log_core(x * 0x1.0p54) - 54.0 * 6.93147180559945286227e-01;  // subnormal
+    const bool ok = x >= 0x1.0p-1022 && x < __builtin_inf();
+    double r = log_core(ok ? x : 1.0);
+    if (__builtin_expect(!ok, 0)) r = log_rare(x);
+    return r;
 }
 
 }  // namespace atl
