@@ -30,6 +30,9 @@
 #ifndef ATL_FUSED_WAVES
 #define ATL_FUSED_WAVES 3  // waves per SIMD the register allocation must allow (<= 168 VGPRs)
 #endif
+#ifndef ATL_PV_GROUP
+#define ATL_PV_GROUP 1
+#endif
 #ifndef ATL_ROW_CACHE
 #define ATL_ROW_CACHE 3
 #endif
@@ -50,23 +53,22 @@ __device__ __forceinline__ double np_clip(double x, double lo, double hi) {
     return np_min(np_max(x, lo), hi);
 }
 
+// Loads of the lane's two cells.  c0 / c1 are SAFE cell indices (always inside the cube, equal to
+// the lane's real cells when those exist, else cells 0 / 1), so the loads are unconditional:
+// no branch, no per-load wait - the caller masks the result of invalid lanes afterwards.
+// Every input byte is read exactly once -> nontemporal (+5..8 % measured); with VEC the two
+// loads fuse into one global_load_dwordx4 nt.
 template <bool VEC>
-__device__ __forceinline__ double2 ld2(const double *__restrict__ p, int64_t off, bool v0, bool v1) {
+__device__ __forceinline__ double2 ld2(const double *__restrict__ p, int64_t base, int64_t c0, int64_t c1) {
     double2 r;
     if constexpr (VEC) {
-        // S even and base 16-B aligned: both cells valid or both invalid
-        if (v0) {
-            // every input byte is read exactly once: nontemporal (measured +5..8 % on pv, heat,
-            // wind series; the two loads fuse into one global_load_dwordx4 nt)
-            r.x = __builtin_nontemporal_load(p + off);
-            r.y = __builtin_nontemporal_load(p + off + 1);
-        } else {
-            r.x = 0.0;
-            r.y = 0.0;
-        }
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        const f64x2 t = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(p + base + c0));
+        r.x = t.x;
+        r.y = t.y;
     } else {
-        r.x = v0 ? __builtin_nontemporal_load(p + off) : 0.0;
-        r.y = v1 ? __builtin_nontemporal_load(p + off + 1) : 0.0;
+        r.x = __builtin_nontemporal_load(p + base + c0);
+        r.y = __builtin_nontemporal_load(p + base + c1);
     }
     return r;
 }
@@ -91,10 +93,14 @@ struct IdentityConv {
     using Cell = NoCell;
     __device__ void block_init(double *) const {}
     __device__ Cell cell_setup(int64_t, bool, bool) const { return {}; }
+    static constexpr int kGroup = 8;  // slots whose loads are issued before any compute
+    using Raw = double2;
     template <bool VEC>
-    __device__ __forceinline__ double2 eval(int64_t slot, int64_t c0, bool v0, bool v1, const Cell &,
-                                            const double *) const {
-        return ld2<VEC>(d, slot * S + c0, v0, v1);
+    __device__ __forceinline__ Raw load(int64_t slot, int64_t c0, int64_t c1, const Cell &) const {
+        return ld2<VEC>(d, slot * S, c0, c1);
+    }
+    __device__ __forceinline__ double2 compute(const Raw &r, bool, bool, const Cell &, const double *) const {
+        return r;
     }
 };
 
@@ -113,10 +119,13 @@ struct RunoffConv {
         c.h.y = (height && v1) ? height[c0 + 1] : 1.0;
         return c;
     }
+    static constexpr int kGroup = 8;
+    using Raw = double2;
     template <bool VEC>
-    __device__ __forceinline__ double2 eval(int64_t slot, int64_t c0, bool v0, bool v1, const Cell &c,
-                                            const double *) const {
-        double2 r = ld2<VEC>(runoff, slot * S + c0, v0, v1);
+    __device__ __forceinline__ Raw load(int64_t slot, int64_t c0, int64_t c1, const Cell &) const {
+        return ld2<VEC>(runoff, slot * S, c0, c1);
+    }
+    __device__ __forceinline__ double2 compute(Raw r, bool, bool, const Cell &c, const double *) const {
         if (height) {
             r.x *= c.h.x;
             r.y *= c.h.y;
@@ -143,10 +152,13 @@ struct ThermoConv {
         }
         return x;
     }
+    static constexpr int kGroup = 8;
+    using Raw = double2;
     template <bool VEC>
-    __device__ __forceinline__ double2 eval(int64_t slot, int64_t c0_, bool v0, bool v1, const Cell &,
-                                            const double *) const {
-        const double2 v = ld2<VEC>(var, slot * S + c0_, v0, v1);
+    __device__ __forceinline__ Raw load(int64_t slot, int64_t c0_, int64_t c1_, const Cell &) const {
+        return ld2<VEC>(var, slot * S, c0_, c1_);
+    }
+    __device__ __forceinline__ double2 compute(const Raw &v, bool v0, bool v1, const Cell &, const double *) const {
         double2 r;
         r.x = v0 ? f(v.x) : 0.0;
         r.y = v1 ? f(v.y) : 0.0;
@@ -164,26 +176,32 @@ struct HeatConv {
     using Cell = NoCell;
     __device__ void block_init(double *) const {}
     __device__ Cell cell_setup(int64_t, bool, bool) const { return {}; }
+    static constexpr int kGroup = 1;  // a slot is a whole day: its own loop keeps 8 loads in flight
+    struct Raw {
+        double sx, sy;
+        int nx, ny;
+    };
     template <bool VEC>
-    __device__ __forceinline__ double2 eval(int64_t slot, int64_t c0, bool v0, bool v1, const Cell &,
-                                            const double *) const {
+    __device__ __forceinline__ Raw load(int64_t slot, int64_t c0, int64_t c1, const Cell &) const {
         const int64_t t0 = day_ptr[slot], t1 = day_ptr[slot + 1];
-        double sx = 0.0, sy = 0.0;
-        int nx = 0, ny = 0;
+        Raw r{0.0, 0.0, 0, 0};
 #pragma unroll 8
         for (int64_t t = t0; t < t1; ++t) {
-            double2 v = ld2<VEC>(temperature, t * S + c0, v0, v1);
+            const double2 v = ld2<VEC>(temperature, t * S, c0, c1);
             if (!dnan(v.x)) {
-                sx += v.x;
-                ++nx;
+                r.sx += v.x;
+                ++r.nx;
             }
             if (!dnan(v.y)) {
-                sy += v.y;
-                ++ny;
+                r.sy += v.y;
+                ++r.ny;
             }
         }
+        return r;
+    }
+    __device__ __forceinline__ double2 compute(const Raw &q, bool, bool, const Cell &, const double *) const {
         // mean over an empty / all-NaN group is NaN (0/0), like xarray's resample().mean()
-        const double mx = sx / double(nx), my = sy / double(ny);
+        const double mx = q.sx / double(q.nx), my = q.sy / double(q.ny);
         double hx = cooling ? a * (mx - threshold_K) : a * (threshold_K - mx);
         double hy = cooling ? a * (my - threshold_K) : a * (threshold_K - my);
         hx = np_max(hx, 0.0);
@@ -308,12 +326,21 @@ struct WindConvT {
         }
         return r;
     }
+    static constexpr int kGroup = 4;
+    struct Raw {
+        double2 v, z;
+    };
     template <bool VEC>
-    __device__ __forceinline__ double2 eval(int64_t slot, int64_t c0, bool v0, bool v1, const Cell &c,
-                                            const double *lds) const {
-        double2 v = ld2<VEC>(wnd, slot * S + c0, v0, v1);
-        double2 z = c.aux;
-        if (METHOD != ATL_WIND_NONE && !aux_static) z = ld2<VEC>(aux, slot * S + c0, v0, v1);
+    __device__ __forceinline__ Raw load(int64_t slot, int64_t c0, int64_t c1, const Cell &c) const {
+        Raw r;
+        r.v = ld2<VEC>(wnd, slot * S, c0, c1);
+        r.z = c.aux;
+        if (METHOD != ATL_WIND_NONE && !aux_static) r.z = ld2<VEC>(aux, slot * S, c0, c1);
+        return r;
+    }
+    __device__ __forceinline__ double2 compute(const Raw &q, bool v0, bool v1, const Cell &c,
+                                               const double *lds) const {
+        const double2 v = q.v, z = q.z;
         double2 r;
         if constexpr (METHOD < 0) {
             r.x = interp_generic(hub_speed_literal(v.x, z.x), lds);
@@ -475,28 +502,44 @@ struct PvConvT {
         }
         return c;
     }
+    static constexpr int kGroup = ATL_PV_GROUP;  // 7 x 16 B per lane per slot already; registers are the limit
+    struct Raw {
+        double2 dir, dif, toa, alb, tmp;
+        double2 a, b;    // getter: altitude, azimuth   SP: hour angle, cos(hour angle)
+        double sd, cd;   // SP: sin / cos declination of the slot
+    };
     template <bool VEC>
-    __device__ __forceinline__ double2 eval(int64_t slot, int64_t c0, bool v0, bool v1, const Cell &c,
-                                            const double *) const {
-        const int64_t off = slot * S + c0;
-        const double2 dir = ld2<VEC>(in.d_influx_direct, off, v0, v1);
-        const double2 dif = ld2<VEC>(in.d_influx_diffuse, off, v0, v1);
-        const double2 toa = ld2<VEC>(in.d_influx_toa, off, v0, v1);
-        const double2 alb = ld2<VEC>(in.d_albedo, off, v0, v1);
-        const double2 tmp = ld2<VEC>(in.d_temperature, off, v0, v1);
+    __device__ __forceinline__ Raw load(int64_t slot, int64_t c0, int64_t c1, const Cell &c) const {
+        const int64_t off = slot * S;
+        Raw r;
+        r.dir = ld2<VEC>(in.d_influx_direct, off, c0, c1);
+        r.dif = ld2<VEC>(in.d_influx_diffuse, off, c0, c1);
+        r.toa = ld2<VEC>(in.d_influx_toa, off, c0, c1);
+        r.alb = ld2<VEC>(in.d_albedo, off, c0, c1);
+        r.tmp = ld2<VEC>(in.d_temperature, off, c0, c1);
+        if constexpr (SP) {
+            r.sd = in.d_sin_dec[slot];
+            r.cd = in.d_cos_dec[slot];
+            const int64_t hb = slot * in.X;
+            r.a.x = in.d_hour_angle[hb + c.x0];
+            r.a.y = in.d_hour_angle[hb + c.x1];
+            r.b.x = in.d_cos_hour_angle[hb + c.x0];
+            r.b.y = in.d_cos_hour_angle[hb + c.x1];
+        } else {
+            r.sd = r.cd = 0.0;
+            r.a = ld2<VEC>(in.d_solar_altitude, off, c0, c1);
+            r.b = ld2<VEC>(in.d_solar_azimuth, off, c0, c1);
+        }
+        return r;
+    }
+    __device__ __forceinline__ double2 compute(const Raw &q, bool v0, bool v1, const Cell &c, const double *) const {
         double2 r;
         if constexpr (SP) {
-            const double sd = in.d_sin_dec[slot], cd = in.d_cos_dec[slot];
-            const int64_t hb = slot * in.X;
-            const double h0 = in.d_hour_angle[hb + c.x0], h1 = in.d_hour_angle[hb + c.x1];
-            const double ch0 = in.d_cos_hour_angle[hb + c.x0], ch1 = in.d_cos_hour_angle[hb + c.x1];
-            r.x = v0 ? pv_cell_sp(dir.x, dif.x, toa.x, alb.x, tmp.x, sd, cd, c.sl0, c.cl0, h0, ch0, c.o0, c.a0, k) : 0.0;
-            r.y = v1 ? pv_cell_sp(dir.y, dif.y, toa.y, alb.y, tmp.y, sd, cd, c.sl1, c.cl1, h1, ch1, c.o1, c.a1, k) : 0.0;
+            r.x = v0 ? pv_cell_sp(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.sd, q.cd, c.sl0, c.cl0, q.a.x, q.b.x, c.o0, c.a0, k) : 0.0;
+            r.y = v1 ? pv_cell_sp(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.sd, q.cd, c.sl1, c.cl1, q.a.y, q.b.y, c.o1, c.a1, k) : 0.0;
         } else {
-            const double2 alt = ld2<VEC>(in.d_solar_altitude, off, v0, v1);
-            const double2 az = ld2<VEC>(in.d_solar_azimuth, off, v0, v1);
-            r.x = v0 ? pv_cell(dir.x, dif.x, toa.x, alb.x, tmp.x, alt.x, az.x, c.o0, k) : 0.0;
-            r.y = v1 ? pv_cell(dir.y, dif.y, toa.y, alb.y, tmp.y, alt.y, az.y, c.o1, k) : 0.0;
+            r.x = v0 ? pv_cell(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.a.x, q.b.x, c.o0, k) : 0.0;
+            r.y = v1 ? pv_cell(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.a.y, q.b.y, c.o1, k) : 0.0;
         }
         return r;
     }
@@ -676,32 +719,38 @@ struct PvxConv {
         *alt = a;
         *az = z;
     }
+    static constexpr int kGroup = 1;
+    struct Raw {
+        double2 dir, dif, inf, toa, alb, ouf, tmp, hum, alt, az;
+    };
     template <bool VEC>
-    __device__ __forceinline__ double2 eval(int64_t slot, int64_t c0, bool v0, bool v1, const Cell &c,
-                                            const double *) const {
-        const int64_t off = slot * S + c0;
+    __device__ __forceinline__ Raw load(int64_t slot, int64_t c0, int64_t c1, const Cell &c) const {
+        const int64_t off = slot * S;
         const double2 zero = {0.0, 0.0};
-        const double2 dir = in.d_influx_direct ? ld2<VEC>(in.d_influx_direct, off, v0, v1) : zero;
-        const double2 dif = in.d_influx_diffuse ? ld2<VEC>(in.d_influx_diffuse, off, v0, v1) : zero;
-        const double2 inf = in.d_influx ? ld2<VEC>(in.d_influx, off, v0, v1) : zero;
-        const double2 toa = ld2<VEC>(in.d_influx_toa, off, v0, v1);
-        const double2 alb = in.d_albedo ? ld2<VEC>(in.d_albedo, off, v0, v1) : zero;
-        const double2 ouf = in.d_outflux ? ld2<VEC>(in.d_outflux, off, v0, v1) : zero;
-        const double2 tmp = in.d_temperature ? ld2<VEC>(in.d_temperature, off, v0, v1) : zero;
-        const double2 hum = in.d_humidity ? ld2<VEC>(in.d_humidity, off, v0, v1) : zero;
-        double2 alt, az;
+        Raw r;
+        r.dir = in.d_influx_direct ? ld2<VEC>(in.d_influx_direct, off, c0, c1) : zero;
+        r.dif = in.d_influx_diffuse ? ld2<VEC>(in.d_influx_diffuse, off, c0, c1) : zero;
+        r.inf = in.d_influx ? ld2<VEC>(in.d_influx, off, c0, c1) : zero;
+        r.toa = ld2<VEC>(in.d_influx_toa, off, c0, c1);
+        r.alb = in.d_albedo ? ld2<VEC>(in.d_albedo, off, c0, c1) : zero;
+        r.ouf = in.d_outflux ? ld2<VEC>(in.d_outflux, off, c0, c1) : zero;
+        r.tmp = in.d_temperature ? ld2<VEC>(in.d_temperature, off, c0, c1) : zero;
+        r.hum = in.d_humidity ? ld2<VEC>(in.d_humidity, off, c0, c1) : zero;
         if (in.d_solar_altitude) {
-            alt = ld2<VEC>(in.d_solar_altitude, off, v0, v1);
-            az = ld2<VEC>(in.d_solar_azimuth, off, v0, v1);
+            r.alt = ld2<VEC>(in.d_solar_altitude, off, c0, c1);
+            r.az = ld2<VEC>(in.d_solar_azimuth, off, c0, c1);
         } else {
             const double sd = in.d_sin_dec[slot], cd = in.d_cos_dec[slot];
             const int64_t hb = slot * in.X;
-            solar(sd, cd, c.slat0, c.clat0, in.d_hour_angle[hb + c.x0], in.d_cos_hour_angle[hb + c.x0], &alt.x, &az.x);
-            solar(sd, cd, c.slat1, c.clat1, in.d_hour_angle[hb + c.x1], in.d_cos_hour_angle[hb + c.x1], &alt.y, &az.y);
+            solar(sd, cd, c.slat0, c.clat0, in.d_hour_angle[hb + c.x0], in.d_cos_hour_angle[hb + c.x0], &r.alt.x, &r.az.x);
+            solar(sd, cd, c.slat1, c.clat1, in.d_hour_angle[hb + c.x1], in.d_cos_hour_angle[hb + c.x1], &r.alt.y, &r.az.y);
         }
+        return r;
+    }
+    __device__ __forceinline__ double2 compute(const Raw &q, bool v0, bool v1, const Cell &c, const double *) const {
         double2 r;
-        r.x = v0 ? pvx_cell(dir.x, dif.x, inf.x, toa.x, alb.x, ouf.x, tmp.x, hum.x, alt.x, az.x, c.sl0, c.az0, k, o) : 0.0;
-        r.y = v1 ? pvx_cell(dir.y, dif.y, inf.y, toa.y, alb.y, ouf.y, tmp.y, hum.y, alt.y, az.y, c.sl1, c.az1, k, o) : 0.0;
+        r.x = v0 ? pvx_cell(q.dir.x, q.dif.x, q.inf.x, q.toa.x, q.alb.x, q.ouf.x, q.tmp.x, q.hum.x, q.alt.x, q.az.x, c.sl0, c.az0, k, o) : 0.0;
+        r.y = v1 ? pvx_cell(q.dir.y, q.dif.y, q.inf.y, q.toa.y, q.alb.y, q.ouf.y, q.tmp.y, q.hum.y, q.alt.y, q.az.y, c.sl1, c.az1, k, o) : 0.0;
         return r;
     }
 };
@@ -720,14 +769,20 @@ __global__ __launch_bounds__(256) void k_cells_series(Conv conv, int64_t n_slots
     __syncthreads();
     const int64_t c0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * 2;
     const bool v0 = c0 < S, v1 = c0 + 1 < S;
+    const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);  // safe indices
     const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1);
     const int64_t s0 = int64_t(blockIdx.y) * kSeriesSlots;
-#pragma unroll 2
-    for (int i = 0; i < kSeriesSlots; ++i) {
-        const int64_t slot = s0 + i;
-        if (slot >= n_slots) break;
-        const double2 r = conv.template eval<VEC>(slot, c0, v0, v1, cell, lds);
-        st2<VEC>(out, slot * S + c0, v0, v1, r);
+    const int64_t s1 = min(s0 + int64_t(kSeriesSlots), n_slots);
+    constexpr int G = Conv::kGroup >= 4 ? 4 : Conv::kGroup;
+    for (int64_t sg = s0; sg < s1; sg += G) {
+        typename Conv::Raw raw[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) raw[g] = conv.template load<VEC>(min(sg + g, s1 - 1), s0c, s1c, cell);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const double2 r = conv.compute(raw[g], v0, v1, cell, lds);
+            if (sg + g < s1) st2<VEC>(out, (sg + g) * S + c0, v0, v1, r);
+        }
     }
 }
 
@@ -743,20 +798,28 @@ __global__ __launch_bounds__(256) void k_cells_timered(Conv conv, int64_t n_slot
     __syncthreads();
     const int64_t c0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * 2;
     const bool v0 = c0 < S, v1 = c0 + 1 < S;
+    const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);  // safe indices
     const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1);
     const int64_t s0 = int64_t(blockIdx.y) * chunk_len;
     const int64_t s1 = min(s0 + chunk_len, n_slots);
     double2 acc = {0.0, 0.0}, cnt = {0.0, 0.0};
-#pragma unroll 2
-    for (int64_t slot = s0; slot < s1; ++slot) {
-        const double2 r = conv.template eval<VEC>(slot, c0, v0, v1, cell, lds);
-        if (!dnan(r.x)) {
-            acc.x += r.x;
-            cnt.x += 1.0;
-        }
-        if (!dnan(r.y)) {
-            acc.y += r.y;
-            cnt.y += 1.0;
+    constexpr int G = Conv::kGroup >= 4 ? 4 : Conv::kGroup;
+    for (int64_t sg = s0; sg < s1; sg += G) {
+        typename Conv::Raw raw[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) raw[g] = conv.template load<VEC>(min(sg + g, s1 - 1), s0c, s1c, cell);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const double2 r = conv.compute(raw[g], v0, v1, cell, lds);
+            const bool live = sg + g < s1;
+            if (live && !dnan(r.x)) {
+                acc.x += r.x;
+                cnt.x += 1.0;
+            }
+            if (live && !dnan(r.y)) {
+                acc.y += r.y;
+                cnt.y += 1.0;
+            }
         }
     }
     const int64_t o = int64_t(blockIdx.y) * S + c0;
@@ -874,6 +937,7 @@ __global__ __launch_bounds__(256, ATL_FUSED_WAVES) void k_fused_segred(Conv conv
     const int64_t c0 = gy * plan.X + gx;
     const bool v0 = gy < plan.Y && gx >= 0 && gx < plan.X;
     const bool v1 = gy < plan.Y && gx + 1 >= 0 && gx + 1 < plan.X;
+    const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);  // safe indices: loads never branch
     const int32_t p0 = plan.seg_ptr[seg], p1 = plan.seg_ptr[seg + 1];
     if (p0 == p1) return;  // no shape touches this tile: nothing to read
     const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1);
@@ -897,17 +961,27 @@ __global__ __launch_bounds__(256, ATL_FUSED_WAVES) void k_fused_segred(Conv conv
     for (int64_t sb = sbeg; sb < send; sb += kBatch) {
         double2 v[kBatch];
         bool finite = true;
+        // kGroup slots are LOADED before any of them is converted, so a light converter keeps 8
+        // independent 1-KiB loads in flight per wave; slots past the end of a ragged chunk re-load
+        // its last slot (loads stay unconditional) and are zeroed afterwards.
+        constexpr int G = Conv::kGroup;
 #pragma unroll
-        for (int i = 0; i < kBatch; ++i) {
-            const int64_t slot = sb + i;
-            if (slot < send) {
-                v[i] = conv.template eval<VEC>(slot, c0, v0, v1, cell, lds);
-            } else {
-                v[i].x = 0.0;
-                v[i].y = 0.0;
+        for (int i0 = 0; i0 < kBatch; i0 += G) {
+            typename Conv::Raw raw[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                raw[g] = conv.template load<VEC>(min(sb + i0 + g, send - 1), s0c, s1c, cell);
             }
-            // |x| < inf is false for NaN and +-inf
-            finite = finite && (__builtin_fabs(v[i].x) < __builtin_inf()) && (__builtin_fabs(v[i].y) < __builtin_inf());
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int i = i0 + g;
+                const bool live = sb + i < send;
+                v[i] = conv.compute(raw[g], v0, v1, cell, lds);
+                v[i].x = live ? v[i].x : 0.0;
+                v[i].y = live ? v[i].y : 0.0;
+                // |x| < inf is false for NaN and +-inf
+                finite = finite && (__builtin_fabs(v[i].x) < __builtin_inf()) && (__builtin_fabs(v[i].y) < __builtin_inf());
+            }
         }
 #ifdef ATL_ABLATE_NOREDUCE  // experiment: conversion only, one dummy store per batch
         {
