@@ -145,6 +145,14 @@ SIGNATURES = {
     "atl_upload": (_i, [_vp, _vp, _vp, _sz]),
     "atl_download": (_i, [_vp, _vp, _vp, _sz]),
     "atl_memset": (_i, [_vp, _vp, _i, _sz]),
+    "atl_host_register": (_i, [_vp, _sz]),
+    "atl_host_unregister": (_i, [_vp]),
+    "atl_upload_async": (_i, [_vp, _vp, _vp, _sz]),
+    "atl_event_create": (_i, [_vp, C.POINTER(_vp)]),
+    "atl_event_destroy": (_i, [_vp]),
+    "atl_event_record": (_i, [_vp, _vp, _i]),
+    "atl_stream_wait_event": (_i, [_vp, _i, _vp]),
+    "atl_event_synchronize": (_i, [_vp]),
     "atl_timer_start": (_i, [_vp]),
     "atl_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
     "atl_set_profiling": (_i, [_vp, _i]),

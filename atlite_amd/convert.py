@@ -41,16 +41,40 @@ logger = logging.getLogger(__name__)
 # converter descriptors
 # --------------------------------------------------------------------------------------
 class _Spec:
-    """A resolved conversion: knows its output time axis and how to launch itself."""
+    """
+    A resolved conversion: knows its output time axis and how to launch itself, either on the whole
+    dataset (``run``) or slab by slab for host-resident data (``atlite_amd.streaming``):
+    ``time_vars`` / ``static_vars`` name the inputs, ``slab_edges`` cuts the time axis,
+    ``for_slab`` returns the spec restricted to a slab, ``out_slots`` its output slot range,
+    ``prepare`` uploads per-call constant tables once.
+    """
 
     name = None
     attrs = {}
+    time_vars = ()
+    static_vars = ()
 
     def time_coord(self, ds):
         return ds.coords["time"]
 
-    def run(self, ctx, ds, plan, time_agg):  # -> DeviceArray
+    def n_slots(self, ds):
+        return len(self.time_coord(ds))
+
+    def run(self, ctx, ds, plan, time_agg, out=None):  # -> DeviceArray
         raise NotImplementedError
+
+    # -- slab interface ----------------------------------------------------------------------
+    def slab_edges(self, T, steps):
+        return [(a, min(a + steps, T)) for a in range(0, T, steps)]
+
+    def for_slab(self, t0, t1):
+        return self
+
+    def out_slots(self, t0, t1):
+        return t0, t1
+
+    def prepare(self, ctx, ds):
+        pass
 
 
 def _need(ds, names, exc, msg):
@@ -164,16 +188,39 @@ class _PvSpec(_Spec):
             return float(a)
         return np.ascontiguousarray(np.broadcast_to(a, (Y, X))).reshape(-1)
 
-    def run(self, ctx, ds, plan, time_agg):
+    @property
+    def time_vars(self):
+        return tuple(dict.fromkeys(self.vars))
+
+    def prepare(self, ctx, ds):
+        """Upload the per-call constant tables once (per-cell orientation, solar position tables)."""
+        S = len(ds.coords["y"]) * len(ds.coords["x"])
+        if np.ndim(self.slope) != np.ndim(self.azimuth):  # mixed scalar / per-cell -> per-cell
+            self.slope = np.broadcast_to(self.slope, (S,))
+            self.azimuth = np.broadcast_to(self.azimuth, (S,))
+        if isinstance(self.slope, np.ndarray):
+            self.slope, self.azimuth = ctx.upload(self.slope), ctx.upload(self.azimuth)
+        if self.solar_tables is not None and isinstance(self.solar_tables["h"], np.ndarray):
+            self.solar_tables = {k: ctx.upload(np.ascontiguousarray(v)) for k, v in self.solar_tables.items()}
+
+    def for_slab(self, t0, t1):
+        if self.solar_tables is None:
+            return self
+        import copy
+
+        sub = copy.copy(self)
+        tb = self.solar_tables
+        sub.solar_tables = dict(tb, sin_dec=tb["sin_dec"].slab(t0, t1), cos_dec=tb["cos_dec"].slab(t0, t1),
+                                h=tb["h"].slab(t0, t1), cos_h=tb["cos_h"].slab(t0, t1))
+        return sub
+
+    def run(self, ctx, ds, plan, time_agg, out=None):
         T, S = len(ds.coords["time"]), len(ds.coords["y"]) * len(ds.coords["x"])
         inputs = {n: ds.device(ctx, n) for n in dict.fromkeys(self.vars)}
-        slope, azimuth = self.slope, self.azimuth
-        if np.ndim(slope) != np.ndim(azimuth):  # mixed scalar / per-cell -> per-cell
-            slope = np.broadcast_to(slope, (S,))
-            azimuth = np.broadcast_to(azimuth, (S,))
-        params = dict(self.panel, slope=slope, azimuth=azimuth)
+        self.prepare(ctx, ds)
+        params = dict(self.panel, slope=self.slope, azimuth=self.azimuth)
         return ctx.pv(inputs, params, T, S, plan=plan, time_agg=time_agg, solar_tables=self.solar_tables,
-                      options=self.options)
+                      options=self.options, out=out)
 
 
 class _IrradiationSpec(_PvSpec):
@@ -227,12 +274,16 @@ class _WindSpec(_Spec):
                 )
         self.to_height = float(to_height)
 
-    def run(self, ctx, ds, plan, time_agg):
+    @property
+    def time_vars(self):
+        return (self.wnd,) + ((self.aux,) if self.aux else ())
+
+    def run(self, ctx, ds, plan, time_agg, out=None):
         T, S = len(ds.coords["time"]), len(ds.coords["y"]) * len(ds.coords["x"])
         wnd = ds.device(ctx, self.wnd)
         aux = ds.device(ctx, self.aux) if self.aux else None
         return ctx.wind(wnd, aux, self.V, self.POWn, self.to_height, self.from_height, self.method, T, S,
-                        plan=plan, time_agg=time_agg)
+                        plan=plan, time_agg=time_agg, out=out)
 
 
 class _ThermoSpec(_Spec):
@@ -244,10 +295,14 @@ class _ThermoSpec(_Spec):
         _need(ds, [var], KeyError, var)
         self.var, self.fillna0, self.cop, self.name = var, fillna0, cop, name
 
-    def run(self, ctx, ds, plan, time_agg):
+    @property
+    def time_vars(self):
+        return (self.var,)
+
+    def run(self, ctx, ds, plan, time_agg, out=None):
         T, S = len(ds.coords["time"]), len(ds.coords["y"]) * len(ds.coords["x"])
         return ctx.thermo(ds.device(ctx, self.var), T, S, fillna0=self.fillna0, cop=self.cop, plan=plan,
-                          time_agg=time_agg)
+                          time_agg=time_agg, out=out)
 
 
 def _cop_spec(ds, source, sink_T, c0, c1, c2):
@@ -281,13 +336,45 @@ class _HeatSpec(_Spec):
             edges = np.append(self.days.values, self.days.values[-1] + np.timedelta64(1, "D"))
             self.day_ptr = np.searchsorted(day.values, edges).astype(np.int64)
 
+    time_vars = ("temperature",)
+
     def time_coord(self, ds):
         return self.days
 
-    def run(self, ctx, ds, plan, time_agg):
+    def n_slots(self, ds):
+        return len(self.days)
+
+    # slabs are whole calendar days of the shifted axis
+    def slab_edges(self, T, steps):
+        ptr, edges, a = self.day_ptr, [], 0
+        while a < len(ptr) - 1:
+            b = a + 1
+            while b < len(ptr) - 1 and ptr[b + 1] - ptr[a] <= steps:
+                b += 1
+            edges.append((int(ptr[a]), int(ptr[b])))
+            a = b
+        return [e for e in edges if e[1] > e[0]] or ([(0, T)] if T else [])
+
+    def for_slab(self, t0, t1):
+        import copy
+
+        d0, d1 = self.out_slots(t0, t1)
+        sub = copy.copy(self)
+        sub.day_ptr = self.day_ptr[d0 : d1 + 1] - t0
+        sub.days = self.days[d0:d1]
+        sub._d_day_ptr = None
+        return sub
+
+    def out_slots(self, t0, t1):
+        # groups whose range lies in [t0, t1); empty groups at a slab boundary go to the earlier slab
+        d0 = int(np.searchsorted(self.day_ptr[:-1], t0, side="left"))
+        d1 = int(np.searchsorted(self.day_ptr[1:], t1, side="right"))
+        return d0, d1
+
+    def run(self, ctx, ds, plan, time_agg, out=None):
         T, S = len(ds.coords["time"]), len(ds.coords["y"]) * len(ds.coords["x"])
         return ctx.heat_demand(ds.device(ctx, "temperature"), self.day_ptr, self.threshold_K, self.a,
-                               self.constant, T, S, plan=plan, time_agg=time_agg, cooling=self.cooling)
+                               self.constant, T, S, plan=plan, time_agg=time_agg, cooling=self.cooling, out=out)
 
 
 class _CoolSpec(_HeatSpec):
@@ -305,16 +392,35 @@ class _RunoffSpec(_Spec):
             _need(ds, ["height"], KeyError, "height")
         self.weight_with_height = weight_with_height
 
-    def run(self, ctx, ds, plan, time_agg):
+    time_vars = ("runoff",)
+
+    @property
+    def static_vars(self):
+        return ("height",) if self.weight_with_height else ()
+
+    def run(self, ctx, ds, plan, time_agg, out=None):
         T, S = len(ds.coords["time"]), len(ds.coords["y"]) * len(ds.coords["x"])
         h = ds.device(ctx, "height") if self.weight_with_height else None
-        return ctx.runoff(ds.device(ctx, "runoff"), h, T, S, plan=plan, time_agg=time_agg)
+        return ctx.runoff(ds.device(ctx, "runoff"), h, T, S, plan=plan, time_agg=time_agg, out=out)
+
+
+def _execute(ctx, spec, ds, plan, time_agg):
+    """Whole-dataset launch, or the slab pipeline for large host-resident inputs."""
+    from . import streaming
+
+    if streaming.wanted(ds, spec) and (plan is not None or time_agg in (None, "sum")):
+        out = streaming.run(ctx, spec, ds, plan, None if plan is not None else time_agg)
+        if plan is not None and time_agg is not None:  # small (N, T) result: reduce on the host
+            la = LabeledArray(out.numpy(), ("i", "time"))
+            return ctx.upload(_aggregate_time(la, time_agg).values)
+        return out
+    return spec.run(ctx, ds, plan, time_agg)
 
 
 def _per_cell(spec, ds):
     """Run a spec without aggregation and wrap the (time, y, x) result (device-resident)."""
     ctx = default_context()
-    out = spec.run(ctx, ds, None, None)
+    out = _execute(ctx, spec, ds, None, None)
     Y, X = len(ds.coords["y"]), len(ds.coords["x"])
     tc = spec.time_coord(ds)
     return LabeledArray(out.reshape(len(tc), Y, X), ("time", "y", "x"),
@@ -407,7 +513,7 @@ class _CubeSpec(_Spec):
     def time_coord(self, ds):
         return pd.DatetimeIndex(self.da.coords["time"]) if "time" in self.da.coords else ds.coords["time"]
 
-    def run(self, ctx, ds, plan, time_agg):
+    def run(self, ctx, ds, plan, time_agg, out=None):
         d = ctx.asdevice(self.da.data)
         T = d.shape[0]
         d = d.reshape(T, -1)
@@ -416,7 +522,7 @@ class _CubeSpec(_Spec):
                 return d
             # identity conversion + time reduction on the device (runoff kernel without height)
             return ctx.runoff(d, None, T, d.shape[1], plan=None, time_agg=time_agg)
-        return ctx.spmm(plan, d, time_agg=time_agg)
+        return ctx.spmm(plan, d, time_agg=time_agg, out=out)
 
 
 # --------------------------------------------------------------------------------------
@@ -527,7 +633,7 @@ def convert_and_aggregate(
         if per_unit or return_capacity:
             raise ValueError("One of `matrix`, `shapes` and `layout` must be given for `per_unit` or `return_capacity`")
         agg = "sum" if aggregate_time == "legacy" else aggregate_time
-        out = spec.run(ctx, ds, None, agg)
+        out = _execute(ctx, spec, ds, None, agg)
         if agg is None:
             tc = spec.time_coord(ds)
             res = LabeledArray(out.reshape(len(tc), Y, X), ("time", "y", "x"),
@@ -582,7 +688,7 @@ def convert_and_aggregate(
     # per-unit needs the series on the host anyway (fillna(0) precedes the time reduction)
     on_device_time = aggregate_time if (aggregate_time in ("sum", "mean") and not per_unit) else None
     plan = ctx.plan(matrix, row_len=X)
-    out = spec.run(ctx, ds, plan, on_device_time).numpy()
+    out = _execute(ctx, spec, ds, plan, on_device_time).numpy()
     plan.close()
     tc = spec.time_coord(ds)
     attrs = {}

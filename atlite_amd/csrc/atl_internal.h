@@ -63,6 +63,7 @@ struct atl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t copy_stream = nullptr;  // created on first use (atl_upload_async)
     // scratch arena (grown on demand, stream-ordered reuse)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -74,6 +75,11 @@ struct atl_ctx {
     bool profiling = false;
     bool have_kernel_time = false;
     int n_cu = 256;
+};
+
+struct atl_event {
+    hipEvent_t ev = nullptr;
+    int device = 0;
 };
 
 struct atl_agg {

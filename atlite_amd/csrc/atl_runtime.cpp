@@ -129,6 +129,10 @@ int atl_destroy(atl_ctx *ctx) {
     (void)hipEventDestroy(ctx->ev_t1);
     (void)hipEventDestroy(ctx->ev_k0);
     (void)hipEventDestroy(ctx->ev_k1);
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return ATL_OK;
@@ -185,6 +189,88 @@ int atl_memset(atl_ctx *ctx, void *d_dst, int byte_value, size_t bytes) {
     ATL_REQUIRE(ctx && (bytes == 0 || d_dst), "atl_memset: bad argument");
     if (!bytes) return ATL_OK;
     ATL_HIP_TRY(hipMemsetAsync(d_dst, byte_value, bytes, ctx->stream));
+    return ATL_OK;
+}
+
+// ---- host-resident cutouts: copy stream + events ------------------------------------------
+static int copy_stream_of(atl_ctx *ctx, hipStream_t *out) {
+    if (!ctx->copy_stream) {
+        ATL_HIP_TRY(hipSetDevice(ctx->device));
+        ATL_HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    }
+    *out = ctx->copy_stream;
+    return ATL_OK;
+}
+
+int atl_host_register(void *h_ptr, size_t bytes) {
+    ATL_REQUIRE(h_ptr && bytes, "atl_host_register: bad argument");
+    ATL_HIP_TRY(hipHostRegister(h_ptr, bytes, hipHostRegisterDefault));
+    return ATL_OK;
+}
+
+int atl_host_unregister(void *h_ptr) {
+    ATL_REQUIRE(h_ptr, "atl_host_unregister: bad argument");
+    ATL_HIP_TRY(hipHostUnregister(h_ptr));
+    return ATL_OK;
+}
+
+int atl_upload_async(atl_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    ATL_REQUIRE(ctx && (bytes == 0 || (d_dst && h_src)), "atl_upload_async: bad argument");
+    if (!bytes) return ATL_OK;
+    hipStream_t cs;
+    int rc = copy_stream_of(ctx, &cs);
+    if (rc) return rc;
+    ATL_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, cs));
+    return ATL_OK;
+}
+
+int atl_event_create(atl_ctx *ctx, atl_event **out) {
+    ATL_REQUIRE(ctx && out, "atl_event_create: bad argument");
+    ATL_HIP_TRY(hipSetDevice(ctx->device));
+    atl_event *e = new atl_event();
+    e->device = ctx->device;
+    hipError_t err = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming);
+    if (err != hipSuccess) {
+        delete e;
+        set_error("hipEventCreate failed: %s", hipGetErrorString(err));
+        return ATL_E_HIP;
+    }
+    *out = e;
+    return ATL_OK;
+}
+
+int atl_event_destroy(atl_event *ev) {
+    if (!ev) return ATL_OK;
+    (void)hipEventDestroy(ev->ev);
+    delete ev;
+    return ATL_OK;
+}
+
+int atl_event_record(atl_ctx *ctx, atl_event *ev, int which_stream) {
+    ATL_REQUIRE(ctx && ev, "atl_event_record: bad argument");
+    hipStream_t st = ctx->stream;
+    if (which_stream == 1) {
+        int rc = copy_stream_of(ctx, &st);
+        if (rc) return rc;
+    }
+    ATL_HIP_TRY(hipEventRecord(ev->ev, st));
+    return ATL_OK;
+}
+
+int atl_stream_wait_event(atl_ctx *ctx, int which_stream, atl_event *ev) {
+    ATL_REQUIRE(ctx && ev, "atl_stream_wait_event: bad argument");
+    hipStream_t st = ctx->stream;
+    if (which_stream == 1) {
+        int rc = copy_stream_of(ctx, &st);
+        if (rc) return rc;
+    }
+    ATL_HIP_TRY(hipStreamWaitEvent(st, ev->ev, 0));
+    return ATL_OK;
+}
+
+int atl_event_synchronize(atl_event *ev) {
+    ATL_REQUIRE(ev, "atl_event_synchronize: ev is NULL");
+    ATL_HIP_TRY(hipEventSynchronize(ev->ev));
     return ATL_OK;
 }
 

@@ -207,23 +207,26 @@ class Context:
         return AggPlan(self, matrix, row_len=row_len)
 
     # -- conversions (device in, device out) ------------------------------------------------
-    def _out(self, plan, n_slots, S, time_agg):
+    def _out(self, plan, n_slots, S, time_agg, out=None):
+        """-> (result array or None, pointer, row stride).  ``out=(ptr, ld)`` makes the call write
+        into caller memory - a view of a larger result, used by the slab pipeline."""
+        if out is not None:
+            return None, int(out[0]), int(out[1])
         if plan is None:
-            return self.empty((n_slots, S)) if time_agg is None else self.empty((S,))
-        N = plan.shape[0]
-        return self.empty((N, n_slots)) if time_agg is None else self.empty((N,))
+            a = self.empty((n_slots, S)) if time_agg is None else self.empty((S,))
+        else:
+            N = plan.shape[0]
+            a = self.empty((N, n_slots)) if time_agg is None else self.empty((N,))
+        return a, a.ptr, max(n_slots, 1)
 
-    def spmm(self, plan, dense, time_agg=None):
+    def spmm(self, plan, dense, time_agg=None, out=None):
         T, S = dense.shape
-        out = self._out(plan, T, S, time_agg)
-        check(
-            self.lib.atl_spmm_csr(
-                self.handle, plan.handle, dense.ptr, T, S, _TIME_CODES[time_agg], out.ptr, max(T, 1)
-            )
-        )
-        return out
+        res, optr, ld = self._out(plan, T, S, time_agg, out)
+        check(self.lib.atl_spmm_csr(self.handle, plan.handle, dense.ptr, T, S, _TIME_CODES[time_agg], optr, ld))
+        return res
 
-    def pv(self, inputs: dict, params: dict, T, S, plan=None, time_agg=None, solar_tables=None, options=None):
+    def pv(self, inputs: dict, params: dict, T, S, plan=None, time_agg=None, solar_tables=None, options=None,
+           out=None):
         """
         inputs: name -> DeviceArray (T,S): influx_toa plus either influx_direct + influx_diffuse or
         influx; albedo or outflux; temperature; humidity (enhanced clearsky); solar_altitude +
@@ -243,10 +246,12 @@ class Context:
             pin.d_solar_altitude = pin.d_solar_azimuth = None
             for field, key in (("d_sin_dec", "sin_dec"), ("d_cos_dec", "cos_dec"), ("d_hour_angle", "h"),
                                ("d_cos_hour_angle", "cos_h"), ("d_sin_lat", "sin_lat"), ("d_cos_lat", "cos_lat")):
-                t = self.asdevice(np.ascontiguousarray(solar_tables[key], dtype=np.float64))
-                keep.append(t)
+                v = solar_tables[key]
+                t = v if isinstance(v, DeviceArray) else self.upload(np.ascontiguousarray(v, dtype=np.float64))
+                if t is not v:
+                    keep.append(t)
                 setattr(pin, field, t.ptr)
-            pin.X = int(np.shape(solar_tables["h"])[1])
+            pin.X = int(solar_tables["h"].shape[1])
         pp = _lib.PvParams()
         model = options.get("panel_model", params.get("model", "huld"))
         pp.panel_model = _lib.PANEL[model]
@@ -267,26 +272,28 @@ class Context:
         pp.clearsky_model = _lib.CLEARSKY[options.get("clearsky_model") or "simple"]
         pp.irradiation = _lib.IRRADIATION[options.get("irradiation", "total")]
         slope, azimuth = params["slope"], params["azimuth"]
-        if np.ndim(slope) == 0 and np.ndim(azimuth) == 0:
+        if not isinstance(slope, DeviceArray) and np.ndim(slope) == 0 and np.ndim(azimuth) == 0:
             pp.slope, pp.azimuth = float(slope), float(azimuth)
             pp.d_cell_slope = pp.d_cell_azimuth = None
         else:
-            ds = self.asdevice(np.broadcast_to(np.asarray(slope, dtype=np.float64), (S,)))
-            da = self.asdevice(np.broadcast_to(np.asarray(azimuth, dtype=np.float64), (S,)))
-            keep += [ds, da]
+            if isinstance(slope, DeviceArray):
+                ds, da = slope, azimuth
+            else:
+                ds = self.upload(np.broadcast_to(np.asarray(slope, dtype=np.float64), (S,)))
+                da = self.upload(np.broadcast_to(np.asarray(azimuth, dtype=np.float64), (S,)))
+                keep += [ds, da]
             pp.d_cell_slope, pp.d_cell_azimuth = ds.ptr, da.ptr
-        out = self._out(plan, T, S, time_agg)
+        res, optr, ld = self._out(plan, T, S, time_agg, out)
         if plan is None:
-            check(self.lib.atl_pv_convert(self.handle, C.byref(pin), C.byref(pp), T, S,
-                                          _TIME_CODES[time_agg], out.ptr))
+            check(self.lib.atl_pv_convert(self.handle, C.byref(pin), C.byref(pp), T, S, _TIME_CODES[time_agg], optr))
         else:
-            check(self.lib.atl_pv_convert_aggregate(self.handle, C.byref(pin), C.byref(pp), T, S,
-                                                    plan.handle, _TIME_CODES[time_agg], out.ptr, max(T, 1)))
+            check(self.lib.atl_pv_convert_aggregate(self.handle, C.byref(pin), C.byref(pp), T, S, plan.handle,
+                                                    _TIME_CODES[time_agg], optr, ld))
         if keep:
-            self.sync()
-        return out
+            self.sync()  # temporaries uploaded for this call must outlive the kernels
+        return res
 
-    def wind(self, wnd, aux, V, POWn, to_height, from_height, method, T, S, plan=None, time_agg=None):
+    def wind(self, wnd, aux, V, POWn, to_height, from_height, method, T, S, plan=None, time_agg=None, out=None):
         V = np.ascontiguousarray(V, dtype=np.float64)
         POWn = np.ascontiguousarray(POWn, dtype=np.float64)
         win = _lib.WindInputs(
@@ -300,55 +307,57 @@ class Context:
             V.ctypes.data_as(_lib.c_double_p),
             POWn.ctypes.data_as(_lib.c_double_p),
         )
-        out = self._out(plan, T, S, time_agg)
+        res, optr, ld = self._out(plan, T, S, time_agg, out)
         if plan is None:
-            check(self.lib.atl_wind_convert(self.handle, C.byref(win), C.byref(wp), T, S,
-                                            _TIME_CODES[time_agg], out.ptr))
+            check(self.lib.atl_wind_convert(self.handle, C.byref(win), C.byref(wp), T, S, _TIME_CODES[time_agg], optr))
         else:
-            check(self.lib.atl_wind_convert_aggregate(self.handle, C.byref(win), C.byref(wp), T, S,
-                                                      plan.handle, _TIME_CODES[time_agg], out.ptr, max(T, 1)))
-        return out
+            check(self.lib.atl_wind_convert_aggregate(self.handle, C.byref(win), C.byref(wp), T, S, plan.handle,
+                                                      _TIME_CODES[time_agg], optr, ld))
+        return res
 
-    def thermo(self, var, T, S, offset=-273.15, fillna0=False, cop=None, plan=None, time_agg=None):
+    def thermo(self, var, T, S, offset=-273.15, fillna0=False, cop=None, plan=None, time_agg=None, out=None):
         """temperature family (var + offset [, fillna 0]) and, with cop=(sink_T, c0, c1, c2), the COP."""
         tp = _lib.ThermoParams(float(offset), 1 if fillna0 else 0, 0 if cop is None else 1,
                                *(map(float, cop) if cop is not None else (0.0, 0.0, 0.0, 0.0)))
-        out = self._out(plan, T, S, time_agg)
+        res, optr, ld = self._out(plan, T, S, time_agg, out)
         if plan is None:
-            check(self.lib.atl_thermo_convert(self.handle, var.ptr, C.byref(tp), T, S, _TIME_CODES[time_agg], out.ptr))
+            check(self.lib.atl_thermo_convert(self.handle, var.ptr, C.byref(tp), T, S, _TIME_CODES[time_agg], optr))
         else:
             check(self.lib.atl_thermo_convert_aggregate(self.handle, var.ptr, C.byref(tp), T, S, plan.handle,
-                                                        _TIME_CODES[time_agg], out.ptr, max(T, 1)))
-        return out
+                                                        _TIME_CODES[time_agg], optr, ld))
+        return res
 
     def heat_demand(self, temperature, day_ptr, threshold_K, a, constant, T, S, plan=None, time_agg=None,
-                    cooling=False):
-        day_ptr = np.ascontiguousarray(day_ptr, dtype=np.int64)
-        D = len(day_ptr) - 1
-        assert D >= 0 and day_ptr[0] >= 0 and day_ptr[-1] <= T and np.all(np.diff(day_ptr) >= 0)
-        d_ptr = self.upload(day_ptr, np.int64)
+                    cooling=False, out=None):
+        """day_ptr: host offsets (uploaded, call synchronises) or an int64 DeviceArray (D+1,)."""
+        if isinstance(day_ptr, DeviceArray):
+            d_ptr, D, fresh = day_ptr, day_ptr.shape[0] - 1, False
+        else:
+            day_ptr = np.ascontiguousarray(day_ptr, dtype=np.int64)
+            D = len(day_ptr) - 1
+            assert D >= 0 and day_ptr[0] >= 0 and day_ptr[-1] <= T and np.all(np.diff(day_ptr) >= 0)
+            d_ptr, fresh = self.upload(day_ptr, np.int64), True
         hp = _lib.HeatParams(float(threshold_K), float(a), float(constant), D, d_ptr.ptr, 1 if cooling else 0)
-        out = self._out(plan, D, S, time_agg)
+        res, optr, ld = self._out(plan, D, S, time_agg, out)
         if plan is None:
             check(self.lib.atl_heat_demand_convert(self.handle, temperature.ptr, C.byref(hp), T, S,
-                                                   _TIME_CODES[time_agg], out.ptr))
+                                                   _TIME_CODES[time_agg], optr))
         else:
             check(self.lib.atl_heat_demand_convert_aggregate(self.handle, temperature.ptr, C.byref(hp), T, S,
-                                                             plan.handle, _TIME_CODES[time_agg], out.ptr,
-                                                             max(D, 1)))
-        self.sync()  # d_ptr must outlive the kernels
-        return out
+                                                             plan.handle, _TIME_CODES[time_agg], optr, ld))
+        if fresh:
+            self.sync()  # d_ptr must outlive the kernels
+        return res
 
-    def runoff(self, runoff, height, T, S, plan=None, time_agg=None):
-        out = self._out(plan, T, S, time_agg)
+    def runoff(self, runoff, height, T, S, plan=None, time_agg=None, out=None):
+        res, optr, ld = self._out(plan, T, S, time_agg, out)
         hptr = height.ptr if height is not None else None
         if plan is None:
-            check(self.lib.atl_runoff_convert(self.handle, runoff.ptr, hptr, T, S, _TIME_CODES[time_agg],
-                                              out.ptr))
+            check(self.lib.atl_runoff_convert(self.handle, runoff.ptr, hptr, T, S, _TIME_CODES[time_agg], optr))
         else:
             check(self.lib.atl_runoff_convert_aggregate(self.handle, runoff.ptr, hptr, T, S, plan.handle,
-                                                        _TIME_CODES[time_agg], out.ptr, max(T, 1)))
-        return out
+                                                        _TIME_CODES[time_agg], optr, ld))
+        return res
 
     # -- synthetic fields -------------------------------------------------------------------
     def synth_field(self, kind, seed, var_id, p0, p1, T, S, per_cell_static=False):

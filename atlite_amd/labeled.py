@@ -236,6 +236,36 @@ class Dataset:
     def indexes(self):
         return {k: pd.Index(v) for k, v in self.coords.items() if k in ("time", "y", "x")}
 
+    def pin(self):
+        """Page-lock the host arrays in place so that the slab pipeline (atlite_amd.streaming) DMAs
+        them at PCIe rate without re-registering on every call.  Undone by ``unpin()`` / deletion."""
+        from . import _lib
+
+        lib = _lib.load()
+        self._pinned = getattr(self, "_pinned", {})
+        for k, la in self._vars.items():
+            a = la.data
+            if isinstance(a, np.ndarray) and a.nbytes and a.flags.c_contiguous and k not in self._pinned:
+                if lib.atl_host_register(a.ctypes.data, a.nbytes) == 0:
+                    self._pinned[k] = (a.ctypes.data, a.nbytes)
+        return self
+
+    def unpin(self):
+        from . import _lib
+
+        for ptr, _ in getattr(self, "_pinned", {}).values():
+            _lib.load().atl_host_unregister(ptr)
+        self._pinned = {}
+
+    def pinned_ranges(self):
+        return list(getattr(self, "_pinned", {}).values())
+
+    def __del__(self):
+        try:
+            self.unpin()
+        except Exception:
+            pass
+
     def device(self, ctx, name):
         """DeviceArray of variable ``name`` flattened to (T, S) or (S,); uploads host data once."""
         la = self._vars[name]

@@ -1,0 +1,137 @@
+"""
+Pipelined execution for cutouts that live in HOST memory (or do not fit in HBM).
+
+The time axis is cut into slabs; while the conversion kernels work on slab ``i`` (compute
+stream), the input variables of slab ``i+1`` are DMA'd from pinned host memory on the copy
+stream into the other half of a double buffer; events order the two streams.  Device memory
+is bounded by two slabs of every input variable, the end-to-end rate approaches the PCIe rate
+(the kernels are ~100x faster than the link).  SURVEY.md 8 f-4; the reference reads its
+cutouts chunk by chunk through dask (atlite/cutout.py:143) - this is the device-side analogue.
+
+Used automatically by ``convert_and_aggregate`` for host-resident datasets above
+``ATLITE_HIP_STREAM_MIN_BYTES`` (default 256 MiB; ``ATLITE_HIP_STREAM=0/1`` forces it off/on).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._lib import check
+from .device import DeviceArray
+
+COMPUTE, COPY = 0, 1
+
+
+def _host_array(la):
+    d = la.data
+    return d if isinstance(d, np.ndarray) else None
+
+
+def wanted(ds, spec):
+    """Stream iff every time-dependent input is a host ndarray and the total is large enough."""
+    mode = os.environ.get("ATLITE_HIP_STREAM", "auto")
+    if mode == "0" or not getattr(spec, "time_vars", None):
+        return False
+    arrs = [_host_array(ds[n]) for n in spec.time_vars]
+    if any(a is None for a in arrs):
+        return False
+    if mode == "1":
+        return True
+    return sum(a.nbytes for a in arrs) >= int(os.environ.get("ATLITE_HIP_STREAM_MIN_BYTES", 256 << 20))
+
+
+class _Pinned:
+    """Pins host arrays in place for the duration of a run (no-op if pinning fails)."""
+
+    def __init__(self, lib, arrays, already=()):
+        self.lib, self.ptrs = lib, []
+        if os.environ.get("ATLITE_HIP_PIN", "1") == "0":
+            return
+        for a in arrays:
+            lo, hi = a.ctypes.data, a.ctypes.data + a.nbytes
+            if any(p <= lo and hi <= p + n for p, n in already):
+                continue  # Dataset.pin() already page-locked this array
+            if a.nbytes and lib.atl_host_register(a.ctypes.data, a.nbytes) == 0:
+                self.ptrs.append(a.ctypes.data)
+
+    def release(self):
+        for p in self.ptrs:
+            self.lib.atl_host_unregister(p)
+        self.ptrs = []
+
+
+class _SlabView:
+    """Dataset look-alike for one slab: ``coords`` with the slab's times, ``device()`` of its buffers."""
+
+    def __init__(self, ds, bufs, static, t0, t1):
+        self.coords = dict(ds.coords)
+        self.coords["time"] = ds.coords["time"][t0:t1]
+        self._bufs, self._static, self._n = bufs, static, t1 - t0
+
+    def device(self, ctx, name):
+        if name in self._bufs:
+            return self._bufs[name].slab(0, self._n)
+        return self._static[name]
+
+
+def run(ctx, spec, ds, plan, time_agg):
+    """
+    Execute ``spec`` slab by slab.  Returns a DeviceArray shaped like ``spec.run`` would return
+    for ``time_agg=None`` ((N, slots) with a plan, (slots, S) without) or, for per-cell
+    ``time_agg="sum"``, the (S,) sum.  Other time reductions are left to the caller.
+    """
+    assert time_agg in (None, "sum")
+    lib = ctx.lib
+    T = len(ds.coords["time"])
+    S = len(ds.coords["y"]) * len(ds.coords["x"])
+    host = {n: np.ascontiguousarray(_host_array(ds[n]), dtype=np.float64).reshape(T, S) for n in spec.time_vars}
+    steps = int(os.environ.get("ATLITE_HIP_SLAB_STEPS", 0)) or max(8, min(T, (128 << 20) // max(S * 8, 1)) // 8 * 8)
+    edges = spec.slab_edges(T, steps)
+    n_slots = spec.n_slots(ds)
+    static = {n: ds.device(ctx, n) for n in getattr(spec, "static_vars", ())}
+    spec.prepare(ctx, ds)
+    max_len = max((b - a for a, b in edges), default=0)
+    bufs = [{n: ctx.empty((max(max_len, 1), S)) for n in host} for _ in range(2)]
+    ev_ready, ev_done = [], []
+    for _ in range(2):
+        for lst in (ev_ready, ev_done):
+            h = C.c_void_p()
+            check(lib.atl_event_create(ctx.handle, C.byref(h)))
+            lst.append(h)
+    if plan is not None:
+        out = ctx.empty((plan.shape[0], n_slots))
+    elif time_agg is None:
+        out = ctx.empty((n_slots, S))
+    else:
+        out, host_acc = None, np.zeros(S)
+    pinned = _Pinned(lib, list(host.values()), getattr(ds, "pinned_ranges", lambda: [])())
+    try:
+        for i, (t0, t1) in enumerate(edges):
+            b = i % 2
+            if i >= 2:
+                check(lib.atl_stream_wait_event(ctx.handle, COPY, ev_done[b]))
+            for n, a in host.items():
+                blk = a[t0:t1]
+                check(lib.atl_upload_async(ctx.handle, bufs[b][n].ptr, blk.ctypes.data, blk.nbytes))
+            check(lib.atl_event_record(ctx.handle, ev_ready[b], COPY))
+            check(lib.atl_stream_wait_event(ctx.handle, COMPUTE, ev_ready[b]))
+            view = _SlabView(ds, bufs[b], static, t0, t1)
+            sub = spec.for_slab(t0, t1)
+            s0, s1 = spec.out_slots(t0, t1)
+            if plan is not None:
+                sub.run(ctx, view, plan, None, out=(out.ptr + s0 * 8, n_slots))
+            elif time_agg is None:
+                sub.run(ctx, view, None, None, out=(out.ptr + s0 * S * 8, S))
+            else:
+                host_acc += sub.run(ctx, view, None, "sum").numpy()  # (S,) per slab: tiny
+            check(lib.atl_event_record(ctx.handle, ev_done[b], COMPUTE))
+        ctx.sync()
+    finally:
+        ctx.sync()
+        pinned.release()
+        for h in ev_ready + ev_done:
+            lib.atl_event_destroy(h)
+    return out if out is not None else ctx.upload(host_acc)

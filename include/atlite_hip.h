@@ -68,6 +68,23 @@ int atl_upload(atl_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /*
 int atl_download(atl_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* blocking */
 int atl_memset(atl_ctx *ctx, void *d_dst, int byte_value, size_t bytes);
 
+/* ---- host-resident cutouts: overlap H2D with compute -------------------------------------------
+ * A context owns a second (copy) stream.  atl_upload_async enqueues on it; events order the
+ * two streams, so a caller can double-buffer time slabs of a cutout that lives in host memory
+ * (or does not fit in HBM) while the conversion kernels run: see atlite_amd/streaming.py.
+ * atl_host_register pins caller memory in place (DMA at PCIe rate, no staging copy).
+ * which_stream: 0 = compute stream (all convert calls), 1 = copy stream.
+ */
+typedef struct atl_event atl_event;
+int atl_host_register(void *h_ptr, size_t bytes);
+int atl_host_unregister(void *h_ptr);
+int atl_upload_async(atl_ctx *ctx, void *d_dst, const void *h_src, size_t bytes); /* copy stream */
+int atl_event_create(atl_ctx *ctx, atl_event **out);
+int atl_event_destroy(atl_event *ev);
+int atl_event_record(atl_ctx *ctx, atl_event *ev, int which_stream);
+int atl_stream_wait_event(atl_ctx *ctx, int which_stream, atl_event *ev);
+int atl_event_synchronize(atl_event *ev);
+
 /* ---- timing (HIP events on the context's stream) ----------------------------------- */
 /* Bracket any sequence of calls; atl_timer_stop synchronises and returns elapsed ms. */
 int atl_timer_start(atl_ctx *ctx);

@@ -193,3 +193,67 @@ def test_tile_layouts(ctx, monkeypatch, tile, Y, X):
     ds = H.pv_dataset(T, Y, X, seed=3)
     ref = orc.aggregate_matrix(orc.convert_pv(ds, H.CSI, dict(slope=np.radians(30.0), azimuth=np.radians(180.0))), M)
     close(ctx.pv(up(ctx, ds), PV_PARAMS, T, Y * X, plan=plan).numpy(), ref)
+
+
+# ---- edge cases: empty and ragged inputs, degenerate matrices ------------------------------------
+def test_empty_and_degenerate_shapes(ctx):
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(0)
+    # no shapes at all / a shape with no cells / an all-zero matrix
+    D = rng.random((5, 40))
+    assert ctx.spmm(ctx.plan(sp.csr_matrix((0, 40))), ctx.upload(D)).numpy().shape == (0, 5)
+    M = sp.csr_matrix(([1.0], ([1], [3])), shape=(3, 40))
+    out = ctx.spmm(ctx.plan(M, row_len=8), ctx.upload(D)).numpy()
+    np.testing.assert_array_equal(out[0], 0.0)
+    np.testing.assert_array_equal(out[2], 0.0)
+    np.testing.assert_allclose(out[1], D[:, 3])
+    # empty time axis
+    E = ctx.spmm(ctx.plan(M), ctx.upload(np.zeros((0, 40)))).numpy()
+    assert E.shape == (3, 0)
+    assert ctx.spmm(ctx.plan(M), ctx.upload(np.zeros((0, 40))), time_agg="sum").numpy().tolist() == [0.0, 0.0, 0.0]
+    assert np.isnan(ctx.spmm(ctx.plan(M), ctx.upload(np.zeros((0, 40))), time_agg="mean").numpy()).all()
+    # single cell, single step; chunk tails (T not a multiple of 8 / 64)
+    for T, S in ((1, 1), (1, 2), (7, 3), (65, 130), (129, 64)):
+        D = rng.standard_normal((T, S))
+        M = sp.random(4, S, density=0.6, random_state=T, format="csr")
+        close(ctx.spmm(ctx.plan(M), ctx.upload(D)).numpy(), M @ D.T, atol_scale=1e-13)
+        close(ctx.runoff(ctx.upload(D), None, T, S, time_agg="sum").numpy(), D.sum(0), atol_scale=1e-13)
+        close(ctx.runoff(ctx.upload(D), None, T, S).numpy(), D)
+    # duplicate entries are summed like scipy does on conversion
+    M = sp.csr_matrix((np.array([1.0, 2.0, 0.5]), np.array([2, 2, 5]), np.array([0, 3])), shape=(1, 9))
+    D = rng.random((3, 9))
+    close(ctx.spmm(ctx.plan(M), ctx.upload(D)).numpy(), (3.0 * D[:, 2] + 0.5 * D[:, 5])[None, :], atol_scale=1e-14)
+    # a NaN weight poisons its whole row (what the scipy product gives), other rows stay clean
+    M = sp.csr_matrix((np.array([np.nan, 1.0]), (np.array([0, 1]), np.array([1, 2]))), shape=(2, 9))
+    out = ctx.spmm(ctx.plan(M), ctx.upload(D)).numpy()
+    assert np.isnan(out[0]).all() and np.isfinite(out[1]).all()
+
+
+def test_bad_arguments_raise(ctx):
+    import scipy.sparse as sp
+
+    M = sp.csr_matrix(np.ones((2, 10)))
+    with pytest.raises(ValueError, match="columns"):
+        ctx.spmm(ctx.plan(M), ctx.upload(np.zeros((3, 12))))
+    with pytest.raises(ValueError, match="increasing"):
+        ctx.wind(ctx.upload(np.ones((2, 4))), None, [0, 5, 3], [0, 1, 1], 80, 80, None, 2, 4)
+    with pytest.raises(ValueError):
+        ctx.plan(sp.csr_matrix((np.ones(1), np.array([11]), np.array([0, 1])), shape=(1, 12)).__class__(
+            (np.ones(1), np.array([5]), np.array([0, 1])), shape=(1, 4)))
+
+
+def test_many_shapes_and_large_tile_rows(ctx):
+    """More shapes per tile than the register-cached rows (generic row loop) and a dense matrix."""
+    import scipy.sparse as sp
+
+    T, Y, X, N = 19, 8, 32, 40
+    rng = np.random.default_rng(5)
+    D = rng.standard_normal((T, Y * X))
+    M = sp.csr_matrix(rng.random((N, Y * X)) * (rng.random((N, Y * X)) < 0.7))
+    close(ctx.spmm(ctx.plan(M, row_len=X), ctx.upload(D)).numpy(), M @ D.T, atol_scale=1e-13)
+    D[3, 17] = np.nan
+    D[5, 100] = np.inf
+    ref = M @ D.T
+    got = ctx.spmm(ctx.plan(M, row_len=X), ctx.upload(D)).numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-12, equal_nan=True)
