@@ -20,6 +20,7 @@
 //   heat : convert.py:405-418      runoff : convert.py:1028-1034
 //   agg  : aggregate.py:16-35 (scipy CSR product), convert.py:51-56 (_aggregate_time)
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <type_traits>
 
@@ -917,9 +918,10 @@ __device__ __forceinline__ void reduce_row(const double2 (&v)[kBatch], double2 w
 constexpr int kRowCache = ATL_ROW_CACHE;  // partial rows of a tile whose weights stay in registers
 
 template <class Conv, bool VEC>
-__global__ __launch_bounds__(256, ATL_FUSED_WAVES) void k_fused_segred(Conv conv, PlanDev plan, int64_t n_slots,
-                                                      int64_t S, int32_t chunk_slots, int64_t n_units,
-                                                      double *__restrict__ partials, int64_t ldp) {
+__global__ __launch_bounds__(256, ATL_FUSED_WAVES) void k_fused_segred(Conv conv, PlanDev plan, int64_t slot0,
+                                                      int64_t n_slots, int64_t S, int32_t chunk_slots,
+                                                      int64_t n_units, double *__restrict__ partials,
+                                                      int64_t ldp) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     conv.block_init(lds);
     __syncthreads();
@@ -956,8 +958,10 @@ __global__ __launch_bounds__(256, ATL_FUSED_WAVES) void k_fused_segred(Conv conv
             present |= (a0 ? 1u : 0u) << (2 * r) | (a1 ? 1u : 0u) << (2 * r + 1);
         }
     }
-    const int64_t sbeg = chunk * chunk_slots;
-    const int64_t send = min(sbeg + int64_t(chunk_slots), n_slots);
+    // this launch covers output slots [slot0, slot0 + n_slots); partials are window-relative
+    const int64_t sbeg = slot0 + chunk * chunk_slots;
+    const int64_t send = min(sbeg + int64_t(chunk_slots), slot0 + n_slots);
+    partials -= slot0;
     for (int64_t sb = sbeg; sb < send; sb += kBatch) {
         double2 v[kBatch];
         bool finite = true;
@@ -1241,10 +1245,18 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
     const int64_t N = plan.n_rows;
     if (N == 0) return ATL_OK;
     vec = vec && (plan.X % 2 == 0);  // the lane's cell pair must not straddle a grid row
-    const int64_t ldp = int64_t(align_up(size_t(std::max<int64_t>(n_slots, 1)), 8));
+    // Partial rows live in scratch as [P][window]; the slot axis is processed in windows so that the
+    // scratch stays below ~1 GiB however dense the matrix is (P = tiles x shapes for a dense one).
     const int64_t P = plan.n_prows;
+    int64_t window = std::max<int64_t>(n_slots, 1);
+    int64_t budget = int64_t(1) << 27;  // doubles = 1 GiB
+    if (const char *env = getenv("ATLITE_HIP_PARTIAL_BUDGET")) budget = std::max<int64_t>(1, atoll(env));  // tests
+    const int64_t budget_slots = budget / std::max<int64_t>(P, 1);
+    if (window > budget_slots) window = std::max<int64_t>(64, budget_slots / 64 * 64);
+    const int64_t ldp = int64_t(align_up(size_t(window), 8));
+    const int64_t lds_series = int64_t(align_up(size_t(std::max<int64_t>(n_slots, 1)), 8));
     size_t bytes_partials = align_up(size_t(std::max<int64_t>(P, 1) * ldp) * sizeof(double), 256);
-    size_t bytes_series = time_agg == ATL_TIME_NONE ? 0 : align_up(size_t(N * ldp) * sizeof(double), 256);
+    size_t bytes_series = time_agg == ATL_TIME_NONE ? 0 : align_up(size_t(N * lds_series) * sizeof(double), 256);
     void *scr = nullptr;
     int rc = scratch_reserve(ctx, bytes_partials + bytes_series, &scr);
     if (rc) return rc;
@@ -1252,24 +1264,25 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
     double *series = time_agg == ATL_TIME_NONE
                          ? d_out
                          : reinterpret_cast<double *>(static_cast<char *>(scr) + bytes_partials);
-    const int64_t ld_series = time_agg == ATL_TIME_NONE ? ld_out : ldp;
-    if (n_slots > 0 && P > 0) {
-        const int32_t chunk_slots = pick_chunk_slots(ctx, n_slots, plan.n_segs);
-        const int64_t n_chunks = (n_slots + chunk_slots - 1) / chunk_slots;
-        const int64_t n_units = n_chunks * plan.n_segs;
-        const dim3 grid(unsigned((n_units + kWavesPerBlock - 1) / kWavesPerBlock));
-        KernelBracket kb(ctx);
-        if (vec)
-            hipLaunchKernelGGL((k_fused_segred<Conv, true>), grid, dim3(256), lds_bytes, ctx->stream, conv, plan,
-                               n_slots, S, chunk_slots, n_units, partials, ldp);
-        else
-            hipLaunchKernelGGL((k_fused_segred<Conv, false>), grid, dim3(256), lds_bytes, ctx->stream, conv,
-                               plan, n_slots, S, chunk_slots, n_units, partials, ldp);
-        if ((rc = check_launch(what))) return rc;
-    }
-    if (n_slots > 0) {
-        const dim3 grid(unsigned((n_slots + 255) / 256), unsigned(N));
-        hipLaunchKernelGGL(k_combine, grid, dim3(256), 0, ctx->stream, plan, partials, ldp, n_slots, series,
+    const int64_t ld_series = time_agg == ATL_TIME_NONE ? ld_out : lds_series;
+    for (int64_t w0 = 0; w0 < n_slots; w0 += window) {
+        const int64_t wn = std::min(window, n_slots - w0);
+        if (P > 0) {
+            const int32_t chunk_slots = pick_chunk_slots(ctx, wn, plan.n_segs);
+            const int64_t n_chunks = (wn + chunk_slots - 1) / chunk_slots;
+            const int64_t n_units = n_chunks * plan.n_segs;
+            const dim3 grid(unsigned((n_units + kWavesPerBlock - 1) / kWavesPerBlock));
+            KernelBracket kb(ctx);
+            if (vec)
+                hipLaunchKernelGGL((k_fused_segred<Conv, true>), grid, dim3(256), lds_bytes, ctx->stream, conv, plan,
+                                   w0, wn, S, chunk_slots, n_units, partials, ldp);
+            else
+                hipLaunchKernelGGL((k_fused_segred<Conv, false>), grid, dim3(256), lds_bytes, ctx->stream, conv,
+                                   plan, w0, wn, S, chunk_slots, n_units, partials, ldp);
+            if ((rc = check_launch(what))) return rc;
+        }
+        const dim3 grid(unsigned((wn + 255) / 256), unsigned(N));
+        hipLaunchKernelGGL(k_combine, grid, dim3(256), 0, ctx->stream, plan, partials, ldp, wn, series + w0,
                            ld_series);
         if ((rc = check_launch(what))) return rc;
     }

@@ -10,6 +10,10 @@ result is reassembled with ONE collective over RCCL/xGMI:
 * ``"sum"`` / ``"mean"``   -> all-reduce of per-rank (sum, count)      (``reduce_time``)
 
 ``torch.distributed`` is the transport ("nccl" = RCCL on ROCm; "gloo" in the CPU tests).
+Stream ordering: create the ``Context`` on a NON-default torch stream and make it current
+(``s = torch.cuda.Stream(); torch.cuda.set_stream(s); Context(dev, stream=s.cuda_stream)``), then
+the collectives issued here are ordered after the kernels without a host sync (the default
+stream's handle is 0, which ``atl_create`` reads as "create a private stream").
 The reference has no distributed path (its parallelism is dask threads over time chunks,
 atlite/cutout.py:143); this module is the MI355X-native counterpart of that chunking.
 """

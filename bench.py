@@ -94,8 +94,12 @@ def main():
     n_gpus = world
     assert a.gpus == n_gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
-    # enqueue on torch's current stream so the RCCL collective is stream-ordered with our kernels
-    ctx = Context(local, stream=torch.cuda.current_stream().cuda_stream)
+    # One explicit (non-default) torch stream carries both our kernels and the RCCL collective, so
+    # they are stream-ordered.  (The default stream's handle is 0 = "create your own" for atl_create.)
+    stream = torch.cuda.Stream(device=local)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    ctx = Context(local, stream=stream.cuda_stream)
 
     T, Y, X, S = a.T, a.Y, a.X, a.Y * a.X
     if a.scaling == "weak":

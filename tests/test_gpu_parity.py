@@ -257,3 +257,21 @@ def test_many_shapes_and_large_tile_rows(ctx):
     ref = M @ D.T
     got = ctx.spmm(ctx.plan(M, row_len=X), ctx.upload(D)).numpy()
     np.testing.assert_allclose(got, ref, rtol=1e-12, equal_nan=True)
+
+
+def test_partial_row_windowing(ctx, monkeypatch):
+    """Dense matrices: the slot axis is processed in windows so that scratch stays bounded."""
+    import scipy.sparse as sp
+
+    T, Y, X, N = 300, 6, 40, 9
+    rng = np.random.default_rng(11)
+    D = rng.standard_normal((T, Y * X))
+    M = sp.csr_matrix(rng.random((N, Y * X)))
+    ref = M @ D.T
+    monkeypatch.setenv("ATLITE_HIP_PARTIAL_BUDGET", "2000")  # -> windows of 64 slots
+    plan = ctx.plan(M, row_len=X)
+    close(ctx.spmm(plan, ctx.upload(D)).numpy(), ref, atol_scale=1e-13)
+    close(ctx.spmm(plan, ctx.upload(D), time_agg="mean").numpy(), ref.mean(1), atol_scale=1e-13)
+    ds = H.pv_dataset(T, Y, X, seed=1)
+    refpv = orc.aggregate_matrix(orc.convert_pv(ds, H.CSI, dict(slope=np.radians(30.0), azimuth=np.radians(180.0))), M)
+    close(ctx.pv(up(ctx, ds), PV_PARAMS, T, Y * X, plan=plan).numpy(), refpv)
