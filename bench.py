@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3200, help="time steps of the CPU baseline sample")
+    ap.add_argument("--debug-gloo-one-gpu", action="store_true",
+                    help="testing only: all ranks share GPU 0 and the collective runs over gloo on host copies")
     return ap.parse_args()
 
 
@@ -86,11 +88,16 @@ def main():
     from atlite_amd.device import Context
 
     dist = None
+    if a.debug_gloo_one_gpu:
+        local = 0
     if world > 1:
         import torch.distributed as dist
 
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.debug_gloo_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     n_gpus = world
     assert a.gpus == n_gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
@@ -139,6 +146,9 @@ def main():
     def step():
         _lib.check(ctx.lib.atl_pv_convert_aggregate(ctx.handle, C.byref(pin), C.byref(pp), T_loc, S,
                                                     plan.handle, 0, out_local.data_ptr(), T_loc))
+        if world > 1 and a.debug_gloo_one_gpu:
+            torch.cuda.current_stream().synchronize()
+            return D.gather_time(out_local.cpu(), lens=shard_lens)
         if world > 1:
             return D.gather_time(out_local, lens=shard_lens)  # (N, world * T_loc) on every rank
         return out_local
@@ -159,8 +169,14 @@ def main():
         kernel_ms.append(ctx.last_kernel_ms())  # waits for this step's fused kernel only
     fence()
     dt = time.perf_counter() - t0
+    if world > 1:  # the reassembled (shapes x all time steps) result holds this rank's block in place
+        full = step()
+        fence()
+        assert tuple(full.shape) == (N, world * T_loc), full.shape
+        mine = full[:, rank * T_loc:(rank + 1) * T_loc]
+        assert torch.equal(mine.to(out_local.device), out_local), "all-gather misplaced this rank's block"
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if a.debug_gloo_one_gpu else f"cuda:{local}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / a.steps * 1e3
