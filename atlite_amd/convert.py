@@ -855,10 +855,6 @@ def coefficient_of_performance(cutout, source="air", sink_T=55.0, c0=None, c1=No
     )
 
 
-def _values_of(r):
-    return np.asarray(r.values)
-
-
 def runoff(cutout, smooth=None, lower_threshold_quantile=None, normalize_using_yearly=None, **params):
     """
     Runoff (optionally height-weighted) aggregated to shapes, with the reference's

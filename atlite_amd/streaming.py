@@ -20,7 +20,6 @@ import os
 import numpy as np
 
 from ._lib import check
-from .device import DeviceArray
 
 COMPUTE, COPY = 0, 1
 
