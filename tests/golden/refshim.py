@@ -430,6 +430,14 @@ class Dataset:
             out.update(v.sizes)
         return out
 
+    def __getattr__(self, key):
+        if key.startswith("_"):
+            raise AttributeError(key)
+        try:
+            return self[key]
+        except KeyError:
+            raise AttributeError(key)
+
     def rename(self, mapping):
         return Dataset({mapping.get(k, k): v for k, v in self._vars.items()}, coords=self._coords, attrs=self.attrs)
 
@@ -450,10 +458,19 @@ def date_range(start, periods=None, freq=None, **kw):
     return pd.date_range(start, periods=periods, freq=freq, **kw)
 
 
+def _assert_identical(a, b):
+    assert type(a) is type(b), (type(a), type(b))
+    assert a.dims == b.dims and a.name == b.name, (a.dims, b.dims, a.name, b.name)
+    np.testing.assert_array_equal(a.values, b.values)
+    assert a.attrs == b.attrs, (a.attrs, b.attrs)
+
+
 def _make_xarray():
     m = types.ModuleType("xarray")
     m.DataArray, m.Dataset, m.Coordinates = DataArray, Dataset, Coordinates
     m.apply_ufunc, m.date_range = apply_ufunc, date_range
+    m.testing = types.SimpleNamespace(assert_identical=_assert_identical,
+                                      assert_allclose=lambda a, b, **k: np.testing.assert_allclose(a.values, b.values, **k))
     m.__version__ = "0.0.shim"
     return m
 
