@@ -226,6 +226,8 @@ def main():
             "frac": achieved / 8000.0,
             "traffic": traffic,
             "kernel_ms": k_ms,
+            "kernel_ms_median": float(np.median(kernel_ms)),
+            "kernel_ms_min": float(np.min(kernel_ms)),
             "algorithmic_bytes": algo_bytes,
         },
     }
@@ -234,7 +236,8 @@ def main():
         # parity of this very run: a spread of time steps (night, sunrise, noon, sunset)
         from oracle import atlite_oracle as orc
 
-        sel = np.unique(np.clip(np.concatenate([np.arange(0, 48), np.arange(4000, 4048), [T_loc - 1]]), 0, T_loc - 1))
+        # 10 winter + 10 summer days (every sunrise / sunset in them) + the last step: >= 240 steps
+        sel = np.unique(np.clip(np.concatenate([np.arange(0, 240), np.arange(4000, 4240), [T_loc - 1]]), 0, T_loc - 1))
         got = out_local.cpu().numpy()[:, sel]
         host = {}
         for k in synthetic.PV_VARS:
@@ -261,6 +264,8 @@ def main():
         by_mem = max(1, int(0.4 * avail / (25 * 100 * S * 8)))
         cores = max(1, min(os.cpu_count() or 1, n_chunks, by_mem))
         cdt = min(cpu_baseline(host, M, cores)[0] for _ in range(2))
+        T1 = min(400, Tc)
+        cdt1 = cpu_baseline({k: v[:T1] for k, v in host.items()}, M, 1)[0]
         result["cpu_baseline"] = {
             "value": Tc * S / cdt,
             "unit": "cell-timesteps/s",
@@ -268,6 +273,8 @@ def main():
             "kind": "port",
             "sample": f"{Tc} of {T_loc} time steps (t={t_a}..{t_a + Tc}) of the same cutout and shapes; NumPy "
                       f"oracle over time chunks of 100 on a {cores}-thread pool ({cdt:.2f} s)",
+            "single_thread_value": T1 * S / cdt1,
+            "single_thread_sample": f"{T1} time steps, 1 thread ({cdt1:.2f} s)",
         }
 
     if rank == 0:
