@@ -449,7 +449,9 @@ __device__ __forceinline__ double pv_cell_sp(double dir, double dif, double toa,
     return pv_tail(direct, diffuse, influx, alb, tmp, s, ca, a.csaz * caz + a.ssaz * saz, o, k);
 }
 
-template <bool SP>
+// SP: in-kernel solar position; PC: per-cell orientation (else the scalar orientation is read from
+// the kernel arguments = SGPRs and costs no per-lane registers)
+template <bool SP, bool PC = false>
 struct PvConvT {
     atl_pv_inputs in;
     int64_t S;
@@ -463,10 +465,12 @@ struct PvConvT {
         int x0, x1;                 // grid column of the two cells
     };
     struct NoSp {};
-    struct Cell : std::conditional_t<SP, SpCell, NoSp> {
+    struct OriCell {
         PvOri o0, o1;
         PvAz<SP> a0, a1;
     };
+    struct NoOri {};
+    struct Cell : std::conditional_t<SP, SpCell, NoSp>, std::conditional_t<PC, OriCell, NoOri> {};
     __device__ void block_init(double *) const {}
     __device__ static PvOri make_ori(double slope, double azimuth) {
         PvOri r;
@@ -478,18 +482,13 @@ struct PvConvT {
     }
     __device__ Cell cell_setup(int64_t c0, bool v0, bool v1) const {
         Cell c;
-        if (cell_slope) {
+        if constexpr (PC) {
             c.o0 = make_ori(v0 ? cell_slope[c0] : 0.0, v0 ? cell_azimuth[c0] : 0.0);
             c.o1 = make_ori(v1 ? cell_slope[c0 + 1] : 0.0, v1 ? cell_azimuth[c0 + 1] : 0.0);
             if constexpr (SP) {
                 lean_sincos(c.o0.saz, &c.a0.ssaz, &c.a0.csaz);
                 lean_sincos(c.o1.saz, &c.a1.ssaz, &c.a1.csaz);
             }
-        } else {
-            c.o0 = o;
-            c.o1 = o;
-            c.a0 = oa;
-            c.a1 = oa;
         }
         if constexpr (SP) {
             const int64_t a = v0 ? c0 : 0, b = v1 ? c0 + 1 : 0;
@@ -534,19 +533,27 @@ struct PvConvT {
         return r;
     }
     __device__ __forceinline__ double2 compute(const Raw &q, bool v0, bool v1, const Cell &c, const double *) const {
+        const PvOri &o0 = [&]() -> const PvOri & { if constexpr (PC) return c.o0; else return o; }();
+        const PvOri &o1 = [&]() -> const PvOri & { if constexpr (PC) return c.o1; else return o; }();
         double2 r;
         if constexpr (SP) {
-            r.x = v0 ? pv_cell_sp(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.sd, q.cd, c.sl0, c.cl0, q.a.x, q.b.x, c.o0, c.a0, k) : 0.0;
-            r.y = v1 ? pv_cell_sp(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.sd, q.cd, c.sl1, c.cl1, q.a.y, q.b.y, c.o1, c.a1, k) : 0.0;
+            const PvAz<true> &a0 = [&]() -> const PvAz<true> & { if constexpr (PC) return c.a0; else return oa; }();
+            const PvAz<true> &a1 = [&]() -> const PvAz<true> & { if constexpr (PC) return c.a1; else return oa; }();
+            r.x = v0 ? pv_cell_sp(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.sd, q.cd, c.sl0, c.cl0, q.a.x, q.b.x, o0, a0, k) : 0.0;
+            r.y = v1 ? pv_cell_sp(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.sd, q.cd, c.sl1, c.cl1, q.a.y, q.b.y, o1, a1, k) : 0.0;
         } else {
-            r.x = v0 ? pv_cell(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.a.x, q.b.x, c.o0, k) : 0.0;
-            r.y = v1 ? pv_cell(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.a.y, q.b.y, c.o1, k) : 0.0;
+            r.x = v0 ? pv_cell(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.a.x, q.b.x, o0, k) : 0.0;
+            r.y = v1 ? pv_cell(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.a.y, q.b.y, o1, k) : 0.0;
         }
         return r;
     }
 };
 using PvConv = PvConvT<false>;
 using PvConvSP = PvConvT<true>;
+template <class T>
+struct pv_is_sp : std::false_type {};
+template <bool PC>
+struct pv_is_sp<PvConvT<true, PC>> : std::true_type {};
 
 // ---------------------------------------------------------------------------------------
 // general pv converter: every option of convert_pv / convert_irradiation / convert_solar_thermal
@@ -1332,7 +1339,7 @@ int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t 
     c->o.hp = (1.0 + c->o.cs) / 2.0;
     c->o.hm = (1.0 - c->o.cs) / 2.0;
     c->o.saz = p->azimuth;
-    if constexpr (std::is_same_v<PV, PvConvSP>) {
+    if constexpr (pv_is_sp<PV>::value) {
         c->oa.csaz = cos(p->azimuth);
         c->oa.ssaz = sin(p->azimuth);
     }
@@ -1341,6 +1348,15 @@ int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t 
     *vec = vec_ok(S, {in->d_influx_direct, in->d_influx_diffuse, in->d_influx_toa, in->d_albedo,
                       in->d_temperature, in->d_solar_altitude, in->d_solar_azimuth});
     return ATL_OK;
+}
+
+// f(converter instance) with the PvConvT instantiation for (stored / computed solar position,
+// scalar / per-cell orientation)
+template <class F>
+int pv_dispatch(const atl_pv_inputs *in, const atl_pv_params *p, F &&f) {
+    const bool sp = !(in->d_solar_altitude || in->d_solar_azimuth), pc = p->d_cell_slope != nullptr;
+    if (sp) return pc ? f(PvConvT<true, true>()) : f(PvConvT<true, false>());
+    return pc ? f(PvConvT<false, true>()) : f(PvConvT<false, false>());
 }
 
 bool pv_needs_general(const atl_pv_inputs *in, const atl_pv_params *p) {
@@ -1524,16 +1540,11 @@ int atl_pv_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p
         if (rc) return rc;
         return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
     }
-    if (in->d_solar_altitude || in->d_solar_azimuth) {
-        PvConv c;
+    return pv_dispatch(in, p, [&](auto c) {
         int rc = make_pv(in, p, T, S, &c, &vec);
         if (rc) return rc;
         return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
-    }
-    PvConvSP c;
-    int rc = make_pv(in, p, T, S, &c, &vec);
-    if (rc) return rc;
-    return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
+    });
 }
 
 int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T,
@@ -1546,16 +1557,11 @@ int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv
         if (rc) return rc;
         return run_fused(ctx, c, vec, 0, T, S, agg, time_agg, d_out, ld_out, "atl_pv_convert_aggregate");
     }
-    if (in->d_solar_altitude || in->d_solar_azimuth) {
-        PvConv c;
+    return pv_dispatch(in, p, [&](auto c) {
         int rc = make_pv(in, p, T, S, &c, &vec);
         if (rc) return rc;
         return run_fused(ctx, c, vec, 0, T, S, agg, time_agg, d_out, ld_out, "atl_pv_convert_aggregate");
-    }
-    PvConvSP c;
-    int rc = make_pv(in, p, T, S, &c, &vec);
-    if (rc) return rc;
-    return run_fused(ctx, c, vec, 0, T, S, agg, time_agg, d_out, ld_out, "atl_pv_convert_aggregate");
+    });
 }
 
 int atl_wind_convert(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p, int64_t T,
