@@ -189,6 +189,11 @@ SIGNATURES = {
          C.POINTER(_vp)],
     ),
     "atl_host_free": (_i, [_vp]),
+    "atl_comm_unique_id": (_i, [_vp]),
+    "atl_comm_init": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
+    "atl_comm_destroy": (_i, [_vp]),
+    "atl_allgather_time": (_i, [_vp, _vp, _i64, _i64, _vp, _i64]),
+    "atl_allreduce_sum": (_i, [_vp, _vp, _i64]),
     "atl_math_probe": (_i, [_vp, _i, _vp, _i64, _vp]),
     "atl_synth_field": (
         _i,

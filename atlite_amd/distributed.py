@@ -99,3 +99,59 @@ def reduce_time(local_sum, local_count, mean, group=None):
         dist.all_reduce(both, group=group)
     out = both[0] / both[1] if mean else both[0]
     return out.numpy() if is_np else out
+
+
+class RcclComm:
+    """
+    The library's own RCCL communicator (C ABI ``atl_comm_*``) for hosts that do not use
+    torch.distributed: rank 0 calls ``RcclComm.unique_id()`` and ships the 128 bytes to the other
+    ranks by any means; every rank then constructs ``RcclComm(ctx, n_ranks, rank, uid)``.
+    """
+
+    def __init__(self, ctx, n_ranks, rank, uid):
+        import ctypes as C
+
+        from ._lib import check
+
+        assert len(uid) == 128
+        self.ctx, self.n_ranks, self.rank = ctx, int(n_ranks), int(rank)
+        buf = C.create_string_buffer(bytes(uid), 128)
+        h = C.c_void_p()
+        check(ctx.lib.atl_comm_init(ctx.handle, self.n_ranks, self.rank, buf, C.byref(h)))
+        self.handle = h
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+
+        from . import _lib
+
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().atl_comm_unique_id(buf))
+        return bytes(buf.raw)
+
+    def gather_time(self, local):
+        """local: DeviceArray (N, T_r), same T_r on every rank -> DeviceArray (N, n_ranks * T_r)."""
+        from ._lib import check
+
+        N, T_r = local.shape
+        out = self.ctx.empty((N, self.n_ranks * T_r))
+        check(self.ctx.lib.atl_allgather_time(self.handle, local.ptr, N, T_r, out.ptr, self.n_ranks * T_r))
+        return out
+
+    def allreduce_sum(self, buf):
+        from ._lib import check
+
+        check(self.ctx.lib.atl_allreduce_sum(self.handle, buf.ptr, buf.size))
+        return buf
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.lib.atl_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -290,6 +290,27 @@ int atl_indicator_polygons(int64_t n_shapes, const int64_t *h_shape_ring_ptr, in
                            double **out_data);
 int atl_host_free(void *p);
 
+/* ---- multi-GPU (RCCL over xGMI) ------------------------------------------------------------------
+ * One process (and one atl_ctx) per GPU, the TIME axis sharded: rank r converts and aggregates its
+ * own time slab; the small (shapes x time) result is reassembled with one collective.  The
+ * reference has no distributed path (its parallelism is dask threads over time chunks,
+ * atlite/cutout.py:143).  RCCL is opened lazily - single-GPU use does not need it.
+ *   rank 0: atl_comm_unique_id(id) -> ship the 128 bytes to every rank (MPI, sockets, a file ...)
+ *   all   : atl_comm_init(ctx, n_ranks, rank, id, &comm)
+ * atl_allgather_time: every rank holds a contiguous (N x T_r) block, same T_r everywhere; on return
+ * d_out (N x n_ranks*T_r, row stride ld_out) holds the blocks in rank order on every rank.
+ * atl_allreduce_sum: in-place sum over ranks (time sums and counts of aggregate_time="sum"/"mean").
+ * Both are enqueued on the context's stream.
+ */
+#define ATL_COMM_ID_BYTES 128
+typedef struct atl_comm atl_comm;
+int atl_comm_unique_id(void *h_id128);
+int atl_comm_init(atl_ctx *ctx, int n_ranks, int rank, const void *h_id128, atl_comm **out);
+int atl_comm_destroy(atl_comm *comm);
+int atl_allgather_time(atl_comm *comm, const double *d_local, int64_t N, int64_t T_r, double *d_out,
+                       int64_t ld_out);
+int atl_allreduce_sum(atl_comm *comm, double *d_buf, int64_t n);
+
 /* ---- diagnostics ------------------------------------------------------------------------
  * Evaluates the kernels' lean fp64 math (atl_math.h) elementwise, for accuracy tests:
  * fn 0 sin, 1 cos, 2 log: d_in (n) -> d_out (n);  3 sincos: d_out (2n) = sin | cos;

@@ -275,3 +275,17 @@ def test_partial_row_windowing(ctx, monkeypatch):
     ds = H.pv_dataset(T, Y, X, seed=1)
     refpv = orc.aggregate_matrix(orc.convert_pv(ds, H.CSI, dict(slope=np.radians(30.0), azimuth=np.radians(180.0))), M)
     close(ctx.pv(up(ctx, ds), PV_PARAMS, T, Y * X, plan=plan).numpy(), refpv)
+
+
+def test_rccl_comm_single_rank(ctx):
+    """C-ABI RCCL communicator: with one rank the all-gather is a placement copy and the all-reduce
+    the identity (the multi-rank flow is covered by tests/test_distributed_gloo.py and by
+    `bench.py --debug-gloo-one-gpu`)."""
+    from atlite_amd.distributed import RcclComm
+
+    comm = RcclComm(ctx, 1, 0, RcclComm.unique_id())
+    a = np.random.default_rng(0).random((5, 37))
+    d = ctx.upload(a)
+    np.testing.assert_array_equal(comm.gather_time(d).numpy(), a)
+    np.testing.assert_array_equal(comm.allreduce_sum(d).numpy(), a)
+    comm.close()
