@@ -86,6 +86,20 @@ __device__ __forceinline__ void st2(double *__restrict__ p, int64_t off, bool v0
 // converters
 // ---------------------------------------------------------------------------------------
 struct NoCell {};
+struct NoCarry {};  // per-wave state a converter may keep across consecutive slots (pv night skip)
+// converters may define batch_prefetch<VEC>(sb, send, c0, c1, carry); the others get this no-op
+template <bool VEC, class Conv, class Carry>
+__device__ __forceinline__ auto batch_prefetch(const Conv &conv, int64_t sb, int64_t send, int64_t c0, int64_t c1,
+                                               Carry &carry, int) -> decltype(conv.template batch_prefetch<VEC>(sb, send, c0, c1, carry)) {
+    conv.template batch_prefetch<VEC>(sb, send, c0, c1, carry);
+}
+template <bool VEC, class Conv, class Carry>
+__device__ __forceinline__ void batch_prefetch(const Conv &, int64_t, int64_t, int64_t, int64_t, Carry &, long) {}
+
+template <class C>
+__device__ __forceinline__ C carry_init() {
+    return C{};
+}
 
 // generic dense cube (aggregate_matrix on an arbitrary converted DataArray)
 struct IdentityConv {
@@ -96,8 +110,9 @@ struct IdentityConv {
     __device__ Cell cell_setup(int64_t, bool, bool) const { return {}; }
     static constexpr int kGroup = 8;  // slots whose loads are issued before any compute
     using Raw = double2;
+    using Carry = NoCarry;
     template <bool VEC>
-    __device__ __forceinline__ Raw load(int64_t slot, int64_t c0, int64_t c1, const Cell &) const {
+    __device__ __forceinline__ Raw load(int64_t slot, int, int64_t c0, int64_t c1, const Cell &, Carry &) const {
         return ld2<VEC>(d, slot * S, c0, c1);
     }
     __device__ __forceinline__ double2 compute(const Raw &r, bool, bool, const Cell &, const double *) const {
@@ -122,8 +137,9 @@ struct RunoffConv {
     }
     static constexpr int kGroup = 8;
     using Raw = double2;
+    using Carry = NoCarry;
     template <bool VEC>
-    __device__ __forceinline__ Raw load(int64_t slot, int64_t c0, int64_t c1, const Cell &) const {
+    __device__ __forceinline__ Raw load(int64_t slot, int, int64_t c0, int64_t c1, const Cell &, Carry &) const {
         return ld2<VEC>(runoff, slot * S, c0, c1);
     }
     __device__ __forceinline__ double2 compute(Raw r, bool, bool, const Cell &c, const double *) const {
@@ -155,8 +171,9 @@ struct ThermoConv {
     }
     static constexpr int kGroup = 8;
     using Raw = double2;
+    using Carry = NoCarry;
     template <bool VEC>
-    __device__ __forceinline__ Raw load(int64_t slot, int64_t c0_, int64_t c1_, const Cell &) const {
+    __device__ __forceinline__ Raw load(int64_t slot, int, int64_t c0_, int64_t c1_, const Cell &, Carry &) const {
         return ld2<VEC>(var, slot * S, c0_, c1_);
     }
     __device__ __forceinline__ double2 compute(const Raw &v, bool v0, bool v1, const Cell &, const double *) const {
@@ -182,8 +199,9 @@ struct HeatConv {
         double sx, sy;
         int nx, ny;
     };
+    using Carry = NoCarry;
     template <bool VEC>
-    __device__ __forceinline__ Raw load(int64_t slot, int64_t c0, int64_t c1, const Cell &) const {
+    __device__ __forceinline__ Raw load(int64_t slot, int, int64_t c0, int64_t c1, const Cell &, Carry &) const {
         const int64_t t0 = day_ptr[slot], t1 = day_ptr[slot + 1];
         Raw r{0.0, 0.0, 0, 0};
 #pragma unroll 8
@@ -331,8 +349,9 @@ struct WindConvT {
     struct Raw {
         double2 v, z;
     };
+    using Carry = NoCarry;
     template <bool VEC>
-    __device__ __forceinline__ Raw load(int64_t slot, int64_t c0, int64_t c1, const Cell &c) const {
+    __device__ __forceinline__ Raw load(int64_t slot, int, int64_t c0, int64_t c1, const Cell &c, Carry &) const {
         Raw r;
         r.v = ld2<VEC>(wnd, slot * S, c0, c1);
         r.z = c.aux;
@@ -451,8 +470,13 @@ __device__ __forceinline__ double pv_cell_sp(double dir, double dif, double toa,
 
 // SP: in-kernel solar position; PC: per-cell orientation (else the scalar orientation is read from
 // the kernel arguments = SGPRs and costs no per-lane registers)
-template <bool SP, bool PC = false>
+// SKIP: night early-out (stored solar position only): when every valid cell of the wave is below
+// the altitude cut-off the other six streams are not read - the result is exactly +0.0 whatever
+// they hold (pv_cell).  The altitude of the NEXT slot is prefetched together with the current slot's
+// streams (Carry), so day-time slots still cost one memory round trip.
+template <bool SP, bool PC = false, bool SKIP = false>
 struct PvConvT {
+    static_assert(!(SP && SKIP), "night skip is implemented for stored solar angles");
     atl_pv_inputs in;
     int64_t S;
     PvConst k;
@@ -470,7 +494,9 @@ struct PvConvT {
         PvAz<SP> a0, a1;
     };
     struct NoOri {};
-    struct Cell : std::conditional_t<SP, SpCell, NoSp>, std::conditional_t<PC, OriCell, NoOri> {};
+    struct Cell : std::conditional_t<SP, SpCell, NoSp>, std::conditional_t<PC, OriCell, NoOri> {
+        bool no_cell;  // SKIP: this lane owns no cell at all (tile padding)
+    };
     __device__ void block_init(double *) const {}
     __device__ static PvOri make_ori(double slope, double azimuth) {
         PvOri r;
@@ -482,6 +508,7 @@ struct PvConvT {
     }
     __device__ Cell cell_setup(int64_t c0, bool v0, bool v1) const {
         Cell c;
+        c.no_cell = !v0 && !v1;
         if constexpr (PC) {
             c.o0 = make_ori(v0 ? cell_slope[c0] : 0.0, v0 ? cell_azimuth[c0] : 0.0);
             c.o1 = make_ori(v1 ? cell_slope[c0 + 1] : 0.0, v1 ? cell_azimuth[c0 + 1] : 0.0);
@@ -508,10 +535,43 @@ struct PvConvT {
         double2 a, b;    // getter: altitude, azimuth   SP: hour angle, cos(hour angle)
         double sd, cd;   // SP: sin / cos declination of the slot
     };
+    struct SkipCarry {
+        double2 alt[kBatch];  // solar altitude of the batch's slots, prefetched one batch ahead
+    };
+    using Carry = std::conditional_t<SKIP, SkipCarry, NoCarry>;
+    // called before the first batch and again right after a batch has been converted (i.e. while it
+    // is being reduced): the next batch's altitudes are in flight behind the wave reduction
     template <bool VEC>
-    __device__ __forceinline__ Raw load(int64_t slot, int64_t c0, int64_t c1, const Cell &c) const {
+    __device__ __forceinline__ void batch_prefetch(int64_t sb, int64_t send, int64_t c0, int64_t c1, Carry &carry) const {
+        if constexpr (SKIP) {
+#pragma unroll
+            for (int i = 0; i < kBatch; ++i)
+                carry.alt[i] = ld2<VEC>(in.d_solar_altitude, min(sb + i, send - 1) * S, c0, c1);
+        }
+    }
+    template <bool VEC>
+    __device__ __forceinline__ Raw load(int64_t slot, int i, int64_t c0, int64_t c1, const Cell &c, Carry &carry) const {
         const int64_t off = slot * S;
         Raw r;
+        if constexpr (SKIP) {
+            r.a = carry.alt[i];
+            r.sd = r.cd = 0.0;
+            // capped <=> alt < threshold (a NaN altitude is NOT capped); lanes that own no cell loaded
+            // some other cell's altitude and vote "night" unconditionally
+            const bool night = (r.a.x < k.alt_thr) && (r.a.y < k.alt_thr);
+            if (__all(night || c.no_cell)) {
+                const double2 z = {0.0, 0.0};
+                r.dir = r.dif = r.toa = r.alb = r.tmp = r.b = z;
+                return r;
+            }
+            r.dir = ld2<VEC>(in.d_influx_direct, off, c0, c1);
+            r.dif = ld2<VEC>(in.d_influx_diffuse, off, c0, c1);
+            r.toa = ld2<VEC>(in.d_influx_toa, off, c0, c1);
+            r.alb = ld2<VEC>(in.d_albedo, off, c0, c1);
+            r.tmp = ld2<VEC>(in.d_temperature, off, c0, c1);
+            r.b = ld2<VEC>(in.d_solar_azimuth, off, c0, c1);
+            return r;
+        }
         r.dir = ld2<VEC>(in.d_influx_direct, off, c0, c1);
         r.dif = ld2<VEC>(in.d_influx_diffuse, off, c0, c1);
         r.toa = ld2<VEC>(in.d_influx_toa, off, c0, c1);
@@ -552,8 +612,8 @@ using PvConv = PvConvT<false>;
 using PvConvSP = PvConvT<true>;
 template <class T>
 struct pv_is_sp : std::false_type {};
-template <bool PC>
-struct pv_is_sp<PvConvT<true, PC>> : std::true_type {};
+template <bool PC, bool SK>
+struct pv_is_sp<PvConvT<true, PC, SK>> : std::true_type {};
 
 // ---------------------------------------------------------------------------------------
 // general pv converter: every option of convert_pv / convert_irradiation / convert_solar_thermal
@@ -731,8 +791,9 @@ struct PvxConv {
     struct Raw {
         double2 dir, dif, inf, toa, alb, ouf, tmp, hum, alt, az;
     };
+    using Carry = NoCarry;
     template <bool VEC>
-    __device__ __forceinline__ Raw load(int64_t slot, int64_t c0, int64_t c1, const Cell &c) const {
+    __device__ __forceinline__ Raw load(int64_t slot, int, int64_t c0, int64_t c1, const Cell &c, Carry &) const {
         const int64_t off = slot * S;
         const double2 zero = {0.0, 0.0};
         Raw r;
@@ -782,10 +843,11 @@ __global__ __launch_bounds__(256) void k_cells_series(Conv conv, int64_t n_slots
     const int64_t s0 = int64_t(blockIdx.y) * kSeriesSlots;
     const int64_t s1 = min(s0 + int64_t(kSeriesSlots), n_slots);
     constexpr int G = Conv::kGroup >= 4 ? 4 : Conv::kGroup;
+    typename Conv::Carry carry = carry_init<typename Conv::Carry>();
     for (int64_t sg = s0; sg < s1; sg += G) {
         typename Conv::Raw raw[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) raw[g] = conv.template load<VEC>(min(sg + g, s1 - 1), s0c, s1c, cell);
+        for (int g = 0; g < G; ++g) raw[g] = conv.template load<VEC>(min(sg + g, s1 - 1), g, s0c, s1c, cell, carry);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const double2 r = conv.compute(raw[g], v0, v1, cell, lds);
@@ -812,10 +874,11 @@ __global__ __launch_bounds__(256) void k_cells_timered(Conv conv, int64_t n_slot
     const int64_t s1 = min(s0 + chunk_len, n_slots);
     double2 acc = {0.0, 0.0}, cnt = {0.0, 0.0};
     constexpr int G = Conv::kGroup >= 4 ? 4 : Conv::kGroup;
+    typename Conv::Carry carry = carry_init<typename Conv::Carry>();
     for (int64_t sg = s0; sg < s1; sg += G) {
         typename Conv::Raw raw[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) raw[g] = conv.template load<VEC>(min(sg + g, s1 - 1), s0c, s1c, cell);
+        for (int g = 0; g < G; ++g) raw[g] = conv.template load<VEC>(min(sg + g, s1 - 1), g, s0c, s1c, cell, carry);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const double2 r = conv.compute(raw[g], v0, v1, cell, lds);
@@ -969,6 +1032,8 @@ __global__ __launch_bounds__(256, ATL_FUSED_WAVES) void k_fused_segred(Conv conv
     const int64_t sbeg = slot0 + chunk * chunk_slots;
     const int64_t send = min(sbeg + int64_t(chunk_slots), slot0 + n_slots);
     partials -= slot0;
+    typename Conv::Carry carry = carry_init<typename Conv::Carry>();
+    batch_prefetch<VEC>(conv, sbeg, send, s0c, s1c, carry, 0);
     for (int64_t sb = sbeg; sb < send; sb += kBatch) {
         double2 v[kBatch];
         bool finite = true;
@@ -981,7 +1046,7 @@ __global__ __launch_bounds__(256, ATL_FUSED_WAVES) void k_fused_segred(Conv conv
             typename Conv::Raw raw[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                raw[g] = conv.template load<VEC>(min(sb + i0 + g, send - 1), s0c, s1c, cell);
+                raw[g] = conv.template load<VEC>(min(sb + i0 + g, send - 1), i0 + g, s0c, s1c, cell, carry);
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
@@ -994,6 +1059,7 @@ __global__ __launch_bounds__(256, ATL_FUSED_WAVES) void k_fused_segred(Conv conv
                 finite = finite && (__builtin_fabs(v[i].x) < __builtin_inf()) && (__builtin_fabs(v[i].y) < __builtin_inf());
             }
         }
+        if (sb + kBatch < send) batch_prefetch<VEC>(conv, sb + kBatch, send, s0c, s1c, carry, 0);
 #ifdef ATL_ABLATE_NOREDUCE  // experiment: conversion only, one dummy store per batch
         {
             double acc = 0.0;
@@ -1353,9 +1419,10 @@ int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t 
 // f(converter instance) with the PvConvT instantiation for (stored / computed solar position,
 // scalar / per-cell orientation)
 template <class F>
-int pv_dispatch(const atl_pv_inputs *in, const atl_pv_params *p, F &&f) {
+int pv_dispatch(const atl_pv_inputs *in, const atl_pv_params *p, bool allow_skip, F &&f) {
     const bool sp = !(in->d_solar_altitude || in->d_solar_azimuth), pc = p->d_cell_slope != nullptr;
     if (sp) return pc ? f(PvConvT<true, true>()) : f(PvConvT<true, false>());
+    if (p->night_skip && allow_skip) return pc ? f(PvConvT<false, true, true>()) : f(PvConvT<false, false, true>());
     return pc ? f(PvConvT<false, true>()) : f(PvConvT<false, false>());
 }
 
@@ -1540,7 +1607,7 @@ int atl_pv_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p
         if (rc) return rc;
         return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
     }
-    return pv_dispatch(in, p, [&](auto c) {
+    return pv_dispatch(in, p, false, [&](auto c) {  // night skip: fused (aggregating) kernel only
         int rc = make_pv(in, p, T, S, &c, &vec);
         if (rc) return rc;
         return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
@@ -1557,7 +1624,7 @@ int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv
         if (rc) return rc;
         return run_fused(ctx, c, vec, 0, T, S, agg, time_agg, d_out, ld_out, "atl_pv_convert_aggregate");
     }
-    return pv_dispatch(in, p, [&](auto c) {
+    return pv_dispatch(in, p, true, [&](auto c) {
         int rc = make_pv(in, p, T, S, &c, &vec);
         if (rc) return rc;
         return run_fused(ctx, c, vec, 0, T, S, agg, time_agg, d_out, ld_out, "atl_pv_convert_aggregate");

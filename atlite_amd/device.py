@@ -7,6 +7,7 @@ reference's Python interface lives in ``atlite_amd.convert``.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -271,6 +272,7 @@ class Context:
         pp.trigon_model = _lib.TRIGON[options.get("trigon_model", "simple")]
         pp.clearsky_model = _lib.CLEARSKY[options.get("clearsky_model") or "simple"]
         pp.irradiation = _lib.IRRADIATION[options.get("irradiation", "total")]
+        pp.night_skip = 1 if options.get("night_skip", os.environ.get("ATLITE_HIP_NIGHT_SKIP", "1") == "1") else 0
         slope, azimuth = params["slope"], params["azimuth"]
         if not isinstance(slope, DeviceArray) and np.ndim(slope) == 0 and np.ndim(azimuth) == 0:
             pp.slope, pp.azimuth = float(slope), float(azimuth)

@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3200, help="time steps of the CPU baseline sample")
+    ap.add_argument("--night-skip", action="store_true",
+                    help="enable the night early-out (not the default measurement: it reads fewer bytes than "
+                         "the 56 B/cell the roofline figure assumes)")
     ap.add_argument("--debug-gloo-one-gpu", action="store_true",
                     help="testing only: all ranks share GPU 0 and the collective runs over gloo on host copies")
     return ap.parse_args()
@@ -142,6 +145,7 @@ def main():
         setattr(pp, k if k not in ("slope", "azimuth") else k, float(v))
     pp.d_cell_slope = pp.d_cell_azimuth = None
     pp.altitude_threshold = float(np.radians(1.0))
+    pp.night_skip = 1 if a.night_skip else 0
 
     def step():
         _lib.check(ctx.lib.atl_pv_convert_aggregate(ctx.handle, C.byref(pin), C.byref(pp), T_loc, S,
@@ -214,6 +218,7 @@ def main():
                         f"{N} {a.shape_kind} polygon shapes, aggregate_time=None",
             "parallelism": f"time-sharded x{world}" + (" + RCCL all-gather" if world > 1 else ""),
             "time_steps_per_gpu": T_loc,
+            "night_skip": bool(a.night_skip),
             "cell_tile": f"{plan_info['tile_w']}x{plan_info['tile_h']}",
             "partial_rows": plan_info["n_partial_rows"],
         },

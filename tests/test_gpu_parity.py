@@ -289,3 +289,27 @@ def test_rccl_comm_single_rank(ctx):
     np.testing.assert_array_equal(comm.gather_time(d).numpy(), a)
     np.testing.assert_array_equal(comm.allreduce_sum(d).numpy(), a)
     comm.close()
+
+
+@pytest.mark.parametrize("Y,X", [(12, 20), (5, 27)])
+def test_pv_night_skip_is_bit_identical(ctx, Y, X):
+    """night_skip only avoids reading streams whose values cannot matter: identical bits, for the
+    fused, per-cell and time-reduced kernels, scalar and per-cell orientation, NaN altitudes."""
+    T, N = 72, 5
+    ds = H.pv_dataset(T, Y, X, seed=9)
+    ds["solar_altitude"][40, 3] = np.nan          # a NaN altitude is not "night"
+    ds["temperature"][2, :] = np.nan              # night rows: NaN inputs must not leak either way
+    ds["influx_direct"][3, :] = np.inf
+    M = H.blob_matrix(N, Y, X, seed=10)
+    plan = ctx.plan(M, row_len=X)
+    dev = up(ctx, ds)
+    _, y = H.grid(Y, X)
+    lo = orc.orientation_latitude_optimal(np.radians(y))
+    for params in (PV_PARAMS, dict(H.CSI, slope=np.repeat(lo["slope"], X), azimuth=np.repeat(lo["azimuth"], X))):
+        for kw in (dict(plan=plan), dict(), dict(time_agg="sum"), dict(plan=plan, time_agg="mean")):
+            a = ctx.pv(dev, params, T, Y * X, options=dict(night_skip=False), **kw).numpy()
+            b = ctx.pv(dev, params, T, Y * X, options=dict(night_skip=True), **kw).numpy()
+            np.testing.assert_array_equal(a, b)
+    ref = orc.aggregate_matrix(orc.convert_pv(ds, H.CSI, dict(slope=np.radians(30.0), azimuth=np.radians(180.0))), M)
+    got = ctx.pv(dev, PV_PARAMS, T, Y * X, plan=plan, options=dict(night_skip=True)).numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-12 * np.nanmax(np.abs(ref[np.isfinite(ref)])), equal_nan=True)
