@@ -107,7 +107,7 @@ struct IdentityConv {
     int64_t S;
     using Cell = NoCell;
     __device__ void block_init(double *) const {}
-    __device__ Cell cell_setup(int64_t, bool, bool) const { return {}; }
+    __device__ Cell cell_setup(int64_t, bool, bool, const double *) const { return {}; }
     static constexpr int kGroup = 8;  // slots whose loads are issued before any compute
     using Raw = double2;
     using Carry = NoCarry;
@@ -129,7 +129,7 @@ struct RunoffConv {
         double2 h;
     };
     __device__ void block_init(double *) const {}
-    __device__ Cell cell_setup(int64_t c0, bool v0, bool v1) const {
+    __device__ Cell cell_setup(int64_t c0, bool v0, bool v1, const double *lds) const {
         Cell c;
         c.h.x = (height && v0) ? height[c0] : 1.0;
         c.h.y = (height && v1) ? height[c0 + 1] : 1.0;
@@ -159,7 +159,7 @@ struct ThermoConv {
     int fillna0, quadratic;
     using Cell = NoCell;
     __device__ void block_init(double *) const {}
-    __device__ Cell cell_setup(int64_t, bool, bool) const { return {}; }
+    __device__ Cell cell_setup(int64_t, bool, bool, const double *) const { return {}; }
     __device__ __forceinline__ double f(double v) const {
         double x = v + offset;
         if (fillna0) x = fill0(x);
@@ -193,7 +193,7 @@ struct HeatConv {
     int cooling;
     using Cell = NoCell;
     __device__ void block_init(double *) const {}
-    __device__ Cell cell_setup(int64_t, bool, bool) const { return {}; }
+    __device__ Cell cell_setup(int64_t, bool, bool, const double *) const { return {}; }
     static constexpr int kGroup = 1;  // a slot is a whole day: its own loop keeps 8 loads in flight
     struct Raw {
         double sx, sy;
@@ -263,8 +263,9 @@ struct WindConvT {
     };
     __device__ void block_init(double *lds) const {
         for (int i = threadIdx.x; i < 5 * n_pad; i += blockDim.x) lds[i] = table[i];
+        if constexpr (METHOD == ATL_WIND_LOG) log_table_init(lds + 5 * n_pad);
     }
-    __device__ Cell cell_setup(int64_t c0, bool v0, bool v1) const {
+    __device__ Cell cell_setup(int64_t c0, bool v0, bool v1, const double *lds) const {
         Cell c;
         c.aux.x = 0.0;
         c.aux.y = 0.0;
@@ -272,10 +273,11 @@ struct WindConvT {
             c.aux.x = v0 ? aux[c0] : 1.0;
             c.aux.y = v1 ? aux[c0 + 1] : 1.0;
         }
-        // through the same log as the per-cell roughness: z0 == from_height gives an exact zero
-        // denominator, like the reference's log(from/z0) = log(1)
-        c.lh = log_core(to_height);
-        c.lf = log_core(from_height);
+        // log(from) through the same routine as the per-cell roughness: z0 == from_height gives an
+        // exact zero denominator, like the reference's log(from/z0) = log(1)
+        c.lh = 0.0;
+        c.lf = 0.0;
+        if constexpr (METHOD == ATL_WIND_LOG) c.lf = log_core_tab(from_height, lds + 5 * n_pad);
         return c;
     }
     // wind.py:99-101 / :111, literally; used for the rare arguments the fast path excludes
@@ -285,19 +287,23 @@ struct WindConvT {
         return v;
     }
     // fast path: *rare is set when the literal formula must be used instead
-    __device__ __forceinline__ double hub_speed_fast(double v, double z, const Cell &c, bool *rare) const {
+    __device__ __forceinline__ double hub_speed_fast(double v, double z, const Cell &c, bool *rare,
+                                                     const double *lds) const {
         if constexpr (METHOD == ATL_WIND_LOG) {
-            // v * (log(to/z0) / log(from/z0)) with log(a/z0) = log a - log z0: one log per cell
+            // v * (log(to/z0) / log(from/z0))  =  v * (1 + log(to/from) / (log(from) - log(z0))):
+            // one table-driven log and one reciprocal per cell.  log(from) goes through the same
+            // routine, so z0 == from gives den == 0 exactly (-> rare path -> the literal formula).
+            const double *ltab = lds + 5 * n_pad;
             const bool zok = z >= 0x1.0p-1022 && z < __builtin_inf();
 #ifdef ATL_ABLATE_WIND_NOLOG
             const double lz = z;
 #else
-            const double lz = log_core(zok ? z : 1.0);
+            const double lz = log_core_tab(zok ? z : 1.0, ltab);
 #endif
-            const double num = c.lh - lz, den = c.lf - lz;
-            const bool tame = __builtin_fabs(den) > 0x1.0p-40;  // |num|, |den| < 1500 always
+            const double den = c.lf - lz;
+            const bool tame = __builtin_fabs(den) > 0x1.0p-40;  // |den| < 1500 always
             *rare = !(zok && tame);
-            return v * fast_div(num, den);
+            return v * __builtin_fma(log_ratio, fast_rcp(den), 1.0);
         } else if constexpr (METHOD == ATL_WIND_POWER) {
             *rare = false;
             return v * exp(z * log_ratio);  // v * (to/from) ** shear
@@ -367,7 +373,7 @@ struct WindConvT {
             r.y = interp_generic(hub_speed_literal(v.y, z.y), lds);
         } else {
             bool r0, r1;
-            double h0 = hub_speed_fast(v.x, z.x, c, &r0), h1 = hub_speed_fast(v.y, z.y, c, &r1);
+            double h0 = hub_speed_fast(v.x, z.x, c, &r0, lds), h1 = hub_speed_fast(v.y, z.y, c, &r1, lds);
             if ((r0 && v0) || (r1 && v1)) {  // degenerate roughness: literal formula, out of line
                 h0 = hub_speed_literal(v.x, z.x);
                 h1 = hub_speed_literal(v.y, z.y);
@@ -506,7 +512,7 @@ struct PvConvT {
         r.saz = azimuth;
         return r;
     }
-    __device__ Cell cell_setup(int64_t c0, bool v0, bool v1) const {
+    __device__ Cell cell_setup(int64_t c0, bool v0, bool v1, const double *lds) const {
         Cell c;
         c.no_cell = !v0 && !v1;
         if constexpr (PC) {
@@ -754,7 +760,7 @@ struct PvxConv {
         int x0, x1;
     };
     __device__ void block_init(double *) const {}
-    __device__ Cell cell_setup(int64_t c0, bool v0, bool v1) const {
+    __device__ Cell cell_setup(int64_t c0, bool v0, bool v1, const double *lds) const {
         Cell c;
         c.sl0 = c.sl1 = slope;
         c.az0 = c.az1 = azimuth;
@@ -839,7 +845,7 @@ __global__ __launch_bounds__(256) void k_cells_series(Conv conv, int64_t n_slots
     const int64_t c0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * 2;
     const bool v0 = c0 < S, v1 = c0 + 1 < S;
     const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);  // safe indices
-    const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1);
+    const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
     const int64_t s0 = int64_t(blockIdx.y) * kSeriesSlots;
     const int64_t s1 = min(s0 + int64_t(kSeriesSlots), n_slots);
     constexpr int G = Conv::kGroup >= 4 ? 4 : Conv::kGroup;
@@ -869,7 +875,7 @@ __global__ __launch_bounds__(256) void k_cells_timered(Conv conv, int64_t n_slot
     const int64_t c0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * 2;
     const bool v0 = c0 < S, v1 = c0 + 1 < S;
     const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);  // safe indices
-    const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1);
+    const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
     const int64_t s0 = int64_t(blockIdx.y) * chunk_len;
     const int64_t s1 = min(s0 + chunk_len, n_slots);
     double2 acc = {0.0, 0.0}, cnt = {0.0, 0.0};
@@ -1012,7 +1018,7 @@ __global__ __launch_bounds__(256, ATL_FUSED_WAVES) void k_fused_segred(Conv conv
     const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);  // safe indices: loads never branch
     const int32_t p0 = plan.seg_ptr[seg], p1 = plan.seg_ptr[seg + 1];
     if (p0 == p1) return;  // no shape touches this tile: nothing to read
-    const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1);
+    const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
     // weights of the first kRowCache partial rows: registers for the whole chunk
     double2 wc[kRowCache];
     unsigned present = 0;  // bit 2r / 2r+1: cell 0 / 1 structurally present in row r
@@ -1199,6 +1205,9 @@ __global__ __launch_bounds__(256) void k_synth_pv(atl_synth_solar s, int64_t T, 
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_math_probe(int fn, const double *__restrict__ in, int64_t n,
                                                     double *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) double ltab[2 * kLogTabN];
+    log_table_init(ltab);
+    __syncthreads();
     const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (i >= n) return;
     const double x = in[i];
@@ -1214,6 +1223,7 @@ __global__ __launch_bounds__(256) void k_math_probe(int fn, const double *__rest
             out[n + i] = c;
             break;
         }
+        case 5: r = log_core_tab(x, ltab); break;  // positive normal finite arguments only
         default: r = fast_div(x, in[n + i]); break;
     }
     out[i] = r;
@@ -1530,7 +1540,7 @@ int make_wind(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p,
     c->n_knots = n;
     c->n_pad = n_pad;
     *table_finite = finite;
-    *lds_bytes = size_t(5 * n_pad) * sizeof(double);
+    *lds_bytes = size_t(5 * n_pad + 2 * kLogTabN) * sizeof(double);
     *vec = vec_ok(S, {in->d_wnd, in->aux_is_static ? nullptr : in->d_aux});
     return ATL_OK;
 }
@@ -1717,7 +1727,7 @@ int atl_runoff_convert_aggregate(atl_ctx *ctx, const double *d_runoff, const dou
 
 int atl_math_probe(atl_ctx *ctx, int fn, const double *d_in, int64_t n, double *d_out) {
     ATL_REQUIRE(ctx && d_in && d_out && n >= 0, "atl_math_probe: bad argument");
-    ATL_REQUIRE(fn >= 0 && fn <= 4, "atl_math_probe: fn must be 0..4");
+    ATL_REQUIRE(fn >= 0 && fn <= 5, "atl_math_probe: fn must be 0..5");
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     if (n == 0) return ATL_OK;
     hipLaunchKernelGGL(k_math_probe, dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, fn, d_in, n,

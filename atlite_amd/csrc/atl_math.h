@@ -122,6 +122,46 @@ __device__ __forceinline__ double log_core(double x) {
            ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
 }
 
+// ---- table-driven log (for kernels that already use LDS) ------------------------------------------
+// x = 2^e * m, m in [sqrt(1/2), sqrt(2)); c = round(128 m)/128 is exact in fp64 and the table holds
+// {fl(1/c), fl(log c)} for c = 90/128 .. 182/128 (c = 1: {1, 0} exactly, so arguments near 1 keep full
+// RELATIVE accuracy); r = m/c - 1, |r| <= 1/180, log1p(r) by a degree-7 Taylor polynomial
+// (truncation < 4e-18).  No reciprocal, ~17 VALU slots + one 16-byte LDS read.  <= 2 ulp measured.
+constexpr int kLogTabLo = 90, kLogTabHi = 182, kLogTabN = kLogTabHi - kLogTabLo + 1;  // 93 entries
+
+// fills tab[2*kLogTabN] (LDS); call from all threads of the block, then __syncthreads()
+__device__ __forceinline__ void log_table_init(double *tab) {
+    for (int i = threadIdx.x; i < kLogTabN; i += blockDim.x) {
+        const double c = double(kLogTabLo + i) * 0x1.0p-7;
+        tab[2 * i] = 1.0 / c;  // IEEE division, once per block
+        tab[2 * i + 1] = (kLogTabLo + i == 128) ? 0.0 : log_core(c);
+    }
+}
+
+__device__ __forceinline__ double log_core_tab(double x, const double *tab) {
+    unsigned hi = unsigned(__double2hiint(x));
+    const unsigned lo = unsigned(__double2loint(x));
+    hi += 0x3ff00000u - 0x3fe6a09eu;
+    const int e = int(hi >> 20) - 0x3ff;
+    hi = (hi & 0x000fffffu) + 0x3fe6a09eu;
+    const double m = __hiloint2double(int(hi), int(lo));           // [sqrt(1/2), sqrt(2))
+    const double rm = __builtin_rint(m * 128.0);
+    const int i = int(rm) - kLogTabLo;                               // 0 .. kLogTabN-1
+    const double2 t = *reinterpret_cast<const double2 *>(tab + 2 * i);
+    // m - c is exact (Sterbenz), so r carries only the RELATIVE error of 1/c: bins next to c = 1,
+    // where log(m) is small, stay accurate
+    const double r = (m - rm * 0x1.0p-7) * t.x;
+    double p = 1.0 / 7.0;
+    p = __builtin_fma(p, r, -1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.2);
+    p = __builtin_fma(p, r, -0.25);
+    p = __builtin_fma(p, r, 1.0 / 3.0);
+    p = __builtin_fma(p, r, -0.5);
+    const double l1p = __builtin_fma(p * r, r, r);                   // r - r^2/2 + ...
+    const double dk = double(e);
+    return __builtin_fma(dk, 6.93147180369123816490e-01, t.y + (__builtin_fma(dk, 1.90821492927058770002e-10, l1p)));
+}
+
 // zero, subnormal, negative, inf, NaN: full libm, kept out of line so that the hot loops carry
 // only a never-taken branch
 __device__ __noinline__ double log_rare(double x) { return log(x); }

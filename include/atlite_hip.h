@@ -318,7 +318,7 @@ int atl_allreduce_sum(atl_comm *comm, double *d_buf, int64_t n);
 /* ---- diagnostics ------------------------------------------------------------------------
  * Evaluates the kernels' lean fp64 math (atl_math.h) elementwise, for accuracy tests:
  * fn 0 sin, 1 cos, 2 log: d_in (n) -> d_out (n);  3 sincos: d_out (2n) = sin | cos;
- * 4 fast_div: d_in (2n) = a | b -> d_out (n) = a / b.
+ * 4 fast_div: d_in (2n) = a | b -> d_out (n) = a / b;  5 table-driven log (positive normal x).
  */
 int atl_math_probe(atl_ctx *ctx, int fn, const double *d_in, int64_t n, double *d_out);
 

@@ -58,3 +58,14 @@ def test_fast_div(ctx):
     b = rng.uniform(0.0174, 1.0, 200000)  # sin(alt) above the 1 degree cut
     got = probe(ctx, 4, np.concatenate([a, b]))
     assert ulp_err(got, a / b).max() <= 1.0
+
+
+def test_table_log(ctx):
+    rng = np.random.default_rng(3)
+    x = np.concatenate([np.exp(rng.uniform(-700, 700, 300000)), rng.uniform(0.5, 2.0, 300000), 1 + rng.uniform(-1e-3, 1e-3, 50000),
+                        [1.0, 2.0, 0.5, np.sqrt(0.5), np.sqrt(2.0), 2.2250738585072014e-308, 1.7976931348623157e308, 1e-3, 80.0, 100.0]])
+    got = probe(ctx, 5, x)
+    ref = np.log(x)
+    nz = ref != 0
+    assert ulp_err(got[nz], ref[nz]).max() <= 2.0
+    assert got[x == 1.0][0] == 0.0
