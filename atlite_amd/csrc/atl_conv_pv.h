@@ -1,0 +1,444 @@
+// Solar converters: fast pv path (stored or in-kernel solar position, night early-out) and the
+// general kernel (tracking, Hay-Davies, Reindl, bofinger, irradiation, solar thermal).
+// Reference: atlite/convert.py:550-574, 748-767, 840-854; atlite/pv/*.py.
+// Part of libatlite_hip.so (gfx950); included by atl_kernels.hip inside its anonymous namespace.
+#pragma once
+
+// solar PV, ERA5-shaped inputs with stored solar position
+struct PvConst {
+    double c_amb, c_irr, r_tmod, inv_r_irr, k1, k2, k3, k4, k5, k6, inv_eff, alt_thr, sin_alt_thr;
+};
+
+// per-cell orientation factors: sin/cos(slope), (1 +- cos(slope))/2, panel azimuth
+struct PvOri {
+    double ss, cs, hp, hm, saz;
+};
+// cos/sin of the panel azimuth: only the in-kernel solar position variant needs them
+template <bool SP>
+struct PvAz {
+    double csaz, ssaz;
+};
+template <>
+struct PvAz<false> {};
+
+// irradiation on the tilted surface + Huld panel model, from sin/cos of the solar altitude and
+// cos(surface_azimuth - sun_azimuth)   (irradiation.py:214-226, solar_panel_model.py:22-41)
+__device__ __forceinline__ double pv_tail(double direct, double diffuse, double influx, double alb, double tmp,
+                                          double sa, double ca, double cosd, const PvOri &o, const PvConst &k) {
+    // orientation.py:114-117,188
+    double cosinc = o.ss * ca * cosd + o.cs * sa;
+    cosinc = np_max(cosinc, 0.0);
+    const double kk = fast_div(cosinc, sa);
+    const double direct_t = kk * direct;
+    const double diffuse_t = o.hp * diffuse;
+    const double ground_t = alb * influx * o.hm;
+    const double G = fill0(direct_t) + fill0(diffuse_t) + fill0(ground_t);
+    const double T_ = (k.c_amb * tmp + k.c_irr * G) - k.r_tmod;
+    const double G_ = G * k.inv_r_irr;
+    double eff = 0.0;
+    if (G_ > 0.0) {
+        const double l = lean_log(G_);
+        const double l2 = l * l;
+        eff = 1.0 + k.k1 * l + k.k2 * l2 + T_ * (k.k3 + k.k4 * l + k.k5 * l2) + k.k6 * (T_ * T_);
+        eff = fill0(eff);
+        eff = eff < 0.0 ? 0.0 : eff;
+    }
+    return G_ * eff * k.inv_eff;
+}
+
+__device__ __forceinline__ double pv_cell(double dir, double dif, double toa, double alb, double tmp,
+                                          double alt, double az, const PvOri &o, const PvConst &k) {
+    // irradiation.py:206-208
+    const double direct = np_clip(dir, 0.0, toa);
+    const double diffuse = np_clip(dif, 0.0, toa - direct);
+    const double influx = direct + diffuse;
+    // irradiation.py:251-252 (NaN compares false: a NaN altitude is not capped)
+    const bool capped = (alt < k.alt_thr) || (influx <= 0.01);
+#ifdef ATL_ABLATE_NOMATH  // experiment: keep the 7 streams, drop the physics
+    return influx + alb + tmp + alt + az;
+#endif
+    if (capped) return 0.0;  // G = 0 -> G_ = 0, eff -> 0 : 0*0*inv
+    double sa, ca;
+    lean_sincos(alt, &sa, &ca);
+    return pv_tail(direct, diffuse, influx, alb, tmp, sa, ca, lean_cos(o.saz - az), o, k);
+}
+
+// same, with the solar position computed from the separable tables instead of read:
+// pv/solar_position.py:100-114.  sin(alt) = s directly, cos(alt) = sqrt(1-s^2),
+// cos(az) = clip(.../cos(alt)), sin(az) = +-sqrt(1-cos^2 az) by the sign of the hour angle, so
+// cos(surface_az - az) needs no inverse trig at all.  The cut alt < thr becomes s < sin(thr).
+__device__ __forceinline__ double pv_cell_sp(double dir, double dif, double toa, double alb, double tmp,
+                                             double sd, double cd, double sl, double cl, double h, double ch,
+                                             const PvOri &o, const PvAz<true> &a, const PvConst &k) {
+    const double direct = np_clip(dir, 0.0, toa);
+    const double diffuse = np_clip(dif, 0.0, toa - direct);
+    const double influx = direct + diffuse;
+    const double s = np_clip(sd * sl + cd * cl * ch, -1.0, 1.0);  // :103-105
+    const bool capped = (s < k.sin_alt_thr) || (influx <= 0.01);
+    if (capped) return 0.0;
+    const double ca = sqrt((1.0 - s) * (1.0 + s));
+    const double num = sd * cl - cd * sl * ch;
+    double q = fast_div(num, ca);
+    if (!(ca > 0x1.0p-500)) q = num / ca;  // zenith / NaN: IEEE division like the reference
+    const double caz = np_clip(q, -1.0, 1.0);  // :109-113
+    double saz = sqrt((1.0 - caz) * (1.0 + caz));
+    saz = (h <= 0.0) ? saz : -saz;  // :114  az = az if h <= 0 else 2 pi - az
+    return pv_tail(direct, diffuse, influx, alb, tmp, s, ca, a.csaz * caz + a.ssaz * saz, o, k);
+}
+
+// SP: in-kernel solar position; PC: per-cell orientation (else the scalar orientation is read from
+// the kernel arguments = SGPRs and costs no per-lane registers)
+// SKIP: night early-out (stored solar position only): when every valid cell of the wave is below
+// the altitude cut-off the other six streams are not read - the result is exactly +0.0 whatever
+// they hold (pv_cell).  The altitude of the NEXT slot is prefetched together with the current slot's
+// streams (Carry), so day-time slots still cost one memory round trip.
+template <bool SP, bool PC = false, bool SKIP = false>
+struct PvConvT {
+    static_assert(!(SP && SKIP), "night skip is implemented for stored solar angles");
+    atl_pv_inputs in;
+    int64_t S;
+    PvConst k;
+    PvOri o;                     // scalar orientation
+    PvAz<SP> oa;
+    const double *cell_slope;    // (S) or nullptr
+    const double *cell_azimuth;  // (S)
+    struct SpCell {
+        double sl0, cl0, sl1, cl1;  // sin/cos(lat) of the two cells
+        int x0, x1;                 // grid column of the two cells
+    };
+    struct NoSp {};
+    struct OriCell {
+        PvOri o0, o1;
+        PvAz<SP> a0, a1;
+    };
+    struct NoOri {};
+    struct Cell : std::conditional_t<SP, SpCell, NoSp>, std::conditional_t<PC, OriCell, NoOri> {
+        bool no_cell;  // SKIP: this lane owns no cell at all (tile padding)
+    };
+    __device__ void block_init(double *) const {}
+    __device__ static PvOri make_ori(double slope, double azimuth) {
+        PvOri r;
+        lean_sincos(slope, &r.ss, &r.cs);
+        r.hp = (1.0 + r.cs) / 2.0;
+        r.hm = (1.0 - r.cs) / 2.0;
+        r.saz = azimuth;
+        return r;
+    }
+    __device__ Cell cell_setup(int64_t c0, bool v0, bool v1, const double *lds) const {
+        Cell c;
+        c.no_cell = !v0 && !v1;
+        if constexpr (PC) {
+            c.o0 = make_ori(v0 ? cell_slope[c0] : 0.0, v0 ? cell_azimuth[c0] : 0.0);
+            c.o1 = make_ori(v1 ? cell_slope[c0 + 1] : 0.0, v1 ? cell_azimuth[c0 + 1] : 0.0);
+            if constexpr (SP) {
+                lean_sincos(c.o0.saz, &c.a0.ssaz, &c.a0.csaz);
+                lean_sincos(c.o1.saz, &c.a1.ssaz, &c.a1.csaz);
+            }
+        }
+        if constexpr (SP) {
+            const int64_t a = v0 ? c0 : 0, b = v1 ? c0 + 1 : 0;
+            const int64_t y0 = a / in.X, y1 = b / in.X;
+            c.x0 = int(a - y0 * in.X);
+            c.x1 = int(b - y1 * in.X);
+            c.sl0 = in.d_sin_lat[y0];
+            c.cl0 = in.d_cos_lat[y0];
+            c.sl1 = in.d_sin_lat[y1];
+            c.cl1 = in.d_cos_lat[y1];
+        }
+        return c;
+    }
+    static constexpr int kGroup = ATL_PV_GROUP;  // 7 x 16 B per lane per slot already; registers are the limit
+    struct Raw {
+        double2 dir, dif, toa, alb, tmp;
+        double2 a, b;    // getter: altitude, azimuth   SP: hour angle, cos(hour angle)
+        double sd, cd;   // SP: sin / cos declination of the slot
+    };
+    struct SkipCarry {
+        double2 alt[kBatch];  // solar altitude of the batch's slots, prefetched one batch ahead
+    };
+    using Carry = std::conditional_t<SKIP, SkipCarry, NoCarry>;
+    // called before the first batch and again right after a batch has been converted (i.e. while it
+    // is being reduced): the next batch's altitudes are in flight behind the wave reduction
+    template <bool VEC>
+    __device__ __forceinline__ void batch_prefetch(int64_t sb, int64_t send, int64_t c0, int64_t c1, Carry &carry) const {
+        if constexpr (SKIP) {
+#pragma unroll
+            for (int i = 0; i < kBatch; ++i)
+                carry.alt[i] = ld2<VEC>(in.d_solar_altitude, min(sb + i, send - 1) * S, c0, c1);
+        }
+    }
+    template <bool VEC>
+    __device__ __forceinline__ Raw load(int64_t slot, int i, int64_t c0, int64_t c1, const Cell &c, Carry &carry) const {
+        const int64_t off = slot * S;
+        Raw r;
+        if constexpr (SKIP) {
+            r.a = carry.alt[i];
+            r.sd = r.cd = 0.0;
+            // capped <=> alt < threshold (a NaN altitude is NOT capped); lanes that own no cell loaded
+            // some other cell's altitude and vote "night" unconditionally
+            const bool night = (r.a.x < k.alt_thr) && (r.a.y < k.alt_thr);
+            if (__all(night || c.no_cell)) {
+                const double2 z = {0.0, 0.0};
+                r.dir = r.dif = r.toa = r.alb = r.tmp = r.b = z;
+                return r;
+            }
+            r.dir = ld2<VEC>(in.d_influx_direct, off, c0, c1);
+            r.dif = ld2<VEC>(in.d_influx_diffuse, off, c0, c1);
+            r.toa = ld2<VEC>(in.d_influx_toa, off, c0, c1);
+            r.alb = ld2<VEC>(in.d_albedo, off, c0, c1);
+            r.tmp = ld2<VEC>(in.d_temperature, off, c0, c1);
+            r.b = ld2<VEC>(in.d_solar_azimuth, off, c0, c1);
+            return r;
+        }
+        r.dir = ld2<VEC>(in.d_influx_direct, off, c0, c1);
+        r.dif = ld2<VEC>(in.d_influx_diffuse, off, c0, c1);
+        r.toa = ld2<VEC>(in.d_influx_toa, off, c0, c1);
+        r.alb = ld2<VEC>(in.d_albedo, off, c0, c1);
+        r.tmp = ld2<VEC>(in.d_temperature, off, c0, c1);
+        if constexpr (SP) {
+            r.sd = in.d_sin_dec[slot];
+            r.cd = in.d_cos_dec[slot];
+            const int64_t hb = slot * in.X;
+            r.a.x = in.d_hour_angle[hb + c.x0];
+            r.a.y = in.d_hour_angle[hb + c.x1];
+            r.b.x = in.d_cos_hour_angle[hb + c.x0];
+            r.b.y = in.d_cos_hour_angle[hb + c.x1];
+        } else {
+            r.sd = r.cd = 0.0;
+            r.a = ld2<VEC>(in.d_solar_altitude, off, c0, c1);
+            r.b = ld2<VEC>(in.d_solar_azimuth, off, c0, c1);
+        }
+        return r;
+    }
+    __device__ __forceinline__ double2 compute(const Raw &q, bool v0, bool v1, const Cell &c, const double *) const {
+        const PvOri &o0 = [&]() -> const PvOri & { if constexpr (PC) return c.o0; else return o; }();
+        const PvOri &o1 = [&]() -> const PvOri & { if constexpr (PC) return c.o1; else return o; }();
+        double2 r;
+        if constexpr (SP) {
+            const PvAz<true> &a0 = [&]() -> const PvAz<true> & { if constexpr (PC) return c.a0; else return oa; }();
+            const PvAz<true> &a1 = [&]() -> const PvAz<true> & { if constexpr (PC) return c.a1; else return oa; }();
+            r.x = v0 ? pv_cell_sp(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.sd, q.cd, c.sl0, c.cl0, q.a.x, q.b.x, o0, a0, k) : 0.0;
+            r.y = v1 ? pv_cell_sp(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.sd, q.cd, c.sl1, c.cl1, q.a.y, q.b.y, o1, a1, k) : 0.0;
+        } else {
+            r.x = v0 ? pv_cell(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.a.x, q.b.x, o0, k) : 0.0;
+            r.y = v1 ? pv_cell(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.a.y, q.b.y, o1, k) : 0.0;
+        }
+        return r;
+    }
+};
+using PvConv = PvConvT<false>;
+using PvConvSP = PvConvT<true>;
+template <class T>
+struct pv_is_sp : std::false_type {};
+template <bool PC, bool SK>
+struct pv_is_sp<PvConvT<true, PC, SK>> : std::true_type {};
+
+// ---------------------------------------------------------------------------------------
+// general pv converter: every option of convert_pv / convert_irradiation / convert_solar_thermal
+// (tracking modes, Hay-Davies, Reindl split, albedo from outflux, bofinger, irradiation
+// quantities).  A literal transcription of the reference with full-precision libm - selected
+// only when an option differs from the defaults the fast PvConvT path covers.
+// ---------------------------------------------------------------------------------------
+struct PvxOpt {
+    int tracking, trigon, clearsky, irradiation, panel, has_influx, has_albedo;
+    double bA, bB, bC, bD, bNOCT, bTstd, bTamb, bIntc, bta, bthr;
+    double c0, c1, t_store;
+    double r_irr;  // Huld division kept literal here
+};
+
+__device__ double pvx_cell(double dir, double dif, double infl, double toa, double albv, double outf, double tmp,
+                           double rh, double alt, double az, double slope, double sazim, const PvConst &k,
+                           const PvxOpt &o) {
+    const double pi = 3.14159265358979323846;
+    const double nan = __builtin_nan("");
+    const double sa = sin(alt), ca = cos(alt);
+    // ---- SurfaceOrientation (orientation.py:113-188) ---------------------------------------
+    double surface_slope = slope, cosinc;
+    if (o.tracking == ATL_TRACK_NONE) {
+        cosinc = sin(slope) * ca * cos(sazim - az) + cos(slope) * sa;
+    } else if (o.tracking == ATL_TRACK_HORIZONTAL) {
+        const double rotation = atan((ca / sa) * sin(az - sazim));
+        surface_slope = fabs(rotation);
+        const double surface_azimuth = sazim + asin(sin(rotation) / sin(surface_slope));
+        cosinc = cos(surface_slope) * sa + sin(surface_slope) * ca * cos(az - surface_azimuth);
+    } else if (o.tracking == ATL_TRACK_TILTED_HORIZONTAL) {
+        const double tilt = slope;
+        double rotation = atan((ca * sin(az - sazim)) / (ca * cos(az - sazim) * sin(tilt) + sa * cos(tilt)));
+        surface_slope = acos(cos(rotation) * cos(tilt));
+        double ad = az - sazim;
+        ad = ad > pi ? ad - 2 * pi : ad;
+        ad = ad < -pi ? 2 * pi + ad : ad;
+        rotation = (rotation < 0 && ad > 0) ? rotation + pi : rotation;
+        rotation = (rotation > 0 && ad < 0) ? rotation - pi : rotation;
+        cosinc = cos(rotation) * (sin(tilt) * ca * cos(az - sazim) + cos(tilt) * sa) + sin(rotation) * ca * sin(az - sazim);
+    } else if (o.tracking == ATL_TRACK_VERTICAL) {
+        cosinc = sin(slope) * ca + cos(slope) * sa;
+    } else {
+        cosinc = 1.0;
+    }
+    cosinc = np_max(cosinc, 0.0);
+    // ---- direct / diffuse horizontal (irradiation.py:202-208, 13-73) ------------------------
+    double direct, diffuse;
+    if (o.has_influx) {
+        const double influx = np_clip(infl, 0.0, toa);
+        const double kk = influx / toa;
+        double fraction;
+        const double m1 = (kk > 0.0 && kk <= 0.3) ? 1.0 : 0.0, m2 = (kk > 0.3 && kk < 0.78) ? 1.0 : 0.0,
+                     m3 = (kk >= 0.78) ? 1.0 : 0.0;
+        if (o.clearsky == ATL_CLEARSKY_SIMPLE) {
+            fraction = m1 * fmin(1.0, 1.020 - 0.254 * kk + 0.0123 * sa) +
+                       m2 * fmin(0.97, fmax(0.1, 1.400 - 1.749 * kk + 0.177 * sa)) +
+                       m3 * fmax(0.1, 0.486 * kk - 0.182 * sa);
+        } else {
+            fraction = m1 * fmin(1.0, 1.000 - 0.232 * kk + 0.0239 * sa - 0.000682 * tmp + 0.0195 * rh) +
+                       m2 * fmin(0.97, fmax(0.1, 1.329 - 1.716 * kk + 0.267 * sa - 0.00357 * tmp + 0.106 * rh)) +
+                       m3 * fmax(0.1, 0.426 * kk - 0.256 * sa + 0.00349 * tmp + 0.0734 * rh);
+        }
+        diffuse = influx * fraction;
+        direct = influx - diffuse;
+    } else {
+        direct = np_clip(dir, 0.0, toa);
+        diffuse = np_clip(dif, 0.0, toa - direct);
+    }
+    const double influx = direct + diffuse;
+    // ---- albedo (irradiation.py:128-139) ---------------------------------------------------------
+    double alb = albv;
+    if (!o.has_albedo) {
+        alb = fill0(outf / (influx != 0.0 ? influx : nan));
+        alb = np_min(alb, 1.0);
+    }
+    // ---- tilted irradiation ---------------------------------------------------------------------
+    double direct_t, diffuse_t, ground_t, total_t;
+    if (o.trigon == ATL_TRIGON_SIMPLE) {
+        const double kk = cosinc / sa;
+        const double cs = (o.tracking != ATL_TRACK_DUAL) ? cos(surface_slope) : sa;
+        direct_t = kk * direct;
+        diffuse_t = (1.0 + cs) / 2.0 * diffuse;
+        ground_t = alb * influx * ((1.0 - cs) / 2.0);
+        total_t = fill0(direct_t) + fill0(diffuse_t) + fill0(ground_t);
+    } else {
+        const double f = fill0(sqrt(direct / influx));
+        const double A = direct / toa;
+        const double R_b = cosinc / sa;
+        const double sh = sin(surface_slope / 2.0);
+        diffuse_t = ((1.0 - A) * ((1 + cos(surface_slope)) / 2.0) * (1.0 + f * (sh * sh * sh)) + A * R_b) * diffuse;
+        diffuse_t = fill0(np_max(diffuse_t, 0.0));
+        direct_t = R_b * direct;
+        ground_t = influx * alb * (1.0 - cos(surface_slope)) / 2.0;
+        total_t = direct_t + diffuse_t + ground_t;
+    }
+    double G = o.irradiation == ATL_IRR_TOTAL    ? total_t
+               : o.irradiation == ATL_IRR_DIRECT ? direct_t
+               : o.irradiation == ATL_IRR_DIFFUSE ? diffuse_t
+                                                  : ground_t;
+    if ((alt < k.alt_thr) || (influx <= 0.01)) G = 0.0;  // :251-252
+    // ---- panel ------------------------------------------------------------------------------------
+    if (o.panel == ATL_PANEL_NONE) return G;
+    if (o.panel == ATL_PANEL_HULD) {
+        const double T_ = (k.c_amb * tmp + k.c_irr * G) - k.r_tmod;
+        const double G_ = G / o.r_irr;
+        const double l = log(G_ > 0.0 ? G_ : nan);
+        double eff = 1.0 + k.k1 * l + k.k2 * (l * l) + T_ * (k.k3 + k.k4 * l + k.k5 * (l * l)) + k.k6 * (T_ * T_);
+        eff = fill0(eff);
+        eff = eff < 0.0 ? 0.0 : eff;
+        return G_ * eff * k.inv_eff;
+    }
+    if (o.panel == ATL_PANEL_BOFINGER) {
+        const double fraction = (o.bNOCT - o.bTamb) / o.bIntc;
+        const double eta_ref = o.bA + o.bB * G + o.bC * log(G != 0.0 ? G : nan);
+        const double eta = fill0(eta_ref * (1.0 + o.bD * (fraction * G + (tmp - o.bTstd))) /
+                                 (1.0 + o.bD * fraction / o.bta * eta_ref * G));
+        const double capacity = (o.bA + o.bB * 1000.0 + o.bC * log(1000.0)) * 1e3;
+        const double power = G * eta * (k.inv_eff / capacity);
+        return (G >= o.bthr) ? power : 0.0;
+    }
+    // solar thermal (convert.py:565-574)
+    const double eta = o.c0 - o.c1 * fill0((o.t_store - tmp) / (G != 0.0 ? G : nan));
+    const double output = G * eta;
+    return output > 0.0 ? output : 0.0;
+}
+
+struct PvxConv {
+    atl_pv_inputs in;
+    int64_t S;
+    PvConst k;
+    PvxOpt o;
+    double slope, azimuth;       // scalar orientation (radians)
+    const double *cell_slope;    // (S) or nullptr
+    const double *cell_azimuth;  // (S)
+    struct Cell {
+        double sl0, sl1, az0, az1;   // panel slope / azimuth of the two cells
+        double slat0, clat0, slat1, clat1;
+        int x0, x1;
+    };
+    __device__ void block_init(double *) const {}
+    __device__ Cell cell_setup(int64_t c0, bool v0, bool v1, const double *lds) const {
+        Cell c;
+        c.sl0 = c.sl1 = slope;
+        c.az0 = c.az1 = azimuth;
+        if (cell_slope) {
+            c.sl0 = v0 ? cell_slope[c0] : 0.0;
+            c.sl1 = v1 ? cell_slope[c0 + 1] : 0.0;
+            c.az0 = v0 ? cell_azimuth[c0] : 0.0;
+            c.az1 = v1 ? cell_azimuth[c0 + 1] : 0.0;
+        }
+        c.slat0 = c.clat0 = c.slat1 = c.clat1 = 0.0;
+        c.x0 = c.x1 = 0;
+        if (!in.d_solar_altitude) {
+            const int64_t a = v0 ? c0 : 0, b = v1 ? c0 + 1 : 0;
+            const int64_t y0 = a / in.X, y1 = b / in.X;
+            c.x0 = int(a - y0 * in.X);
+            c.x1 = int(b - y1 * in.X);
+            c.slat0 = in.d_sin_lat[y0];
+            c.clat0 = in.d_cos_lat[y0];
+            c.slat1 = in.d_sin_lat[y1];
+            c.clat1 = in.d_cos_lat[y1];
+        }
+        return c;
+    }
+    // pv/solar_position.py:100-114, literally
+    __device__ static void solar(double sd, double cd, double sl, double cl, double h, double ch, double *alt,
+                                 double *az) {
+        const double a = asin(np_clip(sd * sl + cd * cl * ch, -1.0, 1.0));
+        double z = acos(np_clip((sd * cl - cd * sl * ch) / cos(a), -1.0, 1.0));
+        z = (h <= 0.0) ? z : 2.0 * 3.14159265358979323846 - z;
+        *alt = a;
+        *az = z;
+    }
+    static constexpr int kGroup = 1;
+    struct Raw {
+        double2 dir, dif, inf, toa, alb, ouf, tmp, hum, alt, az;
+    };
+    using Carry = NoCarry;
+    template <bool VEC>
+    __device__ __forceinline__ Raw load(int64_t slot, int, int64_t c0, int64_t c1, const Cell &c, Carry &) const {
+        const int64_t off = slot * S;
+        const double2 zero = {0.0, 0.0};
+        Raw r;
+        r.dir = in.d_influx_direct ? ld2<VEC>(in.d_influx_direct, off, c0, c1) : zero;
+        r.dif = in.d_influx_diffuse ? ld2<VEC>(in.d_influx_diffuse, off, c0, c1) : zero;
+        r.inf = in.d_influx ? ld2<VEC>(in.d_influx, off, c0, c1) : zero;
+        r.toa = ld2<VEC>(in.d_influx_toa, off, c0, c1);
+        r.alb = in.d_albedo ? ld2<VEC>(in.d_albedo, off, c0, c1) : zero;
+        r.ouf = in.d_outflux ? ld2<VEC>(in.d_outflux, off, c0, c1) : zero;
+        r.tmp = in.d_temperature ? ld2<VEC>(in.d_temperature, off, c0, c1) : zero;
+        r.hum = in.d_humidity ? ld2<VEC>(in.d_humidity, off, c0, c1) : zero;
+        if (in.d_solar_altitude) {
+            r.alt = ld2<VEC>(in.d_solar_altitude, off, c0, c1);
+            r.az = ld2<VEC>(in.d_solar_azimuth, off, c0, c1);
+        } else {
+            const double sd = in.d_sin_dec[slot], cd = in.d_cos_dec[slot];
+            const int64_t hb = slot * in.X;
+            solar(sd, cd, c.slat0, c.clat0, in.d_hour_angle[hb + c.x0], in.d_cos_hour_angle[hb + c.x0], &r.alt.x, &r.az.x);
+            solar(sd, cd, c.slat1, c.clat1, in.d_hour_angle[hb + c.x1], in.d_cos_hour_angle[hb + c.x1], &r.alt.y, &r.az.y);
+        }
+        return r;
+    }
+    __device__ __forceinline__ double2 compute(const Raw &q, bool v0, bool v1, const Cell &c, const double *) const {
+        double2 r;
+        r.x = v0 ? pvx_cell(q.dir.x, q.dif.x, q.inf.x, q.toa.x, q.alb.x, q.ouf.x, q.tmp.x, q.hum.x, q.alt.x, q.az.x, c.sl0, c.az0, k, o) : 0.0;
+        r.y = v1 ? pvx_cell(q.dir.y, q.dif.y, q.inf.y, q.toa.y, q.alb.y, q.ouf.y, q.tmp.y, q.hum.y, q.alt.y, q.az.y, c.sl1, c.az1, k, o) : 0.0;
+        return r;
+    }
+};
+

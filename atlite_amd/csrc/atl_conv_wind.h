@@ -1,0 +1,165 @@
+// Wind converter: hub-height extrapolation + power-curve interpolation.
+// Reference: atlite/wind.py:76-112, atlite/convert.py:634-662 (np.interp).
+// Part of libatlite_hip.so (gfx950); included by atl_kernels.hip inside its anonymous namespace.
+#pragma once
+
+// wind: hub-height extrapolation + power curve (wind.py:76-112, convert.py:648-649)
+//
+// LDS table, built on the host (make_wind): n_pad = power of two > n_knots,
+//   V[n_pad]  knots, padded with +inf          (search never needs a bounds check)
+//   K[n_pad]  records {V[j], F[j], slope[j], 0} (slope[n-1] = 0)
+// np.interp(x, V, F) (numpy arr_interp) for a FINITE table reduces to
+//   xc = clamp(x, V[0], V[n-1]);  j = largest index with V[j] <= xc;
+//   r  = fma(slope[j], xc - V[j], F[j])
+// which returns F[j] exactly on knots, F[0] / F[n-1] outside the range (also for +-inf), NaN
+// for NaN, and takes the upper one of repeated knots - all without a branch.  Tables holding
+// non-finite values take interp_generic(), the literal transcription of arr_interp.
+// METHOD: ATL_WIND_NONE / LOG / POWER fixed at compile time for finite tables (the hot
+// instantiations carry no dead paths); METHOD = -1 is the generic converter: runtime method,
+// any table (interp_generic).
+template <int METHOD>
+struct WindConvT {
+    const double *wnd;
+    const double *aux;
+    int64_t S;
+    int aux_static;
+    int method;
+    double to_height, from_height;
+    double log_ratio;      // log(to/from)   (power law)
+    const double *table;   // device: V[n_pad] | K[n_pad][4]
+    int n_knots, n_pad;
+    struct Cell {
+        double2 aux;
+        double lh, lf;  // lean_log(to_height), lean_log(from_height)
+    };
+    __device__ void block_init(double *lds) const {
+        for (int i = threadIdx.x; i < 5 * n_pad; i += blockDim.x) lds[i] = table[i];
+        if constexpr (METHOD == ATL_WIND_LOG) log_table_init(lds + 5 * n_pad);
+    }
+    __device__ Cell cell_setup(int64_t c0, bool v0, bool v1, const double *lds) const {
+        Cell c;
+        c.aux.x = 0.0;
+        c.aux.y = 0.0;
+        if (method != ATL_WIND_NONE && aux_static) {
+            c.aux.x = v0 ? aux[c0] : 1.0;
+            c.aux.y = v1 ? aux[c0 + 1] : 1.0;
+        }
+        // log(from) through the same routine as the per-cell roughness: z0 == from_height gives an
+        // exact zero denominator, like the reference's log(from/z0) = log(1)
+        c.lh = 0.0;
+        c.lf = 0.0;
+        if constexpr (METHOD == ATL_WIND_LOG) c.lf = log_core_tab(from_height, lds + 5 * n_pad);
+        return c;
+    }
+    // wind.py:99-101 / :111, literally; used for the rare arguments the fast path excludes
+    __device__ __noinline__ double hub_speed_literal(double v, double z) const {
+        if (method == ATL_WIND_LOG) return v * (log(to_height / z) / log(from_height / z));
+        if (method == ATL_WIND_POWER) return v * pow(to_height / from_height, z);
+        return v;
+    }
+    // fast path: *rare is set when the literal formula must be used instead
+    __device__ __forceinline__ double hub_speed_fast(double v, double z, const Cell &c, bool *rare,
+                                                     const double *lds) const {
+        if constexpr (METHOD == ATL_WIND_LOG) {
+            // v * (log(to/z0) / log(from/z0))  =  v * (1 + log(to/from) / (log(from) - log(z0))):
+            // one table-driven log and one reciprocal per cell.  log(from) goes through the same
+            // routine, so z0 == from gives den == 0 exactly (-> rare path -> the literal formula).
+            const double *ltab = lds + 5 * n_pad;
+            const bool zok = z >= 0x1.0p-1022 && z < __builtin_inf();
+#ifdef ATL_ABLATE_WIND_NOLOG
+            const double lz = z;
+#else
+            const double lz = log_core_tab(zok ? z : 1.0, ltab);
+#endif
+            const double den = c.lf - lz;
+            const bool tame = __builtin_fabs(den) > 0x1.0p-40;  // |den| < 1500 always
+            *rare = !(zok && tame);
+            return v * __builtin_fma(log_ratio, fast_rcp(den), 1.0);
+        } else if constexpr (METHOD == ATL_WIND_POWER) {
+            *rare = false;
+            return v * exp(z * log_ratio);  // v * (to/from) ** shear
+        } else {
+            *rare = false;
+            return v;
+        }
+    }
+    __device__ __forceinline__ double interp(double x, const double *lds) const {
+        const double *V = lds;
+        const double *K = lds + n_pad;
+        const double vmin = V[0], vmax = V[n_knots - 1];
+        double xc = x > vmax ? vmax : x;
+        xc = xc < vmin ? vmin : xc;  // NaN stays NaN
+        int j = 0;
+        for (int step = n_pad >> 1; step > 0; step >>= 1) {
+            const int cand = j + step;
+            j = (V[cand] <= xc) ? cand : j;
+        }
+        const double2 k0 = *reinterpret_cast<const double2 *>(K + 4 * j);
+        const double sl = K[4 * j + 2];
+        return __builtin_fma(sl, xc - k0.x, k0.y);
+    }
+    // literal numpy/_core/src/multiarray/compiled_base.c arr_interp (any table)
+    __device__ __noinline__ double interp_generic(double x, const double *lds) const {
+        const double *V = lds;
+        const double *K = lds + n_pad;
+        const int n = n_knots;
+        if (dnan(x)) return x;
+        if (x < V[0]) return K[1];
+        if (x > V[n - 1]) return K[4 * (n - 1) + 1];
+        int j = 0;
+        for (int step = n_pad >> 1; step > 0; step >>= 1) {
+            const int cand = j + step;
+            if (V[cand] <= x) j = cand;
+        }
+        const double xj = K[4 * j], fj = K[4 * j + 1];
+        if (j == n - 1) return fj;
+        if (xj == x) return fj;
+        const double slope = (K[4 * (j + 1) + 1] - fj) / (K[4 * (j + 1)] - xj);
+        double r = slope * (x - xj) + fj;
+        if (dnan(r)) {
+            r = slope * (x - K[4 * (j + 1)]) + K[4 * (j + 1) + 1];
+            if (dnan(r) && fj == K[4 * (j + 1) + 1]) r = fj;
+        }
+        return r;
+    }
+    static constexpr int kGroup = 4;
+    struct Raw {
+        double2 v, z;
+    };
+    using Carry = NoCarry;
+    template <bool VEC>
+    __device__ __forceinline__ Raw load(int64_t slot, int, int64_t c0, int64_t c1, const Cell &c, Carry &) const {
+        Raw r;
+        r.v = ld2<VEC>(wnd, slot * S, c0, c1);
+        r.z = c.aux;
+        if (METHOD != ATL_WIND_NONE && !aux_static) r.z = ld2<VEC>(aux, slot * S, c0, c1);
+        return r;
+    }
+    __device__ __forceinline__ double2 compute(const Raw &q, bool v0, bool v1, const Cell &c,
+                                               const double *lds) const {
+        const double2 v = q.v, z = q.z;
+        double2 r;
+        if constexpr (METHOD < 0) {
+            r.x = interp_generic(hub_speed_literal(v.x, z.x), lds);
+            r.y = interp_generic(hub_speed_literal(v.y, z.y), lds);
+        } else {
+            bool r0, r1;
+            double h0 = hub_speed_fast(v.x, z.x, c, &r0, lds), h1 = hub_speed_fast(v.y, z.y, c, &r1, lds);
+            if ((r0 && v0) || (r1 && v1)) {  // degenerate roughness: literal formula, out of line
+                h0 = hub_speed_literal(v.x, z.x);
+                h1 = hub_speed_literal(v.y, z.y);
+            }
+#ifdef ATL_ABLATE_WIND_NOINTERP
+            r.x = h0;
+            r.y = h1;
+#else
+            r.x = interp(h0, lds);
+            r.y = interp(h1, lds);
+#endif
+        }
+        r.x = v0 ? r.x : 0.0;
+        r.y = v1 ? r.y : 0.0;
+        return r;
+    }
+};
+
