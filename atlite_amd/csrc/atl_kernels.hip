@@ -195,10 +195,10 @@ __device__ __forceinline__ void reduce_row(const double2 (&v)[kBatch], double2 w
 #pragma unroll
     for (int i = 0; i < kBatch; ++i) {
         if constexpr (GUARD) {
-            // structural zeros must not turn NaN/inf cells into NaN (scipy CSR skips them)
+            // structural zeros must not turn NaN/inf cells into NaN (scipy CSR skips them); same
+            // expression as the unguarded path, so a row gives the same bits whichever path it takes
             const double t0 = a0 ? w.x * v[i].x : 0.0;
-            const double t1 = a1 ? w.y * v[i].y : 0.0;
-            c[i] = t0 + t1;
+            c[i] = a1 ? __builtin_fma(w.y, v[i].y, t0) : t0;
         } else {
             c[i] = __builtin_fma(w.y, v[i].y, w.x * v[i].x);  // w = 0 where absent, v finite
         }
