@@ -164,3 +164,33 @@ def test_labeled_containers():
         ds["missing"]
     with pytest.raises(ValueError):
         Dataset({"bad": np.zeros((5, 5))}, dict(time=t, y=[1.0, 2.0], x=[0.0, 1.0, 2.0]))
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """sizeof / field offsets of every struct in include/atlite_hip.h (plain C, gcc) equal the ctypes
+    mirrors in atlite_amd/_lib.py and the stub printed in INTEGRATION.md."""
+    import ctypes as C
+    import subprocess
+
+    structs = {"atl_pv_inputs": _lib.PvInputs, "atl_pv_params": _lib.PvParams, "atl_wind_inputs": _lib.WindInputs,
+               "atl_wind_params": _lib.WindParams, "atl_heat_params": _lib.HeatParams,
+               "atl_thermo_params": _lib.ThermoParams, "atl_synth_solar": _lib.SynthSolar}
+    last = {k: v._fields_[-1][0] for k, v in structs.items()}
+    prog = "#include <stdio.h>\n#include <stddef.h>\n#include \"atlite_hip.h\"\nint main(void){\n"
+    for k in structs:
+        prog += f'printf("{k} %zu %zu\\n", sizeof({k}), offsetof({k}, {last[k]}));\n'
+    prog += "return 0;}\n"
+    src = tmp_path / "sizes.c"
+    src.write_text(prog)
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    for line in filter(None, out):
+        name, size, off = line.split()
+        st = structs[name]
+        assert C.sizeof(st) == int(size), (name, C.sizeof(st), size)
+        assert getattr(st, last[name]).offset == int(off), (name, last[name])
+    doc = (ROOT / "INTEGRATION.md").read_text()
+    ns = {"C": C}
+    exec(doc[doc.index("class PvInputs(C.Structure)"):doc.index("class Ctx:")], ns)
+    assert C.sizeof(ns["PvInputs"]) == C.sizeof(_lib.PvInputs) and C.sizeof(ns["PvParams"]) == C.sizeof(_lib.PvParams)
