@@ -236,8 +236,9 @@ struct pv_is_sp<PvConvT<true, PC, SK>> : std::true_type {};
 // ---------------------------------------------------------------------------------------
 // general pv converter: every option of convert_pv / convert_irradiation / convert_solar_thermal
 // (tracking modes, Hay-Davies, Reindl split, albedo from outflux, bofinger, irradiation
-// quantities).  A literal transcription of the reference with full-precision libm - selected
-// only when an option differs from the defaults the fast PvConvT path covers.
+// quantities).  A literal transcription of the reference, operation by operation (lean sin/cos/log
+// of atl_math.h, libm for atan/asin/acos/sqrt) - selected only when an option differs from the
+// defaults the fast PvConvT path covers.
 // ---------------------------------------------------------------------------------------
 struct PvxOpt {
     int tracking, trigon, clearsky, irradiation, panel, has_influx, has_albedo;
@@ -251,28 +252,29 @@ __device__ double pvx_cell(double dir, double dif, double infl, double toa, doub
                            const PvxOpt &o) {
     const double pi = 3.14159265358979323846;
     const double nan = __builtin_nan("");
-    const double sa = sin(alt), ca = cos(alt);
+    double sa, ca;
+    lean_sincos(alt, &sa, &ca);
     // ---- SurfaceOrientation (orientation.py:113-188) ---------------------------------------
     double surface_slope = slope, cosinc;
     if (o.tracking == ATL_TRACK_NONE) {
-        cosinc = sin(slope) * ca * cos(sazim - az) + cos(slope) * sa;
+        cosinc = lean_sin(slope) * ca * lean_cos(sazim - az) + lean_cos(slope) * sa;
     } else if (o.tracking == ATL_TRACK_HORIZONTAL) {
-        const double rotation = atan((ca / sa) * sin(az - sazim));
+        const double rotation = atan((ca / sa) * lean_sin(az - sazim));
         surface_slope = fabs(rotation);
-        const double surface_azimuth = sazim + asin(sin(rotation) / sin(surface_slope));
-        cosinc = cos(surface_slope) * sa + sin(surface_slope) * ca * cos(az - surface_azimuth);
+        const double surface_azimuth = sazim + asin(lean_sin(rotation) / lean_sin(surface_slope));
+        cosinc = lean_cos(surface_slope) * sa + lean_sin(surface_slope) * ca * lean_cos(az - surface_azimuth);
     } else if (o.tracking == ATL_TRACK_TILTED_HORIZONTAL) {
         const double tilt = slope;
-        double rotation = atan((ca * sin(az - sazim)) / (ca * cos(az - sazim) * sin(tilt) + sa * cos(tilt)));
-        surface_slope = acos(cos(rotation) * cos(tilt));
+        double rotation = atan((ca * lean_sin(az - sazim)) / (ca * lean_cos(az - sazim) * lean_sin(tilt) + sa * lean_cos(tilt)));
+        surface_slope = acos(lean_cos(rotation) * lean_cos(tilt));
         double ad = az - sazim;
         ad = ad > pi ? ad - 2 * pi : ad;
         ad = ad < -pi ? 2 * pi + ad : ad;
         rotation = (rotation < 0 && ad > 0) ? rotation + pi : rotation;
         rotation = (rotation > 0 && ad < 0) ? rotation - pi : rotation;
-        cosinc = cos(rotation) * (sin(tilt) * ca * cos(az - sazim) + cos(tilt) * sa) + sin(rotation) * ca * sin(az - sazim);
+        cosinc = lean_cos(rotation) * (lean_sin(tilt) * ca * lean_cos(az - sazim) + lean_cos(tilt) * sa) + lean_sin(rotation) * ca * lean_sin(az - sazim);
     } else if (o.tracking == ATL_TRACK_VERTICAL) {
-        cosinc = sin(slope) * ca + cos(slope) * sa;
+        cosinc = lean_sin(slope) * ca + lean_cos(slope) * sa;
     } else {
         cosinc = 1.0;
     }
@@ -311,7 +313,7 @@ __device__ double pvx_cell(double dir, double dif, double infl, double toa, doub
     double direct_t, diffuse_t, ground_t, total_t;
     if (o.trigon == ATL_TRIGON_SIMPLE) {
         const double kk = cosinc / sa;
-        const double cs = (o.tracking != ATL_TRACK_DUAL) ? cos(surface_slope) : sa;
+        const double cs = (o.tracking != ATL_TRACK_DUAL) ? lean_cos(surface_slope) : sa;
         direct_t = kk * direct;
         diffuse_t = (1.0 + cs) / 2.0 * diffuse;
         ground_t = alb * influx * ((1.0 - cs) / 2.0);
@@ -320,11 +322,11 @@ __device__ double pvx_cell(double dir, double dif, double infl, double toa, doub
         const double f = fill0(sqrt(direct / influx));
         const double A = direct / toa;
         const double R_b = cosinc / sa;
-        const double sh = sin(surface_slope / 2.0);
-        diffuse_t = ((1.0 - A) * ((1 + cos(surface_slope)) / 2.0) * (1.0 + f * (sh * sh * sh)) + A * R_b) * diffuse;
+        const double sh = lean_sin(surface_slope / 2.0);
+        diffuse_t = ((1.0 - A) * ((1 + lean_cos(surface_slope)) / 2.0) * (1.0 + f * (sh * sh * sh)) + A * R_b) * diffuse;
         diffuse_t = fill0(np_max(diffuse_t, 0.0));
         direct_t = R_b * direct;
-        ground_t = influx * alb * (1.0 - cos(surface_slope)) / 2.0;
+        ground_t = influx * alb * (1.0 - lean_cos(surface_slope)) / 2.0;
         total_t = direct_t + diffuse_t + ground_t;
     }
     double G = o.irradiation == ATL_IRR_TOTAL    ? total_t
@@ -337,7 +339,7 @@ __device__ double pvx_cell(double dir, double dif, double infl, double toa, doub
     if (o.panel == ATL_PANEL_HULD) {
         const double T_ = (k.c_amb * tmp + k.c_irr * G) - k.r_tmod;
         const double G_ = G / o.r_irr;
-        const double l = log(G_ > 0.0 ? G_ : nan);
+        const double l = (G_ > 0.0) ? lean_log(G_) : nan;
         double eff = 1.0 + k.k1 * l + k.k2 * (l * l) + T_ * (k.k3 + k.k4 * l + k.k5 * (l * l)) + k.k6 * (T_ * T_);
         eff = fill0(eff);
         eff = eff < 0.0 ? 0.0 : eff;
@@ -359,6 +361,7 @@ __device__ double pvx_cell(double dir, double dif, double infl, double toa, doub
 }
 
 struct PvxConv {
+    static constexpr int kMinWaves = 1;  // let the register allocator use the whole file
     atl_pv_inputs in;
     int64_t S;
     PvConst k;

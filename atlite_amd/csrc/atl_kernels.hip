@@ -210,8 +210,19 @@ __device__ __forceinline__ void reduce_row(const double2 (&v)[kBatch], double2 w
 
 constexpr int kRowCache = ATL_ROW_CACHE;  // partial rows of a tile whose weights stay in registers
 
+// register budget of the fused kernel: ATL_FUSED_WAVES waves per SIMD unless the converter asks for
+// more registers (the general pv kernel is a long literal transcription and would spill)
+template <class Conv, class = void>
+struct conv_min_waves : std::integral_constant<int, ATL_FUSED_WAVES> {};
+template <class Conv>
+struct conv_min_waves<Conv, std::void_t<decltype(Conv::kMinWaves)>> : std::integral_constant<int, Conv::kMinWaves> {};
+template <class Conv>
+constexpr int min_waves() {
+    return conv_min_waves<Conv>::value;
+}
+
 template <class Conv, bool VEC>
-__global__ __launch_bounds__(256, ATL_FUSED_WAVES) void k_fused_segred(Conv conv, PlanDev plan, int64_t slot0,
+__global__ __launch_bounds__(256, min_waves<Conv>()) void k_fused_segred(Conv conv, PlanDev plan, int64_t slot0,
                                                       int64_t n_slots, int64_t S, int32_t chunk_slots,
                                                       int64_t n_units, double *__restrict__ partials,
                                                       int64_t ldp) {

@@ -95,7 +95,7 @@ def main():
         inputs, _ = synthetic.pv_inputs(ctx, T, Y, X)
         plan = ctx.plan(shapes_matrix(Y, X, 500), row_len=X)
         info = plan.info()
-        report("C4s", 56, T * S, *timed(ctx, lambda: ctx.pv(inputs, CSI, T, S, plan=plan)),
+        report("C4s", 56, T * S, *timed(ctx, lambda: ctx.pv(inputs, CSI, T, S, plan=plan, options=dict(night_skip=False))),
                f"pv 500 shapes {info['tile_w']}x{info['tile_h']} P={info['n_partial_rows']}")
     print(json.dumps(res))
 

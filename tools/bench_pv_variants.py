@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""pv kernel variants on the C2 shape (8760x200x200, 100 shapes): dominant-kernel time from HIP events."""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from atlite_amd import gis, solar, synthetic  # noqa: E402
+from atlite_amd.device import Context  # noqa: E402
+
+CSI = dict(c_temp_amb=1, c_temp_irrad=0.035, r_tmod=298, r_irradiance=1000, k_1=-0.017162, k_2=-0.040289,
+           k_3=-0.004681, k_4=0.000148, k_5=0.000169, k_6=0.000005, inverter_efficiency=0.9)
+T, Y, X, N = 8760, 200, 200, 100
+ctx = Context(0)
+inputs, coords = synthetic.pv_inputs(ctx, T, Y, X)
+x, y = coords["x"], coords["y"]
+dx, dy = x[1] - x[0], y[1] - y[0]
+M = gis.compute_indicatormatrix(x, y, gis.random_tessellation(N, (x[0] - dx / 2, y[0] - dy / 2, x[-1] + dx / 2, y[-1] + dy / 2)))
+plan = ctx.plan(M, row_len=X)
+S = Y * X
+h, dec = solar.hour_angle(coords["time"], x, "-30min")
+lat = np.radians(y)
+tables = {k: ctx.upload(np.ascontiguousarray(v)) for k, v in dict(sin_dec=np.sin(dec), cos_dec=np.cos(dec), h=h,
+                                                                   cos_h=np.cos(h), sin_lat=np.sin(lat), cos_lat=np.cos(lat)).items()}
+scal = dict(CSI, slope=np.radians(30.0), azimuth=np.radians(180.0))
+alat = np.abs(lat)
+slope = np.where(alat <= np.radians(25), 0.87 * alat, np.where(alat <= np.radians(50), 0.76 * alat + np.radians(0.31), np.radians(40.0)))
+percell = dict(CSI, slope=ctx.upload(np.repeat(slope, X)), azimuth=ctx.upload(np.full(S, np.pi)))
+five = {k: v for k, v in inputs.items() if not k.startswith("solar_")}
+
+
+def timed(fn, reps=5):
+    ctx.set_profiling(True)
+    ms = []
+    for i in range(reps + 2):
+        out = fn()
+        t = ctx.last_kernel_ms()
+        if i >= 2:
+            ms.append(t)
+    return float(np.median(ms)), out
+
+
+ref = None
+for name, nbytes, fn in (
+    ("getter, scalar orientation (bench.py)", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(night_skip=False))),
+    ("getter + night early-out", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(night_skip=True))),
+    ("getter, per-cell orientation (latitude_optimal)", 56, lambda: ctx.pv(inputs, percell, T, S, plan=plan, options=dict(night_skip=False))),
+    ("in-kernel solar position (5 cubes + tables)", 40, lambda: ctx.pv(five, scal, T, S, plan=plan, solar_tables=tables)),
+    ("general kernel: tracking='horizontal'", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="horizontal"))),
+    ("general kernel: trigon_model='other'", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(trigon_model="other"))),
+    ("per-cell series out (no matrix)", 64, lambda: ctx.pv(inputs, scal, T, S)),
+):
+    ms, out = timed(fn)
+    gbs = nbytes * T * S / (ms * 1e-3) / 1e9
+    extra = ""
+    if ref is None:
+        ref = out.numpy()
+    elif "in-kernel" in name:
+        o = out.numpy()
+        extra = f"  max rel diff vs getter {np.max(np.abs(o - ref) / np.maximum(np.abs(ref), 1e-12 * ref.max())):.1e}"
+    print(f"{name:52s} {ms:8.3f} ms  {gbs:6.0f} GB/s ({nbytes} B/cell)  {T * S / (ms * 1e-3):.3e} cell-steps/s{extra}", flush=True)
+    del out
