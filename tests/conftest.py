@@ -11,6 +11,12 @@ if str(ROOT) not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # the shared library is a build artefact (git-ignored): build it on a fresh checkout
+    lib = ROOT / "atlite_amd" / "lib" / "libatlite_hip.so"
+    if not lib.exists() and os.environ.get("ATLITE_HIP_LIB") is None:
+        import __graft_entry__
+
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
