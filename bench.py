@@ -87,6 +87,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
 
+    if not (ROOT / "atlite_amd" / "lib" / "libatlite_hip.so").exists() and "ATLITE_HIP_LIB" not in os.environ:
+        if rank == 0:
+            import __graft_entry__
+
+            __graft_entry__.build()  # fresh checkout: the library is a (git-ignored) build artefact
+        while not (ROOT / "atlite_amd" / "lib" / "libatlite_hip.so").exists():
+            time.sleep(1.0)
     from atlite_amd import gis, synthetic
     from atlite_amd.device import Context
 
