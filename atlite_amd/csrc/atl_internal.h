@@ -67,8 +67,12 @@ struct atl_ctx {
     // scratch arena (grown on demand, stream-ordered reuse)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
-    // small table buffer for per-call host tables (wind knots)
+    // small table buffer for per-call host tables (wind knots): device copy + pinned host staging;
+    // ev_table marks the completion of the last H2D so the staging buffer is never overwritten early
     double *d_table = nullptr;
+    double *h_table = nullptr;
+    hipEvent_t ev_table = nullptr;
+    bool table_pending = false;
     // timing
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // atl_timer_*
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;  // dominant-kernel bracket

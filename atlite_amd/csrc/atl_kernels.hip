@@ -21,6 +21,7 @@
 //   agg  : aggregate.py:16-35 (scipy CSR product), convert.py:51-56 (_aggregate_time)
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <limits>
 #include <type_traits>
 
@@ -753,9 +754,14 @@ int make_wind(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p,
                                                         : 0.0;
         finite = finite && std::isfinite(k[0]) && std::isfinite(k[1]) && std::isfinite(k[2]);
     }
-    // stream-ordered after any earlier kernel that still reads the table
-    ATL_HIP_TRY(hipMemcpyAsync(ctx->d_table, tbl.data(), tbl.size() * sizeof(double), hipMemcpyHostToDevice,
+    // pinned staging buffer: wait until the previous call's copy has left it, then enqueue the H2D
+    // stream-ordered after any earlier kernel that still reads the device table
+    if (ctx->table_pending) ATL_HIP_TRY(hipEventSynchronize(ctx->ev_table));
+    memcpy(ctx->h_table, tbl.data(), tbl.size() * sizeof(double));
+    ATL_HIP_TRY(hipMemcpyAsync(ctx->d_table, ctx->h_table, tbl.size() * sizeof(double), hipMemcpyHostToDevice,
                                ctx->stream));
+    ATL_HIP_TRY(hipEventRecord(ctx->ev_table, ctx->stream));
+    ctx->table_pending = true;
     c->wnd = in->d_wnd;
     c->aux = in->d_aux;
     c->S = S;

@@ -109,8 +109,10 @@ int atl_create(int device, void *stream, atl_ctx **out) {
     (void)hipEventCreate(&c->ev_t1);
     (void)hipEventCreate(&c->ev_k0);
     (void)hipEventCreate(&c->ev_k1);
-    if (hipMalloc(reinterpret_cast<void **>(&c->d_table), 5 * 2 * kMaxKnots * sizeof(double)) !=
-        hipSuccess) {
+    (void)hipEventCreateWithFlags(&c->ev_table, hipEventDisableTiming);
+    if (hipMalloc(reinterpret_cast<void **>(&c->d_table), 5 * 2 * kMaxKnots * sizeof(double)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&c->h_table), 5 * 2 * kMaxKnots * sizeof(double), hipHostMallocDefault) !=
+            hipSuccess) {
         set_error("atl_create: table allocation failed");
         delete c;
         return ATL_E_NOMEM;
@@ -125,6 +127,8 @@ int atl_destroy(atl_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->d_table) (void)hipFree(ctx->d_table);
+    if (ctx->h_table) (void)hipHostFree(ctx->h_table);
+    if (ctx->ev_table) (void)hipEventDestroy(ctx->ev_table);
     (void)hipEventDestroy(ctx->ev_t0);
     (void)hipEventDestroy(ctx->ev_t1);
     (void)hipEventDestroy(ctx->ev_k0);
