@@ -231,10 +231,27 @@ __global__ __launch_bounds__(256, min_waves<Conv>()) void k_fused_segred(Conv co
     conv.block_init(lds);
     __syncthreads();
     const int lane = threadIdx.x & 63;
+#ifndef ATL_XCD_MAP
+    // Linear order: consecutive blocks (= consecutive XCDs, block b runs on XCD b % 8) take consecutive
+    // tile groups of the same time chunk, so the chip as a whole streams contiguous memory.
     const int64_t unit = int64_t(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
     if (unit >= n_units) return;
     const int32_t seg = int32_t(unit % plan.n_segs);
     const int64_t chunk = unit / plan.n_segs;
+#else
+    // XCD-affine order (measured and REJECTED: C2 3.44 vs 3.41 ms, C4 shard 6.18 vs 5.83 ms, runoff
+    // 0.96 vs 0.89 ms): a group of 4 tiles always lands on the same XCD for every time chunk, so its
+    // weights sit in one XCD's L2 instead of eight.  There is almost no reuse to win - the weights
+    // are register-cached per 64-slot chunk and make up < 1 % of the traffic.
+    const int64_t n_groups = (int64_t(plan.n_segs) + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t per_xcd = (n_groups + 7) / 8;
+    const int64_t j = int64_t(blockIdx.x) >> 3;
+    const int64_t group = int64_t(blockIdx.x & 7) + 8 * (j % per_xcd);
+    const int64_t chunk = j / per_xcd;
+    const int64_t seg64 = group * kWavesPerBlock + (threadIdx.x >> 6);
+    if (group >= n_groups || seg64 >= plan.n_segs || chunk * chunk_slots >= n_slots) return;
+    const int32_t seg = int32_t(seg64);
+#endif
     // tile coordinates -> the lane's two adjacent cells
     // (columns sheared by (gy*X) mod 16 cells: tile rows start on 128-byte lines)
     const int32_t ty = seg / plan.ntx, tx = seg - ty * plan.ntx;
@@ -583,7 +600,12 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
             const int32_t chunk_slots = pick_chunk_slots(ctx, wn, plan.n_segs);
             const int64_t n_chunks = (wn + chunk_slots - 1) / chunk_slots;
             const int64_t n_units = n_chunks * plan.n_segs;
+#ifndef ATL_XCD_MAP
             const dim3 grid(unsigned((n_units + kWavesPerBlock - 1) / kWavesPerBlock));
+#else
+            const int64_t n_groups = (int64_t(plan.n_segs) + kWavesPerBlock - 1) / kWavesPerBlock;
+            const dim3 grid(unsigned(8 * ((n_groups + 7) / 8) * n_chunks));
+#endif
             KernelBracket kb(ctx);
             if (vec)
                 hipLaunchKernelGGL((k_fused_segred<Conv, true>), grid, dim3(256), lds_bytes, ctx->stream, conv, plan,
