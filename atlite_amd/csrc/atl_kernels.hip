@@ -239,10 +239,10 @@ __global__ __launch_bounds__(256, min_waves<Conv>()) void k_fused_segred(Conv co
     const int32_t seg = int32_t(unit % plan.n_segs);
     const int64_t chunk = unit / plan.n_segs;
 #else
-    // XCD-affine order (measured and REJECTED: C2 3.44 vs 3.41 ms, C4 shard 6.18 vs 5.83 ms, runoff
-    // 0.96 vs 0.89 ms): a group of 4 tiles always lands on the same XCD for every time chunk, so its
-    // weights sit in one XCD's L2 instead of eight.  There is almost no reuse to win - the weights
-    // are register-cached per 64-slot chunk and make up < 1 % of the traffic.
+    // XCD-affine order (-DATL_XCD_MAP; measured: no gain - C2 3.44 vs 3.41 ms, C4 shard 6.12 vs
+    // 6.13 ms, runoff 0.97 vs 0.97 ms): a group of 4 tiles always lands on the same XCD for every time
+    // chunk, so its weights sit in one XCD's L2 instead of eight.  There is no reuse to win - the
+    // weights are register-cached per 64-slot chunk and make up < 1 % of the traffic.
     const int64_t n_groups = (int64_t(plan.n_segs) + kWavesPerBlock - 1) / kWavesPerBlock;
     const int64_t per_xcd = (n_groups + 7) / 8;
     const int64_t j = int64_t(blockIdx.x) >> 3;
