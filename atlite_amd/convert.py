@@ -688,8 +688,7 @@ def convert_and_aggregate(
     # per-unit needs the series on the host anyway (fillna(0) precedes the time reduction)
     on_device_time = aggregate_time if (aggregate_time in ("sum", "mean") and not per_unit) else None
     plan = ctx.plan(matrix, row_len=X)
-    out = _execute(ctx, spec, ds, plan, on_device_time).numpy()
-    plan.close()
+    out = _execute(ctx, spec, ds, plan, on_device_time).numpy()  # the plan stays in ctx's cache
     tc = spec.time_coord(ds)
     attrs = {}
 

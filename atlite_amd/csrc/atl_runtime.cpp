@@ -390,23 +390,38 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_le
             cands.resize(1);
         }
     }
+    // Entries arrive grouped by row (CSR).  For a layout, the distinct tiles a row touches are found
+    // with a per-row marker array in O(nnz): no sorting of the entries.
+    const size_t n_raw = raw.size();
+    std::vector<int64_t> row_begin(static_cast<size_t>(n_rows) + 1, 0);
+    for (const Raw &e : raw) row_begin[size_t(e.row) + 1]++;
+    for (int64_t r = 0; r < n_rows; ++r) row_begin[r + 1] += row_begin[r];
+
+    auto n_tiles_of = [&](const Layout &L) {
+        const int h = kLanes >> L.w2_log2;
+        return n_cells > 0 ? ntx_of(L) * ((L.Y + h - 1) / h) : int64_t(0);
+    };
     size_t best = 0;
     if (cands.size() > 1) {
         double best_cost = 0;
-        std::vector<int64_t> keys(raw.size());
+        std::vector<int32_t> mark;
+        std::vector<uint8_t> used;
         for (size_t c = 0; c < cands.size(); ++c) {
+            const int64_t nt = n_tiles_of(cands[c]);
+            mark.assign(size_t(nt), -1);
+            used.assign(size_t(nt), 0);
+            int64_t P = 0, tiles = 0;
             int32_t loc;
-            for (size_t i = 0; i < raw.size(); ++i)
-                keys[i] = tile_of(cands[c], raw[i].cell, &loc) * n_rows + raw[i].row;
-            std::sort(keys.begin(), keys.end());
-            int64_t P = 0, tiles = 0, last = -1, last_tile = -1;
-            for (int64_t k : keys) {
-                if (k != last) {
-                    ++P;
-                    last = k;
-                    if (k / n_rows != last_tile) {
-                        ++tiles;
-                        last_tile = k / n_rows;
+            for (int64_t r = 0; r < n_rows; ++r) {
+                for (int64_t k = row_begin[r]; k < row_begin[r + 1]; ++k) {
+                    const int64_t t = tile_of(cands[c], raw[size_t(k)].cell, &loc);
+                    if (mark[size_t(t)] != int32_t(r)) {
+                        mark[size_t(t)] = int32_t(r);
+                        ++P;
+                        if (!used[size_t(t)]) {
+                            used[size_t(t)] = 1;
+                            ++tiles;
+                        }
                     }
                 }
             }
@@ -426,56 +441,60 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_le
     const int64_t ntx = ntx_of(L), nty = (L.Y + th - 1) / th;
     const int64_t n_segs = n_cells > 0 ? ntx * nty : 0;
 
-    struct Ent {
-        int64_t key;  // tile * n_rows + row
-        int32_t local;
-        double w;
-    };
-    std::vector<Ent> ents(raw.size());
-    for (size_t i = 0; i < raw.size(); ++i) {
-        int32_t loc;
-        const int64_t t = tile_of(L, raw[i].cell, &loc);
-        ents[i] = {t * n_rows + raw[i].row, loc, raw[i].w};
-    }
-    std::stable_sort(ents.begin(), ents.end(),
-                     [](const Ent &a, const Ent &b) { return a.key < b.key; });
-
+    // ---- partial rows: one per (tile, row) pair, ordered by tile then row ------------------------
+    // pass 1: per row, the tiles it touches (first-touch order), counted per tile
     std::vector<int32_t> seg_ptr(static_cast<size_t>(n_segs) + 1, 0);
-    std::vector<int32_t> prow_shape;
+    std::vector<int64_t> pair_tile;  // (row-major) tile of every (row, tile) pair
+    std::vector<int64_t> pair_ptr(static_cast<size_t>(n_rows) + 1, 0);
     {
-        int64_t last = -1;
-        for (const Ent &e : ents) {
-            if (e.key != last) {
-                last = e.key;
-                prow_shape.push_back(int32_t(e.key % n_rows));
-                seg_ptr[size_t(e.key / n_rows) + 1]++;
+        std::vector<int32_t> mark(static_cast<size_t>(n_segs), -1);
+        int32_t loc;
+        for (int64_t r = 0; r < n_rows; ++r) {
+            for (int64_t k = row_begin[r]; k < row_begin[r + 1]; ++k) {
+                const int64_t t = tile_of(L, raw[size_t(k)].cell, &loc);
+                if (mark[size_t(t)] != int32_t(r)) {
+                    mark[size_t(t)] = int32_t(r);
+                    pair_tile.push_back(t);
+                    seg_ptr[size_t(t) + 1]++;
+                }
             }
+            pair_ptr[r + 1] = int64_t(pair_tile.size());
         }
-        for (int64_t s = 0; s < n_segs; ++s) seg_ptr[s + 1] += seg_ptr[s];
+        for (int64_t s2 = 0; s2 < n_segs; ++s2) seg_ptr[s2 + 1] += seg_ptr[s2];
     }
-    const int64_t P = int64_t(prow_shape.size());
-    ATL_REQUIRE(P < (int64_t(1) << 31) / 1, "atl_agg_create: too many partial rows");
+    const int64_t P = int64_t(pair_tile.size());
+    ATL_REQUIRE(P < (int64_t(1) << 31), "atl_agg_create: too many partial rows");
+    // pass 2: rows are visited in ascending order, so filling each tile's slots in visiting order
+    // sorts the partial rows of a tile by row
+    std::vector<int32_t> pair_prow(static_cast<size_t>(P));
+    {
+        std::vector<int32_t> fill(seg_ptr.begin(), seg_ptr.end() - 1);
+        for (int64_t q = 0; q < P; ++q) pair_prow[size_t(q)] = fill[size_t(pair_tile[size_t(q)])]++;
+    }
+    // pass 3: weights
     std::vector<double> prow_w(static_cast<size_t>(P) * kSegCells,
                                std::numeric_limits<double>::quiet_NaN());
-    {
-        int64_t last = -1, p = -1;
-        for (const Ent &e : ents) {
-            if (e.key != last) {
-                last = e.key;
-                ++p;
-            }
-            double &slot = prow_w[size_t(p) * kSegCells + e.local];
-            slot = std::isnan(slot) ? e.w : slot + e.w;  // duplicates are summed (scipy CSR)
-        }
-    }
     std::vector<int32_t> shape_ptr(static_cast<size_t>(n_rows) + 1, 0);
     std::vector<int32_t> shape_prow(static_cast<size_t>(P), 0);
-    for (int64_t p = 0; p < P; ++p) shape_ptr[size_t(prow_shape[p]) + 1]++;
-    for (int64_t r = 0; r < n_rows; ++r) shape_ptr[r + 1] += shape_ptr[r];
     {
-        std::vector<int32_t> fill(shape_ptr.begin(), shape_ptr.end() - 1);
-        for (int64_t p = 0; p < P; ++p) shape_prow[size_t(fill[prow_shape[p]]++)] = int32_t(p);
+        std::vector<int32_t> tile_prow(static_cast<size_t>(n_segs), -1);
+        int32_t loc;
+        for (int64_t r = 0; r < n_rows; ++r) {
+            for (int64_t q = pair_ptr[r]; q < pair_ptr[r + 1]; ++q) tile_prow[size_t(pair_tile[size_t(q)])] = pair_prow[size_t(q)];
+            for (int64_t k = row_begin[r]; k < row_begin[r + 1]; ++k) {
+                const Raw &e = raw[size_t(k)];
+                const int64_t t = tile_of(L, e.cell, &loc);
+                double &slot = prow_w[size_t(tile_prow[size_t(t)]) * kSegCells + size_t(loc)];
+                slot = std::isnan(slot) ? e.w : slot + e.w;  // duplicates are summed (scipy CSR)
+            }
+            // the shape's partial rows in ascending tile (= ascending partial row) order
+            shape_ptr[r + 1] = shape_ptr[r] + int32_t(pair_ptr[r + 1] - pair_ptr[r]);
+            std::vector<int32_t> mine(pair_prow.begin() + pair_ptr[r], pair_prow.begin() + pair_ptr[r + 1]);
+            std::sort(mine.begin(), mine.end());
+            std::copy(mine.begin(), mine.end(), shape_prow.begin() + shape_ptr[r]);
+        }
     }
+    (void)n_raw;
 
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     atl_agg *a = new atl_agg();

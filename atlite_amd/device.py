@@ -203,9 +203,39 @@ class Context:
         return ms.value
 
     # -- plans ----------------------------------------------------------------------------
-    def plan(self, matrix, row_len=None):
-        """row_len = X of the (Y, X) grid lets the plan use compact 2-d cell tiles."""
-        return AggPlan(self, matrix, row_len=row_len)
+    def plan(self, matrix, row_len=None, cache=True):
+        """
+        Aggregation plan of a (N x S) matrix; row_len = X of the (Y, X) grid lets the plan use compact
+        2-d cell tiles.  Plans are cached per context by matrix content (8 most recent), so repeated
+        conversions over the same shapes skip the host-side preprocessing; cached plans are owned by
+        the context (do not close them).
+        """
+        if not cache:
+            return AggPlan(self, matrix, row_len=row_len)
+        import scipy.sparse as sp
+
+        m = sp.csr_matrix(matrix)
+        try:
+            import xxhash
+
+            h = xxhash.xxh3_128()
+        except Exception:  # pragma: no cover
+            import hashlib
+
+            h = hashlib.blake2b(digest_size=16)
+        for a in (m.indptr, m.indices, m.data):
+            h.update(np.ascontiguousarray(a).view(np.uint8))
+        key = (m.shape, int(row_len or 0), m.indptr.dtype.str, m.indices.dtype.str, h.hexdigest(),
+               os.environ.get("ATLITE_HIP_TILE", ""))
+        cache_ = self.__dict__.setdefault("_plan_cache", {})
+        if key in cache_:
+            cache_[key] = cache_.pop(key)  # most recently used last
+            return cache_[key]
+        plan = AggPlan(self, m, row_len=row_len)
+        cache_[key] = plan
+        while len(cache_) > 8:
+            cache_.pop(next(iter(cache_))).close()
+        return plan
 
     # -- conversions (device in, device out) ------------------------------------------------
     def _out(self, plan, n_slots, S, time_agg, out=None):
@@ -369,6 +399,8 @@ class Context:
         return out
 
     def close(self):
+        for p in self.__dict__.pop("_plan_cache", {}).values():
+            p.close()
         if getattr(self, "handle", None):
             self.lib.atl_destroy(self.handle)
             self.handle = None
