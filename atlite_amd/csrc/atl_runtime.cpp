@@ -426,9 +426,10 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_le
                 }
             }
             // a tile costs its conversion work even for masked lanes, a partial row one wave
-            // reduction; narrow tile rows (128 B per row at 16x8) stream from HBM less
-            // efficiently than 256-B+ rows (measured on C2: 32x4 3.51 ms vs 16x8 3.69 ms)
-            static const double row_eff[7] = {0, 0, 0, 1.25, 1.0, 0.97, 0.95};
+            // reduction.  With 128-byte-aligned (sheared) tile rows and nontemporal loads the row width
+            // itself hardly matters any more (C2: 16x8 3.27-3.37 ms, 32x4 3.34-3.45, flat 3.39-3.48,
+            // 64x2 3.58), so the partial-row count decides; 64x2 keeps a small measured penalty.
+            static const double row_eff[7] = {0, 0, 0, 1.0, 1.0, 1.05, 1.0};
             const double cost = (4.0 * double(tiles) + double(P)) * row_eff[cands[c].w2_log2];
             if (c == 0 || cost < best_cost) {
                 best_cost = cost;
