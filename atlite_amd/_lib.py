@@ -132,6 +132,23 @@ class SynthSolar(C.Structure):
 
 # name -> (restype, argtypes); must list every symbol include/atlite_hip.h declares
 _vp, _i, _i64, _sz, _d = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_double
+class NcVar(C.Structure):
+    """atl_nc_var (include/atlite_hip.h)."""
+
+    _fields_ = (
+        [(n, C.c_int32) for n in ("ndim", "dtype", "elem_size", "big_endian")]
+        + [("shape", C.c_int64 * 4), ("chunk", C.c_int64 * 4)]
+        + [(n, C.c_int32) for n in ("layout", "shuffle", "deflate", "fletcher32", "has_scale", "has_fill",
+                                    "has_missing", "reserved_")]
+        + [(n, C.c_double) for n in ("scale_factor", "add_offset", "fill_value", "missing_value")]
+        + [("n_chunks", C.c_int64), ("stored_bytes", C.c_int64)]
+    )
+
+
+NC_DTYPES = {1: "float32", 2: "float64", 3: "int8", 4: "int16", 5: "int32", 6: "int64", 7: "uint8", 8: "uint16",
+             9: "uint32", 10: "uint64"}
+NC_CODES = {v: k for k, v in NC_DTYPES.items()}
+
 SIGNATURES = {
     "atl_version": (_i, []),
     "atl_last_error": (C.c_char_p, []),
@@ -189,6 +206,16 @@ SIGNATURES = {
          C.POINTER(_vp)],
     ),
     "atl_host_free": (_i, [_vp]),
+    "atl_nc_open": (_i, [C.c_char_p, C.POINTER(_vp)]),
+    "atl_nc_close": (_i, [_vp]),
+    "atl_nc_list": (_i, [_vp, C.c_char_p, _i64, C.POINTER(_i64)]),
+    "atl_nc_inquire": (_i, [_vp, C.c_char_p, C.POINTER(NcVar)]),
+    "atl_nc_dims": (_i, [_vp, C.c_char_p, C.c_char_p, _i64, C.POINTER(_i64)]),
+    "atl_nc_att_text": (_i, [_vp, C.c_char_p, C.c_char_p, C.c_char_p, _i64, C.POINTER(_i64)]),
+    "atl_nc_att_double": (_i, [_vp, C.c_char_p, C.c_char_p, _vp, _i64, C.POINTER(_i64)]),
+    "atl_nc_read_host": (_i, [_vp, C.c_char_p, _i64, _i64, _vp]),
+    "atl_nc_read_slab": (_i, [_vp, _vp, C.c_char_p, _i64, _i64, _vp, _i]),
+    "atl_upload_convert_async": (_i, [_vp, _vp, _vp, _i, _i64]),
     "atl_comm_unique_id": (_i, [_vp]),
     "atl_comm_init": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
     "atl_comm_destroy": (_i, [_vp]),

@@ -79,6 +79,9 @@ struct atl_ctx {
     bool profiling = false;
     bool have_kernel_time = false;
     int n_cu = 256;
+    // file / narrow-dtype ingest (atl_ingest.hip): staging buffers, created on first use
+    void *ingest = nullptr;
+    void (*ingest_free)(void *) = nullptr;
 };
 
 struct atl_event {
@@ -95,5 +98,7 @@ struct atl_agg {
 namespace atl {
 // scratch: returns a device pointer valid until the next scratch_reserve on this ctx.
 int scratch_reserve(atl_ctx *ctx, size_t bytes, void **out);
+// the context's copy stream (created on first use)
+int copy_stream_of(atl_ctx *ctx, hipStream_t *out);
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 }  // namespace atl

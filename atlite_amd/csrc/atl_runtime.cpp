@@ -58,6 +58,17 @@ static int to_device(atl_agg *a, const std::vector<T> &v, const T **out) {
     return ATL_OK;
 }
 
+namespace atl {
+int copy_stream_of(atl_ctx *ctx, hipStream_t *out) {
+    if (!ctx->copy_stream) {
+        ATL_HIP_TRY(hipSetDevice(ctx->device));
+        ATL_HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    }
+    *out = ctx->copy_stream;
+    return ATL_OK;
+}
+}  // namespace atl
+
 extern "C" {
 
 int atl_version(void) { return ATL_VERSION; }
@@ -133,10 +144,9 @@ int atl_destroy(atl_ctx *ctx) {
     (void)hipEventDestroy(ctx->ev_t1);
     (void)hipEventDestroy(ctx->ev_k0);
     (void)hipEventDestroy(ctx->ev_k1);
-    if (ctx->copy_stream) {
-        (void)hipStreamSynchronize(ctx->copy_stream);
-        (void)hipStreamDestroy(ctx->copy_stream);
-    }
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    if (ctx->ingest && ctx->ingest_free) ctx->ingest_free(ctx->ingest);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return ATL_OK;
@@ -197,14 +207,6 @@ int atl_memset(atl_ctx *ctx, void *d_dst, int byte_value, size_t bytes) {
 }
 
 // ---- host-resident cutouts: copy stream + events ------------------------------------------
-static int copy_stream_of(atl_ctx *ctx, hipStream_t *out) {
-    if (!ctx->copy_stream) {
-        ATL_HIP_TRY(hipSetDevice(ctx->device));
-        ATL_HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    }
-    *out = ctx->copy_stream;
-    return ATL_OK;
-}
 
 int atl_host_register(void *h_ptr, size_t bytes) {
     ATL_REQUIRE(h_ptr && bytes, "atl_host_register: bad argument");

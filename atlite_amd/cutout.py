@@ -1,10 +1,12 @@
 """
 A duck-typed cutout: exactly what the hot path touches on ``atlite.Cutout`` - ``.data``,
 ``.grid``, ``.indicatormatrix`` and the conversion methods bound as attributes
-(atlite/cutout.py:355-376, 492-515, 653-689).  Creating / preparing / reading cutouts
-(NetCDF, CDS downloads, GIS reprojection) is outside the hot path and not provided; build a
-``Dataset`` from arrays you already hold (host NumPy, torch CUDA tensors or DeviceArrays), or
-pass an ``xarray.Dataset`` where xarray is installed.
+(atlite/cutout.py:355-376, 492-515, 653-689).  ``Cutout(path)`` opens an existing NetCDF-4
+cutout file through the native reader (``atlite_amd.io``; variables stay on disk and are streamed
+to the device), like ``atlite.Cutout(path)`` on a prepared cutout (cutout.py:143,151-153).
+Creating / preparing cutouts (CDS downloads, GIS reprojection) is outside the hot path and not
+provided; alternatively build a ``Dataset`` from arrays you already hold (host NumPy, torch CUDA
+tensors or DeviceArrays), or pass an ``xarray.Dataset`` where xarray is installed.
 """
 
 from __future__ import annotations
@@ -18,11 +20,23 @@ from .labeled import Dataset
 
 
 class Cutout:
-    def __init__(self, data, crs=4326):
+    def __init__(self, data=None, crs=4326, path=None):
+        import os
+
+        if path is not None and data is None:
+            data = path
+        if isinstance(data, (str, os.PathLike)):
+            from .io import open_cutout
+
+            if not os.path.exists(data):
+                raise NotImplementedError(
+                    f"{data}: no such cutout file; creating / preparing cutouts is not part of atlite_amd")
+            self.path = os.fspath(data)
+            data = open_cutout(data)
         if labeled.xr is not None and isinstance(data, labeled.xr.Dataset):
             data = Dataset.from_xarray(data)
         if not isinstance(data, Dataset):
-            raise TypeError("Cutout needs an atlite_amd.Dataset (or an xarray.Dataset)")
+            raise TypeError("Cutout needs a cutout file path, an atlite_amd.Dataset or an xarray.Dataset")
         self.data = data
         self.crs = crs
 

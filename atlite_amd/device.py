@@ -170,6 +170,8 @@ class Context:
         """DeviceArray as is; torch CUDA tensor zero-copy; anything else is uploaded."""
         if isinstance(x, DeviceArray):
             return x
+        if getattr(x, "is_file_array", False):  # atlite_amd.io.FileArray: inflate + decode on the way in
+            return x.to_device(self)
         if type(x).__module__.startswith("torch") and hasattr(x, "data_ptr"):
             if x.is_cuda:
                 assert x.is_contiguous() and x.element_size() == np.dtype(dtype).itemsize
@@ -179,6 +181,16 @@ class Context:
 
     def sync(self):
         check(self.lib.atl_sync(self.handle))
+
+    def copy_barrier(self):
+        """Make the compute stream wait for everything enqueued on the copy stream so far."""
+        ev = self.__dict__.get("_copy_ev")
+        if ev is None:
+            ev = C.c_void_p()
+            check(self.lib.atl_event_create(self.handle, C.byref(ev)))
+            self._copy_ev = ev
+        check(self.lib.atl_event_record(self.handle, ev, 1))
+        check(self.lib.atl_stream_wait_event(self.handle, 0, ev))
 
     def name(self):
         buf = C.create_string_buffer(256)
@@ -401,6 +413,9 @@ class Context:
     def close(self):
         for p in self.__dict__.pop("_plan_cache", {}).values():
             p.close()
+        ev = self.__dict__.pop("_copy_ev", None)
+        if ev is not None:
+            self.lib.atl_event_destroy(ev)
         if getattr(self, "handle", None):
             self.lib.atl_destroy(self.handle)
             self.handle = None

@@ -24,11 +24,16 @@ def _is_device(x):
     return type(x).__name__ == "DeviceArray"
 
 
+def _is_lazy(x):
+    """File-backed variable (atlite_amd.io.FileArray): kept as is, read on demand."""
+    return getattr(x, "is_file_array", False)
+
+
 class LabeledArray:
     """``values`` + ``dims`` + ``coords`` + ``attrs`` + ``name`` (a tiny DataArray stand-in)."""
 
     def __init__(self, values, dims, coords=None, attrs=None, name=None):
-        self._values = values if _is_device(values) else np.asarray(values)
+        self._values = values if (_is_device(values) or _is_lazy(values)) else np.asarray(values)
         self.dims = tuple(dims)
         if len(self.dims) != len(self._values.shape):
             raise ValueError(f"dims {self.dims} do not match shape {self._values.shape}")
@@ -48,6 +53,8 @@ class LabeledArray:
     def values(self):
         if _is_device(self._values):
             return self._values.numpy()
+        if _is_lazy(self._values):
+            return np.asarray(self._values)
         return self._values
 
     def __array__(self, dtype=None, copy=None):
@@ -138,7 +145,7 @@ class LabeledArray:
                             attrs=self.attrs, name=self.name)
 
     def __repr__(self):
-        where = "device" if _is_device(self._values) else "host"
+        where = "device" if _is_device(self._values) else "file" if _is_lazy(self._values) else "host"
         return f"<LabeledArray {self.name!r} {self.sizes} [{where}] attrs={self.attrs}>"
 
 

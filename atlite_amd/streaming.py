@@ -8,8 +8,15 @@ is bounded by two slabs of every input variable, the end-to-end rate approaches 
 (the kernels are ~100x faster than the link).  SURVEY.md 8 f-4; the reference reads its
 cutouts chunk by chunk through dask (atlite/cutout.py:143) - this is the device-side analogue.
 
-Used automatically by ``convert_and_aggregate`` for host-resident datasets above
-``ATLITE_HIP_STREAM_MIN_BYTES`` (default 256 MiB; ``ATLITE_HIP_STREAM=0/1`` forces it off/on).
+Three kinds of sources feed a slab buffer:
+  * host fp64 arrays: one DMA (``atl_upload_async``);
+  * host arrays of a narrower dtype (float32 is what xarray hands over for a real cutout): DMA'd
+    as they are and widened on the device (``atl_upload_convert_async``) - half the PCIe bytes;
+  * variables of a cutout FILE (``atlite_amd.io.FileArray``): chunks inflated on host threads,
+    DMA'd in the on-disk dtype, un-shuffled / CF-decoded on the device (``atl_nc_read_slab``).
+
+Used automatically by ``convert_and_aggregate`` for file-backed datasets and for host-resident ones
+above ``ATLITE_HIP_STREAM_MIN_BYTES`` (default 256 MiB; ``ATLITE_HIP_STREAM=0/1`` forces it off/on).
 """
 
 from __future__ import annotations
@@ -19,14 +26,29 @@ import os
 
 import numpy as np
 
-from ._lib import check
+from ._lib import NC_CODES, check
 
 COMPUTE, COPY = 0, 1
 
 
 def _host_array(la):
+    """The variable's host-side source: ndarray or FileArray; None for device-resident data."""
     d = la.data
-    return d if isinstance(d, np.ndarray) else None
+    return d if isinstance(d, np.ndarray) or getattr(d, "is_file_array", False) else None
+
+
+def _is_file(a):
+    return getattr(a, "is_file_array", False)
+
+
+def _source(a, T, S):
+    """Normalise one source: FileArray as is; ndarray C-contiguous (T, S) in a dtype the device decodes."""
+    if _is_file(a):
+        return a
+    if a.dtype.str.lstrip("<=|") not in ("f8", "f4", "i1", "i2", "i4", "i8", "u1", "u2", "u4", "u8") or \
+            a.dtype.byteorder == ">":
+        a = a.astype(np.float64)
+    return np.ascontiguousarray(a).reshape(T, S)
 
 
 def wanted(ds, spec):
@@ -37,7 +59,7 @@ def wanted(ds, spec):
     arrs = [_host_array(ds[n]) for n in spec.time_vars]
     if any(a is None for a in arrs):
         return False
-    if mode == "1":
+    if mode == "1" or any(_is_file(a) for a in arrs):
         return True
     return sum(a.nbytes for a in arrs) >= int(os.environ.get("ATLITE_HIP_STREAM_MIN_BYTES", 256 << 20))
 
@@ -86,8 +108,12 @@ def run(ctx, spec, ds, plan, time_agg):
     lib = ctx.lib
     T = len(ds.coords["time"])
     S = len(ds.coords["y"]) * len(ds.coords["x"])
-    host = {n: np.ascontiguousarray(_host_array(ds[n]), dtype=np.float64).reshape(T, S) for n in spec.time_vars}
+    host = {n: _source(_host_array(ds[n]), T, S) for n in spec.time_vars}
     steps = int(os.environ.get("ATLITE_HIP_SLAB_STEPS", 0)) or max(8, min(T, (128 << 20) // max(S * 8, 1)) // 8 * 8)
+    # file sources: whole chunks per slab, so that no chunk is inflated twice
+    tchunk = max([a.var.chunks[0] for a in host.values() if _is_file(a) and a.var.layout == "chunked"], default=0)
+    if tchunk and not os.environ.get("ATLITE_HIP_SLAB_STEPS"):
+        steps = max(tchunk, steps // tchunk * tchunk)
     edges = spec.slab_edges(T, steps)
     n_slots = spec.n_slots(ds)
     static = {n: ds.device(ctx, n) for n in getattr(spec, "static_vars", ())}
@@ -106,15 +132,22 @@ def run(ctx, spec, ds, plan, time_agg):
         out = ctx.empty((n_slots, S))
     else:
         out, host_acc = None, np.zeros(S)
-    pinned = _Pinned(lib, list(host.values()), getattr(ds, "pinned_ranges", lambda: [])())
+    pinned = _Pinned(lib, [a for a in host.values() if not _is_file(a)], getattr(ds, "pinned_ranges", lambda: [])())
     try:
         for i, (t0, t1) in enumerate(edges):
             b = i % 2
             if i >= 2:
                 check(lib.atl_stream_wait_event(ctx.handle, COPY, ev_done[b]))
             for n, a in host.items():
+                if _is_file(a):
+                    a.read_slab(ctx, t0, t1, bufs[b][n].ptr)
+                    continue
                 blk = a[t0:t1]
-                check(lib.atl_upload_async(ctx.handle, bufs[b][n].ptr, blk.ctypes.data, blk.nbytes))
+                if a.dtype == np.float64:
+                    check(lib.atl_upload_async(ctx.handle, bufs[b][n].ptr, blk.ctypes.data, blk.nbytes))
+                else:
+                    check(lib.atl_upload_convert_async(ctx.handle, bufs[b][n].ptr, blk.ctypes.data,
+                                                       NC_CODES[a.dtype.name], blk.size))
             check(lib.atl_event_record(ctx.handle, ev_ready[b], COPY))
             check(lib.atl_stream_wait_event(ctx.handle, COMPUTE, ev_ready[b]))
             view = _SlabView(ds, bufs[b], static, t0, t1)

@@ -294,6 +294,70 @@ int atl_indicator_polygons(int64_t n_shapes, const int64_t *h_shape_ring_ptr, in
                            double **out_data);
 int atl_host_free(void *p);
 
+/* ---- cutout files: NetCDF-4 (HDF5) ingest -------------------------------------------------------
+ * Replaces `xr.open_dataset(path, chunks=...)` + dask chunk reads for the inputs of the path
+ * (atlite/cutout.py:143,151-153; files are written with zlib + shuffle, atlite/data.py:139,246-248).
+ * The container is parsed natively (no libhdf5); chunk payloads are inflated on host threads into
+ * pinned staging, DMA'd on the context's copy stream and un-shuffled / widened to fp64 / CF-decoded
+ * (`_FillValue`, `missing_value` -> NaN; `scale_factor`, `add_offset`) ON THE DEVICE.  Everything
+ * except atl_nc_read_slab / atl_upload_convert_async is host-only code and works without a GPU. */
+typedef struct atl_nc atl_nc;
+
+#define ATL_NC_F32 1
+#define ATL_NC_F64 2
+#define ATL_NC_I8 3
+#define ATL_NC_I16 4
+#define ATL_NC_I32 5
+#define ATL_NC_I64 6
+#define ATL_NC_U8 7
+#define ATL_NC_U16 8
+#define ATL_NC_U32 9
+#define ATL_NC_U64 10
+#define ATL_NC_OTHER 0 /* strings, compounds, references: listed, not readable */
+
+typedef struct atl_nc_var {
+    int32_t ndim;    /* <= 4 reported; read functions take <= 3 */
+    int32_t dtype;   /* ATL_NC_* */
+    int32_t elem_size;
+    int32_t big_endian;
+    int64_t shape[4];
+    int64_t chunk[4];       /* == shape for contiguous / compact storage */
+    int32_t layout;         /* 0 compact, 1 contiguous, 2 chunked; < 0: index type not supported */
+    int32_t shuffle;        /* 1 if the shuffle filter is in the pipeline */
+    int32_t deflate;        /* deflate level + 1, 0 = not compressed */
+    int32_t fletcher32;
+    int32_t has_scale;      /* scale_factor / add_offset present */
+    int32_t has_fill;       /* _FillValue present */
+    int32_t has_missing;    /* missing_value present */
+    int32_t reserved_;
+    double scale_factor, add_offset, fill_value, missing_value;
+    int64_t n_chunks;       /* chunks in the grid */
+    int64_t stored_bytes;   /* bytes on disk */
+} atl_nc_var;
+
+int atl_nc_open(const char *path, atl_nc **out);
+int atl_nc_close(atl_nc *f);
+/* '\n'-separated names of all datasets (groups as "grp/var"); *needed = bytes incl. the NUL */
+int atl_nc_list(atl_nc *f, char *buf, int64_t buflen, int64_t *needed);
+int atl_nc_inquire(atl_nc *f, const char *name, atl_nc_var *info);
+/* '\n'-separated dimension names of a variable (DIMENSION_LIST; else matched by length; "" unknown) */
+int atl_nc_dims(atl_nc *f, const char *name, char *buf, int64_t buflen, int64_t *needed);
+/* attributes; var = NULL or "" for global ones.  *needed / *n = 0 when the attribute is absent */
+int atl_nc_att_text(atl_nc *f, const char *var, const char *att, char *buf, int64_t buflen, int64_t *needed);
+int atl_nc_att_double(atl_nc *f, const char *var, const char *att, double *out, int64_t max_n, int64_t *n);
+/* rows [start0, start0 + count0) along the first dimension, CF-decoded to fp64 on the host
+ * (coordinates, static fields, tests); out holds count0 * prod(shape[1:]) doubles */
+int atl_nc_read_host(atl_nc *f, const char *name, int64_t start0, int64_t count0, double *out);
+/* same rows as an fp64 (count0, prod(shape[1:])) block at d_out, asynchronously: returns after the
+ * host inflate; the copy + device decode are enqueued on the copy stream (order against the
+ * compute stream with atl_event_record(ev, 1) / atl_stream_wait_event(ctx, 0, ev)).
+ * n_threads <= 0: min(hardware threads, 32, $ATLITE_HIP_IO_THREADS). */
+int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, int64_t count0,
+                     double *d_out, int n_threads);
+/* host array of a narrower dtype (what xarray hands over for a float32 cutout) -> fp64 on the
+ * device through the same staging + decode kernel; halves the PCIe bytes of atl_upload_async */
+int atl_upload_convert_async(atl_ctx *ctx, double *d_dst, const void *h_src, int dtype, int64_t n);
+
 /* ---- multi-GPU (RCCL over xGMI) ------------------------------------------------------------------
  * One process (and one atl_ctx) per GPU, the TIME axis sharded: rank r converts and aggregates its
  * own time slab; the small (shapes x time) result is reassembled with one collective.  The

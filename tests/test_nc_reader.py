@@ -1,0 +1,200 @@
+"""
+Native NetCDF-4 / HDF5 container reader (atlite_amd/csrc/atl_h5.cpp, atl_nc_* in
+include/atlite_hip.h) - host-only entry points, no GPU needed.  Fixtures: tests/golden/nc/*.nc
+written by h5py under the conda interpreter (tests/golden/make_nc_fixtures.py) with the
+expected fp64 values beside them; when that interpreter is present, random shapes / chunkings
+are generated on the fly as well.  SURVEY.md section 8 row f-4.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from atlite_amd import _lib, io
+
+NC = os.path.join(os.path.dirname(__file__), "golden", "nc")
+CONDA = "/opt/conda/bin/python3.9"
+MAKE = os.path.join(os.path.dirname(__file__), "golden", "make_nc_fixtures.py")
+
+
+def _have_h5py():
+    try:
+        return subprocess.run([CONDA, "-c", "import h5py"], capture_output=True, timeout=120).returncode == 0
+    except Exception:
+        return False
+
+
+@pytest.mark.parametrize("name", ["cutout_nc4", "cutout_earliest", "cutout_latest", "cutout_many", "userblock"])
+def test_fixture_values(name):
+    """Every variable of every container flavour decodes to the values h5py wrote."""
+    f = io.NcFile(f"{NC}/{name}.nc")
+    exp = np.load(f"{NC}/{name}.npz")
+    assert set(exp.files) == set(f.variables)
+    for v in exp.files:
+        got = f.read(v)
+        assert got.shape == exp[v].shape, v
+        assert np.array_equal(got, exp[v], equal_nan=True), v
+    f.close()
+
+
+def test_partial_rows_and_edge_chunks():
+    f = io.NcFile(f"{NC}/cutout_nc4.nc")
+    exp = np.load(f"{NC}/cutout_nc4.npz")
+    T = exp["runoff"].shape[0]
+    for name in ("runoff", "albedo", "soil_temperature", "roughness", "u16cube", "count_i32"):
+        for t0, n in ((0, 1), (3, 9), (9, 2), (10, 10), (T - 1, 1), (5, T - 5), (7, 0)):
+            got = f.read(name, t0, n)
+            assert np.array_equal(got, exp[name][t0:t0 + n], equal_nan=True), (name, t0, n)
+    with pytest.raises(ValueError, match="outside"):
+        f.read("runoff", T - 1, 2)
+    with pytest.raises(KeyError):
+        f.read("nope")
+
+
+def test_metadata():
+    f = io.NcFile(f"{NC}/cutout_nc4.nc")
+    v = f.variables["runoff"]
+    assert v.dtype == "int16" and v.shape == (23, 7, 9) and v.chunks == (10, 4, 5)
+    assert v.dims == ("time", "y", "x")  # resolved through DIMENSION_LIST object references
+    assert v.layout == "chunked" and v.shuffle and v.fletcher32 and v.deflate == 4
+    assert v.scale_factor == 1.5e-4 and v.add_offset == 4.25 and v.fill_value == -32767.0
+    assert v.n_chunks == 3 * 2 * 2
+    a = f.variables["albedo"]
+    assert a.big_endian and a.dtype == "float32" and a.missing_value == float(np.float32(9.96921e36))
+    assert f.variables["height"].layout == "contiguous" and f.variables["height"].dims == ("y", "x")
+    assert f.variables["temperature"].deflate == 9
+    # attributes: fixed strings, variable-length strings, scalars, arrays; dense storage (> 8 attributes)
+    assert f.attr("time", "units") == "hours since 1900-01-01 00:00:00.0"
+    assert f.attr(None, "module") == "era5"
+    assert f.attr(None, "vlen_note") == "written as a variable-length string"
+    assert f.attr(None, "dx") == 0.25
+    assert f.attr("temperature", "extra_11") == 11 * 1.25
+    assert np.array_equal(f.attr("temperature", "ints"), np.arange(5.0))
+    assert f.attr("temperature", "absent") is None
+    # old-style file: same answers through symbol tables / v1 headers
+    g = io.NcFile(f"{NC}/cutout_earliest.nc")
+    assert g.variables["runoff"].dims == ("time", "y", "x")
+    assert g.attr("temperature", "extra_11") == 11 * 1.25
+
+
+def test_many_links_two_level_index():
+    f = io.NcFile(f"{NC}/cutout_many.nc")
+    assert sum(n.startswith("aux_") for n in f.variables) == 160
+    assert np.array_equal(f.read("aux_0159"), 159.0 + np.arange(3))
+
+
+def test_unsupported_and_corrupt_inputs(tmp_path):
+    f = io.NcFile(f"{NC}/unlimited_latest.nc")  # opens; the extensible-array indexed variable is refused
+    with pytest.raises(NotImplementedError, match="chunk index"):
+        f.read("influx")
+    assert np.array_equal(f.read("y"), np.arange(4.0))
+    with pytest.raises(ValueError, match="cannot open"):
+        io.NcFile(tmp_path / "missing.nc")
+    p = tmp_path / "text.nc"
+    p.write_bytes(b"not an hdf5 file at all, but long enough to pass the size check........")
+    with pytest.raises(ValueError, match="not an HDF5"):
+        io.NcFile(p)
+    import scipy.io
+
+    p3 = tmp_path / "classic.nc"
+    with scipy.io.netcdf_file(str(p3), "w") as nc3:
+        nc3.createDimension("x", 4)
+        nc3.createVariable("x", "d", ("x",))[:] = np.arange(4.0)
+    with pytest.raises(NotImplementedError, match="NetCDF-3"):
+        io.NcFile(p3)
+    # truncations and bit flips must give errors (or still-valid data), never a crash
+    raw = open(f"{NC}/cutout_nc4.nc", "rb").read()
+    rng = np.random.default_rng(0)
+    for k in range(40):
+        b = bytearray(raw)
+        if k % 2:
+            b = b[: int(rng.integers(64, len(raw)))]
+        else:
+            for pos in rng.integers(0, min(len(raw), 20000), size=8):
+                b[int(pos)] ^= 0xFF
+        q = tmp_path / f"bad{k}.nc"
+        q.write_bytes(bytes(b))
+        try:
+            g = io.NcFile(q)
+            for name, var in list(g.variables.items())[:6]:
+                if var.dtype and 1 <= var.ndim <= 3 and np.prod(var.shape) < 10**6:
+                    try:
+                        g.read(name)
+                    except (ValueError, NotImplementedError, MemoryError):
+                        pass
+            g.close()
+        except (ValueError, NotImplementedError, MemoryError):
+            pass
+
+
+def test_decode_time():
+    t = io.decode_time([990552, 990553.5], "hours since 1900-01-01 00:00:00.0", "proleptic_gregorian")
+    assert list(t) == [pd.Timestamp("2013-01-01 00:00"), pd.Timestamp("2013-01-01 01:30")]
+    t = io.decode_time(np.arange(3), "days since 2013-01-01", None)
+    assert list(t) == list(pd.date_range("2013-01-01", periods=3, freq="D"))
+    t = io.decode_time([60], "minutes since 2013-01-01T00:00:00+00:00")
+    assert t[0] == pd.Timestamp("2013-01-01 01:00")
+    with pytest.raises(ValueError):
+        io.decode_time([0], "fortnights since 2013-01-01")
+    with pytest.raises(NotImplementedError):
+        io.decode_time([0], "hours since 2013-01-01", "360_day")
+
+
+def test_open_cutout_dataset():
+    """Dataset view of a cutout file: coordinates, lazy cubes, eager static fields (no GPU involved)."""
+    ds = io.open_cutout(f"{NC}/cutout_small_f32.nc")
+    assert ds.chunked  # like the reference's dask-backed file cutouts (cutout.py:143)
+    assert ds.sizes == {"time": 48, "y": 9, "x": 12}
+    assert ds.coords["time"][0] == pd.Timestamp("2013-01-01 00:00") and ds.coords["time"][-1] == pd.Timestamp(
+        "2013-01-02 23:00")
+    assert np.allclose(ds.coords["x"], -5.0 + 0.25 * np.arange(12)) and np.array_equal(ds.coords["lon"], ds.coords["x"])
+    assert "influx_direct" in ds and "soil temperature" in ds and "lon" not in ds
+    la = ds["temperature"]
+    assert la.dims == ("time", "y", "x") and la.shape == (48, 9, 12) and getattr(la.data, "is_file_array", False)
+    assert isinstance(ds["height"].data, np.ndarray) and ds["height"].shape == (9, 12)
+    v = la.values  # host materialisation goes through atl_nc_read_host
+    assert v.dtype == np.float64 and 268 <= v.min() and v.max() <= 298
+    assert np.array_equal(la.data[5:9], v[5:9])
+    assert ds.attrs["module"] == "era5"
+    from atlite_amd import Cutout
+
+    c = Cutout(f"{NC}/cutout_small_f32.nc")
+    assert c.shape == (9, 12) and abs(c.dx - 0.25) < 1e-12
+    with pytest.raises(NotImplementedError):
+        Cutout("/nonexistent/dir/new-cutout.nc")
+
+
+@pytest.mark.skipif(not _have_h5py(), reason="needs the conda interpreter with h5py to write random files")
+@pytest.mark.parametrize("seed", range(6))
+def test_random_files(tmp_path, seed):
+    rng = np.random.default_rng(100 + seed)
+    T, Y, X = (int(v) for v in rng.integers(1, 30, size=3))
+    ct, cy, cx = (int(rng.integers(1, d + 3)) for d in (T, Y, X))
+    ct, cy, cx = min(ct, T), min(cy, Y), min(cx, X)
+    libver = ["v108", "earliest", "latest"][seed % 3]
+    path = tmp_path / "case.nc"
+    r = subprocess.run([CONDA, MAKE, "--case", str(path), str(T), str(Y), str(X), str(ct), str(cy), str(cx), libver,
+                        str(seed % 2), str(seed)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    f = io.NcFile(path)
+    exp = np.load(tmp_path / "case.npz")
+    for v in exp.files:
+        assert np.array_equal(f.read(v), exp[v], equal_nan=True), (v, T, Y, X, ct, cy, cx, libver)
+
+
+def test_c_struct_layout_matches_ctypes():
+    """atl_nc_var in the header and _lib.NcVar agree (size checked against the C compiler)."""
+    import tempfile
+
+    root = os.path.dirname(os.path.dirname(__file__))
+    src = '#include <stdio.h>\n#include "atlite_hip.h"\nint main(void){printf("%zu %zu %zu", sizeof(atl_nc_var),' \
+          ' __builtin_offsetof(atl_nc_var, scale_factor), __builtin_offsetof(atl_nc_var, n_chunks));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(f"{d}/t.c", "w").write(src)
+        subprocess.run(["gcc", "-std=c99", f"-I{root}/include", f"{d}/t.c", "-o", f"{d}/t"], check=True)
+        size, off_scale, off_n = (int(v) for v in subprocess.run([f"{d}/t"], capture_output=True, text=True).stdout.split())
+    assert size == C.sizeof(_lib.NcVar)
+    assert off_scale == _lib.NcVar.scale_factor.offset and off_n == _lib.NcVar.n_chunks.offset
