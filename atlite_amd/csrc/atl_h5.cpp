@@ -45,6 +45,7 @@ constexpr int kMaxDepth = 64;
 
 File::~File() {
     if (map_) munmap(const_cast<uint8_t *>(map_), size_);
+    if (fd_ >= 0) ::close(fd_);
 }
 
 const uint8_t *File::at(uint64_t off, uint64_t n) const {
@@ -76,13 +77,14 @@ int File::open(const char *path) {
     }
     size_ = uint64_t(st.st_size);
     void *m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd, 0);
-    ::close(fd);
     if (m == MAP_FAILED) {
+        ::close(fd);
         set_error("atl_nc_open: mmap of '%s' failed: %s", path, strerror(errno));
         map_ = nullptr;
         return ATL_E_NOMEM;
     }
     map_ = static_cast<const uint8_t *>(m);
+    fd_ = fd;
     try {
         static const uint8_t sig[8] = {0x89, 'H', 'D', 'F', '\r', '\n', 0x1a, '\n'};
         uint64_t sb = ~0ull;
@@ -824,10 +826,25 @@ void File::resolve_dims() {
 }
 
 // ---- chunk payloads -------------------------------------------------------------------------------
-int chunk_inflate(const Dataset &d, const Chunk &c, const uint8_t *file_base, uint8_t *dst, uint64_t dst_n,
+int chunk_inflate(const Dataset &d, const Chunk &c, const uint8_t *file_base, int fd, uint8_t *dst, uint64_t dst_n,
                   bool *shuffled) {
     const uint8_t *src = file_base + c.addr;
     uint64_t n = c.size;
+    if (fd >= 0) {
+        static thread_local std::vector<uint8_t> buf;
+        if (buf.size() < n) buf.resize(size_t(n + n / 2));
+        uint64_t got = 0;
+        while (got < n) {
+            const ssize_t r = pread(fd, buf.data() + got, size_t(n - got), off_t(c.addr + got));
+            if (r <= 0) {
+                set_error("dataset '%s': read of %llu bytes at offset %llu failed", d.name.c_str(),
+                          (unsigned long long)n, (unsigned long long)c.addr);
+                return ATL_E_INVALID;
+            }
+            got += uint64_t(r);
+        }
+        src = buf.data();
+    }
     *shuffled = false;
     int i_shuffle = -1, i_deflate = -1;
     bool deflate = false;

@@ -84,6 +84,7 @@ class File {
     const Dataset *find(const std::string &name) const;
     const std::vector<Attribute> &global_attrs() const { return gattrs_; }
     const uint8_t *base() const { return map_; }
+    int fd() const { return fd_; }
     uint64_t size() const { return size_; }
     // vlen payload (global heap object) of one vlen element descriptor {len, addr, index}
     bool vlen_payload(const uint8_t *desc, const uint8_t **p, uint64_t *n, uint32_t *count) const;
@@ -97,6 +98,7 @@ class File {
         uint32_t size;
     };
     const uint8_t *map_ = nullptr;
+    int fd_ = -1;
     uint64_t size_ = 0;
     uint64_t base_ = 0;
     int O_ = 8, L_ = 8;
@@ -132,7 +134,9 @@ class File {
 // decode helpers shared by the host reader and the slab pipeline
 // apply the reverse filter pipeline except shuffle: returns inflated bytes in dst (dst_n = chunk
 // bytes); *shuffled tells the caller whether the payload is still byte-shuffled.
-int chunk_inflate(const Dataset &d, const Chunk &c, const uint8_t *file_base, uint8_t *dst, uint64_t dst_n,
+// The stored bytes come from pread(fd) into a per-thread buffer when fd >= 0 (many threads faulting
+// pages of one mapping in contend on the address-space lock), else straight from the mapping.
+int chunk_inflate(const Dataset &d, const Chunk &c, const uint8_t *file_base, int fd, uint8_t *dst, uint64_t dst_n,
                   bool *shuffled);
 
 }}  // namespace atl::h5

@@ -13,6 +13,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -296,14 +300,105 @@ int submit(atl_ctx *ctx, Slot *sl, size_t payload, const std::vector<UnpackDesc>
     return ATL_OK;
 }
 
+// CPUs this process may actually use: the cgroup CPU quota (containers routinely expose all host
+// threads but grant a fraction of them), else the hardware thread count
+int usable_cpus() {
+    static const int cached = [] {
+        int hw = int(std::max(1u, std::thread::hardware_concurrency()));
+        long long quota = -1, period = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+            char q[32] = {0};
+            if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else {
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+                if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+                fclose(g);
+            }
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (fscanf(g, "%lld", &period) != 1) period = 0;
+                fclose(g);
+            }
+        }
+        if (quota > 0 && period > 0) hw = int(std::min<long long>(hw, (quota + period - 1) / period));
+        return std::max(1, hw);
+    }();
+    return cached;
+}
+
 int pick_threads(int requested, size_t n_items) {
     int n = requested;
     if (n <= 0) {
-        n = int(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u));
+        // a few more threads than CPUs smooths over stragglers; measured best on a 16-CPU quota: 32
+        n = std::min(2 * usable_cpus(), 128);
         if (const char *e = getenv("ATLITE_HIP_IO_THREADS")) n = std::max(1, atoi(e));
     }
     return int(std::max<size_t>(1, std::min<size_t>(size_t(n), n_items)));
 }
+
+// Persistent worker pool: a read call fans its chunks out to up to 128 threads several times per
+// slab, so the threads are created once per process and parked on a condition variable in between.
+class Pool {
+   public:
+    static Pool &get() {
+        static Pool p;
+        return p;
+    }
+    // run body() on the caller + up to (n_threads - 1) workers; returns when all have finished
+    void run(int n_threads, const std::function<void()> &body) {
+        std::lock_guard<std::mutex> serial(run_m_);
+        const int helpers = std::max(0, n_threads - 1);
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            while (int(workers_.size()) < helpers) workers_.emplace_back([this] { loop(); });
+            body_ = &body;
+            want_ = helpers;
+            started_ = finished_ = 0;
+            ++gen_;
+        }
+        cv_.notify_all();
+        body();
+        std::unique_lock<std::mutex> lk(m_);
+        want_ = started_;  // late wakers find nothing to do
+        done_.wait(lk, [this] { return finished_ == started_; });
+        body_ = nullptr;
+    }
+
+   private:
+    Pool() = default;
+    ~Pool() {
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    void loop() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+            if (stop_) return;
+            seen = gen_;
+            if (!body_ || started_ >= want_) continue;
+            ++started_;
+            const std::function<void()> *b = body_;
+            lk.unlock();
+            (*b)();
+            lk.lock();
+            ++finished_;
+            if (finished_ == started_) done_.notify_all();
+        }
+    }
+    std::mutex run_m_, m_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> workers_;
+    const std::function<void()> *body_ = nullptr;
+    int want_ = 0, started_ = 0, finished_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
 
 // run fn(i) for i in [0, n) on up to n_threads threads; first failure wins (message carried over,
 // since atl_last_error is thread-local)
@@ -313,7 +408,7 @@ int parallel_for(size_t n, int n_threads, F fn) {
     std::atomic<int> err{0};
     std::string msg;
     std::atomic<bool> have_msg{false};
-    auto body = [&] {
+    std::function<void()> body = [&] {
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= n || err.load()) return;
@@ -327,13 +422,10 @@ int parallel_for(size_t n, int n_threads, F fn) {
             }
         }
     };
-    if (n_threads <= 1) {
+    if (n_threads <= 1 || n <= 1) {
         body();
     } else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < n_threads - 1; ++t) th.emplace_back(body);
-        body();
-        for (auto &t : th) t.join();
+        Pool::get().run(n_threads, body);
     }
     if (err.load() && have_msg) set_error("%s", msg.c_str());
     return err.load();
@@ -563,7 +655,7 @@ int atl_nc_read_host(atl_nc *f, const char *name, int64_t start0, int64_t count0
         const bool missing = c.size == 0;
         if (!missing) {
             tmp.resize(size_t(chunk_bytes));
-            const int e = h5::chunk_inflate(*d, c, f->file.base(), tmp.data(), uint64_t(chunk_bytes), &shuffled);
+            const int e = h5::chunk_inflate(*d, c, f->file.base(), -1, tmp.data(), uint64_t(chunk_bytes), &shuffled);
             if (e) return e;
         }
         const double fillv = dc.has_fill ? cf_decode(dc.fill, dc) : __builtin_nan("");
@@ -658,7 +750,7 @@ int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, 
                 return ATL_OK;
             }
             bool shuffled = false;
-            const int e = h5::chunk_inflate(*d, c, f->file.base(), sl->h + ds.src_off, uint64_t(chunk_bytes), &shuffled);
+            const int e = h5::chunk_inflate(*d, c, f->file.base(), f->file.fd(), sl->h + ds.src_off, uint64_t(chunk_bytes), &shuffled);
             ds.shuffled = shuffled;
             return e;
         });

@@ -109,7 +109,11 @@ def run(ctx, spec, ds, plan, time_agg):
     T = len(ds.coords["time"])
     S = len(ds.coords["y"]) * len(ds.coords["x"])
     host = {n: _source(_host_array(ds[n]), T, S) for n in spec.time_vars}
-    steps = int(os.environ.get("ATLITE_HIP_SLAB_STEPS", 0)) or max(8, min(T, (128 << 20) // max(S * 8, 1)) // 8 * 8)
+    # slab = 128 MiB of fp64 per variable (DMA sources), 512 MiB for file sources: one read call inflates
+    # a slab's chunks in parallel, so a bigger slab keeps more host threads busy
+    from_file = any(_is_file(a) for a in host.values())
+    slab_bytes = int(os.environ.get("ATLITE_HIP_SLAB_BYTES", (512 << 20) if from_file else (128 << 20)))
+    steps = int(os.environ.get("ATLITE_HIP_SLAB_STEPS", 0)) or max(8, min(T, slab_bytes // max(S * 8, 1)) // 8 * 8)
     # file sources: whole chunks per slab, so that no chunk is inflated twice
     tchunk = max([a.var.chunks[0] for a in host.values() if _is_file(a) and a.var.layout == "chunked"], default=0)
     if tchunk and not os.environ.get("ATLITE_HIP_SLAB_STEPS"):

@@ -58,6 +58,24 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cpus():
+    """CPUs this process may use: the cgroup CPU quota if one is set, else os.cpu_count()."""
+    n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, -(-q // p)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(inputs_host, M, n_threads):
     """Oracle (NumPy restatement of the reference's eager op sequence) over time chunks of 100 on a
     thread pool - mirrors chunks={'time': 100} + dask's threaded scheduler (atlite/cutout.py:143)."""
@@ -274,7 +292,7 @@ def main():
         except Exception:
             avail = 16 << 30
         by_mem = max(1, int(0.4 * avail / (25 * 100 * S * 8)))
-        cores = max(1, min(os.cpu_count() or 1, n_chunks, by_mem))
+        cores = max(1, min(usable_cpus(), n_chunks, by_mem))
         cdt = min(cpu_baseline(host, M, cores)[0] for _ in range(2))
         T1 = min(400, Tc)
         cdt1 = cpu_baseline({k: v[:T1] for k, v in host.items()}, M, 1)[0]
@@ -284,7 +302,8 @@ def main():
             "cores": cores,
             "kind": "port",
             "sample": f"{Tc} of {T_loc} time steps (t={t_a}..{t_a + Tc}) of the same cutout and shapes; NumPy "
-                      f"oracle over time chunks of 100 on a {cores}-thread pool ({cdt:.2f} s)",
+                      f"oracle over time chunks of 100 on a {cores}-thread pool ({cdt:.2f} s; the box exposes "
+                      f"{os.cpu_count()} hardware threads, its cgroup grants {usable_cpus()} CPUs)",
             "single_thread_value": T1 * S / cdt1,
             "single_thread_sample": f"{T1} time steps, 1 thread ({cdt1:.2f} s)",
         }

@@ -351,7 +351,7 @@ int atl_nc_read_host(atl_nc *f, const char *name, int64_t start0, int64_t count0
 /* same rows as an fp64 (count0, prod(shape[1:])) block at d_out, asynchronously: returns after the
  * host inflate; the copy + device decode are enqueued on the copy stream (order against the
  * compute stream with atl_event_record(ev, 1) / atl_stream_wait_event(ctx, 0, ev)).
- * n_threads <= 0: min(hardware threads, 32, $ATLITE_HIP_IO_THREADS). */
+ * n_threads <= 0: $ATLITE_HIP_IO_THREADS, else min(2 x usable CPUs (cgroup quota aware), 128). */
 int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, int64_t count0,
                      double *d_out, int n_threads);
 /* host array of a narrower dtype (what xarray hands over for a float32 cutout) -> fp64 on the
