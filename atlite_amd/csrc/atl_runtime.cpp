@@ -361,15 +361,23 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_le
         int w2_log2;  // lanes per tile row
     };
     // Tile columns are sheared per grid row by shift(y) = (y*X) mod 16 cells so that every
-    // tile row starts on a 128-byte line of the stacked (time, cell) cube (when S % 16 == 0).
+    // tile row starts on a 128-byte line of the stacked (time, cell) cube (when S % 16 == 0); a line
+    // straddling two grid rows is owned by the lower row's first tile column (see tile_of).
     auto ntx_of = [](const Layout &L) {
         const int w = 2 << L.w2_log2;
         const int64_t max_shift = (L.Y > 1 && L.X % 16 != 0) ? 15 : 0;
         return (L.X - 1 + max_shift) / w + 1;
     };
     auto tile_of = [&ntx_of](const Layout &L, int64_t cell, int32_t *local) {
-        const int64_t y = cell / L.X, x = cell % L.X;
+        int64_t y = cell / L.X, x = cell % L.X;
         const int w = 2 << L.w2_log2, h = kLanes >> L.w2_log2;
+        // the 128-byte line holding cell (y+1, 0) belongs wholly to row y+1's first tile column:
+        // the tail cells of row y that share it are addressed from there with negative x
+        const int64_t shn = ((y + 1) * L.X) & 15;
+        if (y + 1 < L.Y && x >= L.X - shn) {
+            x -= L.X;
+            ++y;
+        }
         const int64_t xs = x + ((y * L.X) & 15);
         const int64_t tx = xs / w, ty = y / h;
         const int lane = int((y % h) << L.w2_log2) + int((xs % w) >> 1);
