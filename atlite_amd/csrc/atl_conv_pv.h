@@ -236,9 +236,9 @@ struct pv_is_sp<PvConvT<true, PC, SK>> : std::true_type {};
 // ---------------------------------------------------------------------------------------
 // general pv converter: every option of convert_pv / convert_irradiation / convert_solar_thermal
 // (tracking modes, Hay-Davies, Reindl split, albedo from outflux, bofinger, irradiation
-// quantities).  A literal transcription of the reference, operation by operation (lean sin/cos/log
-// of atl_math.h, libm for atan/asin/acos/sqrt) - selected only when an option differs from the
-// defaults the fast PvConvT path covers.
+// quantities).  A transcription of the reference, operation by operation (lean sin/cos/log of
+// atl_math.h), except for the rotating trackers' geometry, which is evaluated in closed form
+// (panel_geom) - selected only when an option differs from the defaults the fast PvConvT path covers.
 // ---------------------------------------------------------------------------------------
 struct PvxOpt {
     int tracking, trigon, clearsky, irradiation, panel, has_influx, has_albedo;
@@ -247,43 +247,111 @@ struct PvxOpt {
     double r_irr;  // Huld division kept literal here
 };
 
-__device__ double pvx_cell(double dir, double dif, double infl, double toa, double albv, double outf, double tmp,
-                           double rh, double alt, double az, double slope, double sazim, const PvConst &k,
-                           const PvxOpt &o) {
+// ---- SurfaceOrientation for the general kernel (orientation.py:113-188) -----------------------------
+// What the irradiation model needs of the panel geometry: cos(incidence) (before the clip at 0),
+// cos(surface slope) and - Hay-Davies only - sin(surface slope / 2).
+struct PanelGeom {
+    double cosinc, cs, sh;
+};
+
+// The reference's formulas as written (atan / asin / acos through libm).  Out of line: it only runs
+// for the degenerate arguments the closed forms below exclude.
+__device__ __noinline__ PanelGeom panel_geom_literal(int tracking, double sa, double ca, double az, double slope,
+                                                     double sazim) {
     const double pi = 3.14159265358979323846;
-    const double nan = __builtin_nan("");
-    double sa, ca;
-    lean_sincos(alt, &sa, &ca);
-    // ---- SurfaceOrientation (orientation.py:113-188) ---------------------------------------
-    double surface_slope = slope, cosinc;
-    if (o.tracking == ATL_TRACK_NONE) {
-        cosinc = lean_sin(slope) * ca * lean_cos(sazim - az) + lean_cos(slope) * sa;
-    } else if (o.tracking == ATL_TRACK_HORIZONTAL) {
-        const double rotation = atan((ca / sa) * lean_sin(az - sazim));
+    double surface_slope, cosinc;
+    if (tracking == ATL_TRACK_HORIZONTAL) {
+        const double rotation = atan((ca / sa) * sin(az - sazim));
         surface_slope = fabs(rotation);
-        const double surface_azimuth = sazim + asin(lean_sin(rotation) / lean_sin(surface_slope));
-        cosinc = lean_cos(surface_slope) * sa + lean_sin(surface_slope) * ca * lean_cos(az - surface_azimuth);
-    } else if (o.tracking == ATL_TRACK_TILTED_HORIZONTAL) {
+        const double surface_azimuth = sazim + asin(sin(rotation) / sin(surface_slope));
+        cosinc = cos(surface_slope) * sa + sin(surface_slope) * ca * cos(az - surface_azimuth);
+    } else {  // tilted_horizontal
         const double tilt = slope;
-        double rotation = atan((ca * lean_sin(az - sazim)) / (ca * lean_cos(az - sazim) * lean_sin(tilt) + sa * lean_cos(tilt)));
-        surface_slope = acos(lean_cos(rotation) * lean_cos(tilt));
+        double rotation = atan((ca * sin(az - sazim)) / (ca * cos(az - sazim) * sin(tilt) + sa * cos(tilt)));
+        surface_slope = acos(cos(rotation) * cos(tilt));
         double ad = az - sazim;
         ad = ad > pi ? ad - 2 * pi : ad;
         ad = ad < -pi ? 2 * pi + ad : ad;
         rotation = (rotation < 0 && ad > 0) ? rotation + pi : rotation;
         rotation = (rotation > 0 && ad < 0) ? rotation - pi : rotation;
-        cosinc = lean_cos(rotation) * (lean_sin(tilt) * ca * lean_cos(az - sazim) + lean_cos(tilt) * sa) + lean_sin(rotation) * ca * lean_sin(az - sazim);
-    } else if (o.tracking == ATL_TRACK_VERTICAL) {
-        cosinc = lean_sin(slope) * ca + lean_cos(slope) * sa;
-    } else {
-        cosinc = 1.0;
+        cosinc = cos(rotation) * (sin(tilt) * ca * cos(az - sazim) + cos(tilt) * sa) + sin(rotation) * ca * sin(az - sazim);
     }
-    cosinc = np_max(cosinc, 0.0);
+    return PanelGeom{cosinc, cos(surface_slope), sin(surface_slope / 2.0)};
+}
+
+// The rotating trackers without inverse trigonometry.  With q = tan(rotation):
+//   cos(atan q) = 1 / sqrt(1 + q^2),  sin(atan q) = q / sqrt(1 + q^2)
+// horizontal:        slope' = |rotation|;  asin(sin r / sin|r|) = asin(+-1) = +-pi/2, so
+//                    cos(az - azimuth') = sgn(q) sin(az - azimuth)  and
+//                    cosinc = (sa + q ca sin d) / sqrt(1 + q^2);  q = 0 gives 0/0 = NaN in the reference
+// tilted_horizontal: cos(slope') = cos(r) cos(tilt) (the acos is only ever fed back into cos / sin(./2));
+//                    the +-pi correction of the rotation flips the sign of both cos(r) and sin(r)
+// The results agree with the literal sequence to a few ulp (tests: reference-generated vectors at
+// rtol 1e-10); arguments for which the closed forms are not valid (q zero / non-finite) take the
+// literal routine.
+template <int TRACK, bool NEED_SH>
+__device__ __forceinline__ PanelGeom panel_geom(double sa, double ca, double az, double slope, double sazim) {
+    const double pi = 3.14159265358979323846;
+    PanelGeom g;
+    g.sh = 0.0;
+    if constexpr (TRACK == ATL_TRACK_NONE) {
+        g.cs = lean_cos(slope);
+        g.cosinc = lean_sin(slope) * ca * lean_cos(sazim - az) + g.cs * sa;
+        if constexpr (NEED_SH) g.sh = lean_sin(slope / 2.0);
+    } else if constexpr (TRACK == ATL_TRACK_VERTICAL) {
+        g.cs = lean_cos(slope);
+        g.cosinc = lean_sin(slope) * ca + g.cs * sa;
+        if constexpr (NEED_SH) g.sh = lean_sin(slope / 2.0);
+    } else if constexpr (TRACK == ATL_TRACK_DUAL) {
+        g.cs = lean_cos(slope);  // the slope stays the panel's; the simple model substitutes sin(alt) itself
+        g.cosinc = 1.0;
+        if constexpr (NEED_SH) g.sh = lean_sin(slope / 2.0);
+    } else if constexpr (TRACK == ATL_TRACK_HORIZONTAL) {
+        const double sd = lean_sin(az - sazim);
+        const double q = guarded_div(ca, sa) * sd;
+        const bool ok = q != 0.0 && __builtin_fabs(q) < 0x1.0p500;  // false for NaN / inf too
+        const double w = __builtin_sqrt(__builtin_fma(q, q, 1.0));
+        const double cr = fast_rcp(w);  // w in [1, 2^500] whenever ok
+        g.cs = cr;
+        g.cosinc = cr * (sa + q * ca * sd);
+        if constexpr (NEED_SH) g.sh = __builtin_fabs(q) * fast_rcp(__builtin_sqrt(2.0 * w * (w + 1.0)));
+        if (__builtin_expect(!ok, 0)) g = panel_geom_literal(TRACK, sa, ca, az, slope, sazim);
+    } else {  // ATL_TRACK_TILTED_HORIZONTAL
+        double sd, cd;
+        lean_sincos(az - sazim, &sd, &cd);
+        const double st = lean_sin(slope), ct = lean_cos(slope);
+        const double num = ca * sd;
+        const double den = ca * cd * st + sa * ct;
+        const double q = guarded_div(num, den);
+        const bool ok = den != 0.0 && __builtin_fabs(q) < 0x1.0p500;
+        const double cr = fast_rcp(__builtin_sqrt(__builtin_fma(q, q, 1.0)));
+        g.cs = cr * ct;
+        double ad = az - sazim;
+        ad = ad > pi ? ad - 2 * pi : ad;
+        ad = ad < -pi ? 2 * pi + ad : ad;
+        const bool flip = (q < 0.0 && ad > 0.0) || (q > 0.0 && ad < 0.0);
+        const double c = cr * (den + q * num);
+        g.cosinc = flip ? -c : c;
+        if constexpr (NEED_SH) g.sh = __builtin_sqrt(0.5 * (1.0 - g.cs));
+        if (__builtin_expect(!ok, 0)) g = panel_geom_literal(TRACK, sa, ca, az, slope, sazim);
+    }
+    return g;
+}
+
+// TRACK / TRIGON are compile-time: they decide the instruction mix and the register footprint;
+// everything else is a wave-uniform run-time switch.
+template <int TRACK, int TRIGON>
+__device__ double pvx_cell(double dir, double dif, double infl, double toa, double albv, double outf, double tmp,
+                           double rh, double alt, double az, double slope, double sazim, const PvConst &k,
+                           const PvxOpt &o) {
+    const double nan = __builtin_nan("");
+    double sa, ca;
+    lean_sincos(alt, &sa, &ca);
     // ---- direct / diffuse horizontal (irradiation.py:202-208, 13-73) ------------------------
     double direct, diffuse;
     if (o.has_influx) {
         const double influx = np_clip(infl, 0.0, toa);
-        const double kk = influx / toa;
+        const double kk = guarded_div(influx, toa);
         double fraction;
         const double m1 = (kk > 0.0 && kk <= 0.3) ? 1.0 : 0.0, m2 = (kk > 0.3 && kk < 0.78) ? 1.0 : 0.0,
                      m3 = (kk >= 0.78) ? 1.0 : 0.0;
@@ -303,42 +371,49 @@ __device__ double pvx_cell(double dir, double dif, double infl, double toa, doub
         diffuse = np_clip(dif, 0.0, toa - direct);
     }
     const double influx = direct + diffuse;
+    // irradiation.py:251-252 sets the tilted irradiation to 0 here, and every panel model below maps
+    // G = 0 to an output of 0 (Huld: 0 * fillna(eff); bofinger: 0 * fillna(eta) resp. the threshold;
+    // solar thermal: 0 * eta; none: G) - so night / overcast cells leave before the geometry.  The
+    // cells that stay have sin(alt) >= sin(threshold) > 0 and influx_toa >= influx > 0.01.
+    if ((alt < k.alt_thr) || (influx <= 0.01)) return 0.0;
+    // ---- SurfaceOrientation ----------------------------------------------------------------------
+    const PanelGeom geom = panel_geom<TRACK, TRIGON == ATL_TRIGON_OTHER>(sa, ca, az, slope, sazim);
+    const double cosinc = np_max(geom.cosinc, 0.0);
     // ---- albedo (irradiation.py:128-139) ---------------------------------------------------------
     double alb = albv;
     if (!o.has_albedo) {
-        alb = fill0(outf / (influx != 0.0 ? influx : nan));
+        alb = fill0(guarded_div(outf, influx != 0.0 ? influx : nan));
         alb = np_min(alb, 1.0);
     }
     // ---- tilted irradiation ---------------------------------------------------------------------
     double direct_t, diffuse_t, ground_t, total_t;
-    if (o.trigon == ATL_TRIGON_SIMPLE) {
-        const double kk = cosinc / sa;
-        const double cs = (o.tracking != ATL_TRACK_DUAL) ? lean_cos(surface_slope) : sa;
+    if constexpr (TRIGON == ATL_TRIGON_SIMPLE) {
+        const double kk = guarded_div(cosinc, sa);
+        const double cs = (TRACK != ATL_TRACK_DUAL) ? geom.cs : sa;
         direct_t = kk * direct;
         diffuse_t = (1.0 + cs) / 2.0 * diffuse;
         ground_t = alb * influx * ((1.0 - cs) / 2.0);
         total_t = fill0(direct_t) + fill0(diffuse_t) + fill0(ground_t);
     } else {
-        const double f = fill0(sqrt(direct / influx));
-        const double A = direct / toa;
-        const double R_b = cosinc / sa;
-        const double sh = lean_sin(surface_slope / 2.0);
-        diffuse_t = ((1.0 - A) * ((1 + lean_cos(surface_slope)) / 2.0) * (1.0 + f * (sh * sh * sh)) + A * R_b) * diffuse;
+        const double f = fill0(sqrt(guarded_div(direct, influx)));
+        const double A = guarded_div(direct, toa);
+        const double R_b = guarded_div(cosinc, sa);
+        const double sh = geom.sh;
+        diffuse_t = ((1.0 - A) * ((1 + geom.cs) / 2.0) * (1.0 + f * (sh * sh * sh)) + A * R_b) * diffuse;
         diffuse_t = fill0(np_max(diffuse_t, 0.0));
         direct_t = R_b * direct;
-        ground_t = influx * alb * (1.0 - lean_cos(surface_slope)) / 2.0;
+        ground_t = influx * alb * (1.0 - geom.cs) / 2.0;
         total_t = direct_t + diffuse_t + ground_t;
     }
     double G = o.irradiation == ATL_IRR_TOTAL    ? total_t
                : o.irradiation == ATL_IRR_DIRECT ? direct_t
                : o.irradiation == ATL_IRR_DIFFUSE ? diffuse_t
                                                   : ground_t;
-    if ((alt < k.alt_thr) || (influx <= 0.01)) G = 0.0;  // :251-252
     // ---- panel ------------------------------------------------------------------------------------
     if (o.panel == ATL_PANEL_NONE) return G;
     if (o.panel == ATL_PANEL_HULD) {
         const double T_ = (k.c_amb * tmp + k.c_irr * G) - k.r_tmod;
-        const double G_ = G / o.r_irr;
+        const double G_ = guarded_div(G, o.r_irr);
         const double l = (G_ > 0.0) ? lean_log(G_) : nan;
         double eff = 1.0 + k.k1 * l + k.k2 * (l * l) + T_ * (k.k3 + k.k4 * l + k.k5 * (l * l)) + k.k6 * (T_ * T_);
         eff = fill0(eff);
@@ -360,8 +435,9 @@ __device__ double pvx_cell(double dir, double dif, double infl, double toa, doub
     return output > 0.0 ? output : 0.0;
 }
 
-struct PvxConv {
-    static constexpr int kMinWaves = 1;  // let the register allocator use the whole file
+template <int TRACK, int TRIGON>
+struct PvxConvT {
+    static constexpr int kMinWaves = 2;
     atl_pv_inputs in;
     int64_t S;
     PvConst k;
@@ -439,8 +515,8 @@ struct PvxConv {
     }
     __device__ __forceinline__ double2 compute(const Raw &q, bool v0, bool v1, const Cell &c, const double *) const {
         double2 r;
-        r.x = v0 ? pvx_cell(q.dir.x, q.dif.x, q.inf.x, q.toa.x, q.alb.x, q.ouf.x, q.tmp.x, q.hum.x, q.alt.x, q.az.x, c.sl0, c.az0, k, o) : 0.0;
-        r.y = v1 ? pvx_cell(q.dir.y, q.dif.y, q.inf.y, q.toa.y, q.alb.y, q.ouf.y, q.tmp.y, q.hum.y, q.alt.y, q.az.y, c.sl1, c.az1, k, o) : 0.0;
+        r.x = v0 ? pvx_cell<TRACK, TRIGON>(q.dir.x, q.dif.x, q.inf.x, q.toa.x, q.alb.x, q.ouf.x, q.tmp.x, q.hum.x, q.alt.x, q.az.x, c.sl0, c.az0, k, o) : 0.0;
+        r.y = v1 ? pvx_cell<TRACK, TRIGON>(q.dir.y, q.dif.y, q.inf.y, q.toa.y, q.alb.y, q.ouf.y, q.tmp.y, q.hum.y, q.alt.y, q.az.y, c.sl1, c.az1, k, o) : 0.0;
         return r;
     }
 };

@@ -690,12 +690,32 @@ int pv_dispatch(const atl_pv_inputs *in, const atl_pv_params *p, bool allow_skip
     return pc ? f(PvConvT<false, true>()) : f(PvConvT<false, false>());
 }
 
+// f(converter instance) with the PvxConvT instantiation for (tracking, trigon model)
+template <class F>
+int pvx_dispatch(const atl_pv_params *p, F &&f) {
+    const bool other = p->trigon_model == ATL_TRIGON_OTHER;
+    switch (p->tracking) {
+        case ATL_TRACK_HORIZONTAL:
+            return other ? f(PvxConvT<ATL_TRACK_HORIZONTAL, ATL_TRIGON_OTHER>()) : f(PvxConvT<ATL_TRACK_HORIZONTAL, ATL_TRIGON_SIMPLE>());
+        case ATL_TRACK_TILTED_HORIZONTAL:
+            return other ? f(PvxConvT<ATL_TRACK_TILTED_HORIZONTAL, ATL_TRIGON_OTHER>())
+                         : f(PvxConvT<ATL_TRACK_TILTED_HORIZONTAL, ATL_TRIGON_SIMPLE>());
+        case ATL_TRACK_VERTICAL:
+            return other ? f(PvxConvT<ATL_TRACK_VERTICAL, ATL_TRIGON_OTHER>()) : f(PvxConvT<ATL_TRACK_VERTICAL, ATL_TRIGON_SIMPLE>());
+        case ATL_TRACK_DUAL:
+            return other ? f(PvxConvT<ATL_TRACK_DUAL, ATL_TRIGON_OTHER>()) : f(PvxConvT<ATL_TRACK_DUAL, ATL_TRIGON_SIMPLE>());
+        default:  // ATL_TRACK_NONE; out-of-range codes are rejected by make_pvx
+            return other ? f(PvxConvT<ATL_TRACK_NONE, ATL_TRIGON_OTHER>()) : f(PvxConvT<ATL_TRACK_NONE, ATL_TRIGON_SIMPLE>());
+    }
+}
+
 bool pv_needs_general(const atl_pv_inputs *in, const atl_pv_params *p) {
     return p->tracking != ATL_TRACK_NONE || p->trigon_model != ATL_TRIGON_SIMPLE || p->irradiation != ATL_IRR_TOTAL ||
            p->panel_model != ATL_PANEL_HULD || in->d_influx != nullptr || in->d_albedo == nullptr;
 }
 
-int make_pvx(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S, PvxConv *c, bool *vec) {
+template <class PVX>
+int make_pvx(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S, PVX *c, bool *vec) {
     ATL_REQUIRE(in && p, "atl_pv: inputs/params is NULL");
     ATL_REQUIRE(T >= 0 && S >= 0, "atl_pv: negative shape");
     ATL_REQUIRE(p->tracking >= ATL_TRACK_NONE && p->tracking <= ATL_TRACK_DUAL, "atl_pv: bad tracking code %d",
@@ -871,10 +891,11 @@ int atl_pv_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p
     ATL_REQUIRE(ctx && in && p, "atl_pv_convert: ctx/inputs/params is NULL");
     bool vec;
     if (pv_needs_general(in, p)) {
-        PvxConv c;
-        int rc = make_pvx(in, p, T, S, &c, &vec);
-        if (rc) return rc;
-        return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
+        return pvx_dispatch(p, [&](auto c) {
+            int rc = make_pvx(in, p, T, S, &c, &vec);
+            if (rc) return rc;
+            return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
+        });
     }
     return pv_dispatch(in, p, false, [&](auto c) {  // night skip: fused (aggregating) kernel only
         int rc = make_pv(in, p, T, S, &c, &vec);
@@ -888,10 +909,11 @@ int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv
     ATL_REQUIRE(ctx && in && p, "atl_pv_convert_aggregate: ctx/inputs/params is NULL");
     bool vec;
     if (pv_needs_general(in, p)) {
-        PvxConv c;
-        int rc = make_pvx(in, p, T, S, &c, &vec);
-        if (rc) return rc;
-        return run_fused(ctx, c, vec, 0, T, S, agg, time_agg, d_out, ld_out, "atl_pv_convert_aggregate");
+        return pvx_dispatch(p, [&](auto c) {
+            int rc = make_pvx(in, p, T, S, &c, &vec);
+            if (rc) return rc;
+            return run_fused(ctx, c, vec, 0, T, S, agg, time_agg, d_out, ld_out, "atl_pv_convert_aggregate");
+        });
     }
     return pv_dispatch(in, p, true, [&](auto c) {
         int rc = make_pv(in, p, T, S, &c, &vec);

@@ -32,6 +32,17 @@ __device__ __forceinline__ double fast_div(double a, double b) {
     return __builtin_fma(r, y, q);
 }
 
+// a / b through the reciprocal path when both operands sit comfortably inside the normal range,
+// IEEE division (zeros, infinities, NaN, denormals) otherwise: <= 1 ulp from the IEEE quotient,
+// identical special-case behaviour.  The slow branch is out of the common path of a wave.
+__device__ __forceinline__ double guarded_div(double a, double b) {
+    const double ab = __builtin_fabs(b);
+    const bool ok = ab > 0x1.0p-400 && ab < 0x1.0p400 && __builtin_fabs(a) < 0x1.0p400;
+    double r = fast_div(ok ? a : 0.0, ok ? b : 1.0);
+    if (__builtin_expect(!ok, 0)) r = a / b;
+    return r;
+}
+
 // reduce x to r in [-pi/4, pi/4] (+ tiny slack), quadrant in *q
 __device__ __forceinline__ double reduce_pio2(double x, int *q) {
     const double k = __builtin_rint(x * 6.36619772367581382433e-01);  // 2/pi

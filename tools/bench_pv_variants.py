@@ -49,6 +49,10 @@ for name, nbytes, fn in (
     ("getter, per-cell orientation (latitude_optimal)", 56, lambda: ctx.pv(inputs, percell, T, S, plan=plan, options=dict(night_skip=False))),
     ("in-kernel solar position (5 cubes + tables)", 40, lambda: ctx.pv(five, scal, T, S, plan=plan, solar_tables=tables)),
     ("general kernel: tracking='horizontal'", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="horizontal"))),
+    ("general kernel: tracking='tilted_horizontal'", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="tilted_horizontal"))),
+    ("general kernel: tracking='vertical'", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="vertical"))),
+    ("general kernel: tracking='dual'", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="dual"))),
+    ("general kernel: irradiation (no panel model)", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none"))),
     ("general kernel: trigon_model='other'", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(trigon_model="other"))),
     ("per-cell series out (no matrix)", 64, lambda: ctx.pv(inputs, scal, T, S)),
 ):
