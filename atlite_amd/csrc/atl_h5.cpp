@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "atl_internal.h"
@@ -880,7 +881,12 @@ int chunk_inflate(const Dataset &d, const Chunk &c, const uint8_t *file_base, in
         return ATL_E_UNSUPPORTED;
     }
     if (deflate) {
-        uLongf out_n = uLongf(dst_n);
+        static const bool use_fast = [] {
+            const char *e = getenv("ATLITE_HIP_INFLATE");
+            return !(e && strcmp(e, "zlib") == 0);
+        }();
+        if (use_fast && fast_inflate_zlib(src, n, dst, dst_n) == 0) return ATL_OK;
+        uLongf out_n = uLongf(dst_n);  // zlib decides everything the fast decoder did not accept
         const int rc = uncompress(dst, &out_n, src, uLong(n));
         if (rc != Z_OK || out_n != dst_n) {
             set_error("dataset '%s': corrupt deflate stream (zlib rc %d, %llu of %llu bytes)", d.name.c_str(), rc,

@@ -139,4 +139,9 @@ class File {
 int chunk_inflate(const Dataset &d, const Chunk &c, const uint8_t *file_base, int fd, uint8_t *dst, uint64_t dst_n,
                   bool *shuffled);
 
+// zlib-wrapped DEFLATE stream -> exactly dst_n bytes (atl_inflate.cpp).  0 = done and Adler-32
+// verified; non-zero = not handled (malformed, truncated, checksum or size mismatch): the caller must
+// let zlib's own inflate decide.
+int fast_inflate_zlib(const uint8_t *src, uint64_t src_n, uint8_t *dst, uint64_t dst_n);
+
 }}  // namespace atl::h5

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -22,6 +23,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <zlib.h>
 
 #include "atl_h5.h"
 #include "atl_internal.h"
@@ -757,6 +760,33 @@ int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, 
         if (rc) return rc;
     }
     return submit(ctx, sl, payload, sel.desc, p, max_elems, d_out);
+}
+
+int atl_inflate_probe(const void *h_src, size_t src_n, void *h_dst, size_t dst_n, int which, int64_t *ns) {
+    ATL_REQUIRE(h_src && (h_dst || dst_n == 0) && which >= 0 && which <= 2, "atl_inflate_probe: bad argument");
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = ATL_OK;
+    const uint8_t *src = static_cast<const uint8_t *>(h_src);
+    uint8_t *dst = static_cast<uint8_t *>(h_dst);
+    bool done = false;
+    if (which != 1) {
+        done = h5::fast_inflate_zlib(src, src_n, dst, dst_n) == 0;
+        if (!done && which == 0) {
+            set_error("atl_inflate_probe: the fast decoder declined the stream");
+            rc = ATL_E_UNSUPPORTED;
+        }
+    }
+    if (!done && which != 0) {
+        uLongf out_n = uLongf(dst_n);
+        const int z = uncompress(dst, &out_n, src, uLong(src_n));
+        if (z != Z_OK || out_n != dst_n) {
+            set_error("atl_inflate_probe: zlib rc %d, %llu of %llu bytes", z, (unsigned long long)out_n,
+                      (unsigned long long)dst_n);
+            rc = ATL_E_INVALID;
+        }
+    }
+    if (ns) *ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
 }
 
 int atl_upload_convert_async(atl_ctx *ctx, double *d_dst, const void *h_src, int dtype, int64_t n) {

@@ -384,6 +384,10 @@ int atl_allreduce_sum(atl_comm *comm, double *d_buf, int64_t n);
  * fn 0 sin, 1 cos, 2 log: d_in (n) -> d_out (n);  3 sincos: d_out (2n) = sin | cos;
  * 4 fast_div: d_in (2n) = a | b -> d_out (n) = a / b;  5 table-driven log (positive normal x).
  */
+/* zlib-wrapped DEFLATE stream -> exactly dst_n bytes on the host.  which = 0: the library's fast
+ * decoder alone (ATL_E_UNSUPPORTED if it declines the stream), 1: zlib alone, 2: the product
+ * combination (fast, zlib on any doubt).  *ns = wall time of the decode.  Host only. */
+int atl_inflate_probe(const void *h_src, size_t src_n, void *h_dst, size_t dst_n, int which, int64_t *ns);
 int atl_math_probe(atl_ctx *ctx, int fn, const double *d_in, int64_t n, double *d_out);
 
 /* ---- synthetic ERA5-shaped inputs (bench/test tooling) ----------
