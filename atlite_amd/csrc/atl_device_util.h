@@ -23,6 +23,7 @@ __device__ __forceinline__ double np_clip(double x, double lo, double hi) {
 template <bool VEC>
 __device__ __forceinline__ double2 ld2(const double *__restrict__ p, int64_t base, int64_t c0, int64_t c1) {
     double2 r;
+#ifdef ATL_FLAT_LOADS  // experiment: generic-pointer loads (flat_load_*: count against LDS waits too)
     if constexpr (VEC) {
         typedef double f64x2 __attribute__((ext_vector_type(2)));
         const f64x2 t = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(p + base + c0));
@@ -32,6 +33,22 @@ __device__ __forceinline__ double2 ld2(const double *__restrict__ p, int64_t bas
         r.x = __builtin_nontemporal_load(p + base + c0);
         r.y = __builtin_nontemporal_load(p + base + c1);
     }
+#else
+    // The cubes live in device memory: tell the compiler (pointers inside the by-value converter
+    // structs are generic to it), so it emits global_load_* instead of flat_load_* - flat loads also
+    // tick the LDS counter, which makes every LDS table read of the wind kernel wait for them.
+    typedef __attribute__((address_space(1))) const double gdouble;
+    if constexpr (VEC) {
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(1))) const f64x2 gf64x2;
+        const f64x2 t = __builtin_nontemporal_load((gf64x2 *)(p + base + c0));
+        r.x = t.x;
+        r.y = t.y;
+    } else {
+        r.x = __builtin_nontemporal_load((gdouble *)(p + base + c0));
+        r.y = __builtin_nontemporal_load((gdouble *)(p + base + c1));
+    }
+#endif
     return r;
 }
 
