@@ -9,6 +9,9 @@ result is reassembled with ONE collective over RCCL/xGMI:
 * ``aggregate_time=None``  -> all-gather of the (N x T_r) blocks      (``gather_time``)
 * ``"sum"`` / ``"mean"``   -> all-reduce of per-rank (sum, count)      (``reduce_time``)
 
+A rank takes its shard of any dataset - host arrays, device arrays or a cutout FILE - without
+copying or reading the rest: ``ds.isel_time(*time_partition(T, world)[rank:rank + 2])``.
+
 ``torch.distributed`` is the transport ("nccl" = RCCL on ROCm; "gloo" in the CPU tests).
 Stream ordering: create the ``Context`` on a NON-default torch stream and make it current
 (``s = torch.cuda.Stream(); torch.cuda.set_stream(s); Context(dev, stream=s.cuda_stream)``), then

@@ -143,15 +143,21 @@ class NcFile:
 class FileArray:
     """
     A variable that lives in the file: shape / dtype of the DECODED array (fp64), rows read on
-    demand.  ``np.asarray(a)`` and ``a[t0:t1]`` read on the host; ``read_slab`` feeds the device.
+    demand.  ``np.asarray(a)`` and ``a[t0:t1]`` read on the host; ``read_slab`` feeds the device;
+    ``slab(t0, t1)`` is a lazy view of a row range (a rank's time shard, ``Dataset.isel_time``).
     """
 
     is_file_array = True
 
-    def __init__(self, file, name):
+    def __init__(self, file, name, row0=0, rows=None):
         self.file, self.name = file, name
         self.var = file.variables[name]
-        self.shape = self.var.shape
+        full = self.var.shape
+        self.row0 = int(row0)
+        rows = full[0] - self.row0 if rows is None else int(rows)
+        if not (0 <= self.row0 and 0 <= rows and self.row0 + rows <= full[0]):
+            raise IndexError(f"rows [{self.row0}, {self.row0 + rows}) outside {name!r} with {full[0]} rows")
+        self.shape = (rows,) + full[1:]
         self.dtype = np.dtype(np.float64)
         self.ndim = len(self.shape)
 
@@ -163,19 +169,25 @@ class FileArray:
     def nbytes(self):
         return self.size * 8
 
+    def slab(self, start, stop):
+        start, stop = int(start), int(stop)
+        if not 0 <= start <= stop <= self.shape[0]:
+            raise IndexError(f"slab [{start}, {stop}) outside {self.shape[0]} rows")
+        return FileArray(self.file, self.name, self.row0 + start, stop - start)
+
     def __array__(self, dtype=None, copy=None):
-        a = self.file.read(self.name)
+        a = self.file.read(self.name, self.row0, self.shape[0])
         return a if dtype is None else a.astype(dtype)
 
     def __getitem__(self, key):
         if isinstance(key, slice):
             start, stop, step = key.indices(self.shape[0])
             if step == 1:
-                return self.file.read(self.name, start, max(stop - start, 0))
+                return self.file.read(self.name, self.row0 + start, max(stop - start, 0))
         return np.asarray(self)[key]
 
     def read_slab(self, ctx, t0, t1, dptr):
-        self.file.read_slab(ctx, self.name, t0, t1 - t0, dptr)
+        self.file.read_slab(ctx, self.name, self.row0 + t0, t1 - t0, dptr)
 
     def to_device(self, ctx, block_bytes=256 << 20):
         """Whole variable as a DeviceArray (rows in blocks so that the pinned staging stays bounded)."""
@@ -191,7 +203,8 @@ class FileArray:
         return out
 
     def __repr__(self):
-        return f"<FileArray {self.name!r} {self.shape} in {self.file.path!r}>"
+        rows = f"rows {self.row0}:{self.row0 + self.shape[0]} of " if self.shape[0] != self.var.shape[0] else ""
+        return f"<FileArray {rows}{self.name!r} {self.shape} in {self.file.path!r}>"
 
 
 def open_cutout(path, chunked=True):

@@ -243,6 +243,34 @@ class Dataset:
     def indexes(self):
         return {k: pd.Index(v) for k, v in self.coords.items() if k in ("time", "y", "x")}
 
+    def isel_time(self, start, stop):
+        """
+        The dataset restricted to time steps ``[start, stop)`` without copying or reading anything:
+        host arrays and device arrays become views, file-backed variables lazy row ranges.  One
+        rank's shard in a multi-GPU run: ``ds.isel_time(*edges[rank:rank + 2])`` with the edges of
+        ``atlite_amd.distributed.time_partition``.
+        """
+        T = len(self.coords["time"])
+        start, stop = int(start), int(stop)
+        if not 0 <= start <= stop <= T:
+            raise IndexError(f"time range [{start}, {stop}) outside the dataset's {T} steps")
+        coords = dict(self.coords)
+        coords["time"] = self.coords["time"][start:stop]
+        out = Dataset({}, coords, self.attrs, chunked=self.chunked)
+        for k, la in self._vars.items():
+            if "time" not in la.dims:
+                out[k] = la
+                continue
+            d = la.data
+            if _is_device(d) or _is_lazy(d):
+                d = d.slab(start, stop)
+            else:
+                d = d[start:stop]
+            out[k] = LabeledArray(d, la.dims, attrs=la.attrs, name=la.name)
+        if hasattr(self, "file"):
+            out.file = self.file
+        return out
+
     def pin(self):
         """Page-lock the host arrays in place so that the slab pipeline (atlite_amd.streaming) DMAs
         them at PCIe rate without re-registering on every call.  Undone by ``unpin()`` / deletion."""

@@ -163,3 +163,22 @@ def test_file_array_to_device(ctx):
     assert np.array_equal(d.numpy(), np.asarray(fa))
     dev = ds.device(ctx, "temperature")  # Dataset.device() goes the same way and caches
     assert dev.shape == (48, 9 * 12) and ds.device(ctx, "temperature").ptr == dev.ptr
+
+
+def test_time_shards_of_a_file_cutout(monkeypatch):
+    """Two ranks' shards (Dataset.isel_time) processed one after the other == the whole run."""
+    from atlite_amd.distributed import time_partition
+
+    ds = io.open_cutout(f"{NC}/cutout_small_f32.nc")
+    Y, X = 9, 12
+    M = H.blob_matrix(3, Y, X, seed=4)
+    kw = dict(panel="CSi", orientation={"slope": 30.0, "azimuth": 180.0}, matrix=M, aggregate_time=None)
+    whole = Cutout(ds).pv(**kw).values
+    edges = time_partition(48, 2)
+    parts = [Cutout(ds.isel_time(edges[r], edges[r + 1])).pv(**kw).values for r in range(2)]
+    np.testing.assert_array_equal(np.concatenate(parts, axis=0), whole)
+    # heat demand: shard boundaries on calendar days
+    edges = time_partition(48, 2, align=24)
+    whole = Cutout(ds).heat_demand(matrix=M, aggregate_time=None).values
+    parts = [Cutout(ds.isel_time(edges[r], edges[r + 1])).heat_demand(matrix=M, aggregate_time=None).values for r in range(2)]
+    np.testing.assert_array_equal(np.concatenate(parts, axis=0), whole)

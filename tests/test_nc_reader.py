@@ -258,3 +258,26 @@ def test_fast_inflate_matches_zlib():
         if ok:
             assert out == z
         _inflate(b, len(d), 0)  # the fast decoder alone: any verdict, no crash
+
+
+def test_isel_time_is_lazy():
+    """A rank's time shard of a file-backed cutout: coordinates sliced, variables still on disk."""
+    ds = io.open_cutout(f"{NC}/cutout_small_f32.nc")
+    sub = ds.isel_time(10, 31)
+    assert sub.sizes == {"time": 21, "y": 9, "x": 12} and sub.coords["time"][0] == ds.coords["time"][10]
+    fa = sub["temperature"].data
+    assert fa.is_file_array and fa.shape == (21, 9, 12) and fa.row0 == 10
+    full = np.asarray(ds["temperature"].data)
+    assert np.array_equal(np.asarray(fa), full[10:31])
+    assert np.array_equal(fa[3:7], full[13:17])
+    assert np.array_equal(np.asarray(fa.slab(5, 9)), full[15:19])
+    assert sub["height"].data is ds["height"].data  # static fields are shared
+    with pytest.raises(IndexError):
+        ds.isel_time(40, 50)
+    # in-memory datasets: views, no copies
+    from atlite_amd import Dataset
+
+    a = np.arange(4 * 2 * 3, dtype=float).reshape(4, 2, 3)
+    m = Dataset({"runoff": a}, dict(time=pd.date_range("2013-01-01", periods=4, freq="h"), y=[0.0, 1.0], x=[0.0, 1.0, 2.0]))
+    v = m.isel_time(1, 3)["runoff"].data
+    assert v.shape == (2, 2, 3) and np.shares_memory(v, a)
