@@ -17,7 +17,11 @@
 // METHOD: ATL_WIND_NONE / LOG / POWER fixed at compile time for finite tables (the hot
 // instantiations carry no dead paths); METHOD = -1 is the generic converter: runtime method,
 // any table (interp_generic).
-template <int METHOD>
+// STEPS > 0: the table is padded to exactly 2^STEPS knots and the search is STEPS unrolled,
+// branch-free probes, so the searches of a group's 8 cells interleave and hide each other's LDS
+// latency; STEPS = 0 searches a table of run-time size in a loop (13 instructions and one exposed LDS
+// round trip per probe - measured 52 of the ~125 instructions per cell before the specialisation).
+template <int METHOD, int STEPS = 0>
 struct WindConvT {
     const double *wnd;
     const double *aux;
@@ -90,9 +94,17 @@ struct WindConvT {
         double xc = x > vmax ? vmax : x;
         xc = xc < vmin ? vmin : xc;  // NaN stays NaN
         int j = 0;
-        for (int step = n_pad >> 1; step > 0; step >>= 1) {
-            const int cand = j + step;
-            j = (V[cand] <= xc) ? cand : j;
+        if constexpr (STEPS > 0) {
+#pragma unroll
+            for (int s = STEPS - 1; s >= 0; --s) {
+                const int cand = j + (1 << s);
+                j = (V[cand] <= xc) ? cand : j;
+            }
+        } else {
+            for (int step = n_pad >> 1; step > 0; step >>= 1) {
+                const int cand = j + step;
+                j = (V[cand] <= xc) ? cand : j;
+            }
         }
         const double2 k0 = *reinterpret_cast<const double2 *>(K + 4 * j);
         const double sl = K[4 * j + 2];

@@ -782,8 +782,9 @@ int make_wind(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p,
     ATL_REQUIRE(p->n_knots >= 1 && p->n_knots <= kMaxKnots && p->h_V && p->h_POWn,
                 "atl_wind: power curve needs 1..%d knots", kMaxKnots);
     const int n = p->n_knots;
-    int n_pad = 2;
-    while (n_pad <= n) n_pad *= 2;  // power of two > n: V[n..n_pad) = +inf
+    // power of two > n: V[n..n_pad) = +inf; the sizes with an unrolled search are 16, 32 and 128
+    int n_pad = n < 16 ? 16 : n < 32 ? 32 : 128;
+    while (n_pad <= n) n_pad *= 2;
     std::vector<double> tbl(size_t(5 * n_pad), 0.0);
     bool finite = true;
     for (int i = 0; i < n_pad; ++i) tbl[i] = std::numeric_limits<double>::infinity();
@@ -840,9 +841,9 @@ int make_heat(const double *d_temperature, const atl_heat_params *p, int64_t T, 
     return ATL_OK;
 }
 
-template <int M>
-WindConvT<M> wind_as(const WindConvT<-1> &g) {
-    WindConvT<M> c;
+template <int M, int STEPS = 0>
+WindConvT<M, STEPS> wind_as(const WindConvT<-1> &g) {
+    WindConvT<M, STEPS> c;
     c.wnd = g.wnd;
     c.aux = g.aux;
     c.S = g.S;
@@ -865,7 +866,11 @@ int wind_dispatch(const WindConvT<-1> &g, bool finite, F &&f) {
                             std::isfinite(g.from_height);
     if (!finite || (g.method == ATL_WIND_LOG && !heights_ok)) return f(g);
     switch (g.method) {
-        case ATL_WIND_LOG: return f(wind_as<ATL_WIND_LOG>(g));
+        case ATL_WIND_LOG:  // the default method: unrolled knot search for the usual table sizes
+            if (g.n_pad == 16) return f(wind_as<ATL_WIND_LOG, 4>(g));
+            if (g.n_pad == 32) return f(wind_as<ATL_WIND_LOG, 5>(g));
+            if (g.n_pad == 128) return f(wind_as<ATL_WIND_LOG, 7>(g));
+            return f(wind_as<ATL_WIND_LOG>(g));
         case ATL_WIND_POWER: return f(wind_as<ATL_WIND_POWER>(g));
         default: return f(wind_as<ATL_WIND_NONE>(g));
     }
