@@ -134,7 +134,13 @@ struct WindConvT {
         }
         return r;
     }
-    static constexpr int kGroup = 4;
+#ifndef ATL_WIND_GROUP
+#define ATL_WIND_GROUP 4
+#endif
+    static constexpr int kGroup = ATL_WIND_GROUP;
+#ifdef ATL_WIND_WAVES
+    static constexpr int kMinWaves = ATL_WIND_WAVES;
+#endif
     struct Raw {
         double2 v, z;
     };
