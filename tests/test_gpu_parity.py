@@ -313,3 +313,22 @@ def test_pv_night_skip_is_bit_identical(ctx, Y, X):
     ref = orc.aggregate_matrix(orc.convert_pv(ds, H.CSI, dict(slope=np.radians(30.0), azimuth=np.radians(180.0))), M)
     got = ctx.pv(dev, PV_PARAMS, T, Y * X, plan=plan, options=dict(night_skip=True)).numpy()
     np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-12 * np.nanmax(np.abs(ref[np.isfinite(ref)])), equal_nan=True)
+
+
+@pytest.mark.parametrize("tile", ["16x8", "32x4", "64x2"])
+def test_every_cell_owned_exactly_once(ctx, monkeypatch, tile):
+    """A 128-byte line that straddles two grid rows belongs to ONE tile (the lower row's first tile
+    column reaches back into the upper row's tail): with a dense matrix every cell must be counted
+    exactly once, for every residue of X modulo 16 and for grids shorter than a tile."""
+    import scipy.sparse as sp
+
+    monkeypatch.setenv("ATLITE_HIP_TILE", tile)
+    rng = np.random.default_rng(5)
+    for Y, X in [(5, x) for x in range(17, 34)] + [(1, 37), (2, 7), (9, 3), (17, 15), (11, 200)]:
+        S, T = Y * X, 11
+        D = rng.standard_normal((T, S))
+        W = rng.random((3, S)) + 0.5  # every cell in every shape
+        W[1, :] = 1.0  # plain sum of all cells: a cell counted twice or never shows up at once
+        M = sp.csr_matrix(W)
+        out = ctx.spmm(ctx.plan(M, row_len=X, cache=False), ctx.upload(D)).numpy()
+        close(out, W @ D.T, atol_scale=1e-13)
