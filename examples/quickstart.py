@@ -62,3 +62,12 @@ print("runoff  ", ro.dims, ro.shape)
 
 irr = cutout.irradiation(orientation={"slope": 30.0, "azimuth": 180.0}, tracking="horizontal", aggregate_time="mean")
 print("irradiation (1-axis tracking) mean W/m2", float(irr.values.mean()))
+
+# the same calls straight from a prepared NetCDF-4 cutout file: parsed natively (no xarray / netCDF4 /
+# libhdf5), chunks inflated on host threads, un-shuffled and widened to fp64 on the GPU, slab by slab
+nc = Path(__file__).resolve().parent.parent / "tests" / "golden" / "nc" / "cutout_small_f32.nc"
+filecut = Cutout(nc)
+print(filecut.data)
+few = pd.Series(gis.random_tessellation(3, filecut.bounds[[0, 1, 2, 3]], seed=2), index=pd.Index(["a", "b", "c"], name="bus"))
+pv_f = filecut.pv(panel="CSi", orientation={"slope": 30.0, "azimuth": 180.0}, shapes=few, aggregate_time=None)
+print("pv(file)", pv_f.dims, pv_f.shape)
