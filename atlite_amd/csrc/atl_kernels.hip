@@ -509,6 +509,10 @@ int check_launch(const char *what) {
 int32_t pick_chunk_slots(const atl_ctx *ctx, int64_t n_slots, int64_t n_segs) {
     // aim for >= ~16 waves per CU worth of units, chunks a multiple of kBatch in [8, 64]
     int64_t chunk = 64;
+    if (const char *e = getenv("ATLITE_HIP_CHUNK")) {  // experiments: any multiple of kBatch
+        const int64_t v = atoll(e);
+        if (v >= kBatch && v % kBatch == 0) return int32_t(v);
+    }
     const int64_t want_units = int64_t(ctx->n_cu) * 64;
     while (chunk > kBatch && n_segs * ((n_slots + chunk - 1) / chunk) < want_units) chunk /= 2;
     return int32_t(chunk);
