@@ -259,3 +259,39 @@ def open_cutout(path, chunked=True):
             ds[n] = LabeledArray(f.read(n), ("y", "x"))
     ds.file = f
     return ds
+
+
+def describe(path):
+    """Human-readable summary of a NetCDF-4 / HDF5 file (``python -m atlite_amd.io <file>``)."""
+    f = NcFile(path)
+    lines = [f"{f.path}: {os.path.getsize(f.path) / 1e6:.1f} MB, {len(f.variables)} variables"]
+    for name, v in sorted(f.variables.items()):
+        dims = ", ".join(f"{d or '?'}={n}" for d, n in zip(v.dims or ("?",) * v.ndim, v.shape))
+        enc = []
+        if v.layout == "chunked":
+            enc.append("chunks " + "x".join(str(c) for c in v.chunks))
+        else:
+            enc.append(v.layout)
+        if v.shuffle:
+            enc.append("shuffle")
+        if v.deflate is not None:
+            enc.append(f"deflate {v.deflate}")
+        if v.fletcher32:
+            enc.append("fletcher32")
+        if v.scale_factor is not None:
+            enc.append(f"scale {v.scale_factor:g} offset {v.add_offset:g}")
+        if v.fill_value is not None:
+            enc.append(f"_FillValue {v.fill_value:g}")
+        raw = int(np.prod(v.shape, dtype=np.int64)) * (np.dtype(v.dtype).itemsize if v.dtype else 0)
+        ratio = f", {v.stored_bytes / raw:.2f} of raw" if raw and v.stored_bytes else ""
+        lines.append(f"  {name:24s} {v.dtype or 'non-numeric':8s}{'>' if v.big_endian else ' '} ({dims})  "
+                     f"[{'; '.join(enc)}]  {v.stored_bytes / 1e6:.2f} MB stored{ratio}")
+    f.close()
+    return "\n".join(lines)
+
+
+if __name__ == "__main__":
+    import sys
+
+    for p in sys.argv[1:]:
+        print(describe(p))
