@@ -281,3 +281,21 @@ def test_isel_time_is_lazy():
     m = Dataset({"runoff": a}, dict(time=pd.date_range("2013-01-01", periods=4, freq="h"), y=[0.0, 1.0], x=[0.0, 1.0, 2.0]))
     v = m.isel_time(1, 3)["runoff"].data
     assert v.shape == (2, 2, 3) and np.shares_memory(v, a)
+
+
+@pytest.mark.skipif(not _have_h5py(), reason="needs the conda interpreter with h5py to write the files")
+@pytest.mark.parametrize("args,n_chunks", [(("700", "6", "7", "1", "6", "7", "v108", "1", "5"), 700),
+                                           (("40", "30", "31", "1", "2", "3", "latest", "1", "6"), 6600)])
+def test_many_chunks(tmp_path, args, n_chunks):
+    """One time step per chunk (netCDF-C's default for an unlimited time axis): a multi-level v1 chunk
+    B-tree; libver=latest with thousands of chunks: a paged fixed-array index."""
+    path = tmp_path / "many.nc"
+    r = subprocess.run([CONDA, MAKE, "--case", str(path), *args], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    f = io.NcFile(path)
+    exp = np.load(tmp_path / "many.npz")
+    assert f.variables["temperature"].n_chunks == n_chunks
+    for v in exp.files:
+        assert np.array_equal(f.read(v), exp[v], equal_nan=True), v
+    t0 = int(args[0]) // 2
+    assert np.array_equal(f.read("runoff", t0, 3), exp["runoff"][t0:t0 + 3], equal_nan=True)
