@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""
+Randomised differential test of the gateway (GPU vs the NumPy oracle): converter family (wind with
+random turbines / methods / smoothing, heat and cooling demand with random thresholds and hour shifts,
+runoff, temperatures) x aggregation (none, random sparse matrix with explicit zeros / negative / NaN
+weights / empty rows, layout, matrix + layout) x per_unit x aggregate_time x grid shape x chunked or
+not x host / streamed execution, with NaN / inf / degenerate values in the inputs.
+
+    python tools/fuzz_gateway.py [n_cases] [seed]
+"""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from atlite_amd import Cutout, Dataset, LabeledArray  # noqa: E402
+from atlite_amd.resource import get_windturbineconfig, windturbine_smooth  # noqa: E402
+from oracle import atlite_oracle as orc  # noqa: E402
+from tests import helpers as H  # noqa: E402
+
+TURBINES = ["Vestas_V112_3MW", "Enercon_E101_3000kW", "NREL_ReferenceTurbine_5MW_offshore", "Vestas_V90_3MW",
+            "Siemens_SWT_2300kW", "NREL_ReferenceTurbine_2020ATB_15MW_offshore"]
+
+
+def random_matrix(rng, N, S):
+    dens = float(rng.choice([0.02, 0.2, 1.0]))
+    M = sp.random(N, S, density=dens, random_state=int(rng.integers(1 << 30)), format="csr")
+    M.data = M.data * rng.choice([1.0, 5.0])
+    if M.nnz and rng.random() < 0.5:  # explicit zeros and negative weights
+        k = rng.integers(0, M.nnz, size=max(1, M.nnz // 20))
+        M.data[k] = rng.choice([0.0, -1.5], size=len(k))
+    return M
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    worst, worst_case, fails = 0.0, "", 0
+    for case in range(n):
+        T, Y, X = int(rng.integers(1, 80)), int(rng.integers(1, 12)), int(rng.integers(1, 40))
+        S = Y * X
+        x, y = H.grid(Y, X) if X > 1 and Y > 1 else (np.arange(X) * 0.25, np.arange(Y) * 0.25 + 40)
+        start = str(rng.choice(["2013-01-01", "2013-03-30 07:00", "2012-12-31 23:00"]))
+        time = H.times(T, start)
+        fam = str(rng.choice(["wind", "heat", "cool", "runoff", "temperature", "soil"]))
+        chunked = bool(rng.random() < 0.5)
+        os.environ["ATLITE_HIP_STREAM"] = str(rng.choice(["0", "1"]))
+        os.environ["ATLITE_HIP_SLAB_STEPS"] = str(int(rng.choice([8, 16, 24, 40])))
+        dtype = np.float32 if (os.environ["ATLITE_HIP_STREAM"] == "1" and rng.random() < 0.3) else np.float64
+        ds, kw = {}, {}
+        if fam == "wind":
+            v = (12 * rng.random((T, Y, X)) ** 1.5).astype(dtype)
+            z0 = np.exp(np.log(1e-3) + rng.random((T, Y, X)) * np.log(2e3)).astype(dtype)
+            m = rng.random((T, Y, X)) < 0.02
+            v[m] = rng.choice([np.nan, 0.0, 25.0, 13.0, 1e3, np.inf, -1.0])
+            m = rng.random((T, Y, X)) < 0.02
+            z0[m] = rng.choice([0.0, -1.0, np.nan, 100.0, np.inf, 1e-320])
+            ds = dict(wnd100m=v, roughness=z0)
+            name = str(rng.choice(TURBINES))
+            tb = get_windturbineconfig(name)
+            smooth = bool(rng.random() < 0.25)
+            kw = dict(turbine=name, smooth=smooth)
+            if smooth:
+                tb = windturbine_smooth(tb, params=True)
+            with np.errstate(all="ignore"):
+                da = orc.convert_wind(v.astype(np.float64).reshape(T, S), z0.astype(np.float64).reshape(T, S), np.asarray(tb["V"], float),
+                                      np.asarray(tb["POW"], float), float(tb["P"]), float(tb["hub_height"]), 100.0, "logarithmic")
+            call, slots_time = "wind", time
+        elif fam in ("heat", "cool"):
+            tk = (283 + 12 * rng.standard_normal((T, Y, X))).astype(dtype)
+            tk[rng.random((T, Y, X)) < 0.03] = np.nan
+            ds = dict(temperature=tk)
+            shift = float(rng.choice([0.0, 1.0, -5.0, 3.5]))
+            kw = dict(threshold=float(rng.choice([15.0, 23.0, 10.5])), a=float(rng.choice([1.0, 2.5])),
+                      constant=float(rng.choice([0.0, 1.25])), hour_shift=shift)
+            ptr, labels = orc.day_groups(time, shift)
+            f = orc.convert_heat_demand if fam == "heat" else orc.convert_cooling_demand
+            da = f(tk.astype(np.float64).reshape(T, S), ptr, kw["threshold"], kw["a"], kw["constant"])
+            call, slots_time = ("heat_demand" if fam == "heat" else "cooling_demand"), labels
+        elif fam == "runoff":
+            r = rng.random((T, Y, X)).astype(dtype) * 1e-3
+            r[rng.random((T, Y, X)) < 0.02] = np.nan
+            h = (2000 * rng.random((Y, X))).astype(np.float64)
+            ds = dict(runoff=r, height=h)
+            wh = bool(rng.random() < 0.7)
+            kw = dict(weight_with_height=wh)
+            da = orc.convert_runoff(r.astype(np.float64).reshape(T, S), h.reshape(S) if wh else None)
+            call, slots_time = "runoff", time
+        else:
+            tk = (283 + 12 * rng.standard_normal((T, Y, X))).astype(dtype)
+            tk[rng.random((T, Y, X)) < 0.03] = np.nan
+            var = "temperature" if fam == "temperature" else "soil temperature"
+            ds = {var: tk}
+            da = (orc.convert_temperature if fam == "temperature" else orc.convert_soil_temperature)(
+                tk.astype(np.float64).reshape(T, S))
+            call, slots_time = ("temperature" if fam == "temperature" else "soil_temperature"), time
+        c = Cutout(Dataset(ds, dict(time=time, y=y, x=x), chunked=chunked))
+        agg = str(rng.choice(["none", "matrix", "layout", "both"]))
+        tagg = [None, "sum", "mean"][int(rng.integers(3))]
+        per_unit = bool(agg != "none" and rng.random() < 0.4)
+        N = int(rng.integers(1, 9))
+        M = random_matrix(rng, N, S) if agg in ("matrix", "both") else None
+        lay = rng.random((Y, X)) * 3 if agg in ("layout", "both") else None
+        if lay is not None and rng.random() < 0.3:
+            lay[rng.random((Y, X)) < 0.3] = 0.0
+        gkw = dict(kw)
+        if M is not None:
+            gkw["matrix"] = M
+        if lay is not None:
+            gkw["layout"] = LabeledArray(lay, ("y", "x"), {"y": y, "x": x})
+        if per_unit:
+            gkw["per_unit"] = True
+        try:
+            with np.errstate(all="ignore"):
+                got = getattr(c, call)(aggregate_time=tagg, **gkw)
+                ref, _ = orc.gateway(da, M, lay, per_unit, tagg)
+        except Exception as e:  # noqa: BLE001
+            print(f"case {case}: {fam} agg={agg} tagg={tagg} pu={per_unit} ({T},{Y},{X}) chunked={chunked} RAISED "
+                  f"{type(e).__name__}: {e}")
+            fails += 1
+            continue
+        g = np.asarray(got.values, dtype=np.float64)
+        if agg == "none":
+            ref = ref.reshape((len(slots_time), Y, X)) if tagg is None else ref.reshape(Y, X)
+        elif tagg is None and chunked:
+            ref = ref.T  # dask branch: (time, index)
+        if g.shape != np.shape(ref):
+            print(f"case {case}: {fam} agg={agg} tagg={tagg} shape {g.shape} vs {np.shape(ref)} dims {got.dims}")
+            fails += 1
+            continue
+        scale = np.nanmax(np.abs(ref[np.isfinite(ref)])) if np.isfinite(ref).any() else 1.0
+        atol = (1e-9 * kw.get("a", 1.0) if fam in ("heat", "cool") else 0.0) + 1e-12 * max(scale, 1e-300)
+        with np.errstate(all="ignore"):
+            err = np.abs(g - ref) / (1e-10 * np.abs(ref) + atol)
+        same = (g == ref) | (np.isnan(g) & np.isnan(ref))
+        err = np.where(same, 0.0, err)
+        err = np.where(np.isnan(err), np.inf, err)  # NaN / inf pattern differs
+        e = float(err.max()) if err.size else 0.0
+        if e > worst and np.isfinite(e):
+            worst, worst_case = e, f"{fam} agg={agg} tagg={tagg} pu={per_unit} ({T},{Y},{X})"
+        if e > 1.0:
+            fails += 1
+            i = np.unravel_index(np.argmax(err), err.shape)
+            print(f"case {case}: {fam} {kw} agg={agg} tagg={tagg} pu={per_unit} ({T},{Y},{X}) chunked={chunked} stream="
+                  f"{os.environ['ATLITE_HIP_STREAM']} {np.dtype(dtype).name}: error {e:.3e} of the allowance at {i}: got {g[i]!r} ref {ref[i]!r}")
+    print(f"{n} cases, {fails} failures, worst error {worst:.3e} of the allowance: {worst_case}")
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
