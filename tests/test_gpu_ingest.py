@@ -182,3 +182,36 @@ def test_time_shards_of_a_file_cutout(monkeypatch):
     whole = Cutout(ds).heat_demand(matrix=M, aggregate_time=None).values
     parts = [Cutout(ds.isel_time(edges[r], edges[r + 1])).heat_demand(matrix=M, aggregate_time=None).values for r in range(2)]
     np.testing.assert_array_equal(np.concatenate(parts, axis=0), whole)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_read_slab_random_files(ctx, tmp_path, seed):
+    """Random shapes / chunkings / container flavours written by h5py on the spot (when the conda
+    interpreter is there): device decode == host decode == what was written, for random row ranges."""
+    import subprocess
+
+    conda = "/opt/conda/bin/python3.9"
+    make = os.path.join(os.path.dirname(__file__), "golden", "make_nc_fixtures.py")
+    try:
+        ok = subprocess.run([conda, "-c", "import h5py"], capture_output=True, timeout=120).returncode == 0
+    except Exception:
+        ok = False
+    if not ok:
+        pytest.skip("needs the conda interpreter with h5py")
+    rng = np.random.default_rng(500 + seed)
+    T, Y, X = (int(v) for v in rng.integers(1, 40, size=3))
+    ct, cy, cx = (int(min(rng.integers(1, d + 3), d)) for d in (T, Y, X))
+    libver = ["v108", "earliest", "latest"][seed % 3]
+    path = tmp_path / "case.nc"
+    r = subprocess.run([conda, make, "--case", str(path), str(T), str(Y), str(X), str(ct), str(cy), str(cx), libver,
+                        str(seed % 2), str(seed)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    f = io.NcFile(path)
+    exp = np.load(tmp_path / "case.npz")
+    for v in exp.files:
+        n0 = exp[v].shape[0]
+        for _ in range(3):
+            t0 = int(rng.integers(0, n0))
+            n = int(rng.integers(1, n0 - t0 + 1))
+            got = slab(ctx, f, v, t0, n)
+            assert np.array_equal(got, exp[v][t0:t0 + n], equal_nan=True), (v, t0, n, T, Y, X, ct, cy, cx, libver)
