@@ -6,7 +6,7 @@ runoff, temperatures) x aggregation (none, random sparse matrix with explicit ze
 weights / empty rows, layout, matrix + layout) x per_unit x aggregate_time x grid shape x chunked or
 not x host / streamed execution, with NaN / inf / degenerate values in the inputs.
 
-    python tools/fuzz_gateway.py [n_cases] [seed]
+    python tests/fuzz_gateway.py [n_cases] [seed]
 """
 import os
 import sys

@@ -5,7 +5,7 @@ tracking x trigon model x panel x orientation kind x dataset flavour (direct/dif
 albedo or outflux) x grid shape x aggregation, with hostile values mixed in (NaN / zero / negative
 radiation, sun exactly at the horizon, exactly in the panel azimuth, zenith).  Run on the GPU box:
 
-    python tools/fuzz_pv_options.py [n_cases] [seed]
+    python tests/fuzz_pv_options.py [n_cases] [seed]
 """
 import sys
 from pathlib import Path

@@ -1,6 +1,6 @@
-"""GPU: short runs of the randomised differential fuzzers (tools/fuzz_pv_options.py, tools/fuzz_gateway.py)
+"""GPU: short runs of the randomised differential fuzzers (tests/fuzz_pv_options.py, tests/fuzz_gateway.py)
 - random points of the option / aggregation space with hostile input values, GPU result against the
-NumPy oracle at the repository tolerance (rtol 1e-10, atol 1e-12 max).  Longer runs: the tools' CLI."""
+NumPy oracle at the repository tolerance (rtol 1e-10, atol 1e-12 max).  Longer runs: python tests/fuzz_*.py <n> <seed>."""
 import importlib.util
 import sys
 from pathlib import Path
@@ -8,7 +8,7 @@ from pathlib import Path
 import pytest
 
 pytestmark = pytest.mark.gpu
-TOOLS = Path(__file__).resolve().parent.parent / "tools"
+TOOLS = Path(__file__).resolve().parent
 
 
 def _run(name, n, seed, monkeypatch):
