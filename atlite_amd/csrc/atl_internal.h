@@ -57,6 +57,42 @@ struct PlanDev {
     const uint8_t *row_poison;  // [N] 1 = row has a NaN weight -> output row is NaN
 };
 
+// ---- cell tiles: ONE definition of which cells a lane of a tile owns ---------------------------------
+// The stacked cell axis (flat index f = y*X + x) is cut into 128-byte lines of 16 cells.  The tile row
+// of grid row y starts at lo(y) = the first cell of the line holding cell (y, 0) and owns the flat
+// range [lo(y), lo(y+1)) (the last row: up to S): consecutive, disjoint, line-aligned ranges, so every
+// tile row starts on a 128-byte line and a line that straddles grid rows is read by ONE tile row - the
+// lowest grid row that starts in it.  (For X < 16 several grid rows start in the same line; all but
+// the last of them own nothing.)  Lane l of tile column tx sits at position p = tx*w + 2*(l % (w/2))
+// of its row's range.  The kernels call tile_lane_cells(); the plan builder uses the inverse
+// (tile_of_cell, atl_runtime.cpp); atl_agg_selfcheck() proves on the host that the two agree and that
+// every cell is owned exactly once.
+struct TileLane {
+    int64_t c0;   // flat index of the lane's first cell (the second is c0 + 1), always inside [0, S]
+    bool v0, v1;  // the lane owns c0 / c0 + 1
+};
+
+__host__ __device__ inline int64_t tile_row_lo(int64_t X, int64_t y) { return (y * X) & ~int64_t(15); }
+
+__host__ __device__ inline TileLane tile_lane_cells(int64_t X, int64_t Y, int32_t ntx, int32_t w2_log2,
+                                                    int32_t seg, int lane) {
+    const int32_t ty = seg / ntx, tx = seg - ty * ntx;
+    const int64_t gy = int64_t(ty) * (kLanes >> w2_log2) + (lane >> w2_log2);
+    const int64_t p = (int64_t(tx) << (w2_log2 + 1)) + ((lane & ((1 << w2_log2) - 1)) << 1);
+    const int64_t hi = gy + 1 < Y ? tile_row_lo(X, gy + 1) : X * Y;
+    TileLane t;
+    t.c0 = tile_row_lo(X, gy) + p;
+    t.v0 = gy < Y && t.c0 < hi;
+    t.v1 = gy < Y && t.c0 + 1 < hi;
+    return t;
+}
+
+inline int64_t tile_columns(int64_t X, int64_t Y, int w2_log2) {
+    const int w = 2 << w2_log2;
+    const int64_t max_shift = (Y > 1 && X % 16 != 0) ? 15 : 0;
+    return (X - 1 + max_shift) / w + 1;
+}
+
 }  // namespace atl
 
 struct atl_ctx {

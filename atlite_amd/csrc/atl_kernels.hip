@@ -252,18 +252,10 @@ __global__ __launch_bounds__(256, min_waves<Conv>()) void k_fused_segred(Conv co
     if (group >= n_groups || seg64 >= plan.n_segs || chunk * chunk_slots >= n_slots) return;
     const int32_t seg = int32_t(seg64);
 #endif
-    // tile coordinates -> the lane's two adjacent cells
-    // (columns sheared by (gy*X) mod 16 cells: tile rows start on 128-byte lines).  A 128-byte line
-    // that straddles two grid rows belongs WHOLLY to the first tile column of the lower row (gx < 0
-    // addresses the upper row's tail through the flat index), so no line is fetched by two waves.
-    const int32_t ty = seg / plan.ntx, tx = seg - ty * plan.ntx;
-    const int64_t gy = int64_t(ty) * (kLanes >> plan.w2_log2) + (lane >> plan.w2_log2);
-    const int64_t gx = (int64_t(tx) << (plan.w2_log2 + 1)) + ((lane & ((1 << plan.w2_log2) - 1)) << 1) -
-                       ((gy * plan.X) & 15);
-    const int64_t c0 = gy * plan.X + gx;
-    const int64_t xe = gy + 1 < plan.Y ? plan.X - (((gy + 1) * plan.X) & 15) : plan.X;  // tail given to row gy+1
-    const bool v0 = gy < plan.Y && (gx >= 0 ? gx < xe : gy >= 1);
-    const bool v1 = gy < plan.Y && (gx + 1 >= 0 ? gx + 1 < xe : gy >= 1);
+    // tile coordinates -> the lane's two adjacent cells (atl_internal.h: tile_lane_cells)
+    const TileLane tl = tile_lane_cells(plan.X, plan.Y, plan.ntx, plan.w2_log2, seg, lane);
+    const int64_t c0 = tl.c0;
+    const bool v0 = tl.v0, v1 = tl.v1;
     const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);  // safe indices: loads never branch
     const int32_t p0 = plan.seg_ptr[seg], p1 = plan.seg_ptr[seg + 1];
     if (p0 == p1) return;  // no shape touches this tile: nothing to read

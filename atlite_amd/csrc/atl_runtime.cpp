@@ -69,6 +69,29 @@ int copy_stream_of(atl_ctx *ctx, hipStream_t *out) {
 }
 }  // namespace atl
 
+namespace atl {
+// grid layout of a plan: (Y, X) cells in tiles of (2 << w2_log2) x (64 >> w2_log2) cells
+struct Layout {
+    int64_t X, Y;
+    int w2_log2;  // log2 of the lanes per tile row
+};
+
+// inverse of tile_lane_cells (atl_internal.h): the tile that owns `cell` and the cell's slot
+// (2 * lane + {0, 1}) inside it
+int64_t tile_of_cell(const Layout &L, int64_t cell, int32_t *local) {
+    const int w = 2 << L.w2_log2, h = kLanes >> L.w2_log2;
+    // the grid row whose flat range [lo(y), lo(y+1)) holds the cell: its own row, or - when the line
+    // it lies in is shared with the start of later rows - the last row that starts in that line
+    int64_t y = cell / L.X;
+    while (y + 1 < L.Y && cell >= tile_row_lo(L.X, y + 1)) ++y;
+    const int64_t p = cell - tile_row_lo(L.X, y);
+    const int64_t tx = p / w, ty = y / h;
+    const int lane = int((y % h) << L.w2_log2) + int((p % w) >> 1);
+    *local = lane * 2 + int(p & 1);
+    return ty * tile_columns(L.X, L.Y, L.w2_log2) + tx;
+}
+}  // namespace atl
+
 extern "C" {
 
 int atl_version(void) { return ATL_VERSION; }
@@ -356,34 +379,8 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_le
     }
 
     // ---- choose the tile shape --------------------------------------------------------------
-    struct Layout {
-        int64_t X, Y;
-        int w2_log2;  // lanes per tile row
-    };
-    // Tile columns are sheared per grid row by shift(y) = (y*X) mod 16 cells so that every
-    // tile row starts on a 128-byte line of the stacked (time, cell) cube (when S % 16 == 0); a line
-    // straddling two grid rows is owned by the lower row's first tile column (see tile_of).
-    auto ntx_of = [](const Layout &L) {
-        const int w = 2 << L.w2_log2;
-        const int64_t max_shift = (L.Y > 1 && L.X % 16 != 0) ? 15 : 0;
-        return (L.X - 1 + max_shift) / w + 1;
-    };
-    auto tile_of = [&ntx_of](const Layout &L, int64_t cell, int32_t *local) {
-        int64_t y = cell / L.X, x = cell % L.X;
-        const int w = 2 << L.w2_log2, h = kLanes >> L.w2_log2;
-        // the 128-byte line holding cell (y+1, 0) belongs wholly to row y+1's first tile column:
-        // the tail cells of row y that share it are addressed from there with negative x
-        const int64_t shn = ((y + 1) * L.X) & 15;
-        if (y + 1 < L.Y && x >= L.X - shn) {
-            x -= L.X;
-            ++y;
-        }
-        const int64_t xs = x + ((y * L.X) & 15);
-        const int64_t tx = xs / w, ty = y / h;
-        const int lane = int((y % h) << L.w2_log2) + int((xs % w) >> 1);
-        *local = lane * 2 + int(xs & 1);
-        return ty * ntx_of(L) + tx;
-    };
+    auto ntx_of = [](const Layout &L) { return tile_columns(L.X, L.Y, L.w2_log2); };
+    auto tile_of = [](const Layout &L, int64_t cell, int32_t *local) { return tile_of_cell(L, cell, local); };
     std::vector<Layout> cands;
     cands.push_back({n_cells > 0 ? n_cells : 1, 1, 6});  // flat 128 x 1 over the stacked axis
     if (row_len > 0 && n_cells / row_len > 1) {
@@ -528,6 +525,44 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_le
         return rc;
     }
     *out = a;
+    return ATL_OK;
+}
+
+int atl_agg_selfcheck(int64_t n_cells, int64_t row_len, int tile_w, int64_t *n_tiles, int64_t *n_owned,
+                      int64_t *n_errors) {
+    ATL_REQUIRE(n_cells >= 0 && n_cells < (int64_t(1) << 31) && n_tiles && n_owned && n_errors,
+                "atl_agg_selfcheck: bad argument");
+    ATL_REQUIRE(tile_w == 16 || tile_w == 32 || tile_w == 64 || tile_w == 128, "atl_agg_selfcheck: tile_w must be 16, 32, 64 or 128");
+    ATL_REQUIRE(row_len >= 0 && (row_len == 0 || n_cells % row_len == 0), "atl_agg_selfcheck: row_len does not divide n_cells");
+    int l2 = 0;
+    while ((2 << l2) < tile_w) ++l2;
+    Layout L{row_len > 0 ? row_len : std::max<int64_t>(n_cells, 1), row_len > 0 ? n_cells / row_len : 1, l2};
+    const int h = kLanes >> L.w2_log2;
+    const int64_t ntx = tile_columns(L.X, L.Y, L.w2_log2), nty = (L.Y + h - 1) / h;
+    *n_tiles = n_cells > 0 ? ntx * nty : 0;
+    *n_owned = 0;
+    *n_errors = 0;
+    std::vector<uint8_t> seen(static_cast<size_t>(n_cells), 0);
+    for (int64_t seg = 0; seg < *n_tiles; ++seg) {
+        for (int lane = 0; lane < kLanes; ++lane) {
+            const TileLane t = tile_lane_cells(L.X, L.Y, int32_t(ntx), L.w2_log2, int32_t(seg), lane);
+            for (int k = 0; k < 2; ++k) {
+                if (!(k ? t.v1 : t.v0)) continue;
+                const int64_t c = t.c0 + k;
+                if (c < 0 || c >= n_cells) {
+                    ++*n_errors;  // the kernel would read outside the cube
+                    continue;
+                }
+                ++*n_owned;
+                if (seen[size_t(c)]++) ++*n_errors;  // owned twice
+                int32_t loc = -1;
+                const int64_t back = tile_of_cell(L, c, &loc);
+                if (back != seg || loc != 2 * lane + k) ++*n_errors;  // plan builder and kernel disagree
+            }
+        }
+    }
+    for (int64_t c = 0; c < n_cells; ++c)
+        if (!seen[size_t(c)]) ++*n_errors;  // never owned
     return ATL_OK;
 }
 

@@ -108,6 +108,13 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_le
                    const int64_t *h_indptr, const int32_t *h_indices, const double *h_data,
                    atl_agg **out);
 int atl_agg_destroy(atl_agg *agg);
+/* Host-only self check of the cell-tile geometry (no GPU needed): for a grid of n_cells cells in rows
+ * of row_len (0 = one flat row) and tiles tile_w cells wide (16, 32, 64 or 128), enumerate every lane
+ * of every tile with the mapping the kernels use and verify that every cell is owned by exactly one
+ * lane, that no lane points outside the cube, and that the plan builder's inverse mapping agrees.
+ * *n_errors = 0 means consistent. */
+int atl_agg_selfcheck(int64_t n_cells, int64_t row_len, int tile_w, int64_t *n_tiles, int64_t *n_owned,
+                      int64_t *n_errors);
 int atl_agg_info(const atl_agg *agg, int64_t *n_rows, int64_t *n_cells, int64_t *n_segments,
                  int64_t *n_partial_rows, int32_t *tile_w, int32_t *tile_h);
 

@@ -194,3 +194,29 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     ns = {"C": C}
     exec(doc[doc.index("class PvInputs(C.Structure)"):doc.index("class Ctx:")], ns)
     assert C.sizeof(ns["PvInputs"]) == C.sizeof(_lib.PvInputs) and C.sizeof(ns["PvParams"]) == C.sizeof(_lib.PvParams)
+
+
+def test_tile_geometry_selfcheck():
+    """Cell-tile geometry on the HOST (atl_agg_selfcheck): the lane -> cell mapping the kernels use and
+    the plan builder's inverse agree, every cell is owned by exactly one lane and no lane points outside
+    the cube - for every row-length residue modulo 16 (straddling 128-byte lines), odd row lengths,
+    grids smaller than a tile, single rows and the benchmark grids."""
+    import ctypes as C
+
+    from atlite_amd import _lib
+
+    lib = _lib.load()
+    grids = [(5, x) for x in range(1, 70)] + [(1, 37), (1, 1), (2, 7), (9, 3), (17, 15), (64, 16), (130, 31),
+                                              (200, 200), (400, 400), (33, 250), (7, 1000)]
+    for Y, X in grids:
+        for tw in (16, 32, 64, 128):
+            nt, no, ne = C.c_int64(), C.c_int64(), C.c_int64()
+            _lib.check(lib.atl_agg_selfcheck(Y * X, X, tw, C.byref(nt), C.byref(no), C.byref(ne)))
+            assert ne.value == 0 and no.value == Y * X, (Y, X, tw, nt.value, no.value, ne.value)
+    # flat layout (unknown grid): one row of n cells in 128-cell tiles
+    for n in (1, 127, 128, 129, 40000):
+        nt, no, ne = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(lib.atl_agg_selfcheck(n, 0, 128, C.byref(nt), C.byref(no), C.byref(ne)))
+        assert ne.value == 0 and no.value == n and nt.value == (n + 127) // 128
+    with pytest.raises(ValueError):
+        _lib.check(lib.atl_agg_selfcheck(10, 3, 16, C.byref(nt), C.byref(no), C.byref(ne)))
