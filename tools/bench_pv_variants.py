@@ -55,6 +55,7 @@ for name, nbytes, fn in (
     ("general kernel: irradiation (no panel model)", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none"))),
     ("general kernel: trigon_model='other'", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(trigon_model="other"))),
     ("per-cell series out (no matrix)", 64, lambda: ctx.pv(inputs, scal, T, S)),
+    ("per-cell time-mean (capacity factor map)", 56, lambda: ctx.pv(inputs, scal, T, S, time_agg="mean")),
 ):
     ms, out = timed(fn)
     gbs = nbytes * T * S / (ms * 1e-3) / 1e9
