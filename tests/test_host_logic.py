@@ -1,6 +1,7 @@
 """CPU: host-side logic that needs no GPU - C ABI surface, argument validation of the gateway
 (raised before any device work), resources, orientation factories, indicator matrix, labelled
 containers."""
+import os
 import re
 from pathlib import Path
 
@@ -220,3 +221,65 @@ def test_tile_geometry_selfcheck():
         assert ne.value == 0 and no.value == n and nt.value == (n + 127) // 128
     with pytest.raises(ValueError):
         _lib.check(lib.atl_agg_selfcheck(10, 3, 16, C.byref(nt), C.byref(no), C.byref(ne)))
+
+
+def test_streaming_sources_and_policy(monkeypatch):
+    """Host-side policy of the slab pipeline (no GPU): which datasets stream, and how sources are
+    normalised (fp64 as is, narrower native dtypes kept for the device decode, exotic ones widened)."""
+    from atlite_amd import Dataset, io, streaming
+
+    T, Y, X = 6, 2, 3
+    t = pd.date_range("2013-01-01", periods=T, freq="h")
+    coords = dict(time=t, y=[0.0, 1.0], x=[0.0, 1.0, 2.0])
+
+    class Spec:
+        time_vars = ("runoff",)
+
+    a64 = np.arange(T * Y * X, dtype=np.float64).reshape(T, Y, X)
+    ds = Dataset({"runoff": a64}, coords)
+    monkeypatch.setenv("ATLITE_HIP_STREAM", "auto")
+    assert not streaming.wanted(ds, Spec())  # small host data: whole-variable upload
+    monkeypatch.setenv("ATLITE_HIP_STREAM_MIN_BYTES", "1")
+    assert streaming.wanted(ds, Spec())
+    monkeypatch.setenv("ATLITE_HIP_STREAM", "0")
+    assert not streaming.wanted(ds, Spec())
+    monkeypatch.setenv("ATLITE_HIP_STREAM", "auto")
+    monkeypatch.delenv("ATLITE_HIP_STREAM_MIN_BYTES")
+    fds = io.open_cutout(os.path.join(os.path.dirname(__file__), "golden", "nc", "cutout_small_f32.nc"))
+    assert streaming.wanted(fds, Spec())  # file-backed variables always stream
+
+    class NoTime:
+        time_vars = ()
+
+    assert not streaming.wanted(fds, NoTime())
+    # source normalisation
+    s = streaming._source(a64, T, Y * X)
+    assert s.dtype == np.float64 and s.shape == (T, Y * X) and np.shares_memory(s, a64)
+    for dt in ("float32", "int16", "uint8", "int64"):
+        s = streaming._source(a64.astype(dt), T, Y * X)
+        assert s.dtype == np.dtype(dt) and s.flags.c_contiguous
+    assert streaming._source(a64.astype(">f4"), T, Y * X).dtype == np.float64  # big-endian: widened on the host
+    assert streaming._source(a64.astype(np.float16), T, Y * X).dtype == np.float64
+    assert streaming._source(a64.astype(bool), T, Y * X).dtype == np.float64
+    nc = np.asfortranarray(a64.astype(np.float32))
+    s = streaming._source(nc, T, Y * X)
+    assert s.flags.c_contiguous and np.array_equal(s.reshape(T, Y, X), nc)
+    fa = fds["temperature"].data
+    assert streaming._source(fa, 48, 108) is fa
+
+
+def test_time_partition_properties():
+    from atlite_amd.distributed import time_partition
+
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        n, w = int(rng.integers(0, 5000)), int(rng.integers(1, 17))
+        align = int(rng.choice([1, 24]))
+        first = int(rng.integers(0, 24)) if align > 1 else 0
+        e = time_partition(n, w, align=align, first=first)
+        assert len(e) == w + 1 and e[0] == 0 and e[-1] == n and all(b >= a for a, b in zip(e, e[1:]))
+        if align > 1:
+            assert all((v - first) % align == 0 or v in (0, n) for v in e[1:-1])
+        if n >= w * 2 * align:
+            sizes = np.diff(e)
+            assert sizes.max() - sizes.min() <= 2 * align
