@@ -7,7 +7,13 @@
 // solar PV, ERA5-shaped inputs with stored solar position
 struct PvConst {
     double c_amb, c_irr, r_tmod, inv_r_irr, k1, k2, k3, k4, k5, k6, inv_eff, alt_thr, sin_alt_thr;
+    // tails other than the Huld panel (PvConvT<..., TAIL>): solar thermal collector, plain irradiation
+    double st_c0, st_c1, st_t_store;
+    int irr;  // ATL_IRR_*: which component the irradiation tail returns
 };
+
+// what follows the tilted irradiation in the fast kernel family
+constexpr int kTailHuld = 0, kTailThermal = 1, kTailIrradiation = 2;
 
 // per-cell orientation factors: sin/cos(slope), (1 +- cos(slope))/2, panel azimuth
 struct PvOri {
@@ -23,6 +29,7 @@ struct PvAz<false> {};
 
 // irradiation on the tilted surface + Huld panel model, from sin/cos of the solar altitude and
 // cos(surface_azimuth - sun_azimuth)   (irradiation.py:214-226, solar_panel_model.py:22-41)
+template <int TAIL = kTailHuld>
 __device__ __forceinline__ double pv_tail(double direct, double diffuse, double influx, double alb, double tmp,
                                           double sa, double ca, double cosd, const PvOri &o, const PvConst &k) {
     // orientation.py:114-117,188
@@ -33,6 +40,14 @@ __device__ __forceinline__ double pv_tail(double direct, double diffuse, double 
     const double diffuse_t = o.hp * diffuse;
     const double ground_t = alb * influx * o.hm;
     const double G = fill0(direct_t) + fill0(diffuse_t) + fill0(ground_t);
+    if constexpr (TAIL == kTailIrradiation) {  // convert_irradiation, convert.py:748-767
+        return k.irr == ATL_IRR_TOTAL ? G : k.irr == ATL_IRR_DIRECT ? direct_t : k.irr == ATL_IRR_DIFFUSE ? diffuse_t : ground_t;
+    }
+    if constexpr (TAIL == kTailThermal) {  // convert_solar_thermal, convert.py:565-574
+        const double eta = k.st_c0 - k.st_c1 * fill0(guarded_div(k.st_t_store - tmp, G != 0.0 ? G : __builtin_nan("")));
+        const double output = G * eta;
+        return output > 0.0 ? output : 0.0;
+    }
     const double T_ = (k.c_amb * tmp + k.c_irr * G) - k.r_tmod;
     const double G_ = G * k.inv_r_irr;
     double eff = 0.0;
@@ -46,6 +61,7 @@ __device__ __forceinline__ double pv_tail(double direct, double diffuse, double 
     return G_ * eff * k.inv_eff;
 }
 
+template <int TAIL = kTailHuld>
 __device__ __forceinline__ double pv_cell(double dir, double dif, double toa, double alb, double tmp,
                                           double alt, double az, const PvOri &o, const PvConst &k) {
     // irradiation.py:206-208
@@ -60,7 +76,7 @@ __device__ __forceinline__ double pv_cell(double dir, double dif, double toa, do
     if (capped) return 0.0;  // G = 0 -> G_ = 0, eff -> 0 : 0*0*inv
     double sa, ca;
     lean_sincos(alt, &sa, &ca);
-    return pv_tail(direct, diffuse, influx, alb, tmp, sa, ca, lean_cos(o.saz - az), o, k);
+    return pv_tail<TAIL>(direct, diffuse, influx, alb, tmp, sa, ca, lean_cos(o.saz - az), o, k);
 }
 
 // same, with the solar position computed from the separable tables instead of read:
@@ -92,9 +108,13 @@ __device__ __forceinline__ double pv_cell_sp(double dir, double dif, double toa,
 // the altitude cut-off the other six streams are not read - the result is exactly +0.0 whatever
 // they hold (pv_cell).  The altitude of the NEXT slot is prefetched together with the current slot's
 // streams (Carry), so day-time slots still cost one memory round trip.
-template <bool SP, bool PC = false, bool SKIP = false>
+// TAIL: the Huld panel model (pv), the solar thermal collector or the plain tilted irradiation - the two
+// non-panel tails exist for stored solar angles without night skip (everything else of those calls
+// goes through the general kernel).
+template <bool SP, bool PC = false, bool SKIP = false, int TAIL = kTailHuld>
 struct PvConvT {
     static_assert(!(SP && SKIP), "night skip is implemented for stored solar angles");
+    static_assert(TAIL == kTailHuld || (!SP && !SKIP), "the non-panel tails are built for stored angles, no skip");
     atl_pv_inputs in;
     int64_t S;
     PvConst k;
@@ -220,8 +240,8 @@ struct PvConvT {
             r.x = v0 ? pv_cell_sp(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.sd, q.cd, c.sl0, c.cl0, q.a.x, q.b.x, o0, a0, k) : 0.0;
             r.y = v1 ? pv_cell_sp(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.sd, q.cd, c.sl1, c.cl1, q.a.y, q.b.y, o1, a1, k) : 0.0;
         } else {
-            r.x = v0 ? pv_cell(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.a.x, q.b.x, o0, k) : 0.0;
-            r.y = v1 ? pv_cell(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.a.y, q.b.y, o1, k) : 0.0;
+            r.x = v0 ? pv_cell<TAIL>(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.a.x, q.b.x, o0, k) : 0.0;
+            r.y = v1 ? pv_cell<TAIL>(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.a.y, q.b.y, o1, k) : 0.0;
         }
         return r;
     }
@@ -230,8 +250,8 @@ using PvConv = PvConvT<false>;
 using PvConvSP = PvConvT<true>;
 template <class T>
 struct pv_is_sp : std::false_type {};
-template <bool PC, bool SK>
-struct pv_is_sp<PvConvT<true, PC, SK>> : std::true_type {};
+template <bool PC, bool SK, int TL>
+struct pv_is_sp<PvConvT<true, PC, SK, TL>> : std::true_type {};
 
 // ---------------------------------------------------------------------------------------
 // general pv converter: every option of convert_pv / convert_irradiation / convert_solar_thermal

@@ -659,7 +659,8 @@ int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t 
     c->S = S;
     c->k = PvConst{p->c_temp_amb, p->c_temp_irrad, p->r_tmod, 1.0 / p->r_irradiance, p->k_1, p->k_2,
                    p->k_3,        p->k_4,          p->k_5,    p->k_6,                 p->inverter_efficiency,
-                   p->altitude_threshold, sin(p->altitude_threshold)};
+                   p->altitude_threshold, sin(p->altitude_threshold),
+                   p->st_c0, p->st_c1, p->st_t_store_K, p->irradiation};
     c->o.ss = sin(p->slope);
     c->o.cs = cos(p->slope);
     c->o.hp = (1.0 + c->o.cs) / 2.0;
@@ -681,6 +682,10 @@ int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t 
 template <class F>
 int pv_dispatch(const atl_pv_inputs *in, const atl_pv_params *p, bool allow_skip, F &&f) {
     const bool sp = !(in->d_solar_altitude || in->d_solar_azimuth), pc = p->d_cell_slope != nullptr;
+    if (p->panel_model == ATL_PANEL_SOLAR_THERMAL)  // pv_needs_general() admits these only with stored angles
+        return pc ? f(PvConvT<false, true, false, kTailThermal>()) : f(PvConvT<false, false, false, kTailThermal>());
+    if (p->panel_model == ATL_PANEL_NONE)
+        return pc ? f(PvConvT<false, true, false, kTailIrradiation>()) : f(PvConvT<false, false, false, kTailIrradiation>());
     if (sp) return pc ? f(PvConvT<true, true>()) : f(PvConvT<true, false>());
     if (p->night_skip && allow_skip) return pc ? f(PvConvT<false, true, true>()) : f(PvConvT<false, false, true>());
     return pc ? f(PvConvT<false, true>()) : f(PvConvT<false, false>());
@@ -706,8 +711,19 @@ int pvx_dispatch(const atl_pv_params *p, F &&f) {
 }
 
 bool pv_needs_general(const atl_pv_inputs *in, const atl_pv_params *p) {
-    return p->tracking != ATL_TRACK_NONE || p->trigon_model != ATL_TRIGON_SIMPLE || p->irradiation != ATL_IRR_TOTAL ||
-           p->panel_model != ATL_PANEL_HULD || in->d_influx != nullptr || in->d_albedo == nullptr;
+    if (p->tracking != ATL_TRACK_NONE || p->trigon_model != ATL_TRIGON_SIMPLE || in->d_influx != nullptr ||
+        in->d_albedo == nullptr)
+        return true;
+    // fixed panel, simple trigon model, direct / diffuse / albedo cubes: the fast kernel family, with the
+    // Huld panel, the solar thermal collector or the plain irradiation as its tail
+    const bool stored = in->d_solar_altitude != nullptr, all7 = stored && in->d_temperature != nullptr;
+    switch (p->panel_model) {
+        case ATL_PANEL_HULD: return p->irradiation != ATL_IRR_TOTAL;
+        case ATL_PANEL_SOLAR_THERMAL: return !(all7 && p->irradiation == ATL_IRR_TOTAL);
+        case ATL_PANEL_NONE:
+            return !(all7 && p->irradiation >= ATL_IRR_TOTAL && p->irradiation <= ATL_IRR_GROUND);
+        default: return true;  // bofinger
+    }
 }
 
 template <class PVX>

@@ -52,7 +52,10 @@ for name, nbytes, fn in (
     ("general kernel: tracking='tilted_horizontal'", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="tilted_horizontal"))),
     ("general kernel: tracking='vertical'", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="vertical"))),
     ("general kernel: tracking='dual'", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="dual"))),
-    ("general kernel: irradiation (no panel model)", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none"))),
+    ("irradiation() - fast family, no panel model (48 B/cell: temperature is not read)", 48,
+     lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none"))),
+    ("solar_thermal() - fast family, collector tail", 56,
+     lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="solar_thermal", c0=0.8, c1=3.0, t_store_K=353.15))),
     ("general kernel: trigon_model='other'", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(trigon_model="other"))),
     ("per-cell series out (no matrix)", 64, lambda: ctx.pv(inputs, scal, T, S)),
     ("per-cell time-mean (capacity factor map)", 56, lambda: ctx.pv(inputs, scal, T, S, time_agg="mean")),
