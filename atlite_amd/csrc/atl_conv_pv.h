@@ -13,11 +13,12 @@ struct PvConst {
 };
 
 // what follows the tilted irradiation in the fast kernel family
-constexpr int kTailHuld = 0, kTailThermal = 1, kTailIrradiation = 2;
+constexpr int kTailHuld = 0, kTailThermal = 1, kTailIrradiation = 2, kTailHuldHayDavies = 3;
 
 // per-cell orientation factors: sin/cos(slope), (1 +- cos(slope))/2, panel azimuth
 struct PvOri {
     double ss, cs, hp, hm, saz;
+    double sh3;  // sin(slope / 2)^3: Hay-Davies horizon brightening (irradiation.py:101-108)
 };
 // cos/sin of the panel azimuth: only the in-kernel solar position variant needs them
 template <bool SP>
@@ -30,16 +31,28 @@ struct PvAz<false> {};
 // irradiation on the tilted surface + Huld panel model, from sin/cos of the solar altitude and
 // cos(surface_azimuth - sun_azimuth)   (irradiation.py:214-226, solar_panel_model.py:22-41)
 template <int TAIL = kTailHuld>
-__device__ __forceinline__ double pv_tail(double direct, double diffuse, double influx, double alb, double tmp,
-                                          double sa, double ca, double cosd, const PvOri &o, const PvConst &k) {
+__device__ __forceinline__ double pv_tail(double direct, double diffuse, double influx, double toa, double alb,
+                                          double tmp, double sa, double ca, double cosd, const PvOri &o,
+                                          const PvConst &k) {
     // orientation.py:114-117,188
     double cosinc = o.ss * ca * cosd + o.cs * sa;
     cosinc = np_max(cosinc, 0.0);
     const double kk = fast_div(cosinc, sa);
     const double direct_t = kk * direct;
-    const double diffuse_t = o.hp * diffuse;
-    const double ground_t = alb * influx * o.hm;
-    const double G = fill0(direct_t) + fill0(diffuse_t) + fill0(ground_t);
+    double G;
+    [[maybe_unused]] double diffuse_t = 0.0, ground_t = 0.0;
+    if constexpr (TAIL == kTailHuldHayDavies) {  // trigon_model="other", irradiation.py:76-145, 227-245
+        const double f = fill0(sqrt(guarded_div(direct, influx)));
+        const double A = guarded_div(direct, toa);
+        diffuse_t = ((1.0 - A) * o.hp * (1.0 + f * o.sh3) + A * kk) * diffuse;
+        diffuse_t = fill0(np_max(diffuse_t, 0.0));
+        ground_t = influx * alb * o.hm;
+        G = direct_t + diffuse_t + ground_t;  // no fillna here: a NaN component makes the total NaN
+    } else {
+        diffuse_t = o.hp * diffuse;
+        ground_t = alb * influx * o.hm;
+        G = fill0(direct_t) + fill0(diffuse_t) + fill0(ground_t);
+    }
     if constexpr (TAIL == kTailIrradiation) {  // convert_irradiation, convert.py:748-767
         return k.irr == ATL_IRR_TOTAL ? G : k.irr == ATL_IRR_DIRECT ? direct_t : k.irr == ATL_IRR_DIFFUSE ? diffuse_t : ground_t;
     }
@@ -76,7 +89,7 @@ __device__ __forceinline__ double pv_cell(double dir, double dif, double toa, do
     if (capped) return 0.0;  // G = 0 -> G_ = 0, eff -> 0 : 0*0*inv
     double sa, ca;
     lean_sincos(alt, &sa, &ca);
-    return pv_tail<TAIL>(direct, diffuse, influx, alb, tmp, sa, ca, lean_cos(o.saz - az), o, k);
+    return pv_tail<TAIL>(direct, diffuse, influx, toa, alb, tmp, sa, ca, lean_cos(o.saz - az), o, k);
 }
 
 // same, with the solar position computed from the separable tables instead of read:
@@ -99,7 +112,7 @@ __device__ __forceinline__ double pv_cell_sp(double dir, double dif, double toa,
     const double caz = np_clip(q, -1.0, 1.0);  // :109-113
     double saz = sqrt((1.0 - caz) * (1.0 + caz));
     saz = (h <= 0.0) ? saz : -saz;  // :114  az = az if h <= 0 else 2 pi - az
-    return pv_tail(direct, diffuse, influx, alb, tmp, s, ca, a.csaz * caz + a.ssaz * saz, o, k);
+    return pv_tail(direct, diffuse, influx, toa, alb, tmp, s, ca, a.csaz * caz + a.ssaz * saz, o, k);
 }
 
 // SP: in-kernel solar position; PC: per-cell orientation (else the scalar orientation is read from
@@ -142,6 +155,11 @@ struct PvConvT {
         r.hp = (1.0 + r.cs) / 2.0;
         r.hm = (1.0 - r.cs) / 2.0;
         r.saz = azimuth;
+        r.sh3 = 0.0;
+        if constexpr (TAIL == kTailHuldHayDavies) {
+            const double sh = lean_sin(slope / 2.0);
+            r.sh3 = sh * sh * sh;
+        }
         return r;
     }
     __device__ Cell cell_setup(int64_t c0, bool v0, bool v1, const double *lds) const {

@@ -666,6 +666,10 @@ int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t 
     c->o.hp = (1.0 + c->o.cs) / 2.0;
     c->o.hm = (1.0 - c->o.cs) / 2.0;
     c->o.saz = p->azimuth;
+    {
+        const double sh = sin(p->slope / 2.0);
+        c->o.sh3 = sh * sh * sh;
+    }
     if constexpr (pv_is_sp<PV>::value) {
         c->oa.csaz = cos(p->azimuth);
         c->oa.ssaz = sin(p->azimuth);
@@ -682,7 +686,9 @@ int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t 
 template <class F>
 int pv_dispatch(const atl_pv_inputs *in, const atl_pv_params *p, bool allow_skip, F &&f) {
     const bool sp = !(in->d_solar_altitude || in->d_solar_azimuth), pc = p->d_cell_slope != nullptr;
-    if (p->panel_model == ATL_PANEL_SOLAR_THERMAL)  // pv_needs_general() admits these only with stored angles
+    if (p->trigon_model == ATL_TRIGON_OTHER)  // pv_needs_general() admits these only with stored angles + Huld
+        return pc ? f(PvConvT<false, true, false, kTailHuldHayDavies>()) : f(PvConvT<false, false, false, kTailHuldHayDavies>());
+    if (p->panel_model == ATL_PANEL_SOLAR_THERMAL)
         return pc ? f(PvConvT<false, true, false, kTailThermal>()) : f(PvConvT<false, false, false, kTailThermal>());
     if (p->panel_model == ATL_PANEL_NONE)
         return pc ? f(PvConvT<false, true, false, kTailIrradiation>()) : f(PvConvT<false, false, false, kTailIrradiation>());
@@ -711,9 +717,10 @@ int pvx_dispatch(const atl_pv_params *p, F &&f) {
 }
 
 bool pv_needs_general(const atl_pv_inputs *in, const atl_pv_params *p) {
-    if (p->tracking != ATL_TRACK_NONE || p->trigon_model != ATL_TRIGON_SIMPLE || in->d_influx != nullptr ||
-        in->d_albedo == nullptr)
-        return true;
+    if (p->tracking != ATL_TRACK_NONE || in->d_influx != nullptr || in->d_albedo == nullptr) return true;
+    if (p->trigon_model != ATL_TRIGON_SIMPLE)  // Hay-Davies: fast family only for pv() itself
+        return !(p->trigon_model == ATL_TRIGON_OTHER && p->panel_model == ATL_PANEL_HULD &&
+                 p->irradiation == ATL_IRR_TOTAL && in->d_solar_altitude != nullptr && in->d_temperature != nullptr);
     // fixed panel, simple trigon model, direct / diffuse / albedo cubes: the fast kernel family, with the
     // Huld panel, the solar thermal collector or the plain irradiation as its tail
     const bool stored = in->d_solar_altitude != nullptr, all7 = stored && in->d_temperature != nullptr;

@@ -56,7 +56,7 @@ for name, nbytes, fn in (
      lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none"))),
     ("solar_thermal() - fast family, collector tail", 56,
      lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="solar_thermal", c0=0.8, c1=3.0, t_store_K=353.15))),
-    ("general kernel: trigon_model='other'", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(trigon_model="other"))),
+    ("pv(trigon_model='other') - fast family, Hay-Davies tail", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(trigon_model="other"))),
     ("per-cell series out (no matrix)", 64, lambda: ctx.pv(inputs, scal, T, S)),
     ("per-cell time-mean (capacity factor map)", 56, lambda: ctx.pv(inputs, scal, T, S, time_agg="mean")),
 ):
