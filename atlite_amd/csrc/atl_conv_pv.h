@@ -18,6 +18,7 @@ constexpr int kTailHuld = 0, kTailThermal = 1, kTailIrradiation = 2, kTailHuldHa
 // per-cell orientation factors: sin/cos(slope), (1 +- cos(slope))/2, panel azimuth
 struct PvOri {
     double ss, cs, hp, hm, saz;
+    double slope;  // radians: the trackers' closed forms start from the angle itself
     double sh3;  // sin(slope / 2)^3: Hay-Davies horizon brightening (irradiation.py:101-108)
 };
 // cos/sin of the panel azimuth: only the in-kernel solar position variant needs them
@@ -28,15 +29,107 @@ struct PvAz {
 template <>
 struct PvAz<false> {};
 
+// ---- SurfaceOrientation with a tracker (orientation.py:113-188), fast family and general kernel -----------------------------
+// What the irradiation model needs of the panel geometry: cos(incidence) (before the clip at 0),
+// cos(surface slope) and - Hay-Davies only - sin(surface slope / 2).
+struct PanelGeom {
+    double cosinc, cs, sh;
+};
+
+// The reference's formulas as written (atan / asin / acos through libm).  Out of line: it only runs
+// for the degenerate arguments the closed forms below exclude.
+__device__ __noinline__ PanelGeom panel_geom_literal(int tracking, double sa, double ca, double az, double slope,
+                                                     double sazim) {
+    const double pi = 3.14159265358979323846;
+    double surface_slope, cosinc;
+    if (tracking == ATL_TRACK_HORIZONTAL) {
+        const double rotation = atan((ca / sa) * sin(az - sazim));
+        surface_slope = fabs(rotation);
+        const double surface_azimuth = sazim + asin(sin(rotation) / sin(surface_slope));
+        cosinc = cos(surface_slope) * sa + sin(surface_slope) * ca * cos(az - surface_azimuth);
+    } else {  // tilted_horizontal
+        const double tilt = slope;
+        double rotation = atan((ca * sin(az - sazim)) / (ca * cos(az - sazim) * sin(tilt) + sa * cos(tilt)));
+        surface_slope = acos(cos(rotation) * cos(tilt));
+        double ad = az - sazim;
+        ad = ad > pi ? ad - 2 * pi : ad;
+        ad = ad < -pi ? 2 * pi + ad : ad;
+        rotation = (rotation < 0 && ad > 0) ? rotation + pi : rotation;
+        rotation = (rotation > 0 && ad < 0) ? rotation - pi : rotation;
+        cosinc = cos(rotation) * (sin(tilt) * ca * cos(az - sazim) + cos(tilt) * sa) + sin(rotation) * ca * sin(az - sazim);
+    }
+    return PanelGeom{cosinc, cos(surface_slope), sin(surface_slope / 2.0)};
+}
+
+// The rotating trackers without inverse trigonometry.  With q = tan(rotation):
+//   cos(atan q) = 1 / sqrt(1 + q^2),  sin(atan q) = q / sqrt(1 + q^2)
+// horizontal:        slope' = |rotation|;  asin(sin r / sin|r|) = asin(+-1) = +-pi/2, so
+//                    cos(az - azimuth') = sgn(q) sin(az - azimuth)  and
+//                    cosinc = (sa + q ca sin d) / sqrt(1 + q^2);  q = 0 gives 0/0 = NaN in the reference
+// tilted_horizontal: cos(slope') = cos(r) cos(tilt) (the acos is only ever fed back into cos / sin(./2));
+//                    the +-pi correction of the rotation flips the sign of both cos(r) and sin(r)
+// The results agree with the literal sequence to a few ulp (tests: reference-generated vectors at
+// rtol 1e-10); arguments for which the closed forms are not valid (q zero / non-finite) take the
+// literal routine.
+template <int TRACK, bool NEED_SH>
+__device__ __forceinline__ PanelGeom panel_geom(double sa, double ca, double az, double slope, double sazim) {
+    const double pi = 3.14159265358979323846;
+    PanelGeom g;
+    g.sh = 0.0;
+    if constexpr (TRACK == ATL_TRACK_NONE) {
+        g.cs = lean_cos(slope);
+        g.cosinc = lean_sin(slope) * ca * lean_cos(sazim - az) + g.cs * sa;
+        if constexpr (NEED_SH) g.sh = lean_sin(slope / 2.0);
+    } else if constexpr (TRACK == ATL_TRACK_VERTICAL) {
+        g.cs = lean_cos(slope);
+        g.cosinc = lean_sin(slope) * ca + g.cs * sa;
+        if constexpr (NEED_SH) g.sh = lean_sin(slope / 2.0);
+    } else if constexpr (TRACK == ATL_TRACK_DUAL) {
+        g.cs = lean_cos(slope);  // the slope stays the panel's; the simple model substitutes sin(alt) itself
+        g.cosinc = 1.0;
+        if constexpr (NEED_SH) g.sh = lean_sin(slope / 2.0);
+    } else if constexpr (TRACK == ATL_TRACK_HORIZONTAL) {
+        const double sd = lean_sin(az - sazim);
+        const double q = guarded_div(ca, sa) * sd;
+        const bool ok = q != 0.0 && __builtin_fabs(q) < 0x1.0p500;  // false for NaN / inf too
+        const double w = __builtin_sqrt(__builtin_fma(q, q, 1.0));
+        const double cr = fast_rcp(w);  // w in [1, 2^500] whenever ok
+        g.cs = cr;
+        g.cosinc = cr * (sa + q * ca * sd);
+        if constexpr (NEED_SH) g.sh = __builtin_fabs(q) * fast_rcp(__builtin_sqrt(2.0 * w * (w + 1.0)));
+        if (__builtin_expect(!ok, 0)) g = panel_geom_literal(TRACK, sa, ca, az, slope, sazim);
+    } else {  // ATL_TRACK_TILTED_HORIZONTAL
+        double sd, cd;
+        lean_sincos(az - sazim, &sd, &cd);
+        const double st = lean_sin(slope), ct = lean_cos(slope);
+        const double num = ca * sd;
+        const double den = ca * cd * st + sa * ct;
+        const double q = guarded_div(num, den);
+        const bool ok = den != 0.0 && __builtin_fabs(q) < 0x1.0p500;
+        const double cr = fast_rcp(__builtin_sqrt(__builtin_fma(q, q, 1.0)));
+        g.cs = cr * ct;
+        double ad = az - sazim;
+        ad = ad > pi ? ad - 2 * pi : ad;
+        ad = ad < -pi ? 2 * pi + ad : ad;
+        const bool flip = (q < 0.0 && ad > 0.0) || (q > 0.0 && ad < 0.0);
+        const double c = cr * (den + q * num);
+        g.cosinc = flip ? -c : c;
+        if constexpr (NEED_SH) g.sh = __builtin_sqrt(0.5 * (1.0 - g.cs));
+        if (__builtin_expect(!ok, 0)) g = panel_geom_literal(TRACK, sa, ca, az, slope, sazim);
+    }
+    return g;
+}
+
 // irradiation on the tilted surface + Huld panel model, from sin/cos of the solar altitude and
 // cos(surface_azimuth - sun_azimuth)   (irradiation.py:214-226, solar_panel_model.py:22-41)
+// from the clipped cos(incidence) and the (1 +- cos(surface slope)) / 2 factors to the converter's output
 template <int TAIL = kTailHuld>
-__device__ __forceinline__ double pv_tail(double direct, double diffuse, double influx, double toa, double alb,
-                                          double tmp, double sa, double ca, double cosd, const PvOri &o,
-                                          const PvConst &k) {
-    // orientation.py:114-117,188
-    double cosinc = o.ss * ca * cosd + o.cs * sa;
-    cosinc = np_max(cosinc, 0.0);
+__device__ __forceinline__ double pv_tail_core(double direct, double diffuse, double influx, double toa, double alb,
+                                               double tmp, double sa, double cosinc, double hp, double hm,
+                                               double sh3, const PvConst &k) {
+    struct {
+        double hp, hm, sh3;
+    } o{hp, hm, sh3};
     const double kk = fast_div(cosinc, sa);
     const double direct_t = kk * direct;
     double G;
@@ -74,7 +167,16 @@ __device__ __forceinline__ double pv_tail(double direct, double diffuse, double 
     return G_ * eff * k.inv_eff;
 }
 
+// fixed panel: cos(incidence) from the precomputed orientation factors (orientation.py:114-117,188)
 template <int TAIL = kTailHuld>
+__device__ __forceinline__ double pv_tail(double direct, double diffuse, double influx, double toa, double alb,
+                                          double tmp, double sa, double ca, double cosd, const PvOri &o,
+                                          const PvConst &k) {
+    const double cosinc = np_max(o.ss * ca * cosd + o.cs * sa, 0.0);
+    return pv_tail_core<TAIL>(direct, diffuse, influx, toa, alb, tmp, sa, cosinc, o.hp, o.hm, o.sh3, k);
+}
+
+template <int TAIL = kTailHuld, int TRACK = ATL_TRACK_NONE>
 __device__ __forceinline__ double pv_cell(double dir, double dif, double toa, double alb, double tmp,
                                           double alt, double az, const PvOri &o, const PvConst &k) {
     // irradiation.py:206-208
@@ -89,6 +191,12 @@ __device__ __forceinline__ double pv_cell(double dir, double dif, double toa, do
     if (capped) return 0.0;  // G = 0 -> G_ = 0, eff -> 0 : 0*0*inv
     double sa, ca;
     lean_sincos(alt, &sa, &ca);
+    if constexpr (TRACK != ATL_TRACK_NONE) {  // tracker: panel_geom's closed forms, simple trigon model
+        const PanelGeom g = panel_geom<TRACK, false>(sa, ca, az, o.slope, o.saz);
+        const double cs = (TRACK != ATL_TRACK_DUAL) ? g.cs : sa;  // irradiation.py:216-219
+        return pv_tail_core<TAIL>(direct, diffuse, influx, toa, alb, tmp, sa, np_max(g.cosinc, 0.0), (1.0 + cs) / 2.0,
+                                  (1.0 - cs) / 2.0, 0.0, k);
+    }
     return pv_tail<TAIL>(direct, diffuse, influx, toa, alb, tmp, sa, ca, lean_cos(o.saz - az), o, k);
 }
 
@@ -124,10 +232,13 @@ __device__ __forceinline__ double pv_cell_sp(double dir, double dif, double toa,
 // TAIL: the Huld panel model (pv), the solar thermal collector or the plain tilted irradiation - the two
 // non-panel tails exist for stored solar angles without night skip (everything else of those calls
 // goes through the general kernel).
-template <bool SP, bool PC = false, bool SKIP = false, int TAIL = kTailHuld>
+// TRACK: a tracker (pv(tracking=...)) with the Huld panel, the simple trigon model, one orientation for
+// the whole grid and stored solar angles - the common way trackers are used; other mixes stay general.
+template <bool SP, bool PC = false, bool SKIP = false, int TAIL = kTailHuld, int TRACK = ATL_TRACK_NONE>
 struct PvConvT {
     static_assert(!(SP && SKIP), "night skip is implemented for stored solar angles");
     static_assert(TAIL == kTailHuld || (!SP && !SKIP), "the non-panel tails are built for stored angles, no skip");
+    static_assert(TRACK == ATL_TRACK_NONE || (!SP && !PC && !SKIP && TAIL == kTailHuld), "trackers: scalar orientation, Huld");
     atl_pv_inputs in;
     int64_t S;
     PvConst k;
@@ -155,6 +266,7 @@ struct PvConvT {
         r.hp = (1.0 + r.cs) / 2.0;
         r.hm = (1.0 - r.cs) / 2.0;
         r.saz = azimuth;
+        r.slope = slope;
         r.sh3 = 0.0;
         if constexpr (TAIL == kTailHuldHayDavies) {
             const double sh = lean_sin(slope / 2.0);
@@ -258,8 +370,8 @@ struct PvConvT {
             r.x = v0 ? pv_cell_sp(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.sd, q.cd, c.sl0, c.cl0, q.a.x, q.b.x, o0, a0, k) : 0.0;
             r.y = v1 ? pv_cell_sp(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.sd, q.cd, c.sl1, c.cl1, q.a.y, q.b.y, o1, a1, k) : 0.0;
         } else {
-            r.x = v0 ? pv_cell<TAIL>(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.a.x, q.b.x, o0, k) : 0.0;
-            r.y = v1 ? pv_cell<TAIL>(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.a.y, q.b.y, o1, k) : 0.0;
+            r.x = v0 ? pv_cell<TAIL, TRACK>(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.a.x, q.b.x, o0, k) : 0.0;
+            r.y = v1 ? pv_cell<TAIL, TRACK>(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.a.y, q.b.y, o1, k) : 0.0;
         }
         return r;
     }
@@ -268,8 +380,8 @@ using PvConv = PvConvT<false>;
 using PvConvSP = PvConvT<true>;
 template <class T>
 struct pv_is_sp : std::false_type {};
-template <bool PC, bool SK, int TL>
-struct pv_is_sp<PvConvT<true, PC, SK, TL>> : std::true_type {};
+template <bool PC, bool SK, int TL, int TR>
+struct pv_is_sp<PvConvT<true, PC, SK, TL, TR>> : std::true_type {};
 
 // ---------------------------------------------------------------------------------------
 // general pv converter: every option of convert_pv / convert_irradiation / convert_solar_thermal
@@ -284,97 +396,6 @@ struct PvxOpt {
     double c0, c1, t_store;
     double r_irr;  // Huld division kept literal here
 };
-
-// ---- SurfaceOrientation for the general kernel (orientation.py:113-188) -----------------------------
-// What the irradiation model needs of the panel geometry: cos(incidence) (before the clip at 0),
-// cos(surface slope) and - Hay-Davies only - sin(surface slope / 2).
-struct PanelGeom {
-    double cosinc, cs, sh;
-};
-
-// The reference's formulas as written (atan / asin / acos through libm).  Out of line: it only runs
-// for the degenerate arguments the closed forms below exclude.
-__device__ __noinline__ PanelGeom panel_geom_literal(int tracking, double sa, double ca, double az, double slope,
-                                                     double sazim) {
-    const double pi = 3.14159265358979323846;
-    double surface_slope, cosinc;
-    if (tracking == ATL_TRACK_HORIZONTAL) {
-        const double rotation = atan((ca / sa) * sin(az - sazim));
-        surface_slope = fabs(rotation);
-        const double surface_azimuth = sazim + asin(sin(rotation) / sin(surface_slope));
-        cosinc = cos(surface_slope) * sa + sin(surface_slope) * ca * cos(az - surface_azimuth);
-    } else {  // tilted_horizontal
-        const double tilt = slope;
-        double rotation = atan((ca * sin(az - sazim)) / (ca * cos(az - sazim) * sin(tilt) + sa * cos(tilt)));
-        surface_slope = acos(cos(rotation) * cos(tilt));
-        double ad = az - sazim;
-        ad = ad > pi ? ad - 2 * pi : ad;
-        ad = ad < -pi ? 2 * pi + ad : ad;
-        rotation = (rotation < 0 && ad > 0) ? rotation + pi : rotation;
-        rotation = (rotation > 0 && ad < 0) ? rotation - pi : rotation;
-        cosinc = cos(rotation) * (sin(tilt) * ca * cos(az - sazim) + cos(tilt) * sa) + sin(rotation) * ca * sin(az - sazim);
-    }
-    return PanelGeom{cosinc, cos(surface_slope), sin(surface_slope / 2.0)};
-}
-
-// The rotating trackers without inverse trigonometry.  With q = tan(rotation):
-//   cos(atan q) = 1 / sqrt(1 + q^2),  sin(atan q) = q / sqrt(1 + q^2)
-// horizontal:        slope' = |rotation|;  asin(sin r / sin|r|) = asin(+-1) = +-pi/2, so
-//                    cos(az - azimuth') = sgn(q) sin(az - azimuth)  and
-//                    cosinc = (sa + q ca sin d) / sqrt(1 + q^2);  q = 0 gives 0/0 = NaN in the reference
-// tilted_horizontal: cos(slope') = cos(r) cos(tilt) (the acos is only ever fed back into cos / sin(./2));
-//                    the +-pi correction of the rotation flips the sign of both cos(r) and sin(r)
-// The results agree with the literal sequence to a few ulp (tests: reference-generated vectors at
-// rtol 1e-10); arguments for which the closed forms are not valid (q zero / non-finite) take the
-// literal routine.
-template <int TRACK, bool NEED_SH>
-__device__ __forceinline__ PanelGeom panel_geom(double sa, double ca, double az, double slope, double sazim) {
-    const double pi = 3.14159265358979323846;
-    PanelGeom g;
-    g.sh = 0.0;
-    if constexpr (TRACK == ATL_TRACK_NONE) {
-        g.cs = lean_cos(slope);
-        g.cosinc = lean_sin(slope) * ca * lean_cos(sazim - az) + g.cs * sa;
-        if constexpr (NEED_SH) g.sh = lean_sin(slope / 2.0);
-    } else if constexpr (TRACK == ATL_TRACK_VERTICAL) {
-        g.cs = lean_cos(slope);
-        g.cosinc = lean_sin(slope) * ca + g.cs * sa;
-        if constexpr (NEED_SH) g.sh = lean_sin(slope / 2.0);
-    } else if constexpr (TRACK == ATL_TRACK_DUAL) {
-        g.cs = lean_cos(slope);  // the slope stays the panel's; the simple model substitutes sin(alt) itself
-        g.cosinc = 1.0;
-        if constexpr (NEED_SH) g.sh = lean_sin(slope / 2.0);
-    } else if constexpr (TRACK == ATL_TRACK_HORIZONTAL) {
-        const double sd = lean_sin(az - sazim);
-        const double q = guarded_div(ca, sa) * sd;
-        const bool ok = q != 0.0 && __builtin_fabs(q) < 0x1.0p500;  // false for NaN / inf too
-        const double w = __builtin_sqrt(__builtin_fma(q, q, 1.0));
-        const double cr = fast_rcp(w);  // w in [1, 2^500] whenever ok
-        g.cs = cr;
-        g.cosinc = cr * (sa + q * ca * sd);
-        if constexpr (NEED_SH) g.sh = __builtin_fabs(q) * fast_rcp(__builtin_sqrt(2.0 * w * (w + 1.0)));
-        if (__builtin_expect(!ok, 0)) g = panel_geom_literal(TRACK, sa, ca, az, slope, sazim);
-    } else {  // ATL_TRACK_TILTED_HORIZONTAL
-        double sd, cd;
-        lean_sincos(az - sazim, &sd, &cd);
-        const double st = lean_sin(slope), ct = lean_cos(slope);
-        const double num = ca * sd;
-        const double den = ca * cd * st + sa * ct;
-        const double q = guarded_div(num, den);
-        const bool ok = den != 0.0 && __builtin_fabs(q) < 0x1.0p500;
-        const double cr = fast_rcp(__builtin_sqrt(__builtin_fma(q, q, 1.0)));
-        g.cs = cr * ct;
-        double ad = az - sazim;
-        ad = ad > pi ? ad - 2 * pi : ad;
-        ad = ad < -pi ? 2 * pi + ad : ad;
-        const bool flip = (q < 0.0 && ad > 0.0) || (q > 0.0 && ad < 0.0);
-        const double c = cr * (den + q * num);
-        g.cosinc = flip ? -c : c;
-        if constexpr (NEED_SH) g.sh = __builtin_sqrt(0.5 * (1.0 - g.cs));
-        if (__builtin_expect(!ok, 0)) g = panel_geom_literal(TRACK, sa, ca, az, slope, sazim);
-    }
-    return g;
-}
 
 // TRACK / TRIGON are compile-time: they decide the instruction mix and the register footprint;
 // everything else is a wave-uniform run-time switch.

@@ -666,6 +666,7 @@ int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t 
     c->o.hp = (1.0 + c->o.cs) / 2.0;
     c->o.hm = (1.0 - c->o.cs) / 2.0;
     c->o.saz = p->azimuth;
+    c->o.slope = p->slope;
     {
         const double sh = sin(p->slope / 2.0);
         c->o.sh3 = sh * sh * sh;
@@ -686,7 +687,14 @@ int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t 
 template <class F>
 int pv_dispatch(const atl_pv_inputs *in, const atl_pv_params *p, bool allow_skip, F &&f) {
     const bool sp = !(in->d_solar_altitude || in->d_solar_azimuth), pc = p->d_cell_slope != nullptr;
-    if (p->trigon_model == ATL_TRIGON_OTHER)  // pv_needs_general() admits these only with stored angles + Huld
+    switch (p->tracking) {  // pv_needs_general() admits trackers only with stored angles, Huld, one orientation
+        case ATL_TRACK_HORIZONTAL: return f(PvConvT<false, false, false, kTailHuld, ATL_TRACK_HORIZONTAL>());
+        case ATL_TRACK_TILTED_HORIZONTAL: return f(PvConvT<false, false, false, kTailHuld, ATL_TRACK_TILTED_HORIZONTAL>());
+        case ATL_TRACK_VERTICAL: return f(PvConvT<false, false, false, kTailHuld, ATL_TRACK_VERTICAL>());
+        case ATL_TRACK_DUAL: return f(PvConvT<false, false, false, kTailHuld, ATL_TRACK_DUAL>());
+        default: break;
+    }
+    if (p->trigon_model == ATL_TRIGON_OTHER)  // ... and Hay-Davies only with stored angles + Huld
         return pc ? f(PvConvT<false, true, false, kTailHuldHayDavies>()) : f(PvConvT<false, false, false, kTailHuldHayDavies>());
     if (p->panel_model == ATL_PANEL_SOLAR_THERMAL)
         return pc ? f(PvConvT<false, true, false, kTailThermal>()) : f(PvConvT<false, false, false, kTailThermal>());
@@ -717,7 +725,12 @@ int pvx_dispatch(const atl_pv_params *p, F &&f) {
 }
 
 bool pv_needs_general(const atl_pv_inputs *in, const atl_pv_params *p) {
-    if (p->tracking != ATL_TRACK_NONE || in->d_influx != nullptr || in->d_albedo == nullptr) return true;
+    if (in->d_influx != nullptr || in->d_albedo == nullptr) return true;
+    if (p->tracking != ATL_TRACK_NONE)  // trackers: fast family for pv() with one orientation for the grid
+        return !(p->tracking >= ATL_TRACK_HORIZONTAL && p->tracking <= ATL_TRACK_DUAL &&
+                 p->trigon_model == ATL_TRIGON_SIMPLE && p->panel_model == ATL_PANEL_HULD &&
+                 p->irradiation == ATL_IRR_TOTAL && in->d_solar_altitude != nullptr && in->d_temperature != nullptr &&
+                 p->d_cell_slope == nullptr);
     if (p->trigon_model != ATL_TRIGON_SIMPLE)  // Hay-Davies: fast family only for pv() itself
         return !(p->trigon_model == ATL_TRIGON_OTHER && p->panel_model == ATL_PANEL_HULD &&
                  p->irradiation == ATL_IRR_TOTAL && in->d_solar_altitude != nullptr && in->d_temperature != nullptr);

@@ -48,15 +48,17 @@ for name, nbytes, fn in (
     ("getter + night early-out", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(night_skip=True))),
     ("getter, per-cell orientation (latitude_optimal)", 56, lambda: ctx.pv(inputs, percell, T, S, plan=plan, options=dict(night_skip=False))),
     ("in-kernel solar position (5 cubes + tables)", 40, lambda: ctx.pv(five, scal, T, S, plan=plan, solar_tables=tables)),
-    ("general kernel: tracking='horizontal'", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="horizontal"))),
-    ("general kernel: tracking='tilted_horizontal'", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="tilted_horizontal"))),
-    ("general kernel: tracking='vertical'", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="vertical"))),
-    ("general kernel: tracking='dual'", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="dual"))),
+    ("pv(tracking='horizontal') - fast family, closed-form tracker", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="horizontal"))),
+    ("pv(tracking='tilted_horizontal') - fast family", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="tilted_horizontal"))),
+    ("pv(tracking='vertical') - fast family (48 B/cell: azimuth not read)", 48, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="vertical"))),
+    ("pv(tracking='dual') - fast family (48 B/cell: azimuth not read)", 48, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="dual"))),
     ("irradiation() - fast family, no panel model (48 B/cell: temperature is not read)", 48,
      lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none"))),
     ("solar_thermal() - fast family, collector tail", 56,
      lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="solar_thermal", c0=0.8, c1=3.0, t_store_K=353.15))),
     ("pv(trigon_model='other') - fast family, Hay-Davies tail", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(trigon_model="other"))),
+    ("general kernel: tracking='horizontal' + Hay-Davies", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="horizontal", trigon_model="other"))),
+    ("general kernel: tracking='tilted_horizontal', per-cell orientation", 56, lambda: ctx.pv(inputs, percell, T, S, plan=plan, options=dict(tracking="tilted_horizontal"))),
     ("per-cell series out (no matrix)", 64, lambda: ctx.pv(inputs, scal, T, S)),
     ("per-cell time-mean (capacity factor map)", 56, lambda: ctx.pv(inputs, scal, T, S, time_agg="mean")),
 ):
