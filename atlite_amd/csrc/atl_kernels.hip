@@ -897,14 +897,18 @@ int wind_dispatch(const WindConvT<-1> &g, bool finite, F &&f) {
     const bool heights_ok = g.to_height > 0 && g.from_height > 0 && std::isfinite(g.to_height) &&
                             std::isfinite(g.from_height);
     if (!finite || (g.method == ATL_WIND_LOG && !heights_ok)) return f(g);
+    // unrolled knot search for the usual table sizes (make_wind pads to 16 / 32 / 128 knots)
+    auto sized = [&](auto method) {
+        constexpr int M = decltype(method)::value;
+        if (g.n_pad == 16) return f(wind_as<M, 4>(g));
+        if (g.n_pad == 32) return f(wind_as<M, 5>(g));
+        if (g.n_pad == 128) return f(wind_as<M, 7>(g));
+        return f(wind_as<M>(g));
+    };
     switch (g.method) {
-        case ATL_WIND_LOG:  // the default method: unrolled knot search for the usual table sizes
-            if (g.n_pad == 16) return f(wind_as<ATL_WIND_LOG, 4>(g));
-            if (g.n_pad == 32) return f(wind_as<ATL_WIND_LOG, 5>(g));
-            if (g.n_pad == 128) return f(wind_as<ATL_WIND_LOG, 7>(g));
-            return f(wind_as<ATL_WIND_LOG>(g));
-        case ATL_WIND_POWER: return f(wind_as<ATL_WIND_POWER>(g));
-        default: return f(wind_as<ATL_WIND_NONE>(g));
+        case ATL_WIND_LOG: return sized(std::integral_constant<int, ATL_WIND_LOG>());
+        case ATL_WIND_POWER: return sized(std::integral_constant<int, ATL_WIND_POWER>());
+        default: return sized(std::integral_constant<int, ATL_WIND_NONE>());
     }
 }
 
