@@ -224,6 +224,8 @@ SIGNATURES = {
     "atl_allgather_time": (_i, [_vp, _vp, _i64, _i64, _vp, _i64]),
     "atl_allreduce_sum": (_i, [_vp, _vp, _i64]),
     "atl_math_probe": (_i, [_vp, _i, _vp, _i64, _vp]),
+    "atl_math_probe_host": (_i, [_i, _vp, _i64, _vp]),
+    "atl_wind_interp_host": (_i, [_vp, _vp, _i, _vp, _i64, _vp]),
     "atl_synth_field": (
         _i,
         [_vp, _i, C.c_uint64, C.c_uint64, _d, _d, _i, _i64, _i64, _vp],

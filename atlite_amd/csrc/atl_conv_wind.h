@@ -88,27 +88,7 @@ struct WindConvT {
         }
     }
     __device__ __forceinline__ double interp(double x, const double *lds) const {
-        const double *V = lds;
-        const double *K = lds + n_pad;
-        const double vmin = V[0], vmax = V[n_knots - 1];
-        double xc = x > vmax ? vmax : x;
-        xc = xc < vmin ? vmin : xc;  // NaN stays NaN
-        int j = 0;
-        if constexpr (STEPS > 0) {
-#pragma unroll
-            for (int s = STEPS - 1; s >= 0; --s) {
-                const int cand = j + (1 << s);
-                j = (V[cand] <= xc) ? cand : j;
-            }
-        } else {
-            for (int step = n_pad >> 1; step > 0; step >>= 1) {
-                const int cand = j + step;
-                j = (V[cand] <= xc) ? cand : j;
-            }
-        }
-        const double2 k0 = *reinterpret_cast<const double2 *>(K + 4 * j);
-        const double sl = K[4 * j + 2];
-        return __builtin_fma(sl, xc - k0.x, k0.y);
+        return interp_padded<STEPS>(lds, n_knots, n_pad, x);  // atl_math.h (shared with the host probe)
     }
     // literal numpy/_core/src/multiarray/compiled_base.c arr_interp (any table)
     __device__ __noinline__ double interp_generic(double x, const double *lds) const {

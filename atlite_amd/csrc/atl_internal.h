@@ -87,6 +87,47 @@ __host__ __device__ inline TileLane tile_lane_cells(int64_t X, int64_t Y, int32_
     return t;
 }
 
+// ---- wind power-curve table (host) ---------------------------------------------------------------------
+// Padded size of a table of n knots: the sizes with an unrolled search are 16, 32 and 128 (a power of two
+// > n in any case, so that V[n..n_pad) = +inf terminates every probe sequence).
+inline int wind_table_pad(int n) {
+    int n_pad = n < 16 ? 16 : n < 32 ? 32 : 128;
+    while (n_pad <= n) n_pad *= 2;
+    return n_pad;
+}
+
+// tbl = V[n_pad] | K[n_pad][4] = {V[j], F[j], slope[j], 0}, the layout interp_padded() (atl_math.h) reads.
+// Returns the number of knots in the table (-1 if V is not non-decreasing) and its padded size;
+// *finite = every knot, value and slope is finite.  A REPEATED FIRST knot gets a guard knot one ulp
+// below it carrying F[0]: np.interp answers F[0] left of the table but the upper duplicate's value AT the
+// knot, and the clamped search could not tell the two apart otherwise.
+inline int wind_table_build(const double *V, const double *F, int n, std::vector<double> &tbl, int *n_pad_out,
+                            bool *finite) {
+    std::vector<double> v(V, V + n), f(F, F + n);
+    for (int i = 1; i < n; ++i)
+        if (!(v[size_t(i)] >= v[size_t(i - 1)])) return -1;
+    if (n >= 2 && v[1] == v[0] && __builtin_isfinite(v[0])) {
+        v.insert(v.begin(), __builtin_nextafter(v[0], -__builtin_inf()));
+        f.insert(f.begin(), f[0]);
+        ++n;
+    }
+    const int n_pad = wind_table_pad(n);
+    tbl.assign(size_t(5) * size_t(n_pad), 0.0);
+    *finite = true;
+    for (int i = 0; i < n_pad; ++i) tbl[size_t(i)] = __builtin_inf();
+    for (int i = 0; i < n; ++i) {
+        tbl[size_t(i)] = v[size_t(i)];
+        double *k = &tbl[size_t(n_pad) + 4 * size_t(i)];
+        k[0] = v[size_t(i)];
+        k[1] = f[size_t(i)];
+        // slope as numpy precomputes it; only the upper one of repeated knots is ever selected
+        k[2] = (i + 1 < n && v[size_t(i + 1)] > v[size_t(i)]) ? (f[size_t(i + 1)] - f[size_t(i)]) / (v[size_t(i + 1)] - v[size_t(i)]) : 0.0;
+        *finite = *finite && __builtin_isfinite(k[0]) && __builtin_isfinite(k[1]) && __builtin_isfinite(k[2]);
+    }
+    if (n_pad_out) *n_pad_out = n_pad;
+    return n;
+}
+
 inline int64_t tile_columns(int64_t X, int64_t Y, int w2_log2) {
     const int w = 2 << w2_log2;
     const int64_t max_shift = (Y > 1 && X % 16 != 0) ? 15 : 0;

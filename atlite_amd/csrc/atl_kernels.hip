@@ -813,25 +813,12 @@ int make_wind(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p,
                 "atl_wind: method needs roughness / wnd_shear_exp (wind.py:94-98,106-110)");
     ATL_REQUIRE(p->n_knots >= 1 && p->n_knots <= kMaxKnots && p->h_V && p->h_POWn,
                 "atl_wind: power curve needs 1..%d knots", kMaxKnots);
-    const int n = p->n_knots;
-    // power of two > n: V[n..n_pad) = +inf; the sizes with an unrolled search are 16, 32 and 128
-    int n_pad = n < 16 ? 16 : n < 32 ? 32 : 128;
-    while (n_pad <= n) n_pad *= 2;
-    std::vector<double> tbl(size_t(5 * n_pad), 0.0);
+    std::vector<double> tbl;
     bool finite = true;
-    for (int i = 0; i < n_pad; ++i) tbl[i] = std::numeric_limits<double>::infinity();
-    for (int i = 0; i < n; ++i) {
-        ATL_REQUIRE(i == 0 || p->h_V[i] >= p->h_V[i - 1],
-                    "wind speed 'V' in the turbine config is expected to be increasing");
-        tbl[i] = p->h_V[i];
-        double *k = &tbl[size_t(n_pad) + 4 * size_t(i)];
-        k[0] = p->h_V[i];
-        k[1] = p->h_POWn[i];
-        // slope as numpy precomputes it; only the upper one of repeated knots is ever selected
-        k[2] = (i + 1 < n && p->h_V[i + 1] > p->h_V[i]) ? (p->h_POWn[i + 1] - p->h_POWn[i]) / (p->h_V[i + 1] - p->h_V[i])
-                                                        : 0.0;
-        finite = finite && std::isfinite(k[0]) && std::isfinite(k[1]) && std::isfinite(k[2]);
-    }
+    int n_pad = 0;
+    const int n = wind_table_build(p->h_V, p->h_POWn, p->n_knots, tbl, &n_pad, &finite);
+    ATL_REQUIRE(n > 0, "wind speed 'V' in the turbine config is expected to be increasing");
+    ATL_REQUIRE(n <= kMaxKnots, "atl_wind: power curve needs 1..%d knots", kMaxKnots);
     // pinned staging buffer: wait until the previous call's copy has left it, then enqueue the H2D
     // stream-ordered after any earlier kernel that still reads the device table
     if (ctx->table_pending) ATL_HIP_TRY(hipEventSynchronize(ctx->ev_table));

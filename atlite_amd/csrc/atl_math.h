@@ -15,17 +15,60 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Every routine is __host__ __device__: the kernels use the device instantiation (identical code to a
+// device-only build), atl_math_probe_host() runs the SAME source on the CPU, so `pytest -m "not gpu"`
+// checks the polynomials, reductions and special-case handling without a GPU.  Only the hardware
+// seeds differ on the host: 1/b for v_rcp_f64 (the Newton steps still run), memcpy for the
+// hi/lo-word intrinsics.
+#define ATL_HD __host__ __device__
+
 namespace atl {
 
-__device__ __forceinline__ double fast_rcp(double b) {
-    double y = __builtin_amdgcn_rcp(b);  // v_rcp_f64: ~2^-25 relative
+ATL_HD __forceinline__ double rcp_seed(double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(b);  // v_rcp_f64: ~2^-25 relative
+#else
+    return 1.0 / b;
+#endif
+}
+ATL_HD __forceinline__ int dbl_hi(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __double2hiint(x);
+#else
+    unsigned long long u;
+    __builtin_memcpy(&u, &x, 8);
+    return int(u >> 32);
+#endif
+}
+ATL_HD __forceinline__ int dbl_lo(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __double2loint(x);
+#else
+    unsigned long long u;
+    __builtin_memcpy(&u, &x, 8);
+    return int(u & 0xffffffffu);
+#endif
+}
+ATL_HD __forceinline__ double dbl_make(int hi, int lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hiloint2double(hi, lo);
+#else
+    const unsigned long long u = (static_cast<unsigned long long>(static_cast<unsigned>(hi)) << 32) | static_cast<unsigned>(lo);
+    double x;
+    __builtin_memcpy(&x, &u, 8);
+    return x;
+#endif
+}
+
+ATL_HD __forceinline__ double fast_rcp(double b) {
+    double y = rcp_seed(b);
     y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
     y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
     return y;
 }
 
 // a / b to ~1 ulp for normal, well-scaled operands (no denormal / overflow fix-ups)
-__device__ __forceinline__ double fast_div(double a, double b) {
+ATL_HD __forceinline__ double fast_div(double a, double b) {
     const double y = fast_rcp(b);
     const double q = a * y;
     const double r = __builtin_fma(-b, q, a);
@@ -35,7 +78,7 @@ __device__ __forceinline__ double fast_div(double a, double b) {
 // a / b through the reciprocal path when both operands sit comfortably inside the normal range,
 // IEEE division (zeros, infinities, NaN, denormals) otherwise: <= 1 ulp from the IEEE quotient,
 // identical special-case behaviour.  The slow branch is out of the common path of a wave.
-__device__ __forceinline__ double guarded_div(double a, double b) {
+ATL_HD __forceinline__ double guarded_div(double a, double b) {
     const double ab = __builtin_fabs(b);
     const bool ok = ab > 0x1.0p-400 && ab < 0x1.0p400 && __builtin_fabs(a) < 0x1.0p400;
     double r = fast_div(ok ? a : 0.0, ok ? b : 1.0);
@@ -44,7 +87,7 @@ __device__ __forceinline__ double guarded_div(double a, double b) {
 }
 
 // reduce x to r in [-pi/4, pi/4] (+ tiny slack), quadrant in *q
-__device__ __forceinline__ double reduce_pio2(double x, int *q) {
+ATL_HD __forceinline__ double reduce_pio2(double x, int *q) {
     const double k = __builtin_rint(x * 6.36619772367581382433e-01);  // 2/pi
     // pi/2 split into three doubles; every FMA is exact before its single rounding
     double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);
@@ -54,7 +97,7 @@ __device__ __forceinline__ double reduce_pio2(double x, int *q) {
     return r;
 }
 
-__device__ __forceinline__ double poly_sin(double r, double z) {
+ATL_HD __forceinline__ double poly_sin(double r, double z) {
     double p = 1.58969099521155010221e-10;
     p = __builtin_fma(p, z, -2.50507602534068634195e-08);
     p = __builtin_fma(p, z, 2.75573137070700676789e-06);
@@ -64,7 +107,7 @@ __device__ __forceinline__ double poly_sin(double r, double z) {
     return __builtin_fma(r * z, p, r);
 }
 
-__device__ __forceinline__ double poly_cos(double z) {
+ATL_HD __forceinline__ double poly_cos(double z) {
     double p = -1.13596475577881948265e-11;
     p = __builtin_fma(p, z, 2.08757232129817482790e-09);
     p = __builtin_fma(p, z, -2.75573143513906633035e-07);
@@ -77,7 +120,7 @@ __device__ __forceinline__ double poly_cos(double z) {
     return w + (((1.0 - w) - hz) + z * z * p);
 }
 
-__device__ __forceinline__ void lean_sincos(double x, double *s, double *c) {
+ATL_HD __forceinline__ void lean_sincos(double x, double *s, double *c) {
     int q;
     const double r = reduce_pio2(x, &q);
     const double z = r * r;
@@ -91,7 +134,7 @@ __device__ __forceinline__ void lean_sincos(double x, double *s, double *c) {
     *c = ok ? cc : __builtin_nan("");
 }
 
-__device__ __forceinline__ double lean_cos(double x) {
+ATL_HD __forceinline__ double lean_cos(double x) {
     int q;
     const double r = reduce_pio2(x, &q);
     const double z = r * r;
@@ -100,7 +143,7 @@ __device__ __forceinline__ double lean_cos(double x) {
     return __builtin_fabs(x) < 0x1.0p30 ? cc : __builtin_nan("");
 }
 
-__device__ __forceinline__ double lean_sin(double x) {
+ATL_HD __forceinline__ double lean_sin(double x) {
     int q;
     const double r = reduce_pio2(x, &q);
     const double z = r * r;
@@ -110,14 +153,14 @@ __device__ __forceinline__ double lean_sin(double x) {
 }
 
 // log of a positive, normal, finite double: no special cases, integer exponent split
-__device__ __forceinline__ double log_core(double x) {
+ATL_HD __forceinline__ double log_core(double x) {
     // x = 2^e * m, m in [sqrt(1/2), sqrt(2)): shift the mantissa window by sqrt(2)/2 like fdlibm
-    unsigned hi = unsigned(__double2hiint(x));
-    const unsigned lo = unsigned(__double2loint(x));
+    unsigned hi = unsigned(dbl_hi(x));
+    const unsigned lo = unsigned(dbl_lo(x));
     hi += 0x3ff00000u - 0x3fe6a09eu;
     const int e = int(hi >> 20) - 0x3ff;
     hi = (hi & 0x000fffffu) + 0x3fe6a09eu;
-    const double m = __hiloint2double(int(hi), int(lo));
+    const double m = dbl_make(int(hi), int(lo));
     const double f = m - 1.0;
     const double s = f * fast_rcp(2.0 + f);
     const double z = s * s, w = z * z;
@@ -141,21 +184,22 @@ __device__ __forceinline__ double log_core(double x) {
 constexpr int kLogTabLo = 90, kLogTabHi = 182, kLogTabN = kLogTabHi - kLogTabLo + 1;  // 93 entries
 
 // fills tab[2*kLogTabN] (LDS); call from all threads of the block, then __syncthreads()
+ATL_HD __forceinline__ void log_table_entry(double *tab, int i) {
+    const double c = double(kLogTabLo + i) * 0x1.0p-7;
+    tab[2 * i] = 1.0 / c;  // IEEE division, once per block
+    tab[2 * i + 1] = (kLogTabLo + i == 128) ? 0.0 : log_core(c);
+}
 __device__ __forceinline__ void log_table_init(double *tab) {
-    for (int i = threadIdx.x; i < kLogTabN; i += blockDim.x) {
-        const double c = double(kLogTabLo + i) * 0x1.0p-7;
-        tab[2 * i] = 1.0 / c;  // IEEE division, once per block
-        tab[2 * i + 1] = (kLogTabLo + i == 128) ? 0.0 : log_core(c);
-    }
+    for (int i = threadIdx.x; i < kLogTabN; i += blockDim.x) log_table_entry(tab, i);
 }
 
-__device__ __forceinline__ double log_core_tab(double x, const double *tab) {
-    unsigned hi = unsigned(__double2hiint(x));
-    const unsigned lo = unsigned(__double2loint(x));
+ATL_HD __forceinline__ double log_core_tab(double x, const double *tab) {
+    unsigned hi = unsigned(dbl_hi(x));
+    const unsigned lo = unsigned(dbl_lo(x));
     hi += 0x3ff00000u - 0x3fe6a09eu;
     const int e = int(hi >> 20) - 0x3ff;
     hi = (hi & 0x000fffffu) + 0x3fe6a09eu;
-    const double m = __hiloint2double(int(hi), int(lo));           // [sqrt(1/2), sqrt(2))
+    const double m = dbl_make(int(hi), int(lo));           // [sqrt(1/2), sqrt(2))
     const double rm = __builtin_rint(m * 128.0);
     const int i = int(rm) - kLogTabLo;                               // 0 .. kLogTabN-1
     const double2 t = *reinterpret_cast<const double2 *>(tab + 2 * i);
@@ -175,13 +219,45 @@ __device__ __forceinline__ double log_core_tab(double x, const double *tab) {
 
 // zero, subnormal, negative, inf, NaN: full libm, kept out of line so that the hot loops carry
 // only a never-taken branch
-__device__ __noinline__ double log_rare(double x) { return log(x); }
+ATL_HD inline __noinline__ double log_rare(double x) { return log(x); }
 
-__device__ __forceinline__ double lean_log(double x) {
+ATL_HD __forceinline__ double lean_log(double x) {
     const bool ok = x >= 0x1.0p-1022 && x < __builtin_inf();
     double r = log_core(ok ? x : 1.0);
     if (__builtin_expect(!ok, 0)) r = log_rare(x);
     return r;
+}
+
+// ---- np.interp on a padded knot table (wind power curves) ---------------------------------------------
+// Table layout (built on the host by wind_table_build, atl_internal.h): V[n_pad] knots padded with +inf,
+// then K[n_pad][4] records {V[j], F[j], slope[j], 0}.  For a FINITE table
+//   xc = clamp(x, V[0], V[n-1]);  j = largest index with V[j] <= xc;  r = fma(slope[j], xc - V[j], F[j])
+// reproduces numpy's arr_interp exactly: F[j] on knots, F[0] / F[n-1] outside the range (+-inf too), NaN
+// for NaN, the upper one of repeated knots.  STEPS > 0: the table has exactly 2^STEPS entries and the
+// search is STEPS unrolled probes; STEPS = 0: run-time size.
+template <int STEPS>
+ATL_HD __forceinline__ double interp_padded(const double *tab, int n_knots, int n_pad, double x) {
+    const double *V = tab;
+    const double *K = tab + n_pad;
+    const double vmin = V[0], vmax = V[n_knots - 1];
+    double xc = x > vmax ? vmax : x;
+    xc = xc < vmin ? vmin : xc;  // NaN stays NaN
+    int j = 0;
+    if constexpr (STEPS > 0) {
+#pragma unroll
+        for (int s = STEPS - 1; s >= 0; --s) {
+            const int cand = j + (1 << s);
+            j = (V[cand] <= xc) ? cand : j;
+        }
+    } else {
+        for (int step = n_pad >> 1; step > 0; step >>= 1) {
+            const int cand = j + step;
+            j = (V[cand] <= xc) ? cand : j;
+        }
+    }
+    const double2 k0 = *reinterpret_cast<const double2 *>(K + 4 * j);
+    const double sl = K[4 * j + 2];
+    return __builtin_fma(sl, xc - k0.x, k0.y);
 }
 
 }  // namespace atl

@@ -10,6 +10,7 @@
 #include <numeric>
 
 #include "atl_internal.h"
+#include "atl_math.h"
 
 namespace atl {
 
@@ -525,6 +526,57 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_le
         return rc;
     }
     *out = a;
+    return ATL_OK;
+}
+
+int atl_math_probe_host(int fn, const double *h_in, int64_t n, double *h_out) {
+    ATL_REQUIRE(fn >= 0 && fn <= 6 && n >= 0 && (n == 0 || (h_in && h_out)), "atl_math_probe_host: bad argument");
+    double ltab[2 * kLogTabN];
+    for (int i = 0; i < kLogTabN; ++i) log_table_entry(ltab, i);
+    for (int64_t i = 0; i < n; ++i) {
+        const double x = h_in[i];
+        double r;
+        switch (fn) {
+            case 0: r = lean_sin(x); break;
+            case 1: r = lean_cos(x); break;
+            case 2: r = lean_log(x); break;
+            case 3: {
+                double sn, cs;
+                lean_sincos(x, &sn, &cs);
+                r = sn;
+                h_out[n + i] = cs;
+                break;
+            }
+            case 5: r = log_core_tab(x, ltab); break;
+            case 6: r = guarded_div(x, h_in[n + i]); break;
+            default: r = fast_div(x, h_in[n + i]); break;
+        }
+        h_out[i] = r;
+    }
+    return ATL_OK;
+}
+
+int atl_wind_interp_host(const double *h_V, const double *h_F, int n_knots, const double *h_x, int64_t m,
+                         double *h_out) {
+    ATL_REQUIRE(h_V && h_F && n_knots >= 1 && n_knots <= kMaxKnots && m >= 0 && (m == 0 || (h_x && h_out)),
+                "atl_wind_interp_host: bad argument");
+    std::vector<double> tbl;
+    bool finite = true;
+    int n_pad = 0;
+    n_knots = wind_table_build(h_V, h_F, n_knots, tbl, &n_pad, &finite);
+    ATL_REQUIRE(n_knots > 0, "wind speed 'V' in the turbine config is expected to be increasing");
+    if (!finite) {
+        set_error("atl_wind_interp_host: the branch-free search is defined for finite tables only");
+        return ATL_E_UNSUPPORTED;
+    }
+    for (int64_t i = 0; i < m; ++i) {
+        switch (n_pad) {  // the instantiations wind_dispatch() selects
+            case 16: h_out[i] = interp_padded<4>(tbl.data(), n_knots, n_pad, h_x[i]); break;
+            case 32: h_out[i] = interp_padded<5>(tbl.data(), n_knots, n_pad, h_x[i]); break;
+            case 128: h_out[i] = interp_padded<7>(tbl.data(), n_knots, n_pad, h_x[i]); break;
+            default: h_out[i] = interp_padded<0>(tbl.data(), n_knots, n_pad, h_x[i]); break;
+        }
+    }
     return ATL_OK;
 }
 

@@ -391,11 +391,20 @@ int atl_allreduce_sum(atl_comm *comm, double *d_buf, int64_t n);
  * fn 0 sin, 1 cos, 2 log: d_in (n) -> d_out (n);  3 sincos: d_out (2n) = sin | cos;
  * 4 fast_div: d_in (2n) = a | b -> d_out (n) = a / b;  5 table-driven log (positive normal x).
  */
+int atl_math_probe(atl_ctx *ctx, int fn, const double *d_in, int64_t n, double *d_out);
+/* the same routines (same source, compiled for the host) on host arrays: lets the CPU test suite check
+ * the polynomials, argument reductions and special cases without a GPU.  fn as above, plus 6 =
+ * guarded_div (a | b -> a / b with IEEE behaviour for zeros / infinities / NaN / denormals). */
+int atl_math_probe_host(int fn, const double *h_in, int64_t n, double *h_out);
+/* np.interp(x, V, F) through the padded-table search the wind kernels use (same source, host build):
+ * bit-for-bit numpy at knots (the upper one of repeated knots), outside the range, at +-inf and for NaN;
+ * inside an interval one FMA replaces numpy's multiply-add (<= 1 ulp apart). */
+int atl_wind_interp_host(const double *h_V, const double *h_F, int n_knots, const double *h_x, int64_t m,
+                         double *h_out);
 /* zlib-wrapped DEFLATE stream -> exactly dst_n bytes on the host.  which = 0: the library's fast
  * decoder alone (ATL_E_UNSUPPORTED if it declines the stream), 1: zlib alone, 2: the product
  * combination (fast, zlib on any doubt).  *ns = wall time of the decode.  Host only. */
 int atl_inflate_probe(const void *h_src, size_t src_n, void *h_dst, size_t dst_n, int which, int64_t *ns);
-int atl_math_probe(atl_ctx *ctx, int fn, const double *d_in, int64_t n, double *d_out);
 
 /* ---- synthetic ERA5-shaped inputs (bench/test tooling) ----------
  * Fills device cubes with a stateless splitmix64-hash field so that any (t, cell) slice can

@@ -332,3 +332,18 @@ def test_every_cell_owned_exactly_once(ctx, monkeypatch, tile):
         M = sp.csr_matrix(W)
         out = ctx.spmm(ctx.plan(M, row_len=X, cache=False), ctx.upload(D)).numpy()
         close(out, W @ D.T, atol_scale=1e-13)
+
+
+def test_wind_repeated_first_knot(ctx):
+    """np.interp answers F[0] left of the table but the upper duplicate's value AT a repeated first knot;
+    the table builder adds a guard knot one ulp below for that (found by the host-side interp test)."""
+    T, Y, X = 6, 2, 8
+    rng = np.random.default_rng(0)
+    V = np.array([3.0, 3.0, 5.0, 9.0, 12.0, 25.0, 25.0])
+    POW = np.array([0.1, 0.4, 0.9, 2.0, 3.0, 3.0, 0.0])
+    wnd = rng.uniform(0.0, 30.0, (T, Y * X))
+    wnd[0, :6] = [3.0, np.nextafter(3.0, 0), 2.0, 0.0, 25.0, 26.0]
+    out = ctx.wind(ctx.upload(wnd), None, V, POW / 3.0, 100.0, 100.0, None, T, Y * X).numpy()  # method None: no extrapolation
+    ref = np.interp(wnd, V, POW / 3.0)
+    np.testing.assert_allclose(out, ref, rtol=1e-14, atol=1e-16)
+    assert out[0, 0] == ref[0, 0] and out[0, 1] == ref[0, 1] == POW[0] / 3.0 and out[0, 2] == POW[0] / 3.0
