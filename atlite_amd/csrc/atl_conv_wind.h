@@ -90,29 +90,9 @@ struct WindConvT {
     __device__ __forceinline__ double interp(double x, const double *lds) const {
         return interp_padded<STEPS>(lds, n_knots, n_pad, x);  // atl_math.h (shared with the host probe)
     }
-    // literal numpy/_core/src/multiarray/compiled_base.c arr_interp (any table)
+    // literal numpy arr_interp (any table): atl_math.h, shared with the host probe
     __device__ __noinline__ double interp_generic(double x, const double *lds) const {
-        const double *V = lds;
-        const double *K = lds + n_pad;
-        const int n = n_knots;
-        if (dnan(x)) return x;
-        if (x < V[0]) return K[1];
-        if (x > V[n - 1]) return K[4 * (n - 1) + 1];
-        int j = 0;
-        for (int step = n_pad >> 1; step > 0; step >>= 1) {
-            const int cand = j + step;
-            if (V[cand] <= x) j = cand;
-        }
-        const double xj = K[4 * j], fj = K[4 * j + 1];
-        if (j == n - 1) return fj;
-        if (xj == x) return fj;
-        const double slope = (K[4 * (j + 1) + 1] - fj) / (K[4 * (j + 1)] - xj);
-        double r = slope * (x - xj) + fj;
-        if (dnan(r)) {
-            r = slope * (x - K[4 * (j + 1)]) + K[4 * (j + 1) + 1];
-            if (dnan(r) && fj == K[4 * (j + 1) + 1]) r = fj;
-        }
-        return r;
+        return interp_literal(lds, n_knots, n_pad, x);
     }
 #ifndef ATL_WIND_GROUP
 #define ATL_WIND_GROUP 4

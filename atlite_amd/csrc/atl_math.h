@@ -260,4 +260,30 @@ ATL_HD __forceinline__ double interp_padded(const double *tab, int n_knots, int 
     return __builtin_fma(sl, xc - k0.x, k0.y);
 }
 
+// literal numpy/_core/src/multiarray/compiled_base.c arr_interp, for tables that hold non-finite values
+// (same table layout; the slope is formed on the fly like numpy does when it has not precomputed it)
+ATL_HD __forceinline__ double interp_literal(const double *tab, int n_knots, int n_pad, double x) {
+    const double *V = tab;
+    const double *K = tab + n_pad;
+    const int n = n_knots;
+    if (x != x) return x;
+    if (x < V[0]) return K[1];
+    if (x > V[n - 1]) return K[4 * (n - 1) + 1];
+    int j = 0;
+    for (int step = n_pad >> 1; step > 0; step >>= 1) {
+        const int cand = j + step;
+        if (cand < n && V[cand] <= x) j = cand;  // cand < n: a real +inf knot must not run into the +inf padding
+    }
+    const double xj = K[4 * j], fj = K[4 * j + 1];
+    if (j == n - 1) return fj;
+    if (xj == x) return fj;
+    const double slope = (K[4 * (j + 1) + 1] - fj) / (K[4 * (j + 1)] - xj);
+    double r = slope * (x - xj) + fj;
+    if (r != r) {
+        r = slope * (x - K[4 * (j + 1)]) + K[4 * (j + 1) + 1];
+        if (r != r && fj == K[4 * (j + 1) + 1]) r = fj;
+    }
+    return r;
+}
+
 }  // namespace atl

@@ -565,11 +565,11 @@ int atl_wind_interp_host(const double *h_V, const double *h_F, int n_knots, cons
     int n_pad = 0;
     n_knots = wind_table_build(h_V, h_F, n_knots, tbl, &n_pad, &finite);
     ATL_REQUIRE(n_knots > 0, "wind speed 'V' in the turbine config is expected to be increasing");
-    if (!finite) {
-        set_error("atl_wind_interp_host: the branch-free search is defined for finite tables only");
-        return ATL_E_UNSUPPORTED;
-    }
     for (int64_t i = 0; i < m; ++i) {
+        if (!finite) {  // non-finite knots / values: the literal transcription (wind_dispatch's generic converter)
+            h_out[i] = interp_literal(tbl.data(), n_knots, n_pad, h_x[i]);
+            continue;
+        }
         switch (n_pad) {  // the instantiations wind_dispatch() selects
             case 16: h_out[i] = interp_padded<4>(tbl.data(), n_knots, n_pad, h_x[i]); break;
             case 32: h_out[i] = interp_padded<5>(tbl.data(), n_knots, n_pad, h_x[i]); break;

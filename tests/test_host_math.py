@@ -129,3 +129,26 @@ def test_interp_matches_numpy():
     bad = np.array([0.0, 2.0, 1.0])
     with pytest.raises(ValueError, match="increasing"):
         check(lib.atl_wind_interp_host(bad.ctypes.data, bad.ctypes.data, 3, bad.ctypes.data, 3, bad.ctypes.data))
+
+
+def test_interp_nonfinite_tables_literal_path():
+    """Tables holding inf / NaN take the literal transcription of numpy's arr_interp: identical results,
+    including numpy's NaN-repair rules (slope * dx = NaN -> evaluate from the right knot, equal values)."""
+    lib = _lib.load()
+    rng = np.random.default_rng(8)
+    for case in range(200):
+        n = int(rng.integers(2, 40))
+        V = np.sort(np.round(rng.random(n) * 30, 1))
+        F = rng.random(n)
+        k = rng.integers(0, n, size=int(rng.integers(1, 4)))
+        F[k] = rng.choice([np.inf, -np.inf, np.nan], size=len(k))
+        if rng.random() < 0.3:
+            V[-1] = np.inf
+        if rng.random() < 0.2:
+            V[0] = -np.inf
+        x = np.concatenate([V[np.isfinite(V)], rng.uniform(-5, 35, 300), [np.nan, np.inf, -np.inf]])
+        out = np.empty_like(x)
+        check(lib.atl_wind_interp_host(V.ctypes.data, F.ctypes.data, n, x.ctypes.data, len(x), out.ctypes.data))
+        with np.errstate(all="ignore"):
+            ref = np.interp(x, V, F)
+        assert np.array_equal(out, ref, equal_nan=True), (case, V, F, x[~((out == ref) | (np.isnan(out) & np.isnan(ref)))][:5])
