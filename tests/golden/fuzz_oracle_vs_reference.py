@@ -36,6 +36,16 @@ orient = refshim.reference("atlite.pv.orientation")
 TRACK = [None, "horizontal", "tilted_horizontal", "vertical", "dual"]
 
 
+class MockCutout:  # as in the reference's test/test_aggregate_time.py:13-17
+    def __init__(self, data):
+        self.data = data
+        grid_coords = np.array([(xx, yy) for yy in data["y"].values for xx in data["x"].values])
+        self.grid = pd.DataFrame(grid_coords, columns=["x", "y"])
+
+
+MockCutout.convert_and_aggregate = conv.convert_and_aggregate
+
+
 def dataset(variables, time, x, y):
     coords = {"time": time, "y": y, "x": x}
     return xr.Dataset(
@@ -161,6 +171,38 @@ def main():
                 got = orc.convert_runoff(r, h if wh else None)
                 what = "runoff"
         compare(got, ref, f"case {case} ({T},{Y},{X}) {what}", stats)
+        # gateway algebra of convert_and_aggregate on the same case (runoff only: any cube does)
+        if fam == "runoff":
+            import scipy.sparse as sp
+
+            with warnings.catch_warnings(), np.errstate(all="ignore"):
+                warnings.simplefilter("ignore")
+                S = Y * X
+                agg = str(rng.choice(["matrix", "layout", "both"]))
+                tagg = [None, "sum", "mean"][int(rng.integers(3))]
+                pu = bool(rng.random() < 0.4)
+                M = None
+                if agg in ("matrix", "both"):
+                    M = sp.random(int(rng.integers(1, 6)), S, density=float(rng.choice([0.1, 0.5, 1.0])),
+                                  random_state=int(rng.integers(1 << 30)), format="csr")
+                    if M.nnz:
+                        M.data[rng.integers(0, M.nnz, size=max(1, M.nnz // 10))] = rng.choice([0.0, -1.5])
+                lay = None
+                if agg in ("layout", "both"):
+                    lay = rng.random((Y, X)) * 3
+                    lay[rng.random((Y, X)) < 0.2] = 0.0
+                cut = MockCutout(xds)
+                kw = dict(weight_with_height=wh, aggregate_time=tagg, per_unit=pu)
+                if M is not None:
+                    kw["matrix"] = M
+                if lay is not None:
+                    kw["layout"] = xr.DataArray(lay, dims=["y", "x"], coords={"y": y, "x": x})
+                gref = conv.runoff(cut, **kw)
+                gref = gref.values
+                gor, _ = orc.gateway(orc.convert_runoff(r, h if wh else None).reshape(T, S), M, lay, pu, tagg)
+                if gref.shape != np.shape(gor) and gref.T.shape == np.shape(gor):
+                    gref = gref.T
+            compare(gor, gref, f"case {case} gateway agg={agg} tagg={tagg} per_unit={pu}", stats)
     print(f"{n} cases, {stats['fails']} mismatches, worst error {stats['worst']:.3e} of the rtol 1e-10 / atol 1e-12 max allowance")
     return 1 if stats["fails"] else 0
 
