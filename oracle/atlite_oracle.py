@@ -21,7 +21,7 @@ solar position / runoff / temperatures, <= 5e-15 relative elsewhere).  The stand
 validated by the reference's own test/test_aggregate_time.py running green under it
 (tests/golden/run_reference_tests.py).  Beyond the fixed vectors, tests/golden/fuzz_oracle_vs_reference.py
 compares this module with the reference's code on random points of the option space with hostile values
-(830 cases: no mismatch, results identical bit for bit; log beside the script).  The reference ships no
+(1380 cases incl. the gateway algebra: no mismatch, results identical bit for bit; log beside the script).  The reference ships no
 numeric golden vectors of its own for this path.
 """
 
