@@ -38,7 +38,7 @@ struct PanelGeom {
 
 // The reference's formulas as written (atan / asin / acos through libm).  Out of line: it only runs
 // for the degenerate arguments the closed forms below exclude.
-__device__ __noinline__ PanelGeom panel_geom_literal(int tracking, double sa, double ca, double az, double slope,
+ATL_HD __noinline__ PanelGeom panel_geom_literal(int tracking, double sa, double ca, double az, double slope,
                                                      double sazim) {
     const double pi = 3.14159265358979323846;
     double surface_slope, cosinc;
@@ -72,7 +72,7 @@ __device__ __noinline__ PanelGeom panel_geom_literal(int tracking, double sa, do
 // rtol 1e-10); arguments for which the closed forms are not valid (q zero / non-finite) take the
 // literal routine.
 template <int TRACK, bool NEED_SH>
-__device__ __forceinline__ PanelGeom panel_geom(double sa, double ca, double az, double slope, double sazim) {
+ATL_HD __forceinline__ PanelGeom panel_geom(double sa, double ca, double az, double slope, double sazim) {
     const double pi = 3.14159265358979323846;
     PanelGeom g;
     g.sh = 0.0;
@@ -124,7 +124,7 @@ __device__ __forceinline__ PanelGeom panel_geom(double sa, double ca, double az,
 // cos(surface_azimuth - sun_azimuth)   (irradiation.py:214-226, solar_panel_model.py:22-41)
 // from the clipped cos(incidence) and the (1 +- cos(surface slope)) / 2 factors to the converter's output
 template <int TAIL = kTailHuld>
-__device__ __forceinline__ double pv_tail_core(double direct, double diffuse, double influx, double toa, double alb,
+ATL_HD __forceinline__ double pv_tail_core(double direct, double diffuse, double influx, double toa, double alb,
                                                double tmp, double sa, double cosinc, double hp, double hm,
                                                double sh3, const PvConst &k) {
     struct {
@@ -169,7 +169,7 @@ __device__ __forceinline__ double pv_tail_core(double direct, double diffuse, do
 
 // fixed panel: cos(incidence) from the precomputed orientation factors (orientation.py:114-117,188)
 template <int TAIL = kTailHuld>
-__device__ __forceinline__ double pv_tail(double direct, double diffuse, double influx, double toa, double alb,
+ATL_HD __forceinline__ double pv_tail(double direct, double diffuse, double influx, double toa, double alb,
                                           double tmp, double sa, double ca, double cosd, const PvOri &o,
                                           const PvConst &k) {
     const double cosinc = np_max(o.ss * ca * cosd + o.cs * sa, 0.0);
@@ -177,7 +177,7 @@ __device__ __forceinline__ double pv_tail(double direct, double diffuse, double 
 }
 
 template <int TAIL = kTailHuld, int TRACK = ATL_TRACK_NONE>
-__device__ __forceinline__ double pv_cell(double dir, double dif, double toa, double alb, double tmp,
+ATL_HD __forceinline__ double pv_cell(double dir, double dif, double toa, double alb, double tmp,
                                           double alt, double az, const PvOri &o, const PvConst &k) {
     // irradiation.py:206-208
     const double direct = np_clip(dir, 0.0, toa);
@@ -204,7 +204,7 @@ __device__ __forceinline__ double pv_cell(double dir, double dif, double toa, do
 // pv/solar_position.py:100-114.  sin(alt) = s directly, cos(alt) = sqrt(1-s^2),
 // cos(az) = clip(.../cos(alt)), sin(az) = +-sqrt(1-cos^2 az) by the sign of the hour angle, so
 // cos(surface_az - az) needs no inverse trig at all.  The cut alt < thr becomes s < sin(thr).
-__device__ __forceinline__ double pv_cell_sp(double dir, double dif, double toa, double alb, double tmp,
+ATL_HD __forceinline__ double pv_cell_sp(double dir, double dif, double toa, double alb, double tmp,
                                              double sd, double cd, double sl, double cl, double h, double ch,
                                              const PvOri &o, const PvAz<true> &a, const PvConst &k) {
     const double direct = np_clip(dir, 0.0, toa);
@@ -260,7 +260,7 @@ struct PvConvT {
         bool no_cell;  // SKIP: this lane owns no cell at all (tile padding)
     };
     __device__ void block_init(double *) const {}
-    __device__ static PvOri make_ori(double slope, double azimuth) {
+    ATL_HD static PvOri make_ori(double slope, double azimuth) {
         PvOri r;
         lean_sincos(slope, &r.ss, &r.cs);
         r.hp = (1.0 + r.cs) / 2.0;
@@ -397,10 +397,24 @@ struct PvxOpt {
     double r_irr;  // Huld division kept literal here
 };
 
+// host: the constant blocks the converters carry, from the C-ABI parameter struct
+inline PvConst pv_const_of(const atl_pv_params *p) {
+    return PvConst{p->c_temp_amb, p->c_temp_irrad, p->r_tmod, 1.0 / p->r_irradiance, p->k_1, p->k_2,
+                   p->k_3,        p->k_4,          p->k_5,    p->k_6,                 p->inverter_efficiency,
+                   p->altitude_threshold, sin(p->altitude_threshold),
+                   p->st_c0, p->st_c1, p->st_t_store_K, p->irradiation};
+}
+inline PvxOpt pvx_opt_of(const atl_pv_params *p, bool has_influx, bool has_albedo) {
+    return PvxOpt{p->tracking, p->trigon_model, p->clearsky_model, p->irradiation, p->panel_model,
+                  has_influx ? 1 : 0, has_albedo ? 1 : 0,
+                  p->bof_A, p->bof_B, p->bof_C, p->bof_D, p->bof_NOCT, p->bof_Tstd, p->bof_Tamb, p->bof_Intc, p->bof_ta,
+                  p->bof_threshold, p->st_c0, p->st_c1, p->st_t_store_K, p->r_irradiance};
+}
+
 // TRACK / TRIGON are compile-time: they decide the instruction mix and the register footprint;
 // everything else is a wave-uniform run-time switch.
 template <int TRACK, int TRIGON>
-__device__ double pvx_cell(double dir, double dif, double infl, double toa, double albv, double outf, double tmp,
+ATL_HD double pvx_cell(double dir, double dif, double infl, double toa, double albv, double outf, double tmp,
                            double rh, double alt, double az, double slope, double sazim, const PvConst &k,
                            const PvxOpt &o) {
     const double nan = __builtin_nan("");

@@ -6,12 +6,12 @@
 // ---------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ bool dnan(double x) { return x != x; }
-__device__ __forceinline__ double fill0(double x) { return dnan(x) ? 0.0 : x; }
+ATL_HD __forceinline__ bool dnan(double x) { return x != x; }
+ATL_HD __forceinline__ double fill0(double x) { return dnan(x) ? 0.0 : x; }
 // numpy clip/maximum/minimum semantics: NaN in either operand propagates
-__device__ __forceinline__ double np_max(double a, double b) { return (a > b || dnan(a)) ? a : b; }
-__device__ __forceinline__ double np_min(double a, double b) { return (a < b || dnan(a)) ? a : b; }
-__device__ __forceinline__ double np_clip(double x, double lo, double hi) {
+ATL_HD __forceinline__ double np_max(double a, double b) { return (a > b || dnan(a)) ? a : b; }
+ATL_HD __forceinline__ double np_min(double a, double b) { return (a < b || dnan(a)) ? a : b; }
+ATL_HD __forceinline__ double np_clip(double x, double lo, double hi) {
     return np_min(np_max(x, lo), hi);
 }
 

@@ -657,10 +657,7 @@ int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t 
                 "atl_pv: d_cell_slope and d_cell_azimuth must be given together");
     c->in = *in;
     c->S = S;
-    c->k = PvConst{p->c_temp_amb, p->c_temp_irrad, p->r_tmod, 1.0 / p->r_irradiance, p->k_1, p->k_2,
-                   p->k_3,        p->k_4,          p->k_5,    p->k_6,                 p->inverter_efficiency,
-                   p->altitude_threshold, sin(p->altitude_threshold),
-                   p->st_c0, p->st_c1, p->st_t_store_K, p->irradiation};
+    c->k = pv_const_of(p);
     c->o.ss = sin(p->slope);
     c->o.cs = cos(p->slope);
     c->o.hp = (1.0 + c->o.cs) / 2.0;
@@ -786,13 +783,8 @@ int make_pvx(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t
                 "atl_pv: d_cell_slope and d_cell_azimuth must be given together");
     c->in = *in;
     c->S = S;
-    c->k = PvConst{p->c_temp_amb, p->c_temp_irrad, p->r_tmod, 1.0 / p->r_irradiance, p->k_1, p->k_2,
-                   p->k_3,        p->k_4,          p->k_5,    p->k_6,                 p->inverter_efficiency,
-                   p->altitude_threshold, sin(p->altitude_threshold)};
-    c->o = PvxOpt{p->tracking, p->trigon_model, p->clearsky_model, p->irradiation, p->panel_model,
-                  in->d_influx ? 1 : 0, in->d_albedo ? 1 : 0,
-                  p->bof_A, p->bof_B, p->bof_C, p->bof_D, p->bof_NOCT, p->bof_Tstd, p->bof_Tamb, p->bof_Intc, p->bof_ta,
-                  p->bof_threshold, p->st_c0, p->st_c1, p->st_t_store_K, p->r_irradiance};
+    c->k = pv_const_of(p);
+    c->o = pvx_opt_of(p, in->d_influx != nullptr, in->d_albedo != nullptr);
     c->slope = p->slope;
     c->azimuth = p->azimuth;
     c->cell_slope = p->d_cell_slope;

@@ -12,6 +12,18 @@
 #include "atl_internal.h"
 #include "atl_math.h"
 
+// The pv converter math (free functions of atl_conv_pv.h) is __host__ __device__; included here the
+// way atl_kernels.hip includes it, so that atl_pv_probe_host() runs the kernels' own source on the CPU.
+#ifndef ATL_PV_GROUP
+#define ATL_PV_GROUP 1
+#endif
+namespace {
+using namespace atl;
+#include "atl_device_util.h"
+#include "atl_conv_basic.h"
+#include "atl_conv_pv.h"
+}  // namespace
+
 namespace atl {
 
 static thread_local char g_err[512] = "";
@@ -92,6 +104,19 @@ int64_t tile_of_cell(const Layout &L, int64_t cell, int32_t *local) {
     return ty * tile_columns(L.X, L.Y, L.w2_log2) + tx;
 }
 }  // namespace atl
+
+// pv_cell<TAIL, TRACK> / pvx_cell<TRACK, TRIGON> for run-time option codes
+template <class F>
+static int pv_probe_switch(int tracking, F &&f) {
+    switch (tracking) {
+        case ATL_TRACK_NONE: return f(std::integral_constant<int, ATL_TRACK_NONE>());
+        case ATL_TRACK_HORIZONTAL: return f(std::integral_constant<int, ATL_TRACK_HORIZONTAL>());
+        case ATL_TRACK_TILTED_HORIZONTAL: return f(std::integral_constant<int, ATL_TRACK_TILTED_HORIZONTAL>());
+        case ATL_TRACK_VERTICAL: return f(std::integral_constant<int, ATL_TRACK_VERTICAL>());
+        case ATL_TRACK_DUAL: return f(std::integral_constant<int, ATL_TRACK_DUAL>());
+        default: set_error("atl_pv_probe_host: bad tracking code %d", tracking); return ATL_E_INVALID;
+    }
+}
 
 extern "C" {
 
@@ -578,6 +603,54 @@ int atl_wind_interp_host(const double *h_V, const double *h_F, int n_knots, cons
         }
     }
     return ATL_OK;
+}
+
+int atl_pv_probe_host(const atl_pv_params *p, int family, int64_t n, const double *const *h_in, double *h_out) {
+    ATL_REQUIRE(p && n >= 0 && h_in && (n == 0 || h_out), "atl_pv_probe_host: bad argument");
+    for (int k : {3, 8, 9, 10, 11}) ATL_REQUIRE(h_in[k], "atl_pv_probe_host: toa, altitude, azimuth and the panel angles are needed");
+    const double *dir = h_in[0], *dif = h_in[1], *infl = h_in[2], *toa = h_in[3], *alb = h_in[4], *outf = h_in[5],
+                 *tmp = h_in[6], *hum = h_in[7], *alt = h_in[8], *az = h_in[9], *slope = h_in[10], *pazim = h_in[11];
+    const PvConst k = pv_const_of(p);
+    auto at = [](const double *a, int64_t i) { return a ? a[i] : 0.0; };
+    if (family == 1) {  // the general kernel's per-cell routine
+        ATL_REQUIRE((infl != nullptr) != (dir != nullptr && dif != nullptr) || infl, "atl_pv_probe_host: need influx or direct + diffuse");
+        const PvxOpt o = pvx_opt_of(p, infl != nullptr, alb != nullptr);
+        const bool other = p->trigon_model == ATL_TRIGON_OTHER;
+        return pv_probe_switch(p->tracking, [&](auto tr) {
+            constexpr int TR = decltype(tr)::value;
+            for (int64_t i = 0; i < n; ++i) {
+                h_out[i] = other ? pvx_cell<TR, ATL_TRIGON_OTHER>(at(dir, i), at(dif, i), at(infl, i), toa[i], at(alb, i), at(outf, i),
+                                                                  at(tmp, i), at(hum, i), alt[i], az[i], slope[i], pazim[i], k, o)
+                                 : pvx_cell<TR, ATL_TRIGON_SIMPLE>(at(dir, i), at(dif, i), at(infl, i), toa[i], at(alb, i), at(outf, i),
+                                                                   at(tmp, i), at(hum, i), alt[i], az[i], slope[i], pazim[i], k, o);
+            }
+            return int(ATL_OK);
+        });
+    }
+    // the fast family: stored angles, direct / diffuse / albedo / temperature; tail and tracker from the options
+    ATL_REQUIRE(family == 0 && dir && dif && alb && tmp, "atl_pv_probe_host: the fast family needs direct, diffuse, albedo, temperature");
+    const int tail = p->trigon_model == ATL_TRIGON_OTHER         ? kTailHuldHayDavies
+                     : p->panel_model == ATL_PANEL_SOLAR_THERMAL ? kTailThermal
+                     : p->panel_model == ATL_PANEL_NONE          ? kTailIrradiation
+                                                                 : kTailHuld;
+    ATL_REQUIRE(p->tracking == ATL_TRACK_NONE || tail == kTailHuld, "atl_pv_probe_host: the fast family pairs trackers with the Huld tail");
+    auto run = [&](auto tl, auto tr) {
+        constexpr int TL = decltype(tl)::value, TR = decltype(tr)::value;
+        for (int64_t i = 0; i < n; ++i) {
+            const PvOri o = PvConvT<false, true, false, TL>::make_ori(slope[i], pazim[i]);
+            h_out[i] = pv_cell<TL, TR>(dir[i], dif[i], toa[i], alb[i], tmp[i], alt[i], az[i], o, k);
+        }
+        return int(ATL_OK);
+    };
+    if (p->tracking != ATL_TRACK_NONE)
+        return pv_probe_switch(p->tracking, [&](auto tr) { return run(std::integral_constant<int, kTailHuld>(), tr); });
+    using None = std::integral_constant<int, ATL_TRACK_NONE>;
+    switch (tail) {
+        case kTailHuldHayDavies: return run(std::integral_constant<int, kTailHuldHayDavies>(), None());
+        case kTailThermal: return run(std::integral_constant<int, kTailThermal>(), None());
+        case kTailIrradiation: return run(std::integral_constant<int, kTailIrradiation>(), None());
+        default: return run(std::integral_constant<int, kTailHuld>(), None());
+    }
 }
 
 int atl_agg_selfcheck(int64_t n_cells, int64_t row_len, int tile_w, int64_t *n_tiles, int64_t *n_owned,

@@ -396,6 +396,12 @@ int atl_math_probe(atl_ctx *ctx, int fn, const double *d_in, int64_t n, double *
  * the polynomials, argument reductions and special cases without a GPU.  fn as above, plus 6 =
  * guarded_div (a | b -> a / b with IEEE behaviour for zeros / infinities / NaN / denormals). */
 int atl_math_probe_host(int fn, const double *h_in, int64_t n, double *h_out);
+/* The pv conversion of n independent cells on the HOST through the kernels' own per-cell routines
+ * (same source, host build) - for the CPU test suite.  h_in: 12 arrays of n doubles (NULL = variable
+ * absent): influx_direct, influx_diffuse, influx, influx_toa, albedo, outflux, temperature, humidity,
+ * solar_altitude, solar_azimuth, panel slope [rad], panel azimuth [rad].  family 0: the fast kernel family
+ * (tail and tracker chosen from the options like the dispatcher does), 1: the general kernel's routine. */
+int atl_pv_probe_host(const atl_pv_params *p, int family, int64_t n, const double *const *h_in, double *h_out);
 /* np.interp(x, V, F) through the padded-table search the wind kernels use (same source, host build):
  * bit-for-bit numpy at knots (the upper one of repeated knots), outside the range, at +-inf and for NaN;
  * inside an interval one FMA replaces numpy's multiply-add (<= 1 ulp apart). */
