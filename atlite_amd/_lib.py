@@ -225,6 +225,7 @@ SIGNATURES = {
     "atl_allreduce_sum": (_i, [_vp, _vp, _i64]),
     "atl_math_probe": (_i, [_vp, _i, _vp, _i64, _vp]),
     "atl_math_probe_host": (_i, [_i, _vp, _i64, _vp]),
+    "atl_wind_probe_host": (_i, [C.POINTER(WindParams), _i64, _vp, _vp, _vp]),
     "atl_pv_probe_host": (_i, [C.POINTER(PvParams), _i, _i64, C.POINTER(_vp), _vp]),
     "atl_wind_interp_host": (_i, [_vp, _vp, _i, _vp, _i64, _vp]),
     "atl_synth_field": (

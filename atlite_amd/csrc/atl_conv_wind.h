@@ -40,7 +40,7 @@ struct WindConvT {
         for (int i = threadIdx.x; i < 5 * n_pad; i += blockDim.x) lds[i] = table[i];
         if constexpr (METHOD == ATL_WIND_LOG) log_table_init(lds + 5 * n_pad);
     }
-    __device__ Cell cell_setup(int64_t c0, bool v0, bool v1, const double *lds) const {
+    ATL_HD Cell cell_setup(int64_t c0, bool v0, bool v1, const double *lds) const {
         Cell c;
         c.aux.x = 0.0;
         c.aux.y = 0.0;
@@ -56,13 +56,13 @@ struct WindConvT {
         return c;
     }
     // wind.py:99-101 / :111, literally; used for the rare arguments the fast path excludes
-    __device__ __noinline__ double hub_speed_literal(double v, double z) const {
+    ATL_HD __noinline__ double hub_speed_literal(double v, double z) const {
         if (method == ATL_WIND_LOG) return v * (log(to_height / z) / log(from_height / z));
         if (method == ATL_WIND_POWER) return v * pow(to_height / from_height, z);
         return v;
     }
     // fast path: *rare is set when the literal formula must be used instead
-    __device__ __forceinline__ double hub_speed_fast(double v, double z, const Cell &c, bool *rare,
+    ATL_HD __forceinline__ double hub_speed_fast(double v, double z, const Cell &c, bool *rare,
                                                      const double *lds) const {
         if constexpr (METHOD == ATL_WIND_LOG) {
             // v * (log(to/z0) / log(from/z0))  =  v * (1 + log(to/from) / (log(from) - log(z0))):
@@ -87,11 +87,11 @@ struct WindConvT {
             return v;
         }
     }
-    __device__ __forceinline__ double interp(double x, const double *lds) const {
+    ATL_HD __forceinline__ double interp(double x, const double *lds) const {
         return interp_padded<STEPS>(lds, n_knots, n_pad, x);  // atl_math.h (shared with the host probe)
     }
     // literal numpy arr_interp (any table): atl_math.h, shared with the host probe
-    __device__ __noinline__ double interp_generic(double x, const double *lds) const {
+    ATL_HD __noinline__ double interp_generic(double x, const double *lds) const {
         return interp_literal(lds, n_knots, n_pad, x);
     }
 #ifndef ATL_WIND_GROUP
@@ -113,7 +113,7 @@ struct WindConvT {
         if (METHOD != ATL_WIND_NONE && !aux_static) r.z = ld2<VEC>(aux, slot * S, c0, c1);
         return r;
     }
-    __device__ __forceinline__ double2 compute(const Raw &q, bool v0, bool v1, const Cell &c,
+    ATL_HD __forceinline__ double2 compute(const Raw &q, bool v0, bool v1, const Cell &c,
                                                const double *lds) const {
         const double2 v = q.v, z = q.z;
         double2 r;

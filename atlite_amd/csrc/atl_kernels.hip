@@ -823,7 +823,9 @@ int make_wind(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p,
     c->aux = in->d_aux;
     c->S = S;
     c->aux_static = in->aux_is_static;
-    c->method = p->method;
+    // (to / from) ** shear with to == from is 1 whatever the shear exponent holds (pow(1, NaN) = 1, which
+    // exp(NaN * log 1) would not give): no extrapolation at all
+    c->method = (p->method == ATL_WIND_POWER && p->to_height == p->from_height) ? ATL_WIND_NONE : p->method;
     c->to_height = p->to_height;
     c->from_height = p->from_height;
     c->log_ratio = log(p->to_height / p->from_height);

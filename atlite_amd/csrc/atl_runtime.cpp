@@ -21,6 +21,7 @@ namespace {
 using namespace atl;
 #include "atl_device_util.h"
 #include "atl_conv_basic.h"
+#include "atl_conv_wind.h"
 #include "atl_conv_pv.h"
 }  // namespace
 
@@ -651,6 +652,58 @@ int atl_pv_probe_host(const atl_pv_params *p, int family, int64_t n, const doubl
         case kTailIrradiation: return run(std::integral_constant<int, kTailIrradiation>(), None());
         default: return run(std::integral_constant<int, kTailHuld>(), None());
     }
+}
+
+int atl_wind_probe_host(const atl_wind_params *p, int64_t n, const double *h_wnd, const double *h_aux, double *h_out) {
+    ATL_REQUIRE(p && n >= 0 && (n == 0 || (h_wnd && h_out)), "atl_wind_probe_host: bad argument");
+    ATL_REQUIRE(p->method == ATL_WIND_NONE || p->method == ATL_WIND_LOG || p->method == ATL_WIND_POWER,
+                "Interpolation method must be 'logarithmic' or 'power' (got code %d)", p->method);
+    ATL_REQUIRE(p->method == ATL_WIND_NONE || h_aux, "atl_wind_probe_host: method needs roughness / wnd_shear_exp");
+    ATL_REQUIRE(p->n_knots >= 1 && p->n_knots <= kMaxKnots && p->h_V && p->h_POWn, "atl_wind_probe_host: bad power curve");
+    std::vector<double> tbl;
+    bool finite = true;
+    int n_pad = 0;
+    const int nk = wind_table_build(p->h_V, p->h_POWn, p->n_knots, tbl, &n_pad, &finite);
+    ATL_REQUIRE(nk > 0, "wind speed 'V' in the turbine config is expected to be increasing");
+    // the "LDS" image of a block: power-curve table, then the log table
+    std::vector<double> lds(tbl.size() + 2 * size_t(kLogTabN));
+    memcpy(lds.data(), tbl.data(), tbl.size() * sizeof(double));
+    for (int i = 0; i < kLogTabN; ++i) log_table_entry(lds.data() + tbl.size(), i);
+    const int method = (p->method == ATL_WIND_POWER && p->to_height == p->from_height) ? ATL_WIND_NONE : p->method;  // make_wind
+    auto fill = [&](auto &c) {
+        c.wnd = h_wnd;
+        c.aux = h_aux;
+        c.S = n;
+        c.aux_static = 0;
+        c.method = method;
+        c.to_height = p->to_height;
+        c.from_height = p->from_height;
+        c.log_ratio = log(p->to_height / p->from_height);
+        c.table = nullptr;
+        c.n_knots = nk;
+        c.n_pad = n_pad;
+    };
+    auto run = [&](auto conv) {
+        fill(conv);
+        const auto cell = conv.cell_setup(0, true, true, lds.data());
+        for (int64_t i = 0; i < n; ++i) {
+            typename decltype(conv)::Raw q;
+            q.v.x = q.v.y = h_wnd[i];
+            q.z.x = q.z.y = h_aux ? h_aux[i] : 0.0;
+            h_out[i] = conv.compute(q, true, false, cell, lds.data()).x;
+        }
+        return int(ATL_OK);
+    };
+    const bool heights_ok = p->to_height > 0 && p->from_height > 0 && std::isfinite(p->to_height) && std::isfinite(p->from_height);
+    if (!finite || (method == ATL_WIND_LOG && !heights_ok)) return run(WindConvT<-1>());  // as wind_dispatch()
+    if (method == ATL_WIND_LOG) {
+        if (n_pad == 16) return run(WindConvT<ATL_WIND_LOG, 4>());
+        if (n_pad == 32) return run(WindConvT<ATL_WIND_LOG, 5>());
+        if (n_pad == 128) return run(WindConvT<ATL_WIND_LOG, 7>());
+        return run(WindConvT<ATL_WIND_LOG>());
+    }
+    if (method == ATL_WIND_POWER) return n_pad == 16 ? run(WindConvT<ATL_WIND_POWER, 4>()) : run(WindConvT<ATL_WIND_POWER>());
+    return n_pad == 32 ? run(WindConvT<ATL_WIND_NONE, 5>()) : run(WindConvT<ATL_WIND_NONE>());
 }
 
 int atl_agg_selfcheck(int64_t n_cells, int64_t row_len, int tile_w, int64_t *n_tiles, int64_t *n_owned,

@@ -402,6 +402,10 @@ int atl_math_probe_host(int fn, const double *h_in, int64_t n, double *h_out);
  * solar_altitude, solar_azimuth, panel slope [rad], panel azimuth [rad].  family 0: the fast kernel family
  * (tail and tracker chosen from the options like the dispatcher does), 1: the general kernel's routine. */
 int atl_pv_probe_host(const atl_pv_params *p, int family, int64_t n, const double *const *h_in, double *h_out);
+/* The wind conversion (hub-height extrapolation + power curve) of n independent cell-steps on the HOST
+ * through the wind converter's own routines (same source, host build; h_aux = roughness or shear exponent,
+ * NULL for ATL_WIND_NONE). */
+int atl_wind_probe_host(const atl_wind_params *p, int64_t n, const double *h_wnd, const double *h_aux, double *h_out);
 /* np.interp(x, V, F) through the padded-table search the wind kernels use (same source, host build):
  * bit-for-bit numpy at knots (the upper one of repeated knots), outside the range, at +-inf and for NaN;
  * inside an interval one FMA replaces numpy's multiply-add (<= 1 ulp apart). */

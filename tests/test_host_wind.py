@@ -1,0 +1,74 @@
+"""
+The wind converter's own routines on the HOST (atl_wind_probe_host: same source as the kernels, host
+build) against the oracle: every shipped turbine, smoothed curves, both extrapolation laws and the fast
+lane, with hostile wind speeds and roughness values (NaN, +-inf, zero, negative, subnormal, z0 equal to
+the measurement height) that must take the literal out-of-line formula.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import yaml
+
+from atlite_amd import _lib
+from atlite_amd._lib import check
+from atlite_amd.resource import get_windturbineconfig, windturbine_smooth
+from oracle import atlite_oracle as orc
+
+import os
+
+ROOT = os.path.dirname(os.path.dirname(__file__))
+NAMES = list(yaml.safe_load(open(f"{ROOT}/atlite_amd/resources/technologies.yaml"))["windturbine"])
+
+
+def probe(V, POWn, method, to_h, from_h, wnd, aux):
+    V = np.ascontiguousarray(V, dtype=np.float64)
+    POWn = np.ascontiguousarray(POWn, dtype=np.float64)
+    wp = _lib.WindParams({None: _lib.WIND_NONE, "logarithmic": _lib.WIND_LOG, "power": _lib.WIND_POWER}[method], float(to_h),
+                         float(from_h), len(V), V.ctypes.data_as(_lib.c_double_p), POWn.ctypes.data_as(_lib.c_double_p))
+    wnd = np.ascontiguousarray(wnd, dtype=np.float64)
+    out = np.empty_like(wnd)
+    a = np.ascontiguousarray(aux, dtype=np.float64) if aux is not None else None
+    check(_lib.load().atl_wind_probe_host(C.byref(wp), wnd.size, wnd.ctypes.data, a.ctypes.data if a is not None else None,
+                                          out.ctypes.data))
+    return out
+
+
+def allowance_error(got, ref):
+    scale = np.nanmax(np.abs(ref[np.isfinite(ref)])) if np.isfinite(ref).any() else 1.0
+    with np.errstate(all="ignore"):
+        err = np.abs(got - ref) / (1e-10 * np.abs(ref) + 1e-12 * max(scale, 1e-300))
+    same = (got == ref) | (np.isnan(got) & np.isnan(ref))
+    return float(np.where(np.isnan(np.where(same, 0.0, err)), np.inf, np.where(same, 0.0, err)).max())
+
+
+@pytest.mark.parametrize("method", ["logarithmic", "power", None])
+def test_host_wind_against_oracle(method):
+    rng = np.random.default_rng(11)
+    worst = 0.0
+    for name in NAMES + ["smooth:Vestas_V112_3MW", "smooth:Enercon_E101_3000kW"]:
+        tb = get_windturbineconfig(name.split(":")[-1])
+        if name.startswith("smooth:"):
+            tb = windturbine_smooth(tb, params=True)
+        V, POW, P = np.asarray(tb["V"], float), np.asarray(tb["POW"], float), float(tb["P"])
+        n = 6000
+        wnd = 14 * rng.random(n) ** 1.3
+        if method == "power":
+            aux = 0.05 + 0.3 * rng.random(n)
+            aux[rng.random(n) < 0.02] = rng.choice([np.nan, 0.0, -0.2, np.inf])
+        else:
+            aux = np.exp(np.log(1e-4) + rng.random(n) * np.log(5e4))
+            aux[rng.random(n) < 0.04] = rng.choice([0.0, -1.0, np.nan, 100.0, np.inf, 1e-320, 5e-324])
+        wnd[rng.random(n) < 0.03] = rng.choice([np.nan, 0.0, 25.0, 13.0, 1e3, np.inf, -np.inf, -1.0])
+        wnd[:len(V)] = V  # exact knot hits after extrapolation are rare; at least feed the knots
+        to_h = float(tb["hub_height"])
+        with np.errstate(all="ignore"):
+            if method is None:
+                ref = np.interp(wnd, V, POW / P)  # fast lane: the wind speed at hub height exists (wind.py:76-78)
+            else:
+                ref = orc.convert_wind(wnd, aux, V, POW, P, to_h, 100.0, method)
+        got = probe(V, POW / P, method, to_h, 100.0, wnd, aux if method else None)
+        e = allowance_error(got, ref)
+        assert e <= 1.0, (name, method, e)
+        worst = max(worst, e)
+    assert worst < 0.05
