@@ -283,3 +283,20 @@ def test_time_partition_properties():
         if n >= w * 2 * align:
             sizes = np.diff(e)
             assert sizes.max() - sizes.min() <= 2 * align
+
+
+def test_product_never_calls_the_host_probes():
+    """The host builds of the kernel math (atl_*_probe_host, atl_wind_interp_host, atl_agg_selfcheck,
+    atl_inflate_probe) are test entry points: the package only declares their signatures, no product
+    module calls them - there is no CPU path to fall back on."""
+    pkg = Path(__file__).resolve().parent.parent / "atlite_amd"
+    names = ("atl_math_probe_host", "atl_pv_probe_host", "atl_wind_probe_host", "atl_wind_interp_host", "atl_agg_selfcheck",
+             "atl_inflate_probe")
+    for py in pkg.rglob("*.py"):
+        text = py.read_text()
+        for n in names:
+            hits = [l for l in text.splitlines() if n in l]
+            if py.name == "_lib.py":
+                assert all(l.strip().startswith(f'"{n}"') for l in hits), (py, n, hits)  # the signature table only
+            else:
+                assert not hits, (py, n)
