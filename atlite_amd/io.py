@@ -229,6 +229,11 @@ def open_cutout(path, chunked=True):
     if not (yn and xn):
         raise ValueError(f"{path}: no y/x (or lat/lon) coordinate variables found; is this a cutout?")
     coords = {"y": f.read(yn), "x": f.read(xn)}
+    for k in ("y", "x"):
+        if len(coords[k]) > 1 and not np.all(np.diff(coords[k]) > 0):
+            raise NotImplementedError(
+                f"{path}: coordinate {k!r} is not ascending; atlite cutouts store x and y ascending "
+                "(atlite/gis.py:63-74) - re-save the dataset sorted, e.g. ds.sortby([\"y\", \"x\"])")
     if tn:
         units = f.attr(tn, "units")
         cal = f.attr(tn, "calendar")
