@@ -21,6 +21,21 @@
 // branch-free probes, so the searches of a group's 8 cells interleave and hide each other's LDS
 // latency; STEPS = 0 searches a table of run-time size in a loop (13 instructions and one exposed LDS
 // round trip per probe - measured 52 of the ~125 instructions per cell before the specialisation).
+// Out-of-line rare paths are FREE functions taking scalars by value: a __noinline__ member function
+// needs `this`, i.e. the whole converter struct spilled to a scratch frame by every thread at kernel
+// entry (80 B/lane of extra HBM writes in round 1's wind kernels).
+// wind.py:99-101 / :111, literally; used for the rare arguments the fast path excludes
+ATL_HD inline __noinline__ double wind_hub_speed_literal(int method, double to_height, double from_height, double v,
+                                                         double z) {
+    if (method == ATL_WIND_LOG) return v * (log(to_height / z) / log(from_height / z));
+    if (method == ATL_WIND_POWER) return v * pow(to_height / from_height, z);
+    return v;
+}
+// literal numpy arr_interp (any table): atl_math.h, shared with the host probe
+ATL_HD inline __noinline__ double wind_interp_generic(const double *lds, int n_knots, int n_pad, double x) {
+    return interp_literal(lds, n_knots, n_pad, x);
+}
+
 template <int METHOD, int STEPS = 0>
 struct WindConvT {
     const double *wnd;
@@ -55,11 +70,8 @@ struct WindConvT {
         if constexpr (METHOD == ATL_WIND_LOG) c.lf = log_core_tab(from_height, lds + 5 * n_pad);
         return c;
     }
-    // wind.py:99-101 / :111, literally; used for the rare arguments the fast path excludes
-    ATL_HD __noinline__ double hub_speed_literal(double v, double z) const {
-        if (method == ATL_WIND_LOG) return v * (log(to_height / z) / log(from_height / z));
-        if (method == ATL_WIND_POWER) return v * pow(to_height / from_height, z);
-        return v;
+    ATL_HD __forceinline__ double hub_speed_literal(double v, double z) const {
+        return wind_hub_speed_literal(method, to_height, from_height, v, z);
     }
     // fast path: *rare is set when the literal formula must be used instead
     ATL_HD __forceinline__ double hub_speed_fast(double v, double z, const Cell &c, bool *rare,
@@ -90,9 +102,8 @@ struct WindConvT {
     ATL_HD __forceinline__ double interp(double x, const double *lds) const {
         return interp_padded<STEPS>(lds, n_knots, n_pad, x);  // atl_math.h (shared with the host probe)
     }
-    // literal numpy arr_interp (any table): atl_math.h, shared with the host probe
-    ATL_HD __noinline__ double interp_generic(double x, const double *lds) const {
-        return interp_literal(lds, n_knots, n_pad, x);
+    ATL_HD __forceinline__ double interp_generic(double x, const double *lds) const {
+        return wind_interp_generic(lds, n_knots, n_pad, x);
     }
 #ifndef ATL_WIND_GROUP
 #define ATL_WIND_GROUP 4
