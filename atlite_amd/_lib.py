@@ -174,6 +174,7 @@ SIGNATURES = {
     "atl_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
     "atl_set_profiling": (_i, [_vp, _i]),
     "atl_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_float)]),
+    "atl_kernel_times": (_i, [_vp, C.POINTER(C.c_float), _i64, C.POINTER(_i64)]),
     "atl_agg_create": (_i, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(_vp)]),
     "atl_agg_destroy": (_i, [_vp]),
     "atl_agg_selfcheck": (_i, [_i64, _i64, _i, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),

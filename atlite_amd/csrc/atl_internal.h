@@ -152,9 +152,11 @@ struct atl_ctx {
     bool table_pending = false;
     // timing
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // atl_timer_*
-    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;  // dominant-kernel bracket
+    // dominant-kernel brackets: a ring of event pairs (atl_set_profiling(ctx, n)), so a benchmark loop
+    // can time every launch of a run without a host sync per step
+    std::vector<hipEvent_t> ev_ring;  // 2 * ring size: {start, stop} per slot
+    int64_t ring_count = 0;           // launches bracketed since profiling was enabled
     bool profiling = false;
-    bool have_kernel_time = false;
     int n_cu = 256;
     // file / narrow-dtype ingest (atl_ingest.hip): staging buffers, created on first use
     void *ingest = nullptr;

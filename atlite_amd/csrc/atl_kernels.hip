@@ -477,13 +477,17 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 struct KernelBracket {
     atl_ctx *ctx;
+    size_t slot = 0;
     explicit KernelBracket(atl_ctx *c) : ctx(c) {
-        if (ctx->profiling) (void)hipEventRecord(ctx->ev_k0, ctx->stream);
+        if (ctx->profiling) {
+            slot = size_t(ctx->ring_count % int64_t(ctx->ev_ring.size() / 2));
+            (void)hipEventRecord(ctx->ev_ring[2 * slot], ctx->stream);
+        }
     }
     ~KernelBracket() {
         if (ctx->profiling) {
-            (void)hipEventRecord(ctx->ev_k1, ctx->stream);
-            ctx->have_kernel_time = true;
+            (void)hipEventRecord(ctx->ev_ring[2 * slot + 1], ctx->stream);
+            ++ctx->ring_count;
         }
     }
 };

@@ -168,8 +168,6 @@ int atl_create(int device, void *stream, atl_ctx **out) {
     }
     (void)hipEventCreate(&c->ev_t0);
     (void)hipEventCreate(&c->ev_t1);
-    (void)hipEventCreate(&c->ev_k0);
-    (void)hipEventCreate(&c->ev_k1);
     (void)hipEventCreateWithFlags(&c->ev_table, hipEventDisableTiming);
     if (hipMalloc(reinterpret_cast<void **>(&c->d_table), 5 * 2 * kMaxKnots * sizeof(double)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&c->h_table), 5 * 2 * kMaxKnots * sizeof(double), hipHostMallocDefault) !=
@@ -192,8 +190,7 @@ int atl_destroy(atl_ctx *ctx) {
     if (ctx->ev_table) (void)hipEventDestroy(ctx->ev_table);
     (void)hipEventDestroy(ctx->ev_t0);
     (void)hipEventDestroy(ctx->ev_t1);
-    (void)hipEventDestroy(ctx->ev_k0);
-    (void)hipEventDestroy(ctx->ev_k1);
+    for (hipEvent_t e : ctx->ev_ring) (void)hipEventDestroy(e);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     if (ctx->ingest && ctx->ingest_free) ctx->ingest_free(ctx->ingest);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
@@ -346,17 +343,46 @@ int atl_timer_stop(atl_ctx *ctx, float *ms) {
 
 int atl_set_profiling(atl_ctx *ctx, int enabled) {
     ATL_REQUIRE(ctx, "atl_set_profiling: ctx is NULL");
+    ATL_REQUIRE(enabled >= 0 && enabled <= (1 << 20), "atl_set_profiling: ring size %d out of range", enabled);
+    ATL_HIP_TRY(hipSetDevice(ctx->device));
+    ATL_HIP_TRY(hipStreamSynchronize(ctx->stream));  // no bracket of an earlier launch is in flight
+    const size_t want = 2 * size_t(enabled);
+    while (ctx->ev_ring.size() > want) {
+        (void)hipEventDestroy(ctx->ev_ring.back());
+        ctx->ev_ring.pop_back();
+    }
+    while (ctx->ev_ring.size() < want) {
+        hipEvent_t e = nullptr;
+        ATL_HIP_TRY(hipEventCreate(&e));
+        ctx->ev_ring.push_back(e);
+    }
     ctx->profiling = enabled != 0;
-    ctx->have_kernel_time = false;
+    ctx->ring_count = 0;
     return ATL_OK;
 }
 
 int atl_last_kernel_ms(atl_ctx *ctx, float *ms) {
     ATL_REQUIRE(ctx && ms, "atl_last_kernel_ms: bad argument");
-    ATL_REQUIRE(ctx->have_kernel_time,
+    ATL_REQUIRE(ctx->profiling && ctx->ring_count > 0,
                 "atl_last_kernel_ms: no profiled kernel (call atl_set_profiling(ctx,1) first)");
-    ATL_HIP_TRY(hipEventSynchronize(ctx->ev_k1));
-    ATL_HIP_TRY(hipEventElapsedTime(ms, ctx->ev_k0, ctx->ev_k1));
+    const size_t slot = size_t((ctx->ring_count - 1) % int64_t(ctx->ev_ring.size() / 2));
+    ATL_HIP_TRY(hipEventSynchronize(ctx->ev_ring[2 * slot + 1]));
+    ATL_HIP_TRY(hipEventElapsedTime(ms, ctx->ev_ring[2 * slot], ctx->ev_ring[2 * slot + 1]));
+    return ATL_OK;
+}
+
+int atl_kernel_times(atl_ctx *ctx, float *ms, int64_t cap, int64_t *n_out) {
+    ATL_REQUIRE(ctx && n_out && (ms || cap == 0) && cap >= 0, "atl_kernel_times: bad argument");
+    *n_out = 0;
+    if (!ctx->profiling || ctx->ring_count == 0) return ATL_OK;
+    const int64_t ring = int64_t(ctx->ev_ring.size() / 2);
+    const int64_t have = std::min(ctx->ring_count, ring), n = std::min(have, cap);
+    for (int64_t i = 0; i < n; ++i) {  // oldest of the n most recent first
+        const size_t slot = size_t((ctx->ring_count - n + i) % ring);
+        ATL_HIP_TRY(hipEventSynchronize(ctx->ev_ring[2 * slot + 1]));
+        ATL_HIP_TRY(hipEventElapsedTime(ms + i, ctx->ev_ring[2 * slot], ctx->ev_ring[2 * slot + 1]));
+    }
+    *n_out = n;
     return ATL_OK;
 }
 

@@ -207,7 +207,15 @@ class Context:
         return ms.value
 
     def set_profiling(self, on=True):
-        check(self.lib.atl_set_profiling(self.handle, 1 if on else 0))
+        """on: False / True, or an int n > 1 = keep the brackets of the n most recent launches."""
+        check(self.lib.atl_set_profiling(self.handle, int(on)))
+
+    def kernel_times(self, cap=1 << 16):
+        """Durations (ms) of the most recent profiled launches, oldest first (synchronises)."""
+        buf = (C.c_float * int(cap))()
+        n = C.c_int64()
+        check(self.lib.atl_kernel_times(self.handle, buf, int(cap), C.byref(n)))
+        return np.asarray(buf[: n.value], dtype=np.float64)
 
     def last_kernel_ms(self):
         ms = C.c_float()

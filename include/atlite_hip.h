@@ -94,6 +94,10 @@ int atl_timer_stop(atl_ctx *ctx, float *ms);
  * returns the duration of the most recent one. */
 int atl_set_profiling(atl_ctx *ctx, int enabled);
 int atl_last_kernel_ms(atl_ctx *ctx, float *ms);
+/* atl_set_profiling(ctx, n) with n > 1 keeps the brackets of the n most recent launches (a ring
+ * of event pairs); atl_kernel_times synchronises and returns up to cap of them, oldest first, so a
+ * benchmark loop times every launch of its timed region without a host sync per step. */
+int atl_kernel_times(atl_ctx *ctx, float *ms, int64_t cap, int64_t *n_out);
 
 /* ---- aggregation plan ----------------------------------------------------------------
  * Replaces: the scipy CSR matrix built in convert_and_aggregate (convert.py:213-251) and

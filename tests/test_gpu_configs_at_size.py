@@ -1,0 +1,259 @@
+"""
+GPU, BASELINE.json configs[2], [3], [4] at THEIR OWN sizes against the CPU oracle (configs[1] at size:
+tests/test_gpu_fullsize_properties.py).  The cubes are generated in HBM; the oracle cannot run a
+full cube in seconds, so each run is compared with it on >= 150 sampled time steps (night, sunrise,
+noon, a day boundary, the last step) and - for the time-reduced outputs - on sampled grid cells over
+ALL time steps.  Tolerance: rtol 1e-10, atol 1e-12 * max (north_star).
+
+  config 3  Cutout.wind('Vestas_V112_3MW') per cell, 8760 x 400 x 400: series AND the
+            aggregate_time="mean" capacity-factor map          (atlite/convert.py:634-662)
+  config 4  Cutout.pv() 8760 x 800 x 800, 500 shapes: first / middle / last 1095-step shard with
+            stored solar angles + the whole year with the in-kernel solar position, one launch
+            (atlite/convert.py:840-854)
+  config 5  Cutout.heat_demand() + Cutout.runoff(), 35040 x 400 x 400, 50 shapes, hour_shift != 0,
+            and day-aligned shards == the single launch         (atlite/convert.py:405-418, 1028-1034)
+"""
+import ctypes as C
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from atlite_amd import Cutout, Dataset, _lib, distributed, gis, solar, synthetic
+from atlite_amd._lib import check
+from atlite_amd.resource import get_windturbineconfig
+from oracle import atlite_oracle as orc
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+
+
+def close(got, ref, atol_scale=1e-12):
+    scale = float(np.nanmax(np.abs(ref))) if np.size(ref) else 0.0
+    np.testing.assert_allclose(got, ref, rtol=RTOL, atol=atol_scale * scale, equal_nan=True)
+
+
+def rows(dev, sel):
+    """Host copy of the selected time steps of a (T, S) DeviceArray."""
+    return np.stack([dev.slab(int(t), int(t) + 1).numpy()[0] for t in sel])
+
+
+def sample_steps(T, n_random=40, seed=0):
+    """Two whole days in winter, two in summer (every night / sunrise / noon / sunset and the day
+    boundaries between them), the last day incl. the last step, plus random steps: >= 150."""
+    rng = np.random.default_rng(seed)
+    mid = (T // 2) // 24 * 24
+    sel = np.concatenate([np.arange(0, 48), np.arange(mid, mid + 48), np.arange(T - 24, T),
+                          rng.integers(0, T, n_random)])
+    return np.unique(np.clip(sel, 0, T - 1))
+
+
+def tessellation_matrix(Y, X, n, kind="tessellation", seed=42):
+    x, y = synthetic.grid_coords(Y, X)
+    dx, dy = x[1] - x[0], y[1] - y[0]
+    b = (x[0] - dx / 2, y[0] - dy / 2, x[-1] + dx / 2, y[-1] + dy / 2)
+    polys = gis.random_tessellation(n, b, seed=seed) if kind == "tessellation" else gis.random_star_polygons(n, b, seed=seed)
+    return gis.compute_indicatormatrix(x, y, polys), polys
+
+
+# ------------------------------------------------------------------------------------------
+# config 3: wind per cell
+# ------------------------------------------------------------------------------------------
+def test_config3_wind_series_and_capacity_factor_map(ctx):
+    import torch
+
+    T, Y, X = 8760, 400, 400
+    S = Y * X
+    # torch owns the input cubes so that single grid cells can be pulled over all time steps
+    wnd_t = torch.empty((T, S), dtype=torch.float64, device="cuda:0")
+    z0_t = torch.empty((T, S), dtype=torch.float64, device="cuda:0")
+    wnd, z0 = ctx.asdevice(wnd_t), ctx.asdevice(z0_t)
+    check(ctx.lib.atl_synth_field(ctx.handle, _lib.SYN_RAYLEIGH, 42, 5, 8.0, 0.0, 0, T, S, wnd.ptr))
+    check(ctx.lib.atl_synth_field(ctx.handle, _lib.SYN_EXPLOG, 42, 6, 1e-3, 1.5e3, 0, T, S, z0.ptr))
+    ctx.sync()
+    x, y = synthetic.grid_coords(Y, X)
+    cutout = Cutout(Dataset({"wnd100m": wnd, "roughness": z0}, dict(time=synthetic.time_index(T), y=y, x=x)))
+    turb = get_windturbineconfig("Vestas_V112_3MW")
+    assert turb["hub_height"] != 100  # the extrapolation is exercised
+
+    series = cutout.wind(turbine="Vestas_V112_3MW", aggregate_time=None)  # (time, y, x) on the device
+    assert series.dims == ("time", "y", "x") and series.shape == (T, Y, X)
+    sdev = series.data.reshape(T, S)
+    sel = sample_steps(T)
+    assert len(sel) >= 150
+    ref = orc.convert_wind(rows(wnd, sel), rows(z0, sel), turb["V"], turb["POW"], turb["P"], turb["hub_height"], 100.0)
+    got = rows(sdev, sel)
+    close(got, ref)
+    assert got.min() >= 0.0 and got.max() <= 1.0 + 1e-12 and (got > 0.5).any() and (got == 0.0).any()
+
+    # capacity-factor map (a different kernel: per-cell time reduction)
+    cf = np.asarray(cutout.wind(turbine="Vestas_V112_3MW", aggregate_time="mean").values).reshape(S)
+    # (i) every cell against the host mean of the series the first kernel wrote
+    acc = np.zeros(S)
+    for t0 in range(0, T, 730):
+        acc += sdev.slab(t0, min(t0 + 730, T)).numpy().sum(axis=0)
+    np.testing.assert_allclose(cf, acc / T, rtol=1e-12)
+    # (ii) sampled cells (corners, a row boundary, random) over ALL 8760 steps against the oracle
+    rng = np.random.default_rng(1)
+    cells = np.unique(np.concatenate([[0, X - 1, X, S - X, S - 1], rng.integers(0, S, 300)]))
+    idx = torch.as_tensor(cells, device="cuda:0")
+    w_c, z_c = wnd_t[:, idx].cpu().numpy(), z0_t[:, idx].cpu().numpy()
+    ref_cf = orc.convert_wind(w_c, z_c, turb["V"], turb["POW"], turb["P"], turb["hub_height"], 100.0).mean(axis=0)
+    close(cf[cells], ref_cf)
+
+
+# ------------------------------------------------------------------------------------------
+# config 4: pv 800 x 800, 500 shapes
+# ------------------------------------------------------------------------------------------
+C4 = dict(T=8760, Y=800, X=800, N=500, TS=1095)
+ORI = dict(slope=np.radians(30.0), azimuth=np.radians(180.0))
+PARAMS = dict(H.CSI, **ORI)
+
+
+@pytest.fixture(scope="module")
+def c4_matrix():
+    M, _ = tessellation_matrix(C4["Y"], C4["X"], C4["N"])
+    return M
+
+
+def oracle_pv_agg(host, M, batch=8):
+    """orc.convert_pv + aggregate on (n, S) host rows, in batches (the oracle holds ~25 temporaries)."""
+    n = next(iter(host.values())).shape[0]
+    out = []
+    for a in range(0, n, batch):
+        ds = {k: v[a:a + batch] for k, v in host.items()}
+        out.append(orc.aggregate_matrix(orc.convert_pv(ds, H.CSI, ORI), M))
+    return np.concatenate(out, axis=1)
+
+
+@pytest.mark.parametrize("shard", [0, 4, 7])
+def test_config4_pv_shard_stored_angles(ctx, c4_matrix, shard):
+    """One rank's 1095-step shard of the 8-way time partition (first, middle, last)."""
+    T, Y, X, N, TS = (C4[k] for k in ("T", "Y", "X", "N", "TS"))
+    S = Y * X
+    edges = distributed.time_partition(T, 8)
+    assert edges[shard + 1] - edges[shard] == TS
+    inputs, _ = synthetic.pv_inputs(ctx, TS, Y, X, offset_hours=edges[shard])
+    plan = ctx.plan(c4_matrix, row_len=X)
+    info = plan.info()
+    assert info["n_rows"] == N and info["n_partial_rows"] > 3 * info["n_segments"] // 2  # rows beyond the register cache exist
+    out = ctx.pv(inputs, PARAMS, TS, S, plan=plan, options=dict(night_skip=False)).numpy()
+    skip = ctx.pv(inputs, PARAMS, TS, S, plan=plan, options=dict(night_skip=True)).numpy()
+    np.testing.assert_array_equal(skip, out)
+    sel = sample_steps(TS, n_random=0)[::2]  # 60 steps per shard, 180 over the three shards
+    host = {k: rows(inputs[k], sel) for k in synthetic.PV_VARS}
+    dark = (host["solar_altitude"] < np.radians(1.0)).all(axis=1)
+    # (the summer shard has no step that is dark everywhere: midnight sun in the north of the grid)
+    assert (~dark).any() and (dark.any() or shard == 4)
+    assert (out[:, sel[dark]] == 0.0).all()
+    close(out[:, sel], oracle_pv_agg(host, c4_matrix))
+    del inputs
+
+
+def test_config4_pv_full_year_in_kernel_solar_position(ctx, c4_matrix):
+    """The whole 8760 x 800 x 800 cutout resident on ONE device (5 cubes, 224 GB) in one launch."""
+    T, Y, X, N, TS = (C4[k] for k in ("T", "Y", "X", "N", "TS"))
+    S = Y * X
+    x, y = synthetic.grid_coords(Y, X)
+    five = [k for k in synthetic.PV_VARS if not k.startswith("solar_")]
+    big = {k: ctx.empty((T, S)) for k in five}
+    alt, az = ctx.empty((TS, S)), ctx.empty((TS, S))  # generator scratch (not read by the run)
+    for r in range(T // TS):
+        off = r * TS
+        t = synthetic.time_index(TS, "2013-01-01", off)
+        h, dec = solar.hour_angle(t, x, "-30min")
+        doy, hour = np.asarray(t.dayofyear, float), np.asarray(t.hour, float)
+        tseason = 283.15 + 12.0 * np.sin(2 * np.pi * (doy - 110.0) / 365.0) + 5.0 * np.sin(2 * np.pi * (hour - 9.0) / 24.0)
+        tabs = [ctx.upload(a) for a in (np.sin(dec), np.cos(dec), h, np.radians(y), tseason)]
+        s = _lib.SynthSolar(*[a.ptr for a in tabs], X, Y, 42 + 1000003 * off)
+        ptrs = [big[k].ptr + off * S * 8 for k in five] + [alt.ptr, az.ptr]
+        check(ctx.lib.atl_synth_pv_inputs(ctx.handle, C.byref(s), TS, S, *ptrs))
+        ctx.sync()
+    del alt, az
+    time_all = synthetic.time_index(T)
+    h, dec = solar.hour_angle(time_all, x, "-30min")
+    lat = np.radians(y)
+    tables = dict(sin_dec=np.sin(dec), cos_dec=np.cos(dec), h=h, cos_h=np.cos(h), sin_lat=np.sin(lat), cos_lat=np.cos(lat))
+    plan = ctx.plan(c4_matrix, row_len=X)
+    out = ctx.pv(big, PARAMS, T, S, plan=plan, solar_tables=tables).numpy()
+    assert out.shape == (N, T) and np.isfinite(out).all() and out.min() >= 0.0
+    sel = sample_steps(T, n_random=30)[::2]
+    assert len(sel) >= 75
+    host = {k: rows(big[k], sel) for k in five}
+    a_, z_ = orc.solar_position(time_all[sel], x, y, "-30min")
+    host["solar_altitude"], host["solar_azimuth"] = a_.reshape(len(sel), S), z_.reshape(len(sel), S)
+    close(out[:, sel], oracle_pv_agg(host, c4_matrix))
+    del big
+
+
+# ------------------------------------------------------------------------------------------
+# config 5: heat demand + runoff, ten years hourly
+# ------------------------------------------------------------------------------------------
+def test_config5_heat_demand_and_runoff(ctx):
+    T, Y, X, N = 35040, 400, 400, 50
+    S = Y * X
+    assert T * S > 2 ** 32  # every index path runs in its 64-bit range
+    inp = synthetic.heat_runoff_inputs(ctx, T, Y, X)
+    x, y = synthetic.grid_coords(Y, X)
+    time = synthetic.time_index(T, "2011-01-01")
+    M, polys = tessellation_matrix(Y, X, N)
+    cutout = Cutout(Dataset({"temperature": inp["temperature"], "runoff": inp["runoff"], "height": inp["height"]},
+                            dict(time=time, y=y, x=x)))
+    height = inp["height"].numpy()
+
+    # runoff through the public API, (shapes x time)
+    ro = cutout.runoff(matrix=M, aggregate_time=None)
+    assert ro.dims == ("dim_0", "time") and ro.shape == (N, T)
+    ro = np.asarray(ro.values)
+    sel = sample_steps(T)
+    ref = orc.aggregate_matrix(orc.convert_runoff(rows(inp["runoff"], sel), height[None, :]), M)
+    close(ro[:, sel], ref)
+
+    # heat demand with a non-zero hour shift: partial first and last day, 1461 bins
+    hs = 3.0
+    hd = cutout.heat_demand(matrix=M, threshold=15.0, a=1.3, constant=0.5, hour_shift=hs, aggregate_time=None)
+    day_ptr, labels = orc.day_groups(time, hs)
+    D = len(labels)
+    assert hd.shape == (N, D) and D == T // 24 + 1 and day_ptr[1] - day_ptr[0] == 21 and day_ptr[-1] - day_ptr[-2] == 3
+    assert (pd.DatetimeIndex(hd.coords["time"]) == labels).all()
+    hd = np.asarray(hd.values)
+    rng = np.random.default_rng(2)
+    days = np.unique(np.concatenate([[0, 1, D // 2, D - 2, D - 1], rng.integers(0, D, 8)]))
+    for d in days:
+        blk = inp["temperature"].slab(int(day_ptr[d]), int(day_ptr[d + 1])).numpy()
+        r = orc.convert_heat_demand(blk, np.array([0, blk.shape[0]]), threshold=15.0, a=1.3, constant=0.5)
+        ref_d = orc.aggregate_matrix(r, M)[:, 0]
+        np.testing.assert_allclose(hd[:, d], ref_d, rtol=RTOL, atol=1e-9 * 1.3)
+
+    # day-aligned shards (what 8 ranks run) reproduce the single launch bit for bit
+    plan = ctx.plan(M, row_len=X)
+    edges = distributed.time_partition(T, 8, align=24, first=int(day_ptr[1]))
+    assert all((e - day_ptr[1]) % 24 == 0 for e in edges[1:-1])
+    parts = []
+    for r in range(8):
+        t0, t1 = edges[r], edges[r + 1]
+        dp = day_ptr[(day_ptr >= t0) & (day_ptr <= t1)] - t0
+        parts.append(ctx.heat_demand(inp["temperature"].slab(t0, t1), dp, 15.0 + 273.15, 1.3, 0.5, t1 - t0, S,
+                                     plan=plan).numpy())
+    np.testing.assert_array_equal(np.concatenate(parts, axis=1), hd)
+    del inp
+
+
+# ------------------------------------------------------------------------------------------
+# config 2 with the shapes BASELINE names: overlapping star-convex random polygons
+# ------------------------------------------------------------------------------------------
+def test_config2_pv_star_polygons(ctx):
+    T, Y, X, N = 8760, 200, 200, 100
+    S = Y * X
+    inputs, _ = synthetic.pv_inputs(ctx, T, Y, X)
+    M, _ = tessellation_matrix(Y, X, N, kind="star")
+    per_cell = np.asarray((M > 0).sum(0)).ravel()
+    assert per_cell.max() >= 2 and per_cell.min() == 0  # overlaps and uncovered cells both occur
+    out = ctx.pv(inputs, PARAMS, T, S, plan=ctx.plan(M, row_len=X), options=dict(night_skip=False)).numpy()
+    sel = sample_steps(T)
+    host = {k: rows(inputs[k], sel) for k in synthetic.PV_VARS}
+    close(out[:, sel], oracle_pv_agg(host, M, batch=64))
+    skip = ctx.pv(inputs, PARAMS, T, S, plan=ctx.plan(M, row_len=X), options=dict(night_skip=True)).numpy()
+    np.testing.assert_array_equal(skip, out)
+    del inputs
