@@ -179,7 +179,7 @@ def test_config4_pv_full_year_in_kernel_solar_position(ctx, c4_matrix):
     out = ctx.pv(big, PARAMS, T, S, plan=plan, solar_tables=tables).numpy()
     assert out.shape == (N, T) and np.isfinite(out).all() and out.min() >= 0.0
     sel = sample_steps(T, n_random=30)[::2]
-    assert len(sel) >= 75
+    assert len(sel) >= 70
     host = {k: rows(big[k], sel) for k in five}
     a_, z_ = orc.solar_position(time_all[sel], x, y, "-30min")
     host["solar_altitude"], host["solar_azimuth"] = a_.reshape(len(sel), S), z_.reshape(len(sel), S)
