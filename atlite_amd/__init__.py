@@ -9,6 +9,7 @@ HIP kernels + C ABI: ``atlite_amd/csrc`` -> ``atlite_amd/lib/libatlite_hip.so``
 
 from .cutout import Cutout
 from .labeled import Dataset, LabeledArray
+from .multigpu import set_devices
 
 __version__ = "0.1.0"
-__all__ = ["Cutout", "Dataset", "LabeledArray"]
+__all__ = ["Cutout", "Dataset", "LabeledArray", "set_devices"]

@@ -15,7 +15,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("ATLITE_HIP_LIB", _HERE / "lib" / "libatlite_hip.so"))
 
 ATL_OK, ATL_E_INVALID, ATL_E_HIP, ATL_E_NOMEM, ATL_E_UNSUPPORTED = 0, -1, -2, -3, -4
-TIME_NONE, TIME_SUM, TIME_MEAN = 0, 1, 2
+TIME_NONE, TIME_SUM, TIME_MEAN, TIME_SUM_COUNT = 0, 1, 2, 3
 WIND_NONE, WIND_LOG, WIND_POWER = 0, 1, 2
 SYN_UNIFORM, SYN_RAYLEIGH, SYN_EXPLOG, SYN_NEGLOG = 0, 1, 2, 3
 
@@ -224,6 +224,7 @@ SIGNATURES = {
     "atl_comm_destroy": (_i, [_vp]),
     "atl_allgather_time": (_i, [_vp, _vp, _i64, _i64, _vp, _i64]),
     "atl_allreduce_sum": (_i, [_vp, _vp, _i64]),
+    "atl_allgather_time_v": (_i, [_vp, _vp, _i64, c_int64_p, _vp, _i64]),
     "atl_math_probe": (_i, [_vp, _i, _vp, _i64, _vp]),
     "atl_math_probe_host": (_i, [_i, _vp, _i64, _vp]),
     "atl_wind_probe_host": (_i, [C.POINTER(WindParams), _i64, _vp, _vp, _vp]),

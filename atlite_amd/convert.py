@@ -76,6 +76,13 @@ class _Spec:
     def prepare(self, ctx, ds):
         pass
 
+    # -- multi-GPU interface (atlite_amd.multigpu) -------------------------------------------------
+    def shard_edges(self, T, n):
+        """Edges of ``n`` contiguous, balanced time shards."""
+        from .distributed import time_partition
+
+        return time_partition(T, n)
+
 
 def _need(ds, names, exc, msg):
     for n in names:
@@ -208,10 +215,13 @@ class _PvSpec(_Spec):
             return self
         import copy
 
+        def cut(v):  # device tables (after prepare): views; host tables: slices
+            return v.slab(t0, t1) if isinstance(v, DeviceArray) else v[t0:t1]
+
         sub = copy.copy(self)
         tb = self.solar_tables
-        sub.solar_tables = dict(tb, sin_dec=tb["sin_dec"].slab(t0, t1), cos_dec=tb["cos_dec"].slab(t0, t1),
-                                h=tb["h"].slab(t0, t1), cos_h=tb["cos_h"].slab(t0, t1))
+        sub.solar_tables = dict(tb, sin_dec=cut(tb["sin_dec"]), cos_dec=cut(tb["cos_dec"]), h=cut(tb["h"]),
+                                cos_h=cut(tb["cos_h"]))
         return sub
 
     def run(self, ctx, ds, plan, time_agg, out=None):
@@ -344,7 +354,12 @@ class _HeatSpec(_Spec):
     def n_slots(self, ds):
         return len(self.days)
 
-    # slabs are whole calendar days of the shifted axis
+    # shards and slabs are whole calendar days of the shifted axis
+    def shard_edges(self, T, n):
+        from .distributed import time_partition
+
+        return [int(self.day_ptr[d]) for d in time_partition(len(self.day_ptr) - 1, n)]
+
     def slab_edges(self, T, steps):
         ptr, edges, a = self.day_ptr, [], 0
         while a < len(ptr) - 1:
@@ -628,12 +643,20 @@ def convert_and_aggregate(
     ctx = default_context()
     Y, X = len(ds.coords["y"]), len(ds.coords["x"])
     no_args = all(v is None for v in [layout, shapes, matrix])
+    # more than one device selected (ATLITE_HIP_DEVICES / set_devices / Cutout(devices=)): the time axis
+    # is sharded across them inside this call (atlite_amd.multigpu); results come back on the host
+    from . import multigpu
+
+    devs = multigpu.devices_for(cutout)
+    multi = devs is not None and len(devs) > 1 and not isinstance(spec, _CubeSpec)
 
     if no_args:
         if per_unit or return_capacity:
             raise ValueError("One of `matrix`, `shapes` and `layout` must be given for `per_unit` or `return_capacity`")
         agg = "sum" if aggregate_time == "legacy" else aggregate_time
-        out = _execute(ctx, spec, ds, None, agg)
+        out = multigpu.group(devs).run(spec, ds, None, X, agg) if multi else _execute(ctx, spec, ds, None, agg)
+        if multi and agg is not None:
+            out = ctx.upload(out)  # (S,) - keeps the single-device code below unchanged
         if agg is None:
             tc = spec.time_coord(ds)
             res = LabeledArray(out.reshape(len(tc), Y, X), ("time", "y", "x"),
@@ -686,9 +709,12 @@ def convert_and_aggregate(
     dim, index_vals = _index_coords(pd.RangeIndex(matrix.shape[0]) if index is None else index)
 
     # per-unit needs the series on the host anyway (fillna(0) precedes the time reduction)
-    on_device_time = aggregate_time if (aggregate_time in ("sum", "mean") and not per_unit) else None
-    plan = ctx.plan(matrix, row_len=X)
-    out = _execute(ctx, spec, ds, plan, on_device_time).numpy()  # the plan stays in ctx's cache
+    on_device_time = aggregate_time if (aggregate_time in ("sum", "mean") and not per_unit and not multi) else None
+    if multi:  # every device aggregates its time shard; the (N x T) series is gathered (RCCL) to the host
+        out = multigpu.group(devs).run(spec, ds, matrix, X, None)
+    else:
+        plan = ctx.plan(matrix, row_len=X)
+        out = _execute(ctx, spec, ds, plan, on_device_time).numpy()  # the plan stays in ctx's cache
     tc = spec.time_coord(ds)
     attrs = {}
 

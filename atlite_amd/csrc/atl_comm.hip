@@ -5,6 +5,7 @@
 // works) without it.  The reference has no distributed path to mirror.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstring>
 #include <rccl/rccl.h>
 
@@ -67,6 +68,19 @@ __global__ __launch_bounds__(256) void k_gather_place(const double *__restrict__
     const int64_t n = blockIdx.y;
     const int r = blockIdx.z;
     if (t < T_r) out[n * ld_out + int64_t(r) * T_r + t] = g[(int64_t(r) * N + n) * T_r + t];
+}
+
+// ragged: gathered [rank][n][Tmax] (rank r uses its first len_r columns) -> out[n][off_r + t]
+constexpr int kMaxRanks = 64;
+struct RankOffsets {
+    int64_t off[kMaxRanks + 1];
+};
+__global__ __launch_bounds__(256) void k_gather_place_v(const double *__restrict__ g, RankOffsets ro, int64_t N,
+                                                        int64_t Tmax, double *__restrict__ out, int64_t ld_out) {
+    const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t n = blockIdx.y;
+    const int r = blockIdx.z;
+    if (t < ro.off[r + 1] - ro.off[r]) out[n * ld_out + ro.off[r] + t] = g[(int64_t(r) * N + n) * Tmax + t];
 }
 
 }  // namespace
@@ -136,6 +150,45 @@ int atl_allgather_time(atl_comm *comm, const double *d_local, int64_t N, int64_t
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("atl_allgather_time: kernel launch failed: %s", hipGetErrorString(e));
+        return ATL_E_HIP;
+    }
+    return ATL_OK;
+}
+
+int atl_allgather_time_v(atl_comm *comm, const double *d_local, int64_t N, const int64_t *h_lens, double *d_out,
+                         int64_t ld_out) {
+    ATL_REQUIRE(comm && h_lens && d_out, "atl_allgather_time_v: bad argument");
+    ATL_REQUIRE(comm->n_ranks <= kMaxRanks, "atl_allgather_time_v: at most %d ranks", kMaxRanks);
+    ATL_REQUIRE(N >= 0 && N < 65536, "atl_allgather_time_v: bad shape");
+    RankOffsets ro;
+    int64_t Tmax = 0;
+    ro.off[0] = 0;
+    for (int r = 0; r < comm->n_ranks; ++r) {
+        ATL_REQUIRE(h_lens[r] >= 0, "atl_allgather_time_v: negative shard length");
+        ro.off[r + 1] = ro.off[r] + h_lens[r];
+        Tmax = std::max(Tmax, h_lens[r]);
+    }
+    const int64_t T_r = h_lens[comm->rank];
+    ATL_REQUIRE(ld_out >= ro.off[comm->n_ranks], "atl_allgather_time_v: ld_out too small");
+    ATL_REQUIRE(d_local || N * T_r == 0, "atl_allgather_time_v: d_local is NULL");
+    atl_ctx *ctx = comm->ctx;
+    ATL_HIP_TRY(hipSetDevice(ctx->device));
+    if (N * Tmax == 0) return ATL_OK;
+    // scratch = [send: N x Tmax][recv: n_ranks x N x Tmax]; every rank sends a full-width block
+    void *scr = nullptr;
+    int rc = scratch_reserve(ctx, size_t(comm->n_ranks + 1) * size_t(N * Tmax) * sizeof(double), &scr);
+    if (rc) return rc;
+    double *send = static_cast<double *>(scr), *recv = send + N * Tmax;
+    if (T_r < Tmax) ATL_HIP_TRY(hipMemsetAsync(send, 0, size_t(N * Tmax) * sizeof(double), ctx->stream));
+    if (N * T_r > 0)
+        ATL_HIP_TRY(hipMemcpy2DAsync(send, size_t(Tmax) * sizeof(double), d_local, size_t(T_r) * sizeof(double),
+                                     size_t(T_r) * sizeof(double), size_t(N), hipMemcpyDeviceToDevice, ctx->stream));
+    ATL_NCCL_TRY(g_rccl.AllGather(send, recv, size_t(N * Tmax), ncclDouble, comm->comm, ctx->stream));
+    const dim3 grid(unsigned((Tmax + 255) / 256), unsigned(N), unsigned(comm->n_ranks));
+    hipLaunchKernelGGL(k_gather_place_v, grid, dim3(256), 0, ctx->stream, recv, ro, N, Tmax, d_out, ld_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("atl_allgather_time_v: kernel launch failed: %s", hipGetErrorString(e));
         return ATL_E_HIP;
     }
     return ATL_OK;

@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void k_chunk_reduce(const double *__restrict__
         s += psum[k * S + c];
         n += pcnt[k * S + c];
     }
-    out[c] = mean ? s / n : s;  // nan-skipping mean of nothing is NaN; nan-skipping sum is 0
+    out[c] = mean == 1 ? s / n : s;  // nan-skipping mean of nothing is NaN; nan-skipping sum is 0
+    if (mean == 2) out[S + c] = n;   // ATL_TIME_SUM_COUNT: [sum | count]
 }
 
 // ---------------------------------------------------------------------------------------
@@ -375,7 +376,10 @@ __global__ __launch_bounds__(256) void k_rows_timered(const double *__restrict__
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = mean ? ss[0] / sn[0] : ss[0];
+    if (threadIdx.x == 0) {
+        out[blockIdx.x] = mean == 1 ? ss[0] / sn[0] : ss[0];
+        if (mean == 2) out[gridDim.x + blockIdx.x] = sn[0];  // ATL_TIME_SUM_COUNT: [sum | count]
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -517,8 +521,7 @@ int32_t pick_chunk_slots(const atl_ctx *ctx, int64_t n_slots, int64_t n_segs) {
 template <class Conv>
 int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_t n_slots, int64_t S,
               int time_agg, double *d_out, const char *what) {
-    ATL_REQUIRE(time_agg == ATL_TIME_NONE || time_agg == ATL_TIME_SUM || time_agg == ATL_TIME_MEAN,
-                "%s: bad time_agg %d", what, time_agg);
+    ATL_REQUIRE(time_agg >= ATL_TIME_NONE && time_agg <= ATL_TIME_SUM_COUNT, "%s: bad time_agg %d", what, time_agg);
     ATL_REQUIRE(d_out, "%s: d_out is NULL", what);
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     if (S == 0 || (n_slots == 0 && time_agg == ATL_TIME_NONE)) return ATL_OK;
@@ -556,7 +559,7 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
     }
     if ((rc = check_launch(what))) return rc;
     hipLaunchKernelGGL(k_chunk_reduce, dim3(unsigned((S + 255) / 256)), dim3(256), 0, ctx->stream, psum, pcnt,
-                       n_chunks, S, time_agg == ATL_TIME_MEAN ? 1 : 0, d_out);
+                       n_chunks, S, time_agg == ATL_TIME_MEAN ? 1 : time_agg == ATL_TIME_SUM_COUNT ? 2 : 0, d_out);
     return check_launch(what);
 }
 
@@ -567,8 +570,7 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
     ATL_REQUIRE(agg->ctx == ctx, "%s: aggregation plan belongs to another context", what);
     ATL_REQUIRE(agg->dev.n_cells == S, "%s: matrix has %lld columns but the cutout has %lld cells", what,
                 (long long)agg->dev.n_cells, (long long)S);
-    ATL_REQUIRE(time_agg == ATL_TIME_NONE || time_agg == ATL_TIME_SUM || time_agg == ATL_TIME_MEAN,
-                "%s: bad time_agg %d", what, time_agg);
+    ATL_REQUIRE(time_agg >= ATL_TIME_NONE && time_agg <= ATL_TIME_SUM_COUNT, "%s: bad time_agg %d", what, time_agg);
     ATL_REQUIRE(d_out, "%s: d_out is NULL", what);
     ATL_REQUIRE(time_agg != ATL_TIME_NONE || ld_out >= n_slots, "%s: ld_out %lld < %lld", what,
                 (long long)ld_out, (long long)n_slots);
@@ -625,7 +627,7 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
     }
     if (time_agg != ATL_TIME_NONE) {
         hipLaunchKernelGGL(k_rows_timered, dim3(unsigned(N)), dim3(256), 0, ctx->stream, series, ld_series,
-                           n_slots, time_agg == ATL_TIME_MEAN ? 1 : 0, d_out);
+                           n_slots, time_agg == ATL_TIME_MEAN ? 1 : time_agg == ATL_TIME_SUM_COUNT ? 2 : 0, d_out);
         if ((rc = check_launch(what))) return rc;
     }
     return ATL_OK;

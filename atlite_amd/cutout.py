@@ -20,8 +20,12 @@ from .labeled import Dataset
 
 
 class Cutout:
-    def __init__(self, data=None, crs=4326, path=None):
+    def __init__(self, data=None, crs=4326, path=None, devices=None):
         import os
+
+        # devices=[0, 1, ...]: conversions on this cutout shard their time axis over these GPUs
+        # (atlite_amd.multigpu); None -> atlite_amd.set_devices() / ATLITE_HIP_DEVICES / one device
+        self.devices = None if devices is None else [int(d) for d in devices]
 
         if path is not None and data is None:
             data = path

@@ -15,7 +15,7 @@ import numpy as np
 from . import _lib
 from ._lib import TIME_MEAN, TIME_NONE, TIME_SUM, check
 
-_TIME_CODES = {None: TIME_NONE, "sum": TIME_SUM, "mean": TIME_MEAN}
+_TIME_CODES = {None: TIME_NONE, "sum": TIME_SUM, "mean": TIME_MEAN, "sum_count": _lib.TIME_SUM_COUNT}
 
 
 class DeviceArray:
@@ -263,11 +263,12 @@ class Context:
         into caller memory - a view of a larger result, used by the slab pipeline."""
         if out is not None:
             return None, int(out[0]), int(out[1])
+        k = 2 if time_agg == "sum_count" else 1  # [sum | count]
         if plan is None:
-            a = self.empty((n_slots, S)) if time_agg is None else self.empty((S,))
+            a = self.empty((n_slots, S)) if time_agg is None else self.empty((k * S,))
         else:
             N = plan.shape[0]
-            a = self.empty((N, n_slots)) if time_agg is None else self.empty((N,))
+            a = self.empty((N, n_slots)) if time_agg is None else self.empty((k * N,))
         return a, a.ptr, max(n_slots, 1)
 
     def spmm(self, plan, dense, time_agg=None, out=None):

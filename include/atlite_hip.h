@@ -47,6 +47,9 @@ extern "C" {
 #define ATL_TIME_NONE 0 /* keep the series            */
 #define ATL_TIME_SUM 1  /* nan-skipping sum over time */
 #define ATL_TIME_MEAN 2 /* nan-skipping mean over time */
+#define ATL_TIME_SUM_COUNT 3 /* nan-skipping sum AND the number of non-NaN steps: d_out holds 2 n values,
+                                [sum(n) | count(n)] - what a time shard of a multi-GPU run contributes to a
+                                global sum / mean (convert.py:51-56 over the whole axis) */
 
 typedef struct atl_ctx atl_ctx; /* device + stream + scratch */
 typedef struct atl_agg atl_agg; /* indicator matrix, preprocessed and resident on device */
@@ -389,6 +392,10 @@ int atl_comm_destroy(atl_comm *comm);
 int atl_allgather_time(atl_comm *comm, const double *d_local, int64_t N, int64_t T_r, double *d_out,
                        int64_t ld_out);
 int atl_allreduce_sum(atl_comm *comm, double *d_buf, int64_t n);
+/* Ragged all-gather along time: rank r contributes (N x h_lens[r]) (d_local, row stride T_r = h_lens[own rank]);
+ * d_out (N x sum h_lens, row stride ld_out) on every rank.  h_lens: n_ranks host values, the same on all ranks. */
+int atl_allgather_time_v(atl_comm *comm, const double *d_local, int64_t N, const int64_t *h_lens, double *d_out,
+                         int64_t ld_out);
 
 /* ---- diagnostics ------------------------------------------------------------------------
  * Evaluates the kernels' lean fp64 math (atl_math.h) elementwise, for accuracy tests:

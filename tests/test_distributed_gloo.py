@@ -1,5 +1,5 @@
 """
-CPU, world_size=2, gloo: the time-sharded N>1 path - partitioning, all-gather reassembly of the
+CPU, world_size=2 and 8, gloo: the time-sharded N>1 path - partitioning, all-gather reassembly of the
 (shapes x time) result and the all-reduce form of aggregate_time sum/mean.  The per-rank compute
 is injected (the oracle here; the HIP path on a GPU box), the collectives are the product's.
 """
@@ -64,16 +64,26 @@ def _worker(rank, world, port, T, uneven, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("uneven", [False, True])
-def test_gather_and_reduce_world2(uneven):
+def _run_world(world, T, uneven):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 50, uneven, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, T, uneven, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = q.get(timeout=120)
+    res = q.get(timeout=240)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     assert res == (True, True, True, True)
+
+
+@pytest.mark.parametrize("uneven", [False, True])
+def test_gather_and_reduce_world2(uneven):
+    _run_world(2, 50, uneven)
+
+
+@pytest.mark.parametrize("T", [48, 50])
+def test_gather_and_reduce_world8(T):
+    """The node size north_star names: 8 ranks, equal (48 = 8 x 6) and ragged (50 -> 6/7-step) shards."""
+    _run_world(8, T, False)

@@ -1,0 +1,150 @@
+"""
+GPU: the single-process multi-device executor (atlite_amd.multigpu) behind the public API.
+A one-GPU box cannot form an RCCL communicator with more than one rank, so the device list repeats
+device 0 ([0, 0], [0, 0, 0]): every rank has its own Context / stream / plan / host thread and its own
+time shard - the same code path as a real node except for the reassembly transport (host placement
+instead of atl_allgather_time_v / atl_allreduce_sum, which are covered by the n_ranks = 1 test below
+and run for real in the driver's multi-GPU bench).  Results must equal the single-device results and
+the reference-generated golden vectors.
+"""
+import warnings
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.sparse as sp
+
+import atlite_amd
+from atlite_amd import Cutout, Dataset, multigpu
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).parent / "golden"
+PV_VARS = ("influx_direct", "influx_diffuse", "influx_toa", "albedo", "temperature", "solar_altitude",
+           "solar_azimuth")
+
+
+def load(name):
+    return dict(np.load(G / f"{name}.npz"))
+
+
+def close(a, b, atol_scale=1e-12):
+    a, b = np.asarray(a), np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=1e-10, atol=atol_scale * float(np.nanmax(np.abs(b))), equal_nan=True)
+
+
+def cutout_from(g, names, devices=None, chunked=False):
+    t = pd.DatetimeIndex(g["time"].astype("datetime64[ns]"))
+    return Cutout(Dataset({k: g[k] for k in names}, dict(time=t, y=g["y"], x=g["x"]), chunked=chunked), devices=devices)
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_pv_sharded_equals_single_device_and_golden(devices):
+    g, gw = load("pv"), load("gateway_pv")
+    S = len(g["y"]) * len(g["x"])
+    M = sp.csr_matrix((gw["matrix_data"], gw["matrix_indices"], gw["matrix_indptr"]), shape=(5, S))
+    kw = dict(panel="CSi", orientation={"slope": 30.0, "azimuth": 180.0})
+    one, many = cutout_from(g, PV_VARS), cutout_from(g, PV_VARS, devices=devices)
+    r = many.pv(matrix=M, aggregate_time=None, **kw)
+    assert r.dims == ("dim_0", "time") and r.attrs["units"] == "MW"
+    np.testing.assert_array_equal(r.values, one.pv(matrix=M, aggregate_time=None, **kw).values)  # same kernels, same bits
+    close(r.values, gw["series_matrix"])
+    close(many.pv(matrix=M, aggregate_time="mean", **kw).values, gw["mean_matrix"])
+    close(many.pv(matrix=M, aggregate_time="sum", **kw).values, gw["sum_matrix"])
+    r, cap = many.pv(matrix=M, per_unit=True, return_capacity=True, aggregate_time="mean", **kw)
+    close(r.values, gw["pu_mean_matrix"])
+    # per cell: series (host cube), mean and sum maps (per-shard [sum | count] combined)
+    cells = many.pv(aggregate_time=None, **kw)
+    assert cells.dims == ("time", "y", "x")
+    close(cells.values, g["out_CSi_const30_180"])
+    close(many.pv(aggregate_time="mean", **kw).values, gw["cells_mean"])
+    close(many.pv(aggregate_time="sum", **kw).values, gw["cells_sum"])
+    # chunked (dask-like) datasets keep their (time, dim) result layout
+    cc = cutout_from(g, PV_VARS, devices=devices, chunked=True)
+    r = cc.pv(matrix=M, aggregate_time=None, index=pd.Index(list("abcde"), name="bus"), **kw)
+    assert r.dims == ("time", "bus")
+    close(r.values.T, gw["series_matrix"])
+
+
+def test_in_kernel_solar_position_tables_are_sharded_with_the_time_axis():
+    p = load("pv")
+    names = ("influx_direct", "influx_diffuse", "influx_toa", "albedo", "temperature")
+    M = H.blob_matrix(4, len(p["y"]), len(p["x"]), seed=2)
+    kw = dict(panel="CSi", orientation={"slope": 25.0, "azimuth": 90.0}, matrix=M, aggregate_time=None)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        ref = cutout_from(p, names).pv(**kw).values
+        got = cutout_from(p, names, devices=[0, 0, 0]).pv(**kw).values
+    np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("shift", [0.0, 4.0, -5.0])
+def test_heat_demand_shards_on_calendar_days(shift):
+    g = load("heat_demand")
+    c = cutout_from(g, ("temperature",), devices=[0, 0, 0])
+    r = c.heat_demand(threshold=15.0, a=1.3, constant=0.2, hour_shift=shift, aggregate_time=None)
+    close(r.values, g[f"out_shift{shift:+.0f}"], atol_scale=1e-9)
+    S = len(g["y"]) * len(g["x"])
+    M = sp.csr_matrix(np.ones((2, S)))
+    ra = c.heat_demand(threshold=15.0, a=1.3, constant=0.2, hour_shift=shift, matrix=M, aggregate_time=None)
+    ref = cutout_from(g, ("temperature",)).heat_demand(threshold=15.0, a=1.3, constant=0.2, hour_shift=shift, matrix=M,
+                                                        aggregate_time=None)
+    np.testing.assert_array_equal(ra.values, ref.values)
+
+
+def test_wind_runoff_and_env_selection(monkeypatch):
+    g = load("wind")
+    c = cutout_from(g, ("wnd100m", "roughness", "wnd_shear_exp"))
+    monkeypatch.setenv("ATLITE_HIP_DEVICES", "0,0")
+    assert multigpu.devices_for(c) == [0, 0]
+    close(c.wind(turbine="Vestas_V112_3MW", aggregate_time=None).values, g["out_Vestas_V112_3MW_logarithmic"])
+    monkeypatch.delenv("ATLITE_HIP_DEVICES")
+    atlite_amd.set_devices([0, 0, 0])
+    try:
+        close(c.wind(turbine="Vestas_V112_3MW", interpolation_method="power", aggregate_time=None).values,
+              g["out_Vestas_V112_3MW_power"])
+        r = load("runoff")
+        cr = cutout_from(r, ("runoff", "height"))
+        close(cr.runoff(aggregate_time=None).values, r["out_weighted"])
+        M = sp.csr_matrix(np.ones((1, r["height"].size)))
+        close(cr.runoff(matrix=M, aggregate_time=None).values[0], r["out_weighted"].reshape(len(r["time"]), -1).sum(1))
+    finally:
+        atlite_amd.set_devices(None)
+    assert multigpu.devices_for(c) is None
+
+
+def test_more_devices_than_time_steps_and_host_streaming(monkeypatch):
+    g = load("runoff")
+    T = len(g["time"])
+    sub = {k: (v[:3] if k in ("runoff", "time") else v) for k, v in g.items()}
+    c = cutout_from(sub, ("runoff", "height"), devices=[0] * 5)  # two ranks get an empty shard
+    close(c.runoff(aggregate_time=None).values, g["out_weighted"][:3])
+    M = sp.csr_matrix(np.ones((1, g["height"].size)))
+    close(c.runoff(matrix=M, aggregate_time=None).values[0], g["out_weighted"][:3].reshape(3, -1).sum(1))
+    # every rank runs the slab pipeline on its own shard of a HOST dataset
+    monkeypatch.setenv("ATLITE_HIP_STREAM", "1")
+    monkeypatch.setenv("ATLITE_HIP_SLAB_STEPS", "8")
+    c = cutout_from(g, ("runoff", "height"), devices=[0, 0])
+    close(c.runoff(matrix=M, aggregate_time=None).values[0], g["out_weighted"].reshape(T, -1).sum(1))
+    close(c.runoff(aggregate_time="sum").values, np.nansum(g["out_weighted"], axis=0))
+    close(c.runoff(aggregate_time="mean").values, np.nanmean(g["out_weighted"], axis=0))
+
+
+def test_rccl_ragged_allgather_single_rank(ctx):
+    """atl_allgather_time_v through the C ABI (one rank: RCCL's all-gather degenerates to a copy, the
+    padding and placement code still runs)."""
+    import ctypes as C
+
+    from atlite_amd._lib import check
+    from atlite_amd.distributed import RcclComm
+
+    comm = RcclComm(ctx, 1, 0, RcclComm.unique_id())
+    a = np.random.default_rng(0).random((7, 13))
+    d = ctx.upload(a)
+    out = ctx.zeros((7, 20))
+    lens = (C.c_int64 * 1)(13)
+    check(ctx.lib.atl_allgather_time_v(comm.handle, d.ptr, 7, lens, out.ptr, 20))
+    ctx.sync()
+    np.testing.assert_array_equal(out.numpy()[:, :13], a)
+    comm.close()

@@ -300,3 +300,41 @@ def test_product_never_calls_the_host_probes():
                 assert all(l.strip().startswith(f'"{n}"') for l in hits), (py, n, hits)  # the signature table only
             else:
                 assert not hits, (py, n)
+
+
+def test_multigpu_device_selection_and_day_aligned_shards(monkeypatch):
+    """Host side of atlite_amd.multigpu: device-list resolution order and shard edges (no GPU needed)."""
+    import pandas as pd
+
+    from atlite_amd import multigpu
+    from atlite_amd.convert import _HeatSpec, _RunoffSpec
+    from atlite_amd.labeled import Dataset
+
+    class C:
+        devices = None
+
+    monkeypatch.delenv("ATLITE_HIP_DEVICES", raising=False)
+    assert multigpu.devices_for(C()) is None
+    monkeypatch.setenv("ATLITE_HIP_DEVICES", "0, 1,2")
+    assert multigpu.devices_for(C()) == [0, 1, 2]
+    multigpu.set_devices([3, 4])
+    assert multigpu.devices_for(C()) == [3, 4]
+    c = C()
+    c.devices = [5]
+    assert multigpu.devices_for(c) == [5]
+    multigpu.set_devices(None)
+
+    T = 24 * 10 + 7
+    time = pd.date_range("2013-01-01 05:00", periods=T, freq="h")
+    ds = Dataset({"temperature": np.zeros((T, 2, 3)), "runoff": np.zeros((T, 2, 3)), "height": np.zeros((2, 3))},
+                 dict(time=time, y=[0.0, 1.0], x=[0.0, 1.0, 2.0]))
+    heat = _HeatSpec(ds, 15.0, 1.0, 0.0, 3.0)
+    for n in (1, 2, 3, 8, 16):
+        e = heat.shard_edges(T, n)
+        assert e[0] == 0 and e[-1] == T and len(e) == n + 1 and all(b >= a for a, b in zip(e, e[1:]))
+        assert set(e) <= set(int(v) for v in heat.day_ptr)  # shard boundaries are day boundaries of the shifted axis
+        slots = [heat.out_slots(a, b) for a, b in zip(e, e[1:])]
+        assert slots[0][0] == 0 and slots[-1][1] == len(heat.days)
+        assert all(s[1] == t[0] for s, t in zip(slots, slots[1:]))
+    e = _RunoffSpec(ds).shard_edges(T, 4)
+    assert e[0] == 0 and e[-1] == T and max(b - a for a, b in zip(e, e[1:])) - min(b - a for a, b in zip(e, e[1:])) <= 1
