@@ -21,6 +21,9 @@
 // branch-free probes, so the searches of a group's 8 cells interleave and hide each other's LDS
 // latency; STEPS = 0 searches a table of run-time size in a loop (13 instructions and one exposed LDS
 // round trip per probe - measured 52 of the ~125 instructions per cell before the specialisation).
+// STEPS = kWindGrid: grid-aligned knots (integer / half-integer ... wind speeds, which is what nearly every
+// shipped power curve has): the interval comes from one bucket lookup, no search (interp_grid, atl_math.h).
+constexpr int kWindGrid = -1;
 // Out-of-line rare paths are FREE functions taking scalars by value: a __noinline__ member function
 // needs `this`, i.e. the whole converter struct spilled to a scratch frame by every thread at kernel
 // entry (80 B/lane of extra HBM writes in round 1's wind kernels).
@@ -45,15 +48,18 @@ struct WindConvT {
     int method;
     double to_height, from_height;
     double log_ratio;      // log(to/from)   (power law)
-    const double *table;   // device: V[n_pad] | K[n_pad][4]
+    const double *table;   // device: V[n_pad] | K[n_pad][4]   (grid mode: G[n_buckets][4])
     int n_knots, n_pad;
+    int tab_doubles;       // size of the interpolation table in LDS (the log table follows it)
+    double vmin, vmax, inv_w;  // grid mode: first / last knot, buckets per unit wind speed
+    int b0;                    // grid mode: bucket index of the first knot
     struct Cell {
         double2 aux;
         double lh, lf;  // lean_log(to_height), lean_log(from_height)
     };
     __device__ void block_init(double *lds) const {
-        for (int i = threadIdx.x; i < 5 * n_pad; i += blockDim.x) lds[i] = table[i];
-        if constexpr (METHOD == ATL_WIND_LOG) log_table_init(lds + 5 * n_pad);
+        for (int i = threadIdx.x; i < tab_doubles; i += blockDim.x) lds[i] = table[i];
+        if constexpr (METHOD == ATL_WIND_LOG) log_table_init(lds + tab_doubles);
     }
     ATL_HD Cell cell_setup(int64_t c0, bool v0, bool v1, const double *lds) const {
         Cell c;
@@ -67,7 +73,7 @@ struct WindConvT {
         // exact zero denominator, like the reference's log(from/z0) = log(1)
         c.lh = 0.0;
         c.lf = 0.0;
-        if constexpr (METHOD == ATL_WIND_LOG) c.lf = log_core_tab(from_height, lds + 5 * n_pad);
+        if constexpr (METHOD == ATL_WIND_LOG) c.lf = log_core_tab(from_height, lds + tab_doubles);
         return c;
     }
     ATL_HD __forceinline__ double hub_speed_literal(double v, double z) const {
@@ -80,17 +86,25 @@ struct WindConvT {
             // v * (log(to/z0) / log(from/z0))  =  v * (1 + log(to/from) / (log(from) - log(z0))):
             // one table-driven log and one reciprocal per cell.  log(from) goes through the same
             // routine, so z0 == from gives den == 0 exactly (-> rare path -> the literal formula).
-            const double *ltab = lds + 5 * n_pad;
+            const double *ltab = lds + tab_doubles;
             const bool zok = z >= 0x1.0p-1022 && z < __builtin_inf();
 #ifdef ATL_ABLATE_WIND_NOLOG
             const double lz = z;
 #else
-            const double lz = log_core_tab(zok ? z : 1.0, ltab);
+            // no substitute for a bad z: log_core_tab builds its mantissa (and with it the table index) from
+            // the fraction bits alone, so any bit pattern reads inside the table; the value is discarded (rare)
+            const double lz = log_core_tab(z, ltab);
 #endif
             const double den = c.lf - lz;
-            const bool tame = __builtin_fabs(den) > 0x1.0p-40;  // |den| < 1500 always
+            // |den| < 1500 always.  Both logs carry ~1e-15 of absolute error: below 2^-20 the difference would
+            // lose the 1e-10 the result must keep, so roughness within 1e-6 (relative) of the source height
+            // takes the literal formula like the exactly-zero denominator does.
+            const bool tame = __builtin_fabs(den) > 0x1.0p-20;
             *rare = !(zok && tame);
-            return v * __builtin_fma(log_ratio, fast_rcp(den), 1.0);
+            // one Newton step on v_rcp_f64 (2^-25 -> ~2^-50): 1e-15 on a factor of order one
+            double y = rcp_seed(den);
+            y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
+            return v * __builtin_fma(log_ratio, y, 1.0);
         } else if constexpr (METHOD == ATL_WIND_POWER) {
             *rare = false;
             return v * exp(z * log_ratio);  // v * (to/from) ** shear
@@ -99,8 +113,11 @@ struct WindConvT {
             return v;
         }
     }
-    ATL_HD __forceinline__ double interp(double x, const double *lds) const {
-        return interp_padded<STEPS>(lds, n_knots, n_pad, x);  // atl_math.h (shared with the host probe)
+    ATL_HD __forceinline__ double interp(double x, const double *lds) const {  // atl_math.h (shared with the host probe)
+        if constexpr (STEPS == kWindGrid)
+            return interp_grid(lds, vmin, vmax, inv_w, b0, x);
+        else
+            return interp_padded<STEPS>(lds, n_knots, n_pad, x);
     }
     ATL_HD __forceinline__ double interp_generic(double x, const double *lds) const {
         return wind_interp_generic(lds, n_knots, n_pad, x);

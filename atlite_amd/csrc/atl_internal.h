@@ -128,6 +128,39 @@ inline int wind_table_build(const double *V, const double *F, int n, std::vector
     return n;
 }
 
+// Grid-aligned variant of the table (interp_grid, atl_math.h): returns the number of buckets, 0 if the knots
+// are not all non-negative multiples of a w in {1, 1/2, 1/4, 1/8} (or the table is not finite / too long).
+// v, f: the knots AFTER wind_table_build's guard-knot insertion (a guard knot is never grid-aligned).
+constexpr int kMaxWindBuckets = 512;
+inline int wind_grid_build(const double *tbl_search, int n, int n_pad, std::vector<double> &grid, double *inv_w_out,
+                           int *b0_out) {
+    const double *V = tbl_search;
+    const double *K = tbl_search + n_pad;
+    if (n < 1 || !(V[0] >= 0.0)) return 0;
+    for (double inv_w : {1.0, 2.0, 4.0, 8.0}) {
+        bool ok = true;
+        for (int i = 0; i < n && ok; ++i) {
+            const double t = V[i] * inv_w;
+            ok = __builtin_isfinite(t) && t == __builtin_floor(t) && t < 1e6;
+        }
+        if (!ok) continue;
+        const int b0 = int(V[0] * inv_w), b1 = int(V[n - 1] * inv_w);
+        const int n_b = b1 - b0 + 1;
+        if (n_b > kMaxWindBuckets) return 0;
+        grid.assign(size_t(4) * size_t(n_b), 0.0);
+        int j = 0;
+        for (int b = 0; b < n_b; ++b) {
+            const double start = double(b + b0) / inv_w;  // exact
+            while (j + 1 < n && V[j + 1] <= start) ++j;
+            for (int q = 0; q < 3; ++q) grid[size_t(4 * b + q)] = K[4 * j + q];
+        }
+        *inv_w_out = inv_w;
+        *b0_out = b0;
+        return n_b;
+    }
+    return 0;
+}
+
 inline int64_t tile_columns(int64_t X, int64_t Y, int w2_log2) {
     const int w = 2 << w2_log2;
     const int64_t max_shift = (Y > 1 && X % 16 != 0) ? 15 : 0;

@@ -817,6 +817,13 @@ int make_wind(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p,
     const int n = wind_table_build(p->h_V, p->h_POWn, p->n_knots, tbl, &n_pad, &finite);
     ATL_REQUIRE(n > 0, "wind speed 'V' in the turbine config is expected to be increasing");
     ATL_REQUIRE(n <= kMaxKnots, "atl_wind: power curve needs 1..%d knots", kMaxKnots);
+    // grid-aligned knots (the usual case): the bucket table replaces the search table
+    std::vector<double> grid;
+    double inv_w = 0.0;
+    int b0 = 0;
+    const int n_grid = (finite && !getenv("ATLITE_HIP_WIND_NO_GRID")) ? wind_grid_build(tbl.data(), n, n_pad, grid, &inv_w, &b0) : 0;
+    const std::vector<double> tbl_search = tbl;  // vmin / vmax below
+    if (n_grid > 0) tbl = grid;
     // pinned staging buffer: wait until the previous call's copy has left it, then enqueue the H2D
     // stream-ordered after any earlier kernel that still reads the device table
     if (ctx->table_pending) ATL_HIP_TRY(hipEventSynchronize(ctx->ev_table));
@@ -838,8 +845,18 @@ int make_wind(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p,
     c->table = ctx->d_table;
     c->n_knots = n;
     c->n_pad = n_pad;
+    c->tab_doubles = 5 * n_pad;
+    c->vmin = tbl_search[0];
+    c->vmax = tbl_search[size_t(n - 1)];
+    c->inv_w = 0.0;  // 0: not grid-aligned
+    c->b0 = 0;
+    if (n_grid > 0) {
+        c->tab_doubles = 4 * n_grid;
+        c->inv_w = inv_w;
+        c->b0 = b0;
+    }
     *table_finite = finite;
-    *lds_bytes = size_t(5 * n_pad + 2 * kLogTabN) * sizeof(double);
+    *lds_bytes = size_t(c->tab_doubles + 2 * kLogTabN) * sizeof(double);
     *vec = vec_ok(S, {in->d_wnd, in->aux_is_static ? nullptr : in->d_aux});
     return ATL_OK;
 }
@@ -874,6 +891,11 @@ WindConvT<M, STEPS> wind_as(const WindConvT<-1> &g) {
     c.table = g.table;
     c.n_knots = g.n_knots;
     c.n_pad = g.n_pad;
+    c.tab_doubles = g.tab_doubles;
+    c.vmin = g.vmin;
+    c.vmax = g.vmax;
+    c.inv_w = g.inv_w;
+    c.b0 = g.b0;
     return c;
 }
 
@@ -887,6 +909,7 @@ int wind_dispatch(const WindConvT<-1> &g, bool finite, F &&f) {
     // unrolled knot search for the usual table sizes (make_wind pads to 16 / 32 / 128 knots)
     auto sized = [&](auto method) {
         constexpr int M = decltype(method)::value;
+        if (g.inv_w > 0.0) return f(wind_as<M, kWindGrid>(g));
         if (g.n_pad == 16) return f(wind_as<M, 4>(g));
         if (g.n_pad == 32) return f(wind_as<M, 5>(g));
         if (g.n_pad == 128) return f(wind_as<M, 7>(g));
@@ -918,36 +941,56 @@ int atl_pv_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p
                    int time_agg, double *d_out) {
     ATL_REQUIRE(ctx && in && p, "atl_pv_convert: ctx/inputs/params is NULL");
     bool vec;
+#ifdef ATL_NO_PV  // experimental builds (tools/build_variant.sh): leave a kernel family out to compile in seconds
+    set_error("built without the pv kernels");
+    return ATL_E_UNSUPPORTED;
+#else
     if (pv_needs_general(in, p)) {
+#ifdef ATL_NO_PVX
+        set_error("built without the general pv kernel");
+        return ATL_E_UNSUPPORTED;
+#else
         return pvx_dispatch(p, [&](auto c) {
             int rc = make_pvx(in, p, T, S, &c, &vec);
             if (rc) return rc;
             return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
         });
+#endif
     }
     return pv_dispatch(in, p, false, [&](auto c) {  // night skip: fused (aggregating) kernel only
         int rc = make_pv(in, p, T, S, &c, &vec);
         if (rc) return rc;
         return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
     });
+#endif
 }
 
 int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T,
                              int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out) {
     ATL_REQUIRE(ctx && in && p, "atl_pv_convert_aggregate: ctx/inputs/params is NULL");
     bool vec;
+#ifdef ATL_NO_PV
+    set_error("built without the pv kernels");
+    return ATL_E_UNSUPPORTED;
+#else
     if (pv_needs_general(in, p)) {
+#ifdef ATL_NO_PVX
+        set_error("built without the general pv kernel");
+        return ATL_E_UNSUPPORTED;
+#else
         return pvx_dispatch(p, [&](auto c) {
             int rc = make_pvx(in, p, T, S, &c, &vec);
             if (rc) return rc;
             return run_fused(ctx, c, vec, 0, T, S, agg, time_agg, d_out, ld_out, "atl_pv_convert_aggregate");
         });
+#endif
     }
     return pv_dispatch(in, p, true, [&](auto c) {
         int rc = make_pv(in, p, T, S, &c, &vec);
         if (rc) return rc;
         return run_fused(ctx, c, vec, 0, T, S, agg, time_agg, d_out, ld_out, "atl_pv_convert_aggregate");
     });
+#endif
 }
 
 int atl_wind_convert(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p, int64_t T,

@@ -260,6 +260,22 @@ ATL_HD __forceinline__ double interp_padded(const double *tab, int n_knots, int 
     return __builtin_fma(sl, xc - k0.x, k0.y);
 }
 
+// GRID-ALIGNED knot tables (every knot a multiple of w = 2^-k, V[0] >= 0, finite; built on the host by
+// wind_grid_build, atl_internal.h): one record {V[j], F[j], slope[j], 0} per bucket [b w, (b+1) w), j = the
+// largest index with V[j] <= b w.  Since no knot lies strictly inside a bucket that j is also the largest
+// index with V[j] <= xc for every xc of the bucket, and xc * inv_w is exact (inv_w is a power of two), so
+// the lookup selects the same interval as the search above and returns the same bits - with one LDS round
+// trip instead of STEPS dependent ones (most shipped power curves have integer or half-integer knots).
+ATL_HD __forceinline__ double interp_grid(const double *tab, double vmin, double vmax, double inv_w, int b0, double x) {
+    double xc = x > vmax ? vmax : x;
+    xc = xc < vmin ? vmin : xc;  // NaN stays NaN
+    const double t = xc * inv_w;
+    const int b = int(t != t ? vmin * inv_w : t) - b0;  // t >= 0: truncation is floor; NaN -> bucket 0
+    const double2 k0 = *reinterpret_cast<const double2 *>(tab + 4 * b);
+    const double sl = tab[4 * b + 2];
+    return __builtin_fma(sl, xc - k0.x, k0.y);
+}
+
 // literal numpy/_core/src/multiarray/compiled_base.c arr_interp, for tables that hold non-finite values
 // (same table layout; the slope is formed on the fly like numpy does when it has not precomputed it)
 ATL_HD __forceinline__ double interp_literal(const double *tab, int n_knots, int n_pad, double x) {

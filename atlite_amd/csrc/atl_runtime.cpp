@@ -617,7 +617,16 @@ int atl_wind_interp_host(const double *h_V, const double *h_F, int n_knots, cons
     int n_pad = 0;
     n_knots = wind_table_build(h_V, h_F, n_knots, tbl, &n_pad, &finite);
     ATL_REQUIRE(n_knots > 0, "wind speed 'V' in the turbine config is expected to be increasing");
+    // grid-aligned knots: the bucket lookup make_wind() selects (ATLITE_HIP_WIND_NO_GRID forces the search)
+    std::vector<double> grid;
+    double inv_w = 0.0;
+    int b0 = 0;
+    const int n_grid = (finite && !getenv("ATLITE_HIP_WIND_NO_GRID")) ? wind_grid_build(tbl.data(), n_knots, n_pad, grid, &inv_w, &b0) : 0;
     for (int64_t i = 0; i < m; ++i) {
+        if (n_grid > 0) {
+            h_out[i] = interp_grid(grid.data(), tbl[0], tbl[size_t(n_knots - 1)], inv_w, b0, h_x[i]);
+            continue;
+        }
         if (!finite) {  // non-finite knots / values: the literal transcription (wind_dispatch's generic converter)
             h_out[i] = interp_literal(tbl.data(), n_knots, n_pad, h_x[i]);
             continue;
@@ -691,6 +700,12 @@ int atl_wind_probe_host(const atl_wind_params *p, int64_t n, const double *h_wnd
     int n_pad = 0;
     const int nk = wind_table_build(p->h_V, p->h_POWn, p->n_knots, tbl, &n_pad, &finite);
     ATL_REQUIRE(nk > 0, "wind speed 'V' in the turbine config is expected to be increasing");
+    std::vector<double> grid;
+    double inv_w = 0.0;
+    int b0 = 0;
+    const int n_grid = (finite && !getenv("ATLITE_HIP_WIND_NO_GRID")) ? wind_grid_build(tbl.data(), nk, n_pad, grid, &inv_w, &b0) : 0;
+    const double vmin = tbl[0], vmax = tbl[size_t(nk - 1)];
+    if (n_grid > 0) tbl = grid;
     // the "LDS" image of a block: power-curve table, then the log table
     std::vector<double> lds(tbl.size() + 2 * size_t(kLogTabN));
     memcpy(lds.data(), tbl.data(), tbl.size() * sizeof(double));
@@ -708,6 +723,11 @@ int atl_wind_probe_host(const atl_wind_params *p, int64_t n, const double *h_wnd
         c.table = nullptr;
         c.n_knots = nk;
         c.n_pad = n_pad;
+        c.tab_doubles = int(tbl.size());
+        c.vmin = vmin;
+        c.vmax = vmax;
+        c.inv_w = n_grid > 0 ? inv_w : 0.0;
+        c.b0 = b0;
     };
     auto run = [&](auto conv) {
         fill(conv);
@@ -722,6 +742,11 @@ int atl_wind_probe_host(const atl_wind_params *p, int64_t n, const double *h_wnd
     };
     const bool heights_ok = p->to_height > 0 && p->from_height > 0 && std::isfinite(p->to_height) && std::isfinite(p->from_height);
     if (!finite || (method == ATL_WIND_LOG && !heights_ok)) return run(WindConvT<-1>());  // as wind_dispatch()
+    if (n_grid > 0) {
+        if (method == ATL_WIND_LOG) return run(WindConvT<ATL_WIND_LOG, kWindGrid>());
+        if (method == ATL_WIND_POWER) return run(WindConvT<ATL_WIND_POWER, kWindGrid>());
+        return run(WindConvT<ATL_WIND_NONE, kWindGrid>());
+    }
     if (method == ATL_WIND_LOG) {
         if (n_pad == 16) return run(WindConvT<ATL_WIND_LOG, 4>());
         if (n_pad == 32) return run(WindConvT<ATL_WIND_LOG, 5>());

@@ -347,3 +347,34 @@ def test_wind_repeated_first_knot(ctx):
     ref = np.interp(wnd, V, POW / 3.0)
     np.testing.assert_allclose(out, ref, rtol=1e-14, atol=1e-16)
     assert out[0, 0] == ref[0, 0] and out[0, 1] == ref[0, 1] == POW[0] / 3.0 and out[0, 2] == POW[0] / 3.0
+
+
+def test_wind_grid_lookup_equals_knot_search(ctx, monkeypatch):
+    """Power curves whose knots are all multiples of 1, 1/2, 1/4 or 1/8 m/s take a bucket lookup instead of
+    the binary knot search (interp_grid, atl_math.h): both must select the same interval, i.e. give the
+    same bits - for every shipped turbine, hostile wind speeds, per cell and aggregated."""
+    from atlite_amd.resource import get_windturbineconfig, windturbines
+
+    T, Y, X = 16, 6, 20
+    rng = np.random.default_rng(3)
+    wnd = 30.0 * rng.random((T, Y * X)) ** 1.5
+    z0 = np.exp(np.log(1e-3) + rng.random((T, Y * X)) * np.log(1.5e3))
+    wnd[0, :10] = [0.0, 2.0, 25.0, np.nextafter(25.0, 0), np.nextafter(25.0, 30), 30.0, np.nan, np.inf, -1.0, 12.5]
+    d_w, d_z = ctx.upload(wnd), ctx.upload(z0)
+    M = H.blob_matrix(3, Y, X, seed=1)
+    n_grid = 0
+    for name in windturbines():
+        tb = get_windturbineconfig(name)
+        V, F = np.asarray(tb["V"], float), np.asarray(tb["POW"], float) / tb["P"]
+        aligned = bool(np.all(V * 8 == np.floor(V * 8)))
+        n_grid += aligned
+        args = (d_w, d_z, V, F, float(tb["hub_height"]), 100.0, "logarithmic", T, Y * X)
+        monkeypatch.delenv("ATLITE_HIP_WIND_NO_GRID", raising=False)
+        a, fa = ctx.wind(*args).numpy(), ctx.wind(*args[:8], Y * X, time_agg="mean").numpy()
+        lane = ctx.wind(d_w, None, V, F, 80.0, 80.0, None, T, Y * X).numpy()
+        monkeypatch.setenv("ATLITE_HIP_WIND_NO_GRID", "1")
+        b, fb = ctx.wind(*args).numpy(), ctx.wind(*args[:8], Y * X, time_agg="mean").numpy()
+        np.testing.assert_array_equal(a, b, err_msg=name)
+        np.testing.assert_array_equal(fa, fb, err_msg=name)
+        np.testing.assert_array_equal(lane, np.interp(wnd, V, F), err_msg=name)  # fast lane == np.interp, bit for bit
+    assert n_grid >= 20  # the lookup is what the shipped turbines actually run

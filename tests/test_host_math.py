@@ -6,9 +6,20 @@ reduction, table-driven log, special cases and the guarded division are checked 
 tests/test_gpu_math.py checks the device instantiation with the same bounds.
 """
 import numpy as np
+import pytest
 
 from atlite_amd import _lib
 from atlite_amd._lib import check
+
+
+@pytest.fixture(autouse=True, params=["grid", "search"])
+def wind_table_mode(request, monkeypatch):
+    """Power curves with grid-aligned knots use a bucket lookup, the others a binary search: run every
+    test through both (ATLITE_HIP_WIND_NO_GRID forces the search for aligned tables too)."""
+    if request.param == "search":
+        monkeypatch.setenv("ATLITE_HIP_WIND_NO_GRID", "1")
+    else:
+        monkeypatch.delenv("ATLITE_HIP_WIND_NO_GRID", raising=False)
 
 
 def probe(fn, x, n_out=1):

@@ -21,6 +21,16 @@ ROOT = os.path.dirname(os.path.dirname(__file__))
 NAMES = list(yaml.safe_load(open(f"{ROOT}/atlite_amd/resources/technologies.yaml"))["windturbine"])
 
 
+@pytest.fixture(autouse=True, params=["grid", "search"])
+def wind_table_mode(request, monkeypatch):
+    """Power curves with grid-aligned knots use a bucket lookup, the others a binary search: run every
+    test through both (ATLITE_HIP_WIND_NO_GRID forces the search for aligned tables too)."""
+    if request.param == "search":
+        monkeypatch.setenv("ATLITE_HIP_WIND_NO_GRID", "1")
+    else:
+        monkeypatch.delenv("ATLITE_HIP_WIND_NO_GRID", raising=False)
+
+
 def probe(V, POWn, method, to_h, from_h, wnd, aux):
     V = np.ascontiguousarray(V, dtype=np.float64)
     POWn = np.ascontiguousarray(POWn, dtype=np.float64)
