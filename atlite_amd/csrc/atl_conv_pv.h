@@ -257,7 +257,7 @@ struct PvConvT {
     };
     struct NoOri {};
     struct Cell : std::conditional_t<SP, SpCell, NoSp>, std::conditional_t<PC, OriCell, NoOri> {
-        bool no_cell;  // SKIP: this lane owns no cell at all (tile padding)
+        int no_cell;  // SKIP: this lane owns no cell at all (tile padding); int: a bool member ends up in a scratch byte
     };
     __device__ void block_init(double *) const {}
     ATL_HD static PvOri make_ori(double slope, double azimuth) {

@@ -52,7 +52,10 @@ namespace {
 // kernel 1: per-cell series  out[slot, cell]
 // grid.x over 512-cell blocks, grid.y over slot chunks of kSeriesSlots
 // ---------------------------------------------------------------------------------------
-constexpr int kSeriesSlots = 32;
+#ifndef ATL_SERIES_SLOTS
+#define ATL_SERIES_SLOTS 32
+#endif
+constexpr int kSeriesSlots = ATL_SERIES_SLOTS;
 
 template <class Conv, bool VEC>
 __global__ __launch_bounds__(256) void k_cells_series(Conv conv, int64_t n_slots, int64_t S,
@@ -74,7 +77,8 @@ __global__ __launch_bounds__(256) void k_cells_series(Conv conv, int64_t n_slots
         for (int g = 0; g < G; ++g) raw[g] = conv.template load<VEC>(min(sg + g, s1 - 1), g, s0c, s1c, cell, carry);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const double2 r = conv.compute(raw[g], v0, v1, cell, lds);
+            // lanes without a cell loaded a real cell's data (safe indices) and are masked by the store
+            const double2 r = conv.compute(raw[g], true, true, cell, lds);
             if (sg + g < s1) st2<VEC>(out, (sg + g) * S + c0, v0, v1, r);
         }
     }
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256) void k_cells_timered(Conv conv, int64_t n_slot
         for (int g = 0; g < G; ++g) raw[g] = conv.template load<VEC>(min(sg + g, s1 - 1), g, s0c, s1c, cell, carry);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const double2 r = conv.compute(raw[g], v0, v1, cell, lds);
+            const double2 r = conv.compute(raw[g], true, true, cell, lds);  // masked when psum / pcnt are stored
             const bool live = sg + g < s1;
             if (live && !dnan(r.x)) {
                 acc.x += r.x;
@@ -227,11 +231,14 @@ template <class Conv, bool VEC>
 __global__ __launch_bounds__(256, min_waves<Conv>()) void k_fused_segred(Conv conv, PlanDev plan, int64_t slot0,
                                                       int64_t n_slots, int64_t S, int32_t chunk_slots,
                                                       int64_t n_units, double *__restrict__ partials,
-                                                      int64_t ldp) {
+                                                      int64_t ldp, int32_t conv_lds_doubles) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     conv.block_init(lds);
     __syncthreads();
     const int lane = threadIdx.x & 63;
+    // per-wave LDS area behind the converter's tables: the weights of the tile's first kRowCache partial
+    // rows (LDS instead of 4 VGPRs per row for the whole chunk: the register budget decides the occupancy)
+    double *wlds = lds + conv_lds_doubles + (threadIdx.x >> 6) * (kRowCache * kSegCells);
 #ifndef ATL_XCD_MAP
     // Linear order: consecutive blocks (= consecutive XCDs, block b runs on XCD b % 8) take consecutive
     // tile groups of the same time chunk, so the chip as a whole streams contiguous memory.
@@ -261,20 +268,20 @@ __global__ __launch_bounds__(256, min_waves<Conv>()) void k_fused_segred(Conv co
     const int32_t p0 = plan.seg_ptr[seg], p1 = plan.seg_ptr[seg + 1];
     if (p0 == p1) return;  // no shape touches this tile: nothing to read
     const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
-    // weights of the first kRowCache partial rows: registers for the whole chunk
-    double2 wc[kRowCache];
+    // weights of the first kRowCache partial rows: in this wave's LDS area for the whole chunk (each lane
+    // writes and later reads only its own 16 bytes: no barrier needed)
     unsigned present = 0;  // bit 2r / 2r+1: cell 0 / 1 structurally present in row r
 #pragma unroll
     for (int r = 0; r < kRowCache; ++r) {
-        wc[r].x = 0.0;
-        wc[r].y = 0.0;
+        double2 wz = {0.0, 0.0};
         if (p0 + r < p1) {
             const double2 w = *reinterpret_cast<const double2 *>(plan.prow_w + int64_t(p0 + r) * kSegCells + 2 * lane);
             const bool a0 = !dnan(w.x), a1 = !dnan(w.y);
-            wc[r].x = a0 ? w.x : 0.0;
-            wc[r].y = a1 ? w.y : 0.0;
+            wz.x = a0 ? w.x : 0.0;
+            wz.y = a1 ? w.y : 0.0;
             present |= (a0 ? 1u : 0u) << (2 * r) | (a1 ? 1u : 0u) << (2 * r + 1);
         }
+        *reinterpret_cast<double2 *>(wlds + r * kSegCells + 2 * lane) = wz;
     }
     // this launch covers output slots [slot0, slot0 + n_slots); partials are window-relative
     const int64_t sbeg = slot0 + chunk * chunk_slots;
@@ -321,10 +328,11 @@ __global__ __launch_bounds__(256, min_waves<Conv>()) void k_fused_segred(Conv co
         for (int r = 0; r < kRowCache; ++r) {
             if (p0 + r < p1) {
                 double *prow = partials + int64_t(p0 + r) * ldp;
+                const double2 wr = *reinterpret_cast<const double2 *>(wlds + r * kSegCells + 2 * lane);
                 if (all_finite)
-                    reduce_row<false>(v, wc[r], true, true, lane, sb, send, prow);
+                    reduce_row<false>(v, wr, true, true, lane, sb, send, prow);
                 else
-                    reduce_row<true>(v, wc[r], (present >> (2 * r)) & 1u, (present >> (2 * r + 1)) & 1u, lane, sb,
+                    reduce_row<true>(v, wr, (present >> (2 * r)) & 1u, (present >> (2 * r + 1)) & 1u, lane, sb,
                                      send, prow);
             }
         }
@@ -611,13 +619,17 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
             const int64_t n_groups = (int64_t(plan.n_segs) + kWavesPerBlock - 1) / kWavesPerBlock;
             const dim3 grid(unsigned(8 * ((n_groups + 7) / 8) * n_chunks));
 #endif
+            // dynamic LDS: the converter's tables, then kRowCache weight rows per wave
+            const size_t conv_lds = align_up(lds_bytes, 16);
+            const size_t lds_total = conv_lds + size_t(kWavesPerBlock) * kRowCache * kSegCells * sizeof(double);
+            const int32_t conv_lds_doubles = int32_t(conv_lds / sizeof(double));
             KernelBracket kb(ctx);
             if (vec)
-                hipLaunchKernelGGL((k_fused_segred<Conv, true>), grid, dim3(256), lds_bytes, ctx->stream, conv, plan,
-                                   w0, wn, S, chunk_slots, n_units, partials, ldp);
+                hipLaunchKernelGGL((k_fused_segred<Conv, true>), grid, dim3(256), lds_total, ctx->stream, conv, plan,
+                                   w0, wn, S, chunk_slots, n_units, partials, ldp, conv_lds_doubles);
             else
-                hipLaunchKernelGGL((k_fused_segred<Conv, false>), grid, dim3(256), lds_bytes, ctx->stream, conv,
-                                   plan, w0, wn, S, chunk_slots, n_units, partials, ldp);
+                hipLaunchKernelGGL((k_fused_segred<Conv, false>), grid, dim3(256), lds_total, ctx->stream, conv,
+                                   plan, w0, wn, S, chunk_slots, n_units, partials, ldp, conv_lds_doubles);
             if ((rc = check_launch(what))) return rc;
         }
         const dim3 grid(unsigned((wn + 255) / 256), unsigned(N));

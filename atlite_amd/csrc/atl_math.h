@@ -267,13 +267,14 @@ ATL_HD __forceinline__ double interp_padded(const double *tab, int n_knots, int 
 // the lookup selects the same interval as the search above and returns the same bits - with one LDS round
 // trip instead of STEPS dependent ones (most shipped power curves have integer or half-integer knots).
 ATL_HD __forceinline__ double interp_grid(const double *tab, double vmin, double vmax, double inv_w, int b0, double x) {
-    double xc = x > vmax ? vmax : x;
-    xc = xc < vmin ? vmin : xc;  // NaN stays NaN
-    const double t = xc * inv_w;
-    const int b = int(t != t ? vmin * inv_w : t) - b0;  // t >= 0: truncation is floor; NaN -> bucket 0
-    const double2 k0 = *reinterpret_cast<const double2 *>(tab + 4 * b);
-    const double sl = tab[4 * b + 2];
-    return __builtin_fma(sl, xc - k0.x, k0.y);
+    // clamp with min / max (they drop a NaN operand, so xc is always a number and the bucket index is always
+    // inside the table) and put the NaN back at the end: 5 instructions instead of 9 for the select-based clamp
+    const double xc = __builtin_fmax(__builtin_fmin(x, vmax), vmin);
+    const int b = int(xc * inv_w);  // exact product, >= 0: truncation is floor
+    const double *rec = (tab - 4 * b0) + 4 * b;  // (tab - 4 b0) is loop-invariant
+    const double2 k0 = *reinterpret_cast<const double2 *>(rec);
+    const double r = __builtin_fma(rec[2], xc - k0.x, k0.y);
+    return x != x ? x : r;
 }
 
 // literal numpy/_core/src/multiarray/compiled_base.c arr_interp, for tables that hold non-finite values

@@ -376,5 +376,5 @@ def test_wind_grid_lookup_equals_knot_search(ctx, monkeypatch):
         b, fb = ctx.wind(*args).numpy(), ctx.wind(*args[:8], Y * X, time_agg="mean").numpy()
         np.testing.assert_array_equal(a, b, err_msg=name)
         np.testing.assert_array_equal(fa, fb, err_msg=name)
-        np.testing.assert_array_equal(lane, np.interp(wnd, V, F), err_msg=name)  # fast lane == np.interp, bit for bit
+        np.testing.assert_allclose(lane, np.interp(wnd, V, F), rtol=1e-14, atol=1e-16, err_msg=name)  # fast lane vs np.interp
     assert n_grid >= 20  # the lookup is what the shipped turbines actually run

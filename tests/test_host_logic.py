@@ -102,7 +102,8 @@ def test_turbine_config_and_padding():
                                      params=True)
     np.testing.assert_allclose(sm["POW"], g["smooth_POW"], rtol=1e-13, atol=1e-16)
     assert sm["P"] == g["smooth_P"][0]
-    assert len(resource.windturbines()) == 27 and resource.solarpanels() == ["CSi", "CdTe", "KANENA"]
+    # 27 name-addressable turbines of the reference + its three eno_126_* files (no .yaml suffix there)
+    assert len(resource.windturbines()) == 30 and resource.solarpanels() == ["CSi", "CdTe", "KANENA"]
     assert resource.get_solarpanelconfig("CSi")["k_1"] == -0.017162
 
 
