@@ -10,10 +10,13 @@ struct PvConst {
     // tails other than the Huld panel (PvConvT<..., TAIL>): solar thermal collector, plain irradiation
     double st_c0, st_c1, st_t_store;
     int irr;  // ATL_IRR_*: which component the irradiation tail returns
+    // bofinger panel (solar_panel_model.py:47-74): A, B, C, D, (NOCT - Tamb) / Intc, D * that / ta, Tstd, threshold,
+    // inverter efficiency / capacity
+    double bA, bB, bC, bD, bfrac, bDf_ta, bTstd, bthr, bscale;
 };
 
 // what follows the tilted irradiation in the fast kernel family
-constexpr int kTailHuld = 0, kTailThermal = 1, kTailIrradiation = 2, kTailHuldHayDavies = 3;
+constexpr int kTailHuld = 0, kTailThermal = 1, kTailIrradiation = 2, kTailHuldHayDavies = 3, kTailBofinger = 4;
 
 // per-cell orientation factors: sin/cos(slope), (1 +- cos(slope))/2, panel azimuth
 struct PvOri {
@@ -149,6 +152,13 @@ ATL_HD __forceinline__ double pv_tail_core(double direct, double diffuse, double
     if constexpr (TAIL == kTailIrradiation) {  // convert_irradiation, convert.py:748-767
         return k.irr == ATL_IRR_TOTAL ? G : k.irr == ATL_IRR_DIRECT ? direct_t : k.irr == ATL_IRR_DIFFUSE ? diffuse_t : ground_t;
     }
+    if constexpr (TAIL == kTailBofinger) {  // SolarPanelModel, bofinger branch: solar_panel_model.py:47-74
+        const double eta_ref = k.bA + k.bB * G + k.bC * lean_log(G != 0.0 ? G : __builtin_nan(""));
+        const double eta = fill0(guarded_div(eta_ref * (1.0 + k.bD * (k.bfrac * G + (tmp - k.bTstd))),
+                                             1.0 + k.bDf_ta * eta_ref * G));
+        const double power = G * eta * k.bscale;
+        return (G >= k.bthr) ? power : 0.0;
+    }
     if constexpr (TAIL == kTailThermal) {  // convert_solar_thermal, convert.py:565-574
         const double eta = k.st_c0 - k.st_c1 * fill0(guarded_div(k.st_t_store - tmp, G != 0.0 ? G : __builtin_nan("")));
         const double output = G * eta;
@@ -191,11 +201,14 @@ ATL_HD __forceinline__ double pv_cell(double dir, double dif, double toa, double
     if (capped) return 0.0;  // G = 0 -> G_ = 0, eff -> 0 : 0*0*inv
     double sa, ca;
     lean_sincos(alt, &sa, &ca);
-    if constexpr (TRACK != ATL_TRACK_NONE) {  // tracker: panel_geom's closed forms, simple trigon model
-        const PanelGeom g = panel_geom<TRACK, false>(sa, ca, az, o.slope, o.saz);
-        const double cs = (TRACK != ATL_TRACK_DUAL) ? g.cs : sa;  // irradiation.py:216-219
+    if constexpr (TRACK != ATL_TRACK_NONE) {  // tracker: panel_geom's closed forms
+        constexpr bool HD = TAIL == kTailHuldHayDavies;
+        const PanelGeom g = panel_geom<TRACK, HD>(sa, ca, az, o.slope, o.saz);
+        // simple model: a dual-axis tracker's surface slope is the sun's zenith angle (irradiation.py:216-219);
+        // Hay-Davies keeps the orientation's own slope (:227-245)
+        const double cs = (TRACK != ATL_TRACK_DUAL || HD) ? g.cs : sa;
         return pv_tail_core<TAIL>(direct, diffuse, influx, toa, alb, tmp, sa, np_max(g.cosinc, 0.0), (1.0 + cs) / 2.0,
-                                  (1.0 - cs) / 2.0, 0.0, k);
+                                  (1.0 - cs) / 2.0, HD ? g.sh * g.sh * g.sh : 0.0, k);
     }
     return pv_tail<TAIL>(direct, diffuse, influx, toa, alb, tmp, sa, ca, lean_cos(o.saz - az), o, k);
 }
@@ -232,13 +245,14 @@ ATL_HD __forceinline__ double pv_cell_sp(double dir, double dif, double toa, dou
 // TAIL: the Huld panel model (pv), the solar thermal collector or the plain tilted irradiation - the two
 // non-panel tails exist for stored solar angles without night skip (everything else of those calls
 // goes through the general kernel).
-// TRACK: a tracker (pv(tracking=...)) with the Huld panel, the simple trigon model, one orientation for
-// the whole grid and stored solar angles - the common way trackers are used; other mixes stay general.
+// TRACK: a tracker (pv(tracking=...)) with the Huld panel, either trigon model, scalar or per-cell orientation
+// and stored solar angles - the ways trackers are used with pv(); other mixes stay general.
 template <bool SP, bool PC = false, bool SKIP = false, int TAIL = kTailHuld, int TRACK = ATL_TRACK_NONE>
 struct PvConvT {
     static_assert(!(SP && SKIP), "night skip is implemented for stored solar angles");
     static_assert(TAIL == kTailHuld || (!SP && !SKIP), "the non-panel tails are built for stored angles, no skip");
-    static_assert(TRACK == ATL_TRACK_NONE || (!SP && !PC && !SKIP && TAIL == kTailHuld), "trackers: scalar orientation, Huld");
+    static_assert(TRACK == ATL_TRACK_NONE || (!SP && !SKIP && (TAIL == kTailHuld || TAIL == kTailHuldHayDavies)),
+                  "trackers: stored angles, Huld panel (either trigon model)");
     atl_pv_inputs in;
     int64_t S;
     PvConst k;
@@ -399,10 +413,25 @@ struct PvxOpt {
 
 // host: the constant blocks the converters carry, from the C-ABI parameter struct
 inline PvConst pv_const_of(const atl_pv_params *p) {
-    return PvConst{p->c_temp_amb, p->c_temp_irrad, p->r_tmod, 1.0 / p->r_irradiance, p->k_1, p->k_2,
-                   p->k_3,        p->k_4,          p->k_5,    p->k_6,                 p->inverter_efficiency,
-                   p->altitude_threshold, sin(p->altitude_threshold),
-                   p->st_c0, p->st_c1, p->st_t_store_K, p->irradiation};
+    PvConst k{p->c_temp_amb, p->c_temp_irrad, p->r_tmod, 1.0 / p->r_irradiance, p->k_1, p->k_2,
+              p->k_3,        p->k_4,          p->k_5,    p->k_6,                 p->inverter_efficiency,
+              p->altitude_threshold, sin(p->altitude_threshold),
+              p->st_c0, p->st_c1, p->st_t_store_K, p->irradiation,
+              0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (p->panel_model == ATL_PANEL_BOFINGER) {  // the uniform sub-expressions of pvx_cell's bofinger branch, same order
+        const double fraction = (p->bof_NOCT - p->bof_Tamb) / p->bof_Intc;
+        const double capacity = (p->bof_A + p->bof_B * 1000.0 + p->bof_C * log(1000.0)) * 1e3;
+        k.bA = p->bof_A;
+        k.bB = p->bof_B;
+        k.bC = p->bof_C;
+        k.bD = p->bof_D;
+        k.bfrac = fraction;
+        k.bDf_ta = p->bof_D * fraction / p->bof_ta;
+        k.bTstd = p->bof_Tstd;
+        k.bthr = p->bof_threshold;
+        k.bscale = p->inverter_efficiency / capacity;
+    }
+    return k;
 }
 inline PvxOpt pvx_opt_of(const atl_pv_params *p, bool has_influx, bool has_albedo) {
     return PvxOpt{p->tracking, p->trigon_model, p->clearsky_model, p->irradiation, p->panel_model,
@@ -416,8 +445,18 @@ inline PvxOpt pvx_opt_of(const atl_pv_params *p, bool has_influx, bool has_albed
 template <int TRACK, int TRIGON>
 ATL_HD double pvx_cell(double dir, double dif, double infl, double toa, double albv, double outf, double tmp,
                            double rh, double alt, double az, double slope, double sazim, const PvConst &k,
-                           const PvxOpt &o) {
+                           const PvxOpt &o_) {
     const double nan = __builtin_nan("");
+#ifdef ATL_PVX_FIXED  // experiment: how many registers do the run-time switches cost?
+    PvxOpt o = o_;
+    o.panel = ATL_PVX_PANEL;
+    o.has_influx = ATL_PVX_INFLUX;
+    o.has_albedo = 1 - ATL_PVX_INFLUX;
+    o.irradiation = ATL_IRR_TOTAL;
+    o.clearsky = ATL_CLEARSKY_SIMPLE;
+#else
+    const PvxOpt &o = o_;
+#endif
     double sa, ca;
     lean_sincos(alt, &sa, &ca);
     // ---- direct / diffuse horizontal (irradiation.py:202-208, 13-73) ------------------------
@@ -575,7 +614,11 @@ struct PvxConvT {
         r.ouf = in.d_outflux ? ld2<VEC>(in.d_outflux, off, c0, c1) : zero;
         r.tmp = in.d_temperature ? ld2<VEC>(in.d_temperature, off, c0, c1) : zero;
         r.hum = in.d_humidity ? ld2<VEC>(in.d_humidity, off, c0, c1) : zero;
+#ifdef ATL_PVX_NO_SP
+        if (true) {
+#else
         if (in.d_solar_altitude) {
+#endif
             r.alt = ld2<VEC>(in.d_solar_altitude, off, c0, c1);
             r.az = ld2<VEC>(in.d_solar_azimuth, off, c0, c1);
         } else {
@@ -589,6 +632,9 @@ struct PvxConvT {
     __device__ __forceinline__ double2 compute(const Raw &q, bool v0, bool v1, const Cell &c, const double *) const {
         double2 r;
         r.x = v0 ? pvx_cell<TRACK, TRIGON>(q.dir.x, q.dif.x, q.inf.x, q.toa.x, q.alb.x, q.ouf.x, q.tmp.x, q.hum.x, q.alt.x, q.az.x, c.sl0, c.az0, k, o) : 0.0;
+#if defined(ATL_PVX_SCHED_BARRIER) && defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_sched_barrier(0);  // do not interleave the two cells: halves the live temporaries
+#endif
         r.y = v1 ? pvx_cell<TRACK, TRIGON>(q.dir.y, q.dif.y, q.inf.y, q.toa.y, q.alb.y, q.ouf.y, q.tmp.y, q.hum.y, q.alt.y, q.az.y, c.sl1, c.az1, k, o) : 0.0;
         return r;
     }

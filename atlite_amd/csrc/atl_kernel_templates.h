@@ -1,0 +1,546 @@
+// Kernel templates and launch plumbing shared by the translation units of libatlite_hip.so
+// (atl_kernels.hip: wind / heat / runoff / thermo / spmm + tooling; atl_kernels_pv.hip: the fast pv
+// family; atl_kernels_pvx.hip: the general pv kernel).  Everything here lives in the including file's
+// anonymous namespace: the build compiles the three units in parallel.
+#pragma once
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <type_traits>
+
+#include "atl_internal.h"
+#include "atl_math.h"
+
+// tuning knobs of the fused kernel (A/B-tested with tools/build_variant.sh + tools/ab_bench.sh)
+#ifndef ATL_FUSED_WAVES
+#define ATL_FUSED_WAVES 3  // waves per SIMD the register allocation must allow (<= 168 VGPRs)
+#endif
+#ifndef ATL_PV_GROUP
+#define ATL_PV_GROUP 1
+#endif
+#ifndef ATL_ROW_CACHE
+#define ATL_ROW_CACHE 3
+#endif
+
+using namespace atl;
+
+namespace {
+
+#include "atl_device_util.h"
+#include "atl_conv_basic.h"
+
+// ---------------------------------------------------------------------------------------
+// kernel 1: per-cell series  out[slot, cell]
+// grid.x over 512-cell blocks, grid.y over slot chunks of kSeriesSlots
+// ---------------------------------------------------------------------------------------
+#ifndef ATL_SERIES_SLOTS
+#define ATL_SERIES_SLOTS 32
+#endif
+constexpr int kSeriesSlots = ATL_SERIES_SLOTS;
+
+template <class Conv, bool VEC>
+__global__ __launch_bounds__(256) void k_cells_series(Conv conv, int64_t n_slots, int64_t S,
+                                                      double *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    conv.block_init(lds);
+    __syncthreads();
+    const int64_t c0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * 2;
+    const bool v0 = c0 < S, v1 = c0 + 1 < S;
+    const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);  // safe indices
+    const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
+    const int64_t s0 = int64_t(blockIdx.y) * kSeriesSlots;
+    const int64_t s1 = min(s0 + int64_t(kSeriesSlots), n_slots);
+    constexpr int G = Conv::kGroup >= 4 ? 4 : Conv::kGroup;
+    typename Conv::Carry carry = carry_init<typename Conv::Carry>();
+    for (int64_t sg = s0; sg < s1; sg += G) {
+        typename Conv::Raw raw[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) raw[g] = conv.template load<VEC>(min(sg + g, s1 - 1), g, s0c, s1c, cell, carry);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            // lanes without a cell loaded a real cell's data (safe indices) and are masked by the store
+            const double2 r = conv.compute(raw[g], true, true, cell, lds);
+            if (sg + g < s1) st2<VEC>(out, (sg + g) * S + c0, v0, v1, r);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// kernel 2: per-cell time reduction.  psum/pcnt[chunk, cell] then k_chunk_reduce.
+// ---------------------------------------------------------------------------------------
+template <class Conv, bool VEC>
+__global__ __launch_bounds__(256) void k_cells_timered(Conv conv, int64_t n_slots, int64_t S,
+                                                       int64_t chunk_len, double *__restrict__ psum,
+                                                       double *__restrict__ pcnt) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    conv.block_init(lds);
+    __syncthreads();
+    const int64_t c0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * 2;
+    const bool v0 = c0 < S, v1 = c0 + 1 < S;
+    const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);  // safe indices
+    const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
+    const int64_t s0 = int64_t(blockIdx.y) * chunk_len;
+    const int64_t s1 = min(s0 + chunk_len, n_slots);
+    double2 acc = {0.0, 0.0}, cnt = {0.0, 0.0};
+    constexpr int G = Conv::kGroup >= 4 ? 4 : Conv::kGroup;
+    typename Conv::Carry carry = carry_init<typename Conv::Carry>();
+    for (int64_t sg = s0; sg < s1; sg += G) {
+        typename Conv::Raw raw[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) raw[g] = conv.template load<VEC>(min(sg + g, s1 - 1), g, s0c, s1c, cell, carry);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const double2 r = conv.compute(raw[g], true, true, cell, lds);  // masked when psum / pcnt are stored
+            const bool live = sg + g < s1;
+            if (live && !dnan(r.x)) {
+                acc.x += r.x;
+                cnt.x += 1.0;
+            }
+            if (live && !dnan(r.y)) {
+                acc.y += r.y;
+                cnt.y += 1.0;
+            }
+        }
+    }
+    const int64_t o = int64_t(blockIdx.y) * S + c0;
+    if (v0) {
+        psum[o] = acc.x;
+        pcnt[o] = cnt.x;
+    }
+    if (v1) {
+        psum[o + 1] = acc.y;
+        pcnt[o + 1] = cnt.y;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_chunk_reduce(const double *__restrict__ psum,
+                                                      const double *__restrict__ pcnt, int64_t n_chunks,
+                                                      int64_t S, int mean, double *__restrict__ out) {
+    const int64_t c = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (c >= S) return;
+    double s = 0.0, n = 0.0;
+    for (int64_t k = 0; k < n_chunks; ++k) {
+        s += psum[k * S + c];
+        n += pcnt[k * S + c];
+    }
+    out[c] = mean == 1 ? s / n : s;  // nan-skipping mean of nothing is NaN; nan-skipping sum is 0
+    if (mean == 2) out[S + c] = n;   // ATL_TIME_SUM_COUNT: [sum | count]
+}
+
+// ---------------------------------------------------------------------------------------
+// kernel 3: fused convert + segment reduce
+// ---------------------------------------------------------------------------------------
+// ---- wave butterfly -----------------------------------------------------------------------
+// c[i] (i = slot in batch) per lane -> every lane of the 8-lane group g holds sum over all 64
+// lanes of c[g].  Stage 32 and 16 use the gfx950 lane-swap instructions (v_permlane32_swap /
+// v_permlane16_swap: no selects, no LDS), stages 8..1 are DPP moves inside a row of 16 lanes.
+// Deterministic: a fixed reduction tree.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double swap_add32(double a, double b) {
+    // a kept by lanes 0-31, b kept by lanes 32-63:  lo: a[l] + a[l+32]   hi: b[l-32] + b[l]
+    const u32x2 lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const u32x2 hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi.x, lo.x) + __hiloint2double(hi.y, lo.y);
+}
+
+__device__ __forceinline__ double swap_add16(double a, double b) {
+    // a kept by even rows of 16 lanes, b kept by odd rows
+    const u32x2 lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const u32x2 hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi.x, lo.x) + __hiloint2double(hi.y, lo.y);
+}
+
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ double dpp_mov(double old, double src) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xF, BANK_MASK, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xF, BANK_MASK, false);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int kDppRor8 = 0x128, kDppHalfMirror = 0x141, kDppQuad1032 = 0xB1, kDppQuad2301 = 0x4E;
+
+__device__ __forceinline__ double butterfly8(const double (&c)[kBatch]) {
+    const double d0 = swap_add32(c[0], c[4]), d1 = swap_add32(c[1], c[5]);
+    const double d2 = swap_add32(c[2], c[6]), d3 = swap_add32(c[3], c[7]);
+    const double e0 = swap_add16(d0, d2), e1 = swap_add16(d1, d3);
+    // lanes 0-7 of a row keep e0, lanes 8-15 keep e1 (bank masks select the written lanes)
+    const double u = dpp_mov<kDppRor8, 0x3>(e1, e0);  // lanes 0-7: e0[l+8]   lanes 8-15: e1[l]
+    const double w = dpp_mov<kDppRor8, 0xC>(e0, e1);  // lanes 0-7: e0[l]     lanes 8-15: e1[l-8]
+    double f = u + w;
+    f += dpp_mov<kDppHalfMirror, 0xF>(f, f);
+    f += dpp_mov<kDppQuad1032, 0xF>(f, f);
+    f += dpp_mov<kDppQuad2301, 0xF>(f, f);
+    return f;  // slot index held by lane l: 4*(l>>5) + 2*((l>>4)&1) + ((l>>3)&1) = (l >> 3)
+}
+
+// one partial row: weight the batch, reduce, store 8 consecutive slots
+template <bool GUARD>
+__device__ __forceinline__ void reduce_row(const double2 (&v)[kBatch], double2 w, bool a0, bool a1, int lane,
+                                           int64_t sb, int64_t send, double *__restrict__ prow) {
+    double c[kBatch];
+#pragma unroll
+    for (int i = 0; i < kBatch; ++i) {
+        if constexpr (GUARD) {
+            // structural zeros must not turn NaN/inf cells into NaN (scipy CSR skips them); same
+            // expression as the unguarded path, so a row gives the same bits whichever path it takes
+            const double t0 = a0 ? w.x * v[i].x : 0.0;
+            c[i] = a1 ? __builtin_fma(w.y, v[i].y, t0) : t0;
+        } else {
+            c[i] = __builtin_fma(w.y, v[i].y, w.x * v[i].x);  // w = 0 where absent, v finite
+        }
+    }
+    const double f = butterfly8(c);
+    const int g = lane >> 3;
+    if ((lane & 7) == 0 && sb + g < send) prow[sb + g] = f;
+}
+
+constexpr int kRowCache = ATL_ROW_CACHE;  // partial rows of a tile whose weights stay in registers
+
+// register budget of the fused kernel: ATL_FUSED_WAVES waves per SIMD unless the converter asks for
+// more registers (the general pv kernel is a long literal transcription and would spill)
+template <class Conv, class = void>
+struct conv_min_waves : std::integral_constant<int, ATL_FUSED_WAVES> {};
+template <class Conv>
+struct conv_min_waves<Conv, std::void_t<decltype(Conv::kMinWaves)>> : std::integral_constant<int, Conv::kMinWaves> {};
+template <class Conv>
+constexpr int min_waves() {
+    return conv_min_waves<Conv>::value;
+}
+
+template <class Conv, bool VEC>
+__global__ __launch_bounds__(256, min_waves<Conv>()) void k_fused_segred(Conv conv, PlanDev plan, int64_t slot0,
+                                                      int64_t n_slots, int64_t S, int32_t chunk_slots,
+                                                      int64_t n_units, double *__restrict__ partials,
+                                                      int64_t ldp, int32_t conv_lds_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    conv.block_init(lds);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    // per-wave LDS area behind the converter's tables: the weights of the tile's first kRowCache partial
+    // rows (LDS instead of 4 VGPRs per row for the whole chunk: the register budget decides the occupancy)
+    double *wlds = lds + conv_lds_doubles + (threadIdx.x >> 6) * (kRowCache * kSegCells);
+#ifndef ATL_XCD_MAP
+    // Linear order: consecutive blocks (= consecutive XCDs, block b runs on XCD b % 8) take consecutive
+    // tile groups of the same time chunk, so the chip as a whole streams contiguous memory.
+    const int64_t unit = int64_t(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+    if (unit >= n_units) return;
+    const int32_t seg = int32_t(unit % plan.n_segs);
+    const int64_t chunk = unit / plan.n_segs;
+#else
+    // XCD-affine order (-DATL_XCD_MAP; measured: no gain - C2 3.44 vs 3.41 ms, C4 shard 6.12 vs
+    // 6.13 ms, runoff 0.97 vs 0.97 ms): a group of 4 tiles always lands on the same XCD for every time
+    // chunk, so its weights sit in one XCD's L2 instead of eight.  There is no reuse to win - the
+    // weights are register-cached per 64-slot chunk and make up < 1 % of the traffic.
+    const int64_t n_groups = (int64_t(plan.n_segs) + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t per_xcd = (n_groups + 7) / 8;
+    const int64_t j = int64_t(blockIdx.x) >> 3;
+    const int64_t group = int64_t(blockIdx.x & 7) + 8 * (j % per_xcd);
+    const int64_t chunk = j / per_xcd;
+    const int64_t seg64 = group * kWavesPerBlock + (threadIdx.x >> 6);
+    if (group >= n_groups || seg64 >= plan.n_segs || chunk * chunk_slots >= n_slots) return;
+    const int32_t seg = int32_t(seg64);
+#endif
+    // tile coordinates -> the lane's two adjacent cells (atl_internal.h: tile_lane_cells)
+    const TileLane tl = tile_lane_cells(plan.X, plan.Y, plan.ntx, plan.w2_log2, seg, lane);
+    const int64_t c0 = tl.c0;
+    const bool v0 = tl.v0, v1 = tl.v1;
+    const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);  // safe indices: loads never branch
+    const int32_t p0 = plan.seg_ptr[seg], p1 = plan.seg_ptr[seg + 1];
+    if (p0 == p1) return;  // no shape touches this tile: nothing to read
+    const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
+    // weights of the first kRowCache partial rows: in this wave's LDS area for the whole chunk (each lane
+    // writes and later reads only its own 16 bytes: no barrier needed)
+    unsigned present = 0;  // bit 2r / 2r+1: cell 0 / 1 structurally present in row r
+#pragma unroll
+    for (int r = 0; r < kRowCache; ++r) {
+        double2 wz = {0.0, 0.0};
+        if (p0 + r < p1) {
+            const double2 w = *reinterpret_cast<const double2 *>(plan.prow_w + int64_t(p0 + r) * kSegCells + 2 * lane);
+            const bool a0 = !dnan(w.x), a1 = !dnan(w.y);
+            wz.x = a0 ? w.x : 0.0;
+            wz.y = a1 ? w.y : 0.0;
+            present |= (a0 ? 1u : 0u) << (2 * r) | (a1 ? 1u : 0u) << (2 * r + 1);
+        }
+        *reinterpret_cast<double2 *>(wlds + r * kSegCells + 2 * lane) = wz;
+    }
+    // this launch covers output slots [slot0, slot0 + n_slots); partials are window-relative
+    const int64_t sbeg = slot0 + chunk * chunk_slots;
+    const int64_t send = min(sbeg + int64_t(chunk_slots), slot0 + n_slots);
+    partials -= slot0;
+    typename Conv::Carry carry = carry_init<typename Conv::Carry>();
+    batch_prefetch<VEC>(conv, sbeg, send, s0c, s1c, carry, 0);
+    for (int64_t sb = sbeg; sb < send; sb += kBatch) {
+        double2 v[kBatch];
+        bool finite = true;
+        // kGroup slots are LOADED before any of them is converted, so a light converter keeps 8
+        // independent 1-KiB loads in flight per wave; slots past the end of a ragged chunk re-load
+        // its last slot (loads stay unconditional) and are zeroed afterwards.
+        constexpr int G = Conv::kGroup;
+#pragma unroll
+        for (int i0 = 0; i0 < kBatch; i0 += G) {
+            typename Conv::Raw raw[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                raw[g] = conv.template load<VEC>(min(sb + i0 + g, send - 1), i0 + g, s0c, s1c, cell, carry);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int i = i0 + g;
+                const bool live = sb + i < send;
+                v[i] = conv.compute(raw[g], v0, v1, cell, lds);
+                v[i].x = live ? v[i].x : 0.0;
+                v[i].y = live ? v[i].y : 0.0;
+                // |x| < inf is false for NaN and +-inf
+                finite = finite && (__builtin_fabs(v[i].x) < __builtin_inf()) && (__builtin_fabs(v[i].y) < __builtin_inf());
+            }
+        }
+        if (sb + kBatch < send) batch_prefetch<VEC>(conv, sb + kBatch, send, s0c, s1c, carry, 0);
+#ifdef ATL_ABLATE_NOREDUCE  // experiment: conversion only, one dummy store per batch
+        {
+            double acc = 0.0;
+            for (int i = 0; i < kBatch; ++i) acc += v[i].x + v[i].y;
+            if (acc == 1.2345e300) partials[sb] = acc;
+            continue;
+        }
+#endif
+        const bool all_finite = __all(finite);  // wave-uniform
+#pragma unroll
+        for (int r = 0; r < kRowCache; ++r) {
+            if (p0 + r < p1) {
+                double *prow = partials + int64_t(p0 + r) * ldp;
+                const double2 wr = *reinterpret_cast<const double2 *>(wlds + r * kSegCells + 2 * lane);
+                if (all_finite)
+                    reduce_row<false>(v, wr, true, true, lane, sb, send, prow);
+                else
+                    reduce_row<true>(v, wr, (present >> (2 * r)) & 1u, (present >> (2 * r + 1)) & 1u, lane, sb,
+                                     send, prow);
+            }
+        }
+        for (int32_t p = p0 + kRowCache; p < p1; ++p) {
+            const double2 w = *reinterpret_cast<const double2 *>(plan.prow_w + int64_t(p) * kSegCells + 2 * lane);
+            const bool a0 = !dnan(w.x), a1 = !dnan(w.y);
+            double2 wz;
+            wz.x = a0 ? w.x : 0.0;
+            wz.y = a1 ? w.y : 0.0;
+            reduce_row<true>(v, wz, a0, a1, lane, sb, send, partials + int64_t(p) * ldp);
+        }
+    }
+}
+
+// out[n, t] = sum over the shape's partial rows (ascending segment order)
+__global__ __launch_bounds__(256) void k_combine(PlanDev plan, const double *__restrict__ partials,
+                                                 int64_t ldp, int64_t n_slots, double *__restrict__ out,
+                                                 int64_t ld_out) {
+    const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t n = blockIdx.y;
+    if (t >= n_slots) return;
+    double s = 0.0;
+    const int32_t q0 = plan.shape_ptr[n], q1 = plan.shape_ptr[n + 1];
+    for (int32_t q = q0; q < q1; ++q) s += partials[int64_t(plan.shape_prow[q]) * ldp + t];
+    if (plan.row_poison[n]) s = __builtin_nan("");
+    out[n * ld_out + t] = s;
+}
+
+// nan-skipping sum / mean of each row of a (rows x len) matrix; one block per row
+__global__ __launch_bounds__(256) void k_rows_timered(const double *__restrict__ in, int64_t ld,
+                                                      int64_t len, int mean, double *__restrict__ out) {
+    __shared__ double ss[256], sn[256];
+    const double *row = in + int64_t(blockIdx.x) * ld;
+    double s = 0.0, n = 0.0;
+    for (int64_t t = threadIdx.x; t < len; t += 256) {
+        const double v = row[t];
+        if (!dnan(v)) {
+            s += v;
+            n += 1.0;
+        }
+    }
+    ss[threadIdx.x] = s;
+    sn[threadIdx.x] = n;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (int(threadIdx.x) < w) {
+            ss[threadIdx.x] += ss[threadIdx.x + w];
+            sn[threadIdx.x] += sn[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[blockIdx.x] = mean == 1 ? ss[0] / sn[0] : ss[0];
+        if (mean == 2) out[gridDim.x + blockIdx.x] = sn[0];  // ATL_TIME_SUM_COUNT: [sum | count]
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host-side launch plumbing
+// ---------------------------------------------------------------------------------------
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+struct KernelBracket {
+    atl_ctx *ctx;
+    size_t slot = 0;
+    explicit KernelBracket(atl_ctx *c) : ctx(c) {
+        if (ctx->profiling) {
+            slot = size_t(ctx->ring_count % int64_t(ctx->ev_ring.size() / 2));
+            (void)hipEventRecord(ctx->ev_ring[2 * slot], ctx->stream);
+        }
+    }
+    ~KernelBracket() {
+        if (ctx->profiling) {
+            (void)hipEventRecord(ctx->ev_ring[2 * slot + 1], ctx->stream);
+            ++ctx->ring_count;
+        }
+    }
+};
+
+int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: kernel launch failed: %s", what, hipGetErrorString(e));
+        return ATL_E_HIP;
+    }
+    return ATL_OK;
+}
+
+// chunk of output slots walked by one wave of the fused kernel
+int32_t pick_chunk_slots(const atl_ctx *ctx, int64_t n_slots, int64_t n_segs) {
+    // aim for >= ~16 waves per CU worth of units, chunks a multiple of kBatch in [8, 64]
+    int64_t chunk = 64;
+    if (const char *e = getenv("ATLITE_HIP_CHUNK")) {  // experiments: any multiple of kBatch
+        const int64_t v = atoll(e);
+        if (v >= kBatch && v % kBatch == 0) return int32_t(v);
+    }
+    const int64_t want_units = int64_t(ctx->n_cu) * 64;
+    while (chunk > kBatch && n_segs * ((n_slots + chunk - 1) / chunk) < want_units) chunk /= 2;
+    return int32_t(chunk);
+}
+
+template <class Conv>
+int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_t n_slots, int64_t S,
+              int time_agg, double *d_out, const char *what) {
+    ATL_REQUIRE(time_agg >= ATL_TIME_NONE && time_agg <= ATL_TIME_SUM_COUNT, "%s: bad time_agg %d", what, time_agg);
+    ATL_REQUIRE(d_out, "%s: d_out is NULL", what);
+    ATL_HIP_TRY(hipSetDevice(ctx->device));
+    if (S == 0 || (n_slots == 0 && time_agg == ATL_TIME_NONE)) return ATL_OK;
+    const unsigned gx = unsigned((S + 511) / 512);
+    vec = vec && aligned16(d_out);
+    if (time_agg == ATL_TIME_NONE) {
+        const dim3 grid(gx, unsigned((n_slots + kSeriesSlots - 1) / kSeriesSlots));
+        KernelBracket kb(ctx);
+        if (vec)
+            hipLaunchKernelGGL((k_cells_series<Conv, true>), grid, dim3(256), lds_bytes, ctx->stream, conv,
+                               n_slots, S, d_out);
+        else
+            hipLaunchKernelGGL((k_cells_series<Conv, false>), grid, dim3(256), lds_bytes, ctx->stream, conv,
+                               n_slots, S, d_out);
+        return check_launch(what);
+    }
+    // time-reduced: split the slot axis so that the grid fills the chip
+    int64_t n_chunks = std::max<int64_t>(1, std::min<int64_t>((n_slots + 15) / 16,
+                                                               (int64_t(ctx->n_cu) * 16 + gx - 1) / gx));
+    const int64_t chunk_len = std::max<int64_t>(1, (n_slots + n_chunks - 1) / n_chunks);
+    n_chunks = std::max<int64_t>(1, (n_slots + chunk_len - 1) / chunk_len);
+    void *scr = nullptr;
+    int rc = scratch_reserve(ctx, size_t(2 * n_chunks * S) * sizeof(double), &scr);
+    if (rc) return rc;
+    double *psum = static_cast<double *>(scr), *pcnt = psum + n_chunks * S;
+    {
+        const dim3 grid(gx, unsigned(n_chunks));
+        KernelBracket kb(ctx);
+        if (vec)
+            hipLaunchKernelGGL((k_cells_timered<Conv, true>), grid, dim3(256), lds_bytes, ctx->stream, conv,
+                               n_slots, S, chunk_len, psum, pcnt);
+        else
+            hipLaunchKernelGGL((k_cells_timered<Conv, false>), grid, dim3(256), lds_bytes, ctx->stream, conv,
+                               n_slots, S, chunk_len, psum, pcnt);
+    }
+    if ((rc = check_launch(what))) return rc;
+    hipLaunchKernelGGL(k_chunk_reduce, dim3(unsigned((S + 255) / 256)), dim3(256), 0, ctx->stream, psum, pcnt,
+                       n_chunks, S, time_agg == ATL_TIME_MEAN ? 1 : time_agg == ATL_TIME_SUM_COUNT ? 2 : 0, d_out);
+    return check_launch(what);
+}
+
+template <class Conv>
+int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_t n_slots, int64_t S,
+              const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out, const char *what) {
+    ATL_REQUIRE(agg, "%s: agg is NULL", what);
+    ATL_REQUIRE(agg->ctx == ctx, "%s: aggregation plan belongs to another context", what);
+    ATL_REQUIRE(agg->dev.n_cells == S, "%s: matrix has %lld columns but the cutout has %lld cells", what,
+                (long long)agg->dev.n_cells, (long long)S);
+    ATL_REQUIRE(time_agg >= ATL_TIME_NONE && time_agg <= ATL_TIME_SUM_COUNT, "%s: bad time_agg %d", what, time_agg);
+    ATL_REQUIRE(d_out, "%s: d_out is NULL", what);
+    ATL_REQUIRE(time_agg != ATL_TIME_NONE || ld_out >= n_slots, "%s: ld_out %lld < %lld", what,
+                (long long)ld_out, (long long)n_slots);
+    ATL_HIP_TRY(hipSetDevice(ctx->device));
+    const PlanDev &plan = agg->dev;
+    const int64_t N = plan.n_rows;
+    if (N == 0) return ATL_OK;
+    vec = vec && (plan.X % 2 == 0);  // the lane's cell pair must not straddle a grid row
+    // Partial rows live in scratch as [P][window]; the slot axis is processed in windows so that the
+    // scratch stays below ~1 GiB however dense the matrix is (P = tiles x shapes for a dense one).
+    const int64_t P = plan.n_prows;
+    int64_t window = std::max<int64_t>(n_slots, 1);
+    int64_t budget = int64_t(1) << 27;  // doubles = 1 GiB
+    if (const char *env = getenv("ATLITE_HIP_PARTIAL_BUDGET")) budget = std::max<int64_t>(1, atoll(env));  // tests
+    const int64_t budget_slots = budget / std::max<int64_t>(P, 1);
+    if (window > budget_slots) window = std::max<int64_t>(64, budget_slots / 64 * 64);
+    const int64_t ldp = int64_t(align_up(size_t(window), 8));
+    const int64_t lds_series = int64_t(align_up(size_t(std::max<int64_t>(n_slots, 1)), 8));
+    size_t bytes_partials = align_up(size_t(std::max<int64_t>(P, 1) * ldp) * sizeof(double), 256);
+    size_t bytes_series = time_agg == ATL_TIME_NONE ? 0 : align_up(size_t(N * lds_series) * sizeof(double), 256);
+    void *scr = nullptr;
+    int rc = scratch_reserve(ctx, bytes_partials + bytes_series, &scr);
+    if (rc) return rc;
+    double *partials = static_cast<double *>(scr);
+    double *series = time_agg == ATL_TIME_NONE
+                         ? d_out
+                         : reinterpret_cast<double *>(static_cast<char *>(scr) + bytes_partials);
+    const int64_t ld_series = time_agg == ATL_TIME_NONE ? ld_out : lds_series;
+    for (int64_t w0 = 0; w0 < n_slots; w0 += window) {
+        const int64_t wn = std::min(window, n_slots - w0);
+        if (P > 0) {
+            const int32_t chunk_slots = pick_chunk_slots(ctx, wn, plan.n_segs);
+            const int64_t n_chunks = (wn + chunk_slots - 1) / chunk_slots;
+            const int64_t n_units = n_chunks * plan.n_segs;
+#ifndef ATL_XCD_MAP
+            const dim3 grid(unsigned((n_units + kWavesPerBlock - 1) / kWavesPerBlock));
+#else
+            const int64_t n_groups = (int64_t(plan.n_segs) + kWavesPerBlock - 1) / kWavesPerBlock;
+            const dim3 grid(unsigned(8 * ((n_groups + 7) / 8) * n_chunks));
+#endif
+            // dynamic LDS: the converter's tables, then kRowCache weight rows per wave
+            const size_t conv_lds = align_up(lds_bytes, 16);
+            const size_t lds_total = conv_lds + size_t(kWavesPerBlock) * kRowCache * kSegCells * sizeof(double);
+            const int32_t conv_lds_doubles = int32_t(conv_lds / sizeof(double));
+            KernelBracket kb(ctx);
+            if (vec)
+                hipLaunchKernelGGL((k_fused_segred<Conv, true>), grid, dim3(256), lds_total, ctx->stream, conv, plan,
+                                   w0, wn, S, chunk_slots, n_units, partials, ldp, conv_lds_doubles);
+            else
+                hipLaunchKernelGGL((k_fused_segred<Conv, false>), grid, dim3(256), lds_total, ctx->stream, conv,
+                                   plan, w0, wn, S, chunk_slots, n_units, partials, ldp, conv_lds_doubles);
+            if ((rc = check_launch(what))) return rc;
+        }
+        const dim3 grid(unsigned((wn + 255) / 256), unsigned(N));
+        hipLaunchKernelGGL(k_combine, grid, dim3(256), 0, ctx->stream, plan, partials, ldp, wn, series + w0,
+                           ld_series);
+        if ((rc = check_launch(what))) return rc;
+    }
+    if (time_agg != ATL_TIME_NONE) {
+        hipLaunchKernelGGL(k_rows_timered, dim3(unsigned(N)), dim3(256), 0, ctx->stream, series, ld_series,
+                           n_slots, time_agg == ATL_TIME_MEAN ? 1 : time_agg == ATL_TIME_SUM_COUNT ? 2 : 0, d_out);
+        if ((rc = check_launch(what))) return rc;
+    }
+    return ATL_OK;
+}
+
+bool vec_ok(int64_t S, std::initializer_list<const void *> ptrs) {
+    if (S % 2) return false;
+    for (const void *p : ptrs)
+        if (p && !aligned16(p)) return false;
+    return true;
+}
+
+}  // namespace

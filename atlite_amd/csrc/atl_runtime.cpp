@@ -668,8 +668,10 @@ int atl_pv_probe_host(const atl_pv_params *p, int family, int64_t n, const doubl
     const int tail = p->trigon_model == ATL_TRIGON_OTHER         ? kTailHuldHayDavies
                      : p->panel_model == ATL_PANEL_SOLAR_THERMAL ? kTailThermal
                      : p->panel_model == ATL_PANEL_NONE          ? kTailIrradiation
+                     : p->panel_model == ATL_PANEL_BOFINGER      ? kTailBofinger
                                                                  : kTailHuld;
-    ATL_REQUIRE(p->tracking == ATL_TRACK_NONE || tail == kTailHuld, "atl_pv_probe_host: the fast family pairs trackers with the Huld tail");
+    ATL_REQUIRE(p->tracking == ATL_TRACK_NONE || ((tail == kTailHuld || tail == kTailHuldHayDavies) && p->panel_model == ATL_PANEL_HULD),
+                "atl_pv_probe_host: the fast family pairs trackers with the Huld panel");
     auto run = [&](auto tl, auto tr) {
         constexpr int TL = decltype(tl)::value, TR = decltype(tr)::value;
         for (int64_t i = 0; i < n; ++i) {
@@ -679,12 +681,16 @@ int atl_pv_probe_host(const atl_pv_params *p, int family, int64_t n, const doubl
         return int(ATL_OK);
     };
     if (p->tracking != ATL_TRACK_NONE)
-        return pv_probe_switch(p->tracking, [&](auto tr) { return run(std::integral_constant<int, kTailHuld>(), tr); });
+        return pv_probe_switch(p->tracking, [&](auto tr) {
+            return tail == kTailHuldHayDavies ? run(std::integral_constant<int, kTailHuldHayDavies>(), tr)
+                                              : run(std::integral_constant<int, kTailHuld>(), tr);
+        });
     using None = std::integral_constant<int, ATL_TRACK_NONE>;
     switch (tail) {
         case kTailHuldHayDavies: return run(std::integral_constant<int, kTailHuldHayDavies>(), None());
         case kTailThermal: return run(std::integral_constant<int, kTailThermal>(), None());
         case kTailIrradiation: return run(std::integral_constant<int, kTailIrradiation>(), None());
+        case kTailBofinger: return run(std::integral_constant<int, kTailBofinger>(), None());
         default: return run(std::integral_constant<int, kTailHuld>(), None());
     }
 }

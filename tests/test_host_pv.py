@@ -2,7 +2,8 @@
 The pv kernels' per-cell routines on the HOST (atl_pv_probe_host: the same source as the kernels, host
 build) against the oracle, on random points of the option space with hostile values - the CPU-side twin
 of tests/fuzz_pv_options.py.  Both families are exercised for every option combination they implement:
-the fast family (Huld / Hay-Davies / solar thermal / irradiation tails, closed-form trackers) and the
+the fast family (Huld / Hay-Davies / bofinger / solar thermal / irradiation tails, closed-form trackers with
+either trigon model) and the
 general kernel's routine (every tracker x trigon model x panel x dataset flavour).
 """
 import ctypes as C
@@ -125,9 +126,9 @@ def test_host_pv_math_against_oracle(seed):
         # the fast family wherever the dispatcher would use it
         model = pp.panel_model
         fast_ok = flavour == "split" and (
-            (trk is None and (model != _lib.PANEL["bofinger"]) and not (tm == "other" and what != "pv") and
+            (trk is None and not (tm == "other" and (what != "pv" or model == _lib.PANEL["bofinger"])) and
              not (what == "pv" and irr != "total")) or
-            (trk is not None and tm == "simple" and what == "pv" and model == _lib.PANEL["huld"]))
+            (trk is not None and what == "pv" and model == _lib.PANEL["huld"]))
         if fast_ok:
             got = probe(pp, 0, ds, ori["slope"], ori["azimuth"])
             e = allowance_error(got, ref)

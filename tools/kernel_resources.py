@@ -4,8 +4,10 @@ import re
 import subprocess
 import sys
 
-path = sys.argv[1] if len(sys.argv) > 1 else "atlite_amd/csrc/atl_kernels.resource.txt"
-txt = open(path).read()
+import glob
+
+paths = [sys.argv[1]] if len(sys.argv) > 1 else sorted(glob.glob("atlite_amd/csrc/*.resource.txt"))
+txt = "".join(open(p).read() for p in paths)
 pat = re.compile(
     r"Function Name: (\S+).*?SGPRs: (\d+).*?VGPRs: (\d+).*?AGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)"
     r".*?Occupancy \[waves/SIMD\]: (\d+).*?LDS Size \[bytes/block\]: (\d+)", re.S)
