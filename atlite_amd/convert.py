@@ -664,7 +664,9 @@ def convert_and_aggregate(
         else:
             res = LabeledArray(out.numpy().reshape(Y, X), ("y", "x"), {"y": ds.coords["y"], "x": ds.coords["x"]},
                                dict(spec.attrs), spec.name)
-        return _finish(res) if agg is not None else res
+        # the reference returns a computed DataArray here too (convert.py:200-211); without xarray the
+        # series stays a LabeledArray over device memory (copied to the host on first .values)
+        return _finish(res)
 
     if matrix is not None:
         if shapes is not None:
