@@ -213,6 +213,67 @@ ATL_HD __forceinline__ double pv_cell(double dir, double dif, double toa, double
     return pv_tail<TAIL>(direct, diffuse, influx, toa, alb, tmp, sa, ca, lean_cos(o.saz - az), o, k);
 }
 
+// ---- the lane's two cells at once, common case first (fixed panel, simple trigon model, Huld panel) ------------
+// When all seven inputs of a cell are finite and no intermediate overflows, the reference's NaN-aware
+// clip / fillna steps reduce to plain min / max / sums: the pair is evaluated that way, both cells in ONE
+// branch-free block (their dependent fp64 chains interleave; per-cell early-outs put each cell into an exec
+// region of its own) without the select chains of the general routines - ~165 instead of ~230 VALU
+// instructions per cell.  The arithmetic itself is pv_cell's, operation for operation, so wherever this
+// evaluation is valid it returns pv_cell's bits (night skip on / off stay bit-identical).  A cell whose inputs
+// or result are not finite is re-evaluated by pv_cell (never in physical data; the hostile-value tests go there).
+#ifndef ATL_PV_PLAIN
+#define ATL_PV_PLAIN 1
+#endif
+struct PvPlain {
+    double r;
+    bool ok;
+};
+ATL_HD __forceinline__ PvPlain pv_cell_plain(double dir, double dif, double toa, double alb, double tmp, double alt,
+                                                 double az, const PvOri &o, const PvConst &k) {
+    const double inf = __builtin_inf();
+    const bool plain = __builtin_fabs(dir) < inf && __builtin_fabs(dif) < inf && __builtin_fabs(toa) < inf &&
+                       __builtin_fabs(alb) < inf && __builtin_fabs(tmp) < inf && __builtin_fabs(alt) < 0x1.0p30 &&
+                       __builtin_fabs(az) < 0x1.0p29 && __builtin_fabs(o.saz) < 0x1.0p29;
+    const double direct = __builtin_fmin(__builtin_fmax(dir, 0.0), toa);
+    const double diffuse = __builtin_fmin(__builtin_fmax(dif, 0.0), toa - direct);
+    const double influx = direct + diffuse;
+    const bool capped = (alt < k.alt_thr) || (influx <= 0.01);
+    double sa, ca;
+    sincos_core(alt, &sa, &ca);
+    const double cosd = cos_core(o.saz - az);
+    const double cosinc = __builtin_fmax(o.ss * ca * cosd + o.cs * sa, 0.0);
+    const double kk = fast_div(cosinc, sa);
+    const double direct_t = kk * direct;
+    const double diffuse_t = o.hp * diffuse;
+    const double ground_t = alb * influx * o.hm;
+    const double G = direct_t + diffuse_t + ground_t;
+    const double T_ = (k.c_amb * tmp + k.c_irr * G) - k.r_tmod;
+    const double G_ = G * k.inv_r_irr;
+    const bool pos = G_ > 0.0;
+    const double l = log_core(pos ? G_ : 1.0);
+    const double l2 = l * l;
+    double eff = 1.0 + k.k1 * l + k.k2 * l2 + T_ * (k.k3 + k.k4 * l + k.k5 * l2) + k.k6 * (T_ * T_);
+    eff = pos ? __builtin_fmax(eff, 0.0) : 0.0;
+    const double r = G_ * eff * k.inv_eff;
+    PvPlain out;
+    out.r = capped ? 0.0 : r;
+    // subnormal G_ (log_core wants a normal argument) and any overflow on the way show in these two tests
+    out.ok = plain && (capped || (__builtin_fabs(r) < inf && !(pos && G_ < 0x1.0p-1022)));
+    return out;
+}
+
+// what the kernels evaluate for one cell: the plain evaluation where it is valid, pv_cell otherwise (the
+// kernels do the two cells of a lane side by side, PvConvT::compute; the host probe calls this)
+template <int TAIL, int TRACK>
+ATL_HD __forceinline__ double pv_cell_auto(double dir, double dif, double toa, double alb, double tmp, double alt,
+                                               double az, const PvOri &o, const PvConst &k) {
+    if constexpr (TAIL == kTailHuld && TRACK == ATL_TRACK_NONE && ATL_PV_PLAIN != 0) {
+        const PvPlain p = pv_cell_plain(dir, dif, toa, alb, tmp, alt, az, o, k);
+        if (p.ok) return p.r;
+    }
+    return pv_cell<TAIL, TRACK>(dir, dif, toa, alb, tmp, alt, az, o, k);
+}
+
 // same, with the solar position computed from the separable tables instead of read:
 // pv/solar_position.py:100-114.  sin(alt) = s directly, cos(alt) = sqrt(1-s^2),
 // cos(az) = clip(.../cos(alt)), sin(az) = +-sqrt(1-cos^2 az) by the sign of the hour angle, so
@@ -247,6 +308,9 @@ ATL_HD __forceinline__ double pv_cell_sp(double dir, double dif, double toa, dou
 // goes through the general kernel).
 // TRACK: a tracker (pv(tracking=...)) with the Huld panel, either trigon model, scalar or per-cell orientation
 // and stored solar angles - the ways trackers are used with pv(); other mixes stay general.
+#ifndef ATL_SKIP_MODE
+#define ATL_SKIP_MODE 8  // bit 3: k_fused_segred_night (pipelined day-slot loop); bit 2: altitudes parked in LDS + a day mask (frees 32 VGPRs: two slots of loads in flight); bit 0: night loads redirected to a cached line instead of a branch per slot; bit 1: whole-batch early-out
+#endif
 template <bool SP, bool PC = false, bool SKIP = false, int TAIL = kTailHuld, int TRACK = ATL_TRACK_NONE>
 struct PvConvT {
     static_assert(!(SP && SKIP), "night skip is implemented for stored solar angles");
@@ -311,7 +375,11 @@ struct PvConvT {
         }
         return c;
     }
-    static constexpr int kGroup = ATL_PV_GROUP;  // 7 x 16 B per lane per slot already; registers are the limit
+#ifndef ATL_SKIP_GROUP
+#define ATL_SKIP_GROUP 1
+#endif
+    // 7 x 16 B per lane per slot already; registers are the limit
+    static constexpr int kGroup = SKIP ? ATL_SKIP_GROUP : ATL_PV_GROUP;
     struct Raw {
         double2 dir, dif, toa, alb, tmp;
         double2 a, b;    // getter: altitude, azimuth   SP: hour angle, cos(hour angle)
@@ -319,8 +387,20 @@ struct PvConvT {
     };
     struct SkipCarry {
         double2 alt[kBatch];  // solar altitude of the batch's slots, prefetched one batch ahead
+        int64_t hot;          // offset of an altitude line this wave has fetched already (the batch's first slot)
+        unsigned day;         // bit i: slot i of the batch has a cell above the cut-off somewhere in the tile (wave-uniform)
+        double *lds;          // this lane's 16 bytes of the wave's altitude area (kBatch rows of kSegCells doubles)
     };
+    // per-wave LDS the kernel reserves behind the row-weight cache: the batch's altitudes are parked there once
+    // the votes are taken, so the 32 VGPRs they arrived in are free while the batch is converted
+    static constexpr int kWaveLdsDoubles = (SKIP && (ATL_SKIP_MODE & 4) != 0) ? kBatch * kSegCells : 0;
     using Carry = std::conditional_t<SKIP, SkipCarry, NoCarry>;
+    __device__ __forceinline__ void carry_bind(Carry &carry, double *wave_lds, int lane) const {
+        if constexpr (SKIP) {
+            carry.lds = wave_lds + 2 * lane;
+            carry.day = 0;
+        }
+    }
     // called before the first batch and again right after a batch has been converted (i.e. while it
     // is being reduced): the next batch's altitudes are in flight behind the wave reduction
     template <bool VEC>
@@ -329,18 +409,105 @@ struct PvConvT {
 #pragma unroll
             for (int i = 0; i < kBatch; ++i)
                 carry.alt[i] = ld2<VEC>(in.d_solar_altitude, min(sb + i, send - 1) * S, c0, c1);
+            carry.hot = sb * S;
         }
+    }
+    // wave-uniform: every cell of the tile is capped in every slot of the batch, so the batch converts to
+    // exactly +0.0 (pv_cell) and the kernel skips its loads and conversions altogether
+    __device__ __forceinline__ bool batch_begin(const Cell &c, Carry &carry) const {
+        if constexpr (SKIP && (ATL_SKIP_MODE & 4) != 0) {
+            unsigned day = 0;
+#pragma unroll
+            for (int i = 0; i < kBatch; ++i) {
+                // capped <=> alt < threshold (a NaN altitude is NOT capped); lanes that own no cell loaded some
+                // other cell's altitude and vote "night" unconditionally
+                const bool night = (carry.alt[i].x < k.alt_thr) && (carry.alt[i].y < k.alt_thr);
+                day |= __all(night || c.no_cell) ? 0u : 1u << i;
+            }
+            carry.day = day;
+            if (day == 0) return true;
+#pragma unroll
+            for (int i = 0; i < kBatch; ++i) *reinterpret_cast<double2 *>(carry.lds + i * kSegCells) = carry.alt[i];
+            return false;
+        } else if constexpr (SKIP && (ATL_SKIP_MODE & 2) != 0) {
+            bool night = true;
+#pragma unroll
+            for (int i = 0; i < kBatch; ++i) night = night && (carry.alt[i].x < k.alt_thr) && (carry.alt[i].y < k.alt_thr);
+            return __all(night || c.no_cell);
+        }
+        return false;
+    }
+    // ---- k_fused_segred_night interface (night early-out, stored solar angles) ---------------------------------
+    // key = the slot's solar altitude; a cell below the cut-off converts to +0.0 whatever the other six cubes
+    // hold (pv_cell: capped; a NaN altitude is NOT capped)
+    static constexpr bool kNightPipe = SKIP && (ATL_SKIP_MODE & 8) != 0;
+    // register budget of the fused kernels: the night kernel with one orientation for the grid fits 4 waves per SIMD
+    static constexpr int kMinWaves = (kNightPipe && !PC) ? 4 : 3;
+    template <bool VEC>
+    __device__ __forceinline__ double2 key_load(int64_t slot, int64_t c0, int64_t c1) const {
+        return ld2<VEC>(in.d_solar_altitude, slot * S, c0, c1);
+    }
+    __device__ __forceinline__ bool key_is_zero(double2 alt) const { return (alt.x < k.alt_thr) && (alt.y < k.alt_thr); }
+    template <bool VEC>
+    __device__ __forceinline__ Raw rest_load(int64_t slot, int64_t c0, int64_t c1, const Cell &) const {
+        const int64_t off = slot * S;
+        Raw r;
+        r.sd = r.cd = 0.0;
+        r.a = double2{0.0, 0.0};
+        r.dir = ld2<VEC>(in.d_influx_direct, off, c0, c1);
+        r.dif = ld2<VEC>(in.d_influx_diffuse, off, c0, c1);
+        r.toa = ld2<VEC>(in.d_influx_toa, off, c0, c1);
+        r.alb = ld2<VEC>(in.d_albedo, off, c0, c1);
+        r.tmp = ld2<VEC>(in.d_temperature, off, c0, c1);
+        r.b = ld2<VEC>(in.d_solar_azimuth, off, c0, c1);
+        return r;
+    }
+    __device__ __forceinline__ double2 compute_keyed(const Raw &q, double2 alt, bool v0, bool v1, const Cell &c,
+                                                     const double *lds) const {
+        Raw r = q;
+        r.a = alt;
+        return compute(r, v0, v1, c, lds);
     }
     template <bool VEC>
     __device__ __forceinline__ Raw load(int64_t slot, int i, int64_t c0, int64_t c1, const Cell &c, Carry &carry) const {
         const int64_t off = slot * S;
         Raw r;
-        if constexpr (SKIP) {
+        if constexpr (SKIP && (ATL_SKIP_MODE & 4) != 0) {
+            r.sd = r.cd = 0.0;
+            if (!((carry.day >> i) & 1u)) {  // wave-uniform: zero influx converts to exactly +0.0 (pv_cell: capped)
+                const double2 z = {0.0, 0.0};
+                r.dir = r.dif = r.toa = r.alb = r.tmp = r.a = r.b = z;
+                return r;
+            }
+            r.a = *reinterpret_cast<const double2 *>(carry.lds + i * kSegCells);
+            r.dir = ld2<VEC>(in.d_influx_direct, off, c0, c1);
+            r.dif = ld2<VEC>(in.d_influx_diffuse, off, c0, c1);
+            r.toa = ld2<VEC>(in.d_influx_toa, off, c0, c1);
+            r.alb = ld2<VEC>(in.d_albedo, off, c0, c1);
+            r.tmp = ld2<VEC>(in.d_temperature, off, c0, c1);
+            r.b = ld2<VEC>(in.d_solar_azimuth, off, c0, c1);
+            return r;
+        } else if constexpr (SKIP) {
             r.a = carry.alt[i];
             r.sd = r.cd = 0.0;
             // capped <=> alt < threshold (a NaN altitude is NOT capped); lanes that own no cell loaded
             // some other cell's altitude and vote "night" unconditionally
             const bool night = (r.a.x < k.alt_thr) && (r.a.y < k.alt_thr);
+#if ATL_SKIP_MODE & 1
+            // Night slot: the same six loads, redirected to an altitude line this wave has fetched already
+            // (a cache hit, no HBM traffic).  The slot converts to +0.0 whatever they return, and the batch
+            // stays one branch-free block whose loads the compiler schedules ahead of the conversions -
+            // a branch per slot left one slot's 6 KiB in flight per wave (5.2 TB/s on the bytes moved).
+            const bool skip = __all(night || c.no_cell);
+            const int64_t o2 = skip ? carry.hot : off;
+            r.dir = ld2<VEC>(skip ? in.d_solar_altitude : in.d_influx_direct, o2, c0, c1);
+            r.dif = ld2<VEC>(skip ? in.d_solar_altitude : in.d_influx_diffuse, o2, c0, c1);
+            r.toa = ld2<VEC>(skip ? in.d_solar_altitude : in.d_influx_toa, o2, c0, c1);
+            r.alb = ld2<VEC>(skip ? in.d_solar_altitude : in.d_albedo, o2, c0, c1);
+            r.tmp = ld2<VEC>(skip ? in.d_solar_altitude : in.d_temperature, o2, c0, c1);
+            r.b = ld2<VEC>(skip ? in.d_solar_altitude : in.d_solar_azimuth, o2, c0, c1);
+            return r;
+#endif
             if (__all(night || c.no_cell)) {
                 const double2 z = {0.0, 0.0};
                 r.dir = r.dif = r.toa = r.alb = r.tmp = r.b = z;
@@ -383,6 +550,31 @@ struct PvConvT {
             const PvAz<true> &a1 = [&]() -> const PvAz<true> & { if constexpr (PC) return c.a1; else return oa; }();
             r.x = v0 ? pv_cell_sp(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.sd, q.cd, c.sl0, c.cl0, q.a.x, q.b.x, o0, a0, k) : 0.0;
             r.y = v1 ? pv_cell_sp(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.sd, q.cd, c.sl1, c.cl1, q.a.y, q.b.y, o1, a1, k) : 0.0;
+        } else if constexpr (TAIL == kTailHuld && TRACK == ATL_TRACK_NONE && ATL_PV_PLAIN != 0) {
+            // (in every kernel of the family, so that night skip on / off, fused / per-cell results share their bits)
+            // a pair of night cells (or a lane without cells) leaves at once: a wave in the dark skips the math.
+            // The test reads ALL seven values of both cells (`tame`): were it a function of the altitude alone,
+            // the compiler would sink the other six loads behind the branch - a per-lane night skip that
+            // serialises the loads and makes the kernel read less than the 56 B/cell its roofline figure assumes.
+            const double inf = __builtin_inf();
+            const bool tame = __builtin_fabs(q.dir.x) < inf && __builtin_fabs(q.dir.y) < inf && __builtin_fabs(q.dif.x) < inf &&
+                              __builtin_fabs(q.dif.y) < inf && __builtin_fabs(q.toa.x) < inf && __builtin_fabs(q.toa.y) < inf &&
+                              __builtin_fabs(q.alb.x) < inf && __builtin_fabs(q.alb.y) < inf && __builtin_fabs(q.tmp.x) < inf &&
+                              __builtin_fabs(q.tmp.y) < inf && __builtin_fabs(q.b.x) < inf && __builtin_fabs(q.b.y) < inf;
+            const bool dark0 = !v0 || q.a.x < k.alt_thr, dark1 = !v1 || q.a.y < k.alt_thr;
+            r.x = r.y = 0.0;
+            if (!(dark0 && dark1 && tame)) {
+                const PvPlain p0 = pv_cell_plain(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.a.x, q.b.x, o0, k);
+                const PvPlain p1 = pv_cell_plain(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.a.y, q.b.y, o1, k);
+                r.x = p0.r;
+                r.y = p1.r;
+                if (__builtin_expect(!(p0.ok && p1.ok), 0)) {
+                    r.x = pv_cell<TAIL, TRACK>(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.a.x, q.b.x, o0, k);
+                    r.y = pv_cell<TAIL, TRACK>(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.a.y, q.b.y, o1, k);
+                }
+                r.x = v0 ? r.x : 0.0;
+                r.y = v1 ? r.y : 0.0;
+            }
         } else {
             r.x = v0 ? pv_cell<TAIL, TRACK>(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.a.x, q.b.x, o0, k) : 0.0;
             r.y = v1 ? pv_cell<TAIL, TRACK>(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.a.y, q.b.y, o1, k) : 0.0;

@@ -16,7 +16,10 @@ namespace atl {
 constexpr int kLanes = 64;               // gfx950 wavefront
 constexpr int kSegCells = 2 * kLanes;    // one wave covers 128 consecutive cells, 2 per lane
 constexpr int kBatch = 8;                // output slots reduced per butterfly
-constexpr int kWavesPerBlock = 4;        // 256-thread workgroups, waves independent
+#ifndef ATL_WAVES_PER_BLOCK
+#define ATL_WAVES_PER_BLOCK 4
+#endif
+constexpr int kWavesPerBlock = ATL_WAVES_PER_BLOCK;  // waves of a fused-kernel workgroup (independent of each other)
 constexpr int kMaxKnots = 1023;          // wind power-curve table limit (LDS: 5 x 1024 doubles = 40 KiB)
 
 void set_error(const char *fmt, ...);

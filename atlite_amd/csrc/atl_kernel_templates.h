@@ -199,6 +199,36 @@ __device__ __forceinline__ void reduce_row(const double2 (&v)[kBatch], double2 w
 
 constexpr int kRowCache = ATL_ROW_CACHE;  // partial rows of a tile whose weights stay in registers
 
+// all partial rows of the tile for one converted batch: the first kRowCache rows with their weights from the
+// wave's LDS area, the others from global memory (guarded path)
+template <int ROWS = kRowCache>
+__device__ __forceinline__ void reduce_batch(const double2 (&v)[kBatch], bool finite, const PlanDev &plan, int32_t p0,
+                                             int32_t p1, const double *wlds, unsigned present, int lane, int64_t sb,
+                                             int64_t send, double *__restrict__ partials, int64_t ldp) {
+    const bool all_finite = __all(finite);  // wave-uniform
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        if (p0 + r < p1) {
+            double *prow = partials + int64_t(p0 + r) * ldp;
+            const double2 wr = *reinterpret_cast<const double2 *>(wlds + r * kSegCells + 2 * lane);
+            if (all_finite)
+                reduce_row<false>(v, wr, true, true, lane, sb, send, prow);
+            else
+                reduce_row<true>(v, wr, (present >> (2 * r)) & 1u, (present >> (2 * r + 1)) & 1u, lane, sb,
+                                 send, prow);
+        }
+    }
+    for (int32_t p = p0 + ROWS; p < p1; ++p) {
+        const double2 w = *reinterpret_cast<const double2 *>(plan.prow_w + int64_t(p) * kSegCells + 2 * lane);
+        const bool a0 = !dnan(w.x), a1 = !dnan(w.y);
+        double2 wz;
+        wz.x = a0 ? w.x : 0.0;
+        wz.y = a1 ? w.y : 0.0;
+        reduce_row<true>(v, wz, a0, a1, lane, sb, send, partials + int64_t(p) * ldp);
+    }
+}
+
+
 // register budget of the fused kernel: ATL_FUSED_WAVES waves per SIMD unless the converter asks for
 // more registers (the general pv kernel is a long literal transcription and would spill)
 template <class Conv, class = void>
@@ -211,7 +241,7 @@ constexpr int min_waves() {
 }
 
 template <class Conv, bool VEC>
-__global__ __launch_bounds__(256, min_waves<Conv>()) void k_fused_segred(Conv conv, PlanDev plan, int64_t slot0,
+__global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fused_segred(Conv conv, PlanDev plan, int64_t slot0,
                                                       int64_t n_slots, int64_t S, int32_t chunk_slots,
                                                       int64_t n_units, double *__restrict__ partials,
                                                       int64_t ldp, int32_t conv_lds_doubles) {
@@ -219,13 +249,17 @@ __global__ __launch_bounds__(256, min_waves<Conv>()) void k_fused_segred(Conv co
     conv.block_init(lds);
     __syncthreads();
     const int lane = threadIdx.x & 63;
+    // the wave index is uniform: say so, and the unit / tile / chunk / slot arithmetic, the loop control and the
+    // partial-row pointers live in SGPRs (they took ~16 VGPRs and 64-bit VALU multiplies per slot)
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
     // per-wave LDS area behind the converter's tables: the weights of the tile's first kRowCache partial
     // rows (LDS instead of 4 VGPRs per row for the whole chunk: the register budget decides the occupancy)
-    double *wlds = lds + conv_lds_doubles + (threadIdx.x >> 6) * (kRowCache * kSegCells);
+    constexpr int kWaveLds = kRowCache * kSegCells + conv_wave_lds<Conv>::value;
+    double *wlds = lds + conv_lds_doubles + wave * kWaveLds;
 #ifndef ATL_XCD_MAP
     // Linear order: consecutive blocks (= consecutive XCDs, block b runs on XCD b % 8) take consecutive
     // tile groups of the same time chunk, so the chip as a whole streams contiguous memory.
-    const int64_t unit = int64_t(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t unit = int64_t(blockIdx.x) * kWavesPerBlock + wave;
     if (unit >= n_units) return;
     const int32_t seg = int32_t(unit % plan.n_segs);
     const int64_t chunk = unit / plan.n_segs;
@@ -239,7 +273,7 @@ __global__ __launch_bounds__(256, min_waves<Conv>()) void k_fused_segred(Conv co
     const int64_t j = int64_t(blockIdx.x) >> 3;
     const int64_t group = int64_t(blockIdx.x & 7) + 8 * (j % per_xcd);
     const int64_t chunk = j / per_xcd;
-    const int64_t seg64 = group * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t seg64 = group * kWavesPerBlock + wave;
     if (group >= n_groups || seg64 >= plan.n_segs || chunk * chunk_slots >= n_slots) return;
     const int32_t seg = int32_t(seg64);
 #endif
@@ -271,6 +305,7 @@ __global__ __launch_bounds__(256, min_waves<Conv>()) void k_fused_segred(Conv co
     const int64_t send = min(sbeg + int64_t(chunk_slots), slot0 + n_slots);
     partials -= slot0;
     typename Conv::Carry carry = carry_init<typename Conv::Carry>();
+    carry_bind(conv, carry, wlds + kRowCache * kSegCells, lane, 0);
     batch_prefetch<VEC>(conv, sbeg, send, s0c, s1c, carry, 0);
     for (int64_t sb = sbeg; sb < send; sb += kBatch) {
         double2 v[kBatch];
@@ -279,22 +314,27 @@ __global__ __launch_bounds__(256, min_waves<Conv>()) void k_fused_segred(Conv co
         // independent 1-KiB loads in flight per wave; slots past the end of a ragged chunk re-load
         // its last slot (loads stay unconditional) and are zeroed afterwards.
         constexpr int G = Conv::kGroup;
+        if (batch_begin(conv, cell, carry, 0)) {  // wave-uniform (pv night early-out): nothing to read or convert
 #pragma unroll
-        for (int i0 = 0; i0 < kBatch; i0 += G) {
-            typename Conv::Raw raw[G];
+            for (int i = 0; i < kBatch; ++i) v[i] = double2{0.0, 0.0};
+        } else {
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                raw[g] = conv.template load<VEC>(min(sb + i0 + g, send - 1), i0 + g, s0c, s1c, cell, carry);
-            }
+            for (int i0 = 0; i0 < kBatch; i0 += G) {
+                typename Conv::Raw raw[G];
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const int i = i0 + g;
-                const bool live = sb + i < send;
-                v[i] = conv.compute(raw[g], v0, v1, cell, lds);
-                v[i].x = live ? v[i].x : 0.0;
-                v[i].y = live ? v[i].y : 0.0;
-                // |x| < inf is false for NaN and +-inf
-                finite = finite && (__builtin_fabs(v[i].x) < __builtin_inf()) && (__builtin_fabs(v[i].y) < __builtin_inf());
+                for (int g = 0; g < G; ++g) {
+                    raw[g] = conv.template load<VEC>(min(sb + i0 + g, send - 1), i0 + g, s0c, s1c, cell, carry);
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int i = i0 + g;
+                    const bool live = sb + i < send;
+                    v[i] = conv.compute(raw[g], v0, v1, cell, lds);
+                    v[i].x = live ? v[i].x : 0.0;
+                    v[i].y = live ? v[i].y : 0.0;
+                    // |x| < inf is false for NaN and +-inf
+                    finite = finite && (__builtin_fabs(v[i].x) < __builtin_inf()) && (__builtin_fabs(v[i].y) < __builtin_inf());
+                }
             }
         }
         if (sb + kBatch < send) batch_prefetch<VEC>(conv, sb + kBatch, send, s0c, s1c, carry, 0);
@@ -306,27 +346,105 @@ __global__ __launch_bounds__(256, min_waves<Conv>()) void k_fused_segred(Conv co
             continue;
         }
 #endif
-        const bool all_finite = __all(finite);  // wave-uniform
+        reduce_batch(v, finite, plan, p0, p1, wlds, present, lane, sb, send, partials, ldp);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// kernel 3b: fused convert + segment reduce with a per-slot early-out (pv night skip)
+// ---------------------------------------------------------------------------------------
+// Same tiles, chunks, partial rows and reduction as k_fused_segred - bit-identical output - but the slots of
+// a batch that convert to +0.0 for the whole tile (every cell below the altitude cut-off) are neither read nor
+// converted.  The batch's key values (altitudes) are prefetched one batch ahead, voted on (wave-uniform day
+// mask) and parked in the wave's LDS rows; a loop over the set bits of the mask converts the day slots and
+// overwrites their rows, night rows hold +0.0, and the reduction reads the eight rows back.  With the values in
+// LDS and a loop instead of eight unrolled slots the kernel needs < 128 VGPRs: 4 waves per SIMD, for which
+// the LDS budget (160 KiB / 16 waves) leaves kRowCacheNight = 2 weight rows per wave.  Converters opt in with
+// kNightPipe and provide key_load / key_is_zero / rest_load / compute_keyed.
+constexpr int kRowCacheNight = 2;
+template <class Conv, class = void>
+struct conv_night_pipe : std::false_type {};
+template <class Conv>
+struct conv_night_pipe<Conv, std::void_t<decltype(Conv::kNightPipe)>> : std::integral_constant<bool, Conv::kNightPipe> {};
+
+template <class Conv, bool VEC>
+__global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fused_segred_night(Conv conv, PlanDev plan, int64_t slot0,
+                                                      int64_t n_slots, int64_t S, int32_t chunk_slots,
+                                                      int64_t n_units, double *__restrict__ partials,
+                                                      int64_t ldp, int32_t conv_lds_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    conv.block_init(lds);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    constexpr int kWaveLds = (kRowCacheNight + kBatch) * kSegCells;
+    double *wlds = lds + conv_lds_doubles + wave * kWaveLds;
+    double *vrow = wlds + kRowCacheNight * kSegCells + 2 * lane;  // this lane's 16 bytes of value row 0
+    const int64_t unit = int64_t(blockIdx.x) * kWavesPerBlock + wave;
+    if (unit >= n_units) return;
+    const int32_t seg = int32_t(unit % plan.n_segs);
+    const int64_t chunk = unit / plan.n_segs;
+    const TileLane tl = tile_lane_cells(plan.X, plan.Y, plan.ntx, plan.w2_log2, seg, lane);
+    const int64_t c0 = tl.c0;
+    const bool v0 = tl.v0, v1 = tl.v1;
+    const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);
+    const int32_t p0 = plan.seg_ptr[seg], p1 = plan.seg_ptr[seg + 1];
+    if (p0 == p1) return;
+    const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
+    const bool no_cell = !v0 && !v1;
+    unsigned present = 0;
 #pragma unroll
-        for (int r = 0; r < kRowCache; ++r) {
-            if (p0 + r < p1) {
-                double *prow = partials + int64_t(p0 + r) * ldp;
-                const double2 wr = *reinterpret_cast<const double2 *>(wlds + r * kSegCells + 2 * lane);
-                if (all_finite)
-                    reduce_row<false>(v, wr, true, true, lane, sb, send, prow);
-                else
-                    reduce_row<true>(v, wr, (present >> (2 * r)) & 1u, (present >> (2 * r + 1)) & 1u, lane, sb,
-                                     send, prow);
-            }
-        }
-        for (int32_t p = p0 + kRowCache; p < p1; ++p) {
-            const double2 w = *reinterpret_cast<const double2 *>(plan.prow_w + int64_t(p) * kSegCells + 2 * lane);
+    for (int r = 0; r < kRowCacheNight; ++r) {
+        double2 wz = {0.0, 0.0};
+        if (p0 + r < p1) {
+            const double2 w = *reinterpret_cast<const double2 *>(plan.prow_w + int64_t(p0 + r) * kSegCells + 2 * lane);
             const bool a0 = !dnan(w.x), a1 = !dnan(w.y);
-            double2 wz;
             wz.x = a0 ? w.x : 0.0;
             wz.y = a1 ? w.y : 0.0;
-            reduce_row<true>(v, wz, a0, a1, lane, sb, send, partials + int64_t(p) * ldp);
+            present |= (a0 ? 1u : 0u) << (2 * r) | (a1 ? 1u : 0u) << (2 * r + 1);
         }
+        *reinterpret_cast<double2 *>(wlds + r * kSegCells + 2 * lane) = wz;
+    }
+    const int64_t sbeg = slot0 + chunk * chunk_slots;
+    const int64_t send = min(sbeg + int64_t(chunk_slots), slot0 + n_slots);
+    partials -= slot0;
+    double2 key[kBatch];
+#pragma unroll
+    for (int i = 0; i < kBatch; ++i) key[i] = conv.template key_load<VEC>(min(sbeg + i, send - 1), s0c, s1c);
+    for (int64_t sb = sbeg; sb < send; sb += kBatch) {
+        // votes: bit i of day = some cell of the tile is converted in slot sb + i
+        unsigned day = 0;
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+            const bool d = (sb + i < send) && !__all(conv.key_is_zero(key[i]) || no_cell);
+            day |= d ? 1u << i : 0u;
+            *reinterpret_cast<double2 *>(vrow + i * kSegCells) = d ? key[i] : double2{0.0, 0.0};
+        }
+        bool finite = true;
+        if (day != 0) {
+            unsigned m = day;
+            // one register set per wave and no software pipelining: what hides the latency is the FOURTH wave per
+            // SIMD the smaller footprint allows (measured on C2: pipelined day slots with two register sets at 3
+            // waves 2.32 ms, this loop at 3 waves 2.19 ms, at 4 waves 2.13 ms)
+            while (m) {
+                const int p = __builtin_ctz(m);
+                m &= m - 1;
+                const typename Conv::Raw A = conv.template rest_load<VEC>(sb + p, s0c, s1c, cell);
+                const double2 kv = *reinterpret_cast<const double2 *>(vrow + p * kSegCells);
+                const double2 r = conv.compute_keyed(A, kv, v0, v1, cell, lds);
+                finite = finite && (__builtin_fabs(r.x) < __builtin_inf()) && (__builtin_fabs(r.y) < __builtin_inf());
+                *reinterpret_cast<double2 *>(vrow + p * kSegCells) = r;
+            }
+        }
+        // next batch's keys: in flight behind the reduction
+        if (sb + kBatch < send) {
+#pragma unroll
+            for (int i = 0; i < kBatch; ++i) key[i] = conv.template key_load<VEC>(min(sb + kBatch + i, send - 1), s0c, s1c);
+        }
+        double2 v[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) v[i] = *reinterpret_cast<const double2 *>(vrow + i * kSegCells);
+        reduce_batch<kRowCacheNight>(v, finite, plan, p0, p1, wlds, present, lane, sb, send, partials, ldp);
     }
 }
 
@@ -512,14 +630,22 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
 #endif
             // dynamic LDS: the converter's tables, then kRowCache weight rows per wave
             const size_t conv_lds = align_up(lds_bytes, 16);
-            const size_t lds_total = conv_lds + size_t(kWavesPerBlock) * kRowCache * kSegCells * sizeof(double);
+            const size_t lds_total = conv_lds + size_t(kWavesPerBlock) * (kRowCache * kSegCells + conv_wave_lds<Conv>::value) * sizeof(double);
             const int32_t conv_lds_doubles = int32_t(conv_lds / sizeof(double));
             KernelBracket kb(ctx);
-            if (vec)
-                hipLaunchKernelGGL((k_fused_segred<Conv, true>), grid, dim3(256), lds_total, ctx->stream, conv, plan,
+            if constexpr (conv_night_pipe<Conv>::value) {
+                const size_t lds_night = conv_lds + size_t(kWavesPerBlock) * (kRowCacheNight + kBatch) * kSegCells * sizeof(double);
+                if (vec)
+                    hipLaunchKernelGGL((k_fused_segred_night<Conv, true>), grid, dim3(kWavesPerBlock * 64), lds_night, ctx->stream, conv,
+                                       plan, w0, wn, S, chunk_slots, n_units, partials, ldp, conv_lds_doubles);
+                else
+                    hipLaunchKernelGGL((k_fused_segred_night<Conv, false>), grid, dim3(kWavesPerBlock * 64), lds_night, ctx->stream, conv,
+                                       plan, w0, wn, S, chunk_slots, n_units, partials, ldp, conv_lds_doubles);
+            } else if (vec)
+                hipLaunchKernelGGL((k_fused_segred<Conv, true>), grid, dim3(kWavesPerBlock * 64), lds_total, ctx->stream, conv, plan,
                                    w0, wn, S, chunk_slots, n_units, partials, ldp, conv_lds_doubles);
             else
-                hipLaunchKernelGGL((k_fused_segred<Conv, false>), grid, dim3(256), lds_total, ctx->stream, conv,
+                hipLaunchKernelGGL((k_fused_segred<Conv, false>), grid, dim3(kWavesPerBlock * 64), lds_total, ctx->stream, conv,
                                    plan, w0, wn, S, chunk_slots, n_units, partials, ldp, conv_lds_doubles);
             if ((rc = check_launch(what))) return rc;
         }

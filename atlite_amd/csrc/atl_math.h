@@ -134,6 +134,26 @@ ATL_HD __forceinline__ void lean_sincos(double x, double *s, double *c) {
     *c = ok ? cc : __builtin_nan("");
 }
 
+// the same without the |x| < 2^30 guard: callers that have checked the range themselves
+ATL_HD __forceinline__ void sincos_core(double x, double *s, double *c) {
+    int q;
+    const double r = reduce_pio2(x, &q);
+    const double z = r * r;
+    const double ps = poly_sin(r, z), pc = poly_cos(z);
+    const double ss = (q & 1) ? pc : ps;
+    const double cc = (q & 1) ? ps : pc;
+    *s = (q & 2) ? -ss : ss;
+    *c = ((q + 1) & 2) ? -cc : cc;
+}
+ATL_HD __forceinline__ double cos_core(double x) {
+    int q;
+    const double r = reduce_pio2(x, &q);
+    const double z = r * r;
+    // both polynomials, one select: a branch on the quadrant diverges in every wave and costs the same
+    const double ps = poly_sin(r, z), pc = poly_cos(z);
+    const double cc = (q & 1) ? ps : pc;
+    return ((q + 1) & 2) ? -cc : cc;
+}
 ATL_HD __forceinline__ double lean_cos(double x) {
     int q;
     const double r = reduce_pio2(x, &q);

@@ -676,7 +676,7 @@ int atl_pv_probe_host(const atl_pv_params *p, int family, int64_t n, const doubl
         constexpr int TL = decltype(tl)::value, TR = decltype(tr)::value;
         for (int64_t i = 0; i < n; ++i) {
             const PvOri o = PvConvT<false, true, false, TL>::make_ori(slope[i], pazim[i]);
-            h_out[i] = pv_cell<TL, TR>(dir[i], dif[i], toa[i], alb[i], tmp[i], alt[i], az[i], o, k);
+            h_out[i] = pv_cell_auto<TL, TR>(dir[i], dif[i], toa[i], alb[i], tmp[i], alt[i], az[i], o, k);
         }
         return int(ATL_OK);
     };
