@@ -7,38 +7,7 @@
 // converters
 // ---------------------------------------------------------------------------------------
 struct NoCell {};
-struct NoCarry {};  // per-wave state a converter may keep across consecutive slots (pv night skip)
-// converters may define batch_prefetch<VEC>(sb, send, c0, c1, carry); the others get this no-op
-template <bool VEC, class Conv, class Carry>
-__device__ __forceinline__ auto batch_prefetch(const Conv &conv, int64_t sb, int64_t send, int64_t c0, int64_t c1,
-                                               Carry &carry, int) -> decltype(conv.template batch_prefetch<VEC>(sb, send, c0, c1, carry)) {
-    conv.template batch_prefetch<VEC>(sb, send, c0, c1, carry);
-}
-template <bool VEC, class Conv, class Carry>
-__device__ __forceinline__ void batch_prefetch(const Conv &, int64_t, int64_t, int64_t, int64_t, Carry &, long) {}
-
-// converters may define batch_begin(cell, carry), called before a batch's loads: returns wave-uniform "this
-// batch converts to +0.0 everywhere" (pv night early-out)
-template <class Conv, class Cell, class Carry>
-__device__ __forceinline__ auto batch_begin(const Conv &conv, const Cell &c, Carry &carry, int) -> decltype(conv.batch_begin(c, carry)) {
-    return conv.batch_begin(c, carry);
-}
-template <class Conv, class Cell, class Carry>
-__device__ __forceinline__ bool batch_begin(const Conv &, const Cell &, Carry &, long) {
-    return false;
-}
-// ... and kWaveLdsDoubles + carry_bind(carry, wave_lds, lane): per-wave LDS for the carry state
-template <class Conv, class = void>
-struct conv_wave_lds : std::integral_constant<int, 0> {};
-template <class Conv>
-struct conv_wave_lds<Conv, std::void_t<decltype(Conv::kWaveLdsDoubles)>> : std::integral_constant<int, Conv::kWaveLdsDoubles> {};
-template <class Conv, class Carry>
-__device__ __forceinline__ auto carry_bind(const Conv &conv, Carry &carry, double *wave_lds, int lane, int) -> decltype(conv.carry_bind(carry, wave_lds, lane)) {
-    conv.carry_bind(carry, wave_lds, lane);
-}
-template <class Conv, class Carry>
-__device__ __forceinline__ void carry_bind(const Conv &, Carry &, double *, int, long) {}
-
+struct NoCarry {};  // per-wave state a converter may keep across consecutive slots (none does at present)
 template <class C>
 __device__ __forceinline__ C carry_init() {
     return C{};

@@ -299,21 +299,17 @@ ATL_HD __forceinline__ double pv_cell_sp(double dir, double dif, double toa, dou
 
 // SP: in-kernel solar position; PC: per-cell orientation (else the scalar orientation is read from
 // the kernel arguments = SGPRs and costs no per-lane registers)
-// SKIP: night early-out (stored solar position only): when every valid cell of the wave is below
-// the altitude cut-off the other six streams are not read - the result is exactly +0.0 whatever
-// they hold (pv_cell).  The altitude of the NEXT slot is prefetched together with the current slot's
-// streams (Carry), so day-time slots still cost one memory round trip.
+// SKIP: night early-out - the fused kernel is k_fused_segred_night: slots in which every cell of the wave's tile
+// is below the altitude cut-off are neither read nor converted (the result is exactly +0.0 whatever the other
+// cubes hold, pv_cell).  Stored angles: the altitude cube decides (8 B/cell still read); in-kernel solar
+// position: the (T, X) hour-angle table decides, no cube byte is read at night.
 // TAIL: the Huld panel model (pv), the solar thermal collector or the plain tilted irradiation - the two
 // non-panel tails exist for stored solar angles without night skip (everything else of those calls
 // goes through the general kernel).
 // TRACK: a tracker (pv(tracking=...)) with the Huld panel, either trigon model, scalar or per-cell orientation
 // and stored solar angles - the ways trackers are used with pv(); other mixes stay general.
-#ifndef ATL_SKIP_MODE
-#define ATL_SKIP_MODE 8  // bit 3: k_fused_segred_night (pipelined day-slot loop); bit 2: altitudes parked in LDS + a day mask (frees 32 VGPRs: two slots of loads in flight); bit 0: night loads redirected to a cached line instead of a branch per slot; bit 1: whole-batch early-out
-#endif
 template <bool SP, bool PC = false, bool SKIP = false, int TAIL = kTailHuld, int TRACK = ATL_TRACK_NONE>
 struct PvConvT {
-    static_assert(!(SP && SKIP), "night skip is implemented for stored solar angles");
     static_assert(TAIL == kTailHuld || (!SP && !SKIP), "the non-panel tails are built for stored angles, no skip");
     static_assert(TRACK == ATL_TRACK_NONE || (!SP && !SKIP && (TAIL == kTailHuld || TAIL == kTailHuldHayDavies)),
                   "trackers: stored angles, Huld panel (either trigon model)");
@@ -335,7 +331,7 @@ struct PvConvT {
     };
     struct NoOri {};
     struct Cell : std::conditional_t<SP, SpCell, NoSp>, std::conditional_t<PC, OriCell, NoOri> {
-        int no_cell;  // SKIP: this lane owns no cell at all (tile padding); int: a bool member ends up in a scratch byte
+        int no_cell;  // this lane owns no cell at all (tile padding); int: a bool member ends up in a scratch byte
     };
     __device__ void block_init(double *) const {}
     ATL_HD static PvOri make_ori(double slope, double azimuth) {
@@ -375,152 +371,75 @@ struct PvConvT {
         }
         return c;
     }
-#ifndef ATL_SKIP_GROUP
-#define ATL_SKIP_GROUP 1
-#endif
-    // 7 x 16 B per lane per slot already; registers are the limit
-    static constexpr int kGroup = SKIP ? ATL_SKIP_GROUP : ATL_PV_GROUP;
+    static constexpr int kGroup = ATL_PV_GROUP;  // 7 x 16 B per lane per slot already; registers are the limit
     struct Raw {
         double2 dir, dif, toa, alb, tmp;
         double2 a, b;    // getter: altitude, azimuth   SP: hour angle, cos(hour angle)
         double sd, cd;   // SP: sin / cos declination of the slot
     };
-    struct SkipCarry {
-        double2 alt[kBatch];  // solar altitude of the batch's slots, prefetched one batch ahead
-        int64_t hot;          // offset of an altitude line this wave has fetched already (the batch's first slot)
-        unsigned day;         // bit i: slot i of the batch has a cell above the cut-off somewhere in the tile (wave-uniform)
-        double *lds;          // this lane's 16 bytes of the wave's altitude area (kBatch rows of kSegCells doubles)
-    };
-    // per-wave LDS the kernel reserves behind the row-weight cache: the batch's altitudes are parked there once
-    // the votes are taken, so the 32 VGPRs they arrived in are free while the batch is converted
-    static constexpr int kWaveLdsDoubles = (SKIP && (ATL_SKIP_MODE & 4) != 0) ? kBatch * kSegCells : 0;
-    using Carry = std::conditional_t<SKIP, SkipCarry, NoCarry>;
-    __device__ __forceinline__ void carry_bind(Carry &carry, double *wave_lds, int lane) const {
-        if constexpr (SKIP) {
-            carry.lds = wave_lds + 2 * lane;
-            carry.day = 0;
+    using Carry = NoCarry;
+    // ---- k_fused_segred_night interface (night early-out) -----------------------------------------------------
+    // a cell below the altitude cut-off converts to +0.0 whatever the other cubes hold (pv_cell: capped; a NaN
+    // altitude is NOT capped)
+    static constexpr bool kNightPipe = SKIP;
+    // register budget of the fused kernels: the night kernel with stored angles and one orientation for the grid
+    // fits 4 waves per SIMD
+    static constexpr int kMinWaves = (kNightPipe && !PC && !SP) ? 4 : 3;
+    // stored angles: key = the slot's solar altitude.  In-kernel solar position: key = cos(hour angle) of the
+    // lane's two grid columns (a (T, X) table), from which sin(altitude) follows with the slot's declination and
+    // the cells' latitude - night is known before a single byte of the cubes is read.
+    template <bool VEC>
+    __device__ __forceinline__ double2 key_load(int64_t slot, int64_t c0, int64_t c1, const Cell &c) const {
+        if constexpr (SP) {
+            const int64_t hb = slot * in.X;
+            return double2{in.d_cos_hour_angle[hb + c.x0], in.d_cos_hour_angle[hb + c.x1]};
+        } else {
+            return ld2<VEC>(in.d_solar_altitude, slot * S, c0, c1);
         }
     }
-    // called before the first batch and again right after a batch has been converted (i.e. while it
-    // is being reduced): the next batch's altitudes are in flight behind the wave reduction
-    template <bool VEC>
-    __device__ __forceinline__ void batch_prefetch(int64_t sb, int64_t send, int64_t c0, int64_t c1, Carry &carry) const {
-        if constexpr (SKIP) {
-#pragma unroll
-            for (int i = 0; i < kBatch; ++i)
-                carry.alt[i] = ld2<VEC>(in.d_solar_altitude, min(sb + i, send - 1) * S, c0, c1);
-            carry.hot = sb * S;
+    __device__ __forceinline__ bool key_is_zero(double2 key, int64_t slot, const Cell &c) const {
+        if constexpr (SP) {  // pv_cell_sp's own test, same operations: s < sin(threshold)
+            const double sd = in.d_sin_dec[slot], cd = in.d_cos_dec[slot];
+            const double s0 = np_clip(sd * c.sl0 + cd * c.cl0 * key.x, -1.0, 1.0);
+            const double s1 = np_clip(sd * c.sl1 + cd * c.cl1 * key.y, -1.0, 1.0);
+            return (s0 < k.sin_alt_thr) && (s1 < k.sin_alt_thr);
+        } else {
+            return (key.x < k.alt_thr) && (key.y < k.alt_thr);
         }
     }
-    // wave-uniform: every cell of the tile is capped in every slot of the batch, so the batch converts to
-    // exactly +0.0 (pv_cell) and the kernel skips its loads and conversions altogether
-    __device__ __forceinline__ bool batch_begin(const Cell &c, Carry &carry) const {
-        if constexpr (SKIP && (ATL_SKIP_MODE & 4) != 0) {
-            unsigned day = 0;
-#pragma unroll
-            for (int i = 0; i < kBatch; ++i) {
-                // capped <=> alt < threshold (a NaN altitude is NOT capped); lanes that own no cell loaded some
-                // other cell's altitude and vote "night" unconditionally
-                const bool night = (carry.alt[i].x < k.alt_thr) && (carry.alt[i].y < k.alt_thr);
-                day |= __all(night || c.no_cell) ? 0u : 1u << i;
-            }
-            carry.day = day;
-            if (day == 0) return true;
-#pragma unroll
-            for (int i = 0; i < kBatch; ++i) *reinterpret_cast<double2 *>(carry.lds + i * kSegCells) = carry.alt[i];
-            return false;
-        } else if constexpr (SKIP && (ATL_SKIP_MODE & 2) != 0) {
-            bool night = true;
-#pragma unroll
-            for (int i = 0; i < kBatch; ++i) night = night && (carry.alt[i].x < k.alt_thr) && (carry.alt[i].y < k.alt_thr);
-            return __all(night || c.no_cell);
-        }
-        return false;
-    }
-    // ---- k_fused_segred_night interface (night early-out, stored solar angles) ---------------------------------
-    // key = the slot's solar altitude; a cell below the cut-off converts to +0.0 whatever the other six cubes
-    // hold (pv_cell: capped; a NaN altitude is NOT capped)
-    static constexpr bool kNightPipe = SKIP && (ATL_SKIP_MODE & 8) != 0;
-    // register budget of the fused kernels: the night kernel with one orientation for the grid fits 4 waves per SIMD
-    static constexpr int kMinWaves = (kNightPipe && !PC) ? 4 : 3;
     template <bool VEC>
-    __device__ __forceinline__ double2 key_load(int64_t slot, int64_t c0, int64_t c1) const {
-        return ld2<VEC>(in.d_solar_altitude, slot * S, c0, c1);
-    }
-    __device__ __forceinline__ bool key_is_zero(double2 alt) const { return (alt.x < k.alt_thr) && (alt.y < k.alt_thr); }
-    template <bool VEC>
-    __device__ __forceinline__ Raw rest_load(int64_t slot, int64_t c0, int64_t c1, const Cell &) const {
+    __device__ __forceinline__ Raw rest_load(int64_t slot, int64_t c0, int64_t c1, const Cell &c) const {
         const int64_t off = slot * S;
         Raw r;
-        r.sd = r.cd = 0.0;
-        r.a = double2{0.0, 0.0};
         r.dir = ld2<VEC>(in.d_influx_direct, off, c0, c1);
         r.dif = ld2<VEC>(in.d_influx_diffuse, off, c0, c1);
         r.toa = ld2<VEC>(in.d_influx_toa, off, c0, c1);
         r.alb = ld2<VEC>(in.d_albedo, off, c0, c1);
         r.tmp = ld2<VEC>(in.d_temperature, off, c0, c1);
-        r.b = ld2<VEC>(in.d_solar_azimuth, off, c0, c1);
+        if constexpr (SP) {
+            r.sd = in.d_sin_dec[slot];
+            r.cd = in.d_cos_dec[slot];
+            const int64_t hb = slot * in.X;
+            r.a.x = in.d_hour_angle[hb + c.x0];
+            r.a.y = in.d_hour_angle[hb + c.x1];
+            r.b = double2{0.0, 0.0};
+        } else {
+            r.sd = r.cd = 0.0;
+            r.a = double2{0.0, 0.0};
+            r.b = ld2<VEC>(in.d_solar_azimuth, off, c0, c1);
+        }
         return r;
     }
-    __device__ __forceinline__ double2 compute_keyed(const Raw &q, double2 alt, bool v0, bool v1, const Cell &c,
+    __device__ __forceinline__ double2 compute_keyed(const Raw &q, double2 key, bool v0, bool v1, const Cell &c,
                                                      const double *lds) const {
         Raw r = q;
-        r.a = alt;
+        if constexpr (SP) r.b = key; else r.a = key;
         return compute(r, v0, v1, c, lds);
     }
     template <bool VEC>
     __device__ __forceinline__ Raw load(int64_t slot, int i, int64_t c0, int64_t c1, const Cell &c, Carry &carry) const {
         const int64_t off = slot * S;
         Raw r;
-        if constexpr (SKIP && (ATL_SKIP_MODE & 4) != 0) {
-            r.sd = r.cd = 0.0;
-            if (!((carry.day >> i) & 1u)) {  // wave-uniform: zero influx converts to exactly +0.0 (pv_cell: capped)
-                const double2 z = {0.0, 0.0};
-                r.dir = r.dif = r.toa = r.alb = r.tmp = r.a = r.b = z;
-                return r;
-            }
-            r.a = *reinterpret_cast<const double2 *>(carry.lds + i * kSegCells);
-            r.dir = ld2<VEC>(in.d_influx_direct, off, c0, c1);
-            r.dif = ld2<VEC>(in.d_influx_diffuse, off, c0, c1);
-            r.toa = ld2<VEC>(in.d_influx_toa, off, c0, c1);
-            r.alb = ld2<VEC>(in.d_albedo, off, c0, c1);
-            r.tmp = ld2<VEC>(in.d_temperature, off, c0, c1);
-            r.b = ld2<VEC>(in.d_solar_azimuth, off, c0, c1);
-            return r;
-        } else if constexpr (SKIP) {
-            r.a = carry.alt[i];
-            r.sd = r.cd = 0.0;
-            // capped <=> alt < threshold (a NaN altitude is NOT capped); lanes that own no cell loaded
-            // some other cell's altitude and vote "night" unconditionally
-            const bool night = (r.a.x < k.alt_thr) && (r.a.y < k.alt_thr);
-#if ATL_SKIP_MODE & 1
-            // Night slot: the same six loads, redirected to an altitude line this wave has fetched already
-            // (a cache hit, no HBM traffic).  The slot converts to +0.0 whatever they return, and the batch
-            // stays one branch-free block whose loads the compiler schedules ahead of the conversions -
-            // a branch per slot left one slot's 6 KiB in flight per wave (5.2 TB/s on the bytes moved).
-            const bool skip = __all(night || c.no_cell);
-            const int64_t o2 = skip ? carry.hot : off;
-            r.dir = ld2<VEC>(skip ? in.d_solar_altitude : in.d_influx_direct, o2, c0, c1);
-            r.dif = ld2<VEC>(skip ? in.d_solar_altitude : in.d_influx_diffuse, o2, c0, c1);
-            r.toa = ld2<VEC>(skip ? in.d_solar_altitude : in.d_influx_toa, o2, c0, c1);
-            r.alb = ld2<VEC>(skip ? in.d_solar_altitude : in.d_albedo, o2, c0, c1);
-            r.tmp = ld2<VEC>(skip ? in.d_solar_altitude : in.d_temperature, o2, c0, c1);
-            r.b = ld2<VEC>(skip ? in.d_solar_altitude : in.d_solar_azimuth, o2, c0, c1);
-            return r;
-#endif
-            if (__all(night || c.no_cell)) {
-                const double2 z = {0.0, 0.0};
-                r.dir = r.dif = r.toa = r.alb = r.tmp = r.b = z;
-                return r;
-            }
-            r.dir = ld2<VEC>(in.d_influx_direct, off, c0, c1);
-            r.dif = ld2<VEC>(in.d_influx_diffuse, off, c0, c1);
-            r.toa = ld2<VEC>(in.d_influx_toa, off, c0, c1);
-            r.alb = ld2<VEC>(in.d_albedo, off, c0, c1);
-            r.tmp = ld2<VEC>(in.d_temperature, off, c0, c1);
-            r.b = ld2<VEC>(in.d_solar_azimuth, off, c0, c1);
-            return r;
-        }
         r.dir = ld2<VEC>(in.d_influx_direct, off, c0, c1);
         r.dif = ld2<VEC>(in.d_influx_diffuse, off, c0, c1);
         r.toa = ld2<VEC>(in.d_influx_toa, off, c0, c1);

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fuse
     const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
     // per-wave LDS area behind the converter's tables: the weights of the tile's first kRowCache partial
     // rows (LDS instead of 4 VGPRs per row for the whole chunk: the register budget decides the occupancy)
-    constexpr int kWaveLds = kRowCache * kSegCells + conv_wave_lds<Conv>::value;
+    constexpr int kWaveLds = kRowCache * kSegCells;
     double *wlds = lds + conv_lds_doubles + wave * kWaveLds;
 #ifndef ATL_XCD_MAP
     // Linear order: consecutive blocks (= consecutive XCDs, block b runs on XCD b % 8) take consecutive
@@ -305,8 +305,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fuse
     const int64_t send = min(sbeg + int64_t(chunk_slots), slot0 + n_slots);
     partials -= slot0;
     typename Conv::Carry carry = carry_init<typename Conv::Carry>();
-    carry_bind(conv, carry, wlds + kRowCache * kSegCells, lane, 0);
-    batch_prefetch<VEC>(conv, sbeg, send, s0c, s1c, carry, 0);
     for (int64_t sb = sbeg; sb < send; sb += kBatch) {
         double2 v[kBatch];
         bool finite = true;
@@ -314,30 +312,24 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fuse
         // independent 1-KiB loads in flight per wave; slots past the end of a ragged chunk re-load
         // its last slot (loads stay unconditional) and are zeroed afterwards.
         constexpr int G = Conv::kGroup;
-        if (batch_begin(conv, cell, carry, 0)) {  // wave-uniform (pv night early-out): nothing to read or convert
 #pragma unroll
-            for (int i = 0; i < kBatch; ++i) v[i] = double2{0.0, 0.0};
-        } else {
+        for (int i0 = 0; i0 < kBatch; i0 += G) {
+            typename Conv::Raw raw[G];
 #pragma unroll
-            for (int i0 = 0; i0 < kBatch; i0 += G) {
-                typename Conv::Raw raw[G];
+            for (int g = 0; g < G; ++g) {
+                raw[g] = conv.template load<VEC>(min(sb + i0 + g, send - 1), i0 + g, s0c, s1c, cell, carry);
+            }
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    raw[g] = conv.template load<VEC>(min(sb + i0 + g, send - 1), i0 + g, s0c, s1c, cell, carry);
-                }
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const int i = i0 + g;
-                    const bool live = sb + i < send;
-                    v[i] = conv.compute(raw[g], v0, v1, cell, lds);
-                    v[i].x = live ? v[i].x : 0.0;
-                    v[i].y = live ? v[i].y : 0.0;
-                    // |x| < inf is false for NaN and +-inf
-                    finite = finite && (__builtin_fabs(v[i].x) < __builtin_inf()) && (__builtin_fabs(v[i].y) < __builtin_inf());
-                }
+            for (int g = 0; g < G; ++g) {
+                const int i = i0 + g;
+                const bool live = sb + i < send;
+                v[i] = conv.compute(raw[g], v0, v1, cell, lds);
+                v[i].x = live ? v[i].x : 0.0;
+                v[i].y = live ? v[i].y : 0.0;
+                // |x| < inf is false for NaN and +-inf
+                finite = finite && (__builtin_fabs(v[i].x) < __builtin_inf()) && (__builtin_fabs(v[i].y) < __builtin_inf());
             }
         }
-        if (sb + kBatch < send) batch_prefetch<VEC>(conv, sb + kBatch, send, s0c, s1c, carry, 0);
 #ifdef ATL_ABLATE_NOREDUCE  // experiment: conversion only, one dummy store per batch
         {
             double acc = 0.0;
@@ -410,13 +402,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fuse
     partials -= slot0;
     double2 key[kBatch];
 #pragma unroll
-    for (int i = 0; i < kBatch; ++i) key[i] = conv.template key_load<VEC>(min(sbeg + i, send - 1), s0c, s1c);
+    for (int i = 0; i < kBatch; ++i) key[i] = conv.template key_load<VEC>(min(sbeg + i, send - 1), s0c, s1c, cell);
     for (int64_t sb = sbeg; sb < send; sb += kBatch) {
         // votes: bit i of day = some cell of the tile is converted in slot sb + i
         unsigned day = 0;
 #pragma unroll
         for (int i = 0; i < kBatch; ++i) {
-            const bool d = (sb + i < send) && !__all(conv.key_is_zero(key[i]) || no_cell);
+            const bool d = (sb + i < send) && !__all(conv.key_is_zero(key[i], min(sb + i, send - 1), cell) || no_cell);
             day |= d ? 1u << i : 0u;
             *reinterpret_cast<double2 *>(vrow + i * kSegCells) = d ? key[i] : double2{0.0, 0.0};
         }
@@ -439,7 +431,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fuse
         // next batch's keys: in flight behind the reduction
         if (sb + kBatch < send) {
 #pragma unroll
-            for (int i = 0; i < kBatch; ++i) key[i] = conv.template key_load<VEC>(min(sb + kBatch + i, send - 1), s0c, s1c);
+            for (int i = 0; i < kBatch; ++i) key[i] = conv.template key_load<VEC>(min(sb + kBatch + i, send - 1), s0c, s1c, cell);
         }
         double2 v[kBatch];
 #pragma unroll
@@ -630,7 +622,7 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
 #endif
             // dynamic LDS: the converter's tables, then kRowCache weight rows per wave
             const size_t conv_lds = align_up(lds_bytes, 16);
-            const size_t lds_total = conv_lds + size_t(kWavesPerBlock) * (kRowCache * kSegCells + conv_wave_lds<Conv>::value) * sizeof(double);
+            const size_t lds_total = conv_lds + size_t(kWavesPerBlock) * kRowCache * kSegCells * sizeof(double);
             const int32_t conv_lds_doubles = int32_t(conv_lds / sizeof(double));
             KernelBracket kb(ctx);
             if constexpr (conv_night_pipe<Conv>::value) {

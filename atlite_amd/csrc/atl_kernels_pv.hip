@@ -88,8 +88,11 @@ int pv_dispatch(const atl_pv_inputs *in, const atl_pv_params *p, bool allow_skip
         return pc ? f(PvConvT<false, true, false, kTailThermal>()) : f(PvConvT<false, false, false, kTailThermal>());
     if (p->panel_model == ATL_PANEL_NONE)
         return pc ? f(PvConvT<false, true, false, kTailIrradiation>()) : f(PvConvT<false, false, false, kTailIrradiation>());
+    if (p->night_skip && allow_skip) {
+        if (sp) return pc ? f(PvConvT<true, true, true>()) : f(PvConvT<true, false, true>());
+        return pc ? f(PvConvT<false, true, true>()) : f(PvConvT<false, false, true>());
+    }
     if (sp) return pc ? f(PvConvT<true, true>()) : f(PvConvT<true, false>());
-    if (p->night_skip && allow_skip) return pc ? f(PvConvT<false, true, true>()) : f(PvConvT<false, false, true>());
     return pc ? f(PvConvT<false, true>()) : f(PvConvT<false, false>());
 }
 
@@ -126,9 +129,13 @@ int atl_pv_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p
     if (pv_needs_general(in, p)) return pvx_convert(ctx, in, p, T, S, time_agg, d_out);
     bool vec;
     return pv_dispatch(in, p, false, [&](auto c) {  // night skip: fused (aggregating) kernel only
-        int rc = make_pv(in, p, T, S, &c, &vec);
-        if (rc) return rc;
-        return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
+        if constexpr (decltype(c)::kNightPipe) {  // never dispatched here (allow_skip = false): no per-cell kernels for it
+            return int(ATL_E_INVALID);
+        } else {
+            int rc = make_pv(in, p, T, S, &c, &vec);
+            if (rc) return rc;
+            return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
+        }
     });
 }
 

@@ -315,6 +315,40 @@ def test_pv_night_skip_is_bit_identical(ctx, Y, X):
     np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-12 * np.nanmax(np.abs(ref[np.isfinite(ref)])), equal_nan=True)
 
 
+@pytest.mark.parametrize("T,Y,X,N", [(72, 12, 20, 5), (61, 9, 27, 40)])
+def test_pv_night_skip_in_kernel_solar_position(ctx, T, Y, X, N):
+    """The night early-out with the in-kernel solar position: night follows from the (T, X) hour-angle table,
+    the declination and the latitude before any cube byte is read.  Same bits as without the skip (ragged last
+    batch, tiles with more partial rows than the LDS cache holds, NaN / inf inputs in night rows), and the
+    oracle's values."""
+    from atlite_amd import solar
+
+    ds = H.pv_dataset(T, Y, X, seed=21)
+    ds["temperature"][2, :] = np.nan
+    ds["influx_direct"][3, :] = np.inf
+    x, y = H.grid(Y, X)
+    time = H.times(T)
+    h, dec = solar.hour_angle(time, x, "0h")
+    lat = np.radians(y)
+    tables = dict(sin_dec=np.sin(dec), cos_dec=np.cos(dec), h=h, cos_h=np.cos(h), sin_lat=np.sin(lat), cos_lat=np.cos(lat))
+    five = {k: ctx.upload(ds[k].reshape(T, -1)) for k in ("influx_direct", "influx_diffuse", "influx_toa", "albedo", "temperature")}
+    M = H.blob_matrix(N, Y, X, seed=22)
+    plan = ctx.plan(M, row_len=X)
+    _, ygrid = H.grid(Y, X)
+    lo = orc.orientation_latitude_optimal(np.radians(ygrid))
+    for params in (PV_PARAMS, dict(H.CSI, slope=np.repeat(lo["slope"], X), azimuth=np.repeat(lo["azimuth"], X))):
+        for kw in (dict(), dict(time_agg="mean")):
+            a = ctx.pv(five, params, T, Y * X, plan=plan, solar_tables=tables, options=dict(night_skip=False), **kw).numpy()
+            b = ctx.pv(five, params, T, Y * X, plan=plan, solar_tables=tables, options=dict(night_skip=True), **kw).numpy()
+            np.testing.assert_array_equal(a, b)
+    alt, az = orc.solar_position(time, x, y, "0h")
+    full = dict(ds, solar_altitude=alt.reshape(T, -1), solar_azimuth=az.reshape(T, -1))
+    ref = orc.aggregate_matrix(orc.convert_pv(full, H.CSI, dict(slope=np.radians(30.0), azimuth=np.radians(180.0))), M)
+    got = ctx.pv(five, PV_PARAMS, T, Y * X, plan=plan, solar_tables=tables, options=dict(night_skip=True)).numpy()
+    assert (got == 0).any() and got.max() > 0
+    np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-12 * np.nanmax(np.abs(ref[np.isfinite(ref)])), equal_nan=True)
+
+
 @pytest.mark.parametrize("tile", ["16x8", "32x4", "64x2"])
 def test_every_cell_owned_exactly_once(ctx, monkeypatch, tile):
     """A 128-byte line that straddles two grid rows belongs to ONE tile (the lower row's first tile
