@@ -882,20 +882,10 @@ def coefficient_of_performance(cutout, source="air", sink_T=55.0, c0=None, c1=No
     )
 
 
-def runoff(cutout, smooth=None, lower_threshold_quantile=None, normalize_using_yearly=None, **params):
-    """
-    Runoff (optionally height-weighted) aggregated to shapes, with the reference's
-    post-processing of the small (shapes x time) result on the host (convert.py:1037-1084).
-    """
-    result = cutout.convert_and_aggregate(convert_func=convert_runoff, **params)
-    cap = None
-    if "return_capacity" in params.keys() and isinstance(result, tuple):
-        result, cap = result
-    is_xr = labeled.xr is not None and isinstance(result, labeled.xr.DataArray)
-    la = result if not is_xr else LabeledArray(result.values, result.dims,
-                                               {d: result.coords[d].values for d in result.dims},
-                                               dict(result.attrs), result.name)
-
+def _runoff_postprocess(la, smooth=None, lower_threshold_quantile=None, normalize_using_yearly=None):
+    """convert.py:1045-1082 on the small (shapes x time) result, host side: rolling mean over `smooth` steps
+    (min_periods=1), values below the `lower_threshold_quantile` quantile of all values set to 0, and scaling to
+    reported yearly totals over the full years the series and `normalize_using_yearly` share."""
     if smooth is not None:
         if smooth is True:
             smooth = 24 * 7
@@ -931,6 +921,24 @@ def runoff(cutout, smooth=None, lower_threshold_quantile=None, normalize_using_y
         shape = [1, 1]
         shape[1 - ax] = -1
         la = LabeledArray(la.values * fac.reshape(shape), la.dims, la.coords, la.attrs, la.name)
+    return la
+
+
+def runoff(cutout, smooth=None, lower_threshold_quantile=None, normalize_using_yearly=None, **params):
+    """
+    Runoff (optionally height-weighted) aggregated to shapes, with the reference's
+    post-processing of the small (shapes x time) result on the host (convert.py:1037-1084).
+    """
+    result = cutout.convert_and_aggregate(convert_func=convert_runoff, **params)
+    cap = None
+    if "return_capacity" in params.keys() and isinstance(result, tuple):
+        result, cap = result
+    is_xr = labeled.xr is not None and isinstance(result, labeled.xr.DataArray)
+    la = result if not is_xr else LabeledArray(result.values, result.dims,
+                                               {d: result.coords[d].values for d in result.dims},
+                                               dict(result.attrs), result.name)
+
+    la = _runoff_postprocess(la, smooth, lower_threshold_quantile, normalize_using_yearly)
 
     out = _finish(la) if is_xr or labeled.xr is not None else la
     return (out, cap) if cap is not None else out

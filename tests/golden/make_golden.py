@@ -262,6 +262,41 @@ def main():
         g["legacy_matrix"] = run(matrix=M).values  # legacy = series
         g["capfactor"] = run(capacity_factor=True).values
     save("gateway_pv", **g)
+
+    # ---------------------------------------------------------------- runoff() post-processing ---
+    # convert.py:1037-1084 (smooth / lower_threshold_quantile / normalize_using_yearly) needs whole years: two
+    # years + a stub on a 3 x 4 grid.  The input cube is NOT stored: the test regenerates it from the seed
+    # (tests/helpers.py: runoff_post_inputs); outputs are kept at the sampled time steps `sel`.
+    sys.path.insert(0, str(HERE.parents[1]))
+    from tests.helpers import runoff_post_inputs, runoff_post_sample  # seeded inputs shared with the tests
+
+    ro2, height2, M2, names, t2, y2, x2 = runoff_post_inputs()
+    ds2 = xr.Dataset(
+        {"runoff": xr.DataArray(ro2, dims=["time", "y", "x"], coords={"time": t2, "y": y2, "x": x2}),
+         "height": xr.DataArray(height2, dims=["y", "x"], coords={"y": y2, "x": x2})},
+        coords={"time": t2, "y": y2, "x": x2, "lon": ("x", x2), "lat": ("y", y2)})
+    cut2 = MockCutout(ds2)
+    idx = pd.Index(names, name="countries")
+    sel = runoff_post_sample(len(t2))
+    yearly_dt = pd.DataFrame([[3.0, 5.0, 1.5], [2.0, 4.0, 1.0], [7.0, 7.0, 7.0]],
+                             index=pd.to_datetime(["2012-01-01", "2013-01-01", "2015-01-01"]), columns=names)
+    yearly_str = pd.DataFrame([[1.0, 2.0, 3.0], [3.0, 5.0, 1.5], [2.0, 4.0, 1.0]], index=["2011", "2012", "2013"],
+                              columns=names)
+    rp = dict(M=M2.toarray(), height=height2, sel=sel)
+    cases = {
+        "plain": dict(),
+        "smooth_true": dict(smooth=True),
+        "smooth24_q": dict(smooth=24, lower_threshold_quantile=True),
+        "q30": dict(lower_threshold_quantile=0.3),
+        "norm_dt_smooth48": dict(smooth=48, normalize_using_yearly=yearly_dt),
+        "norm_str": dict(normalize_using_yearly=yearly_str),
+        "noheight_norm": dict(normalize_using_yearly=yearly_str, weight_with_height=False),
+    }
+    for name, kw in cases.items():
+        r = conv.runoff(cut2, matrix=M2, index=idx, **kw)
+        assert r.dims == ("countries", "time"), r.dims
+        rp[name] = r.values[:, sel]
+    save("runoff_post", **rp)
     print("done")
 
 

@@ -102,6 +102,8 @@ class DataArray:
     __array_priority__ = 50
 
     def __init__(self, data=None, coords=None, dims=None, name=None, attrs=None, _index=False):
+        if isinstance(data, pd.Series) and coords is None and dims is not None and len(dims) == 1:
+            coords = {dims[0]: np.asarray(data.index)}  # xarray: a pandas object brings its index along
         data = data.values if _is_da(data) else np.asarray(data)
         if dims is None:
             if isinstance(coords, _Coords):
@@ -160,6 +162,12 @@ class DataArray:
         if isinstance(other, Dataset):
             return NotImplemented
         if _is_da(other):
+            for d in self.dims:  # xarray aligns (inner join) on shared indexed dimensions
+                if d in other.dims and d in self._coords and d in other._coords:
+                    a_i, b_i = pd.Index(self._coords[d].values), pd.Index(other._coords[d].values)
+                    if not a_i.equals(b_i):
+                        common = a_i.intersection(b_i)
+                        return self.reindex(**{d: common})._binary(other.reindex(**{d: common}), op, reflexive)
             out_dims = list(self.dims) + [d for d in other.dims if d not in self.dims]
             if reflexive:
                 out_dims = list(other.dims) + [d for d in self.dims if d not in other.dims]
@@ -315,6 +323,44 @@ class DataArray:
         coords = _Coords({d: other.coords[d] for d in self.dims if d in other.coords})
         return DataArray(vals, coords=coords, dims=self.dims, name=self.name, attrs=self.attrs)
 
+    def get_axis_num(self, dim):
+        return self.dims.index(dim)
+
+    def reindex(self, **kw):
+        vals, coords = self._values, _Coords(dict(self._coords))
+        for d, want in kw.items():
+            ax = self.dims.index(d)
+            want = pd.Index(want.values if _is_da(want) else np.asarray(want))
+            have = pd.Index(np.asarray(self._coords[d].values))
+            idx = have.get_indexer(want)
+            taken = np.take(vals, np.where(idx < 0, 0, idx), axis=ax)
+            if (idx < 0).any():
+                mask = (idx < 0).reshape([-1 if i == ax else 1 for i in range(vals.ndim)])
+                taken = np.where(mask, np.nan, taken.astype(float))
+            vals = taken
+            coords[d] = DataArray(np.asarray(want), dims=[d], _index=True)
+        return DataArray(vals, coords=coords, dims=self.dims, name=self.name, attrs=self.attrs)
+
+    def sel(self, **kw):
+        out = self
+        for d, key in kw.items():
+            idx = pd.Index(np.asarray(out._coords[d].values))
+            assert isinstance(key, slice), "the stand-in selects label slices only"
+            if isinstance(idx, pd.DatetimeIndex) or np.issubdtype(np.asarray(idx).dtype, np.datetime64):
+                idx = pd.DatetimeIndex(idx)
+            pos = idx.slice_indexer(key.start, key.stop)  # label based, both ends inclusive, partial date strings
+            ax = out.dims.index(d)
+            vals = np.take(out._values, np.arange(len(idx))[pos], axis=ax)
+            coords = _Coords(dict(out._coords))
+            coords[d] = DataArray(np.asarray(idx)[pos], dims=[d], _index=True)
+            out = DataArray(vals, coords=coords, dims=out.dims, name=out.name, attrs=out.attrs)
+        return out
+
+    def rolling(self, min_periods=None, center=False, **kw):
+        ((dim, window),) = kw.items()
+        assert not center
+        return _Rolling(self, dim, int(window), min_periods)
+
     def resample(self, **kw):
         ((dim, freq),) = kw.items()
         assert freq == "1D"
@@ -344,6 +390,28 @@ for _n, _f in dict(lt=np.less, le=np.less_equal, gt=np.greater, ge=np.greater_eq
                    ne=np.not_equal).items():
     setattr(DataArray, f"__{_n}__", _mk_op(_f)[0])
 DataArray.__hash__ = object.__hash__
+
+
+class _Rolling:
+    """da.rolling(time=w, min_periods=m).mean(): trailing window, NaN-skipping, like pandas' rolling."""
+
+    def __init__(self, da, dim, window, min_periods):
+        self.da, self.dim, self.window = da, dim, window
+        self.min_periods = window if min_periods is None else min_periods
+
+    def mean(self):
+        da = self.da
+        ax = da.dims.index(self.dim)
+        v = np.moveaxis(np.asarray(da.values, dtype=float), ax, 0)
+        # xarray without bottleneck: NaN-padded window view along the dimension, then nanmean over the window
+        pad = np.full((self.window - 1,) + v.shape[1:], np.nan)
+        win = np.lib.stride_tricks.sliding_window_view(np.concatenate([pad, v], axis=0), self.window, axis=0)
+        valid = ~np.isnan(win)
+        cnt = valid.sum(axis=-1)
+        with np.errstate(all="ignore"):
+            out = np.where(valid, win, 0.0).sum(axis=-1) / cnt
+        out = np.where(cnt >= self.min_periods, out, np.nan)
+        return da._new(np.moveaxis(out, 0, ax))
 
 
 class _Resample:

@@ -73,3 +73,22 @@ def blob_matrix(N, Y, X, seed=0, overlap=True):
         cols += list(j)
         vals += list(w.ravel()[j])
     return sp.csr_matrix((vals, (rows, cols)), shape=(N, Y * X))
+
+
+def runoff_post_inputs():
+    """Seeded inputs of the runoff() post-processing vectors (tests/golden/make_golden.py freezes the reference's
+    outputs for exactly these; two years + a stub of hourly runoff on a 3 x 4 grid, 3 shapes)."""
+    r = np.random.default_rng(20240917)
+    t2 = pd.date_range("2012-01-01", "2014-01-05", freq="h", inclusive="left")  # 2012 (leap), 2013, 96 h of 2014
+    Y2, X2 = 3, 4
+    season = 1.0 + 0.8 * np.sin(2 * np.pi * (np.asarray(t2.dayofyear) - 100.0) / 365.0)
+    ro2 = -1e-4 * np.log1p(-r.random((len(t2), Y2, X2))) * season[:, None, None]
+    height2 = 2000 * r.random((Y2, X2))
+    M2 = sp.csr_matrix(np.where(r.random((3, Y2 * X2)) < 0.6, r.random((3, Y2 * X2)), 0.0))
+    x2 = 5.0 + 0.25 * np.arange(X2)
+    y2 = 45.0 + 0.25 * np.arange(Y2)
+    return ro2, height2, M2, ["AT", "CH", "NO"], t2, y2, x2
+
+
+def runoff_post_sample(T):
+    return np.unique(np.concatenate([np.arange(0, 240), np.arange(0, T, 37), np.arange(8700, 8900), np.arange(T - 240, T)]))

@@ -142,6 +142,24 @@ def test_runoff():
     np.testing.assert_allclose(rs.values[0], exp, rtol=1e-12)
 
 
+@pytest.mark.parametrize("case", ["smooth24_q", "q30", "norm_dt_smooth48", "norm_str", "noheight_norm"])
+def test_runoff_postprocessing(case):
+    """Cutout.runoff(smooth=, lower_threshold_quantile=, normalize_using_yearly=) end to end (device conversion +
+    aggregation over two years and a stub, host post-processing) against the reference's own runoff() outputs."""
+    from tests import helpers as H
+    from tests.test_oracle_golden import RUNOFF_POST_CASES, runoff_post_yearly
+
+    g = load("runoff_post")
+    ro, height, M, names, t, y, x = H.runoff_post_inputs()
+    c = Cutout(Dataset({"runoff": ro, "height": height}, dict(time=t, y=y, x=x)))
+    kw = dict(RUNOFF_POST_CASES[case])
+    if "normalize_using_yearly" in kw:
+        kw["normalize_using_yearly"] = runoff_post_yearly(kw["normalize_using_yearly"])
+    r = c.runoff(matrix=M, index=pd.Index(names, name="countries"), **kw)
+    assert r.dims == ("countries", "time")
+    close(r.values[:, g["sel"]], g[case])
+
+
 # ---- gateway semantics pinned by the reference's test/test_aggregate_time.py ------------------
 def identity_convert(ds, **kwargs):
     return ds["var"]

@@ -201,3 +201,51 @@ def test_temperatures_cop_cooling():
         ptr, _ = orc.day_groups(times(g["time"]), shift)
         np.testing.assert_allclose(orc.convert_cooling_demand(g["temperature"], ptr, 3.0, 0.7, 0.1),
                                    g[f"cool_shift{shift:+.0f}"], rtol=1e-15, equal_nan=True)
+
+
+RUNOFF_POST_CASES = {
+    "plain": dict(),
+    "smooth_true": dict(smooth=True),
+    "smooth24_q": dict(smooth=24, lower_threshold_quantile=True),
+    "q30": dict(lower_threshold_quantile=0.3),
+    "norm_dt_smooth48": dict(smooth=48, normalize_using_yearly="dt"),
+    "norm_str": dict(normalize_using_yearly="str"),
+    "noheight_norm": dict(normalize_using_yearly="str", weight_with_height=False),
+}
+
+
+def runoff_post_yearly(kind):
+    names = ["AT", "CH", "NO"]
+    if kind == "dt":
+        return pd.DataFrame([[3.0, 5.0, 1.5], [2.0, 4.0, 1.0], [7.0, 7.0, 7.0]],
+                            index=pd.to_datetime(["2012-01-01", "2013-01-01", "2015-01-01"]), columns=names)
+    return pd.DataFrame([[1.0, 2.0, 3.0], [3.0, 5.0, 1.5], [2.0, 4.0, 1.0]], index=["2011", "2012", "2013"], columns=names)
+
+
+@pytest.mark.parametrize("case", list(RUNOFF_POST_CASES))
+def test_runoff_postprocessing_host(case):
+    """runoff(smooth / lower_threshold_quantile / normalize_using_yearly), convert.py:1045-1082: the product's host
+    routine on the oracle's aggregated series against the outputs the reference's own runoff() produced under the
+    stand-in (two years + a stub, so the "full years" selection, the partial-year drop and the yearly scaling all run)."""
+    from atlite_amd.convert import _runoff_postprocess
+    from atlite_amd.labeled import LabeledArray
+
+    g = load("runoff_post")
+    ro, height, M, names, t, y, x = H.runoff_post_inputs()
+    np.testing.assert_array_equal(M.toarray(), g["M"])
+    np.testing.assert_array_equal(height, g["height"])
+    kw = dict(RUNOFF_POST_CASES[case])
+    weighted = kw.pop("weight_with_height", True)
+    cells = orc.convert_runoff(ro, height[None] if weighted else None).reshape(len(t), -1)
+    series = orc.aggregate_matrix(cells, M)  # (shapes, time)
+    if case in ("plain", "noheight_norm"):
+        exact_or_close = np.testing.assert_allclose
+        if case == "plain":
+            exact_or_close(series[:, g["sel"]], g["plain"], rtol=1e-14)
+    if "normalize_using_yearly" in kw:
+        kw["normalize_using_yearly"] = runoff_post_yearly(kw["normalize_using_yearly"])
+    la = LabeledArray(series, ("countries", "time"), {"countries": np.asarray(names), "time": t})
+    out = _runoff_postprocess(la, **kw)
+    assert out.dims == ("countries", "time")
+    np.testing.assert_allclose(out.values[:, g["sel"]], g[case], rtol=1e-10, atol=1e-12 * np.abs(g[case]).max())
+
