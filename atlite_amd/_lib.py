@@ -69,7 +69,7 @@ class PvParams(C.Structure):
         ("irradiation", C.c_int),
         ("panel_model", C.c_int),
     ] + [(n, C.c_double) for n in ("bof_A", "bof_B", "bof_C", "bof_D", "bof_NOCT", "bof_Tstd", "bof_Tamb", "bof_Intc",
-                                   "bof_ta", "bof_threshold", "st_c0", "st_c1", "st_t_store_K")] + [("night_skip", C.c_int)]
+                                   "bof_ta", "bof_threshold", "st_c0", "st_c1", "st_t_store_K")] + [("night_skip", C.c_int), ("orientation_per_time", C.c_int)]
 
 
 TRACKING = {None: 0, "horizontal": 1, "tilted_horizontal": 2, "vertical": 3, "dual": 4}

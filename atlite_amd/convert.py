@@ -90,6 +90,55 @@ def _need(ds, names, exc, msg):
             raise exc(msg)
 
 
+class _SolarPositionView:
+    """What orientation callbacks receive as ``solar_position`` (the reference hands over the Dataset SolarPosition
+    returns, pv/orientation.py:107): ``view["altitude"]`` / ``view["azimuth"]`` (or ``.altitude`` / ``.azimuth``)
+    are (time, y, x) LabeledArrays in radians on the HOST - copied from the device or computed on first access
+    only, since the shipped orientation factories never look at them."""
+
+    _names = ("altitude", "azimuth")
+
+    def __init__(self, ds):
+        self._ds, self._cache = ds, {}
+
+    def _get(self, name):
+        if name not in self._names:
+            raise KeyError(name)
+        if not self._cache:
+            ds = self._ds
+            c = {k: ds.coords[k] for k in ("time", "y", "x")}
+            if "solar_altitude" in ds and "solar_azimuth" in ds:  # the getter branch, solar_position.py:54-60
+                alt, az = ds["solar_altitude"].values, ds["solar_azimuth"].values
+            else:
+                from . import solar
+
+                alt, az = solar.position(ds.coords["time"], ds.coords["lon"], ds.coords["lat"], "0h")
+            shape = tuple(len(c[k]) for k in ("time", "y", "x"))
+            for n, v in (("altitude", alt), ("azimuth", az)):
+                self._cache[n] = LabeledArray(np.asarray(v).reshape(shape), ("time", "y", "x"), c, {"units": "rad"}, n)
+        return self._cache[name]
+
+    def __getitem__(self, name):
+        return self._get(name)
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        try:
+            return self._get(name)
+        except KeyError:
+            raise AttributeError(name) from None
+
+    def __contains__(self, name):
+        return name in self._names
+
+    def keys(self):
+        return list(self._names)
+
+    def __iter__(self):
+        return iter(self._names)
+
+
 class _PvSpec(_Spec):
     """convert_pv / convert_irradiation / convert_solar_thermal: one kernel family."""
 
@@ -169,30 +218,42 @@ class _PvSpec(_Spec):
             self.name, self.attrs = "AC power", {}
         elif panel_model == "solar_thermal":
             self.name, self.attrs = None, {}
-        # orientation callback evaluated on the host with radian lon / lat (orientation.py:104-107)
+        # orientation callback evaluated on the host with radian lon / lat and the sun's position
+        # (orientation.py:104-107); the shipped factories ignore the third argument, a user callback may
+        # read solar_position["altitude"] / ["azimuth"] (fetched or computed only then) and return angles
+        # that depend on time - those become two more cubes for the general kernel
         x, y = ds.coords["x"], ds.coords["y"]
         lon = LabeledArray(np.radians(ds.coords["lon"]), ("x",), {"x": x}, name="lon")
         lat = LabeledArray(np.radians(ds.coords["lat"]), ("y",), {"y": y}, name="lat")
-        o = orientation(lon, lat, None)
-        self.slope = self._cellwise(o["slope"], len(y), len(x))
-        self.azimuth = self._cellwise(o["azimuth"], len(y), len(x))
+        o = orientation(lon, lat, _SolarPositionView(ds))
+        T = len(ds.coords["time"])
+        self.slope = self._cellwise(o["slope"], T, len(y), len(x))
+        self.azimuth = self._cellwise(o["azimuth"], T, len(y), len(x))
+        self.per_time = any(np.ndim(v) == 2 for v in (self.slope, self.azimuth))
+        if self.per_time:
+            self.slope = np.ascontiguousarray(np.broadcast_to(self.slope, (T, len(y) * len(x))))
+            self.azimuth = np.ascontiguousarray(np.broadcast_to(self.azimuth, (T, len(y) * len(x))))
 
     @staticmethod
-    def _cellwise(v, Y, X):
+    def _cellwise(v, T, Y, X):
+        """Orientation angle -> float, (S,) per cell or (T, S) per time step and cell."""
+        if labeled.xr is not None and isinstance(v, labeled.xr.DataArray):
+            v = LabeledArray(v.values, v.dims)
         if isinstance(v, LabeledArray):
+            a = np.asarray(v.values, dtype=np.float64)
+            full = ("time", "y", "x")
+            if any(d not in full for d in v.dims):
+                raise ValueError(f"orientation angles must be over (time, y, x), got dims {v.dims}")
+            a = np.transpose(a, [v.dims.index(d) for d in full if d in v.dims])
+            a = a.reshape([n if d in v.dims else 1 for d, n in zip(full, (T, Y, X))])
             if "time" in v.dims:
-                raise NotImplementedError("time-dependent orientation is not implemented on the GPU path")
-            a = v.values
-            if v.dims == ("y",):
-                a = np.broadcast_to(a[:, None], (Y, X))
-            elif v.dims == ("x",):
-                a = np.broadcast_to(a[None, :], (Y, X))
-            elif v.dims == ("x", "y"):
-                a = a.T
-            return np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+                return np.ascontiguousarray(np.broadcast_to(a, (T, Y, X))).reshape(T, Y * X)
+            return np.ascontiguousarray(np.broadcast_to(a[0], (Y, X))).reshape(-1)
         a = np.asarray(v, dtype=np.float64)
         if a.ndim == 0:
             return float(a)
+        if a.ndim == 3:
+            return np.ascontiguousarray(np.broadcast_to(a, (T, Y, X))).reshape(T, Y * X)
         return np.ascontiguousarray(np.broadcast_to(a, (Y, X))).reshape(-1)
 
     @property
@@ -202,8 +263,8 @@ class _PvSpec(_Spec):
     def prepare(self, ctx, ds):
         """Upload the per-call constant tables once (per-cell orientation, solar position tables)."""
         S = len(ds.coords["y"]) * len(ds.coords["x"])
-        if np.ndim(self.slope) != np.ndim(self.azimuth):  # mixed scalar / per-cell -> per-cell
-            self.slope = np.broadcast_to(self.slope, (S,))
+        if not isinstance(self.slope, DeviceArray) and np.ndim(self.slope) != np.ndim(self.azimuth):
+            self.slope = np.broadcast_to(self.slope, (S,))  # mixed scalar / per-cell -> per-cell
             self.azimuth = np.broadcast_to(self.azimuth, (S,))
         if isinstance(self.slope, np.ndarray):
             self.slope, self.azimuth = ctx.upload(self.slope), ctx.upload(self.azimuth)
@@ -211,7 +272,7 @@ class _PvSpec(_Spec):
             self.solar_tables = {k: ctx.upload(np.ascontiguousarray(v)) for k, v in self.solar_tables.items()}
 
     def for_slab(self, t0, t1):
-        if self.solar_tables is None:
+        if self.solar_tables is None and not self.per_time:
             return self
         import copy
 
@@ -219,9 +280,12 @@ class _PvSpec(_Spec):
             return v.slab(t0, t1) if isinstance(v, DeviceArray) else v[t0:t1]
 
         sub = copy.copy(self)
-        tb = self.solar_tables
-        sub.solar_tables = dict(tb, sin_dec=cut(tb["sin_dec"]), cos_dec=cut(tb["cos_dec"]), h=cut(tb["h"]),
-                                cos_h=cut(tb["cos_h"]))
+        if self.solar_tables is not None:
+            tb = self.solar_tables
+            sub.solar_tables = dict(tb, sin_dec=cut(tb["sin_dec"]), cos_dec=cut(tb["cos_dec"]), h=cut(tb["h"]),
+                                    cos_h=cut(tb["cos_h"]))
+        if self.per_time:  # the orientation cubes are cut along time with the inputs
+            sub.slope, sub.azimuth = cut(self.slope), cut(self.azimuth)
         return sub
 
     def run(self, ctx, ds, plan, time_agg, out=None):

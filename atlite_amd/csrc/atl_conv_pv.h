@@ -666,8 +666,9 @@ struct PvxConvT {
     PvConst k;
     PvxOpt o;
     double slope, azimuth;       // scalar orientation (radians)
-    const double *cell_slope;    // (S) or nullptr
-    const double *cell_azimuth;  // (S)
+    const double *cell_slope;    // (S), (T,S) with ori_per_time, or nullptr
+    const double *cell_azimuth;  // same
+    int ori_per_time;            // the orientation follows the sun: two more cubes, read per slot
     struct Cell {
         double sl0, sl1, az0, az1;   // panel slope / azimuth of the two cells
         double slat0, clat0, slat1, clat1;
@@ -678,7 +679,7 @@ struct PvxConvT {
         Cell c;
         c.sl0 = c.sl1 = slope;
         c.az0 = c.az1 = azimuth;
-        if (cell_slope) {
+        if (cell_slope && !ori_per_time) {
             c.sl0 = v0 ? cell_slope[c0] : 0.0;
             c.sl1 = v1 ? cell_slope[c0 + 1] : 0.0;
             c.az0 = v0 ? cell_azimuth[c0] : 0.0;
@@ -710,6 +711,7 @@ struct PvxConvT {
     static constexpr int kGroup = 1;
     struct Raw {
         double2 dir, dif, inf, toa, alb, ouf, tmp, hum, alt, az;
+        double2 osl, oaz;  // panel slope / azimuth of the slot (ori_per_time) or of the cells
     };
     using Carry = NoCarry;
     template <bool VEC>
@@ -725,6 +727,8 @@ struct PvxConvT {
         r.ouf = in.d_outflux ? ld2<VEC>(in.d_outflux, off, c0, c1) : zero;
         r.tmp = in.d_temperature ? ld2<VEC>(in.d_temperature, off, c0, c1) : zero;
         r.hum = in.d_humidity ? ld2<VEC>(in.d_humidity, off, c0, c1) : zero;
+        r.osl = ori_per_time ? ld2<VEC>(cell_slope, off, c0, c1) : double2{c.sl0, c.sl1};
+        r.oaz = ori_per_time ? ld2<VEC>(cell_azimuth, off, c0, c1) : double2{c.az0, c.az1};
 #ifdef ATL_PVX_NO_SP
         if (true) {
 #else
@@ -742,11 +746,11 @@ struct PvxConvT {
     }
     __device__ __forceinline__ double2 compute(const Raw &q, bool v0, bool v1, const Cell &c, const double *) const {
         double2 r;
-        r.x = v0 ? pvx_cell<TRACK, TRIGON>(q.dir.x, q.dif.x, q.inf.x, q.toa.x, q.alb.x, q.ouf.x, q.tmp.x, q.hum.x, q.alt.x, q.az.x, c.sl0, c.az0, k, o) : 0.0;
+        r.x = v0 ? pvx_cell<TRACK, TRIGON>(q.dir.x, q.dif.x, q.inf.x, q.toa.x, q.alb.x, q.ouf.x, q.tmp.x, q.hum.x, q.alt.x, q.az.x, q.osl.x, q.oaz.x, k, o) : 0.0;
 #if defined(ATL_PVX_SCHED_BARRIER) && defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_sched_barrier(0);  // do not interleave the two cells: halves the live temporaries
 #endif
-        r.y = v1 ? pvx_cell<TRACK, TRIGON>(q.dir.y, q.dif.y, q.inf.y, q.toa.y, q.alb.y, q.ouf.y, q.tmp.y, q.hum.y, q.alt.y, q.az.y, c.sl1, c.az1, k, o) : 0.0;
+        r.y = v1 ? pvx_cell<TRACK, TRIGON>(q.dir.y, q.dif.y, q.inf.y, q.toa.y, q.alb.y, q.ouf.y, q.tmp.y, q.hum.y, q.alt.y, q.az.y, q.osl.y, q.oaz.y, k, o) : 0.0;
         return r;
     }
 };

@@ -97,7 +97,7 @@ int pv_dispatch(const atl_pv_inputs *in, const atl_pv_params *p, bool allow_skip
 }
 
 bool pv_needs_general(const atl_pv_inputs *in, const atl_pv_params *p) {
-    if (in->d_influx != nullptr || in->d_albedo == nullptr) return true;
+    if (in->d_influx != nullptr || in->d_albedo == nullptr || p->orientation_per_time) return true;
     if (p->tracking != ATL_TRACK_NONE)  // trackers: fast family for pv() with the Huld panel
         return !(p->tracking >= ATL_TRACK_HORIZONTAL && p->tracking <= ATL_TRACK_DUAL &&
                  (p->trigon_model == ATL_TRIGON_SIMPLE || p->trigon_model == ATL_TRIGON_OTHER) &&

@@ -74,8 +74,11 @@ int make_pvx(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t
     c->azimuth = p->azimuth;
     c->cell_slope = p->d_cell_slope;
     c->cell_azimuth = p->d_cell_azimuth;
+    c->ori_per_time = p->orientation_per_time ? 1 : 0;
+    ATL_REQUIRE(!p->orientation_per_time || p->d_cell_slope, "atl_pv: orientation_per_time needs the (T,S) slope / azimuth cubes");
     *vec = vec_ok(S, {in->d_influx_direct, in->d_influx_diffuse, in->d_influx, in->d_influx_toa, in->d_albedo,
-                      in->d_outflux, in->d_temperature, in->d_humidity, in->d_solar_altitude, in->d_solar_azimuth});
+                      in->d_outflux, in->d_temperature, in->d_humidity, in->d_solar_altitude, in->d_solar_azimuth,
+                      p->orientation_per_time ? p->d_cell_slope : nullptr, p->orientation_per_time ? p->d_cell_azimuth : nullptr});
     return ATL_OK;
 }
 

@@ -329,13 +329,19 @@ class Context:
             pp.slope, pp.azimuth = float(slope), float(azimuth)
             pp.d_cell_slope = pp.d_cell_azimuth = None
         else:
-            if isinstance(slope, DeviceArray):
+            # one pair per cell (S,) or - an orientation that follows the sun - per cell and time step (T, S)
+            per_time = any(len(getattr(v, "shape", ())) == 2 for v in (slope, azimuth))
+            shape = (T, S) if per_time else (S,)
+            if isinstance(slope, DeviceArray) and isinstance(azimuth, DeviceArray):
                 ds, da = slope, azimuth
             else:
-                ds = self.upload(np.broadcast_to(np.asarray(slope, dtype=np.float64), (S,)))
-                da = self.upload(np.broadcast_to(np.asarray(azimuth, dtype=np.float64), (S,)))
+                ds = self.upload(np.ascontiguousarray(np.broadcast_to(np.asarray(slope, dtype=np.float64), shape)))
+                da = self.upload(np.ascontiguousarray(np.broadcast_to(np.asarray(azimuth, dtype=np.float64), shape)))
                 keep += [ds, da]
+            if tuple(ds.shape) != shape or tuple(da.shape) != shape:
+                raise ValueError(f"orientation arrays must have shape {shape}, got {tuple(ds.shape)} / {tuple(da.shape)}")
             pp.d_cell_slope, pp.d_cell_azimuth = ds.ptr, da.ptr
+            pp.orientation_per_time = 1 if per_time else 0
         res, optr, ld = self._out(plan, T, S, time_agg, out)
         if plan is None:
             check(self.lib.atl_pv_convert(self.handle, C.byref(pin), C.byref(pp), T, S, _TIME_CODES[time_agg], optr))

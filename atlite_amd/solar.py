@@ -37,3 +37,18 @@ def hour_angle(time, lon_deg, time_shift="0h"):
     lmst = a["lmst0"][:, None] + np.asarray(lon_deg, dtype=np.float64)[None, :]
     h = (np.radians(lmst) - a["ra"][:, None] + np.pi) % (2 * np.pi) - np.pi
     return h, a["dec"]
+
+
+def position(time, lon_deg, lat_deg, time_shift="0h"):
+    """(T, Y, X) altitude and azimuth in radians on the HOST (solar_position.py:100-114).  Only used to hand a
+    ``solar_position`` object to user orientation callbacks of datasets that do not store the angles; the
+    conversion itself evaluates this part inside the kernel."""
+    h, dec = hour_angle(time, lon_deg, time_shift)
+    lat = np.radians(np.asarray(lat_deg, dtype=np.float64))[None, :, None]
+    dec, h = dec[:, None, None], h[:, None, :]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        alt = np.arcsin(np.clip(np.sin(dec) * np.sin(lat) + np.cos(dec) * np.cos(lat) * np.cos(h), -1.0, 1.0))
+        az = np.arccos(np.clip((np.sin(dec) * np.cos(lat) - np.cos(dec) * np.sin(lat) * np.cos(h)) / np.cos(alt), -1.0, 1.0))
+    az = np.where(h <= 0, az, 2 * np.pi - az)
+    return alt, az
+

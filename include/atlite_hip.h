@@ -204,6 +204,10 @@ typedef struct {
      * other six cubes (its result is exactly +0.0 whatever they hold).  Identical output, ~40 % less
      * HBM traffic on a year of data; 0 (default) reads every byte - what bench.py measures. */
     int night_skip;
+    /* 1: d_cell_slope / d_cell_azimuth are (T,S) cubes - an orientation callback that follows the sun
+     * (orientation(lon, lat, solar_position), pv/orientation.py:104-107, returning time-dependent angles);
+     * evaluated by the general kernel.  0 (default): one value per cell. */
+    int orientation_per_time;
 } atl_pv_params;
 
 /* per-cell output: time_agg NONE -> d_out (T x S); SUM/MEAN -> d_out (S) */

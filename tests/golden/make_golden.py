@@ -297,6 +297,20 @@ def main():
         assert r.dims == ("countries", "time"), r.dims
         rp[name] = r.values[:, sel]
     save("runoff_post", **rp)
+
+    # ---------------------------------------------------------------- orientation callbacks that read the sun ---
+    # pv/orientation.py:104-107: orientation(lon, lat, solar_position) may return angles that depend on time
+    from tests.helpers import orientation_follow_sun
+
+    cb = {}
+    for tm in ("simple", "other"):
+        da = conv.convert_pv(ds, csi, orientation_follow_sun, tracking=None, trigon_model=tm)
+        cb[f"follow_{tm}"] = da.transpose("time", "y", "x").values
+    ds5 = dataset({k: v[k] for k in ("influx_direct", "influx_diffuse", "influx_toa", "albedo", "temperature")}, t)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        cb["follow_computed_position"] = conv.convert_pv(ds5, csi, orientation_follow_sun, tracking=None).transpose("time", "y", "x").values
+    save("pv_callback", **cb)
     print("done")
 
 

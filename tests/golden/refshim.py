@@ -123,6 +123,8 @@ class DataArray:
                 if _is_da(v):
                     if all(d in self.dims for d in v.dims):
                         self._coords[k] = v
+                elif isinstance(v, tuple) and len(v) == 2 and v[0] in self.dims:  # xarray's (dim, values) form
+                    self._coords[k] = DataArray(np.asarray(v[1]), dims=[v[0]], _index=(k == v[0]))
                 elif k in self.dims:
                     self._coords[k] = DataArray(np.asarray(v), dims=[k], _index=True)
         if _index:

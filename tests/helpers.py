@@ -92,3 +92,28 @@ def runoff_post_inputs():
 
 def runoff_post_sample(T):
     return np.unique(np.concatenate([np.arange(0, 240), np.arange(0, T, 37), np.arange(8700, 8900), np.arange(T - 240, T)]))
+
+
+def xarray_stand_in():
+    """The eager xarray stand-in the golden generator runs the reference under (tests/golden/refshim.py), as a
+    module object: xarray itself cannot be installed in this image, so tests of the product's xarray bridge
+    (LabeledArray.to_xarray, Dataset.from_xarray, the gateway's isinstance branches) patch it in as a test double."""
+    import importlib.util
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("_atl_refshim", Path(__file__).parent / "golden" / "refshim.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod._make_xarray()
+
+
+def orientation_follow_sun(lon, lat, solar_position):
+    """A user orientation callback that reads the sun (pv/orientation.py:104-107 passes solar_position): the panel
+    azimuth follows the sun's, the slope is the (clipped) zenith angle.  Written against what both xarray and the
+    product's LabeledArray offer (.values, .dims, .coords, the constructor keywords), so make_golden.py runs it inside the reference and the tests inside
+    the product."""
+    alt = solar_position["altitude"]
+    slope = np.clip(np.pi / 2 - np.asarray(alt.values), 0.1, 1.4)  # (time, y, x)
+    # a labelled array of the caller's own kind (xr.DataArray / the stand-in / LabeledArray share these keywords)
+    return dict(slope=type(alt)(slope, dims=alt.dims, coords=alt.coords), azimuth=solar_position["azimuth"])
+

@@ -160,6 +160,41 @@ def test_runoff_postprocessing(case):
     close(r.values[:, g["sel"]], g[case])
 
 
+def test_gateway_returns_dataarrays_when_xarray_is_importable(monkeypatch):
+    """north star: "return xarray DataArrays".  xarray cannot be installed in this image, so the branch is run
+    against a DataArray / Dataset double: every result branch of the gateway (per-cell series, per-cell time
+    reduction, matrix series, layout + capacity) hands back DataArrays with the reference's dims / names / attrs,
+    and xarray inputs (cutout.data as Dataset, matrix and layout as DataArray) are accepted."""
+    from atlite_amd import labeled
+    from tests import helpers as H
+
+    xr = H.xarray_stand_in()
+    monkeypatch.setattr(labeled, "xr", xr)
+    g, p = load("gateway_pv"), load("pv")
+    t = pd.DatetimeIndex(p["time"].astype("datetime64[ns]"))
+    y, x = p["y"], p["x"]
+    ds = xr.Dataset({k: xr.DataArray(p[k], dims=["time", "y", "x"], coords={"time": t, "y": y, "x": x}) for k in PV_VARS},
+                    coords={"time": t, "y": y, "x": x})
+    c = Cutout(ds)
+    kw = dict(panel="CSi", orientation={"slope": 30.0, "azimuth": 180.0})
+    r = c.pv(**kw, aggregate_time=None)  # the branch that used to return the raw LabeledArray
+    assert isinstance(r, xr.DataArray) and r.dims == ("time", "y", "x") and r.name == "specific generation"
+    close(r.values, p["out_CSi_const30_180"])
+    r = c.pv(**kw, aggregate_time="mean")
+    assert isinstance(r, xr.DataArray) and r.dims == ("y", "x")
+    close(r.values, g["cells_mean"])
+    S = len(y) * len(x)
+    M = sp.csr_matrix((g["matrix_data"], g["matrix_indices"], g["matrix_indptr"]), shape=(5, S))
+    r = c.pv(**kw, matrix=M, aggregate_time=None)
+    assert isinstance(r, xr.DataArray) and r.dims[1] == "time"
+    close(r.values, g["series_matrix"])
+    lay = xr.DataArray(g["layout"], dims=["y", "x"], coords={"y": y, "x": x})
+    r, cap = c.pv(**kw, matrix=M, layout=lay, per_unit=True, return_capacity=True, aggregate_time=None)
+    assert isinstance(r, xr.DataArray) and isinstance(cap, xr.DataArray)
+    close(r.values, g["pu_matrix_layout"])
+    close(cap.values, g["capacity_matrix_layout"])
+
+
 # ---- gateway semantics pinned by the reference's test/test_aggregate_time.py ------------------
 def identity_convert(ds, **kwargs):
     return ds["var"]
@@ -287,6 +322,39 @@ def test_pv_in_kernel_solar_position():
         with pytest.warns(DeprecationWarning):
             ra = c.pv(panel="CSi", orientation=ospec, matrix=M, aggregate_time=None)
         close(ra.values, orc.aggregate_matrix(ref.reshape(ref.shape[0], -1), M))
+
+
+def test_pv_orientation_callback_reads_the_sun():
+    """A user orientation callback gets a solar_position object (stored angles: fetched from the device on first
+    access; none stored: computed on the host) and may return angles that depend on time; the cubes go through
+    the general kernel (atl_pv_params.orientation_per_time).  Against the reference's outputs for the same
+    callback (pv_callback.npz), per cell and aggregated, whole launch and sliced along time."""
+    from oracle import atlite_oracle as orc
+    from tests import helpers as H
+
+    p, cbk = load("pv"), load("pv_callback")
+    c = cutout_from(p, PV_VARS)
+    for tm in ("simple", "other"):
+        r = c.pv(panel="CSi", orientation=H.orientation_follow_sun, trigon_model=tm, aggregate_time=None)
+        close(r.values, cbk[f"follow_{tm}"])
+    M = H.blob_matrix(4, len(p["y"]), len(p["x"]), seed=5)
+    ra = c.pv(panel="CSi", orientation=H.orientation_follow_sun, matrix=M, aggregate_time=None)
+    ref = cbk["follow_simple"]
+    close(ra.values, orc.aggregate_matrix(ref.reshape(ref.shape[0], -1), M))
+    names = ("influx_direct", "influx_diffuse", "influx_toa", "albedo", "temperature")
+    c5 = cutout_from(p, names)
+    with pytest.warns(DeprecationWarning, match="solar position"):
+        r = c5.pv(panel="CSi", orientation=H.orientation_follow_sun, aggregate_time=None)
+    close(r.values, cbk["follow_computed_position"])
+
+    def seen(lon, lat, solar_position):  # the object offers the reference's access patterns
+        assert "altitude" in solar_position and set(solar_position.keys()) == {"altitude", "azimuth"}
+        assert solar_position.altitude.dims == ("time", "y", "x") and solar_position["azimuth"].shape == p["solar_azimuth"].shape
+        np.testing.assert_array_equal(np.isnan(solar_position["altitude"].values), np.isnan(p["solar_altitude"]))
+        return dict(slope=0.3, azimuth=np.pi)
+
+    close(c.pv(panel="CSi", orientation=seen, aggregate_time=None).values,
+          orc.convert_pv({k: p[k] for k in PV_VARS}, H.CSI, dict(slope=0.3, azimuth=np.pi)))
 
 
 # ---- remaining pv options (SURVEY 8 f-1), against reference-generated vectors ------------------

@@ -339,3 +339,41 @@ def test_multigpu_device_selection_and_day_aligned_shards(monkeypatch):
         assert all(s[1] == t[0] for s, t in zip(slots, slots[1:]))
     e = _RunoffSpec(ds).shard_edges(T, 4)
     assert e[0] == 0 and e[-1] == T and max(b - a for a, b in zip(e, e[1:])) - min(b - a for a, b in zip(e, e[1:])) <= 1
+
+
+def test_xarray_bridge_with_the_stand_in(monkeypatch):
+    """LabeledArray.to_xarray / Dataset.from_xarray / _finish against a DataArray / Dataset double (xarray is not
+    installable here): dims, coords, attrs, name and values survive both directions, dimension order is normalised
+    to (time, y, x) on the way in."""
+    import pandas as pd
+
+    from atlite_amd import convert, labeled
+    from atlite_amd.labeled import Dataset, LabeledArray
+    from tests import helpers as H
+
+    xr = H.xarray_stand_in()
+    monkeypatch.setattr(labeled, "xr", xr)
+    t = pd.date_range("2013-01-01", periods=4, freq="h")
+    la = LabeledArray(np.arange(8.0).reshape(2, 4), ("bus", "time"), {"bus": np.array(["a", "b"]), "time": t},
+                      {"units": "MWh/MWp"}, "specific generation")
+    da = la.to_xarray()
+    assert isinstance(da, xr.DataArray) and da.dims == ("bus", "time") and da.name == "specific generation"
+    assert da.attrs == {"units": "MWh/MWp"}
+    np.testing.assert_array_equal(da.values, la.values)
+    np.testing.assert_array_equal(da.coords["bus"].values, ["a", "b"])
+    np.testing.assert_array_equal(pd.DatetimeIndex(da.coords["time"].values), t)
+    assert isinstance(convert._finish(la), xr.DataArray)
+
+    y, x = np.array([50.0, 50.25, 50.5]), np.array([8.0, 8.25])
+    cube = np.arange(24.0).reshape(4, 3, 2)
+    ds = xr.Dataset(
+        {"temperature": xr.DataArray(cube.transpose(2, 0, 1), dims=["x", "time", "y"], coords={"x": x, "time": t, "y": y}),
+         "height": xr.DataArray(np.ones((3, 2)), dims=["y", "x"], coords={"y": y, "x": x})},
+        coords={"time": t, "y": y, "x": x}, attrs={"module": "era5"})
+    d = Dataset.from_xarray(ds)
+    assert d["temperature"].dims == ("time", "y", "x") and d["height"].dims == ("y", "x")
+    np.testing.assert_array_equal(d["temperature"].values, cube)
+    np.testing.assert_array_equal(d.coords["y"], y)
+    assert d.attrs == {"module": "era5"} and not d.chunked
+    assert isinstance(convert._as_dataset(ds), Dataset)
+

@@ -249,3 +249,30 @@ def test_runoff_postprocessing_host(case):
     assert out.dims == ("countries", "time")
     np.testing.assert_allclose(out.values[:, g["sel"]], g[case], rtol=1e-10, atol=1e-12 * np.abs(g[case]).max())
 
+
+class _Arr:
+    """values + dims + coords: what tests.helpers.orientation_follow_sun needs of a labelled array."""
+
+    def __init__(self, values, dims=None, coords=None):
+        self.values, self.dims, self.coords = np.asarray(values), dims, coords
+
+
+def test_orientation_callback_that_reads_the_sun():
+    """orientation(lon, lat, solar_position) returning time-dependent angles (pv/orientation.py:104-107): the
+    oracle's pv chain with (T, Y, X) slope / azimuth against what the reference produced for the same callback."""
+    g, cbk = load("pv"), load("pv_callback")
+    ds = {k: g[k] for k in ("influx_direct", "influx_diffuse", "influx_toa", "albedo", "temperature", "solar_altitude",
+                            "solar_azimuth")}
+    sp_ = dict(altitude=_Arr(g["solar_altitude"]), azimuth=_Arr(g["solar_azimuth"]))
+    o = H.orientation_follow_sun(None, None, sp_)
+    ori = dict(slope=o["slope"].values, azimuth=o["azimuth"].values)
+    for tm in ("simple", "other"):
+        np.testing.assert_allclose(orc.convert_pv_general(ds, H.CSI, ori, trigon_model=tm), cbk[f"follow_{tm}"], rtol=1e-13,
+                                   atol=1e-15)
+    t = times(g["time"])
+    alt, az = orc.solar_position(t, g["x"], g["y"])
+    ds2 = dict(ds, solar_altitude=alt, solar_azimuth=az)
+    o = H.orientation_follow_sun(None, None, dict(altitude=_Arr(alt), azimuth=_Arr(az)))
+    np.testing.assert_allclose(orc.convert_pv_general(ds2, H.CSI, dict(slope=o["slope"].values, azimuth=o["azimuth"].values)),
+                               cbk["follow_computed_position"], rtol=1e-13, atol=1e-15)
+
