@@ -93,7 +93,13 @@ ATL_HD __forceinline__ double reduce_pio2(double x, int *q) {
     double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);
     r = __builtin_fma(-k, 6.12323399573676603587e-17, r);
     r = __builtin_fma(-k, -1.49738490485916983506e-33, r);
-    *q = int(k) & 3;  // |k| < 2^31 guaranteed by the caller's range check
+#if defined(__HIP_DEVICE_COMPILE__)
+    // callers discard the result for |x| >= 2^30 / NaN; v_cvt_i32_f64 saturates there (the build passes
+    // -fno-strict-float-cast-overflow, so the conversion is the instruction's, never poison)
+    *q = int(k) & 3;
+#else
+    *q = (k > -2147483648.0 && k < 2147483648.0) ? int(k) & 3 : 0;  // C++: out-of-range / NaN conversion is undefined
+#endif
     return r;
 }
 
