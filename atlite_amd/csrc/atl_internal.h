@@ -58,7 +58,27 @@ struct PlanDev {
     const int32_t *shape_ptr;   // [N+1]
     const int32_t *shape_prow;  // [P] partial rows of each shape in ascending segment order
     const uint8_t *row_poison;  // [N] 1 = row has a NaN weight -> output row is NaN
+    // Dense tiles (>= kMfmaRows partial rows): their rows are contracted on the matrix cores
+    // (v_mfma_f64_16x16x4_f64: 16 rows x 16 slots x 4 cells per instruction).  seg_wm[s] = offset into prow_wm of
+    // tile s's operand image, -1 for sparse tiles; per group of 16 rows and K-step k4 (4 cells) one 64-lane A
+    // fragment: prow_wm[off + (g * 32 + k4) * 64 + lane] = weight(row 16 g + lane % 16, cell 4 k4 + lane / 16),
+    // 0.0 where structurally absent or past the tile's last row.  nullptr when the plan has no dense tile.
+    const int64_t *seg_wm;
+    const double *prow_wm;
 };
+
+constexpr int kMfmaRows = 16;      // rows per MFMA group
+constexpr int kMfmaMinRows = 12;   // rows from which a (last, partial) group beats the butterfly path (measured)
+// LDS value rows of a wave (one row per slot of the batch, kSegCells doubles): cell c of row i sits at position
+// c ^ (4 i), so that the B-fragment read of an MFMA K-step - 16 lanes = 8 rows at the same 4 cells - touches 32
+// different banks instead of one, at no padding cost; a lane's own cell pair stays one aligned 16-byte slot.
+// (SW = false: plain rows - kernels whose plan has no dense tile never read fragments and keep ONE address)
+template <bool SW>
+__host__ __device__ inline int vrow_pair(int i, int lane) { return i * kSegCells + 2 * (SW ? lane ^ (2 * i) : lane); }
+// MFMA groups of a tile with n partial rows: full groups, plus one more if >= kMfmaMinRows rows remain
+__host__ __device__ inline int mfma_groups(int n) {
+    return n < kMfmaRows ? 0 : n / kMfmaRows + ((n % kMfmaRows) >= kMfmaMinRows ? 1 : 0);
+}
 
 // ---- cell tiles: ONE definition of which cells a lane of a tile owns ---------------------------------
 // The stacked cell axis (flat index f = y*X + x) is cut into 128-byte lines of 16 cells.  The tile row

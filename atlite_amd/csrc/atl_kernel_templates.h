@@ -231,6 +231,46 @@ __device__ __forceinline__ void reduce_batch(const double2 (&v)[kBatch], bool fi
 
 // register budget of the fused kernel: ATL_FUSED_WAVES waves per SIMD unless the converter asks for
 // more registers (the general pv kernel is a long literal transcription and would spill)
+// ---- dense tiles: the contraction on the matrix cores ------------------------------------------------------
+// out[row][slot] = sum over the tile's 128 cells of weight[row][cell] * value[cell][slot] for 16 rows x 8 slots
+// per group: 32 v_mfma_f64_16x16x4_f64 (A = 16 rows x 4 cells from the plan's operand image, one coalesced 512-byte
+// load; B = 4 cells x 16 slots from the wave's LDS value rows, slots 8-15 are copies nobody stores; layouts
+// verified by tools/probes/mfma_f64_layout.hip: A[i][k] lane 16 k + i, B[k][j] lane 16 k + j, D[4 r + l / 16][l % 16]
+// in register r).  No shuffles at all, ~4x fewer issue cycles per partial row than the butterfly.  Only taken when
+// every value of the batch is finite: 0 * NaN would leak through structural zeros (the guarded VALU path runs then).
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+template <int U = 8>  // K-steps whose operands are in flight together (4 VGPRs each)
+__device__ __forceinline__ void reduce_dense_mfma(const double *vl, const double *__restrict__ wm, int G, int n_rows,
+                                                  int32_t p0, int lane, int64_t sb, int64_t send,
+                                                  double *__restrict__ partials, int64_t ldp) {
+    typedef __attribute__((address_space(1))) const double gdouble;
+    const int j = lane & 15, kq = lane >> 4, jj = j & 7;
+    const double *brow = vl + jj * kSegCells + kq;
+    for (int g = 0; g < G; ++g) {
+        // two accumulators (even / odd K-steps): back-to-back MFMAs on ONE accumulator wait for each other
+        d4 acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        gdouble *a = (gdouble *)(wm + (int64_t(g) * 32) * 64 + lane);
+        // U K-steps per trip of a loop that is NOT unrolled: U operand pairs in flight, not all 32
+#pragma unroll 1
+        for (int k8 = 0; k8 < 32; k8 += U) {
+#pragma unroll
+            for (int u = 0; u < U; u += 2) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(k8 + u) * 64], brow[4 * ((k8 + u) ^ jj)], acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(k8 + u + 1) * 64], brow[4 * ((k8 + u + 1) ^ jj)], acc1, 0, 0, 0);
+            }
+        }
+        acc += acc1;
+        if (j < kBatch && sb + j < send) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = kMfmaRows * g + 4 * r + kq;
+                if (row < n_rows) partials[int64_t(p0 + row) * ldp + sb + j] = acc[r];
+            }
+        }
+    }
+}
+
 template <class Conv, class = void>
 struct conv_min_waves : std::integral_constant<int, ATL_FUSED_WAVES> {};
 template <class Conv>
@@ -240,7 +280,7 @@ constexpr int min_waves() {
     return conv_min_waves<Conv>::value;
 }
 
-template <class Conv, bool VEC>
+template <class Conv, bool VEC, bool DENSE>
 __global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fused_segred(Conv conv, PlanDev plan, int64_t slot0,
                                                       int64_t n_slots, int64_t S, int32_t chunk_slots,
                                                       int64_t n_units, double *__restrict__ partials,
@@ -284,6 +324,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fuse
     const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);  // safe indices: loads never branch
     const int32_t p0 = plan.seg_ptr[seg], p1 = plan.seg_ptr[seg + 1];
     if (p0 == p1) return;  // no shape touches this tile: nothing to read
+    // dense tile: its first 16 G rows go through the matrix cores (reduce_dense_mfma), the LDS value rows sit behind
+    // the weight caches of the block (allocated only for plans that have dense tiles)
+    // (DENSE = the plan has dense tiles: a separate instantiation, so that the common one keeps its registers)
+    const int n_mfma = DENSE ? mfma_groups(p1 - p0) : 0;  // groups of 16 rows
+    const double *wm = n_mfma ? plan.prow_wm + plan.seg_wm[seg] : nullptr;
+    double *vl = lds + conv_lds_doubles + kWavesPerBlock * (kRowCache * kSegCells) + wave * (kBatch * kSegCells);
     const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
     // weights of the first kRowCache partial rows: in this wave's LDS area for the whole chunk (each lane
     // writes and later reads only its own 16 bytes: no barrier needed)
@@ -338,7 +384,19 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fuse
             continue;
         }
 #endif
-        reduce_batch(v, finite, plan, p0, p1, wlds, present, lane, sb, send, partials, ldp);
+        if (DENSE && n_mfma > 0) {
+            const int32_t pm = p0 + min(kMfmaRows * n_mfma, p1 - p0);  // rows past the MFMA groups (< kMfmaMinRows of them)
+            if (__all(finite)) {
+#pragma unroll
+                for (int i = 0; i < kBatch; ++i) *reinterpret_cast<double2 *>(vl + vrow_pair<DENSE>(i, lane)) = v[i];
+                reduce_batch<0>(v, true, plan, pm, p1, wlds, 0u, lane, sb, send, partials, ldp);  // v's registers die here
+                reduce_dense_mfma(vl, wm, n_mfma, p1 - p0, p0, lane, sb, send, partials, ldp);
+            } else {
+                reduce_batch<0>(v, false, plan, p0, p1, wlds, 0u, lane, sb, send, partials, ldp);
+            }
+        } else {
+            reduce_batch(v, finite, plan, p0, p1, wlds, present, lane, sb, send, partials, ldp);
+        }
     }
 }
 
@@ -359,8 +417,8 @@ struct conv_night_pipe : std::false_type {};
 template <class Conv>
 struct conv_night_pipe<Conv, std::void_t<decltype(Conv::kNightPipe)>> : std::integral_constant<bool, Conv::kNightPipe> {};
 
-template <class Conv, bool VEC>
-__global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fused_segred_night(Conv conv, PlanDev plan, int64_t slot0,
+template <class Conv, bool VEC, bool DENSE>
+__global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 3 : min_waves<Conv>()) void k_fused_segred_night(Conv conv, PlanDev plan, int64_t slot0,
                                                       int64_t n_slots, int64_t S, int32_t chunk_slots,
                                                       int64_t n_units, double *__restrict__ partials,
                                                       int64_t ldp, int32_t conv_lds_doubles) {
@@ -371,7 +429,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fuse
     const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
     constexpr int kWaveLds = (kRowCacheNight + kBatch) * kSegCells;
     double *wlds = lds + conv_lds_doubles + wave * kWaveLds;
-    double *vrow = wlds + kRowCacheNight * kSegCells + 2 * lane;  // this lane's 16 bytes of value row 0
+    double *vl = wlds + kRowCacheNight * kSegCells;  // the wave's value rows (swizzled when DENSE: vrow_pair)
     const int64_t unit = int64_t(blockIdx.x) * kWavesPerBlock + wave;
     if (unit >= n_units) return;
     const int32_t seg = int32_t(unit % plan.n_segs);
@@ -382,6 +440,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fuse
     const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);
     const int32_t p0 = plan.seg_ptr[seg], p1 = plan.seg_ptr[seg + 1];
     if (p0 == p1) return;
+    const int G = DENSE ? mfma_groups(p1 - p0) : 0;
+    const double *wm = G ? plan.prow_wm + plan.seg_wm[seg] : nullptr;
     const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
     const bool no_cell = !v0 && !v1;
     unsigned present = 0;
@@ -410,7 +470,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fuse
         for (int i = 0; i < kBatch; ++i) {
             const bool d = (sb + i < send) && !__all(conv.key_is_zero(key[i], min(sb + i, send - 1), cell) || no_cell);
             day |= d ? 1u << i : 0u;
-            *reinterpret_cast<double2 *>(vrow + i * kSegCells) = d ? key[i] : double2{0.0, 0.0};
+            *reinterpret_cast<double2 *>(vl + vrow_pair<DENSE>(i, lane)) = d ? key[i] : double2{0.0, 0.0};
         }
         bool finite = true;
         if (day != 0) {
@@ -422,21 +482,29 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fuse
                 const int p = __builtin_ctz(m);
                 m &= m - 1;
                 const typename Conv::Raw A = conv.template rest_load<VEC>(sb + p, s0c, s1c, cell);
-                const double2 kv = *reinterpret_cast<const double2 *>(vrow + p * kSegCells);
+                const double2 kv = *reinterpret_cast<const double2 *>(vl + vrow_pair<DENSE>(p, lane));
                 const double2 r = conv.compute_keyed(A, kv, v0, v1, cell, lds);
                 finite = finite && (__builtin_fabs(r.x) < __builtin_inf()) && (__builtin_fabs(r.y) < __builtin_inf());
-                *reinterpret_cast<double2 *>(vrow + p * kSegCells) = r;
+                *reinterpret_cast<double2 *>(vl + vrow_pair<DENSE>(p, lane)) = r;
             }
         }
-        // next batch's keys: in flight behind the reduction
+        const bool dense = DENSE && G > 0 && __all(finite);  // wave-uniform
+        if (dense) reduce_dense_mfma(vl, wm, G, p1 - p0, p0, lane, sb, send, partials, ldp);
+        // next batch's keys: in flight behind the (VALU) reduction; a dense tile's MFMA phase runs before the
+        // prefetch so that its operands and the 32 key registers are not live together
         if (sb + kBatch < send) {
 #pragma unroll
             for (int i = 0; i < kBatch; ++i) key[i] = conv.template key_load<VEC>(min(sb + kBatch + i, send - 1), s0c, s1c, cell);
         }
-        double2 v[kBatch];
+        if (!dense || kMfmaRows * G < p1 - p0) {
+            double2 v[kBatch];
 #pragma unroll
-        for (int i = 0; i < kBatch; ++i) v[i] = *reinterpret_cast<const double2 *>(vrow + i * kSegCells);
-        reduce_batch<kRowCacheNight>(v, finite, plan, p0, p1, wlds, present, lane, sb, send, partials, ldp);
+            for (int i = 0; i < kBatch; ++i) v[i] = *reinterpret_cast<const double2 *>(vl + vrow_pair<DENSE>(i, lane));
+            if (G > 0)
+                reduce_batch<0>(v, finite, plan, dense ? p0 + kMfmaRows * G : p0, p1, wlds, 0u, lane, sb, send, partials, ldp);
+            else
+                reduce_batch<kRowCacheNight>(v, finite, plan, p0, p1, wlds, present, lane, sb, send, partials, ldp);
+        }
     }
 }
 
@@ -622,23 +690,25 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
 #endif
             // dynamic LDS: the converter's tables, then kRowCache weight rows per wave
             const size_t conv_lds = align_up(lds_bytes, 16);
-            const size_t lds_total = conv_lds + size_t(kWavesPerBlock) * kRowCache * kSegCells * sizeof(double);
+            const size_t lds_total = conv_lds + size_t(kWavesPerBlock) * (kRowCache + (plan.prow_wm ? kBatch : 0)) * kSegCells * sizeof(double);
             const int32_t conv_lds_doubles = int32_t(conv_lds / sizeof(double));
             KernelBracket kb(ctx);
+            const bool dense = plan.prow_wm != nullptr;
+            auto launch = [&](auto kern, size_t lds_sz) {
+                hipLaunchKernelGGL(kern, grid, dim3(kWavesPerBlock * 64), lds_sz, ctx->stream, conv, plan, w0, wn, S,
+                                   chunk_slots, n_units, partials, ldp, conv_lds_doubles);
+            };
             if constexpr (conv_night_pipe<Conv>::value) {
                 const size_t lds_night = conv_lds + size_t(kWavesPerBlock) * (kRowCacheNight + kBatch) * kSegCells * sizeof(double);
                 if (vec)
-                    hipLaunchKernelGGL((k_fused_segred_night<Conv, true>), grid, dim3(kWavesPerBlock * 64), lds_night, ctx->stream, conv,
-                                       plan, w0, wn, S, chunk_slots, n_units, partials, ldp, conv_lds_doubles);
+                    dense ? launch(k_fused_segred_night<Conv, true, true>, lds_night) : launch(k_fused_segred_night<Conv, true, false>, lds_night);
                 else
-                    hipLaunchKernelGGL((k_fused_segred_night<Conv, false>), grid, dim3(kWavesPerBlock * 64), lds_night, ctx->stream, conv,
-                                       plan, w0, wn, S, chunk_slots, n_units, partials, ldp, conv_lds_doubles);
-            } else if (vec)
-                hipLaunchKernelGGL((k_fused_segred<Conv, true>), grid, dim3(kWavesPerBlock * 64), lds_total, ctx->stream, conv, plan,
-                                   w0, wn, S, chunk_slots, n_units, partials, ldp, conv_lds_doubles);
-            else
-                hipLaunchKernelGGL((k_fused_segred<Conv, false>), grid, dim3(kWavesPerBlock * 64), lds_total, ctx->stream, conv,
-                                   plan, w0, wn, S, chunk_slots, n_units, partials, ldp, conv_lds_doubles);
+                    dense ? launch(k_fused_segred_night<Conv, false, true>, lds_night) : launch(k_fused_segred_night<Conv, false, false>, lds_night);
+            } else if (vec) {
+                dense ? launch(k_fused_segred<Conv, true, true>, lds_total) : launch(k_fused_segred<Conv, true, false>, lds_total);
+            } else {
+                dense ? launch(k_fused_segred<Conv, false, true>, lds_total) : launch(k_fused_segred<Conv, false, false>, lds_total);
+            }
             if ((rc = check_launch(what))) return rc;
         }
         const dim3 grid(unsigned((wn + 255) / 256), unsigned(N));

@@ -556,6 +556,40 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_le
         }
     }
     (void)n_raw;
+    // pass 4: the MFMA operand image of dense tiles (PlanDev::prow_wm)
+    std::vector<int64_t> seg_wm;
+    std::vector<double> prow_wm;
+    if (!getenv("ATLITE_HIP_NO_MFMA")) {
+        // Only for plans DOMINATED by dense tiles (3/4 of the partial rows in MFMA groups): the kernel instantiation that carries the MFMA path costs every tile
+        // ~20 VGPRs and 8 KiB of LDS per wave (measured: a stack of 8 tessellations, 12.8 rows per tile on average with
+        // a third of them in dense tiles, ran 11 % slower with it; 16 / 32 dense rows per tile run 12 / 19 % faster).
+        int64_t total = 0, dense_rows = 0;
+        for (int64_t t = 0; t < n_segs; ++t) {
+            const int n = seg_ptr[size_t(t) + 1] - seg_ptr[size_t(t)], G = mfma_groups(n);
+            total += int64_t(G) * 32 * 64;
+            dense_rows += std::min(n, G * kMfmaRows);
+        }
+        if (total > 0 && (4 * dense_rows >= 3 * P || getenv("ATLITE_HIP_FORCE_MFMA"))) {
+            seg_wm.assign(static_cast<size_t>(n_segs), -1);
+            prow_wm.assign(static_cast<size_t>(total), 0.0);
+            int64_t off = 0;
+            for (int64_t t = 0; t < n_segs; ++t) {
+                const int32_t q0 = seg_ptr[size_t(t)], n = seg_ptr[size_t(t) + 1] - q0;
+                const int G = mfma_groups(n);
+                if (G == 0) continue;
+                seg_wm[size_t(t)] = off;
+                for (int g = 0; g < G; ++g)
+                    for (int k4 = 0; k4 < 32; ++k4)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int row = kMfmaRows * g + lane % 16, cell = 4 * k4 + lane / 16;
+                            if (row >= n) continue;
+                            const double w = prow_w[size_t(q0 + row) * kSegCells + size_t(cell)];
+                            if (!std::isnan(w)) prow_wm[size_t(off) + (size_t(g) * 32 + size_t(k4)) * 64 + size_t(lane)] = w;
+                        }
+                off += int64_t(G) * 32 * 64;
+            }
+        }
+    }
 
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     atl_agg *a = new atl_agg();
@@ -573,7 +607,8 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_le
         (rc = to_device(a, prow_w, &a->dev.prow_w)) ||
         (rc = to_device(a, shape_ptr, &a->dev.shape_ptr)) ||
         (rc = to_device(a, shape_prow, &a->dev.shape_prow)) ||
-        (rc = to_device(a, poison, &a->dev.row_poison))) {
+        (rc = to_device(a, poison, &a->dev.row_poison)) ||
+        (!prow_wm.empty() && ((rc = to_device(a, seg_wm, &a->dev.seg_wm)) || (rc = to_device(a, prow_wm, &a->dev.prow_wm))))) {
         atl_agg_destroy(a);
         return rc;
     }

@@ -315,6 +315,50 @@ def test_pv_night_skip_is_bit_identical(ctx, Y, X):
     np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-12 * np.nanmax(np.abs(ref[np.isfinite(ref)])), equal_nan=True)
 
 
+@pytest.mark.parametrize("R", [16, 17, 28, 40])
+def test_dense_tiles_on_the_matrix_cores(ctx, monkeypatch, R):
+    """Tiles with >= 16 partial rows are contracted with v_mfma_f64_16x16x4_f64 (groups of 16 rows, a last group from
+    12 rows, the rest through the butterfly path): dense rows with explicit zeros and negative weights against scipy,
+    for the generic cube, runoff, pv with and without the night early-out; a batch that holds NaN / inf takes the
+    guarded path (structural zeros must not leak NaN), ragged time axis, grid rows that are not a multiple of a line."""
+    import scipy.sparse as sp
+
+    monkeypatch.setenv("ATLITE_HIP_FORCE_MFMA", "1")
+    T, Y, X = 43, 11, 27
+    S = Y * X
+    rng = np.random.default_rng(R)
+    W = rng.normal(size=(R, S))
+    W[rng.random((R, S)) < 0.3] = 0.0          # structurally absent
+    M = sp.csr_matrix(W)
+    M.data[::7] = 0.0                           # explicit zeros stay structural entries
+    plan = ctx.plan(M, row_len=X)
+    D = rng.normal(size=(T, S)) * 10.0
+    out = ctx.spmm(plan, ctx.upload(D)).numpy()
+    ref = (M @ D.T)
+    np.testing.assert_allclose(out, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+    Dn = D.copy()
+    Dn[5, 17] = np.nan
+    Dn[20, 3] = np.inf
+    Dn[21, 200] = -np.inf
+    out = ctx.spmm(plan, ctx.upload(Dn)).numpy()
+    with np.errstate(invalid="ignore"):
+        ref = np.asarray(M @ Dn.T)
+    assert np.isnan(ref).any() and np.isinf(ref).any()
+    np.testing.assert_allclose(out, ref, rtol=1e-12, atol=1e-12 * np.abs(ref[np.isfinite(ref)]).max(), equal_nan=True)
+    # converters: pv (both kernels) and runoff through the same plan
+    ds = H.pv_dataset(T, Y, X, seed=3)
+    dev = up(ctx, ds)
+    refpv = orc.aggregate_matrix(orc.convert_pv(ds, H.CSI, dict(slope=np.radians(30.0), azimuth=np.radians(180.0))), M)
+    for skip in (False, True):
+        got = ctx.pv(dev, PV_PARAMS, T, S, plan=plan, options=dict(night_skip=skip)).numpy()
+        np.testing.assert_allclose(got, refpv, rtol=1e-10, atol=1e-12 * np.abs(refpv).max())
+    ro = rng.random((T, S))
+    h = rng.random(S) * 1000.0
+    got = ctx.runoff(ctx.upload(ro), ctx.upload(h), T, S, plan=plan).numpy()
+    refr = np.asarray(M @ (ro * h[None, :]).T)
+    np.testing.assert_allclose(got, refr, rtol=1e-12, atol=1e-12 * np.abs(refr).max())
+
+
 @pytest.mark.parametrize("T,Y,X,N", [(72, 12, 20, 5), (61, 9, 27, 40)])
 def test_pv_night_skip_in_kernel_solar_position(ctx, T, Y, X, N):
     """The night early-out with the in-kernel solar position: night follows from the (T, X) hour-angle table,
