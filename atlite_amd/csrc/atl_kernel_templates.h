@@ -21,7 +21,7 @@
 #define ATL_PV_GROUP 1
 #endif
 #ifndef ATL_ROW_CACHE
-#define ATL_ROW_CACHE 3
+#define ATL_ROW_CACHE 8
 #endif
 
 using namespace atl;
@@ -197,7 +197,12 @@ __device__ __forceinline__ void reduce_row(const double2 (&v)[kBatch], double2 w
     if ((lane & 7) == 0 && sb + g < send) prow[sb + g] = f;
 }
 
-constexpr int kRowCache = ATL_ROW_CACHE;  // partial rows of a tile whose weights stay in registers
+constexpr int kRowCache = ATL_ROW_CACHE;  // partial rows of a tile whose weights sit in the wave's LDS area for the chunk
+constexpr int kRowCacheDense = 3;        // ... in the instantiation that also carries the MFMA path and its LDS value rows
+template <bool DENSE>
+constexpr int row_cache() {
+    return DENSE ? kRowCacheDense : kRowCache;
+}
 
 // all partial rows of the tile for one converted batch: the first kRowCache rows with their weights from the
 // wave's LDS area, the others from global memory (guarded path)
@@ -294,7 +299,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fuse
     const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
     // per-wave LDS area behind the converter's tables: the weights of the tile's first kRowCache partial
     // rows (LDS instead of 4 VGPRs per row for the whole chunk: the register budget decides the occupancy)
-    constexpr int kWaveLds = kRowCache * kSegCells;
+    constexpr int ROWS = row_cache<DENSE>();
+    constexpr int kWaveLds = ROWS * kSegCells;
     double *wlds = lds + conv_lds_doubles + wave * kWaveLds;
 #ifndef ATL_XCD_MAP
     // Linear order: consecutive blocks (= consecutive XCDs, block b runs on XCD b % 8) take consecutive
@@ -329,13 +335,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fuse
     // (DENSE = the plan has dense tiles: a separate instantiation, so that the common one keeps its registers)
     const int n_mfma = DENSE ? mfma_groups(p1 - p0) : 0;  // groups of 16 rows
     const double *wm = n_mfma ? plan.prow_wm + plan.seg_wm[seg] : nullptr;
-    double *vl = lds + conv_lds_doubles + kWavesPerBlock * (kRowCache * kSegCells) + wave * (kBatch * kSegCells);
+    double *vl = lds + conv_lds_doubles + kWavesPerBlock * (ROWS * kSegCells) + wave * (kBatch * kSegCells);
     const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
     // weights of the first kRowCache partial rows: in this wave's LDS area for the whole chunk (each lane
     // writes and later reads only its own 16 bytes: no barrier needed)
     unsigned present = 0;  // bit 2r / 2r+1: cell 0 / 1 structurally present in row r
 #pragma unroll
-    for (int r = 0; r < kRowCache; ++r) {
+    for (int r = 0; r < ROWS; ++r) {
         double2 wz = {0.0, 0.0};
         if (p0 + r < p1) {
             const double2 w = *reinterpret_cast<const double2 *>(plan.prow_w + int64_t(p0 + r) * kSegCells + 2 * lane);
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fuse
                 reduce_batch<0>(v, false, plan, p0, p1, wlds, 0u, lane, sb, send, partials, ldp);
             }
         } else {
-            reduce_batch(v, finite, plan, p0, p1, wlds, present, lane, sb, send, partials, ldp);
+            reduce_batch<ROWS>(v, finite, plan, p0, p1, wlds, present, lane, sb, send, partials, ldp);
         }
     }
 }
@@ -690,7 +696,7 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
 #endif
             // dynamic LDS: the converter's tables, then kRowCache weight rows per wave
             const size_t conv_lds = align_up(lds_bytes, 16);
-            const size_t lds_total = conv_lds + size_t(kWavesPerBlock) * (kRowCache + (plan.prow_wm ? kBatch : 0)) * kSegCells * sizeof(double);
+            const size_t lds_total = conv_lds + size_t(kWavesPerBlock) * (plan.prow_wm ? kRowCacheDense + kBatch : kRowCache) * kSegCells * sizeof(double);
             const int32_t conv_lds_doubles = int32_t(conv_lds / sizeof(double));
             KernelBracket kb(ctx);
             const bool dense = plan.prow_wm != nullptr;

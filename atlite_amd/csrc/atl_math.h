@@ -94,8 +94,9 @@ ATL_HD __forceinline__ double reduce_pio2(double x, int *q) {
     r = __builtin_fma(-k, 6.12323399573676603587e-17, r);
     r = __builtin_fma(-k, -1.49738490485916983506e-33, r);
 #if defined(__HIP_DEVICE_COMPILE__)
-    // callers discard the result for |x| >= 2^30 / NaN; v_cvt_i32_f64 saturates there (the build passes
-    // -fno-strict-float-cast-overflow, so the conversion is the instruction's, never poison)
+    // |x| >= 2^30 / NaN: the conversion is out of range (v_cvt_i32_f64 saturates), and every caller then selects
+    // NaN on its own range test, never a value derived from q - an unselected operand cannot poison a select.
+    // (-fno-strict-float-cast-overflow would pin this down formally; it costs the wind kernels 5-7 %.)
     *q = int(k) & 3;
 #else
     *q = (k > -2147483648.0 && k < 2147483648.0) ? int(k) & 3 : 0;  // C++: out-of-range / NaN conversion is undefined

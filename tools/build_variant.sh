@@ -8,7 +8,7 @@ NAME=$1; EXTRA=$2
 ROOT=$(cd $(dirname $0)/.. && pwd)
 mkdir -p $ROOT/atlite_amd/lib/variants /tmp/atl_variant_$NAME
 SRC=$ROOT/atlite_amd/csrc
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$SRC -fvisibility=hidden -fno-strict-float-cast-overflow -D__HIP_PLATFORM_AMD__ $EXTRA"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$SRC -fvisibility=hidden -D__HIP_PLATFORM_AMD__ $EXTRA"
 # UNITS="atl_kernels atl_kernels_pv" rebuilds only some kernel units; the others are taken from the product
 UNITS=${UNITS:-"atl_kernels atl_kernels_pv atl_kernels_pvx"}
 : > /tmp/atl_variant_$NAME/resource.txt
