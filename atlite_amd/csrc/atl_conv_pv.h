@@ -186,6 +186,39 @@ ATL_HD __forceinline__ double pv_tail(double direct, double diffuse, double infl
     return pv_tail_core<TAIL>(direct, diffuse, influx, toa, alb, tmp, sa, cosinc, o.hp, o.hm, o.sh3, k);
 }
 
+// Datasets that store the total influx and the reflected outflux instead of a direct / diffuse split and an albedo
+// (SARAH-shaped, irradiation.py:202-205, 128-139): the Reindl split with the "simple" clearsky model (:33-42) and
+// albedo = outflux / influx.  pvx_cell evaluates the same expressions (both clearsky models) for the general kernel.
+ATL_HD __forceinline__ void reindl_simple(double infl, double toa, double sa, double *direct, double *diffuse) {
+    const double influx = np_clip(infl, 0.0, toa);
+    const double kk = guarded_div(influx, toa);
+    const double m1 = (kk > 0.0 && kk <= 0.3) ? 1.0 : 0.0, m2 = (kk > 0.3 && kk < 0.78) ? 1.0 : 0.0,
+                 m3 = (kk >= 0.78) ? 1.0 : 0.0;
+    const double fraction = m1 * fmin(1.0, 1.020 - 0.254 * kk + 0.0123 * sa) +
+                            m2 * fmin(0.97, fmax(0.1, 1.400 - 1.749 * kk + 0.177 * sa)) +
+                            m3 * fmax(0.1, 0.486 * kk - 0.182 * sa);
+    *diffuse = influx * fraction;
+    *direct = influx - *diffuse;
+}
+ATL_HD __forceinline__ double albedo_from_outflux(double outf, double influx) {
+    const double alb = fill0(guarded_div(outf, influx != 0.0 ? influx : __builtin_nan("")));
+    return np_min(alb, 1.0);
+}
+
+// fixed panel, stored angles, influx / outflux dataset: the head above, then the family's usual tail
+template <int TAIL = kTailHuld>
+ATL_HD __forceinline__ double pv_cell_influx(double infl, double outf, double toa, double tmp, double alt, double az,
+                                                 const PvOri &o, const PvConst &k) {
+    double sa, ca;
+    lean_sincos(alt, &sa, &ca);
+    double direct, diffuse;
+    reindl_simple(infl, toa, sa, &direct, &diffuse);
+    const double influx = direct + diffuse;
+    if ((alt < k.alt_thr) || (influx <= 0.01)) return 0.0;
+    const double alb = albedo_from_outflux(outf, influx);
+    return pv_tail<TAIL>(direct, diffuse, influx, toa, alb, tmp, sa, ca, lean_cos(o.saz - az), o, k);
+}
+
 template <int TAIL = kTailHuld, int TRACK = ATL_TRACK_NONE>
 ATL_HD __forceinline__ double pv_cell(double dir, double dif, double toa, double alb, double tmp,
                                           double alt, double az, const PvOri &o, const PvConst &k) {
@@ -308,8 +341,11 @@ ATL_HD __forceinline__ double pv_cell_sp(double dir, double dif, double toa, dou
 // goes through the general kernel).
 // TRACK: a tracker (pv(tracking=...)) with the Huld panel, either trigon model, scalar or per-cell orientation
 // and stored solar angles - the ways trackers are used with pv(); other mixes stay general.
-template <bool SP, bool PC = false, bool SKIP = false, int TAIL = kTailHuld, int TRACK = ATL_TRACK_NONE>
+// HEAD: 1 = influx / outflux dataset (Reindl split + albedo from outflux; stored angles, Huld panel, fixed
+// orientation): influx rides in Raw::dir, outflux in Raw::alb, the diffuse slot is not loaded (48 B/cell).
+template <bool SP, bool PC = false, bool SKIP = false, int TAIL = kTailHuld, int TRACK = ATL_TRACK_NONE, int HEAD = 0>
 struct PvConvT {
+    static_assert(HEAD == 0 || (!SP && TAIL == kTailHuld && TRACK == ATL_TRACK_NONE), "influx head: stored angles, Huld panel, no tracker");
     static_assert(TAIL == kTailHuld || (!SP && !SKIP), "the non-panel tails are built for stored angles, no skip");
     static_assert(TRACK == ATL_TRACK_NONE || (!SP && !SKIP && (TAIL == kTailHuld || TAIL == kTailHuldHayDavies)),
                   "trackers: stored angles, Huld panel (either trigon model)");
@@ -411,10 +447,16 @@ struct PvConvT {
     __device__ __forceinline__ Raw rest_load(int64_t slot, int64_t c0, int64_t c1, const Cell &c) const {
         const int64_t off = slot * S;
         Raw r;
-        r.dir = ld2<VEC>(in.d_influx_direct, off, c0, c1);
-        r.dif = ld2<VEC>(in.d_influx_diffuse, off, c0, c1);
+        if constexpr (HEAD == 1) {
+            r.dir = ld2<VEC>(in.d_influx, off, c0, c1);
+            r.dif = double2{0.0, 0.0};
+            r.alb = ld2<VEC>(in.d_outflux, off, c0, c1);
+        } else {
+            r.dir = ld2<VEC>(in.d_influx_direct, off, c0, c1);
+            r.dif = ld2<VEC>(in.d_influx_diffuse, off, c0, c1);
+            r.alb = ld2<VEC>(in.d_albedo, off, c0, c1);
+        }
         r.toa = ld2<VEC>(in.d_influx_toa, off, c0, c1);
-        r.alb = ld2<VEC>(in.d_albedo, off, c0, c1);
         r.tmp = ld2<VEC>(in.d_temperature, off, c0, c1);
         if constexpr (SP) {
             r.sd = in.d_sin_dec[slot];
@@ -440,10 +482,16 @@ struct PvConvT {
     __device__ __forceinline__ Raw load(int64_t slot, int i, int64_t c0, int64_t c1, const Cell &c, Carry &carry) const {
         const int64_t off = slot * S;
         Raw r;
-        r.dir = ld2<VEC>(in.d_influx_direct, off, c0, c1);
-        r.dif = ld2<VEC>(in.d_influx_diffuse, off, c0, c1);
+        if constexpr (HEAD == 1) {
+            r.dir = ld2<VEC>(in.d_influx, off, c0, c1);
+            r.dif = double2{0.0, 0.0};
+            r.alb = ld2<VEC>(in.d_outflux, off, c0, c1);
+        } else {
+            r.dir = ld2<VEC>(in.d_influx_direct, off, c0, c1);
+            r.dif = ld2<VEC>(in.d_influx_diffuse, off, c0, c1);
+            r.alb = ld2<VEC>(in.d_albedo, off, c0, c1);
+        }
         r.toa = ld2<VEC>(in.d_influx_toa, off, c0, c1);
-        r.alb = ld2<VEC>(in.d_albedo, off, c0, c1);
         r.tmp = ld2<VEC>(in.d_temperature, off, c0, c1);
         if constexpr (SP) {
             r.sd = in.d_sin_dec[slot];
@@ -469,6 +517,9 @@ struct PvConvT {
             const PvAz<true> &a1 = [&]() -> const PvAz<true> & { if constexpr (PC) return c.a1; else return oa; }();
             r.x = v0 ? pv_cell_sp(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.sd, q.cd, c.sl0, c.cl0, q.a.x, q.b.x, o0, a0, k) : 0.0;
             r.y = v1 ? pv_cell_sp(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.sd, q.cd, c.sl1, c.cl1, q.a.y, q.b.y, o1, a1, k) : 0.0;
+        } else if constexpr (HEAD == 1) {
+            r.x = v0 ? pv_cell_influx<TAIL>(q.dir.x, q.alb.x, q.toa.x, q.tmp.x, q.a.x, q.b.x, o0, k) : 0.0;
+            r.y = v1 ? pv_cell_influx<TAIL>(q.dir.y, q.alb.y, q.toa.y, q.tmp.y, q.a.y, q.b.y, o1, k) : 0.0;
         } else if constexpr (TAIL == kTailHuld && TRACK == ATL_TRACK_NONE && ATL_PV_PLAIN != 0) {
             // (in every kernel of the family, so that night skip on / off, fused / per-cell results share their bits)
             // a pair of night cells (or a lane without cells) leaves at once: a wave in the dark skips the math.
@@ -505,8 +556,8 @@ using PvConv = PvConvT<false>;
 using PvConvSP = PvConvT<true>;
 template <class T>
 struct pv_is_sp : std::false_type {};
-template <bool PC, bool SK, int TL, int TR>
-struct pv_is_sp<PvConvT<true, PC, SK, TL, TR>> : std::true_type {};
+template <bool PC, bool SK, int TL, int TR, int HD>
+struct pv_is_sp<PvConvT<true, PC, SK, TL, TR, HD>> : std::true_type {};
 
 // ---------------------------------------------------------------------------------------
 // general pv converter: every option of convert_pv / convert_irradiation / convert_solar_thermal
@@ -658,9 +709,12 @@ ATL_HD double pvx_cell(double dir, double dif, double infl, double toa, double a
     return output > 0.0 ? output : 0.0;
 }
 
-template <int TRACK, int TRIGON>
+// OT: the orientation follows the sun (two more cubes, read per slot) - its own instantiation, so that the
+// others do not carry the four extra registers per cell pair through a kernel that spills as it is
+template <int TRACK, int TRIGON, bool OT = false>
 struct PvxConvT {
     static constexpr int kMinWaves = 2;
+    static constexpr bool kDenseOk = false;  // no MFMA-carrying instantiation of these (rare options x rare matrices)
     atl_pv_inputs in;
     int64_t S;
     PvConst k;
@@ -679,7 +733,7 @@ struct PvxConvT {
         Cell c;
         c.sl0 = c.sl1 = slope;
         c.az0 = c.az1 = azimuth;
-        if (cell_slope && !ori_per_time) {
+        if (cell_slope && !OT) {
             c.sl0 = v0 ? cell_slope[c0] : 0.0;
             c.sl1 = v1 ? cell_slope[c0 + 1] : 0.0;
             c.az0 = v0 ? cell_azimuth[c0] : 0.0;
@@ -709,9 +763,12 @@ struct PvxConvT {
         *az = z;
     }
     static constexpr int kGroup = 1;
-    struct Raw {
+    struct OriRaw {
+        double2 osl, oaz;  // panel slope / azimuth of the slot
+    };
+    struct NoOriRaw {};
+    struct Raw : std::conditional_t<OT, OriRaw, NoOriRaw> {
         double2 dir, dif, inf, toa, alb, ouf, tmp, hum, alt, az;
-        double2 osl, oaz;  // panel slope / azimuth of the slot (ori_per_time) or of the cells
     };
     using Carry = NoCarry;
     template <bool VEC>
@@ -727,8 +784,10 @@ struct PvxConvT {
         r.ouf = in.d_outflux ? ld2<VEC>(in.d_outflux, off, c0, c1) : zero;
         r.tmp = in.d_temperature ? ld2<VEC>(in.d_temperature, off, c0, c1) : zero;
         r.hum = in.d_humidity ? ld2<VEC>(in.d_humidity, off, c0, c1) : zero;
-        r.osl = ori_per_time ? ld2<VEC>(cell_slope, off, c0, c1) : double2{c.sl0, c.sl1};
-        r.oaz = ori_per_time ? ld2<VEC>(cell_azimuth, off, c0, c1) : double2{c.az0, c.az1};
+        if constexpr (OT) {
+            r.osl = ld2<VEC>(cell_slope, off, c0, c1);
+            r.oaz = ld2<VEC>(cell_azimuth, off, c0, c1);
+        }
 #ifdef ATL_PVX_NO_SP
         if (true) {
 #else
@@ -746,11 +805,18 @@ struct PvxConvT {
     }
     __device__ __forceinline__ double2 compute(const Raw &q, bool v0, bool v1, const Cell &c, const double *) const {
         double2 r;
-        r.x = v0 ? pvx_cell<TRACK, TRIGON>(q.dir.x, q.dif.x, q.inf.x, q.toa.x, q.alb.x, q.ouf.x, q.tmp.x, q.hum.x, q.alt.x, q.az.x, q.osl.x, q.oaz.x, k, o) : 0.0;
+        double sl0 = c.sl0, sl1 = c.sl1, az0 = c.az0, az1 = c.az1;
+        if constexpr (OT) {
+            sl0 = q.osl.x;
+            sl1 = q.osl.y;
+            az0 = q.oaz.x;
+            az1 = q.oaz.y;
+        }
+        r.x = v0 ? pvx_cell<TRACK, TRIGON>(q.dir.x, q.dif.x, q.inf.x, q.toa.x, q.alb.x, q.ouf.x, q.tmp.x, q.hum.x, q.alt.x, q.az.x, sl0, az0, k, o) : 0.0;
 #if defined(ATL_PVX_SCHED_BARRIER) && defined(__HIP_DEVICE_COMPILE__)
         __builtin_amdgcn_sched_barrier(0);  // do not interleave the two cells: halves the live temporaries
 #endif
-        r.y = v1 ? pvx_cell<TRACK, TRIGON>(q.dir.y, q.dif.y, q.inf.y, q.toa.y, q.alb.y, q.ouf.y, q.tmp.y, q.hum.y, q.alt.y, q.az.y, q.osl.y, q.oaz.y, k, o) : 0.0;
+        r.y = v1 ? pvx_cell<TRACK, TRIGON>(q.dir.y, q.dif.y, q.inf.y, q.toa.y, q.alb.y, q.ouf.y, q.tmp.y, q.hum.y, q.alt.y, q.az.y, sl1, az1, k, o) : 0.0;
         return r;
     }
 };

@@ -419,6 +419,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fuse
 // kNightPipe and provide key_load / key_is_zero / rest_load / compute_keyed.
 constexpr int kRowCacheNight = 2;
 template <class Conv, class = void>
+struct conv_dense_ok : std::true_type {};
+template <class Conv>
+struct conv_dense_ok<Conv, std::void_t<decltype(Conv::kDenseOk)>> : std::integral_constant<bool, Conv::kDenseOk> {};
+template <class Conv, class = void>
 struct conv_night_pipe : std::false_type {};
 template <class Conv>
 struct conv_night_pipe<Conv, std::void_t<decltype(Conv::kNightPipe)>> : std::integral_constant<bool, Conv::kNightPipe> {};
@@ -696,24 +700,30 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
 #endif
             // dynamic LDS: the converter's tables, then kRowCache weight rows per wave
             const size_t conv_lds = align_up(lds_bytes, 16);
-            const size_t lds_total = conv_lds + size_t(kWavesPerBlock) * (plan.prow_wm ? kRowCacheDense + kBatch : kRowCache) * kSegCells * sizeof(double);
             const int32_t conv_lds_doubles = int32_t(conv_lds / sizeof(double));
             KernelBracket kb(ctx);
-            const bool dense = plan.prow_wm != nullptr;
+            // the MFMA-carrying instantiation exists for the vectorised kernels of converters that opt in (kDenseOk,
+            // default yes); everything else reduces dense tiles on the butterfly path - correct, just slower there
+            const bool dense = plan.prow_wm != nullptr && vec && conv_dense_ok<Conv>::value;
             auto launch = [&](auto kern, size_t lds_sz) {
                 hipLaunchKernelGGL(kern, grid, dim3(kWavesPerBlock * 64), lds_sz, ctx->stream, conv, plan, w0, wn, S,
                                    chunk_slots, n_units, partials, ldp, conv_lds_doubles);
             };
+            const size_t lds_base = conv_lds + size_t(kWavesPerBlock) * (dense ? kRowCacheDense + kBatch : kRowCache) * kSegCells * sizeof(double);
             if constexpr (conv_night_pipe<Conv>::value) {
                 const size_t lds_night = conv_lds + size_t(kWavesPerBlock) * (kRowCacheNight + kBatch) * kSegCells * sizeof(double);
-                if (vec)
+                if (!vec)
+                    launch(k_fused_segred_night<Conv, false, false>, lds_night);
+                else if constexpr (conv_dense_ok<Conv>::value)
                     dense ? launch(k_fused_segred_night<Conv, true, true>, lds_night) : launch(k_fused_segred_night<Conv, true, false>, lds_night);
                 else
-                    dense ? launch(k_fused_segred_night<Conv, false, true>, lds_night) : launch(k_fused_segred_night<Conv, false, false>, lds_night);
-            } else if (vec) {
-                dense ? launch(k_fused_segred<Conv, true, true>, lds_total) : launch(k_fused_segred<Conv, true, false>, lds_total);
+                    launch(k_fused_segred_night<Conv, true, false>, lds_night);
+            } else if (!vec) {
+                launch(k_fused_segred<Conv, false, false>, lds_base);
+            } else if constexpr (conv_dense_ok<Conv>::value) {
+                dense ? launch(k_fused_segred<Conv, true, true>, lds_base) : launch(k_fused_segred<Conv, true, false>, lds_base);
             } else {
-                dense ? launch(k_fused_segred<Conv, false, true>, lds_total) : launch(k_fused_segred<Conv, false, false>, lds_total);
+                launch(k_fused_segred<Conv, true, false>, lds_base);
             }
             if ((rc = check_launch(what))) return rc;
         }

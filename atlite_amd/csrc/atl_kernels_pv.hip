@@ -21,9 +21,13 @@ template <class PV>
 int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S, PV *c, bool *vec) {
     ATL_REQUIRE(in && p, "atl_pv: inputs/params is NULL");
     ATL_REQUIRE(T >= 0 && S >= 0, "atl_pv: negative shape");
-    ATL_REQUIRE(in->d_influx_direct && in->d_influx_diffuse && in->d_influx_toa,
-                "atl_pv: need influx_direct, influx_diffuse and influx_toa (irradiation.py:209-213)");
-    ATL_REQUIRE(in->d_albedo, "atl_pv: need albedo (irradiation.py:128-139)");
+    if (in->d_influx) {  // the influx / outflux head (pv_influx_fast)
+        ATL_REQUIRE(in->d_outflux && in->d_influx_toa, "atl_pv: an influx dataset needs outflux and influx_toa here");
+    } else {
+        ATL_REQUIRE(in->d_influx_direct && in->d_influx_diffuse && in->d_influx_toa,
+                    "atl_pv: need influx_direct, influx_diffuse and influx_toa (irradiation.py:209-213)");
+        ATL_REQUIRE(in->d_albedo, "atl_pv: need albedo (irradiation.py:128-139)");
+    }
     ATL_REQUIRE(in->d_temperature, "atl_pv: need temperature");
     if (in->d_solar_altitude || in->d_solar_azimuth) {
         ATL_REQUIRE(in->d_solar_altitude && in->d_solar_azimuth,
@@ -57,15 +61,29 @@ int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t 
     c->cell_slope = p->d_cell_slope;
     c->cell_azimuth = p->d_cell_azimuth;
     *vec = vec_ok(S, {in->d_influx_direct, in->d_influx_diffuse, in->d_influx_toa, in->d_albedo,
-                      in->d_temperature, in->d_solar_altitude, in->d_solar_azimuth});
+                      in->d_temperature, in->d_solar_altitude, in->d_solar_azimuth, in->d_influx, in->d_outflux});
     return ATL_OK;
 }
 
 // f(converter instance) with the PvConvT instantiation for (stored / computed solar position,
 // scalar / per-cell orientation)
+// influx / outflux datasets the fast family takes: pv() defaults on a SARAH-shaped cutout (total influx + outflux,
+// "simple" clearsky model, stored solar angles, Huld panel, fixed panel, simple trigon model)
+bool pv_influx_fast(const atl_pv_inputs *in, const atl_pv_params *p) {
+    return in->d_influx && in->d_outflux && !in->d_albedo && !in->d_influx_direct && !in->d_influx_diffuse &&
+           in->d_solar_altitude && in->d_solar_azimuth && in->d_temperature && p->clearsky_model == ATL_CLEARSKY_SIMPLE &&
+           p->panel_model == ATL_PANEL_HULD && p->tracking == ATL_TRACK_NONE && p->trigon_model == ATL_TRIGON_SIMPLE &&
+           p->irradiation == ATL_IRR_TOTAL && !p->orientation_per_time;
+}
+
 template <class F>
 int pv_dispatch(const atl_pv_inputs *in, const atl_pv_params *p, bool allow_skip, F &&f) {
     const bool sp = !(in->d_solar_altitude || in->d_solar_azimuth), pc = p->d_cell_slope != nullptr;
+    if (pv_influx_fast(in, p)) {
+        if (p->night_skip && allow_skip)
+            return pc ? f(PvConvT<false, true, true, kTailHuld, ATL_TRACK_NONE, 1>()) : f(PvConvT<false, false, true, kTailHuld, ATL_TRACK_NONE, 1>());
+        return pc ? f(PvConvT<false, true, false, kTailHuld, ATL_TRACK_NONE, 1>()) : f(PvConvT<false, false, false, kTailHuld, ATL_TRACK_NONE, 1>());
+    }
     // pv_needs_general() admits trackers only with stored angles and the Huld panel
     auto tracker = [&](auto trk) {
         constexpr int TR = decltype(trk)::value;
@@ -97,6 +115,7 @@ int pv_dispatch(const atl_pv_inputs *in, const atl_pv_params *p, bool allow_skip
 }
 
 bool pv_needs_general(const atl_pv_inputs *in, const atl_pv_params *p) {
+    if (pv_influx_fast(in, p)) return false;
     if (in->d_influx != nullptr || in->d_albedo == nullptr || p->orientation_per_time) return true;
     if (p->tracking != ATL_TRACK_NONE)  // trackers: fast family for pv() with the Huld panel
         return !(p->tracking >= ATL_TRACK_HORIZONTAL && p->tracking <= ATL_TRACK_DUAL &&

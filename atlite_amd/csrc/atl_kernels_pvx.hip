@@ -24,6 +24,8 @@ int pvx_dispatch(const atl_pv_params *p, F &&f) {
         case ATL_TRACK_DUAL:
             return other ? f(PvxConvT<ATL_TRACK_DUAL, ATL_TRIGON_OTHER>()) : f(PvxConvT<ATL_TRACK_DUAL, ATL_TRIGON_SIMPLE>());
         default:  // ATL_TRACK_NONE; out-of-range codes are rejected by make_pvx
+            if (p->orientation_per_time)
+                return other ? f(PvxConvT<ATL_TRACK_NONE, ATL_TRIGON_OTHER, true>()) : f(PvxConvT<ATL_TRACK_NONE, ATL_TRIGON_SIMPLE, true>());
             return other ? f(PvxConvT<ATL_TRACK_NONE, ATL_TRIGON_OTHER>()) : f(PvxConvT<ATL_TRACK_NONE, ATL_TRIGON_SIMPLE>());
     }
 }
@@ -76,6 +78,8 @@ int make_pvx(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t
     c->cell_azimuth = p->d_cell_azimuth;
     c->ori_per_time = p->orientation_per_time ? 1 : 0;
     ATL_REQUIRE(!p->orientation_per_time || p->d_cell_slope, "atl_pv: orientation_per_time needs the (T,S) slope / azimuth cubes");
+    ATL_REQUIRE(!p->orientation_per_time || p->tracking == ATL_TRACK_NONE,
+                "atl_pv: an orientation that depends on time cannot be combined with a tracker");
     *vec = vec_ok(S, {in->d_influx_direct, in->d_influx_diffuse, in->d_influx, in->d_influx_toa, in->d_albedo,
                       in->d_outflux, in->d_temperature, in->d_humidity, in->d_solar_altitude, in->d_solar_azimuth,
                       p->orientation_per_time ? p->d_cell_slope : nullptr, p->orientation_per_time ? p->d_cell_azimuth : nullptr});

@@ -315,6 +315,49 @@ def test_pv_night_skip_is_bit_identical(ctx, Y, X):
     np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-12 * np.nanmax(np.abs(ref[np.isfinite(ref)])), equal_nan=True)
 
 
+def test_pv_influx_outflux_dataset_fast_family(ctx):
+    """SARAH-shaped datasets (total influx + outflux, no direct / diffuse split, no albedo): pv() with its defaults
+    runs in the fast kernel family (Reindl split and albedo = outflux / influx in the converter's head, 48 B/cell)
+    instead of the general kernel - per cell, aggregated, with the night early-out (same bits), against the oracle;
+    hostile values in the two new streams included."""
+    T, Y, X, N = 61, 10, 22, 7
+    S = Y * X
+    ds = H.pv_dataset(T, Y, X, seed=31)
+    infl = ds["influx_direct"] + ds["influx_diffuse"]
+    outf = ds["albedo"] * infl
+    rng = np.random.default_rng(5)
+    day = np.argwhere(infl > 50.0)
+    for n, (t, c) in enumerate(day[:: max(1, len(day) // 8)][:8]):
+        if n == 0: infl[t, c] = -3.0            # clipped to 0
+        if n == 1: infl[t, c] = 1e6             # clipped to toa
+        if n == 2: outf[t, c] = np.nan          # albedo NaN -> 0
+        if n == 3: outf[t, c] = 5e3             # albedo capped at 1
+        if n == 4: infl[t, c] = np.nan
+        if n == 5: outf[t, c] = -1.0
+    sar = {k: ds[k] for k in ("influx_toa", "temperature", "solar_altitude", "solar_azimuth")}
+    sar["influx"], sar["outflux"] = infl, outf
+    dev = {k: ctx.upload(v) for k, v in sar.items()}
+    ori = dict(slope=np.radians(30.0), azimuth=np.radians(180.0))
+    ref = orc.convert_pv_general(sar, H.CSI, ori, clearsky_model="simple")
+    got = ctx.pv(dev, PV_PARAMS, T, S, options=dict(clearsky_model="simple")).numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-12 * np.nanmax(np.abs(ref)), equal_nan=True)
+    M = H.blob_matrix(N, Y, X, seed=32)
+    plan = ctx.plan(M, row_len=X)
+    with np.errstate(invalid="ignore"):
+        refa = orc.aggregate_matrix(ref, M)
+    a = ctx.pv(dev, PV_PARAMS, T, S, plan=plan, options=dict(clearsky_model="simple", night_skip=False)).numpy()
+    b = ctx.pv(dev, PV_PARAMS, T, S, plan=plan, options=dict(clearsky_model="simple", night_skip=True)).numpy()
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_allclose(a, refa, rtol=1e-10, atol=1e-12 * np.nanmax(np.abs(refa[np.isfinite(refa)])), equal_nan=True)
+    _, ygrid = H.grid(Y, X)
+    lo = orc.orientation_latitude_optimal(np.radians(ygrid))
+    pc = dict(H.CSI, slope=np.repeat(lo["slope"], X), azimuth=np.repeat(lo["azimuth"], X))
+    refpc = orc.convert_pv_general(sar, H.CSI, dict(slope=np.repeat(lo["slope"], X)[None, :], azimuth=np.repeat(lo["azimuth"], X)[None, :]),
+                                   clearsky_model="simple")
+    got = ctx.pv(dev, pc, T, S, options=dict(clearsky_model="simple")).numpy()
+    np.testing.assert_allclose(got, refpc, rtol=1e-10, atol=1e-12 * np.nanmax(np.abs(refpc)), equal_nan=True)
+
+
 @pytest.mark.parametrize("R", [16, 17, 28, 40])
 def test_dense_tiles_on_the_matrix_cores(ctx, monkeypatch, R):
     """Tiles with >= 16 partial rows are contracted with v_mfma_f64_16x16x4_f64 (groups of 16 rows, a last group from
