@@ -65,6 +65,10 @@ struct PlanDev {
     // 0.0 where structurally absent or past the tile's last row.  nullptr when the plan has no dense tile.
     const int64_t *seg_wm;
     const double *prow_wm;
+    // [n_segs] bit l = lane l of the tile owns a cell that carries a weight in some partial row.  The other lanes
+    // (cells outside every shape: sea, neighbouring countries, tile padding) issue no loads at all - their values
+    // could only ever meet structural zeros - so a 128-byte line without a covered cell is never fetched.
+    const uint64_t *seg_mask;
 };
 
 constexpr int kMfmaRows = 16;      // rows per MFMA group

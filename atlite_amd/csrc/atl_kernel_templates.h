@@ -336,6 +336,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fuse
     const int n_mfma = DENSE ? mfma_groups(p1 - p0) : 0;  // groups of 16 rows
     const double *wm = n_mfma ? plan.prow_wm + plan.seg_wm[seg] : nullptr;
     double *vl = lds + conv_lds_doubles + kWavesPerBlock * (ROWS * kSegCells) + wave * (kBatch * kSegCells);
+    // lanes whose cells carry no weight in any partial row do not load (PlanDev::seg_mask)
+    const bool covered = (plan.seg_mask[seg] >> lane) & 1u;
     const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
     // weights of the first kRowCache partial rows: in this wave's LDS area for the whole chunk (each lane
     // writes and later reads only its own 16 bytes: no barrier needed)
@@ -366,15 +368,17 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fuse
         constexpr int G = Conv::kGroup;
 #pragma unroll
         for (int i0 = 0; i0 < kBatch; i0 += G) {
-            typename Conv::Raw raw[G];
+            typename Conv::Raw raw[G] = {};
+            if (covered) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                raw[g] = conv.template load<VEC>(min(sb + i0 + g, send - 1), i0 + g, s0c, s1c, cell, carry);
+                for (int g = 0; g < G; ++g) {
+                    raw[g] = conv.template load<VEC>(min(sb + i0 + g, send - 1), i0 + g, s0c, s1c, cell, carry);
+                }
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const int i = i0 + g;
-                const bool live = sb + i < send;
+                const bool live = covered && sb + i < send;  // an uncovered lane converts zeros: whatever comes out is dropped
                 v[i] = conv.compute(raw[g], v0, v1, cell, lds);
                 v[i].x = live ? v[i].x : 0.0;
                 v[i].y = live ? v[i].y : 0.0;
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 3 : min_waves<Conv>())
     const int G = DENSE ? mfma_groups(p1 - p0) : 0;
     const double *wm = G ? plan.prow_wm + plan.seg_wm[seg] : nullptr;
     const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
-    const bool no_cell = !v0 && !v1;
+    const bool covered = (plan.seg_mask[seg] >> lane) & 1u;  // lanes without a weighted cell do not load and vote "night"
     unsigned present = 0;
 #pragma unroll
     for (int r = 0; r < kRowCacheNight; ++r) {
@@ -472,13 +476,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 3 : min_waves<Conv>())
     partials -= slot0;
     double2 key[kBatch];
 #pragma unroll
-    for (int i = 0; i < kBatch; ++i) key[i] = conv.template key_load<VEC>(min(sbeg + i, send - 1), s0c, s1c, cell);
+    for (int i = 0; i < kBatch; ++i) key[i] = covered ? conv.template key_load<VEC>(min(sbeg + i, send - 1), s0c, s1c, cell) : double2{0.0, 0.0};
     for (int64_t sb = sbeg; sb < send; sb += kBatch) {
         // votes: bit i of day = some cell of the tile is converted in slot sb + i
         unsigned day = 0;
 #pragma unroll
         for (int i = 0; i < kBatch; ++i) {
-            const bool d = (sb + i < send) && !__all(conv.key_is_zero(key[i], min(sb + i, send - 1), cell) || no_cell);
+            const bool d = (sb + i < send) && !__all(conv.key_is_zero(key[i], min(sb + i, send - 1), cell) || !covered);
             day |= d ? 1u << i : 0u;
             *reinterpret_cast<double2 *>(vl + vrow_pair<DENSE>(i, lane)) = d ? key[i] : double2{0.0, 0.0};
         }
@@ -491,9 +495,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 3 : min_waves<Conv>())
             while (m) {
                 const int p = __builtin_ctz(m);
                 m &= m - 1;
-                const typename Conv::Raw A = conv.template rest_load<VEC>(sb + p, s0c, s1c, cell);
+                typename Conv::Raw A = {};
+                if (covered) A = conv.template rest_load<VEC>(sb + p, s0c, s1c, cell);
                 const double2 kv = *reinterpret_cast<const double2 *>(vl + vrow_pair<DENSE>(p, lane));
-                const double2 r = conv.compute_keyed(A, kv, v0, v1, cell, lds);
+                double2 r = conv.compute_keyed(A, kv, v0, v1, cell, lds);
+                r.x = covered ? r.x : 0.0;
+                r.y = covered ? r.y : 0.0;
                 finite = finite && (__builtin_fabs(r.x) < __builtin_inf()) && (__builtin_fabs(r.y) < __builtin_inf());
                 *reinterpret_cast<double2 *>(vl + vrow_pair<DENSE>(p, lane)) = r;
             }
@@ -504,7 +511,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 3 : min_waves<Conv>())
         // prefetch so that its operands and the 32 key registers are not live together
         if (sb + kBatch < send) {
 #pragma unroll
-            for (int i = 0; i < kBatch; ++i) key[i] = conv.template key_load<VEC>(min(sb + kBatch + i, send - 1), s0c, s1c, cell);
+            for (int i = 0; i < kBatch; ++i) key[i] = covered ? conv.template key_load<VEC>(min(sb + kBatch + i, send - 1), s0c, s1c, cell) : double2{0.0, 0.0};
         }
         if (!dense || kMfmaRows * G < p1 - p0) {
             double2 v[kBatch];

@@ -556,6 +556,12 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_le
         }
     }
     (void)n_raw;
+    // lanes of each tile that own a weighted cell (PlanDev::seg_mask)
+    std::vector<uint64_t> seg_mask(static_cast<size_t>(n_segs), 0);
+    for (int64_t t = 0; t < n_segs; ++t)
+        for (int32_t q = seg_ptr[size_t(t)]; q < seg_ptr[size_t(t) + 1]; ++q)
+            for (int c = 0; c < kSegCells; ++c)
+                if (!std::isnan(prow_w[size_t(q) * kSegCells + size_t(c)])) seg_mask[size_t(t)] |= uint64_t(1) << (c >> 1);
     // pass 4: the MFMA operand image of dense tiles (PlanDev::prow_wm)
     std::vector<int64_t> seg_wm;
     std::vector<double> prow_wm;
@@ -608,6 +614,7 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_le
         (rc = to_device(a, shape_ptr, &a->dev.shape_ptr)) ||
         (rc = to_device(a, shape_prow, &a->dev.shape_prow)) ||
         (rc = to_device(a, poison, &a->dev.row_poison)) ||
+        (rc = to_device(a, seg_mask, &a->dev.seg_mask)) ||
         (!prow_wm.empty() && ((rc = to_device(a, seg_wm, &a->dev.seg_wm)) || (rc = to_device(a, prow_wm, &a->dev.prow_wm))))) {
         atl_agg_destroy(a);
         return rc;
