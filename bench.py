@@ -467,6 +467,7 @@ def main():
                 "covered_cells": covered, "max_shapes_per_cell": int(np.asarray((M_s != 0).sum(0)).max()),
                 "algorithmic_bytes": bpc * T_loc * covered, "traffic": tr, "traffic_source": src,
                 "achieved_GBps_on_covered_cells": bpc * T_loc * covered / (float(kk.mean()) * 1e-3) / 1e9,
+                "achieved_on_traffic_GBps": (tr / (float(kk.mean()) * 1e-3) / 1e9) if tr else None,
             }
             plan = plan_main
         # (3) what a user of the drop-in API waits for: cutout.pv(...) on a device-resident Dataset
