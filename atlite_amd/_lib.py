@@ -207,6 +207,11 @@ SIGNATURES = {
         [_i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _d, _d, _d, _d, C.POINTER(_vp), C.POINTER(_vp),
          C.POINTER(_vp)],
     ),
+    "atl_indicator_polygons_device": (
+        _i,
+        [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _d, _d, _d, _d, C.POINTER(_vp), C.POINTER(_vp),
+         C.POINTER(_vp)],
+    ),
     "atl_host_free": (_i, [_vp]),
     "atl_nc_open": (_i, [C.c_char_p, C.POINTER(_vp)]),
     "atl_nc_close": (_i, [_vp]),

@@ -11,6 +11,8 @@ tensors or DeviceArrays), or pass an ``xarray.Dataset`` where xarray is installe
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import pandas as pd
 
@@ -79,11 +81,23 @@ class Cutout:
         xs, ys = np.meshgrid(self.coords["x"], self.coords["y"])
         return pd.DataFrame({"x": np.ravel(xs), "y": np.ravel(ys)})
 
-    def indicatormatrix(self, shapes, shapes_crs=4326):
-        """Share of every grid cell lying in every shape, sparse (N x Y*X) (cutout.py:492-515)."""
+    def indicatormatrix(self, shapes, shapes_crs=4326, where=None):
+        """Share of every grid cell lying in every shape, sparse (N x Y*X) (cutout.py:492-515).
+
+        where: "device" (the areas are line integrals evaluated on the GPU), "host" (the C++ polygon clipper) or
+        None = ATLITE_HIP_INDICATOR, default "device".  Both implement the same contract (1e-13 of a cell apart);
+        the conversion itself has no host path either way."""
         if shapes_crs != self.crs:
             raise NotImplementedError("reprojection of shapes needs pyproj; pass shapes in the cutout's crs")
-        return gis.compute_indicatormatrix(self.coords["x"], self.coords["y"], shapes)
+        where = where or os.environ.get("ATLITE_HIP_INDICATOR", "device")
+        if where not in ("device", "host"):
+            raise ValueError(f"where must be 'device' or 'host', not {where!r}")
+        ctx = None
+        if where == "device":
+            from .device import default_context
+
+            ctx = default_context()
+        return gis.compute_indicatormatrix(self.coords["x"], self.coords["y"], shapes, ctx=ctx)
 
     def uniform_layout(self):
         from .labeled import LabeledArray

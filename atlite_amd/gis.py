@@ -52,13 +52,15 @@ def _rings_of(shape):
     return [(a, False)]
 
 
-def compute_indicatormatrix(x, y, shapes):
+def compute_indicatormatrix(x, y, shapes, ctx=None):
     """
     Indicator matrix ``I[i, j]`` = share of grid cell ``j`` (``j = iy * X + ix``, cell = box of
     centre +- half spacing) lying in ``shapes[i]``; returns ``scipy.sparse.csr_matrix (N, Y*X)``.
 
     x, y : 1-d ascending, evenly spaced cell-centre coordinates (cutout.coords['x'/'y']).
     shapes : sequence (or pandas Series) of polygons, see ``_rings_of``.
+    ctx : a ``device.Context`` -> the areas are evaluated on that GPU (``atl_indicator_polygons_device``: exact
+          line integrals per candidate cell); ``None`` -> the host clipper (``atl_indicator_polygons``).
     """
     x = np.asarray(x, dtype=np.float64)
     y = np.asarray(y, dtype=np.float64)
@@ -81,13 +83,13 @@ def compute_indicatormatrix(x, y, shapes):
     xy = np.concatenate(xy) if xy else np.zeros((0, 2))
     lib = _lib.load()
     p_ip, p_ix, p_d = C.c_void_p(), C.c_void_p(), C.c_void_p()
-    _lib.check(
-        lib.atl_indicator_polygons(
-            len(shapes), shape_ptr.ctypes.data, len(holes), ring_ptr.ctypes.data,
+    args = (len(shapes), shape_ptr.ctypes.data, len(holes), ring_ptr.ctypes.data,
             holes.ctypes.data if len(holes) else None, xy.ctypes.data if len(xy) else None,
-            X, Y, float(x[0]), dx, float(y[0]), dy, C.byref(p_ip), C.byref(p_ix), C.byref(p_d),
-        )
-    )
+            X, Y, float(x[0]), dx, float(y[0]), dy, C.byref(p_ip), C.byref(p_ix), C.byref(p_d))
+    if ctx is not None:
+        _lib.check(lib.atl_indicator_polygons_device(ctx.handle, *args))
+    else:
+        _lib.check(lib.atl_indicator_polygons(*args))
     try:
         N = len(shapes)
         indptr = np.ctypeslib.as_array(C.cast(p_ip, C.POINTER(C.c_int64)), (N + 1,)).copy()

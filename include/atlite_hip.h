@@ -311,6 +311,15 @@ int atl_indicator_polygons(int64_t n_shapes, const int64_t *h_shape_ring_ptr, in
                            double dy, int64_t **out_indptr, int32_t **out_indices,
                            double **out_data);
 int atl_host_free(void *p);
+/* The same contract evaluated on the device (one thread per candidate cell of a shape's bounding box, exact
+ * line integrals over the ring edges that overlap the cell's grid column; the host only buckets the edges by
+ * column and compacts the result): SURVEY 8 f-2, second half.  Entries below 1e-12 of a cell are dropped
+ * (the residue of cells the shape does not reach); otherwise equal to atl_indicator_polygons to ~1e-13. */
+int atl_indicator_polygons_device(atl_ctx *ctx, int64_t n_shapes, const int64_t *h_shape_ring_ptr, int64_t n_rings,
+                                  const int64_t *h_ring_ptr, const uint8_t *h_ring_is_hole,
+                                  const double *h_xy, int64_t X, int64_t Y, double x0, double dx, double y0,
+                                  double dy, int64_t **out_indptr, int32_t **out_indices,
+                                  double **out_data);
 
 /* ---- cutout files: NetCDF-4 (HDF5) ingest -------------------------------------------------------
  * Replaces `xr.open_dataset(path, chunks=...)` + dask chunk reads for the inputs of the path

@@ -499,3 +499,55 @@ def test_wind_grid_lookup_equals_knot_search(ctx, monkeypatch):
         np.testing.assert_array_equal(fa, fb, err_msg=name)
         np.testing.assert_allclose(lane, np.interp(wnd, V, F), rtol=1e-14, atol=1e-16, err_msg=name)  # fast lane vs np.interp
     assert n_grid >= 20  # the lookup is what the shipped turbines actually run
+
+
+def test_indicator_matrix_on_the_device(ctx):
+    """SURVEY 8 f-2, device half: area(shape n cell) / area(cell) as line integrals on the GPU against the host
+    polygon clipper (same contract, atlite/gis.py:104-145) - rectangles with exact answers, ring orientation,
+    holes, multi-part shapes, shapes reaching past the grid, finely digitised borders (many edges per cell column),
+    area conservation of star polygons, a tessellation covering every cell exactly once."""
+    import time
+
+    from atlite_amd import gis
+
+    x, y = np.arange(10.0), 10.0 + 2.0 * np.arange(5.0)
+    cell = np.array([[1.5, 11], [2.5, 11], [2.5, 13], [1.5, 13]])
+    M = gis.compute_indicatormatrix(x, y, [cell], ctx=ctx)
+    assert M.nnz == 1 and abs(M[0, 1 * 10 + 2] - 1.0) < 1e-13
+    rect = np.array([[0.25, 9.5], [3.5, 9.5], [3.5, 12.0], [0.25, 12.0]])
+    hole = np.array([[1.0, 10.0], [2.0, 10.0], [2.0, 11.0], [1.0, 11.0]])
+    far = rect + np.array([5.0, 0.0])
+    outside = rect + np.array([8.0, 6.0])          # partly past the grid's upper right corner
+    nowhere = rect + np.array([100.0, 100.0])      # no overlap at all: an empty row
+    shapes = [rect, rect[::-1], dict(exterior=rect, holes=[hole]), [rect, far], outside, nowhere]
+    D = gis.compute_indicatormatrix(x, y, shapes, ctx=ctx)
+    Hm = gis.compute_indicatormatrix(x, y, shapes)
+    assert D.shape == Hm.shape and D[5].nnz == 0
+    np.testing.assert_allclose(D.toarray(), Hm.toarray(), rtol=0, atol=1e-13)
+    assert abs(D[2].sum() * 2.0 - (3.25 * 2.5 - 1.0)) < 1e-12
+
+    X = Y = 120
+    xx, yy = -25 + (70 / X) * np.arange(X), 30 + (42 / Y) * np.arange(Y)
+    ca = (70 / X) * (42 / Y)
+    polys = gis.random_star_polygons(40, (-15, 35, 35, 66), seed=3)
+    # a finely digitised border: 4000 vertices on a wobbly circle, ~100 edges per cell column
+    th = np.linspace(0, 2 * np.pi, 4000, endpoint=False)
+    rad = 9.0 + 0.8 * np.sin(17 * th) + 0.3 * np.cos(61 * th)
+    polys.append(np.stack([5.0 + 1.6 * rad * np.cos(th), 50.0 + rad * np.sin(th)], axis=1))
+    Dm = gis.compute_indicatormatrix(xx, yy, polys, ctx=ctx)
+    Hm = gis.compute_indicatormatrix(xx, yy, polys)
+    np.testing.assert_allclose(Dm.toarray(), Hm.toarray(), rtol=0, atol=1e-12)
+    for i, p in enumerate(polys[:-1]):
+        a = 0.5 * abs(np.sum(p[:, 0] * np.roll(p[:, 1], -1) - np.roll(p[:, 0], -1) * p[:, 1]))
+        assert abs(Dm[i].sum() * ca - a) < 1e-10 * a
+    tess = gis.random_tessellation(50, (xx[0] - 35 / X, yy[0] - 21 / Y, xx[-1] + 35 / X, yy[-1] + 21 / Y), seed=1)
+    t0 = time.perf_counter()
+    Dt = gis.compute_indicatormatrix(xx, yy, tess, ctx=ctx)
+    t_dev = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    Ht = gis.compute_indicatormatrix(xx, yy, tess)
+    t_host = time.perf_counter() - t0
+    np.testing.assert_allclose(np.asarray(Dt.sum(0)).ravel(), 1.0, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(Dt.toarray(), Ht.toarray(), rtol=0, atol=1e-12)
+    print(f"indicator matrix 50 shapes x 120x120: device {t_dev * 1e3:.1f} ms, host {t_host * 1e3:.1f} ms")
+
