@@ -602,6 +602,19 @@ inline PvxOpt pvx_opt_of(const atl_pv_params *p, bool has_influx, bool has_albed
                   p->bof_threshold, p->st_c0, p->st_c1, p->st_t_store_K, p->r_irradiance};
 }
 
+// SolarPanelModel, bofinger branch (solar_panel_model.py:47-74), literally; out of line like pvx_solar_literal
+ATL_HD __noinline__ double pvx_bofinger_literal(double G, double tmp, double bA, double bB, double bC, double bD,
+                                                    double bNOCT, double bTamb, double bIntc, double bTstd, double bta,
+                                                    double bthr, double inv_eff) {
+    const double nan = __builtin_nan("");
+    const double fraction = (bNOCT - bTamb) / bIntc;
+    const double eta_ref = bA + bB * G + bC * lean_log(G != 0.0 ? G : nan);  // <= 1 ulp; zero / negative / NaN go to libm
+    const double eta = fill0(eta_ref * (1.0 + bD * (fraction * G + (tmp - bTstd))) / (1.0 + bD * fraction / bta * eta_ref * G));
+    const double capacity = (bA + bB * 1000.0 + bC * log(1000.0)) * 1e3;
+    const double power = G * eta * (inv_eff / capacity);
+    return (G >= bthr) ? power : 0.0;
+}
+
 // TRACK / TRIGON are compile-time: they decide the instruction mix and the register footprint;
 // everything else is a wave-uniform run-time switch.
 template <int TRACK, int TRIGON>
@@ -694,15 +707,8 @@ ATL_HD double pvx_cell(double dir, double dif, double infl, double toa, double a
         eff = eff < 0.0 ? 0.0 : eff;
         return G_ * eff * k.inv_eff;
     }
-    if (o.panel == ATL_PANEL_BOFINGER) {
-        const double fraction = (o.bNOCT - o.bTamb) / o.bIntc;
-        const double eta_ref = o.bA + o.bB * G + o.bC * log(G != 0.0 ? G : nan);
-        const double eta = fill0(eta_ref * (1.0 + o.bD * (fraction * G + (tmp - o.bTstd))) /
-                                 (1.0 + o.bD * fraction / o.bta * eta_ref * G));
-        const double capacity = (o.bA + o.bB * 1000.0 + o.bC * log(1000.0)) * 1e3;
-        const double power = G * eta * (k.inv_eff / capacity);
-        return (G >= o.bthr) ? power : 0.0;
-    }
+    if (o.panel == ATL_PANEL_BOFINGER)
+        return pvx_bofinger_literal(G, tmp, o.bA, o.bB, o.bC, o.bD, o.bNOCT, o.bTamb, o.bIntc, o.bTstd, o.bta, o.bthr, k.inv_eff);
     // solar thermal (convert.py:565-574)
     const double eta = o.c0 - o.c1 * fill0((o.t_store - tmp) / (G != 0.0 ? G : nan));
     const double output = G * eta;
@@ -711,9 +717,22 @@ ATL_HD double pvx_cell(double dir, double dif, double infl, double toa, double a
 
 // OT: the orientation follows the sun (two more cubes, read per slot) - its own instantiation, so that the
 // others do not carry the four extra registers per cell pair through a kernel that spills as it is
+// The libm-heavy pieces of the general kernel, out of line and with scalar arguments: inlined, their polynomial
+// constants get hoisted into VGPRs that stay occupied through the whole kernel.
+// pv/solar_position.py:100-114, literally (altitude, azimuth)
+ATL_HD __noinline__ double2 pvx_solar_literal(double sd, double cd, double sl, double cl, double h, double ch) {
+    const double a = asin(np_clip(sd * sl + cd * cl * ch, -1.0, 1.0));
+    double z = acos(np_clip((sd * cl - cd * sl * ch) / cos(a), -1.0, 1.0));
+    z = (h <= 0.0) ? z : 2.0 * 3.14159265358979323846 - z;
+    return double2{a, z};
+}
+
+#ifndef ATL_PVX_WAVES
+#define ATL_PVX_WAVES 2  // waves per SIMD the general kernel is compiled for (256 VGPRs)
+#endif
 template <int TRACK, int TRIGON, bool OT = false>
 struct PvxConvT {
-    static constexpr int kMinWaves = 2;
+    static constexpr int kMinWaves = ATL_PVX_WAVES;
     static constexpr bool kDenseOk = false;  // no MFMA-carrying instantiation of these (rare options x rare matrices)
     atl_pv_inputs in;
     int64_t S;
@@ -753,14 +772,11 @@ struct PvxConvT {
         }
         return c;
     }
-    // pv/solar_position.py:100-114, literally
     __device__ static void solar(double sd, double cd, double sl, double cl, double h, double ch, double *alt,
                                  double *az) {
-        const double a = asin(np_clip(sd * sl + cd * cl * ch, -1.0, 1.0));
-        double z = acos(np_clip((sd * cl - cd * sl * ch) / cos(a), -1.0, 1.0));
-        z = (h <= 0.0) ? z : 2.0 * 3.14159265358979323846 - z;
-        *alt = a;
-        *az = z;
+        const double2 r = pvx_solar_literal(sd, cd, sl, cl, h, ch);
+        *alt = r.x;
+        *az = r.y;
     }
     static constexpr int kGroup = 1;
     struct OriRaw {
