@@ -76,6 +76,9 @@ def parse():
     ap.add_argument("--night-skip", action="store_true",
                     help="enable the night early-out in the MAIN measurement (it reads fewer bytes than the "
                          "56 B/cell the roofline figure assumes; always reported separately at N=1)")
+    ap.add_argument("--debug-rccl-self", action="store_true",
+                    help="testing only (one GPU, one process): open a 1-rank RCCL process group and route the step "
+                         "through the collective branch (async all-gather on the group's stream, placement copy)")
     ap.add_argument("--debug-gloo-one-gpu", action="store_true",
                     help="testing only: all ranks share GPU 0 and the collective runs over gloo on host copies")
     return ap.parse_args()
@@ -187,6 +190,13 @@ def main():
     dist = None
     if a.debug_gloo_one_gpu:
         local = 0
+    if a.debug_rccl_self and world == 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
     if world > 1:
         import torch.distributed as dist
 
@@ -265,7 +275,8 @@ def main():
     assert equal or world == 1 or P == 1, "pipelined gather needs equal shards"
     full = torch.empty((N, sum(shard_lens)), dtype=torch.float64, device=dev)  # (shapes x all time steps)
     piece = [torch.empty((N, pe[i + 1] - pe[i]), dtype=torch.float64, device=dev) for i in range(P)]
-    gbuf = [torch.empty((parts, N, pe[i + 1] - pe[i]), dtype=torch.float64, device=dev) for i in range(P)] if parts > 1 else None
+    collective = parts > 1 or (a.debug_rccl_self and dist is not None)
+    gbuf = [torch.empty((parts, N, pe[i + 1] - pe[i]), dtype=torch.float64, device=dev) for i in range(P)] if collective else None
     cube_ptrs = {k: getattr(pin, k) for k in ("d_influx_direct", "d_influx_diffuse", "d_influx_toa", "d_albedo",
                                               "d_temperature", "d_solar_altitude", "d_solar_azimuth")}
     tab_ptrs = {k: getattr(pin, k) for k in ("d_sin_dec", "d_cos_dec", "d_hour_angle", "d_cos_hour_angle")}
@@ -292,7 +303,7 @@ def main():
                                                     plan.handle, 0, out_t.data_ptr(), out_t.stride(0)))
 
     def step(pp):
-        if parts == 1:
+        if not collective:
             for i in range(P):  # P == 1 unless asked otherwise: straight into the result
                 launch(pp, i, full[:, pe[i]:pe[i + 1]] if P == 1 else piece[i])
                 if P > 1:
@@ -525,6 +536,7 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
+    if dist is not None:
         dist.destroy_process_group()
 
 

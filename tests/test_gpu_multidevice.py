@@ -148,3 +148,26 @@ def test_rccl_ragged_allgather_single_rank(ctx):
     ctx.sync()
     np.testing.assert_array_equal(out.numpy()[:, :13], a)
     comm.close()
+
+
+def test_bench_collective_branch_over_rccl_on_one_rank():
+    """bench.py's N > 1 step (async RCCL all-gather on the process group's stream, ordered against the kernels' stream
+    by torch, strided placement copy) on a 1-rank RCCL group - what can be exercised of it with a single GPU; the
+    parity leg checks the reassembled result against the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--debug-rccl-self", "--pipeline", "2", "--steps", "3", "--warmup", "1",
+                        "--T", "960", "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["parity"]["ok"] and j["parity"]["max_rel_err"] < 1e-10, j["parity"]
+
