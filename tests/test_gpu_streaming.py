@@ -87,3 +87,29 @@ def test_wind_heat_runoff_streamed(monkeypatch, forced):
     # arbitrary convert_func on host data: cube streamed through atl_spmm_csr
     w, s = both(monkeypatch, lambda: c.convert_and_aggregate(lambda d: d["runoff"], matrix=M, aggregate_time=None).values)
     np.testing.assert_array_equal(w, s)
+
+
+def test_time_dependent_orientation_streamed_and_sharded(monkeypatch, forced):
+    """An orientation callback that follows the sun produces (time, cell) slope / azimuth cubes: they are cut along
+    time with the inputs, by the slab pipeline and by the multi-device executor alike - same bits as one launch."""
+    T, Y, X, N = 61, 6, 10, 4
+    ds = H.pv_dataset(T, Y, X, seed=13)
+    x, y = H.grid(Y, X)
+    M = H.blob_matrix(N, Y, X, seed=14)
+    kw = dict(panel="CSi", orientation=H.orientation_follow_sun, matrix=M, aggregate_time=None)
+    c = Cutout(Dataset(ds, dict(time=H.times(T), y=y, x=x)))
+    whole, streamed = both(monkeypatch, lambda: c.pv(**kw).values)
+    np.testing.assert_array_equal(whole, streamed)
+    sp_ = dict(altitude=ds["solar_altitude"].reshape(T, Y, X), azimuth=ds["solar_azimuth"].reshape(T, Y, X))
+
+    class A:
+        def __init__(self, v, dims=None, coords=None):
+            self.values, self.dims, self.coords = np.asarray(v), dims, coords
+
+    o = H.orientation_follow_sun(None, None, {k: A(v) for k, v in sp_.items()})
+    ref = orc.convert_pv_general(ds, H.CSI, dict(slope=o["slope"].values.reshape(T, -1), azimuth=o["azimuth"].values.reshape(T, -1)))
+    close(whole, orc.aggregate_matrix(ref, M))
+    monkeypatch.setenv("ATLITE_HIP_STREAM", "0")
+    many = Cutout(Dataset(ds, dict(time=H.times(T), y=y, x=x)), devices=[0, 0, 0])
+    np.testing.assert_array_equal(many.pv(**kw).values, whole)
+
