@@ -420,7 +420,7 @@ struct PvConvT {
     static constexpr bool kNightPipe = SKIP;
     // register budget of the fused kernels: the night kernel with stored angles and one orientation for the grid
     // fits 4 waves per SIMD
-    static constexpr int kMinWaves = (kNightPipe && !PC && !SP) ? 4 : 3;
+    static constexpr int kMinWaves = (kNightPipe && !PC && !SP && HEAD == 0) ? 4 : 3;
     // stored angles: key = the slot's solar altitude.  In-kernel solar position: key = cos(hour angle) of the
     // lane's two grid columns (a (T, X) table), from which sin(altitude) follows with the slot's declination and
     // the cells' latitude - night is known before a single byte of the cubes is read.

@@ -286,7 +286,7 @@ constexpr int min_waves() {
 }
 
 template <class Conv, bool VEC, bool DENSE>
-__global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fused_segred(Conv conv, PlanDev plan, int64_t slot0,
+__global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2 ? 2 : min_waves<Conv>()) void k_fused_segred(Conv conv, PlanDev plan, int64_t slot0,
                                                       int64_t n_slots, int64_t S, int32_t chunk_slots,
                                                       int64_t n_units, double *__restrict__ partials,
                                                       int64_t ldp, int32_t conv_lds_doubles) {
@@ -432,7 +432,7 @@ template <class Conv>
 struct conv_night_pipe<Conv, std::void_t<decltype(Conv::kNightPipe)>> : std::integral_constant<bool, Conv::kNightPipe> {};
 
 template <class Conv, bool VEC, bool DENSE>
-__global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 3 : min_waves<Conv>()) void k_fused_segred_night(Conv conv, PlanDev plan, int64_t slot0,
+__global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 2 : min_waves<Conv>()) void k_fused_segred_night(Conv conv, PlanDev plan, int64_t slot0,
                                                       int64_t n_slots, int64_t S, int32_t chunk_slots,
                                                       int64_t n_units, double *__restrict__ partials,
                                                       int64_t ldp, int32_t conv_lds_doubles) {
