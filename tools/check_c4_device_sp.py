@@ -54,14 +54,18 @@ tables = dict(sin_dec=np.sin(dec), cos_dec=np.cos(dec), h=h, cos_h=np.cos(h), si
 tables = {k: ctx.upload(np.ascontiguousarray(v)) for k, v in tables.items()}
 scal = dict(CSI, slope=np.radians(30.0), azimuth=np.radians(180.0))
 ctx.set_profiling(True)
-ms = []
-for _ in range(4):
-    out = ctx.pv(big, scal, T, S, plan=plan, solar_tables=tables)
-    ms.append(ctx.last_kernel_ms())
-out = out.numpy()
-k = float(np.median(ms[1:]))
-print(f"pv {T}x{Y}x{X}, {N} shapes, device-resident, in-kernel solar position: fused kernel {k:.2f} ms = "
-      f"{40 * T * S / k / 1e6:.0f} GB/s of the 40 B/cell it reads = {T * S / k * 1e3:.3e} cell-timesteps/s")
+outs = {}
+for skip in (False, True):
+    ms = []
+    for _ in range(4):
+        out = ctx.pv(big, scal, T, S, plan=plan, solar_tables=tables, options=dict(night_skip=skip))
+        ms.append(ctx.last_kernel_ms())
+    outs[skip] = out.numpy()
+    k = float(np.median(ms[1:]))
+    print(f"pv {T}x{Y}x{X}, {N} shapes, device-resident, in-kernel solar position, night early-out {'on' if skip else 'off'}: "
+          f"fused kernel {k:.2f} ms = {40 * T * S / k / 1e6:.0f} GB/s of 40 B/cell = {T * S / k * 1e3:.3e} cell-timesteps/s", flush=True)
+print("night early-out on == off (bits):", bool(np.array_equal(outs[False], outs[True])))
+out = outs[False]
 shard = {kk: big[kk].slab(0, TS) for kk in five}
 shard.update(first)
 ref = ctx.pv(shard, scal, TS, S, plan=plan, options=dict(night_skip=False)).numpy()
