@@ -261,19 +261,11 @@ struct PvPlain {
     double r;
     bool ok;
 };
-ATL_HD __forceinline__ PvPlain pv_cell_plain(double dir, double dif, double toa, double alb, double tmp, double alt,
-                                                 double az, const PvOri &o, const PvConst &k) {
+// from cos(incidence) on: tilted irradiation (simple trigon model) + Huld panel, plain arithmetic
+ATL_HD __forceinline__ PvPlain pv_tail_plain(double direct, double diffuse, double influx, double alb, double tmp,
+                                                 double sa, double ca, double cosd, bool plain, bool capped,
+                                                 const PvOri &o, const PvConst &k) {
     const double inf = __builtin_inf();
-    const bool plain = __builtin_fabs(dir) < inf && __builtin_fabs(dif) < inf && __builtin_fabs(toa) < inf &&
-                       __builtin_fabs(alb) < inf && __builtin_fabs(tmp) < inf && __builtin_fabs(alt) < 0x1.0p30 &&
-                       __builtin_fabs(az) < 0x1.0p29 && __builtin_fabs(o.saz) < 0x1.0p29;
-    const double direct = __builtin_fmin(__builtin_fmax(dir, 0.0), toa);
-    const double diffuse = __builtin_fmin(__builtin_fmax(dif, 0.0), toa - direct);
-    const double influx = direct + diffuse;
-    const bool capped = (alt < k.alt_thr) || (influx <= 0.01);
-    double sa, ca;
-    sincos_core(alt, &sa, &ca);
-    const double cosd = cos_core(o.saz - az);
     const double cosinc = __builtin_fmax(o.ss * ca * cosd + o.cs * sa, 0.0);
     const double kk = fast_div(cosinc, sa);
     const double direct_t = kk * direct;
@@ -293,6 +285,46 @@ ATL_HD __forceinline__ PvPlain pv_cell_plain(double dir, double dif, double toa,
     // subnormal G_ (log_core wants a normal argument) and any overflow on the way show in these two tests
     out.ok = plain && (capped || (__builtin_fabs(r) < inf && !(pos && G_ < 0x1.0p-1022)));
     return out;
+}
+
+ATL_HD __forceinline__ PvPlain pv_cell_plain(double dir, double dif, double toa, double alb, double tmp, double alt,
+                                                 double az, const PvOri &o, const PvConst &k) {
+    const double inf = __builtin_inf();
+    const bool plain = __builtin_fabs(dir) < inf && __builtin_fabs(dif) < inf && __builtin_fabs(toa) < inf &&
+                       __builtin_fabs(alb) < inf && __builtin_fabs(tmp) < inf && __builtin_fabs(alt) < 0x1.0p30 &&
+                       __builtin_fabs(az) < 0x1.0p29 && __builtin_fabs(o.saz) < 0x1.0p29;
+    const double direct = __builtin_fmin(__builtin_fmax(dir, 0.0), toa);
+    const double diffuse = __builtin_fmin(__builtin_fmax(dif, 0.0), toa - direct);
+    const double influx = direct + diffuse;
+    const bool capped = (alt < k.alt_thr) || (influx <= 0.01);
+    double sa, ca;
+    sincos_core(alt, &sa, &ca);
+    const double cosd = cos_core(o.saz - az);
+    return pv_tail_plain(direct, diffuse, influx, alb, tmp, sa, ca, cosd, plain, capped, o, k);
+}
+
+// the same with the solar position from the separable tables (pv_cell_sp's front end, plain arithmetic)
+ATL_HD __forceinline__ PvPlain pv_cell_sp_plain(double dir, double dif, double toa, double alb, double tmp, double sd,
+                                                    double cd, double sl, double cl, double h, double ch, const PvOri &o,
+                                                    const PvAz<true> &a, const PvConst &k) {
+    const double inf = __builtin_inf();
+    const double sraw = sd * sl + cd * cl * ch;
+    const double num = sd * cl - cd * sl * ch;
+    bool plain = __builtin_fabs(dir) < inf && __builtin_fabs(dif) < inf && __builtin_fabs(toa) < inf &&
+                 __builtin_fabs(alb) < inf && __builtin_fabs(tmp) < inf && __builtin_fabs(sraw) < inf &&
+                 __builtin_fabs(num) < inf && __builtin_fabs(h) < inf;
+    const double direct = __builtin_fmin(__builtin_fmax(dir, 0.0), toa);
+    const double diffuse = __builtin_fmin(__builtin_fmax(dif, 0.0), toa - direct);
+    const double influx = direct + diffuse;
+    const double s = __builtin_fmin(__builtin_fmax(sraw, -1.0), 1.0);
+    const bool capped = (s < k.sin_alt_thr) || (influx <= 0.01);
+    const double ca = sqrt((1.0 - s) * (1.0 + s));
+    plain = plain && (capped || ca > 0x1.0p-500);  // the sun exactly in the zenith divides literally (pv_cell_sp)
+    const double q = fast_div(num, ca > 0x1.0p-500 ? ca : 1.0);
+    const double caz = __builtin_fmin(__builtin_fmax(q, -1.0), 1.0);
+    double saz = sqrt((1.0 - caz) * (1.0 + caz));
+    saz = (h <= 0.0) ? saz : -saz;
+    return pv_tail_plain(direct, diffuse, influx, alb, tmp, s, ca, a.csaz * caz + a.ssaz * saz, plain, capped, o, k);
 }
 
 // what the kernels evaluate for one cell: the plain evaluation where it is valid, pv_cell otherwise (the
@@ -420,7 +452,10 @@ struct PvConvT {
     static constexpr bool kNightPipe = SKIP;
     // register budget of the fused kernels: the night kernel with stored angles and one orientation for the grid
     // fits 4 waves per SIMD
-    static constexpr int kMinWaves = (kNightPipe && !PC && !SP && HEAD == 0) ? 4 : 3;
+#ifndef ATL_SP_NIGHT_WAVES
+#define ATL_SP_NIGHT_WAVES 3
+#endif
+    static constexpr int kMinWaves = (kNightPipe && !PC && HEAD == 0) ? (SP ? ATL_SP_NIGHT_WAVES : 4) : 3;
     // stored angles: key = the slot's solar altitude.  In-kernel solar position: key = cos(hour angle) of the
     // lane's two grid columns (a (T, X) table), from which sin(altitude) follows with the slot's declination and
     // the cells' latitude - night is known before a single byte of the cubes is read.
@@ -515,8 +550,32 @@ struct PvConvT {
         if constexpr (SP) {
             const PvAz<true> &a0 = [&]() -> const PvAz<true> & { if constexpr (PC) return c.a0; else return oa; }();
             const PvAz<true> &a1 = [&]() -> const PvAz<true> & { if constexpr (PC) return c.a1; else return oa; }();
-            r.x = v0 ? pv_cell_sp(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.sd, q.cd, c.sl0, c.cl0, q.a.x, q.b.x, o0, a0, k) : 0.0;
-            r.y = v1 ? pv_cell_sp(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.sd, q.cd, c.sl1, c.cl1, q.a.y, q.b.y, o1, a1, k) : 0.0;
+            if constexpr (TAIL == kTailHuld && ATL_PV_PLAIN != 0) {
+                // the pair side by side like the stored-angle case below; the dark test reads every loaded value
+                const double inf = __builtin_inf();
+                const bool tame = __builtin_fabs(q.dir.x) < inf && __builtin_fabs(q.dir.y) < inf && __builtin_fabs(q.dif.x) < inf &&
+                                  __builtin_fabs(q.dif.y) < inf && __builtin_fabs(q.toa.x) < inf && __builtin_fabs(q.toa.y) < inf &&
+                                  __builtin_fabs(q.alb.x) < inf && __builtin_fabs(q.alb.y) < inf && __builtin_fabs(q.tmp.x) < inf &&
+                                  __builtin_fabs(q.tmp.y) < inf && __builtin_fabs(q.a.x) < inf && __builtin_fabs(q.a.y) < inf;
+                const bool dark0 = !v0 || (q.sd * c.sl0 + q.cd * c.cl0 * q.b.x) < k.sin_alt_thr - 1e-9;
+                const bool dark1 = !v1 || (q.sd * c.sl1 + q.cd * c.cl1 * q.b.y) < k.sin_alt_thr - 1e-9;
+                r.x = r.y = 0.0;
+                if (!(dark0 && dark1 && tame)) {
+                    const PvPlain p0 = pv_cell_sp_plain(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.sd, q.cd, c.sl0, c.cl0, q.a.x, q.b.x, o0, a0, k);
+                    const PvPlain p1 = pv_cell_sp_plain(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.sd, q.cd, c.sl1, c.cl1, q.a.y, q.b.y, o1, a1, k);
+                    r.x = p0.r;
+                    r.y = p1.r;
+                    if (__builtin_expect(!(p0.ok && p1.ok), 0)) {
+                        r.x = pv_cell_sp(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.sd, q.cd, c.sl0, c.cl0, q.a.x, q.b.x, o0, a0, k);
+                        r.y = pv_cell_sp(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.sd, q.cd, c.sl1, c.cl1, q.a.y, q.b.y, o1, a1, k);
+                    }
+                    r.x = v0 ? r.x : 0.0;
+                    r.y = v1 ? r.y : 0.0;
+                }
+            } else {
+                r.x = v0 ? pv_cell_sp(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.sd, q.cd, c.sl0, c.cl0, q.a.x, q.b.x, o0, a0, k) : 0.0;
+                r.y = v1 ? pv_cell_sp(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.sd, q.cd, c.sl1, c.cl1, q.a.y, q.b.y, o1, a1, k) : 0.0;
+            }
         } else if constexpr (HEAD == 1) {
             r.x = v0 ? pv_cell_influx<TAIL>(q.dir.x, q.alb.x, q.toa.x, q.tmp.x, q.a.x, q.b.x, o0, k) : 0.0;
             r.y = v1 ? pv_cell_influx<TAIL>(q.dir.y, q.alb.y, q.toa.y, q.tmp.y, q.a.y, q.b.y, o1, k) : 0.0;
