@@ -318,11 +318,11 @@ ATL_HD __forceinline__ PvPlain pv_cell_sp_plain(double dir, double dif, double t
     const double influx = direct + diffuse;
     const double s = __builtin_fmin(__builtin_fmax(sraw, -1.0), 1.0);
     const bool capped = (s < k.sin_alt_thr) || (influx <= 0.01);
-    const double ca = sqrt((1.0 - s) * (1.0 + s));
+    const double ca = lean_sqrt((1.0 - s) * (1.0 + s));
     plain = plain && (capped || ca > 0x1.0p-500);  // the sun exactly in the zenith divides literally (pv_cell_sp)
     const double q = fast_div(num, ca > 0x1.0p-500 ? ca : 1.0);
     const double caz = __builtin_fmin(__builtin_fmax(q, -1.0), 1.0);
-    double saz = sqrt((1.0 - caz) * (1.0 + caz));
+    double saz = lean_sqrt((1.0 - caz) * (1.0 + caz));
     saz = (h <= 0.0) ? saz : -saz;
     return pv_tail_plain(direct, diffuse, influx, alb, tmp, s, ca, a.csaz * caz + a.ssaz * saz, plain, capped, o, k);
 }
@@ -352,12 +352,12 @@ ATL_HD __forceinline__ double pv_cell_sp(double dir, double dif, double toa, dou
     const double s = np_clip(sd * sl + cd * cl * ch, -1.0, 1.0);  // :103-105
     const bool capped = (s < k.sin_alt_thr) || (influx <= 0.01);
     if (capped) return 0.0;
-    const double ca = sqrt((1.0 - s) * (1.0 + s));
+    const double ca = lean_sqrt((1.0 - s) * (1.0 + s));
     const double num = sd * cl - cd * sl * ch;
     double q = fast_div(num, ca);
     if (!(ca > 0x1.0p-500)) q = num / ca;  // zenith / NaN: IEEE division like the reference
     const double caz = np_clip(q, -1.0, 1.0);  // :109-113
-    double saz = sqrt((1.0 - caz) * (1.0 + caz));
+    double saz = lean_sqrt((1.0 - caz) * (1.0 + caz));
     saz = (h <= 0.0) ? saz : -saz;  // :114  az = az if h <= 0 else 2 pi - az
     return pv_tail(direct, diffuse, influx, toa, alb, tmp, s, ca, a.csaz * caz + a.ssaz * saz, o, k);
 }

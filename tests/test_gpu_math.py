@@ -69,3 +69,17 @@ def test_table_log(ctx):
     nz = ref != 0
     assert ulp_err(got[nz], ref[nz]).max() <= 2.0
     assert got[x == 1.0][0] == 0.0
+
+
+def test_lean_sqrt(ctx):
+    """v_rsq_f64 seed + one coupled Newton step + residual correction: <= 1 ulp on [0, 2^500), zeros exact, NaN for
+    negative / NaN arguments (the in-kernel solar position takes cos(altitude) and sin(azimuth) through it)."""
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.random(300000), 10.0 ** rng.uniform(-300, 150, 100000), [0.0, 1.0, 4.0, 1e-300, 2.0 ** 499],
+                        1.0 - 10.0 ** rng.uniform(-16, -1, 20000)])
+    got = probe(ctx, 7, x)
+    assert ulp_err(got[x > 0], np.sqrt(x[x > 0])).max() <= 1.0
+    assert (got[x == 0] == 0.0).all()
+    bad = probe(ctx, 7, np.array([-1.0, np.nan, -0.0]))
+    assert np.isnan(bad[0]) and np.isnan(bad[1]) and bad[2] == 0.0
+

@@ -77,6 +77,19 @@ def test_table_log_host():
         probe(5, np.array([-1.0, 0.0, np.nan, np.inf, 5e-324, -np.inf]))
 
 
+def test_lean_sqrt_host():
+    """lean_sqrt (reciprocal-square-root seed, one coupled Newton step, residual correction): <= 1 ulp on [0, 2^500),
+    exact zeros, NaN for negative / NaN arguments."""
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.random(20000), 10.0 ** rng.uniform(-300, 150, 20000), [0.0, 1.0, 4.0, 1e-300, 2.0 ** 499],
+                        1.0 - 10.0 ** rng.uniform(-16, -1, 2000)])
+    got = probe(7, x)
+    assert ulp_err(got[x > 0], np.sqrt(x[x > 0])).max() <= 1.0
+    assert got[x == 0].tolist() == [0.0]
+    bad = probe(7, np.array([-1.0, np.nan, -0.0]))
+    assert np.isnan(bad[0]) and np.isnan(bad[1]) and bad[2] == 0.0 and np.signbit(bad[2])
+
+
 def test_divisions_host():
     rng = np.random.default_rng(2)
     a, b = rng.uniform(0, 2, 100000), rng.uniform(0.0174, 1.0, 100000)  # sin(alt) above the 1 degree cut
