@@ -43,14 +43,14 @@ def main():
         ds["solar_azimuth"][m] = np.pi  # exactly the panel azimuth: tan(rotation) = 0 for the trackers
         m = rng.random((T, Y, X)) < 0.01
         ds["influx_toa"][m] = 0.0
-        flavour = rng.choice(["split", "influx", "outflux"])
-        if flavour == "influx":
+        flavour = rng.choice(["split", "influx", "outflux", "sarah"])
+        if flavour in ("outflux", "sarah"):  # "sarah": total influx AND outflux (the fast family's influx head)
+            ds["outflux"] = (ds["influx_direct"] + ds["influx_diffuse"]) * ds["albedo"]
+            del ds["albedo"]
+        if flavour in ("influx", "sarah"):
             ds["influx"] = ds["influx_direct"] + ds["influx_diffuse"]
             ds["humidity"] = rng.random((T, Y, X))
             del ds["influx_direct"], ds["influx_diffuse"]
-        if flavour == "outflux":
-            ds["outflux"] = (ds["influx_direct"] + ds["influx_diffuse"]) * ds["albedo"]
-            del ds["albedo"]
         # a quarter of the cases carry no stored solar angles: in-kernel solar position (the oracle
         # computes the angles the way pv/solar_position.py does)
         computed_sp = bool(rng.random() < 0.25)
