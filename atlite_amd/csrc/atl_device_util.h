@@ -65,6 +65,7 @@ __device__ __forceinline__ void st2(double *__restrict__ p, int64_t off, bool v0
         f64x2 t;
         t.x = v.x;
         t.y = v.y;
+        // (temporal stores instead: wind series 6.0 -> 6.4 ms, pv series 4.2 -> 4.4 ms)
         if (v0) __builtin_nontemporal_store(t, (gf64x2 *)(p + off));
         return;
     }
