@@ -97,7 +97,8 @@ class Cutout:
             from .device import default_context
 
             ctx = default_context()
-        return gis.compute_indicatormatrix(self.coords["x"], self.coords["y"], shapes, ctx=ctx)
+        cache = self.__dict__.setdefault("_indicator_cache", {})
+        return gis.compute_indicatormatrix(self.coords["x"], self.coords["y"], shapes, ctx=ctx, cache=cache)
 
     def uniform_layout(self):
         from .labeled import LabeledArray

@@ -52,7 +52,7 @@ def _rings_of(shape):
     return [(a, False)]
 
 
-def compute_indicatormatrix(x, y, shapes, ctx=None):
+def compute_indicatormatrix(x, y, shapes, ctx=None, cache=None):
     """
     Indicator matrix ``I[i, j]`` = share of grid cell ``j`` (``j = iy * X + ix``, cell = box of
     centre +- half spacing) lying in ``shapes[i]``; returns ``scipy.sparse.csr_matrix (N, Y*X)``.
@@ -61,6 +61,8 @@ def compute_indicatormatrix(x, y, shapes, ctx=None):
     shapes : sequence (or pandas Series) of polygons, see ``_rings_of``.
     ctx : a ``device.Context`` -> the areas are evaluated on that GPU (``atl_indicator_polygons_device``: exact
           line integrals per candidate cell); ``None`` -> the host clipper (``atl_indicator_polygons``).
+    cache : optional dict; the matrix is stored under a digest of the grid and the ring coordinates and a copy is
+          handed back when the same shapes come again - repeated ``Cutout.pv(shapes=...)`` calls.
     """
     x = np.asarray(x, dtype=np.float64)
     y = np.asarray(y, dtype=np.float64)
@@ -81,6 +83,16 @@ def compute_indicatormatrix(x, y, shapes, ctx=None):
     ring_ptr = np.asarray(ring_ptr, dtype=np.int64)
     holes = np.asarray(holes, dtype=np.uint8)
     xy = np.concatenate(xy) if xy else np.zeros((0, 2))
+    key = None
+    if cache is not None:
+        import hashlib
+
+        hsh = hashlib.blake2b(digest_size=16)
+        for a in (np.asarray([X, Y, x[0], dx, y[0], dy, 1.0 if ctx is not None else 0.0]), shape_ptr, ring_ptr, holes, xy):
+            hsh.update(np.ascontiguousarray(a).tobytes())
+        key = hsh.digest()
+        if key in cache:
+            return cache[key].copy()  # the cached matrix stays private: callers may modify what they get
     lib = _lib.load()
     p_ip, p_ix, p_d = C.c_void_p(), C.c_void_p(), C.c_void_p()
     args = (len(shapes), shape_ptr.ctypes.data, len(holes), ring_ptr.ctypes.data,
@@ -99,7 +111,12 @@ def compute_indicatormatrix(x, y, shapes, ctx=None):
     finally:
         for p in (p_ip, p_ix, p_d):
             lib.atl_host_free(p)
-    return sp.csr_matrix((data, indices, indptr), shape=(N, Y * X))
+    M = sp.csr_matrix((data, indices, indptr), shape=(N, Y * X))
+    if cache is not None:
+        if len(cache) >= 8:  # a handful of shape sets per cutout
+            cache.pop(next(iter(cache)))
+        cache[key] = M.copy()
+    return M
 
 
 def random_star_polygons(n, bounds, seed=42, n_vertices=8):
