@@ -706,6 +706,17 @@ int atl_pv_probe_host(const atl_pv_params *p, int family, int64_t n, const doubl
             return int(ATL_OK);
         });
     }
+    // the fast family's influx / outflux head (pv_influx_fast in atl_kernels_pv.hip): Reindl split + albedo from outflux
+    if (family == 0 && infl && outf && !dir && !dif && !alb) {
+        ATL_REQUIRE(tmp && p->tracking == ATL_TRACK_NONE && p->trigon_model == ATL_TRIGON_SIMPLE &&
+                        p->clearsky_model == ATL_CLEARSKY_SIMPLE && p->panel_model == ATL_PANEL_HULD && p->irradiation == ATL_IRR_TOTAL,
+                    "atl_pv_probe_host: the influx / outflux head serves pv() with its defaults only");
+        for (int64_t i = 0; i < n; ++i) {
+            const PvOri o = PvConvT<false, true, false, kTailHuld>::make_ori(slope[i], pazim[i]);
+            h_out[i] = pv_cell_influx<kTailHuld>(infl[i], outf[i], toa[i], tmp[i], alt[i], az[i], o, k);
+        }
+        return ATL_OK;
+    }
     // the fast family: stored angles, direct / diffuse / albedo / temperature; tail and tracker from the options
     ATL_REQUIRE(family == 0 && dir && dif && alb && tmp, "atl_pv_probe_host: the fast family needs direct, diffuse, albedo, temperature");
     const int tail = p->trigon_model == ATL_TRIGON_OTHER         ? kTailHuldHayDavies

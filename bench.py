@@ -239,7 +239,7 @@ def main():
 
     def shapes_of(kind):
         polys = (gis.random_tessellation if kind == "tessellation" else gis.random_star_polygons)(cfg["shapes"], bounds, seed=42)
-        return polys, gis.compute_indicatormatrix(x, y, polys)
+        return polys, gis.compute_indicatormatrix(x, y, polys, ctx=ctx)  # on the device, as Cutout.indicatormatrix does
 
     polys, M = shapes_of(a.shape_kind)
     plan = ctx.plan(M, row_len=X)

@@ -87,14 +87,15 @@ def test_host_pv_math_against_oracle(seed):
     for case in range(120):
         shape = (int(rng.integers(3, 40)), int(rng.integers(1, 6)), int(rng.integers(1, 9)))
         ds = hostile_dataset(rng, shape)
-        flavour = str(rng.choice(["split", "split", "influx", "outflux"]))
-        if flavour == "influx":
+        flavour = str(rng.choice(["split", "split", "influx", "outflux", "sarah"]))
+        if flavour in ("outflux", "sarah"):  # "sarah": total influx and outflux (the fast family's influx head)
+            ds["outflux"] = (ds["influx_direct"] + ds["influx_diffuse"]) * ds["albedo"]
+            ds["outflux"][rng.random(shape) < 0.03] = rng.choice([np.nan, 0.0, -5.0, 1e4])
+            del ds["albedo"]
+        if flavour in ("influx", "sarah"):
             ds["influx"] = ds["influx_direct"] + ds["influx_diffuse"]
             ds["humidity"] = rng.random(shape)
             del ds["influx_direct"], ds["influx_diffuse"]
-        if flavour == "outflux":
-            ds["outflux"] = (ds["influx_direct"] + ds["influx_diffuse"]) * ds["albedo"]
-            del ds["albedo"]
         trk = TRACK[int(rng.integers(5))]
         tm, cs = str(rng.choice(["simple", "other"])), str(rng.choice(["simple", "enhanced"]))
         what = str(rng.choice(["pv", "pv", "irradiation", "thermal"]))
@@ -129,9 +130,11 @@ def test_host_pv_math_against_oracle(seed):
             (trk is None and not (tm == "other" and (what != "pv" or model == _lib.PANEL["bofinger"])) and
              not (what == "pv" and irr != "total")) or
             (trk is not None and what == "pv" and model == _lib.PANEL["huld"]))
+        if flavour == "sarah":  # pv() with its defaults on an influx / outflux dataset
+            fast_ok = what == "pv" and trk is None and tm == "simple" and cs == "simple" and model == _lib.PANEL["huld"]
         if fast_ok:
             got = probe(pp, 0, ds, ori["slope"], ori["azimuth"])
             e = allowance_error(got, ref)
-            assert e <= 1.0, ("fast", what, trk, tm, cs, pname, e)
+            assert e <= 1.0, ("fast", what, trk, tm, cs, pname, flavour, e)
             worst = max(worst, e)
     assert worst < 0.05  # far inside the allowance, like on the device
