@@ -388,11 +388,20 @@ int atl_kernel_times(atl_ctx *ctx, float *ms, int64_t cap, int64_t *n_out) {
 
 // ---- aggregation plan ------------------------------------------------------------------
 
-int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_len,
-                   const int64_t *h_indptr, const int32_t *h_indices, const double *h_data,
-                   atl_agg **out) {
-    ATL_REQUIRE(ctx && out, "atl_agg_create: bad argument");
-    *out = nullptr;
+// The plan as host arrays: everything atl_agg_create uploads (PlanDev's members by the same names).  Pure host code:
+// atl_agg_check_host() builds and verifies it without a device (CPU tests, the sanitizer build).
+struct PlanHost {
+    int64_t X = 0, Y = 0, ntx = 0, n_segs = 0, P = 0;
+    int w2_log2 = 0;
+    std::vector<int32_t> seg_ptr, shape_ptr, shape_prow;
+    std::vector<double> prow_w, prow_wm;
+    std::vector<uint8_t> poison;
+    std::vector<uint64_t> seg_mask;
+    std::vector<int64_t> seg_wm;
+};
+
+static int build_plan(int64_t n_rows, int64_t n_cells, int64_t row_len, const int64_t *h_indptr, const int32_t *h_indices,
+                      const double *h_data, PlanHost *plan) {
     ATL_REQUIRE(n_rows >= 0 && n_cells >= 0, "atl_agg_create: negative shape (%lld, %lld)",
                 (long long)n_rows, (long long)n_cells);
     ATL_REQUIRE(n_rows < 65536, "atl_agg_create: at most 65535 rows (shapes) are supported");
@@ -596,18 +605,49 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_le
             }
         }
     }
+    plan->X = L.X;
+    plan->Y = L.Y;
+    plan->ntx = ntx;
+    plan->n_segs = n_segs;
+    plan->P = P;
+    plan->w2_log2 = L.w2_log2;
+    plan->seg_ptr = std::move(seg_ptr);
+    plan->shape_ptr = std::move(shape_ptr);
+    plan->shape_prow = std::move(shape_prow);
+    plan->prow_w = std::move(prow_w);
+    plan->prow_wm = std::move(prow_wm);
+    plan->poison = std::move(poison);
+    plan->seg_mask = std::move(seg_mask);
+    plan->seg_wm = std::move(seg_wm);
+    return ATL_OK;
+}
 
+int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_len,
+                   const int64_t *h_indptr, const int32_t *h_indices, const double *h_data,
+                   atl_agg **out) {
+    ATL_REQUIRE(ctx && out, "atl_agg_create: bad argument");
+    *out = nullptr;
+    PlanHost ph;
+    {
+        const int brc = build_plan(n_rows, n_cells, row_len, h_indptr, h_indices, h_data, &ph);
+        if (brc) return brc;
+    }
+    const std::vector<int32_t> &seg_ptr = ph.seg_ptr, &shape_ptr = ph.shape_ptr, &shape_prow = ph.shape_prow;
+    const std::vector<double> &prow_w = ph.prow_w, &prow_wm = ph.prow_wm;
+    const std::vector<uint8_t> &poison = ph.poison;
+    const std::vector<uint64_t> &seg_mask = ph.seg_mask;
+    const std::vector<int64_t> &seg_wm = ph.seg_wm;
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     atl_agg *a = new atl_agg();
     a->ctx = ctx;
     a->dev.n_rows = n_rows;
     a->dev.n_cells = n_cells;
-    a->dev.X = L.X;
-    a->dev.Y = L.Y;
-    a->dev.ntx = int32_t(ntx);
-    a->dev.w2_log2 = L.w2_log2;
-    a->dev.n_segs = int32_t(n_segs);
-    a->dev.n_prows = int32_t(P);
+    a->dev.X = ph.X;
+    a->dev.Y = ph.Y;
+    a->dev.ntx = int32_t(ph.ntx);
+    a->dev.w2_log2 = ph.w2_log2;
+    a->dev.n_segs = int32_t(ph.n_segs);
+    a->dev.n_prows = int32_t(ph.P);
     int rc = ATL_OK;
     if ((rc = to_device(a, seg_ptr, &a->dev.seg_ptr)) ||
         (rc = to_device(a, prow_w, &a->dev.prow_w)) ||
@@ -620,6 +660,98 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_le
         return rc;
     }
     *out = a;
+    return ATL_OK;
+}
+
+
+int atl_agg_check_host(int64_t n_rows, int64_t n_cells, int64_t row_len, const int64_t *h_indptr, const int32_t *h_indices,
+                       const double *h_data, int64_t *n_partial_rows, int64_t *n_dense_tiles, int64_t *n_errors) {
+    ATL_REQUIRE(n_errors, "atl_agg_check_host: n_errors is NULL");
+    *n_errors = -1;
+    PlanHost ph;
+    const int rc = build_plan(n_rows, n_cells, row_len, h_indptr, h_indices, h_data, &ph);
+    if (rc) return rc;
+    int64_t err = 0, dense = 0;
+    const Layout L{ph.X, ph.Y, ph.w2_log2};
+    // (1) every CSR entry (duplicates summed, NaN weights poison their row) sits at ONE place of the partial rows of
+    //     its shape, and nothing else does: rebuild the dense (row x cell) matrix from the plan and from the CSR
+    std::vector<double> want(size_t(n_rows) * size_t(n_cells), std::numeric_limits<double>::quiet_NaN()), got = want;
+    std::vector<uint8_t> poison(size_t(n_rows), 0);
+    for (int64_t r = 0; r < n_rows; ++r)
+        for (int64_t k = h_indptr[r]; k < h_indptr[r + 1]; ++k) {
+            if (std::isnan(h_data[k])) {
+                poison[size_t(r)] = 1;
+                continue;
+            }
+            double &w = want[size_t(r) * size_t(n_cells) + size_t(h_indices[k])];
+            w = std::isnan(w) ? h_data[k] : w + h_data[k];
+        }
+    // which tile a partial row belongs to
+    std::vector<int32_t> prow_tile(size_t(ph.P), -1);
+    for (int64_t t = 0; t < ph.n_segs; ++t) {
+        if (ph.seg_ptr[size_t(t) + 1] < ph.seg_ptr[size_t(t)]) ++err;
+        for (int32_t q = ph.seg_ptr[size_t(t)]; q < ph.seg_ptr[size_t(t) + 1]; ++q) prow_tile[size_t(q)] = int32_t(t);
+    }
+    for (int64_t r = 0; r < n_rows; ++r) {
+        if (poison[size_t(r)] != ph.poison[size_t(r)]) ++err;
+        int32_t last = -1;
+        for (int32_t i = ph.shape_ptr[size_t(r)]; i < ph.shape_ptr[size_t(r) + 1]; ++i) {
+            const int32_t q = ph.shape_prow[size_t(i)];
+            if (q <= last || q < 0 || q >= ph.P) {  // ascending partial rows = ascending tiles: k_combine's fixed order
+                ++err;
+                continue;
+            }
+            last = q;
+            const int32_t t = prow_tile[size_t(q)];
+            for (int lane = 0; lane < kLanes; ++lane) {
+                const TileLane tl = tile_lane_cells(ph.X, ph.Y, int32_t(ph.ntx), ph.w2_log2, t, lane);
+                for (int j = 0; j < 2; ++j) {
+                    const double w = ph.prow_w[size_t(q) * kSegCells + size_t(2 * lane + j)];
+                    if (std::isnan(w)) continue;
+                    if (!(j == 0 ? tl.v0 : tl.v1)) {  // a weight on a lane that owns no cell
+                        ++err;
+                        continue;
+                    }
+                    double &g = got[size_t(r) * size_t(n_cells) + size_t(tl.c0 + j)];
+                    if (!std::isnan(g)) ++err;  // the same (row, cell) twice
+                    g = w;
+                }
+            }
+        }
+    }
+    for (size_t i = 0; i < want.size(); ++i) {
+        const bool a = std::isnan(want[i]), b = std::isnan(got[i]);
+        if (a != b || (!a && want[i] != got[i])) ++err;
+    }
+    // (2) the coverage mask = lanes with a weight in some partial row of the tile; (3) the MFMA operand image
+    for (int64_t t = 0; t < ph.n_segs; ++t) {
+        uint64_t m = 0;
+        const int32_t q0 = ph.seg_ptr[size_t(t)], n = ph.seg_ptr[size_t(t) + 1] - q0;
+        for (int32_t q = q0; q < q0 + n; ++q)
+            for (int c = 0; c < kSegCells; ++c)
+                if (!std::isnan(ph.prow_w[size_t(q) * kSegCells + size_t(c)])) m |= uint64_t(1) << (c >> 1);
+        if (m != ph.seg_mask[size_t(t)]) ++err;
+        if (ph.prow_wm.empty()) continue;
+        const int G = mfma_groups(n);
+        if ((G == 0) != (ph.seg_wm[size_t(t)] < 0)) {
+            ++err;
+            continue;
+        }
+        if (G == 0) continue;
+        ++dense;
+        for (int g = 0; g < G; ++g)
+            for (int k4 = 0; k4 < 32; ++k4)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int row = kMfmaRows * g + lane % 16, cell = 4 * k4 + lane / 16;
+                    const double img = ph.prow_wm[size_t(ph.seg_wm[size_t(t)]) + (size_t(g) * 32 + size_t(k4)) * 64 + size_t(lane)];
+                    const double w = row < n ? ph.prow_w[size_t(q0 + row) * kSegCells + size_t(cell)] : std::numeric_limits<double>::quiet_NaN();
+                    if (img != (std::isnan(w) ? 0.0 : w)) ++err;
+                }
+    }
+    (void)L;
+    if (n_partial_rows) *n_partial_rows = ph.P;
+    if (n_dense_tiles) *n_dense_tiles = dense;
+    *n_errors = err;
     return ATL_OK;
 }
 

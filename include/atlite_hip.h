@@ -122,6 +122,13 @@ int atl_agg_destroy(atl_agg *agg);
  * *n_errors = 0 means consistent. */
 int atl_agg_selfcheck(int64_t n_cells, int64_t row_len, int tile_w, int64_t *n_tiles, int64_t *n_owned,
                       int64_t *n_errors);
+/* Host-only: builds the plan of a CSR matrix exactly as atl_agg_create does (no device involved) and verifies it
+ * against the matrix - every entry at exactly one place of its shape's partial rows (duplicates summed, NaN weights
+ * poison the row), partial rows of a shape in ascending tile order, the per-tile coverage masks, the MFMA operand
+ * image of dense tiles.  *n_errors = 0 means consistent.  For the CPU test suite and the sanitizer build. */
+int atl_agg_check_host(int64_t n_rows, int64_t n_cells, int64_t row_len, const int64_t *h_indptr,
+                       const int32_t *h_indices, const double *h_data, int64_t *n_partial_rows,
+                       int64_t *n_dense_tiles, int64_t *n_errors);
 int atl_agg_info(const atl_agg *agg, int64_t *n_rows, int64_t *n_cells, int64_t *n_segments,
                  int64_t *n_partial_rows, int32_t *tile_w, int32_t *tile_h);
 

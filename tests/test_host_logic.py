@@ -8,6 +8,7 @@ from pathlib import Path
 import numpy as np
 import pandas as pd
 import pytest
+import scipy.sparse as sp
 
 from atlite_amd import Cutout, Dataset, LabeledArray, _lib, gis, resource
 from atlite_amd.convert import convert_and_aggregate
@@ -376,4 +377,70 @@ def test_xarray_bridge_with_the_stand_in(monkeypatch):
     np.testing.assert_array_equal(d.coords["y"], y)
     assert d.attrs == {"module": "era5"} and not d.chunked
     assert isinstance(convert._as_dataset(ds), Dataset)
+
+
+def _check_plan(M, row_len, env=None):
+    import ctypes as C
+
+    from atlite_amd import _lib
+
+    M = sp.csr_matrix(M)
+    indptr = np.ascontiguousarray(M.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(M.indices, dtype=np.int32)
+    data = np.ascontiguousarray(M.data, dtype=np.float64)
+    P, dense, err = C.c_int64(), C.c_int64(), C.c_int64()
+    _lib.check(_lib.load().atl_agg_check_host(M.shape[0], M.shape[1], row_len, indptr.ctypes.data,
+                                              indices.ctypes.data if len(indices) else None,
+                                              data.ctypes.data if len(data) else None, C.byref(P), C.byref(dense), C.byref(err)))
+    return P.value, dense.value, err.value
+
+
+@pytest.mark.parametrize("tile", [None, "16x8", "32x4", "64x2", "flat"])
+def test_plan_builder_is_consistent_with_its_matrix(monkeypatch, tile):
+    """The aggregation plan (partial rows per tile, their order per shape, coverage masks, the MFMA operand image of
+    dense tiles) rebuilt on the host and verified entry by entry against the CSR matrix it was built from - no device:
+    random sparse matrices with explicit zeros, negative and NaN weights, empty rows and columns, unsorted columns,
+    grids whose rows are not a multiple of a 128-byte line, dense stacks of rows, degenerate shapes."""
+    if tile:
+        monkeypatch.setenv("ATLITE_HIP_TILE", tile)
+    rng = np.random.default_rng(5)
+    for case in range(24):
+        Y, X = int(rng.integers(1, 40)), int(rng.integers(1, 70))
+        N = int(rng.integers(1, 60))
+        dens = float(rng.choice([0.01, 0.1, 0.5, 1.0]))
+        M = sp.random(N, Y * X, density=dens, random_state=int(rng.integers(1 << 30)), format="csr")
+        M.data[:] = rng.normal(size=M.nnz)
+        if M.nnz:
+            M.data[rng.random(M.nnz) < 0.05] = 0.0          # explicit zeros are structural entries
+            if case % 5 == 0:
+                M.data[int(rng.integers(M.nnz))] = np.nan    # poisons its row
+        row_len = X if case % 4 else 0                        # unknown grid: flat 128-cell tiles
+        P, dense, err = _check_plan(M, row_len)
+        assert err == 0, (case, Y, X, N, dens, tile)
+        assert P <= M.nnz or M.nnz == 0
+    # duplicates (COO-style input) are summed; columns need not be sorted
+    indptr = np.array([0, 4, 4, 6], dtype=np.int64)
+    indices = np.array([5, 2, 5, 0, 7, 7], dtype=np.int32)
+    data = np.array([1.0, 2.0, 3.0, 4.0, -1.0, 1.0])
+    import ctypes as C
+
+    from atlite_amd import _lib
+
+    P, dense, err = C.c_int64(), C.c_int64(), C.c_int64()
+    _lib.check(_lib.load().atl_agg_check_host(3, 12, 4, indptr.ctypes.data, indices.ctypes.data, data.ctypes.data,
+                                              C.byref(P), C.byref(dense), C.byref(err)))
+    assert err.value == 0 and P.value >= 2
+    # dense stacks: every tile carries 16 / 17 / 40 rows -> MFMA operand images
+    monkeypatch.setenv("ATLITE_HIP_FORCE_MFMA", "1")
+    for R in (16, 17, 28, 40):
+        W = rng.normal(size=(R, 11 * 27))
+        W[rng.random(W.shape) < 0.3] = 0.0
+        P, dense, err = _check_plan(sp.csr_matrix(W), 27)
+        assert err == 0 and dense > 0, (R, dense, err)
+    # bad input is refused, not crashed on
+    nerr = C.c_int64()
+    with pytest.raises(ValueError):
+        _lib.check(_lib.load().atl_agg_check_host(1, 4, 0, np.array([0, 1], dtype=np.int64).ctypes.data,
+                                                  np.array([9], dtype=np.int32).ctypes.data, np.array([1.0]).ctypes.data,
+                                                  None, None, C.byref(nerr)))
 
