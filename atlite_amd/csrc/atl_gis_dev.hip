@@ -26,7 +26,7 @@ struct Edge {
 };
 
 // integral of (clamp(y, 0, h) - 0) dx along the edge restricted to 0 <= x <= w, coordinates relative to the cell
-__device__ __forceinline__ double edge_term(double x1, double y1, double x2, double y2, double w, double h) {
+__host__ __device__ __forceinline__ double edge_term(double x1, double y1, double x2, double y2, double w, double h) {
     const double dx = x2 - x1;
     if (dx == 0.0) return 0.0;
     // parameter range of the edge inside the column
@@ -96,13 +96,13 @@ double ring_area(const double *xy, int64_t n) {
 
 }  // namespace
 
-extern "C" {
-
-int atl_indicator_polygons_device(atl_ctx *ctx, int64_t n_shapes, const int64_t *h_shape_ring_ptr, int64_t n_rings,
-                                  const int64_t *h_ring_ptr, const uint8_t *h_ring_is_hole, const double *h_xy,
-                                  int64_t X, int64_t Y, double x0, double dx, double y0, double dy,
-                                  int64_t **out_indptr, int32_t **out_indices, double **out_data) {
-    ATL_REQUIRE(ctx && out_indptr && out_indices && out_data, "atl_indicator_polygons_device: NULL argument");
+// ctx == nullptr: the candidate cells are evaluated by a host loop over the same edge_term() (same source, host
+// build) - lets the CPU test suite check the bucketing, the integrals and the compaction against the clipper
+static int indicator_integral(atl_ctx *ctx, int64_t n_shapes, const int64_t *h_shape_ring_ptr, int64_t n_rings,
+                              const int64_t *h_ring_ptr, const uint8_t *h_ring_is_hole, const double *h_xy,
+                              int64_t X, int64_t Y, double x0, double dx, double y0, double dy,
+                              int64_t **out_indptr, int32_t **out_indices, double **out_data) {
+    ATL_REQUIRE(out_indptr && out_indices && out_data, "atl_indicator_polygons_device: NULL argument");
     *out_indptr = nullptr;
     *out_indices = nullptr;
     *out_data = nullptr;
@@ -217,7 +217,18 @@ int atl_indicator_polygons_device(atl_ctx *ctx, int64_t n_shapes, const int64_t 
     }
     // ---- device: one thread per candidate cell ------------------------------------------------------------------
     std::vector<double> cand(size_t(n_cand), 0.0);
-    if (n_cand > 0) {
+    if (n_cand > 0 && !ctx) {
+        for (int64_t b = 0; b < n_buckets; ++b)
+            for (int32_t r = 0; r < bucket_nrows[size_t(b)]; ++r) {
+                const double xa = xlo + double(bucket_col[size_t(b)]) * dx, ya = ylo + double(bucket_row0[size_t(b)] + r) * dy;
+                double a = 0.0;
+                for (int64_t e = bucket_ptr[size_t(b)]; e < bucket_ptr[size_t(b) + 1]; ++e) {
+                    const Edge &g = bedges[size_t(e)];
+                    a -= edge_term(g.x1 - xa, g.y1 - ya, g.x2 - xa, g.y2 - ya, dx, dy);
+                }
+                cand[size_t(bucket_out[size_t(b)] + r)] = a;
+            }
+    } else if (n_cand > 0) {
         ATL_HIP_TRY(hipSetDevice(ctx->device));
         Edge *d_edges = nullptr;
         int64_t *d_ptr = nullptr, *d_out_off = nullptr;
@@ -294,6 +305,25 @@ int atl_indicator_polygons_device(atl_ctx *ctx, int64_t n_shapes, const int64_t 
     *out_indices = pj;
     *out_data = pd;
     return ATL_OK;
+}
+
+extern "C" {
+
+int atl_indicator_polygons_device(atl_ctx *ctx, int64_t n_shapes, const int64_t *h_shape_ring_ptr, int64_t n_rings,
+                                  const int64_t *h_ring_ptr, const uint8_t *h_ring_is_hole, const double *h_xy,
+                                  int64_t X, int64_t Y, double x0, double dx, double y0, double dy,
+                                  int64_t **out_indptr, int32_t **out_indices, double **out_data) {
+    ATL_REQUIRE(ctx, "atl_indicator_polygons_device: ctx is NULL");
+    return indicator_integral(ctx, n_shapes, h_shape_ring_ptr, n_rings, h_ring_ptr, h_ring_is_hole, h_xy, X, Y, x0, dx, y0, dy,
+                              out_indptr, out_indices, out_data);
+}
+
+int atl_indicator_polygons_integral_host(int64_t n_shapes, const int64_t *h_shape_ring_ptr, int64_t n_rings,
+                                         const int64_t *h_ring_ptr, const uint8_t *h_ring_is_hole, const double *h_xy,
+                                         int64_t X, int64_t Y, double x0, double dx, double y0, double dy,
+                                         int64_t **out_indptr, int32_t **out_indices, double **out_data) {
+    return indicator_integral(nullptr, n_shapes, h_shape_ring_ptr, n_rings, h_ring_ptr, h_ring_is_hole, h_xy, X, Y, x0, dx, y0, dy,
+                              out_indptr, out_indices, out_data);
 }
 
 }  // extern "C"

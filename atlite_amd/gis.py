@@ -98,7 +98,9 @@ def compute_indicatormatrix(x, y, shapes, ctx=None, cache=None):
     args = (len(shapes), shape_ptr.ctypes.data, len(holes), ring_ptr.ctypes.data,
             holes.ctypes.data if len(holes) else None, xy.ctypes.data if len(xy) else None,
             X, Y, float(x[0]), dx, float(y[0]), dy, C.byref(p_ip), C.byref(p_ix), C.byref(p_d))
-    if ctx is not None:
+    if ctx == "integral-host":  # tests: the device algorithm with its candidate cells evaluated on the host
+        _lib.check(lib.atl_indicator_polygons_integral_host(*args))
+    elif ctx is not None:
         _lib.check(lib.atl_indicator_polygons_device(ctx.handle, *args))
     else:
         _lib.check(lib.atl_indicator_polygons(*args))

@@ -322,6 +322,13 @@ int atl_host_free(void *p);
  * line integrals over the ring edges that overlap the cell's grid column; the host only buckets the edges by
  * column and compacts the result): SURVEY 8 f-2, second half.  Entries below 1e-12 of a cell are dropped
  * (the residue of cells the shape does not reach); otherwise equal to atl_indicator_polygons to ~1e-13. */
+/* atl_indicator_polygons_device's algorithm with the candidate cells evaluated on the HOST (same source: the edge
+ * bucketing, the per-edge integrals and the compaction) - no device; for the CPU test suite. */
+int atl_indicator_polygons_integral_host(int64_t n_shapes, const int64_t *h_shape_ring_ptr, int64_t n_rings,
+                                         const int64_t *h_ring_ptr, const uint8_t *h_ring_is_hole,
+                                         const double *h_xy, int64_t X, int64_t Y, double x0, double dx,
+                                         double y0, double dy, int64_t **out_indptr,
+                                         int32_t **out_indices, double **out_data);
 int atl_indicator_polygons_device(atl_ctx *ctx, int64_t n_shapes, const int64_t *h_shape_ring_ptr, int64_t n_rings,
                                   const int64_t *h_ring_ptr, const uint8_t *h_ring_is_hole,
                                   const double *h_xy, int64_t X, int64_t Y, double x0, double dx, double y0,

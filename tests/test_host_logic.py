@@ -444,3 +444,30 @@ def test_plan_builder_is_consistent_with_its_matrix(monkeypatch, tile):
                                                   np.array([9], dtype=np.int32).ctypes.data, np.array([1.0]).ctypes.data,
                                                   None, None, C.byref(nerr)))
 
+
+def test_indicator_matrix_line_integrals_against_the_clipper():
+    """The device indicator-matrix algorithm (edges bucketed by grid column, area(shape n cell) as a line integral of the
+    clamped edge heights, compaction) with its candidate cells evaluated on the HOST - the same source as the kernel -
+    against the polygon clipper: two independent algorithms for the same contract (atlite/gis.py:104-145)."""
+    x, y = np.arange(10.0), 10.0 + 2.0 * np.arange(5.0)
+    rect = np.array([[0.25, 9.5], [3.5, 9.5], [3.5, 12.0], [0.25, 12.0]])
+    hole = np.array([[1.0, 10.0], [2.0, 10.0], [2.0, 11.0], [1.0, 11.0]])
+    shapes = [rect, rect[::-1], dict(exterior=rect, holes=[hole]), [rect, rect + np.array([5.0, 0.0])],
+              rect + np.array([8.0, 6.0]), rect + np.array([100.0, 100.0]),
+              np.array([[1.5, 11], [2.5, 11], [2.5, 13], [1.5, 13]])]
+    A = gis.compute_indicatormatrix(x, y, shapes, ctx="integral-host")
+    B = gis.compute_indicatormatrix(x, y, shapes)
+    assert (A != 0).toarray().tolist() == (B != 0).toarray().tolist()
+    np.testing.assert_allclose(A.toarray(), B.toarray(), rtol=0, atol=1e-13)
+    X = Y = 90
+    xx, yy = -25 + (70 / X) * np.arange(X), 30 + (42 / Y) * np.arange(Y)
+    polys = gis.random_star_polygons(30, (-15, 35, 35, 66), seed=3)
+    th = np.linspace(0, 2 * np.pi, 3000, endpoint=False)
+    rad = 9.0 + 0.8 * np.sin(17 * th) + 0.3 * np.cos(61 * th)
+    polys.append(np.stack([5.0 + 1.6 * rad * np.cos(th), 50.0 + rad * np.sin(th)], axis=1))  # ~100 edges per column
+    polys += gis.random_tessellation(20, (xx[0] - 35 / X, yy[0] - 21 / Y, xx[-1] + 35 / X, yy[-1] + 21 / Y), seed=1)
+    A = gis.compute_indicatormatrix(xx, yy, polys, ctx="integral-host")
+    B = gis.compute_indicatormatrix(xx, yy, polys)
+    np.testing.assert_allclose(A.toarray(), B.toarray(), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(np.asarray(A[31:].sum(0)).ravel(), 1.0, rtol=0, atol=1e-11)  # the tessellation covers every cell once
+
