@@ -147,14 +147,10 @@ int atl_pv_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p
     ATL_REQUIRE(ctx && in && p, "atl_pv_convert: ctx/inputs/params is NULL");
     if (pv_needs_general(in, p)) return pvx_convert(ctx, in, p, T, S, time_agg, d_out);
     bool vec;
-    return pv_dispatch(in, p, false, [&](auto c) {  // night skip: fused (aggregating) kernel only
-        if constexpr (decltype(c)::kNightPipe) {  // never dispatched here (allow_skip = false): no per-cell kernels for it
-            return int(ATL_E_INVALID);
-        } else {
-            int rc = make_pv(in, p, T, S, &c, &vec);
-            if (rc) return rc;
-            return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
-        }
+    return pv_dispatch(in, p, true, [&](auto c) {  // night skip: k_cells_night for the SKIP converters
+        int rc = make_pv(in, p, T, S, &c, &vec);
+        if (rc) return rc;
+        return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
     });
 }
 

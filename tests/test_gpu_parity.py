@@ -349,6 +349,10 @@ def test_pv_influx_outflux_dataset_fast_family(ctx):
     b = ctx.pv(dev, PV_PARAMS, T, S, plan=plan, options=dict(clearsky_model="simple", night_skip=True)).numpy()
     np.testing.assert_array_equal(a, b)
     np.testing.assert_allclose(a, refa, rtol=1e-10, atol=1e-12 * np.nanmax(np.abs(refa[np.isfinite(refa)])), equal_nan=True)
+    for kw in (dict(), dict(time_agg="mean")):  # per-cell kernels with the early-out
+        a = ctx.pv(dev, PV_PARAMS, T, S, options=dict(clearsky_model="simple", night_skip=False), **kw).numpy()
+        b = ctx.pv(dev, PV_PARAMS, T, S, options=dict(clearsky_model="simple", night_skip=True), **kw).numpy()
+        np.testing.assert_array_equal(a, b)
     _, ygrid = H.grid(Y, X)
     lo = orc.orientation_latitude_optimal(np.radians(ygrid))
     pc = dict(H.CSI, slope=np.repeat(lo["slope"], X), azimuth=np.repeat(lo["azimuth"], X))
@@ -427,6 +431,10 @@ def test_pv_night_skip_in_kernel_solar_position(ctx, T, Y, X, N):
         for kw in (dict(), dict(time_agg="mean")):
             a = ctx.pv(five, params, T, Y * X, plan=plan, solar_tables=tables, options=dict(night_skip=False), **kw).numpy()
             b = ctx.pv(five, params, T, Y * X, plan=plan, solar_tables=tables, options=dict(night_skip=True), **kw).numpy()
+            np.testing.assert_array_equal(a, b)
+        for kw in (dict(), dict(time_agg="sum")):  # per-cell kernels (series, capacity-factor map)
+            a = ctx.pv(five, params, T, Y * X, solar_tables=tables, options=dict(night_skip=False), **kw).numpy()
+            b = ctx.pv(five, params, T, Y * X, solar_tables=tables, options=dict(night_skip=True), **kw).numpy()
             np.testing.assert_array_equal(a, b)
     alt, az = orc.solar_position(time, x, y, "0h")
     full = dict(ds, solar_altitude=alt.reshape(T, -1), solar_azimuth=az.reshape(T, -1))

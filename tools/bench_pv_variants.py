@@ -69,15 +69,18 @@ for name, nbytes, fn in (
     ("general kernel: bofinger + Hay-Davies", 56, lambda: ctx.pv(inputs, kanena, T, S, plan=plan, options=dict(trigon_model="other"))),
     ("general kernel: irradiation(tracking='dual')", 48, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none", tracking="dual"))),
     ("general kernel: influx-only dataset (Reindl split, albedo from outflux)", 48, lambda: ctx.pv(influx_ds, scal, T, S, plan=plan)),
-    ("per-cell series out (no matrix)", 64, lambda: ctx.pv(inputs, scal, T, S)),
-    ("per-cell time-mean (capacity factor map)", 56, lambda: ctx.pv(inputs, scal, T, S, time_agg="mean")),
+    ("per-cell series out (no matrix), no early-out", 64, lambda: ctx.pv(inputs, scal, T, S, options=dict(night_skip=False))),
+    ("per-cell series out (no matrix) + night early-out", 64, lambda: ctx.pv(inputs, scal, T, S, options=dict(night_skip=True))),
+    ("per-cell time-mean (capacity factor map), no early-out", 56, lambda: ctx.pv(inputs, scal, T, S, time_agg="mean", options=dict(night_skip=False))),
+    ("per-cell time-mean (capacity factor map) + night early-out", 56, lambda: ctx.pv(inputs, scal, T, S, time_agg="mean", options=dict(night_skip=True))),
+    ("per-cell time-mean, in-kernel solar position + early-out", 40, lambda: ctx.pv(five, scal, T, S, time_agg="mean", solar_tables=tables, options=dict(night_skip=True))),
 ):
     ms, out = timed(fn)
     gbs = nbytes * T * S / (ms * 1e-3) / 1e9
     extra = ""
     if ref is None:
         ref = out.numpy()
-    elif "in-kernel" in name:
+    elif "in-kernel" in name and "per-cell" not in name:
         o = out.numpy()
         extra = f"  max rel diff vs getter {np.max(np.abs(o - ref) / np.maximum(np.abs(ref), 1e-12 * ref.max())):.1e}"
     print(f"{name:52s} {ms:8.3f} ms  {gbs:6.0f} GB/s ({nbytes} B/cell)  {T * S / (ms * 1e-3):.3e} cell-steps/s{extra}", flush=True)
