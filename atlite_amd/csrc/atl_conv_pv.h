@@ -16,7 +16,15 @@ struct PvConst {
 };
 
 // what follows the tilted irradiation in the fast kernel family
-constexpr int kTailHuld = 0, kTailThermal = 1, kTailIrradiation = 2, kTailHuldHayDavies = 3, kTailBofinger = 4;
+// (panel model x transposition model): the Huld panel, the solar thermal collector, the plain irradiation or the bofinger
+// panel, each after the simple or the Hay-Davies ("other") trigon model
+constexpr int kTailHuld = 0, kTailThermal = 1, kTailIrradiation = 2, kTailHuldHayDavies = 3, kTailBofinger = 4,
+              kTailThermalHayDavies = 5, kTailIrradiationHayDavies = 6, kTailBofingerHayDavies = 7;
+constexpr bool tail_hay_davies(int t) { return t == kTailHuldHayDavies || t >= kTailThermalHayDavies; }
+constexpr int tail_panel(int t) {  // the simple-model tail with the same panel
+    return t == kTailHuldHayDavies ? kTailHuld : t == kTailThermalHayDavies ? kTailThermal : t == kTailIrradiationHayDavies ? kTailIrradiation
+           : t == kTailBofingerHayDavies ? kTailBofinger : t;
+}
 
 // per-cell orientation factors: sin/cos(slope), (1 +- cos(slope))/2, panel azimuth
 struct PvOri {
@@ -137,7 +145,8 @@ ATL_HD __forceinline__ double pv_tail_core(double direct, double diffuse, double
     const double direct_t = kk * direct;
     double G;
     [[maybe_unused]] double diffuse_t = 0.0, ground_t = 0.0;
-    if constexpr (TAIL == kTailHuldHayDavies) {  // trigon_model="other", irradiation.py:76-145, 227-245
+    constexpr int PANEL = tail_panel(TAIL);
+    if constexpr (tail_hay_davies(TAIL)) {  // trigon_model="other", irradiation.py:76-145, 227-245
         const double f = fill0(sqrt(guarded_div(direct, influx)));
         const double A = guarded_div(direct, toa);
         diffuse_t = ((1.0 - A) * o.hp * (1.0 + f * o.sh3) + A * kk) * diffuse;
@@ -149,17 +158,17 @@ ATL_HD __forceinline__ double pv_tail_core(double direct, double diffuse, double
         ground_t = alb * influx * o.hm;
         G = fill0(direct_t) + fill0(diffuse_t) + fill0(ground_t);
     }
-    if constexpr (TAIL == kTailIrradiation) {  // convert_irradiation, convert.py:748-767
+    if constexpr (PANEL == kTailIrradiation) {  // convert_irradiation, convert.py:748-767
         return k.irr == ATL_IRR_TOTAL ? G : k.irr == ATL_IRR_DIRECT ? direct_t : k.irr == ATL_IRR_DIFFUSE ? diffuse_t : ground_t;
     }
-    if constexpr (TAIL == kTailBofinger) {  // SolarPanelModel, bofinger branch: solar_panel_model.py:47-74
+    if constexpr (PANEL == kTailBofinger) {  // SolarPanelModel, bofinger branch: solar_panel_model.py:47-74
         const double eta_ref = k.bA + k.bB * G + k.bC * lean_log(G != 0.0 ? G : __builtin_nan(""));
         const double eta = fill0(guarded_div(eta_ref * (1.0 + k.bD * (k.bfrac * G + (tmp - k.bTstd))),
                                              1.0 + k.bDf_ta * eta_ref * G));
         const double power = G * eta * k.bscale;
         return (G >= k.bthr) ? power : 0.0;
     }
-    if constexpr (TAIL == kTailThermal) {  // convert_solar_thermal, convert.py:565-574
+    if constexpr (PANEL == kTailThermal) {  // convert_solar_thermal, convert.py:565-574
         const double eta = k.st_c0 - k.st_c1 * fill0(guarded_div(k.st_t_store - tmp, G != 0.0 ? G : __builtin_nan("")));
         const double output = G * eta;
         return output > 0.0 ? output : 0.0;
@@ -235,7 +244,7 @@ ATL_HD __forceinline__ double pv_cell(double dir, double dif, double toa, double
     double sa, ca;
     lean_sincos(alt, &sa, &ca);
     if constexpr (TRACK != ATL_TRACK_NONE) {  // tracker: panel_geom's closed forms
-        constexpr bool HD = TAIL == kTailHuldHayDavies;
+        constexpr bool HD = tail_hay_davies(TAIL);
         const PanelGeom g = panel_geom<TRACK, HD>(sa, ca, az, o.slope, o.saz);
         // simple model: a dual-axis tracker's surface slope is the sun's zenith angle (irradiation.py:216-219);
         // Hay-Davies keeps the orientation's own slope (:227-245)
@@ -410,7 +419,7 @@ struct PvConvT {
         r.saz = azimuth;
         r.slope = slope;
         r.sh3 = 0.0;
-        if constexpr (TAIL == kTailHuldHayDavies) {
+        if constexpr (tail_hay_davies(TAIL)) {
             const double sh = lean_sin(slope / 2.0);
             r.sh3 = sh * sh * sh;
         }
@@ -654,6 +663,8 @@ inline PvConst pv_const_of(const atl_pv_params *p) {
     }
     return k;
 }
+
+
 inline PvxOpt pvx_opt_of(const atl_pv_params *p, bool has_influx, bool has_albedo) {
     return PvxOpt{p->tracking, p->trigon_model, p->clearsky_model, p->irradiation, p->panel_model,
                   has_influx ? 1 : 0, has_albedo ? 1 : 0,

@@ -683,6 +683,14 @@ int32_t pick_chunk_slots(const atl_ctx *ctx, int64_t n_slots, int64_t n_segs) {
     return int32_t(chunk);
 }
 
+// slots per block of the per-cell kernels that walk a slot range: as long as possible while the grid still fills the chip
+// (16 blocks per CU), whole batches
+inline int64_t slot_chunk_len(const atl_ctx *ctx, int64_t n_slots, unsigned gx) {
+    const int64_t n_chunks = std::max<int64_t>(1, std::min<int64_t>((n_slots + 15) / 16, (int64_t(ctx->n_cu) * 16 + gx - 1) / gx));
+    const int64_t len = std::max<int64_t>(1, (n_slots + n_chunks - 1) / n_chunks);
+    return (len + kBatch - 1) / kBatch * kBatch;
+}
+
 template <class Conv>
 int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_t n_slots, int64_t S,
               int time_agg, double *d_out, const char *what) {
@@ -695,13 +703,15 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
     if (time_agg == ATL_TIME_NONE) {
         const dim3 grid(gx, unsigned((n_slots + kSeriesSlots - 1) / kSeriesSlots));
         KernelBracket kb(ctx);
-        if constexpr (conv_night_pipe<Conv>::value) {
+        if constexpr (conv_night_pipe<Conv>::value) {  // long slot ranges: the keys are fetched one batch ahead
+            const int64_t len = slot_chunk_len(ctx, n_slots, gx);
+            const dim3 gridn(gx, unsigned((n_slots + len - 1) / len));
             if (vec)
-                hipLaunchKernelGGL((k_cells_night<Conv, true, true>), grid, dim3(256), lds_bytes, ctx->stream, conv, n_slots, S,
-                                   int64_t(kSeriesSlots), d_out, static_cast<double *>(nullptr));
+                hipLaunchKernelGGL((k_cells_night<Conv, true, true>), gridn, dim3(256), lds_bytes, ctx->stream, conv, n_slots, S,
+                                   len, d_out, static_cast<double *>(nullptr));
             else
-                hipLaunchKernelGGL((k_cells_night<Conv, false, true>), grid, dim3(256), lds_bytes, ctx->stream, conv, n_slots, S,
-                                   int64_t(kSeriesSlots), d_out, static_cast<double *>(nullptr));
+                hipLaunchKernelGGL((k_cells_night<Conv, false, true>), gridn, dim3(256), lds_bytes, ctx->stream, conv, n_slots, S,
+                                   len, d_out, static_cast<double *>(nullptr));
             return check_launch(what);
         }
         if (vec)
@@ -713,10 +723,8 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
         return check_launch(what);
     }
     // time-reduced: split the slot axis so that the grid fills the chip
-    int64_t n_chunks = std::max<int64_t>(1, std::min<int64_t>((n_slots + 15) / 16,
-                                                               (int64_t(ctx->n_cu) * 16 + gx - 1) / gx));
-    const int64_t chunk_len = std::max<int64_t>(1, (n_slots + n_chunks - 1) / n_chunks);
-    n_chunks = std::max<int64_t>(1, (n_slots + chunk_len - 1) / chunk_len);
+    const int64_t chunk_len = slot_chunk_len(ctx, n_slots, gx);
+    const int64_t n_chunks = std::max<int64_t>(1, (n_slots + chunk_len - 1) / chunk_len);
     void *scr = nullptr;
     int rc = scratch_reserve(ctx, size_t(2 * n_chunks * S) * sizeof(double), &scr);
     if (rc) return rc;

@@ -851,12 +851,12 @@ int atl_pv_probe_host(const atl_pv_params *p, int family, int64_t n, const doubl
     }
     // the fast family: stored angles, direct / diffuse / albedo / temperature; tail and tracker from the options
     ATL_REQUIRE(family == 0 && dir && dif && alb && tmp, "atl_pv_probe_host: the fast family needs direct, diffuse, albedo, temperature");
-    const int tail = p->trigon_model == ATL_TRIGON_OTHER         ? kTailHuldHayDavies
-                     : p->panel_model == ATL_PANEL_SOLAR_THERMAL ? kTailThermal
-                     : p->panel_model == ATL_PANEL_NONE          ? kTailIrradiation
-                     : p->panel_model == ATL_PANEL_BOFINGER      ? kTailBofinger
-                                                                 : kTailHuld;
-    ATL_REQUIRE(p->tracking == ATL_TRACK_NONE || ((tail == kTailHuld || tail == kTailHuldHayDavies) && p->panel_model == ATL_PANEL_HULD),
+    const bool hd = p->trigon_model == ATL_TRIGON_OTHER;
+    const int tail = p->panel_model == ATL_PANEL_SOLAR_THERMAL ? (hd ? kTailThermalHayDavies : kTailThermal)
+                     : p->panel_model == ATL_PANEL_NONE        ? (hd ? kTailIrradiationHayDavies : kTailIrradiation)
+                     : p->panel_model == ATL_PANEL_BOFINGER    ? (hd ? kTailBofingerHayDavies : kTailBofinger)
+                                                               : (hd ? kTailHuldHayDavies : kTailHuld);
+    ATL_REQUIRE(p->tracking == ATL_TRACK_NONE || p->panel_model == ATL_PANEL_HULD,
                 "atl_pv_probe_host: the fast family pairs trackers with the Huld panel");
     auto run = [&](auto tl, auto tr) {
         constexpr int TL = decltype(tl)::value, TR = decltype(tr)::value;
@@ -877,6 +877,9 @@ int atl_pv_probe_host(const atl_pv_params *p, int family, int64_t n, const doubl
         case kTailThermal: return run(std::integral_constant<int, kTailThermal>(), None());
         case kTailIrradiation: return run(std::integral_constant<int, kTailIrradiation>(), None());
         case kTailBofinger: return run(std::integral_constant<int, kTailBofinger>(), None());
+        case kTailThermalHayDavies: return run(std::integral_constant<int, kTailThermalHayDavies>(), None());
+        case kTailIrradiationHayDavies: return run(std::integral_constant<int, kTailIrradiationHayDavies>(), None());
+        case kTailBofingerHayDavies: return run(std::integral_constant<int, kTailBofingerHayDavies>(), None());
         default: return run(std::integral_constant<int, kTailHuld>(), None());
     }
 }

@@ -66,7 +66,11 @@ for name, nbytes, fn in (
     ("tracking='horizontal' + Hay-Davies - fast family (r02)", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="horizontal", trigon_model="other"))),
     ("tracking='tilted_horizontal', per-cell orientation - fast family (r02)", 56, lambda: ctx.pv(inputs, percell, T, S, plan=plan, options=dict(tracking="tilted_horizontal"))),
     ("pv(panel='KANENA') bofinger - fast family (r02)", 56, lambda: ctx.pv(inputs, kanena, T, S, plan=plan, options=dict(night_skip=False))),
-    ("general kernel: bofinger + Hay-Davies", 56, lambda: ctx.pv(inputs, kanena, T, S, plan=plan, options=dict(trigon_model="other"))),
+    ("bofinger + Hay-Davies - fast family (r02; was the general kernel)", 56, lambda: ctx.pv(inputs, kanena, T, S, plan=plan, options=dict(trigon_model="other"))),
+    ("irradiation(trigon_model='other') - fast family (r02)", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none", trigon_model="other"))),
+    ("solar_thermal(trigon_model='other') - fast family (r02)", 56,
+     lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="solar_thermal", c0=0.8, c1=3.0, t_store_K=353.15, trigon_model="other"))),
+    ("general kernel: bofinger + tracking='horizontal'", 56, lambda: ctx.pv(inputs, kanena, T, S, plan=plan, options=dict(tracking="horizontal"))),
     ("general kernel: irradiation(tracking='dual')", 48, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none", tracking="dual"))),
     ("general kernel: influx-only dataset (Reindl split, albedo from outflux)", 48, lambda: ctx.pv(influx_ds, scal, T, S, plan=plan)),
     ("per-cell series out (no matrix), no early-out", 64, lambda: ctx.pv(inputs, scal, T, S, options=dict(night_skip=False))),
