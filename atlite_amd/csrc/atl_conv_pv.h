@@ -388,8 +388,9 @@ template <bool SP, bool PC = false, bool SKIP = false, int TAIL = kTailHuld, int
 struct PvConvT {
     static_assert(HEAD == 0 || (!SP && TAIL == kTailHuld && TRACK == ATL_TRACK_NONE), "influx head: stored angles, Huld panel, no tracker");
     static_assert(TAIL == kTailHuld || (!SP && !SKIP), "the non-panel tails are built for stored angles, no skip");
-    static_assert(TRACK == ATL_TRACK_NONE || (!SP && !SKIP && (TAIL == kTailHuld || TAIL == kTailHuldHayDavies)),
-                  "trackers: stored angles, Huld panel (either trigon model)");
+    static_assert(TRACK == ATL_TRACK_NONE || (!SP && !SKIP), "trackers: stored angles, no skip");
+    // the MFMA-carrying instantiation (dense matrices) only for pv() with its defaults: rare options x rare matrices
+    static constexpr bool kDenseOk = TAIL == kTailHuld && TRACK == ATL_TRACK_NONE;
     atl_pv_inputs in;
     int64_t S;
     PvConst k;
@@ -464,7 +465,13 @@ struct PvConvT {
 #ifndef ATL_SP_NIGHT_WAVES
 #define ATL_SP_NIGHT_WAVES 3
 #endif
-    static constexpr int kMinWaves = (kNightPipe && !PC && HEAD == 0) ? (SP ? ATL_SP_NIGHT_WAVES : 4) : 3;
+#ifndef ATL_PV_BOFTRK_WAVES
+#define ATL_PV_BOFTRK_WAVES 3  // bofinger panel behind a tracker, the family's largest converters: 3 waves with 16-80 B of
+                               // scratch beat 2 waves without (C2: 3.23 vs 3.50 ms horizontal, 3.62 vs 4.00 ms tilted + Hay-Davies + per-cell)
+#endif
+    static constexpr int kMinWaves = (kNightPipe && !PC && HEAD == 0)                            ? (SP ? ATL_SP_NIGHT_WAVES : 4)
+                                     : (tail_panel(TAIL) == kTailBofinger && TRACK != ATL_TRACK_NONE) ? ATL_PV_BOFTRK_WAVES
+                                                                                                    : 3;
     // stored angles: key = the slot's solar altitude.  In-kernel solar position: key = cos(hour angle) of the
     // lane's two grid columns (a (T, X) table), from which sin(altitude) follows with the slot's declination and
     // the cells' latitude - night is known before a single byte of the cubes is read.

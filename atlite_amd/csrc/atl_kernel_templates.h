@@ -157,10 +157,16 @@ struct conv_night_pipe<Conv, std::void_t<decltype(Conv::kNightPipe)>> : std::int
 // compute_keyed).  Used for pv capacity-factor maps and per-cell series: 40 % fewer bytes on a year of data.
 template <class Conv, bool VEC, bool SERIES>
 __global__ __launch_bounds__(256, min_waves<Conv>()) void k_cells_night(Conv conv, int64_t n_slots, int64_t S, int64_t chunk_len,
-                                                     double *__restrict__ out_a, double *__restrict__ out_b) {
+                                                                        double *__restrict__ out_a, double *__restrict__ out_b,
+                                                                        int32_t conv_lds_doubles) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     conv.block_init(lds);
     __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    // the wave's key rows: each lane parks the keys of a batch here and reads its own back inside the (rolled) slot
+    // loop - eight unrolled conversions are 55 KB of code, the whole instruction cache
+    double *vl = lds + conv_lds_doubles + wave * (kBatch * kSegCells) + 2 * lane;
     const int64_t c0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * 2;
     const bool v0 = c0 < S, v1 = c0 + 1 < S;
     const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);
@@ -179,21 +185,31 @@ __global__ __launch_bounds__(256, min_waves<Conv>()) void k_cells_night(Conv con
         for (int i = 0; i < kBatch; ++i) {
             const bool d = (sb + i < s1) && !__all(conv.key_is_zero(key[i], min(sb + i, s1 - 1), cell) || !v0);
             day |= d ? 1u << i : 0u;
+            *reinterpret_cast<double2 *>(vl + i * kSegCells) = key[i];
         }
-        const bool more = sb + kBatch < s1;
+        const int nb = int(min(int64_t(kBatch), s1 - sb));
+        if (sb + kBatch < s1) {  // next batch's keys: in flight behind this batch's conversions
 #pragma unroll
-        for (int i = 0; i < kBatch; ++i) {
-            if (sb + i >= s1) break;
-            double2 r = {0.0, 0.0};
-            if ((day >> i) & 1u) {  // wave-uniform
-                const typename Conv::Raw A = conv.template rest_load<VEC>(sb + i, s0c, s1c, cell);
-                r = conv.compute_keyed(A, key[i], true, true, cell, lds);
-            }
-            // rolling prefetch: the key of the slot one batch ahead takes this slot's registers
-            if (more && v0) key[i] = conv.template key_load<VEC>(min(sb + kBatch + i, s1 - 1), s0c, s1c, cell);
-            if constexpr (SERIES) {
+            for (int i = 0; i < kBatch; ++i)
+                key[i] = v0 ? conv.template key_load<VEC>(min(sb + kBatch + i, s1 - 1), s0c, s1c, cell) : double2{0.0, 0.0};
+        }
+        if constexpr (SERIES) {
+#pragma unroll 1
+            for (int i = 0; i < nb; ++i) {
+                double2 r = {0.0, 0.0};
+                if ((day >> i) & 1u) {  // wave-uniform
+                    const typename Conv::Raw A = conv.template rest_load<VEC>(sb + i, s0c, s1c, cell);
+                    r = conv.compute_keyed(A, *reinterpret_cast<const double2 *>(vl + i * kSegCells), true, true, cell, lds);
+                }
                 st2<VEC>(out_a, (sb + i) * S + c0, v0, v1, r);
-            } else {
+            }
+        } else {
+            unsigned m = day;
+            while (m) {
+                const int i = __builtin_ctz(m);
+                m &= m - 1;
+                const typename Conv::Raw A = conv.template rest_load<VEC>(sb + i, s0c, s1c, cell);
+                const double2 r = conv.compute_keyed(A, *reinterpret_cast<const double2 *>(vl + i * kSegCells), true, true, cell, lds);
                 if (!dnan(r.x)) {
                     acc.x += r.x;
                     ++cnt0;
@@ -203,6 +219,9 @@ __global__ __launch_bounds__(256, min_waves<Conv>()) void k_cells_night(Conv con
                     ++cnt1;
                 }
             }
+            const int night = nb - __builtin_popcount(day);  // night slots are valid zeros
+            cnt0 += night;
+            cnt1 += night;
         }
     }
     if constexpr (!SERIES) {
@@ -683,6 +702,8 @@ int32_t pick_chunk_slots(const atl_ctx *ctx, int64_t n_slots, int64_t n_segs) {
     return int32_t(chunk);
 }
 
+constexpr size_t kCellsNightLds = 4 * kBatch * kSegCells * sizeof(double);  // k_cells_night: key rows of the block's four waves
+
 // slots per block of the per-cell kernels that walk a slot range: as long as possible while the grid still fills the chip
 // (16 blocks per CU), whole batches
 inline int64_t slot_chunk_len(const atl_ctx *ctx, int64_t n_slots, unsigned gx) {
@@ -707,11 +728,11 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
             const int64_t len = slot_chunk_len(ctx, n_slots, gx);
             const dim3 gridn(gx, unsigned((n_slots + len - 1) / len));
             if (vec)
-                hipLaunchKernelGGL((k_cells_night<Conv, true, true>), gridn, dim3(256), lds_bytes, ctx->stream, conv, n_slots, S,
-                                   len, d_out, static_cast<double *>(nullptr));
+                hipLaunchKernelGGL((k_cells_night<Conv, true, true>), gridn, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
+                                   len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)));
             else
-                hipLaunchKernelGGL((k_cells_night<Conv, false, true>), gridn, dim3(256), lds_bytes, ctx->stream, conv, n_slots, S,
-                                   len, d_out, static_cast<double *>(nullptr));
+                hipLaunchKernelGGL((k_cells_night<Conv, false, true>), gridn, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
+                                   len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)));
             return check_launch(what);
         }
         if (vec)
@@ -734,11 +755,11 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
         KernelBracket kb(ctx);
         if constexpr (conv_night_pipe<Conv>::value) {
             if (vec)
-                hipLaunchKernelGGL((k_cells_night<Conv, true, false>), grid, dim3(256), lds_bytes, ctx->stream, conv, n_slots, S,
-                                   chunk_len, psum, pcnt);
+                hipLaunchKernelGGL((k_cells_night<Conv, true, false>), grid, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
+                                   chunk_len, psum, pcnt, int32_t(lds_bytes / sizeof(double)));
             else
-                hipLaunchKernelGGL((k_cells_night<Conv, false, false>), grid, dim3(256), lds_bytes, ctx->stream, conv, n_slots, S,
-                                   chunk_len, psum, pcnt);
+                hipLaunchKernelGGL((k_cells_night<Conv, false, false>), grid, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
+                                   chunk_len, psum, pcnt, int32_t(lds_bytes / sizeof(double)));
         } else if (vec)
             hipLaunchKernelGGL((k_cells_timered<Conv, true>), grid, dim3(256), lds_bytes, ctx->stream, conv,
                                n_slots, S, chunk_len, psum, pcnt);

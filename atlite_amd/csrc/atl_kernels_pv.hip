@@ -69,11 +69,11 @@ int pv_dispatch(const atl_pv_inputs *in, const atl_pv_params *p, bool allow_skip
 bool pv_needs_general(const atl_pv_inputs *in, const atl_pv_params *p) {
     if (pv_influx_fast(in, p)) return false;
     if (in->d_influx != nullptr || in->d_albedo == nullptr || p->orientation_per_time) return true;
-    if (p->tracking != ATL_TRACK_NONE)  // trackers: fast family for pv() with the Huld panel
-        return !(p->tracking >= ATL_TRACK_HORIZONTAL && p->tracking <= ATL_TRACK_DUAL &&
-                 (p->trigon_model == ATL_TRIGON_SIMPLE || p->trigon_model == ATL_TRIGON_OTHER) &&
-                 p->panel_model == ATL_PANEL_HULD && p->irradiation == ATL_IRR_TOTAL &&
-                 in->d_solar_altitude != nullptr && in->d_temperature != nullptr);
+    if (p->tracking != ATL_TRACK_NONE) {  // trackers: fast family with stored angles; no solar thermal collector
+        if (!(p->tracking >= ATL_TRACK_HORIZONTAL && p->tracking <= ATL_TRACK_DUAL && in->d_solar_altitude != nullptr &&
+              in->d_temperature != nullptr && p->panel_model != ATL_PANEL_SOLAR_THERMAL))
+            return true;
+    }
     // fixed panel, direct / diffuse / albedo cubes, either trigon model: the fast kernel family, with the Huld panel,
     // the bofinger panel, the solar thermal collector or the plain irradiation as its tail
     if (p->trigon_model != ATL_TRIGON_SIMPLE && p->trigon_model != ATL_TRIGON_OTHER) return true;
@@ -91,7 +91,7 @@ bool pv_needs_general(const atl_pv_inputs *in, const atl_pv_params *p) {
 
 // ... of which the tails other than the Huld panel are compiled in atl_kernels_pvt.hip
 bool pv_other_tail(const atl_pv_inputs *in, const atl_pv_params *p) {
-    return !pv_influx_fast(in, p) && p->tracking == ATL_TRACK_NONE && p->panel_model != ATL_PANEL_HULD;
+    return !pv_influx_fast(in, p) && p->panel_model != ATL_PANEL_HULD;
 }
 
 }  // namespace

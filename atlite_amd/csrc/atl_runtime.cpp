@@ -856,32 +856,29 @@ int atl_pv_probe_host(const atl_pv_params *p, int family, int64_t n, const doubl
                      : p->panel_model == ATL_PANEL_NONE        ? (hd ? kTailIrradiationHayDavies : kTailIrradiation)
                      : p->panel_model == ATL_PANEL_BOFINGER    ? (hd ? kTailBofingerHayDavies : kTailBofinger)
                                                                : (hd ? kTailHuldHayDavies : kTailHuld);
-    ATL_REQUIRE(p->tracking == ATL_TRACK_NONE || p->panel_model == ATL_PANEL_HULD,
-                "atl_pv_probe_host: the fast family pairs trackers with the Huld panel");
-    auto run = [&](auto tl, auto tr) {
-        constexpr int TL = decltype(tl)::value, TR = decltype(tr)::value;
-        for (int64_t i = 0; i < n; ++i) {
-            const PvOri o = PvConvT<false, true, false, TL>::make_ori(slope[i], pazim[i]);
-            h_out[i] = pv_cell_auto<TL, TR>(dir[i], dif[i], toa[i], alb[i], tmp[i], alt[i], az[i], o, k);
+    ATL_REQUIRE(p->tracking == ATL_TRACK_NONE || p->panel_model != ATL_PANEL_SOLAR_THERMAL,
+                "atl_pv_probe_host: the fast family has no tracker for the solar thermal collector");
+    return pv_probe_switch(p->tracking, [&](auto tr) {
+        constexpr int TR = decltype(tr)::value;
+        auto run = [&](auto tl) {
+            constexpr int TL = decltype(tl)::value;
+            for (int64_t i = 0; i < n; ++i) {
+                const PvOri o = PvConvT<false, true, false, TL>::make_ori(slope[i], pazim[i]);
+                h_out[i] = pv_cell_auto<TL, TR>(dir[i], dif[i], toa[i], alb[i], tmp[i], alt[i], az[i], o, k);
+            }
+            return int(ATL_OK);
+        };
+        switch (tail) {
+            case kTailHuldHayDavies: return run(std::integral_constant<int, kTailHuldHayDavies>());
+            case kTailThermal: return run(std::integral_constant<int, kTailThermal>());
+            case kTailIrradiation: return run(std::integral_constant<int, kTailIrradiation>());
+            case kTailBofinger: return run(std::integral_constant<int, kTailBofinger>());
+            case kTailThermalHayDavies: return run(std::integral_constant<int, kTailThermalHayDavies>());
+            case kTailIrradiationHayDavies: return run(std::integral_constant<int, kTailIrradiationHayDavies>());
+            case kTailBofingerHayDavies: return run(std::integral_constant<int, kTailBofingerHayDavies>());
+            default: return run(std::integral_constant<int, kTailHuld>());
         }
-        return int(ATL_OK);
-    };
-    if (p->tracking != ATL_TRACK_NONE)
-        return pv_probe_switch(p->tracking, [&](auto tr) {
-            return tail == kTailHuldHayDavies ? run(std::integral_constant<int, kTailHuldHayDavies>(), tr)
-                                              : run(std::integral_constant<int, kTailHuld>(), tr);
-        });
-    using None = std::integral_constant<int, ATL_TRACK_NONE>;
-    switch (tail) {
-        case kTailHuldHayDavies: return run(std::integral_constant<int, kTailHuldHayDavies>(), None());
-        case kTailThermal: return run(std::integral_constant<int, kTailThermal>(), None());
-        case kTailIrradiation: return run(std::integral_constant<int, kTailIrradiation>(), None());
-        case kTailBofinger: return run(std::integral_constant<int, kTailBofinger>(), None());
-        case kTailThermalHayDavies: return run(std::integral_constant<int, kTailThermalHayDavies>(), None());
-        case kTailIrradiationHayDavies: return run(std::integral_constant<int, kTailIrradiationHayDavies>(), None());
-        case kTailBofingerHayDavies: return run(std::integral_constant<int, kTailBofingerHayDavies>(), None());
-        default: return run(std::integral_constant<int, kTailHuld>(), None());
-    }
+    });
 }
 
 int atl_wind_probe_host(const atl_wind_params *p, int64_t n, const double *h_wnd, const double *h_aux, double *h_out) {

@@ -70,8 +70,10 @@ for name, nbytes, fn in (
     ("irradiation(trigon_model='other') - fast family (r02)", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none", trigon_model="other"))),
     ("solar_thermal(trigon_model='other') - fast family (r02)", 56,
      lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="solar_thermal", c0=0.8, c1=3.0, t_store_K=353.15, trigon_model="other"))),
-    ("general kernel: bofinger + tracking='horizontal'", 56, lambda: ctx.pv(inputs, kanena, T, S, plan=plan, options=dict(tracking="horizontal"))),
-    ("general kernel: irradiation(tracking='dual')", 48, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none", tracking="dual"))),
+    ("bofinger + tracking='horizontal' - fast family (r02; was the general kernel)", 56, lambda: ctx.pv(inputs, kanena, T, S, plan=plan, options=dict(tracking="horizontal"))),
+    ("irradiation(tracking='dual') - fast family (r02; was the general kernel)", 48, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none", tracking="dual"))),
+    ("bofinger + tracking='tilted_horizontal' + Hay-Davies, per-cell orientation - fast family (r02)", 56,
+     lambda: ctx.pv(inputs, dict(kanena, slope=percell["slope"], azimuth=percell["azimuth"]), T, S, plan=plan, options=dict(tracking="tilted_horizontal", trigon_model="other"))),
     ("general kernel: influx-only dataset (Reindl split, albedo from outflux)", 48, lambda: ctx.pv(influx_ds, scal, T, S, plan=plan)),
     ("per-cell series out (no matrix), no early-out", 64, lambda: ctx.pv(inputs, scal, T, S, options=dict(night_skip=False))),
     ("per-cell series out (no matrix) + night early-out", 64, lambda: ctx.pv(inputs, scal, T, S, options=dict(night_skip=True))),
