@@ -21,6 +21,20 @@ from . import gis, labeled
 from .labeled import Dataset
 
 
+class Affine(tuple):
+    """The six coefficients (a, b, c, d, e, f) of x' = a*col + b*row + c, y' = d*col + e*row + f; stands in for
+    rasterio's Affine, which is not a dependency here."""
+
+    def __new__(cls, a, b, c, d, e, f):
+        return super().__new__(cls, (float(a), float(b), float(c), float(d), float(e), float(f)))
+
+    a, b, c, d, e, f = (property(lambda self, i=i: self[i]) for i in range(6))
+
+    def __mul__(self, colrow):
+        col, row = colrow
+        return (self[0] * col + self[1] * row + self[2], self[3] * col + self[4] * row + self[5])
+
+
 class Cutout:
     def __init__(self, data=None, crs=4326, path=None, devices=None):
         import os
@@ -58,12 +72,12 @@ class Cutout:
     @property
     def dx(self):
         x = self.coords["x"]
-        return float((x[-1] - x[0]) / (len(x) - 1)) if len(x) > 1 else 1.0
+        return round(float((x[-1] - x[0]) / (len(x) - 1)), 8) if len(x) > 1 else 1.0  # cutout.py:314-320
 
     @property
     def dy(self):
         y = self.coords["y"]
-        return float((y[-1] - y[0]) / (len(y) - 1)) if len(y) > 1 else 1.0
+        return round(float((y[-1] - y[0]) / (len(y) - 1)), 8) if len(y) > 1 else 1.0
 
     @property
     def extent(self):
@@ -106,6 +120,97 @@ class Cutout:
         Y, X = self.shape
         return LabeledArray(np.ones((Y, X)), ("y", "x"), {"y": self.coords["y"], "x": self.coords["x"]},
                             name="Capacity")
+
+    def _layout(self, values, name=None):
+        from .labeled import LabeledArray
+
+        return _convert._finish(LabeledArray(np.asarray(values, dtype=np.float64), ("y", "x"),
+                                             {"y": self.coords["y"], "x": self.coords["x"]}, name=name))
+
+    def area(self, crs=None):
+        """Area per grid cell, (y, x) (cutout.py:537-558).  In the cutout's own crs the reference's
+        ``grid.to_crs(crs).area`` is the planar area of the cell boxes, dx * dy; any other crs needs pyproj."""
+        if crs is not None and crs != self.crs:
+            raise NotImplementedError("areas in another crs need pyproj; only the cutout's own crs is supported")
+        return self._layout(np.full(self.shape, abs(self.dx * self.dy)))
+
+    def uniform_density_layout(self, capacity_density, crs=None):
+        """Capacity layout from a uniform capacity density (cutout.py:566-585)."""
+        a = self.area(crs)
+        return self._layout(capacity_density * np.asarray(a.values))
+
+    def layout_from_capacity_list(self, data, col="Capacity"):
+        """Capacity layout from a list of plants with columns 'x', 'y' and ``col``: every entry is added to the grid
+        cell nearest to its coordinate, entries outside the cutout to the border cells (cutout.py:596-642)."""
+        xg, yg = np.asarray(self.coords["x"]), np.asarray(self.coords["y"])
+        px, py = np.asarray(data["x"], dtype=np.float64), np.asarray(data["y"], dtype=np.float64)
+
+        def nearest(grid, v):
+            i = np.clip(np.searchsorted(grid, v, side="left"), 0, len(grid) - 1)
+            # like the reference, i == 0 compares with grid[-1]: an entry at or below the first coordinate lands in the LAST
+            # cell (index -1) - kept, so that layouts equal the reference's for the same list
+            return i - (v - grid[i - 1] < grid[i] - v)
+
+        ix, iy = nearest(xg, px), nearest(yg, py)
+        out = np.zeros(self.shape)
+        np.add.at(out, (iy, ix), np.asarray(data[col], dtype=np.float64))
+        return self._layout(out, name=col)
+
+    def equals(self, other):
+        """Same coordinates and variables, value by value (NaN == NaN); the path is ignored (cutout.py:587-594)."""
+        if not isinstance(other, Cutout):
+            return NotImplemented
+        a, b = self.data, other.data
+        if set(a.data_vars) != set(b.data_vars):
+            return False
+        for k in ("time", "y", "x"):
+            if (k in a.coords) != (k in b.coords) or (k in a.coords and not np.array_equal(np.asarray(a.coords[k]), np.asarray(b.coords[k]))):
+                return False
+        for k in a.data_vars:
+            u, v = a[k], b[k]
+            if u.dims != v.dims or not np.array_equal(np.asarray(u.values), np.asarray(v.values), equal_nan=True):
+                return False
+        return True
+
+    # -- descriptive properties (cutout.py:216-248, 284-345) ----------------------------------
+    @property
+    def name(self):
+        p = getattr(self, "path", None)
+        return os.path.splitext(os.path.basename(p))[0] if p else None
+
+    @property
+    def module(self):
+        return self.data.attrs.get("module")
+
+    @property
+    def chunks(self):
+        c = getattr(getattr(self.data, "file", None), "chunks", None)
+        return c if c else None
+
+    @property
+    def transform(self):
+        """(a, b, c, d, e, f) of the affine cell-index -> coordinate map, the argument order of rasterio's Affine."""
+        return Affine(self.dx, 0.0, float(self.coords["x"][0]) - self.dx / 2, 0.0, self.dy, float(self.coords["y"][0]) - self.dy / 2)
+
+    @property
+    def transform_r(self):
+        return Affine(self.dx, 0.0, float(self.coords["x"][0]) - self.dx / 2, 0.0, -self.dy, float(self.coords["y"][-1]) + self.dy / 2)
+
+    @property
+    def dt(self):
+        t = self.coords["time"]
+        return pd.infer_freq(t) if len(t) >= 3 else None
+
+    @property
+    def prepared_features(self):
+        """Series of the variables indexed by (module, feature) where the variables carry those attributes
+        (cutout.py:335-345); variables without them are listed under the dataset's module and their own name."""
+        idx = []
+        for v in self.data:
+            at = getattr(self.data[v], "attrs", None) or {}
+            idx.append((at.get("module", self.module), at.get("feature", v)))
+        index = pd.MultiIndex.from_tuples(idx, names=["module", "feature"]) if idx else pd.MultiIndex.from_arrays([[], []], names=["module", "feature"])
+        return pd.Series(list(self.data), index, dtype=object)
 
     # -- conversion methods bound like the reference does (cutout.py:653-689) -----------------
     convert_and_aggregate = _convert.convert_and_aggregate

@@ -71,3 +71,26 @@ def test_night_is_exactly_zero_and_sample_matches_oracle(ctx, c2):
     assert (out[:, sel[dark]] == 0.0).all()
     ref = orc.aggregate_matrix(orc.convert_pv(host, H.CSI, dict(slope=np.radians(30.0), azimuth=np.radians(180.0))), M)
     np.testing.assert_allclose(out[:, sel], ref, rtol=1e-10, atol=1e-12 * ref.max())
+
+
+def test_per_cell_kernels_with_the_night_early_out(ctx, c2):
+    """Capacity-factor map and per-cell series at full size (k_cells_night: what Cutout.pv() without shapes runs):
+    the same bits as the kernels without the early-out, the map equal to the reduced series, sampled steps equal to
+    the oracle."""
+    inputs, M, out = c2
+    S = Y * X
+    a = ctx.pv(inputs, PARAMS, T, S, time_agg="mean", options=dict(night_skip=False)).numpy()
+    b = ctx.pv(inputs, PARAMS, T, S, time_agg="mean", options=dict(night_skip=True)).numpy()
+    np.testing.assert_array_equal(a, b)
+    ser = ctx.pv(inputs, PARAMS, T, S, options=dict(night_skip=True)).numpy()
+    assert ser.shape == (T, S) and np.isfinite(ser).all()
+    np.testing.assert_allclose(b, ser.mean(0), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(M @ ser.T, out, rtol=1e-11, atol=1e-12 * out.max())  # and the fused path agrees
+    sel = np.concatenate([np.arange(0, 40), np.arange(4300, 4340), [T - 1]])
+    host = {k: np.stack([v.slab(int(t), int(t) + 1).numpy()[0] for t in sel]) for k, v in inputs.items()}
+    ref = orc.convert_pv(host, H.CSI, dict(slope=np.radians(30.0), azimuth=np.radians(180.0)))
+    np.testing.assert_allclose(ser[sel], ref, rtol=1e-10, atol=1e-12 * ref.max())
+    dark = (host["solar_altitude"] < np.radians(1.0)).all(axis=1)
+    assert dark.any() and (ser[sel[dark]] == 0.0).all()
+    nos = ctx.pv(inputs, PARAMS, T, S, options=dict(night_skip=False))
+    np.testing.assert_array_equal(nos.slab(4300, 4400).numpy(), ser[4300:4400])
