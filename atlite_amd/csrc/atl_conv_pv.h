@@ -387,8 +387,8 @@ ATL_HD __forceinline__ double pv_cell_sp(double dir, double dif, double toa, dou
 template <bool SP, bool PC = false, bool SKIP = false, int TAIL = kTailHuld, int TRACK = ATL_TRACK_NONE, int HEAD = 0>
 struct PvConvT {
     static_assert(HEAD == 0 || (!SP && TAIL == kTailHuld && TRACK == ATL_TRACK_NONE), "influx head: stored angles, Huld panel, no tracker");
-    static_assert(TAIL == kTailHuld || (!SP && !SKIP), "the non-panel tails are built for stored angles, no skip");
-    static_assert(TRACK == ATL_TRACK_NONE || (!SP && !SKIP), "trackers: stored angles, no skip");
+    static_assert(TAIL == kTailHuld || !SP, "the tails other than the Huld panel after the simple trigon model are built for stored angles");
+    static_assert(TRACK == ATL_TRACK_NONE || !SP, "trackers: stored angles");
     // the MFMA-carrying instantiation (dense matrices) only for pv() with its defaults: rare options x rare matrices
     static constexpr bool kDenseOk = TAIL == kTailHuld && TRACK == ATL_TRACK_NONE;
     atl_pv_inputs in;
@@ -465,12 +465,16 @@ struct PvConvT {
 #ifndef ATL_SP_NIGHT_WAVES
 #define ATL_SP_NIGHT_WAVES 3
 #endif
+#ifndef ATL_PV_TRKNIGHT_WAVES
+#define ATL_PV_TRKNIGHT_WAVES 3  // night early-out behind a tracker: 48-112 B of scratch at 3 waves (C2 horizontal 2.74 ms) beat 2 waves (2.89 ms)
+#endif
 #ifndef ATL_PV_BOFTRK_WAVES
 #define ATL_PV_BOFTRK_WAVES 3  // bofinger panel behind a tracker, the family's largest converters: 3 waves with 16-80 B of
                                // scratch beat 2 waves without (C2: 3.23 vs 3.50 ms horizontal, 3.62 vs 4.00 ms tilted + Hay-Davies + per-cell)
 #endif
-    static constexpr int kMinWaves = (kNightPipe && !PC && HEAD == 0)                            ? (SP ? ATL_SP_NIGHT_WAVES : 4)
+    static constexpr int kMinWaves = (kNightPipe && !PC && HEAD == 0 && TAIL == kTailHuld && TRACK == ATL_TRACK_NONE) ? (SP ? ATL_SP_NIGHT_WAVES : 4)
                                      : (tail_panel(TAIL) == kTailBofinger && TRACK != ATL_TRACK_NONE) ? ATL_PV_BOFTRK_WAVES
+                                     : (kNightPipe && TRACK != ATL_TRACK_NONE)                        ? ATL_PV_TRKNIGHT_WAVES
                                                                                                     : 3;
     // stored angles: key = the slot's solar altitude.  In-kernel solar position: key = cos(hour angle) of the
     // lane's two grid columns (a (T, X) table), from which sin(altitude) follows with the slot's declination and

@@ -1,6 +1,7 @@
 // Fast pv kernel family (PvConvT: stored or in-kernel solar position, night early-out, the Huld panel after either
-// trigon model, closed-form trackers) and the pv entry points of the C ABI.  The family's other tails (bofinger, solar
-// thermal, irradiation) are compiled in atl_kernels_pvt.hip and reached through atl::pvt_convert*.
+// trigon model, fixed panel) and the pv entry points of the C ABI.  The family's other tails (bofinger, solar thermal,
+// irradiation) are compiled in atl_kernels_pvt.hip (atl::pvt_convert*), the Huld panel behind the closed-form trackers
+// in atl_kernels_pvk.hip (atl::pvk_convert*).
 // The general kernel (PvxConvT) is compiled in atl_kernels_pvx.hip and reached through atl::pvx_convert*.
 // Reference arithmetic: atlite/convert.py:550-574, 748-767, 840-854; atlite/pv/*.py.
 #include "atl_kernel_templates.h"
@@ -15,6 +16,11 @@ int pvx_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_pa
 int pvt_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S, int time_agg,
                 double *d_out);
 int pvt_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S,
+                          const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out);
+// atl_kernels_pvk.hip
+int pvk_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S, int time_agg,
+                double *d_out);
+int pvk_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S,
                           const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out);
 }  // namespace atl
 
@@ -42,22 +48,11 @@ int pv_dispatch(const atl_pv_inputs *in, const atl_pv_params *p, bool allow_skip
             return pc ? f(PvConvT<false, true, true, kTailHuld, ATL_TRACK_NONE, 1>()) : f(PvConvT<false, false, true, kTailHuld, ATL_TRACK_NONE, 1>());
         return pc ? f(PvConvT<false, true, false, kTailHuld, ATL_TRACK_NONE, 1>()) : f(PvConvT<false, false, false, kTailHuld, ATL_TRACK_NONE, 1>());
     }
-    // pv_needs_general() admits trackers only with stored angles and the Huld panel
-    auto tracker = [&](auto trk) {
-        constexpr int TR = decltype(trk)::value;
-        if (p->trigon_model == ATL_TRIGON_OTHER)
-            return pc ? f(PvConvT<false, true, false, kTailHuldHayDavies, TR>()) : f(PvConvT<false, false, false, kTailHuldHayDavies, TR>());
-        return pc ? f(PvConvT<false, true, false, kTailHuld, TR>()) : f(PvConvT<false, false, false, kTailHuld, TR>());
-    };
-    switch (p->tracking) {
-        case ATL_TRACK_HORIZONTAL: return tracker(std::integral_constant<int, ATL_TRACK_HORIZONTAL>());
-        case ATL_TRACK_TILTED_HORIZONTAL: return tracker(std::integral_constant<int, ATL_TRACK_TILTED_HORIZONTAL>());
-        case ATL_TRACK_VERTICAL: return tracker(std::integral_constant<int, ATL_TRACK_VERTICAL>());
-        case ATL_TRACK_DUAL: return tracker(std::integral_constant<int, ATL_TRACK_DUAL>());
-        default: break;
-    }
-    if (p->trigon_model == ATL_TRIGON_OTHER)  // Hay-Davies with stored angles (pv_needs_general); other panels: pv_other_tail
+    if (p->trigon_model == ATL_TRIGON_OTHER) {  // Hay-Davies with stored angles (pv_needs_general); other panels: pv_other_tail
+        if (p->night_skip && allow_skip)
+            return pc ? f(PvConvT<false, true, true, kTailHuldHayDavies>()) : f(PvConvT<false, false, true, kTailHuldHayDavies>());
         return pc ? f(PvConvT<false, true, false, kTailHuldHayDavies>()) : f(PvConvT<false, false, false, kTailHuldHayDavies>());
+    }
     if (p->night_skip && allow_skip) {
         if (sp) return pc ? f(PvConvT<true, true, true>()) : f(PvConvT<true, false, true>());
         return pc ? f(PvConvT<false, true, true>()) : f(PvConvT<false, false, true>());
@@ -89,9 +84,13 @@ bool pv_needs_general(const atl_pv_inputs *in, const atl_pv_params *p) {
     }
 }
 
-// ... of which the tails other than the Huld panel are compiled in atl_kernels_pvt.hip
+// ... of which the tails other than the Huld panel are compiled in atl_kernels_pvt.hip,
 bool pv_other_tail(const atl_pv_inputs *in, const atl_pv_params *p) {
     return !pv_influx_fast(in, p) && p->panel_model != ATL_PANEL_HULD;
+}
+// the Huld panel behind a tracker in atl_kernels_pvk.hip
+bool pv_tracked(const atl_pv_inputs *in, const atl_pv_params *p) {
+    return !pv_influx_fast(in, p) && p->panel_model == ATL_PANEL_HULD && p->tracking != ATL_TRACK_NONE;
 }
 
 }  // namespace
@@ -103,6 +102,7 @@ int atl_pv_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p
     ATL_REQUIRE(ctx && in && p, "atl_pv_convert: ctx/inputs/params is NULL");
     if (pv_needs_general(in, p)) return pvx_convert(ctx, in, p, T, S, time_agg, d_out);
     if (pv_other_tail(in, p)) return pvt_convert(ctx, in, p, T, S, time_agg, d_out);
+    if (pv_tracked(in, p)) return pvk_convert(ctx, in, p, T, S, time_agg, d_out);
     bool vec;
     return pv_dispatch(in, p, true, [&](auto c) {  // night skip: k_cells_night for the SKIP converters
         int rc = make_pv(in, p, T, S, &c, &vec);
@@ -116,6 +116,7 @@ int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv
     ATL_REQUIRE(ctx && in && p, "atl_pv_convert_aggregate: ctx/inputs/params is NULL");
     if (pv_needs_general(in, p)) return pvx_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);
     if (pv_other_tail(in, p)) return pvt_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);
+    if (pv_tracked(in, p)) return pvk_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);
     bool vec;
     return pv_dispatch(in, p, true, [&](auto c) {
         int rc = make_pv(in, p, T, S, &c, &vec);

@@ -1,0 +1,62 @@
+// The fast pv kernel family behind a tracker: pv(tracking="horizontal" | "tilted_horizontal" | "vertical" | "dual") with
+// the Huld panel, either trigon model, one orientation for the grid or one per cell, stored solar angles, with and
+// without the night early-out.  Same PvConvT template as atl_kernels_pv.hip; a translation unit of its own so that
+// the kernel files compile in parallel.
+// Reference arithmetic: atlite/pv/orientation.py:104-196 (closed forms: panel_geom in atl_conv_pv.h),
+// atlite/pv/irradiation.py:76-145, 214-255; atlite/pv/solar_panel_model.py:22-41.
+#include "atl_kernel_templates.h"
+
+namespace {
+
+#include "atl_conv_pv.h"
+#include "atl_pv_make.h"
+
+// f(converter instance) for (tracker, trigon model, scalar / per-cell orientation, night early-out)
+template <class F>
+int pvk_dispatch(const atl_pv_params *p, F &&f) {
+    const bool pc = p->d_cell_slope != nullptr, hd = p->trigon_model == ATL_TRIGON_OTHER, skip = p->night_skip != 0;
+    auto tracker = [&](auto trk) {
+        constexpr int TR = decltype(trk)::value;
+        if (hd) {
+            if (skip) return pc ? f(PvConvT<false, true, true, kTailHuldHayDavies, TR>()) : f(PvConvT<false, false, true, kTailHuldHayDavies, TR>());
+            return pc ? f(PvConvT<false, true, false, kTailHuldHayDavies, TR>()) : f(PvConvT<false, false, false, kTailHuldHayDavies, TR>());
+        }
+        if (skip) return pc ? f(PvConvT<false, true, true, kTailHuld, TR>()) : f(PvConvT<false, false, true, kTailHuld, TR>());
+        return pc ? f(PvConvT<false, true, false, kTailHuld, TR>()) : f(PvConvT<false, false, false, kTailHuld, TR>());
+    };
+    switch (p->tracking) {
+        case ATL_TRACK_HORIZONTAL: return tracker(std::integral_constant<int, ATL_TRACK_HORIZONTAL>());
+        case ATL_TRACK_TILTED_HORIZONTAL: return tracker(std::integral_constant<int, ATL_TRACK_TILTED_HORIZONTAL>());
+        case ATL_TRACK_VERTICAL: return tracker(std::integral_constant<int, ATL_TRACK_VERTICAL>());
+        case ATL_TRACK_DUAL: return tracker(std::integral_constant<int, ATL_TRACK_DUAL>());
+        default: break;
+    }
+    atl::set_error("atl_pv: tracking code %d has no tracker in the fast family", p->tracking);
+    return ATL_E_INVALID;
+}
+
+}  // namespace
+
+namespace atl {
+
+int pvk_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S, int time_agg,
+                double *d_out) {
+    bool vec;
+    return pvk_dispatch(p, [&](auto c) {
+        int rc = make_pv(in, p, T, S, &c, &vec);
+        if (rc) return rc;
+        return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
+    });
+}
+
+int pvk_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S,
+                          const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out) {
+    bool vec;
+    return pvk_dispatch(p, [&](auto c) {
+        int rc = make_pv(in, p, T, S, &c, &vec);
+        if (rc) return rc;
+        return run_fused(ctx, c, vec, 0, T, S, agg, time_agg, d_out, ld_out, "atl_pv_convert_aggregate");
+    });
+}
+
+}  // namespace atl

@@ -17,6 +17,12 @@ int pvt_dispatch(const atl_pv_params *p, F &&f) {
     const bool pc = p->d_cell_slope != nullptr, hd = p->trigon_model == ATL_TRIGON_OTHER;
     auto with = [&](auto simple, auto other, auto trk) {
         constexpr int TS = decltype(simple)::value, TO = decltype(other)::value, TR = decltype(trk)::value;
+        if constexpr (TR == ATL_TRACK_NONE) {  // the night early-out: fixed panels only here (compile time)
+            if (p->night_skip) {
+                if (hd) return pc ? f(PvConvT<false, true, true, TO>()) : f(PvConvT<false, false, true, TO>());
+                return pc ? f(PvConvT<false, true, true, TS>()) : f(PvConvT<false, false, true, TS>());
+            }
+        }
         if (hd) return pc ? f(PvConvT<false, true, false, TO, TR>()) : f(PvConvT<false, false, false, TO, TR>());
         return pc ? f(PvConvT<false, true, false, TS, TR>()) : f(PvConvT<false, false, false, TS, TR>());
     };

@@ -315,6 +315,51 @@ def test_pv_night_skip_is_bit_identical(ctx, Y, X):
     np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-12 * np.nanmax(np.abs(ref[np.isfinite(ref)])), equal_nan=True)
 
 
+@pytest.mark.parametrize("opts", [
+    dict(tracking="horizontal"), dict(tracking="tilted_horizontal", trigon_model="other"), dict(tracking="vertical"),
+    dict(tracking="dual", trigon_model="other"), dict(trigon_model="other"), dict(panel_model="none"),
+    dict(panel_model="none", trigon_model="other", irradiation="diffuse"),
+    dict(panel_model="solar_thermal", c0=0.8, c1=3.0, t_store_K=353.15),
+    dict(panel_model="solar_thermal", c0=0.8, c1=3.0, t_store_K=353.15, trigon_model="other"),
+    dict(panel="KANENA"), dict(panel="KANENA", trigon_model="other")])
+def test_pv_night_skip_other_tails_and_trackers(ctx, opts):
+    """The night early-out for the family's other members - trackers with the Huld panel, and the bofinger /
+    solar thermal / irradiation tails after either trigon model with a fixed panel: the same bits as without it (fused,
+    per-cell series, time reduction; one orientation or one per cell; NaN / inf in night rows), oracle values."""
+    from atlite_amd.resource import get_solarpanelconfig
+
+    T, Y, X, N = 61, 9, 20, 6
+    opts = dict(opts)
+    panel = get_solarpanelconfig(opts.pop("panel")) if "panel" in opts else H.CSI
+    ds = H.pv_dataset(T, Y, X, seed=41)
+    ds["solar_altitude"][30, 5] = np.nan
+    ds["temperature"][2, :] = np.nan
+    ds["influx_direct"][3, :] = np.inf
+    M = H.blob_matrix(N, Y, X, seed=42)
+    plan = ctx.plan(M, row_len=X)
+    dev = up(ctx, ds)
+    _, y = H.grid(Y, X)
+    lo = orc.orientation_latitude_optimal(np.radians(y))
+    scal = dict(panel, slope=np.radians(30.0), azimuth=np.radians(180.0))
+    for params in (scal, dict(panel, slope=np.repeat(lo["slope"], X), azimuth=np.repeat(lo["azimuth"], X))):
+        for kw in (dict(plan=plan), dict(), dict(time_agg="sum")):
+            a = ctx.pv(dev, params, T, Y * X, options=dict(opts, night_skip=False), **kw).numpy()
+            b = ctx.pv(dev, params, T, Y * X, options=dict(opts, night_skip=True), **kw).numpy()
+            np.testing.assert_array_equal(a, b)
+    ori = dict(slope=np.radians(30.0), azimuth=np.radians(180.0))
+    trk, tm = opts.get("tracking"), opts.get("trigon_model", "simple")
+    with np.errstate(all="ignore"):
+        if opts.get("panel_model") == "none":
+            ref = orc.convert_irradiation(ds, ori, trk, opts.get("irradiation", "total"), tm, "simple")
+        elif opts.get("panel_model") == "solar_thermal":
+            ref = orc.convert_solar_thermal(ds, ori, tm, "simple", 0.8, 3.0, 80.0)
+        else:
+            ref = orc.convert_pv_general(ds, panel, ori, trk, tm, "simple")
+    got = ctx.pv(dev, scal, T, Y * X, options=dict(opts, night_skip=True)).numpy()
+    ref = np.asarray(ref).reshape(T, -1)
+    np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-12 * np.nanmax(np.abs(ref[np.isfinite(ref)])), equal_nan=True)
+
+
 def test_pv_influx_outflux_dataset_fast_family(ctx):
     """SARAH-shaped datasets (total influx + outflux, no direct / diffuse split, no albedo): pv() with its defaults
     runs in the fast kernel family (Reindl split and albedo = outflux / influx in the converter's head, 48 B/cell)

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
 """pv kernel variants on the C2 shape (8760x200x200, 100 shapes): dominant-kernel time from HIP events."""
+import os
+
+os.environ["ATLITE_HIP_NIGHT_SKIP"] = "0"  # lines without an explicit night_skip read every byte
 import sys
 from pathlib import Path
 
@@ -54,6 +57,7 @@ for name, nbytes, fn in (
     ("getter + night early-out", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(night_skip=True))),
     ("getter, per-cell orientation (latitude_optimal)", 56, lambda: ctx.pv(inputs, percell, T, S, plan=plan, options=dict(night_skip=False))),
     ("in-kernel solar position (5 cubes + tables)", 40, lambda: ctx.pv(five, scal, T, S, plan=plan, solar_tables=tables)),
+    ("in-kernel solar position + night early-out", 40, lambda: ctx.pv(five, scal, T, S, plan=plan, solar_tables=tables, options=dict(night_skip=True))),
     ("pv(tracking='horizontal') - fast family, closed-form tracker", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="horizontal"))),
     ("pv(tracking='tilted_horizontal') - fast family", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="tilted_horizontal"))),
     ("pv(tracking='vertical') - fast family (48 B/cell: azimuth not read)", 48, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="vertical"))),
@@ -74,6 +78,15 @@ for name, nbytes, fn in (
     ("irradiation(tracking='dual') - fast family (r02; was the general kernel)", 48, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none", tracking="dual"))),
     ("bofinger + tracking='tilted_horizontal' + Hay-Davies, per-cell orientation - fast family (r02)", 56,
      lambda: ctx.pv(inputs, dict(kanena, slope=percell["slope"], azimuth=percell["azimuth"]), T, S, plan=plan, options=dict(tracking="tilted_horizontal", trigon_model="other"))),
+    ("pv(tracking='horizontal') + night early-out (r02)", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="horizontal", night_skip=True))),
+    ("pv(tracking='tilted_horizontal') + night early-out (r02)", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="tilted_horizontal", night_skip=True))),
+    ("pv(tracking='dual') + night early-out (r02)", 48, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="dual", night_skip=True))),
+    ("tracking='horizontal' + Hay-Davies, per-cell orientation + night early-out (r02)", 56, lambda: ctx.pv(inputs, percell, T, S, plan=plan, options=dict(tracking="horizontal", trigon_model="other", night_skip=True))),
+    ("pv(trigon_model='other') + night early-out (r02)", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(trigon_model="other", night_skip=True))),
+    ("pv(panel='KANENA') + night early-out (r02)", 56, lambda: ctx.pv(inputs, kanena, T, S, plan=plan, options=dict(night_skip=True))),
+    ("irradiation() + night early-out (r02)", 48, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none", night_skip=True))),
+    ("solar_thermal() + night early-out (r02)", 56,
+     lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="solar_thermal", c0=0.8, c1=3.0, t_store_K=353.15, night_skip=True))),
     ("general kernel: influx-only dataset (Reindl split, albedo from outflux)", 48, lambda: ctx.pv(influx_ds, scal, T, S, plan=plan)),
     ("per-cell series out (no matrix), no early-out", 64, lambda: ctx.pv(inputs, scal, T, S, options=dict(night_skip=False))),
     ("per-cell series out (no matrix) + night early-out", 64, lambda: ctx.pv(inputs, scal, T, S, options=dict(night_skip=True))),
