@@ -101,13 +101,21 @@ ATL_HD __forceinline__ PanelGeom panel_geom(double sa, double ca, double az, dou
         if constexpr (NEED_SH) g.sh = lean_sin(slope / 2.0);
     } else if constexpr (TRACK == ATL_TRACK_HORIZONTAL) {
         const double sd = lean_sin(az - sazim);
+#ifdef ATL_TRK_FASTDIV  // experiment: the reciprocal path without the range guard (non-finite q takes the literal routine anyway)
+        const double q = fast_div(ca, sa) * sd;
+#else
         const double q = guarded_div(ca, sa) * sd;
-        const bool ok = q != 0.0 && __builtin_fabs(q) < 0x1.0p500;  // false for NaN / inf too
-        const double w = __builtin_sqrt(__builtin_fma(q, q, 1.0));
-        const double cr = fast_rcp(w);  // w in [1, 2^500] whenever ok
+#endif
+        const bool ok = q != 0.0 && __builtin_fabs(q) < 0x1.0p200;  // false for NaN / inf too
+        double cr;  // 1 / w, w = sqrt(1 + q^2) in [1, 2^200] whenever ok
+        [[maybe_unused]] const double w = lean_sqrt_rsqrt(__builtin_fma(q, q, 1.0), &cr);
         g.cs = cr;
         g.cosinc = cr * (sa + q * ca * sd);
-        if constexpr (NEED_SH) g.sh = __builtin_fabs(q) * fast_rcp(__builtin_sqrt(2.0 * w * (w + 1.0)));
+        if constexpr (NEED_SH) {
+            double rs;
+            lean_sqrt_rsqrt(2.0 * w * (w + 1.0), &rs);
+            g.sh = __builtin_fabs(q) * rs;
+        }
         if (__builtin_expect(!ok, 0)) g = panel_geom_literal(TRACK, sa, ca, az, slope, sazim);
     } else {  // ATL_TRACK_TILTED_HORIZONTAL
         double sd, cd;
@@ -116,8 +124,9 @@ ATL_HD __forceinline__ PanelGeom panel_geom(double sa, double ca, double az, dou
         const double num = ca * sd;
         const double den = ca * cd * st + sa * ct;
         const double q = guarded_div(num, den);
-        const bool ok = den != 0.0 && __builtin_fabs(q) < 0x1.0p500;
-        const double cr = fast_rcp(__builtin_sqrt(__builtin_fma(q, q, 1.0)));
+        const bool ok = den != 0.0 && __builtin_fabs(q) < 0x1.0p200;
+        double cr;
+        lean_sqrt_rsqrt(__builtin_fma(q, q, 1.0), &cr);
         g.cs = cr * ct;
         double ad = az - sazim;
         ad = ad > pi ? ad - 2 * pi : ad;
@@ -125,7 +134,7 @@ ATL_HD __forceinline__ PanelGeom panel_geom(double sa, double ca, double az, dou
         const bool flip = (q < 0.0 && ad > 0.0) || (q > 0.0 && ad < 0.0);
         const double c = cr * (den + q * num);
         g.cosinc = flip ? -c : c;
-        if constexpr (NEED_SH) g.sh = __builtin_sqrt(0.5 * (1.0 - g.cs));
+        if constexpr (NEED_SH) g.sh = lean_sqrt(0.5 * (1.0 - g.cs));  // cs <= 1: the argument is never negative
         if (__builtin_expect(!ok, 0)) g = panel_geom_literal(TRACK, sa, ca, az, slope, sazim);
     }
     return g;

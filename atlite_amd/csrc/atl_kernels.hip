@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void k_math_probe(int fn, const double *__rest
         }
         case 5: r = log_core_tab(x, ltab); break;  // positive normal finite arguments only
         case 7: r = lean_sqrt(x); break;
+        case 8: r = lean_sqrt_rsqrt(x, &out[n + i]); break;
         default: r = fast_div(x, in[n + i]); break;
     }
     out[i] = r;
@@ -341,7 +342,7 @@ int atl_runoff_convert_aggregate(atl_ctx *ctx, const double *d_runoff, const dou
 
 int atl_math_probe(atl_ctx *ctx, int fn, const double *d_in, int64_t n, double *d_out) {
     ATL_REQUIRE(ctx && d_in && d_out && n >= 0, "atl_math_probe: bad argument");
-    ATL_REQUIRE((fn >= 0 && fn <= 5) || fn == 7, "atl_math_probe: fn must be 0..5 or 7");
+    ATL_REQUIRE((fn >= 0 && fn <= 5) || fn == 7 || fn == 8, "atl_math_probe: fn must be 0..5, 7 or 8");
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     if (n == 0) return ATL_OK;
     hipLaunchKernelGGL(k_math_probe, dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, fn, d_in, n,

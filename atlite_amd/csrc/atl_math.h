@@ -85,6 +85,26 @@ ATL_HD __forceinline__ double lean_sqrt(double x) {
     return x == 0.0 ? x : g;  // 0 * inf; negative and NaN arguments come out NaN through the seed
 }
 
+// sqrt(x) and 1 / sqrt(x) together for 2^-500 < x < 2^500: the same coupled iteration, one more step on the reciprocal
+// half - both <= 1-2 ulp; replaces sqrt() + a division (or a reciprocal) in the trackers' closed forms
+ATL_HD __forceinline__ double lean_sqrt_rsqrt(double x, double *rs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = __builtin_amdgcn_rsq(x);
+#else
+    const double y = 1.0 / __builtin_sqrt(x);
+#endif
+    double g = x * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    r = __builtin_fma(-h, g, 0.5);
+    h = __builtin_fma(h, r, h);
+    *rs = h + h;
+    return g;
+}
+
 // a / b to ~1 ulp for normal, well-scaled operands (no denormal / overflow fix-ups)
 ATL_HD __forceinline__ double fast_div(double a, double b) {
     const double y = fast_rcp(b);

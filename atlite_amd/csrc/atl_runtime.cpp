@@ -756,7 +756,7 @@ int atl_agg_check_host(int64_t n_rows, int64_t n_cells, int64_t row_len, const i
 }
 
 int atl_math_probe_host(int fn, const double *h_in, int64_t n, double *h_out) {
-    ATL_REQUIRE(fn >= 0 && fn <= 7 && n >= 0 && (n == 0 || (h_in && h_out)), "atl_math_probe_host: bad argument");
+    ATL_REQUIRE(fn >= 0 && fn <= 8 && n >= 0 && (n == 0 || (h_in && h_out)), "atl_math_probe_host: bad argument");
     double ltab[2 * kLogTabN];
     for (int i = 0; i < kLogTabN; ++i) log_table_entry(ltab, i);
     for (int64_t i = 0; i < n; ++i) {
@@ -775,6 +775,7 @@ int atl_math_probe_host(int fn, const double *h_in, int64_t n, double *h_out) {
             }
             case 5: r = log_core_tab(x, ltab); break;
             case 7: r = lean_sqrt(x); break;
+            case 8: r = lean_sqrt_rsqrt(x, &h_out[n + i]); break;
             case 6: r = guarded_div(x, h_in[n + i]); break;
             default: r = fast_div(x, h_in[n + i]); break;
         }

@@ -428,7 +428,7 @@ int atl_allgather_time_v(atl_comm *comm, const double *d_local, int64_t N, const
  * Evaluates the kernels' lean fp64 math (atl_math.h) elementwise, for accuracy tests:
  * fn 0 sin, 1 cos, 2 log: d_in (n) -> d_out (n);  3 sincos: d_out (2n) = sin | cos;
  * 4 fast_div: d_in (2n) = a | b -> d_out (n) = a / b;  5 table-driven log (positive normal x);
- * 7 lean_sqrt (0 <= x < 2^500).
+ * 7 lean_sqrt (0 <= x < 2^500);  8 lean_sqrt_rsqrt (2^-500 < x < 2^500): d_out (2n) = sqrt | 1 / sqrt.
  */
 int atl_math_probe(atl_ctx *ctx, int fn, const double *d_in, int64_t n, double *d_out);
 /* the same routines (same source, compiled for the host) on host arrays: lets the CPU test suite check

@@ -83,3 +83,14 @@ def test_lean_sqrt(ctx):
     bad = probe(ctx, 7, np.array([-1.0, np.nan, -0.0]))
     assert np.isnan(bad[0]) and np.isnan(bad[1]) and bad[2] == 0.0
 
+
+
+def test_lean_sqrt_rsqrt(ctx):
+    """sqrt and 1 / sqrt from one coupled iteration on the v_rsq_f64 seed (the trackers' 1 / sqrt(1 + q^2))."""
+    rng = np.random.default_rng(12)
+    x = np.concatenate([1.0 + rng.random(200000) * 10.0, 1.0 + 10.0 ** rng.uniform(-16, 120, 100000), 10.0 ** rng.uniform(-140, 140, 100000),
+                        [1.0, 2.0, 4.0, 2.0 ** 401]])
+    got = probe(ctx, 8, x, n_out=2)
+    n = x.size
+    assert ulp_err(got[:n], np.sqrt(x)).max() <= 1.0
+    assert ulp_err(got[n:], 1.0 / np.sqrt(x)).max() <= 2.0

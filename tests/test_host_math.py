@@ -176,3 +176,15 @@ def test_interp_nonfinite_tables_literal_path():
         with np.errstate(all="ignore"):
             ref = np.interp(x, V, F)
         assert np.array_equal(out, ref, equal_nan=True), (case, V, F, x[~((out == ref) | (np.isnan(out) & np.isnan(ref)))][:5])
+
+
+def test_lean_sqrt_rsqrt_host():
+    """sqrt and 1 / sqrt from one coupled iteration (the trackers' closed forms: 1 / sqrt(1 + q^2)): <= 1 / <= 2 ulp
+    on the range the callers use (1 <= x < 2^401) and well beyond."""
+    rng = np.random.default_rng(12)
+    x = np.concatenate([1.0 + rng.random(20000) * 10.0, 1.0 + 10.0 ** rng.uniform(-16, 120, 20000), 10.0 ** rng.uniform(-140, 140, 20000),
+                        [1.0, 2.0, 4.0, 2.0 ** 401]])
+    got = probe(8, x, n_out=2)
+    n = x.size
+    assert ulp_err(got[:n], np.sqrt(x)).max() <= 1.0
+    assert ulp_err(got[n:], 1.0 / np.sqrt(x)).max() <= 2.0
