@@ -101,11 +101,9 @@ ATL_HD __forceinline__ PanelGeom panel_geom(double sa, double ca, double az, dou
         if constexpr (NEED_SH) g.sh = lean_sin(slope / 2.0);
     } else if constexpr (TRACK == ATL_TRACK_HORIZONTAL) {
         const double sd = lean_sin(az - sazim);
-#ifdef ATL_TRK_FASTDIV  // experiment: the reciprocal path without the range guard (non-finite q takes the literal routine anyway)
+        // the reciprocal path without guarded_div's range check: a quotient that leaves the normal range makes q zero /
+        // non-finite / huge, and those take the literal routine below anyway (C2: 2.65 -> 2.59 ms with the early-out)
         const double q = fast_div(ca, sa) * sd;
-#else
-        const double q = guarded_div(ca, sa) * sd;
-#endif
         const bool ok = q != 0.0 && __builtin_fabs(q) < 0x1.0p200;  // false for NaN / inf too
         double cr;  // 1 / w, w = sqrt(1 + q^2) in [1, 2^200] whenever ok
         [[maybe_unused]] const double w = lean_sqrt_rsqrt(__builtin_fma(q, q, 1.0), &cr);

@@ -70,12 +70,23 @@ ATL_HD __forceinline__ double fast_rcp(double b) {
 // sqrt(x) for 0 <= x < 2^500 (and NaN, -0): the hardware reciprocal-square-root seed (~2^-26), one coupled
 // Newton step on (g ~ sqrt x, h ~ 1 / (2 sqrt x)) and a final residual correction - <= 1 ulp, 8 instructions; the
 // compiler's IEEE expansion of sqrt() (pre-scaling for denormals and huge arguments, two steps) is ~20.
-ATL_HD __forceinline__ double lean_sqrt(double x) {
+// the seed: v_rsq_f64 on the device; the host build (same-source tests) degrades the exact value to the ~2^-24 the
+// hardware seed is good for, so that the CPU suite exercises the iterations' convergence, not the libm's
+ATL_HD __forceinline__ double rsq_seed(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const double y = __builtin_amdgcn_rsq(x);
+    return __builtin_amdgcn_rsq(x);
 #else
-    const double y = 1.0 / __builtin_sqrt(x);
+    double y = 1.0 / __builtin_sqrt(x);
+    uint64_t u;
+    __builtin_memcpy(&u, &y, 8);
+    u &= ~uint64_t(0x0FFFFFFF);  // keep 24 mantissa bits (inf / NaN / zero unchanged in kind)
+    __builtin_memcpy(&y, &u, 8);
+    return y;
 #endif
+}
+
+ATL_HD __forceinline__ double lean_sqrt(double x) {
+    const double y = rsq_seed(x);
     double g = x * y, h = 0.5 * y;
     const double r = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, r, g);
@@ -85,23 +96,20 @@ ATL_HD __forceinline__ double lean_sqrt(double x) {
     return x == 0.0 ? x : g;  // 0 * inf; negative and NaN arguments come out NaN through the seed
 }
 
-// sqrt(x) and 1 / sqrt(x) together for 2^-500 < x < 2^500: the same coupled iteration, one more step on the reciprocal
-// half - both <= 1-2 ulp; replaces sqrt() + a division (or a reciprocal) in the trackers' closed forms
+// sqrt(x) and 1 / sqrt(x) together for 2^-500 < x < 2^500: the same coupled iteration, then a Newton step on the
+// reciprocal - both <= 1-2 ulp; replaces sqrt() + a division (or a reciprocal) in the trackers' closed forms
 ATL_HD __forceinline__ double lean_sqrt_rsqrt(double x, double *rs) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const double y = __builtin_amdgcn_rsq(x);
-#else
-    const double y = 1.0 / __builtin_sqrt(x);
-#endif
+    const double y = rsq_seed(x);
     double g = x * y, h = 0.5 * y;
-    double r = __builtin_fma(-h, g, 0.5);
+    const double r = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, r, g);
     h = __builtin_fma(h, r, h);
     const double d = __builtin_fma(-g, g, x);
     g = __builtin_fma(d, h, g);
-    r = __builtin_fma(-h, g, 0.5);
-    h = __builtin_fma(h, r, h);
-    *rs = h + h;
+    // the reciprocal half gets a Newton step of its own (1 - x y^2): refining it with h * g would only halve its error
+    const double y2 = h + h;
+    const double e = __builtin_fma(-(x * y2), y2, 1.0);
+    *rs = __builtin_fma(0.5 * y2, e, y2);
     return g;
 }
 
