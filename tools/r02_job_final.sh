@@ -16,3 +16,6 @@ python bench.py --debug-rccl-self --pipeline 2 --steps 5 --warmup 2 --no-cpu-bas
 ( timeout 600 python tools/check_c4_device_sp.py 2>&1 | tail -5; timeout 600 python tools/check_c5_fullsize.py 2>&1 | tail -3 ) > gpurun_out/final/r02_fullsize_c4_c5.log
 timeout 900 python bench.py --config c4 --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | grep "^{" > gpurun_out/final/r02_bench_c4_n1.json
 cat gpurun_out/final/r02_fullsize_c4_c5.log
+bash tools/r02_job_cells_prof.sh > gpurun_out/final/r02_cells_prof.log 2>&1
+cp gpurun_out/summ/r02_pv_c2_cells.* gpurun_out/final/ 2>/dev/null
+tail -12 gpurun_out/final/r02_cells_prof.log
