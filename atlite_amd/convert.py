@@ -294,7 +294,7 @@ class _PvSpec(_Spec):
         self.prepare(ctx, ds)
         params = dict(self.panel, slope=self.slope, azimuth=self.azimuth)
         return ctx.pv(inputs, params, T, S, plan=plan, time_agg=time_agg, solar_tables=self.solar_tables,
-                      options=self.options, out=out)
+                      options=dict(self.options, row_len=len(ds.coords["x"])), out=out)
 
 
 class _IrradiationSpec(_PvSpec):

@@ -158,7 +158,7 @@ struct conv_night_pipe<Conv, std::void_t<decltype(Conv::kNightPipe)>> : std::int
 template <class Conv, bool VEC, bool SERIES>
 __global__ __launch_bounds__(256, min_waves<Conv>()) void k_cells_night(Conv conv, int64_t n_slots, int64_t S, int64_t chunk_len,
                                                                         double *__restrict__ out_a, double *__restrict__ out_b,
-                                                                        int32_t conv_lds_doubles) {
+                                                                        int32_t conv_lds_doubles, int64_t X, int64_t Y, int32_t ntx) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     conv.block_init(lds);
     __syncthreads();
@@ -167,8 +167,19 @@ __global__ __launch_bounds__(256, min_waves<Conv>()) void k_cells_night(Conv con
     // the wave's key rows: each lane parks the keys of a batch here and reads its own back inside the (rolled) slot
     // loop - eight unrolled conversions are 55 KB of code, the whole instruction cache
     double *vl = lds + conv_lds_doubles + wave * (kBatch * kSegCells) + 2 * lane;
-    const int64_t c0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * 2;
-    const bool v0 = c0 < S, v1 = c0 + 1 < S;
+    // the wave's 128 cells: a 16 x 8 tile of the grid when its row length is known (the fused kernels' tiles: the day /
+    // night line crosses a compact tile in an eighth of the slots it takes to cross a 128-cell strip: 11.8 instead of
+    // 13.7 GB read on C2), else 128 consecutive cells
+    int64_t c0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * 2;
+    bool v0 = c0 < S, v1 = c0 + 1 < S;
+    if (X > 0) {
+        const int64_t seg = int64_t(blockIdx.x) * 4 + wave;
+        if (seg >= int64_t(ntx) * ((Y + 7) / 8)) return;
+        const TileLane tl = tile_lane_cells(X, Y, ntx, 3, int32_t(seg), lane);
+        c0 = tl.c0;
+        v0 = tl.v0;
+        v1 = tl.v1;
+    }
     const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);
     const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
     const int64_t s0 = int64_t(blockIdx.y) * chunk_len;
@@ -714,25 +725,38 @@ inline int64_t slot_chunk_len(const atl_ctx *ctx, int64_t n_slots, unsigned gx) 
 
 template <class Conv>
 int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_t n_slots, int64_t S,
-              int time_agg, double *d_out, const char *what) {
+              int time_agg, double *d_out, const char *what, int64_t row_len = 0) {
     ATL_REQUIRE(time_agg >= ATL_TIME_NONE && time_agg <= ATL_TIME_SUM_COUNT, "%s: bad time_agg %d", what, time_agg);
     ATL_REQUIRE(d_out, "%s: d_out is NULL", what);
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     if (S == 0 || (n_slots == 0 && time_agg == ATL_TIME_NONE)) return ATL_OK;
-    const unsigned gx = unsigned((S + 511) / 512);
+    unsigned gx = unsigned((S + 511) / 512);
+    const unsigned gx_cells = gx;  // the slot chunking follows the cell count alone: the same summation order in every variant
     vec = vec && aligned16(d_out);
+    // row_len = X of the (Y, X) grid, when the caller knows it: the early-out kernels then walk 16 x 8 tiles
+    int64_t tX = 0, tY = 0;
+    int32_t ntx = 0;
+    if constexpr (conv_night_pipe<Conv>::value) {
+        if (row_len > 0 && S % row_len == 0 && S / row_len < (int64_t(1) << 30)) {
+            tX = row_len;
+            tY = S / row_len;
+            ntx = int32_t(tile_columns(tX, tY, 3));
+            gx = unsigned((int64_t(ntx) * ((tY + 7) / 8) + 3) / 4);
+            vec = vec && (tX % 2 == 0);  // the lane's cell pair must not straddle a tile row's end
+        }
+    }
     if (time_agg == ATL_TIME_NONE) {
         const dim3 grid(gx, unsigned((n_slots + kSeriesSlots - 1) / kSeriesSlots));
         KernelBracket kb(ctx);
         if constexpr (conv_night_pipe<Conv>::value) {  // long slot ranges: the keys are fetched one batch ahead
-            const int64_t len = slot_chunk_len(ctx, n_slots, gx);
+            const int64_t len = slot_chunk_len(ctx, n_slots, gx_cells);
             const dim3 gridn(gx, unsigned((n_slots + len - 1) / len));
             if (vec)
                 hipLaunchKernelGGL((k_cells_night<Conv, true, true>), gridn, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
-                                   len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)));
+                                   len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)), tX, tY, ntx);
             else
                 hipLaunchKernelGGL((k_cells_night<Conv, false, true>), gridn, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
-                                   len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)));
+                                   len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)), tX, tY, ntx);
             return check_launch(what);
         }
         if (vec)
@@ -744,7 +768,7 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
         return check_launch(what);
     }
     // time-reduced: split the slot axis so that the grid fills the chip
-    const int64_t chunk_len = slot_chunk_len(ctx, n_slots, gx);
+    const int64_t chunk_len = slot_chunk_len(ctx, n_slots, gx_cells);
     const int64_t n_chunks = std::max<int64_t>(1, (n_slots + chunk_len - 1) / chunk_len);
     void *scr = nullptr;
     int rc = scratch_reserve(ctx, size_t(2 * n_chunks * S) * sizeof(double), &scr);
@@ -756,10 +780,10 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
         if constexpr (conv_night_pipe<Conv>::value) {
             if (vec)
                 hipLaunchKernelGGL((k_cells_night<Conv, true, false>), grid, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
-                                   chunk_len, psum, pcnt, int32_t(lds_bytes / sizeof(double)));
+                                   chunk_len, psum, pcnt, int32_t(lds_bytes / sizeof(double)), tX, tY, ntx);
             else
                 hipLaunchKernelGGL((k_cells_night<Conv, false, false>), grid, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
-                                   chunk_len, psum, pcnt, int32_t(lds_bytes / sizeof(double)));
+                                   chunk_len, psum, pcnt, int32_t(lds_bytes / sizeof(double)), tX, tY, ntx);
         } else if (vec)
             hipLaunchKernelGGL((k_cells_timered<Conv, true>), grid, dim3(256), lds_bytes, ctx->stream, conv,
                                n_slots, S, chunk_len, psum, pcnt);

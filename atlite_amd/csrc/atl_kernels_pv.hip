@@ -107,7 +107,7 @@ int atl_pv_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p
     return pv_dispatch(in, p, true, [&](auto c) {  // night skip: k_cells_night for the SKIP converters
         int rc = make_pv(in, p, T, S, &c, &vec);
         if (rc) return rc;
-        return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
+        return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert", in->X);
     });
 }
 

@@ -60,7 +60,7 @@ int pvt_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, i
     return pvt_dispatch(p, [&](auto c) {
         int rc = make_pv(in, p, T, S, &c, &vec);
         if (rc) return rc;
-        return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
+        return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert", in->X);
     });
 }
 

@@ -304,6 +304,8 @@ class Context:
                     keep.append(t)
                 setattr(pin, field, t.ptr)
             pin.X = int(solar_tables["h"].shape[1])
+        elif options.get("row_len"):  # X of the (Y, X) grid: lets the per-cell early-out kernels walk compact tiles
+            pin.X = int(options["row_len"]) if S % int(options["row_len"]) == 0 else 0
         pp = _lib.PvParams()
         model = options.get("panel_model", params.get("model", "huld"))
         pp.panel_model = _lib.PANEL[model]

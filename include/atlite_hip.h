@@ -164,7 +164,9 @@ typedef struct {
     const double *d_cos_hour_angle; /* (T,X) cos(h)                                     */
     const double *d_sin_lat;        /* (Y)   sin(radians(lat))                  :100    */
     const double *d_cos_lat;        /* (Y)   cos(radians(lat))                          */
-    int64_t X;                      /* cells per grid row (needed for the tables)       */
+    int64_t X;                      /* cells per grid row: needed for the tables; optional
+                                     * otherwise (0 = unknown) - with it the per-cell kernels'
+                                     * night early-out walks 16 x 8 tiles of the grid         */
     /* datasets without a direct/diffuse split or without albedo (irradiation.py:202-205,
      * 128-139): total influx -> Reindl split in the kernel; albedo = outflux / influx */
     const double *d_influx;         /* (T,S) or NULL (then influx_direct/diffuse are used) */

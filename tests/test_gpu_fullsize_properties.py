@@ -80,9 +80,10 @@ def test_per_cell_kernels_with_the_night_early_out(ctx, c2):
     inputs, M, out = c2
     S = Y * X
     a = ctx.pv(inputs, PARAMS, T, S, time_agg="mean", options=dict(night_skip=False)).numpy()
-    b = ctx.pv(inputs, PARAMS, T, S, time_agg="mean", options=dict(night_skip=True)).numpy()
+    b = ctx.pv(inputs, PARAMS, T, S, time_agg="mean", options=dict(night_skip=True, row_len=X)).numpy()
     np.testing.assert_array_equal(a, b)
-    ser = ctx.pv(inputs, PARAMS, T, S, options=dict(night_skip=True)).numpy()
+    np.testing.assert_array_equal(a, ctx.pv(inputs, PARAMS, T, S, time_agg="mean", options=dict(night_skip=True)).numpy())  # strips
+    ser = ctx.pv(inputs, PARAMS, T, S, options=dict(night_skip=True, row_len=X)).numpy()
     assert ser.shape == (T, S) and np.isfinite(ser).all()
     np.testing.assert_allclose(b, ser.mean(0), rtol=1e-12, atol=1e-15)
     np.testing.assert_allclose(M @ ser.T, out, rtol=1e-11, atol=1e-12 * out.max())  # and the fused path agrees

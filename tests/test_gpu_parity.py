@@ -315,6 +315,36 @@ def test_pv_night_skip_is_bit_identical(ctx, Y, X):
     np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-12 * np.nanmax(np.abs(ref[np.isfinite(ref)])), equal_nan=True)
 
 
+@pytest.mark.parametrize("Y,X", [(3, 5), (9, 16), (17, 33), (8, 200), (40, 7), (1, 130), (25, 2)])
+def test_pv_night_skip_per_cell_kernels_on_grid_tiles(ctx, Y, X):
+    """With the grid's row length (atl_pv_inputs.X / options row_len, what Cutout.pv() passes) the per-cell early-out
+    kernels walk the fused kernels' 16 x 8 tiles instead of 128-cell strips: every cell still owned exactly once -
+    the same bits as the kernels without the early-out, for rows shorter than a tile, odd row lengths (unvectorised),
+    single rows and columns, stored angles and the in-kernel solar position."""
+    from atlite_amd import solar
+
+    T = 50
+    ds = H.pv_dataset(T, Y, X, seed=5)
+    ds["temperature"][2, :] = np.nan
+    dev = up(ctx, ds)
+    x, y = H.grid(Y, X)
+    h, dec = solar.hour_angle(H.times(T), x, "-30min")
+    lat = np.radians(y)
+    tables = dict(sin_dec=np.sin(dec), cos_dec=np.cos(dec), h=h, cos_h=np.cos(h), sin_lat=np.sin(lat), cos_lat=np.cos(lat))
+    five = {k: v for k, v in dev.items() if not k.startswith("solar_")}
+    lo = orc.orientation_latitude_optimal(lat)
+    for params in (PV_PARAMS, dict(H.CSI, slope=np.repeat(lo["slope"], X), azimuth=np.repeat(lo["azimuth"], X))):
+        for kw in (dict(), dict(time_agg="sum"), dict(time_agg="mean")):
+            a = ctx.pv(dev, params, T, Y * X, options=dict(night_skip=False), **kw).numpy()
+            b = ctx.pv(dev, params, T, Y * X, options=dict(night_skip=True, row_len=X), **kw).numpy()
+            np.testing.assert_array_equal(a, b)
+            a = ctx.pv(five, params, T, Y * X, solar_tables=tables, options=dict(night_skip=False), **kw).numpy()
+            b = ctx.pv(five, params, T, Y * X, solar_tables=tables, options=dict(night_skip=True), **kw).numpy()
+            np.testing.assert_array_equal(a, b)
+            if not kw:
+                assert (a == 0).any() and a.max() > 0
+
+
 @pytest.mark.parametrize("opts", [
     dict(tracking="horizontal"), dict(tracking="tilted_horizontal", trigon_model="other"), dict(tracking="vertical"),
     dict(tracking="dual", trigon_model="other"), dict(trigon_model="other"), dict(panel_model="none"),

@@ -89,9 +89,9 @@ for name, nbytes, fn in (
      lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="solar_thermal", c0=0.8, c1=3.0, t_store_K=353.15, night_skip=True))),
     ("general kernel: influx-only dataset (Reindl split, albedo from outflux)", 48, lambda: ctx.pv(influx_ds, scal, T, S, plan=plan)),
     ("per-cell series out (no matrix), no early-out", 64, lambda: ctx.pv(inputs, scal, T, S, options=dict(night_skip=False))),
-    ("per-cell series out (no matrix) + night early-out", 64, lambda: ctx.pv(inputs, scal, T, S, options=dict(night_skip=True))),
+    ("per-cell series out (no matrix) + night early-out", 64, lambda: ctx.pv(inputs, scal, T, S, options=dict(night_skip=True, row_len=X))),
     ("per-cell time-mean (capacity factor map), no early-out", 56, lambda: ctx.pv(inputs, scal, T, S, time_agg="mean", options=dict(night_skip=False))),
-    ("per-cell time-mean (capacity factor map) + night early-out", 56, lambda: ctx.pv(inputs, scal, T, S, time_agg="mean", options=dict(night_skip=True))),
+    ("per-cell time-mean (capacity factor map) + night early-out", 56, lambda: ctx.pv(inputs, scal, T, S, time_agg="mean", options=dict(night_skip=True, row_len=X))),
     ("per-cell time-mean, in-kernel solar position + early-out", 40, lambda: ctx.pv(five, scal, T, S, time_agg="mean", solar_tables=tables, options=dict(night_skip=True))),
 ):
     ms, out = timed(fn)

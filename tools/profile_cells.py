@@ -15,8 +15,8 @@ S = Y * X
 inputs, _ = synthetic.pv_inputs(ctx, T, Y, X)
 for skip in (True, False):
     for _ in range(4):
-        out = ctx.pv(inputs, CSI, T, S, time_agg="mean", options=dict(night_skip=skip))
+        out = ctx.pv(inputs, CSI, T, S, time_agg="mean", options=dict(night_skip=skip, row_len=X))
     for _ in range(4):
-        out = ctx.pv(inputs, CSI, T, S, options=dict(night_skip=skip))
+        out = ctx.pv(inputs, CSI, T, S, options=dict(night_skip=skip, row_len=X))
     ctx.sync()
     del out
