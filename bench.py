@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--shapes", type=int, default=None)
     ap.add_argument("--shape-kind", choices=["tessellation", "star"], default="tessellation")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--no-step-overlap", action="store_true",
+                    help="N > 1: finish a step's all-gather and placement before the next step's kernel starts "
+                         "(default: they run behind it, on the collective's and a side stream)")
     ap.add_argument("--pipeline", type=int, default=0,
                     help="sub-launches per step whose all-gathers overlap the next sub-launch (0 = auto: 1 at "
                          "N=1 and for shards below 1e8 cell-steps, else 2)")
@@ -268,15 +271,26 @@ def main():
     # auto: two sub-launches per step (the first one's all-gather overlaps the second) once a rank's shard is big
     # enough to pay for the extra launch - measured on a 1/8 shard of C2 (4.4e7 cell-steps): 0.417 ms with one
     # launch, 0.450 ms with two, against an all-gather of 7 MB that takes less than the difference
-    P = a.pipeline if a.pipeline > 0 else (1 if parts == 1 or T_loc * S < 1.0e8 else 2)
+    equal = len(set(shard_lens)) == 1
+    collective = parts > 1 or (a.debug_rccl_self and dist is not None)
+    # RCCL path: the all-gather and the placement copy of a step run behind the NEXT step's kernel - a second set of
+    # (piece, gather) buffers by step parity, the placement on a side stream, buffer reuse ordered by events; the timed
+    # region ends with a device-wide synchronize, so every step's result is in place when the clock stops.  One
+    # launch per step then: there is nothing left for sub-launches to hide.
+    overlap = collective and equal and not (a.emulate_shard or a.debug_gloo_one_gpu or a.no_step_overlap)
+    P = a.pipeline if a.pipeline > 0 else (1 if parts == 1 or overlap or T_loc * S < 1.0e8 else 2)
     P = max(1, min(P, T_loc // 8 or 1))
     pe = D.time_partition(T_loc, P)  # sub-launch edges inside this rank's shard
-    equal = len(set(shard_lens)) == 1
     assert equal or world == 1 or P == 1, "pipelined gather needs equal shards"
     full = torch.empty((N, sum(shard_lens)), dtype=torch.float64, device=dev)  # (shapes x all time steps)
     piece = [torch.empty((N, pe[i + 1] - pe[i]), dtype=torch.float64, device=dev) for i in range(P)]
-    collective = parts > 1 or (a.debug_rccl_self and dist is not None)
     gbuf = [torch.empty((parts, N, pe[i + 1] - pe[i]), dtype=torch.float64, device=dev) for i in range(P)] if collective else None
+    if overlap:
+        piece2 = [piece, [torch.empty_like(t) for t in piece]]
+        gbuf2 = [gbuf, [torch.empty_like(t) for t in gbuf]]
+        side = torch.cuda.Stream(device=dev)
+        placed = [[None] * P, [None] * P]  # event: the placement copy that last read (piece, gather)[parity][i] is done
+        step_no = [0]
     cube_ptrs = {k: getattr(pin, k) for k in ("d_influx_direct", "d_influx_diffuse", "d_influx_toa", "d_albedo",
                                               "d_temperature", "d_solar_altitude", "d_solar_azimuth")}
     tab_ptrs = {k: getattr(pin, k) for k in ("d_sin_dec", "d_cos_dec", "d_hour_angle", "d_cos_hour_angle")}
@@ -308,6 +322,22 @@ def main():
                 launch(pp, i, full[:, pe[i]:pe[i + 1]] if P == 1 else piece[i])
                 if P > 1:
                     full[:, pe[i]:pe[i + 1]].copy_(piece[i])
+            return full
+        if overlap:
+            par = step_no[0] & 1
+            step_no[0] += 1
+            main = torch.cuda.current_stream()
+            for i in range(P):
+                if placed[par][i] is not None:
+                    main.wait_event(placed[par][i])  # two steps back: long done, costs nothing
+                launch(pp, i, piece2[par][i])
+                w = dist.all_gather_into_tensor(gbuf2[par][i].view(-1), piece2[par][i].view(-1), async_op=True)
+                with torch.cuda.stream(side):
+                    w.wait()  # the side stream waits for the collective; the main stream goes on to the next launch
+                    full3[:, :, pe[i]:pe[i + 1]].copy_(gbuf2[par][i].permute(1, 0, 2))
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    placed[par][i] = ev
             return full
         works = []
         for i in range(P):
@@ -402,7 +432,8 @@ def main():
                         f"aggregate_time=None, " + ("stored solar angles (7 cubes)" if cfg["stored_angles"]
                                                     else "in-kernel solar position (5 cubes)") +
                         "; timed call = atl_pv_convert_aggregate (C ABI) on a prebuilt plan, result left in HBM",
-            "parallelism": f"time-sharded x{world}" + (f" + RCCL all-gather, {P} pipelined piece(s) per step" if world > 1 else ""),
+            "parallelism": f"time-sharded x{world}" + (f" + RCCL all-gather, {P} pipelined piece(s) per step" if world > 1 else "") +
+                           (", gather + placement of a step behind the next step's kernel" if overlap and world > 1 else ""),
             "time_steps_per_gpu": T_loc,
             "night_skip": bool(a.night_skip),
             "cell_tile": f"{plan_info['tile_w']}x{plan_info['tile_h']}",
