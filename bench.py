@@ -16,9 +16,12 @@ cutout (inputs resident in HBM), producing the (shapes x time) result on every r
 N > 1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling by default - the fixed
 workload's time axis is cut into N contiguous shards (the reference's own parallel axis: time chunks,
 atlite/cutout.py:143, aggregate.py:21-32), each rank converts + aggregates its shard and an RCCL
-all-gather over xGMI reassembles the (shapes x time) result on every rank, inside the timed step.
-``--pipeline P`` cuts a rank's shard into P sub-launches so that the all-gather of one piece overlaps
-the kernel of the next.  ``--scaling weak`` gives every rank a whole 8760-step year instead.
+all-gather over xGMI reassembles the (shapes x time) result on every rank, inside the timed region:
+a step's all-gather and placement copy run behind the NEXT step's kernel (double-buffered, ordered by
+events; the region ends with a device-wide synchronize, so the last step's result is in place when the
+clock stops).  ``--no-step-overlap`` finishes every step before the next starts; ``--pipeline P`` cuts a
+rank's shard into P sub-launches so that the all-gather of one piece overlaps the kernel of the next.
+``--scaling weak`` gives every rank a whole 8760-step year instead.
 
 Prints ONE JSON line on rank 0.  At N = 1 (config c2) the line also carries: the same workload with
 the night early-out (the Python API's default), with BASELINE's overlapping star-convex polygons, the
