@@ -197,6 +197,10 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     ns = {"C": C}
     exec(doc[doc.index("class PvInputs(C.Structure)"):doc.index("class Ctx:")], ns)
     assert C.sizeof(ns["PvInputs"]) == C.sizeof(_lib.PvInputs) and C.sizeof(ns["PvParams"]) == C.sizeof(_lib.PvParams)
+    for name in ("PvInputs", "PvParams"):  # sizeof alone hides a trailing int inside the padding
+        mine, doc_st = getattr(_lib, name), ns[name]
+        assert [f[0] for f in doc_st._fields_] == [f[0] for f in mine._fields_], name
+        assert all(getattr(doc_st, f[0]).offset == getattr(mine, f[0]).offset for f in mine._fields_), name
 
 
 def test_tile_geometry_selfcheck():
