@@ -184,12 +184,12 @@ __global__ __launch_bounds__(256, min_waves<Conv>()) void k_cells_night(Conv con
     const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
     const int64_t s0 = int64_t(blockIdx.y) * chunk_len;
     const int64_t s1 = min(s0 + chunk_len, n_slots);
-    if (s0 >= s1) return;
     double2 acc = {0.0, 0.0};
     int cnt0 = 0, cnt1 = 0;  // slots per chunk fit an int
     double2 key[kBatch];
+    const bool any = s0 < s1;  // an empty time axis still writes its (0, 0) partials
 #pragma unroll
-    for (int i = 0; i < kBatch; ++i) key[i] = v0 ? conv.template key_load<VEC>(min(s0 + i, s1 - 1), s0c, s1c, cell) : double2{0.0, 0.0};
+    for (int i = 0; i < kBatch; ++i) key[i] = (v0 && any) ? conv.template key_load<VEC>(min(s0 + i, s1 - 1), s0c, s1c, cell) : double2{0.0, 0.0};
     for (int64_t sb = s0; sb < s1; sb += kBatch) {
         unsigned day = 0;
 #pragma unroll

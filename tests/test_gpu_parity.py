@@ -213,6 +213,16 @@ def test_empty_and_degenerate_shapes(ctx):
     assert E.shape == (3, 0)
     assert ctx.spmm(ctx.plan(M), ctx.upload(np.zeros((0, 40))), time_agg="sum").numpy().tolist() == [0.0, 0.0, 0.0]
     assert np.isnan(ctx.spmm(ctx.plan(M), ctx.upload(np.zeros((0, 40))), time_agg="mean").numpy()).all()
+    # ... also for the per-cell pv kernels, with and without the night early-out
+    ds0 = {k: ctx.upload(np.zeros((0, 40))) for k in H.pv_dataset(1, 5, 8)}
+    for skip in (False, True):
+        opt = dict(night_skip=skip, row_len=8)
+        assert ctx.pv(ds0, PV_PARAMS, 0, 40, options=opt).numpy().shape == (0, 40)
+        assert (ctx.pv(ds0, PV_PARAMS, 0, 40, time_agg="sum", options=opt).numpy() == 0.0).all()
+        assert np.isnan(ctx.pv(ds0, PV_PARAMS, 0, 40, time_agg="mean", options=opt).numpy()).all()
+        pl = ctx.plan(M, row_len=8)
+        assert ctx.pv(ds0, PV_PARAMS, 0, 40, plan=pl, options=opt).numpy().shape == (3, 0)
+        assert ctx.pv(ds0, PV_PARAMS, 0, 40, plan=pl, time_agg="sum", options=opt).numpy().tolist() == [0.0, 0.0, 0.0]
     # single cell, single step; chunk tails (T not a multiple of 8 / 64)
     for T, S in ((1, 1), (1, 2), (7, 3), (65, 130), (129, 64)):
         D = rng.standard_normal((T, S))
