@@ -755,7 +755,8 @@ def convert_and_aggregate(
         matrix = sp.csr_matrix(matrix)
 
     if shapes is not None:
-        if isinstance(shapes, pd.Series) and index is None:
+        # pandas Series / GeoSeries / GeoDataFrame-like: the result is labelled with their index (convert.py:236-238)
+        if index is None and isinstance(getattr(shapes, "index", None), pd.Index):
             index = shapes.index
         matrix = sp.csr_matrix(cutout.indicatormatrix(shapes, shapes_crs))
 

@@ -34,6 +34,22 @@ def _rings_of(shape):
             out.append((np.asarray(p.exterior.coords, dtype=np.float64)[:, :2], False))
             out += [(np.asarray(h.coords, dtype=np.float64)[:, :2], True) for h in p.interiors]
         return out
+    if not isinstance(shape, dict) and hasattr(shape, "__geo_interface__"):  # any geometry that speaks GeoJSON
+        shape = shape.__geo_interface__
+    if isinstance(shape, dict) and "coordinates" in shape:  # GeoJSON Polygon / MultiPolygon (first ring = exterior)
+        kind = shape.get("type")
+        if kind == "Feature":
+            return _rings_of(shape["geometry"])
+        if kind not in ("Polygon", "MultiPolygon"):
+            raise ValueError(f"GeoJSON geometry of type {kind!r} is not a polygon")
+        polys = [shape["coordinates"]] if kind == "Polygon" else shape["coordinates"]
+        out = []
+        for rings in polys:
+            for k, ring in enumerate(rings):
+                out.append((np.asarray(ring, dtype=np.float64)[:, :2], k > 0))
+        return out
+    if isinstance(shape, dict) and shape.get("type") == "Feature":
+        return _rings_of(shape["geometry"])
     if isinstance(shape, dict):
         out = [(np.asarray(shape["exterior"], dtype=np.float64), False)]
         out += [(np.asarray(h, dtype=np.float64), True) for h in shape.get("holes", ())]
@@ -47,8 +63,8 @@ def _rings_of(shape):
             return out
     a = np.asarray(shape, dtype=np.float64)
     if a.ndim != 2 or a.shape[1] != 2:
-        raise ValueError("a shape must be an (n, 2) vertex array, a dict(exterior=, holes=), "
-                         "a list of those, or a shapely polygon")
+        raise ValueError("a shape must be an (n, 2) vertex array, a dict(exterior=, holes=), a GeoJSON Polygon / "
+                         "MultiPolygon mapping, a list of those, or a shapely polygon")
     return [(a, False)]
 
 
@@ -71,6 +87,8 @@ def compute_indicatormatrix(x, y, shapes, ctx=None, cache=None):
     dy = float(y[1] - y[0]) if Y > 1 else 1.0
     if dx <= 0 or dy <= 0:
         raise ValueError("grid coordinates must be ascending")
+    if hasattr(shapes, "geometry") and not isinstance(shapes, (dict, np.ndarray)):  # GeoDataFrame-like (atlite/gis.py:127)
+        shapes = shapes.geometry
     shapes = list(shapes.values) if hasattr(shapes, "values") and not isinstance(shapes, np.ndarray) else list(shapes)
     shape_ptr, ring_ptr, holes, xy = [0], [0], [], []
     for s in shapes:

@@ -296,6 +296,21 @@ def test_config1_wind_tiny_rectangle():
     close(r.values, ref)
     close(cap.values, refcap)
 
+    # the same shape as a GeoDataFrame-like frame of GeoJSON-speaking geometries: labelled with the frame's index
+    class Geom:
+        def __init__(self, ring):
+            self.__geo_interface__ = {"type": "Polygon", "coordinates": [np.vstack([ring, ring[:1]]).tolist()]}
+
+    class Frame:
+        def __init__(self, geoms, index):
+            self.geometry = pd.Series(geoms, index=index)
+            self.index = self.geometry.index
+
+    r2 = c.wind(turbine="Vestas_V112_3MW", shapes=Frame([Geom(rect)], pd.Index(["box"], name="region")), per_unit=True,
+                aggregate_time=None)
+    assert r2.dims == ("region", "time")
+    np.testing.assert_array_equal(r2.values, r.values)
+
 
 def test_pv_in_kernel_solar_position():
     """Datasets without stored solar angles: SolarPosition's compute branch

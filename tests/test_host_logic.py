@@ -518,3 +518,37 @@ def test_cutout_descriptive_properties_and_layout_helpers():
     assert c.equals(other) and c.equals(c)
     other.data["temperature"].values[0, 0, 0] += 1.0
     assert not c.equals(other) and c.equals(3) is NotImplemented
+
+
+def test_shapes_as_geojson_and_geodataframe_like():
+    """Shapes may come as GeoJSON Polygon / MultiPolygon mappings, Features, objects with __geo_interface__ (what
+    shapely / geopandas geometries expose) or a GeoDataFrame-like object with .geometry and .index
+    (atlite/gis.py:127, convert.py:236-238) - the same matrix as the plain vertex arrays."""
+    import pandas as pd
+
+    from atlite_amd import gis
+
+    x, y = np.linspace(0.0, 9.0, 10), np.linspace(50.0, 55.0, 6)
+    outer = np.array([[1.2, 50.6], [6.7, 50.9], [7.4, 54.1], [2.0, 53.8]])
+    hole = np.array([[3.0, 51.5], [4.5, 51.6], [4.4, 52.9], [3.1, 52.7]])
+    tri = np.array([[7.5, 50.0], [9.4, 50.2], [8.8, 52.0]])
+    ref = gis.compute_indicatormatrix(x, y, [dict(exterior=outer, holes=[hole]), [outer, tri], tri]).toarray()
+    closed = lambda r: np.vstack([r, r[:1]]).tolist()  # noqa: E731  (GeoJSON rings repeat their first vertex)
+    gj = [{"type": "Polygon", "coordinates": [closed(outer), closed(hole)]},
+          {"type": "MultiPolygon", "coordinates": [[closed(outer)], [closed(tri)]]},
+          {"type": "Feature", "properties": {}, "geometry": {"type": "Polygon", "coordinates": [closed(tri)]}}]
+    np.testing.assert_allclose(gis.compute_indicatormatrix(x, y, gj).toarray(), ref, rtol=0, atol=1e-14)
+
+    class Geom:
+        def __init__(self, m):
+            self.__geo_interface__ = m
+
+    class Frame:  # the two attributes the gateway reads off a GeoDataFrame
+        def __init__(self, geoms, index):
+            self.geometry = pd.Series(geoms, index=index)
+            self.index = self.geometry.index
+
+    frame = Frame([Geom(m) for m in gj], pd.Index(["a", "b", "c"], name="region"))
+    np.testing.assert_allclose(gis.compute_indicatormatrix(x, y, frame).toarray(), ref, rtol=0, atol=1e-14)
+    with pytest.raises(ValueError, match="not a polygon"):
+        gis.compute_indicatormatrix(x, y, [{"type": "LineString", "coordinates": [[0, 0], [1, 1]]}])
