@@ -757,14 +757,13 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
             else
                 hipLaunchKernelGGL((k_cells_night<Conv, false, true>), gridn, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
                                    len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)), tX, tY, ntx);
-            return check_launch(what);
-        }
-        if (vec)
+        } else if (vec) {  // (else: the early-out converters do not instantiate the plain series kernel)
             hipLaunchKernelGGL((k_cells_series<Conv, true>), grid, dim3(256), lds_bytes, ctx->stream, conv,
                                n_slots, S, d_out);
-        else
+        } else {
             hipLaunchKernelGGL((k_cells_series<Conv, false>), grid, dim3(256), lds_bytes, ctx->stream, conv,
                                n_slots, S, d_out);
+        }
         return check_launch(what);
     }
     // time-reduced: split the slot axis so that the grid fills the chip
