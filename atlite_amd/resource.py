@@ -73,6 +73,25 @@ def get_solarpanelconfig(panel):
         return yaml.safe_load(f)
 
 
+def solarpanel_rated_capacity_per_unit(panel):
+    """Rated capacity of one unit of a capacity layout (atlite/resource.py:204-217): the panel efficiency per m^2 for the
+    Huld model, one panel's capacity for bofinger."""
+    if isinstance(panel, (str, Path)):
+        panel = get_solarpanelconfig(panel)
+    model = panel.get("model", "huld")
+    if model == "huld":
+        return panel["efficiency"]
+    if model == "bofinger":
+        return (panel["A"] + panel["B"] * 1000.0 + panel["C"] * np.log(1000.0)) * 1e3
+
+
+def windturbine_rated_capacity_per_unit(turbine):
+    """Rated power of one turbine in MW (atlite/resource.py:220-224)."""
+    if isinstance(turbine, (str, Path)):
+        turbine = get_windturbineconfig(turbine)
+    return turbine["P"]
+
+
 def _max_v_is_zero_pow(turbine):
     return np.any(turbine["POW"][turbine["V"] == turbine["V"].max()] == 0)
 

@@ -552,3 +552,13 @@ def test_shapes_as_geojson_and_geodataframe_like():
     np.testing.assert_allclose(gis.compute_indicatormatrix(x, y, frame).toarray(), ref, rtol=0, atol=1e-14)
     with pytest.raises(ValueError, match="not a polygon"):
         gis.compute_indicatormatrix(x, y, [{"type": "LineString", "coordinates": [[0, 0], [1, 1]]}])
+
+
+def test_rated_capacity_helpers():
+    """resource.solarpanel_rated_capacity_per_unit / windturbine_rated_capacity_per_unit (atlite/resource.py:204-224)."""
+    from atlite_amd import resource as r
+
+    assert r.solarpanel_rated_capacity_per_unit("CSi") == r.get_solarpanelconfig("CSi")["efficiency"] == 0.1
+    k = r.get_solarpanelconfig("KANENA")
+    assert r.solarpanel_rated_capacity_per_unit(k) == (k["A"] + k["B"] * 1000.0 + k["C"] * np.log(1000.0)) * 1e3
+    assert r.windturbine_rated_capacity_per_unit("Vestas_V112_3MW") == r.get_windturbineconfig("Vestas_V112_3MW")["P"]
