@@ -9,7 +9,9 @@ HIP kernels + C ABI: ``atlite_amd/csrc`` -> ``atlite_amd/lib/libatlite_hip.so``
 
 from .cutout import Cutout
 from .labeled import Dataset, LabeledArray
+from .gis import compute_indicatormatrix
 from .multigpu import set_devices
+from .resource import solarpanels, windturbines
 
 __version__ = "0.1.0"
-__all__ = ["Cutout", "Dataset", "LabeledArray", "set_devices"]
+__all__ = ["Cutout", "Dataset", "LabeledArray", "set_devices", "compute_indicatormatrix", "solarpanels", "windturbines"]

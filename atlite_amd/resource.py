@@ -32,12 +32,63 @@ def _table():
     return _cache
 
 
-def windturbines():
-    return sorted(_table()["windturbine"])
+class _Catalogue(dict):
+    """The reference's ``atlite.windturbines`` / ``atlite.solarpanels`` (resource.py:514-515: an attribute-access dict
+    name -> yaml path, ``atlite.windturbines.Vestas_V112_3MW``).  Here the values are the names themselves - what
+    ``get_windturbineconfig`` / ``get_solarpanelconfig`` and the ``turbine=`` / ``panel=`` arguments take - filled on first
+    use from the one consolidated table; calling it lists the names."""
+
+    def __init__(self, kind):
+        super().__init__()
+        self._kind, self._full = kind, False
+
+    def _fill(self):
+        if not self._full:
+            self._full = True
+            for k in _table()[self._kind]:
+                dict.__setitem__(self, k, k)
+        return self
+
+    def __getattr__(self, item):
+        if item.startswith("_"):
+            raise AttributeError(item)
+        try:
+            return self._fill()[item]
+        except KeyError as e:
+            raise AttributeError(e.args[0])
+
+    def __missing__(self, key):
+        if not self._full and key in self._fill():
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def __call__(self):
+        return sorted(self._fill())
+
+    def __dir__(self):
+        return [k for k in self._fill() if k.isidentifier()]
+
+    def __iter__(self):
+        return dict.__iter__(self._fill())
+
+    def __len__(self):
+        return dict.__len__(self._fill())
+
+    def __contains__(self, key):
+        return dict.__contains__(self._fill(), key)
+
+    def keys(self):
+        return dict.keys(self._fill())
+
+    def values(self):
+        return dict.values(self._fill())
+
+    def items(self):
+        return dict.items(self._fill())
 
 
-def solarpanels():
-    return sorted(_table()["solarpanel"])
+windturbines = _Catalogue("windturbine")
+solarpanels = _Catalogue("solarpanel")
 
 
 def _strip_yaml(name):

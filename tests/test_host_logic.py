@@ -562,3 +562,22 @@ def test_rated_capacity_helpers():
     k = r.get_solarpanelconfig("KANENA")
     assert r.solarpanel_rated_capacity_per_unit(k) == (k["A"] + k["B"] * 1000.0 + k["C"] * np.log(1000.0)) * 1e3
     assert r.windturbine_rated_capacity_per_unit("Vestas_V112_3MW") == r.get_windturbineconfig("Vestas_V112_3MW")["P"]
+
+
+def test_turbine_and_panel_catalogues_like_the_reference():
+    """atlite.windturbines / atlite.solarpanels (resource.py:514-515): attribute and item access, iteration; the values
+    are what the turbine= / panel= arguments accept."""
+    import atlite_amd
+    from atlite_amd import resource
+
+    wt = atlite_amd.windturbines
+    assert wt is resource.windturbines and wt.Vestas_V112_3MW == wt["Vestas_V112_3MW"] == "Vestas_V112_3MW"
+    assert len(wt) == 30 and "Vestas_V112_3MW" in wt and sorted(wt) == wt() and "Vestas_V112_3MW" in dir(wt)
+    assert resource.get_windturbineconfig(wt.Vestas_V112_3MW)["P"] == 3.06
+    assert atlite_amd.solarpanels() == ["CSi", "CdTe", "KANENA"] and atlite_amd.solarpanels.KANENA == "KANENA"
+    assert resource.get_solarpanelconfig(atlite_amd.solarpanels.CSi)["efficiency"] == 0.1
+    with pytest.raises(AttributeError):
+        wt.no_such_turbine
+    with pytest.raises(KeyError):
+        wt["no_such_turbine"]
+    assert atlite_amd.compute_indicatormatrix is atlite_amd.gis.compute_indicatormatrix
