@@ -9,7 +9,7 @@ HIP kernels + C ABI: ``atlite_amd/csrc`` -> ``atlite_amd/lib/libatlite_hip.so``
 
 from .cutout import Cutout
 from .labeled import Dataset, LabeledArray
-from .gis import compute_indicatormatrix
+from .gis import indicatormatrix_of_grid as compute_indicatormatrix  # the reference's (orig, dest, orig_crs, dest_crs)
 from .multigpu import set_devices
 from .resource import solarpanels, windturbines
 

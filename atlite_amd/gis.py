@@ -197,3 +197,20 @@ def random_tessellation(n, bounds, seed=42):
             poly = np.asarray(out, dtype=np.float64).reshape(-1, 2)
         polys.append(poly)
     return polys
+
+
+def indicatormatrix_of_grid(orig, dest, orig_crs=4326, dest_crs=4326):
+    """``atlite.compute_indicatormatrix(orig, dest, orig_crs, dest_crs)`` (atlite/gis.py:104-145) for the case the hot
+    path uses: ``orig`` is a cutout's grid (``cutout.grid``: a frame with the cell centres in columns 'x' and 'y', cells
+    in y-major order), ``dest`` the shapes.  Other collections of polygons as ``orig`` and shapes in another crs are
+    outside this library (no polygon-polygon overlay, no pyproj)."""
+    if orig_crs != dest_crs:
+        raise NotImplementedError("reprojection of shapes needs pyproj; pass shapes in the grid's crs")
+    cols = getattr(orig, "columns", ())
+    if "x" not in cols or "y" not in cols:
+        raise NotImplementedError("orig must be a cutout grid frame with 'x' and 'y' columns (Cutout.grid)")
+    gx, gy = np.asarray(orig["x"], dtype=np.float64), np.asarray(orig["y"], dtype=np.float64)
+    x, y = np.unique(gx), np.unique(gy)
+    if len(x) * len(y) != len(gx) or not (np.array_equal(gx, np.tile(x, len(y))) and np.array_equal(gy, np.repeat(y, len(x)))):
+        raise NotImplementedError("orig is not a regular y-major grid of cell centres")
+    return compute_indicatormatrix(x, y, dest)

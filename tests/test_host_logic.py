@@ -580,4 +580,16 @@ def test_turbine_and_panel_catalogues_like_the_reference():
         wt.no_such_turbine
     with pytest.raises(KeyError):
         wt["no_such_turbine"]
-    assert atlite_amd.compute_indicatormatrix is atlite_amd.gis.compute_indicatormatrix
+    # atlite.compute_indicatormatrix(cutout.grid, shapes) - the reference's calling convention
+    from atlite_amd import Cutout, Dataset, gis
+    import pandas as pd
+
+    x, y = np.linspace(0.0, 4.0, 5), np.linspace(40.0, 42.0, 3)
+    c = Cutout(Dataset({"temperature": np.zeros((2, 3, 5))}, dict(time=pd.date_range("2013-01-01", periods=2, freq="h"), y=y, x=x)))
+    tri = np.array([[0.2, 39.8], [3.7, 40.3], [1.9, 42.2]])
+    a = atlite_amd.compute_indicatormatrix(c.grid, [tri])
+    np.testing.assert_array_equal(a.toarray(), gis.compute_indicatormatrix(x, y, [tri]).toarray())
+    with pytest.raises(NotImplementedError):
+        atlite_amd.compute_indicatormatrix(c.grid, [tri], 4326, 3035)
+    with pytest.raises(NotImplementedError):
+        atlite_amd.compute_indicatormatrix(c.grid.iloc[::-1], [tri])
