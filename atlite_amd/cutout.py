@@ -156,6 +156,22 @@ class Cutout:
         np.add.at(out, (iy, ix), np.asarray(data[col], dtype=np.float64))
         return self._layout(out, name=col)
 
+    def sel(self, path=None, bounds=None, buffer=0, **kwargs):
+        """Select parts of the cutout (cutout.py:387-414): ``bounds`` = (x1, y1, x2, y2) with an optional ``buffer``
+        around them, and / or label selections along time, y, x as for ``xarray.Dataset.sel`` (``Dataset.sel``).
+        Returns a new Cutout; nothing is written (``path`` only names it)."""
+        if bounds is not None:
+            x1, y1, x2, y2 = (float(b) for b in bounds)
+            if buffer > 0:  # shapely's box(*bounds).buffer(buffer).bounds: the box grown by the buffer on every side
+                x1, y1, x2, y2 = x1 - buffer, y1 - buffer, x2 + buffer, y2 + buffer
+            kwargs.update(x=slice(x1, x2), y=slice(y1, y2))
+        out = Cutout(self.data.sel(**kwargs), crs=self.crs, devices=self.devices)
+        if path is not None:
+            out.path = os.fspath(path)
+        elif getattr(self, "path", None):
+            out.path = self.path
+        return out
+
     def equals(self, other):
         """Same coordinates and variables, value by value (NaN == NaN); the path is ignored (cutout.py:587-594)."""
         if not isinstance(other, Cutout):

@@ -271,6 +271,58 @@ class Dataset:
             out.file = self.file
         return out
 
+    def sel(self, **indexers):
+        """
+        Label-based selection along ``time`` / ``y`` / ``x`` like ``xarray.Dataset.sel`` for what cutouts are cut
+        with (atlite/cutout.py:387-414): a ``slice`` of labels (both ends inclusive), a single label, or a sequence
+        of labels.  A contiguous time range stays a view (device arrays and file-backed variables included); spatial
+        selections and scattered time steps copy - device-resident variables come back as host arrays then.
+        """
+        unknown = set(indexers) - {"time", "y", "x"}
+        if unknown:
+            raise KeyError(f"cannot select along {sorted(unknown)}: a cutout has time, y and x")
+        pos = {}
+        for dim, ix in indexers.items():
+            idx = pd.Index(self.coords[dim])
+            if isinstance(ix, slice):
+                if ix.step not in (None, 1):
+                    raise NotImplementedError("label slices with a step")
+                lo, hi = idx.slice_locs(ix.start, ix.stop)
+                pos[dim] = np.arange(lo, hi)
+            elif np.ndim(ix) == 0 or isinstance(ix, str):
+                loc = idx.get_loc(ix)  # (a date string selects its whole period, like pandas / xarray)
+                pos[dim] = np.arange(loc.start, loc.stop) if isinstance(loc, slice) else np.atleast_1d(np.arange(len(idx))[loc])
+            else:
+                want = pd.DatetimeIndex(ix) if dim == "time" else pd.Index(np.asarray(ix, dtype=np.float64))
+                loc = idx.get_indexer(want)
+                if (loc < 0).any():
+                    raise KeyError(f"not all values found in index {dim!r}")
+                pos[dim] = loc
+        out = self
+        tp = pos.pop("time", None)
+        if tp is not None:
+            contiguous = len(tp) > 0 and np.array_equal(tp, np.arange(tp[0], tp[0] + len(tp)))
+            if contiguous or len(tp) == 0:
+                out = out.isel_time(int(tp[0]) if len(tp) else 0, int(tp[0]) + len(tp) if len(tp) else 0)
+                tp = None
+        if tp is None and not pos:
+            return out
+        coords = dict(out.coords)
+        for dim, p in ([("time", tp)] if tp is not None else []) + list(pos.items()):
+            coords[dim] = out.coords[dim][p]
+            for alias, of in (("lon", "x"), ("lat", "y")):
+                if of == dim and alias in coords:
+                    coords[alias] = coords[dim]
+        new = Dataset({}, coords, out.attrs, chunked=out.chunked)
+        for k, la in out._vars.items():
+            v = np.asarray(la.data.numpy() if _is_device(la.data) else la.data)
+            for ax, dim in enumerate(la.dims):
+                p = tp if dim == "time" else pos.get(dim)
+                if p is not None:
+                    v = np.take(v, p, axis=ax)
+            new[k] = LabeledArray(np.ascontiguousarray(v), la.dims, attrs=la.attrs, name=la.name)
+        return new
+
     def pin(self):
         """Page-lock the host arrays in place so that the slab pipeline (atlite_amd.streaming) DMAs
         them at PCIe rate without re-registering on every call.  Undone by ``unpin()`` / deletion."""

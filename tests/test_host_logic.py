@@ -593,3 +593,38 @@ def test_turbine_and_panel_catalogues_like_the_reference():
         atlite_amd.compute_indicatormatrix(c.grid, [tri], 4326, 3035)
     with pytest.raises(NotImplementedError):
         atlite_amd.compute_indicatormatrix(c.grid.iloc[::-1], [tri])
+
+
+def test_cutout_sel_time_and_space():
+    """Cutout.sel (cutout.py:387-414): label slices are inclusive on both ends like xarray's, a contiguous time range is
+    a view, lists of snapshots and spatial windows copy; bounds + buffer; unknown labels raise KeyError."""
+    import pandas as pd
+
+    from atlite_amd import Cutout, Dataset
+
+    x, y = np.linspace(5.0, 8.0, 13), np.linspace(47.0, 49.0, 9)
+    t = pd.date_range("2013-01-01", periods=72, freq="h")
+    rng = np.random.default_rng(0)
+    temp, height = rng.random((72, 9, 13)), rng.random((9, 13))
+    c = Cutout(Dataset({"temperature": temp, "height": height}, dict(time=t, y=y, x=x), attrs={"module": "era5"}))
+    a = c.sel(time=slice("2013-01-02", "2013-01-02 23:00"))
+    assert list(a.coords["time"]) == list(t[24:48]) and a.data["height"].values is not None
+    assert np.shares_memory(np.asarray(a.data["temperature"].values), temp)  # a view
+    np.testing.assert_array_equal(a.data["temperature"].values, temp[24:48])
+    assert len(c.sel(time="2013-01-03").coords["time"]) == 24  # a day string selects the day, like pandas / xarray
+    snaps = t[::7]
+    b = c.sel(time=snaps)
+    np.testing.assert_array_equal(b.data["temperature"].values, temp[::7])
+    assert list(b.coords["time"]) == list(snaps) and b.data.attrs["module"] == "era5"
+    w = c.sel(x=slice(5.5, 6.75), y=slice(47.25, 48.0))
+    assert w.shape == (4, 6) and w.coords["x"][0] == 5.5 and w.coords["x"][-1] == 6.75 and w.coords["lon"][0] == 5.5
+    np.testing.assert_array_equal(w.data["temperature"].values, temp[:, 1:5, 2:8])
+    np.testing.assert_array_equal(w.data["height"].values, height[1:5, 2:8])
+    bb = c.sel(bounds=(6.0, 47.5, 6.5, 48.0), buffer=0.25, time=slice(t[3], t[10]))
+    np.testing.assert_array_equal(bb.data["temperature"].values, temp[3:11, 1:6, 3:8])
+    assert bb.dx == 0.25 and np.allclose(bb.bounds, [5.625, 47.125, 6.875, 48.375])
+    with pytest.raises(KeyError):
+        c.sel(time=[pd.Timestamp("2014-01-01")])
+    with pytest.raises(KeyError):
+        c.sel(level=3)
+    assert c.sel(time=slice("2015", "2016")).data.sizes["time"] == 0
