@@ -1,6 +1,6 @@
 // Light converters: identity (generic aggregate_matrix), runoff, temperature family / COP, heat and
 // cooling demand.  Reference: atlite/convert.py:292-418, 475-490, 1028-1034; aggregate.py:16-35.
-// Part of libatlite_hip.so (gfx950); included by atl_kernels.hip inside its anonymous namespace.
+// Part of libatlite_hip.so (gfx950); included through atl_kernel_templates.h by every kernel file, inside its anonymous namespace.
 #pragma once
 
 // ---------------------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 // Solar converters: fast pv path (stored or in-kernel solar position, night early-out) and the
 // general kernel (tracking, Hay-Davies, Reindl, bofinger, irradiation, solar thermal).
 // Reference: atlite/convert.py:550-574, 748-767, 840-854; atlite/pv/*.py.
-// Part of libatlite_hip.so (gfx950); included by atl_kernels.hip inside its anonymous namespace.
+// Part of libatlite_hip.so (gfx950); included by the pv kernel files (atl_kernels_pv*.hip) and atl_runtime.cpp (host probes) inside their anonymous namespace.
 #pragma once
 
 // solar PV, ERA5-shaped inputs with stored solar position

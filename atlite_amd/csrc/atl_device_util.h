@@ -1,6 +1,6 @@
 // Device helpers shared by all converters: numpy-compatible NaN semantics, unconditional nontemporal
 // loads / stores of a lane's two cells, per-wave carry state.
-// Part of libatlite_hip.so (gfx950); included by atl_kernels.hip inside its anonymous namespace.
+// Part of libatlite_hip.so (gfx950); included through atl_kernel_templates.h by every kernel file, inside its anonymous namespace.
 #pragma once
 
 // ---------------------------------------------------------------------------------------

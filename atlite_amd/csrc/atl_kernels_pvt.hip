@@ -1,7 +1,7 @@
 // The fast pv kernel family's tails other than the Huld panel: the bofinger panel (pv(panel="KANENA")), the solar
 // thermal collector (solar_thermal()) and the plain tilted irradiation (irradiation()), each after the simple or the
 // Hay-Davies ("other") trigon model, fixed panel or (bofinger, irradiation) one of the four trackers, stored solar angles.  Same PvConvT template as atl_kernels_pv.hip;
-// a translation unit of its own so that the four kernel files compile in parallel.
+// a translation unit of its own so that the kernel files compile in parallel.
 // Reference arithmetic: atlite/convert.py:550-574, 748-767; atlite/pv/irradiation.py:76-145, 214-255;
 // atlite/pv/solar_panel_model.py:47-74.
 #include "atl_kernel_templates.h"
