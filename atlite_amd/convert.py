@@ -314,7 +314,7 @@ class _WindSpec(_Spec):
     attrs = {"units": "MWh/MWp"}
 
     def __init__(self, ds, turbine, interpolation_method):
-        self.V = np.asarray(turbine["V"], dtype=np.float64)
+        self.V = None if turbine["V"] is None else np.asarray(turbine["V"], dtype=np.float64)
         self.POWn = np.asarray(turbine["POW"] / turbine["P"], dtype=np.float64)  # convert.py:649
         to_height = turbine["hub_height"]
         # extrapolate_wind_speed, atlite/wind.py:75-117
@@ -358,6 +358,26 @@ class _WindSpec(_Spec):
         aux = ds.device(ctx, self.aux) if self.aux else None
         return ctx.wind(wnd, aux, self.V, self.POWn, self.to_height, self.from_height, self.method, T, S,
                         plan=plan, time_agg=time_agg, out=out)
+
+
+class _WindSpeedSpec(_WindSpec):
+    """extrapolate_wind_speed as an operation of its own (atlite/wind.py:23-125): the wind converter without a power
+    curve (atl_wind_params.n_knots = 0)."""
+
+    attrs = {"units": "m s**-1"}
+
+    def __init__(self, ds, to_height, from_height=None, method="logarithmic"):
+        if from_height is not None:  # a given source height replaces the "closest height" rule
+            if f"wnd{int(from_height):0d}m" not in ds:
+                raise KeyError(f"wnd{int(from_height):0d}m")
+            ds = {k: None for k in ds if not re.match(r"wnd\d+m", k) or k == f"wnd{int(from_height):0d}m"}
+        super().__init__(ds, dict(V=None, POW=np.zeros(0), P=1.0, hub_height=to_height), method)
+        self.V = self.POWn = None
+        self.name = f"wnd{int(to_height):0d}m"
+        if self.method is not None:
+            desc = "logarithmic method with roughness" if self.method == "logarithmic" else "power method with wind shear exponent"
+            self.attrs = {"long name": f"extrapolated {to_height} m wind speed using {desc}  and {int(self.from_height)} m wind speed",
+                          "units": "m s**-1"}
 
 
 class _ThermoSpec(_Spec):

@@ -24,6 +24,9 @@
 // STEPS = kWindGrid: grid-aligned knots (integer / half-integer ... wind speeds, which is what nearly every
 // shipped power curve has): the interval comes from one bucket lookup, no search (interp_grid, atl_math.h).
 constexpr int kWindGrid = -1;
+// STEPS = kWindIdentity: no power curve at all (atl_wind_params.n_knots == 0): the converter's output is the
+// extrapolated wind speed itself - atlite.wind.extrapolate_wind_speed (wind.py:76-112) as an operation of its own
+constexpr int kWindIdentity = -2;
 // Out-of-line rare paths are FREE functions taking scalars by value: a __noinline__ member function
 // needs `this`, i.e. the whole converter struct spilled to a scratch frame by every thread at kernel
 // entry (80 B/lane of extra HBM writes in round 1's wind kernels).
@@ -114,7 +117,9 @@ struct WindConvT {
         }
     }
     ATL_HD __forceinline__ double interp(double x, const double *lds) const {  // atl_math.h (shared with the host probe)
-        if constexpr (STEPS == kWindGrid)
+        if constexpr (STEPS == kWindIdentity)
+            return x;
+        else if constexpr (STEPS == kWindGrid)
             return interp_grid(lds, vmin, vmax, inv_w, b0, x);
         else
             return interp_padded<STEPS>(lds, n_knots, n_pad, x);

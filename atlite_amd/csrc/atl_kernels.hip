@@ -128,6 +128,26 @@ int make_wind(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p,
                 "Interpolation method must be 'logarithmic' or 'power' (got code %d)", p->method);
     ATL_REQUIRE(p->method == ATL_WIND_NONE || in->d_aux,
                 "atl_wind: method needs roughness / wnd_shear_exp (wind.py:94-98,106-110)");
+    if (p->n_knots == 0) {  // no power curve: the extrapolated wind speed itself (wind.py:76-112)
+        ATL_REQUIRE(p->method == ATL_WIND_NONE || (p->to_height > 0 && p->from_height > 0 && std::isfinite(p->to_height) &&
+                                                    std::isfinite(p->from_height)),
+                    "atl_wind: heights must be positive and finite");
+        c->wnd = in->d_wnd;
+        c->aux = in->d_aux;
+        c->S = S;
+        c->aux_static = in->aux_is_static;
+        c->method = (p->method == ATL_WIND_POWER && p->to_height == p->from_height) ? ATL_WIND_NONE : p->method;
+        c->to_height = p->to_height;
+        c->from_height = p->from_height;
+        c->log_ratio = log(p->to_height / p->from_height);
+        c->table = nullptr;
+        c->n_knots = c->n_pad = c->tab_doubles = c->b0 = 0;
+        c->vmin = c->vmax = c->inv_w = 0.0;
+        *table_finite = true;
+        *lds_bytes = size_t(2 * kLogTabN) * sizeof(double);
+        *vec = vec_ok(S, {in->d_wnd, in->aux_is_static ? nullptr : in->d_aux});
+        return ATL_OK;
+    }
     ATL_REQUIRE(p->n_knots >= 1 && p->n_knots <= kMaxKnots && p->h_V && p->h_POWn,
                 "atl_wind: power curve needs 1..%d knots", kMaxKnots);
     std::vector<double> tbl;
@@ -224,6 +244,13 @@ int wind_dispatch(const WindConvT<-1> &g, bool finite, F &&f) {
     // the fast log-law path also needs positive, finite heights (their logs are taken once)
     const bool heights_ok = g.to_height > 0 && g.from_height > 0 && std::isfinite(g.to_height) &&
                             std::isfinite(g.from_height);
+    if (g.n_knots == 0) {  // no power curve (make_wind has checked the heights)
+        switch (g.method) {
+            case ATL_WIND_LOG: return f(wind_as<ATL_WIND_LOG, kWindIdentity>(g));
+            case ATL_WIND_POWER: return f(wind_as<ATL_WIND_POWER, kWindIdentity>(g));
+            default: return f(wind_as<ATL_WIND_NONE, kWindIdentity>(g));
+        }
+    }
     if (!finite || (g.method == ATL_WIND_LOG && !heights_ok)) return f(g);
     // unrolled knot search for the usual table sizes (make_wind pads to 16 / 32 / 128 knots)
     auto sized = [&](auto method) {

@@ -887,6 +887,38 @@ int atl_wind_probe_host(const atl_wind_params *p, int64_t n, const double *h_wnd
     ATL_REQUIRE(p->method == ATL_WIND_NONE || p->method == ATL_WIND_LOG || p->method == ATL_WIND_POWER,
                 "Interpolation method must be 'logarithmic' or 'power' (got code %d)", p->method);
     ATL_REQUIRE(p->method == ATL_WIND_NONE || h_aux, "atl_wind_probe_host: method needs roughness / wnd_shear_exp");
+    if (p->n_knots == 0) {  // no power curve: the extrapolated wind speed (kWindIdentity, as make_wind / wind_dispatch)
+        ATL_REQUIRE(p->method == ATL_WIND_NONE || (p->to_height > 0 && p->from_height > 0 && std::isfinite(p->to_height) &&
+                                                    std::isfinite(p->from_height)),
+                    "atl_wind: heights must be positive and finite");
+        std::vector<double> lds0(2 * size_t(kLogTabN));
+        for (int i = 0; i < kLogTabN; ++i) log_table_entry(lds0.data(), i);
+        const int method0 = (p->method == ATL_WIND_POWER && p->to_height == p->from_height) ? ATL_WIND_NONE : p->method;
+        auto run0 = [&](auto conv) {
+            conv.wnd = h_wnd;
+            conv.aux = h_aux;
+            conv.S = n;
+            conv.aux_static = 0;
+            conv.method = method0;
+            conv.to_height = p->to_height;
+            conv.from_height = p->from_height;
+            conv.log_ratio = log(p->to_height / p->from_height);
+            conv.table = nullptr;
+            conv.n_knots = conv.n_pad = conv.tab_doubles = conv.b0 = 0;
+            conv.vmin = conv.vmax = conv.inv_w = 0.0;
+            const auto cell = conv.cell_setup(0, true, true, lds0.data());
+            for (int64_t i = 0; i < n; ++i) {
+                typename decltype(conv)::Raw q;
+                q.v.x = q.v.y = h_wnd[i];
+                q.z.x = q.z.y = h_aux ? h_aux[i] : 0.0;
+                h_out[i] = conv.compute(q, true, false, cell, lds0.data()).x;
+            }
+            return int(ATL_OK);
+        };
+        if (method0 == ATL_WIND_LOG) return run0(WindConvT<ATL_WIND_LOG, kWindIdentity>());
+        if (method0 == ATL_WIND_POWER) return run0(WindConvT<ATL_WIND_POWER, kWindIdentity>());
+        return run0(WindConvT<ATL_WIND_NONE, kWindIdentity>());
+    }
     ATL_REQUIRE(p->n_knots >= 1 && p->n_knots <= kMaxKnots && p->h_V && p->h_POWn, "atl_wind_probe_host: bad power curve");
     std::vector<double> tbl;
     bool finite = true;

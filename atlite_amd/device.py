@@ -355,8 +355,9 @@ class Context:
         return res
 
     def wind(self, wnd, aux, V, POWn, to_height, from_height, method, T, S, plan=None, time_agg=None, out=None):
-        V = np.ascontiguousarray(V, dtype=np.float64)
-        POWn = np.ascontiguousarray(POWn, dtype=np.float64)
+        """V / POWn: the power curve (POW / P); V = None: no power curve - the extrapolated wind speed itself."""
+        V = np.ascontiguousarray(V if V is not None else [], dtype=np.float64)
+        POWn = np.ascontiguousarray(POWn if POWn is not None else [], dtype=np.float64)
         win = _lib.WindInputs(
             wnd.ptr, aux.ptr if aux is not None else None, 1 if (aux is not None and aux.ndim == 1) else 0
         )

@@ -244,7 +244,8 @@ typedef struct {
 typedef struct {
     int method; /* ATL_WIND_* */
     double to_height, from_height;
-    int n_knots;          /* >= 1 */
+    int n_knots;          /* >= 1; 0 = no power curve: the output is the extrapolated wind speed
+                           * itself, atlite.wind.extrapolate_wind_speed (wind.py:76-112) */
     const double *h_V;    /* HOST (n_knots) ascending (ties allowed, resource.py:346-355) */
     const double *h_POWn; /* HOST (n_knots) POW / P */
 } atl_wind_params;

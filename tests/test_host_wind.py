@@ -82,3 +82,30 @@ def test_host_wind_against_oracle(method):
         assert e <= 1.0, (name, method, e)
         worst = max(worst, e)
     assert worst < 0.05
+
+
+@pytest.mark.parametrize("method", ["logarithmic", "power", None])
+def test_host_extrapolated_speed_without_a_power_curve(method):
+    """n_knots = 0: the converter's output is the extrapolated wind speed itself (atlite.wind.extrapolate_wind_speed,
+    wind.py:76-112) - ordinary data, hostile roughness / shear / speeds (zero, negative, NaN, inf, roughness at and
+    around the source height), several height pairs."""
+    rng = np.random.default_rng(5)
+    n = 20000
+    wnd = rng.gamma(2.0, 4.0, n)
+    if method == "logarithmic":
+        aux = 10.0 ** rng.uniform(-4, 0.5, n)
+    elif method == "power":
+        aux = rng.uniform(-0.1, 0.6, n)
+    else:
+        aux = None
+    for to_h, from_h in ((80.0, 100.0), (137.5, 100.0), (10.0, 100.0), (100.0, 100.0)):
+        w, a = wnd.copy(), None if aux is None else aux.copy()
+        w[:8] = [0.0, -3.0, np.nan, np.inf, 1e-300, 25.0, 1e6, 5.0]
+        if a is not None:
+            a[8:20] = [0.0, -1.0, np.nan, np.inf, from_h, np.nextafter(from_h, 0), np.nextafter(from_h, 1e9), to_h, 1e-320, 1e308, 1.0, 5e-324]
+        got = probe([], [], method, to_h, from_h, w, a)
+        ref = orc.extrapolate_wind_speed(w, a, to_h, from_h, method)
+        assert allowance_error(got, ref) <= 1.0, (method, to_h, from_h)
+    if method is not None:
+        with pytest.raises(ValueError, match="positive and finite"):
+            probe([], [], method, -5.0, 100.0, wnd[:4], aux[:4])

@@ -40,6 +40,10 @@ influx_ds = dict(influx=inputs["influx_direct"], influx_toa=inputs["influx_toa"]
                  temperature=inputs["temperature"], solar_altitude=inputs["solar_altitude"], solar_azimuth=inputs["solar_azimuth"])
 
 
+FILTER = [f for f in os.environ.get("ATL_VARIANTS", "").split("|") if f]  # substrings of the lines to run (default: all)
+REPS = int(os.environ.get("ATL_VARIANT_REPS", "5"))
+
+
 def timed(fn, reps=5):
     ctx.set_profiling(True)
     ms = []
@@ -94,12 +98,14 @@ for name, nbytes, fn in (
     ("per-cell time-mean (capacity factor map) + night early-out", 56, lambda: ctx.pv(inputs, scal, T, S, time_agg="mean", options=dict(night_skip=True, row_len=X))),
     ("per-cell time-mean, in-kernel solar position + early-out", 40, lambda: ctx.pv(five, scal, T, S, time_agg="mean", solar_tables=tables, options=dict(night_skip=True))),
 ):
-    ms, out = timed(fn)
+    if FILTER and not any(f in name for f in FILTER):
+        continue
+    ms, out = timed(fn, REPS)
     gbs = nbytes * T * S / (ms * 1e-3) / 1e9
     extra = ""
     if ref is None:
         ref = out.numpy()
-    elif "in-kernel" in name and "per-cell" not in name:
+    elif "in-kernel" in name and "per-cell" not in name and not FILTER:
         o = out.numpy()
         extra = f"  max rel diff vs getter {np.max(np.abs(o - ref) / np.maximum(np.abs(ref), 1e-12 * ref.max())):.1e}"
     print(f"{name:52s} {ms:8.3f} ms  {gbs:6.0f} GB/s ({nbytes} B/cell)  {T * S / (ms * 1e-3):.3e} cell-steps/s{extra}", flush=True)
