@@ -91,7 +91,9 @@ for name, nbytes, fn in (
     ("irradiation() + night early-out (r02)", 48, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none", night_skip=True))),
     ("solar_thermal() + night early-out (r02)", 56,
      lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="solar_thermal", c0=0.8, c1=3.0, t_store_K=353.15, night_skip=True))),
-    ("general kernel: influx-only dataset (Reindl split, albedo from outflux)", 48, lambda: ctx.pv(influx_ds, scal, T, S, plan=plan)),
+    ("influx / outflux dataset (Reindl split, albedo from outflux) - fast family head (r02; was the general kernel)", 48,
+     lambda: ctx.pv(influx_ds, scal, T, S, plan=plan)),
+    ("general kernel: influx / outflux dataset + Hay-Davies", 48, lambda: ctx.pv(influx_ds, scal, T, S, plan=plan, options=dict(trigon_model="other"))),
     ("per-cell series out (no matrix), no early-out", 64, lambda: ctx.pv(inputs, scal, T, S, options=dict(night_skip=False))),
     ("per-cell series out (no matrix) + night early-out", 64, lambda: ctx.pv(inputs, scal, T, S, options=dict(night_skip=True, row_len=X))),
     ("per-cell time-mean (capacity factor map), no early-out", 56, lambda: ctx.pv(inputs, scal, T, S, time_agg="mean", options=dict(night_skip=False))),

@@ -10,7 +10,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault("ATL_VARIANT_REPS", "2")
-os.environ.setdefault("ATL_VARIANTS", "general kernel|pv(tracking='horizontal')|KANENA|bofinger + tracking='horizontal'|irradiation(tracking='dual')")
+os.environ.setdefault("ATL_VARIANTS", "influx / outflux dataset|pv(tracking='horizontal')|KANENA|bofinger + tracking='horizontal'|irradiation(tracking='dual')")
 sys.argv = [sys.argv[0], "C3", "C3m", "C3a"]
 runpy.run_path(str(ROOT / "tools" / "bench_configs.py"), run_name="__main__")
 runpy.run_path(str(ROOT / "tools" / "bench_pv_variants.py"), run_name="__main__")
