@@ -125,6 +125,65 @@ class LabeledArray:
         out.name = name
         return out
 
+    def sel(self, **labels):
+        """Label-based selection along dimensions that carry a coordinate: a label, a list of labels or a slice of
+        labels (both ends included), like ``xarray.DataArray.sel``."""
+        pos = {}
+        for d, lab in labels.items():
+            if d not in self.coords:
+                raise KeyError(f"no coordinate along {d!r}")
+            idx = pd.Index(self.coords[d])
+            if isinstance(lab, slice):
+                lo, hi = idx.slice_locs(lab.start, lab.stop)
+                pos[d] = np.arange(lo, hi)
+            elif np.ndim(lab) == 0 or isinstance(lab, str):
+                loc = idx.get_loc(lab)
+                pos[d] = int(loc) if isinstance(loc, (int, np.integer)) else (
+                    np.arange(loc.start, loc.stop) if isinstance(loc, slice) else np.flatnonzero(loc))
+            else:
+                loc = idx.get_indexer(pd.Index(lab))
+                if (loc < 0).any():
+                    raise KeyError(f"not all values found in index {d!r}")
+                pos[d] = loc
+        return self.isel(**pos)
+
+    # elementwise arithmetic on the (small, host) results: operands are aligned by dimension NAME, new dimensions are
+    # appended in order of first appearance, attributes are dropped - xarray's rules for the cases that arise here
+    def _binary(self, other, op, reflexive=False):
+        a = self.values
+        if isinstance(other, LabeledArray):
+            dims = list(self.dims) + [d for d in other.dims if d not in self.dims]
+
+            def expand(la):
+                v = la.values
+                order = [la.dims.index(d) for d in dims if d in la.dims]
+                v = np.transpose(v, order)
+                return v.reshape([v.shape[[d for d in dims if d in la.dims].index(d)] if d in la.dims else 1 for d in dims])
+
+            for d in set(self.dims) & set(other.dims):
+                if self.sizes[d] != other.sizes[d]:
+                    raise ValueError(f"operands disagree along {d!r}: {self.sizes[d]} vs {other.sizes[d]}")
+            a, b = expand(self), expand(other)
+            coords = {**{k: v for k, v in other.coords.items() if k in dims}, **{k: v for k, v in self.coords.items() if k in dims}}
+            name = self.name if self.name == other.name else None
+        else:
+            dims, b, coords, name = self.dims, (other.numpy() if _is_device(other) else other), self.coords, self.name
+        with np.errstate(all="ignore"):
+            out = op(b, a) if reflexive else op(a, b)
+        return LabeledArray(out, dims, {k: v for k, v in coords.items() if k in dims}, None, name)
+
+    def __neg__(self):
+        return LabeledArray(-self.values, self.dims, self.coords, None, self.name)
+
+    def __abs__(self):
+        return LabeledArray(np.abs(self.values), self.dims, self.coords, None, self.name)
+
+    def max(self, dim=None):
+        return np.nanmax(self.values) if dim is None else self._reduce(lambda v, ax: np.nanmax(v, axis=ax), dim)
+
+    def min(self, dim=None):
+        return np.nanmin(self.values) if dim is None else self._reduce(lambda v, ax: np.nanmin(v, axis=ax), dim)
+
     def to_pandas(self):
         v = self.values
         if self.ndim == 1:
@@ -147,6 +206,20 @@ class LabeledArray:
     def __repr__(self):
         where = "device" if _is_device(self._values) else "file" if _is_lazy(self._values) else "host"
         return f"<LabeledArray {self.name!r} {self.sizes} [{where}] attrs={self.attrs}>"
+
+
+def _install_operators():
+    import operator as _op
+
+    for name, fn in (("add", _op.add), ("sub", _op.sub), ("mul", _op.mul), ("truediv", _op.truediv), ("pow", _op.pow),
+                     ("lt", _op.lt), ("le", _op.le), ("gt", _op.gt), ("ge", _op.ge)):
+        setattr(LabeledArray, f"__{name}__", lambda self, other, fn=fn: self._binary(other, fn))
+        if name in ("add", "sub", "mul", "truediv", "pow"):
+            setattr(LabeledArray, f"__r{name}__", lambda self, other, fn=fn: self._binary(other, fn, reflexive=True))
+    LabeledArray.__array_priority__ = 1000  # ndarray <op> LabeledArray defers to the methods above
+
+
+_install_operators()
 
 
 class Dataset:

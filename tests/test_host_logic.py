@@ -628,3 +628,39 @@ def test_cutout_sel_time_and_space():
     with pytest.raises(KeyError):
         c.sel(level=3)
     assert c.sel(time=slice("2015", "2016")).data.sizes["time"] == 0
+
+
+def test_labeled_array_arithmetic_and_sel():
+    """Without xarray the results are LabeledArrays: elementwise arithmetic aligned by dimension name (new dimensions
+    appended in order of first appearance, attributes dropped), comparisons, label selection."""
+    import pandas as pd
+
+    from atlite_amd import LabeledArray
+
+    t = pd.date_range("2013-01-01", periods=4, freq="h")
+    rng = np.random.default_rng(0)
+    a = LabeledArray(rng.random((3, 4)), ("region", "time"), {"region": pd.Index(["DE", "FR", "PL"], name="region"), "time": t},
+                     {"units": "MW"}, "power")
+    cap = LabeledArray(np.array([2.0, 4.0, 0.0]), ("region",), {"region": pd.Index(["DE", "FR", "PL"])}, {"units": "MW"}, "cap")
+    with np.errstate(all="ignore"):
+        pu = a / cap
+    assert pu.dims == ("region", "time") and pu.attrs == {} and pu.name is None
+    with np.errstate(all="ignore"):
+        np.testing.assert_array_equal(pu.values, a.values / cap.values[:, None])
+    np.testing.assert_array_equal((2 * a + 1).values, 2 * a.values + 1)
+    np.testing.assert_array_equal((1 - a).values, 1 - a.values)
+    np.testing.assert_array_equal((a.values * a).values, a.values ** 2)  # ndarray on the left defers to LabeledArray
+    tt = LabeledArray(np.arange(4.0), ("time",), {"time": t})
+    np.testing.assert_array_equal((tt * cap).values, np.outer(np.arange(4.0), cap.values))
+    assert (tt * cap).dims == ("time", "region") and (cap * tt).dims == ("region", "time")
+    assert ((a > 0.5).values == (a.values > 0.5)).all() and (-a).values[0, 0] == -a.values[0, 0] and abs(-a).max() == a.max()
+    np.testing.assert_array_equal(a.max("time").values, a.values.max(1))
+    with pytest.raises(ValueError, match="disagree"):
+        a + LabeledArray(np.zeros(5), ("time",))
+    # label selection
+    np.testing.assert_array_equal(a.sel(region="FR").values, a.values[1])
+    assert a.sel(region="FR").dims == ("time",)
+    np.testing.assert_array_equal(a.sel(region=["PL", "DE"]).values, a.values[[2, 0]])
+    np.testing.assert_array_equal(a.sel(time=slice(t[1], t[2])).values, a.values[:, 1:3])
+    with pytest.raises(KeyError):
+        a.sel(region="ES")
