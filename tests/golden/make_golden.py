@@ -311,6 +311,21 @@ def main():
         warnings.simplefilter("ignore", DeprecationWarning)
         cb["follow_computed_position"] = conv.convert_pv(ds5, csi, orientation_follow_sun, tracking=None).transpose("time", "y", "x").values
     save("pv_callback", **cb)
+
+    # ---------------------------------------------------------------- extrapolate_wind_speed on its own (wind.py:23-125) ---
+    # (the wind section's inputs: no further random draws, so every file above stays as it was)
+    windmod = refshim.reference("atlite.wind")
+    ws = {}
+    ds2h = dataset(dict(w, wnd10m=0.7 * w["wnd100m"]), tw)
+    for name, args, kw in (("log_80", (80,), {}), ("power_120p5", (120.5,), dict(method="power")), ("log_30_closest_is_10", (30,), {}),
+                           ("log_30_from_100", (30,), dict(from_height=100)), ("power_15p5_from_100", (15.5,), dict(from_height=100, method="power"))):
+        da = windmod.extrapolate_wind_speed(ds2h, *args, **kw)
+        ws[name] = da.transpose("time", "y", "x").values
+        ws[name + "_long_name"] = np.array(da.attrs["long name"])
+        ws[name + "_name"] = np.array(str(da.name))
+    # (wnd{int(to_height)}m present -> returned as it is, wind.py:76-78: 10.5 m finds wnd10m)
+    ws["fastlane_10p5"] = windmod.extrapolate_wind_speed(ds2h, 10.5).transpose("time", "y", "x").values
+    save("wind_speed", **ws)
     print("done")
 
 

@@ -276,3 +276,51 @@ def test_orientation_callback_that_reads_the_sun():
     np.testing.assert_allclose(orc.convert_pv_general(ds2, H.CSI, dict(slope=o["slope"].values, azimuth=o["azimuth"].values)),
                                cbk["follow_computed_position"], rtol=1e-13, atol=1e-15)
 
+
+
+WIND_SPEED_CASES = [("log_80", 80, None, "logarithmic", 100, 1.0), ("power_120p5", 120.5, None, "power", 100, 1.0),
+                    ("log_30_closest_is_10", 30, None, "logarithmic", 10, 0.7), ("log_30_from_100", 30, 100, "logarithmic", 100, 1.0),
+                    ("power_15p5_from_100", 15.5, 100, "power", 100, 1.0)]
+
+
+@pytest.mark.parametrize("key,to_h,from_arg,method,from_h,scale", WIND_SPEED_CASES)
+def test_extrapolate_wind_speed_on_its_own(key, to_h, from_arg, method, from_h, scale):
+    """atlite.wind.extrapolate_wind_speed (wind.py:23-125) run by the reference itself: the oracle bit for bit, the
+    kernels' host build within the allowance, and the product's variable selection / name / attributes."""
+    import ctypes as C
+
+    from atlite_amd import Dataset, _lib, convert
+
+    g, w = load("wind_speed"), load("wind")
+    aux = w["roughness"] if method == "logarithmic" else w["wnd_shear_exp"]
+    with np.errstate(all="ignore"):
+        ref = orc.extrapolate_wind_speed(scale * w["wnd100m"], aux, to_h, from_h, method)
+    exact(ref, g[key])
+    # the product's spec: same source height, name and attributes as the reference's result
+    ds = Dataset(dict(wnd100m=w["wnd100m"], wnd10m=0.7 * w["wnd100m"], roughness=w["roughness"], wnd_shear_exp=w["wnd_shear_exp"]),
+                 dict(time=times(w["time"]), y=w["y"], x=w["x"]))
+    spec = convert._WindSpeedSpec(ds, to_h, from_arg, method)
+    assert spec.name == str(g[key + "_name"]) and spec.attrs["long name"] == str(g[key + "_long_name"]) and spec.attrs["units"] == "m s**-1"
+    assert spec.wnd == f"wnd{from_h}m" and spec.from_height == from_h and spec.V is None
+    # the kernels' own arithmetic (host build of the wind converter without a power curve)
+    wp = _lib.WindParams({"logarithmic": _lib.WIND_LOG, "power": _lib.WIND_POWER}[method], float(to_h), float(from_h), 0, None, None)
+    v = np.ascontiguousarray((scale * w["wnd100m"]).ravel())
+    a = np.ascontiguousarray(aux.ravel())
+    out = np.empty_like(v)
+    _lib.check(_lib.load().atl_wind_probe_host(C.byref(wp), v.size, v.ctypes.data, a.ctypes.data, out.ctypes.data))
+    refv = g[key].ravel()
+    fin = np.isfinite(refv)
+    np.testing.assert_allclose(out[fin], refv[fin], rtol=1e-10, atol=1e-12 * np.abs(refv[fin]).max())
+    assert (np.isnan(out) == np.isnan(refv)).all() and (out[np.isinf(refv)] == refv[np.isinf(refv)]).all()
+
+
+def test_extrapolate_wind_speed_fast_lane_truncates_the_height():
+    """wnd{int(to_height)}m present -> returned as it is (wind.py:76-78): 10.5 m finds wnd10m."""
+    from atlite_amd import Dataset, wind
+
+    g, w = load("wind_speed"), load("wind")
+    ds = Dataset(dict(wnd100m=w["wnd100m"], wnd10m=0.7 * w["wnd100m"], roughness=w["roughness"]),
+                 dict(time=times(w["time"]), y=w["y"], x=w["x"]))
+    r = wind.extrapolate_wind_speed(ds, 10.5)
+    assert r is ds["wnd10m"]
+    exact(r.values, g["fastlane_10p5"])
