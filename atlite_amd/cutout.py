@@ -172,6 +172,33 @@ class Cutout:
             out.path = self.path
         return out
 
+    def merge(self, other, path=None, **kwargs):
+        """Merge the variables of two cutouts on the same grid and time axis into one (cutout.py:416-450).  The
+        reference hands differing coordinates to ``xarray.merge`` (an outer join filled with NaN); here both cutouts
+        must share their coordinates.  ``module`` and ``prepared_features`` attributes are united like there."""
+        assert isinstance(other, Cutout)
+        for k in ("time", "y", "x"):
+            if not np.array_equal(np.asarray(self.coords[k]), np.asarray(other.coords[k])):
+                raise NotImplementedError(f"merging cutouts with different {k!r} coordinates needs xarray's outer join")
+        both = set(self.data.data_vars) & set(other.data.data_vars)
+        for k in both:
+            if not np.array_equal(np.asarray(self.data[k].values), np.asarray(other.data[k].values), equal_nan=True):
+                raise ValueError(f"conflicting values for variable {k!r} on objects to be combined")
+        attrs = {**self.data.attrs, **other.data.attrs}
+        mods = [m for c in (self, other) for m in np.atleast_1d(c.module if c.module is not None else []).tolist()]
+        attrs["module"] = list(dict.fromkeys(mods))
+        feats = list(dict.fromkeys(list(self.prepared_features.index.unique("feature")) + list(other.prepared_features.index.unique("feature"))))
+        attrs["prepared_features"] = feats
+        variables = {k: self.data[k] for k in self.data.data_vars}
+        variables.update({k: other.data[k] for k in other.data.data_vars if k not in variables})
+        data = Dataset({}, {k: self.coords[k] for k in ("time", "y", "x")}, attrs, chunked=self.data.chunked or other.data.chunked)
+        for k, la in variables.items():
+            data[k] = labeled.LabeledArray(la.data, la.dims, attrs=la.attrs, name=la.name)
+        out = Cutout(data, crs=self.crs, devices=self.devices)
+        if path is not None:
+            out.path = os.fspath(path)
+        return out
+
     def equals(self, other):
         """Same coordinates and variables, value by value (NaN == NaN); the path is ignored (cutout.py:587-594)."""
         if not isinstance(other, Cutout):

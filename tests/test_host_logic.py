@@ -664,3 +664,28 @@ def test_labeled_array_arithmetic_and_sel():
     np.testing.assert_array_equal(a.sel(time=slice(t[1], t[2])).values, a.values[:, 1:3])
     with pytest.raises(KeyError):
         a.sel(region="ES")
+
+
+def test_cutout_merge_same_grid():
+    """Cutout.merge (cutout.py:416-450) for cutouts on the same grid and time axis: the union of the variables, module
+    and prepared_features united; other coordinates would need xarray's outer join."""
+    import pandas as pd
+
+    from atlite_amd import Cutout, Dataset
+
+    x, y = np.linspace(5.0, 8.0, 4), np.linspace(47.0, 49.0, 3)
+    t = pd.date_range("2013-01-01", periods=5, freq="h")
+    rng = np.random.default_rng(0)
+    temp, wnd, h = rng.random((5, 3, 4)), rng.random((5, 3, 4)), rng.random((3, 4))
+    a = Cutout(Dataset({"temperature": temp, "height": h}, dict(time=t, y=y, x=x), attrs={"module": "era5"}))
+    b = Cutout(Dataset({"wnd100m": wnd, "height": h}, dict(time=t, y=y, x=x), attrs={"module": "sarah"}))
+    m = a.merge(b)
+    assert set(m.data.data_vars) == {"temperature", "height", "wnd100m"} and m.module == ["era5", "sarah"]
+    assert sorted(m.data.attrs["prepared_features"]) == ["height", "temperature", "wnd100m"]
+    np.testing.assert_array_equal(m.data["wnd100m"].values, wnd)
+    assert m.data["height"].dims == ("y", "x") and m.equals(b.merge(a))
+    with pytest.raises(NotImplementedError):
+        a.merge(b.sel(x=slice(5.0, 7.0)))
+    c = Cutout(Dataset({"height": h + 1.0}, dict(time=t, y=y, x=x)))
+    with pytest.raises(ValueError, match="conflicting"):
+        a.merge(c)
