@@ -65,7 +65,8 @@ def compare(got, ref, what, stats):
     err = np.where(same, 0.0, err)
     err = np.where(np.isnan(err), np.inf, err)
     e = float(err.max()) if err.size else 0.0
-    stats["worst"] = max(stats["worst"], e if np.isfinite(e) else stats["worst"])
+    if np.isfinite(e) and e > stats["worst"]:
+        stats["worst"], stats["worst_what"] = e, what
     if e > 1.0:
         i = np.unravel_index(np.argmax(err), err.shape)
         print(f"MISMATCH {what}: {e:.3e} of the allowance at {i}: oracle {got[i]!r} reference {ref[i]!r}")
@@ -206,7 +207,8 @@ def main():
                 if gref.shape != np.shape(gor) and gref.T.shape == np.shape(gor):
                     gref = gref.T
             compare(gor, gref, f"case {case} gateway agg={agg} tagg={tagg} per_unit={pu}", stats)
-    print(f"{n} cases, {stats['fails']} mismatches, worst error {stats['worst']:.3e} of the rtol 1e-10 / atol 1e-12 max allowance")
+    print(f"{n} cases, {stats['fails']} mismatches, worst error {stats['worst']:.3e} of the rtol 1e-10 / atol 1e-12 max allowance"
+          + (f" ({stats['worst_what']})" if stats.get("worst_what") else ""))
     return 1 if stats["fails"] else 0
 
 
