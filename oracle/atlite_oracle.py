@@ -429,8 +429,10 @@ def tilted_irradiation_general(ds, alt, so, trigon_model="simple", clearsky_mode
             f = _fillna0(np.sqrt(direct / influx))
             A = direct / influx_toa
             R_b = cosincidence / sinalt
-            diffuse_t = ((1.0 - A) * ((1 + np.cos(surface_slope)) / 2.0) * (1.0 + f * np.sin(surface_slope / 2.0) ** 3)
-                         + A * R_b) * diffuse
+            # sin(slope / 2) ** 3 on a labelled array is numpy's ARRAY power even for one orientation for the whole grid
+            # (a 0-d variable); numpy's scalar power of an np.float64 can differ from it in the last bit
+            s3 = np.power(np.atleast_1d(np.sin(surface_slope / 2.0)), 3).reshape(np.shape(surface_slope))
+            diffuse_t = ((1.0 - A) * ((1 + np.cos(surface_slope)) / 2.0) * (1.0 + f * s3) + A * R_b) * diffuse
             diffuse_t = _fillna0(np.clip(diffuse_t, 0, None))
             direct_t = R_b * direct
             ground_t = influx * _albedo(ds, influx) * (1.0 - np.cos(surface_slope)) / 2.0
