@@ -353,6 +353,9 @@ void File::fractal_objects(uint64_t heap_addr, uint64_t btree_addr, int rec_id_o
     const int cur_rows = int(rd(t + 2 + 2 * L_ + 4 + O_, 2));
     if (!width || !start || (start & (start - 1)) || (width & (width - 1)) || max_direct < start)
         fail(ATL_E_INVALID, "bad fractal heap doubling table");
+    // row r holds blocks of start << max(r - 1, 0) bytes: the shifts below must stay inside 64 bits
+    if (heap_bits < 1 || heap_bits > 64 || cur_rows < 0 || log2floor(start) + std::max(cur_rows - 2, 0) > 62 || width > (1u << 15))
+        fail(ATL_E_INVALID, "bad fractal heap doubling table");
     const int offsz = (heap_bits + 7) / 8;
     const int lensz = enc_size(std::min(max_direct, max_managed));
     const int max_drows = log2floor(max_direct) - log2floor(start) + 2;
@@ -469,7 +472,13 @@ void File::parse_dataspace(const uint8_t *p, uint64_t n, std::vector<uint64_t> &
     }
     if (rank > 32 || q + uint64_t(rank) * L_ > n) fail(ATL_E_INVALID, "bad dataspace message");
     dims.resize(rank);
-    for (int i = 0; i < rank; ++i) dims[i] = rd(p + q + uint64_t(i) * L_, L_);
+    // the element count must stay far inside 64 bits: readers multiply the dimensions (2^48 elements = 2 PiB of fp64)
+    uint64_t total = 1;
+    for (int i = 0; i < rank; ++i) {
+        dims[i] = rd(p + q + uint64_t(i) * L_, L_);
+        if (dims[i] && total > (1ull << 48) / dims[i]) fail(ATL_E_INVALID, "dataspace with more than 2^48 elements");
+        total *= dims[i] ? dims[i] : 1;
+    }
 }
 
 bool File::parse_attribute(const uint8_t *p, uint64_t n, Attribute &a) const {
@@ -588,6 +597,7 @@ void File::fixed_array_chunks(uint64_t hdr, Dataset &d, bool filtered) const {
     const uint64_t db = addr(h + 8 + L_);
     if (undef(db)) return;  // no chunk written yet
     if (nel < d.chunks.size()) fail(ATL_E_INVALID, "fixed array smaller than the chunk grid");
+    if (page_bits < 1 || page_bits > 40) fail(ATL_E_INVALID, "bad fixed array page size (2^%d elements)", page_bits);
     const uint64_t per_page = 1ull << page_bits;
     const bool paged = nel > per_page;
     const uint64_t npages = paged ? (nel + per_page - 1) / per_page : 0;
@@ -737,8 +747,14 @@ void File::parse_dataset(const std::string &name, uint64_t a, const std::vector<
         }
         if (total > (1ull << 22)) fail(ATL_E_UNSUPPORTED, "dataset '%s' has too many chunks", name.c_str());
         d.chunks.assign(size_t(total), Chunk{});
+        // HDF5 itself limits a chunk to 4 GiB - 1; checked factor by factor, the product of three 32-bit dimensions
+        // read from the file would not fit 64 bits (and every reader allocates a buffer of this size per chunk)
         uint64_t chunk_bytes = d.type.size;
-        for (auto c : d.chunk) chunk_bytes *= c;
+        if (!chunk_bytes) fail(ATL_E_INVALID, "dataset '%s' has a zero-size element type", name.c_str());
+        for (auto c : d.chunk) {
+            if (c > 0xffffffffull / chunk_bytes) fail(ATL_E_INVALID, "dataset '%s' has chunks of 4 GiB or more", name.c_str());
+            chunk_bytes *= c;
+        }
         if (ver == 3) {
             if (!undef(bt)) walk_chunk_btree(bt, rank, d, 0);
         } else if (idx == 1) {  // single chunk

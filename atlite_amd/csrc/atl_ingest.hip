@@ -415,7 +415,16 @@ int parallel_for(size_t n, int n_threads, F fn) {
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= n || err.load()) return;
-            const int rc = fn(i);
+            int rc;
+            try {  // an exception must not leave a worker thread (std::terminate): a chunk buffer that cannot be allocated
+                rc = fn(i);
+            } catch (const std::bad_alloc &) {
+                set_error("out of host memory while reading chunk %zu", i);
+                rc = ATL_E_NOMEM;
+            } catch (const std::exception &e) {
+                set_error("%s", e.what());
+                rc = ATL_E_INVALID;
+            }
             if (rc) {
                 int expect = 0;
                 if (err.compare_exchange_strong(expect, rc)) {
