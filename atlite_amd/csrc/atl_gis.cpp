@@ -105,8 +105,8 @@ int atl_indicator_polygons(int64_t n_shapes, const int64_t *h_shape_ring_ptr, in
                 by0 = std::min(by0, p.y);
                 by1 = std::max(by1, p.y);
             }
-            const int64_t j0 = std::max<int64_t>(0, int64_t(std::floor((by0 - ylo) / dy)));
-            const int64_t j1 = std::min<int64_t>(Y - 1, int64_t(std::floor((by1 - ylo) / dy)));
+            const int64_t j0 = atl::clamped_floor((by0 - ylo) / dy, 0, Y);
+            const int64_t j1 = atl::clamped_floor((by1 - ylo) / dy, -1, Y - 1);
             for (int64_t j = j0; j <= j1; ++j) {
                 const double ya = ylo + j * dy, yb = ylo + (j + 1) * dy;
                 clip_halfplane(ring, tmp, 1, ya, +1);
@@ -117,8 +117,8 @@ int atl_indicator_polygons(int64_t n_shapes, const int64_t *h_shape_ring_ptr, in
                     sx0 = std::min(sx0, p.x);
                     sx1 = std::max(sx1, p.x);
                 }
-                const int64_t i0 = std::max<int64_t>(0, int64_t(std::floor((sx0 - xlo) / dx)));
-                const int64_t i1 = std::min<int64_t>(X - 1, int64_t(std::floor((sx1 - xlo) / dx)));
+                const int64_t i0 = atl::clamped_floor((sx0 - xlo) / dx, 0, X);
+                const int64_t i1 = atl::clamped_floor((sx1 - xlo) / dx, -1, X - 1);
                 for (int64_t i = i0; i <= i1; ++i) {
                     const double xa = xlo + i * dx, xb = xlo + (i + 1) * dx;
                     clip_halfplane(strip, tmp, 0, xa, +1);

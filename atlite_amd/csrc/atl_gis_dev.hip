@@ -156,10 +156,10 @@ static int indicator_integral(atl_ctx *ctx, int64_t n_shapes, const int64_t *h_s
         shape_edge0[size_t(s) + 1] = int64_t(all.size());
         if (!any || !(bx1 >= bx0) || !(by1 >= by0)) continue;  // NaN coordinates: no entries
         Box &b = box[size_t(s)];
-        b.i0 = std::max<int64_t>(0, int64_t(std::floor((bx0 - xlo) / dx)));
-        b.i1 = std::min<int64_t>(X - 1, int64_t(std::floor((bx1 - xlo) / dx)));
-        b.j0 = std::max<int64_t>(0, int64_t(std::floor((by0 - ylo) / dy)));
-        b.j1 = std::min<int64_t>(Y - 1, int64_t(std::floor((by1 - ylo) / dy)));
+        b.i0 = clamped_floor((bx0 - xlo) / dx, 0, X);  // X / -1: a box beside the grid stays empty (i0 > i1)
+        b.i1 = clamped_floor((bx1 - xlo) / dx, -1, X - 1);
+        b.j0 = clamped_floor((by0 - ylo) / dy, 0, Y);
+        b.j1 = clamped_floor((by1 - ylo) / dy, -1, Y - 1);
     }
     // buckets: one per (shape, column of its box); counting sort of edge references
     std::vector<int64_t> shape_bucket0(size_t(n_shapes) + 1, 0);
@@ -173,8 +173,8 @@ static int indicator_integral(atl_ctx *ctx, int64_t n_shapes, const int64_t *h_s
     std::vector<int32_t> bucket_col(size_t(n_buckets), 0), bucket_row0(size_t(n_buckets), 0), bucket_nrows(size_t(n_buckets), 0);
     auto col_range = [&](const Edge &e, const Box &b, int64_t *c0, int64_t *c1) {
         const double lo = std::min(e.x1, e.x2), hi = std::max(e.x1, e.x2);
-        *c0 = std::max<int64_t>(b.i0, int64_t(std::floor((lo - xlo) / dx)));
-        *c1 = std::min<int64_t>(b.i1, int64_t(std::floor((hi - xlo) / dx)));
+        *c0 = clamped_floor((lo - xlo) / dx, b.i0, b.i1 + 1);
+        *c1 = clamped_floor((hi - xlo) / dx, b.i0 - 1, b.i1);
     };
     for (int64_t s = 0; s < n_shapes; ++s) {
         const Box &b = box[size_t(s)];

@@ -114,6 +114,14 @@ __host__ __device__ inline TileLane tile_lane_cells(int64_t X, int64_t Y, int32_
     return t;
 }
 
+// floor(v) as a grid index clamped to [lo, hi]: coordinates come from the caller's polygons, and converting a double
+// beyond the 64-bit range (1e300, +-inf) to an integer is undefined; NaN gives lo (callers skip NaN boxes beforehand)
+inline int64_t clamped_floor(double v, int64_t lo, int64_t hi) {
+    if (!(v > double(lo))) return lo;
+    if (v >= double(hi)) return hi;
+    return int64_t(std::floor(v));
+}
+
 // ---- wind power-curve table (host) ---------------------------------------------------------------------
 // Padded size of a table of n knots: the sizes with an unrolled search are 16, 32 and 128 (a power of two
 // > n in any case, so that V[n..n_pad) = +inf terminates every probe sequence).
