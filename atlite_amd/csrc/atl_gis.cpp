@@ -79,6 +79,9 @@ int atl_indicator_polygons(int64_t n_shapes, const int64_t *h_shape_ring_ptr, in
     ATL_REQUIRE(X * Y < (int64_t(1) << 31), "atl_indicator_polygons: grid too large");
     ATL_REQUIRE(n_shapes == 0 || (h_shape_ring_ptr && h_ring_ptr && h_xy),
                 "atl_indicator_polygons: NULL input");
+    ATL_REQUIRE(n_shapes == 0 || (atl::offsets_ok(h_shape_ring_ptr, n_shapes) && h_shape_ring_ptr[n_shapes] <= n_rings &&
+                                  atl::offsets_ok(h_ring_ptr, n_rings)),
+                "atl_indicator_polygons: shape / ring offsets must be non-negative and non-decreasing");
     const double cell_area = dx * dy;
     const double xlo = x0 - 0.5 * dx, ylo = y0 - 0.5 * dy;  // lower-left corner of cell (0,0)
     std::vector<int64_t> indptr(size_t(n_shapes) + 1, 0);

@@ -110,6 +110,9 @@ static int indicator_integral(atl_ctx *ctx, int64_t n_shapes, const int64_t *h_s
     ATL_REQUIRE(dx > 0 && dy > 0, "atl_indicator_polygons_device: grid spacing must be positive (ascending x, y)");
     ATL_REQUIRE(X * Y < (int64_t(1) << 31), "atl_indicator_polygons_device: grid too large");
     ATL_REQUIRE(n_shapes == 0 || (h_shape_ring_ptr && h_ring_ptr && h_xy), "atl_indicator_polygons_device: NULL input");
+    ATL_REQUIRE(n_shapes == 0 || (offsets_ok(h_shape_ring_ptr, n_shapes) && h_shape_ring_ptr[n_shapes] <= n_rings &&
+                                  offsets_ok(h_ring_ptr, n_rings)),
+                "atl_indicator_polygons_device: shape / ring offsets must be non-negative and non-decreasing");
     const double xlo = x0 - 0.5 * dx, ylo = y0 - 0.5 * dy;
     // ---- host preparation: oriented edges, bucketed by (shape, grid column) ---------------------------------
     struct Box {

@@ -114,6 +114,15 @@ __host__ __device__ inline TileLane tile_lane_cells(int64_t X, int64_t Y, int32_
     return t;
 }
 
+// CSR-style offsets p[0..n] handed in by a caller: non-negative and non-decreasing, so that none of them leads past the
+// p[n] entries the arrays they index are promised to hold
+inline bool offsets_ok(const int64_t *p, int64_t n) {
+    if (p[0] < 0) return false;
+    for (int64_t i = 0; i < n; ++i)
+        if (p[i + 1] < p[i]) return false;
+    return true;
+}
+
 // floor(v) as a grid index clamped to [lo, hi]: coordinates come from the caller's polygons, and converting a double
 // beyond the 64-bit range (1e300, +-inf) to an integer is undefined; NaN gives lo (callers skip NaN boxes beforehand)
 inline int64_t clamped_floor(double v, int64_t lo, int64_t hi) {

@@ -414,6 +414,11 @@ static int build_plan(int64_t n_rows, int64_t n_cells, int64_t row_len, const in
     const int64_t nnz = h_indptr[n_rows];
     ATL_REQUIRE(nnz >= 0 && (nnz == 0 || (h_indices && h_data)),
                 "atl_agg_create: indices/data missing");
+    // the row pointers are checked as a whole before any of them is used as an offset: indices / data hold
+    // indptr[n_rows] entries, and a non-monotone interior pointer must not be followed past them
+    for (int64_t r = 0; r < n_rows; ++r)
+        ATL_REQUIRE(h_indptr[r + 1] >= h_indptr[r] && h_indptr[r + 1] <= nnz, "atl_agg_create: indptr not monotone at row %lld",
+                    (long long)r);
 
     // ---- validate, collect (row, cell, weight) -------------------------------------------
     struct Raw {

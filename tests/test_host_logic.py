@@ -689,3 +689,40 @@ def test_cutout_merge_same_grid():
     c = Cutout(Dataset({"height": h + 1.0}, dict(time=t, y=y, x=x)))
     with pytest.raises(ValueError, match="conflicting"):
         a.merge(c)
+
+
+def test_hostile_offsets_are_refused_before_they_are_followed():
+    """Findings of the long host fuzzers (tools/fuzz_plan.py, tools/fuzz_gis.py under ASan + UBSan): CSR row pointers and
+    the shape / ring offsets of the polygon entry points come from the caller - a non-monotone INTERIOR offset used to be
+    followed past the arrays before the per-row check noticed; polygon coordinates of 1e300 / inf went through an
+    undefined double -> int64 conversion.  Both are refused resp. defined now."""
+    import ctypes as C
+
+    from atlite_amd import _lib, gis
+
+    lib = _lib.load()
+    # CSR: 3 rows, 4 entries, the middle pointer far beyond the data
+    indptr = np.array([0, 2, 10**9, 4], dtype=np.int64)
+    indices = np.array([0, 1, 2, 3], dtype=np.int32)
+    data = np.ones(4)
+    err = C.c_int64()
+    with pytest.raises(ValueError, match="monotone"):
+        _lib.check(lib.atl_agg_check_host(3, 8, 0, indptr.ctypes.data, indices.ctypes.data, data.ctypes.data, None, None, C.byref(err)))
+    # polygons: one shape, two rings, the middle ring offset beyond the vertex array / negative
+    xy = np.array([[0.0, 0.0], [1.0, 0.0], [1.0, 1.0], [0.0, 1.0], [0.2, 0.2], [0.4, 0.2], [0.4, 0.4]])
+    shape_ptr = np.array([0, 2], dtype=np.int64)
+    holes = np.array([0, 1], dtype=np.uint8)
+    for bad in ([0, 10**9, 7], [0, -5, 7], [3, 2, 7]):
+        ring_ptr = np.array(bad, dtype=np.int64)
+        for fn in (lib.atl_indicator_polygons, lib.atl_indicator_polygons_integral_host):
+            p_ip, p_ix, p_d = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            with pytest.raises(ValueError, match="offsets"):
+                _lib.check(fn(1, shape_ptr.ctypes.data, 2, ring_ptr.ctypes.data, holes.ctypes.data, xy.ctypes.data, 4, 4, 0.0, 1.0, 0.0, 1.0,
+                              C.byref(p_ip), C.byref(p_ix), C.byref(p_d)))
+    # coordinates far outside the 64-bit index range: no entries, no undefined conversion (the sanitizer suite runs this too)
+    x, y = np.arange(5.0), np.arange(4.0)
+    for ctx in (None, "integral-host"):
+        M = gis.compute_indicatormatrix(x, y, [np.array([[1e300, 0.0], [2e300, 0.0], [2e300, 1e300]]),
+                                               np.array([[-np.inf, 0.0], [1.0, 0.0], [1.0, 1.0]]),
+                                               np.array([[0.5, 0.5], [2.5, 0.5], [2.5, 2.5], [0.5, 2.5]])], ctx=ctx).toarray()
+        assert M[0].sum() == 0.0 and np.isfinite(M).all() and abs(M[2].sum() - 4.0) < 1e-12
