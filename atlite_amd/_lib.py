@@ -235,6 +235,11 @@ SIGNATURES = {
     "atl_allgather_time": (_i, [_vp, _vp, _i64, _i64, _vp, _i64]),
     "atl_allreduce_sum": (_i, [_vp, _vp, _i64]),
     "atl_allgather_time_v": (_i, [_vp, _vp, _i64, c_int64_p, _vp, _i64]),
+    "atl_comm_group_create": (_i, [_i, C.POINTER(_vp)]),
+    "atl_comm_group_destroy": (_i, [_vp]),
+    "atl_comm_init_local": (_i, [_vp, _vp, _i, C.POINTER(_vp)]),
+    "atl_comm_abort": (_i, [_vp]),
+    "atl_gather_place_v_host": (_i, [_vp, _i, _i64, c_int64_p, _vp, _i64]),
     "atl_math_probe": (_i, [_vp, _i, _vp, _i64, _vp]),
     "atl_math_probe_host": (_i, [_i, _vp, _i64, _vp]),
     "atl_wind_probe_host": (_i, [C.POINTER(WindParams), _i64, _vp, _vp, _vp]),

@@ -367,14 +367,20 @@ class _WindSpeedSpec(_WindSpec):
     attrs = {"units": "m s**-1"}
 
     def __init__(self, ds, to_height, from_height=None, method="logarithmic"):
+        to_name = f"wnd{int(to_height):0d}m"
+        if to_name in ds:  # fast lane (wind.py:77-79): the stored variable as it is, whatever from_height says
+            from_height = None
         if from_height is not None:  # a given source height replaces the "closest height" rule
             if f"wnd{int(from_height):0d}m" not in ds:
                 raise KeyError(f"wnd{int(from_height):0d}m")
             ds = {k: None for k in ds if not re.match(r"wnd\d+m", k) or k == f"wnd{int(from_height):0d}m"}
         super().__init__(ds, dict(V=None, POW=np.zeros(0), P=1.0, hub_height=to_height), method)
         self.V = self.POWn = None
-        self.name = f"wnd{int(to_height):0d}m"
-        if self.method is not None:
+        self.name = to_name
+        if self.method is None:  # fast lane: the stored variable keeps its own attrs
+            stored = ds[to_name] if hasattr(ds, "__getitem__") else None
+            self.attrs = dict(getattr(stored, "attrs", None) or self.attrs)
+        else:
             desc = "logarithmic method with roughness" if self.method == "logarithmic" else "power method with wind shear exponent"
             self.attrs = {"long name": f"extrapolated {to_height} m wind speed using {desc}  and {int(self.from_height)} m wind speed",
                           "units": "m s**-1"}

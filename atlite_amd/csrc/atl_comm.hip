@@ -1,12 +1,23 @@
-// Multi-GPU collectives of the hot path over RCCL (xGMI), for hosts that do not go through
-// torch.distributed.  One process per GPU; the time axis is sharded, so the only
-// exchanges are an all-gather of the small (shapes x T_r) result blocks and an all-reduce of
-// time sums.  librccl.so.1 is opened lazily: the library loads (and every single-GPU entry point
-// works) without it.  The reference has no distributed path to mirror.
+// Multi-GPU collectives of the hot path, for hosts that do not go through torch.distributed.  The time axis
+// is sharded, so the only exchanges are an all-gather of the small (shapes x T_r) result
+// blocks and an all-reduce of time sums.  Two transports behind one atl_comm:
+//   * RCCL over xGMI (atl_comm_init): one rank per process or per thread; librccl.so.1 is opened lazily, the
+//     library loads (and every single-GPU entry point works) without it;
+//   * in-process peer copies (atl_comm_init_local): the ranks are host threads of ONE process that share an
+//     atl_comm_group; every rank PULLS its peers' blocks with hipMemcpyPeerAsync on its own stream - on a node
+//     that is seven point-to-point xGMI links read at once, no ring - ordered by events, with a host
+//     rendezvous that times out instead of hanging.  Ranks may share a device (how a one-GPU box runs the
+//     N-rank code, tests/test_gpu_multidevice.py).
+// What is packed, gathered and placed is the same code for both.  The reference has no distributed path to
+// mirror.
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <rccl/rccl.h>
 
 #include "atl_internal.h"
@@ -61,35 +72,166 @@ int load_rccl() {
         }                                                                                       \
     } while (0)
 
-// gathered [rank][n][t] -> out[n][rank * T_r + t]
-__global__ __launch_bounds__(256) void k_gather_place(const double *__restrict__ g, int n_ranks, int64_t N,
-                                                      int64_t T_r, double *__restrict__ out, int64_t ld_out) {
-    const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    const int64_t n = blockIdx.y;
-    const int r = blockIdx.z;
-    if (t < T_r) out[n * ld_out + int64_t(r) * T_r + t] = g[(int64_t(r) * N + n) * T_r + t];
-}
-
-// ragged: gathered [rank][n][Tmax] (rank r uses its first len_r columns) -> out[n][off_r + t]
+// ---- placement: ONE definition of where an element of the gathered buffer goes ----------------------
+// gathered [rank][n][Tmax] (rank r uses its first len_r = off[r+1] - off[r] columns) -> out[n][off[r] + t].
+// The kernel and the host instantiation (atl_gather_place_v_host: what the CPU tests run) share it.
 constexpr int kMaxRanks = 64;
 struct RankOffsets {
     int64_t off[kMaxRanks + 1];
 };
+struct Placement {
+    int64_t src, dst;
+    bool live;
+};
+__host__ __device__ inline Placement gather_placement(const RankOffsets &ro, int r, int64_t n, int64_t t, int64_t N,
+                                                      int64_t Tmax, int64_t ld_out) {
+    Placement p;
+    p.live = t < ro.off[r + 1] - ro.off[r];
+    p.src = (int64_t(r) * N + n) * Tmax + t;
+    p.dst = n * ld_out + ro.off[r] + t;
+    return p;
+}
+
 __global__ __launch_bounds__(256) void k_gather_place_v(const double *__restrict__ g, RankOffsets ro, int64_t N,
                                                         int64_t Tmax, double *__restrict__ out, int64_t ld_out) {
-    const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    const int64_t n = blockIdx.y;
-    const int r = blockIdx.z;
-    if (t < ro.off[r + 1] - ro.off[r]) out[n * ld_out + ro.off[r] + t] = g[(int64_t(r) * N + n) * Tmax + t];
+    const Placement p = gather_placement(ro, int(blockIdx.z), int64_t(blockIdx.y),
+                                         int64_t(blockIdx.x) * 256 + threadIdx.x, N, Tmax, ld_out);
+    if (p.live) out[p.dst] = g[p.src];
+}
+
+// out[i] = sum over ranks (ascending) of g[r][i]: the same bits on every rank
+__global__ __launch_bounds__(256) void k_sum_ranks(const double *__restrict__ g, int n_ranks, int64_t n,
+                                                   double *__restrict__ out) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = g[i];
+    for (int r = 1; r < n_ranks; ++r) s += g[int64_t(r) * n + i];
+    out[i] = s;
+}
+
+int fill_offsets(const char *what, int n_ranks, const int64_t *h_lens, RankOffsets *ro, int64_t *Tmax) {
+    ATL_REQUIRE(n_ranks >= 1 && n_ranks <= kMaxRanks, "%s: 1..%d ranks", what, kMaxRanks);
+    ro->off[0] = 0;
+    *Tmax = 0;
+    for (int r = 0; r < n_ranks; ++r) {
+        ATL_REQUIRE(h_lens[r] >= 0, "%s: negative shard length", what);
+        ro->off[r + 1] = ro->off[r] + h_lens[r];
+        *Tmax = std::max(*Tmax, h_lens[r]);
+    }
+    return ATL_OK;
+}
+
+double comm_timeout_s() {
+    if (const char *e = getenv("ATLITE_HIP_COMM_TIMEOUT_S")) {
+        const double v = atof(e);
+        if (v > 0) return v;
+    }
+    return 120.0;
 }
 
 }  // namespace
 
+// In-process rendezvous of the local transport: n_ranks host threads, one atl_comm each.
+struct atl_comm_group {
+    int n = 1;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    bool aborted = false;
+    int attached = 0;
+    std::vector<const void *> send;   // rank r's block of the collective in flight
+    std::vector<int> device;          // rank r's device
+    std::vector<hipEvent_t> ready;    // recorded on rank r's stream: its block is complete
+    std::vector<hipEvent_t> done;     // recorded on rank r's stream: it has read every peer's block
+
+    // all ranks arrive or nobody leaves with ATL_OK: a missing peer (it failed before the collective) is a
+    // time-out and an error on every waiting rank, never a hang
+    int barrier(const char *what) {
+        std::unique_lock<std::mutex> lk(m);
+        if (aborted) {
+            set_error("%s: the communicator group was aborted", what);
+            return ATL_E_HIP;
+        }
+        const uint64_t gen = generation;
+        if (++arrived == n) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+            return ATL_OK;
+        }
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(comm_timeout_s());
+        while (generation == gen && !aborted) {
+            if (cv.wait_until(lk, deadline) == std::cv_status::timeout && generation == gen) {
+                aborted = true;
+                cv.notify_all();
+                set_error("%s: a rank did not reach the collective within %.0f s (ATLITE_HIP_COMM_TIMEOUT_S)", what,
+                          comm_timeout_s());
+                return ATL_E_HIP;
+            }
+        }
+        if (generation == gen) {
+            set_error("%s: the communicator group was aborted", what);
+            return ATL_E_HIP;
+        }
+        return ATL_OK;
+    }
+};
+
 struct atl_comm {
     atl_ctx *ctx = nullptr;
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;        // RCCL transport
+    atl_comm_group *group = nullptr;  // local transport
     int n_ranks = 1, rank = 0;
 };
+
+namespace {
+
+// recv[q] = rank q's `count` doubles, for every q, on this rank's stream (local transport)
+int local_all_gather(atl_comm *c, const double *send, double *recv, size_t count, const char *what) {
+    atl_comm_group *g = c->group;
+    atl_ctx *ctx = c->ctx;
+    const int r = c->rank;
+    g->send[size_t(r)] = send;
+    ATL_HIP_TRY(hipEventRecord(g->ready[size_t(r)], ctx->stream));
+    int rc = g->barrier(what);  // every block is published and its event recorded
+    if (rc) return rc;
+    for (int k = 0; k < g->n; ++k) {
+        const int q = (r + k) % g->n;  // start with the own block, then the peers in a rotated order: no two ranks
+                                       // read the same peer first
+        if (q != r) ATL_HIP_TRY(hipStreamWaitEvent(ctx->stream, g->ready[size_t(q)], 0));
+        if (g->device[size_t(q)] == ctx->device)
+            ATL_HIP_TRY(hipMemcpyAsync(recv + size_t(q) * count, g->send[size_t(q)], count * sizeof(double),
+                                       hipMemcpyDeviceToDevice, ctx->stream));
+        else
+            ATL_HIP_TRY(hipMemcpyPeerAsync(recv + size_t(q) * count, ctx->device, g->send[size_t(q)],
+                                           g->device[size_t(q)], count * sizeof(double), ctx->stream));
+    }
+    ATL_HIP_TRY(hipEventRecord(g->done[size_t(r)], ctx->stream));
+    rc = g->barrier(what);  // every rank's reads are enqueued and marked
+    if (rc) return rc;
+    // whatever this stream does next (e.g. overwrite the block it sent) waits until every peer has read it
+    for (int q = 0; q < g->n; ++q)
+        if (q != r) ATL_HIP_TRY(hipStreamWaitEvent(ctx->stream, g->done[size_t(q)], 0));
+    return ATL_OK;
+}
+
+int all_gather(atl_comm *c, const double *send, double *recv, size_t count, const char *what) {
+    if (c->group) return local_all_gather(c, send, recv, count, what);
+    ATL_NCCL_TRY(g_rccl.AllGather(send, recv, count, ncclDouble, c->comm, c->ctx->stream));
+    return ATL_OK;
+}
+
+int launched(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: kernel launch failed: %s", what, hipGetErrorString(e));
+        return ATL_E_HIP;
+    }
+    return ATL_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -122,11 +264,99 @@ int atl_comm_init(atl_ctx *ctx, int n_ranks, int rank, const void *h_id128, atl_
     return ATL_OK;
 }
 
+int atl_comm_group_create(int n_ranks, atl_comm_group **out) {
+    ATL_REQUIRE(out, "atl_comm_group_create: out is NULL");
+    *out = nullptr;
+    ATL_REQUIRE(n_ranks >= 1 && n_ranks <= kMaxRanks, "atl_comm_group_create: 1..%d ranks", kMaxRanks);
+    atl_comm_group *g = new atl_comm_group();
+    g->n = n_ranks;
+    g->send.assign(size_t(n_ranks), nullptr);
+    g->device.assign(size_t(n_ranks), -1);
+    g->ready.assign(size_t(n_ranks), nullptr);
+    g->done.assign(size_t(n_ranks), nullptr);
+    *out = g;
+    return ATL_OK;
+}
+
+int atl_comm_group_destroy(atl_comm_group *g) {
+    if (!g) return ATL_OK;
+    ATL_REQUIRE(g->attached == 0, "atl_comm_group_destroy: %d communicator(s) still attached", g->attached);
+    delete g;
+    return ATL_OK;
+}
+
+int atl_comm_init_local(atl_ctx *ctx, atl_comm_group *g, int rank, atl_comm **out) {
+    ATL_REQUIRE(ctx && g && out, "atl_comm_init_local: bad argument");
+    *out = nullptr;
+    ATL_REQUIRE(rank >= 0 && rank < g->n, "atl_comm_init_local: rank %d of %d", rank, g->n);
+    ATL_HIP_TRY(hipSetDevice(ctx->device));
+    hipEvent_t ready = nullptr, done = nullptr;
+    ATL_HIP_TRY(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    ATL_HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    {
+        std::lock_guard<std::mutex> lk(g->m);
+        if (g->ready[size_t(rank)]) {
+            (void)hipEventDestroy(ready);
+            (void)hipEventDestroy(done);
+            set_error("atl_comm_init_local: rank %d is already attached", rank);
+            return ATL_E_INVALID;
+        }
+        g->ready[size_t(rank)] = ready;
+        g->done[size_t(rank)] = done;
+        g->device[size_t(rank)] = ctx->device;
+        ++g->attached;
+    }
+    atl_comm *a = new atl_comm();
+    a->ctx = ctx;
+    a->group = g;
+    a->n_ranks = g->n;
+    a->rank = rank;
+    // every rank attached: peer access towards the other devices (direct xGMI reads; without it the runtime stages
+    // the copy, still correct)
+    int rc = g->barrier("atl_comm_init_local");
+    if (rc) {
+        (void)atl_comm_destroy(a);
+        return rc;
+    }
+    for (int q = 0; q < g->n; ++q) {
+        const int d = g->device[size_t(q)];
+        int can = 0;
+        if (d != ctx->device && hipDeviceCanAccessPeer(&can, ctx->device, d) == hipSuccess && can) {
+            hipError_t e = hipDeviceEnablePeerAccess(d, 0);
+            if (e != hipSuccess) (void)hipGetLastError();  // already enabled: fine
+        }
+    }
+    *out = a;
+    return ATL_OK;
+}
+
+int atl_comm_abort(atl_comm *comm) {
+    if (!comm) return ATL_OK;
+    if (comm->group) {
+        std::lock_guard<std::mutex> lk(comm->group->m);
+        comm->group->aborted = true;
+        comm->group->cv.notify_all();
+    }
+    // RCCL: a rank that never enqueues its collective leaves the others blocked on the device; destroying the
+    // communicator after an error is the caller's recourse (ncclCommAbort is not bound here)
+    return ATL_OK;
+}
+
 int atl_comm_destroy(atl_comm *comm) {
     if (!comm) return ATL_OK;
     if (comm->comm) {
         (void)hipStreamSynchronize(comm->ctx->stream);
         (void)g_rccl.CommDestroy(comm->comm);
+    }
+    if (comm->group) {
+        (void)hipSetDevice(comm->ctx->device);
+        (void)hipStreamSynchronize(comm->ctx->stream);
+        atl_comm_group *g = comm->group;
+        std::lock_guard<std::mutex> lk(g->m);
+        if (g->ready[size_t(comm->rank)]) (void)hipEventDestroy(g->ready[size_t(comm->rank)]);
+        if (g->done[size_t(comm->rank)]) (void)hipEventDestroy(g->done[size_t(comm->rank)]);
+        g->ready[size_t(comm->rank)] = g->done[size_t(comm->rank)] = nullptr;
+        --g->attached;
     }
     delete comm;
     return ATL_OK;
@@ -134,72 +364,86 @@ int atl_comm_destroy(atl_comm *comm) {
 
 int atl_allgather_time(atl_comm *comm, const double *d_local, int64_t N, int64_t T_r, double *d_out,
                        int64_t ld_out) {
-    ATL_REQUIRE(comm && d_local && d_out, "atl_allgather_time: bad argument");
-    ATL_REQUIRE(N >= 0 && T_r >= 0 && N < 65536, "atl_allgather_time: bad shape");
-    ATL_REQUIRE(ld_out >= int64_t(comm->n_ranks) * T_r, "atl_allgather_time: ld_out too small");
-    atl_ctx *ctx = comm->ctx;
-    ATL_HIP_TRY(hipSetDevice(ctx->device));
-    if (N * T_r == 0) return ATL_OK;
-    void *scr = nullptr;
-    int rc = scratch_reserve(ctx, size_t(comm->n_ranks) * size_t(N * T_r) * sizeof(double), &scr);
-    if (rc) return rc;
-    ATL_NCCL_TRY(g_rccl.AllGather(d_local, scr, size_t(N * T_r), ncclDouble, comm->comm, ctx->stream));
-    const dim3 grid(unsigned((T_r + 255) / 256), unsigned(N), unsigned(comm->n_ranks));
-    hipLaunchKernelGGL(k_gather_place, grid, dim3(256), 0, ctx->stream, static_cast<const double *>(scr),
-                       comm->n_ranks, N, T_r, d_out, ld_out);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
-        set_error("atl_allgather_time: kernel launch failed: %s", hipGetErrorString(e));
-        return ATL_E_HIP;
-    }
-    return ATL_OK;
+    ATL_REQUIRE(comm, "atl_allgather_time: comm is NULL");
+    ATL_REQUIRE(T_r >= 0 && comm->n_ranks <= kMaxRanks, "atl_allgather_time: bad shape");
+    int64_t lens[kMaxRanks];
+    for (int r = 0; r < comm->n_ranks; ++r) lens[r] = T_r;
+    return atl_allgather_time_v(comm, d_local, N, lens, d_out, ld_out);  // equal shards: nothing to pad
 }
 
 int atl_allgather_time_v(atl_comm *comm, const double *d_local, int64_t N, const int64_t *h_lens, double *d_out,
                          int64_t ld_out) {
     ATL_REQUIRE(comm && h_lens && d_out, "atl_allgather_time_v: bad argument");
-    ATL_REQUIRE(comm->n_ranks <= kMaxRanks, "atl_allgather_time_v: at most %d ranks", kMaxRanks);
     ATL_REQUIRE(N >= 0 && N < 65536, "atl_allgather_time_v: bad shape");
     RankOffsets ro;
     int64_t Tmax = 0;
-    ro.off[0] = 0;
-    for (int r = 0; r < comm->n_ranks; ++r) {
-        ATL_REQUIRE(h_lens[r] >= 0, "atl_allgather_time_v: negative shard length");
-        ro.off[r + 1] = ro.off[r] + h_lens[r];
-        Tmax = std::max(Tmax, h_lens[r]);
-    }
+    int rc = fill_offsets("atl_allgather_time_v", comm->n_ranks, h_lens, &ro, &Tmax);
+    if (rc) return rc;
     const int64_t T_r = h_lens[comm->rank];
     ATL_REQUIRE(ld_out >= ro.off[comm->n_ranks], "atl_allgather_time_v: ld_out too small");
     ATL_REQUIRE(d_local || N * T_r == 0, "atl_allgather_time_v: d_local is NULL");
     atl_ctx *ctx = comm->ctx;
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     if (N * Tmax == 0) return ATL_OK;
-    // scratch = [send: N x Tmax][recv: n_ranks x N x Tmax]; every rank sends a full-width block
+    // scratch = [send: N x Tmax][recv: n_ranks x N x Tmax]; every rank sends a full-width block (a rank whose
+    // shard has the full width sends its block as it is)
+    const bool pack = T_r < Tmax;
     void *scr = nullptr;
-    int rc = scratch_reserve(ctx, size_t(comm->n_ranks + 1) * size_t(N * Tmax) * sizeof(double), &scr);
+    rc = scratch_reserve(ctx, size_t(comm->n_ranks + 1) * size_t(N * Tmax) * sizeof(double), &scr);
     if (rc) return rc;
     double *send = static_cast<double *>(scr), *recv = send + N * Tmax;
-    if (T_r < Tmax) ATL_HIP_TRY(hipMemsetAsync(send, 0, size_t(N * Tmax) * sizeof(double), ctx->stream));
-    if (N * T_r > 0)
-        ATL_HIP_TRY(hipMemcpy2DAsync(send, size_t(Tmax) * sizeof(double), d_local, size_t(T_r) * sizeof(double),
-                                     size_t(T_r) * sizeof(double), size_t(N), hipMemcpyDeviceToDevice, ctx->stream));
-    ATL_NCCL_TRY(g_rccl.AllGather(send, recv, size_t(N * Tmax), ncclDouble, comm->comm, ctx->stream));
+    if (pack) {
+        ATL_HIP_TRY(hipMemsetAsync(send, 0, size_t(N * Tmax) * sizeof(double), ctx->stream));
+        if (N * T_r > 0)
+            ATL_HIP_TRY(hipMemcpy2DAsync(send, size_t(Tmax) * sizeof(double), d_local, size_t(T_r) * sizeof(double),
+                                         size_t(T_r) * sizeof(double), size_t(N), hipMemcpyDeviceToDevice,
+                                         ctx->stream));
+    }
+    rc = all_gather(comm, pack ? send : d_local, recv, size_t(N * Tmax), "atl_allgather_time_v");
+    if (rc) return rc;
     const dim3 grid(unsigned((Tmax + 255) / 256), unsigned(N), unsigned(comm->n_ranks));
     hipLaunchKernelGGL(k_gather_place_v, grid, dim3(256), 0, ctx->stream, recv, ro, N, Tmax, d_out, ld_out);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
-        set_error("atl_allgather_time_v: kernel launch failed: %s", hipGetErrorString(e));
-        return ATL_E_HIP;
-    }
+    return launched("atl_allgather_time_v");
+}
+
+int atl_gather_place_v_host(const double *h_gathered, int n_ranks, int64_t N, const int64_t *h_lens, double *h_out,
+                            int64_t ld_out) {
+    ATL_REQUIRE(h_gathered && h_lens && h_out && N >= 0, "atl_gather_place_v_host: bad argument");
+    RankOffsets ro;
+    int64_t Tmax = 0;
+    int rc = fill_offsets("atl_gather_place_v_host", n_ranks, h_lens, &ro, &Tmax);
+    if (rc) return rc;
+    ATL_REQUIRE(ld_out >= ro.off[n_ranks], "atl_gather_place_v_host: ld_out too small");
+    // the kernel's grid, walked on the host: (ceil(Tmax / 256) x 256 threads, N, n_ranks)
+    const int64_t gx = (Tmax + 255) / 256;
+    for (int r = 0; r < n_ranks; ++r)
+        for (int64_t n = 0; n < N; ++n)
+            for (int64_t t = 0; t < gx * 256; ++t) {
+                const Placement p = gather_placement(ro, r, n, t, N, Tmax, ld_out);
+                if (p.live) h_out[p.dst] = h_gathered[p.src];
+            }
     return ATL_OK;
 }
 
 int atl_allreduce_sum(atl_comm *comm, double *d_buf, int64_t n) {
     ATL_REQUIRE(comm && (n == 0 || d_buf) && n >= 0, "atl_allreduce_sum: bad argument");
     if (n == 0) return ATL_OK;
-    ATL_HIP_TRY(hipSetDevice(comm->ctx->device));
-    ATL_NCCL_TRY(g_rccl.AllReduce(d_buf, d_buf, size_t(n), ncclDouble, ncclSum, comm->comm, comm->ctx->stream));
-    return ATL_OK;
+    atl_ctx *ctx = comm->ctx;
+    ATL_HIP_TRY(hipSetDevice(ctx->device));
+    if (!comm->group) {
+        ATL_NCCL_TRY(g_rccl.AllReduce(d_buf, d_buf, size_t(n), ncclDouble, ncclSum, comm->comm, ctx->stream));
+        return ATL_OK;
+    }
+    // local transport: gather every rank's vector, then add them in rank order (after the gather's closing waits
+    // nobody still reads d_buf, so the sum may go back in place)
+    void *scr = nullptr;
+    int rc = scratch_reserve(ctx, size_t(comm->n_ranks) * size_t(n) * sizeof(double), &scr);
+    if (rc) return rc;
+    rc = local_all_gather(comm, d_buf, static_cast<double *>(scr), size_t(n), "atl_allreduce_sum");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_sum_ranks, dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       static_cast<const double *>(scr), comm->n_ranks, n, d_buf);
+    return launched("atl_allreduce_sum");
 }
 
 }  // extern "C"

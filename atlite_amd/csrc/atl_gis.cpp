@@ -91,7 +91,8 @@ int atl_indicator_polygons(int64_t n_shapes, const int64_t *h_shape_ring_ptr, in
     std::vector<Pt> ring, strip, tmp, cellp;
     for (int64_t s = 0; s < n_shapes; ++s) {
         acc.clear();
-        for (int64_t r = h_shape_ring_ptr[s]; r < h_shape_ring_ptr[s + 1]; ++r) {
+        const bool finite = atl::shape_is_finite(s, h_shape_ring_ptr, h_ring_ptr, h_xy);  // else: an empty row
+        for (int64_t r = h_shape_ring_ptr[s]; finite && r < h_shape_ring_ptr[s + 1]; ++r) {
             ATL_REQUIRE(r >= 0 && r < n_rings, "atl_indicator_polygons: ring index out of range");
             const int64_t v0 = h_ring_ptr[r], v1 = h_ring_ptr[r + 1];
             ring.clear();

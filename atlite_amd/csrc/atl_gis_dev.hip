@@ -124,7 +124,9 @@ static int indicator_integral(atl_ctx *ctx, int64_t n_shapes, const int64_t *h_s
     for (int64_t s = 0; s < n_shapes; ++s) {
         double bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
         bool any = false;
-        for (int64_t r = h_shape_ring_ptr[s]; r < h_shape_ring_ptr[s + 1]; ++r) {
+        // a NaN / inf vertex anywhere in the shape: no edges, an empty row (as the host clipper)
+        const bool finite = shape_is_finite(s, h_shape_ring_ptr, h_ring_ptr, h_xy);
+        for (int64_t r = h_shape_ring_ptr[s]; finite && r < h_shape_ring_ptr[s + 1]; ++r) {
             ATL_REQUIRE(r >= 0 && r < n_rings, "atl_indicator_polygons_device: ring index out of range");
             const double *p = h_xy + 2 * h_ring_ptr[r];
             int64_t n = h_ring_ptr[r + 1] - h_ring_ptr[r];
@@ -157,7 +159,7 @@ static int indicator_integral(atl_ctx *ctx, int64_t n_shapes, const int64_t *h_s
             }
         }
         shape_edge0[size_t(s) + 1] = int64_t(all.size());
-        if (!any || !(bx1 >= bx0) || !(by1 >= by0)) continue;  // NaN coordinates: no entries
+        if (!any || !(bx1 >= bx0) || !(by1 >= by0)) continue;  // no ring with >= 3 vertices, or a non-finite vertex: no entries
         Box &b = box[size_t(s)];
         b.i0 = clamped_floor((bx0 - xlo) / dx, 0, X);  // X / -1: a box beside the grid stays empty (i0 > i1)
         b.i1 = clamped_floor((bx1 - xlo) / dx, -1, X - 1);

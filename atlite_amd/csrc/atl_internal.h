@@ -123,6 +123,17 @@ inline bool offsets_ok(const int64_t *p, int64_t n) {
     return true;
 }
 
+// every vertex coordinate of every ring of shape s is finite (offsets already validated).  NaN / inf vertices are
+// invalid geometry for the reference's shapely too; both indicator-matrix algorithms give such a shape an EMPTY row -
+// std::min / std::max drop a NaN operand, so a NaN in the MIDDLE of a ring would otherwise leave a valid-looking
+// bounding box around a ring with two broken edges
+inline bool shape_is_finite(int64_t s, const int64_t *shape_ring_ptr, const int64_t *ring_ptr, const double *xy) {
+    for (int64_t r = shape_ring_ptr[s]; r < shape_ring_ptr[s + 1]; ++r)
+        for (int64_t v = 2 * ring_ptr[r]; v < 2 * ring_ptr[r + 1]; ++v)
+            if (!__builtin_isfinite(xy[v])) return false;
+    return true;
+}
+
 // floor(v) as a grid index clamped to [lo, hi]: coordinates come from the caller's polygons, and converting a double
 // beyond the 64-bit range (1e300, +-inf) to an integer is undefined; NaN gives lo (callers skip NaN boxes beforehand)
 inline int64_t clamped_floor(double v, int64_t lo, int64_t hi) {

@@ -133,6 +133,25 @@ class RcclComm:
         _lib.check(_lib.load().atl_comm_unique_id(buf))
         return bytes(buf.raw)
 
+    def abort(self):
+        if getattr(self, "handle", None):
+            self.ctx.lib.atl_comm_abort(self.handle)
+
+    def gather_time_v(self, local, N, lens, out=None):
+        """Ragged all-gather along time: ``local`` = this rank's DeviceArray (N, lens[rank]) (None for an empty
+        shard) -> DeviceArray (N, sum lens), the blocks in rank order (``atl_allgather_time_v``)."""
+        import ctypes as C
+
+        from ._lib import check
+
+        total = int(sum(lens))
+        if out is None:
+            out = self.ctx.empty((N, total))
+        h_lens = (C.c_int64 * self.n_ranks)(*[int(v) for v in lens])
+        check(self.ctx.lib.atl_allgather_time_v(self.handle, local.ptr if local is not None else None, N, h_lens,
+                                                out.ptr, total))
+        return out
+
     def gather_time(self, local):
         """local: DeviceArray (N, T_r), same T_r on every rank -> DeviceArray (N, n_ranks * T_r)."""
         from ._lib import check
@@ -158,3 +177,42 @@ class RcclComm:
             self.close()
         except Exception:
             pass
+
+
+class LocalGroup:
+    """Rendezvous object of the in-process transport (C ABI ``atl_comm_group_*``): create one, hand it to the
+    ``LocalComm`` of every rank (one host thread each - all ranks must be inside the constructor at once)."""
+
+    def __init__(self, n_ranks):
+        import ctypes as C
+
+        from . import _lib
+
+        self.n_ranks = int(n_ranks)
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self.lib.atl_comm_group_create(self.n_ranks, C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.atl_comm_group_destroy(self.handle)
+            self.handle = None
+
+
+class LocalComm(RcclComm):
+    """
+    Communicator of the in-process transport: the ranks are host threads of this process (distinct devices, or one
+    device shared by several ranks), every rank pulls its peers' blocks with peer copies on its own stream.  Same
+    collectives as ``RcclComm``; the all-reduce adds in rank order, so every rank holds the same bits.
+    """
+
+    def __init__(self, ctx, group, rank):
+        import ctypes as C
+
+        from ._lib import check
+
+        self.ctx, self.n_ranks, self.rank, self.group = ctx, group.n_ranks, int(rank), group
+        h = C.c_void_p()
+        check(ctx.lib.atl_comm_init_local(ctx.handle, group.handle, self.rank, C.byref(h)))
+        self.handle = h

@@ -283,8 +283,18 @@ class Dataset:
         if la.name is None:
             la.name = name
         self._vars[name] = la
+        self._invalidate(name)
+
+    def __delitem__(self, name):
+        del self._vars[name]
+        self._invalidate(name)
+
+    def _invalidate(self, name):
+        """A variable was replaced, added or removed: its device copy and every cached time shard of the dataset
+        (the multi-GPU executor's per-rank ``isel_time`` views and THEIR device copies) are stale."""
         if hasattr(self, "_device_cache"):
             self._device_cache.pop(name, None)
+        self.__dict__.pop("_shard_cache", None)
 
     def __getitem__(self, name):
         if name in self._vars:

@@ -17,9 +17,13 @@ thread, so the PCIe links work in parallel), run the same fused kernels on it, a
                                           of the host result, each device downloads its own
 
 Select the devices with ``ATLITE_HIP_DEVICES=0,1,...,7``, ``atlite_amd.set_devices([...])`` or
-``Cutout(..., devices=[...])``.  RCCL cannot put one GPU into a communicator twice, so a device list
-with repeats (``[0, 0]`` - how the tests exercise this module on a one-GPU box) reassembles through
-host memory instead; everything else is the same code.
+``Cutout(..., devices=[...])``.  Transport of the collective (``ATLITE_HIP_GATHER``): ``rccl`` (default for
+distinct devices), ``p2p`` - the library's in-process transport, every rank pulling its peers' blocks with peer
+copies on its own stream (``atl_comm_init_local``; the default for a device list with repeats such as
+``[0, 0, 0]``, which RCCL cannot form a communicator for - how a one-GPU box runs the N-rank collective code,
+ragged shards and all) - or ``host`` (blocks downloaded and placed by the host).  Whatever the transport, the
+ranks call the same ``atl_allgather_time_v`` / ``atl_allreduce_sum``.  A rank that fails aborts the group's
+communicators on its way out, so its peers raise instead of waiting inside a collective.
 """
 
 from __future__ import annotations
@@ -67,35 +71,100 @@ def group(devices):
 
 
 class DeviceGroup:
-    """One Context + one host thread per entry of ``devices`` (a single process, one node)."""
+    """One Context + one host thread per entry of ``devices`` (a single process, one node).
+    ``ctxs`` / ``comm_factory`` are injection points for tests: ``comm_factory(group, rank)`` must return an object
+    with ``gather_time_v`` / ``allreduce_sum`` / ``abort`` / ``close`` (``distributed.RcclComm``'s interface)."""
 
-    def __init__(self, devices):
+    def __init__(self, devices, ctxs=None, comm_factory=None):
         self.devices = tuple(int(d) for d in devices)
         self.n = len(self.devices)
         assert self.n >= 1
-        self.ctxs = [Context(d) for d in self.devices]
+        self.ctxs = list(ctxs) if ctxs is not None else [Context(d) for d in self.devices]
         self.pool = ThreadPoolExecutor(self.n, thread_name_prefix="atlite-hip-dev")
         self.distinct = len(set(self.devices)) == self.n
+        self._comm_factory = comm_factory
         self._comms = None
+        self._comms_transport = None
+        self._local_group = None
 
     def map(self, fn):
-        """fn(rank) on every rank's thread, concurrently (ctypes calls release the GIL)."""
-        futs = [self.pool.submit(fn, r) for r in range(self.n)]
-        return [f.result() for f in futs]
+        """fn(rank) on every rank's thread, concurrently (ctypes calls release the GIL).  The first failure aborts
+        the group's communicators - peers waiting inside a collective for the failed rank raise instead of hanging -
+        and is re-raised once every rank has returned."""
+        failures = []  # in the order they happened: the first one is the cause, the rest are its victims
+
+        def guarded(r):
+            try:
+                return fn(r)
+            except BaseException as e:  # noqa: BLE001 - re-raised by map()
+                failures.append(e)
+                for c in self._comms or ():
+                    try:
+                        c.abort()
+                    except Exception:
+                        pass
+                raise
+
+        futs = [self.pool.submit(guarded, r) for r in range(self.n)]
+        res = []
+        for f in futs:
+            try:
+                res.append(f.result())
+            except BaseException:  # noqa: BLE001
+                res.append(None)
+        if failures:
+            self._drop_comms()  # an aborted group stays aborted: the next call builds a fresh one
+            raise failures[0]
+        return res
 
     @property
-    def use_rccl(self):
-        return self.distinct and self.n > 1 and os.environ.get("ATLITE_HIP_GATHER", "rccl") == "rccl"
+    def transport(self):
+        """'rccl' | 'p2p' | 'host' (see the module docstring)."""
+        if self.n == 1:
+            return "host"
+        if self._comm_factory is not None:
+            return "custom"
+        t = os.environ.get("ATLITE_HIP_GATHER", "").strip().lower() or ("rccl" if self.distinct else "p2p")
+        if t not in ("rccl", "p2p", "host"):
+            raise ValueError(f"ATLITE_HIP_GATHER={t!r}: expected 'rccl', 'p2p' or 'host'")
+        if t == "rccl" and not self.distinct:
+            t = "p2p"  # RCCL cannot put one GPU into a communicator twice
+        return t
+
+    @property
+    def use_collective(self):
+        return self.transport != "host"
 
     def comms(self):
-        """In-process RCCL communicators, rank r on device r's context (ncclCommInitRank rendezvous:
-        all ranks must be inside the call at once, hence one thread each)."""
+        """The group's communicators, rank r on device r's context (the rendezvous of either transport needs all
+        ranks inside the call at once, hence one thread each)."""
+        t = self.transport
+        if self._comms is not None and self._comms_transport != t:  # $ATLITE_HIP_GATHER changed between calls
+            self._drop_comms()
         if self._comms is None:
-            from .distributed import RcclComm
+            from .distributed import LocalComm, LocalGroup, RcclComm
 
-            uid = RcclComm.unique_id()
-            self._comms = self.map(lambda r: RcclComm(self.ctxs[r], self.n, r, uid))
+            self._comms_transport = t
+            if t == "custom":
+                self._comms = self.map(lambda r: self._comm_factory(self, r))
+            elif t == "rccl":
+                uid = RcclComm.unique_id()
+                self._comms = self.map(lambda r: RcclComm(self.ctxs[r], self.n, r, uid))
+            else:
+                self._local_group = LocalGroup(self.n)
+                self._comms = self.map(lambda r: LocalComm(self.ctxs[r], self._local_group, r))
         return self._comms
+
+    def _drop_comms(self):
+        for c in self._comms or ():
+            try:
+                c.close()
+            except Exception:
+                pass
+        self._comms = None
+        if self._local_group is not None:
+            self._local_group.close()
+            self._local_group = None
 
     # -- data placement ------------------------------------------------------------------------
     def _shards(self, ds, edges):
@@ -180,23 +249,26 @@ class DeviceGroup:
             self.map(pull)
             return res
         N = matrix.shape[0]
-        if self.use_rccl and contiguous:
-            comms = self.comms()
-            h_lens = (C.c_int64 * self.n)(*lens)
-
-            def gather(r):
-                ctx = self.ctxs[r]
-                full = ctx.empty((N, n_slots))
-                check(ctx.lib.atl_allgather_time_v(comms[r].handle, outs[r].ptr if outs[r] is not None else None, N,
-                                                   h_lens, full.ptr, n_slots))
-                return full.numpy() if r == 0 else ctx.sync()
-
-            return self.map(gather)[0]
+        if self.use_collective and contiguous:
+            return self._gather_series(outs, N, lens)
         res = np.empty((N, n_slots))
         for r in range(self.n):
             if outs[r] is not None and lens[r]:
                 res[:, slots[r][0]:slots[r][1]] = outs[r].numpy().reshape(N, lens[r])
         return res
+
+    def _gather_series(self, outs, N, lens):
+        """Ragged all-gather of the per-rank (N, lens[r]) blocks along time: every rank ends up with the whole
+        (N, sum lens) series on its device (``atl_allgather_time_v``), rank 0 downloads it."""
+        comms = self.comms()
+
+        def gather(r):
+            # comms[r].gather_time_v allocates the result BEFORE it enters the collective: an allocation failure
+            # raises here (and map() aborts the group) instead of leaving the peers inside the all-gather
+            full = comms[r].gather_time_v(outs[r], N, lens)
+            return full.numpy() if r == 0 else self.ctxs[r].sync()
+
+        return self.map(gather)[0]
 
     def _reduce_cells(self, outs, S, time_agg):
         """Global nan-skipping sum / mean over time from the per-shard (sum, count) (convert.py:51-56)."""
@@ -204,12 +276,11 @@ class DeviceGroup:
         if time_agg == "mean":
             assert have_counts
         k = 2 if have_counts else 1
-        if self.use_rccl and have_counts and all(o is not None for o in outs):
+        if self.use_collective and have_counts and all(o is not None for o in outs):
             comms = self.comms()
 
             def red(r):
-                buf = outs[r][0]
-                check(self.ctxs[r].lib.atl_allreduce_sum(comms[r].handle, buf.ptr, k * S))
+                buf = comms[r].allreduce_sum(outs[r][0])  # [sum | count], 2 S doubles, in place
                 return buf.numpy() if r == 0 else self.ctxs[r].sync()
 
             tot = self.map(red)[0]
@@ -224,9 +295,7 @@ class DeviceGroup:
             return tot[:S] / tot[S:]
 
     def close(self):
-        for c in self._comms or ():
-            c.close()
-        self._comms = None
+        self._drop_comms()
         self.pool.shutdown(wait=True)
         for c in self.ctxs:
             c.close()

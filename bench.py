@@ -175,8 +175,38 @@ def generate_pv(ctx, synthetic, solar, _lib, T_loc, Y, X, off, stored_angles):
     return big, x, y, tables
 
 
+def self_launch(a):
+    """``python bench.py --gpus N`` without an external launcher: re-run this very command line under
+    ``python -m torch.distributed.run`` (one rank per GPU, rendezvous on 127.0.0.1) and hand its exit code back.
+    Returns None when the process is already a rank of a launched job (or N == 1)."""
+    if a.gpus <= 1 or "WORLD_SIZE" in os.environ or a.emulate_shard:
+        return None
+    import socket
+    import subprocess
+
+    if not a.debug_gloo_one_gpu:
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            sys.exit(f"bench.py: --gpus {a.gpus} but this node exposes {have} GPU(s) (torch.cuda.device_count()); "
+                     f"run with --gpus {max(have, 1)} or on a node with {a.gpus} GPUs")
+    with socket.socket() as s:  # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    rc = self_launch(a)
+    if rc is not None:
+        sys.exit(rc)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -212,7 +242,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     n_gpus = world
-    assert a.gpus == n_gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert a.gpus == n_gpus or (world == 1 and a.emulate_shard) or (world == 1 and a.gpus == 1), \
+        f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     # One explicit (non-default) torch stream carries our kernels; the RCCL collectives run on the process
@@ -402,6 +433,28 @@ def main():
           ("_nightskip" if a.night_skip else "")
     traffic, traffic_src = pmc_traffic(tag)
 
+    # per-rank kernel time and the collective by itself (outside the timed region): what a rank's step is made of
+    per_rank_kernel_ms = gather_ms = None
+    if world > 1:
+        cdev = "cpu" if a.debug_gloo_one_gpu else dev
+        mine = torch.tensor([k_ms], dtype=torch.float64, device=cdev)
+        lst = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(lst, mine)
+        per_rank_kernel_ms = [float(v.item()) for v in lst]
+        if not a.debug_gloo_one_gpu:
+            reps = 10
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(reps):  # all-gather of every piece + the strided placement copy, nothing to hide behind
+                for i in range(P):
+                    dist.all_gather_into_tensor(gbuf[i].view(-1), piece[i].view(-1))
+                    if full3 is not None:
+                        full3[:, :, pe[i]:pe[i + 1]].copy_(gbuf[i].permute(1, 0, 2))
+            fence()
+            tg = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device=dev)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            gather_ms = float(tg.item())
+
     # the reassembled result holds every rank's block in place
     if world > 1:
         res = step(pp_main)
@@ -458,6 +511,13 @@ def main():
             "algorithmic_bytes": algo_bytes,
         },
     }
+    if world > 1:
+        result["multi_gpu"] = {
+            "per_rank_kernel_ms": per_rank_kernel_ms,  # fused kernel(s) of one step on each rank's own shard
+            "gather_ms": gather_ms,  # serial all-gather + placement of one step's result (max over ranks), untimed region
+            "result_bytes": int(N * sum(shard_lens) * 8),
+            "transport": "gloo on host copies (debug, all ranks on GPU 0)" if a.debug_gloo_one_gpu else "RCCL over xGMI",
+        }
     if a.emulate_shard:
         # what one rank of an N-way strong-scaling run spends per step besides the collective
         result["emulated_shard"] = {

@@ -426,6 +426,25 @@ int atl_allreduce_sum(atl_comm *comm, double *d_buf, int64_t n);
  * d_out (N x sum h_lens, row stride ld_out) on every rank.  h_lens: n_ranks host values, the same on all ranks. */
 int atl_allgather_time_v(atl_comm *comm, const double *d_local, int64_t N, const int64_t *h_lens, double *d_out,
                          int64_t ld_out);
+/* In-process transport: the ranks are host threads of one process (one atl_ctx each, on distinct devices or - for
+ * tests on a one-GPU box - sharing one).  Every rank pulls its peers' blocks with peer copies on its own stream
+ * (point-to-point xGMI reads, no ring), ordered by events; the host rendezvous inside a collective gives up after
+ * $ATLITE_HIP_COMM_TIMEOUT_S (120 s) and fails every waiting rank instead of hanging when a peer never arrives.
+ *   once : atl_comm_group_create(n_ranks, &group)
+ *   all  : atl_comm_init_local(ctx, group, rank, &comm)      (all ranks inside the call at once, like atl_comm_init)
+ * The collectives above work on either kind of communicator; atl_allreduce_sum adds in rank order here (the same
+ * bits on every rank).  atl_comm_abort wakes the group's waiting ranks with an error (a rank that failed before its
+ * collective calls it on the way out).  Destroy the communicators before the group. */
+typedef struct atl_comm_group atl_comm_group;
+int atl_comm_group_create(int n_ranks, atl_comm_group **out);
+int atl_comm_group_destroy(atl_comm_group *group);
+int atl_comm_init_local(atl_ctx *ctx, atl_comm_group *group, int rank, atl_comm **out);
+int atl_comm_abort(atl_comm *comm);
+/* Host instantiation of the placement step of atl_allgather_time_v (the kernel's own index function walked over the
+ * kernel's own grid): h_gathered = [rank][N][max h_lens] as the collective delivers it -> h_out (N x sum h_lens, row
+ * stride ld_out).  No device needed: the CPU tests pin the placement of ragged ranks with it. */
+int atl_gather_place_v_host(const double *h_gathered, int n_ranks, int64_t N, const int64_t *h_lens, double *h_out,
+                            int64_t ld_out);
 
 /* ---- diagnostics ------------------------------------------------------------------------
  * Evaluates the kernels' lean fp64 math (atl_math.h) elementwise, for accuracy tests:

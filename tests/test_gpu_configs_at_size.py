@@ -1,8 +1,9 @@
 """
 GPU, BASELINE.json configs[2], [3], [4] at THEIR OWN sizes against the CPU oracle (configs[1] at size:
 tests/test_gpu_fullsize_properties.py).  The cubes are generated in HBM; the oracle cannot run a
-full cube in seconds, so each run is compared with it on >= 150 sampled time steps (night, sunrise,
-noon, a day boundary, the last step) and - for the time-reduced outputs - on sampled grid cells over
+full cube in seconds, so each run is compared with it on >= 120 sampled time steps per launch (night, sunrise,
+noon, a day boundary, the last step; for the in-kernel solar position also every step within 2 h of a sunrise or
+sunset at three latitudes on ten days of the year; >= 40 calendar days for heat demand) and - for the time-reduced outputs - on sampled grid cells over
 ALL time steps.  Tolerance: rtol 1e-10, atol 1e-12 * max (north_star).
 
   config 3  Cutout.wind('Vestas_V112_3MW') per cell, 8760 x 400 x 400: series AND the
@@ -47,6 +48,25 @@ def sample_steps(T, n_random=40, seed=0):
     sel = np.concatenate([np.arange(0, 48), np.arange(mid, mid + 48), np.arange(T - 24, T),
                           rng.integers(0, T, n_random)])
     return np.unique(np.clip(sel, 0, T - 1))
+
+
+def twilight_steps(time, x, y, n_days=6, band=2):
+    """Every step within +-``band`` h of a crossing of the 1 degree altitude cut-off (sunrise / sunset) at three
+    latitudes of the grid (south edge, middle, north edge; central meridian) on ``n_days`` days spread over the axis:
+    the steps where the in-kernel solar position and the oracle's could disagree about day and night."""
+    T = len(time)
+    lats = np.array([y[0], y[len(y) // 2], y[-1]])
+    xm = np.array([x[len(x) // 2]])
+    thr = np.radians(1.0)
+    sel = []
+    for d in np.linspace(0, T // 24 - 1, n_days).astype(int):
+        t0, t1 = int(d) * 24, min(int(d) * 24 + 25, T)
+        alt, _ = orc.solar_position(time[t0:t1], xm, lats, "-30min")
+        dark = alt.reshape(t1 - t0, len(lats)) < thr
+        flips = np.nonzero(dark[1:] != dark[:-1])[0]  # (step, latitude) pairs
+        for f in flips:
+            sel.extend(range(t0 + int(f) - band + 1, t0 + int(f) + band + 1))
+    return np.unique(np.clip(np.asarray(sel, dtype=np.int64), 0, T - 1))
 
 
 def tessellation_matrix(Y, X, n, kind="tessellation", seed=42):
@@ -141,7 +161,8 @@ def test_config4_pv_shard_stored_angles(ctx, c4_matrix, shard):
     out = ctx.pv(inputs, PARAMS, TS, S, plan=plan, options=dict(night_skip=False)).numpy()
     skip = ctx.pv(inputs, PARAMS, TS, S, plan=plan, options=dict(night_skip=True)).numpy()
     np.testing.assert_array_equal(skip, out)
-    sel = sample_steps(TS, n_random=0)[::2]  # 60 steps per shard, 180 over the three shards
+    sel = sample_steps(TS, n_random=0)  # 120 steps per shard, 360 over the three shards
+    assert len(sel) >= 120
     host = {k: rows(inputs[k], sel) for k in synthetic.PV_VARS}
     dark = (host["solar_altitude"] < np.radians(1.0)).all(axis=1)
     # (the summer shard has no step that is dark everywhere: midnight sun in the north of the grid)
@@ -178,8 +199,10 @@ def test_config4_pv_full_year_in_kernel_solar_position(ctx, c4_matrix):
     plan = ctx.plan(c4_matrix, row_len=X)
     out = ctx.pv(big, PARAMS, T, S, plan=plan, solar_tables=tables).numpy()
     assert out.shape == (N, T) and np.isfinite(out).all() and out.min() >= 0.0
-    sel = sample_steps(T, n_random=30)[::2]
-    assert len(sel) >= 70
+    tw = twilight_steps(time_all, x, y, n_days=10)  # sunrise / sunset bands at three latitudes, ten days over the year
+    assert len(tw) >= 60
+    sel = np.unique(np.concatenate([sample_steps(T, n_random=30), tw]))
+    assert len(sel) >= 200
     host = {k: rows(big[k], sel) for k in five}
     a_, z_ = orc.solar_position(time_all[sel], x, y, "-30min")
     host["solar_altitude"], host["solar_azimuth"] = a_.reshape(len(sel), S), z_.reshape(len(sel), S)
@@ -219,7 +242,8 @@ def test_config5_heat_demand_and_runoff(ctx):
     assert (pd.DatetimeIndex(hd.coords["time"]) == labels).all()
     hd = np.asarray(hd.values)
     rng = np.random.default_rng(2)
-    days = np.unique(np.concatenate([[0, 1, D // 2, D - 2, D - 1], rng.integers(0, D, 8)]))
+    days = np.unique(np.concatenate([[0, 1, D // 2, D - 2, D - 1], rng.integers(0, D, 40)]))
+    assert len(days) >= 40
     for d in days:
         blk = inp["temperature"].slab(int(day_ptr[d]), int(day_ptr[d + 1])).numpy()
         r = orc.convert_heat_demand(blk, np.array([0, blk.shape[0]]), threshold=15.0, a=1.3, constant=0.5)

@@ -2,10 +2,11 @@
 GPU: the single-process multi-device executor (atlite_amd.multigpu) behind the public API.
 A one-GPU box cannot form an RCCL communicator with more than one rank, so the device list repeats
 device 0 ([0, 0], [0, 0, 0]): every rank has its own Context / stream / plan / host thread and its own
-time shard - the same code path as a real node except for the reassembly transport (host placement
-instead of atl_allgather_time_v / atl_allreduce_sum, which are covered by the n_ranks = 1 test below
-and run for real in the driver's multi-GPU bench).  Results must equal the single-device results and
-the reference-generated golden vectors.
+time shard, and the reassembly runs the N-rank collective code - atl_allgather_time_v (pack, gather, k_gather_place_v
+for ragged ranks) and atl_allreduce_sum - over the library's in-process transport (atl_comm_init_local: every rank
+pulls its peers' blocks with device copies on its own stream).  On a real node the same calls run over RCCL (the
+n_ranks = 1 test below, the driver's multi-GPU bench).  Results must equal the single-device results and the
+reference-generated golden vectors.
 """
 import warnings
 from pathlib import Path
@@ -171,3 +172,107 @@ def test_bench_collective_branch_over_rccl_on_one_rank():
     j = json.loads(line)
     assert j["parity"]["ok"] and j["parity"]["max_rel_err"] < 1e-10, j["parity"]
 
+
+
+# ---- the N-rank collective code on ONE GPU: the in-process transport (atl_comm_init_local) ----------------------
+def _local_ranks(n):
+    """n Contexts on device 0 + their communicators of one local group (each built on its own thread: the rendezvous
+    needs all ranks inside the constructor at once)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from atlite_amd.device import Context
+    from atlite_amd.distributed import LocalComm, LocalGroup
+
+    ctxs = [Context(0) for _ in range(n)]
+    grp = LocalGroup(n)
+    pool = ThreadPoolExecutor(n)
+    comms = list(pool.map(lambda r: LocalComm(ctxs[r], grp, r), range(n)))
+    return ctxs, grp, comms, pool
+
+
+@pytest.mark.parametrize("lens", [[5, 0, 9], [1095, 1096, 1095, 1094], [300, 300, 300], [1, 700, 2, 3, 257]])
+def test_local_transport_ragged_allgather_and_ordered_allreduce(lens):
+    """atl_allgather_time_v / atl_allreduce_sum with MORE THAN ONE rank on the device: pack, gather (every rank pulls
+    its peers' blocks on its own stream), k_gather_place_v for rank >= 1, on every rank."""
+    n, N = len(lens), 7
+    rng = np.random.default_rng(sum(lens))
+    blocks = [rng.normal(size=(N, m)) for m in lens]
+    want = np.concatenate(blocks, axis=1)
+    ctxs, grp, comms, pool = _local_ranks(n)
+    try:
+        def rank(r):
+            local = ctxs[r].upload(blocks[r]) if lens[r] else None
+            full = comms[r].gather_time_v(local, N, lens)
+            again = comms[r].gather_time_v(local, N, lens)  # a second collective reuses events and scratch
+            vec = ctxs[r].upload(np.arange(1000, dtype=np.float64) * (r + 1) + 0.1 * r)
+            comms[r].allreduce_sum(vec)
+            return full.numpy(), again.numpy(), vec.numpy()
+
+        res = list(pool.map(rank, range(n)))
+        tot = np.zeros(1000)
+        for r in range(n):  # rank order: the same bits on every rank
+            tot += np.arange(1000, dtype=np.float64) * (r + 1) + 0.1 * r
+        for full, again, vec in res:
+            np.testing.assert_array_equal(full, want)
+            np.testing.assert_array_equal(again, want)
+            np.testing.assert_array_equal(vec, tot)
+        if len(set(lens)) == 1:  # equal shards: atl_allgather_time is the same code without padding
+            eq = list(pool.map(lambda r: comms[r].gather_time(ctxs[r].upload(blocks[r])).numpy(), range(n)))
+            for e in eq:
+                np.testing.assert_array_equal(e, want)
+    finally:
+        for c in comms:
+            c.close()
+        grp.close()
+        pool.shutdown()
+        for c in ctxs:
+            c.close()
+
+
+def test_local_transport_times_out_instead_of_hanging(monkeypatch):
+    """A rank that never reaches the collective: its peers get an error after $ATLITE_HIP_COMM_TIMEOUT_S."""
+    from atlite_amd._lib import AtliteHipError
+
+    monkeypatch.setenv("ATLITE_HIP_COMM_TIMEOUT_S", "1.5")
+    ctxs, grp, comms, pool = _local_ranks(3)
+    try:
+        def rank(r):
+            if r == 2:
+                return "absent"
+            try:
+                comms[r].gather_time_v(ctxs[r].upload(np.ones((2, 4))), 2, [4, 4, 4])
+            except (AtliteHipError, RuntimeError) as e:
+                return str(e)
+            return "no error"
+
+        res = list(pool.map(rank, range(3)))
+        assert res[2] == "absent"
+        assert all(("did not reach the collective" in m) or ("aborted" in m) for m in res[:2]), res
+    finally:
+        for c in comms:
+            c.close()
+        grp.close()
+        pool.shutdown()
+        for c in ctxs:
+            c.close()
+
+
+def test_executor_uses_the_collective_for_repeated_devices_and_host_placement_on_request(monkeypatch):
+    g, gw = load("pv"), load("gateway_pv")
+    S = len(g["y"]) * len(g["x"])
+    M = sp.csr_matrix((gw["matrix_data"], gw["matrix_indices"], gw["matrix_indptr"]), shape=(5, S))
+    kw = dict(panel="CSi", orientation={"slope": 30.0, "azimuth": 180.0}, matrix=M, aggregate_time=None)
+    monkeypatch.delenv("ATLITE_HIP_GATHER", raising=False)
+    many = cutout_from(g, PV_VARS, devices=[0, 0, 0])
+    grp = multigpu.group([0, 0, 0])
+    assert grp.transport == "p2p"
+    a = many.pv(**kw).values
+    assert grp._comms is not None and len(grp._comms) == 3  # the ragged all-gather ran over three ranks
+    cm = many.pv(aggregate_time="mean", panel="CSi", orientation={"slope": 30.0, "azimuth": 180.0}).values  # all-reduce
+    monkeypatch.setenv("ATLITE_HIP_GATHER", "host")
+    assert grp.transport == "host"
+    b = many.pv(**kw).values
+    np.testing.assert_array_equal(a, b)
+    close(a, gw["series_matrix"])
+    close(cm, gw["cells_mean"])
+    close(many.pv(aggregate_time="mean", panel="CSi", orientation={"slope": 30.0, "azimuth": 180.0}).values, gw["cells_mean"])

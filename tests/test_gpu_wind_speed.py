@@ -55,6 +55,14 @@ def test_extrapolate_wind_speed_api():
     forced = wind.extrapolate_wind_speed(ds, 30, from_height=100)
     close(np.asarray(forced.values).reshape(T, -1), orc.extrapolate_wind_speed(raw["wnd100m"], raw["roughness"], 30, 100, "logarithmic"))
     assert wind.extrapolate_wind_speed(ds, 100) is ds["wnd100m"]  # fast lane
+    # the fast lane also holds for a spec constructed directly, whatever from_height says, and keeps the stored attrs
+    from atlite_amd import convert as cv
+
+    ds["wnd100m"].attrs = {"units": "m s**-1", "long_name": "stored 100 metre wind speed"}
+    spec = cv._WindSpeedSpec(ds, 100, from_height=10)
+    assert spec.method is None and spec.wnd == "wnd100m" and spec.attrs["long_name"] == "stored 100 metre wind speed"
+    lane = cv._finish(cv._per_cell(spec, ds))
+    np.testing.assert_array_equal(np.asarray(lane.values), raw["wnd100m"].reshape(T, Y, X))
     with pytest.raises(ValueError, match="Interpolation method must be 'logarithmic' or 'power'"):
         wind.extrapolate_wind_speed(ds, 80, method="cubic")
     bare = Dataset({"wnd100m": raw["wnd100m"]}, dict(time=H.times(T), y=y, x=x))

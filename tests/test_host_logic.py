@@ -726,3 +726,23 @@ def test_hostile_offsets_are_refused_before_they_are_followed():
                                                np.array([[-np.inf, 0.0], [1.0, 0.0], [1.0, 1.0]]),
                                                np.array([[0.5, 0.5], [2.5, 0.5], [2.5, 2.5], [0.5, 2.5]])], ctx=ctx).toarray()
         assert M[0].sum() == 0.0 and np.isfinite(M).all() and abs(M[2].sum() - 4.0) < 1e-12
+
+
+def test_a_nan_vertex_in_the_middle_of_a_ring_empties_the_shape_in_both_algorithms():
+    """ADVICE r2: std::min / std::max drop a NaN operand, so a NaN vertex that is not the first one used to leave a valid
+    bounding box around a ring with two broken edges (NaN areas in one column, wrong areas elsewhere).  A shape with any
+    non-finite coordinate gets an empty row - from the host clipper and from the line-integral algorithm alike."""
+    from atlite_amd import gis
+
+    x, y = np.arange(6.0), np.arange(5.0)
+    good = np.array([[0.5, 0.5], [3.5, 0.5], [3.5, 2.5], [0.5, 2.5]])
+    for bad_vertex in (np.nan, np.inf, -np.inf):
+        for k in range(4):  # the non-finite vertex at every position of the ring, x or y
+            for xy in (0, 1):
+                ring = good.copy()
+                ring[k, xy] = bad_vertex
+                A = gis.compute_indicatormatrix(x, y, [good, ring, good + 1.0], ctx=None).toarray()
+                B = gis.compute_indicatormatrix(x, y, [good, ring, good + 1.0], ctx="integral-host").toarray()
+                for M in (A, B):
+                    assert np.isfinite(M).all() and not M[1].any() and M[0].any() and M[2].any()
+                np.testing.assert_allclose(A, B, atol=1e-12)
