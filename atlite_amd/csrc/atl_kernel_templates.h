@@ -531,7 +531,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
 // LDS and a loop instead of eight unrolled slots the kernel needs < 128 VGPRs: 4 waves per SIMD, for which
 // the LDS budget (160 KiB / 16 waves) leaves kRowCacheNight = 2 weight rows per wave.  Converters opt in with
 // kNightPipe and provide key_load / key_is_zero / rest_load / compute_keyed.
-constexpr int kRowCacheNight = 2;
+#ifndef ATL_ROW_CACHE_NIGHT
+#define ATL_ROW_CACHE_NIGHT 2
+#endif
+constexpr int kRowCacheNight = ATL_ROW_CACHE_NIGHT;
 template <class Conv, bool VEC, bool DENSE>
 __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 2 : min_waves<Conv>()) void k_fused_segred_night(Conv conv, PlanDev plan, int64_t slot0,
                                                       int64_t n_slots, int64_t S, int32_t chunk_slots,
@@ -690,6 +693,11 @@ struct KernelBracket {
         }
     }
 };
+
+inline bool debug_occupancy() {
+    static const bool on = getenv("ATLITE_HIP_DEBUG_OCCUPANCY") != nullptr;
+    return on;
+}
 
 int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
@@ -852,6 +860,12 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
             // default yes); everything else reduces dense tiles on the butterfly path - correct, just slower there
             const bool dense = plan.prow_wm != nullptr && vec && conv_dense_ok<Conv>::value;
             auto launch = [&](auto kern, size_t lds_sz) {
+                if (debug_occupancy()) {  // $ATLITE_HIP_DEBUG_OCCUPANCY: what the runtime says fits on a CU
+                    int nb = -1;
+                    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, kWavesPerBlock * 64, lds_sz);
+                    fprintf(stderr, "[atlite-hip] %s: fused kernel %d blocks/CU x %d waves, %zu B LDS/block, grid %u, chunk %d slots\n",
+                            what, nb, kWavesPerBlock, lds_sz, grid.x, int(chunk_slots));
+                }
                 hipLaunchKernelGGL(kern, grid, dim3(kWavesPerBlock * 64), lds_sz, ctx->stream, conv, plan, w0, wn, S,
                                    chunk_slots, n_units, partials, ldp, conv_lds_doubles);
             };
