@@ -13,7 +13,13 @@ struct PvConst {
     // bofinger panel (solar_panel_model.py:47-74): A, B, C, D, (NOCT - Tamb) / Intc, D * that / ta, Tstd, threshold,
     // inverter efficiency / capacity
     double bA, bB, bC, bD, bfrac, bDf_ta, bTstd, bthr, bscale;
+    int tracking;  // ATL_TRACK_*: read by the instantiations whose tracker is a run-time switch (kTrackAny)
 };
+// TRACK template value of the converters that choose their tracker at run time (a wave-uniform switch over
+// panel_geom's closed forms): the rarely used tracker x panel / trigon / orientation combinations share ONE
+// instantiation instead of four; pv(tracking="horizontal") - PyPSA-Eur's solar-hsat - keeps its own.
+constexpr int kTrackAny = 100;
+constexpr bool track_is(int TRACK, int rt, int which) { return TRACK == which || (TRACK == kTrackAny && rt == which); }
 
 // what follows the tilted irradiation in the fast kernel family
 // (panel model x transposition model): the Huld panel, the solar thermal collector, the plain irradiation or the bofinger
@@ -83,11 +89,19 @@ ATL_HD __noinline__ PanelGeom panel_geom_literal(int tracking, double sa, double
 // rtol 1e-10); arguments for which the closed forms are not valid (q zero / non-finite) take the
 // literal routine.
 template <int TRACK, bool NEED_SH>
-ATL_HD __forceinline__ PanelGeom panel_geom(double sa, double ca, double az, double slope, double sazim) {
+ATL_HD __forceinline__ PanelGeom panel_geom(double sa, double ca, double az, double slope, double sazim, int tracking_rt = ATL_TRACK_NONE) {
     const double pi = 3.14159265358979323846;
     PanelGeom g;
     g.sh = 0.0;
-    if constexpr (TRACK == ATL_TRACK_NONE) {
+    if constexpr (TRACK == kTrackAny) {  // wave-uniform: every lane of a launch has the same tracker
+        switch (tracking_rt) {
+            case ATL_TRACK_HORIZONTAL: return panel_geom<ATL_TRACK_HORIZONTAL, NEED_SH>(sa, ca, az, slope, sazim);
+            case ATL_TRACK_TILTED_HORIZONTAL: return panel_geom<ATL_TRACK_TILTED_HORIZONTAL, NEED_SH>(sa, ca, az, slope, sazim);
+            case ATL_TRACK_VERTICAL: return panel_geom<ATL_TRACK_VERTICAL, NEED_SH>(sa, ca, az, slope, sazim);
+            case ATL_TRACK_DUAL: return panel_geom<ATL_TRACK_DUAL, NEED_SH>(sa, ca, az, slope, sazim);
+            default: return panel_geom<ATL_TRACK_NONE, NEED_SH>(sa, ca, az, slope, sazim);
+        }
+    } else if constexpr (TRACK == ATL_TRACK_NONE) {
         g.cs = lean_cos(slope);
         g.cosinc = lean_sin(slope) * ca * lean_cos(sazim - az) + g.cs * sa;
         if constexpr (NEED_SH) g.sh = lean_sin(slope / 2.0);
@@ -252,10 +266,10 @@ ATL_HD __forceinline__ double pv_cell(double dir, double dif, double toa, double
     lean_sincos(alt, &sa, &ca);
     if constexpr (TRACK != ATL_TRACK_NONE) {  // tracker: panel_geom's closed forms
         constexpr bool HD = tail_hay_davies(TAIL);
-        const PanelGeom g = panel_geom<TRACK, HD>(sa, ca, az, o.slope, o.saz);
+        const PanelGeom g = panel_geom<TRACK, HD>(sa, ca, az, o.slope, o.saz, k.tracking);
         // simple model: a dual-axis tracker's surface slope is the sun's zenith angle (irradiation.py:216-219);
         // Hay-Davies keeps the orientation's own slope (:227-245)
-        const double cs = (TRACK != ATL_TRACK_DUAL || HD) ? g.cs : sa;
+        const double cs = (!track_is(TRACK, k.tracking, ATL_TRACK_DUAL) || HD) ? g.cs : sa;
         return pv_tail_core<TAIL>(direct, diffuse, influx, toa, alb, tmp, sa, np_max(g.cosinc, 0.0), (1.0 + cs) / 2.0,
                                   (1.0 - cs) / 2.0, HD ? g.sh * g.sh * g.sh : 0.0, k);
     }
@@ -398,6 +412,16 @@ struct PvConvT {
     static_assert(TRACK == ATL_TRACK_NONE || !SP, "trackers: stored angles");
     // the MFMA-carrying instantiation (dense matrices) only for pv() with its defaults: rare options x rare matrices
     static constexpr bool kDenseOk = TAIL == kTailHuld && TRACK == ATL_TRACK_NONE;
+    // the members of the family compiled in atl_kernels_pvt.hip / atl_kernels_pvk.hip (tails other than the Huld
+    // panel, trackers) exist for vectorised launches only; odd cell counts / unaligned cubes take the general kernel
+    // ... and so do the early-out converters: their results are the bits of the converters that read every byte, whose
+    // unvectorised instantiations take such launches
+    static constexpr bool kVecOnly = tail_panel(TAIL) != kTailHuld || TRACK != ATL_TRACK_NONE || SKIP;
+    // a vertical-axis or dual-axis tracker's geometry does not involve the sun's azimuth: that cube is not read
+    // (compile-time trackers: the compiler drops the loads by itself)
+    ATL_HD bool reads_azimuth() const {
+        return !(TRACK == kTrackAny && (k.tracking == ATL_TRACK_VERTICAL || k.tracking == ATL_TRACK_DUAL));
+    }
     atl_pv_inputs in;
     int64_t S;
     PvConst k;
@@ -463,6 +487,43 @@ struct PvConvT {
         double sd, cd;   // SP: sin / cos declination of the slot
     };
     using Carry = NoCarry;
+    // ---- k_fused_segred_glds interface (the cubes of a slot through LDS-DMA) -----------------------------------
+    // stored solar angles without the early-out: the slot's inputs are 7 whole cubes (6 with the influx head)
+    // (offered by the members compiled in atl_kernels_pv.hip: pv() with its defaults, Hay-Davies, the influx head)
+    static constexpr int kStreams = (SP || SKIP || tail_panel(TAIL) != kTailHuld || TRACK != ATL_TRACK_NONE) ? 0 : (HEAD == 1 ? 6 : 7);
+    __device__ __forceinline__ const double *stream(int j) const {
+        if constexpr (HEAD == 1) {
+            const double *const p[6] = {in.d_influx, in.d_outflux, in.d_influx_toa, in.d_temperature, in.d_solar_altitude, in.d_solar_azimuth};
+            return p[j];
+        } else {
+            const double *const p[7] = {in.d_influx_direct, in.d_influx_diffuse, in.d_albedo, in.d_influx_toa, in.d_temperature,
+                                        in.d_solar_altitude, in.d_solar_azimuth};
+            return p[j];
+        }
+    }
+    template <int N>
+    __device__ __forceinline__ Raw from_streams(const double2 (&v)[N], int64_t, const Cell &) const {
+        Raw r;
+        r.sd = r.cd = 0.0;
+        if constexpr (HEAD == 1) {
+            r.dir = v[0];
+            r.dif = double2{0.0, 0.0};
+            r.alb = v[1];
+            r.toa = v[2];
+            r.tmp = v[3];
+            r.a = v[4];
+            r.b = v[5];
+        } else {
+            r.dir = v[0];
+            r.dif = v[1];
+            r.alb = v[2];
+            r.toa = v[3];
+            r.tmp = v[4];
+            r.a = v[5];
+            r.b = v[6];
+        }
+        return r;
+    }
     // ---- k_fused_segred_night interface (night early-out) -----------------------------------------------------
     // a cell below the altitude cut-off converts to +0.0 whatever the other cubes hold (pv_cell: capped; a NaN
     // altitude is NOT capped)
@@ -483,6 +544,9 @@ struct PvConvT {
                                      : (tail_panel(TAIL) == kTailBofinger && TRACK != ATL_TRACK_NONE) ? ATL_PV_BOFTRK_WAVES
                                      : (kNightPipe && TRACK != ATL_TRACK_NONE)                        ? ATL_PV_TRKNIGHT_WAVES
                                                                                                     : 3;
+    // the per-cell early-out kernel behind a tracker: two waves per SIMD, no scratch (the fused kernel's three waves
+    // with 48-112 B of scratch were measured against two; the per-cell kernel carries its accumulators on top)
+    static constexpr int kMinWavesCells = (kNightPipe && TRACK != ATL_TRACK_NONE) ? 2 : kMinWaves;
     // stored angles: key = the slot's solar altitude.  In-kernel solar position: key = cos(hour angle) of the
     // lane's two grid columns (a (T, X) table), from which sin(altitude) follows with the slot's declination and
     // the cells' latitude - night is known before a single byte of the cubes is read.
@@ -530,7 +594,8 @@ struct PvConvT {
         } else {
             r.sd = r.cd = 0.0;
             r.a = double2{0.0, 0.0};
-            r.b = ld2<VEC>(in.d_solar_azimuth, off, c0, c1);
+            r.b = double2{0.0, 0.0};
+            if (reads_azimuth()) r.b = ld2<VEC>(in.d_solar_azimuth, off, c0, c1);
         }
         return r;
     }
@@ -566,7 +631,8 @@ struct PvConvT {
         } else {
             r.sd = r.cd = 0.0;
             r.a = ld2<VEC>(in.d_solar_altitude, off, c0, c1);
-            r.b = ld2<VEC>(in.d_solar_azimuth, off, c0, c1);
+            r.b = double2{0.0, 0.0};
+            if (reads_azimuth()) r.b = ld2<VEC>(in.d_solar_azimuth, off, c0, c1);
         }
         return r;
     }
@@ -665,7 +731,7 @@ inline PvConst pv_const_of(const atl_pv_params *p) {
               p->k_3,        p->k_4,          p->k_5,    p->k_6,                 p->inverter_efficiency,
               p->altitude_threshold, sin(p->altitude_threshold),
               p->st_c0, p->st_c1, p->st_t_store_K, p->irradiation,
-              0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+              0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0};
     if (p->panel_model == ATL_PANEL_BOFINGER) {  // the uniform sub-expressions of pvx_cell's bofinger branch, same order
         const double fraction = (p->bof_NOCT - p->bof_Tamb) / p->bof_Intc;
         const double capacity = (p->bof_A + p->bof_B * 1000.0 + p->bof_C * log(1000.0)) * 1e3;
@@ -679,6 +745,7 @@ inline PvConst pv_const_of(const atl_pv_params *p) {
         k.bthr = p->bof_threshold;
         k.bscale = p->inverter_efficiency / capacity;
     }
+    k.tracking = p->tracking;
     return k;
 }
 
@@ -752,7 +819,7 @@ ATL_HD double pvx_cell(double dir, double dif, double infl, double toa, double a
     // cells that stay have sin(alt) >= sin(threshold) > 0 and influx_toa >= influx > 0.01.
     if ((alt < k.alt_thr) || (influx <= 0.01)) return 0.0;
     // ---- SurfaceOrientation ----------------------------------------------------------------------
-    const PanelGeom geom = panel_geom<TRACK, TRIGON == ATL_TRIGON_OTHER>(sa, ca, az, slope, sazim);
+    const PanelGeom geom = panel_geom<TRACK, TRIGON == ATL_TRIGON_OTHER>(sa, ca, az, slope, sazim, o.tracking);
     const double cosinc = np_max(geom.cosinc, 0.0);
     // ---- albedo (irradiation.py:128-139) ---------------------------------------------------------
     double alb = albv;
@@ -764,7 +831,7 @@ ATL_HD double pvx_cell(double dir, double dif, double infl, double toa, double a
     double direct_t, diffuse_t, ground_t, total_t;
     if constexpr (TRIGON == ATL_TRIGON_SIMPLE) {
         const double kk = guarded_div(cosinc, sa);
-        const double cs = (TRACK != ATL_TRACK_DUAL) ? geom.cs : sa;
+        const double cs = !track_is(TRACK, o.tracking, ATL_TRACK_DUAL) ? geom.cs : sa;
         direct_t = kk * direct;
         diffuse_t = (1.0 + cs) / 2.0 * diffuse;
         ground_t = alb * influx * ((1.0 - cs) / 2.0);

@@ -23,6 +23,9 @@
 #ifndef ATL_ROW_CACHE
 #define ATL_ROW_CACHE 8
 #endif
+#ifndef ATL_GLDS_DEFAULT
+#define ATL_GLDS_DEFAULT 0  // the LDS-DMA fed fused kernel (k_fused_segred_glds) where a converter offers it
+#endif
 
 using namespace atl;
 
@@ -139,10 +142,30 @@ constexpr int min_waves() {
     return conv_min_waves<Conv>::value;
 }
 
+// ... of the per-cell early-out kernel (k_cells_night), where a converter asks for a budget of its own (kMinWavesCells)
+template <class Conv, class = void>
+struct conv_min_waves_cells : std::integral_constant<int, conv_min_waves<Conv>::value> {};
+template <class Conv>
+struct conv_min_waves_cells<Conv, std::void_t<decltype(Conv::kMinWavesCells)>> : std::integral_constant<int, Conv::kMinWavesCells> {};
+
 template <class Conv, class = void>
 struct conv_dense_ok : std::true_type {};
 template <class Conv>
 struct conv_dense_ok<Conv, std::void_t<decltype(Conv::kDenseOk)>> : std::integral_constant<bool, Conv::kDenseOk> {};
+// converters that exist for vectorised launches only (kVecOnly): run_cells / run_fused answer kNeedScalar when a
+// launch cannot be vectorised (odd cell count or row length, unaligned cubes) and the caller takes its generic
+// fallback (the pv family's rarely used members -> the general pv kernel)
+template <class Conv, class = void>
+struct conv_vec_only : std::false_type {};
+template <class Conv>
+struct conv_vec_only<Conv, std::void_t<decltype(Conv::kVecOnly)>> : std::integral_constant<bool, Conv::kVecOnly> {};
+constexpr int kNeedScalar = 1;  // internal status, never returned through the C ABI
+// converters whose per-slot inputs are kStreams whole cubes (each (slots, S) fp64) can be fed through LDS-DMA
+// (k_fused_segred_glds): they name the cubes (stream(j)) and assemble their Raw from the staged values (from_streams)
+template <class Conv, class = void>
+struct conv_streams : std::integral_constant<int, 0> {};
+template <class Conv>
+struct conv_streams<Conv, std::void_t<decltype(Conv::kStreams)>> : std::integral_constant<int, Conv::kStreams> {};
 template <class Conv, class = void>
 struct conv_night_pipe : std::false_type {};
 template <class Conv>
@@ -156,7 +179,7 @@ struct conv_night_pipe<Conv, std::void_t<decltype(Conv::kNightPipe)>> : std::int
 // (write) exactly +0.0.  Same converter interface as k_fused_segred_night (key_load / key_is_zero / rest_load /
 // compute_keyed).  Used for pv capacity-factor maps and per-cell series: 40 % fewer bytes on a year of data.
 template <class Conv, bool VEC, bool SERIES>
-__global__ __launch_bounds__(256, min_waves<Conv>()) void k_cells_night(Conv conv, int64_t n_slots, int64_t S, int64_t chunk_len,
+__global__ __launch_bounds__(256, conv_min_waves_cells<Conv>::value) void k_cells_night(Conv conv, int64_t n_slots, int64_t S, int64_t chunk_len,
                                                                         double *__restrict__ out_a, double *__restrict__ out_b,
                                                                         int32_t conv_lds_doubles, int64_t X, int64_t Y, int32_t ntx) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -521,6 +544,100 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
 }
 
 // ---------------------------------------------------------------------------------------
+// kernel 3a: the fused kernel fed through LDS-DMA, one slot ahead
+// ---------------------------------------------------------------------------------------
+// k_fused_segred converts a slot only after ITS loads have landed and loads the next slot only after that conversion
+// (the branches to the careful per-cell routines separate the slots into basic blocks): a wave has its 7 KiB in
+// flight while it waits and nothing in flight while it computes.  Here the next slot's cubes travel as
+// global_load_lds_dwordx4 (gfx950: 16 bytes per lane straight into the wave's LDS staging rows, no VGPRs) WHILE the
+// current slot is converted: per slot  wait -> 7 x ds_read_b128 -> issue the next slot's 7 DMAs -> convert.
+// Same tiles, chunks, partial rows, reduction and arithmetic as k_fused_segred: bit-identical output.
+// Vectorised, non-dense plans only; LDS per wave = kRowCacheGlds weight rows + kStreams staging rows.
+#ifndef ATL_ROW_CACHE_GLDS
+#define ATL_ROW_CACHE_GLDS 5
+#endif
+constexpr int kRowCacheGlds = ATL_ROW_CACHE_GLDS;
+
+template <class Conv>
+__global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fused_segred_glds(Conv conv, PlanDev plan, int64_t slot0,
+                                                      int64_t n_slots, int64_t S, int32_t chunk_slots,
+                                                      int64_t n_units, double *__restrict__ partials,
+                                                      int64_t ldp, int32_t conv_lds_doubles) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    conv.block_init(lds);
+    __syncthreads();
+    constexpr int NS = conv_streams<Conv>::value;
+    constexpr int ROWS = kRowCacheGlds;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    double *wlds = lds + conv_lds_doubles + wave * ((ROWS + NS) * kSegCells);
+    double *stage = wlds + ROWS * kSegCells;  // [NS][kSegCells]: lane l's cell pair of cube j at stage[j * 128 + 2 l]
+    const int64_t unit = int64_t(blockIdx.x) * kWavesPerBlock + wave;
+    if (unit >= n_units) return;
+    const int32_t seg = int32_t(unit % plan.n_segs);
+    const int64_t chunk = unit / plan.n_segs;
+    const TileLane tl = tile_lane_cells(plan.X, plan.Y, plan.ntx, plan.w2_log2, seg, lane);
+    const int64_t c0 = tl.c0;
+    const bool v0 = tl.v0, v1 = tl.v1;
+    const int32_t p0 = plan.seg_ptr[seg], p1 = plan.seg_ptr[seg + 1];
+    if (p0 == p1) return;
+    const bool covered = (plan.seg_mask[seg] >> lane) & 1u;
+    const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
+    unsigned present = 0;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        double2 wz = {0.0, 0.0};
+        if (p0 + r < p1) {
+            const double2 w = *reinterpret_cast<const double2 *>(plan.prow_w + int64_t(p0 + r) * kSegCells + 2 * lane);
+            const bool a0 = !dnan(w.x), a1 = !dnan(w.y);
+            wz.x = a0 ? w.x : 0.0;
+            wz.y = a1 ? w.y : 0.0;
+            present |= (a0 ? 1u : 0u) << (2 * r) | (a1 ? 1u : 0u) << (2 * r + 1);
+        }
+        *reinterpret_cast<double2 *>(wlds + r * kSegCells + 2 * lane) = wz;
+    }
+    const int64_t sbeg = slot0 + chunk * chunk_slots;
+    const int64_t send = min(sbeg + int64_t(chunk_slots), slot0 + n_slots);
+    partials -= slot0;
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    typedef __attribute__((address_space(1))) const void *glob_ptr;
+    // the lane's 16 bytes of every cube of one slot -> the staging rows (uncovered lanes move nothing: what they read
+    // back from the rows is dropped below).  aux = 2: nontemporal, every byte is read exactly once.
+    auto prefetch = [&](int64_t slot) {
+        if (covered) {
+            const int64_t off = slot * S + c0;
+#pragma unroll
+            for (int j = 0; j < NS; ++j)
+                __builtin_amdgcn_global_load_lds((glob_ptr)(conv.stream(j) + off), (lds_ptr)(stage + j * kSegCells), 16, 0, 2);
+        }
+    };
+    prefetch(sbeg);
+    for (int64_t sb = sbeg; sb < send; sb += kBatch) {
+        double2 v[kBatch];
+        bool finite = true;
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+            // slots past the end of a ragged chunk re-convert its last slot and are zeroed (as k_fused_segred does)
+            const int64_t slot = min(sb + i, send - 1);
+            const int64_t next = min(sb + i + 1, send - 1);
+            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this slot's cubes are in the staging rows
+            double2 in[NS];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) in[j] = *reinterpret_cast<const double2 *>(stage + j * kSegCells + 2 * lane);
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the rows are free again
+            if (next != slot) prefetch(next);     // in flight behind this slot's conversion
+            const typename Conv::Raw raw = conv.from_streams(in, slot, cell);
+            const bool live = covered && sb + i < send;
+            v[i] = conv.compute(raw, v0, v1, cell, lds);
+            v[i].x = live ? v[i].x : 0.0;
+            v[i].y = live ? v[i].y : 0.0;
+            finite = finite && (__builtin_fabs(v[i].x) < __builtin_inf()) && (__builtin_fabs(v[i].y) < __builtin_inf());
+        }
+        reduce_batch<ROWS>(v, finite, plan, p0, p1, wlds, present, lane, sb, send, partials, ldp);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // kernel 3b: fused convert + segment reduce with a per-slot early-out (pv night skip)
 // ---------------------------------------------------------------------------------------
 // Same tiles, chunks, partial rows and reduction as k_fused_segred - bit-identical output - but the slots of
@@ -694,6 +811,12 @@ struct KernelBracket {
     }
 };
 
+// the LDS-DMA fed fused kernel: $ATLITE_HIP_GLDS = 0 / 1 (experiments, A/B inside one process)
+inline bool use_glds() {
+    const char *e = getenv("ATLITE_HIP_GLDS");
+    return e ? atoi(e) != 0 : ATL_GLDS_DEFAULT != 0;
+}
+
 inline bool debug_occupancy() {
     static const bool on = getenv("ATLITE_HIP_DEBUG_OCCUPANCY") != nullptr;
     return on;
@@ -753,6 +876,8 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
             vec = vec && (tX % 2 == 0);  // the lane's cell pair must not straddle a tile row's end
         }
     }
+    constexpr bool kScalarToo = !conv_vec_only<Conv>::value;  // the unvectorised instantiations exist
+    if (!kScalarToo && !vec) return kNeedScalar;
     if (time_agg == ATL_TIME_NONE) {
         const dim3 grid(gx, unsigned((n_slots + kSeriesSlots - 1) / kSeriesSlots));
         KernelBracket kb(ctx);
@@ -762,13 +887,13 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
             if (vec)
                 hipLaunchKernelGGL((k_cells_night<Conv, true, true>), gridn, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
                                    len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)), tX, tY, ntx);
-            else
+            else if constexpr (kScalarToo)
                 hipLaunchKernelGGL((k_cells_night<Conv, false, true>), gridn, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
                                    len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)), tX, tY, ntx);
         } else if (vec) {  // (else: the early-out converters do not instantiate the plain series kernel)
             hipLaunchKernelGGL((k_cells_series<Conv, true>), grid, dim3(256), lds_bytes, ctx->stream, conv,
                                n_slots, S, d_out);
-        } else {
+        } else if constexpr (kScalarToo) {
             hipLaunchKernelGGL((k_cells_series<Conv, false>), grid, dim3(256), lds_bytes, ctx->stream, conv,
                                n_slots, S, d_out);
         }
@@ -788,15 +913,16 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
             if (vec)
                 hipLaunchKernelGGL((k_cells_night<Conv, true, false>), grid, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
                                    chunk_len, psum, pcnt, int32_t(lds_bytes / sizeof(double)), tX, tY, ntx);
-            else
+            else if constexpr (kScalarToo)
                 hipLaunchKernelGGL((k_cells_night<Conv, false, false>), grid, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
                                    chunk_len, psum, pcnt, int32_t(lds_bytes / sizeof(double)), tX, tY, ntx);
-        } else if (vec)
+        } else if (vec) {
             hipLaunchKernelGGL((k_cells_timered<Conv, true>), grid, dim3(256), lds_bytes, ctx->stream, conv,
                                n_slots, S, chunk_len, psum, pcnt);
-        else
+        } else if constexpr (kScalarToo) {
             hipLaunchKernelGGL((k_cells_timered<Conv, false>), grid, dim3(256), lds_bytes, ctx->stream, conv,
                                n_slots, S, chunk_len, psum, pcnt);
+        }
     }
     if ((rc = check_launch(what))) return rc;
     hipLaunchKernelGGL(k_chunk_reduce, dim3(unsigned((S + 255) / 256)), dim3(256), 0, ctx->stream, psum, pcnt,
@@ -820,6 +946,8 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
     const int64_t N = plan.n_rows;
     if (N == 0) return ATL_OK;
     vec = vec && (plan.X % 2 == 0);  // the lane's cell pair must not straddle a grid row
+    constexpr bool kScalarToo = !conv_vec_only<Conv>::value;  // the unvectorised instantiations exist
+    if (!kScalarToo && !vec) return kNeedScalar;
     // Partial rows live in scratch as [P][window]; the slot axis is processed in windows so that the
     // scratch stays below ~1 GiB however dense the matrix is (P = tiles x shapes for a dense one).
     const int64_t P = plan.n_prows;
@@ -872,14 +1000,17 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
             const size_t lds_base = conv_lds + size_t(kWavesPerBlock) * (dense ? kRowCacheDense + kBatch : kRowCache) * kSegCells * sizeof(double);
             if constexpr (conv_night_pipe<Conv>::value) {
                 const size_t lds_night = conv_lds + size_t(kWavesPerBlock) * (kRowCacheNight + kBatch) * kSegCells * sizeof(double);
-                if (!vec)
-                    launch(k_fused_segred_night<Conv, false, false>, lds_night);
-                else if constexpr (conv_dense_ok<Conv>::value)
+                if (!vec) {
+                    if constexpr (kScalarToo) launch(k_fused_segred_night<Conv, false, false>, lds_night);
+                } else if constexpr (conv_dense_ok<Conv>::value)
                     dense ? launch(k_fused_segred_night<Conv, true, true>, lds_night) : launch(k_fused_segred_night<Conv, true, false>, lds_night);
                 else
                     launch(k_fused_segred_night<Conv, true, false>, lds_night);
             } else if (!vec) {
-                launch(k_fused_segred<Conv, false, false>, lds_base);
+                if constexpr (kScalarToo) launch(k_fused_segred<Conv, false, false>, lds_base);
+            } else if (conv_streams<Conv>::value > 0 && !dense && use_glds()) {
+                if constexpr (conv_streams<Conv>::value > 0)
+                    launch(k_fused_segred_glds<Conv>, conv_lds + size_t(kWavesPerBlock) * (kRowCacheGlds + conv_streams<Conv>::value) * kSegCells * sizeof(double));
             } else if constexpr (conv_dense_ok<Conv>::value) {
                 dense ? launch(k_fused_segred<Conv, true, true>, lds_base) : launch(k_fused_segred<Conv, true, false>, lds_base);
             } else {

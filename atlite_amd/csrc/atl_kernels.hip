@@ -255,10 +255,12 @@ int wind_dispatch(const WindConvT<-1> &g, bool finite, F &&f) {
     // unrolled knot search for the usual table sizes (make_wind pads to 16 / 32 / 128 knots)
     auto sized = [&](auto method) {
         constexpr int M = decltype(method)::value;
-        if (g.inv_w > 0.0) return f(wind_as<M, kWindGrid>(g));
-        if (g.n_pad == 16) return f(wind_as<M, 4>(g));
-        if (g.n_pad == 32) return f(wind_as<M, 5>(g));
-        if (g.n_pad == 128) return f(wind_as<M, 7>(g));
+        if (g.inv_w > 0.0) return f(wind_as<M, kWindGrid>(g));  // grid-aligned knots: every shipped turbine but a few
+        if constexpr (M == ATL_WIND_LOG) {  // the default law carries the unrolled searches; the others the sized loop
+            if (g.n_pad == 16) return f(wind_as<M, 4>(g));
+            if (g.n_pad == 32) return f(wind_as<M, 5>(g));
+            if (g.n_pad == 128) return f(wind_as<M, 7>(g));
+        }
         return f(wind_as<M>(g));
     };
     switch (g.method) {

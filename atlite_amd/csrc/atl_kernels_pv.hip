@@ -64,9 +64,9 @@ int pv_dispatch(const atl_pv_inputs *in, const atl_pv_params *p, bool allow_skip
 bool pv_needs_general(const atl_pv_inputs *in, const atl_pv_params *p) {
     if (pv_influx_fast(in, p)) return false;
     if (in->d_influx != nullptr || in->d_albedo == nullptr || p->orientation_per_time) return true;
-    if (p->tracking != ATL_TRACK_NONE) {  // trackers: fast family with stored angles; no solar thermal collector
+    if (p->tracking != ATL_TRACK_NONE) {  // trackers: fast family with stored angles and the Huld panel (atl_kernels_pvk.hip)
         if (!(p->tracking >= ATL_TRACK_HORIZONTAL && p->tracking <= ATL_TRACK_DUAL && in->d_solar_altitude != nullptr &&
-              in->d_temperature != nullptr && p->panel_model != ATL_PANEL_SOLAR_THERMAL))
+              in->d_temperature != nullptr && p->panel_model == ATL_PANEL_HULD))
             return true;
     }
     // fixed panel, direct / diffuse / albedo cubes, either trigon model: the fast kernel family, with the Huld panel,
@@ -104,11 +104,15 @@ int atl_pv_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p
     if (pv_other_tail(in, p)) return pvt_convert(ctx, in, p, T, S, time_agg, d_out);
     if (pv_tracked(in, p)) return pvk_convert(ctx, in, p, T, S, time_agg, d_out);
     bool vec;
-    return pv_dispatch(in, p, true, [&](auto c) {  // night skip: k_cells_night for the SKIP converters
+    auto run = [&](auto c) {  // night skip: k_cells_night for the SKIP converters
         int rc = make_pv(in, p, T, S, &c, &vec);
         if (rc) return rc;
         return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert", in->X);
-    });
+    };
+    const int rc = pv_dispatch(in, p, true, run);
+    // a launch that cannot be vectorised: the early-out converters have no such instantiation - the converters that
+    // read every byte give the same bits
+    return rc == kNeedScalar ? pv_dispatch(in, p, false, run) : rc;
 }
 
 int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T,
@@ -118,11 +122,13 @@ int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv
     if (pv_other_tail(in, p)) return pvt_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);
     if (pv_tracked(in, p)) return pvk_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);
     bool vec;
-    return pv_dispatch(in, p, true, [&](auto c) {
+    auto run = [&](auto c) {
         int rc = make_pv(in, p, T, S, &c, &vec);
         if (rc) return rc;
         return run_fused(ctx, c, vec, 0, T, S, agg, time_agg, d_out, ld_out, "atl_pv_convert_aggregate");
-    });
+    };
+    const int rc = pv_dispatch(in, p, true, run);
+    return rc == kNeedScalar ? pv_dispatch(in, p, false, run) : rc;
 }
 
 }  // extern "C"

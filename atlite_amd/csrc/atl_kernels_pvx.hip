@@ -9,20 +9,16 @@ namespace {
 
 #include "atl_conv_pv.h"
 
-// f(converter instance) with the PvxConvT instantiation for (tracking, trigon model)
+// f(converter instance) with the PvxConvT instantiation for (tracker or none, trigon model)
 template <class F>
 int pvx_dispatch(const atl_pv_params *p, F &&f) {
     const bool other = p->trigon_model == ATL_TRIGON_OTHER;
     switch (p->tracking) {
         case ATL_TRACK_HORIZONTAL:
-            return other ? f(PvxConvT<ATL_TRACK_HORIZONTAL, ATL_TRIGON_OTHER>()) : f(PvxConvT<ATL_TRACK_HORIZONTAL, ATL_TRIGON_SIMPLE>());
         case ATL_TRACK_TILTED_HORIZONTAL:
-            return other ? f(PvxConvT<ATL_TRACK_TILTED_HORIZONTAL, ATL_TRIGON_OTHER>())
-                         : f(PvxConvT<ATL_TRACK_TILTED_HORIZONTAL, ATL_TRIGON_SIMPLE>());
         case ATL_TRACK_VERTICAL:
-            return other ? f(PvxConvT<ATL_TRACK_VERTICAL, ATL_TRIGON_OTHER>()) : f(PvxConvT<ATL_TRACK_VERTICAL, ATL_TRIGON_SIMPLE>());
-        case ATL_TRACK_DUAL:
-            return other ? f(PvxConvT<ATL_TRACK_DUAL, ATL_TRIGON_OTHER>()) : f(PvxConvT<ATL_TRACK_DUAL, ATL_TRIGON_SIMPLE>());
+        case ATL_TRACK_DUAL:  // one instantiation for the four trackers: the geometry is a wave-uniform run-time switch
+            return other ? f(PvxConvT<kTrackAny, ATL_TRIGON_OTHER>()) : f(PvxConvT<kTrackAny, ATL_TRIGON_SIMPLE>());
         default:  // ATL_TRACK_NONE; out-of-range codes are rejected by make_pvx
             if (p->orientation_per_time)
                 return other ? f(PvxConvT<ATL_TRACK_NONE, ATL_TRIGON_OTHER, true>()) : f(PvxConvT<ATL_TRACK_NONE, ATL_TRIGON_SIMPLE, true>());

@@ -112,9 +112,11 @@ static int pv_probe_switch(int tracking, F &&f) {
     switch (tracking) {
         case ATL_TRACK_NONE: return f(std::integral_constant<int, ATL_TRACK_NONE>());
         case ATL_TRACK_HORIZONTAL: return f(std::integral_constant<int, ATL_TRACK_HORIZONTAL>());
-        case ATL_TRACK_TILTED_HORIZONTAL: return f(std::integral_constant<int, ATL_TRACK_TILTED_HORIZONTAL>());
-        case ATL_TRACK_VERTICAL: return f(std::integral_constant<int, ATL_TRACK_VERTICAL>());
-        case ATL_TRACK_DUAL: return f(std::integral_constant<int, ATL_TRACK_DUAL>());
+        // the instantiation the kernels run for these three: the tracker is a run-time switch (kTrackAny) over the same
+        // closed forms
+        case ATL_TRACK_TILTED_HORIZONTAL:
+        case ATL_TRACK_VERTICAL:
+        case ATL_TRACK_DUAL: return f(std::integral_constant<int, kTrackAny>());
         default: set_error("atl_pv_probe_host: bad tracking code %d", tracking); return ATL_E_INVALID;
     }
 }
