@@ -357,6 +357,34 @@ ATL_HD __forceinline__ PvPlain pv_cell_sp_plain(double dir, double dif, double t
     return pv_tail_plain(direct, diffuse, influx, alb, tmp, s, ca, a.csaz * caz + a.ssaz * saz, plain, capped, o, k);
 }
 
+// the influx / outflux head (Reindl split with the "simple" clearsky model, albedo = outflux / influx) the same way: for
+// finite inputs the masks of reindl_simple select ONE of its three candidates (adding exact zeros changes nothing), the
+// clips are plain min / max, and the two divisions take the guarded reciprocal path whenever the cell is not capped
+// (toa >= influx > 0.01 then).  Anything else - non-finite inputs, a toa outside the reciprocal's range - is handed to
+// pv_cell_influx.
+ATL_HD __forceinline__ PvPlain pv_cell_influx_plain(double infl, double outf, double toa, double tmp, double alt, double az,
+                                                        const PvOri &o, const PvConst &k) {
+    const double inf = __builtin_inf();
+    const bool div_ok = toa > 0x1.0p-400 && toa < 0x1.0p400;
+    bool plain = __builtin_fabs(infl) < inf && __builtin_fabs(outf) < 0x1.0p400 && div_ok && __builtin_fabs(tmp) < inf &&
+                 __builtin_fabs(alt) < 0x1.0p30 && __builtin_fabs(az) < 0x1.0p29 && __builtin_fabs(o.saz) < 0x1.0p29;
+    double sa, ca;
+    sincos_core(alt, &sa, &ca);
+    const double influx_c = __builtin_fmin(__builtin_fmax(infl, 0.0), toa);
+    const double kk = fast_div(influx_c, div_ok ? toa : 1.0);
+    const double f1 = __builtin_fmin(1.0, 1.020 - 0.254 * kk + 0.0123 * sa);
+    const double f2 = __builtin_fmin(0.97, __builtin_fmax(0.1, 1.400 - 1.749 * kk + 0.177 * sa));
+    const double f3 = __builtin_fmax(0.1, 0.486 * kk - 0.182 * sa);
+    const double fraction = (kk >= 0.78) ? f3 : (kk > 0.3) ? f2 : (kk > 0.0) ? f1 : 0.0;
+    const double diffuse = influx_c * fraction;
+    const double direct = influx_c - diffuse;
+    const double influx = direct + diffuse;
+    const bool capped = (alt < k.alt_thr) || (influx <= 0.01);
+    const double alb = __builtin_fmin(fast_div(outf, capped ? 1.0 : influx), 1.0);
+    const double cosd = cos_core(o.saz - az);
+    return pv_tail_plain(direct, diffuse, influx, alb, tmp, sa, ca, cosd, plain, capped, o, k);
+}
+
 // what the kernels evaluate for one cell: the plain evaluation where it is valid, pv_cell otherwise (the
 // kernels do the two cells of a lane side by side, PvConvT::compute; the host probe calls this)
 template <int TAIL, int TRACK>
@@ -367,6 +395,17 @@ ATL_HD __forceinline__ double pv_cell_auto(double dir, double dif, double toa, d
         if (p.ok) return p.r;
     }
     return pv_cell<TAIL, TRACK>(dir, dif, toa, alb, tmp, alt, az, o, k);
+}
+
+// the influx / outflux head: what the kernels evaluate for one cell (PvConvT::compute does the lane's pair side by
+// side; the host probe calls this)
+ATL_HD __forceinline__ double pv_cell_influx_auto(double infl, double outf, double toa, double tmp, double alt, double az,
+                                                      const PvOri &o, const PvConst &k) {
+    if constexpr (ATL_PV_PLAIN != 0) {
+        const PvPlain p = pv_cell_influx_plain(infl, outf, toa, tmp, alt, az, o, k);
+        if (p.ok) return p.r;
+    }
+    return pv_cell_influx<kTailHuld>(infl, outf, toa, tmp, alt, az, o, k);
 }
 
 // same, with the solar position computed from the separable tables instead of read:
@@ -487,43 +526,6 @@ struct PvConvT {
         double sd, cd;   // SP: sin / cos declination of the slot
     };
     using Carry = NoCarry;
-    // ---- k_fused_segred_glds interface (the cubes of a slot through LDS-DMA) -----------------------------------
-    // stored solar angles without the early-out: the slot's inputs are 7 whole cubes (6 with the influx head)
-    // (offered by the members compiled in atl_kernels_pv.hip: pv() with its defaults, Hay-Davies, the influx head)
-    static constexpr int kStreams = (SP || SKIP || tail_panel(TAIL) != kTailHuld || TRACK != ATL_TRACK_NONE) ? 0 : (HEAD == 1 ? 6 : 7);
-    __device__ __forceinline__ const double *stream(int j) const {
-        if constexpr (HEAD == 1) {
-            const double *const p[6] = {in.d_influx, in.d_outflux, in.d_influx_toa, in.d_temperature, in.d_solar_altitude, in.d_solar_azimuth};
-            return p[j];
-        } else {
-            const double *const p[7] = {in.d_influx_direct, in.d_influx_diffuse, in.d_albedo, in.d_influx_toa, in.d_temperature,
-                                        in.d_solar_altitude, in.d_solar_azimuth};
-            return p[j];
-        }
-    }
-    template <int N>
-    __device__ __forceinline__ Raw from_streams(const double2 (&v)[N], int64_t, const Cell &) const {
-        Raw r;
-        r.sd = r.cd = 0.0;
-        if constexpr (HEAD == 1) {
-            r.dir = v[0];
-            r.dif = double2{0.0, 0.0};
-            r.alb = v[1];
-            r.toa = v[2];
-            r.tmp = v[3];
-            r.a = v[4];
-            r.b = v[5];
-        } else {
-            r.dir = v[0];
-            r.dif = v[1];
-            r.alb = v[2];
-            r.toa = v[3];
-            r.tmp = v[4];
-            r.a = v[5];
-            r.b = v[6];
-        }
-        return r;
-    }
     // ---- k_fused_segred_night interface (night early-out) -----------------------------------------------------
     // a cell below the altitude cut-off converts to +0.0 whatever the other cubes hold (pv_cell: capped; a NaN
     // altitude is NOT capped)
@@ -668,6 +670,28 @@ struct PvConvT {
             } else {
                 r.x = v0 ? pv_cell_sp(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.sd, q.cd, c.sl0, c.cl0, q.a.x, q.b.x, o0, a0, k) : 0.0;
                 r.y = v1 ? pv_cell_sp(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.sd, q.cd, c.sl1, c.cl1, q.a.y, q.b.y, o1, a1, k) : 0.0;
+            }
+        } else if constexpr (HEAD == 1 && ATL_PV_PLAIN != 0) {
+            // the pair side by side in plain arithmetic, as the direct / diffuse case below (influx rides in dir, outflux
+            // in alb); the dark test reads every loaded value, so no load is sunk behind it
+            const double inf = __builtin_inf();
+            const bool tame = __builtin_fabs(q.dir.x) < inf && __builtin_fabs(q.dir.y) < inf && __builtin_fabs(q.toa.x) < inf &&
+                              __builtin_fabs(q.toa.y) < inf && __builtin_fabs(q.alb.x) < inf && __builtin_fabs(q.alb.y) < inf &&
+                              __builtin_fabs(q.tmp.x) < inf && __builtin_fabs(q.tmp.y) < inf && __builtin_fabs(q.b.x) < inf &&
+                              __builtin_fabs(q.b.y) < inf;
+            const bool dark0 = !v0 || q.a.x < k.alt_thr, dark1 = !v1 || q.a.y < k.alt_thr;
+            r.x = r.y = 0.0;
+            if (!(dark0 && dark1 && tame)) {
+                const PvPlain p0 = pv_cell_influx_plain(q.dir.x, q.alb.x, q.toa.x, q.tmp.x, q.a.x, q.b.x, o0, k);
+                const PvPlain p1 = pv_cell_influx_plain(q.dir.y, q.alb.y, q.toa.y, q.tmp.y, q.a.y, q.b.y, o1, k);
+                r.x = p0.r;
+                r.y = p1.r;
+                if (__builtin_expect(!(p0.ok && p1.ok), 0)) {
+                    r.x = pv_cell_influx<TAIL>(q.dir.x, q.alb.x, q.toa.x, q.tmp.x, q.a.x, q.b.x, o0, k);
+                    r.y = pv_cell_influx<TAIL>(q.dir.y, q.alb.y, q.toa.y, q.tmp.y, q.a.y, q.b.y, o1, k);
+                }
+                r.x = v0 ? r.x : 0.0;
+                r.y = v1 ? r.y : 0.0;
             }
         } else if constexpr (HEAD == 1) {
             r.x = v0 ? pv_cell_influx<TAIL>(q.dir.x, q.alb.x, q.toa.x, q.tmp.x, q.a.x, q.b.x, o0, k) : 0.0;

@@ -23,9 +23,7 @@
 #ifndef ATL_ROW_CACHE
 #define ATL_ROW_CACHE 8
 #endif
-#ifndef ATL_GLDS_DEFAULT
-#define ATL_GLDS_DEFAULT 0  // the LDS-DMA fed fused kernel (k_fused_segred_glds) where a converter offers it
-#endif
+
 
 using namespace atl;
 
@@ -160,12 +158,6 @@ struct conv_vec_only : std::false_type {};
 template <class Conv>
 struct conv_vec_only<Conv, std::void_t<decltype(Conv::kVecOnly)>> : std::integral_constant<bool, Conv::kVecOnly> {};
 constexpr int kNeedScalar = 1;  // internal status, never returned through the C ABI
-// converters whose per-slot inputs are kStreams whole cubes (each (slots, S) fp64) can be fed through LDS-DMA
-// (k_fused_segred_glds): they name the cubes (stream(j)) and assemble their Raw from the staged values (from_streams)
-template <class Conv, class = void>
-struct conv_streams : std::integral_constant<int, 0> {};
-template <class Conv>
-struct conv_streams<Conv, std::void_t<decltype(Conv::kStreams)>> : std::integral_constant<int, Conv::kStreams> {};
 template <class Conv, class = void>
 struct conv_night_pipe : std::false_type {};
 template <class Conv>
@@ -341,6 +333,7 @@ __device__ __forceinline__ void reduce_row(const double2 (&v)[kBatch], double2 w
 
 constexpr int kRowCache = ATL_ROW_CACHE;  // partial rows of a tile whose weights sit in the wave's LDS area for the chunk
 constexpr int kRowCacheDense = 3;        // ... in the instantiation that also carries the MFMA path and its LDS value rows
+constexpr int kDenseSlots = 2 * kBatch;  // slots a dense tile of k_fused_segred contracts per MFMA sweep (= the instruction's 16 columns)
 template <bool DENSE>
 constexpr int row_cache() {
     return DENSE ? kRowCacheDense : kRowCache;
@@ -387,12 +380,15 @@ __device__ __forceinline__ void reduce_batch(const double2 (&v)[kBatch], bool fi
 // every value of the batch is finite: 0 * NaN would leak through structural zeros (the guarded VALU path runs then).
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-template <int U = 8>  // K-steps whose operands are in flight together (4 VGPRs each)
+// NB = slots per batch: 8 (B columns 8-15 repeat 0-7, nobody stores them) or 16 (k_fused_segred's dense tiles: every
+// column of the instruction is a slot, half the MFMAs and half the A-fragment loads per slot)
+template <int U = 8, int NB = kBatch>  // U: K-steps whose operands are in flight together (4 VGPRs each)
 __device__ __forceinline__ void reduce_dense_mfma(const double *vl, const double *__restrict__ wm, int G, int n_rows,
                                                   int32_t p0, int lane, int64_t sb, int64_t send,
                                                   double *__restrict__ partials, int64_t ldp) {
+    static_assert(NB == 8 || NB == 16, "the fp64 MFMA has 16 columns");
     typedef __attribute__((address_space(1))) const double gdouble;
-    const int j = lane & 15, kq = lane >> 4, jj = j & 7;
+    const int j = lane & 15, kq = lane >> 4, jj = NB == 16 ? j : (j & 7);
     const double *brow = vl + jj * kSegCells + kq;
     for (int g = 0; g < G; ++g) {
         // two accumulators (even / odd K-steps): back-to-back MFMAs on ONE accumulator wait for each other
@@ -408,7 +404,7 @@ __device__ __forceinline__ void reduce_dense_mfma(const double *vl, const double
             }
         }
         acc += acc1;
-        if (j < kBatch && sb + j < send) {
+        if (j < NB && sb + j < send) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = kMfmaRows * g + 4 * r + kq;
@@ -468,7 +464,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
     // (DENSE = the plan has dense tiles: a separate instantiation, so that the common one keeps its registers)
     const int n_mfma = DENSE ? mfma_groups(p1 - p0) : 0;  // groups of 16 rows
     const double *wm = n_mfma ? plan.prow_wm + plan.seg_wm[seg] : nullptr;
-    double *vl = lds + conv_lds_doubles + kWavesPerBlock * (ROWS * kSegCells) + wave * (kBatch * kSegCells);
+    double *vl = lds + conv_lds_doubles + kWavesPerBlock * (ROWS * kSegCells) + wave * (kDenseSlots * kSegCells);
     // lanes whose cells carry no weight in any partial row do not load (PlanDev::seg_mask)
     const bool covered = (plan.seg_mask[seg] >> lane) & 1u;
     const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
@@ -492,9 +488,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
     const int64_t send = min(sbeg + int64_t(chunk_slots), slot0 + n_slots);
     partials -= slot0;
     typename Conv::Carry carry = carry_init<typename Conv::Carry>();
-    for (int64_t sb = sbeg; sb < send; sb += kBatch) {
-        double2 v[kBatch];
-        bool finite = true;
+    // one batch: kBatch slots from sb on -> v (and whether every value of it is finite)
+    auto convert_batch = [&](int64_t sb, double2 (&v)[kBatch], bool &finite) {
         // kGroup slots are LOADED before any of them is converted, so a light converter keeps 8
         // independent 1-KiB loads in flight per wave; slots past the end of a ragged chunk re-load
         // its last slot (loads stay unconditional) and are zeroed afterwards.
@@ -519,6 +514,44 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
                 finite = finite && (__builtin_fabs(v[i].x) < __builtin_inf()) && (__builtin_fabs(v[i].y) < __builtin_inf());
             }
         }
+    };
+    if constexpr (DENSE) {
+        if (n_mfma > 0) {
+            // Dense tile: TWO batches per pass, so that all 16 columns of v_mfma_f64_16x16x4_f64 are slots (with 8 the
+            // instruction's other half multiplies copies): both batches are converted into the wave's 16 LDS value rows,
+            // then one MFMA sweep contracts them with the tile's operand image - half the MFMAs and half the operand
+            // loads per slot.  Rows past the MFMA groups, and everything when a value is not finite (0 * NaN would
+            // leak through structural zeros), go through the butterfly, batch by batch, from the rows.
+            const int32_t pm = p0 + min(kMfmaRows * n_mfma, p1 - p0);
+            for (int64_t sb = sbeg; sb < send; sb += kDenseSlots) {
+                bool finite = true;
+#pragma unroll 1
+                for (int h = 0; h < kDenseSlots / kBatch; ++h) {
+                    double2 v[kBatch];
+                    convert_batch(sb + h * kBatch, v, finite);
+#pragma unroll
+                    for (int i = 0; i < kBatch; ++i) *reinterpret_cast<double2 *>(vl + vrow_pair<true>(h * kBatch + i, lane)) = v[i];
+                }
+                const bool all_finite = __all(finite);
+                if (all_finite) reduce_dense_mfma<8, kDenseSlots>(vl, wm, n_mfma, p1 - p0, p0, lane, sb, send, partials, ldp);
+                if (!all_finite || pm < p1) {
+#pragma unroll 1
+                    for (int h = 0; h < kDenseSlots / kBatch; ++h) {
+                        if (sb + h * kBatch >= send) break;
+                        double2 v[kBatch];
+#pragma unroll
+                        for (int i = 0; i < kBatch; ++i) v[i] = *reinterpret_cast<const double2 *>(vl + vrow_pair<true>(h * kBatch + i, lane));
+                        reduce_batch<0>(v, all_finite, plan, all_finite ? pm : p0, p1, wlds, 0u, lane, sb + h * kBatch, send, partials, ldp);
+                    }
+                }
+            }
+            return;
+        }
+    }
+    for (int64_t sb = sbeg; sb < send; sb += kBatch) {
+        double2 v[kBatch];
+        bool finite = true;
+        convert_batch(sb, v, finite);
 #ifdef ATL_ABLATE_NOREDUCE  // experiment: conversion only, one dummy store per batch
         {
             double acc = 0.0;
@@ -527,113 +560,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
             continue;
         }
 #endif
-        if (DENSE && n_mfma > 0) {
-            const int32_t pm = p0 + min(kMfmaRows * n_mfma, p1 - p0);  // rows past the MFMA groups (< kMfmaMinRows of them)
-            if (__all(finite)) {
-#pragma unroll
-                for (int i = 0; i < kBatch; ++i) *reinterpret_cast<double2 *>(vl + vrow_pair<DENSE>(i, lane)) = v[i];
-                reduce_batch<0>(v, true, plan, pm, p1, wlds, 0u, lane, sb, send, partials, ldp);  // v's registers die here
-                reduce_dense_mfma(vl, wm, n_mfma, p1 - p0, p0, lane, sb, send, partials, ldp);
-            } else {
-                reduce_batch<0>(v, false, plan, p0, p1, wlds, 0u, lane, sb, send, partials, ldp);
-            }
-        } else {
-            reduce_batch<ROWS>(v, finite, plan, p0, p1, wlds, present, lane, sb, send, partials, ldp);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// kernel 3a: the fused kernel fed through LDS-DMA, one slot ahead
-// ---------------------------------------------------------------------------------------
-// k_fused_segred converts a slot only after ITS loads have landed and loads the next slot only after that conversion
-// (the branches to the careful per-cell routines separate the slots into basic blocks): a wave has its 7 KiB in
-// flight while it waits and nothing in flight while it computes.  Here the next slot's cubes travel as
-// global_load_lds_dwordx4 (gfx950: 16 bytes per lane straight into the wave's LDS staging rows, no VGPRs) WHILE the
-// current slot is converted: per slot  wait -> 7 x ds_read_b128 -> issue the next slot's 7 DMAs -> convert.
-// Same tiles, chunks, partial rows, reduction and arithmetic as k_fused_segred: bit-identical output.
-// Vectorised, non-dense plans only; LDS per wave = kRowCacheGlds weight rows + kStreams staging rows.
-#ifndef ATL_ROW_CACHE_GLDS
-#define ATL_ROW_CACHE_GLDS 5
-#endif
-constexpr int kRowCacheGlds = ATL_ROW_CACHE_GLDS;
-
-template <class Conv>
-__global__ __launch_bounds__(kWavesPerBlock * 64, min_waves<Conv>()) void k_fused_segred_glds(Conv conv, PlanDev plan, int64_t slot0,
-                                                      int64_t n_slots, int64_t S, int32_t chunk_slots,
-                                                      int64_t n_units, double *__restrict__ partials,
-                                                      int64_t ldp, int32_t conv_lds_doubles) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    conv.block_init(lds);
-    __syncthreads();
-    constexpr int NS = conv_streams<Conv>::value;
-    constexpr int ROWS = kRowCacheGlds;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
-    double *wlds = lds + conv_lds_doubles + wave * ((ROWS + NS) * kSegCells);
-    double *stage = wlds + ROWS * kSegCells;  // [NS][kSegCells]: lane l's cell pair of cube j at stage[j * 128 + 2 l]
-    const int64_t unit = int64_t(blockIdx.x) * kWavesPerBlock + wave;
-    if (unit >= n_units) return;
-    const int32_t seg = int32_t(unit % plan.n_segs);
-    const int64_t chunk = unit / plan.n_segs;
-    const TileLane tl = tile_lane_cells(plan.X, plan.Y, plan.ntx, plan.w2_log2, seg, lane);
-    const int64_t c0 = tl.c0;
-    const bool v0 = tl.v0, v1 = tl.v1;
-    const int32_t p0 = plan.seg_ptr[seg], p1 = plan.seg_ptr[seg + 1];
-    if (p0 == p1) return;
-    const bool covered = (plan.seg_mask[seg] >> lane) & 1u;
-    const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
-    unsigned present = 0;
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        double2 wz = {0.0, 0.0};
-        if (p0 + r < p1) {
-            const double2 w = *reinterpret_cast<const double2 *>(plan.prow_w + int64_t(p0 + r) * kSegCells + 2 * lane);
-            const bool a0 = !dnan(w.x), a1 = !dnan(w.y);
-            wz.x = a0 ? w.x : 0.0;
-            wz.y = a1 ? w.y : 0.0;
-            present |= (a0 ? 1u : 0u) << (2 * r) | (a1 ? 1u : 0u) << (2 * r + 1);
-        }
-        *reinterpret_cast<double2 *>(wlds + r * kSegCells + 2 * lane) = wz;
-    }
-    const int64_t sbeg = slot0 + chunk * chunk_slots;
-    const int64_t send = min(sbeg + int64_t(chunk_slots), slot0 + n_slots);
-    partials -= slot0;
-    typedef __attribute__((address_space(3))) void *lds_ptr;
-    typedef __attribute__((address_space(1))) const void *glob_ptr;
-    // the lane's 16 bytes of every cube of one slot -> the staging rows (uncovered lanes move nothing: what they read
-    // back from the rows is dropped below).  aux = 2: nontemporal, every byte is read exactly once.
-    auto prefetch = [&](int64_t slot) {
-        if (covered) {
-            const int64_t off = slot * S + c0;
-#pragma unroll
-            for (int j = 0; j < NS; ++j)
-                __builtin_amdgcn_global_load_lds((glob_ptr)(conv.stream(j) + off), (lds_ptr)(stage + j * kSegCells), 16, 0, 2);
-        }
-    };
-    prefetch(sbeg);
-    for (int64_t sb = sbeg; sb < send; sb += kBatch) {
-        double2 v[kBatch];
-        bool finite = true;
-#pragma unroll
-        for (int i = 0; i < kBatch; ++i) {
-            // slots past the end of a ragged chunk re-convert its last slot and are zeroed (as k_fused_segred does)
-            const int64_t slot = min(sb + i, send - 1);
-            const int64_t next = min(sb + i + 1, send - 1);
-            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this slot's cubes are in the staging rows
-            double2 in[NS];
-#pragma unroll
-            for (int j = 0; j < NS; ++j) in[j] = *reinterpret_cast<const double2 *>(stage + j * kSegCells + 2 * lane);
-            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the rows are free again
-            if (next != slot) prefetch(next);     // in flight behind this slot's conversion
-            const typename Conv::Raw raw = conv.from_streams(in, slot, cell);
-            const bool live = covered && sb + i < send;
-            v[i] = conv.compute(raw, v0, v1, cell, lds);
-            v[i].x = live ? v[i].x : 0.0;
-            v[i].y = live ? v[i].y : 0.0;
-            finite = finite && (__builtin_fabs(v[i].x) < __builtin_inf()) && (__builtin_fabs(v[i].y) < __builtin_inf());
-        }
-        reduce_batch<ROWS>(v, finite, plan, p0, p1, wlds, present, lane, sb, send, partials, ldp);
+        reduce_batch<ROWS>(v, finite, plan, p0, p1, wlds, present, lane, sb, send, partials, ldp);  // (sparse tile)
     }
 }
 
@@ -810,12 +737,6 @@ struct KernelBracket {
         }
     }
 };
-
-// the LDS-DMA fed fused kernel: $ATLITE_HIP_GLDS = 0 / 1 (experiments, A/B inside one process)
-inline bool use_glds() {
-    const char *e = getenv("ATLITE_HIP_GLDS");
-    return e ? atoi(e) != 0 : ATL_GLDS_DEFAULT != 0;
-}
 
 inline bool debug_occupancy() {
     static const bool on = getenv("ATLITE_HIP_DEBUG_OCCUPANCY") != nullptr;
@@ -997,7 +918,7 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
                 hipLaunchKernelGGL(kern, grid, dim3(kWavesPerBlock * 64), lds_sz, ctx->stream, conv, plan, w0, wn, S,
                                    chunk_slots, n_units, partials, ldp, conv_lds_doubles);
             };
-            const size_t lds_base = conv_lds + size_t(kWavesPerBlock) * (dense ? kRowCacheDense + kBatch : kRowCache) * kSegCells * sizeof(double);
+            const size_t lds_base = conv_lds + size_t(kWavesPerBlock) * (dense ? kRowCacheDense + kDenseSlots : kRowCache) * kSegCells * sizeof(double);
             if constexpr (conv_night_pipe<Conv>::value) {
                 const size_t lds_night = conv_lds + size_t(kWavesPerBlock) * (kRowCacheNight + kBatch) * kSegCells * sizeof(double);
                 if (!vec) {
@@ -1008,9 +929,6 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
                     launch(k_fused_segred_night<Conv, true, false>, lds_night);
             } else if (!vec) {
                 if constexpr (kScalarToo) launch(k_fused_segred<Conv, false, false>, lds_base);
-            } else if (conv_streams<Conv>::value > 0 && !dense && use_glds()) {
-                if constexpr (conv_streams<Conv>::value > 0)
-                    launch(k_fused_segred_glds<Conv>, conv_lds + size_t(kWavesPerBlock) * (kRowCacheGlds + conv_streams<Conv>::value) * kSegCells * sizeof(double));
             } else if constexpr (conv_dense_ok<Conv>::value) {
                 dense ? launch(k_fused_segred<Conv, true, true>, lds_base) : launch(k_fused_segred<Conv, true, false>, lds_base);
             } else {

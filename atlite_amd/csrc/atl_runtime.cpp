@@ -853,7 +853,7 @@ int atl_pv_probe_host(const atl_pv_params *p, int family, int64_t n, const doubl
                     "atl_pv_probe_host: the influx / outflux head serves pv() with its defaults only");
         for (int64_t i = 0; i < n; ++i) {
             const PvOri o = PvConvT<false, true, false, kTailHuld>::make_ori(slope[i], pazim[i]);
-            h_out[i] = pv_cell_influx<kTailHuld>(infl[i], outf[i], toa[i], tmp[i], alt[i], az[i], o, k);
+            h_out[i] = pv_cell_influx_auto(infl[i], outf[i], toa[i], tmp[i], alt[i], az[i], o, k);
         }
         return ATL_OK;
     }

@@ -10,6 +10,7 @@ single-GPU sizes, dominant-kernel time from HIP events, GB/s on algorithmic byte
   C4s pv, 500 shapes                 1095x800x800 (1/8 of the 8760-step config)  56 B
 """
 import json
+import os
 import sys
 from pathlib import Path
 
@@ -27,13 +28,18 @@ CSI = dict(c_temp_amb=1, c_temp_irrad=0.035, r_tmod=298, r_irradiance=1000, k_1=
            slope=np.radians(30.0), azimuth=np.radians(180.0))
 
 
+WARM = int(os.environ.get("ATL_CFG_WARMUP", "10"))  # untimed launches first: the shader clock needs ~30 ms of load to settle
+REPS = int(os.environ.get("ATL_CFG_REPS", "0"))     # (profiles/r03_clock_per_launch.txt); ATL_CFG_REPS overrides a caller's reps
+
+
 def timed(ctx, fn, reps=6):
     ctx.set_profiling(True)
     ms = []
-    for i in range(reps + 2):
+    reps = REPS or reps
+    for i in range(reps + WARM):
         out = fn()
         t = ctx.last_kernel_ms()
-        if i >= 2:
+        if i >= WARM:
             ms.append(t)
         del out
     return float(np.median(ms)), float(np.min(ms))

@@ -53,8 +53,12 @@ def main():
     if "wind" in which:
         w = synthetic.wind_inputs(ctx, T, Y, X)
         runs["wind"] = (16, lambda plan: ctx.wind(w["wnd100m"], w["roughness"], V, POW / 3.06, 80.0, 100.0, "logarithmic", T, S, plan=plan))
-    mats = [(f"dense R={R}", dense_rows(S, R)) for R in (1, 2, 3, 4, 8, 16, 32)]
-    mats += [(f"layers k={k}", layers(Y, X, k)) for k in (1, 2, 4, 8)]
+    import os
+
+    only = [int(v) for v in os.environ.get("ATL_DENSE_R", "").split(",") if v]  # e.g. "16,32": just these row counts
+    mats = [(f"dense R={R}", dense_rows(S, R)) for R in (only or (1, 2, 3, 4, 8, 16, 32))]
+    if not only:
+        mats += [(f"layers k={k}", layers(Y, X, k)) for k in (1, 2, 4, 8)]
     for mname, M in mats:
         plan = ctx.plan(M, row_len=X)
         info = plan.info()
