@@ -39,8 +39,11 @@ __device__ __forceinline__ double2 ld2(const double *__restrict__ p, int64_t bas
     // tick the LDS counter, which makes every LDS table read of the wind kernel wait for them.
     typedef __attribute__((address_space(1))) const double gdouble;
     if constexpr (VEC) {
+        // the pair as ONE 16-byte access that is only promised 8-byte alignment (global_load_dwordx4 takes it): with an
+        // odd cell count every other slot's rows start 8 bytes off a 16-byte boundary
         typedef double f64x2 __attribute__((ext_vector_type(2)));
-        typedef __attribute__((address_space(1))) const f64x2 gf64x2;
+        typedef f64x2 f64x2_a8 __attribute__((aligned(8)));
+        typedef __attribute__((address_space(1))) const f64x2_a8 gf64x2;
         const f64x2 t = __builtin_nontemporal_load((gf64x2 *)(p + base + c0));
         r.x = t.x;
         r.y = t.y;
@@ -59,14 +62,18 @@ __device__ __forceinline__ void st2(double *__restrict__ p, int64_t off, bool v0
 #ifndef ATL_SPLIT_STORES
     if constexpr (VEC) {
         // one 16-byte store per lane: a wave writes whole 128-byte lines with a single instruction
-        // instead of two half-filled ones (wind series 5.96-6.1 -> 5.9 ms, measured A/B)
+        // instead of two half-filled ones (wind series 5.96-6.1 -> 5.9 ms, measured A/B); 8-byte alignment suffices
         typedef double f64x2 __attribute__((ext_vector_type(2)));
-        typedef __attribute__((address_space(1))) f64x2 gf64x2;
+        typedef f64x2 f64x2_a8 __attribute__((aligned(8)));
+        typedef __attribute__((address_space(1))) f64x2_a8 gf64x2;
         f64x2 t;
         t.x = v.x;
         t.y = v.y;
         // (temporal stores instead: wind series 6.0 -> 6.4 ms, pv series 4.2 -> 4.4 ms)
-        if (v0) __builtin_nontemporal_store(t, (gf64x2 *)(p + off));
+        if (v0 && v1) __builtin_nontemporal_store(t, (gf64x2 *)(p + off));
+        // the lane that owns the LAST cell of an odd cell count: its second value belongs to nobody (it would land on
+        // the next slot's first cell)
+        else if (v0) __builtin_nontemporal_store(v.x, p + off);
         return;
     }
 #endif

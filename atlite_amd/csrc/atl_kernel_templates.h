@@ -414,6 +414,40 @@ __device__ __forceinline__ void reduce_dense_mfma(const double *vl, const double
     }
 }
 
+// one batch of the fused kernel: kBatch slots from sb on -> v, and whether every value of it is finite.
+// kGroup slots are LOADED before any of them is converted, so a light converter keeps 8 independent 1-KiB loads in
+// flight per wave; slots past the end of a ragged chunk re-load its last slot (loads stay unconditional) and are zeroed
+// afterwards.  Used by the dense-tile loop only: routed through this function (or a lambda) the SPARSE loop of the wind
+// kernel took 168 VGPRs + 160 B of scratch instead of 106 VGPRs (C3 aggregated 3.65 -> 7.25 ms) and the pv kernel lost
+// 3 % - the sparse loop keeps the same statements inline.
+template <bool VEC, class Conv>
+__device__ __forceinline__ void convert_batch(const Conv &conv, int64_t sb, int64_t send, bool covered, bool v0, bool v1,
+                                              int64_t s0c, int64_t s1c, const typename Conv::Cell &cell,
+                                              typename Conv::Carry &carry, const double *lds, double2 (&v)[kBatch],
+                                              bool &finite) {
+    constexpr int G = Conv::kGroup;
+#pragma unroll
+    for (int i0 = 0; i0 < kBatch; i0 += G) {
+        typename Conv::Raw raw[G] = {};
+        if (covered) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                raw[g] = conv.template load<VEC>(min(sb + i0 + g, send - 1), i0 + g, s0c, s1c, cell, carry);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int i = i0 + g;
+            const bool live = covered && sb + i < send;  // an uncovered lane converts zeros: whatever comes out is dropped
+            v[i] = conv.compute(raw[g], v0, v1, cell, lds);
+            v[i].x = live ? v[i].x : 0.0;
+            v[i].y = live ? v[i].y : 0.0;
+            // |x| < inf is false for NaN and +-inf
+            finite = finite && (__builtin_fabs(v[i].x) < __builtin_inf()) && (__builtin_fabs(v[i].y) < __builtin_inf());
+        }
+    }
+}
+
 template <class Conv, bool VEC, bool DENSE>
 __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2 ? 2 : min_waves<Conv>()) void k_fused_segred(Conv conv, PlanDev plan, int64_t slot0,
                                                       int64_t n_slots, int64_t S, int32_t chunk_slots,
@@ -488,33 +522,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
     const int64_t send = min(sbeg + int64_t(chunk_slots), slot0 + n_slots);
     partials -= slot0;
     typename Conv::Carry carry = carry_init<typename Conv::Carry>();
-    // one batch: kBatch slots from sb on -> v (and whether every value of it is finite)
-    auto convert_batch = [&](int64_t sb, double2 (&v)[kBatch], bool &finite) {
-        // kGroup slots are LOADED before any of them is converted, so a light converter keeps 8
-        // independent 1-KiB loads in flight per wave; slots past the end of a ragged chunk re-load
-        // its last slot (loads stay unconditional) and are zeroed afterwards.
-        constexpr int G = Conv::kGroup;
-#pragma unroll
-        for (int i0 = 0; i0 < kBatch; i0 += G) {
-            typename Conv::Raw raw[G] = {};
-            if (covered) {
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    raw[g] = conv.template load<VEC>(min(sb + i0 + g, send - 1), i0 + g, s0c, s1c, cell, carry);
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const int i = i0 + g;
-                const bool live = covered && sb + i < send;  // an uncovered lane converts zeros: whatever comes out is dropped
-                v[i] = conv.compute(raw[g], v0, v1, cell, lds);
-                v[i].x = live ? v[i].x : 0.0;
-                v[i].y = live ? v[i].y : 0.0;
-                // |x| < inf is false for NaN and +-inf
-                finite = finite && (__builtin_fabs(v[i].x) < __builtin_inf()) && (__builtin_fabs(v[i].y) < __builtin_inf());
-            }
-        }
-    };
     if constexpr (DENSE) {
         if (n_mfma > 0) {
             // Dense tile: TWO batches per pass, so that all 16 columns of v_mfma_f64_16x16x4_f64 are slots (with 8 the
@@ -528,7 +535,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
 #pragma unroll 1
                 for (int h = 0; h < kDenseSlots / kBatch; ++h) {
                     double2 v[kBatch];
-                    convert_batch(sb + h * kBatch, v, finite);
+                    convert_batch<VEC>(conv, sb + h * kBatch, send, covered, v0, v1, s0c, s1c, cell, carry, lds, v, finite);
 #pragma unroll
                     for (int i = 0; i < kBatch; ++i) *reinterpret_cast<double2 *>(vl + vrow_pair<true>(h * kBatch + i, lane)) = v[i];
                 }
@@ -551,7 +558,28 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
     for (int64_t sb = sbeg; sb < send; sb += kBatch) {
         double2 v[kBatch];
         bool finite = true;
-        convert_batch(sb, v, finite);
+        {  // convert_batch's statements, inline (see there)
+            constexpr int G = Conv::kGroup;
+#pragma unroll
+            for (int i0 = 0; i0 < kBatch; i0 += G) {
+                typename Conv::Raw raw[G] = {};
+                if (covered) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        raw[g] = conv.template load<VEC>(min(sb + i0 + g, send - 1), i0 + g, s0c, s1c, cell, carry);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int i = i0 + g;
+                    const bool live = covered && sb + i < send;
+                    v[i] = conv.compute(raw[g], v0, v1, cell, lds);
+                    v[i].x = live ? v[i].x : 0.0;
+                    v[i].y = live ? v[i].y : 0.0;
+                    finite = finite && (__builtin_fabs(v[i].x) < __builtin_inf()) && (__builtin_fabs(v[i].y) < __builtin_inf());
+                }
+            }
+        }
 #ifdef ATL_ABLATE_NOREDUCE  // experiment: conversion only, one dummy store per batch
         {
             double acc = 0.0;
@@ -719,7 +747,9 @@ __global__ __launch_bounds__(256) void k_rows_timered(const double *__restrict__
 // ---------------------------------------------------------------------------------------
 // host-side launch plumbing
 // ---------------------------------------------------------------------------------------
-inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+// $ATLITE_HIP_NO_VEC: every launch through the unvectorised instantiations (tests)
+inline bool no_vec() { return getenv("ATLITE_HIP_NO_VEC") != nullptr; }  // read per call: tests switch it in-process
+inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 
 struct KernelBracket {
     atl_ctx *ctx;
@@ -784,17 +814,18 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
     if (S == 0 || (n_slots == 0 && time_agg == ATL_TIME_NONE)) return ATL_OK;
     unsigned gx = unsigned((S + 511) / 512);
     const unsigned gx_cells = gx;  // the slot chunking follows the cell count alone: the same summation order in every variant
-    vec = vec && aligned16(d_out);
+    vec = vec && aligned8(d_out);
     // row_len = X of the (Y, X) grid, when the caller knows it: the early-out kernels then walk 16 x 8 tiles
     int64_t tX = 0, tY = 0;
     int32_t ntx = 0;
     if constexpr (conv_night_pipe<Conv>::value) {
-        if (row_len > 0 && S % row_len == 0 && S / row_len < (int64_t(1) << 30)) {
+        // (only when the slots' rows are 128-byte aligned, S % 16 == 0: a 16-cell tile row off the line grid costs two
+        // lines; the 128-cell strips lose one line in nine)
+        if (row_len > 0 && S % row_len == 0 && S / row_len < (int64_t(1) << 30) && S % 16 == 0) {
             tX = row_len;
             tY = S / row_len;
             ntx = int32_t(tile_columns(tX, tY, 3));
             gx = unsigned((int64_t(ntx) * ((tY + 7) / 8) + 3) / 4);
-            vec = vec && (tX % 2 == 0);  // the lane's cell pair must not straddle a tile row's end
         }
     }
     constexpr bool kScalarToo = !conv_vec_only<Conv>::value;  // the unvectorised instantiations exist
@@ -866,7 +897,7 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
     const PlanDev &plan = agg->dev;
     const int64_t N = plan.n_rows;
     if (N == 0) return ATL_OK;
-    vec = vec && (plan.X % 2 == 0);  // the lane's cell pair must not straddle a grid row
+    // (a lane's cell pair may straddle two grid rows - odd row lengths: cells are owned by flat index, tile_lane_cells)
     constexpr bool kScalarToo = !conv_vec_only<Conv>::value;  // the unvectorised instantiations exist
     if (!kScalarToo && !vec) return kNeedScalar;
     // Partial rows live in scratch as [P][window]; the slot axis is processed in windows so that the
@@ -949,10 +980,19 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
     return ATL_OK;
 }
 
-bool vec_ok(int64_t S, std::initializer_list<const void *> ptrs) {
-    if (S % 2) return false;
-    for (const void *p : ptrs)
-        if (p && !aligned16(p)) return false;
+// Can the (T, S) fp64 cubes at `ptrs` be read 16 bytes per lane (the lane's two adjacent cells)?  Almost always:
+//  * the accesses need not be 16-byte aligned - ld2 / st2 promise 8 bytes, which global_load / store_dwordx4 take; with
+//    an odd cell count every other slot's rows sit 8 bytes off;
+//  * with an ODD cell count the lane that owns a slot's last cell reads 8 bytes past it: the next slot's first cell or,
+//    in the last slot, 8 bytes past the cube.  Those bytes share the last element's 4 KiB page unless the cube ENDS on
+//    a page boundary - then, and only then, the launch takes the unvectorised instantiation (stores never overrun: st2).
+bool vec_ok(int64_t T, int64_t S, std::initializer_list<const void *> ptrs) {
+    if (no_vec()) return false;
+    for (const void *p : ptrs) {
+        if (!p) continue;
+        if (!aligned8(p)) return false;
+        if ((S & 1) && ((reinterpret_cast<uintptr_t>(p) + size_t(T) * size_t(S) * sizeof(double)) & 4095u) == 0) return false;
+    }
     return true;
 }
 

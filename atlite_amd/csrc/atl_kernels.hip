@@ -145,7 +145,7 @@ int make_wind(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p,
         c->vmin = c->vmax = c->inv_w = 0.0;
         *table_finite = true;
         *lds_bytes = size_t(2 * kLogTabN) * sizeof(double);
-        *vec = vec_ok(S, {in->d_wnd, in->aux_is_static ? nullptr : in->d_aux});
+        *vec = vec_ok(T, S, {in->d_wnd, in->aux_is_static ? nullptr : in->d_aux});
         return ATL_OK;
     }
     ATL_REQUIRE(p->n_knots >= 1 && p->n_knots <= kMaxKnots && p->h_V && p->h_POWn,
@@ -196,7 +196,7 @@ int make_wind(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p,
     }
     *table_finite = finite;
     *lds_bytes = size_t(c->tab_doubles + 2 * kLogTabN) * sizeof(double);
-    *vec = vec_ok(S, {in->d_wnd, in->aux_is_static ? nullptr : in->d_aux});
+    *vec = vec_ok(T, S, {in->d_wnd, in->aux_is_static ? nullptr : in->d_aux});
     return ATL_OK;
 }
 
@@ -212,7 +212,7 @@ int make_heat(const double *d_temperature, const atl_heat_params *p, int64_t T, 
     c->a = p->a;
     c->constant = p->constant;
     c->cooling = p->cooling ? 1 : 0;
-    *vec = vec_ok(S, {d_temperature});
+    *vec = vec_ok(T, S, {d_temperature});
     return ATL_OK;
 }
 
@@ -282,7 +282,7 @@ int atl_spmm_csr(atl_ctx *ctx, const atl_agg *agg, const double *d_dense, int64_
     ATL_REQUIRE(ctx && d_dense, "atl_spmm_csr: bad argument");
     ATL_REQUIRE(T >= 0 && S >= 0, "atl_spmm_csr: negative shape");
     IdentityConv c{d_dense, S};
-    return run_fused(ctx, c, vec_ok(S, {d_dense}), 0, T, S, agg, time_agg, d_out, ld_out, "atl_spmm_csr");
+    return run_fused(ctx, c, vec_ok(T, S, {d_dense}), 0, T, S, agg, time_agg, d_out, ld_out, "atl_spmm_csr");
 }
 
 int atl_wind_convert(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p, int64_t T,
@@ -339,7 +339,7 @@ int atl_thermo_convert(atl_ctx *ctx, const double *d_var, const atl_thermo_param
     ATL_REQUIRE(ctx && d_var && p, "atl_thermo_convert: bad argument");
     ATL_REQUIRE(T >= 0 && S >= 0, "atl_thermo_convert: negative shape");
     ThermoConv c{d_var, S, p->offset, p->sink_T, p->c0, p->c1, p->c2, p->fillna0, p->quadratic};
-    return run_cells(ctx, c, vec_ok(S, {d_var}), 0, T, S, time_agg, d_out, "atl_thermo_convert");
+    return run_cells(ctx, c, vec_ok(T, S, {d_var}), 0, T, S, time_agg, d_out, "atl_thermo_convert");
 }
 
 int atl_thermo_convert_aggregate(atl_ctx *ctx, const double *d_var, const atl_thermo_params *p, int64_t T,
@@ -347,7 +347,7 @@ int atl_thermo_convert_aggregate(atl_ctx *ctx, const double *d_var, const atl_th
     ATL_REQUIRE(ctx && d_var && p, "atl_thermo_convert_aggregate: bad argument");
     ATL_REQUIRE(T >= 0 && S >= 0, "atl_thermo_convert_aggregate: negative shape");
     ThermoConv c{d_var, S, p->offset, p->sink_T, p->c0, p->c1, p->c2, p->fillna0, p->quadratic};
-    return run_fused(ctx, c, vec_ok(S, {d_var}), 0, T, S, agg, time_agg, d_out, ld_out,
+    return run_fused(ctx, c, vec_ok(T, S, {d_var}), 0, T, S, agg, time_agg, d_out, ld_out,
                      "atl_thermo_convert_aggregate");
 }
 
@@ -356,7 +356,7 @@ int atl_runoff_convert(atl_ctx *ctx, const double *d_runoff, const double *d_hei
     ATL_REQUIRE(ctx && d_runoff, "atl_runoff_convert: bad argument");
     ATL_REQUIRE(T >= 0 && S >= 0, "atl_runoff_convert: negative shape");
     RunoffConv c{d_runoff, d_height, S};
-    return run_cells(ctx, c, vec_ok(S, {d_runoff}), 0, T, S, time_agg, d_out, "atl_runoff_convert");
+    return run_cells(ctx, c, vec_ok(T, S, {d_runoff}), 0, T, S, time_agg, d_out, "atl_runoff_convert");
 }
 
 int atl_runoff_convert_aggregate(atl_ctx *ctx, const double *d_runoff, const double *d_height, int64_t T,
@@ -365,7 +365,7 @@ int atl_runoff_convert_aggregate(atl_ctx *ctx, const double *d_runoff, const dou
     ATL_REQUIRE(ctx && d_runoff, "atl_runoff_convert_aggregate: bad argument");
     ATL_REQUIRE(T >= 0 && S >= 0, "atl_runoff_convert_aggregate: negative shape");
     RunoffConv c{d_runoff, d_height, S};
-    return run_fused(ctx, c, vec_ok(S, {d_runoff}), 0, T, S, agg, time_agg, d_out, ld_out,
+    return run_fused(ctx, c, vec_ok(T, S, {d_runoff}), 0, T, S, agg, time_agg, d_out, ld_out,
                      "atl_runoff_convert_aggregate");
 }
 

@@ -76,7 +76,7 @@ int make_pvx(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t
     ATL_REQUIRE(!p->orientation_per_time || p->d_cell_slope, "atl_pv: orientation_per_time needs the (T,S) slope / azimuth cubes");
     ATL_REQUIRE(!p->orientation_per_time || p->tracking == ATL_TRACK_NONE,
                 "atl_pv: an orientation that depends on time cannot be combined with a tracker");
-    *vec = vec_ok(S, {in->d_influx_direct, in->d_influx_diffuse, in->d_influx, in->d_influx_toa, in->d_albedo,
+    *vec = vec_ok(T, S, {in->d_influx_direct, in->d_influx_diffuse, in->d_influx, in->d_influx_toa, in->d_albedo,
                       in->d_outflux, in->d_temperature, in->d_humidity, in->d_solar_altitude, in->d_solar_azimuth,
                       p->orientation_per_time ? p->d_cell_slope : nullptr, p->orientation_per_time ? p->d_cell_azimuth : nullptr});
     return ATL_OK;

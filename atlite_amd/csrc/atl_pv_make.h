@@ -46,7 +46,7 @@ int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t 
     }
     c->cell_slope = p->d_cell_slope;
     c->cell_azimuth = p->d_cell_azimuth;
-    *vec = vec_ok(S, {in->d_influx_direct, in->d_influx_diffuse, in->d_influx_toa, in->d_albedo,
+    *vec = vec_ok(T, S, {in->d_influx_direct, in->d_influx_diffuse, in->d_influx_toa, in->d_albedo,
                       in->d_temperature, in->d_solar_altitude, in->d_solar_azimuth, in->d_influx, in->d_outflux});
     return ATL_OK;
 }

@@ -501,12 +501,26 @@ static int build_plan(int64_t n_rows, int64_t n_cells, int64_t row_len, const in
                     }
                 }
             }
-            // a tile costs its conversion work even for masked lanes, a partial row one wave
-            // reduction.  With 128-byte-aligned (sheared) tile rows and nontemporal loads the row width
-            // itself hardly matters any more (C2: 16x8 3.27-3.37 ms, 32x4 3.34-3.45, flat 3.39-3.48,
-            // 64x2 3.58), so the partial-row count decides; 64x2 keeps a small measured penalty.
+            // A tile costs its memory stream (and conversion work) even for masked lanes, a partial row one wave
+            // reduction: about 40 : 1 (C2, 325 tiles: 16x8 3.09 ms with 1131 partial rows, 32x4 3.11 / 1462, 64x2
+            // 3.20 / 2245, flat 3.26 / 3590 - profiles/r03_tiles_unaligned.txt).  With 128-byte-aligned (sheared) tile
+            // rows and nontemporal loads the row width itself hardly matters, so the partial-row count decides; 64x2
+            // keeps a small measured penalty.
+            // UNLESS the slots' rows are not 128-byte aligned (S % 16 != 0: every real-world grid with odd dimensions):
+            // the line grid then moves with the slot - in a fraction f of the slots (all but those whose phase
+            // (t S) % 16 is 0) a tile row of w cells straddles one line more than its w / 16, shared with its
+            // neighbour: +16 / w of the traffic.  Measured (201 x 200, f = 1/2): 16x8 4.65 ms, 32x4 4.02, 64x2 3.72,
+            // flat 3.63; (189 x 157, odd S): 16x8 4.43, flat 3.01.  Wide tiles win there.
             static const double row_eff[7] = {0, 0, 0, 1.0, 1.0, 1.05, 1.0};
-            const double cost = (4.0 * double(tiles) + double(P)) * row_eff[cands[c].w2_log2];
+            int64_t g = n_cells % 16;  // phases are the multiples of gcd(S % 16, 16)
+            for (int64_t b = 16; b != 0;) {
+                const int64_t r = g % b;
+                g = b;
+                b = r;
+            }
+            const double f_mis = (n_cells % 16 == 0) ? 0.0 : 1.0 - double(g) / 16.0;
+            const int w = 2 << cands[c].w2_log2;
+            const double cost = (40.0 * double(tiles) * (1.0 + f_mis * 16.0 / w) + double(P)) * row_eff[cands[c].w2_log2];
             if (c == 0 || cost < best_cost) {
                 best_cost = cost;
                 best = c;
