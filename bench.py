@@ -435,25 +435,33 @@ def main():
 
     # per-rank kernel time and the collective by itself (outside the timed region): what a rank's step is made of
     per_rank_kernel_ms = gather_ms = None
-    if world > 1:
+
+    def diagnostics():
         cdev = "cpu" if a.debug_gloo_one_gpu else dev
         mine = torch.tensor([k_ms], dtype=torch.float64, device=cdev)
         lst = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(lst, mine)
-        per_rank_kernel_ms = [float(v.item()) for v in lst]
-        if not a.debug_gloo_one_gpu:
-            reps = 10
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(reps):  # all-gather of every piece + the strided placement copy, nothing to hide behind
-                for i in range(P):
-                    dist.all_gather_into_tensor(gbuf[i].view(-1), piece[i].view(-1))
-                    if full3 is not None:
-                        full3[:, :, pe[i]:pe[i + 1]].copy_(gbuf[i].permute(1, 0, 2))
-            fence()
-            tg = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device=dev)
-            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-            gather_ms = float(tg.item())
+        per_rank = [float(v.item()) for v in lst]
+        if a.debug_gloo_one_gpu:
+            return per_rank, None
+        reps = 10
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):  # all-gather of every piece + the strided placement copy, nothing to hide behind
+            for i in range(P):
+                dist.all_gather_into_tensor(gbuf[i].view(-1), piece[i].view(-1))
+                if full3 is not None:
+                    full3[:, :, pe[i]:pe[i + 1]].copy_(gbuf[i].permute(1, 0, 2))
+        fence()
+        tg = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device=dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        return per_rank, float(tg.item())
+
+    if world > 1:
+        try:  # diagnostics only (the same code path on every rank): nothing here may cost the run its result line
+            per_rank_kernel_ms, gather_ms = diagnostics()
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] rank {rank}: multi-GPU diagnostics skipped: {e!r}", file=sys.stderr)
 
     # the reassembled result holds every rank's block in place
     if world > 1:
