@@ -638,6 +638,27 @@ def main():
             "single_thread_sample": f"{T1} time steps, 1 thread ({cdt1:.2f} s)",
         }
 
+    if rank == 0 and single and not a.no_cpu_baseline and cfg["stored_angles"] and "cpu_baseline" in result:
+        # BASELINE.md variant C: the same chain on dask.array 2021.10.0 (the reference's minimum pin), chunks {"time": 100},
+        # threaded scheduler - under the image's second interpreter, which is the one that has dask
+        conda = "/opt/conda/bin/python3.9"
+        if os.path.exists(conda):
+            import subprocess
+
+            try:
+                r = subprocess.run([conda, str(ROOT / "tools" / "cpu_baseline_dask.py"), "800", str(usable_cpus())],
+                                   capture_output=True, text=True, timeout=240)
+                j = json.loads(r.stdout[r.stdout.index("{"):])
+                c = j["C_dask_array_threads"]
+                result["cpu_baseline"]["dask_array"] = {
+                    "value": c["cell_steps_per_s"], "unit": "cell-timesteps/s", "cores": j["host_threads_used"],
+                    "sample": f"800 x 200 x 200 slab, 100 shapes, dask.array {j['versions']['dask']} / numpy {j['versions']['numpy']} "
+                              f"under {conda}, chunks time=100, threaded scheduler ({c['seconds']:.2f} s, {c['graph_tasks']} tasks); "
+                              f"same interpreter, eager NumPy on 1 thread: {j['A_numpy_1_thread']['cell_steps_per_s']:.3g}",
+                    "equals_numpy_chain_max_rel": j["C_equals_B_max_rel"]}
+            except Exception as e:  # noqa: BLE001 - a second opinion, never a reason to lose the line
+                result["cpu_baseline"]["dask_array"] = {"skipped": repr(e)[:200]}
+
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
