@@ -806,7 +806,8 @@ def convert_and_aggregate(
     if multi:  # every device aggregates its time shard; the (N x T) series is gathered (RCCL) to the host
         out = multigpu.group(devs).run(spec, ds, matrix, X, None)
     else:
-        plan = ctx.plan(matrix, row_len=X)
+        # (the slot stride of the dataset's device copies only steers the plan's tile shape)
+        plan = ctx.plan(matrix, row_len=X, ld=getattr(ds, "_slot_stride", lambda: None)())
         out = _execute(ctx, spec, ds, plan, on_device_time).numpy()  # the plan stays in ctx's cache
     tc = spec.time_coord(ds)
     attrs = {}

@@ -178,6 +178,7 @@ struct UnpackDesc {
 
 struct UnpackParams {
     int64_t shape1, shape2;   // trailing dims of the variable
+    int64_t ld;               // elements between the rows of the output block (>= shape1 * shape2)
     int64_t r0, r1;           // rows wanted
     Decode dec;
 };
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ raw,
             }
             v = cf_decode(bits_to_double(b, p.dec.dtype), p.dec);
         }
-        out[(t - p.r0) * (p.shape1 * p.shape2) + y * p.shape2 + x] = v;
+        out[(t - p.r0) * p.ld + y * p.shape2 + x] = v;
     }
 }
 
@@ -710,6 +711,14 @@ int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, 
     UnpackParams p{};
     p.shape1 = g.shape[1];
     p.shape2 = g.shape[2];
+    // rows of the output block: contiguous unless the context asks for padded slots (atl_set_slot_stride) and the
+    // variable has rows to pad (a (time, y, x) cube)
+    p.ld = g.shape[1] * g.shape[2];
+    if (ctx->slot_stride > 0 && d->shape.size() == 3) {
+        ATL_REQUIRE(ctx->slot_stride >= p.ld, "atl_nc_read_slab: slot stride %lld is smaller than a row of %lld cells",
+                    (long long)ctx->slot_stride, (long long)p.ld);
+        p.ld = ctx->slot_stride;
+    }
     p.r0 = r0;
     p.r1 = r1;
     p.dec = dc;
@@ -827,6 +836,7 @@ int atl_upload_convert_async(atl_ctx *ctx, double *d_dst, const void *h_src, int
     UnpackParams p{};
     p.shape1 = 1;
     p.shape2 = 1;
+    p.ld = 1;
     p.r0 = 0;
     p.r1 = n;
     p.dec.dtype = dtype;

@@ -246,6 +246,9 @@ struct atl_ctx {
     int64_t ring_count = 0;           // launches bracketed since profiling was enabled
     bool profiling = false;
     int n_cu = 256;
+    // slots of the INPUT cubes of the next conversion calls are this many cells apart (atl_set_slot_stride); 0 = the
+    // cubes are contiguous (T, S).  The library's own device copies of a cutout pad every slot to a 128-byte line.
+    int64_t slot_stride = 0;
     // file / narrow-dtype ingest (atl_ingest.hip): staging buffers, created on first use
     void *ingest = nullptr;
     void (*ingest_free)(void *) = nullptr;
@@ -268,4 +271,6 @@ int scratch_reserve(atl_ctx *ctx, size_t bytes, void **out);
 // the context's copy stream (created on first use)
 int copy_stream_of(atl_ctx *ctx, hipStream_t *out);
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+// cells between the slots of a call's input cubes: the context's stride if one is set, else the cell count
+inline int64_t slot_stride_of(const atl_ctx *ctx, int64_t S) { return ctx->slot_stride > 0 ? ctx->slot_stride : S; }
 }  // namespace atl

@@ -810,6 +810,8 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
               int time_agg, double *d_out, const char *what, int64_t row_len = 0) {
     ATL_REQUIRE(time_agg >= ATL_TIME_NONE && time_agg <= ATL_TIME_SUM_COUNT, "%s: bad time_agg %d", what, time_agg);
     ATL_REQUIRE(d_out, "%s: d_out is NULL", what);
+    ATL_REQUIRE(slot_stride_of(ctx, S) >= S, "%s: slot stride %lld is smaller than the %lld cells of a slot (atl_set_slot_stride)", what,
+                (long long)slot_stride_of(ctx, S), (long long)S);
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     if (S == 0 || (n_slots == 0 && time_agg == ATL_TIME_NONE)) return ATL_OK;
     unsigned gx = unsigned((S + 511) / 512);
@@ -819,9 +821,9 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
     int64_t tX = 0, tY = 0;
     int32_t ntx = 0;
     if constexpr (conv_night_pipe<Conv>::value) {
-        // (only when the slots' rows are 128-byte aligned, S % 16 == 0: a 16-cell tile row off the line grid costs two
+        // (only when the slots are 128-byte aligned - stride % 16 == 0: a 16-cell tile row off the line grid costs two
         // lines; the 128-cell strips lose one line in nine)
-        if (row_len > 0 && S % row_len == 0 && S / row_len < (int64_t(1) << 30) && S % 16 == 0) {
+        if (row_len > 0 && S % row_len == 0 && S / row_len < (int64_t(1) << 30) && slot_stride_of(ctx, S) % 16 == 0) {
             tX = row_len;
             tY = S / row_len;
             ntx = int32_t(tile_columns(tX, tY, 3));
@@ -893,6 +895,8 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
     ATL_REQUIRE(d_out, "%s: d_out is NULL", what);
     ATL_REQUIRE(time_agg != ATL_TIME_NONE || ld_out >= n_slots, "%s: ld_out %lld < %lld", what,
                 (long long)ld_out, (long long)n_slots);
+    ATL_REQUIRE(slot_stride_of(ctx, S) >= S, "%s: slot stride %lld is smaller than the %lld cells of a slot (atl_set_slot_stride)", what,
+                (long long)slot_stride_of(ctx, S), (long long)S);
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     const PlanDev &plan = agg->dev;
     const int64_t N = plan.n_rows;
@@ -986,12 +990,13 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
 //  * with an ODD cell count the lane that owns a slot's last cell reads 8 bytes past it: the next slot's first cell or,
 //    in the last slot, 8 bytes past the cube.  Those bytes share the last element's 4 KiB page unless the cube ENDS on
 //    a page boundary - then, and only then, the launch takes the unvectorised instantiation (stores never overrun: st2).
-bool vec_ok(int64_t T, int64_t S, std::initializer_list<const void *> ptrs) {
+// (ld = cells between slots, atl_set_slot_stride: a padded slot has the 8 bytes after its last cell to itself.)
+bool vec_ok(int64_t T, int64_t S, int64_t ld, std::initializer_list<const void *> ptrs) {
     if (no_vec()) return false;
     for (const void *p : ptrs) {
         if (!p) continue;
         if (!aligned8(p)) return false;
-        if ((S & 1) && ((reinterpret_cast<uintptr_t>(p) + size_t(T) * size_t(S) * sizeof(double)) & 4095u) == 0) return false;
+        if ((S & 1) && ld == S && ((reinterpret_cast<uintptr_t>(p) + size_t(T) * size_t(S) * sizeof(double)) & 4095u) == 0) return false;
     }
     return true;
 }

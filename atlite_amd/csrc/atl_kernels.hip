@@ -134,7 +134,7 @@ int make_wind(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p,
                     "atl_wind: heights must be positive and finite");
         c->wnd = in->d_wnd;
         c->aux = in->d_aux;
-        c->S = S;
+        c->S = slot_stride_of(ctx, S);  // the converter's S is what separates the slots of its cubes
         c->aux_static = in->aux_is_static;
         c->method = (p->method == ATL_WIND_POWER && p->to_height == p->from_height) ? ATL_WIND_NONE : p->method;
         c->to_height = p->to_height;
@@ -145,7 +145,7 @@ int make_wind(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p,
         c->vmin = c->vmax = c->inv_w = 0.0;
         *table_finite = true;
         *lds_bytes = size_t(2 * kLogTabN) * sizeof(double);
-        *vec = vec_ok(T, S, {in->d_wnd, in->aux_is_static ? nullptr : in->d_aux});
+        *vec = vec_ok(T, S, slot_stride_of(ctx, S), {in->d_wnd, in->aux_is_static ? nullptr : in->d_aux});
         return ATL_OK;
     }
     ATL_REQUIRE(p->n_knots >= 1 && p->n_knots <= kMaxKnots && p->h_V && p->h_POWn,
@@ -173,7 +173,7 @@ int make_wind(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p,
     ctx->table_pending = true;
     c->wnd = in->d_wnd;
     c->aux = in->d_aux;
-    c->S = S;
+    c->S = slot_stride_of(ctx, S);
     c->aux_static = in->aux_is_static;
     // (to / from) ** shear with to == from is 1 whatever the shear exponent holds (pow(1, NaN) = 1, which
     // exp(NaN * log 1) would not give): no extrapolation at all
@@ -196,23 +196,23 @@ int make_wind(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p,
     }
     *table_finite = finite;
     *lds_bytes = size_t(c->tab_doubles + 2 * kLogTabN) * sizeof(double);
-    *vec = vec_ok(T, S, {in->d_wnd, in->aux_is_static ? nullptr : in->d_aux});
+    *vec = vec_ok(T, S, slot_stride_of(ctx, S), {in->d_wnd, in->aux_is_static ? nullptr : in->d_aux});
     return ATL_OK;
 }
 
-int make_heat(const double *d_temperature, const atl_heat_params *p, int64_t T, int64_t S, HeatConv *c,
+int make_heat(const atl_ctx *ctx, const double *d_temperature, const atl_heat_params *p, int64_t T, int64_t S, HeatConv *c,
               bool *vec) {
     ATL_REQUIRE(d_temperature && p, "atl_heat_demand: temperature/params is NULL");
     ATL_REQUIRE(T >= 0 && S >= 0 && p->n_days >= 0, "atl_heat_demand: negative shape");
     ATL_REQUIRE(p->n_days == 0 || p->d_day_ptr, "atl_heat_demand: d_day_ptr is NULL");
     c->temperature = d_temperature;
     c->day_ptr = p->d_day_ptr;
-    c->S = S;
+    c->S = slot_stride_of(ctx, S);
     c->threshold_K = p->threshold_K;
     c->a = p->a;
     c->constant = p->constant;
     c->cooling = p->cooling ? 1 : 0;
-    *vec = vec_ok(T, S, {d_temperature});
+    *vec = vec_ok(T, S, slot_stride_of(ctx, S), {d_temperature});
     return ATL_OK;
 }
 
@@ -281,8 +281,8 @@ int atl_spmm_csr(atl_ctx *ctx, const atl_agg *agg, const double *d_dense, int64_
                  int time_agg, double *d_out, int64_t ld_out) {
     ATL_REQUIRE(ctx && d_dense, "atl_spmm_csr: bad argument");
     ATL_REQUIRE(T >= 0 && S >= 0, "atl_spmm_csr: negative shape");
-    IdentityConv c{d_dense, S};
-    return run_fused(ctx, c, vec_ok(T, S, {d_dense}), 0, T, S, agg, time_agg, d_out, ld_out, "atl_spmm_csr");
+    IdentityConv c{d_dense, slot_stride_of(ctx, S)};
+    return run_fused(ctx, c, vec_ok(T, S, slot_stride_of(ctx, S), {d_dense}), 0, T, S, agg, time_agg, d_out, ld_out, "atl_spmm_csr");
 }
 
 int atl_wind_convert(atl_ctx *ctx, const atl_wind_inputs *in, const atl_wind_params *p, int64_t T,
@@ -317,7 +317,7 @@ int atl_heat_demand_convert(atl_ctx *ctx, const double *d_temperature, const atl
     ATL_REQUIRE(ctx, "atl_heat_demand_convert: ctx is NULL");
     HeatConv c;
     bool vec;
-    int rc = make_heat(d_temperature, p, T, S, &c, &vec);
+    int rc = make_heat(ctx, d_temperature, p, T, S, &c, &vec);
     if (rc) return rc;
     return run_cells(ctx, c, vec, 0, p->n_days, S, time_agg, d_out, "atl_heat_demand_convert");
 }
@@ -328,7 +328,7 @@ int atl_heat_demand_convert_aggregate(atl_ctx *ctx, const double *d_temperature,
     ATL_REQUIRE(ctx, "atl_heat_demand_convert_aggregate: ctx is NULL");
     HeatConv c;
     bool vec;
-    int rc = make_heat(d_temperature, p, T, S, &c, &vec);
+    int rc = make_heat(ctx, d_temperature, p, T, S, &c, &vec);
     if (rc) return rc;
     return run_fused(ctx, c, vec, 0, p->n_days, S, agg, time_agg, d_out, ld_out,
                      "atl_heat_demand_convert_aggregate");
@@ -338,16 +338,16 @@ int atl_thermo_convert(atl_ctx *ctx, const double *d_var, const atl_thermo_param
                        int time_agg, double *d_out) {
     ATL_REQUIRE(ctx && d_var && p, "atl_thermo_convert: bad argument");
     ATL_REQUIRE(T >= 0 && S >= 0, "atl_thermo_convert: negative shape");
-    ThermoConv c{d_var, S, p->offset, p->sink_T, p->c0, p->c1, p->c2, p->fillna0, p->quadratic};
-    return run_cells(ctx, c, vec_ok(T, S, {d_var}), 0, T, S, time_agg, d_out, "atl_thermo_convert");
+    ThermoConv c{d_var, slot_stride_of(ctx, S), p->offset, p->sink_T, p->c0, p->c1, p->c2, p->fillna0, p->quadratic};
+    return run_cells(ctx, c, vec_ok(T, S, slot_stride_of(ctx, S), {d_var}), 0, T, S, time_agg, d_out, "atl_thermo_convert");
 }
 
 int atl_thermo_convert_aggregate(atl_ctx *ctx, const double *d_var, const atl_thermo_params *p, int64_t T,
                                  int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out) {
     ATL_REQUIRE(ctx && d_var && p, "atl_thermo_convert_aggregate: bad argument");
     ATL_REQUIRE(T >= 0 && S >= 0, "atl_thermo_convert_aggregate: negative shape");
-    ThermoConv c{d_var, S, p->offset, p->sink_T, p->c0, p->c1, p->c2, p->fillna0, p->quadratic};
-    return run_fused(ctx, c, vec_ok(T, S, {d_var}), 0, T, S, agg, time_agg, d_out, ld_out,
+    ThermoConv c{d_var, slot_stride_of(ctx, S), p->offset, p->sink_T, p->c0, p->c1, p->c2, p->fillna0, p->quadratic};
+    return run_fused(ctx, c, vec_ok(T, S, slot_stride_of(ctx, S), {d_var}), 0, T, S, agg, time_agg, d_out, ld_out,
                      "atl_thermo_convert_aggregate");
 }
 
@@ -355,8 +355,8 @@ int atl_runoff_convert(atl_ctx *ctx, const double *d_runoff, const double *d_hei
                        int time_agg, double *d_out) {
     ATL_REQUIRE(ctx && d_runoff, "atl_runoff_convert: bad argument");
     ATL_REQUIRE(T >= 0 && S >= 0, "atl_runoff_convert: negative shape");
-    RunoffConv c{d_runoff, d_height, S};
-    return run_cells(ctx, c, vec_ok(T, S, {d_runoff}), 0, T, S, time_agg, d_out, "atl_runoff_convert");
+    RunoffConv c{d_runoff, d_height, slot_stride_of(ctx, S)};
+    return run_cells(ctx, c, vec_ok(T, S, slot_stride_of(ctx, S), {d_runoff}), 0, T, S, time_agg, d_out, "atl_runoff_convert");
 }
 
 int atl_runoff_convert_aggregate(atl_ctx *ctx, const double *d_runoff, const double *d_height, int64_t T,
@@ -364,8 +364,8 @@ int atl_runoff_convert_aggregate(atl_ctx *ctx, const double *d_runoff, const dou
                                  int64_t ld_out) {
     ATL_REQUIRE(ctx && d_runoff, "atl_runoff_convert_aggregate: bad argument");
     ATL_REQUIRE(T >= 0 && S >= 0, "atl_runoff_convert_aggregate: negative shape");
-    RunoffConv c{d_runoff, d_height, S};
-    return run_fused(ctx, c, vec_ok(T, S, {d_runoff}), 0, T, S, agg, time_agg, d_out, ld_out,
+    RunoffConv c{d_runoff, d_height, slot_stride_of(ctx, S)};
+    return run_fused(ctx, c, vec_ok(T, S, slot_stride_of(ctx, S), {d_runoff}), 0, T, S, agg, time_agg, d_out, ld_out,
                      "atl_runoff_convert_aggregate");
 }
 

@@ -105,7 +105,7 @@ int atl_pv_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p
     if (pv_tracked(in, p)) return pvk_convert(ctx, in, p, T, S, time_agg, d_out);
     bool vec;
     auto run = [&](auto c) {  // night skip: k_cells_night for the SKIP converters
-        int rc = make_pv(in, p, T, S, &c, &vec);
+        int rc = make_pv(ctx, in, p, T, S, &c, &vec);
         if (rc) return rc;
         return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert", in->X);
     };
@@ -123,7 +123,7 @@ int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv
     if (pv_tracked(in, p)) return pvk_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);
     bool vec;
     auto run = [&](auto c) {
-        int rc = make_pv(in, p, T, S, &c, &vec);
+        int rc = make_pv(ctx, in, p, T, S, &c, &vec);
         if (rc) return rc;
         return run_fused(ctx, c, vec, 0, T, S, agg, time_agg, d_out, ld_out, "atl_pv_convert_aggregate");
     };

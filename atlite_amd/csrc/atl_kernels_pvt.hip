@@ -55,7 +55,7 @@ int pvt_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, i
                 double *d_out) {
     bool vec;
     const int rc = pvt_dispatch(p, [&](auto c) {
-        int rc = make_pv(in, p, T, S, &c, &vec);
+        int rc = make_pv(ctx, in, p, T, S, &c, &vec);
         if (rc) return rc;
         return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert", in->X);
     });
@@ -66,7 +66,7 @@ int pvt_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_pa
                           const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out) {
     bool vec;
     const int rc = pvt_dispatch(p, [&](auto c) {
-        int rc = make_pv(in, p, T, S, &c, &vec);
+        int rc = make_pv(ctx, in, p, T, S, &c, &vec);
         if (rc) return rc;
         return run_fused(ctx, c, vec, 0, T, S, agg, time_agg, d_out, ld_out, "atl_pv_convert_aggregate");
     });

@@ -27,7 +27,7 @@ int pvx_dispatch(const atl_pv_params *p, F &&f) {
 }
 
 template <class PVX>
-int make_pvx(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S, PVX *c, bool *vec) {
+int make_pvx(const atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S, PVX *c, bool *vec) {
     ATL_REQUIRE(in && p, "atl_pv: inputs/params is NULL");
     ATL_REQUIRE(T >= 0 && S >= 0, "atl_pv: negative shape");
     ATL_REQUIRE(p->tracking >= ATL_TRACK_NONE && p->tracking <= ATL_TRACK_DUAL, "atl_pv: bad tracking code %d",
@@ -64,8 +64,10 @@ int make_pvx(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t
     }
     ATL_REQUIRE((p->d_cell_slope == nullptr) == (p->d_cell_azimuth == nullptr),
                 "atl_pv: d_cell_slope and d_cell_azimuth must be given together");
+    const int64_t ld = slot_stride_of(ctx, S);
+    ATL_REQUIRE(ld >= S, "atl_pv: slot stride %lld is smaller than the %lld cells of a slot (atl_set_slot_stride)", (long long)ld, (long long)S);
     c->in = *in;
-    c->S = S;
+    c->S = ld;  // the converter's S is what separates the slots of its cubes
     c->k = pv_const_of(p);
     c->o = pvx_opt_of(p, in->d_influx != nullptr, in->d_albedo != nullptr);
     c->slope = p->slope;
@@ -76,7 +78,7 @@ int make_pvx(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t
     ATL_REQUIRE(!p->orientation_per_time || p->d_cell_slope, "atl_pv: orientation_per_time needs the (T,S) slope / azimuth cubes");
     ATL_REQUIRE(!p->orientation_per_time || p->tracking == ATL_TRACK_NONE,
                 "atl_pv: an orientation that depends on time cannot be combined with a tracker");
-    *vec = vec_ok(T, S, {in->d_influx_direct, in->d_influx_diffuse, in->d_influx, in->d_influx_toa, in->d_albedo,
+    *vec = vec_ok(T, S, ld, {in->d_influx_direct, in->d_influx_diffuse, in->d_influx, in->d_influx_toa, in->d_albedo,
                       in->d_outflux, in->d_temperature, in->d_humidity, in->d_solar_altitude, in->d_solar_azimuth,
                       p->orientation_per_time ? p->d_cell_slope : nullptr, p->orientation_per_time ? p->d_cell_azimuth : nullptr});
     return ATL_OK;
@@ -90,7 +92,7 @@ int pvx_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, i
                 double *d_out) {
     bool vec;
     return pvx_dispatch(p, [&](auto c) {
-        int rc = make_pvx(in, p, T, S, &c, &vec);
+        int rc = make_pvx(ctx, in, p, T, S, &c, &vec);
         if (rc) return rc;
         return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert");
     });
@@ -100,7 +102,7 @@ int pvx_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_pa
                           const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out) {
     bool vec;
     return pvx_dispatch(p, [&](auto c) {
-        int rc = make_pvx(in, p, T, S, &c, &vec);
+        int rc = make_pvx(ctx, in, p, T, S, &c, &vec);
         if (rc) return rc;
         return run_fused(ctx, c, vec, 0, T, S, agg, time_agg, d_out, ld_out, "atl_pv_convert_aggregate");
     });

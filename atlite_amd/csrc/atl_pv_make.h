@@ -4,7 +4,7 @@
 
 // ---- fast family: converter construction + validation (host) -------------------------
 template <class PV>
-int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S, PV *c, bool *vec) {
+int make_pv(const atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S, PV *c, bool *vec) {
     ATL_REQUIRE(in && p, "atl_pv: inputs/params is NULL");
     ATL_REQUIRE(T >= 0 && S >= 0, "atl_pv: negative shape");
     if (in->d_influx) {  // the influx / outflux head (pv_influx_fast)
@@ -27,8 +27,10 @@ int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t 
     }
     ATL_REQUIRE((p->d_cell_slope == nullptr) == (p->d_cell_azimuth == nullptr),
                 "atl_pv: d_cell_slope and d_cell_azimuth must be given together");
+    const int64_t ld = slot_stride_of(ctx, S);
+    ATL_REQUIRE(ld >= S, "atl_pv: slot stride %lld is smaller than the %lld cells of a slot (atl_set_slot_stride)", (long long)ld, (long long)S);
     c->in = *in;
-    c->S = S;
+    c->S = ld;  // the converter's S is what separates the slots of its cubes
     c->k = pv_const_of(p);
     c->o.ss = sin(p->slope);
     c->o.cs = cos(p->slope);
@@ -46,7 +48,7 @@ int make_pv(const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t 
     }
     c->cell_slope = p->d_cell_slope;
     c->cell_azimuth = p->d_cell_azimuth;
-    *vec = vec_ok(T, S, {in->d_influx_direct, in->d_influx_diffuse, in->d_influx_toa, in->d_albedo,
+    *vec = vec_ok(T, S, ld, {in->d_influx_direct, in->d_influx_diffuse, in->d_influx_toa, in->d_albedo,
                       in->d_temperature, in->d_solar_altitude, in->d_solar_azimuth, in->d_influx, in->d_outflux});
     return ATL_OK;
 }

@@ -248,6 +248,30 @@ int atl_download(atl_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     return ATL_OK;
 }
 
+int atl_set_slot_stride(atl_ctx *ctx, int64_t ld_cells) {
+    ATL_REQUIRE(ctx && ld_cells >= 0, "atl_set_slot_stride: bad argument");
+    ctx->slot_stride = ld_cells;
+    return ATL_OK;
+}
+
+int atl_copy_2d(atl_ctx *ctx, void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width, size_t height,
+                int kind, int async_on_copy_stream) {
+    ATL_REQUIRE(ctx && (width == 0 || height == 0 || (dst && src)), "atl_copy_2d: bad argument");
+    ATL_REQUIRE(dst_pitch >= width && src_pitch >= width, "atl_copy_2d: a pitch is smaller than the row width");
+    ATL_REQUIRE(kind >= 0 && kind <= 2, "atl_copy_2d: kind must be 0 (host to device), 1 (device to host) or 2 (device to device)");
+    if (!width || !height) return ATL_OK;
+    ATL_HIP_TRY(hipSetDevice(ctx->device));
+    const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    hipStream_t st = ctx->stream;
+    if (async_on_copy_stream) {
+        int rc = copy_stream_of(ctx, &st);
+        if (rc) return rc;
+    }
+    ATL_HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width, height, k, st));
+    if (!async_on_copy_stream) ATL_HIP_TRY(hipStreamSynchronize(st));
+    return ATL_OK;
+}
+
 int atl_memset(atl_ctx *ctx, void *d_dst, int byte_value, size_t bytes) {
     ATL_REQUIRE(ctx && (bytes == 0 || d_dst), "atl_memset: bad argument");
     if (!bytes) return ATL_OK;
@@ -402,7 +426,7 @@ struct PlanHost {
     std::vector<int64_t> seg_wm;
 };
 
-static int build_plan(int64_t n_rows, int64_t n_cells, int64_t row_len, const int64_t *h_indptr, const int32_t *h_indices,
+static int build_plan(int64_t n_rows, int64_t n_cells, int64_t row_len, int64_t slot_stride, const int64_t *h_indptr, const int32_t *h_indices,
                       const double *h_data, PlanHost *plan) {
     ATL_REQUIRE(n_rows >= 0 && n_cells >= 0, "atl_agg_create: negative shape (%lld, %lld)",
                 (long long)n_rows, (long long)n_cells);
@@ -512,13 +536,14 @@ static int build_plan(int64_t n_rows, int64_t n_cells, int64_t row_len, const in
             // neighbour: +16 / w of the traffic.  Measured (201 x 200, f = 1/2): 16x8 4.65 ms, 32x4 4.02, 64x2 3.72,
             // flat 3.63; (189 x 157, odd S): 16x8 4.43, flat 3.01.  Wide tiles win there.
             static const double row_eff[7] = {0, 0, 0, 1.0, 1.0, 1.05, 1.0};
-            int64_t g = n_cells % 16;  // phases are the multiples of gcd(S % 16, 16)
+            const int64_t stride = slot_stride > 0 ? slot_stride : n_cells;  // cells between slots (atl_set_slot_stride)
+            int64_t g = stride % 16;  // phases are the multiples of gcd(stride % 16, 16)
             for (int64_t b = 16; b != 0;) {
                 const int64_t r = g % b;
                 g = b;
                 b = r;
             }
-            const double f_mis = (n_cells % 16 == 0) ? 0.0 : 1.0 - double(g) / 16.0;
+            const double f_mis = (stride % 16 == 0) ? 0.0 : 1.0 - double(g) / 16.0;
             const int w = 2 << cands[c].w2_log2;
             const double cost = (40.0 * double(tiles) * (1.0 + f_mis * 16.0 / w) + double(P)) * row_eff[cands[c].w2_log2];
             if (c == 0 || cost < best_cost) {
@@ -650,7 +675,7 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_le
     *out = nullptr;
     PlanHost ph;
     {
-        const int brc = build_plan(n_rows, n_cells, row_len, h_indptr, h_indices, h_data, &ph);
+        const int brc = build_plan(n_rows, n_cells, row_len, ctx->slot_stride, h_indptr, h_indices, h_data, &ph);
         if (brc) return brc;
     }
     const std::vector<int32_t> &seg_ptr = ph.seg_ptr, &shape_ptr = ph.shape_ptr, &shape_prow = ph.shape_prow;
@@ -690,7 +715,7 @@ int atl_agg_check_host(int64_t n_rows, int64_t n_cells, int64_t row_len, const i
     ATL_REQUIRE(n_errors, "atl_agg_check_host: n_errors is NULL");
     *n_errors = -1;
     PlanHost ph;
-    const int rc = build_plan(n_rows, n_cells, row_len, h_indptr, h_indices, h_data, &ph);
+    const int rc = build_plan(n_rows, n_cells, row_len, 0, h_indptr, h_indices, h_data, &ph);
     if (rc) return rc;
     int64_t err = 0, dense = 0;
     const Layout L{ph.X, ph.Y, ph.w2_log2};

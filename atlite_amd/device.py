@@ -18,16 +18,29 @@ from ._lib import TIME_MEAN, TIME_NONE, TIME_SUM, check
 _TIME_CODES = {None: TIME_NONE, "sum": TIME_SUM, "mean": TIME_MEAN, "sum_count": _lib.TIME_SUM_COUNT}
 
 
-class DeviceArray:
-    """A C-contiguous array resident in HBM (fp64 unless stated)."""
+def pitch_for(S):
+    """Slot stride (cells) of the library's own device copies of a (T, S) cube: slots padded to a whole 128-byte line
+    when S is not a multiple of 16 cells, so that every slot starts on a line (the kernels own and stream whole lines:
+    DESIGN.md section 3, round 3).  None = contiguous.  ``ATLITE_HIP_PITCH=0`` switches the padding off."""
+    S = int(S)
+    if S % 16 == 0 or S == 0 or os.environ.get("ATLITE_HIP_PITCH", "1") == "0":
+        return None
+    return (S + 15) // 16 * 16
 
-    def __init__(self, ctx, ptr, shape, dtype=np.float64, owner=None, owned=True):
+
+class DeviceArray:
+    """An array resident in HBM (fp64 unless stated): C-contiguous, or - ``ld`` set - a 2-d (T, S) block whose rows
+    lie ``ld`` elements apart (padded slots; only the first ``shape[1]`` elements of a row are data)."""
+
+    def __init__(self, ctx, ptr, shape, dtype=np.float64, owner=None, owned=True, ld=None):
         self.ctx = ctx
         self.ptr = int(ptr)
         self.shape = tuple(int(s) for s in shape)
         self.dtype = np.dtype(dtype)
         self._owner = owner  # keeps a parent allocation (or a torch tensor) alive
         self._owned = owned and owner is None
+        self.ld = None if ld is None or len(self.shape) != 2 or int(ld) == self.shape[1] else int(ld)
+        assert self.ld is None or self.ld > self.shape[1]
 
     @property
     def size(self):
@@ -43,7 +56,11 @@ class DeviceArray:
 
     def numpy(self):
         out = np.empty(self.shape, dtype=self.dtype)
-        if out.size:
+        if out.size and self.ld is not None:
+            es = self.dtype.itemsize
+            check(self.ctx.lib.atl_copy_2d(self.ctx.handle, out.ctypes.data, self.shape[1] * es, self.ptr, self.ld * es,
+                                           self.shape[1] * es, self.shape[0], 1, 0))
+        elif out.size:
             check(self.ctx.lib.atl_download(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))
         return out
 
@@ -55,9 +72,9 @@ class DeviceArray:
         """View of rows [start, stop) along the first axis (no copy)."""
         start, stop = int(start), int(stop)
         assert 0 <= start <= stop <= self.shape[0]
-        row = int(np.prod(self.shape[1:], dtype=np.int64)) * self.dtype.itemsize
+        row = (self.ld if self.ld is not None else int(np.prod(self.shape[1:], dtype=np.int64))) * self.dtype.itemsize
         return DeviceArray(
-            self.ctx, self.ptr + start * row, (stop - start,) + self.shape[1:], self.dtype, owner=self
+            self.ctx, self.ptr + start * row, (stop - start,) + self.shape[1:], self.dtype, owner=self, ld=self.ld
         )
 
     def reshape(self, *shape):
@@ -68,6 +85,10 @@ class DeviceArray:
             known = int(np.prod([v for v in shape if v != -1], dtype=np.int64))
             shape[shape.index(-1)] = self.size // known if known else 0
         assert int(np.prod(shape, dtype=np.int64)) == self.size, (shape, self.shape)
+        if self.ld is not None:
+            if tuple(shape) != self.shape:
+                raise ValueError(f"a pitched (T, S) block cannot be viewed as {tuple(shape)}; download it first")
+            return self
         return DeviceArray(self.ctx, self.ptr, shape, self.dtype, owner=self)
 
     def free(self):
@@ -82,18 +103,21 @@ class DeviceArray:
             pass
 
     def __repr__(self):
-        return f"DeviceArray(shape={self.shape}, dtype={self.dtype}, device={self.ctx.device})"
+        pitch = "" if self.ld is None else f", ld={self.ld}"
+        return f"DeviceArray(shape={self.shape}{pitch}, dtype={self.dtype}, device={self.ctx.device})"
 
 
 class AggPlan:
     """Indicator matrix (scipy CSR, N x S) preprocessed into the segment-local device layout."""
 
-    def __init__(self, ctx, matrix, row_len=None):
+    def __init__(self, ctx, matrix, row_len=None, ld=None):
         import scipy.sparse as sp
 
         m = sp.csr_matrix(matrix)
         self.ctx = ctx
         self.shape = m.shape
+        # the tile shape depends on whether the slots of the cubes the plan will meet start on 128-byte lines
+        check(ctx.lib.atl_set_slot_stride(ctx.handle, int(ld) if ld and int(ld) != m.shape[1] else 0))
         indptr = np.ascontiguousarray(m.indptr, dtype=np.int64)
         indices = np.ascontiguousarray(m.indices, dtype=np.int32)
         data = np.ascontiguousarray(m.data, dtype=np.float64)
@@ -111,6 +135,7 @@ class AggPlan:
             )
         )
         self.handle = h
+        check(ctx.lib.atl_set_slot_stride(ctx.handle, 0))
 
     def info(self):
         v = [C.c_int64() for _ in range(4)] + [C.c_int32(), C.c_int32()]
@@ -159,12 +184,49 @@ class Context:
         check(self.lib.atl_memset(self.handle, a.ptr, 0, a.nbytes))
         return a
 
-    def upload(self, host, dtype=np.float64):
+    def upload(self, host, dtype=np.float64, ld=None):
+        """Host array -> DeviceArray; ``ld`` (2-d arrays): rows ``ld`` elements apart (padded slots, ``pitch_for``)."""
         host = np.ascontiguousarray(host, dtype=dtype)
+        if ld is not None and host.ndim == 2 and int(ld) > host.shape[1]:
+            a = self.empty_pitched(host.shape, int(ld), dtype)
+            es = a.dtype.itemsize
+            check(self.lib.atl_copy_2d(self.handle, a.ptr, a.ld * es, host.ctypes.data, host.shape[1] * es,
+                                       host.shape[1] * es, host.shape[0], 0, 0))
+            return a
         a = self.empty(host.shape, dtype)
         if host.size:
             check(self.lib.atl_upload(self.handle, a.ptr, host.ctypes.data, host.nbytes))
         return a
+
+    def empty_pitched(self, shape, ld, dtype=np.float64):
+        """(T, S) block with rows ``ld`` elements apart; the padding is zeroed (never read as data, but a stray NaN
+        pattern in it would look alarming in a debugger)."""
+        T, S = (int(v) for v in shape)
+        ld = int(ld)
+        assert ld >= S
+        nbytes = max(T * ld, 1) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        check(self.lib.atl_alloc(self.handle, nbytes, C.byref(p)))
+        if ld > S:
+            check(self.lib.atl_memset(self.handle, p.value, 0, nbytes))
+        return DeviceArray(self, p.value, (T, S), dtype, ld=ld)
+
+    def _stride(self, S, *arrays):
+        """Tell the context how far apart the slots of this call's (T, S) input cubes are: every 2-d input must have
+        the same layout (all contiguous, or all padded to the same ``ld``)."""
+        lds = {(a.ld if a.ld is not None else int(S)) for a in arrays
+               if isinstance(a, DeviceArray) and a.ndim == 2 and a.shape[1] == int(S)}
+        if len(lds) > 1:
+            raise ValueError(f"the input cubes of one call mix slot strides {sorted(lds)}: upload them the same way "
+                             "(Dataset.device pads every cube of a dataset alike; ATLITE_HIP_PITCH=0 switches padding off)")
+        ld = lds.pop() if lds else int(S)
+        check(self.lib.atl_set_slot_stride(self.handle, 0 if ld == int(S) else ld))
+        return ld
+
+    def _unstride(self):
+        """The stride is call-scoped: outside a conversion call the context reads contiguous cubes (the slab pipeline's
+        buffers, atl_nc_read_slab into them)."""
+        check(self.lib.atl_set_slot_stride(self.handle, 0))
 
     def asdevice(self, x, dtype=np.float64):
         """DeviceArray as is; torch CUDA tensor zero-copy; anything else is uploaded."""
@@ -223,7 +285,7 @@ class Context:
         return ms.value
 
     # -- plans ----------------------------------------------------------------------------
-    def plan(self, matrix, row_len=None, cache=True):
+    def plan(self, matrix, row_len=None, cache=True, ld=None):
         """
         Aggregation plan of a (N x S) matrix; row_len = X of the (Y, X) grid lets the plan use compact
         2-d cell tiles.  Plans are cached per context by matrix content (8 most recent), so repeated
@@ -231,7 +293,7 @@ class Context:
         the context (do not close them).
         """
         if not cache:
-            return AggPlan(self, matrix, row_len=row_len)
+            return AggPlan(self, matrix, row_len=row_len, ld=ld)
         import scipy.sparse as sp
 
         m = sp.csr_matrix(matrix)
@@ -246,12 +308,12 @@ class Context:
         for a in (m.indptr, m.indices, m.data):
             h.update(np.ascontiguousarray(a).view(np.uint8))
         key = (m.shape, int(row_len or 0), m.indptr.dtype.str, m.indices.dtype.str, h.hexdigest(),
-               os.environ.get("ATLITE_HIP_TILE", ""))
+               os.environ.get("ATLITE_HIP_TILE", ""), int(ld or 0))
         cache_ = self.__dict__.setdefault("_plan_cache", {})
         if key in cache_:
             cache_[key] = cache_.pop(key)  # most recently used last
             return cache_[key]
-        plan = AggPlan(self, m, row_len=row_len)
+        plan = AggPlan(self, m, row_len=row_len, ld=ld)
         cache_[key] = plan
         while len(cache_) > 8:
             cache_.pop(next(iter(cache_))).close()
@@ -273,8 +335,12 @@ class Context:
 
     def spmm(self, plan, dense, time_agg=None, out=None):
         T, S = dense.shape
-        res, optr, ld = self._out(plan, T, S, time_agg, out)
-        check(self.lib.atl_spmm_csr(self.handle, plan.handle, dense.ptr, T, S, _TIME_CODES[time_agg], optr, ld))
+        self._stride(S, dense)
+        try:
+            res, optr, ld = self._out(plan, T, S, time_agg, out)
+            check(self.lib.atl_spmm_csr(self.handle, plan.handle, dense.ptr, T, S, _TIME_CODES[time_agg], optr, ld))
+        finally:
+            self._unstride()
         return res
 
     def pv(self, inputs: dict, params: dict, T, S, plan=None, time_agg=None, solar_tables=None, options=None,
@@ -337,19 +403,26 @@ class Context:
             if isinstance(slope, DeviceArray) and isinstance(azimuth, DeviceArray):
                 ds, da = slope, azimuth
             else:
-                ds = self.upload(np.ascontiguousarray(np.broadcast_to(np.asarray(slope, dtype=np.float64), shape)))
-                da = self.upload(np.ascontiguousarray(np.broadcast_to(np.asarray(azimuth, dtype=np.float64), shape)))
+                # an orientation cube is an input cube like the others: the same slot padding
+                in_ld = next((v.ld for v in inputs.values() if isinstance(v, DeviceArray) and v.ndim == 2 and v.ld), None)
+                ld_o = in_ld if per_time else None
+                ds = self.upload(np.ascontiguousarray(np.broadcast_to(np.asarray(slope, dtype=np.float64), shape)), ld=ld_o)
+                da = self.upload(np.ascontiguousarray(np.broadcast_to(np.asarray(azimuth, dtype=np.float64), shape)), ld=ld_o)
                 keep += [ds, da]
             if tuple(ds.shape) != shape or tuple(da.shape) != shape:
                 raise ValueError(f"orientation arrays must have shape {shape}, got {tuple(ds.shape)} / {tuple(da.shape)}")
             pp.d_cell_slope, pp.d_cell_azimuth = ds.ptr, da.ptr
             pp.orientation_per_time = 1 if per_time else 0
-        res, optr, ld = self._out(plan, T, S, time_agg, out)
-        if plan is None:
-            check(self.lib.atl_pv_convert(self.handle, C.byref(pin), C.byref(pp), T, S, _TIME_CODES[time_agg], optr))
-        else:
-            check(self.lib.atl_pv_convert_aggregate(self.handle, C.byref(pin), C.byref(pp), T, S, plan.handle,
-                                                    _TIME_CODES[time_agg], optr, ld))
+        self._stride(S, *[v for v in inputs.values() if v is not None], *([ds, da] if pp.orientation_per_time else []))
+        try:
+            res, optr, ld = self._out(plan, T, S, time_agg, out)
+            if plan is None:
+                check(self.lib.atl_pv_convert(self.handle, C.byref(pin), C.byref(pp), T, S, _TIME_CODES[time_agg], optr))
+            else:
+                check(self.lib.atl_pv_convert_aggregate(self.handle, C.byref(pin), C.byref(pp), T, S, plan.handle,
+                                                        _TIME_CODES[time_agg], optr, ld))
+        finally:
+            self._unstride()
         if keep:
             self.sync()  # temporaries uploaded for this call must outlive the kernels
         return res
@@ -369,24 +442,32 @@ class Context:
             V.ctypes.data_as(_lib.c_double_p),
             POWn.ctypes.data_as(_lib.c_double_p),
         )
-        res, optr, ld = self._out(plan, T, S, time_agg, out)
-        if plan is None:
-            check(self.lib.atl_wind_convert(self.handle, C.byref(win), C.byref(wp), T, S, _TIME_CODES[time_agg], optr))
-        else:
-            check(self.lib.atl_wind_convert_aggregate(self.handle, C.byref(win), C.byref(wp), T, S, plan.handle,
-                                                      _TIME_CODES[time_agg], optr, ld))
+        self._stride(S, wnd, aux)
+        try:
+            res, optr, ld = self._out(plan, T, S, time_agg, out)
+            if plan is None:
+                check(self.lib.atl_wind_convert(self.handle, C.byref(win), C.byref(wp), T, S, _TIME_CODES[time_agg], optr))
+            else:
+                check(self.lib.atl_wind_convert_aggregate(self.handle, C.byref(win), C.byref(wp), T, S, plan.handle,
+                                                          _TIME_CODES[time_agg], optr, ld))
+        finally:
+            self._unstride()
         return res
 
     def thermo(self, var, T, S, offset=-273.15, fillna0=False, cop=None, plan=None, time_agg=None, out=None):
         """temperature family (var + offset [, fillna 0]) and, with cop=(sink_T, c0, c1, c2), the COP."""
         tp = _lib.ThermoParams(float(offset), 1 if fillna0 else 0, 0 if cop is None else 1,
                                *(map(float, cop) if cop is not None else (0.0, 0.0, 0.0, 0.0)))
-        res, optr, ld = self._out(plan, T, S, time_agg, out)
-        if plan is None:
-            check(self.lib.atl_thermo_convert(self.handle, var.ptr, C.byref(tp), T, S, _TIME_CODES[time_agg], optr))
-        else:
-            check(self.lib.atl_thermo_convert_aggregate(self.handle, var.ptr, C.byref(tp), T, S, plan.handle,
-                                                        _TIME_CODES[time_agg], optr, ld))
+        self._stride(S, var)
+        try:
+            res, optr, ld = self._out(plan, T, S, time_agg, out)
+            if plan is None:
+                check(self.lib.atl_thermo_convert(self.handle, var.ptr, C.byref(tp), T, S, _TIME_CODES[time_agg], optr))
+            else:
+                check(self.lib.atl_thermo_convert_aggregate(self.handle, var.ptr, C.byref(tp), T, S, plan.handle,
+                                                            _TIME_CODES[time_agg], optr, ld))
+        finally:
+            self._unstride()
         return res
 
     def heat_demand(self, temperature, day_ptr, threshold_K, a, constant, T, S, plan=None, time_agg=None,
@@ -400,25 +481,33 @@ class Context:
             assert D >= 0 and day_ptr[0] >= 0 and day_ptr[-1] <= T and np.all(np.diff(day_ptr) >= 0)
             d_ptr, fresh = self.upload(day_ptr, np.int64), True
         hp = _lib.HeatParams(float(threshold_K), float(a), float(constant), D, d_ptr.ptr, 1 if cooling else 0)
-        res, optr, ld = self._out(plan, D, S, time_agg, out)
-        if plan is None:
-            check(self.lib.atl_heat_demand_convert(self.handle, temperature.ptr, C.byref(hp), T, S,
-                                                   _TIME_CODES[time_agg], optr))
-        else:
-            check(self.lib.atl_heat_demand_convert_aggregate(self.handle, temperature.ptr, C.byref(hp), T, S,
-                                                             plan.handle, _TIME_CODES[time_agg], optr, ld))
+        self._stride(S, temperature)
+        try:
+            res, optr, ld = self._out(plan, D, S, time_agg, out)
+            if plan is None:
+                check(self.lib.atl_heat_demand_convert(self.handle, temperature.ptr, C.byref(hp), T, S,
+                                                       _TIME_CODES[time_agg], optr))
+            else:
+                check(self.lib.atl_heat_demand_convert_aggregate(self.handle, temperature.ptr, C.byref(hp), T, S,
+                                                                 plan.handle, _TIME_CODES[time_agg], optr, ld))
+        finally:
+            self._unstride()
         if fresh:
             self.sync()  # d_ptr must outlive the kernels
         return res
 
     def runoff(self, runoff, height, T, S, plan=None, time_agg=None, out=None):
-        res, optr, ld = self._out(plan, T, S, time_agg, out)
-        hptr = height.ptr if height is not None else None
-        if plan is None:
-            check(self.lib.atl_runoff_convert(self.handle, runoff.ptr, hptr, T, S, _TIME_CODES[time_agg], optr))
-        else:
-            check(self.lib.atl_runoff_convert_aggregate(self.handle, runoff.ptr, hptr, T, S, plan.handle,
-                                                        _TIME_CODES[time_agg], optr, ld))
+        self._stride(S, runoff)
+        try:
+            res, optr, ld = self._out(plan, T, S, time_agg, out)
+            hptr = height.ptr if height is not None else None
+            if plan is None:
+                check(self.lib.atl_runoff_convert(self.handle, runoff.ptr, hptr, T, S, _TIME_CODES[time_agg], optr))
+            else:
+                check(self.lib.atl_runoff_convert_aggregate(self.handle, runoff.ptr, hptr, T, S, plan.handle,
+                                                            _TIME_CODES[time_agg], optr, ld))
+        finally:
+            self._unstride()
         return res
 
     # -- synthetic fields -------------------------------------------------------------------

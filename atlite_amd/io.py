@@ -189,16 +189,25 @@ class FileArray:
     def read_slab(self, ctx, t0, t1, dptr):
         self.file.read_slab(ctx, self.name, self.row0 + t0, t1 - t0, dptr)
 
-    def to_device(self, ctx, block_bytes=256 << 20):
-        """Whole variable as a DeviceArray (rows in blocks so that the pinned staging stays bounded)."""
-        out = ctx.empty(self.shape)
+    def to_device(self, ctx, block_bytes=256 << 20, ld=None):
+        """Whole variable as a DeviceArray (rows in blocks so that the pinned staging stays bounded); ``ld``: a
+        (time, y, x) variable as a (T, S) block with slots ``ld`` cells apart (``device.pitch_for``)."""
+        from ._lib import check
+
         row = max(int(np.prod(self.shape[1:], dtype=np.int64)), 1)
+        pitched = ld is not None and len(self.shape) == 3 and int(ld) > row
+        out = ctx.empty_pitched((self.shape[0], row), int(ld)) if pitched else ctx.empty(self.shape)
+        stride = int(ld) if pitched else row
         step = max(1, block_bytes // (row * 8))
         if self.var.layout == "chunked":
             step = max(self.var.chunks[0], step // self.var.chunks[0] * self.var.chunks[0])
-        for t0 in range(0, self.shape[0], step):
-            t1 = min(self.shape[0], t0 + step)
-            self.read_slab(ctx, t0, t1, out.ptr + t0 * row * 8)
+        check(ctx.lib.atl_set_slot_stride(ctx.handle, stride if pitched else 0))  # where atl_nc_read_slab puts the rows
+        try:
+            for t0 in range(0, self.shape[0], step):
+                t1 = min(self.shape[0], t0 + step)
+                self.read_slab(ctx, t0, t1, out.ptr + t0 * stride * 8)
+        finally:
+            check(ctx.lib.atl_set_slot_stride(ctx.handle, 0))
         ctx.copy_barrier()
         return out
 

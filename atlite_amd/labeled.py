@@ -440,12 +440,35 @@ class Dataset:
         """DeviceArray of variable ``name`` flattened to (T, S) or (S,); uploads host data once."""
         la = self._vars[name]
         if name not in self._device_cache or self._device_cache[name].ctx is not ctx:
-            d = ctx.asdevice(la.data)
-            self._device_cache[name] = d
+            self._device_cache[name] = self._to_device(ctx, la)
         d = self._device_cache[name]
         if la.dims == ("time", "y", "x"):
             return d.reshape(d.shape[0], -1) if d.ndim == 3 else d
         return d.reshape(-1)
+
+    def _slot_stride(self):
+        """Cells between the slots of the device copies this dataset makes of its (time, y, x) variables: padded to a
+        128-byte line when the cell count is not a multiple of 16 (``device.pitch_for``) - unless a variable already
+        lives on a device in the caller's own (contiguous) layout, which every cube of a call must then share."""
+        from .device import pitch_for
+
+        if any(la.dims == ("time", "y", "x") and (_is_device(la.data) or (type(la.data).__module__.startswith("torch")
+                                                                         and getattr(la.data, "is_cuda", False)))
+               for la in self._vars.values()):
+            return None
+        return pitch_for(len(self.coords["y"]) * len(self.coords["x"]))
+
+    def _to_device(self, ctx, la):
+        ld = self._slot_stride() if la.dims == ("time", "y", "x") else None
+        x = la.data
+        if ld is None or _is_device(x):
+            return ctx.asdevice(x)
+        T = x.shape[0]
+        if getattr(x, "is_file_array", False):  # inflate + decode straight into the padded rows
+            return x.to_device(ctx, ld=ld)
+        if type(x).__module__.startswith("torch") and hasattr(x, "data_ptr"):
+            x = x.numpy()
+        return ctx.upload(np.asarray(x).reshape(T, -1), ld=ld)
 
     def __repr__(self):
         return f"<Dataset {self.sizes} vars={list(self._vars)} chunked={self.chunked}>"

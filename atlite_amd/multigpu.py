@@ -217,7 +217,7 @@ class DeviceGroup:
             ctx, sub_ds = self.ctxs[r], shards[r]
             self._localize(sub_ds, ctx, names)
             sub = copy.copy(spec.for_slab(edges[r], edges[r + 1]))
-            plan = ctx.plan(matrix, row_len=row_len) if matrix is not None else None
+            plan = ctx.plan(matrix, row_len=row_len, ld=getattr(sub_ds, "_slot_stride", lambda: None)()) if matrix is not None else None
             if edges[r + 1] == edges[r]:
                 return None
             if per_cell_reduce:

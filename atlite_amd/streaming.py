@@ -123,7 +123,15 @@ def run(ctx, spec, ds, plan, time_agg):
     static = {n: ds.device(ctx, n) for n in getattr(spec, "static_vars", ())}
     spec.prepare(ctx, ds)
     max_len = max((b - a for a, b in edges), default=0)
-    bufs = [{n: ctx.empty((max(max_len, 1), S)) for n in host} for _ in range(2)]
+    # slots padded to a 128-byte line when S is not a multiple of 16 cells (device.pitch_for) - the kernels then read
+    # whole lines; narrow host dtypes are widened by a 1-d device pass and keep contiguous slabs
+    from .device import pitch_for
+
+    ld = pitch_for(S)
+    if ld is not None and any(not _is_file(a) and a.dtype != np.float64 for a in host.values()):
+        ld = None
+    bufs = [{n: (ctx.empty_pitched((max(max_len, 1), S), ld) if ld else ctx.empty((max(max_len, 1), S))) for n in host}
+            for _ in range(2)]
     ev_ready, ev_done = [], []
     for _ in range(2):
         for lst in (ev_ready, ev_done):
@@ -144,10 +152,16 @@ def run(ctx, spec, ds, plan, time_agg):
                 check(lib.atl_stream_wait_event(ctx.handle, COPY, ev_done[b]))
             for n, a in host.items():
                 if _is_file(a):
-                    a.read_slab(ctx, t0, t1, bufs[b][n].ptr)
+                    check(lib.atl_set_slot_stride(ctx.handle, ld or 0))  # where atl_nc_read_slab puts the rows
+                    try:
+                        a.read_slab(ctx, t0, t1, bufs[b][n].ptr)
+                    finally:
+                        check(lib.atl_set_slot_stride(ctx.handle, 0))
                     continue
                 blk = a[t0:t1]
-                if a.dtype == np.float64:
+                if a.dtype == np.float64 and ld:
+                    check(lib.atl_copy_2d(ctx.handle, bufs[b][n].ptr, ld * 8, blk.ctypes.data, S * 8, S * 8, t1 - t0, 0, 1))
+                elif a.dtype == np.float64:
                     check(lib.atl_upload_async(ctx.handle, bufs[b][n].ptr, blk.ctypes.data, blk.nbytes))
                 else:
                     check(lib.atl_upload_convert_async(ctx.handle, bufs[b][n].ptr, blk.ctypes.data,

@@ -70,6 +70,17 @@ int atl_free(atl_ctx *ctx, void *d_ptr);
 int atl_upload(atl_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /* blocking */
 int atl_download(atl_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* blocking */
 int atl_memset(atl_ctx *ctx, void *d_dst, int byte_value, size_t bytes);
+/* Pitched cubes.  The kernels stream whole 128-byte lines and own them by position, so a (T, S) cube is read fastest when
+ * every slot starts on a line: S % 16 == 0, or slots PADDED to a multiple of 16 cells.  atl_set_slot_stride(ctx, ld) tells
+ * the context that the (T, S) INPUT cubes of the following calls (conversions, atl_spmm_csr, atl_agg_create's tile
+ * choice, atl_nc_read_slab's output) have their slots ld cells apart (ld >= S; 0 = contiguous again); per-cell static
+ * arrays, tables and every result stay contiguous.  atl_copy_2d moves pitched blocks (kind 0 host -> device, 1 device ->
+ * host, 2 device -> device; blocking on the compute stream, or enqueued on the copy stream).  The Python layer pads its
+ * own device copies of a cutout this way (atlite_amd.labeled.Dataset.device); the reference has no counterpart - numpy
+ * arrays are contiguous (atlite/convert.py:198). */
+int atl_set_slot_stride(atl_ctx *ctx, int64_t ld_cells);
+int atl_copy_2d(atl_ctx *ctx, void *dst, size_t dst_pitch_bytes, const void *src, size_t src_pitch_bytes,
+                size_t width_bytes, size_t height, int kind, int async_on_copy_stream);
 
 /* ---- host-resident cutouts: overlap H2D with compute -------------------------------------------
  * A context owns a second (copy) stream.  atl_upload_async enqueues on it; events order the

@@ -100,3 +100,81 @@ def test_a_cube_that_ends_on_a_page_boundary_is_not_read_past(ctx):
     M = sp.csr_matrix(np.ones((1, S)))
     agg = ctx.runoff(ctx.upload(ro), ctx.upload(h), T, S, plan=ctx.plan(M, row_len=X)).numpy()
     np.testing.assert_allclose(agg[0], (ro * h[None, :]).sum(axis=1), rtol=1e-13)
+
+
+# ---- padded slots: the library's own device copies of a cutout ---------------------------------------------------
+def test_padded_device_copies_round_trip_and_layout(ctx):
+    from atlite_amd.device import pitch_for
+
+    assert pitch_for(40000) is None and pitch_for(29673) == 29680 and pitch_for(17) == 32
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=(13, 37))
+    d = ctx.upload(a, ld=pitch_for(37))
+    assert d.ld == 48 and d.shape == (13, 37)
+    np.testing.assert_array_equal(d.numpy(), a)
+    np.testing.assert_array_equal(d.slab(3, 9).numpy(), a[3:9])
+    assert d.slab(3, 9).ld == 48 and d.reshape(13, 37) is d
+    with pytest.raises(ValueError, match="pitched"):
+        d.reshape(37, 13)
+    assert ctx.upload(rng.normal(size=(4, 32)), ld=32).ld is None  # nothing to pad
+
+
+@pytest.mark.parametrize("T,Y,X", [(40, 9, 27), (50, 13, 31)])
+def test_api_results_with_padded_slots_equal_contiguous_ones(monkeypatch, T, Y, X):
+    """Cutout.pv / wind / heat_demand / runoff on host arrays: Dataset.device() pads the slots of its device copies when
+    Y * X is not a multiple of 16; per-cell results carry the same bits as with ATLITE_HIP_PITCH=0, aggregated ones
+    agree to rounding (the plan picks another tile shape, so shapes sum their cells in another order)."""
+    import pandas as pd
+
+    from atlite_amd import Cutout, Dataset
+
+    x, y = H.grid(Y, X)
+    t = pd.date_range("2013-03-01", periods=T, freq="h")
+    ds = H.pv_dataset(T, Y, X, seed=3)
+    w = H.wind_dataset(T, Y, X, seed=4)
+    rng = np.random.default_rng(5)
+    data = {k: v.reshape(T, Y, X) for k, v in {**ds, **w}.items()}
+    data["runoff"] = rng.random((T, Y, X))
+    data["height"] = rng.random((Y, X)) * 500.0
+    M = H.blob_matrix(4, Y, X, seed=6)
+
+    def run():
+        c = Cutout(Dataset(dict(data), dict(time=t, y=y, x=x)))
+        kw = dict(panel="CSi", orientation={"slope": 30.0, "azimuth": 180.0})
+        out = dict(
+            pv_cells=c.pv(aggregate_time=None, **kw).values, pv_agg=c.pv(matrix=M, aggregate_time=None, **kw).values,
+            pv_map=c.pv(aggregate_time="mean", **kw).values,
+            wind_cells=c.wind(turbine="Vestas_V112_3MW", aggregate_time=None).values,
+            wind_agg=c.wind(turbine="Vestas_V112_3MW", matrix=M, aggregate_time=None).values,
+            heat=c.heat_demand(matrix=M, aggregate_time=None).values, runoff=c.runoff(matrix=M, aggregate_time=None).values,
+            runoff_cells=c.runoff(aggregate_time="sum").values)
+        lds = {v.ld for v in c.data._device_cache.values() if tuple(v.shape) == (T, Y * X)}  # the (time, cell) cubes
+        return out, lds
+
+    monkeypatch.delenv("ATLITE_HIP_PITCH", raising=False)
+    padded, lds = run()
+    assert lds == {(Y * X + 15) // 16 * 16}
+    monkeypatch.setenv("ATLITE_HIP_PITCH", "0")
+    plain, lds0 = run()
+    assert lds0 == {None}
+    for k in padded:
+        if k.endswith("_agg") or k in ("heat", "runoff"):
+            np.testing.assert_allclose(padded[k], plain[k], rtol=1e-12, atol=1e-13 * np.abs(plain[k]).max(), err_msg=k)
+        else:
+            np.testing.assert_array_equal(padded[k], plain[k], err_msg=k)
+    cells = orc.convert_pv(ds, H.CSI, ORI)
+    close(padded["pv_cells"].reshape(T, -1), cells)
+    close(padded["pv_agg"], orc.aggregate_matrix(cells, M))
+
+
+def test_cubes_of_one_call_must_share_their_layout(ctx):
+    T, Y, X = 12, 5, 7
+    S = Y * X
+    w = H.wind_dataset(T, Y, X, seed=1)
+    V = np.array([0.0, 3.0, 12.0, 25.0, 25.0])
+    P = np.array([0.0, 0.0, 1.0, 1.0, 0.0])
+    with pytest.raises(ValueError, match="mix slot strides"):
+        ctx.wind(ctx.upload(w["wnd100m"], ld=48), ctx.upload(w["roughness"]), V, P, 80.0, 100.0, "logarithmic", T, S)
+    ok = ctx.wind(ctx.upload(w["wnd100m"], ld=48), ctx.upload(w["roughness"], ld=48), V, P, 80.0, 100.0, "logarithmic", T, S).numpy()
+    ref = ctx.wind(ctx.upload(w["wnd100m"]), ctx.upload(w["roughness"]), V, P, 80.0, 100.0, "logarithmic", T, S).numpy()
+    np.testing.assert_array_equal(ok, ref)
