@@ -61,8 +61,10 @@ __global__ __launch_bounds__(256) void k_cells_series(Conv conv, int64_t n_slots
         for (int g = 0; g < G; ++g) raw[g] = conv.template load<VEC>(min(sg + g, s1 - 1), g, s0c, s1c, cell, carry);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            // lanes without a cell loaded a real cell's data (safe indices) and are masked by the store
-            const double2 r = conv.compute(raw[g], true, true, cell, lds);
+            // lanes without a cell loaded a real cell's data (safe indices) and are masked by the store; the converter is
+            // told which of the pair's cells exist, so that what lies beside the last cell (the next slot, slot padding)
+            // cannot steer the pair onto a converter's rare path
+            const double2 r = conv.compute(raw[g], v0, v1, cell, lds);
             if (sg + g < s1) st2<VEC>(out, (sg + g) * S + c0, v0, v1, r);
         }
     }
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void k_cells_timered(Conv conv, int64_t n_slot
         for (int g = 0; g < G; ++g) raw[g] = conv.template load<VEC>(min(sg + g, s1 - 1), g, s0c, s1c, cell, carry);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const double2 r = conv.compute(raw[g], true, true, cell, lds);  // masked when psum / pcnt are stored
+            const double2 r = conv.compute(raw[g], v0, v1, cell, lds);  // (invalid cells: masked when psum / pcnt are stored)
             const bool live = sg + g < s1;
             if (live && !dnan(r.x)) {
                 acc.x += r.x;
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256, conv_min_waves_cells<Conv>::value) void k_cell
                 double2 r = {0.0, 0.0};
                 if ((day >> i) & 1u) {  // wave-uniform
                     const typename Conv::Raw A = conv.template rest_load<VEC>(sb + i, s0c, s1c, cell);
-                    r = conv.compute_keyed(A, *reinterpret_cast<const double2 *>(vl + i * kSegCells), true, true, cell, lds);
+                    r = conv.compute_keyed(A, *reinterpret_cast<const double2 *>(vl + i * kSegCells), v0, v1, cell, lds);
                 }
                 st2<VEC>(out_a, (sb + i) * S + c0, v0, v1, r);
             }
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256, conv_min_waves_cells<Conv>::value) void k_cell
                 const int i = __builtin_ctz(m);
                 m &= m - 1;
                 const typename Conv::Raw A = conv.template rest_load<VEC>(sb + i, s0c, s1c, cell);
-                const double2 r = conv.compute_keyed(A, *reinterpret_cast<const double2 *>(vl + i * kSegCells), true, true, cell, lds);
+                const double2 r = conv.compute_keyed(A, *reinterpret_cast<const double2 *>(vl + i * kSegCells), v0, v1, cell, lds);
                 if (!dnan(r.x)) {
                     acc.x += r.x;
                     ++cnt0;

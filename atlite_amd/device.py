@@ -223,6 +223,14 @@ class Context:
         check(self.lib.atl_set_slot_stride(self.handle, 0 if ld == int(S) else ld))
         return ld
 
+    def _relayout(self, a, ld):
+        """Device copy of the (T, S) block ``a`` with slots ``ld`` elements apart (None: contiguous)."""
+        T, S = a.shape
+        out = self.empty_pitched((T, S), ld) if ld else self.empty((T, S))
+        es = a.dtype.itemsize
+        check(self.lib.atl_copy_2d(self.handle, out.ptr, (ld or S) * es, a.ptr, (a.ld or S) * es, S * es, T, 2, 0))
+        return out
+
     def _unstride(self):
         """The stride is call-scoped: outside a conversion call the context reads contiguous cubes (the slab pipeline's
         buffers, atl_nc_read_slab into them)."""
@@ -400,11 +408,14 @@ class Context:
             # one pair per cell (S,) or - an orientation that follows the sun - per cell and time step (T, S)
             per_time = any(len(getattr(v, "shape", ())) == 2 for v in (slope, azimuth))
             shape = (T, S) if per_time else (S,)
+            # an orientation cube is an input cube like the others: the same slot padding
+            in_ld = next((v.ld for v in inputs.values() if isinstance(v, DeviceArray) and v.ndim == 2 and v.ld), None)
             if isinstance(slope, DeviceArray) and isinstance(azimuth, DeviceArray):
                 ds, da = slope, azimuth
+                if per_time and (ds.ld != in_ld or da.ld != in_ld):  # uploaded before the inputs' layout was known
+                    ds, da = self._relayout(ds, in_ld), self._relayout(da, in_ld)
+                    keep += [ds, da]
             else:
-                # an orientation cube is an input cube like the others: the same slot padding
-                in_ld = next((v.ld for v in inputs.values() if isinstance(v, DeviceArray) and v.ndim == 2 and v.ld), None)
                 ld_o = in_ld if per_time else None
                 ds = self.upload(np.ascontiguousarray(np.broadcast_to(np.asarray(slope, dtype=np.float64), shape)), ld=ld_o)
                 da = self.upload(np.ascontiguousarray(np.broadcast_to(np.asarray(azimuth, dtype=np.float64), shape)), ld=ld_o)
