@@ -228,6 +228,7 @@ SIGNATURES = {
     "atl_nc_read_host": (_i, [_vp, C.c_char_p, _i64, _i64, _vp]),
     "atl_nc_read_slab": (_i, [_vp, _vp, C.c_char_p, _i64, _i64, _vp, _i]),
     "atl_upload_convert_async": (_i, [_vp, _vp, _vp, _i, _i64]),
+    "atl_upload_convert_2d_async": (_i, [_vp, _vp, _i64, _vp, _i, _i64, _i64]),
     "atl_inflate_probe": (_i, [_vp, _sz, _vp, _sz, _i, C.POINTER(_i64)]),
     "atl_comm_unique_id": (_i, [_vp]),
     "atl_comm_init": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),

@@ -808,7 +808,13 @@ int atl_inflate_probe(const void *h_src, size_t src_n, void *h_dst, size_t dst_n
 }
 
 int atl_upload_convert_async(atl_ctx *ctx, double *d_dst, const void *h_src, int dtype, int64_t n) {
-    ATL_REQUIRE(ctx && n >= 0, "atl_upload_convert_async: bad argument");
+    return atl_upload_convert_2d_async(ctx, d_dst, 1, h_src, dtype, n, 1);
+}
+
+int atl_upload_convert_2d_async(atl_ctx *ctx, double *d_dst, int64_t ld_cells, const void *h_src, int dtype, int64_t rows,
+                                int64_t cols) {
+    ATL_REQUIRE(ctx && rows >= 0 && cols >= 0 && ld_cells >= cols, "atl_upload_convert_async: bad argument");
+    const int64_t n = rows * cols;
     if (n == 0) return ATL_OK;
     ATL_REQUIRE(d_dst && h_src, "atl_upload_convert_async: NULL buffer");
     const int es = dtype_size(dtype);
@@ -833,18 +839,18 @@ int atl_upload_convert_async(atl_ctx *ctx, double *d_dst, const void *h_src, int
         });
         if (rc) return rc;
     }
-    UnpackParams p{};
+    UnpackParams p{};  // a (rows, 1, cols) variable in one "chunk": element (r, 0, c) goes to d_dst[r * ld + c]
     p.shape1 = 1;
-    p.shape2 = 1;
-    p.ld = 1;
+    p.shape2 = cols;
+    p.ld = ld_cells;
     p.r0 = 0;
-    p.r1 = n;
+    p.r1 = rows;
     p.dec.dtype = dtype;
     p.dec.esize = es;
     UnpackDesc ds{};
-    ds.dim[0] = n;
+    ds.dim[0] = rows;
     ds.dim[1] = 1;
-    ds.dim[2] = 1;
+    ds.dim[2] = cols;
     std::vector<UnpackDesc> descs{ds};
     return submit(ctx, sl, payload, descs, p, n, d_dst, pinned ? h_src : nullptr);
 }

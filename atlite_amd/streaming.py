@@ -124,12 +124,10 @@ def run(ctx, spec, ds, plan, time_agg):
     spec.prepare(ctx, ds)
     max_len = max((b - a for a, b in edges), default=0)
     # slots padded to a 128-byte line when S is not a multiple of 16 cells (device.pitch_for) - the kernels then read
-    # whole lines; narrow host dtypes are widened by a 1-d device pass and keep contiguous slabs
+    # whole lines
     from .device import pitch_for
 
     ld = pitch_for(S)
-    if ld is not None and any(not _is_file(a) and a.dtype != np.float64 for a in host.values()):
-        ld = None
     bufs = [{n: (ctx.empty_pitched((max(max_len, 1), S), ld) if ld else ctx.empty((max(max_len, 1), S))) for n in host}
             for _ in range(2)]
     ev_ready, ev_done = [], []
@@ -163,6 +161,9 @@ def run(ctx, spec, ds, plan, time_agg):
                     check(lib.atl_copy_2d(ctx.handle, bufs[b][n].ptr, ld * 8, blk.ctypes.data, S * 8, S * 8, t1 - t0, 0, 1))
                 elif a.dtype == np.float64:
                     check(lib.atl_upload_async(ctx.handle, bufs[b][n].ptr, blk.ctypes.data, blk.nbytes))
+                elif ld:
+                    check(lib.atl_upload_convert_2d_async(ctx.handle, bufs[b][n].ptr, ld, blk.ctypes.data,
+                                                          NC_CODES[a.dtype.name], t1 - t0, S))
                 else:
                     check(lib.atl_upload_convert_async(ctx.handle, bufs[b][n].ptr, blk.ctypes.data,
                                                        NC_CODES[a.dtype.name], blk.size))

@@ -412,6 +412,9 @@ int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, 
 /* host array of a narrower dtype (what xarray hands over for a float32 cutout) -> fp64 on the
  * device through the same staging + decode kernel; halves the PCIe bytes of atl_upload_async */
 int atl_upload_convert_async(atl_ctx *ctx, double *d_dst, const void *h_src, int dtype, int64_t n);
+/* the same for a (rows, cols) host block into device rows ld_cells doubles apart (padded slots, atl_set_slot_stride) */
+int atl_upload_convert_2d_async(atl_ctx *ctx, double *d_dst, int64_t ld_cells, const void *h_src, int dtype,
+                                int64_t rows, int64_t cols);
 
 /* ---- multi-GPU (RCCL over xGMI) ------------------------------------------------------------------
  * One process (and one atl_ctx) per GPU, the TIME axis sharded: rank r converts and aggregates its

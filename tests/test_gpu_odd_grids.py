@@ -180,3 +180,34 @@ def test_cubes_of_one_call_must_share_their_layout(ctx):
     # (bit for bit, the last cell included: the per-cell kernels tell the converter that the pad cell beside it does not
     # exist, so its zeros cannot send the pair through the wind converter's literal routine)
     np.testing.assert_array_equal(ok, ref)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_slab_pipeline_pads_its_buffers_too(monkeypatch, dtype):
+    """ATLITE_HIP_STREAM=1 on an odd grid: the double buffers are padded (2-d DMA for fp64, the 2-d widening pass for
+    float32 - what xarray hands over for a real cutout) and the result equals the device-resident run."""
+    import pandas as pd
+
+    from atlite_amd import Cutout, Dataset
+
+    T, Y, X = 53, 9, 21
+    x, y = H.grid(Y, X)
+    t = pd.date_range("2013-01-01", periods=T, freq="h")
+    w = H.wind_dataset(T, Y, X, seed=8)
+    data = {k: v.reshape(T, Y, X).astype(dtype) for k, v in w.items()}
+    M = H.blob_matrix(3, Y, X, seed=9)
+    monkeypatch.setenv("ATLITE_HIP_SLAB_STEPS", "16")
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ATLITE_HIP_STREAM", mode)
+        c = Cutout(Dataset(dict(data), dict(time=t, y=y, x=x)))
+        out[mode] = (c.wind(turbine="Vestas_V112_3MW", matrix=M, aggregate_time=None).values,
+                     c.wind(turbine="Vestas_V112_3MW", aggregate_time=None).values)
+    np.testing.assert_array_equal(out["0"][0], out["1"][0])
+    np.testing.assert_array_equal(out["0"][1], out["1"][1])
+    from atlite_amd.resource import get_windturbineconfig
+
+    tb = get_windturbineconfig("Vestas_V112_3MW")
+    ref = orc.convert_wind(data["wnd100m"].astype(np.float64).reshape(T, -1), data["roughness"].astype(np.float64).reshape(T, -1),
+                           np.asarray(tb["V"], float), np.asarray(tb["POW"], float), tb["P"], tb["hub_height"], 100.0)
+    close(out["1"][1].reshape(T, -1), ref)
