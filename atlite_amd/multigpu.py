@@ -28,6 +28,7 @@ communicators on its way out, so its peers raise instead of waiting inside a col
 
 from __future__ import annotations
 
+import atexit
 import copy
 import ctypes as C
 import os
@@ -59,6 +60,22 @@ def devices_for(cutout=None):
     if d is None and os.environ.get("ATLITE_HIP_DEVICES"):
         d = [int(v) for v in os.environ["ATLITE_HIP_DEVICES"].split(",") if v.strip() != ""]
     return None if d is None else [int(v) for v in d]
+
+
+def _close_groups():
+    """At interpreter exit: communicators first, then their group, then the contexts they enqueue on - left to the
+    garbage collector the order is arbitrary, and a communicator that outlives its context crashes in its destructor."""
+    with _groups_lock:
+        gs = list(_groups.values())
+        _groups.clear()
+    for g in gs:
+        try:
+            g.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_groups)
 
 
 def group(devices):
