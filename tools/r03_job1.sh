@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 3, GPU call 1: the GPU suite (incl. the N-rank collectives on one GPU), bench.py launching its own 8 ranks
+# Round 3, GPU call 1 (kept as the record of how profiles/r03_clock_per_launch.txt, r03_partial_line_probe.txt, r03_occupancy.txt and
+# r03_ab_night_rowcache_waves.txt were produced; the variant libraries it A/B-ed were built with tools/build_variant.sh n0 / n1 / w2):
 # (gloo, all on GPU 0), launch-to-launch spread with per-dispatch shader clocks, the partial-line probe, the star
 # workload's request sizes, and a first A/B of night-kernel variants.   bash tools/r03_job1.sh
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
