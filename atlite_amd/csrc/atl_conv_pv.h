@@ -450,12 +450,15 @@ struct PvConvT {
     static_assert(TAIL == kTailHuld || !SP, "the tails other than the Huld panel after the simple trigon model are built for stored angles");
     static_assert(TRACK == ATL_TRACK_NONE || !SP, "trackers: stored angles");
     // the MFMA-carrying instantiation (dense matrices) only for pv() with its defaults: rare options x rare matrices
-    static constexpr bool kDenseOk = TAIL == kTailHuld && TRACK == ATL_TRACK_NONE;
+    static constexpr bool kDenseOk = TAIL == kTailHuld && TRACK == ATL_TRACK_NONE && !PC;
     // the members of the family compiled in atl_kernels_pvt.hip / atl_kernels_pvk.hip (tails other than the Huld
     // panel, trackers) exist for vectorised launches only; odd cell counts / unaligned cubes take the general kernel
     // ... and so do the early-out converters: their results are the bits of the converters that read every byte, whose
     // unvectorised instantiations take such launches
-    static constexpr bool kVecOnly = tail_panel(TAIL) != kTailHuld || TRACK != ATL_TRACK_NONE || SKIP;
+    // Unvectorised launches are a corner case since round 3 (a contiguous cube with an odd cell count that ends on a page
+    // boundary): only pv() with its defaults - one orientation for the grid, stored or computed solar position - keeps
+    // unvectorised twins; per-cell orientation, Hay-Davies and the influx head take the general kernel there too.
+    static constexpr bool kVecOnly = TAIL != kTailHuld || TRACK != ATL_TRACK_NONE || SKIP || PC || HEAD != 0;
     // a vertical-axis or dual-axis tracker's geometry does not involve the sun's azimuth: that cube is not read
     // (compile-time trackers: the compiler drops the loads by itself)
     ATL_HD bool reads_azimuth() const {

@@ -64,9 +64,9 @@ int pv_dispatch(const atl_pv_inputs *in, const atl_pv_params *p, bool allow_skip
 bool pv_needs_general(const atl_pv_inputs *in, const atl_pv_params *p) {
     if (pv_influx_fast(in, p)) return false;
     if (in->d_influx != nullptr || in->d_albedo == nullptr || p->orientation_per_time) return true;
-    if (p->tracking != ATL_TRACK_NONE) {  // trackers: fast family with stored angles and the Huld panel (atl_kernels_pvk.hip)
+    if (p->tracking != ATL_TRACK_NONE) {  // trackers: fast family with stored angles, the Huld panel and the simple trigon model (atl_kernels_pvk.hip)
         if (!(p->tracking >= ATL_TRACK_HORIZONTAL && p->tracking <= ATL_TRACK_DUAL && in->d_solar_altitude != nullptr &&
-              in->d_temperature != nullptr && p->panel_model == ATL_PANEL_HULD))
+              in->d_temperature != nullptr && p->panel_model == ATL_PANEL_HULD && p->trigon_model == ATL_TRIGON_SIMPLE))
             return true;
     }
     // fixed panel, direct / diffuse / albedo cubes, either trigon model: the fast kernel family, with the Huld panel,
@@ -109,10 +109,11 @@ int atl_pv_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p
         if (rc) return rc;
         return run_cells(ctx, c, vec, 0, T, S, time_agg, d_out, "atl_pv_convert", in->X);
     };
-    const int rc = pv_dispatch(in, p, true, run);
+    int rc = pv_dispatch(in, p, true, run);
     // a launch that cannot be vectorised: the early-out converters have no such instantiation - the converters that
-    // read every byte give the same bits
-    return rc == kNeedScalar ? pv_dispatch(in, p, false, run) : rc;
+    // read every byte give the same bits - and of those only pv() with its defaults has one: the general kernel takes the rest
+    if (rc == kNeedScalar) rc = pv_dispatch(in, p, false, run);
+    return rc == kNeedScalar ? pvx_convert(ctx, in, p, T, S, time_agg, d_out) : rc;
 }
 
 int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T,
@@ -127,8 +128,9 @@ int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv
         if (rc) return rc;
         return run_fused(ctx, c, vec, 0, T, S, agg, time_agg, d_out, ld_out, "atl_pv_convert_aggregate");
     };
-    const int rc = pv_dispatch(in, p, true, run);
-    return rc == kNeedScalar ? pv_dispatch(in, p, false, run) : rc;
+    int rc = pv_dispatch(in, p, true, run);
+    if (rc == kNeedScalar) rc = pv_dispatch(in, p, false, run);
+    return rc == kNeedScalar ? pvx_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out) : rc;
 }
 
 }  // extern "C"

@@ -1,6 +1,6 @@
 // The fast pv kernel family behind a tracker: pv(tracking="horizontal" | "tilted_horizontal" | "vertical" | "dual") with
-// the Huld panel, either trigon model, one orientation for the grid or one per cell, stored solar angles, with and
-// without the night early-out.  Vectorised launches only: odd cell counts / row lengths and unaligned cubes take the
+// the Huld panel, the simple trigon model (Hay-Davies behind a tracker: the general kernel), one orientation for the grid
+// or one per cell, stored solar angles, with and without the night early-out.  Vectorised launches only: odd cell counts / row lengths and unaligned cubes take the
 // general kernel (atl_kernels_pvx.hip), whose tracker is a run-time switch.  Same PvConvT
 // template as atl_kernels_pv.hip; a translation unit of its own so that the kernel files compile in parallel.
 // Reference arithmetic: atlite/pv/orientation.py:104-196 (closed forms: panel_geom in atl_conv_pv.h),
@@ -20,16 +20,12 @@ namespace {
 #include "atl_conv_pv.h"
 #include "atl_pv_make.h"
 
-// f(converter instance) for (tracker, trigon model, scalar / per-cell orientation, night early-out)
+// f(converter instance) for (tracker, scalar / per-cell orientation, night early-out)
 template <class F>
 int pvk_dispatch(const atl_pv_params *p, F &&f) {
-    const bool pc = p->d_cell_slope != nullptr, hd = p->trigon_model == ATL_TRIGON_OTHER, skip = p->night_skip != 0;
+    const bool pc = p->d_cell_slope != nullptr, skip = p->night_skip != 0;
     auto tracker = [&](auto trk) {
         constexpr int TR = decltype(trk)::value;
-        if (hd) {
-            if (skip) return pc ? f(PvConvT<false, true, true, kTailHuldHayDavies, TR>()) : f(PvConvT<false, false, true, kTailHuldHayDavies, TR>());
-            return pc ? f(PvConvT<false, true, false, kTailHuldHayDavies, TR>()) : f(PvConvT<false, false, false, kTailHuldHayDavies, TR>());
-        }
         if (skip) return pc ? f(PvConvT<false, true, true, kTailHuld, TR>()) : f(PvConvT<false, false, true, kTailHuld, TR>());
         return pc ? f(PvConvT<false, true, false, kTailHuld, TR>()) : f(PvConvT<false, false, false, kTailHuld, TR>());
     };
