@@ -84,6 +84,15 @@ class _Spec:
         return time_partition(T, n)
 
 
+def _device_group(ds, ctx, names):
+    """The device copies of the variables one conversion reads (``Dataset.device_group``: cubes the dataset uploads itself
+    share one slot-interleaved allocation)."""
+    group = getattr(ds, "device_group", None)
+    if group is not None:
+        return group(ctx, names)
+    return {n: ds.device(ctx, n) for n in dict.fromkeys(names)}
+
+
 def _need(ds, names, exc, msg):
     for n in names:
         if n not in ds:
@@ -290,7 +299,7 @@ class _PvSpec(_Spec):
 
     def run(self, ctx, ds, plan, time_agg, out=None):
         T, S = len(ds.coords["time"]), len(ds.coords["y"]) * len(ds.coords["x"])
-        inputs = {n: ds.device(ctx, n) for n in dict.fromkeys(self.vars)}
+        inputs = _device_group(ds, ctx, self.vars)
         self.prepare(ctx, ds)
         params = dict(self.panel, slope=self.slope, azimuth=self.azimuth)
         return ctx.pv(inputs, params, T, S, plan=plan, time_agg=time_agg, solar_tables=self.solar_tables,
@@ -354,8 +363,8 @@ class _WindSpec(_Spec):
 
     def run(self, ctx, ds, plan, time_agg, out=None):
         T, S = len(ds.coords["time"]), len(ds.coords["y"]) * len(ds.coords["x"])
-        wnd = ds.device(ctx, self.wnd)
-        aux = ds.device(ctx, self.aux) if self.aux else None
+        g = _device_group(ds, ctx, self.time_vars)
+        wnd, aux = g[self.wnd], (g[self.aux] if self.aux else None)
         return ctx.wind(wnd, aux, self.V, self.POWn, self.to_height, self.from_height, self.method, T, S,
                         plan=plan, time_agg=time_agg, out=out)
 

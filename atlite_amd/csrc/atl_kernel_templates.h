@@ -148,6 +148,13 @@ struct conv_min_waves_cells : std::integral_constant<int, conv_min_waves<Conv>::
 template <class Conv>
 struct conv_min_waves_cells<Conv, std::void_t<decltype(Conv::kMinWavesCells)>> : std::integral_constant<int, Conv::kMinWavesCells> {};
 
+// shortest chunk of slots a wave of the fused kernel walks (kMinChunk; default: two batches).  A converter whose
+// per-wave setup is heavy asks for longer ones.
+template <class Conv, class = void>
+struct conv_min_chunk : std::integral_constant<int, 16> {};
+template <class Conv>
+struct conv_min_chunk<Conv, std::void_t<decltype(Conv::kMinChunk)>> : std::integral_constant<int, Conv::kMinChunk> {};
+
 template <class Conv, class = void>
 struct conv_dense_ok : std::true_type {};
 template <class Conv>
@@ -785,15 +792,21 @@ int check_launch(const char *what) {
 }
 
 // chunk of output slots walked by one wave of the fused kernel
-int32_t pick_chunk_slots(const atl_ctx *ctx, int64_t n_slots, int64_t n_segs) {
+int32_t pick_chunk_slots(const atl_ctx *ctx, int64_t n_slots, int64_t n_segs, int64_t min_chunk) {
     // aim for >= ~16 waves per CU worth of units, chunks a multiple of kBatch in [8, 64]
     int64_t chunk = 64;
     if (const char *e = getenv("ATLITE_HIP_CHUNK")) {  // experiments: any multiple of kBatch
         const int64_t v = atoll(e);
         if (v >= kBatch && v % kBatch == 0) return int32_t(v);
     }
+    // ~12 waves per CU are resident, so the units run in rounds of ~3000: the last, partly filled round is dead time
+    // (measured on C2, 325 tiles: 64-slot chunks = 14 rounds 2.99 ms, 16-slot chunks = 58 rounds 2.94 ms).  Halve the
+    // chunk down to two batches while there are fewer than ~40 rounds; below that only when the chip would not fill.
+    const auto units = [&](int64_t c) { return n_segs * ((n_slots + c - 1) / c); };
+    const int64_t rounds40 = int64_t(ctx->n_cu) * 12 * 40;
+    while (chunk > min_chunk && units(chunk) < rounds40) chunk /= 2;
     const int64_t want_units = int64_t(ctx->n_cu) * 64;
-    while (chunk > kBatch && n_segs * ((n_slots + chunk - 1) / chunk) < want_units) chunk /= 2;
+    while (chunk > kBatch && units(chunk) < want_units) chunk /= 2;
     return int32_t(chunk);
 }
 
@@ -929,7 +942,7 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
     for (int64_t w0 = 0; w0 < n_slots; w0 += window) {
         const int64_t wn = std::min(window, n_slots - w0);
         if (P > 0) {
-            const int32_t chunk_slots = pick_chunk_slots(ctx, wn, plan.n_segs);
+            const int32_t chunk_slots = pick_chunk_slots(ctx, wn, plan.n_segs, std::max<int64_t>(2 * kBatch, conv_min_chunk<Conv>::value));
             const int64_t n_chunks = (wn + chunk_slots - 1) / chunk_slots;
             const int64_t n_units = n_chunks * plan.n_segs;
 #ifndef ATL_XCD_MAP

@@ -54,12 +54,13 @@ __global__ __launch_bounds__(256) void k_synth_field(int kind, uint64_t seed, ui
     }
 }
 
-__global__ __launch_bounds__(256) void k_synth_pv(atl_synth_solar s, int64_t T, int64_t S, double *dir,
+__global__ __launch_bounds__(256) void k_synth_pv(atl_synth_solar s, int64_t T, int64_t S, int64_t ld, double *dir,
                                                   double *dif, double *toa, double *alb, double *tmp,
                                                   double *altp, double *azp) {
     const int64_t n = T * S;
     for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) {
         const int64_t t = i / S, c = i % S;
+        const int64_t o = t * ld + c;  // slots ld cells apart (atl_set_slot_stride); the hash stays on the logical index
         const int64_t y = c / s.X, x = c % s.X;
         const double lat = s.d_lat_rad[y];
         const double sl = sin(lat), cl = cos(lat);
@@ -78,13 +79,13 @@ __global__ __launch_bounds__(256) void k_synth_pv(atl_synth_solar s, int64_t T, 
         const double u3 = hash_u01(s.seed, 3, i), u4 = hash_u01(s.seed, 4, i);
         const double top = 1361.0 * fmax(sa, 0.0);
         const double kt = 0.2 + 0.55 * u1, fd = 0.3 + 0.5 * u2;
-        altp[i] = alt;
-        azp[i] = az;
-        toa[i] = top;
-        dir[i] = top * kt * fd;
-        dif[i] = top * kt * (1.0 - fd);
-        alb[i] = 0.05 + 0.30 * u3;
-        tmp[i] = s.d_tseason[t] - 0.4 * (lat * (180.0 / M_PI) - 50.0) + 4.0 * (u4 - 0.5);
+        altp[o] = alt;
+        azp[o] = az;
+        toa[o] = top;
+        dir[o] = top * kt * fd;
+        dif[o] = top * kt * (1.0 - fd);
+        alb[o] = 0.05 + 0.30 * u3;
+        tmp[o] = s.d_tseason[t] - 0.4 * (lat * (180.0 / M_PI) - 50.0) + 4.0 * (u4 - 0.5);
     }
 }
 
@@ -403,7 +404,7 @@ int atl_synth_pv_inputs(atl_ctx *ctx, const atl_synth_solar *s, int64_t T, int64
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     if (T * S == 0) return ATL_OK;
     const unsigned grid = unsigned(std::min<int64_t>((T * S + 255) / 256, int64_t(ctx->n_cu) * 32));
-    hipLaunchKernelGGL(k_synth_pv, dim3(grid), dim3(256), 0, ctx->stream, *s, T, S, d_influx_direct,
+    hipLaunchKernelGGL(k_synth_pv, dim3(grid), dim3(256), 0, ctx->stream, *s, T, S, slot_stride_of(ctx, S), d_influx_direct,
                        d_influx_diffuse, d_influx_toa, d_albedo, d_temperature, d_solar_altitude,
                        d_solar_azimuth);
     return check_launch("atl_synth_pv_inputs");

@@ -9,6 +9,11 @@
 #include <limits>
 #include <numeric>
 
+#include <execinfo.h>
+#include <signal.h>
+#include <fcntl.h>
+#include <unistd.h>
+
 #include "atl_internal.h"
 #include "atl_math.h"
 
@@ -139,7 +144,37 @@ int atl_device_count(int *count) {
     return ATL_OK;
 }
 
+// $ATLITE_HIP_BACKTRACE=1 (stderr) or =<file> (appended; survives a test runner that captures stderr): a native backtrace
+// when the process dies of SIGABRT / SIGSEGV / SIGBUS (a runtime's abort(), glibc's heap checks, a stray pointer) -
+// library offsets, resolvable with llvm-symbolizer against the same .so
+static int g_backtrace_fd = 2;
+static void fatal_signal_backtrace(int sig) {
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "\n[atlite-hip] fatal signal, native backtrace:\n";
+    (void)!write(g_backtrace_fd, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, n, g_backtrace_fd);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+static void install_backtrace_once() {
+    static const bool once = [] {
+        if (const char *e = getenv("ATLITE_HIP_BACKTRACE")) {
+            if (*e && *e != '0') {
+                if (strcmp(e, "1") != 0) {
+                    const int fd = open(e, O_WRONLY | O_CREAT | O_APPEND, 0644);
+                    if (fd >= 0) g_backtrace_fd = fd;
+                }
+                for (int sig : {SIGABRT, SIGSEGV, SIGBUS}) signal(sig, fatal_signal_backtrace);
+            }
+        }
+        return true;
+    }();
+    (void)once;
+}
+
 int atl_create(int device, void *stream, atl_ctx **out) {
+    install_backtrace_once();
     ATL_REQUIRE(out, "atl_create: out is NULL");
     *out = nullptr;
     int n = 0;

@@ -29,8 +29,9 @@ def pitch_for(S):
 
 
 class DeviceArray:
-    """An array resident in HBM (fp64 unless stated): C-contiguous, or - ``ld`` set - a 2-d (T, S) block whose rows
-    lie ``ld`` elements apart (padded slots; only the first ``shape[1]`` elements of a row are data)."""
+    """An array resident in HBM (fp64 unless stated): C-contiguous, or - ``ld`` set - a (T, S) or (T, Y, X) block whose
+    slots (first-axis items, contiguous in themselves) lie ``ld`` elements apart: padded slots, a cube of a
+    slot-interleaved ``SlotPool``; only the first ``prod(shape[1:])`` elements of a slot are this array's data."""
 
     def __init__(self, ctx, ptr, shape, dtype=np.float64, owner=None, owned=True, ld=None):
         self.ctx = ctx
@@ -39,8 +40,9 @@ class DeviceArray:
         self.dtype = np.dtype(dtype)
         self._owner = owner  # keeps a parent allocation (or a torch tensor) alive
         self._owned = owned and owner is None
-        self.ld = None if ld is None or len(self.shape) != 2 or int(ld) == self.shape[1] else int(ld)
-        assert self.ld is None or self.ld > self.shape[1]
+        inner = int(np.prod(self.shape[1:], dtype=np.int64)) if len(self.shape) > 1 else 0
+        self.ld = None if ld is None or len(self.shape) < 2 or int(ld) == inner else int(ld)
+        assert self.ld is None or self.ld > inner
 
     @property
     def size(self):
@@ -58,8 +60,9 @@ class DeviceArray:
         out = np.empty(self.shape, dtype=self.dtype)
         if out.size and self.ld is not None:
             es = self.dtype.itemsize
-            check(self.ctx.lib.atl_copy_2d(self.ctx.handle, out.ctypes.data, self.shape[1] * es, self.ptr, self.ld * es,
-                                           self.shape[1] * es, self.shape[0], 1, 0))
+            inner = out.size // self.shape[0]
+            check(self.ctx.lib.atl_copy_2d(self.ctx.handle, out.ctypes.data, inner * es, self.ptr, self.ld * es,
+                                           inner * es, self.shape[0], 1, 0))
         elif out.size:
             check(self.ctx.lib.atl_download(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))
         return out
@@ -86,9 +89,14 @@ class DeviceArray:
             shape[shape.index(-1)] = self.size // known if known else 0
         assert int(np.prod(shape, dtype=np.int64)) == self.size, (shape, self.shape)
         if self.ld is not None:
-            if tuple(shape) != self.shape:
-                raise ValueError(f"a pitched (T, S) block cannot be viewed as {tuple(shape)}; download it first")
-            return self
+            if tuple(shape) == self.shape:
+                return self
+            if len(shape) < 2 or shape[0] != self.shape[0]:  # only the inside of a slot is contiguous
+                raise ValueError(f"a pitched {self.shape} block cannot be viewed as {tuple(shape)}; download it first")
+            a = DeviceArray(self.ctx, self.ptr, shape, self.dtype, owner=self, ld=self.ld)
+            if hasattr(self, "_pool"):
+                a._pool = self._pool
+            return a
         return DeviceArray(self.ctx, self.ptr, shape, self.dtype, owner=self)
 
     def free(self):
@@ -105,6 +113,37 @@ class DeviceArray:
     def __repr__(self):
         pitch = "" if self.ld is None else f", ld={self.ld}"
         return f"DeviceArray(shape={self.shape}{pitch}, dtype={self.dtype}, device={self.ctx.device})"
+
+
+def interleave_enabled():
+    """``ATLITE_HIP_INTERLEAVE=0``: every device copy in an allocation of its own (the layout before round 3)."""
+    return os.environ.get("ATLITE_HIP_INTERLEAVE", "1") != "0"
+
+
+class SlotPool:
+    """
+    One allocation that holds the ``n`` (T, S) cubes a conversion reads slot-interleaved: cube ``v`` of time step ``t``
+    starts ``(t * n + v) * Sp`` cells in, so the variables of one time step lie side by side (``Sp``: cells of a slot
+    rounded up to a 128-byte line, ``pitch_for``).  The kernels address cube v, slot t as ``ptr_v + t * ld`` and never
+    see the difference (``ld = n * Sp``, ``atl_set_slot_stride``); the memory system does: with seven separate
+    allocations the fused pv kernel streams at 6.2-6.3 TB/s, with this layout at 6.6-6.8.
+    """
+
+    def __init__(self, ctx, T, S, names, Sp=None):
+        self.ctx, self.T, self.S = ctx, int(T), int(S)
+        self.names = list(names)
+        self.Sp = int(Sp or S)
+        assert self.Sp >= self.S and self.names
+        self.ld = len(self.names) * self.Sp
+        self.base = ctx.empty((max(self.T * self.ld, 1),))
+        if self.Sp > self.S:  # the padding is never read as data; keep it free of stray NaN patterns
+            check(ctx.lib.atl_memset(ctx.handle, self.base.ptr, 0, self.base.nbytes))
+
+    def view(self, name):
+        v = self.names.index(name)
+        a = DeviceArray(self.ctx, self.base.ptr + v * self.Sp * 8, (self.T, self.S), owner=self.base, ld=self.ld)
+        a._pool = self
+        return a
 
 
 class AggPlan:
@@ -184,9 +223,17 @@ class Context:
         check(self.lib.atl_memset(self.handle, a.ptr, 0, a.nbytes))
         return a
 
-    def upload(self, host, dtype=np.float64, ld=None):
-        """Host array -> DeviceArray; ``ld`` (2-d arrays): rows ``ld`` elements apart (padded slots, ``pitch_for``)."""
+    def upload(self, host, dtype=np.float64, ld=None, out=None):
+        """Host array -> DeviceArray; ``ld`` (2-d arrays): rows ``ld`` elements apart (padded slots, ``pitch_for``);
+        ``out``: an existing (T, S) block of the same shape to fill instead (a ``SlotPool`` view)."""
         host = np.ascontiguousarray(host, dtype=dtype)
+        if out is not None:
+            assert out.ndim == 2 and tuple(host.shape) == out.shape and out.dtype == host.dtype, (host.shape, out.shape)
+            es = out.dtype.itemsize
+            if host.size:
+                check(self.lib.atl_copy_2d(self.handle, out.ptr, (out.ld or out.shape[1]) * es, host.ctypes.data,
+                                           host.shape[1] * es, host.shape[1] * es, host.shape[0], 0, 0))
+            return out
         if ld is not None and host.ndim == 2 and int(ld) > host.shape[1]:
             a = self.empty_pitched(host.shape, int(ld), dtype)
             es = a.dtype.itemsize

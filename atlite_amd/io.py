@@ -189,14 +189,19 @@ class FileArray:
     def read_slab(self, ctx, t0, t1, dptr):
         self.file.read_slab(ctx, self.name, self.row0 + t0, t1 - t0, dptr)
 
-    def to_device(self, ctx, block_bytes=256 << 20, ld=None):
+    def to_device(self, ctx, block_bytes=256 << 20, ld=None, out=None):
         """Whole variable as a DeviceArray (rows in blocks so that the pinned staging stays bounded); ``ld``: a
-        (time, y, x) variable as a (T, S) block with slots ``ld`` cells apart (``device.pitch_for``)."""
+        (time, y, x) variable as a (T, S) block with slots ``ld`` cells apart (``device.pitch_for``); ``out``: an
+        existing (T, S) block to fill instead (its own slot stride: a ``device.SlotPool`` view)."""
         from ._lib import check
 
         row = max(int(np.prod(self.shape[1:], dtype=np.int64)), 1)
+        if out is not None:
+            assert len(self.shape) == 3 and out.shape == (self.shape[0], row), (self.shape, out.shape)
+            ld = out.ld
         pitched = ld is not None and len(self.shape) == 3 and int(ld) > row
-        out = ctx.empty_pitched((self.shape[0], row), int(ld)) if pitched else ctx.empty(self.shape)
+        if out is None:
+            out = ctx.empty_pitched((self.shape[0], row), int(ld)) if pitched else ctx.empty(self.shape)
         stride = int(ld) if pitched else row
         step = max(1, block_bytes // (row * 8))
         if self.var.layout == "chunked":

@@ -31,8 +31,10 @@ def time_index(T, start="2013-01-01", offset_hours=0):
     return pd.date_range(pd.Timestamp(start) + pd.Timedelta(hours=int(offset_hours)), periods=T, freq="h")
 
 
-def pv_inputs(ctx, T, Y, X, start="2013-01-01", offset_hours=0, seed=42):
-    """dict name -> DeviceArray (T, Y*X) with the 7 variables convert_pv reads; plus coords."""
+def pv_inputs(ctx, T, Y, X, start="2013-01-01", offset_hours=0, seed=42, interleaved=False):
+    """dict name -> DeviceArray (T, Y*X) with the 7 variables convert_pv reads; plus coords.  ``interleaved``: the seven
+    cubes slot-interleaved in one allocation (``device.SlotPool``, the layout of the library's own device copies)
+    instead of an allocation each."""
     x, y = grid_coords(Y, X)
     t = time_index(T, start, offset_hours)
     h, dec = solar.hour_angle(t, x, "-30min")
@@ -47,11 +49,22 @@ def pv_inputs(ctx, T, Y, X, start="2013-01-01", offset_hours=0, seed=42):
         lat=ctx.upload(np.radians(y)),
         tseason=ctx.upload(tseason),
     )
-    out = {k: ctx.empty((T, S)) for k in PV_VARS}
+    ld = S
+    if interleaved:
+        from .device import SlotPool, pitch_for
+
+        pool = SlotPool(ctx, T, S, PV_VARS, pitch_for(S))
+        out, ld = {k: pool.view(k) for k in PV_VARS}, pool.ld
+    else:
+        out = {k: ctx.empty((T, S)) for k in PV_VARS}
     # the hash is indexed by the GLOBAL linear index so time shards of one cutout are consistent
     s = _lib.SynthSolar(tabs["sin_dec"].ptr, tabs["cos_dec"].ptr, tabs["h"].ptr, tabs["lat"].ptr,
                         tabs["tseason"].ptr, X, Y, int(seed) + 1000003 * int(offset_hours))
-    check(ctx.lib.atl_synth_pv_inputs(ctx.handle, C.byref(s), T, S, *[out[k].ptr for k in PV_VARS]))
+    check(ctx.lib.atl_set_slot_stride(ctx.handle, 0 if ld == S else ld))
+    try:
+        check(ctx.lib.atl_synth_pv_inputs(ctx.handle, C.byref(s), T, S, *[out[k].ptr for k in PV_VARS]))
+    finally:
+        check(ctx.lib.atl_set_slot_stride(ctx.handle, 0))
     ctx.sync()
     return out, dict(x=x, y=y, time=t)
 

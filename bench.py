@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--shapes", type=int, default=None)
     ap.add_argument("--shape-kind", choices=["tessellation", "star"], default="tessellation")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--layout", choices=["interleaved", "separate"], default="interleaved",
+                    help="where the input cubes lie in HBM: slot-interleaved in one allocation (what the library's own device "
+                         "copies use, device.SlotPool) or one allocation per cube")
     ap.add_argument("--no-step-overlap", action="store_true",
                     help="N > 1: finish a step's all-gather and placement before the next step's kernel starts "
                          "(default: they run behind it, on the collective's and a side stream)")
@@ -143,18 +146,26 @@ def pmc_traffic(tag):
     return None, None
 
 
-def generate_pv(ctx, synthetic, solar, _lib, T_loc, Y, X, off, stored_angles):
-    """This rank's (T_loc, S) input cubes generated in HBM; without stored angles the generator's two
+def generate_pv(ctx, synthetic, solar, _lib, T_loc, Y, X, off, stored_angles, interleaved=True):
+    """This rank's (T_loc, S) input cubes generated in HBM - slot-interleaved in one allocation (the layout of the
+    library's own device copies, device.SlotPool) or one allocation per cube; without stored angles the generator's two
     solar-angle outputs go to a reusable scratch and only the 5 cubes the kernel reads are kept."""
+    from atlite_amd.device import SlotPool, pitch_for
+
     S = Y * X
     if stored_angles:
-        inputs, coords = synthetic.pv_inputs(ctx, T_loc, Y, X, offset_hours=off)
+        inputs, coords = synthetic.pv_inputs(ctx, T_loc, Y, X, offset_hours=off, interleaved=interleaved)
         return inputs, coords["x"], coords["y"], None
     x, y = synthetic.grid_coords(Y, X)
     five = [k for k in synthetic.PV_VARS if not k.startswith("solar_")]
-    big = {k: ctx.empty((T_loc, S)) for k in five}
-    g = min(GEN_STEPS, T_loc)
-    alt, az = ctx.empty((g, S)), ctx.empty((g, S))
+    if interleaved:
+        pool = SlotPool(ctx, T_loc, S, five, pitch_for(S))
+        big, ld = {k: pool.view(k) for k in five}, pool.ld
+    else:
+        big, ld = {k: ctx.empty((T_loc, S)) for k in five}, S
+    g = max(1, min(GEN_STEPS * S // ld, T_loc))  # the scratch shares the cubes' slot stride: the same bytes either way
+    alt, az = ctx.empty((g * ld,)), ctx.empty((g * ld,))
+    _lib.check(ctx.lib.atl_set_slot_stride(ctx.handle, 0 if ld == S else ld))
     for a in range(0, T_loc, g):
         n = min(g, T_loc - a)
         t = synthetic.time_index(n, "2013-01-01", off + a)
@@ -163,9 +174,10 @@ def generate_pv(ctx, synthetic, solar, _lib, T_loc, Y, X, off, stored_angles):
         tseason = 283.15 + 12.0 * np.sin(2 * np.pi * (doy - 110.0) / 365.0) + 5.0 * np.sin(2 * np.pi * (hour - 9.0) / 24.0)
         tabs = [ctx.upload(v) for v in (np.sin(dec), np.cos(dec), h, np.radians(y), tseason)]
         s = _lib.SynthSolar(*[v.ptr for v in tabs], X, Y, 42 + 1000003 * (off + a))
-        ptrs = [big[k].ptr + a * S * 8 for k in five] + [alt.ptr, az.ptr]
+        ptrs = [big[k].ptr + a * ld * 8 for k in five] + [alt.ptr, az.ptr]
         _lib.check(ctx.lib.atl_synth_pv_inputs(ctx.handle, C.byref(s), n, S, *ptrs))
         ctx.sync()
+    _lib.check(ctx.lib.atl_set_slot_stride(ctx.handle, 0))
     del alt, az
     t = synthetic.time_index(T_loc, "2013-01-01", off)
     h, dec = solar.hour_angle(t, x, "-30min")
@@ -270,7 +282,9 @@ def main():
         T_total = T
     T_loc, off = edges[my + 1] - edges[my], edges[my]
     shard_lens = [edges[r + 1] - edges[r] for r in range(parts)]
-    inputs, x, y, tables = generate_pv(ctx, synthetic, solar, _lib, T_loc, Y, X, off, cfg["stored_angles"])
+    inputs, x, y, tables = generate_pv(ctx, synthetic, solar, _lib, T_loc, Y, X, off, cfg["stored_angles"],
+                                       interleaved=a.layout == "interleaved")
+    ld = next(iter(inputs.values())).ld or S  # cells between the slots of a cube (S: one allocation per cube)
     dx, dy = x[1] - x[0], y[1] - y[0]
     bounds = (x[0] - dx / 2, y[0] - dy / 2, x[-1] + dx / 2, y[-1] + dy / 2)
 
@@ -279,7 +293,7 @@ def main():
         return polys, gis.compute_indicatormatrix(x, y, polys, ctx=ctx)  # on the device, as Cutout.indicatormatrix does
 
     polys, M = shapes_of(a.shape_kind)
-    plan = ctx.plan(M, row_len=X)
+    plan = ctx.plan(M, row_len=X, ld=None if ld == S else ld)
     plan_info = plan.info()
     N = M.shape[0]
 
@@ -337,7 +351,7 @@ def main():
         C.memmove(C.byref(q), C.byref(pin), C.sizeof(pin))
         for k, p in cube_ptrs.items():
             if p:
-                setattr(q, k, p + t0 * S * 8)
+                setattr(q, k, p + t0 * ld * 8)
         for k, p in tab_ptrs.items():
             if p:
                 setattr(q, k, p + t0 * (X if "hour" in k else 1) * 8)
@@ -346,9 +360,13 @@ def main():
     pins = [pin_at(pe[i]) for i in range(P)]
     full3 = full.view(N, parts, T_loc) if equal else None
 
+    def cabi_pv(pin_, pp, T_, out_ptr, ld_out):
+        """The timed call.  The slot stride is call-scoped context state (the Python wrappers reset it after every op)."""
+        _lib.check(ctx.lib.atl_set_slot_stride(ctx.handle, 0 if ld == S else ld))
+        _lib.check(ctx.lib.atl_pv_convert_aggregate(ctx.handle, C.byref(pin_), C.byref(pp), T_, S, plan.handle, 0, out_ptr, ld_out))
+
     def launch(pp, i, out_t):
-        _lib.check(ctx.lib.atl_pv_convert_aggregate(ctx.handle, C.byref(pins[i]), C.byref(pp), pe[i + 1] - pe[i], S,
-                                                    plan.handle, 0, out_t.data_ptr(), out_t.stride(0)))
+        cabi_pv(pins[i], pp, pe[i + 1] - pe[i], out_t.data_ptr(), out_t.stride(0))
 
     def step(pp):
         if not collective:
@@ -468,8 +486,7 @@ def main():
         res = step(pp_main)
         fence()
         own = torch.empty((N, T_loc), dtype=torch.float64, device=dev)
-        _lib.check(ctx.lib.atl_pv_convert_aggregate(ctx.handle, C.byref(pin), C.byref(pp_main), T_loc, S, plan.handle, 0,
-                                                    own.data_ptr(), T_loc))
+        cabi_pv(pin, pp_main, T_loc, own.data_ptr(), T_loc)
         torch.cuda.synchronize()
         assert torch.equal(res[:, edges[rank]:edges[rank + 1]], own), "all-gather misplaced this rank's block"
         chk = torch.stack([res.sum(), res.abs().sum()])
@@ -500,6 +517,10 @@ def main():
                            (", gather + placement of a step behind the next step's kernel" if overlap and world > 1 else ""),
             "time_steps_per_gpu": T_loc,
             "night_skip": bool(a.night_skip),
+            "layout": ("slot-interleaved: the cubes in ONE allocation, the variables of a time step side by side "
+                       f"(cube v, slot t at base + (t * {len(inputs)} + v) * {ld // len(inputs)} cells) - the layout of the library's own "
+                       "device copies (device.SlotPool, Dataset.device_group)") if a.layout == "interleaved"
+                      else "one allocation per cube",
             "cell_tile": f"{plan_info['tile_w']}x{plan_info['tile_h']}",
             "partial_rows": plan_info["n_partial_rows"],
         },
@@ -576,7 +597,7 @@ def main():
         # (2) BASELINE's "random-polygon" shapes: overlapping star-convex polygons, cells may be uncovered
         if a.shape_kind == "tessellation":
             polys_s, M_s = shapes_of("star")
-            plan_main, plan = plan, ctx.plan(M_s, row_len=X)
+            plan_main, plan = plan, ctx.plan(M_s, row_len=X, ld=None if ld == S else ld)
             dts, kk = timed(pp_main, ks, kw_)
             info_s = plan.info()
             covered = int((np.asarray((M_s != 0).sum(0)).ravel() > 0).sum())
@@ -590,6 +611,24 @@ def main():
                 "achieved_on_traffic_GBps": (tr / (float(kk.mean()) * 1e-3) / 1e9) if tr else None,
             }
             plan = plan_main
+        # (2b) the same cubes in an allocation each (the layout a caller's own device arrays have, and the library's before
+        # round 3): same kernel, same bytes, bit-identical result - the memory system alone makes the difference
+        if a.layout == "interleaved" and not a.night_skip:
+            sep = generate_pv(ctx, synthetic, solar, _lib, T_loc, Y, X, off, cfg["stored_angles"], interleaved=False)[0]
+            plan_sep = ctx.plan(M, row_len=X)
+            ctx.set_profiling(True)
+            run_sep = lambda: ctx.pv(sep, dict(CSI, **ORI), T_loc, S, plan=plan_sep, options=dict(night_skip=False))  # noqa: E731
+            ksep = []
+            for i in range(kw_ + ks):
+                r_sep = run_sep()
+                if i >= kw_:
+                    ksep.append(ctx.last_kernel_ms())
+            ksep_ms = float(np.mean(ksep))
+            result["separate_cubes"] = {"kernel_ms": ksep_ms, "achieved_GBps": algo_bytes / (ksep_ms * 1e-3) / 1e9,
+                                        "frac": algo_bytes / (ksep_ms * 1e-3) / 1e9 / 8000.0,
+                                        "bit_identical": bool(np.array_equal(r_sep.numpy(), step(pp_main).cpu().numpy())),
+                                        "note": "one allocation per cube instead of the slot-interleaved one; same kernel and bytes"}
+            del sep, plan_sep, r_sep
         # (3) what a user of the drop-in API waits for: cutout.pv(...) on a device-resident Dataset
         from atlite_amd import Cutout, Dataset
 

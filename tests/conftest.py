@@ -11,6 +11,10 @@ if str(ROOT) not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # should the process die of a signal inside native code (pytest captures stderr and loses it then), the library
+    # leaves its native backtrace here
+    (ROOT / "gpurun_out").mkdir(exist_ok=True)
+    os.environ.setdefault("ATLITE_HIP_BACKTRACE", str(ROOT / "gpurun_out" / "fatal_backtrace.log"))
     # the shared library is a build artefact (git-ignored): build it on a fresh checkout
     lib = ROOT / "atlite_amd" / "lib" / "libatlite_hip.so"
     if not lib.exists() and os.environ.get("ATLITE_HIP_LIB") is None:

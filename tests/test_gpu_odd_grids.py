@@ -153,8 +153,11 @@ def test_api_results_with_padded_slots_equal_contiguous_ones(monkeypatch, T, Y, 
 
     monkeypatch.delenv("ATLITE_HIP_PITCH", raising=False)
     padded, lds = run()
-    assert lds == {(Y * X + 15) // 16 * 16}
+    Sp = (Y * X + 15) // 16 * 16
+    # (the cubes one conversion reads share a slot-interleaved allocation: 7 padded slots per time step for pv, 2 for wind)
+    assert {ld % Sp for ld in lds} == {0} and 7 * Sp in lds and Sp in lds
     monkeypatch.setenv("ATLITE_HIP_PITCH", "0")
+    monkeypatch.setenv("ATLITE_HIP_INTERLEAVE", "0")
     plain, lds0 = run()
     assert lds0 == {None}
     for k in padded:
