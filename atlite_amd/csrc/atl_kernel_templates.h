@@ -815,7 +815,9 @@ constexpr size_t kCellsNightLds = 4 * kBatch * kSegCells * sizeof(double);  // k
 // slots per block of the per-cell kernels that walk a slot range: as long as possible while the grid still fills the chip
 // (16 blocks per CU), whole batches
 inline int64_t slot_chunk_len(const atl_ctx *ctx, int64_t n_slots, unsigned gx) {
-    const int64_t n_chunks = std::max<int64_t>(1, std::min<int64_t>((n_slots + 15) / 16, (int64_t(ctx->n_cu) * 16 + gx - 1) / gx));
+    int64_t per_cu = 16;
+    if (const char *e = getenv("ATLITE_HIP_CELL_BLOCKS_PER_CU")) per_cu = std::max<int64_t>(1, atoll(e));  // experiments
+    const int64_t n_chunks = std::max<int64_t>(1, std::min<int64_t>((n_slots + 15) / 16, (int64_t(ctx->n_cu) * per_cu + gx - 1) / gx));
     const int64_t len = std::max<int64_t>(1, (n_slots + n_chunks - 1) / n_chunks);
     return (len + kBatch - 1) / kBatch * kBatch;
 }
