@@ -545,6 +545,7 @@ struct PvConvT {
 #define ATL_PV_BOFTRK_WAVES 3  // bofinger panel behind a tracker, the family's largest converters: 3 waves with 16-80 B of
                                // scratch beat 2 waves without (C2: 3.23 vs 3.50 ms horizontal, 3.62 vs 4.00 ms tilted + Hay-Davies + per-cell)
 #endif
+    static constexpr int kCubes = SP ? 5 : 7;  // cubes streamed per slot (fused kernel: how short a chunk may get)
     static constexpr int kMinWaves = (kNightPipe && !PC && HEAD == 0 && TAIL == kTailHuld && TRACK == ATL_TRACK_NONE) ? (SP ? ATL_SP_NIGHT_WAVES : 4)
                                      : (tail_panel(TAIL) == kTailBofinger && TRACK != ATL_TRACK_NONE) ? ATL_PV_BOFTRK_WAVES
                                      : (kNightPipe && TRACK != ATL_TRACK_NONE)                        ? ATL_PV_TRKNIGHT_WAVES

@@ -131,7 +131,8 @@ struct WindConvT {
 #define ATL_WIND_GROUP 4
 #endif
     static constexpr int kGroup = ATL_WIND_GROUP;
-    static constexpr int kMinChunk = 32;  // fused kernel: C3 aggregated 3.70 / 3.77 / 3.96 ms with chunks of 64 / 32 / 16 slots
+    static constexpr int kMinChunk = 64;  // fused kernel: C3 aggregated 3.70 / 3.77 / 3.96 ms with chunks of 64 / 32 / 16 slots
+    static constexpr int kCubes = 2;
 #ifdef ATL_WIND_WAVES
     static constexpr int kMinWaves = ATL_WIND_WAVES;
 #endif

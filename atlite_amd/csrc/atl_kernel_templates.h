@@ -155,6 +155,13 @@ struct conv_min_chunk : std::integral_constant<int, 16> {};
 template <class Conv>
 struct conv_min_chunk<Conv, std::void_t<decltype(Conv::kMinChunk)>> : std::integral_constant<int, Conv::kMinChunk> {};
 
+// cubes a converter streams per slot (kCubes; default 1): with the partial rows per tile it decides how short a chunk may
+// get - every unit re-reads its tile's weight rows (1 KiB each), which a light converter does not amortise over two batches
+template <class Conv, class = void>
+struct conv_cubes : std::integral_constant<int, 1> {};
+template <class Conv>
+struct conv_cubes<Conv, std::void_t<decltype(Conv::kCubes)>> : std::integral_constant<int, Conv::kCubes> {};
+
 template <class Conv, class = void>
 struct conv_dense_ok : std::true_type {};
 template <class Conv>
@@ -944,7 +951,14 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
     for (int64_t w0 = 0; w0 < n_slots; w0 += window) {
         const int64_t wn = std::min(window, n_slots - w0);
         if (P > 0) {
-            const int32_t chunk_slots = pick_chunk_slots(ctx, wn, plan.n_segs, std::max<int64_t>(2 * kBatch, conv_min_chunk<Conv>::value));
+            const bool dense_plan = plan.prow_wm != nullptr && vec && conv_dense_ok<Conv>::value;
+            // shortest chunk: the weight rows a unit reads (P / tiles KiB) against the KiB of cube data per slot, so that they
+            // stay a few % of its traffic (profiles/r03_interleave_probe.txt section 8: runoff wants 64 slots from 4 rows per
+            // tile, pv 16 up to 8 rows); never below the converter's own floor
+            int64_t min_chunk = 2 * kBatch;
+            while (min_chunk < 64 && 2 * min_chunk * conv_cubes<Conv>::value * int64_t(plan.n_segs) <= 24 * P) min_chunk *= 2;
+            min_chunk = std::max<int64_t>(min_chunk, conv_min_chunk<Conv>::value);
+            const int32_t chunk_slots = pick_chunk_slots(ctx, wn, plan.n_segs, min_chunk);
             const int64_t n_chunks = (wn + chunk_slots - 1) / chunk_slots;
             const int64_t n_units = n_chunks * plan.n_segs;
 #ifndef ATL_XCD_MAP
@@ -959,7 +973,7 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
             KernelBracket kb(ctx);
             // the MFMA-carrying instantiation exists for the vectorised kernels of converters that opt in (kDenseOk,
             // default yes); everything else reduces dense tiles on the butterfly path - correct, just slower there
-            const bool dense = plan.prow_wm != nullptr && vec && conv_dense_ok<Conv>::value;
+            const bool dense = dense_plan;
             auto launch = [&](auto kern, size_t lds_sz) {
                 if (debug_occupancy()) {  // $ATLITE_HIP_DEBUG_OCCUPANCY: what the runtime says fits on a CU
                     int nb = -1;

@@ -20,6 +20,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from atlite_amd import gis, synthetic  # noqa: E402
 from atlite_amd.device import Context  # noqa: E402
+from atlite_amd.device import interleave_enabled  # noqa: E402
 
 V = np.array([0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 25, 25], dtype=float)
 POW = np.array([0.000, 0.000, 0.005, 0.150, 0.300, 0.525, 0.905, 1.375, 1.950, 2.580, 2.960, 3.050, 3.060, 3.060, 0.000])
@@ -98,7 +99,7 @@ def main():
     if "C4s" in which:
         T, Y, X = 1095, 800, 800
         S = Y * X
-        inputs, _ = synthetic.pv_inputs(ctx, T, Y, X)
+        inputs, _ = synthetic.pv_inputs(ctx, T, Y, X, interleaved=interleave_enabled())
         plan = ctx.plan(shapes_matrix(Y, X, 500), row_len=X)
         info = plan.info()
         report("C4s", 56, T * S, *timed(ctx, lambda: ctx.pv(inputs, CSI, T, S, plan=plan, options=dict(night_skip=False))),

@@ -20,6 +20,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from atlite_amd import gis, synthetic  # noqa: E402
 from atlite_amd.device import Context  # noqa: E402
+from atlite_amd.device import interleave_enabled  # noqa: E402
 from tools.bench_configs import CSI, POW, V, timed  # noqa: E402
 
 
@@ -44,7 +45,7 @@ def main():
     res = {}
     runs = {}
     if "pv" in which:
-        inputs, _ = synthetic.pv_inputs(ctx, T, Y, X)
+        inputs, _ = synthetic.pv_inputs(ctx, T, Y, X, interleaved=interleave_enabled())
         runs["pv"] = (56, lambda plan: ctx.pv(inputs, CSI, T, S, plan=plan, options=dict(night_skip=False)))
         runs["pv_night"] = (56, lambda plan: ctx.pv(inputs, CSI, T, S, plan=plan, options=dict(night_skip=True)))
     if "runoff" in which:
@@ -59,11 +60,21 @@ def main():
     mats = [(f"dense R={R}", dense_rows(S, R)) for R in (only or (1, 2, 3, 4, 8, 16, 32))]
     if not only:
         mats += [(f"layers k={k}", layers(Y, X, k)) for k in (1, 2, 4, 8)]
+    chunk_sweep = [int(v) for v in os.environ.get("ATL_DENSE_CHUNKS", "").split(",") if v]  # e.g. "16,32,64": ATLITE_HIP_CHUNK A/B in one process
     for mname, M in mats:
         plan = ctx.plan(M, row_len=X)
         info = plan.info()
         rpt = info["n_partial_rows"] / max(1, info["n_segments"])
         for name, (nbytes, fn) in runs.items():
+            if chunk_sweep:
+                row = []
+                for ch in chunk_sweep:
+                    os.environ["ATLITE_HIP_CHUNK"] = str(ch)
+                    row.append(f"chunk {ch}: {timed(ctx, lambda: fn(plan), reps=5)[0]:.3f} ms")
+                del os.environ["ATLITE_HIP_CHUNK"]
+                row.append(f"default: {timed(ctx, lambda: fn(plan), reps=5)[0]:.3f} ms")
+                print(f"{name:9s} {mname:14s} ({rpt:5.1f} rows/tile)  " + "   ".join(row), flush=True)
+                continue
             med, mn = timed(ctx, lambda: fn(plan), reps=4)
             res[f"{name} {mname}"] = dict(ms=med, rows_per_tile=rpt, P=info["n_partial_rows"])
             print(f"{name:9s} {mname:14s} shapes {M.shape[0]:4d}  partial rows {info['n_partial_rows']:6d} ({rpt:5.1f}/tile)  "

@@ -12,12 +12,13 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from atlite_amd import gis, solar, synthetic  # noqa: E402
 from atlite_amd.device import Context  # noqa: E402
+from atlite_amd.device import interleave_enabled  # noqa: E402
 
 CSI = dict(c_temp_amb=1, c_temp_irrad=0.035, r_tmod=298, r_irradiance=1000, k_1=-0.017162, k_2=-0.040289,
            k_3=-0.004681, k_4=0.000148, k_5=0.000169, k_6=0.000005, inverter_efficiency=0.9)
 T, Y, X, N = 8760, 200, 200, 100
 ctx = Context(0)
-inputs, coords = synthetic.pv_inputs(ctx, T, Y, X)
+inputs, coords = synthetic.pv_inputs(ctx, T, Y, X, interleaved=interleave_enabled())
 x, y = coords["x"], coords["y"]
 dx, dy = x[1] - x[0], y[1] - y[0]
 M = gis.compute_indicatormatrix(x, y, gis.random_tessellation(N, (x[0] - dx / 2, y[0] - dy / 2, x[-1] + dx / 2, y[-1] + dy / 2)))

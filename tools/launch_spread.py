@@ -19,6 +19,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from atlite_amd import gis, synthetic  # noqa: E402
 from atlite_amd.device import Context  # noqa: E402
+from atlite_amd.device import interleave_enabled  # noqa: E402
 from tools.bench_configs import CSI, POW, V, shapes_matrix  # noqa: E402
 
 
@@ -50,7 +51,7 @@ def main():
     if "night" in which or "base" in which:
         T, Y, X = 8760, 200, 200
         S = Y * X
-        inputs, _ = synthetic.pv_inputs(ctx, T, Y, X)
+        inputs, _ = synthetic.pv_inputs(ctx, T, Y, X, interleaved=interleave_enabled())
         plan = ctx.plan(shapes_matrix(Y, X, 100), row_len=X)
         for rep in range(2):  # two bursts each: is the pattern inside a burst reproducible?
             if "night" in which:

@@ -5,6 +5,8 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $REPO
 O=$REPO/gpurun_out/r03_job7
 mkdir -p $O/summ
+timeout 900 python -m pytest tests -x -q -m gpu > $O/tests.log 2>&1; echo "gpu tests rc=$?"; tail -2 $O/tests.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_c2.json 2> $O/bench_c2.err; echo "bench rc=$?"; tail -c 400 $O/bench_c2.json
 python bench.py --config c4 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_c4_n1.json 2> $O/bench_c4.err; echo "bench c4 rc=$?"
 timeout 300 python bench.py --gpus 8 --debug-gloo-one-gpu --steps 5 --warmup 2 > $O/gloo8.json 2> $O/gloo8.err; echo "gloo8 rc=$?"
