@@ -611,24 +611,6 @@ def main():
                 "achieved_on_traffic_GBps": (tr / (float(kk.mean()) * 1e-3) / 1e9) if tr else None,
             }
             plan = plan_main
-        # (2b) the same cubes in an allocation each (the layout a caller's own device arrays have, and the library's before
-        # round 3): same kernel, same bytes, bit-identical result - the memory system alone makes the difference
-        if a.layout == "interleaved" and not a.night_skip:
-            sep = generate_pv(ctx, synthetic, solar, _lib, T_loc, Y, X, off, cfg["stored_angles"], interleaved=False)[0]
-            plan_sep = ctx.plan(M, row_len=X)
-            ctx.set_profiling(True)
-            run_sep = lambda: ctx.pv(sep, dict(CSI, **ORI), T_loc, S, plan=plan_sep, options=dict(night_skip=False))  # noqa: E731
-            ksep = []
-            for i in range(kw_ + ks):
-                r_sep = run_sep()
-                if i >= kw_:
-                    ksep.append(ctx.last_kernel_ms())
-            ksep_ms = float(np.mean(ksep))
-            result["separate_cubes"] = {"kernel_ms": ksep_ms, "achieved_GBps": algo_bytes / (ksep_ms * 1e-3) / 1e9,
-                                        "frac": algo_bytes / (ksep_ms * 1e-3) / 1e9 / 8000.0,
-                                        "bit_identical": bool(np.array_equal(r_sep.numpy(), step(pp_main).cpu().numpy())),
-                                        "note": "one allocation per cube instead of the slot-interleaved one; same kernel and bytes"}
-            del sep, plan_sep, r_sep
         # (3) what a user of the drop-in API waits for: cutout.pv(...) on a device-resident Dataset
         from atlite_amd import Cutout, Dataset
 
@@ -648,6 +630,25 @@ def main():
                                         "aggregate_time=None) -> host (shapes x time) labelled array; night early-out on",
                                 "cold": cold, "warm": warm, "warm_matrix_given": warm_m,
                                 "equals_timed_result": same}
+
+        # (4) the same cubes in an allocation each (the layout a caller's own device arrays have, and the library's before
+        # round 3): same kernel, same bytes, bit-identical result - the memory system alone makes the difference
+        if a.layout == "interleaved" and not a.night_skip:
+            sep = generate_pv(ctx, synthetic, solar, _lib, T_loc, Y, X, off, cfg["stored_angles"], interleaved=False)[0]
+            plan_sep = ctx.plan(M, row_len=X)
+            ctx.set_profiling(True)
+            run_sep = lambda: ctx.pv(sep, dict(CSI, **ORI), T_loc, S, plan=plan_sep, options=dict(night_skip=False))  # noqa: E731
+            ksep = []
+            for i in range(kw_ + ks):
+                r_sep = run_sep()
+                if i >= kw_:
+                    ksep.append(ctx.last_kernel_ms())
+            ksep_ms = float(np.mean(ksep))
+            result["separate_cubes"] = {"kernel_ms": ksep_ms, "achieved_GBps": algo_bytes / (ksep_ms * 1e-3) / 1e9,
+                                        "frac": algo_bytes / (ksep_ms * 1e-3) / 1e9 / 8000.0,
+                                        "bit_identical": bool(np.array_equal(r_sep.numpy(), step(pp_main).cpu().numpy())),
+                                        "note": "one allocation per cube instead of the slot-interleaved one; same kernel and bytes"}
+            del sep, plan_sep, r_sep
 
     if rank == 0 and single and not a.no_cpu_baseline and cfg["stored_angles"]:
         Tc = min(a.cpu_steps, T_loc)
