@@ -199,8 +199,78 @@ def chunks(ctx):
     del os.environ["ATLITE_HIP_CHUNK"]
 
 
+def strides(ctx):
+    """One arena (fixed physical memory), the slot-interleaved block with different paddings between the cubes: does the
+    slot stride interact with whatever makes an allocation fast or slow?"""
+    T, Y, X = 8760, 200, 200
+    S = Y * X
+    M = shapes_matrix(Y, X, 100)
+    names = list(synthetic.PV_VARS)
+    sep, _ = synthetic.pv_inputs(ctx, T, Y, X)
+    pads = (0, 16, 32, 256, 2048, 4096, 16384, 131072)  # cells between consecutive cubes of a slot
+    for an in ("arena 1", "arena 2"):
+        arena = ctx.empty((T * 7 * (S + max(pads)) + 64,))
+        for pad in pads:
+            Sp = S + pad
+            ld = 7 * Sp
+            cubes = {}
+            for v, k in enumerate(names):
+                d = DeviceArray(ctx, arena.ptr + v * Sp * 8, (T, S), owner=arena, ld=ld)
+                check(ctx.lib.atl_copy_2d(ctx.handle, d.ptr, ld * 8, sep[k].ptr, S * 8, S * 8, T, 2, 0))
+                cubes[k] = d
+            ctx.sync()
+            plan = ctx.plan(M, row_len=X, ld=ld)
+            med, mn = timed(ctx, lambda: ctx.pv(cubes, CSI, T, S, plan=plan, options=dict(night_skip=False)), reps=8)
+            print(f"{an} base {arena.ptr:#x} pad {pad * 8:>8d} B between cubes (slot stride {ld * 8} B): median {med:.3f} ms min {mn:.3f} ms", flush=True)
+        keep = arena if an == "arena 1" else None  # noqa: F841 - arena 2 must be other memory
+        del cubes
+
+
+def vram_map(ctx):
+    """Speed against position in VRAM: one allocation of most of the device memory, the 19.6 GB slot-interleaved block
+    placed every 8 GiB inside it."""
+    T, Y, X = 8760, 200, 200
+    S = Y * X
+    M = shapes_matrix(Y, X, 100)
+    names = list(synthetic.PV_VARS)
+    sep, _ = synthetic.pv_inputs(ctx, T, Y, X)
+    ld = 7 * S
+    plan = ctx.plan(M, row_len=X, ld=ld)
+    GiB = 1 << 30
+    total = int(sys.argv[2]) if len(sys.argv) > 2 else 240
+    step = float(sys.argv[3]) if len(sys.argv) > 3 else 8.0
+    arena = None
+    while arena is None:
+        try:
+            arena = ctx.empty((total * GiB // 8,))
+        except Exception:  # noqa: BLE001
+            total -= 4
+    need = T * ld * 8
+    print(f"arena {total} GiB at {arena.ptr:#x}", flush=True)
+    off = 0
+    while off + need <= total * GiB:
+        cubes = {}
+        for v, k in enumerate(names):
+            d = DeviceArray(ctx, arena.ptr + off + v * S * 8, (T, S), owner=arena, ld=ld)
+            check(ctx.lib.atl_copy_2d(ctx.handle, d.ptr, ld * 8, sep[k].ptr, S * 8, S * 8, T, 2, 0))
+            cubes[k] = d
+        ctx.sync()
+        med, mn = timed(ctx, lambda: ctx.pv(cubes, CSI, T, S, plan=plan, options=dict(night_skip=False)), reps=6)
+        # a plain one-cube read of the same bytes: the block as (T, 7 S) through the per-cell time sum of runoff
+        one = DeviceArray(ctx, arena.ptr + off, (T, ld), owner=arena)
+        med1, _ = timed(ctx, lambda: ctx.runoff(one, None, T, ld, time_agg="sum"), reps=6)
+        print(f"block at +{off / GiB:6.1f} GiB: fused pv median {med:.3f} ms min {mn:.3f} ms  {56 * T * S / (med * 1e-3) / 1e9:.0f} GB/s   "
+              f"one-cube per-cell sum {med1:.3f} ms {8 * T * ld / (med1 * 1e-3) / 1e9:.0f} GB/s", flush=True)
+        off += int(step * GiB)
+
+
 def main():
     import os
+
+    if sys.argv[1:2] == ["vram"]:
+        return vram_map(Context(0))
+    if sys.argv[1:2] == ["strides"]:
+        return strides(Context(0))
 
     if sys.argv[1:2] == ["chunks"]:
         return chunks(Context(0))
