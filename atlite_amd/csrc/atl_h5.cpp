@@ -457,9 +457,11 @@ void File::parse_datatype(const uint8_t *p, uint64_t n, Datatype &t) const {
     }
 }
 
-void File::parse_dataspace(const uint8_t *p, uint64_t n, std::vector<uint64_t> &dims, bool *null_space) const {
+void File::parse_dataspace(const uint8_t *p, uint64_t n, std::vector<uint64_t> &dims, bool *null_space,
+                           std::vector<uint64_t> *max_dims) const {
     if (n < 4) fail(ATL_E_INVALID, "short dataspace message");
     const int ver = p[0], rank = p[1];
+    const int sflags = p[2];  // bit 0: maximum dimensions follow the current ones
     *null_space = false;
     uint64_t q;
     if (ver == 1) {
@@ -478,6 +480,11 @@ void File::parse_dataspace(const uint8_t *p, uint64_t n, std::vector<uint64_t> &
         dims[i] = rd(p + q + uint64_t(i) * L_, L_);
         if (dims[i] && total > (1ull << 48) / dims[i]) fail(ATL_E_INVALID, "dataspace with more than 2^48 elements");
         total *= dims[i] ? dims[i] : 1;
+    }
+    if (max_dims) {
+        max_dims->clear();
+        if ((sflags & 1) && q + 2ull * rank * L_ <= n)
+            for (int i = 0; i < rank; ++i) max_dims->push_back(rd(p + q + uint64_t(rank + i) * L_, L_));
     }
 }
 
@@ -644,6 +651,164 @@ void File::fixed_array_chunks(uint64_t hdr, Dataset &d, bool filtered) const {
     }
 }
 
+// bytes of the "chunk size" field of a filtered chunk's index entry (H5D_*_COMPUTE_CHUNK_SIZE_LEN)
+static int chunk_size_len(uint64_t chunk_bytes) {
+    int lg = 0;
+    while ((chunk_bytes >> lg) > 1) ++lg;
+    return std::min(8, 1 + (lg + 8) / 8);
+}
+
+// Extensible array chunk index (libver >= 1.10 with ONE unlimited dimension; H5EA*.c): header -> index block (the first
+// elements, the addresses of the first data blocks, the addresses of the super blocks) -> super blocks -> data blocks
+// (paged once they hold more than 2^page_bits elements).  Element i belongs to the chunk with linear index i over the
+// chunk grid whose unlimited dimension was moved to the front ("swizzled", so that the array only ever grows at its end).
+void File::extensible_array_chunks(uint64_t hdr, Dataset &d, bool filtered, int unlim_dim) const {
+    const uint8_t *h = at(base_ + hdr, 12 + 6ull * L_ + O_ + 4);
+    if (memcmp(h, "EAHD", 4) != 0) fail(ATL_E_INVALID, "bad extensible array header");
+    const int esz = h[6], max_bits = h[7], idx_elmts = h[8], min_elmts = h[9], min_ptrs = h[10], page_bits = h[11];
+    const uint64_t iblock = addr(h + 12 + 6ull * L_);
+    if (undef(iblock)) return;  // no chunk written yet
+    auto log2_exact = [](int v) {
+        int l = 0;
+        while ((1 << l) < v) ++l;
+        return (1 << l) == v ? l : -1;
+    };
+    const int lg_min = log2_exact(min_elmts), lg_ptrs = log2_exact(min_ptrs);
+    if (max_bits < 1 || max_bits > 64 || lg_min < 0 || lg_ptrs < 1 || max_bits < lg_min || page_bits < 1 || page_bits > 30)
+        fail(ATL_E_INVALID, "bad extensible array parameters");
+    const uint64_t chunk_bytes = [&] {
+        uint64_t v = d.type.size;
+        for (auto c : d.chunk) v *= c;
+        return v;
+    }();
+    const int szb = filtered ? chunk_size_len(chunk_bytes) : 0;
+    if (esz != (filtered ? O_ + szb + 4 : O_)) fail(ATL_E_INVALID, "bad extensible array element size");
+    const int rank = int(d.grid.size());
+    const uint64_t total = d.chunks.size();
+    // element index -> row-major index over the grid (undo the swizzle)
+    std::vector<int> order;
+    order.push_back(unlim_dim);
+    for (int i = 0; i < rank; ++i)
+        if (i != unlim_dim) order.push_back(i);
+    auto place = [&](uint64_t e, const uint8_t *el) {
+        if (e >= total) return;  // allocated beyond the grid
+        const uint64_t a = addr(el);
+        if (undef(a)) return;
+        uint64_t lin = e;
+        if (unlim_dim != 0) {
+            std::vector<uint64_t> c(rank);
+            uint64_t r = e;
+            for (int k = rank - 1; k >= 0; --k) {
+                c[order[k]] = r % d.grid[order[k]];
+                r /= d.grid[order[k]];
+            }
+            lin = 0;
+            for (int k = 0; k < rank; ++k) lin = lin * d.grid[k] + c[k];
+        }
+        if (filtered)
+            d.chunks[lin] = {base_ + a, rd(el + O_, szb), uint32_t(rd(el + O_ + szb, 4))};
+        else
+            d.chunks[lin] = {base_ + a, chunk_bytes, 0};
+    };
+    const int nsblks = 1 + (max_bits - lg_min);
+    const int iblock_sblks = 2 * lg_ptrs;                   // super blocks whose data blocks hang off the index block
+    const uint64_t ndblk_addrs = 2ull * (min_ptrs - 1);
+    const int nsblk_addrs = std::max(0, nsblks - iblock_sblks);
+    const int off_sz = (max_bits + 7) / 8;
+    const uint64_t page_nelmts = 1ull << page_bits;
+    const uint64_t ib_size = 6 + O_ + uint64_t(idx_elmts) * esz + ndblk_addrs * O_ + uint64_t(nsblk_addrs) * O_ + 4;
+    const uint8_t *ib = at(base_ + iblock, ib_size);
+    if (memcmp(ib, "EAIB", 4) != 0) fail(ATL_E_INVALID, "bad extensible array index block");
+    uint64_t q = 6 + O_;
+    for (int i = 0; i < idx_elmts; ++i) place(uint64_t(i), ib + q + uint64_t(i) * esz);
+    q += uint64_t(idx_elmts) * esz;
+    const uint8_t *dblk_addrs = ib + q;
+    const uint8_t *sblk_addrs = dblk_addrs + ndblk_addrs * O_;
+    // one data block: `nelmts` elements starting at array index `first`
+    auto data_block = [&](uint64_t a, uint64_t nelmts, uint64_t first, const uint8_t *page_init, uint64_t page_bit0) {
+        if (undef(a) || first >= total) return;
+        const uint64_t prefix = 6 + O_ + off_sz;
+        const uint8_t *b = at(base_ + a, prefix);
+        if (memcmp(b, "EADB", 4) != 0) fail(ATL_E_INVALID, "bad extensible array data block");
+        if (nelmts <= page_nelmts) {
+            const uint8_t *e = at(base_ + a + prefix, nelmts * esz);
+            for (uint64_t i = 0; i < nelmts; ++i) place(first + i, e + i * esz);
+            return;
+        }
+        if (!page_init) fail(ATL_E_UNSUPPORTED, "paged extensible array data block below the index block");
+        const uint64_t npages = nelmts / page_nelmts, page_size = page_nelmts * esz + 4;
+        for (uint64_t pg = 0; pg < npages; ++pg) {
+            const uint64_t bit = page_bit0 + pg;
+            if (!((page_init[bit / 8] >> (7 - bit % 8)) & 1)) continue;  // bit 7 first, as H5VM_bit_get
+            const uint8_t *e = at(base_ + a + prefix + 4 + pg * page_size, page_nelmts * esz);
+            for (uint64_t i = 0; i < page_nelmts; ++i) place(first + pg * page_nelmts + i, e + i * esz);
+        }
+    };
+    uint64_t start_idx = uint64_t(idx_elmts), start_dblk = 0;
+    for (int u = 0; u < nsblks && start_idx < total; ++u) {
+        const uint64_t ndblks = 1ull << (u / 2);
+        const uint64_t dblk_nelmts = (1ull << ((u + 1) / 2)) * uint64_t(min_elmts);
+        if (u < iblock_sblks) {
+            for (uint64_t k = 0; k < ndblks; ++k) {
+                if (start_dblk + k >= ndblk_addrs) fail(ATL_E_INVALID, "bad extensible array index block");
+                data_block(addr(dblk_addrs + (start_dblk + k) * O_), dblk_nelmts, start_idx + k * dblk_nelmts, nullptr, 0);
+            }
+        } else {
+            const uint64_t sa = addr(sblk_addrs + uint64_t(u - iblock_sblks) * O_);
+            if (!undef(sa)) {
+                const uint64_t npages = dblk_nelmts > page_nelmts ? dblk_nelmts / page_nelmts : 0;
+                const uint64_t init_size = npages ? (npages + 7) / 8 : 0;
+                if (ndblks > (1ull << 32)) fail(ATL_E_INVALID, "bad extensible array super block");
+                const uint64_t sb_size = 6 + O_ + off_sz + ndblks * init_size + ndblks * O_ + 4;
+                const uint8_t *sb = at(base_ + sa, sb_size);
+                if (memcmp(sb, "EASB", 4) != 0) fail(ATL_E_INVALID, "bad extensible array super block");
+                const uint8_t *page_init = sb + 6 + O_ + off_sz;
+                const uint8_t *da = page_init + ndblks * init_size;
+                for (uint64_t k = 0; k < ndblks; ++k) {
+                    const uint64_t first = start_idx + k * dblk_nelmts;
+                    if (first >= total) break;
+                    // (the page bits of the blocks are packed one after another: bit k * npages + page, H5EA__lookup_elmt)
+                    data_block(addr(da + k * O_), dblk_nelmts, first, npages ? page_init : nullptr, k * npages);
+                }
+            }
+        }
+        start_idx += ndblks * dblk_nelmts;
+        start_dblk += ndblks;
+    }
+}
+
+// v2 B-tree chunk index (more than one unlimited dimension): one record per chunk - address, [filtered: size, filter mask],
+// then the chunk's grid coordinates ("scaled offsets") as 64-bit values
+void File::btree2_chunks(uint64_t hdr, Dataset &d, bool filtered) const {
+    std::vector<const uint8_t *> recs;
+    int rsz = 0;
+    btree2_records(hdr, recs, &rsz);
+    const int rank = int(d.grid.size());
+    const uint64_t chunk_bytes = [&] {
+        uint64_t v = d.type.size;
+        for (auto c : d.chunk) v *= c;
+        return v;
+    }();
+    const int szb = filtered ? chunk_size_len(chunk_bytes) : 0;
+    const int need = O_ + (filtered ? szb + 4 : 0) + 8 * rank;
+    if (!recs.empty() && rsz != need) fail(ATL_E_INVALID, "bad v2 B-tree chunk record size");
+    for (const uint8_t *r : recs) {
+        const uint64_t a = addr(r);
+        const uint8_t *sc = r + O_ + (filtered ? szb + 4 : 0);
+        uint64_t lin = 0;
+        for (int k = 0; k < rank; ++k) {
+            const uint64_t g = rd(sc + 8 * k, 8);
+            if (g >= d.grid[k]) fail(ATL_E_INVALID, "chunk offset outside the dataset '%s'", d.name.c_str());
+            lin = lin * d.grid[k] + g;
+        }
+        if (undef(a)) continue;
+        if (filtered)
+            d.chunks[lin] = {base_ + a, rd(r + O_, szb), uint32_t(rd(r + O_ + szb, 4))};
+        else
+            d.chunks[lin] = {base_ + a, chunk_bytes, 0};
+    }
+}
+
 void File::parse_dataset(const std::string &name, uint64_t a, const std::vector<Msg> &msgs, Dataset &d) const {
     d.name = name;
     d.header_addr = a;
@@ -663,7 +828,8 @@ void File::parse_dataset(const std::string &name, uint64_t a, const std::vector<
         parse_datatype(type->p, type->size, d.type);
     }
     bool null_space = false;
-    parse_dataspace(space->p, space->size, d.shape, &null_space);
+    std::vector<uint64_t> max_dims;
+    parse_dataspace(space->p, space->size, d.shape, &null_space, &max_dims);
     if (pipe && !(pipe->flags & 2)) {
         const uint8_t *p = pipe->p;
         const uint64_t n = pipe->size;
@@ -774,8 +940,22 @@ void File::parse_dataset(const std::string &name, uint64_t a, const std::vector<
         } else if (idx == 3) {  // fixed array
             const uint64_t fa = addr(p + q + 1);
             if (!undef(fa)) fixed_array_chunks(fa, d, !d.filters.empty());
+        } else if (idx == 4) {  // extensible array: one unlimited dimension (H5Dearray.c)
+            if (q + 5 + O_ > n) fail(ATL_E_INVALID, "bad chunked layout");
+            int unlim = -1;
+            for (int i = 0; i < rank && i < int(max_dims.size()); ++i)
+                if (max_dims[i] == ~0ull || (L_ < 8 && max_dims[i] == (1ull << (8 * L_)) - 1)) {
+                    if (unlim < 0) unlim = i;
+                }
+            if (unlim < 0) fail(ATL_E_INVALID, "extensible array index on '%s', which has no unlimited dimension", name.c_str());
+            const uint64_t ea = addr(p + q + 5);
+            if (!undef(ea)) extensible_array_chunks(ea, d, !d.filters.empty(), unlim);
+        } else if (idx == 5) {  // v2 B-tree: several unlimited dimensions (H5Dbtree2.c)
+            if (q + 6 + O_ > n) fail(ATL_E_INVALID, "bad chunked layout");
+            const uint64_t bt2 = addr(p + q + 6);
+            if (!undef(bt2)) btree2_chunks(bt2, d, !d.filters.empty());
         } else {
-            d.layout = -2;  // extensible array / v2 B-tree chunk index
+            d.layout = -2;  // a chunk index this reader does not know
         }
         for (auto &c : d.chunks)
             if (c.size && (c.addr > size_ || c.size > size_ - c.addr))

@@ -121,12 +121,15 @@ class File {
                          std::vector<std::pair<const uint8_t *, uint64_t>> &out) const;
     void btree2_records(uint64_t hdr, std::vector<const uint8_t *> &recs, int *rec_size) const;
     void parse_datatype(const uint8_t *p, uint64_t n, Datatype &t) const;
-    void parse_dataspace(const uint8_t *p, uint64_t n, std::vector<uint64_t> &dims, bool *null_space) const;
+    void parse_dataspace(const uint8_t *p, uint64_t n, std::vector<uint64_t> &dims, bool *null_space,
+                         std::vector<uint64_t> *max_dims = nullptr) const;
     bool parse_attribute(const uint8_t *p, uint64_t n, Attribute &a) const;
     void collect_attrs(const std::vector<Msg> &msgs, std::vector<Attribute> &out) const;
     void parse_dataset(const std::string &name, uint64_t a, const std::vector<Msg> &msgs, Dataset &d) const;
     void walk_chunk_btree(uint64_t node, int rank, Dataset &d, int depth) const;
     void fixed_array_chunks(uint64_t hdr, Dataset &d, bool filtered) const;
+    void extensible_array_chunks(uint64_t hdr, Dataset &d, bool filtered, int unlim_dim) const;
+    void btree2_chunks(uint64_t hdr, Dataset &d, bool filtered) const;
     void resolve_dims();
     void walk(uint64_t header_addr, const std::string &prefix, int depth);
 };

@@ -12,7 +12,8 @@ attribute storage once there are more than 8), dimension scales with DIMENSION_L
 float32 variables with shuffle + deflate, CF packing attributes.  The expected decoded values go
 into <name>.npz (fp64, NaN where _FillValue / missing_value / never written).  Variants cover
 the old symbol-table groups (libver earliest, no order tracking) and the libver=latest chunk
-indexes (single chunk, implicit, fixed array; extensible array must be REFUSED with a clear error).
+indexes (single chunk, implicit, fixed array; with unlimited dimensions the extensible array - one unlimited dimension,
+what netCDF-C >= 4.9 files with an unlimited time axis carry - and the v2 B-tree - several).
 tests/test_nc_reader.py also calls write_case() with random shapes when this interpreter exists.
 """
 import os
@@ -39,7 +40,8 @@ def _attach(v, scales):
 
 
 def write_case(path, T=23, Y=7, X=9, chunks=(10, 4, 5), libver=("earliest", "v108"), track=True, seed=0,
-               n_extra=0, big_attrs=True, variants=True, gzip=9):
+               n_extra=0, big_attrs=True, variants=True, gzip=9, unlimited=()):
+    """``unlimited``: axes of the chunked (time, y, x) variables without an upper bound (maxshape None)."""
     rng = np.random.default_rng(seed)
     exp = {}
     kw = {"track_order": True} if track else {}
@@ -52,6 +54,8 @@ def write_case(path, T=23, Y=7, X=9, chunks=(10, 4, 5), libver=("earliest", "v10
         exp["time"], exp["y"], exp["x"] = t[...].astype(np.float64), y[...], x[...]
 
         def var(name, data, scales=(t, y, x), **opts):
+            if unlimited and data.ndim == 3 and opts.get("chunks"):
+                opts["maxshape"] = tuple(None if i in unlimited else n for i, n in enumerate(data.shape))
             v = f.create_dataset(name, data=data, track_order=track, **opts)
             _attach(v, scales[: data.ndim] if data.ndim == 3 else scales[3 - data.ndim:])
             return v
@@ -92,7 +96,8 @@ def write_case(path, T=23, Y=7, X=9, chunks=(10, 4, 5), libver=("earliest", "v10
             exp["albedo"] = e
             # partially written variable: untouched chunks read back as _FillValue -> NaN
             v = f.create_dataset("soil_temperature", shape=(T, Y, X), dtype="f4", chunks=chunks, compression="gzip",
-                                 shuffle=True, fillvalue=np.float32(-999.0), track_order=track)
+                                 shuffle=True, fillvalue=np.float32(-999.0), track_order=track,
+                                 **({"maxshape": tuple(None if i in unlimited else n for i, n in enumerate((T, Y, X)))} if unlimited else {}))
             _attach(v, (t, y, x))
             v.attrs["_FillValue"] = np.float32(-999.0)
             part = rng.random((chunks[0], Y, X), dtype=np.float32) + 280
@@ -173,10 +178,15 @@ def main(out):
     write_case(f"{out}/cutout_many.nc", T=5, Y=3, X=4, chunks=(2, 2, 3), seed=3, n_extra=160, variants=False)
     # 4. libver latest: v4 layouts (fixed array / implicit / single chunk index)
     write_case(f"{out}/cutout_latest.nc", libver="latest", seed=4)
-    # 5. latest + unlimited time: extensible-array index -> must be refused, not misread
+    # 5. latest + unlimited time: extensible-array chunk index (refused until round 3)
     with h5py.File(f"{out}/unlimited_latest.nc", "w", libver="latest") as f:
         f.create_dataset("influx", data=np.ones((6, 4, 5), "f4"), chunks=(2, 4, 5), maxshape=(None, 4, 5))
         f.create_dataset("y", data=np.arange(4.0))
+    #    ... every variable flavour with an unlimited time axis (one time step per chunk along time, as netCDF-C chunks
+    #    a record dimension), with an unlimited middle axis (the array index is "swizzled"), with two unlimited axes (v2 B-tree)
+    write_case(f"{out}/cutout_unlimited.nc", T=23, Y=7, X=9, chunks=(1, 4, 5), libver="latest", seed=11, unlimited=(0,), big_attrs=False)
+    write_case(f"{out}/cutout_unlimited_y.nc", T=9, Y=7, X=9, chunks=(4, 2, 5), libver="latest", seed=12, unlimited=(1,), big_attrs=False)
+    write_case(f"{out}/cutout_unlimited_ty.nc", T=9, Y=7, X=9, chunks=(4, 3, 5), libver="latest", seed=13, unlimited=(0, 1), big_attrs=False)
     # 6. 4-byte offsets are not reachable from h5py; a user block shifts the superblock instead
     with h5py.File(f"{out}/userblock.nc", "w", userblock_size=512, libver=("earliest", "v108")) as f:
         f.create_dataset("temperature", data=np.arange(24, dtype="f4").reshape(2, 3, 4), chunks=(1, 3, 4),
@@ -192,9 +202,10 @@ if __name__ == "__main__":
         a = sys.argv[2:]
         write_cutout(a[0], int(a[1]), int(a[2]), int(a[3]), (int(a[4]), int(a[5]), int(a[6])), a[7], int(a[8]), gzip=1)
         sys.exit(0)
-    if len(sys.argv) > 2 and sys.argv[1] == "--case":  # --case path T Y X ct cy cx libver track seed
+    if len(sys.argv) > 2 and sys.argv[1] == "--case":  # --case path T Y X ct cy cx libver track seed [unlimited axes, e.g. 0 or 01]
         a = sys.argv[2:]
         lv = a[7] if a[7] in ("earliest", "latest") else ("earliest", "v108")
-        write_case(a[0], int(a[1]), int(a[2]), int(a[3]), (int(a[4]), int(a[5]), int(a[6])), lv, a[8] == "1", int(a[9]))
+        unl = tuple(int(c) for c in a[10]) if len(a) > 10 else ()
+        write_case(a[0], int(a[1]), int(a[2]), int(a[3]), (int(a[4]), int(a[5]), int(a[6])), lv, a[8] == "1", int(a[9]), unlimited=unl)
         sys.exit(0)
     main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "nc"))

@@ -27,7 +27,8 @@ def _have_h5py():
         return False
 
 
-@pytest.mark.parametrize("name", ["cutout_nc4", "cutout_earliest", "cutout_latest", "cutout_many", "userblock"])
+@pytest.mark.parametrize("name", ["cutout_nc4", "cutout_earliest", "cutout_latest", "cutout_many", "userblock",
+                                  "cutout_unlimited", "cutout_unlimited_y", "cutout_unlimited_ty"])
 def test_fixture_values(name):
     """Every variable of every container flavour decodes to the values h5py wrote."""
     f = io.NcFile(f"{NC}/{name}.nc")
@@ -87,10 +88,20 @@ def test_many_links_two_level_index():
 
 
 def test_unsupported_and_corrupt_inputs(tmp_path):
-    f = io.NcFile(f"{NC}/unlimited_latest.nc")  # opens; the extensible-array indexed variable is refused
-    with pytest.raises(NotImplementedError, match="chunk index"):
-        f.read("influx")
+    f = io.NcFile(f"{NC}/unlimited_latest.nc")  # an extensible-array chunk index (refused until round 3)
+    assert np.array_equal(f.read("influx"), np.ones((6, 4, 5)))
     assert np.array_equal(f.read("y"), np.arange(4.0))
+    # a chunk index type this reader does not know (the index-type byte of the layout message patched to 9): refused
+    raw = bytearray(open(f"{NC}/unlimited_latest.nc", "rb").read())
+    i = raw.index(b"EAHD")  # the layout message points at it: version 4, class 2, flags, rank 4, 1-byte dims 2 4 5 4, index type 4
+    hits = [k for k in range(len(raw) - 10) if bytes(raw[k:k + 2]) == b"\x04\x02" and raw[k + 3] == 4 and bytes(raw[k + 5:k + 9]) == b"\x02\x04\x05\x04"
+            and raw[k + 9] == 4]
+    assert len(hits) == 1 and i > 0
+    raw[hits[0] + 9] = 9
+    q = tmp_path / "unknown_index.nc"
+    q.write_bytes(bytes(raw))
+    with pytest.raises(NotImplementedError, match="chunk index"):
+        io.NcFile(q).read("influx")
     with pytest.raises(ValueError, match="cannot open"):
         io.NcFile(tmp_path / "missing.nc")
     p = tmp_path / "text.nc"
@@ -168,16 +179,17 @@ def test_open_cutout_dataset():
 
 
 @pytest.mark.skipif(not _have_h5py(), reason="needs the conda interpreter with h5py to write random files")
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(12))
 def test_random_files(tmp_path, seed):
     rng = np.random.default_rng(100 + seed)
     T, Y, X = (int(v) for v in rng.integers(1, 30, size=3))
     ct, cy, cx = (int(rng.integers(1, d + 3)) for d in (T, Y, X))
     ct, cy, cx = min(ct, T), min(cy, Y), min(cx, X)
     libver = ["v108", "earliest", "latest"][seed % 3]
+    unlimited = ["", "0", "1", "02", "012", "2"][seed % 6]  # earliest / v108: the v1 B-tree whatever the bounds; latest: EA / v2 B-tree
     path = tmp_path / "case.nc"
     r = subprocess.run([CONDA, MAKE, "--case", str(path), str(T), str(Y), str(X), str(ct), str(cy), str(cx), libver,
-                        str(seed % 2), str(seed)], capture_output=True, text=True, timeout=300)
+                        str(seed % 2), str(seed), unlimited], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     f = io.NcFile(path)
     exp = np.load(tmp_path / "case.npz")
@@ -285,10 +297,15 @@ def test_isel_time_is_lazy():
 
 @pytest.mark.skipif(not _have_h5py(), reason="needs the conda interpreter with h5py to write the files")
 @pytest.mark.parametrize("args,n_chunks", [(("700", "6", "7", "1", "6", "7", "v108", "1", "5"), 700),
-                                           (("40", "30", "31", "1", "2", "3", "latest", "1", "6"), 6600)])
+                                           (("40", "30", "31", "1", "2", "3", "latest", "1", "6"), 6600),
+                                           (("3000", "4", "6", "1", "2", "6", "latest", "1", "7", "0"), 6000),
+                                           (("50", "24", "20", "1", "2", "3", "latest", "1", "8", "1"), 4200),
+                                           (("60", "20", "12", "2", "1", "4", "latest", "0", "9", "01"), 1800)])
 def test_many_chunks(tmp_path, args, n_chunks):
     """One time step per chunk (netCDF-C's default for an unlimited time axis): a multi-level v1 chunk
-    B-tree; libver=latest with thousands of chunks: a paged fixed-array index."""
+    B-tree; libver=latest with thousands of chunks: a paged fixed-array index; with an unlimited axis an extensible array
+    deep into its super blocks and paged data blocks (time first, and swizzled: y unlimited); two unlimited axes: a
+    multi-level v2 B-tree."""
     path = tmp_path / "many.nc"
     r = subprocess.run([CONDA, MAKE, "--case", str(path), *args], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
