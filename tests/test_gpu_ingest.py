@@ -30,7 +30,7 @@ def slab(ctx, f, name, t0, n):
     return out.numpy()[:n]
 
 
-@pytest.mark.parametrize("name", ["cutout_nc4", "cutout_earliest", "cutout_latest"])
+@pytest.mark.parametrize("name", ["cutout_nc4", "cutout_earliest", "cutout_latest", "cutout_unlimited", "cutout_unlimited_ty"])
 def test_read_slab_matches_h5py(ctx, name):
     f = io.NcFile(f"{NC}/{name}.nc")
     exp = np.load(f"{NC}/{name}.npz")

@@ -138,3 +138,34 @@ def test_synthetic_generator_writes_the_interleaved_layout(ctx):
         a = ctx.pv(sep, PV, T, Y * X, plan=ctx.plan(M, row_len=X), options=dict(night_skip=skip)).numpy()
         b = ctx.pv(il, PV, T, Y * X, plan=ctx.plan(M, row_len=X, ld=7 * Sp), options=dict(night_skip=skip)).numpy()
         np.testing.assert_allclose(b, a, rtol=1e-12, atol=1e-13 * np.abs(a).max())  # (another tile shape on the padded slots)
+
+
+@pytest.mark.parametrize("fname", ["cutout_small_f32", "cutout_small_f64"])
+def test_file_backed_variables_are_inflated_straight_into_their_slots(monkeypatch, fname):
+    """A cutout file held resident (ATLITE_HIP_STREAM=0): the chunks of every variable a conversion reads are inflated,
+    decoded and scattered into the slot-interleaved block (FileArray.to_device(out=view)); same bits as the in-memory twin."""
+    import os
+
+    from atlite_amd import Cutout, Dataset, io
+
+    monkeypatch.delenv("ATLITE_HIP_INTERLEAVE", raising=False)
+    monkeypatch.setenv("ATLITE_HIP_STREAM", "0")
+    path = os.path.join(os.path.dirname(__file__), "golden", "nc", fname + ".nc")
+    f = io.NcFile(path)
+    ds = io.open_cutout(path)
+    data = {n: f.read(n) for n in ds.keys()}
+    cf = Cutout(ds)
+    cm = Cutout(Dataset(data, {k: ds.coords[k] for k in ("time", "y", "x")}, chunked=True))
+    Y, X = cf.shape
+    M = H.blob_matrix(4, Y, X, seed=2)
+    a = cf.pv(matrix=M, aggregate_time=None, **KW)
+    b = cm.pv(matrix=M, aggregate_time=None, **KW)
+    np.testing.assert_array_equal(a.values, b.values)
+    (pf,), (pm,) = pools(cf.data).values(), pools(cm.data).values()
+    assert len(pf.names) == len(pm.names) == 7 and pf.ld == pm.ld
+    for n in pf.names:  # the file's bytes, widened to fp64, where the kernels read them
+        np.testing.assert_array_equal(cf.data._device_cache[n].numpy().reshape(data[n].shape), data[n].astype(np.float64), err_msg=n)
+    w = cf.wind(turbine="Vestas_V112_3MW", matrix=M, aggregate_time=None)
+    w2 = cm.wind(turbine="Vestas_V112_3MW", matrix=M, aggregate_time=None)
+    np.testing.assert_array_equal(w.values, w2.values)
+    assert sorted(len(p.names) for p in pools(cf.data).values()) == [2, 7]
