@@ -16,9 +16,10 @@ T, Y, X, N = 8760, 200, 200, 100
 PARAMS = dict(H.CSI, slope=np.radians(30.0), azimuth=np.radians(180.0))
 
 
-@pytest.fixture(scope="module")
-def c2(ctx):
-    inputs, coords = synthetic.pv_inputs(ctx, T, Y, X)
+@pytest.fixture(scope="module", params=["one allocation per cube", "slot-interleaved"])
+def c2(ctx, request):
+    # both residencies: a caller's own device arrays, and the layout of the library's own device copies (device.SlotPool)
+    inputs, coords = synthetic.pv_inputs(ctx, T, Y, X, interleaved=request.param == "slot-interleaved")
     x, y = coords["x"], coords["y"]
     dx, dy = x[1] - x[0], y[1] - y[0]
     polys = gis.random_tessellation(N, (x[0] - dx / 2, y[0] - dy / 2, x[-1] + dx / 2, y[-1] + dy / 2), seed=42)
@@ -95,3 +96,18 @@ def test_per_cell_kernels_with_the_night_early_out(ctx, c2):
     assert dark.any() and (ser[sel[dark]] == 0.0).all()
     nos = ctx.pv(inputs, PARAMS, T, S, options=dict(night_skip=False))
     np.testing.assert_array_equal(nos.slab(4300, 4400).numpy(), ser[4300:4400])
+
+
+def test_the_two_residencies_give_the_same_bits(ctx):
+    sep, coords = synthetic.pv_inputs(ctx, T, Y, X)
+    il, _ = synthetic.pv_inputs(ctx, T, Y, X, interleaved=True)
+    assert next(iter(il.values())).ld == 7 * Y * X and next(iter(sep.values())).ld is None
+    x, y = coords["x"], coords["y"]
+    dx, dy = x[1] - x[0], y[1] - y[0]
+    M = gis.compute_indicatormatrix(x, y, gis.random_tessellation(N, (x[0] - dx / 2, y[0] - dy / 2, x[-1] + dx / 2, y[-1] + dy / 2), seed=42))
+    plan = ctx.plan(M, row_len=X)
+    for skip in (False, True):
+        a = ctx.pv(sep, PARAMS, T, Y * X, plan=plan, options=dict(night_skip=skip)).numpy()
+        b = ctx.pv(il, PARAMS, T, Y * X, plan=plan, options=dict(night_skip=skip)).numpy()
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(ctx.pv(sep, PARAMS, T, Y * X, time_agg="mean").numpy(), ctx.pv(il, PARAMS, T, Y * X, time_agg="mean").numpy())
