@@ -126,8 +126,8 @@ def alloc_placed(ctx, n_elems):
     put it.  Device memory has zones (a quarter to a third of it) in which the same access stream runs ~6 % slower, at offsets
     nobody can predict from user space (``profiles/r03_vram_map.txt``).  So for blocks of 1-60 GB up to three candidates are
     allocated one after another, each is read once by a plain one-cube kernel (the per-cell time sum of the runoff converter,
-    ~0.15 ms per GB; 3 % apart between the two kinds of memory), and as soon as two candidates differ by more than 1.5 % the
-    faster one is kept and the others are freed; three alike: the first.  ``ATLITE_HIP_PLACE=0`` switches this off.
+    ~0.15 ms per GB; 3 % apart between the two kinds of memory), and as soon as two candidates differ by more than 1.5 % (or after
+    the third) the fastest one is kept and the others are freed.  ``ATLITE_HIP_PLACE=0`` switches this off.
     """
     nbytes = int(n_elems) * 8
     if os.environ.get("ATLITE_HIP_PLACE", "1") == "0" or not (1 << 30) <= nbytes <= 60 * 10**9:
@@ -160,7 +160,7 @@ def alloc_placed(ctx, n_elems):
         ctx.set_profiling(was)
     if not cands:
         return ctx.empty((n_elems,))
-    best = min(cands, key=lambda c: c[0])[1] if max(t for t, _ in cands) > 1.015 * min(t for t, _ in cands) else cands[0][1]
+    best = min(cands, key=lambda c: c[0])[1]  # (among three alike any will do)
     if os.environ.get("ATLITE_HIP_DEBUG_PLACE"):
         import sys
 
