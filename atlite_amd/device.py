@@ -292,10 +292,18 @@ class Context:
             check(self.lib.atl_copy_2d(self.handle, a.ptr, a.ld * es, host.ctypes.data, host.shape[1] * es,
                                        host.shape[1] * es, host.shape[0], 0, 0))
             return a
-        a = self.empty(host.shape, dtype)
+        a = self.empty_placed(host.shape, dtype)
         if host.size:
             check(self.lib.atl_upload(self.handle, a.ptr, host.ctypes.data, host.nbytes))
         return a
+
+    def empty_placed(self, shape, dtype=np.float64):
+        """``empty`` for long-lived input blocks: large fp64 ones go through ``alloc_placed`` (the faster kind of device memory)."""
+        shape = (shape,) if np.isscalar(shape) else tuple(int(v) for v in shape)
+        if np.dtype(dtype) != np.float64:
+            return self.empty(shape, dtype)
+        a = alloc_placed(self, int(np.prod(shape, dtype=np.int64)))
+        return a if a.shape == shape else a.reshape(shape)
 
     def empty_pitched(self, shape, ld, dtype=np.float64):
         """(T, S) block with rows ``ld`` elements apart; the padding is zeroed (never read as data, but a stray NaN
@@ -303,12 +311,10 @@ class Context:
         T, S = (int(v) for v in shape)
         ld = int(ld)
         assert ld >= S
-        nbytes = max(T * ld, 1) * np.dtype(dtype).itemsize
-        p = C.c_void_p()
-        check(self.lib.atl_alloc(self.handle, nbytes, C.byref(p)))
+        base = self.empty_placed((max(T * ld, 1),), dtype)
         if ld > S:
-            check(self.lib.atl_memset(self.handle, p.value, 0, nbytes))
-        return DeviceArray(self, p.value, (T, S), dtype, ld=ld)
+            check(self.lib.atl_memset(self.handle, base.ptr, 0, base.nbytes))
+        return DeviceArray(self, base.ptr, (T, S), dtype, owner=base, ld=ld) if ld > S else base.reshape(T, S)
 
     def _stride(self, S, *arrays):
         """Tell the context how far apart the slots of this call's (T, S) input cubes are: every 2-d input must have
