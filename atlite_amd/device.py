@@ -629,7 +629,7 @@ class Context:
 
     # -- synthetic fields -------------------------------------------------------------------
     def synth_field(self, kind, seed, var_id, p0, p1, T, S, per_cell_static=False):
-        out = self.empty((S,) if per_cell_static else (T, S))
+        out = self.empty_placed((S,) if per_cell_static else (T, S))  # (an input cube like any the library uploads)
         check(self.lib.atl_synth_field(self.handle, kind, seed, var_id, p0, p1, 1 if per_cell_static else 0,
                                        1 if per_cell_static else T, S, out.ptr))
         return out
