@@ -152,6 +152,7 @@ def test_api_results_with_padded_slots_equal_contiguous_ones(monkeypatch, T, Y, 
         return out, lds
 
     monkeypatch.delenv("ATLITE_HIP_PITCH", raising=False)
+    monkeypatch.delenv("ATLITE_HIP_INTERLEAVE", raising=False)
     padded, lds = run()
     Sp = (Y * X + 15) // 16 * 16
     # (the cubes one conversion reads share a slot-interleaved allocation: 7 padded slots per time step for pv, 2 for wind)
