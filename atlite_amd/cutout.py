@@ -100,9 +100,8 @@ class Cutout:
 
         where: "device" (the areas are line integrals evaluated on the GPU), "host" (the C++ polygon clipper) or
         None = ATLITE_HIP_INDICATOR, default "device".  Both implement the same contract (1e-13 of a cell apart);
-        the conversion itself has no host path either way."""
-        if shapes_crs != self.crs:
-            raise NotImplementedError("reprojection of shapes needs pyproj; pass shapes in the cutout's crs")
+        the conversion itself has no host path either way.  ``shapes_crs`` other than the cutout's: one of the projections
+        written out in ``atlite_amd.crs`` (EPSG:3035, 3857, UTM zones) for a cutout in geographic coordinates."""
         where = where or os.environ.get("ATLITE_HIP_INDICATOR", "device")
         if where not in ("device", "host"):
             raise ValueError(f"where must be 'device' or 'host', not {where!r}")
@@ -112,7 +111,9 @@ class Cutout:
 
             ctx = default_context()
         cache = self.__dict__.setdefault("_indicator_cache", {})
-        return gis.compute_indicatormatrix(self.coords["x"], self.coords["y"], shapes, ctx=ctx, cache=cache)
+        # shapes in another crs: the cell corners are projected into it and the overlaps taken there (host), like the reference
+        return gis.compute_indicatormatrix(self.coords["x"], self.coords["y"], shapes, ctx=ctx, cache=cache,
+                                           shapes_crs=shapes_crs, grid_crs=self.crs)
 
     def uniform_layout(self):
         from .labeled import LabeledArray

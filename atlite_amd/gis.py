@@ -68,7 +68,7 @@ def _rings_of(shape):
     return [(a, False)]
 
 
-def compute_indicatormatrix(x, y, shapes, ctx=None, cache=None):
+def compute_indicatormatrix(x, y, shapes, ctx=None, cache=None, shapes_crs=None, grid_crs=4326):
     """
     Indicator matrix ``I[i, j]`` = share of grid cell ``j`` (``j = iy * X + ix``, cell = box of
     centre +- half spacing) lying in ``shapes[i]``; returns ``scipy.sparse.csr_matrix (N, Y*X)``.
@@ -79,7 +79,16 @@ def compute_indicatormatrix(x, y, shapes, ctx=None, cache=None):
           line integrals per candidate cell); ``None`` -> the host clipper (``atl_indicator_polygons``).
     cache : optional dict; the matrix is stored under a digest of the grid and the ring coordinates and a copy is
           handed back when the same shapes come again - repeated ``Cutout.pv(shapes=...)`` calls.
+    shapes_crs : the shapes' coordinate system when it is not the grid's (``grid_crs``, geographic): like the reference
+          (atlite/gis.py:128-133) the four corners of every cell box are projected into it (``atlite_amd.crs.forward``) and
+          the overlaps are taken there, cell by cell against convex quadrilaterals (``atl_indicator_polygons_quads``, host).
     """
+    from . import crs as _crs
+
+    quads = None
+    if shapes_crs is not None and not _crs.same_crs(shapes_crs, grid_crs):
+        if _crs.epsg_of(grid_crs) not in _crs.GEOGRAPHIC:
+            raise NotImplementedError("shapes in another crs need a cutout in geographic coordinates (EPSG:4326 / 4258)")
     x = np.asarray(x, dtype=np.float64)
     y = np.asarray(y, dtype=np.float64)
     X, Y = len(x), len(y)
@@ -87,6 +96,13 @@ def compute_indicatormatrix(x, y, shapes, ctx=None, cache=None):
     dy = float(y[1] - y[0]) if Y > 1 else 1.0
     if dx <= 0 or dy <= 0:
         raise ValueError("grid coordinates must be ascending")
+    if shapes_crs is not None and not _crs.same_crs(shapes_crs, grid_crs):
+        # shapely's box(minx, miny, maxx, maxy): (maxx, miny), (maxx, maxy), (minx, maxy), (minx, miny)
+        gx, gy = np.meshgrid(x, y)
+        cx = np.stack([gx + dx / 2, gx + dx / 2, gx - dx / 2, gx - dx / 2], axis=-1).reshape(-1, 4)
+        cy = np.stack([gy - dy / 2, gy + dy / 2, gy + dy / 2, gy - dy / 2], axis=-1).reshape(-1, 4)
+        px, py = _crs.forward(shapes_crs, cx, cy)
+        quads = np.ascontiguousarray(np.stack([px, py], axis=-1), dtype=np.float64)  # (Y * X, 4, 2)
     if hasattr(shapes, "geometry") and not isinstance(shapes, (dict, np.ndarray)):  # GeoDataFrame-like (atlite/gis.py:127)
         shapes = shapes.geometry
     shapes = list(shapes.values) if hasattr(shapes, "values") and not isinstance(shapes, np.ndarray) else list(shapes)
@@ -106,7 +122,8 @@ def compute_indicatormatrix(x, y, shapes, ctx=None, cache=None):
         import hashlib
 
         hsh = hashlib.blake2b(digest_size=16)
-        for a in (np.asarray([X, Y, x[0], dx, y[0], dy, 1.0 if ctx is not None else 0.0]), shape_ptr, ring_ptr, holes, xy):
+        for a in (np.asarray([X, Y, x[0], dx, y[0], dy, 1.0 if ctx is not None else 0.0, 0.0 if quads is None else float(_crs.epsg_of(shapes_crs))]),
+                  shape_ptr, ring_ptr, holes, xy):
             hsh.update(np.ascontiguousarray(a).tobytes())
         key = hsh.digest()
         if key in cache:
@@ -116,7 +133,9 @@ def compute_indicatormatrix(x, y, shapes, ctx=None, cache=None):
     args = (len(shapes), shape_ptr.ctypes.data, len(holes), ring_ptr.ctypes.data,
             holes.ctypes.data if len(holes) else None, xy.ctypes.data if len(xy) else None,
             X, Y, float(x[0]), dx, float(y[0]), dy, C.byref(p_ip), C.byref(p_ix), C.byref(p_d))
-    if ctx == "integral-host":  # tests: the device algorithm with its candidate cells evaluated on the host
+    if quads is not None:
+        _lib.check(lib.atl_indicator_polygons_quads(*args[:6], Y * X, quads.ctypes.data, *args[12:]))
+    elif ctx == "integral-host":  # tests: the device algorithm with its candidate cells evaluated on the host
         _lib.check(lib.atl_indicator_polygons_integral_host(*args))
     elif ctx is not None:
         _lib.check(lib.atl_indicator_polygons_device(ctx.handle, *args))
@@ -202,10 +221,8 @@ def random_tessellation(n, bounds, seed=42):
 def indicatormatrix_of_grid(orig, dest, orig_crs=4326, dest_crs=4326):
     """``atlite.compute_indicatormatrix(orig, dest, orig_crs, dest_crs)`` (atlite/gis.py:104-145) for the case the hot
     path uses: ``orig`` is a cutout's grid (``cutout.grid``: a frame with the cell centres in columns 'x' and 'y', cells
-    in y-major order), ``dest`` the shapes.  Other collections of polygons as ``orig`` and shapes in another crs are
-    outside this library (no polygon-polygon overlay, no pyproj)."""
-    if orig_crs != dest_crs:
-        raise NotImplementedError("reprojection of shapes needs pyproj; pass shapes in the grid's crs")
+    in y-major order), ``dest`` the shapes - in the grid's crs or, for a geographic grid, in one of the projections of
+    ``atlite_amd.crs``.  Other collections of polygons as ``orig`` are outside this library (no polygon-polygon overlay)."""
     cols = getattr(orig, "columns", ())
     if "x" not in cols or "y" not in cols:
         raise NotImplementedError("orig must be a cutout grid frame with 'x' and 'y' columns (Cutout.grid)")
@@ -213,4 +230,4 @@ def indicatormatrix_of_grid(orig, dest, orig_crs=4326, dest_crs=4326):
     x, y = np.unique(gx), np.unique(gy)
     if len(x) * len(y) != len(gx) or not (np.array_equal(gx, np.tile(x, len(y))) and np.array_equal(gy, np.repeat(y, len(x)))):
         raise NotImplementedError("orig is not a regular y-major grid of cell centres")
-    return compute_indicatormatrix(x, y, dest)
+    return compute_indicatormatrix(x, y, dest, shapes_crs=dest_crs, grid_crs=orig_crs)

@@ -437,3 +437,29 @@ def test_temperatures_cop_cooling():
     M = sp.csr_matrix(np.ones((1, S)))
     r = c.soil_temperature(matrix=M, aggregate_time=None)
     close(r.values[0], g["out_soil_temperature"].reshape(len(t), -1).sum(1))
+
+
+def test_shapes_in_another_crs_through_the_gateway():
+    """convert_and_aggregate(shapes=..., shapes_crs=...) (atlite/convert.py:235-240): shapes given in ETRS89-LAEA / UTM
+    coordinates for a cutout in EPSG:4326 - the gateway builds the matrix from the projected cell corners
+    (atlite_amd.crs, tests/test_crs.py) and runs the usual fused kernel with it."""
+    from atlite_amd import crs
+    from tests import helpers as H
+
+    T, Y, X = 30, 12, 16
+    x, y = 6.0 + 0.25 * np.arange(X), 47.0 + 0.25 * np.arange(Y)
+    ds = H.pv_dataset(T, Y, X, seed=21)
+    c = Cutout(Dataset({k: v.reshape(T, Y, X) for k, v in ds.items()}, dict(time=pd.date_range("2013-05-01", periods=T, freq="h"), y=y, x=x)))
+    ll = [np.array([[6.3, 47.2], [8.9, 47.4], [9.4, 49.6], [7.0, 49.8]]), np.array([[8.0, 48.0], [9.9, 48.1], [9.7, 49.9]])]
+    kw = dict(panel="CSi", orientation={"slope": 30.0, "azimuth": 180.0}, aggregate_time=None)
+    for code in (3035, 32632):
+        shapes = [np.stack(crs.forward(code, r[:, 0], r[:, 1]), axis=1) for r in ll]
+        M = c.indicatormatrix(shapes, shapes_crs=code)
+        assert M.shape == (2, Y * X) and 0 < M.data.min() and M.data.max() <= 1.0
+        a = c.pv(shapes=shapes, shapes_crs=code, **kw)
+        b = c.pv(matrix=M, **kw)
+        np.testing.assert_array_equal(a.values, b.values)
+        same = c.pv(shapes=ll, **kw)  # the same corner points joined by straight lines in lon / lat: close, not equal
+        assert np.abs(a.values - same.values).max() < 0.05 * np.abs(same.values).max()
+    with pytest.raises(NotImplementedError, match="not among the projections"):
+        c.pv(shapes=ll, shapes_crs=27700, **kw)

@@ -589,8 +589,14 @@ def test_turbine_and_panel_catalogues_like_the_reference():
     tri = np.array([[0.2, 39.8], [3.7, 40.3], [1.9, 42.2]])
     a = atlite_amd.compute_indicatormatrix(c.grid, [tri])
     np.testing.assert_array_equal(a.toarray(), gis.compute_indicatormatrix(x, y, [tri]).toarray())
+    # shapes in a projected crs: the cell corners go through atlite_amd.crs (tests/test_crs.py); other codes are refused
+    from atlite_amd import crs
+
+    tri_laea = np.stack(crs.forward(3035, tri[:, 0], tri[:, 1]), axis=1)
+    b = atlite_amd.compute_indicatormatrix(c.grid, [tri_laea], 4326, 3035)
+    assert b.shape == a.shape and abs(b.sum() - a.sum()) < 0.02 * a.sum() and np.abs((b - a).toarray()).max() < 0.1
     with pytest.raises(NotImplementedError):
-        atlite_amd.compute_indicatormatrix(c.grid, [tri], 4326, 3035)
+        atlite_amd.compute_indicatormatrix(c.grid, [tri], 4326, 27700)
     with pytest.raises(NotImplementedError):
         atlite_amd.compute_indicatormatrix(c.grid.iloc[::-1], [tri])
 
