@@ -538,6 +538,9 @@ struct PvConvT {
 #ifndef ATL_SP_NIGHT_WAVES
 #define ATL_SP_NIGHT_WAVES 3
 #endif
+#ifndef ATL_PV_WAVES
+#define ATL_PV_WAVES 3  // the headline kernel (stored angles, one orientation, every byte read): 149 VGPRs
+#endif
 #ifndef ATL_SP_WAVES
 #define ATL_SP_WAVES 4  // in-kernel solar position, every byte read: 128 VGPRs + 32 B of scratch at 4 waves beat 138 VGPRs at 3 (C2: 2.41 vs 2.53 ms, six alternating runs)
 #endif
@@ -553,6 +556,7 @@ struct PvConvT {
                                      : (tail_panel(TAIL) == kTailBofinger && TRACK != ATL_TRACK_NONE) ? ATL_PV_BOFTRK_WAVES
                                      : (kNightPipe && TRACK != ATL_TRACK_NONE)                        ? ATL_PV_TRKNIGHT_WAVES
                                      : (SP && !kNightPipe && !PC)                                     ? ATL_SP_WAVES
+                                     : (!SP && !kNightPipe && !PC && TAIL == kTailHuld && TRACK == ATL_TRACK_NONE && HEAD == 0) ? ATL_PV_WAVES
                                                                                                     : 3;
     // the per-cell early-out kernel behind a tracker: two waves per SIMD, no scratch (the fused kernel's three waves
     // with 48-112 B of scratch were measured against two; the per-cell kernel carries its accumulators on top)
