@@ -127,10 +127,14 @@ def alloc_placed(ctx, n_elems):
     nobody can predict from user space (``profiles/r03_vram_map.txt``).  So for blocks of 1-60 GB up to six candidates (120 GB
     in all) are allocated one after another, each is read once by a plain one-cube kernel (the per-cell time sum of the runoff converter,
     ~0.15 ms per GB; 3 % apart between the two kinds of memory), and as soon as two candidates differ by more than 1.5 % (or when
-    the candidates run out) the fastest one is kept and the others are freed.  ``ATLITE_HIP_PLACE=0`` switches this off.
+    the candidates run out) the fastest one is kept and the others are freed.
+    EXPERIMENTAL, off unless ``ATLITE_HIP_PLACE=1``: on the box it was developed on it found the faster kind in three of three
+    processes (fused kernel 2.91-2.92 ms against 3.04 without), over the round's later runs in about half - the probe (this
+    one, or the per-cell pv kernel over the zeroed block as seven cubes) does not predict the fused kernel on the real data
+    reliably enough.
     """
     nbytes = int(n_elems) * 8
-    if os.environ.get("ATLITE_HIP_PLACE", "1") == "0" or not (1 << 30) <= nbytes <= 60 * 10**9:
+    if os.environ.get("ATLITE_HIP_PLACE", "0") != "1" or not (1 << 30) <= nbytes <= 60 * 10**9:
         return ctx.empty((n_elems,))
     S = 1 << 18  # the block as (rows, 2 MiB)
     T = nbytes // (S * 8)

@@ -172,14 +172,14 @@ def test_file_backed_variables_are_inflated_straight_into_their_slots(monkeypatc
 
 
 def test_placed_allocation_keeps_one_block_and_frees_the_other_candidates(ctx, monkeypatch, capfd):
-    """device.alloc_placed: up to three candidates for a large block, a timed read of each, the faster kind of device memory
-    wins (profiles/r03_vram_map.txt).  Whatever it picks, exactly one block stays allocated: twelve rounds of 24 GB would
+    """device.alloc_placed (experimental, ATLITE_HIP_PLACE=1): up to six candidates for a large block, a timed read of each, the
+    fastest wins (profiles/r03_vram_map.txt).  Whatever it picks, exactly one block stays allocated: twelve rounds of 24 GB would
     exhaust the device if the losing candidates leaked."""
     from atlite_amd.device import alloc_placed
 
     n = 3 * 2**30  # elements: 24 GiB
     monkeypatch.setenv("ATLITE_HIP_DEBUG_PLACE", "1")
-    monkeypatch.delenv("ATLITE_HIP_PLACE", raising=False)
+    monkeypatch.setenv("ATLITE_HIP_PLACE", "1")  # (experimental: off by default)
     for _ in range(12):
         b = alloc_placed(ctx, n)
         assert b.size == n and b.ptr
@@ -194,6 +194,6 @@ def test_placed_allocation_keeps_one_block_and_frees_the_other_candidates(ctx, m
     assert small.size == 1000
     # profiling state of the context is what it was
     ctx.set_profiling(False)
-    monkeypatch.delenv("ATLITE_HIP_PLACE")
+    monkeypatch.setenv("ATLITE_HIP_PLACE", "1")
     alloc_placed(ctx, 2**27).free()
     assert ctx._profiling == 0
