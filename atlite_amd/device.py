@@ -125,13 +125,14 @@ def alloc_placed(ctx, n_elems):
     ``ctx.empty((n_elems,))`` for the large, long-lived blocks the fused kernels stream from - with a look at WHERE the driver
     put it.  Device memory has zones (a quarter to a third of it) in which the same access stream runs ~6 % slower, at offsets
     nobody can predict from user space (``profiles/r03_vram_map.txt``).  So for blocks of 1-60 GB up to six candidates (120 GB
-    in all) are allocated one after another, each is read once by a plain one-cube kernel (the per-cell time sum of the runoff converter,
+    in all) are allocated one after another, each is filled with random doubles and read by a plain one-cube kernel (the per-cell time sum of the runoff converter,
     ~0.15 ms per GB; 3 % apart between the two kinds of memory), and as soon as two candidates differ by more than 1.5 % (or when
     the candidates run out) the fastest one is kept and the others are freed.
     EXPERIMENTAL, off unless ``ATLITE_HIP_PLACE=1``: on the box it was developed on it found the faster kind in three of three
-    processes (fused kernel 2.91-2.92 ms against 3.04 without), over the round's later runs in about half - the probe (this
-    one, or the per-cell pv kernel over the zeroed block as seven cubes) does not predict the fused kernel on the real data
-    reliably enough.
+    processes (fused kernel 2.91-2.92 ms against 3.04 without); reading whatever the block happened to hold, or zeros, the
+    probe then failed to predict the fused kernel on later boxes (about half right); reading random doubles its pick was the
+    fast kind in eight of eight processes - on two boxes whose first allocation was no slow one either, so the evidence is
+    not in yet.
     """
     nbytes = int(n_elems) * 8
     if os.environ.get("ATLITE_HIP_PLACE", "0") != "1" or not (1 << 30) <= nbytes <= 60 * 10**9:
@@ -140,6 +141,8 @@ def alloc_placed(ctx, n_elems):
     T = nbytes // (S * 8)
 
     def probe(block, warm):
+        if os.environ.get("ATLITE_HIP_PLACE_FILL", "1") == "1":  # read what a cube holds - random doubles - not whatever lies there
+            check(ctx.lib.atl_synth_field(ctx.handle, _lib.SYN_UNIFORM, 12345, 1, 0.0, 1000.0, 0, T, S, block.ptr))
         view = DeviceArray(ctx, block.ptr, (T, S), owned=False)
         ms = []
         for i in range(warm + 6):
