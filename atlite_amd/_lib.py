@@ -240,6 +240,15 @@ SIGNATURES = {
     "atl_allgather_time": (_i, [_vp, _vp, _i64, _i64, _vp, _i64]),
     "atl_allreduce_sum": (_i, [_vp, _vp, _i64]),
     "atl_allgather_time_v": (_i, [_vp, _vp, _i64, c_int64_p, _vp, _i64]),
+    "atl_allgather_time_v_async": (_i, [_vp, _vp, _i64, c_int64_p, _vp, _i64, C.POINTER(_i64)]),
+    "atl_comm_wait": (_i, [_vp, _i64]),
+    "atl_comm_sync": (_i, [_vp]),
+    "atl_comm_init_all": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp)]),
+    "atl_comm_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "atl_capture_begin": (_i, [_vp]),
+    "atl_capture_end": (_i, [_vp, C.POINTER(_vp)]),
+    "atl_graph_launch": (_i, [_vp, _vp]),
+    "atl_graph_destroy": (_i, [_vp]),
     "atl_set_slot_stride": (_i, [_vp, _i64]),
     "atl_copy_2d": (_i, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_size_t, _i, _i]),
     "atl_comm_group_create": (_i, [_i, C.POINTER(_vp)]),

@@ -219,14 +219,23 @@ ATL_HD __forceinline__ double pv_tail(double direct, double diffuse, double infl
 // Datasets that store the total influx and the reflected outflux instead of a direct / diffuse split and an albedo
 // (SARAH-shaped, irradiation.py:202-205, 128-139): the Reindl split with the "simple" clearsky model (:33-42) and
 // albedo = outflux / influx.  pvx_cell evaluates the same expressions (both clearsky models) for the general kernel.
-ATL_HD __forceinline__ void reindl_simple(double infl, double toa, double sa, double *direct, double *diffuse) {
+// ENH: the "enhanced" clearsky model (:43-64), which also reads the air temperature and the relative humidity
+template <bool ENH = false>
+ATL_HD __forceinline__ void reindl_split(double infl, double toa, double sa, double tmp, double rh, double *direct,
+                                             double *diffuse) {
     const double influx = np_clip(infl, 0.0, toa);
     const double kk = guarded_div(influx, toa);
     const double m1 = (kk > 0.0 && kk <= 0.3) ? 1.0 : 0.0, m2 = (kk > 0.3 && kk < 0.78) ? 1.0 : 0.0,
                  m3 = (kk >= 0.78) ? 1.0 : 0.0;
-    const double fraction = m1 * fmin(1.0, 1.020 - 0.254 * kk + 0.0123 * sa) +
-                            m2 * fmin(0.97, fmax(0.1, 1.400 - 1.749 * kk + 0.177 * sa)) +
-                            m3 * fmax(0.1, 0.486 * kk - 0.182 * sa);
+    double fraction;
+    if constexpr (ENH)
+        fraction = m1 * fmin(1.0, 1.000 - 0.232 * kk + 0.0239 * sa - 0.000682 * tmp + 0.0195 * rh) +
+                   m2 * fmin(0.97, fmax(0.1, 1.329 - 1.716 * kk + 0.267 * sa - 0.00357 * tmp + 0.106 * rh)) +
+                   m3 * fmax(0.1, 0.426 * kk - 0.256 * sa + 0.00349 * tmp + 0.0734 * rh);
+    else
+        fraction = m1 * fmin(1.0, 1.020 - 0.254 * kk + 0.0123 * sa) +
+                   m2 * fmin(0.97, fmax(0.1, 1.400 - 1.749 * kk + 0.177 * sa)) +
+                   m3 * fmax(0.1, 0.486 * kk - 0.182 * sa);
     *diffuse = influx * fraction;
     *direct = influx - *diffuse;
 }
@@ -236,13 +245,13 @@ ATL_HD __forceinline__ double albedo_from_outflux(double outf, double influx) {
 }
 
 // fixed panel, stored angles, influx / outflux dataset: the head above, then the family's usual tail
-template <int TAIL = kTailHuld>
-ATL_HD __forceinline__ double pv_cell_influx(double infl, double outf, double toa, double tmp, double alt, double az,
-                                                 const PvOri &o, const PvConst &k) {
+template <int TAIL = kTailHuld, bool ENH = false>
+ATL_HD __forceinline__ double pv_cell_influx(double infl, double outf, double toa, double tmp, double rh, double alt,
+                                                 double az, const PvOri &o, const PvConst &k) {
     double sa, ca;
     lean_sincos(alt, &sa, &ca);
     double direct, diffuse;
-    reindl_simple(infl, toa, sa, &direct, &diffuse);
+    reindl_split<ENH>(infl, toa, sa, tmp, rh, &direct, &diffuse);
     const double influx = direct + diffuse;
     if ((alt < k.alt_thr) || (influx <= 0.01)) return 0.0;
     const double alb = albedo_from_outflux(outf, influx);
@@ -362,19 +371,30 @@ ATL_HD __forceinline__ PvPlain pv_cell_sp_plain(double dir, double dif, double t
 // clips are plain min / max, and the two divisions take the guarded reciprocal path whenever the cell is not capped
 // (toa >= influx > 0.01 then).  Anything else - non-finite inputs, a toa outside the reciprocal's range - is handed to
 // pv_cell_influx.
-ATL_HD __forceinline__ PvPlain pv_cell_influx_plain(double infl, double outf, double toa, double tmp, double alt, double az,
-                                                        const PvOri &o, const PvConst &k) {
+template <bool ENH = false>
+ATL_HD __forceinline__ PvPlain pv_cell_influx_plain(double infl, double outf, double toa, double tmp, double rh, double alt,
+                                                        double az, const PvOri &o, const PvConst &k) {
     const double inf = __builtin_inf();
     const bool div_ok = toa > 0x1.0p-400 && toa < 0x1.0p400;
     bool plain = __builtin_fabs(infl) < inf && __builtin_fabs(outf) < 0x1.0p400 && div_ok && __builtin_fabs(tmp) < inf &&
                  __builtin_fabs(alt) < 0x1.0p30 && __builtin_fabs(az) < 0x1.0p29 && __builtin_fabs(o.saz) < 0x1.0p29;
+    if constexpr (ENH) plain = plain && __builtin_fabs(rh) < inf;
     double sa, ca;
     sincos_core(alt, &sa, &ca);
     const double influx_c = __builtin_fmin(__builtin_fmax(infl, 0.0), toa);
     const double kk = fast_div(influx_c, div_ok ? toa : 1.0);
-    const double f1 = __builtin_fmin(1.0, 1.020 - 0.254 * kk + 0.0123 * sa);
-    const double f2 = __builtin_fmin(0.97, __builtin_fmax(0.1, 1.400 - 1.749 * kk + 0.177 * sa));
-    const double f3 = __builtin_fmax(0.1, 0.486 * kk - 0.182 * sa);
+    double f1, f2, f3;
+    if constexpr (ENH) {
+        f1 = __builtin_fmin(1.0, 1.000 - 0.232 * kk + 0.0239 * sa - 0.000682 * tmp + 0.0195 * rh);
+        f2 = __builtin_fmin(0.97, __builtin_fmax(0.1, 1.329 - 1.716 * kk + 0.267 * sa - 0.00357 * tmp + 0.106 * rh));
+        f3 = __builtin_fmax(0.1, 0.426 * kk - 0.256 * sa + 0.00349 * tmp + 0.0734 * rh);
+        // a candidate that overflowed would be a NaN / inf times a zero mask in the literal sum: hand those over
+        plain = plain && __builtin_fabs(f1) < inf && __builtin_fabs(f2) < inf && __builtin_fabs(f3) < inf;
+    } else {
+        f1 = __builtin_fmin(1.0, 1.020 - 0.254 * kk + 0.0123 * sa);
+        f2 = __builtin_fmin(0.97, __builtin_fmax(0.1, 1.400 - 1.749 * kk + 0.177 * sa));
+        f3 = __builtin_fmax(0.1, 0.486 * kk - 0.182 * sa);
+    }
     const double fraction = (kk >= 0.78) ? f3 : (kk > 0.3) ? f2 : (kk > 0.0) ? f1 : 0.0;
     const double diffuse = influx_c * fraction;
     const double direct = influx_c - diffuse;
@@ -399,13 +419,14 @@ ATL_HD __forceinline__ double pv_cell_auto(double dir, double dif, double toa, d
 
 // the influx / outflux head: what the kernels evaluate for one cell (PvConvT::compute does the lane's pair side by
 // side; the host probe calls this)
-ATL_HD __forceinline__ double pv_cell_influx_auto(double infl, double outf, double toa, double tmp, double alt, double az,
-                                                      const PvOri &o, const PvConst &k) {
-    if constexpr (ATL_PV_PLAIN != 0) {
-        const PvPlain p = pv_cell_influx_plain(infl, outf, toa, tmp, alt, az, o, k);
+template <int TAIL = kTailHuld, bool ENH = false>
+ATL_HD __forceinline__ double pv_cell_influx_auto(double infl, double outf, double toa, double tmp, double rh, double alt,
+                                                      double az, const PvOri &o, const PvConst &k) {
+    if constexpr (ATL_PV_PLAIN != 0 && TAIL == kTailHuld) {
+        const PvPlain p = pv_cell_influx_plain<ENH>(infl, outf, toa, tmp, rh, alt, az, o, k);
         if (p.ok) return p.r;
     }
-    return pv_cell_influx<kTailHuld>(infl, outf, toa, tmp, alt, az, o, k);
+    return pv_cell_influx<TAIL, ENH>(infl, outf, toa, tmp, rh, alt, az, o, k);
 }
 
 // same, with the solar position computed from the separable tables instead of read:
@@ -442,15 +463,18 @@ ATL_HD __forceinline__ double pv_cell_sp(double dir, double dif, double toa, dou
 // goes through the general kernel).
 // TRACK: a tracker (pv(tracking=...)) with the Huld panel, either trigon model, scalar or per-cell orientation
 // and stored solar angles - the ways trackers are used with pv(); other mixes stay general.
-// HEAD: 1 = influx / outflux dataset (Reindl split + albedo from outflux; stored angles, Huld panel, fixed
-// orientation): influx rides in Raw::dir, outflux in Raw::alb, the diffuse slot is not loaded (48 B/cell).
+// HEAD: 1 / 2 = influx / outflux dataset (Reindl split with the "simple" / the "enhanced" clearsky model + albedo from
+// outflux; stored angles, Huld panel after either trigon model, fixed panel): influx rides in Raw::dir, outflux in Raw::alb,
+// the diffuse slot carries the relative humidity of the enhanced model or is not loaded (48 / 56 B/cell).
 template <bool SP, bool PC = false, bool SKIP = false, int TAIL = kTailHuld, int TRACK = ATL_TRACK_NONE, int HEAD = 0>
 struct PvConvT {
-    static_assert(HEAD == 0 || (!SP && TAIL == kTailHuld && TRACK == ATL_TRACK_NONE), "influx head: stored angles, Huld panel, no tracker");
+    static_assert(HEAD >= 0 && HEAD <= 2, "HEAD: 0 direct / diffuse / albedo, 1 influx / outflux (simple clearsky model), 2 (enhanced)");
+    static_assert(HEAD == 0 || (!SP && (TAIL == kTailHuld || TAIL == kTailHuldHayDavies) && TRACK == ATL_TRACK_NONE),
+                  "influx head: stored angles, Huld panel, no tracker");
     static_assert(TAIL == kTailHuld || !SP, "the tails other than the Huld panel after the simple trigon model are built for stored angles");
     static_assert(TRACK == ATL_TRACK_NONE || !SP, "trackers: stored angles");
     // the MFMA-carrying instantiation (dense matrices) only for pv() with its defaults: rare options x rare matrices
-    static constexpr bool kDenseOk = TAIL == kTailHuld && TRACK == ATL_TRACK_NONE && !PC;
+    static constexpr bool kDenseOk = TAIL == kTailHuld && TRACK == ATL_TRACK_NONE && !PC && HEAD == 0;
     // the members of the family compiled in atl_kernels_pvt.hip / atl_kernels_pvk.hip (tails other than the Huld
     // panel, trackers) exist for vectorised launches only; odd cell counts / unaligned cubes take the general kernel
     // ... and so do the early-out converters: their results are the bits of the converters that read every byte, whose
@@ -551,7 +575,7 @@ struct PvConvT {
 #define ATL_PV_BOFTRK_WAVES 3  // bofinger panel behind a tracker, the family's largest converters: 3 waves with 16-80 B of
                                // scratch beat 2 waves without (C2: 3.23 vs 3.50 ms horizontal, 3.62 vs 4.00 ms tilted + Hay-Davies + per-cell)
 #endif
-    static constexpr int kCubes = SP ? 5 : 7;  // cubes streamed per slot (fused kernel: how short a chunk may get)
+    static constexpr int kCubes = SP ? 5 : HEAD == 1 ? 6 : 7;  // cubes streamed per slot (fused kernel: how short a chunk may get)
     static constexpr int kMinWaves = (kNightPipe && !PC && HEAD == 0 && TAIL == kTailHuld && TRACK == ATL_TRACK_NONE) ? (SP ? ATL_SP_NIGHT_WAVES : 4)
                                      : (tail_panel(TAIL) == kTailBofinger && TRACK != ATL_TRACK_NONE) ? ATL_PV_BOFTRK_WAVES
                                      : (kNightPipe && TRACK != ATL_TRACK_NONE)                        ? ATL_PV_TRKNIGHT_WAVES
@@ -587,9 +611,10 @@ struct PvConvT {
     __device__ __forceinline__ Raw rest_load(int64_t slot, int64_t c0, int64_t c1, const Cell &c) const {
         const int64_t off = slot * S;
         Raw r;
-        if constexpr (HEAD == 1) {
+        if constexpr (HEAD != 0) {
             r.dir = ld2<VEC>(in.d_influx, off, c0, c1);
             r.dif = double2{0.0, 0.0};
+            if constexpr (HEAD == 2) r.dif = ld2<VEC>(in.d_humidity, off, c0, c1);
             r.alb = ld2<VEC>(in.d_outflux, off, c0, c1);
         } else {
             r.dir = ld2<VEC>(in.d_influx_direct, off, c0, c1);
@@ -623,9 +648,10 @@ struct PvConvT {
     __device__ __forceinline__ Raw load(int64_t slot, int i, int64_t c0, int64_t c1, const Cell &c, Carry &carry) const {
         const int64_t off = slot * S;
         Raw r;
-        if constexpr (HEAD == 1) {
+        if constexpr (HEAD != 0) {
             r.dir = ld2<VEC>(in.d_influx, off, c0, c1);
             r.dif = double2{0.0, 0.0};
+            if constexpr (HEAD == 2) r.dif = ld2<VEC>(in.d_humidity, off, c0, c1);
             r.alb = ld2<VEC>(in.d_outflux, off, c0, c1);
         } else {
             r.dir = ld2<VEC>(in.d_influx_direct, off, c0, c1);
@@ -683,31 +709,33 @@ struct PvConvT {
                 r.x = v0 ? pv_cell_sp(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.sd, q.cd, c.sl0, c.cl0, q.a.x, q.b.x, o0, a0, k) : 0.0;
                 r.y = v1 ? pv_cell_sp(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.sd, q.cd, c.sl1, c.cl1, q.a.y, q.b.y, o1, a1, k) : 0.0;
             }
-        } else if constexpr (HEAD == 1 && ATL_PV_PLAIN != 0) {
+        } else if constexpr (HEAD != 0 && TAIL == kTailHuld && ATL_PV_PLAIN != 0) {
             // the pair side by side in plain arithmetic, as the direct / diffuse case below (influx rides in dir, outflux
-            // in alb); the dark test reads every loaded value, so no load is sunk behind it
+            // in alb, the humidity of the enhanced clearsky model in dif); the dark test reads every loaded value, so no
+            // load is sunk behind it
+            constexpr bool ENH = HEAD == 2;
             const double inf = __builtin_inf();
             const bool tame = __builtin_fabs(q.dir.x) < inf && __builtin_fabs(q.dir.y) < inf && __builtin_fabs(q.toa.x) < inf &&
                               __builtin_fabs(q.toa.y) < inf && __builtin_fabs(q.alb.x) < inf && __builtin_fabs(q.alb.y) < inf &&
                               __builtin_fabs(q.tmp.x) < inf && __builtin_fabs(q.tmp.y) < inf && __builtin_fabs(q.b.x) < inf &&
-                              __builtin_fabs(q.b.y) < inf;
+                              __builtin_fabs(q.b.y) < inf && (!ENH || (__builtin_fabs(q.dif.x) < inf && __builtin_fabs(q.dif.y) < inf));
             const bool dark0 = !v0 || q.a.x < k.alt_thr, dark1 = !v1 || q.a.y < k.alt_thr;
             r.x = r.y = 0.0;
             if (!(dark0 && dark1 && tame)) {
-                const PvPlain p0 = pv_cell_influx_plain(q.dir.x, q.alb.x, q.toa.x, q.tmp.x, q.a.x, q.b.x, o0, k);
-                const PvPlain p1 = pv_cell_influx_plain(q.dir.y, q.alb.y, q.toa.y, q.tmp.y, q.a.y, q.b.y, o1, k);
+                const PvPlain p0 = pv_cell_influx_plain<ENH>(q.dir.x, q.alb.x, q.toa.x, q.tmp.x, q.dif.x, q.a.x, q.b.x, o0, k);
+                const PvPlain p1 = pv_cell_influx_plain<ENH>(q.dir.y, q.alb.y, q.toa.y, q.tmp.y, q.dif.y, q.a.y, q.b.y, o1, k);
                 r.x = p0.r;
                 r.y = p1.r;
                 if (__builtin_expect(!(p0.ok && p1.ok), 0)) {
-                    r.x = pv_cell_influx<TAIL>(q.dir.x, q.alb.x, q.toa.x, q.tmp.x, q.a.x, q.b.x, o0, k);
-                    r.y = pv_cell_influx<TAIL>(q.dir.y, q.alb.y, q.toa.y, q.tmp.y, q.a.y, q.b.y, o1, k);
+                    r.x = pv_cell_influx<TAIL, ENH>(q.dir.x, q.alb.x, q.toa.x, q.tmp.x, q.dif.x, q.a.x, q.b.x, o0, k);
+                    r.y = pv_cell_influx<TAIL, ENH>(q.dir.y, q.alb.y, q.toa.y, q.tmp.y, q.dif.y, q.a.y, q.b.y, o1, k);
                 }
                 r.x = v0 ? r.x : 0.0;
                 r.y = v1 ? r.y : 0.0;
             }
-        } else if constexpr (HEAD == 1) {
-            r.x = v0 ? pv_cell_influx<TAIL>(q.dir.x, q.alb.x, q.toa.x, q.tmp.x, q.a.x, q.b.x, o0, k) : 0.0;
-            r.y = v1 ? pv_cell_influx<TAIL>(q.dir.y, q.alb.y, q.toa.y, q.tmp.y, q.a.y, q.b.y, o1, k) : 0.0;
+        } else if constexpr (HEAD != 0) {  // (Hay-Davies behind the influx head: the careful routine, cell by cell)
+            r.x = v0 ? pv_cell_influx<TAIL, HEAD == 2>(q.dir.x, q.alb.x, q.toa.x, q.tmp.x, q.dif.x, q.a.x, q.b.x, o0, k) : 0.0;
+            r.y = v1 ? pv_cell_influx<TAIL, HEAD == 2>(q.dir.y, q.alb.y, q.toa.y, q.tmp.y, q.dif.y, q.a.y, q.b.y, o1, k) : 0.0;
         } else if constexpr (TAIL == kTailHuld && TRACK == ATL_TRACK_NONE && ATL_PV_PLAIN != 0) {
             // (in every kernel of the family, so that night skip on / off, fused / per-cell results share their bits)
             // a pair of night cells (or a lane without cells) leaves at once: a wave in the dark skips the math.
@@ -828,22 +856,10 @@ ATL_HD double pvx_cell(double dir, double dif, double infl, double toa, double a
     // ---- direct / diffuse horizontal (irradiation.py:202-208, 13-73) ------------------------
     double direct, diffuse;
     if (o.has_influx) {
-        const double influx = np_clip(infl, 0.0, toa);
-        const double kk = guarded_div(influx, toa);
-        double fraction;
-        const double m1 = (kk > 0.0 && kk <= 0.3) ? 1.0 : 0.0, m2 = (kk > 0.3 && kk < 0.78) ? 1.0 : 0.0,
-                     m3 = (kk >= 0.78) ? 1.0 : 0.0;
-        if (o.clearsky == ATL_CLEARSKY_SIMPLE) {
-            fraction = m1 * fmin(1.0, 1.020 - 0.254 * kk + 0.0123 * sa) +
-                       m2 * fmin(0.97, fmax(0.1, 1.400 - 1.749 * kk + 0.177 * sa)) +
-                       m3 * fmax(0.1, 0.486 * kk - 0.182 * sa);
-        } else {
-            fraction = m1 * fmin(1.0, 1.000 - 0.232 * kk + 0.0239 * sa - 0.000682 * tmp + 0.0195 * rh) +
-                       m2 * fmin(0.97, fmax(0.1, 1.329 - 1.716 * kk + 0.267 * sa - 0.00357 * tmp + 0.106 * rh)) +
-                       m3 * fmax(0.1, 0.426 * kk - 0.256 * sa + 0.00349 * tmp + 0.0734 * rh);
-        }
-        diffuse = influx * fraction;
-        direct = influx - diffuse;
+        if (o.clearsky == ATL_CLEARSKY_SIMPLE)
+            reindl_split<false>(infl, toa, sa, tmp, rh, &direct, &diffuse);
+        else
+            reindl_split<true>(infl, toa, sa, tmp, rh, &direct, &diffuse);
     } else {
         direct = np_clip(dir, 0.0, toa);
         diffuse = np_clip(dif, 0.0, toa - direct);

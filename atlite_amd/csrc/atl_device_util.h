@@ -70,7 +70,26 @@ __device__ __forceinline__ void st2(double *__restrict__ p, int64_t off, bool v0
         t.x = v.x;
         t.y = v.y;
         // (temporal stores instead: wind series 6.0 -> 6.4 ms, pv series 4.2 -> 4.4 ms)
+#if defined(ATL_ST_POLICY) && defined(__HIP_DEVICE_COMPILE__)
+        // experiment (tools/build_variant.sh): the cache policy bits of the result store spelled out.  nt keeps the line
+        // in the XCD's L2 until it is evicted; sc1 / sc0 sc1 write through and drop it (MI355X_MICROARCH.md, store flavours)
+        if (v0 && v1) {
+            double *q = p + off;
+#if ATL_ST_POLICY == 1
+            asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(q), "v"(t) : "memory");
+#elif ATL_ST_POLICY == 2
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(q), "v"(t) : "memory");
+#elif ATL_ST_POLICY == 3
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(q), "v"(t) : "memory");
+#elif ATL_ST_POLICY == 4
+            asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(q), "v"(t) : "memory");
+#else
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(q), "v"(t) : "memory");
+#endif
+        }
+#else
         if (v0 && v1) __builtin_nontemporal_store(t, (gf64x2 *)(p + off));
+#endif
         // the lane that owns the LAST cell of an odd cell count: its second value belongs to nobody (it would land on
         // the next slot's first cell)
         else if (v0) __builtin_nontemporal_store(v.x, p + off);

@@ -249,6 +249,8 @@ struct atl_ctx {
     // slots of the INPUT cubes of the next conversion calls are this many cells apart (atl_set_slot_stride); 0 = the
     // cubes are contiguous (T, S).  The library's own device copies of a cutout pad every slot to a 128-byte line.
     int64_t slot_stride = 0;
+    // atl_capture_begin .. atl_capture_end: the calls in between are recorded into a hipGraph, not executed
+    bool capturing = false;
     // file / narrow-dtype ingest (atl_ingest.hip): staging buffers, created on first use
     void *ingest = nullptr;
     void (*ingest_free)(void *) = nullptr;
@@ -256,6 +258,11 @@ struct atl_ctx {
 
 struct atl_event {
     hipEvent_t ev = nullptr;
+    int device = 0;
+};
+
+struct atl_graph {
+    hipGraphExec_t exec = nullptr;
     int device = 0;
 };
 

@@ -53,12 +53,23 @@ __global__ __launch_bounds__(256) void k_cells_series(Conv conv, int64_t n_slots
     const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
     const int64_t s0 = int64_t(blockIdx.y) * kSeriesSlots;
     const int64_t s1 = min(s0 + int64_t(kSeriesSlots), n_slots);
-    constexpr int G = Conv::kGroup >= 4 ? 4 : Conv::kGroup;
+#ifndef ATL_SERIES_GROUP
+#define ATL_SERIES_GROUP 4
+#endif
+    constexpr int G = Conv::kGroup >= ATL_SERIES_GROUP ? ATL_SERIES_GROUP : Conv::kGroup;
     typename Conv::Carry carry = carry_init<typename Conv::Carry>();
     for (int64_t sg = s0; sg < s1; sg += G) {
         typename Conv::Raw raw[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) raw[g] = conv.template load<VEC>(min(sg + g, s1 - 1), g, s0c, s1c, cell, carry);
+#ifdef ATL_SERIES_BATCH_STORES  // experiment: convert the whole group, then its stores back to back
+        double2 r[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) r[g] = conv.compute(raw[g], v0, v1, cell, lds);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (sg + g < s1) st2<VEC>(out, (sg + g) * S + c0, v0, v1, r[g]);
+#else
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             // lanes without a cell loaded a real cell's data (safe indices) and are masked by the store; the converter is
@@ -67,6 +78,7 @@ __global__ __launch_bounds__(256) void k_cells_series(Conv conv, int64_t n_slots
             const double2 r = conv.compute(raw[g], v0, v1, cell, lds);
             if (sg + g < s1) st2<VEC>(out, (sg + g) * S + c0, v0, v1, r);
         }
+#endif
     }
 }
 
@@ -771,13 +783,13 @@ struct KernelBracket {
     atl_ctx *ctx;
     size_t slot = 0;
     explicit KernelBracket(atl_ctx *c) : ctx(c) {
-        if (ctx->profiling) {
+        if (ctx->profiling && !ctx->capturing) {
             slot = size_t(ctx->ring_count % int64_t(ctx->ev_ring.size() / 2));
             (void)hipEventRecord(ctx->ev_ring[2 * slot], ctx->stream);
         }
     }
     ~KernelBracket() {
-        if (ctx->profiling) {
+        if (ctx->profiling && !ctx->capturing) {
             (void)hipEventRecord(ctx->ev_ring[2 * slot + 1], ctx->stream);
             ++ctx->ring_count;
         }
@@ -1021,13 +1033,16 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
 //  * with an ODD cell count the lane that owns a slot's last cell reads 8 bytes past it: the next slot's first cell or,
 //    in the last slot, 8 bytes past the cube.  Those bytes share the last element's 4 KiB page unless the cube ENDS on
 //    a page boundary - then, and only then, the launch takes the unvectorised instantiation (stores never overrun: st2).
-// (ld = cells between slots, atl_set_slot_stride: a padded slot has the 8 bytes after its last cell to itself.)
+// (ld = cells between slots, atl_set_slot_stride.)
 bool vec_ok(int64_t T, int64_t S, int64_t ld, std::initializer_list<const void *> ptrs) {
     if (no_vec()) return false;
     for (const void *p : ptrs) {
         if (!p) continue;
         if (!aligned8(p)) return false;
-        if ((S & 1) && ld == S && ((reinterpret_cast<uintptr_t>(p) + size_t(T) * size_t(S) * sizeof(double)) & 4095u) == 0) return false;
+        // the final slot's last cell sits (T - 1) * ld + S cells in, whatever the stride is (an unpadded pool of n cubes,
+        // ld = n * S, ends its last cube as abruptly as a contiguous cube does; behind a padded slot's last cell the
+        // address is 8 bytes off a 16-byte boundary and never on a page boundary)
+        if ((S & 1) && T > 0 && ((reinterpret_cast<uintptr_t>(p) + (size_t(T - 1) * size_t(ld) + size_t(S)) * sizeof(double)) & 4095u) == 0) return false;
     }
     return true;
 }

@@ -12,6 +12,11 @@ int pvx_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, i
                 double *d_out);
 int pvx_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S,
                           const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out);
+// atl_kernels_pvi.hip
+int pvi_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S, int time_agg,
+                double *d_out);
+int pvi_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S,
+                          const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out);
 // atl_kernels_pvt.hip
 int pvt_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S, int time_agg,
                 double *d_out);
@@ -29,25 +34,22 @@ namespace {
 #include "atl_conv_pv.h"
 #include "atl_pv_make.h"
 
-// f(converter instance) with the PvConvT instantiation for (stored / computed solar position,
-// scalar / per-cell orientation)
-// influx / outflux datasets the fast family takes: pv() defaults on a SARAH-shaped cutout (total influx + outflux,
-// "simple" clearsky model, stored solar angles, Huld panel, fixed panel, simple trigon model)
+// influx / outflux datasets the fast family takes (atl_kernels_pvi.hip): total influx + outflux, either clearsky model,
+// stored solar angles, the Huld panel on a fixed mount after either trigon model
 bool pv_influx_fast(const atl_pv_inputs *in, const atl_pv_params *p) {
     return in->d_influx && in->d_outflux && !in->d_albedo && !in->d_influx_direct && !in->d_influx_diffuse &&
-           in->d_solar_altitude && in->d_solar_azimuth && in->d_temperature && p->clearsky_model == ATL_CLEARSKY_SIMPLE &&
-           p->panel_model == ATL_PANEL_HULD && p->tracking == ATL_TRACK_NONE && p->trigon_model == ATL_TRIGON_SIMPLE &&
-           p->irradiation == ATL_IRR_TOTAL && !p->orientation_per_time;
+           in->d_solar_altitude && in->d_solar_azimuth && in->d_temperature &&
+           (p->clearsky_model == ATL_CLEARSKY_SIMPLE || (p->clearsky_model == ATL_CLEARSKY_ENHANCED && in->d_humidity)) &&
+           p->panel_model == ATL_PANEL_HULD && p->tracking == ATL_TRACK_NONE &&
+           (p->trigon_model == ATL_TRIGON_SIMPLE || p->trigon_model == ATL_TRIGON_OTHER) && p->irradiation == ATL_IRR_TOTAL &&
+           !p->orientation_per_time;
 }
 
+// f(converter instance) with the PvConvT instantiation for (stored / computed solar position,
+// scalar / per-cell orientation)
 template <class F>
 int pv_dispatch(const atl_pv_inputs *in, const atl_pv_params *p, bool allow_skip, F &&f) {
     const bool sp = !(in->d_solar_altitude || in->d_solar_azimuth), pc = p->d_cell_slope != nullptr;
-    if (pv_influx_fast(in, p)) {
-        if (p->night_skip && allow_skip)
-            return pc ? f(PvConvT<false, true, true, kTailHuld, ATL_TRACK_NONE, 1>()) : f(PvConvT<false, false, true, kTailHuld, ATL_TRACK_NONE, 1>());
-        return pc ? f(PvConvT<false, true, false, kTailHuld, ATL_TRACK_NONE, 1>()) : f(PvConvT<false, false, false, kTailHuld, ATL_TRACK_NONE, 1>());
-    }
     if (p->trigon_model == ATL_TRIGON_OTHER) {  // Hay-Davies with stored angles (pv_needs_general); other panels: pv_other_tail
         if (p->night_skip && allow_skip)
             return pc ? f(PvConvT<false, true, true, kTailHuldHayDavies>()) : f(PvConvT<false, false, true, kTailHuldHayDavies>());
@@ -101,6 +103,7 @@ int atl_pv_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p
                    int time_agg, double *d_out) {
     ATL_REQUIRE(ctx && in && p, "atl_pv_convert: ctx/inputs/params is NULL");
     if (pv_needs_general(in, p)) return pvx_convert(ctx, in, p, T, S, time_agg, d_out);
+    if (pv_influx_fast(in, p)) return pvi_convert(ctx, in, p, T, S, time_agg, d_out);
     if (pv_other_tail(in, p)) return pvt_convert(ctx, in, p, T, S, time_agg, d_out);
     if (pv_tracked(in, p)) return pvk_convert(ctx, in, p, T, S, time_agg, d_out);
     bool vec;
@@ -120,6 +123,7 @@ int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv
                              int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out) {
     ATL_REQUIRE(ctx && in && p, "atl_pv_convert_aggregate: ctx/inputs/params is NULL");
     if (pv_needs_general(in, p)) return pvx_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);
+    if (pv_influx_fast(in, p)) return pvi_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);
     if (pv_other_tail(in, p)) return pvt_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);
     if (pv_tracked(in, p)) return pvk_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);
     bool vec;

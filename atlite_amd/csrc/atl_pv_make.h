@@ -9,6 +9,10 @@ int make_pv(const atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p,
     ATL_REQUIRE(T >= 0 && S >= 0, "atl_pv: negative shape");
     if (in->d_influx) {  // the influx / outflux head (pv_influx_fast)
         ATL_REQUIRE(in->d_outflux && in->d_influx_toa, "atl_pv: an influx dataset needs outflux and influx_toa here");
+        ATL_REQUIRE(p->clearsky_model == ATL_CLEARSKY_SIMPLE || p->clearsky_model == ATL_CLEARSKY_ENHANCED,
+                    "`clearsky model` must be chosen from 'simple' and 'enhanced'");
+        ATL_REQUIRE(p->clearsky_model == ATL_CLEARSKY_SIMPLE || in->d_humidity,
+                    "atl_pv: the enhanced clearsky model needs temperature and humidity");
     } else {
         ATL_REQUIRE(in->d_influx_direct && in->d_influx_diffuse && in->d_influx_toa,
                     "atl_pv: need influx_direct, influx_diffuse and influx_toa (irradiation.py:209-213)");
@@ -49,6 +53,7 @@ int make_pv(const atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p,
     c->cell_slope = p->d_cell_slope;
     c->cell_azimuth = p->d_cell_azimuth;
     *vec = vec_ok(T, S, ld, {in->d_influx_direct, in->d_influx_diffuse, in->d_influx_toa, in->d_albedo,
-                      in->d_temperature, in->d_solar_altitude, in->d_solar_azimuth, in->d_influx, in->d_outflux});
+                      in->d_temperature, in->d_solar_altitude, in->d_solar_azimuth, in->d_influx, in->d_outflux,
+                      in->d_influx && p->clearsky_model == ATL_CLEARSKY_ENHANCED ? in->d_humidity : nullptr});
     return ATL_OK;
 }

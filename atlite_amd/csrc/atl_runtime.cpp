@@ -44,6 +44,11 @@ void set_error(const char *fmt, ...) {
 int scratch_reserve(atl_ctx *ctx, size_t bytes, void **out) {
     bytes = align_up(bytes ? bytes : 256, 256);
     if (bytes > ctx->scratch_bytes) {
+        if (ctx->capturing) {
+            set_error("the scratch arena would have to grow (%zu -> %zu bytes) inside atl_capture_begin / atl_capture_end: "
+                      "run the sequence once before capturing it", ctx->scratch_bytes, bytes);
+            return ATL_E_INVALID;
+        }
         // stream-ordered: earlier kernels may still read the old arena
         ATL_HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->scratch) ATL_HIP_TRY(hipFree(ctx->scratch));
@@ -385,6 +390,51 @@ int atl_stream_wait_event(atl_ctx *ctx, int which_stream, atl_event *ev) {
 int atl_event_synchronize(atl_event *ev) {
     ATL_REQUIRE(ev, "atl_event_synchronize: ev is NULL");
     ATL_HIP_TRY(hipEventSynchronize(ev->ev));
+    return ATL_OK;
+}
+
+int atl_capture_begin(atl_ctx *ctx) {
+    ATL_REQUIRE(ctx, "atl_capture_begin: ctx is NULL");
+    ATL_REQUIRE(!ctx->capturing, "atl_capture_begin: a capture is already open on this context");
+    ATL_HIP_TRY(hipSetDevice(ctx->device));
+    ATL_HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
+    return ATL_OK;
+}
+
+int atl_capture_end(atl_ctx *ctx, atl_graph **out) {
+    ATL_REQUIRE(ctx && out, "atl_capture_end: bad argument");
+    *out = nullptr;
+    ATL_REQUIRE(ctx->capturing, "atl_capture_end: no capture is open on this context");
+    ctx->capturing = false;
+    hipGraph_t g = nullptr;
+    ATL_HIP_TRY(hipStreamEndCapture(ctx->stream, &g));
+    ATL_REQUIRE(g, "atl_capture_end: the capture was invalidated (a call between begin and end synchronised or allocated)");
+    hipGraphExec_t ex = nullptr;
+    hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) {
+        set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        return ATL_E_HIP;
+    }
+    atl_graph *a = new atl_graph();
+    a->exec = ex;
+    a->device = ctx->device;
+    *out = a;
+    return ATL_OK;
+}
+
+int atl_graph_launch(atl_ctx *ctx, atl_graph *graph) {
+    ATL_REQUIRE(ctx && graph && graph->exec, "atl_graph_launch: bad argument");
+    ATL_REQUIRE(graph->device == ctx->device, "atl_graph_launch: the graph was captured on device %d", graph->device);
+    ATL_HIP_TRY(hipGraphLaunch(graph->exec, ctx->stream));
+    return ATL_OK;
+}
+
+int atl_graph_destroy(atl_graph *graph) {
+    if (!graph) return ATL_OK;
+    if (graph->exec) (void)hipGraphExecDestroy(graph->exec);
+    delete graph;
     return ATL_OK;
 }
 
@@ -920,14 +970,25 @@ int atl_pv_probe_host(const atl_pv_params *p, int family, int64_t n, const doubl
             return int(ATL_OK);
         });
     }
-    // the fast family's influx / outflux head (pv_influx_fast in atl_kernels_pv.hip): Reindl split + albedo from outflux
+    // the fast family's influx / outflux head (pv_influx_fast, atl_kernels_pvi.hip): Reindl split (either clearsky model) +
+    // albedo from outflux, then the Huld panel after either trigon model
     if (family == 0 && infl && outf && !dir && !dif && !alb) {
-        ATL_REQUIRE(tmp && p->tracking == ATL_TRACK_NONE && p->trigon_model == ATL_TRIGON_SIMPLE &&
-                        p->clearsky_model == ATL_CLEARSKY_SIMPLE && p->panel_model == ATL_PANEL_HULD && p->irradiation == ATL_IRR_TOTAL,
-                    "atl_pv_probe_host: the influx / outflux head serves pv() with its defaults only");
+        ATL_REQUIRE(tmp && p->tracking == ATL_TRACK_NONE && (p->trigon_model == ATL_TRIGON_SIMPLE || p->trigon_model == ATL_TRIGON_OTHER) &&
+                        (p->clearsky_model == ATL_CLEARSKY_SIMPLE || (p->clearsky_model == ATL_CLEARSKY_ENHANCED && hum)) &&
+                        p->panel_model == ATL_PANEL_HULD && p->irradiation == ATL_IRR_TOTAL,
+                    "atl_pv_probe_host: the influx / outflux head serves the Huld panel on a fixed mount (either trigon / clearsky model)");
+        const bool hd = p->trigon_model == ATL_TRIGON_OTHER, enh = p->clearsky_model == ATL_CLEARSKY_ENHANCED;
         for (int64_t i = 0; i < n; ++i) {
-            const PvOri o = PvConvT<false, true, false, kTailHuld>::make_ori(slope[i], pazim[i]);
-            h_out[i] = pv_cell_influx_auto(infl[i], outf[i], toa[i], tmp[i], alt[i], az[i], o, k);
+            const double rh = at(hum, i);
+            if (hd) {
+                const PvOri o = PvConvT<false, true, false, kTailHuldHayDavies>::make_ori(slope[i], pazim[i]);
+                h_out[i] = enh ? pv_cell_influx_auto<kTailHuldHayDavies, true>(infl[i], outf[i], toa[i], tmp[i], rh, alt[i], az[i], o, k)
+                               : pv_cell_influx_auto<kTailHuldHayDavies, false>(infl[i], outf[i], toa[i], tmp[i], rh, alt[i], az[i], o, k);
+            } else {
+                const PvOri o = PvConvT<false, true, false, kTailHuld>::make_ori(slope[i], pazim[i]);
+                h_out[i] = enh ? pv_cell_influx_auto<kTailHuld, true>(infl[i], outf[i], toa[i], tmp[i], rh, alt[i], az[i], o, k)
+                               : pv_cell_influx_auto<kTailHuld, false>(infl[i], outf[i], toa[i], tmp[i], rh, alt[i], az[i], o, k);
+            }
         }
         return ATL_OK;
     }

@@ -120,65 +120,6 @@ def interleave_enabled():
     return os.environ.get("ATLITE_HIP_INTERLEAVE", "1") != "0"
 
 
-def alloc_placed(ctx, n_elems):
-    """
-    ``ctx.empty((n_elems,))`` for the large, long-lived blocks the fused kernels stream from - with a look at WHERE the driver
-    put it.  Device memory has zones (a quarter to a third of it) in which the same access stream runs ~6 % slower, at offsets
-    nobody can predict from user space (``profiles/r03_vram_map.txt``).  So for blocks of 1-60 GB up to six candidates (120 GB
-    in all) are allocated one after another, each is filled with random doubles and read by a plain one-cube kernel (the per-cell time sum of the runoff converter,
-    ~0.15 ms per GB; 3 % apart between the two kinds of memory), and as soon as two candidates differ by more than 1.5 % (or when
-    the candidates run out) the fastest one is kept and the others are freed.
-    EXPERIMENTAL, off unless ``ATLITE_HIP_PLACE=1``: on the box it was developed on it found the faster kind in three of three
-    processes (fused kernel 2.91-2.92 ms against 3.04 without); reading whatever the block happened to hold, or zeros, the
-    probe then failed to predict the fused kernel on later boxes (about half right); reading random doubles its pick was the
-    fast kind in eight of eight processes - on two boxes whose first allocation was no slow one either, so the evidence is
-    not in yet.
-    """
-    nbytes = int(n_elems) * 8
-    if os.environ.get("ATLITE_HIP_PLACE", "0") != "1" or not (1 << 30) <= nbytes <= 60 * 10**9:
-        return ctx.empty((n_elems,))
-    S = 1 << 18  # the block as (rows, 2 MiB)
-    T = nbytes // (S * 8)
-
-    def probe(block, warm):
-        if os.environ.get("ATLITE_HIP_PLACE_FILL", "1") == "1":  # read what a cube holds - random doubles - not whatever lies there
-            check(ctx.lib.atl_synth_field(ctx.handle, _lib.SYN_UNIFORM, 12345, 1, 0.0, 1000.0, 0, T, S, block.ptr))
-        view = DeviceArray(ctx, block.ptr, (T, S), owned=False)
-        ms = []
-        for i in range(warm + 6):
-            ctx.runoff(view, None, T, S, time_agg="sum")
-            ms.append(ctx.last_kernel_ms())
-        return float(np.min(ms[warm:]))  # (a memory-bound kernel: the minimum is the stable figure)
-
-    cands = []
-    was = getattr(ctx, "_profiling", 0)
-    ctx.set_profiling(True)
-    try:
-        for i in range(max(2, min(6, int(120 * 10**9 // nbytes)))):  # (a slow zone can be 64 GiB long)
-            try:
-                block = ctx.empty((n_elems,))
-            except Exception:  # noqa: BLE001 - no room for another candidate
-                break
-            cands.append((probe(block, 10 if i == 0 else 2), block))  # (the first one also brings the clocks up)
-            ts = [t for t, _ in cands]
-            if len(ts) >= 2 and max(ts) > 1.015 * min(ts):
-                break
-    finally:
-        ctx.set_profiling(was)
-    if not cands:
-        return ctx.empty((n_elems,))
-    best = min(cands, key=lambda c: c[0])[1]  # (among three alike any will do)
-    if os.environ.get("ATLITE_HIP_DEBUG_PLACE"):
-        import sys
-
-        print("[atlite-hip] placement probe (ms per read of %.1f GB): %s -> candidate %d" % (
-            nbytes / 1e9, " ".join(f"{t:.3f}" for t, _ in cands), [b for _, b in cands].index(best)), file=sys.stderr)
-    for _, b in cands:
-        if b is not best:
-            b.free()
-    return best
-
-
 class SlotPool:
     """
     One allocation that holds the ``n`` (T, S) cubes a conversion reads slot-interleaved: cube ``v`` of time step ``t``
@@ -194,7 +135,7 @@ class SlotPool:
         self.Sp = int(Sp or S)
         assert self.Sp >= self.S and self.names
         self.ld = len(self.names) * self.Sp
-        self.base = alloc_placed(ctx, max(self.T * self.ld, 1))
+        self.base = ctx.empty((max(self.T * self.ld, 1),))
         if self.Sp > self.S:  # the padding is never read as data; keep it free of stray NaN patterns
             check(ctx.lib.atl_memset(ctx.handle, self.base.ptr, 0, self.base.nbytes))
 
@@ -215,25 +156,28 @@ class AggPlan:
         self.ctx = ctx
         self.shape = m.shape
         # the tile shape depends on whether the slots of the cubes the plan will meet start on 128-byte lines
-        check(ctx.lib.atl_set_slot_stride(ctx.handle, int(ld) if ld and int(ld) != m.shape[1] else 0))
         indptr = np.ascontiguousarray(m.indptr, dtype=np.int64)
         indices = np.ascontiguousarray(m.indices, dtype=np.int32)
         data = np.ascontiguousarray(m.data, dtype=np.float64)
         h = C.c_void_p()
-        check(
-            ctx.lib.atl_agg_create(
-                ctx.handle,
-                m.shape[0],
-                m.shape[1],
-                int(row_len) if row_len and m.shape[1] % int(row_len) == 0 else 0,
-                indptr.ctypes.data,
-                indices.ctypes.data if indices.size else None,
-                data.ctypes.data if data.size else None,
-                C.byref(h),
+        self.handle = None
+        check(ctx.lib.atl_set_slot_stride(ctx.handle, int(ld) if ld and int(ld) != m.shape[1] else 0))
+        try:  # the stride is call-scoped: a rejected matrix must not leave it set
+            check(
+                ctx.lib.atl_agg_create(
+                    ctx.handle,
+                    m.shape[0],
+                    m.shape[1],
+                    int(row_len) if row_len and m.shape[1] % int(row_len) == 0 else 0,
+                    indptr.ctypes.data,
+                    indices.ctypes.data if indices.size else None,
+                    data.ctypes.data if data.size else None,
+                    C.byref(h),
+                )
             )
-        )
+        finally:
+            ctx.lib.atl_set_slot_stride(ctx.handle, 0)
         self.handle = h
-        check(ctx.lib.atl_set_slot_stride(ctx.handle, 0))
 
     def info(self):
         v = [C.c_int64() for _ in range(4)] + [C.c_int32(), C.c_int32()]
@@ -299,18 +243,10 @@ class Context:
             check(self.lib.atl_copy_2d(self.handle, a.ptr, a.ld * es, host.ctypes.data, host.shape[1] * es,
                                        host.shape[1] * es, host.shape[0], 0, 0))
             return a
-        a = self.empty_placed(host.shape, dtype)
+        a = self.empty(host.shape, dtype)
         if host.size:
             check(self.lib.atl_upload(self.handle, a.ptr, host.ctypes.data, host.nbytes))
         return a
-
-    def empty_placed(self, shape, dtype=np.float64):
-        """``empty`` for long-lived input blocks: large fp64 ones go through ``alloc_placed`` (the faster kind of device memory)."""
-        shape = (shape,) if np.isscalar(shape) else tuple(int(v) for v in shape)
-        if np.dtype(dtype) != np.float64:
-            return self.empty(shape, dtype)
-        a = alloc_placed(self, int(np.prod(shape, dtype=np.int64)))
-        return a if a.shape == shape else a.reshape(shape)
 
     def empty_pitched(self, shape, ld, dtype=np.float64):
         """(T, S) block with rows ``ld`` elements apart; the padding is zeroed (never read as data, but a stray NaN
@@ -318,7 +254,7 @@ class Context:
         T, S = (int(v) for v in shape)
         ld = int(ld)
         assert ld >= S
-        base = self.empty_placed((max(T * ld, 1),), dtype)
+        base = self.empty((max(T * ld, 1),), dtype)
         if ld > S:
             check(self.lib.atl_memset(self.handle, base.ptr, 0, base.nbytes))
         return DeviceArray(self, base.ptr, (T, S), dtype, owner=base, ld=ld) if ld > S else base.reshape(T, S)
@@ -636,7 +572,7 @@ class Context:
 
     # -- synthetic fields -------------------------------------------------------------------
     def synth_field(self, kind, seed, var_id, p0, p1, T, S, per_cell_static=False):
-        out = self.empty_placed((S,) if per_cell_static else (T, S))  # (an input cube like any the library uploads)
+        out = self.empty((S,) if per_cell_static else (T, S))
         check(self.lib.atl_synth_field(self.handle, kind, seed, var_id, p0, p1, 1 if per_cell_static else 0,
                                        1 if per_cell_static else T, S, out.ptr))
         return out

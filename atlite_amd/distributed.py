@@ -123,6 +123,59 @@ class RcclComm:
         check(ctx.lib.atl_comm_init(ctx.handle, self.n_ranks, self.rank, buf, C.byref(h)))
         self.handle = h
 
+    @classmethod
+    def init_all(cls, ctxs):
+        """The communicators of ``ctxs`` (distinct devices of THIS process), rank r on ``ctxs[r]``, created by one thread
+        inside one ncclGroupStart / ncclGroupEnd bracket (``atl_comm_init_all``) - N threads each calling
+        ``ncclCommInitRank`` on its own is the pattern that can wait for itself for good."""
+        import ctypes as C
+
+        from ._lib import check
+
+        n = len(ctxs)
+        hs = (C.c_void_p * n)(*[c.handle.value if hasattr(c.handle, "value") else c.handle for c in ctxs])
+        out = (C.c_void_p * n)()
+        check(ctxs[0].lib.atl_comm_init_all(hs, n, out))
+        comms = []
+        for r, ctx in enumerate(ctxs):
+            c = cls.__new__(cls)
+            c.ctx, c.n_ranks, c.rank, c.handle = ctx, n, r, C.c_void_p(out[r])
+            comms.append(c)
+        return comms
+
+    def info(self):
+        """What the communicator itself reports: ranks in it (ncclCommCount), this rank, its device ordinal, transport."""
+        import ctypes as C
+
+        from ._lib import check
+
+        v = [C.c_int() for _ in range(4)]
+        check(self.ctx.lib.atl_comm_info(self.handle, *[C.byref(x) for x in v]))
+        return dict(n_ranks=v[0].value, rank=v[1].value, device=v[2].value, transport="rccl" if v[3].value == 0 else "local")
+
+    def gather_time_v_async(self, local_ptr, N, lens, out_ptr, ld_out):
+        """``gather_time_v`` on the communicator's own stream, ordered after the context's stream (the next step's kernel
+        overlaps it); device pointers in, a ticket for ``wait`` out (``atl_allgather_time_v_async``)."""
+        import ctypes as C
+
+        from ._lib import check
+
+        h_lens = (C.c_int64 * self.n_ranks)(*[int(v) for v in lens])
+        t = C.c_int64()
+        check(self.ctx.lib.atl_allgather_time_v_async(self.handle, local_ptr, N, h_lens, out_ptr, int(ld_out), C.byref(t)))
+        return t.value
+
+    def wait(self, ticket):
+        """The context's stream waits for the asynchronous collective ``ticket`` (and all before it)."""
+        from ._lib import check
+
+        check(self.ctx.lib.atl_comm_wait(self.handle, int(ticket)))
+
+    def sync(self):
+        from ._lib import check
+
+        check(self.ctx.lib.atl_comm_sync(self.handle))
+
     @staticmethod
     def unique_id():
         import ctypes as C
@@ -196,8 +249,10 @@ class LocalGroup:
 
     def close(self):
         if getattr(self, "handle", None):
-            self.lib.atl_comm_group_destroy(self.handle)
-            self.handle = None
+            from . import _lib
+
+            h, self.handle = self.handle, None
+            _lib.check(self.lib.atl_comm_group_destroy(h))  # communicators still attached: the group leaks - say so
 
 
 class LocalComm(RcclComm):

@@ -201,7 +201,7 @@ class FileArray:
             ld = out.ld
         pitched = ld is not None and len(self.shape) == 3 and int(ld) > row
         if out is None:
-            out = ctx.empty_pitched((self.shape[0], row), int(ld)) if pitched else ctx.empty_placed(self.shape)
+            out = ctx.empty_pitched((self.shape[0], row), int(ld)) if pitched else ctx.empty(self.shape)
         stride = int(ld) if pitched else row
         step = max(1, block_bytes // (row * 8))
         if self.var.layout == "chunked":

@@ -128,6 +128,13 @@ class DeviceGroup:
             try:
                 res.append(f.result())
             except BaseException:  # noqa: BLE001
+                if not failures:  # not a worker's exception: KeyboardInterrupt / SystemExit of the waiting thread itself
+                    for c in self._comms or ():
+                        try:
+                            c.abort()
+                        except Exception:
+                            pass
+                    raise
                 res.append(None)
         if failures:
             self._drop_comms()  # an aborted group stays aborted: the next call builds a fresh one
@@ -165,11 +172,23 @@ class DeviceGroup:
             if t == "custom":
                 self._comms = self.map(lambda r: self._comm_factory(self, r))
             elif t == "rccl":
-                uid = RcclComm.unique_id()
-                self._comms = self.map(lambda r: RcclComm(self.ctxs[r], self.n, r, uid))
+                # ONE thread, one ncclGroupStart / ncclGroupEnd bracket for the N devices (atl_comm_init_all): N threads
+                # each inside ncclCommInitRank on their own can wait for each other for good
+                self._comms = RcclComm.init_all(self.ctxs)
             else:
                 self._local_group = LocalGroup(self.n)
-                self._comms = self.map(lambda r: LocalComm(self.ctxs[r], self._local_group, r))
+                try:
+                    self._comms = self.map(lambda r: LocalComm(self.ctxs[r], self._local_group, r))
+                except BaseException:
+                    # a rank failed inside the constructor: nobody holds the half-built group, its peers were woken by
+                    # the rendezvous' abort - drop it so that the next call starts afresh
+                    self._comms = None
+                    try:
+                        self._local_group.close()
+                    except Exception:
+                        pass
+                    self._local_group = None
+                    raise
         return self._comms
 
     def _drop_comms(self):
@@ -180,7 +199,10 @@ class DeviceGroup:
                 pass
         self._comms = None
         if self._local_group is not None:
-            self._local_group.close()
+            try:
+                self._local_group.close()
+            except Exception:  # a communicator could not be detached: the group object is leaked, not reused
+                pass
             self._local_group = None
 
     # -- data placement ------------------------------------------------------------------------

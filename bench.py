@@ -23,9 +23,19 @@ clock stops).  ``--no-step-overlap`` finishes every step before the next starts;
 rank's shard into P sub-launches so that the all-gather of one piece overlaps the kernel of the next.
 ``--scaling weak`` gives every rank a whole 8760-step year instead.
 
+The collective of N > 1 is the LIBRARY'S OWN (``--collective lib``, the default): ``atl_comm_init`` +
+``atl_allgather_time_v_async`` of the C ABI (RCCL on the communicator's own stream; torch.distributed only ships the
+128-byte unique id and takes the max of the ranks' clocks); ``--collective torch`` gathers with
+``torch.distributed.all_gather_into_tensor`` instead.
+
 Prints ONE JSON line on rank 0.  At N = 1 (config c2) the line also carries: the same workload with
 the night early-out (the Python API's default), with BASELINE's overlapping star-convex polygons, the
-end-to-end time of the public ``Cutout.pv()`` call, and the CPU baseline.
+end-to-end time of the public ``Cutout.pv()`` call, the CPU baseline, and - ``configs`` - the N = 1 legs of the other
+BASELINE.json configurations at their own sizes (C3 wind per cell / aggregated, the C5 shard's heat demand and
+runoff, C4 in full with the in-kernel solar position), each with kernel ms, algorithmic bytes, roofline fraction
+and a parity check against the oracle.  ``--legs a,b`` restricts the run to some legs (what tools/profile_bench.sh
+runs under rocprofv3; its summaries land in profiles/bench_profile_latest.json, from which ``frac_from_profile`` and
+the counter ``traffic`` of every leg are quoted - an entry whose kernel name is not the leg's is refused).
 """
 
 from __future__ import annotations
@@ -85,6 +95,15 @@ def parse():
     ap.add_argument("--night-skip", action="store_true",
                     help="enable the night early-out in the MAIN measurement (it reads fewer bytes than the "
                          "56 B/cell the roofline figure assumes; always reported separately at N=1)")
+    ap.add_argument("--collective", choices=["lib", "torch"], default="lib",
+                    help="N > 1: who gathers - the library's own RCCL communicator (atl_comm_init + atl_allgather_time_v_async, "
+                         "C ABI) or torch.distributed")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay a rank's launches of one step (slot stride, fused kernel, k_combine) as ONE hipGraph "
+                         "(atl_capture_begin / atl_graph_launch)")
+    ap.add_argument("--legs", default="all",
+                    help="comma-separated subset of the N = 1 legs: headline,night_skip,star_polygons,api,separate_cubes,"
+                         "cpu,c3_series,c3_cf_map,c3_aggregated,c5_heat,c5_runoff,c4_full_sp (default: all)")
     ap.add_argument("--debug-rccl-self", action="store_true",
                     help="testing only (one GPU, one process): open a 1-rank RCCL process group and route the step "
                          "through the collective branch (async all-gather on the group's stream, placement copy)")
@@ -132,18 +151,90 @@ def cpu_baseline(inputs_host, M, n_threads):
     return dt, np.concatenate(res, axis=0).T  # (N, T')
 
 
-def pmc_traffic(tag):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/pmc_latest.json: FETCH_SIZE x 2 [gfx950 wide-read correction] + WRITE_SIZE, separate passes)."""
-    f = ROOT / "profiles" / "pmc_latest.json"
+PEAK_GBPS = 8000.0  # HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+# the dominant kernel of every leg, as rocprofv3 names it (tools/rocpd_summary.py strips the anonymous namespace): a
+# profile entry is only quoted for a leg when it was measured on THIS kernel
+KERNELS = {
+    "headline": "k_fused_segred<PvConvT<false, false, false, 0, 0, 0>, true, false>",
+    "night_skip": "k_fused_segred_night<PvConvT<false, false, true, 0, 0, 0>, true, false>",
+    "star_polygons": "k_fused_segred<PvConvT<false, false, false, 0, 0, 0>, true, false>",
+    "star_night_skip": "k_fused_segred_night<PvConvT<false, false, true, 0, 0, 0>, true, false>",
+    "c3_series": "k_cells_series<WindConvT<1, -1>, true>",
+    "c3_cf_map": "k_cells_timered<WindConvT<1, -1>, true>",
+    "c3_aggregated": "k_fused_segred<WindConvT<1, -1>, true, false>",
+    "c5_heat": "k_fused_segred<HeatConv, true, false>",
+    "c5_runoff": "k_fused_segred<RunoffConv, true, false>",
+    "c4_full_sp": "k_fused_segred<PvConvT<true, false, false, 0, 0, 0>, true, false>",
+    "c4_headline": "k_fused_segred<PvConvT<true, false, false, 0, 0, 0>, true, false>",
+}
+
+
+def profile_entry(leg):
+    """The committed rocprofv3 record of a leg (profiles/bench_profile_latest.json, written by tools/profile_bench.sh
+    from --kernel-trace --stats and separate --pmc FETCH_SIZE / WRITE_SIZE passes over THIS file's ``--legs <leg>``
+    run): {kernel, avg_us, median_us, calls, hbm_bytes_per_launch, source}.  None unless the record's kernel is the
+    leg's dominant kernel by name."""
+    f = ROOT / "profiles" / "bench_profile_latest.json"
     try:
-        j = json.loads(f.read_text())
-        ent = j.get("workloads", {}).get(tag) or (j if j.get("workload") == tag else None)
-        if ent:
-            return ent.get("hbm_bytes_per_launch"), f"profiles/pmc_latest.json[{tag}] (rocprofv3 --pmc, not this run)"
+        ent = json.loads(f.read_text()).get("legs", {}).get(leg)
     except Exception:
+        return None
+    if not ent or KERNELS.get(leg) is None or ent.get("kernel") != KERNELS[leg]:
+        return None
+    return ent
+
+
+def roofline_of(leg, algo_bytes, k_ms, extra=None):
+    """The roofline object of a leg: achieved = algorithmic bytes / HIP-event kernel time of this run; from the committed
+    profile of the same leg: the counter traffic per launch and the fraction its average duration gives.  Nothing above
+    the peak is reported as evidence: such a figure is dropped with a note."""
+    k_ms = np.atleast_1d(np.asarray(k_ms, dtype=np.float64))
+    mean = float(k_ms.mean())
+    achieved = algo_bytes / (mean * 1e-3) / 1e9
+    r = {"bound": "hbm", "kernel": KERNELS.get(leg), "achieved": achieved, "peak": PEAK_GBPS, "unit": "GB/s",
+         "frac": achieved / PEAK_GBPS, "traffic": None, "traffic_source": None, "kernel_ms": mean,
+         "kernel_ms_median": float(np.median(k_ms)), "kernel_ms_min": float(k_ms.min()), "algorithmic_bytes": int(algo_bytes)}
+    ent = profile_entry(leg)
+    if ent:
+        src = ent.get("source", "profiles/bench_profile_latest.json")
+        if ent.get("avg_us"):
+            r["profile_kernel_ms"] = ent["avg_us"] * 1e-3
+            r["frac_from_profile"] = algo_bytes / (ent["avg_us"] * 1e-6) / 1e9 / PEAK_GBPS
+            r["profile_source"] = f"{src} (rocprofv3 --kernel-trace --stats, avg of {ent.get('calls')} launches of this leg, not this run)"
+        tr = ent.get("hbm_bytes_per_launch")
+        if tr:
+            on_traffic = tr / (mean * 1e-3) / 1e9
+            if on_traffic <= PEAK_GBPS and tr >= 0.9 * algo_bytes:
+                r["traffic"] = tr
+                r["traffic_source"] = f"{src} (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes, not this run)"
+                r["traffic_over_algorithmic"] = tr / algo_bytes
+                r["achieved_on_traffic"] = on_traffic
+            else:
+                r["traffic_rejected"] = f"profile says {tr:.4g} B per launch = {on_traffic:.0f} GB/s at this run's kernel time: not credible, dropped"
+    if r["achieved"] > PEAK_GBPS:
+        r["invalid"] = "achieved exceeds the HBM peak: the kernel cannot have read its algorithmic bytes"
+    if extra:
+        r.update(extra)
+    return r
+
+
+def device_view(a, torch):
+    """A torch view (no copy) of a DeviceArray - also of a pitched / slot-interleaved one - through __cuda_array_interface__."""
+
+    class _V:
         pass
-    return None, None
+
+    v = _V()
+    es = a.dtype.itemsize
+    inner = int(np.prod(a.shape[1:], dtype=np.int64)) if a.ndim > 1 else 1
+    strides = None
+    if a.ld is not None:
+        assert a.ndim == 2
+        strides = (a.ld * es, es)
+    v.__cuda_array_interface__ = {"shape": tuple(a.shape), "typestr": a.dtype.str, "data": (int(a.ptr), False), "version": 2,
+                                  "strides": strides}
+    return torch.as_tensor(v, device=f"cuda:{a.ctx.device}")
 
 
 def generate_pv(ctx, synthetic, solar, _lib, T_loc, Y, X, off, stored_angles, interleaved=True):
@@ -185,6 +276,189 @@ def generate_pv(ctx, synthetic, solar, _lib, T_loc, Y, X, off, stored_angles, in
     tables = dict(sin_dec=np.sin(dec), cos_dec=np.cos(dec), h=h, cos_h=np.cos(h), sin_lat=np.sin(lat), cos_lat=np.cos(lat))
     tables = {k: ctx.upload(np.ascontiguousarray(v)) for k, v in tables.items()}
     return big, x, y, tables
+
+
+def config_legs(ctx, legs, reps, check=True):
+    """N = 1 legs of the other BASELINE.json configurations at their own sizes, through the same C ABI calls the Python API
+    makes: kernel ms (HIP events of the dominant kernel), algorithmic bytes, roofline fraction, parity of a
+    sample against the oracle (rtol 1e-10, atol 1e-12 max; heat demand atol 1e-9 a).
+      c3_*   configs[2]: Cutout.wind('Vestas_V112_3MW') on 8760 x 400 x 400 - per-cell series (24 B/cell-step), capacity-
+             factor map (16 B), aggregated to 100 shapes (16 B)
+      c5_*   configs[4]: one GPU's 1/8 shard (4380 steps) of the 35040 x 400 x 400 heat demand / runoff run, 50 shapes (8 B each)
+      c4_full_sp  configs[3] on ONE GPU: pv 8760 x 800 x 800, 500 shapes, in-kernel solar position (5 cubes, 40 B, 224 GB)"""
+    import gc
+
+    import torch
+
+    from atlite_amd import _lib, gis, solar, synthetic
+    from atlite_amd.device import SlotPool, pitch_for
+    from atlite_amd.resource import get_windturbineconfig
+    from oracle import atlite_oracle as orc
+
+    out = {}
+    WARM = 10
+
+    def run(fn):
+        ctx.set_profiling(True)
+        ms, r = [], None
+        for i in range(WARM + reps):
+            r = None  # free the previous result first (a per-cell series is 11 GB)
+            r = fn()
+            if i >= WARM:
+                ms.append(ctx.last_kernel_ms())
+        return np.asarray(ms), r
+
+    def rows(dev, sel):
+        return np.stack([dev.slab(int(t), int(t) + 1).numpy()[0] for t in sel])
+
+    def matrix_of(Y, X, n):
+        x, y = synthetic.grid_coords(Y, X)
+        dx, dy = x[1] - x[0], y[1] - y[0]
+        polys = gis.random_tessellation(n, (x[0] - dx / 2, y[0] - dy / 2, x[-1] + dx / 2, y[-1] + dy / 2), seed=42)
+        return gis.compute_indicatormatrix(x, y, polys, ctx=ctx)
+
+    def close(got, ref, atol=None):
+        scale = float(np.nanmax(np.abs(ref))) if np.size(ref) else 0.0
+        atol = 1e-12 * scale if atol is None else atol
+        err = np.abs(got - ref) - atol
+        rel = float(np.nanmax(err / np.maximum(np.abs(ref), 1e-300))) if np.size(ref) else 0.0
+        ok = bool(np.allclose(got, ref, rtol=1e-10, atol=atol, equal_nan=True))
+        return {"ok": ok, "checked_values": int(np.size(ref)), "max_rel_err_beyond_atol": max(rel, 0.0), "rtol": 1e-10}
+
+    def record(leg, workload, bytes_, cells, ms, parity):
+        r = roofline_of(leg, bytes_, ms)
+        e = {"workload": workload, "kernel": r["kernel"], "ms": r["kernel_ms"], "ms_median": r["kernel_ms_median"], "ms_min": r["kernel_ms_min"],
+             "algorithmic_bytes": r["algorithmic_bytes"], "achieved_GBps": r["achieved"], "frac": r["frac"],
+             "value": cells / (r["kernel_ms"] * 1e-3), "unit": "cell-timesteps/s (kernel time)"}
+        for k in ("frac_from_profile", "profile_kernel_ms", "traffic", "traffic_over_algorithmic", "traffic_rejected", "invalid"):
+            if k in r:
+                e[k] = r[k]
+        if parity is not None:
+            e["parity"] = parity
+        out[leg] = e
+
+    # ---- configs[2]: wind per cell -------------------------------------------------------------------------------------
+    c3 = [l for l in legs if l.startswith("c3_")]
+    if c3:
+        T, Y, X = 8760, 400, 400
+        S = Y * X
+        turb = get_windturbineconfig("Vestas_V112_3MW")
+        V, POW, P, hub = turb["V"], turb["POW"], turb["P"], turb["hub_height"]
+        inter = os.environ.get("ATL_BENCH_WIND_LAYOUT", "interleaved") == "interleaved"
+        if inter:  # the layout of the library's own device copies: the two cubes slot-interleaved in one allocation
+            pool = SlotPool(ctx, T, S, ["wnd100m", "roughness"], pitch_for(S))
+            wnd, z0 = pool.view("wnd100m"), pool.view("roughness")
+            tmp = ctx.empty((T, S))
+            for var, kind, p0, p1, dst in ((5, _lib.SYN_RAYLEIGH, 8.0, 0.0, wnd), (6, _lib.SYN_EXPLOG, 1e-3, 1.5e3, z0)):
+                _lib.check(ctx.lib.atl_synth_field(ctx.handle, kind, 42, var, p0, p1, 0, T, S, tmp.ptr))
+                _lib.check(ctx.lib.atl_copy_2d(ctx.handle, dst.ptr, dst.ld * 8, tmp.ptr, S * 8, S * 8, T, 2, 0))
+            ctx.sync()
+            del tmp
+        else:
+            d = synthetic.wind_inputs(ctx, T, Y, X)
+            wnd, z0 = d["wnd100m"], d["roughness"]
+        args = (wnd, z0, V, POW / P, hub, 100.0, "logarithmic", T, S)
+        lay = "the two cubes slot-interleaved in one allocation" if inter else "one allocation per cube"
+        if "c3_series" in c3:
+            ms, ser = run(lambda: ctx.wind(*args))
+            par = None
+            if check:
+                sel = np.unique(np.concatenate([np.arange(0, 6), [T // 2, T - 1]]))
+                par = close(rows(ser, sel), orc.convert_wind(rows(wnd, sel), rows(z0, sel), V, POW, P, hub, 100.0))
+            record("c3_series", f"configs[2]: wind V112 per-cell series, {T}x{Y}x{X}, 16 B read + 8 B written per cell-step; {lay}",
+                   24 * T * S, T * S, ms, par)
+            del ser
+        if "c3_cf_map" in c3:
+            ms, cf = run(lambda: ctx.wind(*args, time_agg="mean"))
+            par = None
+            if check:
+                cells = np.unique(np.concatenate([[0, X - 1, S - 1], np.random.default_rng(1).integers(0, S, 61)]))
+                idx = torch.as_tensor(cells, device=f"cuda:{ctx.device}")
+                w_c, z_c = device_view(wnd, torch)[:, idx].cpu().numpy(), device_view(z0, torch)[:, idx].cpu().numpy()
+                par = close(cf.numpy()[cells], orc.convert_wind(w_c, z_c, V, POW, P, hub, 100.0).mean(axis=0))
+            record("c3_cf_map", f"configs[2]: wind V112 capacity-factor map (aggregate_time='mean'), {T}x{Y}x{X}, 16 B per cell-step; {lay}",
+                   16 * T * S, T * S, ms, par)
+            del cf
+        if "c3_aggregated" in c3:
+            M = matrix_of(Y, X, 100)
+            plan = ctx.plan(M, row_len=X, ld=wnd.ld)
+            ms, agg = run(lambda: ctx.wind(*args, plan=plan))
+            par = None
+            if check:
+                sel = np.unique(np.concatenate([np.arange(0, 20), [T // 2, T - 1]]))
+                par = close(agg.numpy()[:, sel], orc.aggregate_matrix(orc.convert_wind(rows(wnd, sel), rows(z0, sel), V, POW, P, hub, 100.0), M))
+            info = plan.info()
+            record("c3_aggregated", f"configs[2] aggregated: wind V112, {T}x{Y}x{X}, 100 tessellation shapes ({info['tile_w']}x{info['tile_h']} "
+                                    f"tiles, {info['n_partial_rows']} partial rows), 16 B per cell-step; {lay}", 16 * T * S, T * S, ms, par)
+            del agg, plan
+        del wnd, z0, args
+        if inter:
+            del pool
+        gc.collect()
+
+    # ---- configs[4]: one GPU's shard of heat demand + runoff ------------------------------------------------------------
+    c5 = [l for l in legs if l.startswith("c5_")]
+    if c5:
+        T, Y, X = 35040 // 8, 400, 400
+        S = Y * X
+        d = synthetic.heat_runoff_inputs(ctx, T, Y, X)
+        M = matrix_of(Y, X, 50)
+        plan = ctx.plan(M, row_len=X)
+        info = plan.info()
+        tag = f"{T} of 35040 steps x {Y}x{X}, 50 tessellation shapes ({info['tile_w']}x{info['tile_h']} tiles, {info['n_partial_rows']} partial rows), 8 B per cell-step"
+        if "c5_heat" in c5:
+            day_ptr = np.arange(0, T + 1, 24)
+            if day_ptr[-1] != T:
+                day_ptr = np.append(day_ptr, T)
+            ms, hd = run(lambda: ctx.heat_demand(d["temperature"], day_ptr, 288.15, 1.0, 0.0, T, S, plan=plan))
+            par = None
+            if check:
+                days = np.unique(np.concatenate([[0, 1, len(day_ptr) - 2], np.random.default_rng(2).integers(0, len(day_ptr) - 1, 9)]))
+                got, ref = hd.numpy()[:, days], []
+                for dd in days:
+                    blk = d["temperature"].slab(int(day_ptr[dd]), int(day_ptr[dd + 1])).numpy()
+                    ref.append(orc.aggregate_matrix(orc.convert_heat_demand(blk, np.array([0, blk.shape[0]]), threshold=15.0, a=1.0, constant=0.0), M)[:, 0])
+                par = close(got, np.stack(ref, axis=1), atol=1e-9)
+            record("c5_heat", "configs[4], one GPU's shard: heat demand, " + tag, 8 * T * S, T * S, ms, par)
+            del hd
+        if "c5_runoff" in c5:
+            ms, ro = run(lambda: ctx.runoff(d["runoff"], d["height"], T, S, plan=plan))
+            par = None
+            if check:
+                sel = np.unique(np.concatenate([np.arange(0, 20), [T // 2, T - 1]]))
+                par = close(ro.numpy()[:, sel], orc.aggregate_matrix(orc.convert_runoff(rows(d["runoff"], sel), d["height"].numpy()[None, :]), M))
+            record("c5_runoff", "configs[4], one GPU's shard: runoff x height, " + tag, 8 * T * S, T * S, ms, par)
+            del ro
+        del d, plan
+        gc.collect()
+
+    # ---- configs[3] on one GPU: the whole 8760 x 800 x 800 cutout, in-kernel solar position ------------------------------
+    if "c4_full_sp" in legs:
+        T, Y, X, N = 8760, 800, 800, 500
+        S = Y * X
+        big, x, y, tables = generate_pv(ctx, synthetic, solar, _lib, T, Y, X, 0, False, interleaved=True)
+        ld = next(iter(big.values())).ld
+        M = matrix_of(Y, X, N)
+        plan = ctx.plan(M, row_len=X, ld=ld)
+        info = plan.info()
+        tabs = dict(tables)
+        params = dict(CSI, **ORI)
+        ms, res = run(lambda: ctx.pv(big, params, T, S, plan=plan, solar_tables=tabs, options=dict(night_skip=False)))
+        par = None
+        if check:
+            sel = np.unique(np.clip(np.concatenate([np.arange(0, 24), np.arange(4000, 4024), [T - 1]]), 0, T - 1))
+            host = {k: rows(v, sel) for k, v in big.items()}
+            al, az = orc.solar_position(synthetic.time_index(T)[sel], x, y, "-30min")
+            host["solar_altitude"], host["solar_azimuth"] = al.reshape(len(sel), S), az.reshape(len(sel), S)
+            ref = np.concatenate([orc.aggregate_matrix(orc.convert_pv({k: v[i:i + 8] for k, v in host.items()}, CSI, ORI), M)
+                                  for i in range(0, len(sel), 8)], axis=1)
+            par = close(res.numpy()[:, sel], ref)
+        record("c4_full_sp", f"configs[3] on ONE GPU: pv CSi, {T}x{Y}x{X}, {N} tessellation shapes ({info['tile_w']}x{info['tile_h']} tiles, "
+                             f"{info['n_partial_rows']} partial rows), in-kernel solar position, 5 cubes slot-interleaved = 40 B per cell-step (224 GB resident)",
+               40 * T * S, T * S, ms, par)
+        del big, res, plan, tabs, tables
+        gc.collect()
+    return out
 
 
 def self_launch(a):
@@ -238,7 +512,7 @@ def main():
     dist = None
     if a.debug_gloo_one_gpu:
         local = 0
-    if a.debug_rccl_self and world == 1:
+    if a.debug_rccl_self and world == 1 and a.collective == "torch":
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -252,7 +526,10 @@ def main():
         if a.debug_gloo_one_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            # control plane (unique id, clocks, barriers: CPU tensors) over gloo; torch's own RCCL communicator is only
+            # created when --collective torch gathers with it (or the library's communicator cannot be formed)
+            kw = {"device_id": torch.device("cuda", local)} if a.collective == "torch" else {}
+            dist.init_process_group("cpu:gloo,cuda:nccl", **kw)
     n_gpus = world
     assert a.gpus == n_gpus or (world == 1 and a.emulate_shard) or (world == 1 and a.gpus == 1), \
         f"--gpus {a.gpus} but WORLD_SIZE={world}"
@@ -320,25 +597,58 @@ def main():
     # enough to pay for the extra launch - measured on a 1/8 shard of C2 (4.4e7 cell-steps): 0.417 ms with one
     # launch, 0.450 ms with two, against an all-gather of 7 MB that takes less than the difference
     equal = len(set(shard_lens)) == 1
-    collective = parts > 1 or (a.debug_rccl_self and dist is not None)
+    collective = parts > 1 or (a.debug_rccl_self and world == 1)
+    use_lib = collective and a.collective == "lib" and not (a.emulate_shard or a.debug_gloo_one_gpu)
+    comm = None
+    lib_error = None
+    if use_lib:
+        # the library's own communicator (C ABI atl_comm_*): rank 0 draws the unique id, the control group ships it
+        try:
+            uid = D.RcclComm.unique_id() if rank == 0 else None
+        except Exception as e:  # noqa: BLE001
+            uid, lib_error = None, repr(e)
+        if world > 1:
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            uid = box[0]
+        if uid is not None:
+            try:
+                comm = D.RcclComm(ctx, max(world, 1), rank, uid)
+            except Exception as e:  # noqa: BLE001
+                lib_error = repr(e)
+        if world > 1:  # every rank or none: a rank without a communicator would leave the others inside the collective
+            okf = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if int(okf.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                comm = None
+        if comm is None:
+            use_lib = False
+            if rank == 0:
+                print(f"[bench] the library's RCCL communicator is not available ({lib_error}); gathering with "
+                      "torch.distributed instead", file=sys.stderr)
     # RCCL path: the all-gather and the placement copy of a step run behind the NEXT step's kernel - a second set of
     # (piece, gather) buffers by step parity, the placement on a side stream, buffer reuse ordered by events; the timed
     # region ends with a device-wide synchronize, so every step's result is in place when the clock stops.  One
     # launch per step then: there is nothing left for sub-launches to hide.
-    overlap = collective and equal and not (a.emulate_shard or a.debug_gloo_one_gpu or a.no_step_overlap)
+    overlap = collective and (equal or use_lib) and not (a.emulate_shard or a.debug_gloo_one_gpu or a.no_step_overlap)
     P = a.pipeline if a.pipeline > 0 else (1 if parts == 1 or overlap or T_loc * S < 1.0e8 else 2)
     P = max(1, min(P, T_loc // 8 or 1))
+    if use_lib:
+        P = 1  # the library's all-gather places whole shards; with the gather behind the next kernel pieces hide nothing
     pe = D.time_partition(T_loc, P)  # sub-launch edges inside this rank's shard
     assert equal or world == 1 or P == 1, "pipelined gather needs equal shards"
     full = torch.empty((N, sum(shard_lens)), dtype=torch.float64, device=dev)  # (shapes x all time steps)
     piece = [torch.empty((N, pe[i + 1] - pe[i]), dtype=torch.float64, device=dev) for i in range(P)]
-    gbuf = [torch.empty((parts, N, pe[i + 1] - pe[i]), dtype=torch.float64, device=dev) for i in range(P)] if collective else None
+    gbuf = [torch.empty((parts, N, pe[i + 1] - pe[i]), dtype=torch.float64, device=dev) for i in range(P)] if collective and not use_lib else None
+    step_no = [0]
     if overlap:
         piece2 = [piece, [torch.empty_like(t) for t in piece]]
-        gbuf2 = [gbuf, [torch.empty_like(t) for t in gbuf]]
-        side = torch.cuda.Stream(device=dev)
-        placed = [[None] * P, [None] * P]  # event: the placement copy that last read (piece, gather)[parity][i] is done
-        step_no = [0]
+        if not use_lib:
+            gbuf2 = [gbuf, [torch.empty_like(t) for t in gbuf]]
+            side = torch.cuda.Stream(device=dev)
+        placed = [[None] * P, [None] * P]  # event / ticket: the gather + placement that last read piece[parity][i] is done
     cube_ptrs = {k: getattr(pin, k) for k in ("d_influx_direct", "d_influx_diffuse", "d_influx_toa", "d_albedo",
                                               "d_temperature", "d_solar_altitude", "d_solar_azimuth")}
     tab_ptrs = {k: getattr(pin, k) for k in ("d_sin_dec", "d_cos_dec", "d_hour_angle", "d_cos_hour_angle")}
@@ -365,8 +675,23 @@ def main():
         _lib.check(ctx.lib.atl_set_slot_stride(ctx.handle, 0 if ld == S else ld))
         _lib.check(ctx.lib.atl_pv_convert_aggregate(ctx.handle, C.byref(pin_), C.byref(pp), T_, S, plan.handle, 0, out_ptr, ld_out))
 
+    graphs = {}  # --graph: (params identity, piece, output pointer) -> hipGraph of the piece's launches
+
     def launch(pp, i, out_t):
-        cabi_pv(pins[i], pp, pe[i + 1] - pe[i], out_t.data_ptr(), out_t.stride(0))
+        if not a.graph:
+            return cabi_pv(pins[i], pp, pe[i + 1] - pe[i], out_t.data_ptr(), out_t.stride(0))
+        key = (id(pp), i, out_t.data_ptr(), plan.handle.value)
+        g = graphs.get(key)
+        if g is None:
+            cabi_pv(pins[i], pp, pe[i + 1] - pe[i], out_t.data_ptr(), out_t.stride(0))  # once for real: the scratch arena settles
+            _lib.check(ctx.lib.atl_capture_begin(ctx.handle))
+            try:
+                cabi_pv(pins[i], pp, pe[i + 1] - pe[i], out_t.data_ptr(), out_t.stride(0))
+            finally:
+                g = C.c_void_p()
+                _lib.check(ctx.lib.atl_capture_end(ctx.handle, C.byref(g)))
+            graphs[key] = g
+        _lib.check(ctx.lib.atl_graph_launch(ctx.handle, g))
 
     def step(pp):
         if not collective:
@@ -374,6 +699,19 @@ def main():
                 launch(pp, i, full[:, pe[i]:pe[i + 1]] if P == 1 else piece[i])
                 if P > 1:
                     full[:, pe[i]:pe[i + 1]].copy_(piece[i])
+            return full
+        if use_lib:  # the library's own collective (atl_allgather_time_v[_async]): packs ragged shards, gathers, places
+            if overlap:
+                par = step_no[0] & 1
+                step_no[0] += 1
+                if placed[par][0] is not None:
+                    comm.wait(placed[par][0])  # two steps back: long done, costs nothing
+                launch(pp, 0, piece2[par][0])
+                placed[par][0] = comm.gather_time_v_async(piece2[par][0].data_ptr(), N, shard_lens, full.data_ptr(), full.stride(0))
+            else:
+                launch(pp, 0, piece[0])
+                h_lens = (C.c_int64 * len(shard_lens))(*shard_lens)
+                _lib.check(ctx.lib.atl_allgather_time_v(comm.handle, piece[0].data_ptr(), N, h_lens, full.data_ptr(), full.stride(0)))
             return full
         if overlap:
             par = step_no[0] & 1
@@ -413,10 +751,14 @@ def main():
                 full3[:, :, pe[i]:pe[i + 1]].copy_(gbuf[i].permute(1, 0, 2))
         return full
 
+    def barrier():
+        if world > 1:  # over the control group (a CPU tensor: gloo)
+            dist.all_reduce(torch.zeros(1, dtype=torch.int32))
+
     def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()  # device-wide: the communicator's own stream included
+        barrier()
 
     def timed(pp, steps, warmup):
         """-> (seconds over `steps` steps [max over ranks], per-launch kernel ms of the timed region)."""
@@ -432,54 +774,74 @@ def main():
         dt = time.perf_counter() - t0
         k = ctx.kernel_times()
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if a.debug_gloo_one_gpu else dev)
+            tt = torch.tensor([dt], dtype=torch.float64)  # the control group (gloo) carries the clocks
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt, k
 
+    legs = None if a.legs == "all" else {v.strip() for v in a.legs.split(",") if v.strip()}
+
+    def want(leg):
+        return legs is None or leg in legs
+
     pp_main = pv_params(a.night_skip)
+    leg_main = ("headline" if cfg["stored_angles"] else "c4_headline") if a.shape_kind == "tessellation" and not a.night_skip \
+        else ("night_skip" if a.shape_kind == "tessellation" and cfg["stored_angles"] else None)
     dt, kms = timed(pp_main, a.steps, a.warmup)
+    if a.graph:  # the kernel brackets are not part of a captured graph: the kernel's own time from plain launches afterwards
+        a.graph = False
+        kms = timed(pp_main, a.steps, 2)[1]
+        a.graph = True
     assert len(kms) == a.steps * P, (len(kms), a.steps, P)
     ms_per_step = dt / a.steps * 1e3
     value = (T_loc if a.emulate_shard else T_total) * S / (dt / a.steps)
     k_step = kms.reshape(a.steps, P).sum(axis=1)  # fused-kernel time per step on this rank
     k_ms = float(k_step.mean())
     algo_bytes = bpc * T_loc * S
-    achieved = algo_bytes / (k_ms * 1e-3) / 1e9
-    kname = "k_fused_segred<PvConvT<%s>>" % ("stored angles" if cfg["stored_angles"] else "in-kernel solar position")
-    tag = f"pv_{T_loc}x{Y}x{X}_{N}shapes_{a.shape_kind}" + ("" if cfg["stored_angles"] else "_sp") + \
-          ("_nightskip" if a.night_skip else "")
-    traffic, traffic_src = pmc_traffic(tag)
 
     # per-rank kernel time and the collective by itself (outside the timed region): what a rank's step is made of
-    per_rank_kernel_ms = gather_ms = None
+    per_rank_kernel_ms = gather_ms = comm_info = None
 
     def diagnostics():
-        cdev = "cpu" if a.debug_gloo_one_gpu else dev
-        mine = torch.tensor([k_ms], dtype=torch.float64, device=cdev)
+        mine = torch.tensor([k_ms], dtype=torch.float64)
         lst = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(lst, mine)
         per_rank = [float(v.item()) for v in lst]
+        info = None
+        if use_lib:  # what the communicator itself says: ranks in it (ncclCommCount), device ordinal (ncclCommCuDevice)
+            ci = comm.info()
+            mine_i = torch.tensor([ci["n_ranks"], ci["rank"], ci["device"], local], dtype=torch.int64)
+            lst_i = [torch.zeros_like(mine_i) for _ in range(world)]
+            dist.all_gather(lst_i, mine_i)
+            info = {"ranks_seen": [int(v[0]) for v in lst_i], "rank_of": [int(v[1]) for v in lst_i],
+                    "device_of_rank": [int(v[2]) for v in lst_i], "local_rank": [int(v[3]) for v in lst_i]}
         if a.debug_gloo_one_gpu:
-            return per_rank, None
+            return per_rank, None, info
         reps = 10
         fence()
         t0 = time.perf_counter()
-        for _ in range(reps):  # all-gather of every piece + the strided placement copy, nothing to hide behind
+        for _ in range(reps):  # all-gather of every piece + the placement, nothing to hide behind
+            if use_lib:
+                h_lens = (C.c_int64 * len(shard_lens))(*shard_lens)
+                src = piece2[0][0] if overlap else piece[0]
+                _lib.check(ctx.lib.atl_allgather_time_v(comm.handle, src.data_ptr(), N, h_lens, full.data_ptr(), full.stride(0)))
+                continue
             for i in range(P):
                 dist.all_gather_into_tensor(gbuf[i].view(-1), piece[i].view(-1))
                 if full3 is not None:
                     full3[:, :, pe[i]:pe[i + 1]].copy_(gbuf[i].permute(1, 0, 2))
         fence()
-        tg = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device=dev)
+        tg = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64)
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-        return per_rank, float(tg.item())
+        return per_rank, float(tg.item()), info
 
     if world > 1:
         try:  # diagnostics only (the same code path on every rank): nothing here may cost the run its result line
-            per_rank_kernel_ms, gather_ms = diagnostics()
+            per_rank_kernel_ms, gather_ms, comm_info = diagnostics()
         except Exception as e:  # noqa: BLE001
             print(f"[bench] rank {rank}: multi-GPU diagnostics skipped: {e!r}", file=sys.stderr)
+    elif use_lib:
+        comm_info = {"ranks_seen": [comm.info()["n_ranks"]], "device_of_rank": [comm.info()["device"]]}
 
     # the reassembled result holds every rank's block in place
     if world > 1:
@@ -489,12 +851,13 @@ def main():
         cabi_pv(pin, pp_main, T_loc, own.data_ptr(), T_loc)
         torch.cuda.synchronize()
         assert torch.equal(res[:, edges[rank]:edges[rank + 1]], own), "all-gather misplaced this rank's block"
-        chk = torch.stack([res.sum(), res.abs().sum()])
-        chk = chk.cpu() if a.debug_gloo_one_gpu else chk
+        chk = torch.stack([res.sum(), res.abs().sum()]).cpu()
         lst = [torch.zeros_like(chk) for _ in range(world)]
         dist.all_gather(lst, chk)
         assert all(torch.equal(v, chk) for v in lst), "ranks disagree on the gathered result"
 
+    shapes_word = ("a 100-cell Voronoi TESSELLATION (every cell covered: all 56 B/cell-step are read; BASELINE's overlapping "
+                   "star polygons: star_polygons below)") if a.shape_kind == "tessellation" else "overlapping star-convex polygons"
     result = {
         "metric": "grid-cell-timesteps/sec (pv convert+aggregate)",
         "value": value,
@@ -509,12 +872,13 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"{a.config}: pv CSi slope 30 az 180, {T_total}x{Y}x{X} fp64, {N} {a.shape_kind} polygon shapes, "
+            "workload": f"{a.config}: {N} shapes = {shapes_word}; pv CSi slope 30 az 180, {T_total}x{Y}x{X} fp64, "
                         f"aggregate_time=None, " + ("stored solar angles (7 cubes)" if cfg["stored_angles"]
                                                     else "in-kernel solar position (5 cubes)") +
                         "; timed call = atl_pv_convert_aggregate (C ABI) on a prebuilt plan, result left in HBM",
-            "parallelism": f"time-sharded x{world}" + (f" + RCCL all-gather, {P} pipelined piece(s) per step" if world > 1 else "") +
-                           (", gather + placement of a step behind the next step's kernel" if overlap and world > 1 else ""),
+            "parallelism": f"time-sharded x{world}" + (f" + all-gather by {'the library (atl_allgather_time_v' + ('_async' if overlap else '') + ', RCCL)' if use_lib else 'torch.distributed (RCCL)'}, {P} piece(s) per step" if world > 1 else "") +
+                           (", gather + placement of a step behind the next step's kernel" if overlap and world > 1 else "") +
+                           (", a rank's launches replayed as one hipGraph" if a.graph else ""),
             "time_steps_per_gpu": T_loc,
             "night_skip": bool(a.night_skip),
             "layout": ("slot-interleaved: the cubes in ONE allocation, the variables of a time step side by side "
@@ -524,33 +888,27 @@ def main():
             "cell_tile": f"{plan_info['tile_w']}x{plan_info['tile_h']}",
             "partial_rows": plan_info["n_partial_rows"],
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": kname,
-            "achieved": achieved,
-            "peak": 8000.0,
-            "unit": "GB/s",
-            "frac": achieved / 8000.0,
-            "traffic": traffic,
-            "traffic_source": traffic_src,
-            "kernel_ms": k_ms,
-            "kernel_ms_median": float(np.median(k_step)),
-            "kernel_ms_min": float(np.min(k_step)),
-            "launches_per_step": P,
-            "algorithmic_bytes": algo_bytes,
-        },
+        "roofline": roofline_of(leg_main if world == 1 and not a.emulate_shard and T_loc == CONFIGS[a.config]["T"] and
+                                (Y, X, N) == (CONFIGS[a.config]["Y"], CONFIGS[a.config]["X"], CONFIGS[a.config]["shapes"]) else None,
+                                algo_bytes, k_step, {"launches_per_step": P}),
     }
-    if world > 1:
+    if result["roofline"]["kernel"] is None:
+        result["roofline"]["kernel"] = KERNELS["headline" if cfg["stored_angles"] else "c4_headline"] if not a.night_skip else KERNELS["night_skip"]
+    if world > 1 or use_lib:
         result["multi_gpu"] = {
             "per_rank_kernel_ms": per_rank_kernel_ms,  # fused kernel(s) of one step on each rank's own shard
             "gather_ms": gather_ms,  # serial all-gather + placement of one step's result (max over ranks), untimed region
             "result_bytes": int(N * sum(shard_lens) * 8),
+            "collective": ("library: atl_comm_init + atl_allgather_time_v" + ("_async (communicator's own stream)" if overlap else "")) if use_lib
+                          else ("torch.distributed all_gather_into_tensor" + (f" (the library's communicator failed: {lib_error})" if lib_error else "")),
             "transport": "gloo on host copies (debug, all ranks on GPU 0)" if a.debug_gloo_one_gpu else "RCCL over xGMI",
         }
+        if comm_info:
+            result["multi_gpu"].update(comm_info)
     if a.emulate_shard:
         # what one rank of an N-way strong-scaling run spends per step besides the collective
         result["emulated_shard"] = {
-            "of": parts, "pieces": P, "step_ms": ms_per_step, "fused_kernel_ms": k_ms,
+            "of": parts, "pieces": P, "step_ms": ms_per_step, "fused_kernel_ms": k_ms, "graph": bool(a.graph),
             "overhead_ms": ms_per_step - k_ms, "overhead_frac": (ms_per_step - k_ms) / ms_per_step,
             "note": "rank 0's shard of the strong-scaling split on one GPU: fused kernel(s) + k_combine + placement "
                     "copy + host launch path; no collective",
@@ -578,62 +936,77 @@ def main():
         result["parity"] = {"checked_steps": int(len(sel)), "max_rel_err": float(err.max()), "rtol": 1e-10,
                             "ok": bool(err.max() <= 1e-10)}
 
-    if rank == 0 and single and a.config == "c2" and not a.no_extras:
+    extras = rank == 0 and single and a.config == "c2" and not a.no_extras
+    if extras:
         ks = max(3, min(a.steps, 10))
         # warm-up launches of the side legs: after the host-side gap before each of them the shader clock needs ~30 ms
         # of load to settle, and the early-out kernel is issue-bound (profiles/r03_clock_per_launch.txt: 2.3 -> 1.97 ms
         # over the first eight launches of a burst); the headline measurement above keeps the caller's --warmup
         kw_ = 12
         # (1) the Python API's default: night early-out (bit-identical output, fewer bytes read)
-        if not a.night_skip:
+        if not a.night_skip and want("night_skip"):
             ref_out = step(pp_main).clone()
             dts, kk = timed(pv_params(True), ks, kw_)
             same = bool(torch.equal(step(pv_params(True)), ref_out))
-            tr, src = pmc_traffic(tag + "_nightskip")
-            result["night_skip"] = {"ms_per_step": dts / ks * 1e3, "kernel_ms": float(kk.mean()),
-                                    "value": T_total * S / (dts / ks), "bit_identical": same,
-                                    "traffic": tr, "traffic_source": src,
-                                    "achieved_on_traffic_GBps": (tr / (float(kk.mean()) * 1e-3) / 1e9) if tr else None}
+            # algorithmic bytes of the early-out: the altitude cube in full + the six other cubes where a cell is up
+            # (the fewest bytes any per-cell early-out could read; the kernel decides per 128-cell tile and slot)
+            try:
+                alt_t = device_view(inputs["solar_altitude"], torch)
+                n_day = int((alt_t >= float(np.radians(1.0))).sum().item())
+                night_bytes = 8 * T_loc * S + 48 * n_day
+            except Exception as e:  # noqa: BLE001
+                n_day, night_bytes = None, None
+                print(f"[bench] day-cell count skipped: {e!r}", file=sys.stderr)
+            result["night_skip"] = {"ms_per_step": dts / ks * 1e3, "value": T_total * S / (dts / ks), "bit_identical": same,
+                                    "day_cell_steps": n_day,
+                                    "roofline": roofline_of("night_skip", night_bytes or algo_bytes, kk,
+                                                            {"note": "algorithmic bytes = 8 B x every cell-step (altitude) + 48 B x the "
+                                                                     "cell-steps above the 1 degree cut-off; the kernel skips per tile and "
+                                                                     "slot, so its traffic is a little above that"}
+                                                            if night_bytes else {"note": "day-cell count unavailable: bytes of the full-read kernel"})}
         # (2) BASELINE's "random-polygon" shapes: overlapping star-convex polygons, cells may be uncovered
-        if a.shape_kind == "tessellation":
+        if a.shape_kind == "tessellation" and want("star_polygons"):
             polys_s, M_s = shapes_of("star")
             plan_main, plan = plan, ctx.plan(M_s, row_len=X, ld=None if ld == S else ld)
             dts, kk = timed(pp_main, ks, kw_)
             info_s = plan.info()
             covered = int((np.asarray((M_s != 0).sum(0)).ravel() > 0).sum())
-            tr, src = pmc_traffic(f"pv_{T_loc}x{Y}x{X}_{N}shapes_star")
             result["star_polygons"] = {
-                "ms_per_step": dts / ks * 1e3, "kernel_ms": float(kk.mean()), "value": T_total * S / (dts / ks),
+                "ms_per_step": dts / ks * 1e3, "value": T_total * S / (dts / ks),
                 "partial_rows": info_s["n_partial_rows"], "cell_tile": f"{info_s['tile_w']}x{info_s['tile_h']}",
                 "covered_cells": covered, "max_shapes_per_cell": int(np.asarray((M_s != 0).sum(0)).max()),
-                "algorithmic_bytes": bpc * T_loc * covered, "traffic": tr, "traffic_source": src,
-                "achieved_GBps_on_covered_cells": bpc * T_loc * covered / (float(kk.mean()) * 1e-3) / 1e9,
-                "achieved_on_traffic_GBps": (tr / (float(kk.mean()) * 1e-3) / 1e9) if tr else None,
+                "roofline": roofline_of("star_polygons", bpc * T_loc * covered, kk,
+                                        {"min_traffic_ratio": 1.0, "note": "algorithmic bytes = 56 B x the cells some shape covers; whole "
+                                                                          "128-byte lines are fetched along the ragged edges (traffic)"}),
             }
             plan = plan_main
         # (3) what a user of the drop-in API waits for: cutout.pv(...) on a device-resident Dataset
-        from atlite_amd import Cutout, Dataset
+        if want("api"):
+            from atlite_amd import Cutout, Dataset
 
-        cut = Cutout(Dataset(dict(inputs), dict(time=synthetic.time_index(T_loc), y=y, x=x)))
-        kw = dict(panel="CSi", orientation={"slope": 30.0, "azimuth": 180.0}, aggregate_time=None)
+            cut = Cutout(Dataset(dict(inputs), dict(time=synthetic.time_index(T_loc), y=y, x=x)))
+            kw = dict(panel="CSi", orientation={"slope": 30.0, "azimuth": 180.0}, aggregate_time=None)
 
-        def call(**k):
-            t0 = time.perf_counter()
-            r = cut.pv(**kw, **k)
-            return (time.perf_counter() - t0) * 1e3, r
+            def call(**k):
+                t0 = time.perf_counter()
+                r = cut.pv(**kw, **k)
+                return (time.perf_counter() - t0) * 1e3, r
 
-        cold, r0 = call(shapes=polys)  # indicator matrix + plan build + kernel + D2H + labelled result
-        warm = min(call(shapes=polys)[0] for _ in range(3))  # plan cached (matrix content hash)
-        warm_m = min(call(matrix=M)[0] for _ in range(3))
-        same = bool(np.array_equal(np.asarray(r0.values), step(pp_main).cpu().numpy()))
-        result["api_e2e_ms"] = {"call": "cutout.pv(panel='CSi', orientation={slope:30,azimuth:180}, shapes=polys, "
-                                        "aggregate_time=None) -> host (shapes x time) labelled array; night early-out on",
-                                "cold": cold, "warm": warm, "warm_matrix_given": warm_m,
-                                "equals_timed_result": same}
+            cold, r0 = call(shapes=polys)  # indicator matrix + plan build + kernel + D2H + labelled result
+            warm = min(call(shapes=polys)[0] for _ in range(5))  # plan cached
+            warm_m = min(call(matrix=M)[0] for _ in range(5))
+            same = bool(np.array_equal(np.asarray(r0.values), step(pp_main).cpu().numpy()))
+            ctx.set_profiling(True)
+            call(shapes=polys)
+            result["api_e2e_ms"] = {"call": "cutout.pv(panel='CSi', orientation={slope:30,azimuth:180}, shapes=polys, "
+                                            "aggregate_time=None) -> host (shapes x time) labelled array; night early-out on",
+                                    "cold": cold, "warm": warm, "warm_matrix_given": warm_m, "kernel_ms": ctx.last_kernel_ms(),
+                                    "equals_timed_result": same}
+            del cut, r0
 
         # (4) the same cubes in an allocation each (the layout a caller's own device arrays have, and the library's before
         # round 3): same kernel, same bytes, bit-identical result - the memory system alone makes the difference
-        if a.layout == "interleaved" and not a.night_skip:
+        if a.layout == "interleaved" and not a.night_skip and want("separate_cubes"):
             sep = generate_pv(ctx, synthetic, solar, _lib, T_loc, Y, X, off, cfg["stored_angles"], interleaved=False)[0]
             plan_sep = ctx.plan(M, row_len=X)
             ctx.set_profiling(True)
@@ -645,12 +1018,12 @@ def main():
                     ksep.append(ctx.last_kernel_ms())
             ksep_ms = float(np.mean(ksep))
             result["separate_cubes"] = {"kernel_ms": ksep_ms, "achieved_GBps": algo_bytes / (ksep_ms * 1e-3) / 1e9,
-                                        "frac": algo_bytes / (ksep_ms * 1e-3) / 1e9 / 8000.0,
+                                        "frac": algo_bytes / (ksep_ms * 1e-3) / 1e9 / PEAK_GBPS,
                                         "bit_identical": bool(np.array_equal(r_sep.numpy(), step(pp_main).cpu().numpy())),
                                         "note": "one allocation per cube instead of the slot-interleaved one; same kernel and bytes"}
             del sep, plan_sep, r_sep
 
-    if rank == 0 and single and not a.no_cpu_baseline and cfg["stored_angles"]:
+    if rank == 0 and single and not a.no_cpu_baseline and cfg["stored_angles"] and want("cpu"):
         Tc = min(a.cpu_steps, T_loc)
         t_a = 4000 if T_loc >= 4000 + Tc else 0  # daytime-rich slab in summer
         host = {k: inputs[k].slab(t_a, t_a + Tc).numpy() for k in synthetic.PV_VARS}
@@ -677,6 +1050,7 @@ def main():
             "single_thread_value": T1 * S / cdt1,
             "single_thread_sample": f"{T1} time steps, 1 thread ({cdt1:.2f} s)",
         }
+        del host
 
     if rank == 0 and single and not a.no_cpu_baseline and cfg["stored_angles"] and "cpu_baseline" in result:
         # BASELINE.md variant C: the same chain on dask.array 2021.10.0 (the reference's minimum pin), chunks {"time": 100},
@@ -699,10 +1073,24 @@ def main():
             except Exception as e:  # noqa: BLE001 - a second opinion, never a reason to lose the line
                 result["cpu_baseline"]["dask_array"] = {"skipped": repr(e)[:200]}
 
+    # ---- the other BASELINE.json configurations at N = 1, at their own sizes (after the C2 legs: their cubes go first) ----
+    cfg_legs = [l for l in ("c3_series", "c3_cf_map", "c3_aggregated", "c5_heat", "c5_runoff", "c4_full_sp") if want(l)]
+    if extras and cfg_legs:
+        del inputs, plan, full, full3, piece, pin, pins
+        import gc
+
+        gc.collect()
+        try:
+            result["configs"] = config_legs(ctx, cfg_legs, max(3, min(a.steps, 6)), check=not a.no_parity)
+        except Exception as e:  # noqa: BLE001 - never a reason to lose the headline line
+            result["configs"] = {"error": repr(e)[:400]}
+
     if rank == 0:
         print(json.dumps(result))
+    if comm is not None:
+        comm.close()
     if world > 1:
-        dist.barrier()
+        barrier()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -99,6 +99,19 @@ int atl_event_record(atl_ctx *ctx, atl_event *ev, int which_stream);
 int atl_stream_wait_event(atl_ctx *ctx, int which_stream, atl_event *ev);
 int atl_event_synchronize(atl_event *ev);
 
+/* ---- hipGraph capture of a call sequence -------------------------------------------------
+ * A launch-bound inner loop (a rank's 1/8 time shard of a year: fused kernel + k_combine, ~0.4 ms) replays as ONE
+ * graph launch: everything the conversion / aggregation entry points enqueue on the context's stream between
+ * atl_capture_begin and atl_capture_end is recorded instead of executed; atl_graph_launch replays it with the
+ * pointers and sizes of the recorded calls.  Run the sequence once before capturing it (the scratch arena must not
+ * grow inside a capture); blocking entry points (atl_upload, atl_download, atl_sync, atl_alloc) invalidate a
+ * capture; the kernel brackets of atl_set_profiling are not recorded. */
+typedef struct atl_graph atl_graph;
+int atl_capture_begin(atl_ctx *ctx);
+int atl_capture_end(atl_ctx *ctx, atl_graph **out);
+int atl_graph_launch(atl_ctx *ctx, atl_graph *graph);
+int atl_graph_destroy(atl_graph *graph);
+
 /* ---- timing (HIP events on the context's stream) ----------------------------------- */
 /* Bracket any sequence of calls; atl_timer_stop synchronises and returns elapsed ms. */
 int atl_timer_start(atl_ctx *ctx);
@@ -448,6 +461,27 @@ int atl_allreduce_sum(atl_comm *comm, double *d_buf, int64_t n);
  * d_out (N x sum h_lens, row stride ld_out) on every rank.  h_lens: n_ranks host values, the same on all ranks. */
 int atl_allgather_time_v(atl_comm *comm, const double *d_local, int64_t N, const int64_t *h_lens, double *d_out,
                          int64_t ld_out);
+/* The same collective on the COMMUNICATOR'S OWN stream, ordered after everything enqueued on the context's stream so
+ * far: a step's all-gather and placement run behind the NEXT step's kernel (the reference's time chunks are
+ * independent, atlite/aggregate.py:21-32, so nothing but the result buffers orders two steps).  *ticket names the
+ * collective; atl_comm_wait(comm, ticket) makes the context's stream wait for it (and every earlier one) - call it
+ * before a kernel overwrites that collective's d_local or reads its d_out; atl_comm_sync blocks the host until the
+ * communicator's stream has drained.  The staging buffers belong to the communicator. */
+int atl_allgather_time_v_async(atl_comm *comm, const double *d_local, int64_t N, const int64_t *h_lens, double *d_out,
+                               int64_t ld_out, int64_t *ticket);
+int atl_comm_wait(atl_comm *comm, int64_t ticket);
+int atl_comm_sync(atl_comm *comm);
+/* One thread, several devices: the RCCL communicators of ctxs[0..n_ranks) (distinct devices) in ONE ncclGroupStart /
+ * ncclGroupEnd bracket, rank r on ctxs[r] - what a single-process host (atlite_amd.multigpu) uses instead of N threads
+ * each calling atl_comm_init (concurrent ncclCommInitRank calls on distinct devices of one process can wait for each
+ * other for good).  atl_comm_init itself gives up after $ATLITE_HIP_COMM_TIMEOUT_S (120 s) when the other ranks do
+ * not join. */
+int atl_comm_init_all(atl_ctx *const *ctxs, int n_ranks, atl_comm **out);
+/* What the communicator itself says: ranks in it (ncclCommCount), this rank, its device ordinal (ncclCommCuDevice),
+ * the transport.  Any out pointer may be NULL. */
+#define ATL_COMM_RCCL 0
+#define ATL_COMM_LOCAL 1
+int atl_comm_info(atl_comm *comm, int *n_ranks, int *rank, int *device, int *transport);
 /* In-process transport: the ranks are host threads of one process (one atl_ctx each, on distinct devices or - for
  * tests on a one-GPU box - sharing one).  Every rank pulls its peers' blocks with peer copies on its own stream
  * (point-to-point xGMI reads, no ring), ordered by events; the host rendezvous inside a collective gives up after

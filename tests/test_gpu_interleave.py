@@ -169,31 +169,3 @@ def test_file_backed_variables_are_inflated_straight_into_their_slots(monkeypatc
     w2 = cm.wind(turbine="Vestas_V112_3MW", matrix=M, aggregate_time=None)
     np.testing.assert_array_equal(w.values, w2.values)
     assert sorted(len(p.names) for p in pools(cf.data).values()) == [2, 7]
-
-
-def test_placed_allocation_keeps_one_block_and_frees_the_other_candidates(ctx, monkeypatch, capfd):
-    """device.alloc_placed (experimental, ATLITE_HIP_PLACE=1): up to six candidates for a large block, a timed read of each, the
-    fastest wins (profiles/r03_vram_map.txt).  Whatever it picks, exactly one block stays allocated: six rounds of up to five 24 GB candidates
-    would exhaust the device if the losing ones leaked."""
-    from atlite_amd.device import alloc_placed
-
-    n = 3 * 2**30  # elements: 24 GiB
-    monkeypatch.setenv("ATLITE_HIP_DEBUG_PLACE", "1")
-    monkeypatch.setenv("ATLITE_HIP_PLACE", "1")  # (experimental: off by default)
-    for _ in range(6):
-        b = alloc_placed(ctx, n)
-        assert b.size == n and b.ptr
-        b.free()
-    err = capfd.readouterr().err
-    assert err.count("placement probe") == 6 and "-> candidate" in err
-    monkeypatch.setenv("ATLITE_HIP_PLACE", "0")
-    b = alloc_placed(ctx, n)
-    assert "placement probe" not in capfd.readouterr().err
-    b.free()
-    small = alloc_placed(ctx, 1000)  # below 1 GiB: a plain allocation
-    assert small.size == 1000
-    # profiling state of the context is what it was
-    ctx.set_profiling(False)
-    monkeypatch.setenv("ATLITE_HIP_PLACE", "1")
-    alloc_placed(ctx, 2**27).free()
-    assert ctx._profiling == 0

@@ -151,10 +151,14 @@ def test_rccl_ragged_allgather_single_rank(ctx):
     comm.close()
 
 
-def test_bench_collective_branch_over_rccl_on_one_rank():
-    """bench.py's N > 1 step (async RCCL all-gather on the process group's stream, ordered against the kernels' stream
-    by torch, strided placement copy) on a 1-rank RCCL group - what can be exercised of it with a single GPU; the
-    parity leg checks the reassembled result against the oracle."""
+@pytest.mark.parametrize("mode", [["--collective", "lib"], ["--collective", "lib", "--no-step-overlap"],
+                                  ["--collective", "lib", "--graph"], ["--collective", "torch", "--pipeline", "2"]])
+def test_bench_collective_branch_over_rccl_on_one_rank(mode):
+    """bench.py's N > 1 step on a 1-rank RCCL communicator - what can be exercised of it with a single GPU: the library's
+    own collective (atl_comm_init + atl_allgather_time_v_async on the communicator's stream behind the next step's
+    kernel; the blocking form; the step's launches replayed as a hipGraph) and torch.distributed's (async all-gather on
+    the process group's stream + strided placement copy).  The parity leg checks the reassembled result against the
+    oracle."""
     import json
     import os
     import subprocess
@@ -165,12 +169,14 @@ def test_bench_collective_branch_over_rccl_on_one_rank():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, str(root / "bench.py"), "--debug-rccl-self", "--pipeline", "2", "--steps", "3", "--warmup", "1",
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--debug-rccl-self", *mode, "--steps", "3", "--warmup", "1",
                         "--T", "960", "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     j = json.loads(line)
     assert j["parity"]["ok"] and j["parity"]["max_rel_err"] < 1e-10, j["parity"]
+    if "lib" in mode:
+        assert j["multi_gpu"]["collective"].startswith("library") and j["multi_gpu"]["ranks_seen"] == [1], j["multi_gpu"]
 
 
 
@@ -227,6 +233,107 @@ def test_local_transport_ragged_allgather_and_ordered_allreduce(lens):
         pool.shutdown()
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.parametrize("lens", [[40, 40, 40], [5, 0, 9, 33]])
+def test_async_allgather_on_the_communicators_own_stream(lens):
+    """atl_allgather_time_v_async: the collective and its placement run on the communicator's own stream, ordered after
+    the context's stream; atl_comm_wait orders the context's stream behind a ticket.  Several steps in flight with two
+    send buffers by parity (what bench.py's N > 1 step does), N ranks on one GPU over the in-process transport; the
+    communicator reports its size and transport (atl_comm_info)."""
+    n, N, steps = len(lens), 6, 5
+    rng = np.random.default_rng(11)
+    blocks = [[rng.normal(size=(N, m)) for m in lens] for _ in range(steps)]
+    ctxs, grp, comms, pool = _local_ranks(n)
+    try:
+        def rank(r):
+            ctx, comm = ctxs[r], comms[r]
+            assert comm.info() == dict(n_ranks=n, rank=r, device=0, transport="local")
+            send = [ctx.empty((N, max(lens[r], 1))) for _ in range(2)]
+            outs = [ctx.zeros((N, sum(lens))) for _ in range(steps)]
+            tickets = [None, None]
+            for s in range(steps):
+                par = s & 1
+                if tickets[par] is not None:
+                    comm.wait(tickets[par])  # the gather that read send[par] two steps ago
+                if lens[r]:
+                    check(ctx.lib.atl_upload(ctx.handle, send[par].ptr, np.ascontiguousarray(blocks[s][r]).ctypes.data, blocks[s][r].nbytes))
+                tickets[par] = comm.gather_time_v_async(send[par].ptr if lens[r] else None, N, lens, outs[s].ptr, sum(lens))
+            comm.wait(tickets[(steps - 1) & 1])
+            comm.sync()
+            ctx.sync()
+            return [o.numpy() for o in outs]
+
+        from atlite_amd._lib import check
+
+        res = list(pool.map(rank, range(n)))
+        for got in res:
+            for s in range(steps):
+                np.testing.assert_array_equal(got[s], np.concatenate(blocks[s], axis=1))
+    finally:
+        for c in comms:
+            c.close()
+        grp.close()
+        pool.shutdown()
+        for c in ctxs:
+            c.close()
+
+
+def test_rccl_init_all_and_info(ctx):
+    """atl_comm_init_all: the communicators of a device list from ONE thread inside ncclGroupStart / ncclGroupEnd (what
+    multigpu.DeviceGroup uses for distinct devices); with the single device of this box: one rank, which RCCL itself
+    confirms (ncclCommCount / ncclCommCuDevice through atl_comm_info).  A repeated device is refused before RCCL sees it."""
+    from atlite_amd.device import Context
+    from atlite_amd.distributed import RcclComm
+
+    (comm,) = RcclComm.init_all([ctx])
+    assert comm.info() == dict(n_ranks=1, rank=0, device=ctx.device, transport="rccl")
+    a = np.random.default_rng(0).random((5, 37))
+    np.testing.assert_array_equal(comm.gather_time(ctx.upload(a)).numpy(), a)
+    out = ctx.zeros((5, 37))
+    t = comm.gather_time_v_async(ctx.upload(a).ptr, 5, [37], out.ptr, 37)
+    comm.wait(t)
+    ctx.sync()
+    np.testing.assert_array_equal(out.numpy(), a)
+    comm.close()
+    other = Context(ctx.device)
+    with pytest.raises(ValueError, match="appears twice"):
+        RcclComm.init_all([ctx, other])
+    other.close()
+
+
+def test_hipgraph_capture_replays_a_conversion(ctx):
+    """atl_capture_begin / atl_capture_end / atl_graph_launch: a fused pv convert + aggregate call recorded once replays
+    with the same bits; growing the scratch arena inside a capture is refused (run the sequence once first)."""
+    import ctypes as C
+
+    from atlite_amd._lib import check
+    from oracle import atlite_oracle as orc
+
+    T, Y, X, N = 96, 12, 20, 5
+    ds = H.pv_dataset(T, Y, X, seed=4)
+    M = H.blob_matrix(N, Y, X, seed=5)
+    params = dict(H.CSI, slope=np.radians(30.0), azimuth=np.radians(180.0))
+    dev = {k: ctx.upload(v) for k, v in ds.items()}
+    plan = ctx.plan(M, row_len=X)
+    out = ctx.zeros((N, T))
+    ref = ctx.pv(dev, params, T, Y * X, plan=plan).numpy()  # (also settles the scratch arena)
+    check(ctx.lib.atl_capture_begin(ctx.handle))
+    ctx.pv(dev, params, T, Y * X, plan=plan, out=(out.ptr, T))
+    g = C.c_void_p()
+    check(ctx.lib.atl_capture_end(ctx.handle, C.byref(g)))
+    ctx.sync()
+    assert not out.numpy().any()  # recorded, not executed
+    for _ in range(3):
+        check(ctx.lib.atl_memset(ctx.handle, out.ptr, 0, out.nbytes))
+        check(ctx.lib.atl_graph_launch(ctx.handle, g))
+        ctx.sync()
+        np.testing.assert_array_equal(out.numpy(), ref)
+    check(ctx.lib.atl_graph_destroy(g))
+    want = orc.aggregate_matrix(orc.convert_pv(ds, H.CSI, dict(slope=params["slope"], azimuth=params["azimuth"])), M)
+    np.testing.assert_allclose(ref, want, rtol=1e-10, atol=1e-12 * np.abs(want).max())
+    with pytest.raises(ValueError, match="no capture is open"):
+        check(ctx.lib.atl_capture_end(ctx.handle, C.byref(C.c_void_p())))
 
 
 def test_local_transport_times_out_instead_of_hanging(monkeypatch):

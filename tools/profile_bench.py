@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""
+rocprofv3 over bench.py itself, leg by leg (run on the GPU box):
+
+    python tools/profile_bench.py <out_dir> [group ...]        groups: headline night_skip star configs c4
+
+For every group three separate passes of the SAME command (``python bench.py --legs ...``): --kernel-trace --stats,
+--pmc FETCH_SIZE, --pmc WRITE_SIZE (never combined with other trace domains).  The dominant kernel of a leg is found by
+NAME (bench.KERNELS), never by "largest total".  Writes <out_dir>/<group>.txt (per-kernel tables of the three passes)
+and <out_dir>/bench_profile_latest.json:
+
+    {"legs": {leg: {kernel, calls, avg_us, median_us, min_us, max_us, read_bytes, write_bytes, hbm_bytes_per_launch, source}}}
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports
+half of a wide (16 B per lane) streaming read, so the read side is doubled (re-derived with a known-size read in
+profiles/r03_partial_line_probe.txt).  Copy the directory's .txt / .json files into profiles/ to commit them.
+"""
+import glob
+import json
+import os
+import sqlite3
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+GROUPS = {
+    # group -> (bench.py arguments, {leg: kernel name key in bench.KERNELS})
+    "headline": (["--legs", "none"], ["headline"]),
+    "night_skip": (["--legs", "night_skip"], ["night_skip"]),
+    "star": (["--legs", "none", "--shape-kind", "star"], ["star_polygons"]),
+    "configs": (["--legs", "c3_series,c3_cf_map,c3_aggregated,c5_heat,c5_runoff"],
+                ["c3_series", "c3_cf_map", "c3_aggregated", "c5_heat", "c5_runoff"]),
+    "c4": (["--legs", "c4_full_sp"], ["c4_full_sp"]),
+}
+COMMON = ["--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-parity"]
+
+
+def short(n):
+    return n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+
+
+def db(path):
+    f = glob.glob(f"{path}/**/*.db", recursive=True)
+    return sqlite3.connect(f[0]) if f else None
+
+
+def run_pass(out, name, extra):
+    d = f"{out}/{name}"
+    cmd = ["rocprofv3", *extra, "-d", d, "-o", "run", "--", sys.executable, str(ROOT / "bench.py")]
+    return d, cmd
+
+
+def main():
+    out = Path(sys.argv[1]).resolve()
+    groups = sys.argv[2:] or list(GROUPS)
+    out.mkdir(parents=True, exist_ok=True)
+    from bench import KERNELS
+
+    env = dict(os.environ, TMPDIR="/tmp")
+    latest_f = out / "bench_profile_latest.json"
+    latest = json.loads(latest_f.read_text()) if latest_f.exists() else {"note": __doc__.strip().split("\n\n")[0], "legs": {}}
+    tag = os.environ.get("ATL_PROFILE_TAG", "r04")
+    for g in groups:
+        args, legs = GROUPS[g]
+        lines, per_pass = [], {}
+        for pname, extra in (("stats", ["--kernel-trace", "--stats"]), ("fetch", ["--pmc", "FETCH_SIZE", "--kernel-trace"]),
+                             ("write", ["--pmc", "WRITE_SIZE", "--kernel-trace"])):
+            d, cmd = run_pass(out / f"raw_{g}", pname, extra)
+            with open(out / f"{g}.{pname}.log", "w") as log:
+                subprocess.run(cmd + args + COMMON, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, check=False)
+            per_pass[pname] = db(d)
+        stats = {}
+        con = per_pass["stats"]
+        if con:
+            lines.append(f"== {tag} {g}: rocprofv3 --kernel-trace --stats -- python bench.py {' '.join(args + COMMON)}  (durations in us) ==")
+            lines.append(f"{'kernel':72s} {'calls':>6s} {'total':>12s} {'avg':>10s} {'median':>10s} {'min':>10s} {'max':>10s} {'%':>6s}")
+            per = {}
+            for n, du in con.execute("select name, duration from kernels order by start"):
+                per.setdefault(short(n), []).append(du / 1e3)
+            tot = sum(sum(v) for v in per.values())
+            for n, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+                sv = sorted(v)
+                stats[n] = dict(calls=len(v), avg_us=sum(v) / len(v), median_us=sv[len(sv) // 2], min_us=sv[0], max_us=sv[-1])
+                lines.append(f"{n:72s} {len(v):6d} {sum(v):12.1f} {stats[n]['avg_us']:10.1f} {stats[n]['median_us']:10.1f} {sv[0]:10.1f} {sv[-1]:10.1f} {100 * sum(v) / tot:6.2f}")
+            lines.append("")
+            lines.append("== dispatch resources (as rocprofv3 reports them) ==")
+            for n, v, av, sg, l, sc, gx, w in con.execute(
+                    "select name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x from kernels group by name"):
+                lines.append(f"{short(n):72s} vgpr={v} agpr={av} sgpr={sg} lds={l} scratch={sc} grid={gx} wg={w}")
+        pmc = {}
+        for pname, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            con = per_pass[pname]
+            if not con:
+                continue
+            lines.append("")
+            lines.append(f"== rocprofv3 --pmc {cname} (its own pass): per-kernel averages, KiB per launch ==")
+            for k, cn, c, a, mn, mx in con.execute("select kernel_name, counter_name, count(*), avg(v), min(v), max(v) from (select dispatch_id, "
+                                                    "kernel_name, counter_name, sum(value) as v from counters_collection group by dispatch_id, "
+                                                    "kernel_name, counter_name) group by kernel_name, counter_name"):
+                pmc.setdefault(short(k), {})[cn] = a
+                lines.append(f"{short(k):72s} {cn:11s} n={c:3d} avg={a:16.1f} min={mn:16.1f} max={mx:16.1f}")
+        lines.append("")
+        lines.append("== legs of this group (kernel chosen by NAME; read = 2 x FETCH_SIZE KiB [gfx950 wide-read correction], write = WRITE_SIZE KiB) ==")
+        for leg in legs:
+            k = KERNELS[leg]
+            if k not in stats:
+                lines.append(f"{leg}: kernel {k} did not run in this pass")
+                continue
+            e = dict(kernel=k, **stats[k], source=f"profiles/{tag}_bench_{g}.txt")
+            if k in pmc and "FETCH_SIZE" in pmc[k]:
+                e["read_bytes"] = 2.0 * pmc[k]["FETCH_SIZE"] * 1024
+                e["write_bytes"] = pmc[k].get("WRITE_SIZE", 0.0) * 1024
+                e["hbm_bytes_per_launch"] = e["read_bytes"] + e["write_bytes"]
+            latest["legs"][leg] = e
+            lines.append(f"{leg}: {k}  avg {e['avg_us']:.1f} us over {e['calls']} launches" +
+                         (f"  read {e['read_bytes'] / 1e9:.3f} GB  write {e['write_bytes'] / 1e9:.3f} GB" if "read_bytes" in e else ""))
+        (out / f"{tag}_bench_{g}.txt").write_text("\n".join(lines) + "\n")
+        print("\n".join(lines), flush=True)
+        latest_f.write_text(json.dumps(latest, indent=1) + "\n")
+        # the raw databases are large: keep the summaries only
+        subprocess.run(["rm", "-rf", str(out / f"raw_{g}")], check=False)
+
+
+if __name__ == "__main__":
+    main()
