@@ -566,7 +566,7 @@ struct PvConvT {
 #define ATL_PV_WAVES 3  // the headline kernel (stored angles, one orientation, every byte read): 149 VGPRs
 #endif
 #ifndef ATL_SP_WAVES
-#define ATL_SP_WAVES 4  // in-kernel solar position, every byte read: 128 VGPRs + 32 B of scratch at 4 waves beat 138 VGPRs at 3 (C2: 2.41 vs 2.53 ms, six alternating runs)
+#define ATL_SP_WAVES 4  // in-kernel solar position, every byte read: 115 VGPRs with the batch's values parked in LDS (kStageValues; round 3: 128 + 32 B of scratch, 138 at 3 waves)
 #endif
 #ifndef ATL_PV_TRKNIGHT_WAVES
 #define ATL_PV_TRKNIGHT_WAVES 3  // night early-out behind a tracker: 48-112 B of scratch at 3 waves (C2 horizontal 2.74 ms) beat 2 waves (2.89 ms)
@@ -575,6 +575,14 @@ struct PvConvT {
 #define ATL_PV_BOFTRK_WAVES 3  // bofinger panel behind a tracker, the family's largest converters: 3 waves with 16-80 B of
                                // scratch beat 2 waves without (C2: 3.23 vs 3.50 ms horizontal, 3.62 vs 4.00 ms tilted + Hay-Davies + per-cell)
 #endif
+#ifndef ATL_SP_STAGE
+#define ATL_SP_STAGE 1
+#endif
+    // in-kernel solar position, every byte read, one orientation: the batch's converted values wait in LDS
+#ifndef ATL_PV_STAGE
+#define ATL_PV_STAGE 0
+#endif
+    static constexpr bool kStageValues = (ATL_SP_STAGE != 0 && SP && !SKIP && !PC) || (ATL_PV_STAGE != 0 && !SP && !SKIP);
     static constexpr int kCubes = SP ? 5 : HEAD == 1 ? 6 : 7;  // cubes streamed per slot (fused kernel: how short a chunk may get)
     static constexpr int kMinWaves = (kNightPipe && !PC && HEAD == 0 && TAIL == kTailHuld && TRACK == ATL_TRACK_NONE) ? (SP ? ATL_SP_NIGHT_WAVES : 4)
                                      : (tail_panel(TAIL) == kTailBofinger && TRACK != ATL_TRACK_NONE) ? ATL_PV_BOFTRK_WAVES

@@ -186,6 +186,13 @@ struct conv_vec_only : std::false_type {};
 template <class Conv>
 struct conv_vec_only<Conv, std::void_t<decltype(Conv::kVecOnly)>> : std::integral_constant<bool, Conv::kVecOnly> {};
 constexpr int kNeedScalar = 1;  // internal status, never returned through the C ABI
+// converters whose fused kernel parks the converted values of a batch in the wave's LDS rows instead of registers
+// (kStageValues): 32 VGPRs less at the conversion's peak - what lets the in-kernel solar position run 4 waves per SIMD
+// without scratch; the weight cache shrinks to kRowCacheNight rows so that four workgroups still share a CU's 160 KiB
+template <class Conv, class = void>
+struct conv_stage_values : std::false_type {};
+template <class Conv>
+struct conv_stage_values<Conv, std::void_t<decltype(Conv::kStageValues)>> : std::integral_constant<bool, Conv::kStageValues> {};
 template <class Conv, class = void>
 struct conv_night_pipe : std::false_type {};
 template <class Conv>
@@ -359,6 +366,10 @@ __device__ __forceinline__ void reduce_row(const double2 (&v)[kBatch], double2 w
     if ((lane & 7) == 0 && sb + g < send) prow[sb + g] = f;
 }
 
+#ifndef ATL_ROW_CACHE_NIGHT
+#define ATL_ROW_CACHE_NIGHT 2
+#endif
+constexpr int kRowCacheNight = ATL_ROW_CACHE_NIGHT;  // ... in the kernels that also keep a batch's values in LDS rows (4 waves per SIMD)
 constexpr int kRowCache = ATL_ROW_CACHE;  // partial rows of a tile whose weights sit in the wave's LDS area for the chunk
 constexpr int kRowCacheDense = 3;        // ... in the instantiation that also carries the MFMA path and its LDS value rows
 constexpr int kDenseSlots = 2 * kBatch;  // slots a dense tile of k_fused_segred contracts per MFMA sweep (= the instruction's 16 columns)
@@ -490,9 +501,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
     const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
     // per-wave LDS area behind the converter's tables: the weights of the tile's first kRowCache partial
     // rows (LDS instead of 4 VGPRs per row for the whole chunk: the register budget decides the occupancy)
-    constexpr int ROWS = row_cache<DENSE>();
-    constexpr int kWaveLds = ROWS * kSegCells;
+    constexpr bool STAGE = conv_stage_values<Conv>::value && !DENSE;
+    constexpr int ROWS = STAGE ? kRowCacheNight : row_cache<DENSE>();
+    constexpr int kWaveLds = (ROWS + (STAGE ? kBatch : 0)) * kSegCells;
     double *wlds = lds + conv_lds_doubles + wave * kWaveLds;
+    [[maybe_unused]] double *vstage = wlds + ROWS * kSegCells + 2 * lane;  // STAGE: this lane's 16 bytes of the wave's value rows
 #ifndef ATL_XCD_MAP
     // Linear order: consecutive blocks (= consecutive XCDs, block b runs on XCD b % 8) take consecutive
     // tile groups of the same time chunk, so the chip as a whole streams contiguous memory.
@@ -605,7 +618,17 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
                     v[i].x = live ? v[i].x : 0.0;
                     v[i].y = live ? v[i].y : 0.0;
                     finite = finite && (__builtin_fabs(v[i].x) < __builtin_inf()) && (__builtin_fabs(v[i].y) < __builtin_inf());
+                    if constexpr (STAGE) *reinterpret_cast<double2 *>(vstage + i * kSegCells) = v[i];
                 }
+            }
+            if constexpr (STAGE) {
+                // the values went to the wave's LDS rows as they were converted and come back for the reduction: the
+                // compiler must not forward them through registers (each lane reads its own 16 bytes: no barrier)
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" ::: "memory");
+#endif
+#pragma unroll
+                for (int i = 0; i < kBatch; ++i) v[i] = *reinterpret_cast<const double2 *>(vstage + i * kSegCells);
             }
         }
 #ifdef ATL_ABLATE_NOREDUCE  // experiment: conversion only, one dummy store per batch
@@ -631,10 +654,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
 // LDS and a loop instead of eight unrolled slots the kernel needs < 128 VGPRs: 4 waves per SIMD, for which
 // the LDS budget (160 KiB / 16 waves) leaves kRowCacheNight = 2 weight rows per wave.  Converters opt in with
 // kNightPipe and provide key_load / key_is_zero / rest_load / compute_keyed.
-#ifndef ATL_ROW_CACHE_NIGHT
-#define ATL_ROW_CACHE_NIGHT 2
-#endif
-constexpr int kRowCacheNight = ATL_ROW_CACHE_NIGHT;
 template <class Conv, bool VEC, bool DENSE>
 __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 2 : min_waves<Conv>()) void k_fused_segred_night(Conv conv, PlanDev plan, int64_t slot0,
                                                       int64_t n_slots, int64_t S, int32_t chunk_slots,
@@ -996,7 +1015,10 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
                 hipLaunchKernelGGL(kern, grid, dim3(kWavesPerBlock * 64), lds_sz, ctx->stream, conv, plan, w0, wn, S,
                                    chunk_slots, n_units, partials, ldp, conv_lds_doubles);
             };
-            const size_t lds_base = conv_lds + size_t(kWavesPerBlock) * (dense ? kRowCacheDense + kDenseSlots : kRowCache) * kSegCells * sizeof(double);
+            // (converters that park a batch's values in LDS - kStageValues - take the early-out kernels' layout: two cached
+            // weight rows + eight value rows per wave, 40 KiB per workgroup, four workgroups per CU)
+            const bool stage = conv_stage_values<Conv>::value && !dense;
+            const size_t lds_base = conv_lds + size_t(kWavesPerBlock) * (dense ? kRowCacheDense + kDenseSlots : stage ? kRowCacheNight + kBatch : kRowCache) * kSegCells * sizeof(double);
             if constexpr (conv_night_pipe<Conv>::value) {
                 const size_t lds_night = conv_lds + size_t(kWavesPerBlock) * (kRowCacheNight + kBatch) * kSegCells * sizeof(double);
                 if (!vec) {

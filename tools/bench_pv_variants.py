@@ -98,7 +98,15 @@ for name, nbytes, fn in (
      lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="solar_thermal", c0=0.8, c1=3.0, t_store_K=353.15, night_skip=True))),
     ("influx / outflux dataset (Reindl split, albedo from outflux) - fast family head (r02; was the general kernel)", 48,
      lambda: ctx.pv(influx_ds, scal, T, S, plan=plan)),
-    ("general kernel: influx / outflux dataset + Hay-Davies", 48, lambda: ctx.pv(influx_ds, scal, T, S, plan=plan, options=dict(trigon_model="other"))),
+    ("influx / outflux dataset + Hay-Davies - fast family head (r04; was the general kernel)", 48, lambda: ctx.pv(influx_ds, scal, T, S, plan=plan, options=dict(trigon_model="other"))),
+    ("influx / outflux dataset, enhanced clearsky model (humidity) - fast family head (r04; was the general kernel)", 56,
+     lambda: ctx.pv(dict(influx_ds, humidity=inputs["albedo"]), scal, T, S, plan=plan, options=dict(clearsky_model="enhanced"))),
+    ("influx / outflux dataset, enhanced clearsky model + Hay-Davies - fast family head (r04)", 56,
+     lambda: ctx.pv(dict(influx_ds, humidity=inputs["albedo"]), scal, T, S, plan=plan, options=dict(clearsky_model="enhanced", trigon_model="other"))),
+    ("influx / outflux dataset + Hay-Davies + night early-out (r04)", 48, lambda: ctx.pv(influx_ds, scal, T, S, plan=plan, options=dict(trigon_model="other", night_skip=True))),
+    ("general kernel: influx dataset with an albedo cube + Hay-Davies (what is left for it)", 48,
+     lambda: ctx.pv(dict(influx=inputs["influx_direct"], influx_toa=inputs["influx_toa"], albedo=inputs["albedo"], temperature=inputs["temperature"],
+                         solar_altitude=inputs["solar_altitude"], solar_azimuth=inputs["solar_azimuth"]), scal, T, S, plan=plan, options=dict(trigon_model="other"))),
     ("per-cell series out (no matrix), no early-out", 64, lambda: ctx.pv(inputs, scal, T, S, options=dict(night_skip=False))),
     ("per-cell series out (no matrix) + night early-out", 64, lambda: ctx.pv(inputs, scal, T, S, options=dict(night_skip=True, row_len=X))),
     ("per-cell time-mean (capacity factor map), no early-out", 56, lambda: ctx.pv(inputs, scal, T, S, time_agg="mean", options=dict(night_skip=False))),
