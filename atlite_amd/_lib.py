@@ -249,6 +249,10 @@ SIGNATURES = {
     "atl_capture_end": (_i, [_vp, C.POINTER(_vp)]),
     "atl_graph_launch": (_i, [_vp, _vp]),
     "atl_graph_destroy": (_i, [_vp]),
+    "atl_rolling_mean": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64]),
+    "atl_order_statistic": (_i, [_vp, _vp, _i64, _i64, _i64, _d, c_int64_p, c_double_p, c_int64_p, c_int64_p]),
+    "atl_zero_below": (_i, [_vp, _vp, _i64, _i64, _i64, _d]),
+    "atl_normalize_rows": (_i, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "atl_set_slot_stride": (_i, [_vp, _i64]),
     "atl_copy_2d": (_i, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_size_t, _i, _i]),
     "atl_comm_group_create": (_i, [_i, C.POINTER(_vp)]),

@@ -731,6 +731,10 @@ def convert_and_aggregate(
                           FutureWarning, stacklevel=2)
             aggregate_time = None
 
+    # private: a callable (ctx, (N, T) DeviceArray, time coordinate) -> DeviceArray applied to the aggregated series while
+    # it is still in HBM (runoff()'s post-processing, convert.py:1046-1082); only honoured where the (dim, time) series is
+    # the call's result as it leaves the device
+    device_post = convert_kwds.pop("_device_post", None)
     func_name = convert_func.__name__.replace("convert_", "")
     logger.info(f"Convert and aggregate '{func_name}'.")
     ds = _as_dataset(cutout.data)
@@ -817,7 +821,11 @@ def convert_and_aggregate(
     else:
         # (the slot stride of the dataset's device copies only steers the plan's tile shape)
         plan = ctx.plan(matrix, row_len=X, ld=getattr(ds, "_slot_stride", lambda: None)())
-        out = _execute(ctx, spec, ds, plan, on_device_time).numpy()  # the plan stays in ctx's cache
+        out = _execute(ctx, spec, ds, plan, on_device_time)  # the plan stays in ctx's cache
+        if device_post is not None and on_device_time is None and not per_unit and aggregate_time in (None, "legacy"):
+            out = device_post(ctx, out, spec.time_coord(ds))
+            device_post.applied = True
+        out = out.numpy()
     tc = spec.time_coord(ds)
     attrs = {}
 
@@ -983,54 +991,67 @@ def coefficient_of_performance(cutout, source="air", sink_T=55.0, c0=None, c1=No
     )
 
 
-def _runoff_postprocess(la, smooth=None, lower_threshold_quantile=None, normalize_using_yearly=None):
-    """convert.py:1045-1082 on the small (shapes x time) result, host side: rolling mean over `smooth` steps
-    (min_periods=1), values below the `lower_threshold_quantile` quantile of all values set to 0, and scaling to
-    reported yearly totals over the full years the series and `normalize_using_yearly` share."""
-    if smooth is not None:
-        if smooth is True:
-            smooth = 24 * 7
-        ax = la.get_axis_num("time")
-        df = pd.DataFrame(np.moveaxis(la.values, ax, 0))
-        sm = df.rolling(smooth, min_periods=1).mean().values
-        la = LabeledArray(np.moveaxis(sm, 0, ax), la.dims, la.coords, la.attrs, la.name)
+class _RunoffPost:
+    """convert.py:1046-1082 on the (shapes x time) result WHILE IT IS ON THE DEVICE (ctx.rolling_mean / quantile / zero_below /
+    normalize_rows -> atl_rolling_mean, atl_order_statistic, atl_zero_below, atl_normalize_rows): rolling mean over `smooth`
+    steps (min_periods=1), values below the `lower_threshold_quantile` quantile of all values set to 0, scaling to reported
+    yearly totals over the full years the series and `normalize_using_yearly` share.  Called by the gateway with the
+    aggregated series before its download (`applied`), or by runoff() on an uploaded copy of a result that reached the
+    host another way (per_unit, several devices, xarray in / out)."""
 
-    if lower_threshold_quantile is not None:
-        if lower_threshold_quantile is True:
-            lower_threshold_quantile = 5e-3
-        lower_threshold = pd.Series(la.values.ravel()).quantile(lower_threshold_quantile)
-        la = LabeledArray(np.where(la.values >= lower_threshold, la.values, 0.0), la.dims, la.coords, la.attrs,
-                          la.name)
+    def __init__(self, smooth, lower_threshold_quantile, normalize_using_yearly, dim_coords=None):
+        self.smooth = 24 * 7 if smooth is True else smooth
+        self.q = 5e-3 if lower_threshold_quantile is True else lower_threshold_quantile
+        self.norm = normalize_using_yearly
+        self.dim_coords = dim_coords  # labels of the rows (needed by the yearly normalisation); set by runoff()
+        self.applied = False
 
-    if normalize_using_yearly is not None:
-        nidx = normalize_using_yearly.index
+    def __bool__(self):
+        return self.smooth is not None or self.q is not None or self.norm is not None
+
+    def yearly(self, tc):
+        """-> (time mask (T,) of the full years shared with the reported totals, reported total per row label)."""
+        nidx = self.norm.index
         nidx = nidx.year if isinstance(nidx, pd.DatetimeIndex) else nidx.astype(int)
-        tyear = pd.Series(pd.to_datetime(la.coords["time"]).year)
+        tyear = pd.Series(pd.to_datetime(tc).year)
         years = tyear.value_counts().loc[lambda x: x > 8700].index.intersection(nidx)
         assert len(years), "Need at least a full year of data (more is better)"
         lo, hi = min(years), max(years)
-        tmask = ((tyear >= lo) & (tyear <= hi)).values
-        ax = la.get_axis_num("time")
-        dim = la.dims[1 - ax]
-        ref = normalize_using_yearly.copy()
+        ref = self.norm.copy()
         ref.index = nidx
-        ref = ref.loc[lo:hi].sum()
-        ref = ref.reindex(pd.Index(la.coords[dim])).values
-        tot = np.nansum(np.compress(tmask, la.values, axis=ax), axis=ax)
-        with np.errstate(invalid="ignore", divide="ignore"):
-            fac = ref / tot
-        shape = [1, 1]
-        shape[1 - ax] = -1
-        la = LabeledArray(la.values * fac.reshape(shape), la.dims, la.coords, la.attrs, la.name)
-    return la
+        return ((tyear >= lo) & (tyear <= hi)).values, ref.loc[lo:hi].sum()
+
+    def __call__(self, ctx, series, tc):
+        if self.smooth is not None:
+            series = ctx.rolling_mean(series, int(self.smooth), 1)
+        if self.q is not None:
+            series = ctx.zero_below(series, ctx.quantile(series, self.q))
+        if self.norm is not None:
+            tmask, ref = self.yearly(tc)
+            series = ctx.normalize_rows(series, tmask, ref.reindex(pd.Index(self.dim_coords)).values)
+        return series
 
 
 def runoff(cutout, smooth=None, lower_threshold_quantile=None, normalize_using_yearly=None, **params):
     """
-    Runoff (optionally height-weighted) aggregated to shapes, with the reference's
-    post-processing of the small (shapes x time) result on the host (convert.py:1037-1084).
+    Runoff (optionally height-weighted) aggregated to shapes, with the reference's post-processing of the small
+    (shapes x time) result (convert.py:1037-1084) - on the device, before the result is downloaded.
     """
+    post = _RunoffPost(smooth, lower_threshold_quantile, normalize_using_yearly)
+    if post:
+        # row labels of the result, for the yearly normalisation (the gateway's own rule: index, else the shapes' index)
+        idx = params.get("index")
+        if idx is None and isinstance(getattr(params.get("shapes"), "index", None), pd.Index):
+            idx = params["shapes"].index
+        if idx is None and hasattr(params.get("matrix"), "dims"):
+            m = params["matrix"]
+            idx = np.asarray(m.coords[m.dims[0]].values if hasattr(m.coords[m.dims[0]], "values") else m.coords[m.dims[0]])
+        post.dim_coords = idx
+        params = dict(params, _device_post=post)
     result = cutout.convert_and_aggregate(convert_func=convert_runoff, **params)
+    if not post or post.applied:
+        return result
+    # the series reached the host another way (per_unit, a time reduction, several devices): the same device routines on a copy
     cap = None
     if "return_capacity" in params.keys() and isinstance(result, tuple):
         result, cap = result
@@ -1038,8 +1059,13 @@ def runoff(cutout, smooth=None, lower_threshold_quantile=None, normalize_using_y
     la = result if not is_xr else LabeledArray(result.values, result.dims,
                                                {d: result.coords[d].values for d in result.dims},
                                                dict(result.attrs), result.name)
-
-    la = _runoff_postprocess(la, smooth, lower_threshold_quantile, normalize_using_yearly)
-
+    ax = la.get_axis_num("time")  # (a result without a time axis cannot be smoothed: the reference raises as well)
+    dim = la.dims[1 - ax]
+    if post.dim_coords is None or len(post.dim_coords) != la.shape[1 - ax]:
+        post.dim_coords = la.coords.get(dim, np.arange(la.shape[1 - ax]))
+    ctx = default_context()
+    vals = np.ascontiguousarray(np.moveaxis(np.asarray(la.values, dtype=np.float64), ax, 1))
+    out = post(ctx, ctx.upload(vals), la.coords["time"]).numpy()
+    la = LabeledArray(np.moveaxis(out, 1, ax), la.dims, la.coords, la.attrs, la.name)
     out = _finish(la) if is_xr or labeled.xr is not None else la
     return (out, cap) if cap is not None else out

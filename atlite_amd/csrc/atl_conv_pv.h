@@ -300,16 +300,30 @@ struct PvPlain {
     double r;
     bool ok;
 };
-// from cos(incidence) on: tilted irradiation (simple trigon model) + Huld panel, plain arithmetic
+// from cos(incidence) on: tilted irradiation (simple trigon model, or Hay-Davies: HD) + Huld panel, plain arithmetic
+template <bool HD = false>
 ATL_HD __forceinline__ PvPlain pv_tail_plain(double direct, double diffuse, double influx, double alb, double tmp,
                                                  double sa, double ca, double cosd, bool plain, bool capped,
-                                                 const PvOri &o, const PvConst &k) {
+                                                 const PvOri &o, const PvConst &k, double toa = 1.0) {
     const double inf = __builtin_inf();
     const double cosinc = __builtin_fmax(o.ss * ca * cosd + o.cs * sa, 0.0);
     const double kk = fast_div(cosinc, sa);
     const double direct_t = kk * direct;
-    const double diffuse_t = o.hp * diffuse;
-    const double ground_t = alb * influx * o.hm;
+    double diffuse_t;
+    if constexpr (HD) {
+        // irradiation.py:76-145 for a cell that is not capped (toa >= influx > 0.01) with direct >= 0: every quotient is a
+        // well-scaled reciprocal, the root's argument lies in [0, 1]; anything else (checked by the caller's `plain` and
+        // the finiteness of the result) goes to the careful routine
+        // (direct < 0: the enhanced clearsky model's diffuse fraction can exceed one - the root is NaN -> 0 there, fillna)
+        const bool ok = !capped && direct >= 0.0 && influx < 0x1.0p400 && toa > 0x1.0p-400 && toa < 0x1.0p400;
+        const double f = lean_sqrt(fast_div(direct, ok ? influx : 1.0));
+        const double A = fast_div(direct, ok ? toa : 1.0);
+        diffuse_t = __builtin_fmax(((1.0 - A) * o.hp * (1.0 + f * o.sh3) + A * kk) * diffuse, 0.0);
+        plain = plain && (capped || ok);
+    } else {
+        diffuse_t = o.hp * diffuse;
+    }
+    const double ground_t = HD ? influx * alb * o.hm : alb * influx * o.hm;
     const double G = direct_t + diffuse_t + ground_t;
     const double T_ = (k.c_amb * tmp + k.c_irr * G) - k.r_tmod;
     const double G_ = G * k.inv_r_irr;
@@ -371,7 +385,7 @@ ATL_HD __forceinline__ PvPlain pv_cell_sp_plain(double dir, double dif, double t
 // clips are plain min / max, and the two divisions take the guarded reciprocal path whenever the cell is not capped
 // (toa >= influx > 0.01 then).  Anything else - non-finite inputs, a toa outside the reciprocal's range - is handed to
 // pv_cell_influx.
-template <bool ENH = false>
+template <bool ENH = false, bool HD = false>
 ATL_HD __forceinline__ PvPlain pv_cell_influx_plain(double infl, double outf, double toa, double tmp, double rh, double alt,
                                                         double az, const PvOri &o, const PvConst &k) {
     const double inf = __builtin_inf();
@@ -402,7 +416,7 @@ ATL_HD __forceinline__ PvPlain pv_cell_influx_plain(double infl, double outf, do
     const bool capped = (alt < k.alt_thr) || (influx <= 0.01);
     const double alb = __builtin_fmin(fast_div(outf, capped ? 1.0 : influx), 1.0);
     const double cosd = cos_core(o.saz - az);
-    return pv_tail_plain(direct, diffuse, influx, alb, tmp, sa, ca, cosd, plain, capped, o, k);
+    return pv_tail_plain<HD>(direct, diffuse, influx, alb, tmp, sa, ca, cosd, plain, capped, o, k, toa);
 }
 
 // what the kernels evaluate for one cell: the plain evaluation where it is valid, pv_cell otherwise (the
@@ -422,8 +436,8 @@ ATL_HD __forceinline__ double pv_cell_auto(double dir, double dif, double toa, d
 template <int TAIL = kTailHuld, bool ENH = false>
 ATL_HD __forceinline__ double pv_cell_influx_auto(double infl, double outf, double toa, double tmp, double rh, double alt,
                                                       double az, const PvOri &o, const PvConst &k) {
-    if constexpr (ATL_PV_PLAIN != 0 && TAIL == kTailHuld) {
-        const PvPlain p = pv_cell_influx_plain<ENH>(infl, outf, toa, tmp, rh, alt, az, o, k);
+    if constexpr (ATL_PV_PLAIN != 0 && (TAIL == kTailHuld || TAIL == kTailHuldHayDavies)) {
+        const PvPlain p = pv_cell_influx_plain<ENH, TAIL == kTailHuldHayDavies>(infl, outf, toa, tmp, rh, alt, az, o, k);
         if (p.ok) return p.r;
     }
     return pv_cell_influx<TAIL, ENH>(infl, outf, toa, tmp, rh, alt, az, o, k);
@@ -717,11 +731,11 @@ struct PvConvT {
                 r.x = v0 ? pv_cell_sp(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.sd, q.cd, c.sl0, c.cl0, q.a.x, q.b.x, o0, a0, k) : 0.0;
                 r.y = v1 ? pv_cell_sp(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.sd, q.cd, c.sl1, c.cl1, q.a.y, q.b.y, o1, a1, k) : 0.0;
             }
-        } else if constexpr (HEAD != 0 && TAIL == kTailHuld && ATL_PV_PLAIN != 0) {
+        } else if constexpr (HEAD != 0 && (TAIL == kTailHuld || TAIL == kTailHuldHayDavies) && ATL_PV_PLAIN != 0) {
             // the pair side by side in plain arithmetic, as the direct / diffuse case below (influx rides in dir, outflux
             // in alb, the humidity of the enhanced clearsky model in dif); the dark test reads every loaded value, so no
             // load is sunk behind it
-            constexpr bool ENH = HEAD == 2;
+            constexpr bool ENH = HEAD == 2, HDT = TAIL == kTailHuldHayDavies;
             const double inf = __builtin_inf();
             const bool tame = __builtin_fabs(q.dir.x) < inf && __builtin_fabs(q.dir.y) < inf && __builtin_fabs(q.toa.x) < inf &&
                               __builtin_fabs(q.toa.y) < inf && __builtin_fabs(q.alb.x) < inf && __builtin_fabs(q.alb.y) < inf &&
@@ -730,8 +744,8 @@ struct PvConvT {
             const bool dark0 = !v0 || q.a.x < k.alt_thr, dark1 = !v1 || q.a.y < k.alt_thr;
             r.x = r.y = 0.0;
             if (!(dark0 && dark1 && tame)) {
-                const PvPlain p0 = pv_cell_influx_plain<ENH>(q.dir.x, q.alb.x, q.toa.x, q.tmp.x, q.dif.x, q.a.x, q.b.x, o0, k);
-                const PvPlain p1 = pv_cell_influx_plain<ENH>(q.dir.y, q.alb.y, q.toa.y, q.tmp.y, q.dif.y, q.a.y, q.b.y, o1, k);
+                const PvPlain p0 = pv_cell_influx_plain<ENH, HDT>(q.dir.x, q.alb.x, q.toa.x, q.tmp.x, q.dif.x, q.a.x, q.b.x, o0, k);
+                const PvPlain p1 = pv_cell_influx_plain<ENH, HDT>(q.dir.y, q.alb.y, q.toa.y, q.tmp.y, q.dif.y, q.a.y, q.b.y, o1, k);
                 r.x = p0.r;
                 r.y = p1.r;
                 if (__builtin_expect(!(p0.ok && p1.ok), 0)) {
@@ -741,7 +755,7 @@ struct PvConvT {
                 r.x = v0 ? r.x : 0.0;
                 r.y = v1 ? r.y : 0.0;
             }
-        } else if constexpr (HEAD != 0) {  // (Hay-Davies behind the influx head: the careful routine, cell by cell)
+        } else if constexpr (HEAD != 0) {  // (ATL_PV_PLAIN=0 builds: the careful routine, cell by cell)
             r.x = v0 ? pv_cell_influx<TAIL, HEAD == 2>(q.dir.x, q.alb.x, q.toa.x, q.tmp.x, q.dif.x, q.a.x, q.b.x, o0, k) : 0.0;
             r.y = v1 ? pv_cell_influx<TAIL, HEAD == 2>(q.dir.y, q.alb.y, q.toa.y, q.tmp.y, q.dif.y, q.a.y, q.b.y, o1, k) : 0.0;
         } else if constexpr (TAIL == kTailHuld && TRACK == ATL_TRACK_NONE && ATL_PV_PLAIN != 0) {

@@ -570,6 +570,48 @@ class Context:
             self._unstride()
         return res
 
+    # -- post-processing of a small (rows x time) result on the device (runoff: convert.py:1046-1082) ------------
+    def rolling_mean(self, series, window, min_periods=1):
+        """``rolling(time=window, min_periods=min_periods).mean()`` along the last axis of a (rows, T) DeviceArray."""
+        rows, T = series.shape
+        out = self.empty((rows, T))
+        check(self.lib.atl_rolling_mean(self.handle, series.ptr, rows, T, series.ld or T, int(window), int(min_periods), out.ptr, T))
+        return out
+
+    def quantile(self, series, q):
+        """``pd.Series(values.ravel()).quantile(q)`` of a (rows, T) DeviceArray: the two bracketing order statistics come
+        from a radix select on the device; the virtual index and the interpolation between them are numpy's "linear"
+        method as pandas calls it (``np.percentile(values, q * 100)``: the quantile is (q * 100) / 100)."""
+        rows, T = series.shape
+        q = float(np.true_divide(np.asarray(q, dtype=np.float64) * 100.0, 100))
+        n, rank = C.c_int64(), C.c_int64()
+        pair = (C.c_double * 2)()
+        check(self.lib.atl_order_statistic(self.handle, series.ptr, rows, T, series.ld or T, q, C.byref(n), pair, C.byref(rank), None))
+        if n.value == 0:
+            return float("nan")
+        a, b = pair[0], pair[1]
+        t = q * (n.value - 1) - rank.value  # gamma = virtual index - floor(virtual index)
+        if b != b:  # the virtual index is the last element
+            return a
+        diff = b - a  # numpy/lib/_function_base_impl.py: _lerp
+        return b - diff * (1.0 - t) if t >= 0.5 else a + diff * t
+
+    def zero_below(self, series, threshold):
+        """``where(series >= threshold, 0.0)`` in place."""
+        rows, T = series.shape
+        check(self.lib.atl_zero_below(self.handle, series.ptr, rows, T, series.ld or T, float(threshold)))
+        return series
+
+    def normalize_rows(self, series, time_mask, ref):
+        """Row r of the (rows, T) series times ``ref[r]`` / its nan-skipping sum over the steps with ``time_mask[t]``, in place."""
+        rows, T = series.shape
+        m = self.upload(np.ascontiguousarray(time_mask, dtype=np.uint8), np.uint8)
+        r = self.upload(np.ascontiguousarray(ref, dtype=np.float64))
+        assert m.size == T and r.size == rows
+        check(self.lib.atl_normalize_rows(self.handle, series.ptr, rows, T, series.ld or T, m.ptr, r.ptr))
+        self.sync()  # the two small uploads must outlive the kernel
+        return series
+
     # -- synthetic fields -------------------------------------------------------------------
     def synth_field(self, kind, seed, var_id, p0, p1, T, S, per_cell_static=False):
         out = self.empty((S,) if per_cell_static else (T, S))

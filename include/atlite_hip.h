@@ -330,6 +330,29 @@ int atl_runoff_convert_aggregate(atl_ctx *ctx, const double *d_runoff, const dou
                                  int64_t T, int64_t S, const atl_agg *agg, int time_agg,
                                  double *d_out, int64_t ld_out);
 
+/* ---- runoff post-processing on the (rows x time) result, on the device (atlite/convert.py:1046-1082) -------------
+ * The result of atl_runoff_convert_aggregate is a few MB that the reference then smooths, thresholds and rescales
+ * with xarray / pandas on the host; here it stays in HBM until it is final.  d: rows x T, row stride ld (time
+ * contiguous, what the aggregation writes).
+ * atl_rolling_mean     result.rolling(time=window, min_periods=min_periods).mean() (:1046-1052): mean of the finite
+ *                      values among the last `window` steps, NaN with fewer than min_periods of them; out of place.
+ *                      (+-inf counts as missing, as in pandas' rolling; xarray -> bottleneck.move_mean slides an
+ *                      uncompensated sum over the whole row - here compensated sums restart every 256 steps.)
+ * atl_order_statistic  the two order statistics that bracket pd.Series(values.ravel()).quantile(q) (:1054-1061,
+ *                      numpy's "linear" method: virtual index q (n - 1) over the n non-NaN values): h_pair[0] =
+ *                      x_(floor), h_pair[1] = x_(floor + 1) (NaN when there is none), *h_n = n, *h_rank = floor,
+ *                      *h_n_le = values <= x_(floor) (the last two may be NULL).  Radix select, blocks until done.
+ * atl_zero_below       result.where(result >= threshold, 0.0) (:1062), in place (NaN -> 0.0 as there).
+ * atl_normalize_rows   row r *= d_ref[r] / (nan-skipping sum of row r over the steps with d_time_mask[t] != 0)
+ *                      (:1064-1082: the full years the series and the reported totals share), in place. */
+int atl_rolling_mean(atl_ctx *ctx, const double *d_in, int64_t rows, int64_t T, int64_t ld_in, int64_t window,
+                     int64_t min_periods, double *d_out, int64_t ld_out);
+int atl_order_statistic(atl_ctx *ctx, const double *d_in, int64_t rows, int64_t T, int64_t ld, double q, int64_t *h_n,
+                        double *h_pair, int64_t *h_rank, int64_t *h_n_le);
+int atl_zero_below(atl_ctx *ctx, double *d, int64_t rows, int64_t T, int64_t ld, double threshold);
+int atl_normalize_rows(atl_ctx *ctx, double *d, int64_t rows, int64_t T, int64_t ld, const uint8_t *d_time_mask,
+                       const double *d_ref);
+
 /* ---- indicator matrix (host code, no GPU) -----------------------------------------------
  * Replaces compute_indicatormatrix (atlite/gis.py:104-145) for polygon shapes against the
  * cutout grid (cells = boxes centre +- (dx/2, dy/2), atlite/cutout.py:369-376; x, y ascending):

@@ -528,3 +528,37 @@ def convert_cooling_demand(temperature, day_ptr, threshold=23.0, a=1.0, constant
             if blk.shape[0]:
                 Tm[d] = np.nansum(blk, axis=0) / np.sum(~np.isnan(blk), axis=0)
         return constant + np.clip(a * (Tm - (threshold + 273.15)), 0.0, None)
+
+
+def runoff_postprocess(series, time, rows, smooth=None, lower_threshold_quantile=None, normalize_using_yearly=None):
+    """convert.py:1046-1082 on the aggregated (rows x time) runoff series (NumPy array), pandas doing what xarray does there:
+    rolling mean over `smooth` steps with min_periods=1 (:1046-1052), values below the quantile of ALL values -> 0
+    (:1054-1062), scaling to the reported totals of the full years (> 8700 steps) the series shares with
+    `normalize_using_yearly` (a DataFrame: years x rows) (:1064-1082).  `rows`: labels of the series' rows."""
+    import pandas as pd
+
+    vals = np.asarray(series, dtype=np.float64)
+    if smooth is not None:
+        if smooth is True:
+            smooth = 24 * 7  # :1047-1048
+        vals = pd.DataFrame(vals.T).rolling(smooth, min_periods=1).mean().values.T  # :1052
+    if lower_threshold_quantile is not None:
+        if lower_threshold_quantile is True:
+            lower_threshold_quantile = 5e-3  # :1055-1056
+        thr = pd.Series(vals.ravel()).quantile(lower_threshold_quantile)  # :1057-1059
+        vals = np.where(vals >= thr, vals, 0.0)  # :1060
+    if normalize_using_yearly is not None:
+        nidx = normalize_using_yearly.index
+        nidx = nidx.year if isinstance(nidx, pd.DatetimeIndex) else nidx.astype(int)  # :1063-1067
+        tyear = pd.Series(pd.to_datetime(time).year)
+        years = tyear.value_counts().loc[lambda x: x > 8700].index.intersection(nidx)  # :1069-1074
+        assert len(years), "Need at least a full year of data (more is better)"
+        lo, hi = min(years), max(years)
+        tmask = ((tyear >= lo) & (tyear <= hi)).values  # sel(time=slice(str(min), str(max)))
+        ref = normalize_using_yearly.copy()
+        ref.index = nidx
+        ref = ref.loc[lo:hi].sum().reindex(pd.Index(rows)).values  # :1079-1081 (+ reindex to the result's rows)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            vals = vals * (ref / np.nansum(vals[:, tmask], axis=1))[:, None]
+    return vals
+

@@ -224,11 +224,10 @@ def runoff_post_yearly(kind):
 
 @pytest.mark.parametrize("case", list(RUNOFF_POST_CASES))
 def test_runoff_postprocessing_host(case):
-    """runoff(smooth / lower_threshold_quantile / normalize_using_yearly), convert.py:1045-1082: the product's host
-    routine on the oracle's aggregated series against the outputs the reference's own runoff() produced under the
-    stand-in (two years + a stub, so the "full years" selection, the partial-year drop and the yearly scaling all run)."""
-    from atlite_amd.convert import _runoff_postprocess
-    from atlite_amd.labeled import LabeledArray
+    """runoff(smooth / lower_threshold_quantile / normalize_using_yearly), convert.py:1045-1082: the oracle's restatement on
+    its own aggregated series against the outputs the reference's own runoff() produced under the stand-in (two years + a
+    stub, so the "full years" selection, the partial-year drop and the yearly scaling all run).  The product does this on
+    the device (tests/test_gpu_api_golden.py::test_runoff_postprocessing, test_gpu_post.py)."""
 
     g = load("runoff_post")
     ro, height, M, names, t, y, x = H.runoff_post_inputs()
@@ -244,10 +243,8 @@ def test_runoff_postprocessing_host(case):
             exact_or_close(series[:, g["sel"]], g["plain"], rtol=1e-14)
     if "normalize_using_yearly" in kw:
         kw["normalize_using_yearly"] = runoff_post_yearly(kw["normalize_using_yearly"])
-    la = LabeledArray(series, ("countries", "time"), {"countries": np.asarray(names), "time": t})
-    out = _runoff_postprocess(la, **kw)
-    assert out.dims == ("countries", "time")
-    np.testing.assert_allclose(out.values[:, g["sel"]], g[case], rtol=1e-10, atol=1e-12 * np.abs(g[case]).max())
+    out = orc.runoff_postprocess(series, t, names, **kw)
+    np.testing.assert_allclose(out[:, g["sel"]], g[case], rtol=1e-10, atol=1e-12 * np.abs(g[case]).max())
 
 
 class _Arr:

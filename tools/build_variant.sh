@@ -21,6 +21,6 @@ for u in atl_kernels atl_kernels_pv atl_kernels_pvt atl_kernels_pvk atl_kernels_
   if [ -f /tmp/atl_variant_$NAME/$u.o ] && echo "$UNITS" | grep -qw $u; then KO="$KO /tmp/atl_variant_$NAME/$u.o"; cat /tmp/atl_variant_$NAME/$u.resource.txt >> /tmp/atl_variant_$NAME/resource.txt; else KO="$KO $SRC/$u.o"; fi
 done
 OBJS=""
-for f in atl_runtime atl_gis atl_gis_dev atl_comm atl_h5 atl_inflate atl_ingest; do OBJS="$OBJS $SRC/$f.o"; done
+for f in atl_runtime atl_gis atl_gis_dev atl_comm atl_post atl_h5 atl_inflate atl_ingest; do OBJS="$OBJS $SRC/$f.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/atlite_amd/lib/variants/lib_$NAME.so $KO $OBJS -ldl -lz
 echo built $ROOT/atlite_amd/lib/variants/lib_$NAME.so
