@@ -162,6 +162,8 @@ SIGNATURES = {
     "atl_upload": (_i, [_vp, _vp, _vp, _sz]),
     "atl_download": (_i, [_vp, _vp, _vp, _sz]),
     "atl_memset": (_i, [_vp, _vp, _i, _sz]),
+    "atl_pinned_alloc": (_i, [_sz, C.POINTER(_vp)]),
+    "atl_pinned_free": (_i, [_vp]),
     "atl_host_register": (_i, [_vp, _sz]),
     "atl_host_unregister": (_i, [_vp]),
     "atl_upload_async": (_i, [_vp, _vp, _vp, _sz]),
@@ -206,10 +208,6 @@ SIGNATURES = {
         _i,
         [_i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _d, _d, _d, _d, C.POINTER(_vp), C.POINTER(_vp),
          C.POINTER(_vp)],
-    ),
-    "atl_indicator_polygons_quads": (
-        _i,
-        [_i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
     ),
     "atl_agg_check_host": (_i, [_i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "atl_indicator_polygons_integral_host": (

@@ -2,10 +2,11 @@
 Map projections for shapes that come in another coordinate system than the cutout (``shapes_crs`` of
 ``convert_and_aggregate`` / ``Cutout.indicatormatrix``, atlite/convert.py:235-240 -> cutout.py:492-515 -> gis.py:128-133).
 
-The reference hands this to pyproj (``reproject_shapes``: the vertices of the grid-cell boxes are moved from the cutout's
-crs into the shapes' crs and the overlaps are taken there).  pyproj is not part of this image, so the forward transforms of
-the projections energy-system shapes usually come in are written out here, from geographic coordinates on the GRS80 / WGS84
-ellipsoid (EPSG:4326 / 4258 - what ERA5 and SARAH cutouts use):
+The reference hands this to pyproj (``dest = reproject_shapes(dest, dest_crs, orig_crs)``, gis.py:130: the VERTICES OF THE
+SHAPES are moved from their crs into the cutout's, the overlaps are taken there, against the rectangular grid cells).  pyproj
+is not part of this image, so the transforms of the projections energy-system shapes usually come in are written out here,
+to and from geographic coordinates on the GRS80 / WGS84 ellipsoid (EPSG:4326 / 4258 - what ERA5 and SARAH cutouts use;
+``inverse`` is what the indicator matrix needs, ``forward`` is its check):
 
 * EPSG:3035  ETRS89-extended / LAEA Europe  (Lambert azimuthal equal area, EPSG method 9820)
 * EPSG:3857  WGS 84 / Pseudo-Mercator       (EPSG method 1024, spherical formulas on the semi-major axis)
@@ -123,3 +124,86 @@ def forward(crs, lon, lat):
     raise NotImplementedError(
         f"EPSG:{code} is not among the projections written out in atlite_amd.crs (3035, 3857, 326zz / 327zz / 258zz UTM, "
         "4326 / 4258); reproject the shapes first (pyproj is not part of this image)")
+
+
+def _laea_inv(x, y, a, f, lon0, lat0, fe, fn):
+    """Inverse of ``_laea`` (EPSG 9820): the authalic latitude in closed form, the geodetic one from it by the guidance
+    note's series as a start and Newton steps on q(phi) = q_p sin(beta) to the last bit."""
+    e2 = f * (2.0 - f)
+    e = np.sqrt(e2)
+    phi0, lam0 = np.radians(lat0), np.radians(lon0)
+
+    def q_of(p):
+        s = np.sin(p)
+        return (1.0 - e2) * (s / (1.0 - e2 * s * s) - (0.5 / e) * np.log((1.0 - e * s) / (1.0 + e * s)))
+
+    qp = q_of(np.pi / 2.0)
+    beta0 = np.arcsin(q_of(phi0) / qp)
+    rq = a * np.sqrt(qp / 2.0)
+    d = a * (np.cos(phi0) / np.sqrt(1.0 - e2 * np.sin(phi0) ** 2)) / (rq * np.cos(beta0))
+    xp, yp = x - fe, y - fn
+    rho = np.sqrt((xp / d) ** 2 + (d * yp) ** 2)
+    c = 2.0 * np.arcsin(np.clip(rho / (2.0 * rq), -1.0, 1.0))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        sb = np.where(rho > 0.0, np.cos(c) * np.sin(beta0) + d * yp * np.sin(c) * np.cos(beta0) / np.where(rho > 0.0, rho, 1.0),
+                      np.sin(beta0))
+    beta = np.arcsin(np.clip(sb, -1.0, 1.0))
+    lam = lam0 + np.arctan2(xp * np.sin(c), d * rho * np.cos(beta0) * np.cos(c) - d * d * yp * np.sin(beta0) * np.sin(c))
+    e4, e6 = e2 * e2, e2 ** 3
+    phi = beta + (e2 / 3 + 31 * e4 / 180 + 517 * e6 / 5040) * np.sin(2 * beta) + (23 * e4 / 360 + 251 * e6 / 3780) * np.sin(4 * beta) \
+        + (761 * e6 / 45360) * np.sin(6 * beta)
+    q = qp * np.sin(beta)
+    for _ in range(4):  # dq/dphi = 2 (1 - e2) cos(phi) / (1 - e2 sin^2 phi)^2
+        sp_ = np.sin(phi)
+        dq = 2.0 * (1.0 - e2) * np.cos(phi) / (1.0 - e2 * sp_ * sp_) ** 2
+        with np.errstate(invalid="ignore", divide="ignore"):
+            step = np.where(np.abs(dq) > 1e-12, (q - q_of(phi)) / np.where(np.abs(dq) > 1e-12, dq, 1.0), 0.0)
+        phi = phi + step
+    return np.degrees(lam), np.degrees(phi)
+
+
+def _tmerc_inv(x, y, a, f, lon0, k0, fe, fn):
+    """Inverse of ``_tmerc`` (EPSG 9807, Krueger series to n^4)."""
+    n = f / (2.0 - f)
+    n2, n3, n4 = n * n, n ** 3, n ** 4
+    B = a / (1.0 + n) * (1.0 + n2 / 4.0 + n4 / 64.0)
+    h1 = n / 2.0 - 2.0 / 3.0 * n2 + 37.0 / 96.0 * n3 - 1.0 / 360.0 * n4
+    h2 = 1.0 / 48.0 * n2 + 1.0 / 15.0 * n3 - 437.0 / 1440.0 * n4
+    h3 = 17.0 / 480.0 * n3 - 37.0 / 840.0 * n4
+    h4 = 4397.0 / 161280.0 * n4
+    e = np.sqrt(f * (2.0 - f))
+    eta, xi = (x - fe) / (B * k0), (y - fn) / (B * k0)
+    xi0 = xi - (h1 * np.sin(2 * xi) * np.cosh(2 * eta) + h2 * np.sin(4 * xi) * np.cosh(4 * eta)
+                + h3 * np.sin(6 * xi) * np.cosh(6 * eta) + h4 * np.sin(8 * xi) * np.cosh(8 * eta))
+    eta0 = eta - (h1 * np.cos(2 * xi) * np.sinh(2 * eta) + h2 * np.cos(4 * xi) * np.sinh(4 * eta)
+                  + h3 * np.cos(6 * xi) * np.sinh(6 * eta) + h4 * np.cos(8 * xi) * np.sinh(8 * eta))
+    beta = np.arcsin(np.clip(np.sin(xi0) / np.cosh(eta0), -1.0, 1.0))
+    q1 = np.arcsinh(np.tan(beta))
+    q2 = q1
+    for _ in range(8):  # Q'' = Q' + e atanh(e tanh Q''): contracts by e^2 per step
+        q2 = q1 + e * np.arctanh(e * np.tanh(q2))
+    phi = np.arctan(np.sinh(q2))
+    lam = np.radians(lon0) + np.arcsin(np.clip(np.tanh(eta0) / np.cos(beta), -1.0, 1.0))
+    return np.degrees(lam), np.degrees(phi)
+
+
+def inverse(crs, x, y):
+    """Geographic (lon, lat) in degrees of coordinates ``x``, ``y`` in ``crs`` (arrays broadcast) - what
+    ``reproject_shapes(shapes, shapes_crs, cutout.crs)`` (atlite/gis.py:86-101, 130) does to every vertex of a shape."""
+    code = epsg_of(crs)
+    x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+    if code in GEOGRAPHIC:
+        return x + 0.0 * y, y + 0.0 * x
+    if code == 3035:
+        return _laea_inv(x, y, *GRS80, 10.0, 52.0, 4321000.0, 3210000.0)
+    if code == 3857:
+        a = WGS84[0]
+        return np.degrees(x / a) + 0.0 * y, np.degrees(2.0 * np.arctan(np.exp(y / a)) - np.pi / 2.0) + 0.0 * x
+    for base, ell, south in ((32600, WGS84, False), (32700, WGS84, True), (25800, GRS80, False)):
+        zone = code - base
+        if 1 <= zone <= 60:
+            return _tmerc_inv(x, y, *ell, 6.0 * zone - 183.0, 0.9996, 500000.0, 10000000.0 if south else 0.0)
+    raise NotImplementedError(
+        f"EPSG:{code} is not among the projections written out in atlite_amd.crs (3035, 3857, 326zz / 327zz / 258zz UTM, "
+        "4326 / 4258); reproject the shapes first (pyproj is not part of this image)")
+

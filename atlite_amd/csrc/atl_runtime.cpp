@@ -321,6 +321,23 @@ int atl_memset(atl_ctx *ctx, void *d_dst, int byte_value, size_t bytes) {
 
 // ---- host-resident cutouts: copy stream + events ------------------------------------------
 
+int atl_pinned_alloc(size_t bytes, void **h_ptr) {
+    ATL_REQUIRE(h_ptr, "atl_pinned_alloc: h_ptr is NULL");
+    *h_ptr = nullptr;
+    hipError_t e = hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        set_error("hipHostMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        *h_ptr = nullptr;
+        return e == hipErrorOutOfMemory ? ATL_E_NOMEM : ATL_E_HIP;
+    }
+    return ATL_OK;
+}
+
+int atl_pinned_free(void *h_ptr) {
+    if (h_ptr) ATL_HIP_TRY(hipHostFree(h_ptr));
+    return ATL_OK;
+}
+
 int atl_host_register(void *h_ptr, size_t bytes) {
     ATL_REQUIRE(h_ptr && bytes, "atl_host_register: bad argument");
     ATL_HIP_TRY(hipHostRegister(h_ptr, bytes, hipHostRegisterDefault));

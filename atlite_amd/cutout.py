@@ -111,7 +111,7 @@ class Cutout:
 
             ctx = default_context()
         cache = self.__dict__.setdefault("_indicator_cache", {})
-        # shapes in another crs: the cell corners are projected into it and the overlaps taken there (host), like the reference
+        # shapes in another crs: their vertices are moved into the cutout's (atlite/gis.py:130), then the same clippers
         return gis.compute_indicatormatrix(self.coords["x"], self.coords["y"], shapes, ctx=ctx, cache=cache,
                                            shapes_crs=shapes_crs, grid_crs=self.crs)
 

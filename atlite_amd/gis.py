@@ -80,15 +80,15 @@ def compute_indicatormatrix(x, y, shapes, ctx=None, cache=None, shapes_crs=None,
     cache : optional dict; the matrix is stored under a digest of the grid and the ring coordinates and a copy is
           handed back when the same shapes come again - repeated ``Cutout.pv(shapes=...)`` calls.
     shapes_crs : the shapes' coordinate system when it is not the grid's (``grid_crs``, geographic): like the reference
-          (atlite/gis.py:128-133) the four corners of every cell box are projected into it (``atlite_amd.crs.forward``) and
-          the overlaps are taken there, cell by cell against convex quadrilaterals (``atl_indicator_polygons_quads``, host).
+          (``dest = reproject_shapes(dest, dest_crs, orig_crs)``, atlite/gis.py:130) every VERTEX of every shape is moved into the
+          grid's coordinate system (``atlite_amd.crs.inverse``) and the overlaps are taken there, against the rectangular cells -
+          the same clippers, on the device or the host.
     """
     from . import crs as _crs
 
-    quads = None
-    if shapes_crs is not None and not _crs.same_crs(shapes_crs, grid_crs):
-        if _crs.epsg_of(grid_crs) not in _crs.GEOGRAPHIC:
-            raise NotImplementedError("shapes in another crs need a cutout in geographic coordinates (EPSG:4326 / 4258)")
+    reproject = shapes_crs is not None and not _crs.same_crs(shapes_crs, grid_crs)
+    if reproject and _crs.epsg_of(grid_crs) not in _crs.GEOGRAPHIC:
+        raise NotImplementedError("shapes in another crs need a cutout in geographic coordinates (EPSG:4326 / 4258)")
     x = np.asarray(x, dtype=np.float64)
     y = np.asarray(y, dtype=np.float64)
     X, Y = len(x), len(y)
@@ -96,20 +96,32 @@ def compute_indicatormatrix(x, y, shapes, ctx=None, cache=None, shapes_crs=None,
     dy = float(y[1] - y[0]) if Y > 1 else 1.0
     if dx <= 0 or dy <= 0:
         raise ValueError("grid coordinates must be ascending")
-    if shapes_crs is not None and not _crs.same_crs(shapes_crs, grid_crs):
-        # shapely's box(minx, miny, maxx, maxy): (maxx, miny), (maxx, maxy), (minx, maxy), (minx, miny)
-        gx, gy = np.meshgrid(x, y)
-        cx = np.stack([gx + dx / 2, gx + dx / 2, gx - dx / 2, gx - dx / 2], axis=-1).reshape(-1, 4)
-        cy = np.stack([gy - dy / 2, gy + dy / 2, gy + dy / 2, gy - dy / 2], axis=-1).reshape(-1, 4)
-        px, py = _crs.forward(shapes_crs, cx, cy)
-        quads = np.ascontiguousarray(np.stack([px, py], axis=-1), dtype=np.float64)  # (Y * X, 4, 2)
+    fast_key = None
+    if cache is not None and isinstance(shapes, (list, tuple)) and shapes and all(
+            type(s_) is np.ndarray and s_.dtype == np.float64 and s_.ndim == 2 and s_.flags.c_contiguous for s_ in shapes):
+        # plain vertex arrays (what repeated Cutout.pv(shapes=...) calls of a workflow hand over): a digest of their bytes
+        # finds the cached matrix without walking the rings again
+        import hashlib
+
+        hsh = hashlib.blake2b(digest_size=16)
+        hsh.update(np.asarray([X, Y, x[0], dx, y[0], dy, 1.0 if ctx is not None else 0.0,
+                               float(_crs.epsg_of(shapes_crs)) if reproject else 0.0]).tobytes())
+        for s_ in shapes:
+            hsh.update(len(s_).to_bytes(8, "little"))
+            hsh.update(s_)
+        fast_key = b"fast" + hsh.digest()
+        if fast_key in cache:
+            return cache[fast_key].copy()
     if hasattr(shapes, "geometry") and not isinstance(shapes, (dict, np.ndarray)):  # GeoDataFrame-like (atlite/gis.py:127)
         shapes = shapes.geometry
     shapes = list(shapes.values) if hasattr(shapes, "values") and not isinstance(shapes, np.ndarray) else list(shapes)
     shape_ptr, ring_ptr, holes, xy = [0], [0], [], []
     for s in shapes:
         for ring, is_hole in _rings_of(s):
-            xy.append(np.ascontiguousarray(ring, dtype=np.float64))
+            ring = np.ascontiguousarray(ring, dtype=np.float64)
+            if reproject and len(ring):  # vertex by vertex, like shapely.ops.transform with the pyproj transformer
+                ring = np.ascontiguousarray(np.stack(_crs.inverse(shapes_crs, ring[:, 0], ring[:, 1]), axis=1))
+            xy.append(ring)
             ring_ptr.append(ring_ptr[-1] + len(ring))
             holes.append(1 if is_hole else 0)
         shape_ptr.append(len(holes))
@@ -122,20 +134,20 @@ def compute_indicatormatrix(x, y, shapes, ctx=None, cache=None, shapes_crs=None,
         import hashlib
 
         hsh = hashlib.blake2b(digest_size=16)
-        for a in (np.asarray([X, Y, x[0], dx, y[0], dy, 1.0 if ctx is not None else 0.0, 0.0 if quads is None else float(_crs.epsg_of(shapes_crs))]),
+        for a in (np.asarray([X, Y, x[0], dx, y[0], dy, 1.0 if ctx is not None else 0.0, float(_crs.epsg_of(shapes_crs)) if reproject else 0.0]),
                   shape_ptr, ring_ptr, holes, xy):
             hsh.update(np.ascontiguousarray(a).tobytes())
         key = hsh.digest()
         if key in cache:
+            if fast_key is not None:
+                cache[fast_key] = cache[key]
             return cache[key].copy()  # the cached matrix stays private: callers may modify what they get
     lib = _lib.load()
     p_ip, p_ix, p_d = C.c_void_p(), C.c_void_p(), C.c_void_p()
     args = (len(shapes), shape_ptr.ctypes.data, len(holes), ring_ptr.ctypes.data,
             holes.ctypes.data if len(holes) else None, xy.ctypes.data if len(xy) else None,
             X, Y, float(x[0]), dx, float(y[0]), dy, C.byref(p_ip), C.byref(p_ix), C.byref(p_d))
-    if quads is not None:
-        _lib.check(lib.atl_indicator_polygons_quads(*args[:6], Y * X, quads.ctypes.data, *args[12:]))
-    elif ctx == "integral-host":  # tests: the device algorithm with its candidate cells evaluated on the host
+    if ctx == "integral-host":  # tests: the device algorithm with its candidate cells evaluated on the host
         _lib.check(lib.atl_indicator_polygons_integral_host(*args))
     elif ctx is not None:
         _lib.check(lib.atl_indicator_polygons_device(ctx.handle, *args))
@@ -152,9 +164,11 @@ def compute_indicatormatrix(x, y, shapes, ctx=None, cache=None, shapes_crs=None,
             lib.atl_host_free(p)
     M = sp.csr_matrix((data, indices, indptr), shape=(N, Y * X))
     if cache is not None:
-        if len(cache) >= 8:  # a handful of shape sets per cutout
+        while len(cache) >= 16:  # a handful of shape sets per cutout (two keys each: ring digest, raw-bytes digest)
             cache.pop(next(iter(cache)))
         cache[key] = M.copy()
+        if fast_key is not None:
+            cache[fast_key] = cache[key]
     return M
 
 

@@ -290,7 +290,7 @@ def config_legs(ctx, legs, reps, check=True):
 
     import torch
 
-    from atlite_amd import _lib, gis, solar, synthetic
+    from atlite_amd import Cutout, Dataset, _lib, gis, solar, synthetic
     from atlite_amd.device import SlotPool, pitch_for
     from atlite_amd.resource import get_windturbineconfig
     from oracle import atlite_oracle as orc
@@ -324,6 +324,17 @@ def config_legs(ctx, legs, reps, check=True):
         rel = float(np.nanmax(err / np.maximum(np.abs(ref), 1e-300))) if np.size(ref) else 0.0
         ok = bool(np.allclose(got, ref, rtol=1e-10, atol=atol, equal_nan=True))
         return {"ok": ok, "checked_values": int(np.size(ref)), "max_rel_err_beyond_atol": max(rel, 0.0), "rtol": 1e-10}
+
+    def api_times(call, what):
+        t0 = time.perf_counter()
+        call()
+        cold = (time.perf_counter() - t0) * 1e3
+        warm = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            call()
+            warm.append((time.perf_counter() - t0) * 1e3)
+        return {"call": what, "cold": cold, "warm": min(warm)}
 
     def record(leg, workload, bytes_, cells, ms, parity):
         r = roofline_of(leg, bytes_, ms)
@@ -390,7 +401,12 @@ def config_legs(ctx, legs, reps, check=True):
             info = plan.info()
             record("c3_aggregated", f"configs[2] aggregated: wind V112, {T}x{Y}x{X}, 100 tessellation shapes ({info['tile_w']}x{info['tile_h']} "
                                     f"tiles, {info['n_partial_rows']} partial rows), 16 B per cell-step; {lay}", 16 * T * S, T * S, ms, par)
-            del agg, plan
+            # what a user of the drop-in API waits for: cutout.wind(...) on the device-resident dataset -> host result
+            xg, yg = synthetic.grid_coords(Y, X)
+            cut = Cutout(Dataset({"wnd100m": wnd, "roughness": z0}, dict(time=synthetic.time_index(T), y=yg, x=xg)))
+            out["c3_aggregated"]["api_e2e_ms"] = api_times(lambda: cut.wind(turbine="Vestas_V112_3MW", matrix=M, aggregate_time=None),
+                                                           "cutout.wind(turbine='Vestas_V112_3MW', matrix=M, aggregate_time=None) -> host (shapes x time)")
+            del agg, plan, cut
         del wnd, z0, args
         if inter:
             del pool
@@ -428,7 +444,12 @@ def config_legs(ctx, legs, reps, check=True):
                 sel = np.unique(np.concatenate([np.arange(0, 20), [T // 2, T - 1]]))
                 par = close(ro.numpy()[:, sel], orc.aggregate_matrix(orc.convert_runoff(rows(d["runoff"], sel), d["height"].numpy()[None, :]), M))
             record("c5_runoff", "configs[4], one GPU's shard: runoff x height, " + tag, 8 * T * S, T * S, ms, par)
-            del ro
+            xg, yg = synthetic.grid_coords(Y, X)
+            cut = Cutout(Dataset({"runoff": d["runoff"], "height": d["height"]}, dict(time=synthetic.time_index(T, "2011-01-01"), y=yg, x=xg)))
+            out["c5_runoff"]["api_e2e_ms"] = api_times(lambda: cut.runoff(matrix=M, aggregate_time=None, smooth=True),
+                                                       "cutout.runoff(matrix=M, aggregate_time=None, smooth=True): aggregation + 168-step rolling mean "
+                                                       "on the device -> host (shapes x time)")
+            del ro, cut
         del d, plan
         gc.collect()
 

@@ -90,6 +90,11 @@ int atl_copy_2d(atl_ctx *ctx, void *dst, size_t dst_pitch_bytes, const void *src
  * which_stream: 0 = compute stream (all convert calls), 1 = copy stream.
  */
 typedef struct atl_event atl_event;
+/* Page-locked host memory of the library's own (hipHostMalloc): the destination of result downloads that should run at
+ * the link's rate - a (shapes x time) result copied into pageable memory goes through the runtime's bounce buffers at a
+ * fraction of it, which was a quarter of a warm Cutout.pv() call. */
+int atl_pinned_alloc(size_t bytes, void **h_ptr);
+int atl_pinned_free(void *h_ptr);
 int atl_host_register(void *h_ptr, size_t bytes);
 int atl_host_unregister(void *h_ptr);
 int atl_upload_async(atl_ctx *ctx, void *d_dst, const void *h_src, size_t bytes); /* copy stream */
@@ -368,14 +373,6 @@ int atl_indicator_polygons(int64_t n_shapes, const int64_t *h_shape_ring_ptr, in
                            double dy, int64_t **out_indptr, int32_t **out_indices,
                            double **out_data);
 int atl_host_free(void *p);
-/* The same matrix when the shapes come in ANOTHER coordinate system than the cutout (`shapes_crs`, atlite/convert.py:235-240 ->
- * cutout.py:492-515 -> gis.py:128-133): the reference moves the four corners of every cell box into the shapes' system
- * (`reproject_shapes`) and intersects there - so the cells are convex quadrilaterals.  h_quads: n_cells x 4 x (x, y) in the
- * shapes' coordinates, any winding, row j of the result = cell j; I[i, j] = area(shape_i ∩ quad_j) / area(quad_j).  Host only. */
-int atl_indicator_polygons_quads(int64_t n_shapes, const int64_t *h_shape_ring_ptr, int64_t n_rings,
-                                 const int64_t *h_ring_ptr, const uint8_t *h_ring_is_hole, const double *h_xy,
-                                 int64_t n_cells, const double *h_quads, int64_t **out_indptr, int32_t **out_indices,
-                                 double **out_data);
 /* The same contract evaluated on the device (one thread per candidate cell of a shape's bounding box, exact
  * line integrals over the ring edges that overlap the cell's grid column; the host only buckets the edges by
  * column and compacts the result): SURVEY 8 f-2, second half.  Entries below 1e-12 of a cell are dropped

@@ -1,11 +1,12 @@
 """
 CPU: shapes in another coordinate system than the cutout (``shapes_crs``; atlite/convert.py:235-240 -> cutout.py:492-515 ->
-gis.py:128-133: the corners of the cell boxes are reprojected into the shapes' crs, the overlaps are taken there).
-``atlite_amd.crs`` writes the forward projections out (pyproj is not in this image - parity with it is unpinned); they are
-checked against the worked examples of IOGP Guidance Note 7-2, against an independent series (Snyder) and a numerically
-integrated meridian arc for UTM, and against the defining properties (equal area, conformality).  The cell-by-cell overlap
-with convex quadrilaterals (``atl_indicator_polygons_quads``) is checked against the rectangular-grid clipper and by area
-conservation.
+gis.py:130: ``dest = reproject_shapes(dest, dest_crs, orig_crs)`` - the shapes' vertices are moved into the cutout's crs and
+the overlaps are taken against the rectangular cells there).  ``atlite_amd.crs`` writes the projections out (pyproj is not
+in this image - parity with it is unpinned): the forward transforms are checked against the worked examples of IOGP
+Guidance Note 7-2, against an independent series (Snyder) and a numerically integrated meridian arc for UTM, and against
+the defining properties (equal area, conformality); the inverse transforms - what the indicator matrix uses - against the
+guidance note's reverse examples and by round trips to 1e-11 degree; the indicator matrix of projected shapes against the
+matrix of the same vertices given in geographic coordinates.
 """
 import ctypes as C
 
@@ -105,68 +106,34 @@ def test_reading_crs_descriptions():
         crs.epsg_of("+proj=laea +lat_0=52")
 
 
-def _quads_matrix(shapes, quads):
-    lib = _lib.load()
-    shape_ptr, ring_ptr, holes, xy = [0], [0], [], []
-    for s in shapes:
-        for ring, is_hole in gis._rings_of(s):
-            xy.append(np.asarray(ring, dtype=np.float64))
-            ring_ptr.append(ring_ptr[-1] + len(ring))
-            holes.append(int(is_hole))
-        shape_ptr.append(len(holes))
-    shape_ptr, ring_ptr = np.asarray(shape_ptr, np.int64), np.asarray(ring_ptr, np.int64)
-    holes, xy = np.asarray(holes, np.uint8), np.ascontiguousarray(np.concatenate(xy))
-    quads = np.ascontiguousarray(quads, dtype=np.float64)
-    p = [C.c_void_p() for _ in range(3)]
-    _lib.check(lib.atl_indicator_polygons_quads(len(shapes), shape_ptr.ctypes.data, len(holes), ring_ptr.ctypes.data, holes.ctypes.data,
-                                                xy.ctypes.data, len(quads), quads.ctypes.data, *[C.byref(v) for v in p]))
-    N = len(shapes)
-    indptr = np.ctypeslib.as_array(C.cast(p[0], C.POINTER(C.c_int64)), (N + 1,)).copy()
-    nnz = int(indptr[-1])
-    idx = np.ctypeslib.as_array(C.cast(p[1], C.POINTER(C.c_int32)), (max(nnz, 1),))[:nnz].copy()
-    dat = np.ctypeslib.as_array(C.cast(p[2], C.POINTER(C.c_double)), (max(nnz, 1),))[:nnz].copy()
-    for v in p:
-        lib.atl_host_free(v)
-    return sp.csr_matrix((dat, idx, indptr), shape=(N, len(quads)))
-
-
-def _boxes(x, y):
-    dx, dy = x[1] - x[0], y[1] - y[0]
-    gx, gy = np.meshgrid(x, y)
-    cx = np.stack([gx + dx / 2, gx + dx / 2, gx - dx / 2, gx - dx / 2], axis=-1).reshape(-1, 4)
-    cy = np.stack([gy - dy / 2, gy + dy / 2, gy + dy / 2, gy - dy / 2], axis=-1).reshape(-1, 4)
-    return np.stack([cx, cy], axis=-1)
-
-
-@pytest.mark.parametrize("seed", range(4))
-def test_quadrilateral_cells_against_the_rectangular_clipper_and_under_affine_maps(seed):
-    rng = np.random.default_rng(seed)
-    X, Y = int(rng.integers(3, 40)), int(rng.integers(3, 40))
-    x, y = -3.0 + 0.5 * np.arange(X), 41.0 + 0.25 * np.arange(Y)
-    box = (x[0] - 0.25, y[0] - 0.125, x[-1] + 0.25, y[-1] + 0.125)
-    shapes = gis.random_star_polygons(7, box, seed=seed) + gis.random_tessellation(5, box, seed=seed)
-    hole = np.array([[x[1], y[1]], [x[-2], y[1]], [x[-2], y[-2]], [x[1], y[-2]]])
-    inner = hole.mean(0) + 0.3 * (hole - hole.mean(0))
-    shapes.append(dict(exterior=hole, holes=[inner]))
-    ref = gis.compute_indicatormatrix(x, y, shapes)
-    quads = _boxes(x, y)
-    got = _quads_matrix(shapes, quads)
-    assert np.abs((got - ref)).max() < 1e-12 and got.nnz == ref.nnz
-    # area ratios do not change under an affine map of everything; windings may flip (negative determinant)
-    A = rng.normal(size=(2, 2)) + 2.0 * np.eye(2) * rng.choice([-1, 1])
-    t = rng.normal(size=2) * 100
-
-    def mapped(s):
-        if isinstance(s, dict):
-            return dict(exterior=s["exterior"] @ A.T + t, holes=[h @ A.T + t for h in s["holes"]])
-        return np.asarray(s) @ A.T + t
-
-    got2 = _quads_matrix([mapped(s) for s in shapes], quads @ A.T + t)
-    assert np.abs((got2 - ref)).max() < 1e-10
+def test_inverse_guidance_note_examples_and_round_trips():
+    lon, lat = crs.inverse(3035, 3962799.45, 2999718.85)  # GN 7-2 reverse case of the LAEA example
+    assert abs(lon - 5.0) < 2e-7 and abs(lat - 50.0) < 2e-7
+    lon, lat = crs.inverse(3857, -11169055.58, 2800000.00)
+    assert abs(lon + (100 + 20 / 60)) < 1e-7 and abs(lat - (24 + 22 / 60 + 54.433 / 3600)) < 1e-7
+    lon, lat = crs.inverse(3035, 4321000.0, 3210000.0)  # the projection's origin (rho = 0)
+    assert abs(lon - 10.0) < 1e-12 and abs(lat - 52.0) < 1e-12
+    rng = np.random.default_rng(1)
+    lo, la = rng.uniform(-25, 45, 2000), rng.uniform(28, 72, 2000)
+    for code in (3035, 3857, 4326):
+        x, y = crs.forward(code, lo, la)
+        lo2, la2 = crs.inverse(code, x, y)
+        assert np.abs(lo2 - lo).max() < 1e-11 and np.abs(la2 - la).max() < 1e-11, code
+    for zone in (29, 32, 36):
+        lon0 = 6 * zone - 183
+        lo = lon0 + rng.uniform(-4, 4, 2000)
+        for base in (32600, 32700, 25800):
+            x, y = crs.forward(base + zone, lo, la)
+            lo2, la2 = crs.inverse(base + zone, x, y)
+            assert np.abs(lo2 - lo).max() < 1e-11 and np.abs(la2 - la).max() < 1e-11, (base, zone)
+    with pytest.raises(NotImplementedError, match="not among the projections"):
+        crs.inverse(27700, 0.0, 0.0)
 
 
 @pytest.mark.parametrize("code", [3035, 32632, 3857])
-def test_shapes_in_a_projected_crs_conserve_area(code):
+def test_shapes_in_a_projected_crs_are_moved_into_the_cutouts(code):
+    """The reference's method (gis.py:130): only the vertices move; the matrix of projected shapes equals the matrix of
+    the same vertices given in geographic coordinates, on the host and through Cutout.indicatormatrix."""
     from atlite_amd import Cutout, Dataset
 
     x, y = np.arange(5.0, 12.01, 0.25), np.arange(47.0, 53.01, 0.25)
@@ -174,45 +141,20 @@ def test_shapes_in_a_projected_crs_conserve_area(code):
     hole = np.array([[8.0, 49.5], [9.0, 49.5], [9.0, 50.5], [8.0, 50.5]])
     outside = np.array([[11.0, 52.0], [14.0, 52.0], [14.0, 55.0], [11.0, 55.0]])  # partly beside the grid
     proj = lambda r: np.stack(crs.forward(code, r[:, 0], r[:, 1]), axis=1)  # noqa: E731
+    geo = [dict(exterior=ring, holes=[hole]), ring, outside]
     shapes = [dict(exterior=proj(ring), holes=[proj(hole)]), proj(ring), proj(outside)]
     cut = Cutout(Dataset({"height": np.zeros((len(y), len(x)))}, dict(y=y, x=x)))
     M = cut.indicatormatrix(shapes, shapes_crs=code, where="host")
+    M0 = cut.indicatormatrix(geo, where="host")
     assert M.shape == (3, len(x) * len(y)) and M.data.min() > 0 and M.data.max() <= 1.0
-    q = np.stack(crs.forward(code, *np.moveaxis(_boxes(x, y), -1, 0)), axis=-1)
-    cell_area = 0.5 * np.abs(np.sum(q[..., 0] * np.roll(q[..., 1], -1, 1) - np.roll(q[..., 0], -1, 1) * q[..., 1], axis=1))
+    assert np.abs(M - M0).max() < 1e-9 and M.nnz >= M0.nnz - 4  # (vertices round-trip to 1e-11 degree)
+    # areas in degrees of the parts on the grid
+    cell = 0.25 * 0.25
     shoelace = lambda p: 0.5 * abs(np.sum(p[:, 0] * np.roll(p[:, 1], -1) - np.roll(p[:, 0], -1) * p[:, 1]))  # noqa: E731
-    got = M @ cell_area
-    assert abs(got[1] - shoelace(proj(ring))) < 1e-11 * got[1]
-    assert abs(got[0] - (shoelace(proj(ring)) - shoelace(proj(hole)))) < 1e-11 * got[0]
-    assert got[2] < 0.5 * shoelace(proj(outside))  # only the part on the grid counts
-    # the same shapes described in the cutout's own crs differ only by the curvature of the edges between their vertices
-    M0 = cut.indicatormatrix([dict(exterior=ring, holes=[hole]), ring, outside], where="host")
-    assert 0 < np.abs(M - M0).max() < 0.12
+    got = np.asarray(M.sum(1)).ravel() * cell
+    assert abs(got[1] - shoelace(ring)) < 1e-8 and abs(got[0] - (shoelace(ring) - shoelace(hole))) < 1e-8
+    assert got[2] < 0.5 * shoelace(outside)  # only the part on the grid counts
+    # a second call with the same shapes comes from the cutout's cache; another crs code is another key
+    assert np.array_equal(cut.indicatormatrix(shapes, shapes_crs=code, where="host").toarray(), M.toarray())
     with pytest.raises(NotImplementedError, match="geographic"):
         Cutout(Dataset({"height": np.zeros((len(y), len(x)))}, dict(y=y, x=x)), crs=3035).indicatormatrix(shapes, shapes_crs=32632, where="host")
-
-
-def test_hostile_cells_and_shapes():
-    """Degenerate and non-finite cells take no part, a non-convex cell is refused, shapes with non-finite vertices get an
-    empty row, offsets are validated before they are followed."""
-    quads = _boxes(np.arange(4.0), np.arange(3.0))
-    sq = np.array([[0.2, 0.1], [2.6, 0.1], [2.6, 1.7], [0.2, 1.7]])
-    ref = _quads_matrix([sq], quads).toarray()
-    q = quads.copy()
-    q[5] = q[5][0]  # collapsed to a point
-    q[6, 2] = np.nan
-    got = _quads_matrix([sq], q).toarray()
-    keep = np.ones(12, bool)
-    keep[[5, 6]] = False
-    assert np.array_equal(got[:, keep], ref[:, keep]) and not got[:, ~keep].any()
-    bad = quads.copy()
-    bad[3, 1] = bad[3].mean(0) - 0.3 * (bad[3, 1] - bad[3].mean(0))  # a dart: the corner pulled through the centre
-    with pytest.raises(ValueError, match="convex"):
-        _quads_matrix([sq], bad)
-    assert _quads_matrix([np.array([[0.2, 0.1], [np.inf, 0.1], [2.6, 1.7]])], quads).nnz == 0
-    lib = _lib.load()
-    p = [C.c_void_p() for _ in range(3)]
-    ptr = np.array([0, 5, 2], np.int64)  # not monotone
-    rc = lib.atl_indicator_polygons_quads(2, ptr.ctypes.data, 2, ptr.ctypes.data, None, sq.ctypes.data, 12, quads.ctypes.data,
-                                          *[C.byref(v) for v in p])
-    assert rc != 0 and "offsets" in lib.atl_last_error().decode()

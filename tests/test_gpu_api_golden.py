@@ -441,8 +441,9 @@ def test_temperatures_cop_cooling():
 
 def test_shapes_in_another_crs_through_the_gateway():
     """convert_and_aggregate(shapes=..., shapes_crs=...) (atlite/convert.py:235-240): shapes given in ETRS89-LAEA / UTM
-    coordinates for a cutout in EPSG:4326 - the gateway builds the matrix from the projected cell corners
-    (atlite_amd.crs, tests/test_crs.py) and runs the usual fused kernel with it."""
+    coordinates for a cutout in EPSG:4326 - the gateway moves the shapes' vertices into the cutout's crs (the reference's
+    reproject_shapes, atlite/gis.py:130; atlite_amd.crs.inverse, tests/test_crs.py), builds the matrix on the device and
+    runs the usual fused kernel with it."""
     from atlite_amd import crs
     from tests import helpers as H
 
@@ -459,7 +460,7 @@ def test_shapes_in_another_crs_through_the_gateway():
         a = c.pv(shapes=shapes, shapes_crs=code, **kw)
         b = c.pv(matrix=M, **kw)
         np.testing.assert_array_equal(a.values, b.values)
-        same = c.pv(shapes=ll, **kw)  # the same corner points joined by straight lines in lon / lat: close, not equal
-        assert np.abs(a.values - same.values).max() < 0.05 * np.abs(same.values).max()
+        same = c.pv(shapes=ll, **kw)  # the same vertices given in lon / lat: the same matrix up to the round trip's 1e-11 degree
+        np.testing.assert_allclose(a.values, same.values, rtol=1e-8, atol=1e-9 * np.abs(same.values).max())
     with pytest.raises(NotImplementedError, match="not among the projections"):
         c.pv(shapes=ll, shapes_crs=27700, **kw)
