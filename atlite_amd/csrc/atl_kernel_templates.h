@@ -174,6 +174,13 @@ struct conv_cubes : std::integral_constant<int, 1> {};
 template <class Conv>
 struct conv_cubes<Conv, std::void_t<decltype(Conv::kCubes)>> : std::integral_constant<int, Conv::kCubes> {};
 
+// MFMA groups (16 partial rows each) of a dense tile whose operand image a wave keeps IN REGISTERS for its whole chunk
+// (kDenseResident; default 1 = 64 VGPRs; two groups = 128 VGPRs spill at the two waves per SIMD the kernel is built for).  Until round 4 every 16-slot sweep
+// re-read the image from L2 - 16 KiB per group against the 16 KiB of cube data a one-cube converter streams per sweep.
+template <class Conv, class = void>
+struct conv_dense_resident : std::integral_constant<int, 1> {};
+template <class Conv>
+struct conv_dense_resident<Conv, std::void_t<decltype(Conv::kDenseResident)>> : std::integral_constant<int, Conv::kDenseResident> {};
 template <class Conv, class = void>
 struct conv_dense_ok : std::true_type {};
 template <class Conv>
@@ -424,12 +431,12 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 template <int U = 8, int NB = kBatch>  // U: K-steps whose operands are in flight together (4 VGPRs each)
 __device__ __forceinline__ void reduce_dense_mfma(const double *vl, const double *__restrict__ wm, int G, int n_rows,
                                                   int32_t p0, int lane, int64_t sb, int64_t send,
-                                                  double *__restrict__ partials, int64_t ldp) {
+                                                  double *__restrict__ partials, int64_t ldp, int g0 = 0) {
     static_assert(NB == 8 || NB == 16, "the fp64 MFMA has 16 columns");
     typedef __attribute__((address_space(1))) const double gdouble;
     const int j = lane & 15, kq = lane >> 4, jj = NB == 16 ? j : (j & 7);
     const double *brow = vl + jj * kSegCells + kq;
-    for (int g = 0; g < G; ++g) {
+    for (int g = g0; g < G; ++g) {
         // two accumulators (even / odd K-steps): back-to-back MFMAs on ONE accumulator wait for each other
         d4 acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
         gdouble *a = (gdouble *)(wm + (int64_t(g) * 32) * 64 + lane);
@@ -450,6 +457,47 @@ __device__ __forceinline__ void reduce_dense_mfma(const double *vl, const double
                 if (row < n_rows) partials[int64_t(p0 + row) * ldp + sb + j] = acc[r];
             }
         }
+    }
+}
+
+// The same contraction with the operand image of the tile's first GR groups held in registers (areg[g][k] = the lane's A
+// value of group g, K-step k): no global load inside the sweep, and one B-fragment read from LDS serves both groups -
+// their two accumulator chains interleave, so no second accumulator is needed there.  Groups past GR stream their image
+// as before (reduce_dense_mfma from group GR on).
+template <int GR>
+__device__ __forceinline__ void reduce_dense_resident(const double *vl, const double (&areg)[GR][32], int G, int n_rows, int32_t p0,
+                                                      int lane, int64_t sb, int64_t send, double *__restrict__ partials,
+                                                      int64_t ldp) {
+    const int j = lane & 15, kq = lane >> 4;
+    const double *brow = vl + j * kSegCells + kq;
+    const auto store = [&](int g, const d4 &acc) {
+        if (sb + j < send) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = kMfmaRows * g + 4 * r + kq;
+                if (row < n_rows) partials[int64_t(p0 + row) * ldp + sb + j] = acc[r];
+            }
+        }
+    };
+    if (GR >= 2 && G >= 2) {
+        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const double b = brow[4 * (k ^ j)];
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[0][k], b, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[GR >= 2 ? 1 : 0][k], b, acc1, 0, 0, 0);
+        }
+        store(0, acc0);
+        store(1, acc1);
+    } else {
+        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 32; k += 2) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[0][k], brow[4 * (k ^ j)], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[0][k + 1], brow[4 * ((k + 1) ^ j)], acc1, 0, 0, 0);
+        }
+        acc0 += acc1;
+        store(0, acc0);
     }
 }
 
@@ -571,6 +619,18 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
             // loads per slot.  Rows past the MFMA groups, and everything when a value is not finite (0 * NaN would
             // leak through structural zeros), go through the butterfly, batch by batch, from the rows.
             const int32_t pm = p0 + min(kMfmaRows * n_mfma, p1 - p0);
+            // the operand image of the first GR groups: in registers for the whole chunk
+            constexpr int GR = conv_dense_resident<Conv>::value;  // (0: every sweep streams the image, as until round 3)
+            double areg[GR > 0 ? GR : 1][32];
+            if constexpr (GR > 0) {
+                typedef __attribute__((address_space(1))) const double gdouble;
+#pragma unroll
+                for (int g = 0; g < GR; ++g) {
+                    gdouble *a = (gdouble *)(wm + (int64_t(min(g, n_mfma - 1)) * 32) * 64 + lane);
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) areg[g][k] = a[k * 64];
+                }
+            }
             for (int64_t sb = sbeg; sb < send; sb += kDenseSlots) {
                 bool finite = true;
 #pragma unroll 1
@@ -581,7 +641,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
                     for (int i = 0; i < kBatch; ++i) *reinterpret_cast<double2 *>(vl + vrow_pair<true>(h * kBatch + i, lane)) = v[i];
                 }
                 const bool all_finite = __all(finite);
-                if (all_finite) reduce_dense_mfma<8, kDenseSlots>(vl, wm, n_mfma, p1 - p0, p0, lane, sb, send, partials, ldp);
+                if (all_finite) {
+                    if constexpr (GR > 0) reduce_dense_resident<GR>(vl, areg, n_mfma, p1 - p0, p0, lane, sb, send, partials, ldp);
+                    if (n_mfma > GR) reduce_dense_mfma<8, kDenseSlots>(vl, wm, n_mfma, p1 - p0, p0, lane, sb, send, partials, ldp, GR);
+                }
                 if (!all_finite || pm < p1) {
 #pragma unroll 1
                     for (int h = 0; h < kDenseSlots / kBatch; ++h) {

@@ -639,9 +639,9 @@ class Context:
             return float("nan")
         a, b = pair[0], pair[1]
         t = q * (n.value - 1) - rank.value  # gamma = virtual index - floor(virtual index)
-        if b != b:  # the virtual index is the last element
-            return a
-        diff = b - a  # numpy/lib/_function_base_impl.py: _lerp
+        if b != b:  # the virtual index is the last element: numpy clips the upper neighbour to it
+            b = a
+        diff = b - a  # numpy/lib/_function_base_impl.py: _lerp (inf - inf = NaN there as here)
         return b - diff * (1.0 - t) if t >= 0.5 else a + diff * t
 
     def zero_below(self, series, threshold):

@@ -36,6 +36,11 @@ GROUPS = {
     "c4": (["--legs", "c4_full_sp"], ["c4_full_sp"]),
 }
 COMMON = ["--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-parity"]
+# untimed launches of a leg's kernel before bench.py's timed ones (its --warmup, the 12 warm-up launches of the side legs, the
+# 10 of the configs legs): `avg_us` is over every launch of the pass, `avg_us_timed` over those after the warm-up - the
+# figure bench.py's own HIP-event mean is comparable with (the first launches after an idle gap run at a colder clock)
+WARM = {"headline": 3, "star_polygons": 3, "night_skip": 12}
+WARM_CONFIGS = 10
 
 
 def short(n):
@@ -83,7 +88,7 @@ def main():
             tot = sum(sum(v) for v in per.values())
             for n, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
                 sv = sorted(v)
-                stats[n] = dict(calls=len(v), avg_us=sum(v) / len(v), median_us=sv[len(sv) // 2], min_us=sv[0], max_us=sv[-1])
+                stats[n] = dict(calls=len(v), avg_us=sum(v) / len(v), median_us=sv[len(sv) // 2], min_us=sv[0], max_us=sv[-1], in_order_us=v)
                 lines.append(f"{n:72s} {len(v):6d} {sum(v):12.1f} {stats[n]['avg_us']:10.1f} {stats[n]['median_us']:10.1f} {sv[0]:10.1f} {sv[-1]:10.1f} {100 * sum(v) / tot:6.2f}")
             lines.append("")
             lines.append("== dispatch resources (as rocprofv3 reports them) ==")
@@ -109,13 +114,19 @@ def main():
             if k not in stats:
                 lines.append(f"{leg}: kernel {k} did not run in this pass")
                 continue
-            e = dict(kernel=k, **stats[k], source=f"profiles/{tag}_bench_{g}.txt")
+            st = dict(stats[k])
+            seq = st.pop("in_order_us")
+            w = WARM.get(leg, WARM_CONFIGS)
+            n_timed = int(COMMON[COMMON.index("--steps") + 1])  # (launches after those belong to other legs: the API calls)
+            timed = seq[w:w + n_timed] if len(seq) > w else seq
+            e = dict(kernel=k, **st, warmup_launches=w if len(seq) > w else 0, timed_launches=len(timed),
+                     avg_us_timed=sum(timed) / len(timed), source=f"profiles/{tag}_bench_{g}.txt")
             if k in pmc and "FETCH_SIZE" in pmc[k]:
                 e["read_bytes"] = 2.0 * pmc[k]["FETCH_SIZE"] * 1024
                 e["write_bytes"] = pmc[k].get("WRITE_SIZE", 0.0) * 1024
                 e["hbm_bytes_per_launch"] = e["read_bytes"] + e["write_bytes"]
             latest["legs"][leg] = e
-            lines.append(f"{leg}: {k}  avg {e['avg_us']:.1f} us over {e['calls']} launches" +
+            lines.append(f"{leg}: {k}  avg {e['avg_us']:.1f} us over {e['calls']} launches, {e['avg_us_timed']:.1f} us over the {len(timed)} after the warm-up" +
                          (f"  read {e['read_bytes'] / 1e9:.3f} GB  write {e['write_bytes'] / 1e9:.3f} GB" if "read_bytes" in e else ""))
         (out / f"{tag}_bench_{g}.txt").write_text("\n".join(lines) + "\n")
         print("\n".join(lines), flush=True)
