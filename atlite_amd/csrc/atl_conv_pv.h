@@ -489,7 +489,9 @@ struct PvConvT {
     static_assert(TRACK == ATL_TRACK_NONE || !SP, "trackers: stored angles");
     // the MFMA-carrying instantiation (dense matrices) only for pv() with its defaults: rare options x rare matrices
     static constexpr bool kDenseOk = TAIL == kTailHuld && TRACK == ATL_TRACK_NONE && !PC && HEAD == 0;
-    static constexpr int kDenseResident = 1;  // MFMA groups whose operand image stays in registers (64 VGPRs each)
+    static constexpr int kDenseResident = 0;  // the operand image of dense tiles streams from L2 per sweep (resident: 64 VGPRs per
+                                              // group; measured with one group: pv R = 16 / 32 3.38 / 3.74 -> 3.50 / 4.11 ms - its short
+                                              // chunks leave nothing to reuse and the conversion wants the registers)
     // the members of the family compiled in atl_kernels_pvt.hip / atl_kernels_pvk.hip (tails other than the Huld
     // panel, trackers) exist for vectorised launches only; odd cell counts / unaligned cubes take the general kernel
     // ... and so do the early-out converters: their results are the bits of the converters that read every byte, whose

@@ -510,8 +510,10 @@ __device__ __forceinline__ void reduce_dense_resident(const double *vl, const do
 template <bool VEC, class Conv>
 __device__ __forceinline__ void convert_batch(const Conv &conv, int64_t sb, int64_t send, bool covered, bool v0, bool v1,
                                               int64_t s0c, int64_t s1c, const typename Conv::Cell &cell,
-                                              typename Conv::Carry &carry, const double *lds, double2 (&v)[kBatch],
+                                              typename Conv::Carry &carry, const double *lds, double *vl, int row0, int lane,
                                               bool &finite) {
+    // (the values go straight to the wave's swizzled LDS value rows row0 .. row0 + 7: held in registers until the end of
+    // the batch they cost 32 VGPRs the resident operand image needs)
     constexpr int G = Conv::kGroup;
 #pragma unroll
     for (int i0 = 0; i0 < kBatch; i0 += G) {
@@ -526,11 +528,12 @@ __device__ __forceinline__ void convert_batch(const Conv &conv, int64_t sb, int6
         for (int g = 0; g < G; ++g) {
             const int i = i0 + g;
             const bool live = covered && sb + i < send;  // an uncovered lane converts zeros: whatever comes out is dropped
-            v[i] = conv.compute(raw[g], v0, v1, cell, lds);
-            v[i].x = live ? v[i].x : 0.0;
-            v[i].y = live ? v[i].y : 0.0;
+            double2 r = conv.compute(raw[g], v0, v1, cell, lds);
+            r.x = live ? r.x : 0.0;
+            r.y = live ? r.y : 0.0;
             // |x| < inf is false for NaN and +-inf
-            finite = finite && (__builtin_fabs(v[i].x) < __builtin_inf()) && (__builtin_fabs(v[i].y) < __builtin_inf());
+            finite = finite && (__builtin_fabs(r.x) < __builtin_inf()) && (__builtin_fabs(r.y) < __builtin_inf());
+            *reinterpret_cast<double2 *>(vl + vrow_pair<true>(row0 + i, lane)) = r;
         }
     }
 }
@@ -634,12 +637,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
             for (int64_t sb = sbeg; sb < send; sb += kDenseSlots) {
                 bool finite = true;
 #pragma unroll 1
-                for (int h = 0; h < kDenseSlots / kBatch; ++h) {
-                    double2 v[kBatch];
-                    convert_batch<VEC>(conv, sb + h * kBatch, send, covered, v0, v1, s0c, s1c, cell, carry, lds, v, finite);
-#pragma unroll
-                    for (int i = 0; i < kBatch; ++i) *reinterpret_cast<double2 *>(vl + vrow_pair<true>(h * kBatch + i, lane)) = v[i];
-                }
+                for (int h = 0; h < kDenseSlots / kBatch; ++h)
+                    convert_batch<VEC>(conv, sb + h * kBatch, send, covered, v0, v1, s0c, s1c, cell, carry, lds, vl, h * kBatch, lane, finite);
                 const bool all_finite = __all(finite);
                 if (all_finite) {
                     if constexpr (GR > 0) reduce_dense_resident<GR>(vl, areg, n_mfma, p1 - p0, p0, lane, sb, send, partials, ldp);

@@ -7,6 +7,7 @@ reference's Python interface lives in ``atlite_amd.convert``.
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 import threading
 
@@ -88,13 +89,13 @@ class DeviceArray:
         self.dtype = np.dtype(dtype)
         self._owner = owner  # keeps a parent allocation (or a torch tensor) alive
         self._owned = owned and owner is None
-        inner = int(np.prod(self.shape[1:], dtype=np.int64)) if len(self.shape) > 1 else 0
+        inner = math.prod(self.shape[1:]) if len(self.shape) > 1 else 0
         self.ld = None if ld is None or len(self.shape) < 2 or int(ld) == inner else int(ld)
         assert self.ld is None or self.ld > inner
 
     @property
     def size(self):
-        return int(np.prod(self.shape, dtype=np.int64))
+        return math.prod(self.shape)
 
     @property
     def nbytes(self):
@@ -123,7 +124,7 @@ class DeviceArray:
         """View of rows [start, stop) along the first axis (no copy)."""
         start, stop = int(start), int(stop)
         assert 0 <= start <= stop <= self.shape[0]
-        row = (self.ld if self.ld is not None else int(np.prod(self.shape[1:], dtype=np.int64))) * self.dtype.itemsize
+        row = (self.ld if self.ld is not None else math.prod(self.shape[1:])) * self.dtype.itemsize
         return DeviceArray(
             self.ctx, self.ptr + start * row, (stop - start,) + self.shape[1:], self.dtype, owner=self, ld=self.ld
         )
@@ -133,9 +134,9 @@ class DeviceArray:
             shape = tuple(shape[0])
         shape = [int(v) for v in shape]
         if -1 in shape:
-            known = int(np.prod([v for v in shape if v != -1], dtype=np.int64))
+            known = math.prod(v for v in shape if v != -1)
             shape[shape.index(-1)] = self.size // known if known else 0
-        assert int(np.prod(shape, dtype=np.int64)) == self.size, (shape, self.shape)
+        assert math.prod(shape) == self.size, (shape, self.shape)
         if self.ld is not None:
             if tuple(shape) == self.shape:
                 return self
@@ -149,7 +150,8 @@ class DeviceArray:
 
     def free(self):
         if self._owned and self.ptr:
-            check(self.ctx.lib.atl_free(self.ctx.handle, self.ptr))
+            if not self.ctx._recycle(self.ptr, self.nbytes):
+                check(self.ctx.lib.atl_free(self.ctx.handle, self.ptr))
             self.ptr = 0
 
     def __del__(self):
@@ -262,9 +264,29 @@ class Context:
         self.device = int(device)
 
     # -- memory ---------------------------------------------------------------------------
+    # small device blocks (results, per-call tables: <= 64 MiB each, 512 MiB kept) are recycled by size: hipMalloc + hipFree
+    # cost ~0.3 ms a pair - hipFree synchronises the device - which was a tenth of a warm Cutout.pv() call.  Reuse is
+    # ordered by the context's stream like the scratch arena.
+    _POOL_MAX_BLOCK, _POOL_CAP = 64 << 20, 512 << 20
+
+    def _recycle(self, ptr, nbytes):
+        if not (0 < nbytes <= self._POOL_MAX_BLOCK) or getattr(self, "handle", None) is None:
+            return False
+        pool = self.__dict__.setdefault("_dev_pool", {})
+        held = self.__dict__.get("_dev_pooled", 0)
+        if held + nbytes > self._POOL_CAP:
+            return False
+        pool.setdefault(nbytes, []).append(ptr)
+        self._dev_pooled = held + nbytes
+        return True
+
     def empty(self, shape, dtype=np.float64):
         shape = (shape,) if np.isscalar(shape) else tuple(shape)
         nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        free = self.__dict__.get("_dev_pool", {}).get(nbytes)
+        if free:
+            self._dev_pooled -= nbytes
+            return DeviceArray(self, free.pop(), shape, dtype)
         p = C.c_void_p()
         check(self.lib.atl_alloc(self.handle, nbytes, C.byref(p)))
         return DeviceArray(self, p.value, shape, dtype)
@@ -670,6 +692,11 @@ class Context:
     def close(self):
         for p in self.__dict__.pop("_plan_cache", {}).values():
             p.close()
+        if getattr(self, "handle", None):
+            for ptrs in self.__dict__.pop("_dev_pool", {}).values():
+                for ptr in ptrs:
+                    self.lib.atl_free(self.handle, ptr)
+            self._dev_pooled = 0
         ev = self.__dict__.pop("_copy_ev", None)
         if ev is not None:
             self.lib.atl_event_destroy(ev)
