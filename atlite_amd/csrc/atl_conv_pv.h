@@ -307,7 +307,11 @@ ATL_HD __forceinline__ PvPlain pv_tail_plain(double direct, double diffuse, doub
                                                  const PvOri &o, const PvConst &k, double toa = 1.0) {
     const double inf = __builtin_inf();
     const double cosinc = __builtin_fmax(o.ss * ca * cosd + o.cs * sa, 0.0);
+#ifdef ATL_ABLATE_NODIV  // experiment: what the division costs
+    const double kk = cosinc * sa;
+#else
     const double kk = fast_div(cosinc, sa);
+#endif
     const double direct_t = kk * direct;
     double diffuse_t;
     if constexpr (HD) {
@@ -328,7 +332,11 @@ ATL_HD __forceinline__ PvPlain pv_tail_plain(double direct, double diffuse, doub
     const double T_ = (k.c_amb * tmp + k.c_irr * G) - k.r_tmod;
     const double G_ = G * k.inv_r_irr;
     const bool pos = G_ > 0.0;
+#ifdef ATL_ABLATE_NOLOG  // experiment: what the logarithm costs
+    const double l = G_ - 1.0;
+#else
     const double l = log_core(pos ? G_ : 1.0);
+#endif
     const double l2 = l * l;
     double eff = 1.0 + k.k1 * l + k.k2 * l2 + T_ * (k.k3 + k.k4 * l + k.k5 * l2) + k.k6 * (T_ * T_);
     eff = pos ? __builtin_fmax(eff, 0.0) : 0.0;
@@ -371,9 +379,14 @@ ATL_HD __forceinline__ PvPlain pv_cell_sp_plain(double dir, double dif, double t
     const double influx = direct + diffuse;
     const double s = __builtin_fmin(__builtin_fmax(sraw, -1.0), 1.0);
     const bool capped = (s < k.sin_alt_thr) || (influx <= 0.01);
-    const double ca = lean_sqrt((1.0 - s) * (1.0 + s));
-    plain = plain && (capped || ca > 0x1.0p-500);  // the sun exactly in the zenith divides literally (pv_cell_sp)
-    const double q = fast_div(num, ca > 0x1.0p-500 ? ca : 1.0);
+    // cos(alt) and its reciprocal from ONE reciprocal-square-root iteration (lean_sqrt_rsqrt: both <= 2 ulp): the quotient
+    // num / cos(alt) is a product then - 8 VALU instructions less per cell than a root and a division
+    const double c2 = (1.0 - s) * (1.0 + s);
+    const bool cok = c2 > 0x1.0p-500;  // the sun (all but) exactly in the zenith divides literally (pv_cell_sp)
+    double rca;
+    const double ca = lean_sqrt_rsqrt(cok ? c2 : 1.0, &rca);
+    plain = plain && (capped || cok);
+    const double q = num * rca;
     const double caz = __builtin_fmin(__builtin_fmax(q, -1.0), 1.0);
     double saz = lean_sqrt((1.0 - caz) * (1.0 + caz));
     saz = (h <= 0.0) ? saz : -saz;
@@ -718,6 +731,11 @@ struct PvConvT {
                 const bool dark0 = !v0 || (q.sd * c.sl0 + q.cd * c.cl0 * q.b.x) < k.sin_alt_thr - 1e-9;
                 const bool dark1 = !v1 || (q.sd * c.sl1 + q.cd * c.cl1 * q.b.y) < k.sin_alt_thr - 1e-9;
                 r.x = r.y = 0.0;
+#ifdef ATL_ABLATE_SPMATH  // experiment: the kernel's floor with every load and the reduction, no physics
+                r.x = q.dir.x + q.dif.x + q.toa.x + q.alb.x + q.tmp.x + q.a.x + q.b.x;
+                r.y = q.dir.y + q.dif.y + q.toa.y + q.alb.y + q.tmp.y + q.a.y + q.b.y;
+                if (false)
+#endif
                 if (!(dark0 && dark1 && tame)) {
                     const PvPlain p0 = pv_cell_sp_plain(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.sd, q.cd, c.sl0, c.cl0, q.a.x, q.b.x, o0, a0, k);
                     const PvPlain p1 = pv_cell_sp_plain(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.sd, q.cd, c.sl1, c.cl1, q.a.y, q.b.y, o1, a1, k);
