@@ -797,7 +797,12 @@ def convert_and_aggregate(
         # pandas Series / GeoSeries / GeoDataFrame-like: the result is labelled with their index (convert.py:236-238)
         if index is None and isinstance(getattr(shapes, "index", None), pd.Index):
             index = shapes.index
-        matrix = sp.csr_matrix(cutout.indicatormatrix(shapes, shapes_crs))
+        try:  # the cutout's cached matrix itself (not modified below: products create new matrices)
+            matrix = cutout.indicatormatrix(shapes, shapes_crs, _share=True)
+        except TypeError:  # a duck-typed cutout without the private switch
+            matrix = cutout.indicatormatrix(shapes, shapes_crs)
+        if not sp.isspmatrix_csr(matrix):
+            matrix = sp.csr_matrix(matrix)
 
     if layout is not None:
         is_xr = labeled.xr is not None and isinstance(layout, labeled.xr.DataArray)

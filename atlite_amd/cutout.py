@@ -95,7 +95,7 @@ class Cutout:
         xs, ys = np.meshgrid(self.coords["x"], self.coords["y"])
         return pd.DataFrame({"x": np.ravel(xs), "y": np.ravel(ys)})
 
-    def indicatormatrix(self, shapes, shapes_crs=4326, where=None):
+    def indicatormatrix(self, shapes, shapes_crs=4326, where=None, _share=False):
         """Share of every grid cell lying in every shape, sparse (N x Y*X) (cutout.py:492-515).
 
         where: "device" (the areas are line integrals evaluated on the GPU), "host" (the C++ polygon clipper) or
@@ -113,7 +113,7 @@ class Cutout:
         cache = self.__dict__.setdefault("_indicator_cache", {})
         # shapes in another crs: their vertices are moved into the cutout's (atlite/gis.py:130), then the same clippers
         return gis.compute_indicatormatrix(self.coords["x"], self.coords["y"], shapes, ctx=ctx, cache=cache,
-                                           shapes_crs=shapes_crs, grid_crs=self.crs)
+                                           shapes_crs=shapes_crs, grid_crs=self.crs, share=_share)
 
     def uniform_layout(self):
         from .labeled import LabeledArray

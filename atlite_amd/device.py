@@ -423,18 +423,21 @@ class Context:
             return AggPlan(self, matrix, row_len=row_len, ld=ld)
         import scipy.sparse as sp
 
-        m = sp.csr_matrix(matrix)
-        try:
-            import xxhash
+        m = matrix if sp.isspmatrix_csr(matrix) else sp.csr_matrix(matrix)
+        digest = getattr(m, "_atl_digest", None)  # set on the matrices the indicator cache hands to the gateway (never copied out)
+        if digest is None:
+            try:
+                import xxhash
 
-            h = xxhash.xxh3_128()
-        except Exception:  # pragma: no cover
-            import hashlib
+                h = xxhash.xxh3_128()
+            except Exception:  # pragma: no cover
+                import hashlib
 
-            h = hashlib.blake2b(digest_size=16)
-        for a in (m.indptr, m.indices, m.data):
-            h.update(np.ascontiguousarray(a).view(np.uint8))
-        key = (m.shape, int(row_len or 0), m.indptr.dtype.str, m.indices.dtype.str, h.hexdigest(),
+                h = hashlib.blake2b(digest_size=16)
+            for a in (m.indptr, m.indices, m.data):
+                h.update(np.ascontiguousarray(a).view(np.uint8))
+            digest = h.hexdigest()
+        key = (m.shape, int(row_len or 0), m.indptr.dtype.str, m.indices.dtype.str, digest,
                os.environ.get("ATLITE_HIP_TILE", ""), int(ld or 0))
         cache_ = self.__dict__.setdefault("_plan_cache", {})
         if key in cache_:

@@ -68,7 +68,7 @@ def _rings_of(shape):
     return [(a, False)]
 
 
-def compute_indicatormatrix(x, y, shapes, ctx=None, cache=None, shapes_crs=None, grid_crs=4326):
+def compute_indicatormatrix(x, y, shapes, ctx=None, cache=None, shapes_crs=None, grid_crs=4326, share=False):
     """
     Indicator matrix ``I[i, j]`` = share of grid cell ``j`` (``j = iy * X + ix``, cell = box of
     centre +- half spacing) lying in ``shapes[i]``; returns ``scipy.sparse.csr_matrix (N, Y*X)``.
@@ -78,7 +78,9 @@ def compute_indicatormatrix(x, y, shapes, ctx=None, cache=None, shapes_crs=None,
     ctx : a ``device.Context`` -> the areas are evaluated on that GPU (``atl_indicator_polygons_device``: exact
           line integrals per candidate cell); ``None`` -> the host clipper (``atl_indicator_polygons``).
     cache : optional dict; the matrix is stored under a digest of the grid and the ring coordinates and a copy is
-          handed back when the same shapes come again - repeated ``Cutout.pv(shapes=...)`` calls.
+          handed back when the same shapes come again - repeated ``Cutout.pv(shapes=...)`` calls.  ``share``: hand the cached
+          object itself back (the gateway: it does not modify it, and the aggregation plan is then found by the object's
+          own digest instead of hashing 600 KB of CSR arrays per call).
     shapes_crs : the shapes' coordinate system when it is not the grid's (``grid_crs``, geographic): like the reference
           (``dest = reproject_shapes(dest, dest_crs, orig_crs)``, atlite/gis.py:130) every VERTEX of every shape is moved into the
           grid's coordinate system (``atlite_amd.crs.inverse``) and the overlaps are taken there, against the rectangular cells -
@@ -111,7 +113,7 @@ def compute_indicatormatrix(x, y, shapes, ctx=None, cache=None, shapes_crs=None,
             hsh.update(s_)
         fast_key = b"fast" + hsh.digest()
         if fast_key in cache:
-            return cache[fast_key].copy()
+            return cache[fast_key] if share else cache[fast_key].copy()
     if hasattr(shapes, "geometry") and not isinstance(shapes, (dict, np.ndarray)):  # GeoDataFrame-like (atlite/gis.py:127)
         shapes = shapes.geometry
     shapes = list(shapes.values) if hasattr(shapes, "values") and not isinstance(shapes, np.ndarray) else list(shapes)
@@ -141,7 +143,7 @@ def compute_indicatormatrix(x, y, shapes, ctx=None, cache=None, shapes_crs=None,
         if key in cache:
             if fast_key is not None:
                 cache[fast_key] = cache[key]
-            return cache[key].copy()  # the cached matrix stays private: callers may modify what they get
+            return cache[key] if share else cache[key].copy()  # the cached matrix stays private: callers may modify what they get
     lib = _lib.load()
     p_ip, p_ix, p_d = C.c_void_p(), C.c_void_p(), C.c_void_p()
     args = (len(shapes), shape_ptr.ctypes.data, len(holes), ring_ptr.ctypes.data,
@@ -167,8 +169,11 @@ def compute_indicatormatrix(x, y, shapes, ctx=None, cache=None, shapes_crs=None,
         while len(cache) >= 16:  # a handful of shape sets per cutout (two keys each: ring digest, raw-bytes digest)
             cache.pop(next(iter(cache)))
         cache[key] = M.copy()
+        cache[key]._atl_digest = "indicator:" + key.hex()  # content key of the cached object (device.Context.plan)
         if fast_key is not None:
             cache[fast_key] = cache[key]
+        if share:
+            return cache[key]
     return M
 
 
