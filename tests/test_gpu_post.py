@@ -130,3 +130,30 @@ def test_runoff_chain_at_config5_result_size(ctx, chunked):
     ref2 = orc.runoff_postprocess(pu, t, names, smooth=48)
     got2 = np.asarray(r2.values).T if chunked else np.asarray(r2.values)
     close(got2, ref2)
+
+
+def test_small_device_blocks_are_recycled_and_results_arrive_in_pinned_memory(ctx):
+    """Context.empty / DeviceArray.free recycle small blocks by size (hipMalloc + hipFree cost more than a warm result
+    download); DeviceArray.numpy() hands back page-locked memory for results of 64 KiB .. 1 GiB - same values either way."""
+    from atlite_amd import device
+
+    a = np.arange(20000.0).reshape(100, 200)
+    d = ctx.upload(a)
+    ptr = d.ptr
+    h = d.numpy()
+    assert isinstance(h.base, device._PinnedBlock) and np.array_equal(h, a)
+    h[0, 0] = -1.0  # an ordinary writeable array
+    del d
+    e = ctx.empty((200, 100))  # the same number of bytes: the block that was just released
+    assert e.ptr == ptr
+    e2 = ctx.empty((200, 100))
+    assert e2.ptr != ptr
+    tiny = ctx.upload(np.ones(5))
+    assert tiny.numpy().base is None
+    import os
+
+    os.environ["ATLITE_HIP_PINNED_RESULTS"] = "0"
+    try:
+        assert ctx.upload(a).numpy().base is None
+    finally:
+        del os.environ["ATLITE_HIP_PINNED_RESULTS"]

@@ -752,3 +752,50 @@ def test_a_nan_vertex_in_the_middle_of_a_ring_empties_the_shape_in_both_algorith
                 for M in (A, B):
                     assert np.isfinite(M).all() and not M[1].any() and M[0].any() and M[2].any()
                 np.testing.assert_allclose(A, B, atol=1e-12)
+
+
+def test_pinned_result_blocks_are_pooled_and_outlive_their_views():
+    """device._PinnedBlock: a download's destination is page-locked memory wrapped as the base of the NumPy array the caller
+    gets; views keep it alive, the block returns to a pool when the last one dies and the next download of that size reuses
+    it (no GPU needed: the allocator is the only library call)."""
+    import ctypes as C
+    import gc
+
+    from atlite_amd import device
+
+    class FakeLib:
+        def __init__(self):
+            self.live, self.allocs = {}, 0
+
+        def atl_pinned_alloc(self, n, pp):
+            buf = (C.c_char * n)()
+            self.live[C.addressof(buf)] = buf
+            pp._obj.value = C.addressof(buf)
+            self.allocs += 1
+            return 0
+
+        def atl_pinned_free(self, p):
+            self.live.pop(p)
+            return 0
+
+    lib = FakeLib()
+    device._PinnedBlock._pool.clear()
+    device._PinnedBlock._pooled = 0
+    a = device._host_array(lib, (100, 1000), np.float64)
+    assert isinstance(a, np.ndarray) and a.flags.writeable and isinstance(a.base, device._PinnedBlock)
+    a[:] = 3.0
+    view = a[5:10]
+    del a
+    gc.collect()
+    assert view.sum() == 15000.0 and device._PinnedBlock._pooled == 0  # the view keeps the block
+    del view
+    gc.collect()
+    assert device._PinnedBlock._pooled == 800000 and lib.allocs == 1
+    b = device._host_array(lib, (1000, 100), np.float64)  # same size: the pooled block
+    assert lib.allocs == 1 and device._PinnedBlock._pooled == 0
+    small = device._host_array(lib, (10,), np.float64)  # below 64 KiB: ordinary memory
+    assert small.base is None and lib.allocs == 1
+    del b
+    gc.collect()
+    device._PinnedBlock._pool.clear()
+    device._PinnedBlock._pooled = 0
