@@ -71,8 +71,12 @@ def main():
     for g in groups:
         args, legs = GROUPS[g]
         lines, per_pass = [], {}
-        for pname, extra in (("stats", ["--kernel-trace", "--stats"]), ("fetch", ["--pmc", "FETCH_SIZE", "--kernel-trace"]),
-                             ("write", ["--pmc", "WRITE_SIZE", "--kernel-trace"])):
+        passes = [("stats", ["--kernel-trace", "--stats"]), ("fetch", ["--pmc", "FETCH_SIZE", "--kernel-trace"]),
+                  ("write", ["--pmc", "WRITE_SIZE", "--kernel-trace"])]
+        if os.environ.get("ATL_PROFILE_SQ", "1") != "0":  # a fourth pass: how busy the SIMDs are (quad-cycle counters)
+            passes.append(("sq", ["--pmc", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+                                  "GRBM_GUI_ACTIVE", "--kernel-trace"]))
+        for pname, extra in passes:
             d, cmd = run_pass(out / f"raw_{g}", pname, extra)
             with open(out / f"{g}.{pname}.log", "w") as log:
                 subprocess.run(cmd + args + COMMON, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, check=False)
@@ -107,6 +111,34 @@ def main():
                                                     "kernel_name, counter_name) group by kernel_name, counter_name"):
                 pmc.setdefault(short(k), {})[cn] = a
                 lines.append(f"{short(k):72s} {cn:11s} n={c:3d} avg={a:16.1f} min={mn:16.1f} max={mx:16.1f}")
+        sq = {}
+        con = per_pass.get("sq")
+        if con:
+            lines.append("")
+            lines.append("== rocprofv3 --pmc SQ_* / GRBM_GUI_ACTIVE (its own pass; per launch, summed over the counter's instances; SQ wave counters in "
+                         "quad-cycles; dispatches of a --pmc pass are serialised, so clocks are colder than in the stats pass) ==")
+            rows = con.execute("select kernel_name, counter_name, count(*), avg(v) from (select dispatch_id, kernel_name, counter_name, sum(value) as v "
+                               "from counters_collection group by dispatch_id, kernel_name, counter_name) group by kernel_name, counter_name").fetchall()
+            dur = {short(n): a for n, a in con.execute("select name, avg(duration) from kernels group by name")}
+            for k, cn, c, a in rows:
+                sq.setdefault(short(k), {})[cn] = a
+            for k, e in sorted(sq.items()):
+                if not (k.startswith("k_fused") or k.startswith("k_cells")):
+                    continue
+                g = e.get("GRBM_GUI_ACTIVE", 0.0) / 8.0  # shader cycles per XCD
+                der = {}
+                if g > 0 and dur.get(k):
+                    der["clock_GHz"] = g / dur[k]
+                if g > 0 and "SQ_ACTIVE_INST_VALU" in e:
+                    der["valu_busy"] = 4 * e["SQ_ACTIVE_INST_VALU"] / (g * 1024)
+                if g > 0 and "SQ_WAVE_CYCLES" in e:
+                    der["resident_waves_per_simd"] = 4 * e["SQ_WAVE_CYCLES"] / (g * 1024)
+                if e.get("SQ_WAVE_CYCLES"):
+                    for cn, lab in (("SQ_ACTIVE_INST_ANY", "issuing"), ("SQ_WAIT_INST_ANY", "issue_stall"), ("SQ_WAIT_ANY", "waitcnt")):
+                        if cn in e:
+                            der[lab] = e[cn] / e["SQ_WAVE_CYCLES"]
+                e["_derived"] = der
+                lines.append(f"{k:72s} " + " ".join(f"{a}={b:.2f}" for a, b in der.items()))
         lines.append("")
         lines.append("== legs of this group (kernel chosen by NAME; read = 2 x FETCH_SIZE KiB [gfx950 wide-read correction], write = WRITE_SIZE KiB) ==")
         for leg in legs:
@@ -125,6 +157,8 @@ def main():
                 e["read_bytes"] = 2.0 * pmc[k]["FETCH_SIZE"] * 1024
                 e["write_bytes"] = pmc[k].get("WRITE_SIZE", 0.0) * 1024
                 e["hbm_bytes_per_launch"] = e["read_bytes"] + e["write_bytes"]
+            if k in sq and sq[k].get("_derived"):
+                e["sq"] = sq[k]["_derived"]
             latest["legs"][leg] = e
             lines.append(f"{leg}: {k}  avg {e['avg_us']:.1f} us over {e['calls']} launches, {e['avg_us_timed']:.1f} us over the {len(timed)} after the warm-up" +
                          (f"  read {e['read_bytes'] / 1e9:.3f} GB  write {e['write_bytes'] / 1e9:.3f} GB" if "read_bytes" in e else ""))
