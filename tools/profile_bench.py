@@ -125,14 +125,14 @@ def main():
             for k, e in sorted(sq.items()):
                 if not (k.startswith("k_fused") or k.startswith("k_cells")):
                     continue
-                g = e.get("GRBM_GUI_ACTIVE", 0.0) / 8.0  # shader cycles per XCD
+                cyc = e.get("GRBM_GUI_ACTIVE", 0.0) / 8.0  # shader cycles per XCD
                 der = {}
-                if g > 0 and dur.get(k):
-                    der["clock_GHz"] = g / dur[k]
-                if g > 0 and "SQ_ACTIVE_INST_VALU" in e:
-                    der["valu_busy"] = 4 * e["SQ_ACTIVE_INST_VALU"] / (g * 1024)
-                if g > 0 and "SQ_WAVE_CYCLES" in e:
-                    der["resident_waves_per_simd"] = 4 * e["SQ_WAVE_CYCLES"] / (g * 1024)
+                if cyc > 0 and dur.get(k):
+                    der["clock_GHz"] = cyc / dur[k]
+                if cyc > 0 and "SQ_ACTIVE_INST_VALU" in e:
+                    der["valu_busy"] = 4 * e["SQ_ACTIVE_INST_VALU"] / (cyc * 1024)
+                if cyc > 0 and "SQ_WAVE_CYCLES" in e:
+                    der["resident_waves_per_simd"] = 4 * e["SQ_WAVE_CYCLES"] / (cyc * 1024)
                 if e.get("SQ_WAVE_CYCLES"):
                     for cn, lab in (("SQ_ACTIVE_INST_ANY", "issuing"), ("SQ_WAIT_INST_ANY", "issue_stall"), ("SQ_WAIT_ANY", "waitcnt")):
                         if cn in e:
