@@ -14,7 +14,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 from atlite_amd import Cutout, Dataset, gis, synthetic  # noqa: E402
 from atlite_amd.device import default_context  # noqa: E402

@@ -7,7 +7,7 @@ import runpy
 import sys
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault("ATL_VARIANT_REPS", "2")
 os.environ.setdefault("ATL_VARIANTS", "influx / outflux dataset|pv(tracking='horizontal')|KANENA|bofinger + tracking='horizontal'|irradiation(tracking='dual')")

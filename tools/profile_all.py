@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """
 rocprofv3 target of round 3: every dominant kernel of the library on its workload, a few launches each, so that ONE
-set of passes (--kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ counters, tools/r03_job3.sh) covers a
+set of passes (--kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ counters, tools/profile_configs.sh) covers a
 whole group.  usage: profile_all.py <group>
   pvfam  C2 shape: pv() defaults with and without the early-out, in-kernel solar position (both), the influx / outflux
          head, the general kernel (influx + Hay-Davies), a tracker, per-cell series and capacity-factor maps (k_cells_*)
