@@ -11,6 +11,8 @@ attrs, name - and converts to / from real xarray objects when xarray is importab
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import pandas as pd
 
@@ -233,7 +235,12 @@ class Dataset:
     (atlite/aggregate.py:21-35).
     """
 
-    def __init__(self, data_vars, coords, attrs=None, chunked=False):
+    def __init__(self, data_vars, coords, attrs=None, chunked=False, repack=None):
+        # repack: copy (time, y, x) variables the CALLER holds on the device into the library's padded, slot-interleaved
+        # layout on first use when the cell count is not a multiple of 16 (contiguous cubes off the 128-byte line grid run
+        # the fused kernels 15-35 % slower: one extra line per 1-KiB wave load).  Costs one device-to-device copy and the
+        # cubes' size in HBM again; pays off from the second conversion on.  Default: $ATLITE_HIP_REPACK == "1".
+        self.repack = (os.environ.get("ATLITE_HIP_REPACK", "0") == "1") if repack is None else bool(repack)
         self.coords = {}
         for k, v in coords.items():
             self.coords[k] = pd.DatetimeIndex(v) if k == "time" else np.asarray(v, dtype=np.float64)
@@ -339,7 +346,7 @@ class Dataset:
             raise IndexError(f"time range [{start}, {stop}) outside the dataset's {T} steps")
         coords = dict(self.coords)
         coords["time"] = self.coords["time"][start:stop]
-        out = Dataset({}, coords, self.attrs, chunked=self.chunked)
+        out = Dataset({}, coords, self.attrs, chunked=self.chunked, repack=self.repack)
         for k, la in self._vars.items():
             if "time" not in la.dims:
                 out[k] = la
@@ -396,7 +403,7 @@ class Dataset:
             for alias, of in (("lon", "x"), ("lat", "y")):
                 if of == dim and alias in coords:
                     coords[alias] = coords[dim]
-        new = Dataset({}, coords, out.attrs, chunked=out.chunked)
+        new = Dataset({}, coords, out.attrs, chunked=out.chunked, repack=out.repack)
         for k, la in out._vars.items():
             v = np.asarray(la.data.numpy() if _is_device(la.data) else la.data)
             for ax, dim in enumerate(la.dims):
@@ -491,6 +498,11 @@ class Dataset:
         x = self._vars[name].data
         if getattr(x, "is_file_array", False):
             return x.to_device(ctx, out=view)
+        if _is_device(x) or (type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)):
+            r = ctx.asdevice(x).reshape(T, S)  # the caller's own device cube (repack): copied on the device
+            check(ctx.lib.atl_copy_2d(ctx.handle, view.ptr, (view.ld or S) * 8, r.ptr, (r.ld or S) * 8, S * 8, T, 2, 0))
+            ctx.sync()
+            return view
         if type(x).__module__.startswith("torch") and hasattr(x, "data_ptr"):
             x = x.numpy()
         return ctx.upload(np.asarray(x).reshape(T, -1), out=view)
@@ -498,6 +510,8 @@ class Dataset:
     def _caller_layout(self):
         """True when a (time, y, x) variable already lives on a device in the caller's own (contiguous) layout, which every
         cube of a call must then share."""
+        if self.repack and (len(self.coords["y"]) * len(self.coords["x"])) % 16 != 0:
+            return False  # the library makes padded copies of the caller's device cubes (see __init__)
         return any(la.dims == ("time", "y", "x") and (_is_device(la.data) or (type(la.data).__module__.startswith("torch")
                                                                                and getattr(la.data, "is_cuda", False)))
                    for la in self._vars.values())
@@ -515,6 +529,9 @@ class Dataset:
     def _to_device(self, ctx, la):
         ld = self._slot_stride() if la.dims == ("time", "y", "x") else None
         x = la.data
+        if ld is not None and (_is_device(x) or (type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False))):
+            d = ctx.asdevice(x)  # repack: a padded copy of the caller's device cube
+            return ctx._relayout(d.reshape(d.shape[0], -1), ld)
         if ld is None or _is_device(x):
             return ctx.asdevice(x)
         T = x.shape[0]
