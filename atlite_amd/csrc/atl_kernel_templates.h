@@ -410,7 +410,17 @@ __device__ __forceinline__ void reduce_batch(const double2 (&v)[kBatch], bool fi
         double2 wz;
         wz.x = a0 ? w.x : 0.0;
         wz.y = a1 ? w.y : 0.0;
+        // (an all-finite batch needs no guards here either: a zero weight times a finite value is a zero - the same
+        // shortcut the cached rows take; 16 selects less per row and batch, which the early-out kernels with their two
+        // cached rows feel)
+#ifdef ATL_GUARD_UNCACHED_ROWS  // experiment: round 3's behaviour
         reduce_row<true>(v, wz, a0, a1, lane, sb, send, partials + int64_t(p) * ldp);
+#else
+        if (all_finite)
+            reduce_row<false>(v, wz, true, true, lane, sb, send, partials + int64_t(p) * ldp);
+        else
+            reduce_row<true>(v, wz, a0, a1, lane, sb, send, partials + int64_t(p) * ldp);
+#endif
     }
 }
 
