@@ -64,7 +64,9 @@ struct WindConvT {
         for (int i = threadIdx.x; i < tab_doubles; i += blockDim.x) lds[i] = table[i];
         if constexpr (METHOD == ATL_WIND_LOG) log_table_init(lds + tab_doubles);
     }
-    ATL_HD Cell cell_setup(int64_t c0, bool v0, bool v1, const double *lds) const {
+    // cell_setup in two parts (k_cells_series_flat loads the cubes between them): the static roughness / shear needs no table
+    static constexpr bool kEarlyLoad = true;
+    ATL_HD Cell cell_early(int64_t c0, bool v0, bool v1) const {
         Cell c;
         c.aux.x = 0.0;
         c.aux.y = 0.0;
@@ -72,11 +74,18 @@ struct WindConvT {
             c.aux.x = v0 ? aux[c0] : 1.0;
             c.aux.y = v1 ? aux[c0 + 1] : 1.0;
         }
-        // log(from) through the same routine as the per-cell roughness: z0 == from_height gives an
-        // exact zero denominator, like the reference's log(from/z0) = log(1)
         c.lh = 0.0;
         c.lf = 0.0;
+        return c;
+    }
+    ATL_HD void cell_finish(Cell &c, const double *lds) const {
+        // log(from) through the same routine as the per-cell roughness: z0 == from_height gives an
+        // exact zero denominator, like the reference's log(from/z0) = log(1)
         if constexpr (METHOD == ATL_WIND_LOG) c.lf = log_core_tab(from_height, lds + tab_doubles);
+    }
+    ATL_HD Cell cell_setup(int64_t c0, bool v0, bool v1, const double *lds) const {
+        Cell c = cell_early(c0, v0, v1);
+        cell_finish(c, lds);
         return c;
     }
     ATL_HD __forceinline__ double hub_speed_literal(double v, double z) const {
@@ -133,6 +142,7 @@ struct WindConvT {
     static constexpr int kGroup = ATL_WIND_GROUP;
     static constexpr int kMinChunk = 64;  // fused kernel: C3 aggregated 3.70 / 3.77 / 3.96 ms with chunks of 64 / 32 / 16 slots
     static constexpr int kCubes = 2;
+    static constexpr bool kFlatSeries = true;  // per-cell series in flat order (k_cells_series_flat)
     // dense tiles: the log-law converter has no 64 VGPRs to spare for a resident operand image at two waves per SIMD
     static constexpr int kDenseResident = (METHOD == ATL_WIND_LOG || (METHOD == ATL_WIND_POWER && STEPS == 0)) ? 0 : 1;
 #ifdef ATL_WIND_WAVES

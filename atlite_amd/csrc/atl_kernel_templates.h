@@ -83,6 +83,51 @@ __global__ __launch_bounds__(256) void k_cells_series(Conv conv, int64_t n_slots
 }
 
 // ---------------------------------------------------------------------------------------
+// kernel 1f: per-cell series in FLAT order (round 4).  A block converts kFlatChunks x 512 consecutive cells of ONE slot,
+// blockIdx.x fastest: the chip as a whole walks every cube front to back instead of every block walking its cells
+// through 32 slots a whole slot apart.  For a stream that also WRITES a cube that order is worth 10-20 % on this chip
+// (tools/probes/mix_probe.hip: c = a + b over 11 GB cubes, 5.18 ms flat against 6.0-6.3 ms slot-walking; read-only
+// streams do not care).  For converters whose per-cell setup is trivial (kFlatSeries): it is redone per cell and slot here.
+// ---------------------------------------------------------------------------------------
+template <class Conv, class = void>
+struct conv_flat_series : std::false_type {};
+template <class Conv>
+struct conv_flat_series<Conv, std::void_t<decltype(Conv::kFlatSeries)>> : std::integral_constant<bool, Conv::kFlatSeries> {};
+
+// converters whose per-cell setup splits into a part that needs no LDS (cell_early) and one that reads the block's tables
+// (cell_finish): the flat kernel issues the cubes' loads BEFORE it fills the tables, so both latencies overlap
+template <class Conv, class = void>
+struct conv_early_load : std::false_type {};
+template <class Conv>
+struct conv_early_load<Conv, std::void_t<decltype(Conv::kEarlyLoad)>> : std::integral_constant<bool, Conv::kEarlyLoad> {};
+
+template <class Conv>
+__global__ __launch_bounds__(256) void k_cells_series_flat(Conv conv, int64_t S, double *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int64_t slot = blockIdx.y;
+    const int64_t c0 = int64_t(blockIdx.x) * 512 + int64_t(threadIdx.x) * 2;
+    const bool v0 = c0 < S, v1 = c0 + 1 < S;
+    const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);  // safe indices
+    typename Conv::Carry carry = carry_init<typename Conv::Carry>();
+    typename Conv::Raw raw;
+    typename Conv::Cell cell;
+    if constexpr (conv_early_load<Conv>::value) {
+        cell = conv.cell_early(c0, v0, v1);
+        raw = conv.template load<true>(slot, 0, s0c, s1c, cell, carry);
+        conv.block_init(lds);
+        __syncthreads();
+        conv.cell_finish(cell, lds);
+    } else {
+        conv.block_init(lds);
+        __syncthreads();
+        cell = conv.cell_setup(c0, v0, v1, lds);
+        raw = conv.template load<true>(slot, 0, s0c, s1c, cell, carry);
+    }
+    const double2 r = conv.compute(raw, v0, v1, cell, lds);
+    st2<true>(out, slot * S + c0, v0, v1, r);
+}
+
+// ---------------------------------------------------------------------------------------
 // kernel 2: per-cell time reduction.  psum/pcnt[chunk, cell] then k_chunk_reduce.
 // ---------------------------------------------------------------------------------------
 template <class Conv, bool VEC>
@@ -920,6 +965,13 @@ int32_t pick_chunk_slots(const atl_ctx *ctx, int64_t n_slots, int64_t n_segs, in
     return int32_t(chunk);
 }
 
+// per-cell series of the converters marked kFlatSeries go through k_cells_series_flat ($ATLITE_HIP_SERIES_FLAT=0: the
+// slot-walking kernel, for A/B runs)
+inline bool flat_series() {
+    const char *e = getenv("ATLITE_HIP_SERIES_FLAT");
+    return !(e && e[0] == '0');
+}
+
 constexpr size_t kCellsNightLds = 4 * kBatch * kSegCells * sizeof(double);  // k_cells_night: key rows of the block's four waves
 
 // slots per block of the per-cell kernels that walk a slot range: as long as possible while the grid still fills the chip
@@ -971,6 +1023,10 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
             else if constexpr (kScalarToo)
                 hipLaunchKernelGGL((k_cells_night<Conv, false, true>), gridn, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
                                    len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)), tX, tY, ntx);
+        } else if (conv_flat_series<Conv>::value && vec && n_slots <= 65535 && flat_series()) {
+            if constexpr (conv_flat_series<Conv>::value)  // flat order: see k_cells_series_flat
+                hipLaunchKernelGGL((k_cells_series_flat<Conv>), dim3(unsigned((S + 511) / 512), unsigned(n_slots)), dim3(256), lds_bytes, ctx->stream,
+                                   conv, S, d_out);
         } else if (vec) {  // (else: the early-out converters do not instantiate the plain series kernel)
             hipLaunchKernelGGL((k_cells_series<Conv, true>), grid, dim3(256), lds_bytes, ctx->stream, conv,
                                n_slots, S, d_out);

@@ -160,7 +160,7 @@ KERNELS = {
     "night_skip": "k_fused_segred_night<PvConvT<false, false, true, 0, 0, 0>, true, false>",
     "star_polygons": "k_fused_segred<PvConvT<false, false, false, 0, 0, 0>, true, false>",
     "star_night_skip": "k_fused_segred_night<PvConvT<false, false, true, 0, 0, 0>, true, false>",
-    "c3_series": "k_cells_series<WindConvT<1, -1>, true>",
+    "c3_series": "k_cells_series_flat<WindConvT<1, -1>>",
     "c3_cf_map": "k_cells_timered<WindConvT<1, -1>, true>",
     "c3_aggregated": "k_fused_segred<WindConvT<1, -1>, true, false>",
     "c5_heat": "k_fused_segred<HeatConv, true, false>",

@@ -44,7 +44,7 @@ WARM_CONFIGS = 10
 
 
 def short(n):
-    return n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    return n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].replace("> >", ">>")
 
 
 def db(path):
