@@ -102,10 +102,11 @@ template <class Conv>
 struct conv_early_load<Conv, std::void_t<decltype(Conv::kEarlyLoad)>> : std::integral_constant<bool, Conv::kEarlyLoad> {};
 
 template <class Conv>
-__global__ __launch_bounds__(256) void k_cells_series_flat(Conv conv, int64_t S, double *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_cells_series_flat(Conv conv, int64_t S, uint32_t n_chunks, double *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int64_t slot = blockIdx.y;
-    const int64_t c0 = int64_t(blockIdx.x) * 512 + int64_t(threadIdx.x) * 2;
+    const uint32_t slot_u = blockIdx.x / n_chunks;  // blocks in (slot, chunk) order: every stream advances front to back
+    const int64_t slot = slot_u;
+    const int64_t c0 = int64_t(blockIdx.x - slot_u * n_chunks) * 512 + int64_t(threadIdx.x) * 2;
     const bool v0 = c0 < S, v1 = c0 + 1 < S;
     const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);  // safe indices
     typename Conv::Carry carry = carry_init<typename Conv::Carry>();
@@ -348,6 +349,46 @@ __global__ __launch_bounds__(256, conv_min_waves_cells<Conv>::value) void k_cell
             out_b[o + 1] = double(cnt1);
         }
     }
+}
+
+// The early-out per-cell SERIES in flat order (see k_cells_series_flat): a wave converts its 128 cells of ONE slot and
+// ends - key first, the other streams only when a covered cell is in daylight.  No batch of keys in flight ahead: the
+// chip's occupancy hides the two dependent latencies, and the streams advance front to back together.
+template <class Conv, class = void>
+struct conv_flat_night : std::false_type {};
+template <class Conv>
+struct conv_flat_night<Conv, std::void_t<decltype(Conv::kFlatNightSeries)>> : std::integral_constant<bool, Conv::kFlatNightSeries> {};
+
+template <class Conv>
+__global__ __launch_bounds__(256) void k_cells_series_flat_night(Conv conv, int64_t S, uint32_t n_chunks, double *__restrict__ out, int64_t X,
+                                                                 int64_t Y, int32_t ntx) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    conv.block_init(lds);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    const uint32_t slot_u = blockIdx.x / n_chunks;
+    const int64_t slot = slot_u;
+    const int64_t chunk = blockIdx.x - slot_u * n_chunks;
+    int64_t c0 = (chunk * 256 + threadIdx.x) * 2;
+    bool v0 = c0 < S, v1 = c0 + 1 < S;
+    if (X > 0) {  // 16 x 8 tiles, as k_cells_night
+        const int64_t seg = chunk * 4 + wave;
+        if (seg >= int64_t(ntx) * ((Y + 7) / 8)) return;
+        const TileLane tl = tile_lane_cells(X, Y, ntx, 3, int32_t(seg), lane);
+        c0 = tl.c0;
+        v0 = tl.v0;
+        v1 = tl.v1;
+    }
+    const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);
+    const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
+    const double2 key = v0 ? conv.template key_load<true>(slot, s0c, s1c, cell) : double2{0.0, 0.0};
+    double2 r = {0.0, 0.0};
+    if (!__all(conv.key_is_zero(key, slot, cell) || !v0)) {  // wave-uniform
+        const typename Conv::Raw A = conv.template rest_load<true>(slot, s0c, s1c, cell);
+        r = conv.compute_keyed(A, key, v0, v1, cell, lds);
+    }
+    st2<true>(out, slot * S + c0, v0, v1, r);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1017,16 +1058,24 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
         if constexpr (conv_night_pipe<Conv>::value) {  // long slot ranges: the keys are fetched one batch ahead
             const int64_t len = slot_chunk_len(ctx, n_slots, gx_cells);
             const dim3 gridn(gx, unsigned((n_slots + len - 1) / len));
-            if (vec)
+            if (conv_flat_night<Conv>::value && vec && int64_t(gx) * n_slots < (int64_t(1) << 31) && flat_series()) {
+                if constexpr (conv_flat_night<Conv>::value)
+                {
+                    const bool strips = getenv("ATLITE_HIP_SERIES_FLAT_STRIPS") != nullptr;  // experiment: 128-cell strips instead of 16 x 8 tiles
+                    const unsigned gxf = strips ? gx_cells : gx;
+                    hipLaunchKernelGGL((k_cells_series_flat_night<Conv>), dim3(unsigned(int64_t(gxf) * n_slots)), dim3(256), lds_bytes, ctx->stream, conv,
+                                       S, uint32_t(gxf), d_out, strips ? 0 : tX, tY, ntx);
+                }
+            } else if (vec)
                 hipLaunchKernelGGL((k_cells_night<Conv, true, true>), gridn, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
                                    len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)), tX, tY, ntx);
             else if constexpr (kScalarToo)
                 hipLaunchKernelGGL((k_cells_night<Conv, false, true>), gridn, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
                                    len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)), tX, tY, ntx);
-        } else if (conv_flat_series<Conv>::value && vec && n_slots <= 65535 && flat_series()) {
+        } else if (conv_flat_series<Conv>::value && vec && int64_t(gx_cells) * n_slots < (int64_t(1) << 31) && flat_series()) {
             if constexpr (conv_flat_series<Conv>::value)  // flat order: see k_cells_series_flat
-                hipLaunchKernelGGL((k_cells_series_flat<Conv>), dim3(unsigned((S + 511) / 512), unsigned(n_slots)), dim3(256), lds_bytes, ctx->stream,
-                                   conv, S, d_out);
+                hipLaunchKernelGGL((k_cells_series_flat<Conv>), dim3(unsigned(int64_t(gx_cells) * n_slots)), dim3(256), lds_bytes, ctx->stream, conv, S,
+                                   uint32_t(gx_cells), d_out);
         } else if (vec) {  // (else: the early-out converters do not instantiate the plain series kernel)
             hipLaunchKernelGGL((k_cells_series<Conv, true>), grid, dim3(256), lds_bytes, ctx->stream, conv,
                                n_slots, S, d_out);
