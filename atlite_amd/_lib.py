@@ -178,8 +178,10 @@ SIGNATURES = {
     "atl_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_float)]),
     "atl_kernel_times": (_i, [_vp, C.POINTER(C.c_float), _i64, C.POINTER(_i64)]),
     "atl_agg_create": (_i, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "atl_agg_create_aligned": (_i, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(_vp)]),
     "atl_agg_destroy": (_i, [_vp]),
     "atl_agg_selfcheck": (_i, [_i64, _i64, _i, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "atl_agg_selfcheck_aligned": (_i, [_i64, _i64, _i, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "atl_agg_info": (_i, [_vp, c_int64_p, c_int64_p, c_int64_p, c_int64_p, c_int32_p, c_int32_p]),
     "atl_spmm_csr": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _vp, _i64]),
     "atl_pv_convert": (_i, [_vp, C.POINTER(PvInputs), C.POINTER(PvParams), _i64, _i64, _i, _vp]),

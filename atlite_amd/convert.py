@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import datetime as dt
 import logging
+import os
 import re
 import warnings
 from pathlib import Path
@@ -825,8 +826,18 @@ def convert_and_aggregate(
         out = multigpu.group(devs).run(spec, ds, matrix, X, None)
     else:
         # (the slot stride of the dataset's device copies only steers the plan's tile shape)
-        plan = ctx.plan(matrix, row_len=X, ld=getattr(ds, "_slot_stride", lambda: None)())
-        out = _execute(ctx, spec, ds, plan, on_device_time)  # the plan stays in ctx's cache
+        out = None
+        if _aligned_plan_wanted(ds, matrix, Y * X):
+            # the caller's own contiguous device cubes on a grid whose slots do not start on 128-byte lines: the
+            # line-aligned plan (atl_agg_create_aligned); conversions it does not cover answer with an error -> ordinary plan
+            try:
+                out = _execute(ctx, spec, ds, ctx.plan(matrix, row_len=X, aligned=True), on_device_time)
+            except ValueError as e:  # (ATL_E_INVALID)
+                if "line-aligned plan" not in str(e):
+                    raise
+        if out is None:
+            plan = ctx.plan(matrix, row_len=X, ld=getattr(ds, "_slot_stride", lambda: None)())
+            out = _execute(ctx, spec, ds, plan, on_device_time)  # the plan stays in ctx's cache
         if device_post is not None and on_device_time is None and not per_unit and aggregate_time in (None, "legacy"):
             out = device_post(ctx, out, spec.time_coord(ds))
             device_post.applied = True
@@ -862,6 +873,19 @@ def convert_and_aggregate(
     if return_capacity:
         return _finish(results), _finish(capacity)
     return _finish(results)
+
+
+def _aligned_plan_wanted(ds, matrix, S):
+    """A line-aligned plan pays when the dataset's cubes are the caller's own contiguous device arrays and their slots do
+    not start on 128-byte lines; 16 / gcd(S, 16) copies of the matrix must fit the plan's 65535 rows
+    (``ATLITE_HIP_ALIGNED_PLANS=0`` switches it off)."""
+    import math
+
+    if os.environ.get("ATLITE_HIP_ALIGNED_PLANS", "1") == "0" or S % 16 == 0 or S < 16:
+        return False
+    if not getattr(ds, "_caller_layout", lambda: False)():
+        return False
+    return matrix.shape[0] * (16 // math.gcd(S, 16)) < 65536
 
 
 def _reindex_layout(layout, ds):

@@ -16,6 +16,7 @@ __device__ __forceinline__ C carry_init() {
 // generic dense cube (aggregate_matrix on an arbitrary converted DataArray)
 struct IdentityConv {
     static constexpr bool kFlatSeries = true;  // per-cell series in flat order (k_cells_series_flat): the per-cell setup is (next to) nothing
+    static constexpr bool kShiftOk = true;     // line-aligned plans may re-address the cube (S is the slot stride and nothing else)
     const double *d;
     int64_t S;
     using Cell = NoCell;
@@ -36,6 +37,7 @@ struct IdentityConv {
 // runoff * height  (convert.py:1028-1034)
 struct RunoffConv {
     static constexpr bool kFlatSeries = true;  // per-cell series in flat order (k_cells_series_flat): the per-cell setup is (next to) nothing
+    static constexpr bool kShiftOk = true;     // line-aligned plans may re-address the cube (S is the slot stride and nothing else)
     const double *runoff;
     const double *height;  // (S) or nullptr
     int64_t S;
@@ -68,6 +70,7 @@ struct RunoffConv {
 // temperature family + heat-pump COP (convert.py:292-364)
 struct ThermoConv {
     static constexpr bool kFlatSeries = true;  // per-cell series in flat order (k_cells_series_flat): the per-cell setup is (next to) nothing
+    static constexpr bool kShiftOk = true;     // line-aligned plans may re-address the cube (S is the slot stride and nothing else)
     const double *var;
     int64_t S;
     double offset, sink_T, c0, c1, c2;

@@ -504,6 +504,7 @@ struct PvConvT {
     static constexpr bool kDenseOk = TAIL == kTailHuld && TRACK == ATL_TRACK_NONE && !PC && HEAD == 0;
     // per-cell series in flat order (k_cells_series_flat) where the per-cell setup is empty: one orientation for the grid, stored angles
     static constexpr bool kFlatSeries = !SP && !PC && !SKIP;
+    static constexpr bool kShiftOk = !SP;  // line-aligned plans: the stored-angle converters use a slot index for nothing but slot * S
     static constexpr bool kFlatNightSeries = !SP && !PC && SKIP;  // ... and with the early-out (k_cells_series_flat_night)
     static constexpr int kDenseResident = 0;  // the operand image of dense tiles streams from L2 per sweep (resident: 64 VGPRs per
                                               // group; measured with one group: pv R = 16 / 32 3.38 / 3.74 -> 3.50 / 4.11 ms - its short

@@ -143,6 +143,7 @@ struct WindConvT {
     static constexpr int kMinChunk = 64;  // fused kernel: C3 aggregated 3.70 / 3.77 / 3.96 ms with chunks of 64 / 32 / 16 slots
     static constexpr int kCubes = 2;
     static constexpr bool kFlatSeries = true;  // per-cell series in flat order (k_cells_series_flat)
+    static constexpr bool kShiftOk = true;     // line-aligned plans may re-address the cubes (S is the slot stride and nothing else)
     // dense tiles: the log-law converter has no 64 VGPRs to spare for a resident operand image at two waves per SIMD
     static constexpr int kDenseResident = (METHOD == ATL_WIND_LOG || (METHOD == ATL_WIND_POWER && STEPS == 0)) ? 0 : 1;
 #ifdef ATL_WIND_WAVES

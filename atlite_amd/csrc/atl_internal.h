@@ -69,6 +69,16 @@ struct PlanDev {
     // (cells outside every shape: sea, neighbouring countries, tile padding) issue no loads at all - their values
     // could only ever meet structural zeros - so a 128-byte line without a covered cell is never fetched.
     const uint64_t *seg_mask;
+    // Line-aligned plan for CONTIGUOUS (T, S) cubes whose slots do not start on 128-byte lines (S % 16 != 0), built by
+    // atl_agg_create_aligned; shift_classes = 0 for every other plan.  Slot t starts o = (t * S) % 16 cells into a line,
+    // and that offset repeats every p = 16 / gcd(S, 16) slots: class r = the slots r, r + p, ... .  The plan holds p
+    // tilings of the same (Y, X) grid, class r's with its tile rows on the line grid of c + o_r (tile_row_lo): tiles
+    // [r * shift_tiles, (r + 1) * shift_tiles), output rows [r * shift_rows, (r + 1) * shift_rows) - every tile row is
+    // whole lines in every slot of its class.  n_rows is the stacked count, X / Y / ntx / n_cells the grid's own.
+    int32_t shift_classes;  // p (0: an ordinary plan)
+    int32_t shift_rows;     // N, the matrix's row count
+    int32_t shift_tiles;    // tiles per class
+    int32_t shift_pad_;
 };
 
 constexpr int kMfmaRows = 16;      // rows per MFMA group
@@ -99,18 +109,21 @@ struct TileLane {
     bool v0, v1;  // the lane owns c0 / c0 + 1
 };
 
-__host__ __device__ inline int64_t tile_row_lo(int64_t X, int64_t y) { return (y * X) & ~int64_t(15); }
+// `o` (0 .. 15): the grid's first cell sits o cells into a 128-byte line - the alignment class of a line-aligned plan
+// (PlanDev::shift_classes).  Tile rows then start on the line grid of the SHIFTED index c + o; all indices handed out
+// and taken are the grid's own (c0 may be as low as -o: cells before the grid, never owned).
+__host__ __device__ inline int64_t tile_row_lo(int64_t X, int64_t y, int64_t o = 0) { return ((y * X + o) & ~int64_t(15)) - o; }
 
 __host__ __device__ inline TileLane tile_lane_cells(int64_t X, int64_t Y, int32_t ntx, int32_t w2_log2,
-                                                    int32_t seg, int lane) {
+                                                    int32_t seg, int lane, int64_t o = 0) {
     const int32_t ty = seg / ntx, tx = seg - ty * ntx;
     const int64_t gy = int64_t(ty) * (kLanes >> w2_log2) + (lane >> w2_log2);
     const int64_t p = (int64_t(tx) << (w2_log2 + 1)) + ((lane & ((1 << w2_log2) - 1)) << 1);
-    const int64_t hi = gy + 1 < Y ? tile_row_lo(X, gy + 1) : X * Y;
+    const int64_t hi = gy + 1 < Y ? tile_row_lo(X, gy + 1, o) : X * Y;
     TileLane t;
-    t.c0 = tile_row_lo(X, gy) + p;
-    t.v0 = gy < Y && t.c0 < hi;
-    t.v1 = gy < Y && t.c0 + 1 < hi;
+    t.c0 = tile_row_lo(X, gy, o) + p;
+    t.v0 = gy < Y && t.c0 < hi && t.c0 >= 0;
+    t.v1 = gy < Y && t.c0 + 1 < hi && t.c0 + 1 >= 0;
     return t;
 }
 
@@ -216,9 +229,9 @@ inline int wind_grid_build(const double *tbl_search, int n, int n_pad, std::vect
     return 0;
 }
 
-inline int64_t tile_columns(int64_t X, int64_t Y, int w2_log2) {
+inline int64_t tile_columns(int64_t X, int64_t Y, int w2_log2, bool shifted = false) {
     const int w = 2 << w2_log2;
-    const int64_t max_shift = (Y > 1 && X % 16 != 0) ? 15 : 0;
+    const int64_t max_shift = ((Y > 1 && X % 16 != 0) || shifted) ? 15 : 0;  // (shifted: a line-aligned plan's classes)
     return (X - 1 + max_shift) / w + 1;
 }
 

@@ -634,11 +634,55 @@ __device__ __forceinline__ void convert_batch(const Conv &conv, int64_t sb, int6
     }
 }
 
+// converters whose cubes a line-aligned plan (PlanDev::shift_classes, atl_agg_create_aligned) may re-address: `S` is
+// nothing but the distance between two slots, and a slot index means nothing else (no per-time tables, no day groups)
+template <class Conv, class = void>
+struct conv_shift_ok : std::false_type {};
+template <class Conv>
+struct conv_shift_ok<Conv, std::void_t<decltype(Conv::kShiftOk)>> : std::integral_constant<bool, Conv::kShiftOk> {};
+
+// The lane's cells of a unit.  Ordinary plans: the tile's own (tile_lane_cells).  Line-aligned plans: the tile belongs
+// to alignment class r, whose tiling has its rows on the line grid of c + o_r; its VIRTUAL slot i is real slot r + p i,
+// and with the converter's slot stride set to p S the element (virtual slot i, cell c) sits at i (p S) + [r S + c]:
+// `ld` is that bracket for the lane's first cell - 16-byte aligned per lane, 128-byte aligned per tile row, in every slot.
+struct UnitCells {
+    int64_t c0;        // the lane's first cell (cell_setup; the static per-cell fields)
+    bool v0, v1;
+    int64_t ld0, ld1;  // what load / key_load / rest_load index the cubes with (safe: loads never branch)
+    int64_t slots;     // slots of this unit's class (ordinary plans: no limit)
+};
+__device__ __forceinline__ UnitCells unit_cells(const PlanDev &plan, int32_t seg, int lane, int64_t S, int64_t n_real) {
+    UnitCells u;
+    if (plan.shift_classes == 0) {
+        const TileLane tl = tile_lane_cells(plan.X, plan.Y, plan.ntx, plan.w2_log2, seg, lane);
+        u.c0 = tl.c0;
+        u.v0 = tl.v0;
+        u.v1 = tl.v1;
+        u.ld0 = u.v0 ? u.c0 : 0;
+        u.ld1 = u.v1 ? u.c0 + 1 : (S > 1 ? 1 : 0);
+        u.slots = int64_t(1) << 62;
+        return u;
+    }
+    const int32_t r = seg / plan.shift_tiles;  // wave-uniform
+    const int64_t lo = int64_t(r) * S;         // real slot r starts here
+    const int64_t o = lo & 15;
+    const TileLane tl = tile_lane_cells(plan.X, plan.Y, plan.ntx, plan.w2_log2, seg - r * plan.shift_tiles, lane, o);
+    u.c0 = tl.c0;
+    u.v0 = tl.v0;
+    u.v1 = tl.v1;
+    // (a pair with one cell outside the slot reads the neighbouring slot's edge cell - class 0 is unshifted, so never
+    //  before the cube; past the last slot only where the unshifted kernels would as well: vec_ok)
+    u.ld0 = (u.v0 || u.v1) ? lo + u.c0 : lo - o;
+    u.ld1 = u.ld0 + 1;
+    u.slots = (n_real - r + plan.shift_classes - 1) / plan.shift_classes;
+    return u;
+}
+
 template <class Conv, bool VEC, bool DENSE>
 __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2 ? 2 : min_waves<Conv>()) void k_fused_segred(Conv conv, PlanDev plan, int64_t slot0,
                                                       int64_t n_slots, int64_t S, int32_t chunk_slots,
                                                       int64_t n_units, double *__restrict__ partials,
-                                                      int64_t ldp, int32_t conv_lds_doubles) {
+                                                      int64_t ldp, int32_t conv_lds_doubles, int64_t n_real) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     conv.block_init(lds);
     __syncthreads();
@@ -674,11 +718,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
     if (group >= n_groups || seg64 >= plan.n_segs || chunk * chunk_slots >= n_slots) return;
     const int32_t seg = int32_t(seg64);
 #endif
-    // tile coordinates -> the lane's two adjacent cells (atl_internal.h: tile_lane_cells)
-    const TileLane tl = tile_lane_cells(plan.X, plan.Y, plan.ntx, plan.w2_log2, seg, lane);
-    const int64_t c0 = tl.c0;
-    const bool v0 = tl.v0, v1 = tl.v1;
-    const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);  // safe indices: loads never branch
+    // tile coordinates -> the lane's two adjacent cells (atl_internal.h: tile_lane_cells; unit_cells above)
+    const UnitCells uc = unit_cells(plan, seg, lane, S, n_real);
+    const int64_t c0 = uc.c0;
+    const bool v0 = uc.v0, v1 = uc.v1;
+    const int64_t s0c = uc.ld0, s1c = uc.ld1;  // safe indices: loads never branch
     const int32_t p0 = plan.seg_ptr[seg], p1 = plan.seg_ptr[seg + 1];
     if (p0 == p1) return;  // no shape touches this tile: nothing to read
     // dense tile: its first 16 G rows go through the matrix cores (reduce_dense_mfma), the LDS value rows sit behind
@@ -707,7 +751,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
     }
     // this launch covers output slots [slot0, slot0 + n_slots); partials are window-relative
     const int64_t sbeg = slot0 + chunk * chunk_slots;
-    const int64_t send = min(sbeg + int64_t(chunk_slots), slot0 + n_slots);
+    const int64_t send = min(min(sbeg + int64_t(chunk_slots), slot0 + n_slots), uc.slots);
+    if (sbeg >= send) return;  // (a class of a line-aligned plan one slot shorter than the longest)
     partials -= slot0;
     typename Conv::Carry carry = carry_init<typename Conv::Carry>();
     if constexpr (DENSE) {
@@ -816,7 +861,7 @@ template <class Conv, bool VEC, bool DENSE>
 __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 2 : min_waves<Conv>()) void k_fused_segred_night(Conv conv, PlanDev plan, int64_t slot0,
                                                       int64_t n_slots, int64_t S, int32_t chunk_slots,
                                                       int64_t n_units, double *__restrict__ partials,
-                                                      int64_t ldp, int32_t conv_lds_doubles) {
+                                                      int64_t ldp, int32_t conv_lds_doubles, int64_t n_real) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     conv.block_init(lds);
     __syncthreads();
@@ -829,10 +874,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 2 : min_waves<Conv>())
     if (unit >= n_units) return;
     const int32_t seg = int32_t(unit % plan.n_segs);
     const int64_t chunk = unit / plan.n_segs;
-    const TileLane tl = tile_lane_cells(plan.X, plan.Y, plan.ntx, plan.w2_log2, seg, lane);
-    const int64_t c0 = tl.c0;
-    const bool v0 = tl.v0, v1 = tl.v1;
-    const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);
+    const UnitCells uc = unit_cells(plan, seg, lane, S, n_real);
+    const int64_t c0 = uc.c0;
+    const bool v0 = uc.v0, v1 = uc.v1;
+    const int64_t s0c = uc.ld0, s1c = uc.ld1;
     const int32_t p0 = plan.seg_ptr[seg], p1 = plan.seg_ptr[seg + 1];
     if (p0 == p1) return;
     const int G = DENSE ? mfma_groups(p1 - p0) : 0;
@@ -853,7 +898,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 2 : min_waves<Conv>())
         *reinterpret_cast<double2 *>(wlds + r * kSegCells + 2 * lane) = wz;
     }
     const int64_t sbeg = slot0 + chunk * chunk_slots;
-    const int64_t send = min(sbeg + int64_t(chunk_slots), slot0 + n_slots);
+    const int64_t send = min(min(sbeg + int64_t(chunk_slots), slot0 + n_slots), uc.slots);
+    if (sbeg >= send) return;
     partials -= slot0;
     double2 key[kBatch];
 #pragma unroll
@@ -917,6 +963,21 @@ __global__ __launch_bounds__(256) void k_combine(PlanDev plan, const double *__r
     const int32_t q0 = plan.shape_ptr[n], q1 = plan.shape_ptr[n + 1];
     for (int32_t q = q0; q < q1; ++q) s += partials[int64_t(plan.shape_prow[q]) * ldp + t];
     if (plan.row_poison[n]) s = __builtin_nan("");
+    out[n * ld_out + t] = s;
+}
+
+// ... of a line-aligned plan: stacked row r N + n, virtual slot w0 + t  ->  out[n, r + p (w0 + t)]
+__global__ __launch_bounds__(256) void k_combine_aligned(PlanDev plan, const double *__restrict__ partials, int64_t ldp, int64_t w0, int64_t wn,
+                                                         int64_t n_real, double *__restrict__ out, int64_t ld_out) {
+    const int64_t tv = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t row = blockIdx.y;
+    const int64_t r = row / plan.shift_rows, n = row - r * plan.shift_rows;
+    const int64_t t = r + int64_t(plan.shift_classes) * (w0 + tv);
+    if (tv >= wn || t >= n_real) return;
+    double s = 0.0;
+    const int32_t q0 = plan.shape_ptr[row], q1 = plan.shape_ptr[row + 1];
+    for (int32_t q = q0; q < q1; ++q) s += partials[int64_t(plan.shape_prow[q]) * ldp + tv];
+    if (plan.row_poison[row]) s = __builtin_nan("");
     out[n * ld_out + t] = s;
 }
 
@@ -1121,8 +1182,22 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
               const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out, const char *what) {
     ATL_REQUIRE(agg, "%s: agg is NULL", what);
     ATL_REQUIRE(agg->ctx == ctx, "%s: aggregation plan belongs to another context", what);
+    const bool aligned = agg->dev.shift_classes > 0;  // line-aligned plan (atl_agg_create_aligned)
     ATL_REQUIRE(agg->dev.n_cells == S, "%s: matrix has %lld columns but the cutout has %lld cells", what,
                 (long long)agg->dev.n_cells, (long long)S);
+    if (aligned) {
+        ATL_REQUIRE(conv_shift_ok<Conv>::value, "%s: this conversion cannot run on a line-aligned plan (atl_agg_create_aligned)", what);
+        ATL_REQUIRE(slot_stride_of(ctx, S) == S, "%s: a line-aligned plan is for contiguous cubes (slot stride %lld, %lld cells)", what,
+                    (long long)slot_stride_of(ctx, S), (long long)S);
+        ATL_REQUIRE(vec, "%s: a line-aligned plan needs the vectorised kernels (8-byte aligned cubes that do not end on a page boundary)", what);
+        if constexpr (conv_shift_ok<Conv>::value) {
+            if (conv.S != agg->dev.shift_classes * S) {  // the converter's slot stride: p slots of the contiguous cubes
+                Conv strided = conv;
+                strided.S = agg->dev.shift_classes * S;
+                return run_fused(ctx, strided, vec, lds_bytes, n_slots, S, agg, time_agg, d_out, ld_out, what);
+            }
+        }
+    }
     ATL_REQUIRE(time_agg >= ATL_TIME_NONE && time_agg <= ATL_TIME_SUM_COUNT, "%s: bad time_agg %d", what, time_agg);
     ATL_REQUIRE(d_out, "%s: d_out is NULL", what);
     ATL_REQUIRE(time_agg != ATL_TIME_NONE || ld_out >= n_slots, "%s: ld_out %lld < %lld", what,
@@ -1131,8 +1206,11 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
                 (long long)slot_stride_of(ctx, S), (long long)S);
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     const PlanDev &plan = agg->dev;
-    const int64_t N = plan.n_rows;
+    const int64_t N = aligned ? plan.shift_rows : plan.n_rows;
     if (N == 0) return ATL_OK;
+    // line-aligned plan: the kernels walk VIRTUAL slots (slot i of class r = real slot r + p i); k_combine_aligned puts them back
+    const int64_t n_real = n_slots;
+    if (aligned) n_slots = (n_slots + plan.shift_classes - 1) / plan.shift_classes;
     // (a lane's cell pair may straddle two grid rows - odd row lengths: cells are owned by flat index, tile_lane_cells)
     constexpr bool kScalarToo = !conv_vec_only<Conv>::value;  // the unvectorised instantiations exist
     if (!kScalarToo && !vec) return kNeedScalar;
@@ -1145,7 +1223,7 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
     const int64_t budget_slots = budget / std::max<int64_t>(P, 1);
     if (window > budget_slots) window = std::max<int64_t>(64, budget_slots / 64 * 64);
     const int64_t ldp = int64_t(align_up(size_t(window), 8));
-    const int64_t lds_series = int64_t(align_up(size_t(std::max<int64_t>(n_slots, 1)), 8));
+    const int64_t lds_series = int64_t(align_up(size_t(std::max<int64_t>(n_real, 1)), 8));
     size_t bytes_partials = align_up(size_t(std::max<int64_t>(P, 1) * ldp) * sizeof(double), 256);
     size_t bytes_series = time_agg == ATL_TIME_NONE ? 0 : align_up(size_t(N * lds_series) * sizeof(double), 256);
     void *scr = nullptr;
@@ -1190,7 +1268,7 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
                             what, nb, kWavesPerBlock, lds_sz, grid.x, int(chunk_slots));
                 }
                 hipLaunchKernelGGL(kern, grid, dim3(kWavesPerBlock * 64), lds_sz, ctx->stream, conv, plan, w0, wn, S,
-                                   chunk_slots, n_units, partials, ldp, conv_lds_doubles);
+                                   chunk_slots, n_units, partials, ldp, conv_lds_doubles, n_real);
             };
             // (converters that park a batch's values in LDS - kStageValues - take the early-out kernels' layout: two cached
             // weight rows + eight value rows per wave, 40 KiB per workgroup, four workgroups per CU)
@@ -1213,14 +1291,18 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
             }
             if ((rc = check_launch(what))) return rc;
         }
-        const dim3 grid(unsigned((wn + 255) / 256), unsigned(N));
-        hipLaunchKernelGGL(k_combine, grid, dim3(256), 0, ctx->stream, plan, partials, ldp, wn, series + w0,
-                           ld_series);
+        if (aligned) {
+            hipLaunchKernelGGL(k_combine_aligned, dim3(unsigned((wn + 255) / 256), unsigned(plan.n_rows)), dim3(256), 0, ctx->stream, plan, partials, ldp,
+                               w0, wn, n_real, series, ld_series);
+        } else {
+            const dim3 grid(unsigned((wn + 255) / 256), unsigned(N));
+            hipLaunchKernelGGL(k_combine, grid, dim3(256), 0, ctx->stream, plan, partials, ldp, wn, series + w0, ld_series);
+        }
         if ((rc = check_launch(what))) return rc;
     }
     if (time_agg != ATL_TIME_NONE) {
         hipLaunchKernelGGL(k_rows_timered, dim3(unsigned(N)), dim3(256), 0, ctx->stream, series, ld_series,
-                           n_slots, time_agg == ATL_TIME_MEAN ? 1 : time_agg == ATL_TIME_SUM_COUNT ? 2 : 0, d_out);
+                           n_real, time_agg == ATL_TIME_MEAN ? 1 : time_agg == ATL_TIME_SUM_COUNT ? 2 : 0, d_out);
         if ((rc = check_launch(what))) return rc;
     }
     return ATL_OK;

@@ -98,21 +98,36 @@ namespace atl {
 struct Layout {
     int64_t X, Y;
     int w2_log2;  // log2 of the lanes per tile row
+    // line-aligned plans (PlanDev::shift_classes): `classes` tilings of the grid; the builder sees the block-diagonal stack
+    // of the matrix, class r's copy in columns [r * S, (r + 1) * S) with S = X * Y
+    int classes = 0;
 };
+inline int64_t class_origin(const Layout &L, int64_t r) { return (r * L.X * L.Y) & 15; }
+inline int64_t layout_columns(const Layout &L) { return tile_columns(L.X, L.Y, L.w2_log2, L.classes > 0); }
+inline int64_t layout_tiles_per_class(const Layout &L) {
+    const int h = kLanes >> L.w2_log2;
+    return layout_columns(L) * ((L.Y + h - 1) / h);
+}
 
 // inverse of tile_lane_cells (atl_internal.h): the tile that owns `cell` and the cell's slot
 // (2 * lane + {0, 1}) inside it
 int64_t tile_of_cell(const Layout &L, int64_t cell, int32_t *local) {
     const int w = 2 << L.w2_log2, h = kLanes >> L.w2_log2;
+    int64_t r = 0, o = 0;
+    if (L.classes > 0) {  // stacked column -> (class, the grid's own cell)
+        r = cell / (L.X * L.Y);
+        cell -= r * L.X * L.Y;
+        o = class_origin(L, r);
+    }
     // the grid row whose flat range [lo(y), lo(y+1)) holds the cell: its own row, or - when the line
     // it lies in is shared with the start of later rows - the last row that starts in that line
     int64_t y = cell / L.X;
-    while (y + 1 < L.Y && cell >= tile_row_lo(L.X, y + 1)) ++y;
-    const int64_t p = cell - tile_row_lo(L.X, y);
+    while (y + 1 < L.Y && cell >= tile_row_lo(L.X, y + 1, o)) ++y;
+    const int64_t p = cell - tile_row_lo(L.X, y, o);
     const int64_t tx = p / w, ty = y / h;
     const int lane = int((y % h) << L.w2_log2) + int((p % w) >> 1);
     *local = lane * 2 + int(p & 1);
-    return ty * tile_columns(L.X, L.Y, L.w2_log2) + tx;
+    return r * layout_tiles_per_class(L) + ty * layout_columns(L) + tx;
 }
 }  // namespace atl
 
@@ -528,15 +543,18 @@ struct PlanHost {
     std::vector<int64_t> seg_wm;
 };
 
+// classes > 0: a line-aligned plan - the CSR is the block-diagonal stack of `classes` copies of the matrix (n_rows and
+// n_cells are the stacked counts), tiled class by class (Layout::classes)
 static int build_plan(int64_t n_rows, int64_t n_cells, int64_t row_len, int64_t slot_stride, const int64_t *h_indptr, const int32_t *h_indices,
-                      const double *h_data, PlanHost *plan) {
+                      const double *h_data, PlanHost *plan, int classes = 0) {
     ATL_REQUIRE(n_rows >= 0 && n_cells >= 0, "atl_agg_create: negative shape (%lld, %lld)",
                 (long long)n_rows, (long long)n_cells);
     ATL_REQUIRE(n_rows < 65536, "atl_agg_create: at most 65535 rows (shapes) are supported");
     ATL_REQUIRE(n_cells < (int64_t(1) << 31), "atl_agg_create: matrix shape too large");
-    ATL_REQUIRE(row_len >= 0 && (row_len == 0 || n_cells % row_len == 0),
+    const int64_t grid_cells = classes > 0 ? n_cells / classes : n_cells;  // the grid's own cell count
+    ATL_REQUIRE(row_len >= 0 && (row_len == 0 || grid_cells % row_len == 0),
                 "atl_agg_create: row_len %lld does not divide the %lld cells", (long long)row_len,
-                (long long)n_cells);
+                (long long)grid_cells);
     ATL_REQUIRE(h_indptr, "atl_agg_create: indptr is NULL");
     ATL_REQUIRE(h_indptr[0] == 0, "atl_agg_create: indptr[0] must be 0");
     const int64_t nnz = h_indptr[n_rows];
@@ -574,20 +592,20 @@ static int build_plan(int64_t n_rows, int64_t n_cells, int64_t row_len, int64_t 
     }
 
     // ---- choose the tile shape --------------------------------------------------------------
-    auto ntx_of = [](const Layout &L) { return tile_columns(L.X, L.Y, L.w2_log2); };
+    auto ntx_of = [](const Layout &L) { return layout_columns(L); };
     auto tile_of = [](const Layout &L, int64_t cell, int32_t *local) { return tile_of_cell(L, cell, local); };
     std::vector<Layout> cands;
-    cands.push_back({n_cells > 0 ? n_cells : 1, 1, 6});  // flat 128 x 1 over the stacked axis
-    if (row_len > 0 && n_cells / row_len > 1) {
-        const int64_t Yg = n_cells / row_len;
-        for (int l2 : {5, 4, 3}) cands.push_back({row_len, Yg, l2});  // 64x2, 32x4, 16x8
+    cands.push_back({grid_cells > 0 ? grid_cells : 1, 1, 6, classes});  // flat 128 x 1 over the stacked axis
+    if (row_len > 0 && grid_cells / row_len > 1) {
+        const int64_t Yg = grid_cells / row_len;
+        for (int l2 : {5, 4, 3}) cands.push_back({row_len, Yg, l2, classes});  // 64x2, 32x4, 16x8
     }
     if (const char *env = getenv("ATLITE_HIP_TILE")) {  // experiments: "16x8", "32x4", "64x2", "128x1", "flat"
         int w = 0, h = 0;
         if (row_len > 0 && sscanf(env, "%dx%d", &w, &h) == 2 && w * h == kSegCells && w >= 16) {
             int l2 = 0;
             while ((2 << l2) < w) ++l2;
-            cands.assign(1, Layout{row_len, n_cells / row_len, l2});
+            cands.assign(1, Layout{row_len, grid_cells / row_len, l2, classes});
         } else if (strcmp(env, "flat") == 0) {
             cands.resize(1);
         }
@@ -599,10 +617,7 @@ static int build_plan(int64_t n_rows, int64_t n_cells, int64_t row_len, int64_t 
     for (const Raw &e : raw) row_begin[size_t(e.row) + 1]++;
     for (int64_t r = 0; r < n_rows; ++r) row_begin[r + 1] += row_begin[r];
 
-    auto n_tiles_of = [&](const Layout &L) {
-        const int h = kLanes >> L.w2_log2;
-        return n_cells > 0 ? ntx_of(L) * ((L.Y + h - 1) / h) : int64_t(0);
-    };
+    auto n_tiles_of = [&](const Layout &L) { return n_cells > 0 ? layout_tiles_per_class(L) * std::max(1, L.classes) : int64_t(0); };
     size_t best = 0;
     if (cands.size() > 1) {
         double best_cost = 0;
@@ -645,7 +660,7 @@ static int build_plan(int64_t n_rows, int64_t n_cells, int64_t row_len, int64_t 
                 g = b;
                 b = r;
             }
-            const double f_mis = (stride % 16 == 0) ? 0.0 : 1.0 - double(g) / 16.0;
+            const double f_mis = (stride % 16 == 0 || classes > 0) ? 0.0 : 1.0 - double(g) / 16.0;  // (line-aligned plans: no tile row off the line grid)
             const int w = 2 << cands[c].w2_log2;
             const double cost = (40.0 * double(tiles) * (1.0 + f_mis * 16.0 / w) + double(P)) * row_eff[cands[c].w2_log2];
             if (c == 0 || cost < best_cost) {
@@ -655,9 +670,8 @@ static int build_plan(int64_t n_rows, int64_t n_cells, int64_t row_len, int64_t 
         }
     }
     const Layout L = cands[best];
-    const int th = kLanes >> L.w2_log2;
-    const int64_t ntx = ntx_of(L), nty = (L.Y + th - 1) / th;
-    const int64_t n_segs = n_cells > 0 ? ntx * nty : 0;
+    const int64_t ntx = ntx_of(L);
+    const int64_t n_segs = n_tiles_of(L);
 
     // ---- partial rows: one per (tile, row) pair, ordered by tile then row ------------------------
     // pass 1: per row, the tiles it touches (first-touch order), counted per tile
@@ -770,21 +784,8 @@ static int build_plan(int64_t n_rows, int64_t n_cells, int64_t row_len, int64_t 
     return ATL_OK;
 }
 
-int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_len,
-                   const int64_t *h_indptr, const int32_t *h_indices, const double *h_data,
-                   atl_agg **out) {
-    ATL_REQUIRE(ctx && out, "atl_agg_create: bad argument");
-    *out = nullptr;
-    PlanHost ph;
-    {
-        const int brc = build_plan(n_rows, n_cells, row_len, ctx->slot_stride, h_indptr, h_indices, h_data, &ph);
-        if (brc) return brc;
-    }
-    const std::vector<int32_t> &seg_ptr = ph.seg_ptr, &shape_ptr = ph.shape_ptr, &shape_prow = ph.shape_prow;
-    const std::vector<double> &prow_w = ph.prow_w, &prow_wm = ph.prow_wm;
-    const std::vector<uint8_t> &poison = ph.poison;
-    const std::vector<uint64_t> &seg_mask = ph.seg_mask;
-    const std::vector<int64_t> &seg_wm = ph.seg_wm;
+// the device copy of a host plan
+static int plan_to_device(atl_ctx *ctx, const PlanHost &ph, int64_t n_rows, int64_t n_cells, atl_agg **out) {
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     atl_agg *a = new atl_agg();
     a->ctx = ctx;
@@ -797,13 +798,13 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_le
     a->dev.n_segs = int32_t(ph.n_segs);
     a->dev.n_prows = int32_t(ph.P);
     int rc = ATL_OK;
-    if ((rc = to_device(a, seg_ptr, &a->dev.seg_ptr)) ||
-        (rc = to_device(a, prow_w, &a->dev.prow_w)) ||
-        (rc = to_device(a, shape_ptr, &a->dev.shape_ptr)) ||
-        (rc = to_device(a, shape_prow, &a->dev.shape_prow)) ||
-        (rc = to_device(a, poison, &a->dev.row_poison)) ||
-        (rc = to_device(a, seg_mask, &a->dev.seg_mask)) ||
-        (!prow_wm.empty() && ((rc = to_device(a, seg_wm, &a->dev.seg_wm)) || (rc = to_device(a, prow_wm, &a->dev.prow_wm))))) {
+    if ((rc = to_device(a, ph.seg_ptr, &a->dev.seg_ptr)) ||
+        (rc = to_device(a, ph.prow_w, &a->dev.prow_w)) ||
+        (rc = to_device(a, ph.shape_ptr, &a->dev.shape_ptr)) ||
+        (rc = to_device(a, ph.shape_prow, &a->dev.shape_prow)) ||
+        (rc = to_device(a, ph.poison, &a->dev.row_poison)) ||
+        (rc = to_device(a, ph.seg_mask, &a->dev.seg_mask)) ||
+        (!ph.prow_wm.empty() && ((rc = to_device(a, ph.seg_wm, &a->dev.seg_wm)) || (rc = to_device(a, ph.prow_wm, &a->dev.prow_wm))))) {
         atl_agg_destroy(a);
         return rc;
     }
@@ -811,6 +812,78 @@ int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_le
     return ATL_OK;
 }
 
+// alignment classes of contiguous cubes with n_cells cells per slot: 16 / gcd(n_cells, 16)
+static int64_t alignment_classes(int64_t n_cells) {
+    int64_t g = n_cells % 16, b = 16;
+    while (g) {
+        const int64_t t = b % g;
+        b = g;
+        g = t;
+    }
+    return 16 / b;
+}
+
+// block-diagonal stack of p copies of a CSR matrix (copy r in columns [r S, (r + 1) S)): what build_plan tiles class by class
+static int stack_classes(int64_t p, int64_t n_rows, int64_t n_cells, const int64_t *h_indptr, const int32_t *h_indices, const double *h_data,
+                         std::vector<int64_t> *indptr, std::vector<int32_t> *indices, std::vector<double> *data) {
+    ATL_REQUIRE(h_indptr && h_indptr[0] == 0, "atl_agg_create_aligned: indptr is NULL or does not start at 0");
+    for (int64_t r = 0; r < n_rows; ++r)
+        ATL_REQUIRE(h_indptr[r + 1] >= h_indptr[r], "atl_agg_create_aligned: indptr not monotone at row %lld", (long long)r);
+    const int64_t nnz = h_indptr[n_rows];
+    ATL_REQUIRE(nnz == 0 || (h_indices && h_data), "atl_agg_create_aligned: indices/data missing");
+    ATL_REQUIRE(p * n_rows < 65536, "atl_agg_create_aligned: %lld rows x %lld alignment classes exceed 65535 plan rows", (long long)n_rows,
+                (long long)p);
+    ATL_REQUIRE(p * n_cells < (int64_t(1) << 31) && p * nnz < (int64_t(1) << 40), "atl_agg_create_aligned: matrix too large");
+    indptr->assign(size_t(p * n_rows) + 1, 0);
+    indices->resize(size_t(p * nnz));
+    data->resize(size_t(p * nnz));
+    for (int64_t r = 0; r < p; ++r)
+        for (int64_t n = 0; n < n_rows; ++n) {
+            (*indptr)[size_t(r * n_rows + n) + 1] = r * nnz + h_indptr[n + 1];
+            for (int64_t k = h_indptr[n]; k < h_indptr[n + 1]; ++k) {
+                ATL_REQUIRE(h_indices[k] >= 0 && h_indices[k] < n_cells, "atl_agg_create_aligned: column index %lld out of range [0,%lld)",
+                            (long long)h_indices[k], (long long)n_cells);
+                (*indices)[size_t(r * nnz + k)] = int32_t(r * n_cells + h_indices[k]);
+                (*data)[size_t(r * nnz + k)] = h_data[k];
+            }
+        }
+    return ATL_OK;
+}
+
+int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_len,
+                   const int64_t *h_indptr, const int32_t *h_indices, const double *h_data,
+                   atl_agg **out) {
+    ATL_REQUIRE(ctx && out, "atl_agg_create: bad argument");
+    *out = nullptr;
+    PlanHost ph;
+    {
+        const int brc = build_plan(n_rows, n_cells, row_len, ctx->slot_stride, h_indptr, h_indices, h_data, &ph);
+        if (brc) return brc;
+    }
+    return plan_to_device(ctx, ph, n_rows, n_cells, out);
+}
+
+int atl_agg_create_aligned(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_len, const int64_t *h_indptr, const int32_t *h_indices,
+                           const double *h_data, atl_agg **out) {
+    ATL_REQUIRE(ctx && out, "atl_agg_create_aligned: bad argument");
+    *out = nullptr;
+    ATL_REQUIRE(n_rows >= 0 && n_cells >= 16, "atl_agg_create_aligned: needs at least 16 cells (got %lld)", (long long)n_cells);
+    ATL_REQUIRE(n_cells % 16 != 0, "atl_agg_create_aligned: the slots of %lld cells start on 128-byte lines already (use atl_agg_create)",
+                (long long)n_cells);
+    const int64_t p = alignment_classes(n_cells);
+    std::vector<int64_t> indptr;
+    std::vector<int32_t> indices;
+    std::vector<double> data;
+    int rc = stack_classes(p, n_rows, n_cells, h_indptr, h_indices, h_data, &indptr, &indices, &data);
+    if (rc) return rc;
+    PlanHost ph;
+    if ((rc = build_plan(p * n_rows, p * n_cells, row_len, 0, indptr.data(), indices.data(), data.data(), &ph, int(p)))) return rc;
+    if ((rc = plan_to_device(ctx, ph, p * n_rows, n_cells, out))) return rc;
+    (*out)->dev.shift_classes = int32_t(p);
+    (*out)->dev.shift_rows = int32_t(n_rows);
+    (*out)->dev.shift_tiles = int32_t(ph.n_segs / p);
+    return ATL_OK;
+}
 
 int atl_agg_check_host(int64_t n_rows, int64_t n_cells, int64_t row_len, const int64_t *h_indptr, const int32_t *h_indices,
                        const double *h_data, int64_t *n_partial_rows, int64_t *n_dense_tiles, int64_t *n_errors) {
@@ -1179,6 +1252,54 @@ int atl_agg_selfcheck(int64_t n_cells, int64_t row_len, int tile_w, int64_t *n_t
     return ATL_OK;
 }
 
+int atl_agg_selfcheck_aligned(int64_t n_cells, int64_t row_len, int tile_w, int64_t *n_classes, int64_t *n_tiles, int64_t *n_owned,
+                              int64_t *n_errors) {
+    ATL_REQUIRE(n_cells >= 16 && n_cells % 16 != 0 && n_cells < (int64_t(1) << 27) && n_classes && n_tiles && n_owned && n_errors,
+                "atl_agg_selfcheck_aligned: bad argument");
+    ATL_REQUIRE(tile_w == 16 || tile_w == 32 || tile_w == 64 || tile_w == 128, "atl_agg_selfcheck_aligned: tile_w must be 16, 32, 64 or 128");
+    ATL_REQUIRE(row_len >= 0 && (row_len == 0 || n_cells % row_len == 0), "atl_agg_selfcheck_aligned: row_len does not divide n_cells");
+    int l2 = 0;
+    while ((2 << l2) < tile_w) ++l2;
+    const int64_t p = alignment_classes(n_cells);
+    Layout L{row_len > 0 ? row_len : n_cells, row_len > 0 ? n_cells / row_len : 1, l2, int(p)};
+    const int64_t ntx = layout_columns(L), tpc = layout_tiles_per_class(L);
+    *n_classes = p;
+    *n_tiles = p * tpc;
+    *n_owned = 0;
+    *n_errors = 0;
+    std::vector<uint8_t> seen;
+    for (int64_t r = 0; r < p; ++r) {
+        const int64_t o = class_origin(L, r);
+        if (o != ((r * n_cells) & 15)) ++*n_errors;
+        seen.assign(static_cast<size_t>(n_cells), 0);
+        for (int64_t seg = 0; seg < tpc; ++seg) {
+            for (int lane = 0; lane < kLanes; ++lane) {
+                const TileLane t = tile_lane_cells(L.X, L.Y, int32_t(ntx), L.w2_log2, int32_t(seg), lane, o);
+                // the lane's 16-byte load sits at cell r * S + c0 of a cube whose slots are p * S cells apart: aligned in every
+                // slot of the class; the first lane of a tile row starts a 128-byte line
+                if ((t.v0 || t.v1) && ((r * n_cells + t.c0) & 1)) ++*n_errors;
+                if ((t.v0 || t.v1) && (lane & ((1 << L.w2_log2) - 1)) == 0 && ((r * n_cells + t.c0) & 15)) ++*n_errors;
+                for (int k = 0; k < 2; ++k) {
+                    if (!(k ? t.v1 : t.v0)) continue;
+                    const int64_t c = t.c0 + k;
+                    if (c < 0 || c >= n_cells) {
+                        ++*n_errors;  // the kernel would read outside the slot
+                        continue;
+                    }
+                    ++*n_owned;
+                    if (seen[size_t(c)]++) ++*n_errors;  // owned twice within the class
+                    int32_t loc = -1;
+                    const int64_t back = tile_of_cell(L, r * n_cells + c, &loc);  // the stacked column build_plan sees
+                    if (back != r * tpc + seg || loc != 2 * lane + k) ++*n_errors;  // plan builder and kernel disagree
+                }
+            }
+        }
+        for (int64_t c = 0; c < n_cells; ++c)
+            if (!seen[size_t(c)]) ++*n_errors;  // never owned
+    }
+    return ATL_OK;
+}
+
 int atl_agg_destroy(atl_agg *agg) {
     if (!agg) return ATL_OK;
     if (agg->ctx) {
@@ -1193,7 +1314,8 @@ int atl_agg_destroy(atl_agg *agg) {
 int atl_agg_info(const atl_agg *agg, int64_t *n_rows, int64_t *n_cells, int64_t *n_segments,
                  int64_t *n_partial_rows, int32_t *tile_w, int32_t *tile_h) {
     ATL_REQUIRE(agg, "atl_agg_info: agg is NULL");
-    if (n_rows) *n_rows = agg->dev.n_rows;
+    const bool aligned = agg->dev.shift_classes > 0;  // atl_agg_create_aligned: the matrix's own shape, not the stacked one
+    if (n_rows) *n_rows = aligned ? agg->dev.shift_rows : agg->dev.n_rows;
     if (n_cells) *n_cells = agg->dev.n_cells;
     if (n_segments) *n_segments = agg->dev.n_segs;
     if (n_partial_rows) *n_partial_rows = agg->dev.n_prows;

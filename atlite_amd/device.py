@@ -199,18 +199,26 @@ class SlotPool:
 class AggPlan:
     """Indicator matrix (scipy CSR, N x S) preprocessed into the segment-local device layout."""
 
-    def __init__(self, ctx, matrix, row_len=None, ld=None):
+    def __init__(self, ctx, matrix, row_len=None, ld=None, aligned=False):
         import scipy.sparse as sp
 
         m = sp.csr_matrix(matrix)
         self.ctx = ctx
         self.shape = m.shape
+        self.aligned = bool(aligned)
         # the tile shape depends on whether the slots of the cubes the plan will meet start on 128-byte lines
         indptr = np.ascontiguousarray(m.indptr, dtype=np.int64)
         indices = np.ascontiguousarray(m.indices, dtype=np.int32)
         data = np.ascontiguousarray(m.data, dtype=np.float64)
         h = C.c_void_p()
         self.handle = None
+        if aligned:  # line-aligned plan for contiguous cubes whose slots do not start on 128-byte lines (atl_agg_create_aligned)
+            check(ctx.lib.atl_agg_create_aligned(ctx.handle, m.shape[0], m.shape[1],
+                                                 int(row_len) if row_len and m.shape[1] % int(row_len) == 0 else 0, indptr.ctypes.data,
+                                                 indices.ctypes.data if indices.size else None,
+                                                 data.ctypes.data if data.size else None, C.byref(h)))
+            self.handle = h
+            return
         check(ctx.lib.atl_set_slot_stride(ctx.handle, int(ld) if ld and int(ld) != m.shape[1] else 0))
         try:  # the stride is call-scoped: a rejected matrix must not leave it set
             check(
@@ -412,15 +420,16 @@ class Context:
         return ms.value
 
     # -- plans ----------------------------------------------------------------------------
-    def plan(self, matrix, row_len=None, cache=True, ld=None):
+    def plan(self, matrix, row_len=None, cache=True, ld=None, aligned=False):
         """
         Aggregation plan of a (N x S) matrix; row_len = X of the (Y, X) grid lets the plan use compact
         2-d cell tiles.  Plans are cached per context by matrix content (8 most recent), so repeated
         conversions over the same shapes skip the host-side preprocessing; cached plans are owned by
-        the context (do not close them).
+        the context (do not close them).  ``aligned=True``: the line-aligned plan for CONTIGUOUS cubes with
+        S % 16 != 0 (``atl_agg_create_aligned``: pv with stored solar angles, wind, runoff, temperatures, spmm).
         """
         if not cache:
-            return AggPlan(self, matrix, row_len=row_len, ld=ld)
+            return AggPlan(self, matrix, row_len=row_len, ld=ld, aligned=aligned)
         import scipy.sparse as sp
 
         m = matrix if sp.isspmatrix_csr(matrix) else sp.csr_matrix(matrix)
@@ -438,12 +447,12 @@ class Context:
                 h.update(np.ascontiguousarray(a).view(np.uint8))
             digest = h.hexdigest()
         key = (m.shape, int(row_len or 0), m.indptr.dtype.str, m.indices.dtype.str, digest,
-               os.environ.get("ATLITE_HIP_TILE", ""), int(ld or 0))
+               os.environ.get("ATLITE_HIP_TILE", ""), int(ld or 0), bool(aligned))
         cache_ = self.__dict__.setdefault("_plan_cache", {})
         if key in cache_:
             cache_[key] = cache_.pop(key)  # most recently used last
             return cache_[key]
-        plan = AggPlan(self, m, row_len=row_len, ld=ld)
+        plan = AggPlan(self, m, row_len=row_len, ld=ld, aligned=aligned)
         cache_[key] = plan
         while len(cache_) > 8:
             cache_.pop(next(iter(cache_))).close()

@@ -143,6 +143,18 @@ int atl_kernel_times(atl_ctx *ctx, float *ms, int64_t cap, int64_t *n_out);
 int atl_agg_create(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_len,
                    const int64_t *h_indptr, const int32_t *h_indices, const double *h_data,
                    atl_agg **out);
+/* Line-aligned plan for CONTIGUOUS (T, S) cubes whose slots do not start on 128-byte lines (S % 16 != 0 - any ERA5 cutout
+ * with integer-degree bounds that a caller holds as plain C-ordered device arrays; stack(spatial=...), convert.py:244, gives
+ * exactly this layout).  The offset of slot t inside its line, (t * S) % 16 cells, repeats every p = 16 / gcd(S, 16) slots:
+ * the plan holds p tilings of the grid (row_len as in atl_agg_create), class r's with its tile rows on the line grid of
+ * that class's slots, so that every tile row is whole lines in every slot it reads (no line is fetched by two waves, every
+ * lane's 16-byte load is aligned), and the conversions walk each class's slots t = r, r + p, ... .  Same results as atl_agg_create's plan up to the order of the
+ * partial sums.  Accepted by the *_convert_aggregate calls of the converters that index their cubes by slot * S only
+ * (pv with stored solar angles, wind, runoff, the temperature family, atl_spmm_csr) when no slot stride is set, the cubes
+ * are 8-byte aligned and the vectorised kernels apply; refused (ATL_E_ARG) otherwise.  At most 65535 / p rows.  Cubes should
+ * start on a 128-byte line to profit. */
+int atl_agg_create_aligned(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_t row_len, const int64_t *h_indptr,
+                           const int32_t *h_indices, const double *h_data, atl_agg **out);
 int atl_agg_destroy(atl_agg *agg);
 /* Host-only self check of the cell-tile geometry (no GPU needed): for a grid of n_cells cells in rows
  * of row_len (0 = one flat row) and tiles tile_w cells wide (16, 32, 64 or 128), enumerate every lane
@@ -151,6 +163,11 @@ int atl_agg_destroy(atl_agg *agg);
  * *n_errors = 0 means consistent. */
 int atl_agg_selfcheck(int64_t n_cells, int64_t row_len, int tile_w, int64_t *n_tiles, int64_t *n_owned,
                       int64_t *n_errors);
+/* ... of a line-aligned plan's tilings (atl_agg_create_aligned): every alignment class owns every cell exactly once, no lane
+ * points outside a slot, every lane's cell pair is 16-byte aligned and every tile row starts a 128-byte line in the slots
+ * of its class, and the plan builder's inverse mapping agrees. */
+int atl_agg_selfcheck_aligned(int64_t n_cells, int64_t row_len, int tile_w, int64_t *n_classes, int64_t *n_tiles,
+                              int64_t *n_owned, int64_t *n_errors);
 /* Host-only: builds the plan of a CSR matrix exactly as atl_agg_create does (no device involved) and verifies it
  * against the matrix - every entry at exactly one place of its shape's partial rows (duplicates summed, NaN weights
  * poison the row), partial rows of a shape in ascending tile order, the per-tile coverage masks, the MFMA operand

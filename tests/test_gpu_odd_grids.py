@@ -221,7 +221,7 @@ def test_slab_pipeline_pads_its_buffers_too(monkeypatch, dtype):
 def test_repack_of_caller_owned_cubes_off_the_line_grid(ctx):
     """Dataset(repack=True): (time, y, x) cubes the CALLER holds on the device, contiguous, with a cell count that is not a
     multiple of 16, are copied once into the library's padded slot-interleaved pool - later conversions read aligned
-    slots.  Same bits as the contiguous cubes give; without repack the caller's cubes are used where they lie."""
+    slots.  Same values as the contiguous cubes give; without repack the caller's cubes are used where they lie."""
     from atlite_amd import Cutout, Dataset
     from atlite_amd.device import DeviceArray
 
@@ -241,7 +241,10 @@ def test_repack_of_caller_owned_cubes_off_the_line_grid(ctx):
     cached = [c for c in packed.data._device_cache.values() if isinstance(c, DeviceArray) and c.ndim == 2]
     assert len(cached) == 7 and all(c.ld is not None and c.ld % 16 == 0 for c in cached)  # padded pool views
     assert len({c._pool for c in cached}) == 1
-    np.testing.assert_array_equal(a, b)
+    # (the caller's contiguous cubes go through the line-aligned plan since round 4: the same products, summed tile by tile
+    #  of another tiling - equal to rounding, no longer bit for bit)
+    close(a, b, atol_scale=1e-14)
+    np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-12 * np.abs(b).max())
     np.testing.assert_array_equal(packed.pv(**kw).values, b)  # second call: the resident copies
     w = packed.pv(panel="CSi", orientation={"slope": 30.0, "azimuth": 180.0}, aggregate_time="mean").values
     np.testing.assert_array_equal(w, plain.pv(panel="CSi", orientation={"slope": 30.0, "azimuth": 180.0}, aggregate_time="mean").values)

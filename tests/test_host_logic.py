@@ -229,6 +229,34 @@ def test_tile_geometry_selfcheck():
         _lib.check(lib.atl_agg_selfcheck(10, 3, 16, C.byref(nt), C.byref(no), C.byref(ne)))
 
 
+def test_aligned_tile_geometry_selfcheck():
+    """... and the tilings of a line-aligned plan (atl_agg_selfcheck_aligned): for contiguous cubes with S % 16 != 0 every
+    alignment class (16 / gcd(S, 16) of them) tiles the grid with its rows on the line grid of ITS slots - every class owns
+    every cell once, lanes load 16-byte aligned pairs, tile rows start 128-byte lines, the plan builder's inverse agrees."""
+    import ctypes as C
+    import math
+
+    from atlite_amd import _lib
+
+    lib = _lib.load()
+    grids = [(5, x) for x in range(4, 70)] + [(1, 37), (9, 3), (17, 15), (130, 31), (201, 201), (189, 157), (201, 200), (33, 250), (3, 1001)]
+    for Y, X in grids:
+        S = Y * X
+        if S % 16 == 0 or S < 16:
+            continue
+        for tw in (16, 32, 64, 128):
+            nc, nt, no, ne = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+            _lib.check(lib.atl_agg_selfcheck_aligned(S, X, tw, C.byref(nc), C.byref(nt), C.byref(no), C.byref(ne)))
+            assert nc.value == 16 // math.gcd(S, 16)
+            assert ne.value == 0 and no.value == nc.value * S, (Y, X, tw, nc.value, nt.value, no.value, ne.value)
+    for n in (17, 127, 129, 40401):  # flat strips
+        nc, nt, no, ne = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(lib.atl_agg_selfcheck_aligned(n, 0, 128, C.byref(nc), C.byref(nt), C.byref(no), C.byref(ne)))
+        assert ne.value == 0 and no.value == nc.value * n and nt.value == nc.value * ((n + 15 + 127) // 128)
+    with pytest.raises(ValueError):
+        _lib.check(lib.atl_agg_selfcheck_aligned(64, 0, 128, C.byref(nc), C.byref(nt), C.byref(no), C.byref(ne)))
+
+
 def test_streaming_sources_and_policy(monkeypatch):
     """Host-side policy of the slab pipeline (no GPU): which datasets stream, and how sources are
     normalised (fp64 as is, narrower native dtypes kept for the device decode, exotic ones widened)."""

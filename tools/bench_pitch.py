@@ -28,8 +28,8 @@ def main():
         ld = pitch_for(S)
         M = shapes_matrix(Y, X, 100)
         res = {}
-        for name, lay in (("contiguous", None), ("padded", ld)):
-            if name == "padded" and ld is None:
+        for name, lay in (("contiguous", None), ("aligned", None), ("padded", ld)):
+            if name != "contiguous" and ld is None:
                 continue
             cubes = inputs
             if lay:
@@ -38,7 +38,8 @@ def main():
                     p = ctx.empty_pitched((T, S), lay)
                     check(ctx.lib.atl_copy_2d(ctx.handle, p.ptr, lay * 8, v.ptr, S * 8, S * 8, T, 2, 0))
                     cubes[k] = p
-            plan = ctx.plan(M, row_len=X, ld=lay)
+            # "aligned": the contiguous cubes through the line-aligned plan (atl_agg_create_aligned)
+            plan = ctx.plan(M, row_len=X, aligned=True) if name == "aligned" else ctx.plan(M, row_len=X, ld=lay)
             info = plan.info()
             for skip in (False, True):
                 fn = lambda: ctx.pv(cubes, CSI, T, S, plan=plan, options=dict(night_skip=skip))  # noqa: E731
@@ -46,6 +47,8 @@ def main():
                 res[(name, skip)] = fn().numpy()
                 print(f"grid {Y} x {X} (S % 16 = {S % 16}) {name:10s} ld={lay or S} tile {info['tile_w']}x{info['tile_h']} P={info['n_partial_rows']} "
                       f"night_skip={int(skip)}: {med:.3f} ms  {T * S / (med * 1e-3):.3e} cell-steps/s", flush=True)
+            if name == "aligned":
+                continue
             fn = lambda: ctx.pv(cubes, CSI, T, S, time_agg="mean", options=dict(night_skip=True, row_len=X))  # noqa: E731
             med, mn = timed(ctx, fn, reps=6)
             res[(name, "map")] = fn().numpy()
@@ -55,6 +58,9 @@ def main():
             for key in ((False), (True), ("map")):
                 a, b = res[("contiguous", key)], res[("padded", key)]
                 print(f"   padded vs contiguous [{key}]: max rel diff {np.max(np.abs(a - b) / np.maximum(np.abs(a), 1e-300)):.2e}")
+                if ("aligned", key) in res:
+                    b = res[("aligned", key)]
+                    print(f"   aligned plan vs contiguous [{key}]: max rel diff {np.max(np.abs(a - b) / np.maximum(np.abs(a), 1e-300)):.2e}")
         del inputs
 
 
