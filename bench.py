@@ -103,7 +103,7 @@ def parse():
                          "(atl_capture_begin / atl_graph_launch)")
     ap.add_argument("--legs", default="all",
                     help="comma-separated subset of the N = 1 legs: headline,night_skip,star_polygons,api,separate_cubes,"
-                         "cpu,c3_series,c3_cf_map,c3_aggregated,c5_heat,c5_runoff,c4_full_sp (default: all)")
+                         "cpu,c3_series,c3_cf_map,c3_aggregated,c5_heat,c5_runoff,odd_caller,c4_full_sp (default: all)")
     ap.add_argument("--debug-rccl-self", action="store_true",
                     help="testing only (one GPU, one process): open a 1-rank RCCL process group and route the step "
                          "through the collective branch (async all-gather on the group's stream, placement copy)")
@@ -165,6 +165,7 @@ KERNELS = {
     "c3_aggregated": "k_fused_segred<WindConvT<1, -1>, true, false>",
     "c5_heat": "k_fused_segred<HeatConv, true, false>",
     "c5_runoff": "k_fused_segred<RunoffConv, true, false>",
+    "odd_caller": "k_fused_segred<PvConvT<false, false, false, 0, 0, 0>, true, false>",
     "c4_full_sp": "k_fused_segred<PvConvT<true, false, false, 0, 0, 0>, true, false>",
     "c4_headline": "k_fused_segred<PvConvT<true, false, false, 0, 0, 0>, true, false>",
 }
@@ -453,6 +454,31 @@ def config_legs(ctx, legs, reps, check=True):
                                                        "on the device -> host (shapes x time)")
             del ro, cut
         del d, plan
+        gc.collect()
+
+    # ---- a real-world (odd) grid held by the CALLER as contiguous cubes: ordinary plan vs line-aligned plan ----------------
+    if "odd_caller" in legs:
+        T, Y, X = 8760, 201, 201  # 50 x 50 degrees at 0.25: S % 16 = 1, every slot starts somewhere else in its 128-byte line
+        S = Y * X
+        cubes, _ = synthetic.pv_inputs(ctx, T, Y, X)  # one contiguous (T, S) allocation per variable: the caller's own layout
+        M = matrix_of(Y, X, 100)
+        params = dict(CSI, **ORI)
+        plain, aligned = ctx.plan(M, row_len=X), ctx.plan(M, row_len=X, aligned=True)
+        ms0, _r = run(lambda: ctx.pv(cubes, params, T, S, plan=plain, options=dict(night_skip=False)))
+        del _r
+        ms, res = run(lambda: ctx.pv(cubes, params, T, S, plan=aligned, options=dict(night_skip=False)))
+        par = None
+        if check:
+            sel = np.unique(np.concatenate([np.arange(0, 24), [T // 2, T // 2 + 1, T - 1]]))
+            host = {k: rows(v, sel) for k, v in cubes.items()}
+            par = close(res.numpy()[:, sel], orc.aggregate_matrix(orc.convert_pv(host, CSI, ORI), M))
+        info = aligned.info()
+        record("odd_caller", f"pv {T}x{Y}x{X} (S % 16 = 1), 100 tessellation shapes, the seven cubes CONTIGUOUS as a caller holds them (no padded "
+                             f"copy): line-aligned plan (atl_agg_create_aligned: 16 tilings of {info['tile_w']}x{info['tile_h']} tiles, "
+                             f"{info['n_partial_rows']} partial rows), 56 B per cell-step", 56 * T * S, T * S, ms, par)
+        out["odd_caller"]["ordinary_plan_ms"] = float(np.mean(ms0))
+        out["odd_caller"]["ordinary_plan_frac"] = 56 * T * S / (float(np.mean(ms0)) * 1e-3) / 1e9 / PEAK_GBPS
+        del res, cubes, plain, aligned
         gc.collect()
 
     # ---- configs[3] on one GPU: the whole 8760 x 800 x 800 cutout, in-kernel solar position ------------------------------
@@ -1101,7 +1127,7 @@ def main():
                 result["cpu_baseline"]["dask_array"] = {"skipped": repr(e)[:200]}
 
     # ---- the other BASELINE.json configurations at N = 1, at their own sizes (after the C2 legs: their cubes go first) ----
-    cfg_legs = [l for l in ("c3_series", "c3_cf_map", "c3_aggregated", "c5_heat", "c5_runoff", "c4_full_sp") if want(l)]
+    cfg_legs = [l for l in ("c3_series", "c3_cf_map", "c3_aggregated", "c5_heat", "c5_runoff", "odd_caller", "c4_full_sp") if want(l)]
     if extras and cfg_legs:
         del inputs, plan, full, full3, piece, pin, pins
         import gc
