@@ -447,7 +447,7 @@ def test_pv_influx_outflux_dataset_fast_family(ctx):
     np.testing.assert_allclose(got, refpc, rtol=1e-10, atol=1e-12 * np.nanmax(np.abs(refpc)), equal_nan=True)
 
 
-@pytest.mark.parametrize("R", [16, 17, 28, 40])
+@pytest.mark.parametrize("R", [16, 17, 28, 40, 48, 70])
 def test_dense_tiles_on_the_matrix_cores(ctx, monkeypatch, R):
     """Tiles with >= 16 partial rows are contracted with v_mfma_f64_16x16x4_f64 (groups of 16 rows, a last group from
     12 rows, the rest through the butterfly path): dense rows with explicit zeros and negative weights against scipy,
@@ -489,6 +489,9 @@ def test_dense_tiles_on_the_matrix_cores(ctx, monkeypatch, R):
     got = ctx.runoff(ctx.upload(ro), ctx.upload(h), T, S, plan=plan).numpy()
     refr = np.asarray(M @ (ro * h[None, :]).T)
     np.testing.assert_allclose(got, refr, rtol=1e-12, atol=1e-12 * np.abs(refr).max())
+    for T2 in (1, 9, 16, 17, 64):  # every kind of last sweep: one batch only, a ragged second batch, full
+        np.testing.assert_allclose(ctx.spmm(plan, ctx.upload(D[:T2] if T2 <= T else np.tile(D, (2, 1))[:T2])).numpy(),
+                                   (M @ (D[:T2] if T2 <= T else np.tile(D, (2, 1))[:T2]).T), rtol=1e-12, atol=1e-12 * np.abs(ref[np.isfinite(ref)]).max())
 
 
 @pytest.mark.parametrize("T,Y,X,N", [(72, 12, 20, 5), (61, 9, 27, 40)])
