@@ -54,6 +54,7 @@ class _Spec:
     attrs = {}
     time_vars = ()
     static_vars = ()
+    aligned_ok = True  # may run on a line-aligned plan (the library still refuses what it cannot re-address: the gateway falls back)
 
     def time_coord(self, ds):
         return ds.coords["time"]
@@ -431,6 +432,7 @@ class _HeatSpec(_Spec):
     name = "heat_demand"
     attrs = {}
     cooling = False
+    aligned_ok = False  # day groups index the cube by the hour: no line-aligned plans
 
     def __init__(self, ds, threshold, a, constant, hour_shift):
         _need(ds, ["temperature"], KeyError, "temperature")
@@ -827,7 +829,7 @@ def convert_and_aggregate(
     else:
         # (the slot stride of the dataset's device copies only steers the plan's tile shape)
         out = None
-        if _aligned_plan_wanted(ds, matrix, Y * X):
+        if getattr(spec, "aligned_ok", False) and _aligned_plan_wanted(ds, matrix, Y * X):
             # the caller's own contiguous device cubes on a grid whose slots do not start on 128-byte lines: the
             # line-aligned plan (atl_agg_create_aligned); conversions it does not cover answer with an error -> ordinary plan
             try:
