@@ -212,6 +212,7 @@ SIGNATURES = {
          C.POINTER(_vp)],
     ),
     "atl_agg_check_host": (_i, [_i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "atl_agg_check_host_aligned": (_i, [_i64, _i64, _i64, _vp, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "atl_indicator_polygons_integral_host": (
         _i,
         [_i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _d, _d, _d, _d, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],

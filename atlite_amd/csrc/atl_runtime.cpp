@@ -885,15 +885,16 @@ int atl_agg_create_aligned(atl_ctx *ctx, int64_t n_rows, int64_t n_cells, int64_
     return ATL_OK;
 }
 
-int atl_agg_check_host(int64_t n_rows, int64_t n_cells, int64_t row_len, const int64_t *h_indptr, const int32_t *h_indices,
-                       const double *h_data, int64_t *n_partial_rows, int64_t *n_dense_tiles, int64_t *n_errors) {
-    ATL_REQUIRE(n_errors, "atl_agg_check_host: n_errors is NULL");
-    *n_errors = -1;
+// classes > 0: the CSR is the stacked matrix of a line-aligned plan (n_rows, n_cells the stacked counts)
+static int verify_plan(int64_t n_rows, int64_t n_cells, int64_t row_len, const int64_t *h_indptr, const int32_t *h_indices,
+                       const double *h_data, int classes, int64_t *n_partial_rows, int64_t *n_dense_tiles, int64_t *n_errors) {
     PlanHost ph;
-    const int rc = build_plan(n_rows, n_cells, row_len, 0, h_indptr, h_indices, h_data, &ph);
+    const int rc = build_plan(n_rows, n_cells, row_len, 0, h_indptr, h_indices, h_data, &ph, classes);
     if (rc) return rc;
     int64_t err = 0, dense = 0;
-    const Layout L{ph.X, ph.Y, ph.w2_log2};
+    const Layout L{ph.X, ph.Y, ph.w2_log2, classes};
+    const int64_t tpc = std::max<int64_t>(1, layout_tiles_per_class(L)), grid_cells = ph.X * ph.Y;
+    if (ph.n_segs != tpc * std::max(1, classes) && n_cells > 0) ++err;
     // (1) every CSR entry (duplicates summed, NaN weights poison their row) sits at ONE place of the partial rows of
     //     its shape, and nothing else does: rebuild the dense (row x cell) matrix from the plan and from the CSR
     std::vector<double> want(size_t(n_rows) * size_t(n_cells), std::numeric_limits<double>::quiet_NaN()), got = want;
@@ -924,8 +925,12 @@ int atl_agg_check_host(int64_t n_rows, int64_t n_cells, int64_t row_len, const i
             }
             last = q;
             const int32_t t = prow_tile[size_t(q)];
+            // the tile's class: its tiling's origin and where its cells sit in the stacked matrix
+            const int64_t cls = classes > 0 ? t / tpc : 0, col0 = cls * grid_cells;
+            if (classes > 0 && cls != r / (n_rows / classes)) ++err;  // a class's rows live in that class's tiles
             for (int lane = 0; lane < kLanes; ++lane) {
-                const TileLane tl = tile_lane_cells(ph.X, ph.Y, int32_t(ph.ntx), ph.w2_log2, t, lane);
+                const TileLane tl = tile_lane_cells(ph.X, ph.Y, int32_t(ph.ntx), ph.w2_log2, int32_t(t - cls * tpc), lane,
+                                                    classes > 0 ? class_origin(L, cls) : 0);
                 for (int j = 0; j < 2; ++j) {
                     const double w = ph.prow_w[size_t(q) * kSegCells + size_t(2 * lane + j)];
                     if (std::isnan(w)) continue;
@@ -933,7 +938,7 @@ int atl_agg_check_host(int64_t n_rows, int64_t n_cells, int64_t row_len, const i
                         ++err;
                         continue;
                     }
-                    double &g = got[size_t(r) * size_t(n_cells) + size_t(tl.c0 + j)];
+                    double &g = got[size_t(r) * size_t(n_cells) + size_t(col0 + tl.c0 + j)];
                     if (!std::isnan(g)) ++err;  // the same (row, cell) twice
                     g = w;
                 }
@@ -969,11 +974,31 @@ int atl_agg_check_host(int64_t n_rows, int64_t n_cells, int64_t row_len, const i
                     if (img != (std::isnan(w) ? 0.0 : w)) ++err;
                 }
     }
-    (void)L;
     if (n_partial_rows) *n_partial_rows = ph.P;
     if (n_dense_tiles) *n_dense_tiles = dense;
     *n_errors = err;
     return ATL_OK;
+}
+
+int atl_agg_check_host(int64_t n_rows, int64_t n_cells, int64_t row_len, const int64_t *h_indptr, const int32_t *h_indices,
+                       const double *h_data, int64_t *n_partial_rows, int64_t *n_dense_tiles, int64_t *n_errors) {
+    ATL_REQUIRE(n_errors, "atl_agg_check_host: n_errors is NULL");
+    *n_errors = -1;
+    return verify_plan(n_rows, n_cells, row_len, h_indptr, h_indices, h_data, 0, n_partial_rows, n_dense_tiles, n_errors);
+}
+
+int atl_agg_check_host_aligned(int64_t n_rows, int64_t n_cells, int64_t row_len, const int64_t *h_indptr, const int32_t *h_indices,
+                               const double *h_data, int64_t *n_partial_rows, int64_t *n_dense_tiles, int64_t *n_errors) {
+    ATL_REQUIRE(n_errors, "atl_agg_check_host_aligned: n_errors is NULL");
+    *n_errors = -1;
+    ATL_REQUIRE(n_rows >= 0 && n_cells >= 16 && n_cells % 16 != 0, "atl_agg_check_host_aligned: needs a cell count >= 16 that is not a multiple of 16");
+    const int64_t p = alignment_classes(n_cells);
+    std::vector<int64_t> indptr;
+    std::vector<int32_t> indices;
+    std::vector<double> data;
+    const int rc = stack_classes(p, n_rows, n_cells, h_indptr, h_indices, h_data, &indptr, &indices, &data);
+    if (rc) return rc;
+    return verify_plan(p * n_rows, p * n_cells, row_len, indptr.data(), indices.data(), data.data(), int(p), n_partial_rows, n_dense_tiles, n_errors);
 }
 
 int atl_math_probe_host(int fn, const double *h_in, int64_t n, double *h_out) {

@@ -175,6 +175,10 @@ int atl_agg_selfcheck_aligned(int64_t n_cells, int64_t row_len, int tile_w, int6
 int atl_agg_check_host(int64_t n_rows, int64_t n_cells, int64_t row_len, const int64_t *h_indptr,
                        const int32_t *h_indices, const double *h_data, int64_t *n_partial_rows,
                        int64_t *n_dense_tiles, int64_t *n_errors);
+/* ... the plan atl_agg_create_aligned builds for the same matrix (every alignment class's tiling against the stacked matrix). */
+int atl_agg_check_host_aligned(int64_t n_rows, int64_t n_cells, int64_t row_len, const int64_t *h_indptr,
+                               const int32_t *h_indices, const double *h_data, int64_t *n_partial_rows,
+                               int64_t *n_dense_tiles, int64_t *n_errors);
 int atl_agg_info(const atl_agg *agg, int64_t *n_rows, int64_t *n_cells, int64_t *n_segments,
                  int64_t *n_partial_rows, int32_t *tile_w, int32_t *tile_h);
 

@@ -411,7 +411,7 @@ def test_xarray_bridge_with_the_stand_in(monkeypatch):
     assert isinstance(convert._as_dataset(ds), Dataset)
 
 
-def _check_plan(M, row_len, env=None):
+def _check_plan(M, row_len, env=None, aligned=False):
     import ctypes as C
 
     from atlite_amd import _lib
@@ -421,10 +421,40 @@ def _check_plan(M, row_len, env=None):
     indices = np.ascontiguousarray(M.indices, dtype=np.int32)
     data = np.ascontiguousarray(M.data, dtype=np.float64)
     P, dense, err = C.c_int64(), C.c_int64(), C.c_int64()
-    _lib.check(_lib.load().atl_agg_check_host(M.shape[0], M.shape[1], row_len, indptr.ctypes.data,
-                                              indices.ctypes.data if len(indices) else None,
-                                              data.ctypes.data if len(data) else None, C.byref(P), C.byref(dense), C.byref(err)))
+    fn = _lib.load().atl_agg_check_host_aligned if aligned else _lib.load().atl_agg_check_host
+    _lib.check(fn(M.shape[0], M.shape[1], row_len, indptr.ctypes.data, indices.ctypes.data if len(indices) else None,
+                  data.ctypes.data if len(data) else None, C.byref(P), C.byref(dense), C.byref(err)))
     return P.value, dense.value, err.value
+
+
+@pytest.mark.parametrize("tile", [None, "16x8", "64x2", "flat"])
+def test_aligned_plan_builder_is_consistent_with_its_matrix(monkeypatch, tile):
+    """... and the plan of atl_agg_create_aligned: 16 / gcd(S, 16) tilings of the grid, each verified entry by entry against
+    its copy of the matrix (rows of class r only in class r's tiles, every weight on the lane that owns the cell under that
+    class's origin, masks, MFMA images) - no device."""
+    if tile:
+        monkeypatch.setenv("ATLITE_HIP_TILE", tile)
+    rng = np.random.default_rng(11)
+    done = 0
+    while done < 16:
+        Y, X = int(rng.integers(1, 30)), int(rng.integers(1, 60))
+        if (Y * X) % 16 == 0 or Y * X < 16:
+            continue
+        done += 1
+        N = int(rng.integers(1, 30))
+        M = sp.random(N, Y * X, density=float(rng.choice([0.02, 0.2, 1.0])), random_state=int(rng.integers(1 << 30)), format="csr")
+        M.data[:] = rng.normal(size=M.nnz)
+        if M.nnz and done % 4 == 0:
+            M.data[int(rng.integers(M.nnz))] = np.nan
+        P, dense, err = _check_plan(M, X if done % 3 else 0, aligned=True)
+        assert err == 0, (done, Y, X, N, tile)
+    monkeypatch.setenv("ATLITE_HIP_FORCE_MFMA", "1")
+    W = rng.normal(size=(20, 11 * 27))
+    W[rng.random(W.shape) < 0.3] = 0.0
+    P, dense, err = _check_plan(sp.csr_matrix(W), 27, aligned=True)
+    assert err == 0 and dense > 0
+    with pytest.raises(ValueError, match="not a multiple of 16"):
+        _check_plan(sp.csr_matrix(np.ones((2, 64))), 8, aligned=True)
 
 
 @pytest.mark.parametrize("tile", [None, "16x8", "32x4", "64x2", "flat"])
