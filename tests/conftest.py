@@ -29,3 +29,19 @@ def ctx():
     from atlite_amd.device import Context
 
     return Context(int(os.environ.get("ATLITE_HIP_DEVICE", "0")))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _finalize_module_garbage(request):
+    """After every test module: collect cyclic garbage NOW (contexts, device groups, communicators, plans and readers whose
+    finalizers free device memory and destroy streams) and let the device drain - so that such finalizers run at a module
+    boundary, on an idle device, instead of at whatever later allocation happens to trigger the cycle collector."""
+    yield
+    import gc
+
+    gc.collect()
+    if "torch" in sys.modules:
+        torch = sys.modules["torch"]
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    gc.collect()
