@@ -93,6 +93,8 @@ __device__ __forceinline__ void st2(double *__restrict__ p, int64_t off, bool v0
         // the lane that owns the LAST cell of an odd cell count: its second value belongs to nobody (it would land on
         // the next slot's first cell)
         else if (v0) __builtin_nontemporal_store(v.x, p + off);
+        // ... and the lane whose FIRST cell lies before the slot (blocks on a slot's own line grid, k_cells_series_flat)
+        else if (v1) __builtin_nontemporal_store(v.y, p + off + 1);
         return;
     }
 #endif

@@ -102,13 +102,17 @@ template <class Conv>
 struct conv_early_load<Conv, std::void_t<decltype(Conv::kEarlyLoad)>> : std::integral_constant<bool, Conv::kEarlyLoad> {};
 
 template <class Conv>
-__global__ __launch_bounds__(256) void k_cells_series_flat(Conv conv, int64_t S, uint32_t n_chunks, double *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_cells_series_flat(Conv conv, int64_t S, uint32_t n_chunks, double *__restrict__ out, int32_t shift) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const uint32_t slot_u = blockIdx.x / n_chunks;  // blocks in (slot, chunk) order: every stream advances front to back
     const int64_t slot = slot_u;
-    const int64_t c0 = int64_t(blockIdx.x - slot_u * n_chunks) * 512 + int64_t(threadIdx.x) * 2;
-    const bool v0 = c0 < S, v1 = c0 + 1 < S;
-    const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);  // safe indices
+    // slots that do not start on a 128-byte line (the converter's slot stride conv.S is not a multiple of 16 cells: a
+    // caller's contiguous cubes on an odd grid): the chunks of THIS slot start o cells early, on its line grid - every
+    // lane's 16 bytes aligned, every wave's KiB eight whole lines (slot 0 has o = 0: nothing is read before the cube)
+    const int64_t o = shift ? (slot * conv.S) & 15 : 0;
+    const int64_t c0 = int64_t(blockIdx.x - slot_u * n_chunks) * 512 + int64_t(threadIdx.x) * 2 - o;
+    const bool v0 = c0 >= 0 && c0 < S, v1 = c0 + 1 >= 0 && c0 + 1 < S;
+    const int64_t s0c = (v0 || v1) ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);  // safe indices
     typename Conv::Carry carry = carry_init<typename Conv::Carry>();
     typename Conv::Raw raw;
     typename Conv::Cell cell;
@@ -361,7 +365,7 @@ struct conv_flat_night<Conv, std::void_t<decltype(Conv::kFlatNightSeries)>> : st
 
 template <class Conv>
 __global__ __launch_bounds__(256) void k_cells_series_flat_night(Conv conv, int64_t S, uint32_t n_chunks, double *__restrict__ out, int64_t X,
-                                                                 int64_t Y, int32_t ntx) {
+                                                                 int64_t Y, int32_t ntx, int32_t shift) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     conv.block_init(lds);
     __syncthreads();
@@ -370,21 +374,23 @@ __global__ __launch_bounds__(256) void k_cells_series_flat_night(Conv conv, int6
     const uint32_t slot_u = blockIdx.x / n_chunks;
     const int64_t slot = slot_u;
     const int64_t chunk = blockIdx.x - slot_u * n_chunks;
-    int64_t c0 = (chunk * 256 + threadIdx.x) * 2;
-    bool v0 = c0 < S, v1 = c0 + 1 < S;
-    if (X > 0) {  // 16 x 8 tiles, as k_cells_night
+    const int64_t o = shift ? (slot * conv.S) & 15 : 0;  // this slot's offset inside its 128-byte line (see k_cells_series_flat)
+    int64_t c0 = (chunk * 256 + threadIdx.x) * 2 - o;
+    bool v0 = c0 >= 0 && c0 < S, v1 = c0 + 1 >= 0 && c0 + 1 < S;
+    if (X > 0) {  // 16 x 8 tiles, as k_cells_night - their rows on THIS slot's line grid
         const int64_t seg = chunk * 4 + wave;
         if (seg >= int64_t(ntx) * ((Y + 7) / 8)) return;
-        const TileLane tl = tile_lane_cells(X, Y, ntx, 3, int32_t(seg), lane);
+        const TileLane tl = tile_lane_cells(X, Y, ntx, 3, int32_t(seg), lane, o);
         c0 = tl.c0;
         v0 = tl.v0;
         v1 = tl.v1;
     }
-    const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);
+    const int64_t s0c = (v0 || v1) ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);
     const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
-    const double2 key = v0 ? conv.template key_load<true>(slot, s0c, s1c, cell) : double2{0.0, 0.0};
+    const bool any = v0 || v1;  // (a lane may own its second cell only: the first lies before the slot, on a shifted line grid)
+    const double2 key = any ? conv.template key_load<true>(slot, s0c, s1c, cell) : double2{0.0, 0.0};
     double2 r = {0.0, 0.0};
-    if (!__all(conv.key_is_zero(key, slot, cell) || !v0)) {  // wave-uniform
+    if (!__all(conv.key_is_zero(key, slot, cell) || !any)) {  // wave-uniform
         const typename Conv::Raw A = conv.template rest_load<true>(slot, s0c, s1c, cell);
         r = conv.compute_keyed(A, key, v0, v1, cell, lds);
     }
@@ -1119,13 +1125,30 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
         if constexpr (conv_night_pipe<Conv>::value) {  // long slot ranges: the keys are fetched one batch ahead
             const int64_t len = slot_chunk_len(ctx, n_slots, gx_cells);
             const dim3 gridn(gx, unsigned((n_slots + len - 1) / len));
-            if (conv_flat_night<Conv>::value && vec && int64_t(gx) * n_slots < (int64_t(1) << 31) && flat_series()) {
+            if (conv_flat_night<Conv>::value && vec && (int64_t(gx) + int64_t(gx_cells)) * n_slots < (int64_t(1) << 30) && flat_series()) {
                 if constexpr (conv_flat_night<Conv>::value)
                 {
-                    const bool strips = getenv("ATLITE_HIP_SERIES_FLAT_STRIPS") != nullptr;  // experiment: 128-cell strips instead of 16 x 8 tiles
-                    const unsigned gxf = strips ? gx_cells : gx;
+                    // slots off the line grid (a caller's contiguous cubes, S % 16 != 0): one block lives for one slot, so its
+                    // tiles / strips can sit on THAT slot's line grid (o = (slot * stride) % 16 cells; ATLITE_HIP_SERIES_NO_SHIFT: as before)
+                    const int32_t shift = slot_stride_of(ctx, S) % 16 != 0 && !getenv("ATLITE_HIP_SERIES_NO_SHIFT");
+                    int64_t fX = tX, fY = tY;
+                    int32_t fntx = ntx;
+                    unsigned gxf = gx;
+                    if (shift) {
+                        gxf = unsigned((S + 15 + 511) / 512);
+                        if (row_len > 0 && S % row_len == 0 && S / row_len < (int64_t(1) << 30)) {
+                            fX = row_len;
+                            fY = S / row_len;
+                            fntx = int32_t(tile_columns(fX, fY, 3, true));
+                            gxf = unsigned((int64_t(fntx) * ((fY + 7) / 8) + 3) / 4);
+                        }
+                    }
+                    if (getenv("ATLITE_HIP_SERIES_FLAT_STRIPS")) {  // experiment: 128-cell strips instead of 16 x 8 tiles
+                        fX = 0;
+                        gxf = shift ? unsigned((S + 15 + 511) / 512) : gx_cells;
+                    }
                     hipLaunchKernelGGL((k_cells_series_flat_night<Conv>), dim3(unsigned(int64_t(gxf) * n_slots)), dim3(256), lds_bytes, ctx->stream, conv,
-                                       S, uint32_t(gxf), d_out, strips ? 0 : tX, tY, ntx);
+                                       S, uint32_t(gxf), d_out, fX, fY, fntx, shift);
                 }
             } else if (vec)
                 hipLaunchKernelGGL((k_cells_night<Conv, true, true>), gridn, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
@@ -1133,10 +1156,13 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
             else if constexpr (kScalarToo)
                 hipLaunchKernelGGL((k_cells_night<Conv, false, true>), gridn, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
                                    len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)), tX, tY, ntx);
-        } else if (conv_flat_series<Conv>::value && vec && int64_t(gx_cells) * n_slots < (int64_t(1) << 31) && flat_series()) {
-            if constexpr (conv_flat_series<Conv>::value)  // flat order: see k_cells_series_flat
-                hipLaunchKernelGGL((k_cells_series_flat<Conv>), dim3(unsigned(int64_t(gx_cells) * n_slots)), dim3(256), lds_bytes, ctx->stream, conv, S,
-                                   uint32_t(gx_cells), d_out);
+        } else if (conv_flat_series<Conv>::value && vec && int64_t(gx_cells) * n_slots < (int64_t(1) << 30) && flat_series()) {
+            if constexpr (conv_flat_series<Conv>::value) {  // flat order: see k_cells_series_flat
+                const int32_t shift = slot_stride_of(ctx, S) % 16 != 0 && !getenv("ATLITE_HIP_SERIES_NO_SHIFT");
+                const unsigned gxs = shift ? unsigned((S + 15 + 511) / 512) : gx_cells;
+                hipLaunchKernelGGL((k_cells_series_flat<Conv>), dim3(unsigned(int64_t(gxs) * n_slots)), dim3(256), lds_bytes, ctx->stream, conv, S,
+                                   uint32_t(gxs), d_out, shift);
+            }
         } else if (vec) {  // (else: the early-out converters do not instantiate the plain series kernel)
             hipLaunchKernelGGL((k_cells_series<Conv, true>), grid, dim3(256), lds_bytes, ctx->stream, conv,
                                n_slots, S, d_out);
