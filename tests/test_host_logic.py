@@ -257,6 +257,31 @@ def test_aligned_tile_geometry_selfcheck():
         _lib.check(lib.atl_agg_selfcheck_aligned(64, 0, 128, C.byref(nc), C.byref(nt), C.byref(no), C.byref(ne)))
 
 
+def test_gateway_asks_for_line_aligned_plans_only_where_they_pay(monkeypatch):
+    """convert._aligned_plan_wanted: the caller's own contiguous device cubes, a cell count off the 16-cell line grid, and room for
+    16 / gcd(S, 16) stacked copies of the matrix in a plan's 65535 rows; heat / cooling demand never ask (day groups)."""
+    from atlite_amd import convert
+
+    class DS:
+        def __init__(self, caller):
+            self.caller = caller
+
+        def _caller_layout(self):
+            return self.caller
+
+    M = sp.csr_matrix(np.ones((100, 201 * 201)))
+    assert convert._aligned_plan_wanted(DS(True), M, 201 * 201)
+    assert not convert._aligned_plan_wanted(DS(False), M, 201 * 201)       # the library's own padded copies
+    assert not convert._aligned_plan_wanted(DS(True), sp.csr_matrix(np.ones((3, 40000))), 40000)  # slots on the line grid already
+    assert not convert._aligned_plan_wanted(object(), M, 201 * 201)         # a duck-typed dataset without the hook
+    big = sp.csr_matrix((5000, 201 * 201))
+    assert not convert._aligned_plan_wanted(DS(True), big, 201 * 201)       # 16 x 5000 rows do not fit
+    assert convert._aligned_plan_wanted(DS(True), sp.csr_matrix((5000, 40200)), 40200)  # S % 16 = 8: two classes
+    monkeypatch.setenv("ATLITE_HIP_ALIGNED_PLANS", "0")
+    assert not convert._aligned_plan_wanted(DS(True), M, 201 * 201)
+    assert convert._Spec.aligned_ok and not convert._HeatSpec.aligned_ok and not convert._CoolSpec.aligned_ok
+
+
 def test_streaming_sources_and_policy(monkeypatch):
     """Host-side policy of the slab pipeline (no GPU): which datasets stream, and how sources are
     normalised (fp64 as is, narrower native dtypes kept for the device decode, exotic ones widened)."""
