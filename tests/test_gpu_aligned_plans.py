@@ -171,3 +171,25 @@ def test_gateway_uses_the_aligned_plan_for_caller_owned_cubes(ctx, monkeypatch):
     pv0 = c.pv(panel="CSi", orientation=dict(slope=30.0, azimuth=180.0), matrix=M, aggregate_time=None)
     assert used == [("_PvSpec", False)]
     close(np.asarray(pv0.values), np.asarray(pv.values), rtol=1e-12)
+
+
+def test_full_year_on_a_real_world_grid(ctx):
+    """8760 x 201 x 201 (S % 16 = 1, the bench's odd_caller leg), 100 blob shapes, the seven cubes contiguous: the line-aligned
+    plan against the ordinary plan over the whole year, both pv kernels, and a size-independent property - the time sum of
+    the aggregated series equals the weights' product with the per-cell time sum (another kernel, another order)."""
+    from atlite_amd import synthetic
+
+    T, Y, X = 8760, 201, 201
+    S = Y * X
+    cubes, _ = synthetic.pv_inputs(ctx, T, Y, X)
+    M = H.blob_matrix(100, Y, X, seed=7)
+    plain, aligned = ctx.plan(M, row_len=X), ctx.plan(M, row_len=X, aligned=True)
+    assert aligned.info()["n_segments"] == 16 * (aligned.info()["n_segments"] // 16)
+    for skip in (False, True):
+        a = ctx.pv(cubes, PV, T, S, plan=aligned, options=dict(night_skip=skip)).numpy()
+        b = ctx.pv(cubes, PV, T, S, plan=plain, options=dict(night_skip=skip)).numpy()
+        close(a, b, rtol=1e-12)
+        assert a.max() > 0 and (a == 0).any()
+    per_cell_sum = ctx.pv(cubes, PV, T, S, time_agg="sum", options=dict(night_skip=True, row_len=X)).numpy()
+    close(a.sum(axis=1), np.asarray(M @ per_cell_sum).ravel(), rtol=1e-10)
+    close(ctx.pv(cubes, PV, T, S, plan=aligned, time_agg="sum", options=dict(night_skip=True)).numpy(), a.sum(axis=1), rtol=1e-11)
