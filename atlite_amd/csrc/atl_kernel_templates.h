@@ -135,26 +135,49 @@ __global__ __launch_bounds__(256) void k_cells_series_flat(Conv conv, int64_t S,
 // ---------------------------------------------------------------------------------------
 // kernel 2: per-cell time reduction.  psum/pcnt[chunk, cell] then k_chunk_reduce.
 // ---------------------------------------------------------------------------------------
+// Alignment classes (p > 1; cubes whose slots do not start on 128-byte lines - a caller's contiguous cubes, S % 16 != 0; the
+// per-cell counterpart of a line-aligned plan): chunk blockIdx.y belongs to class r = blockIdx.y % p and walks the slots
+// r, r + p, r + 2 p, ... of its range, which all start o_r = (r * stride) % 16 cells into a line - so the block's cells
+// start o_r cells early, on THAT line grid, for the whole walk.  psum / pcnt keep one row per chunk; every cell is in every
+// class, so k_chunk_reduce needs nothing new.
+struct ClassWalk {
+    int64_t o;        // cells the class's slots start into their line
+    int64_t first;    // the class's first slot (r)
+    int64_t step;     // p
+    int64_t s0, s1;   // this chunk's range of the class's slots (indices i: slot = first + step * i)
+};
+__device__ __forceinline__ ClassWalk class_walk(int32_t p, int64_t stride, int64_t n_slots, int64_t chunk_len) {
+    ClassWalk w;
+    const int64_t r = p > 1 ? int64_t(blockIdx.y % unsigned(p)) : 0, j = p > 1 ? int64_t(blockIdx.y / unsigned(p)) : int64_t(blockIdx.y);
+    w.o = p > 1 ? (r * stride) & 15 : 0;
+    w.first = r;
+    w.step = p > 1 ? p : 1;
+    const int64_t n = p > 1 ? (n_slots - r + p - 1) / p : n_slots;  // slots of the class
+    w.s0 = j * chunk_len;
+    w.s1 = min(w.s0 + chunk_len, n);
+    return w;
+}
+
 template <class Conv, bool VEC>
 __global__ __launch_bounds__(256) void k_cells_timered(Conv conv, int64_t n_slots, int64_t S,
                                                        int64_t chunk_len, double *__restrict__ psum,
-                                                       double *__restrict__ pcnt) {
+                                                       double *__restrict__ pcnt, int32_t classes) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     conv.block_init(lds);
     __syncthreads();
-    const int64_t c0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * 2;
-    const bool v0 = c0 < S, v1 = c0 + 1 < S;
-    const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);  // safe indices
+    const ClassWalk w = class_walk(classes, conv.S, n_slots, chunk_len);
+    const int64_t c0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * 2 - w.o;
+    const bool v0 = c0 >= 0 && c0 < S, v1 = c0 + 1 >= 0 && c0 + 1 < S;
+    const int64_t s0c = (v0 || v1) ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);  // safe indices
     const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
-    const int64_t s0 = int64_t(blockIdx.y) * chunk_len;
-    const int64_t s1 = min(s0 + chunk_len, n_slots);
+    const int64_t s0 = w.s0, s1 = w.s1;
     double2 acc = {0.0, 0.0}, cnt = {0.0, 0.0};
     constexpr int G = Conv::kGroup >= 4 ? 4 : Conv::kGroup;
     typename Conv::Carry carry = carry_init<typename Conv::Carry>();
     for (int64_t sg = s0; sg < s1; sg += G) {
         typename Conv::Raw raw[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) raw[g] = conv.template load<VEC>(min(sg + g, s1 - 1), g, s0c, s1c, cell, carry);
+        for (int g = 0; g < G; ++g) raw[g] = conv.template load<VEC>(w.first + w.step * min(sg + g, s1 - 1), g, s0c, s1c, cell, carry);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const double2 r = conv.compute(raw[g], v0, v1, cell, lds);  // (invalid cells: masked when psum / pcnt are stored)
@@ -265,7 +288,7 @@ struct conv_night_pipe<Conv, std::void_t<decltype(Conv::kNightPipe)>> : std::int
 template <class Conv, bool VEC, bool SERIES>
 __global__ __launch_bounds__(256, conv_min_waves_cells<Conv>::value) void k_cells_night(Conv conv, int64_t n_slots, int64_t S, int64_t chunk_len,
                                                                         double *__restrict__ out_a, double *__restrict__ out_b,
-                                                                        int32_t conv_lds_doubles, int64_t X, int64_t Y, int32_t ntx) {
+                                                                        int32_t conv_lds_doubles, int64_t X, int64_t Y, int32_t ntx, int32_t classes) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     conv.block_init(lds);
     __syncthreads();
@@ -277,31 +300,34 @@ __global__ __launch_bounds__(256, conv_min_waves_cells<Conv>::value) void k_cell
     // the wave's 128 cells: a 16 x 8 tile of the grid when its row length is known (the fused kernels' tiles: the day /
     // night line crosses a compact tile in an eighth of the slots it takes to cross a 128-cell strip: 11.8 instead of
     // 13.7 GB read on C2), else 128 consecutive cells
-    int64_t c0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * 2;
-    bool v0 = c0 < S, v1 = c0 + 1 < S;
+    // (SERIES: chunks of consecutive slots, classes = 1; time-reduced: see class_walk above)
+    const ClassWalk w = class_walk(SERIES ? 1 : classes, conv.S, n_slots, chunk_len);
+    const auto slot_of = [&](int64_t i) { return w.first + w.step * i; };
+    int64_t c0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * 2 - w.o;
+    bool v0 = c0 >= 0 && c0 < S, v1 = c0 + 1 >= 0 && c0 + 1 < S;
     if (X > 0) {
         const int64_t seg = int64_t(blockIdx.x) * 4 + wave;
         if (seg >= int64_t(ntx) * ((Y + 7) / 8)) return;
-        const TileLane tl = tile_lane_cells(X, Y, ntx, 3, int32_t(seg), lane);
+        const TileLane tl = tile_lane_cells(X, Y, ntx, 3, int32_t(seg), lane, w.o);
         c0 = tl.c0;
         v0 = tl.v0;
         v1 = tl.v1;
     }
-    const int64_t s0c = v0 ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);
+    const bool own = v0 || v1;  // (on a shifted line grid a lane may own its second cell only)
+    const int64_t s0c = own ? c0 : 0, s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);
     const typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
-    const int64_t s0 = int64_t(blockIdx.y) * chunk_len;
-    const int64_t s1 = min(s0 + chunk_len, n_slots);
+    const int64_t s0 = w.s0, s1 = w.s1;
     double2 acc = {0.0, 0.0};
     int cnt0 = 0, cnt1 = 0;  // slots per chunk fit an int
     double2 key[kBatch];
     const bool any = s0 < s1;  // an empty time axis still writes its (0, 0) partials
 #pragma unroll
-    for (int i = 0; i < kBatch; ++i) key[i] = (v0 && any) ? conv.template key_load<VEC>(min(s0 + i, s1 - 1), s0c, s1c, cell) : double2{0.0, 0.0};
+    for (int i = 0; i < kBatch; ++i) key[i] = (own && any) ? conv.template key_load<VEC>(slot_of(min(s0 + i, s1 - 1)), s0c, s1c, cell) : double2{0.0, 0.0};
     for (int64_t sb = s0; sb < s1; sb += kBatch) {
         unsigned day = 0;
 #pragma unroll
         for (int i = 0; i < kBatch; ++i) {
-            const bool d = (sb + i < s1) && !__all(conv.key_is_zero(key[i], min(sb + i, s1 - 1), cell) || !v0);
+            const bool d = (sb + i < s1) && !__all(conv.key_is_zero(key[i], slot_of(min(sb + i, s1 - 1)), cell) || !own);
             day |= d ? 1u << i : 0u;
             *reinterpret_cast<double2 *>(vl + i * kSegCells) = key[i];
         }
@@ -309,24 +335,24 @@ __global__ __launch_bounds__(256, conv_min_waves_cells<Conv>::value) void k_cell
         if (sb + kBatch < s1) {  // next batch's keys: in flight behind this batch's conversions
 #pragma unroll
             for (int i = 0; i < kBatch; ++i)
-                key[i] = v0 ? conv.template key_load<VEC>(min(sb + kBatch + i, s1 - 1), s0c, s1c, cell) : double2{0.0, 0.0};
+                key[i] = own ? conv.template key_load<VEC>(slot_of(min(sb + kBatch + i, s1 - 1)), s0c, s1c, cell) : double2{0.0, 0.0};
         }
         if constexpr (SERIES) {
 #pragma unroll 1
             for (int i = 0; i < nb; ++i) {
                 double2 r = {0.0, 0.0};
                 if ((day >> i) & 1u) {  // wave-uniform
-                    const typename Conv::Raw A = conv.template rest_load<VEC>(sb + i, s0c, s1c, cell);
+                    const typename Conv::Raw A = conv.template rest_load<VEC>(slot_of(sb + i), s0c, s1c, cell);
                     r = conv.compute_keyed(A, *reinterpret_cast<const double2 *>(vl + i * kSegCells), v0, v1, cell, lds);
                 }
-                st2<VEC>(out_a, (sb + i) * S + c0, v0, v1, r);
+                st2<VEC>(out_a, slot_of(sb + i) * S + c0, v0, v1, r);
             }
         } else {
             unsigned m = day;
             while (m) {
                 const int i = __builtin_ctz(m);
                 m &= m - 1;
-                const typename Conv::Raw A = conv.template rest_load<VEC>(sb + i, s0c, s1c, cell);
+                const typename Conv::Raw A = conv.template rest_load<VEC>(slot_of(sb + i), s0c, s1c, cell);
                 const double2 r = conv.compute_keyed(A, *reinterpret_cast<const double2 *>(vl + i * kSegCells), v0, v1, cell, lds);
                 if (!dnan(r.x)) {
                     acc.x += r.x;
@@ -1152,10 +1178,10 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
                 }
             } else if (vec)
                 hipLaunchKernelGGL((k_cells_night<Conv, true, true>), gridn, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
-                                   len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)), tX, tY, ntx);
+                                   len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)), tX, tY, ntx, 1);
             else if constexpr (kScalarToo)
                 hipLaunchKernelGGL((k_cells_night<Conv, false, true>), gridn, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
-                                   len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)), tX, tY, ntx);
+                                   len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)), tX, tY, ntx, 1);
         } else if (conv_flat_series<Conv>::value && vec && int64_t(gx_cells) * n_slots < (int64_t(1) << 30) && flat_series()) {
             if constexpr (conv_flat_series<Conv>::value) {  // flat order: see k_cells_series_flat
                 const int32_t shift = slot_stride_of(ctx, S) % 16 != 0 && !getenv("ATLITE_HIP_SERIES_NO_SHIFT");
@@ -1173,8 +1199,35 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
         return check_launch(what);
     }
     // time-reduced: split the slot axis so that the grid fills the chip
-    const int64_t chunk_len = slot_chunk_len(ctx, n_slots, gx_cells);
-    const int64_t n_chunks = std::max<int64_t>(1, (n_slots + chunk_len - 1) / chunk_len);
+    int64_t chunk_len = slot_chunk_len(ctx, n_slots, gx_cells);
+    int64_t n_chunks = std::max<int64_t>(1, (n_slots + chunk_len - 1) / chunk_len);
+    // cubes whose slots do not start on 128-byte lines (a caller's contiguous cubes, S % 16 != 0): the chunks split by the
+    // alignment class of their slots, each class on its own line grid (class_walk) - about as many chunks as before
+    int32_t classes = 1;
+    if constexpr (conv_shift_ok<Conv>::value) {
+        const int64_t stride = slot_stride_of(ctx, S);
+        // (the unvectorised instantiations walk the same classes: the same summation order, the same bits)
+        if (stride % 16 != 0 && S >= 16 && !getenv("ATLITE_HIP_SERIES_NO_SHIFT")) {
+            int64_t g = stride % 16, b = 16;
+            while (g) {  // gcd(stride, 16)
+                const int64_t t = b % g;
+                b = g;
+                g = t;
+            }
+            classes = int32_t(16 / b);
+            const int64_t per_class = (n_slots + classes - 1) / classes;           // slots of the longest class
+            const int64_t cpc = std::max<int64_t>(1, (n_chunks + classes - 1) / classes);  // chunks per class
+            chunk_len = std::max<int64_t>(kBatch, ((per_class + cpc - 1) / cpc + kBatch - 1) / kBatch * kBatch);  // (an empty time axis: one empty chunk per class)
+            n_chunks = classes * std::max<int64_t>(1, (per_class + chunk_len - 1) / chunk_len);
+            gx = unsigned((S + 15 + 511) / 512);
+            if (tX > 0 || (conv_night_pipe<Conv>::value && row_len > 0 && S % row_len == 0 && S / row_len < (int64_t(1) << 30))) {
+                tX = row_len;  // the early-out kernel keeps its 16 x 8 tiles, their rows on the class's line grid
+                tY = S / row_len;
+                ntx = int32_t(tile_columns(tX, tY, 3, true));
+                gx = unsigned((int64_t(ntx) * ((tY + 7) / 8) + 3) / 4);
+            }
+        }
+    }
     void *scr = nullptr;
     int rc = scratch_reserve(ctx, size_t(2 * n_chunks * S) * sizeof(double), &scr);
     if (rc) return rc;
@@ -1185,16 +1238,16 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
         if constexpr (conv_night_pipe<Conv>::value) {
             if (vec)
                 hipLaunchKernelGGL((k_cells_night<Conv, true, false>), grid, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
-                                   chunk_len, psum, pcnt, int32_t(lds_bytes / sizeof(double)), tX, tY, ntx);
+                                   chunk_len, psum, pcnt, int32_t(lds_bytes / sizeof(double)), tX, tY, ntx, classes);
             else if constexpr (kScalarToo)
                 hipLaunchKernelGGL((k_cells_night<Conv, false, false>), grid, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
-                                   chunk_len, psum, pcnt, int32_t(lds_bytes / sizeof(double)), tX, tY, ntx);
+                                   chunk_len, psum, pcnt, int32_t(lds_bytes / sizeof(double)), tX, tY, ntx, classes);
         } else if (vec) {
             hipLaunchKernelGGL((k_cells_timered<Conv, true>), grid, dim3(256), lds_bytes, ctx->stream, conv,
-                               n_slots, S, chunk_len, psum, pcnt);
+                               n_slots, S, chunk_len, psum, pcnt, classes);
         } else if constexpr (kScalarToo) {
             hipLaunchKernelGGL((k_cells_timered<Conv, false>), grid, dim3(256), lds_bytes, ctx->stream, conv,
-                               n_slots, S, chunk_len, psum, pcnt);
+                               n_slots, S, chunk_len, psum, pcnt, classes);
         }
     }
     if ((rc = check_launch(what))) return rc;

@@ -163,7 +163,9 @@ def test_api_results_with_padded_slots_equal_contiguous_ones(monkeypatch, T, Y, 
     plain, lds0 = run()
     assert lds0 == {None}
     for k in padded:
-        if k.endswith("_agg") or k in ("heat", "runoff"):
+        # (aggregations sum tile by tile, time reductions chunk by chunk - on contiguous cubes off the line grid the chunks
+        #  follow the slots' alignment classes: the same terms in another order)
+        if k.endswith("_agg") or k in ("heat", "runoff", "pv_map", "runoff_cells"):
             np.testing.assert_allclose(padded[k], plain[k], rtol=1e-12, atol=1e-13 * np.abs(plain[k]).max(), err_msg=k)
         else:
             np.testing.assert_array_equal(padded[k], plain[k], err_msg=k)
@@ -247,4 +249,6 @@ def test_repack_of_caller_owned_cubes_off_the_line_grid(ctx):
     np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-12 * np.abs(b).max())
     np.testing.assert_array_equal(packed.pv(**kw).values, b)  # second call: the resident copies
     w = packed.pv(panel="CSi", orientation={"slope": 30.0, "azimuth": 180.0}, aggregate_time="mean").values
-    np.testing.assert_array_equal(w, plain.pv(panel="CSi", orientation={"slope": 30.0, "azimuth": 180.0}, aggregate_time="mean").values)
+    # (the time reduction over the contiguous cubes walks the slots' alignment classes: the same terms, another order)
+    np.testing.assert_allclose(w, plain.pv(panel="CSi", orientation={"slope": 30.0, "azimuth": 180.0}, aggregate_time="mean").values,
+                               rtol=1e-13, atol=1e-15)
