@@ -1,3 +1,4 @@
+"""Per-cell series on contiguous cubes of odd and even grids (wind, pv with / without the early-out): HIP-event medians.\nRun on the GPU box from the repo root; ATLITE_HIP_SERIES_NO_SHIFT=1 switches the per-slot line-grid placement off."""
 import sys
 sys.path.insert(0, ".")
 import numpy as np
@@ -18,5 +19,5 @@ for (Y, X) in ((400, 400), (401, 401), (201, 201), (200, 200)):
         for skip in (False, True):
             fn = lambda: ctx.pv(inputs, CSI, T, S, options=dict(night_skip=skip, row_len=X))
             med, mn = timed(ctx, fn, reps=6)
-            print(f"pv per-cell series {Y}x{X} contiguous night_skip={int(skip)}: {med:.3f} ms  {T*S/med/1e3:.3e} cell-steps/s", flush=True)
+            print(f"pv per-cell series {Y}x{X} contiguous night_skip={int(skip)}: {med:.3f} ms  {T*S/(med*1e-3):.3e} cell-steps/s", flush=True)
         del inputs
