@@ -34,7 +34,13 @@ GROUPS = {
     "configs": (["--legs", "c3_series,c3_cf_map,c3_aggregated,c5_heat,c5_runoff"],
                 ["c3_series", "c3_cf_map", "c3_aggregated", "c5_heat", "c5_runoff"]),
     "c4": (["--legs", "c4_full_sp"], ["c4_full_sp"]),
+    # the same kernel NAME as the headline: this leg's launches are told apart by their place in the pass (SLICES)
+    "odd": (["--legs", "odd_caller"], ["odd_caller"]),
 }
+# legs whose kernel also runs for other workloads of the same pass: (first launch, launches) of the leg's TIMED launches in
+# the pass's sequence of that kernel.  odd_caller: 9 headline launches, then 10 + 6 on the ordinary plan, then 10 warm-up + 6
+# timed on the line-aligned plan
+SLICES = {"odd_caller": (9 + 16 + 10, 6)}
 COMMON = ["--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-parity"]
 # untimed launches of a leg's kernel before bench.py's timed ones (its --warmup, the 12 warm-up launches of the side legs, the
 # 10 of the configs legs): `avg_us` is over every launch of the pass, `avg_us_timed` over those after the warm-up - the
@@ -99,11 +105,14 @@ def main():
             for n, v, av, sg, l, sc, gx, w in con.execute(
                     "select name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, grid_x, workgroup_x from kernels group by name"):
                 lines.append(f"{short(n):72s} vgpr={v} agpr={av} sgpr={sg} lds={l} scratch={sc} grid={gx} wg={w}")
-        pmc = {}
+        pmc, pmc_seq = {}, {}
         for pname, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             con = per_pass[pname]
             if not con:
                 continue
+            for k, v in con.execute("select kernel_name, sum(value) from counters_collection where counter_name = ? group by dispatch_id, kernel_name "
+                                    "order by dispatch_id", (cname,)):
+                pmc_seq.setdefault(short(k), {}).setdefault(cname, []).append(v)
             lines.append("")
             lines.append(f"== rocprofv3 --pmc {cname} (its own pass): per-kernel averages, KiB per launch ==")
             for k, cn, c, a, mn, mx in con.execute("select kernel_name, counter_name, count(*), avg(v), min(v), max(v) from (select dispatch_id, "
@@ -150,10 +159,23 @@ def main():
             seq = st.pop("in_order_us")
             w = WARM.get(leg, WARM_CONFIGS)
             n_timed = int(COMMON[COMMON.index("--steps") + 1])  # (launches after those belong to other legs: the API calls)
+            if leg in SLICES:
+                w, n_timed = SLICES[leg]
             timed = seq[w:w + n_timed] if len(seq) > w else seq
             e = dict(kernel=k, **st, warmup_launches=w if len(seq) > w else 0, timed_launches=len(timed),
                      avg_us_timed=sum(timed) / len(timed), source=f"profiles/{tag}_bench_{g}.txt")
-            if k in pmc and "FETCH_SIZE" in pmc[k]:
+            if leg in SLICES and k in pmc_seq and len(pmc_seq[k].get("FETCH_SIZE", [])) >= w + n_timed:
+                # the counters of THIS leg's launches only (the kernel's other launches in the pass read other cubes)
+                f = pmc_seq[k]["FETCH_SIZE"][w:w + n_timed]
+                wr = pmc_seq[k].get("WRITE_SIZE", [])[w:w + n_timed]
+                e["read_bytes"] = 2.0 * sum(f) / len(f) * 1024
+                e["write_bytes"] = (sum(wr) / len(wr) * 1024) if wr else 0.0
+                e["hbm_bytes_per_launch"] = e["read_bytes"] + e["write_bytes"]
+                e["calls"] = len(timed)
+                e["avg_us"] = e["avg_us_timed"]
+            elif leg in SLICES:
+                pass  # no trustworthy counters for this leg in this pass
+            elif k in pmc and "FETCH_SIZE" in pmc[k]:
                 e["read_bytes"] = 2.0 * pmc[k]["FETCH_SIZE"] * 1024
                 e["write_bytes"] = pmc[k].get("WRITE_SIZE", 0.0) * 1024
                 e["hbm_bytes_per_launch"] = e["read_bytes"] + e["write_bytes"]
