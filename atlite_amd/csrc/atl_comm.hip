@@ -534,7 +534,7 @@ int atl_comm_destroy(atl_comm *comm) {
         for (int i = 0; i < kTickets; ++i) (void)hipEventDestroy(comm->ring[i]);
         (void)hipStreamDestroy(comm->stream);
     }
-    if (comm->buf) (void)hipFree(comm->buf);
+    if (comm->buf) (void)dev_free(comm->buf);
     delete comm;
     return ATL_OK;
 }
@@ -580,10 +580,10 @@ int atl_allgather_time_v_async(atl_comm *comm, const double *d_local, int64_t N,
     const size_t need = size_t(comm->n_ranks + 1) * size_t(std::max<int64_t>(N * Tmax, 1)) * sizeof(double);
     if (need > comm->buf_bytes) {
         ATL_HIP_TRY(hipStreamSynchronize(comm->stream));
-        if (comm->buf) ATL_HIP_TRY(hipFree(comm->buf));
+        if (comm->buf) ATL_HIP_TRY(dev_free(comm->buf));
         comm->buf = nullptr;
         comm->buf_bytes = 0;
-        hipError_t e = hipMalloc(&comm->buf, need);
+        hipError_t e = dev_malloc(&comm->buf, need);
         if (e != hipSuccess) {
             set_error("atl_allgather_time_v_async: hipMalloc of %zu bytes failed: %s", need, hipGetErrorString(e));
             return comm->group ? local_fail(comm->group, ATL_E_NOMEM) : ATL_E_NOMEM;

@@ -240,7 +240,7 @@ static int indicator_integral(atl_ctx *ctx, int64_t n_shapes, const int64_t *h_s
         int32_t *d_col = nullptr, *d_row0 = nullptr, *d_nrows = nullptr;
         double *d_cand = nullptr;
         auto up = [&](void **d, const void *h, size_t bytes) -> hipError_t {
-            hipError_t e = hipMalloc(d, std::max<size_t>(bytes, 8));
+            hipError_t e = dev_malloc(d, std::max<size_t>(bytes, 8));
             if (e != hipSuccess) return e;
             return bytes ? hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
         };
@@ -250,7 +250,7 @@ static int indicator_integral(atl_ctx *ctx, int64_t n_shapes, const int64_t *h_s
         if (e == hipSuccess) e = up((void **)&d_col, bucket_col.data(), bucket_col.size() * sizeof(int32_t));
         if (e == hipSuccess) e = up((void **)&d_row0, bucket_row0.data(), bucket_row0.size() * sizeof(int32_t));
         if (e == hipSuccess) e = up((void **)&d_nrows, bucket_nrows.data(), bucket_nrows.size() * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMalloc((void **)&d_cand, size_t(n_cand) * sizeof(double));
+        if (e == hipSuccess) e = dev_malloc((void **)&d_cand, size_t(n_cand) * sizeof(double));
         if (e == hipSuccess) {
             // grid.y is limited to 65535 buckets per launch
             for (int64_t k0 = 0; k0 < n_buckets && e == hipSuccess; k0 += 65535) {
@@ -264,7 +264,7 @@ static int indicator_integral(atl_ctx *ctx, int64_t n_shapes, const int64_t *h_s
         if (e == hipSuccess) e = hipMemcpyAsync(cand.data(), d_cand, size_t(n_cand) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         for (void *p : {(void *)d_edges, (void *)d_ptr, (void *)d_out_off, (void *)d_col, (void *)d_row0, (void *)d_nrows, (void *)d_cand})
-            if (p) (void)hipFree(p);
+            if (p) (void)dev_free(p);
         if (e != hipSuccess) {
             set_error("atl_indicator_polygons_device: %s", hipGetErrorString(e));
             return ATL_E_HIP;

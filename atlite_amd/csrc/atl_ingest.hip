@@ -244,7 +244,7 @@ void ingest_free(void *p) {
             (void)hipEventDestroy(sl.ev);
         }
         if (sl.h) (void)hipHostFree(sl.h);
-        if (sl.d) (void)hipFree(sl.d);
+        if (sl.d) (void)dev_free(sl.d);
     }
     delete s;
 }
@@ -264,13 +264,13 @@ int slot_acquire(atl_ctx *ctx, size_t bytes, Slot **out) {
     }
     if (sl.bytes < bytes) {
         if (sl.h) (void)hipHostFree(sl.h);
-        if (sl.d) (void)hipFree(sl.d);
+        if (sl.d) (void)dev_free(sl.d);
         sl.h = nullptr;
         sl.d = nullptr;
         sl.bytes = 0;
         const size_t want = align_up(bytes + bytes / 4, size_t(1) << 20);
         ATL_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sl.h), want, hipHostMallocDefault));
-        ATL_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sl.d), want));
+        ATL_HIP_TRY(dev_malloc(reinterpret_cast<void **>(&sl.d), want));
         sl.bytes = want;
     }
     *out = &sl;

@@ -290,6 +290,15 @@ namespace atl {
 int scratch_reserve(atl_ctx *ctx, size_t bytes, void **out);
 // the context's copy stream (created on first use)
 int copy_stream_of(atl_ctx *ctx, hipStream_t *out);
+// Every device allocation of the library goes through these two.  Normally hipMalloc / hipFree.  With
+// $ATLITE_HIP_FENCE=1 (a debugging mode, tools/hang_hunt.sh) each block is its own virtual-memory mapping whose LAST
+// byte is the last mapped byte before an unmapped guard range (8-byte granularity), with another guard range in
+// front, and a freed block's addresses are never handed out again: an access one element past either end, or after
+// the free, is a page fault on the spot instead of a silent read of a neighbouring allocation.  dev_free does not
+// order anything: callers synchronise first, as they had to for hipFree's sake.
+hipError_t dev_malloc(void **out, size_t bytes);
+hipError_t dev_free(void *p);
+bool fence_mode();
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // cells between the slots of a call's input cubes: the context's stride if one is set, else the cell count
 inline int64_t slot_stride_of(const atl_ctx *ctx, int64_t S) { return ctx->slot_stride > 0 ? ctx->slot_stride : S; }

@@ -7,7 +7,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <numeric>
+#include <unordered_map>
 
 #include <execinfo.h>
 #include <signal.h>
@@ -41,6 +43,97 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// ---- device memory: hipMalloc, or fenced virtual-memory mappings ($ATLITE_HIP_FENCE=1) ---------------------------
+bool fence_mode() {
+    static const bool on = [] {
+        const char *e = getenv("ATLITE_HIP_FENCE");
+        return e && *e && *e != '0';
+    }();
+    return on;
+}
+
+namespace {
+struct FenceBlock {
+    char *va;        // start of the reservation (guard | mapping | guard), never released: a stale pointer must keep faulting
+    size_t mapped;   // bytes mapped at va + guard
+    hipMemGenericAllocationHandle_t handle;
+    int device;
+};
+std::mutex g_fence_m;
+std::unordered_map<void *, FenceBlock> g_fence;
+}  // namespace
+
+hipError_t dev_malloc(void **out, size_t bytes) {
+    if (!fence_mode()) return hipMalloc(out, bytes);
+    *out = nullptr;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    if ((e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum)) != hipSuccess) return e;
+    if (gran == 0) return hipErrorNotSupported;
+    const size_t want = align_up(bytes ? bytes : 8, 8), mapped = align_up(want, gran);
+    FenceBlock b{};
+    b.mapped = mapped;
+    b.device = dev;
+    void *va = nullptr;
+    if ((e = hipMemAddressReserve(&va, mapped + 2 * gran, gran, nullptr, 0)) != hipSuccess) return e;
+    b.va = static_cast<char *>(va);
+    if ((e = hipMemCreate(&b.handle, mapped, &prop, 0)) != hipSuccess) {
+        (void)hipMemAddressFree(va, mapped + 2 * gran);
+        return e;
+    }
+    if ((e = hipMemMap(b.va + gran, mapped, 0, b.handle, 0)) != hipSuccess) {
+        (void)hipMemRelease(b.handle);
+        (void)hipMemAddressFree(va, mapped + 2 * gran);
+        return e;
+    }
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if ((e = hipMemSetAccess(b.va + gran, mapped, &acc, 1)) != hipSuccess) {
+        (void)hipMemUnmap(b.va + gran, mapped);
+        (void)hipMemRelease(b.handle);
+        (void)hipMemAddressFree(va, mapped + 2 * gran);
+        return e;
+    }
+    void *user = b.va + gran + (mapped - want);  // the block ends where the mapping ends
+    {
+        std::lock_guard<std::mutex> lk(g_fence_m);
+        g_fence[user] = b;
+    }
+    *out = user;
+    return hipSuccess;
+}
+
+hipError_t dev_free(void *p) {
+    if (!p) return hipSuccess;
+    if (!fence_mode()) return hipFree(p);
+    FenceBlock b;
+    {
+        std::lock_guard<std::mutex> lk(g_fence_m);
+        auto it = g_fence.find(p);
+        if (it == g_fence.end()) return hipErrorInvalidValue;  // not ours, or freed twice
+        b = it->second;
+        g_fence.erase(it);
+    }
+    hipError_t e = hipDeviceSynchronize();  // what hipFree does implicitly
+    size_t gran = 0;
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = b.device;
+    (void)hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    hipError_t e2 = hipMemUnmap(b.va + gran, b.mapped);
+    hipError_t e3 = hipMemRelease(b.handle);
+    // the reservation stays: the addresses are never reused
+    return e != hipSuccess ? e : e2 != hipSuccess ? e2 : e3;
+}
+
 int scratch_reserve(atl_ctx *ctx, size_t bytes, void **out) {
     bytes = align_up(bytes ? bytes : 256, 256);
     if (bytes > ctx->scratch_bytes) {
@@ -51,14 +144,14 @@ int scratch_reserve(atl_ctx *ctx, size_t bytes, void **out) {
         }
         // stream-ordered: earlier kernels may still read the old arena
         ATL_HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (ctx->scratch) ATL_HIP_TRY(hipFree(ctx->scratch));
+        if (ctx->scratch) ATL_HIP_TRY(dev_free(ctx->scratch));
         ctx->scratch = nullptr;
         ctx->scratch_bytes = 0;
         size_t want = bytes + bytes / 4;
-        hipError_t e = hipMalloc(&ctx->scratch, want);
+        hipError_t e = dev_malloc(&ctx->scratch, want);
         if (e != hipSuccess) {
             want = bytes;
-            ATL_HIP_TRY(hipMalloc(&ctx->scratch, want));
+            ATL_HIP_TRY(dev_malloc(&ctx->scratch, want));
         }
         ctx->scratch_bytes = want;
     }
@@ -74,7 +167,7 @@ template <class T>
 static int to_device(atl_agg *a, const std::vector<T> &v, const T **out) {
     void *d = nullptr;
     size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
-    ATL_HIP_TRY(hipMalloc(&d, bytes));
+    ATL_HIP_TRY(dev_malloc(&d, bytes));
     a->allocs.push_back(d);
     if (!v.empty())
         ATL_HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
@@ -226,7 +319,7 @@ int atl_create(int device, void *stream, atl_ctx **out) {
     (void)hipEventCreate(&c->ev_t0);
     (void)hipEventCreate(&c->ev_t1);
     (void)hipEventCreateWithFlags(&c->ev_table, hipEventDisableTiming);
-    if (hipMalloc(reinterpret_cast<void **>(&c->d_table), 5 * 2 * kMaxKnots * sizeof(double)) != hipSuccess ||
+    if (dev_malloc(reinterpret_cast<void **>(&c->d_table), 5 * 2 * kMaxKnots * sizeof(double)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&c->h_table), 5 * 2 * kMaxKnots * sizeof(double), hipHostMallocDefault) !=
             hipSuccess) {
         set_error("atl_create: table allocation failed");
@@ -241,8 +334,8 @@ int atl_destroy(atl_ctx *ctx) {
     if (!ctx) return ATL_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->scratch) (void)hipFree(ctx->scratch);
-    if (ctx->d_table) (void)hipFree(ctx->d_table);
+    if (ctx->scratch) (void)dev_free(ctx->scratch);
+    if (ctx->d_table) (void)dev_free(ctx->d_table);
     if (ctx->h_table) (void)hipHostFree(ctx->h_table);
     if (ctx->ev_table) (void)hipEventDestroy(ctx->ev_table);
     (void)hipEventDestroy(ctx->ev_t0);
@@ -275,7 +368,7 @@ int atl_alloc(atl_ctx *ctx, size_t bytes, void **d_ptr) {
     ATL_REQUIRE(ctx && d_ptr, "atl_alloc: bad argument");
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     *d_ptr = nullptr;
-    ATL_HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 256));
+    ATL_HIP_TRY(dev_malloc(d_ptr, bytes ? bytes : 256));
     return ATL_OK;
 }
 
@@ -283,7 +376,7 @@ int atl_free(atl_ctx *ctx, void *d_ptr) {
     ATL_REQUIRE(ctx, "atl_free: ctx is NULL");
     if (!d_ptr) return ATL_OK;
     ATL_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ATL_HIP_TRY(hipFree(d_ptr));
+    ATL_HIP_TRY(dev_free(d_ptr));
     return ATL_OK;
 }
 
@@ -1331,7 +1424,7 @@ int atl_agg_destroy(atl_agg *agg) {
         (void)hipSetDevice(agg->ctx->device);
         (void)hipStreamSynchronize(agg->ctx->stream);
     }
-    for (void *p : agg->allocs) (void)hipFree(p);
+    for (void *p : agg->allocs) (void)dev_free(p);
     delete agg;
     return ATL_OK;
 }

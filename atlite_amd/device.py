@@ -32,42 +32,90 @@ def pitch_for(S):
 class _PinnedBlock:
     """Page-locked host memory (``atl_pinned_alloc``) behind a NumPy array: ``np.asarray(block)`` views it through
     ``__array_interface__`` and keeps the block alive as the array's base; when the last view dies the memory goes back to a
-    small pool (page-locking costs ~100 us per allocation, a warm ``Cutout.pv()`` result is downloaded in less)."""
+    small pool (page-locking costs ~100 us per allocation, a warm ``Cutout.pv()`` result is downloaded in less).
+
+    Back-pressure: at most ``BUDGET`` bytes (``ATLITE_HIP_PINNED_BUDGET``, default 2 GiB) are page-locked at a time - blocks
+    users still hold plus the pool; past that ``_host_array`` hands out ordinary memory.  Every download into a block is
+    synchronous (``atl_download`` / ``atl_copy_2d`` return after the stream has drained), so a block that comes back here has
+    no transfer in flight.  The pool is emptied at interpreter exit."""
 
     _pool = {}  # nbytes -> [pointers]
     _pooled = 0
+    _live = 0  # bytes page-locked right now (held by users + pooled)
     _lock = threading.Lock()
     CAP = 512 << 20  # bytes kept for reuse
+    BUDGET = int(os.environ.get("ATLITE_HIP_PINNED_BUDGET", 2 << 30))
 
     def __init__(self, lib, shape, dtype):
         self.lib = lib
+        self.ptr = None
         self.nbytes = max(int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize, 1)
         with _PinnedBlock._lock:
             free = _PinnedBlock._pool.get(self.nbytes)
             self.ptr = free.pop() if free else None
             if self.ptr is not None:
                 _PinnedBlock._pooled -= self.nbytes
+            elif _PinnedBlock._live + self.nbytes > _PinnedBlock.BUDGET:
+                raise MemoryError("page-locked result budget exhausted")
+            else:
+                _PinnedBlock._live += self.nbytes
         if self.ptr is None:
             p = C.c_void_p()
-            check(lib.atl_pinned_alloc(self.nbytes, C.byref(p)))
+            try:
+                check(lib.atl_pinned_alloc(self.nbytes, C.byref(p)))
+            except Exception:
+                with _PinnedBlock._lock:
+                    _PinnedBlock._live -= self.nbytes
+                raise
             self.ptr = p.value
         self.__array_interface__ = {"shape": tuple(int(v) for v in shape), "typestr": np.dtype(dtype).str,
                                     "data": (self.ptr, False), "version": 3}
 
     def __del__(self):
         try:
+            if self.ptr is None:
+                return
             with _PinnedBlock._lock:
-                if _PinnedBlock._pooled + self.nbytes <= _PinnedBlock.CAP:
+                if _PinnedBlock._pool is not None and _PinnedBlock._pooled + self.nbytes <= _PinnedBlock.CAP:
                     _PinnedBlock._pool.setdefault(self.nbytes, []).append(self.ptr)
                     _PinnedBlock._pooled += self.nbytes
                     return
+                _PinnedBlock._live -= self.nbytes
             self.lib.atl_pinned_free(self.ptr)
         except Exception:
             pass
 
+    @staticmethod
+    def trim(lib=None):
+        """Free every pooled block (interpreter exit; tests)."""
+        with _PinnedBlock._lock:
+            ptrs = [p for v in (_PinnedBlock._pool or {}).values() for p in v]
+            held = _PinnedBlock._pooled
+            if _PinnedBlock._pool is not None:
+                _PinnedBlock._pool.clear()
+            _PinnedBlock._pooled = 0
+            _PinnedBlock._live -= held
+        if ptrs:
+            lib = lib or _lib.load()
+            for p in ptrs:
+                lib.atl_pinned_free(p)
+
+
+def _trim_pinned_at_exit():
+    try:
+        _PinnedBlock.trim()
+    except Exception:
+        pass
+
+
+import atexit  # noqa: E402
+
+atexit.register(_trim_pinned_at_exit)
+
 
 def _host_array(lib, shape, dtype):
-    """Destination of a download: page-locked for results between 64 KiB and 1 GiB (``ATLITE_HIP_PINNED_RESULTS=0``: never)."""
+    """Destination of a download: page-locked for results between 64 KiB and 1 GiB (``ATLITE_HIP_PINNED_RESULTS=0``: never;
+    ordinary memory as well once ``_PinnedBlock.BUDGET`` bytes are page-locked)."""
     nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
     if (64 << 10) <= nbytes <= (1 << 30) and os.environ.get("ATLITE_HIP_PINNED_RESULTS", "1") != "0":
         try:
@@ -148,9 +196,15 @@ class DeviceArray:
             return a
         return DeviceArray(self.ctx, self.ptr, shape, self.dtype, owner=self)
 
+    def no_recycle(self):
+        """This block is (or will be) touched by a stream the context does not own - a communicator's, another library's:
+        when it is released it goes back to the driver (``atl_free`` synchronises) instead of the context's pool."""
+        self._no_recycle = True
+        return self
+
     def free(self):
         if self._owned and self.ptr:
-            if not self.ctx._recycle(self.ptr, self.nbytes):
+            if getattr(self, "_no_recycle", False) or not self.ctx._recycle(self.ptr, self.nbytes):
                 check(self.ctx.lib.atl_free(self.ctx.handle, self.ptr))
             self.ptr = 0
 
@@ -273,30 +327,127 @@ class Context:
 
     # -- memory ---------------------------------------------------------------------------
     # small device blocks (results, per-call tables: <= 64 MiB each, 512 MiB kept) are recycled by size: hipMalloc + hipFree
-    # cost ~0.3 ms a pair - hipFree synchronises the device - which was a tenth of a warm Cutout.pv() call.  Reuse is
-    # ordered by the context's stream like the scratch arena.
+    # cost ~0.3 ms a pair - hipFree synchronises the device - which was a tenth of a warm Cutout.pv() call.
+    #
+    # Stream safety by construction (round 5): a block enters the pool together with an event pair recorded at that moment
+    # on the context's compute stream AND its copy stream - every stream of the context that can have touched the block
+    # (blocks handed to a communicator's own stream are never pooled: ``DeviceArray.no_recycle()``) - and ``empty()`` waits on
+    # the pair on the HOST before it hands the block out again, so the next user may run on any stream.  A block released by
+    # a thread other than the context's owner (a ``__del__`` run by the garbage collector) is only queued; the owner records
+    # its events when it next allocates.  ``ATLITE_HIP_RECYCLE=0`` switches recycling off (every free is ``atl_free``, which
+    # synchronises), as does the fenced allocator ``ATLITE_HIP_FENCE=1``.  An allocation that fails for lack of memory
+    # drains the pool and is retried once.
     _POOL_MAX_BLOCK, _POOL_CAP = 64 << 20, 512 << 20
+
+    def _pool_state(self):
+        st = self.__dict__.get("_pool_st")
+        if st is None:
+            on = os.environ.get("ATLITE_HIP_RECYCLE", "1") != "0" and os.environ.get("ATLITE_HIP_FENCE", "0") in ("", "0")
+            st = self.__dict__.setdefault("_pool_st", {"on": on, "lock": threading.Lock(), "free": {}, "held": 0, "deferred": [],
+                                                       "events": [], "owner": threading.get_ident()})
+        return st
+
+    def _fence_events(self):
+        """An event pair marking 'now' on the compute and the copy stream (events are reused)."""
+        st = self._pool_state()
+        pair = st["events"].pop() if st["events"] else None
+        if pair is None:
+            pair = (C.c_void_p(), C.c_void_p())
+            check(self.lib.atl_event_create(self.handle, C.byref(pair[0])))
+            check(self.lib.atl_event_create(self.handle, C.byref(pair[1])))
+        check(self.lib.atl_event_record(self.handle, pair[0], 0))
+        check(self.lib.atl_event_record(self.handle, pair[1], 1))
+        return pair
 
     def _recycle(self, ptr, nbytes):
         if not (0 < nbytes <= self._POOL_MAX_BLOCK) or getattr(self, "handle", None) is None:
             return False
-        pool = self.__dict__.setdefault("_dev_pool", {})
-        held = self.__dict__.get("_dev_pooled", 0)
-        if held + nbytes > self._POOL_CAP:
+        st = self._pool_state()
+        if not st["on"]:
             return False
-        pool.setdefault(nbytes, []).append(ptr)
-        self._dev_pooled = held + nbytes
+        with st["lock"]:
+            if st["held"] + nbytes > self._POOL_CAP:
+                return False
+            st["held"] += nbytes
+            if threading.get_ident() != st["owner"]:
+                st["deferred"].append((ptr, nbytes))  # the owner records the events (``_drain_deferred``)
+                return True
+        try:
+            pair = self._fence_events()
+        except Exception:
+            with st["lock"]:
+                st["held"] -= nbytes
+            return False
+        with st["lock"]:
+            st["free"].setdefault(nbytes, []).append((ptr, pair))
         return True
+
+    def _drain_deferred(self, st):
+        with st["lock"]:
+            todo, st["deferred"] = st["deferred"], []
+        if not todo:
+            return
+        pair = None
+        for ptr, nbytes in todo:
+            try:
+                pair = self._fence_events()
+            except Exception:
+                pair = None
+            if pair is None:
+                with st["lock"]:
+                    st["held"] -= nbytes
+                self.lib.atl_free(self.handle, ptr)
+                continue
+            with st["lock"]:
+                st["free"].setdefault(nbytes, []).append((ptr, pair))
+
+    def _pool_take(self, nbytes):
+        st = self._pool_state()
+        if not st["on"]:
+            return None
+        if st["deferred"] and threading.get_ident() == st["owner"]:
+            self._drain_deferred(st)
+        with st["lock"]:
+            free = st["free"].get(nbytes)
+            if not free:
+                return None
+            ptr, pair = free.pop()
+            st["held"] -= nbytes
+        # everything enqueued on the context's streams before the block was released has finished
+        check(self.lib.atl_event_synchronize(pair[0]))
+        check(self.lib.atl_event_synchronize(pair[1]))
+        with st["lock"]:
+            st["events"].append(pair)
+        return ptr
+
+    def trim(self):
+        """Give every pooled device block back to the driver."""
+        st = self.__dict__.get("_pool_st")
+        if st is None or getattr(self, "handle", None) is None:
+            return
+        with st["lock"]:
+            blocks = [b for v in st["free"].values() for b in v]
+            todo, st["deferred"] = st["deferred"], []
+            st["free"].clear()
+            st["held"] = 0
+        for ptr, pair in blocks:
+            self.lib.atl_free(self.handle, ptr)  # synchronises the compute stream, then hipFree (which waits for the device)
+            st["events"].append(pair)
+        for ptr, _ in todo:
+            self.lib.atl_free(self.handle, ptr)
 
     def empty(self, shape, dtype=np.float64):
         shape = (shape,) if np.isscalar(shape) else tuple(shape)
         nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
-        free = self.__dict__.get("_dev_pool", {}).get(nbytes)
-        if free:
-            self._dev_pooled -= nbytes
-            return DeviceArray(self, free.pop(), shape, dtype)
+        ptr = self._pool_take(nbytes) if 0 < nbytes <= self._POOL_MAX_BLOCK else None
+        if ptr is not None:
+            return DeviceArray(self, ptr, shape, dtype)
         p = C.c_void_p()
-        check(self.lib.atl_alloc(self.handle, nbytes, C.byref(p)))
+        rc = self.lib.atl_alloc(self.handle, nbytes, C.byref(p))
+        if rc == _lib.ATL_E_NOMEM and self.__dict__.get("_pool_st", {}).get("held"):
+            self.trim()
+            rc = self.lib.atl_alloc(self.handle, nbytes, C.byref(p))
+        check(rc)
         return DeviceArray(self, p.value, shape, dtype)
 
     def zeros(self, shape, dtype=np.float64):
@@ -705,10 +856,11 @@ class Context:
         for p in self.__dict__.pop("_plan_cache", {}).values():
             p.close()
         if getattr(self, "handle", None):
-            for ptrs in self.__dict__.pop("_dev_pool", {}).values():
-                for ptr in ptrs:
-                    self.lib.atl_free(self.handle, ptr)
-            self._dev_pooled = 0
+            self.trim()
+            for pair in self.__dict__.get("_pool_st", {}).get("events", []):
+                for ev in pair:
+                    self.lib.atl_event_destroy(ev)
+            self.__dict__.pop("_pool_st", None)
         ev = self.__dict__.pop("_copy_ev", None)
         if ev is not None:
             self.lib.atl_event_destroy(ev)

@@ -199,8 +199,10 @@ class RcclComm:
 
         total = int(sum(lens))
         if out is None:
-            out = self.ctx.empty((N, total))
+            out = self.ctx.empty((N, total)).no_recycle()  # written on the communicator's stream
         h_lens = (C.c_int64 * self.n_ranks)(*[int(v) for v in lens])
+        if local is not None and hasattr(local, "no_recycle"):
+            local.no_recycle()  # read on the communicator's stream
         check(self.ctx.lib.atl_allgather_time_v(self.handle, local.ptr if local is not None else None, N, h_lens,
                                                 out.ptr, total))
         return out
@@ -210,13 +212,14 @@ class RcclComm:
         from ._lib import check
 
         N, T_r = local.shape
-        out = self.ctx.empty((N, self.n_ranks * T_r))
+        out = self.ctx.empty((N, self.n_ranks * T_r)).no_recycle()
         check(self.ctx.lib.atl_allgather_time(self.handle, local.ptr, N, T_r, out.ptr, self.n_ranks * T_r))
         return out
 
     def allreduce_sum(self, buf):
         from ._lib import check
 
+        buf.no_recycle()  # reduced in place on the communicator's stream
         check(self.ctx.lib.atl_allreduce_sum(self.handle, buf.ptr, buf.size))
         return buf
 

@@ -882,3 +882,132 @@ def test_pinned_result_blocks_are_pooled_and_outlive_their_views():
     gc.collect()
     device._PinnedBlock._pool.clear()
     device._PinnedBlock._pooled = 0
+
+
+def test_pinned_results_respect_the_budget_and_trim(monkeypatch):
+    """Past ``_PinnedBlock.BUDGET`` page-locked bytes a download's destination is ordinary memory; ``trim`` frees the pool."""
+    import ctypes as C
+    import gc
+
+    from atlite_amd import device
+
+    class FakeLib:
+        def __init__(self):
+            self.live = {}
+
+        def atl_pinned_alloc(self, n, pp):
+            buf = (C.c_char * n)()
+            self.live[C.addressof(buf)] = buf
+            pp._obj.value = C.addressof(buf)
+            return 0
+
+        def atl_pinned_free(self, p):
+            self.live.pop(p)
+            return 0
+
+    lib = FakeLib()
+    device._PinnedBlock.trim(lib)
+    monkeypatch.setattr(device._PinnedBlock, "_live", 0)
+    monkeypatch.setattr(device._PinnedBlock, "BUDGET", 2_000_000)
+    a = device._host_array(lib, (100, 1000), np.float64)  # 800 kB
+    b = device._host_array(lib, (100, 1000), np.float64)
+    c = device._host_array(lib, (100, 1000), np.float64)  # would be 2.4 MB page-locked: ordinary memory
+    assert isinstance(a.base, device._PinnedBlock) and isinstance(b.base, device._PinnedBlock) and c.base is None
+    assert device._PinnedBlock._live == 1_600_000 and len(lib.live) == 2
+    del a, b
+    gc.collect()
+    assert device._PinnedBlock._pooled == 1_600_000 and device._PinnedBlock._live == 1_600_000
+    device._PinnedBlock.trim(lib)
+    assert device._PinnedBlock._pooled == 0 and device._PinnedBlock._live == 0 and not lib.live
+
+
+def test_device_block_recycling_is_ordered_by_events(monkeypatch):
+    """Context.empty / DeviceArray.free: a released block is handed out again only after the events recorded on the compute
+    and the copy stream at its release have been waited for; releases from another thread are queued for the owner;
+    ``ATLITE_HIP_RECYCLE=0`` and blocks marked ``no_recycle()`` go straight back to the driver; an allocation that fails for
+    lack of memory drains the pool and is retried."""
+    import threading
+
+    from atlite_amd import _lib, device
+
+    class FakeLib:
+        def __init__(self):
+            self.log, self.next, self.fail_once = [], 0x1000, False
+            self.freed = []
+
+        def atl_alloc(self, h, n, pp):
+            if self.fail_once:
+                self.fail_once = False
+                return _lib.ATL_E_NOMEM
+            self.next += 0x1000
+            pp._obj.value = self.next
+            self.log.append(("alloc", self.next))
+            return 0
+
+        def atl_free(self, h, p):
+            self.freed.append(p)
+            return 0
+
+        def atl_event_create(self, h, pe):
+            self.next += 1
+            pe._obj.value = self.next
+            return 0
+
+        def atl_event_record(self, h, ev, which):
+            self.log.append(("record", ev.value, which))
+            return 0
+
+        def atl_event_synchronize(self, ev):
+            self.log.append(("wait", ev.value))
+            return 0
+
+        def atl_event_destroy(self, ev):
+            return 0
+
+        def atl_destroy(self, h):
+            return 0
+
+    def make():
+        ctx = device.Context.__new__(device.Context)
+        ctx.lib, ctx.handle, ctx.device = FakeLib(), object(), 0
+        return ctx
+
+    monkeypatch.delenv("ATLITE_HIP_RECYCLE", raising=False)
+    monkeypatch.delenv("ATLITE_HIP_FENCE", raising=False)
+    ctx = make()
+    a = ctx.empty((1000,))
+    pa = a.ptr
+    del a  # released by the owner: events recorded on both streams right away
+    recs = [e for e in ctx.lib.log if e[0] == "record"]
+    assert [r[2] for r in recs] == [0, 1] and not ctx.lib.freed
+    b = ctx.empty((1000,))  # same size: the pooled block, after both events were waited for
+    waits = [e[1] for e in ctx.lib.log if e[0] == "wait"]
+    assert b.ptr == pa and waits == [recs[0][1], recs[1][1]]
+    c = ctx.empty((999,))  # another size: a fresh allocation
+    assert c.ptr != pa
+    # released by another thread (a garbage collector's __del__): queued, the owner records the events at its next allocation
+    n_rec = len([e for e in ctx.lib.log if e[0] == "record"])
+    t = threading.Thread(target=b.free)
+    t.start()
+    t.join()
+    assert len([e for e in ctx.lib.log if e[0] == "record"]) == n_rec and ctx._pool_st["deferred"]
+    d = ctx.empty((1000,))
+    assert d.ptr == pa and len([e for e in ctx.lib.log if e[0] == "record"]) == n_rec + 2 and not ctx._pool_st["deferred"]
+    # no_recycle(): back to the driver
+    d.no_recycle().free()
+    assert ctx.lib.freed == [pa]
+    # out of memory: the pool is drained, the allocation retried
+    c.free()
+    assert ctx._pool_st["held"] == 999 * 8
+    ctx.lib.fail_once = True
+    e = ctx.empty((5,))
+    assert e.ptr and ctx._pool_st["held"] == 0 and len(ctx.lib.freed) == 2
+    ctx.close()
+    # switched off
+    monkeypatch.setenv("ATLITE_HIP_RECYCLE", "0")
+    ctx2 = make()
+    x = ctx2.empty((1000,))
+    px = x.ptr
+    del x
+    assert ctx2.lib.freed == [px] and not [e for e in ctx2.lib.log if e[0] == "record"]
+    ctx2.close()
