@@ -1023,25 +1023,8 @@ void File::resolve_dims() {
 }
 
 // ---- chunk payloads -------------------------------------------------------------------------------
-int chunk_inflate(const Dataset &d, const Chunk &c, const uint8_t *file_base, int fd, uint8_t *dst, uint64_t dst_n,
-                  bool *shuffled) {
-    const uint8_t *src = file_base + c.addr;
+int chunk_filters(const Dataset &d, const Chunk &c, uint64_t *payload_n, bool *deflate_out, bool *shuffled) {
     uint64_t n = c.size;
-    if (fd >= 0) {
-        static thread_local std::vector<uint8_t> buf;
-        if (buf.size() < n) buf.resize(size_t(n + n / 2));
-        uint64_t got = 0;
-        while (got < n) {
-            const ssize_t r = pread(fd, buf.data() + got, size_t(n - got), off_t(c.addr + got));
-            if (r <= 0) {
-                set_error("dataset '%s': read of %llu bytes at offset %llu failed", d.name.c_str(),
-                          (unsigned long long)n, (unsigned long long)c.addr);
-                return ATL_E_INVALID;
-            }
-            got += uint64_t(r);
-        }
-        src = buf.data();
-    }
     *shuffled = false;
     int i_shuffle = -1, i_deflate = -1;
     bool deflate = false;
@@ -1075,6 +1058,37 @@ int chunk_inflate(const Dataset &d, const Chunk &c, const uint8_t *file_base, in
     if (i_shuffle >= 0 && i_deflate >= 0 && i_shuffle > i_deflate) {
         set_error("dataset '%s': shuffle after deflate is not supported", d.name.c_str());
         return ATL_E_UNSUPPORTED;
+    }
+    *payload_n = n;
+    *deflate_out = deflate;
+    return ATL_OK;
+}
+
+int chunk_inflate(const Dataset &d, const Chunk &c, const uint8_t *file_base, int fd, uint8_t *dst, uint64_t dst_n,
+                  bool *shuffled) {
+    const uint8_t *src = file_base + c.addr;
+    uint64_t n = c.size;
+    if (fd >= 0) {
+        static thread_local std::vector<uint8_t> buf;
+        if (buf.size() < n) buf.resize(size_t(n + n / 2));
+        uint64_t got = 0;
+        while (got < n) {
+            const ssize_t r = pread(fd, buf.data() + got, size_t(n - got), off_t(c.addr + got));
+            if (r <= 0) {
+                set_error("dataset '%s': read of %llu bytes at offset %llu failed", d.name.c_str(),
+                          (unsigned long long)n, (unsigned long long)c.addr);
+                return ATL_E_INVALID;
+            }
+            got += uint64_t(r);
+        }
+        src = buf.data();
+    }
+    bool deflate = false;
+    {
+        uint64_t payload = 0;
+        const int rc = chunk_filters(d, c, &payload, &deflate, shuffled);
+        if (rc) return rc;
+        n = payload;
     }
     if (deflate) {
         static const bool use_fast = [] {

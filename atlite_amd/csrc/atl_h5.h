@@ -141,10 +141,17 @@ class File {
 // pages of one mapping in contend on the address-space lock), else straight from the mapping.
 int chunk_inflate(const Dataset &d, const Chunk &c, const uint8_t *file_base, int fd, uint8_t *dst, uint64_t dst_n,
                   bool *shuffled);
+// what the reverse pipeline of one stored chunk amounts to: the first *payload_n stored bytes are a zlib stream
+// (*deflate) or the chunk itself, still byte-shuffled or not (*shuffled); the fletcher32 trailer is cut off
+int chunk_filters(const Dataset &d, const Chunk &c, uint64_t *payload_n, bool *deflate, bool *shuffled);
 
 // zlib-wrapped DEFLATE stream -> exactly dst_n bytes (atl_inflate.cpp).  0 = done and Adler-32
 // verified; non-zero = not handled (malformed, truncated, checksum or size mismatch): the caller must
 // let zlib's own inflate decide.
 int fast_inflate_zlib(const uint8_t *src, uint64_t src_n, uint8_t *dst, uint64_t dst_n);
+
+// The serial half of the DEVICE decoder (atl_inflate_dev.h) executed on the host: a test entry (atl_inflate_probe which = 3).
+// 0 = exactly dst_n bytes and the Adler-32 matches, else the decoder's dinf::Status.
+int device_inflate_emulated(const uint8_t *src, uint64_t src_n, uint8_t *dst, uint64_t dst_n);
 
 }}  // namespace atl::h5

@@ -15,6 +15,10 @@
 
 #include "atl_h5.h"
 
+#include <vector>
+#define ATL_HD
+#include "atl_inflate_dev.h"
+
 namespace atl { namespace h5 {
 
 namespace {
@@ -459,6 +463,55 @@ int fast_inflate_zlib(const uint8_t *src, uint64_t src_n, uint8_t *dst, uint64_t
     if (b.end - b.p < 4) return 4;
     const uint32_t want = (uint32_t(b.p[0]) << 24) | (uint32_t(b.p[1]) << 16) | (uint32_t(b.p[2]) << 8) | uint32_t(b.p[3]);
     return adler32_of(dst, dst_n) == want ? 0 : 5;
+}
+
+
+// ---- the device decoder's serial half, run on the host (atl_inflate_dev.h) ------------------------------------------
+// Same templates the wave executes, over ordinary memory; the batch resolution (parallel on the device) is the obvious
+// serial loop here.  Returns the decoder's Status (0 = ok and Adler-32 verified).  CPU tests and tools/fuzz_inflate.py
+// hold it against zlib; it is never on the product's path.
+namespace {
+struct HostSink {
+    const uint8_t *src;
+    uint8_t *dst;
+    uint32_t rec[dinf::kQueue];
+    uint64_t pos[dinf::kQueue];
+    uint64_t max_batch = 0;
+    void put(int i, uint32_t r, uint64_t p) {
+        rec[i] = r;
+        pos[i] = p;
+    }
+    void tables_ready() {}
+    void stored(uint64_t byte_pos, uint32_t len, uint64_t out_pos) { memcpy(dst + out_pos, src + byte_pos, len); }
+    void resolve(int n, uint64_t bstart, uint64_t bend) {
+        if (bend - bstart > max_batch) max_batch = bend - bstart;
+        for (int i = 0; i < n; ++i) {
+            if (rec[i] & dinf::kLitFlag) {
+                dst[pos[i]] = uint8_t(rec[i]);
+            } else {
+                const uint32_t len = rec[i] & 0x1FF, dist = (rec[i] & 0x7FFFFFFF) >> 9;
+                for (uint32_t j = 0; j < len; ++j) dst[pos[i] + j] = dst[pos[i] - dist + j];
+            }
+        }
+    }
+};
+}  // namespace
+
+int device_inflate_emulated(const uint8_t *src, uint64_t src_n, uint8_t *dst, uint64_t dst_n) {
+    using namespace dinf;
+    std::vector<uint32_t> words(size_t(src_n / 4 + 3), 0u);
+    if (src_n) memcpy(words.data(), src, size_t(src_n));
+    std::vector<uint32_t> lit(kLitCap), off(kOffCap), codes(320), cnt(16), nxt(16);
+    std::vector<uint8_t> sub_bits(size_t(1) << kLitBits), lens(512);
+    Areas<HostMem> A{lit.data(), off.data(), codes.data(), cnt.data(), nxt.data(), sub_bits.data(), lens.data()};
+    HostSink sink{};
+    sink.src = reinterpret_cast<const uint8_t *>(words.data());
+    sink.dst = dst;
+    uint32_t want = 0;
+    const int st = inflate_stream<HostMem, HostSink>(A, words.data(), uint32_t((src_n + 3) / 4), src_n, dst_n, sink, &want);
+    if (st) return st;
+    if (sink.max_batch > uint64_t(kStage)) return 100;  // the staging area of the device would have overflowed
+    return adler32_of(dst, dst_n) == want ? kOk : kAdler;
 }
 
 }}  // namespace atl::h5

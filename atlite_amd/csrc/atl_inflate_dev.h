@@ -1,0 +1,474 @@
+// DEFLATE (RFC 1951) inside a zlib wrapper (RFC 1950), decoded by ONE WAVEFRONT per stream on the device: the serial half.
+//
+// Why: a cutout file is thousands of independent zlib streams (one per HDF5 chunk, atlite/data.py:246-248 writes them with
+// zlib + shuffle); inflating them on the 16 host cores a container is granted is the whole cost of Cutout(path).pv()
+// (VERDICT r4 item 2).  On the device every chunk gets its own wave: the chip decodes a few thousand streams at once and
+// PCIe carries the COMPRESSED bytes.
+//
+// Split of a wave's work (k_inflate, atl_ingest.hip):
+//   * serial, wave-uniform (this header): bit reader, block headers, canonical Huffman tables in LDS, symbol decode into a
+//     batch of up to 64 (literal | length, distance) records.  Every lane executes the same instructions on the same
+//     values, so the compiler keeps the state in SGPRs and reads the input through the scalar cache; LDS reads come back
+//     through v_readfirstlane.
+//   * parallel (atl_ingest.hip): the batch is resolved into an LDS staging area by all 64 lanes (lane i owns record i)
+//     and flushed to HBM.
+// The serial half is plain C++ over a memory policy M (HostMem: ordinary pointers; the device's WaveMem: LDS pointers,
+// readfirstlane loads, lane-0 stores), so the CPU suite runs exactly this code against zlib
+// (atl_inflate_probe(which = 3), tools/fuzz_inflate.py) without a GPU.  Untrusted input: every table index, every
+// length and every position is bounded here; the decoder can fail, it cannot loop forever or leave its buffers.
+#pragma once
+#include <cstdint>
+
+#ifndef ATL_HD
+#define ATL_HD __host__ __device__
+#endif
+
+namespace atl { namespace dinf {
+
+constexpr int kLitBits = 10, kLitCap = 2048;   // primary table + sub-tables (zlib's bound for a 10-bit root: 1332)
+constexpr int kOffBits = 8, kOffCap = 1024;
+constexpr int kPreBits = 7, kPreCap = 128;
+constexpr int kQueue = 64;                      // records per batch: one per lane
+constexpr int kMaxMatch = 258;
+constexpr int kStage = 2048;                    // output bytes staged per batch (a batch ends once fewer than kMaxMatch are free)
+
+enum Status : int {
+    kOk = 0,
+    kBadHeader = 1,    // not a zlib stream with the deflate method / preset dictionary
+    kBadBlock = 2,     // reserved block type, stored-block length check, truncated header
+    kBadCode = 3,      // over-subscribed / incomplete Huffman code, bad repeat in the code lengths
+    kBadSymbol = 4,    // a bit pattern without a code
+    kBadDistance = 5,  // distance reaches before the start of the output
+    kOutputFull = 6,   // more bytes than the chunk holds
+    kShort = 7,        // stream ended before the chunk was full
+    kInputOverrun = 8, // consumed more bits than the stream has
+    kAdler = 9,        // Adler-32 mismatch (set by the checksum kernel)
+    kNotRun = 15,
+};
+
+// table entry: len (6) | extra (4) << 6 | kind (2) << 10 | value << 16
+enum : uint32_t { kBase = 0, kLiteral = 1, kEnd = 2, kSub = 3 };
+ATL_HD inline uint32_t mk(uint32_t len, uint32_t extra, uint32_t kind, uint32_t value) {
+    return len | (extra << 6) | (kind << 10) | (value << 16);
+}
+ATL_HD inline uint32_t e_len(uint32_t e) { return e & 0x3F; }
+ATL_HD inline uint32_t e_extra(uint32_t e) { return (e >> 6) & 0xF; }
+ATL_HD inline uint32_t e_kind(uint32_t e) { return (e >> 10) & 0x3; }
+ATL_HD inline uint32_t e_value(uint32_t e) { return e >> 16; }
+
+// base values and extra-bit counts of the length / distance symbols, computed (no constant tables to place in device memory)
+ATL_HD inline uint32_t len_extra(int s) {  // s = symbol - 257, 0..28
+    return (s < 8 || s == 28) ? 0u : uint32_t((s - 4) >> 2);
+}
+ATL_HD inline uint32_t len_base(int s) {
+    if (s < 8) return uint32_t(3 + s);
+    if (s == 28) return 258u;
+    const uint32_t x = uint32_t((s - 4) >> 2);
+    return 3u + ((4u + uint32_t(s & 3)) << x);
+}
+ATL_HD inline uint32_t off_extra(int s) {  // s = 0..29
+    return s < 4 ? 0u : uint32_t((s - 2) >> 1);
+}
+ATL_HD inline uint32_t off_base(int s) {
+    if (s < 4) return uint32_t(1 + s);
+    const uint32_t x = uint32_t((s - 2) >> 1);
+    return 1u + ((2u + uint32_t(s & 1)) << x);
+}
+
+ATL_HD inline uint32_t bit_reverse(uint32_t code, int len) {
+    uint32_t r = 0;
+    for (int i = 0; i < len; ++i) {
+        r = (r << 1) | (code & 1);
+        code >>= 1;
+    }
+    return r;
+}
+
+enum TableKind { kLitlenTable, kOffsetTable, kPrecodeTable };
+
+ATL_HD inline uint32_t entry_for(TableKind what, int sym, uint32_t len) {
+    if (what == kPrecodeTable) return mk(len, 0, kLiteral, uint32_t(sym));
+    if (what == kOffsetTable) return sym < 30 ? mk(len, off_extra(sym), kBase, off_base(sym)) : 0u;
+    if (sym < 256) return mk(len, 0, kLiteral, uint32_t(sym));
+    if (sym == 256) return mk(len, 0, kEnd, 0);
+    return sym < 286 ? mk(len, len_extra(sym - 257), kBase, len_base(sym - 257)) : 0u;
+}
+
+// ---- memory policies ---------------------------------------------------------------------------------------------
+struct HostMem {
+    typedef uint32_t *u32p;
+    typedef uint8_t *u8p;
+    typedef const uint32_t *src_t;
+    static inline uint32_t ld32(const uint32_t *p) { return *p; }
+    static inline uint32_t ld8(const uint8_t *p) { return *p; }
+    static inline void st32(uint32_t *p, uint32_t v) { *p = v; }
+    static inline void st8(uint8_t *p, uint32_t v) { *p = uint8_t(v); }
+    static inline uint32_t src(const uint32_t *w, uint32_t i) { return w[i]; }
+};
+
+// LDS areas of one stream's decoder (device: carved out of the workgroup's shared memory; host: a struct on the heap)
+template <class M>
+struct Areas {
+    typename M::u32p lit;      // [kLitCap]
+    typename M::u32p off;      // [kOffCap]  (its first kPreCap entries double as the precode table while a header is parsed)
+    typename M::u32p codes;    // [320]  bit-reversed code of every symbol (table construction)
+    typename M::u32p cnt;      // [16]   codes per length
+    typename M::u32p nxt;      // [16]   next code per length
+    typename M::u8p sub_bits;  // [1 << kLitBits] widest long code behind a primary slot
+    typename M::u8p lens;      // [286 + 30 + 138] code lengths of the block
+};
+
+// canonical Huffman decode table, single lookup + one sub-table level.  Returns false for an invalid code.
+template <class M>
+ATL_HD inline bool build_table(const Areas<M> &A, typename M::u8p lens, int n, int table_bits, int cap, TableKind what,
+                               typename M::u32p table) {
+    for (int l = 0; l < 16; ++l) M::st32(A.cnt + l, 0);
+    for (int i = 0; i < n; ++i) {
+        const uint32_t l = M::ld8(lens + i) & 15u;
+        M::st32(A.cnt + l, M::ld32(A.cnt + l) + 1);
+    }
+    if (int(M::ld32(A.cnt + 0)) == n) return false;  // no codes at all
+    int left = 1, used = 0;
+    uint32_t code = 0, prev_count = 0;
+    uint32_t count1 = 0;
+    for (int l = 1; l <= 15; ++l) {
+        const uint32_t c = M::ld32(A.cnt + l);
+        if (l == 1) count1 = c;
+        left = (left << 1) - int(c);
+        if (left < 0) return false;  // over-subscribed
+        used += int(c);
+        code = (code + prev_count) << 1;  // unused symbols (length 0) take no code space: prev_count starts at 0
+        M::st32(A.nxt + l, code);
+        prev_count = c;
+    }
+    if (left > 0 && !(used == 1 && count1 == 1)) return false;  // incomplete (zlib allows a single 1-bit code)
+    const uint32_t tsize = 1u << table_bits;
+    for (uint32_t i = 0; i < tsize; ++i) {
+        M::st32(table + i, 0);  // len 0 = invalid
+        M::st8(A.sub_bits + i, 0);
+    }
+    bool any_long = false;
+    for (int s = 0; s < n; ++s) {
+        const int l = int(M::ld8(lens + s) & 15u);
+        if (!l) continue;
+        const uint32_t c = M::ld32(A.nxt + l);
+        M::st32(A.nxt + l, c + 1);
+        const uint32_t r = bit_reverse(c, l);
+        M::st32(A.codes + s, r);
+        if (l <= table_bits) {
+            const uint32_t e = entry_for(what, s, uint32_t(l));
+            for (uint32_t i = r; i < tsize; i += 1u << l) M::st32(table + i, e);
+        } else {
+            const uint32_t p = r & (tsize - 1);
+            if (uint32_t(l - table_bits) > M::ld8(A.sub_bits + p)) M::st8(A.sub_bits + p, uint32_t(l - table_bits));
+            any_long = true;
+        }
+    }
+    if (!any_long) return true;
+    uint32_t pos = tsize;
+    for (uint32_t p = 0; p < tsize; ++p) {
+        const uint32_t sb = M::ld8(A.sub_bits + p);
+        if (!sb) continue;
+        if (pos + (1u << sb) > uint32_t(cap)) return false;
+        M::st32(table + p, mk(uint32_t(table_bits), sb, kSub, pos));
+        for (uint32_t i = 0; i < (1u << sb); ++i) M::st32(table + pos + i, 0);
+        pos += 1u << sb;
+    }
+    for (int s = 0; s < n; ++s) {
+        const int l = int(M::ld8(lens + s) & 15u);
+        if (l <= table_bits) continue;
+        const uint32_t r = M::ld32(A.codes + s);
+        const uint32_t p = r & (tsize - 1);
+        const uint32_t link = M::ld32(table + p);
+        const uint32_t start = e_value(link), sb = e_extra(link);
+        const uint32_t e = entry_for(what, s, uint32_t(l - table_bits));
+        for (uint32_t i = r >> table_bits; i < (1u << sb); i += 1u << (l - table_bits)) M::st32(table + start + i, e);
+    }
+    return true;
+}
+
+// ---- bit reader over 32-bit words --------------------------------------------------------------------------------------
+// The stream lies in a word-aligned buffer of n_words words (bytes past the stream's end inside the last word, and any
+// words beyond, read as whatever is there / as zero: consumption is checked against the stream's bit count, and every
+// decoded value is bounded by the tables).  One word is always loaded ahead of its use, so the load's latency hides behind the symbols
+// decoded in between.
+template <class M>
+struct Bits {
+    typename M::src_t w;
+    uint32_t n_words, wpos;  // wpos: index of the word held in `ahead`
+    uint64_t buf;
+    int cnt;
+    uint32_t ahead;
+    uint64_t taken;  // bits handed to the buffer so far
+
+    ATL_HD inline uint32_t word(uint32_t i) const { return i < n_words ? M::src(w, i) : 0u; }
+    ATL_HD inline void start(typename M::src_t words, uint32_t n, uint64_t bit_pos) {
+        w = words;
+        n_words = n;
+        wpos = uint32_t(bit_pos >> 5);
+        buf = 0;
+        cnt = 0;
+        ahead = word(wpos);
+        taken = uint64_t(wpos) * 32;
+        refill();
+        drop(int(bit_pos & 31));
+    }
+    ATL_HD inline void refill() {  // afterwards cnt >= 33
+        if (cnt <= 32) {
+            buf |= uint64_t(ahead) << cnt;
+            cnt += 32;
+            taken += 32;
+            ++wpos;
+            ahead = word(wpos);
+        }
+    }
+    ATL_HD inline uint32_t peek(int n) const { return uint32_t(buf) & ((1u << n) - 1u); }  // n <= 16
+    ATL_HD inline void drop(int n) {
+        buf >>= n;
+        cnt -= n;
+    }
+    ATL_HD inline uint32_t take(int n) {
+        const uint32_t v = peek(n);
+        drop(n);
+        return v;
+    }
+    ATL_HD inline uint64_t consumed() const { return taken - uint64_t(cnt); }  // bits of the stream used so far
+};
+
+// ---- block header -------------------------------------------------------------------------------------------------------
+// type 2: code lengths -> both tables.  type 1: the fixed code's tables.  Returns a Status.
+template <class M>
+ATL_HD inline int dynamic_tables(const Areas<M> &A, Bits<M> &b) {
+    b.refill();
+    const int hlit = int(b.take(5)) + 257;
+    const int hdist = int(b.take(5)) + 1;
+    const int hclen = int(b.take(4)) + 4;
+    if (hlit > 286 || hdist > 30) return kBadCode;
+    // precode lengths in their transmission order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+    for (int i = 0; i < 19; ++i) M::st8(A.lens + i, 0);
+    for (int i = 0; i < hclen; ++i) {
+        b.refill();
+        const uint32_t v = b.take(3);
+        // order[i] computed (no constant table to place in device memory): from i = 4 on it alternates around 8
+        int o;
+        if (i < 3) {
+            o = 16 + i;
+        } else if (i == 3) {
+            o = 0;
+        } else {
+            const int k = i - 4;            // 0 1 2 3 4 ...
+            const int step = (k + 1) >> 1;  // 0 1 1 2 2 3 3 ...
+            o = (k & 1) ? 8 - step : 8 + step;
+        }
+        M::st8(A.lens + o, v);
+    }
+    typename M::u32p pre = A.off;  // the offset table's space: it is rebuilt after the lengths have been read
+    if (!build_table<M>(A, A.lens, 19, kPreBits, kPreCap, kPrecodeTable, pre)) return kBadCode;
+    // the code lengths of both alphabets as one run-length coded sequence (kept past the precode's 19 bytes)
+    typename M::u8p lens = A.lens + 32;
+    const int total = hlit + hdist;
+    int i = 0;
+    uint32_t last = 0;
+    while (i < total) {
+        b.refill();
+        const uint32_t e = M::ld32(pre + b.peek(kPreBits));
+        const int l = int(e_len(e));
+        if (!l) return kBadCode;
+        b.drop(l);
+        const uint32_t sym = e_value(e);
+        if (sym < 16) {
+            M::st8(lens + i, sym);
+            last = sym;
+            ++i;
+            continue;
+        }
+        int rep;
+        uint32_t v;
+        if (sym == 16) {
+            if (i == 0) return kBadCode;
+            rep = 3 + int(b.take(2));
+            v = last;
+        } else if (sym == 17) {
+            rep = 3 + int(b.take(3));
+            v = 0;
+        } else {
+            rep = 11 + int(b.take(7));
+            v = 0;
+        }
+        if (i + rep > total) return kBadCode;  // zlib: "invalid bit length repeat"
+        for (int k = 0; k < rep; ++k) M::st8(lens + i + k, v);
+        last = v;
+        i += rep;
+    }
+    if (M::ld8(lens + 256) == 0) return kBadCode;  // no end-of-block code
+    if (!build_table<M>(A, lens, hlit, kLitBits, kLitCap, kLitlenTable, A.lit)) return kBadCode;
+    bool any_off = false;
+    for (int k = 0; k < hdist; ++k) any_off = any_off || M::ld8(lens + hlit + k) != 0;
+    if (any_off) {
+        if (!build_table<M>(A, lens + hlit, hdist, kOffBits, kOffCap, kOffsetTable, A.off)) return kBadCode;
+    } else {  // a block of literals only may carry an empty offset code
+        for (int k = 0; k < (1 << kOffBits); ++k) M::st32(A.off + k, 0);
+    }
+    return kOk;
+}
+
+template <class M>
+ATL_HD inline int fixed_tables(const Areas<M> &A) {
+    typename M::u8p lens = A.lens + 32;
+    for (int i = 0; i < 288; ++i) M::st8(lens + i, i < 144 ? 8u : i < 256 ? 9u : i < 280 ? 7u : 8u);
+    for (int i = 0; i < 32; ++i) M::st8(lens + 288 + i, 5u);
+    if (!build_table<M>(A, lens, 288, kLitBits, kLitCap, kLitlenTable, A.lit)) return kBadCode;
+    if (!build_table<M>(A, lens + 288, 32, kOffBits, kOffCap, kOffsetTable, A.off)) return kBadCode;
+    return kOk;
+}
+
+// ---- one batch of symbols ---------------------------------------------------------------------------------------------------
+// Records: literal = 0x80000000 | byte; match = length (9 bits) | distance << 9.  `Sink::put(i, record, pos)` stores
+// record i of the batch (device: lane i keeps it in registers; host: arrays).  Decoding stops at the end of the block
+// (*eob), after kQueue records, or when fewer than kMaxMatch bytes of the staging area would be left.
+constexpr uint32_t kLitFlag = 0x80000000u;
+
+template <class M, class Sink>
+ATL_HD inline int decode_batch(const Areas<M> &A, Bits<M> &b, uint64_t &out_pos, uint64_t out_n, Sink &sink, int &n_out,
+                               bool &eob) {
+    const uint64_t bstart = out_pos;
+    int n = 0;
+    eob = false;
+    int status = kOk;
+    while (n < kQueue && out_pos - bstart <= uint64_t(kStage - kMaxMatch)) {
+        b.refill();
+        uint32_t e = M::ld32(A.lit + b.peek(kLitBits));
+        if (e_kind(e) == kSub) {
+            b.drop(kLitBits);
+            e = M::ld32(A.lit + ((e_value(e) + b.peek(int(e_extra(e)))) & uint32_t(kLitCap - 1)));
+        }
+        const int l = int(e_len(e));
+        if (!l) {
+            status = kBadSymbol;
+            break;
+        }
+        b.drop(l);
+        const uint32_t kind = e_kind(e);
+        if (kind == kLiteral) {
+            if (out_pos >= out_n) {
+                status = kOutputFull;
+                break;
+            }
+            sink.put(n, kLitFlag | e_value(e), out_pos);
+            ++n;
+            ++out_pos;
+            continue;
+        }
+        if (kind == kEnd) {
+            eob = true;
+            break;
+        }
+        if (kind != kBase) {  // a sub-table link inside a sub-table: never built
+            status = kBadSymbol;
+            break;
+        }
+        const uint32_t length = e_value(e) + b.take(int(e_extra(e)));
+        b.refill();
+        uint32_t o = M::ld32(A.off + b.peek(kOffBits));
+        if (e_kind(o) == kSub) {
+            b.drop(kOffBits);
+            o = M::ld32(A.off + ((e_value(o) + b.peek(int(e_extra(o)))) & uint32_t(kOffCap - 1)));
+        }
+        const int lo = int(e_len(o));
+        if (!lo || e_kind(o) != kBase) {
+            status = kBadSymbol;
+            break;
+        }
+        b.drop(lo);
+        const uint32_t dist = e_value(o) + b.take(int(e_extra(o)));
+        if (uint64_t(dist) > out_pos || dist == 0) {
+            status = kBadDistance;
+            break;
+        }
+        if (out_n - out_pos < uint64_t(length)) {
+            status = kOutputFull;
+            break;
+        }
+        sink.put(n, length | (dist << 9), out_pos);
+        ++n;
+        out_pos += length;
+    }
+    n_out = n;
+    return status;
+}
+
+// zlib header: deflate method, window <= 32 KiB, header check, no preset dictionary
+ATL_HD inline bool zlib_header_ok(uint32_t first_word) {
+    const uint32_t cmf = first_word & 0xFF, flg = (first_word >> 8) & 0xFF;
+    return (cmf & 0x0F) == 8 && (cmf >> 4) <= 7 && ((cmf << 8) | flg) % 31 == 0 && !(flg & 0x20);
+}
+
+// ---- a whole stream ---------------------------------------------------------------------------------------------------------
+// Sink: put(i, record, pos) (decode_batch), resolve(n, batch_start, batch_end): records 0 .. n-1 -> output bytes
+// [batch_start, batch_end), stored(src_byte, len, out_pos): len input bytes -> output, tables_ready(): the tables written
+// by build_table are about to be read.  *adler_want = the stream's trailer (checked by the caller: k_adler on the device).
+template <class M, class Sink>
+ATL_HD inline int inflate_stream(const Areas<M> &A, typename M::src_t w, uint32_t n_words, uint64_t src_n, uint64_t out_n, Sink &sink,
+                                 uint32_t *adler_want) {
+    if (src_n < 6 || n_words == 0) return kBadHeader;
+    if (!zlib_header_ok(M::src(w, 0))) return kBadHeader;
+    Bits<M> b;
+    b.start(w, n_words, 16);
+    uint64_t out_pos = 0;
+    const uint64_t src_bits = src_n * 8;
+    bool final_block = false;
+    while (!final_block) {
+        b.refill();
+        if (b.consumed() + 3 > src_bits) return kInputOverrun;
+        final_block = b.take(1) != 0;
+        const uint32_t type = b.take(2);
+        if (type == 0) {  // stored: skip to the byte boundary, LEN, ~LEN, the bytes
+            b.drop(int((8 - (b.consumed() & 7)) & 7));
+            b.refill();
+            const uint32_t len = b.take(16);
+            b.refill();
+            const uint32_t nlen = b.take(16);
+            if ((len ^ nlen) != 0xFFFFu) return kBadBlock;
+            const uint64_t byte_pos = b.consumed() >> 3;
+            if (byte_pos + len > src_n) return kInputOverrun;
+            if (out_n - out_pos < len) return kOutputFull;
+            sink.stored(byte_pos, len, out_pos);
+            out_pos += len;
+            b.start(w, n_words, (byte_pos + len) * 8);
+            continue;
+        }
+        int st;
+        if (type == 1) {
+            st = fixed_tables<M>(A);
+        } else if (type == 2) {
+            if (b.consumed() + 14 > src_bits) return kInputOverrun;
+            st = dynamic_tables<M>(A, b);
+        } else {
+            return kBadBlock;
+        }
+        if (st) return st;
+        if (b.consumed() > src_bits) return kInputOverrun;
+        sink.tables_ready();
+        bool eob = false;
+        while (!eob) {
+            int n = 0;
+            const uint64_t bstart = out_pos;
+            st = decode_batch<M, Sink>(A, b, out_pos, out_n, sink, n, eob);
+            if (st) return st;
+            if (b.consumed() > src_bits) return kInputOverrun;
+            sink.resolve(n, bstart, out_pos);
+        }
+    }
+    if (out_pos != out_n) return kShort;
+    b.drop(int((8 - (b.consumed() & 7)) & 7));  // trailer: Adler-32 of the output, big-endian
+    uint32_t want = 0;
+    for (int k = 0; k < 4; ++k) {
+        b.refill();
+        want = (want << 8) | b.take(8);
+    }
+    if (b.consumed() > src_bits) return kInputOverrun;
+    *adler_want = want;
+    return kOk;
+}
+
+}}  // namespace atl::dinf

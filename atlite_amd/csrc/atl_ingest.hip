@@ -26,8 +26,11 @@
 
 #include <zlib.h>
 
+#include <unistd.h>
+
 #include "atl_h5.h"
 #include "atl_internal.h"
+#include "atl_inflate_dev.h"
 
 using namespace atl;
 using atl::h5::Attribute;
@@ -222,46 +225,249 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ raw,
     }
 }
 
+// ---- DEFLATE on the device: one wave per chunk stream (serial half: atl_inflate_dev.h) ---------------------------
+struct InfDesc {
+    int64_t src_off, src_n;  // zlib stream inside the compressed buffer (src_off 16-byte aligned, padded to whole words)
+    int64_t dst_off, dst_n;  // inflated chunk inside the raw buffer (16-byte aligned)
+};
+struct InfResult {
+    int32_t status;       // dinf::Status
+    uint32_t adler_want;  // the stream's trailer; k_adler compares
+};
+
+struct WaveMem {
+    typedef __attribute__((address_space(3))) uint32_t *u32p;
+    typedef __attribute__((address_space(3))) uint8_t *u8p;
+    typedef __attribute__((address_space(4))) const uint32_t *src_t;  // read-only for the kernel's lifetime: scalar loads
+    // every lane reads the same LDS word; the value continues in an SGPR
+    static __device__ __forceinline__ uint32_t ld32(u32p p) { return __builtin_amdgcn_readfirstlane(*p); }
+    static __device__ __forceinline__ uint32_t ld8(u8p p) { return __builtin_amdgcn_readfirstlane(uint32_t(*p)); }
+    static __device__ __forceinline__ void st32(u32p p, uint32_t v) {
+        if (threadIdx.x == 0) *p = v;
+    }
+    static __device__ __forceinline__ void st8(u8p p, uint32_t v) {
+        if (threadIdx.x == 0) *p = uint8_t(v);
+    }
+    static __device__ __forceinline__ uint32_t src(src_t w, uint32_t i) { return w[__builtin_amdgcn_readfirstlane(i)]; }
+};
+
+// The parallel half: lane i owns record i of a batch.  Output bytes of the batch are assembled in the LDS staging area
+// (sources inside the batch are LDS reads, sources before it are this wave's own earlier output in HBM) and flushed.
+struct WaveSink {
+    uint32_t rec = 0, pos = 0;  // this lane's record of the current batch
+    WaveMem::u8p stage;         // [kStage (+ slack)]
+    const uint8_t *src8;        // the stream's bytes (stored blocks)
+    uint8_t *dst;               // the chunk's output
+    __device__ __forceinline__ void put(int i, uint32_t r, uint64_t p) {
+        if (int(threadIdx.x) == i) {
+            rec = r;
+            pos = uint32_t(p);
+        }
+    }
+    __device__ __forceinline__ void tables_ready() { __syncthreads(); }
+    __device__ void stored(uint64_t byte_pos, uint32_t len, uint64_t out_pos) {
+        for (uint32_t j = threadIdx.x; j < len; j += 64) dst[out_pos + j] = src8[byte_pos + j];
+        __threadfence_block();
+    }
+    __device__ void resolve(int n, uint64_t bstart, uint64_t bend) {
+        const uint32_t lane = threadIdx.x;
+        const uint32_t bs = uint32_t(bstart), total = uint32_t(bend - bstart);
+        const bool active = int(lane) < n;
+        const bool lit = (rec & dinf::kLitFlag) != 0;
+        const uint32_t len = rec & 0x1FFu, dist = (rec & 0x7FFFFFFFu) >> 9;
+        const uint32_t rel = pos - bs;
+        bool coop = false;  // matches that wait for the ordered pass: sources inside the batch, or long
+        if (active) {
+            if (lit) {
+                stage[rel] = uint8_t(rec);
+            } else if (pos - dist + len <= bs && len <= 16) {  // short, its whole source precedes the batch: on its own
+                const uint8_t *sp = dst + (pos - dist);
+                for (uint32_t j = 0; j < len; ++j) stage[rel + j] = sp[j];
+            } else {
+                coop = true;
+            }
+        }
+        uint64_t todo = __ballot(coop);
+        __syncthreads();
+        while (todo) {  // in symbol order; every source byte of a match precedes the match
+            const int i = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t r = __builtin_amdgcn_readlane(rec, i), p = __builtin_amdgcn_readlane(pos, i);
+            const uint32_t L = r & 0x1FFu, D = (r & 0x7FFFFFFFu) >> 9, R = p - bs;
+            for (uint32_t j = lane; j < L; j += 64) {
+                const uint32_t k = D >= L ? j : j % D;  // an overlapping match repeats its first D bytes
+                const uint32_t sp = p - D + k;
+                stage[R + j] = sp >= bs ? stage[sp - bs] : dst[sp];
+            }
+            __syncthreads();
+        }
+        for (uint32_t k = lane; k < total; k += 64) dst[bs + k] = stage[k];
+        __threadfence_block();  // later batches read these bytes back
+        __syncthreads();
+    }
+};
+
+__global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp, const InfDesc *__restrict__ desc,
+                                                uint8_t *__restrict__ raw, InfResult *__restrict__ res) {
+    using namespace dinf;
+    __shared__ uint32_t s_lit[kLitCap];
+    __shared__ uint32_t s_off[kOffCap];
+    __shared__ uint32_t s_tmp[320 + 256];  // codes | sub_bits while a table is built; the staging area while symbols are decoded
+    __shared__ uint32_t s_cnt[32];
+    __shared__ uint32_t s_lens[128];
+    static_assert(sizeof(s_tmp) >= size_t(kStage), "staging area");
+    const InfDesc d = desc[blockIdx.x];
+    Areas<WaveMem> A;
+    A.lit = (WaveMem::u32p)s_lit;
+    A.off = (WaveMem::u32p)s_off;
+    A.codes = (WaveMem::u32p)s_tmp;
+    A.sub_bits = (WaveMem::u8p)(s_tmp + 320);
+    A.cnt = (WaveMem::u32p)s_cnt;
+    A.nxt = (WaveMem::u32p)(s_cnt + 16);
+    A.lens = (WaveMem::u8p)s_lens;
+    WaveSink sink;
+    sink.stage = (WaveMem::u8p)s_tmp;
+    sink.src8 = comp + d.src_off;
+    sink.dst = raw + d.dst_off;
+    uint32_t want = 0;
+    const int st = inflate_stream<WaveMem, WaveSink>(A, (WaveMem::src_t)(comp + d.src_off), uint32_t((d.src_n + 3) / 4),
+                                                     uint64_t(d.src_n), uint64_t(d.dst_n), sink, &want);
+    if (threadIdx.x == 0) {
+        res[blockIdx.x].status = st;
+        res[blockIdx.x].adler_want = want;
+    }
+}
+
+// Adler-32 of every inflated chunk against its stream's trailer: s1 = 1 + sum b_i, s2 = n + sum (n - i) b_i (mod 65521);
+// one block per chunk (chunks <= 64 MiB: the weighted sum stays below 2^60)
+__global__ __launch_bounds__(256) void k_adler(const uint8_t *__restrict__ raw, const InfDesc *__restrict__ desc,
+                                               InfResult *__restrict__ res) {
+    __shared__ unsigned long long r1[256], r2[256];
+    const InfDesc d = desc[blockIdx.x];
+    const uint32_t want = res[blockIdx.x].adler_want;
+    if (res[blockIdx.x].status != dinf::kOk) return;  // the same for the whole block
+    const uint8_t *p = raw + d.dst_off;
+    const uint64_t n = uint64_t(d.dst_n), n16 = n / 16;
+    unsigned long long s1 = 0, s2 = 0;
+    for (uint64_t i = threadIdx.x; i < n16; i += 256) {
+        const uint4 v = reinterpret_cast<const uint4 *>(p)[i];
+        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+        uint32_t sum = 0, wsum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t b = (wds[q] >> (8 * k)) & 0xFFu;
+                sum += b;
+                wsum += uint32_t(4 * q + k) * b;
+            }
+        s1 += sum;
+        s2 += (n - i * 16) * sum - wsum;
+    }
+    for (uint64_t i = n16 * 16 + threadIdx.x; i < n; i += 256) {
+        s1 += p[i];
+        s2 += (n - i) * p[i];
+    }
+    r1[threadIdx.x] = s1;
+    r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (int(threadIdx.x) < w) {
+            r1[threadIdx.x] += r1[threadIdx.x + w];
+            r2[threadIdx.x] += r2[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t a = uint32_t((1 + r1[0]) % 65521ull), b = uint32_t((n % 65521ull + r2[0] % 65521ull) % 65521ull);
+        if (((b << 16) | a) != want) res[blockIdx.x].status = dinf::kAdler;
+    }
+}
+
 // ---- per-context staging: two slots, each {pinned host, device raw, descriptor buffers, event} -------------
+// a read whose chunks were inflated on the device and whose verdicts (InfResult) have not been looked at yet
+struct Pending {
+    bool active = false;
+    atl_nc *nc = nullptr;
+    const Dataset *ds = nullptr;
+    std::vector<size_t> lin;         // stream -> linear chunk index
+    std::vector<uint32_t> desc_of;   // stream -> index of its UnpackDesc
+    std::vector<InfDesc> inf;
+    UnpackParams p{};
+    double *d_out = nullptr;
+    int64_t chunk_bytes = 0, max_elems = 0;
+    size_t off_inf = 0, off_unp = 0, off_res = 0;
+};
+
 struct Slot {
     uint8_t *h = nullptr;
     uint8_t *d = nullptr;
     size_t bytes = 0;
+    uint8_t *d_raw = nullptr;  // device path: the inflated chunks
+    size_t raw_bytes = 0;
     hipEvent_t ev = nullptr;
+    hipEvent_t ev_fork[2] = {nullptr, nullptr};
+    hipStream_t st = nullptr;  // device path: the slot's own stream (two reads in flight overlap)
     bool pending = false;
+    Pending job;
 };
 
 struct IngestState {
     Slot slot[2];
     unsigned calls = 0;
+    atl_ctx *ctx = nullptr;
+    int64_t n_device_chunks = 0, n_host_chunks = 0, n_redone = 0;
 };
+
+// live states, so that closing a file can settle the reads that still refer to it
+std::mutex g_states_m;
+std::vector<IngestState *> g_states;
+
+int finish_slot(atl_ctx *ctx, IngestState *st, Slot &sl);
 
 void ingest_free(void *p) {
     IngestState *s = static_cast<IngestState *>(p);
+    {
+        std::lock_guard<std::mutex> lk(g_states_m);
+        g_states.erase(std::remove(g_states.begin(), g_states.end(), s), g_states.end());
+    }
     for (Slot &sl : s->slot) {
         if (sl.ev) {
             if (sl.pending) (void)hipEventSynchronize(sl.ev);
             (void)hipEventDestroy(sl.ev);
         }
+        for (hipEvent_t e : sl.ev_fork)
+            if (e) (void)hipEventDestroy(e);
+        if (sl.st) {
+            (void)hipStreamSynchronize(sl.st);
+            (void)hipStreamDestroy(sl.st);
+        }
         if (sl.h) (void)hipHostFree(sl.h);
         if (sl.d) (void)dev_free(sl.d);
+        if (sl.d_raw) (void)dev_free(sl.d_raw);
     }
     delete s;
 }
 
-int slot_acquire(atl_ctx *ctx, size_t bytes, Slot **out) {
-    ATL_HIP_TRY(hipSetDevice(ctx->device));
+IngestState *state_of(atl_ctx *ctx) {
     if (!ctx->ingest) {
-        ctx->ingest = new IngestState();
+        IngestState *st = new IngestState();
+        st->ctx = ctx;
+        ctx->ingest = st;
         ctx->ingest_free = ingest_free;
+        std::lock_guard<std::mutex> lk(g_states_m);
+        g_states.push_back(st);
     }
-    IngestState *st = static_cast<IngestState *>(ctx->ingest);
+    return static_cast<IngestState *>(ctx->ingest);
+}
+
+int slot_acquire(atl_ctx *ctx, size_t bytes, Slot **out, size_t raw_bytes = 0) {
+    ATL_HIP_TRY(hipSetDevice(ctx->device));
+    IngestState *st = state_of(ctx);
     Slot &sl = st->slot[st->calls++ & 1];
     if (!sl.ev) ATL_HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
-    if (sl.pending) {
-        ATL_HIP_TRY(hipEventSynchronize(sl.ev));  // the previous user of this slot has left the copy stream
-        sl.pending = false;
-    }
+    int rc = finish_slot(ctx, st, sl);  // the previous user of this slot has left its stream; its verdicts are in
+    if (rc) return rc;
     if (sl.bytes < bytes) {
         if (sl.h) (void)hipHostFree(sl.h);
         if (sl.d) (void)dev_free(sl.d);
@@ -272,6 +478,14 @@ int slot_acquire(atl_ctx *ctx, size_t bytes, Slot **out) {
         ATL_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sl.h), want, hipHostMallocDefault));
         ATL_HIP_TRY(dev_malloc(reinterpret_cast<void **>(&sl.d), want));
         sl.bytes = want;
+    }
+    if (sl.raw_bytes < raw_bytes) {
+        if (sl.d_raw) (void)dev_free(sl.d_raw);
+        sl.d_raw = nullptr;
+        sl.raw_bytes = 0;
+        const size_t want = align_up(raw_bytes + raw_bytes / 8, size_t(1) << 20);
+        ATL_HIP_TRY(dev_malloc(reinterpret_cast<void **>(&sl.d_raw), want));
+        sl.raw_bytes = want;
     }
     *out = &sl;
     return ATL_OK;
@@ -477,6 +691,91 @@ int lookup(atl_nc *f, const char *name, const Dataset **out, const char *who) {
     return ATL_OK;
 }
 
+// ---- device inflate: submit, and the settling of its verdicts ---------------------------------------------------------
+bool device_inflate_wanted(size_t n_streams) {
+    const char *e = getenv("ATLITE_HIP_INFLATE");
+    if (e && strcmp(e, "device") == 0) return n_streams > 0;
+    if (e && *e) return false;  // "host", "zlib"
+    size_t min_chunks = 512;    // below that the host threads finish first: a stream is one wave, tens of MB/s
+    if (const char *m = getenv("ATLITE_HIP_INFLATE_MIN_CHUNKS")) min_chunks = size_t(std::max(1, atoi(m)));
+    return n_streams >= min_chunks;
+}
+
+void launch_unpack(hipStream_t st, const uint8_t *raw, const UnpackDesc *d_desc, size_t n_desc, const UnpackParams &p,
+                   int64_t max_chunk_elems, double *d_out) {
+    const unsigned bx = unsigned(std::min<int64_t>((max_chunk_elems + 255) / 256, 2048));
+    for (size_t c0 = 0; c0 < n_desc; c0 += 32768) {
+        const unsigned by = unsigned(std::min<size_t>(n_desc - c0, 32768));
+        hipLaunchKernelGGL(k_unpack, dim3(std::max(bx, 1u), by), dim3(256), 0, st, raw, d_desc + c0, p, d_out);
+    }
+}
+
+// Everything of a device-inflate read is enqueued on the slot's stream; the copy stream waits for it.  The verdicts come
+// back with the last copy and are read by finish_slot: at the slot's next use, when the copy stream is observed
+// (atl_event_record on it), when the file is closed, when the context goes.
+int submit_device(atl_ctx *ctx, Slot *sl, size_t h2d_bytes, double *d_out) {
+    hipStream_t cs;
+    int rc = copy_stream_of(ctx, &cs);
+    if (rc) return rc;
+    Pending &job = sl->job;
+    if (!sl->st) ATL_HIP_TRY(hipStreamCreateWithFlags(&sl->st, hipStreamNonBlocking));
+    // behind whatever the copy stream holds (an earlier read into the same block; what the caller ordered the copy stream
+    // after: Context.copy_after_compute).  NOT behind the compute stream: a slab pipeline reads the next slab while the
+    // previous one is converted
+    if (!sl->ev_fork[0]) ATL_HIP_TRY(hipEventCreateWithFlags(&sl->ev_fork[0], hipEventDisableTiming));
+    ATL_HIP_TRY(hipEventRecord(sl->ev_fork[0], cs));
+    ATL_HIP_TRY(hipStreamWaitEvent(sl->st, sl->ev_fork[0], 0));
+    const size_t n = job.inf.size(), n_desc = (job.off_res - job.off_unp) / sizeof(UnpackDesc);
+    ATL_HIP_TRY(hipMemcpyAsync(sl->d, sl->h, h2d_bytes, hipMemcpyHostToDevice, sl->st));
+    const InfDesc *d_inf = reinterpret_cast<const InfDesc *>(sl->d + job.off_inf);
+    InfResult *d_res = reinterpret_cast<InfResult *>(sl->d + job.off_res);
+    if (n) {
+        hipLaunchKernelGGL(k_inflate, dim3(unsigned(n)), dim3(64), 0, sl->st, sl->d, d_inf, sl->d_raw, d_res);
+        hipLaunchKernelGGL(k_adler, dim3(unsigned(n)), dim3(256), 0, sl->st, sl->d_raw, d_inf, d_res);
+    }
+    launch_unpack(sl->st, sl->d_raw, reinterpret_cast<const UnpackDesc *>(sl->d + job.off_unp), n_desc, job.p, job.max_elems, d_out);
+    ATL_HIP_TRY(hipGetLastError());
+    if (n) ATL_HIP_TRY(hipMemcpyAsync(sl->h + job.off_res, d_res, n * sizeof(InfResult), hipMemcpyDeviceToHost, sl->st));
+    ATL_HIP_TRY(hipEventRecord(sl->ev, sl->st));
+    sl->pending = true;
+    job.active = true;
+    ATL_HIP_TRY(hipStreamWaitEvent(cs, sl->ev, 0));
+    return ATL_OK;
+}
+
+int finish_slot(atl_ctx *ctx, IngestState *st, Slot &sl) {
+    if (sl.pending) {
+        ATL_HIP_TRY(hipEventSynchronize(sl.ev));
+        sl.pending = false;
+    }
+    Pending &job = sl.job;
+    if (!job.active) return ATL_OK;
+    job.active = false;
+    const InfResult *res = reinterpret_cast<const InfResult *>(sl.h + job.off_res);
+    std::vector<size_t> bad;
+    for (size_t i = 0; i < job.inf.size(); ++i)
+        if (res[i].status != dinf::kOk) bad.push_back(i);
+    st->n_device_chunks += int64_t(job.inf.size() - bad.size());
+    if (bad.empty()) return ATL_OK;
+    // streams the device decoder did not accept (corrupt, or a shape of code it declines): the host decoders decide, the chunk
+    // is decoded again from their output; a stream they reject too is the caller's error, as on the host path
+    ATL_HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<uint8_t> tmp(size_t(job.chunk_bytes));
+    const UnpackDesc *d_unp = reinterpret_cast<const UnpackDesc *>(sl.d + job.off_unp);
+    for (size_t i : bad) {
+        bool shuffled = false;
+        const h5::Chunk &c = job.ds->chunks[job.lin[i]];
+        const int e = h5::chunk_inflate(*job.ds, c, job.nc->file.base(), -1, tmp.data(), uint64_t(job.chunk_bytes), &shuffled);
+        if (e) return e;
+        ATL_HIP_TRY(hipMemcpy(sl.d_raw + job.inf[i].dst_off, tmp.data(), size_t(job.chunk_bytes), hipMemcpyHostToDevice));
+        launch_unpack(sl.st, sl.d_raw, d_unp + job.desc_of[i], 1, job.p, job.max_elems, job.d_out);
+        ATL_HIP_TRY(hipGetLastError());
+        ++st->n_redone;
+    }
+    ATL_HIP_TRY(hipStreamSynchronize(sl.st));
+    return ATL_OK;
+}
+
 int copy_text(const std::string &s, char *buf, int64_t buflen, int64_t *needed) {
     if (needed) *needed = int64_t(s.size()) + 1;
     if (buf && buflen > 0) {
@@ -489,7 +788,33 @@ int copy_text(const std::string &s, char *buf, int64_t buflen, int64_t *needed) 
 
 }  // namespace
 
+namespace atl {
+// settle every read of this context whose chunks were inflated on the device (see submit_device): called before the copy
+// stream is observed, so that whoever waits on it sees chunks the device decoder declined decoded by the host decoders
+int ingest_finish(atl_ctx *ctx) {
+    if (!ctx || !ctx->ingest) return ATL_OK;
+    IngestState *st = static_cast<IngestState *>(ctx->ingest);
+    for (Slot &sl : st->slot) {
+        if (!sl.job.active) continue;
+        const int rc = finish_slot(ctx, st, sl);
+        if (rc) return rc;
+    }
+    return ATL_OK;
+}
+}  // namespace atl
+
 extern "C" {
+
+int atl_nc_ingest_stats(atl_ctx *ctx, int64_t *device_chunks, int64_t *host_chunks, int64_t *redone) {
+    ATL_REQUIRE(ctx, "atl_nc_ingest_stats: ctx is NULL");
+    int rc = ingest_finish(ctx);
+    if (rc) return rc;
+    const IngestState *st = static_cast<const IngestState *>(ctx->ingest);
+    if (device_chunks) *device_chunks = st ? st->n_device_chunks : 0;
+    if (host_chunks) *host_chunks = st ? st->n_host_chunks : 0;
+    if (redone) *redone = st ? st->n_redone : 0;
+    return ATL_OK;
+}
 
 int atl_nc_open(const char *path, atl_nc **out) {
     ATL_REQUIRE(path && out, "atl_nc_open: bad argument");
@@ -505,6 +830,12 @@ int atl_nc_open(const char *path, atl_nc **out) {
 }
 
 int atl_nc_close(atl_nc *f) {
+    if (f) {  // reads of this file whose verdicts are still out: settle them while the file is there
+        std::lock_guard<std::mutex> lk(g_states_m);
+        for (IngestState *st : g_states)
+            for (Slot &sl : st->slot)
+                if (sl.job.active && sl.job.nc == f) (void)finish_slot(st->ctx, st, sl);
+    }
     delete f;
     return ATL_OK;
 }
@@ -761,8 +1092,81 @@ int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, 
         select_chunks(g, r0, r1, chunk_bytes, &sel);
         payload = sel.desc.size() * align_up(size_t(chunk_bytes), 16);
         max_elems = g.chunk_elems;
+        // ---- chunks inflated on the device: every stored chunk of the selection is a zlib stream -----------------------
+        size_t n_streams = 0;
+        bool all_deflate = chunk_bytes <= (int64_t(64) << 20);
+        std::vector<uint64_t> pay(sel.lin.size(), 0);
+        for (size_t i = 0; i < sel.lin.size() && all_deflate; ++i) {
+            const h5::Chunk &c = d->chunks[sel.lin[i]];
+            if (c.size == 0) continue;
+            bool defl = false, shuf = false;
+            if (h5::chunk_filters(*d, c, &pay[i], &defl, &shuf) != ATL_OK || !defl || pay[i] < 6 || c.addr > f->file.size() ||
+                c.size > f->file.size() - c.addr) {
+                all_deflate = false;
+                break;
+            }
+            sel.desc[i].shuffled = shuf;
+            ++n_streams;
+        }
+        if (all_deflate && device_inflate_wanted(n_streams)) {
+            // staging: streams (16-byte aligned, whole words) | InfDesc[] | UnpackDesc[] ; behind them, device -> host: InfResult[]
+            std::vector<InfDesc> inf;
+            std::vector<size_t> lin;
+            std::vector<uint32_t> desc_of;
+            inf.reserve(n_streams);
+            size_t off = 0;
+            for (size_t i = 0; i < sel.lin.size(); ++i) {
+                if (d->chunks[sel.lin[i]].size == 0) {
+                    sel.desc[i].missing = 1;
+                    continue;
+                }
+                inf.push_back(InfDesc{int64_t(off), int64_t(pay[i]), sel.desc[i].src_off, chunk_bytes});
+                lin.push_back(sel.lin[i]);
+                desc_of.push_back(uint32_t(i));
+                off += align_up(size_t(pay[i]) + 8, 16);
+            }
+            const size_t off_inf = align_up(off, 256), off_unp = align_up(off_inf + inf.size() * sizeof(InfDesc), 256);
+            const size_t off_res = align_up(off_unp + sel.desc.size() * sizeof(UnpackDesc), 256);
+            rc = slot_acquire(ctx, off_res + inf.size() * sizeof(InfResult) + 256, &sl, payload + 256);
+            if (rc) return rc;
+            const int fd = f->file.fd();
+            const uint8_t *base = f->file.base();
+            rc = parallel_for(inf.size(), pick_threads(n_threads, inf.size()), [&](size_t i) -> int {
+                const h5::Chunk &c = d->chunks[lin[i]];
+                uint8_t *dst = sl->h + inf[i].src_off;
+                const uint64_t n = uint64_t(inf[i].src_n);
+                uint64_t got = 0;
+                while (fd >= 0 && got < n) {  // straight into the pinned staging (a mapping's page faults contend across threads)
+                    const ssize_t r = pread(fd, dst + got, size_t(n - got), off_t(c.addr + got));
+                    if (r <= 0) break;
+                    got += uint64_t(r);
+                }
+                if (got < n) memcpy(dst + got, base + c.addr + got, size_t(n - got));
+                memset(dst + n, 0, size_t(align_up(size_t(n) + 8, 16) - n));  // the bit reader's look-ahead words
+                return ATL_OK;
+            });
+            if (rc) return rc;
+            if (!inf.empty()) memcpy(sl->h + off_inf, inf.data(), inf.size() * sizeof(InfDesc));
+            memcpy(sl->h + off_unp, sel.desc.data(), sel.desc.size() * sizeof(UnpackDesc));
+            Pending &job = sl->job;
+            job.nc = f;
+            job.ds = d;
+            job.lin = std::move(lin);
+            job.desc_of = std::move(desc_of);
+            job.inf = std::move(inf);
+            job.p = p;
+            job.d_out = d_out;
+            job.chunk_bytes = chunk_bytes;
+            job.max_elems = max_elems;
+            job.off_inf = off_inf;
+            job.off_unp = off_unp;
+            job.off_res = off_res;
+            return submit_device(ctx, sl, off_unp + sel.desc.size() * sizeof(UnpackDesc), d_out);
+        }
+        for (UnpackDesc &ds : sel.desc) ds.shuffled = 0;
         rc = slot_acquire(ctx, align_up(payload, 256) + sel.desc.size() * sizeof(UnpackDesc), &sl);
         if (rc) return rc;
+        state_of(ctx)->n_host_chunks += int64_t(sel.lin.size());
         rc = parallel_for(sel.lin.size(), pick_threads(n_threads, sel.lin.size()), [&](size_t i) -> int {
             const h5::Chunk &c = d->chunks[sel.lin[i]];
             UnpackDesc &ds = sel.desc[i];
@@ -781,13 +1185,20 @@ int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, 
 }
 
 int atl_inflate_probe(const void *h_src, size_t src_n, void *h_dst, size_t dst_n, int which, int64_t *ns) {
-    ATL_REQUIRE(h_src && (h_dst || dst_n == 0) && which >= 0 && which <= 2, "atl_inflate_probe: bad argument");
+    ATL_REQUIRE(h_src && (h_dst || dst_n == 0) && which >= 0 && which <= 3, "atl_inflate_probe: bad argument");
     const auto t0 = std::chrono::steady_clock::now();
     int rc = ATL_OK;
     const uint8_t *src = static_cast<const uint8_t *>(h_src);
     uint8_t *dst = static_cast<uint8_t *>(h_dst);
     bool done = false;
-    if (which != 1) {
+    if (which == 3) {  // the device decoder's serial half on the host
+        const int st = h5::device_inflate_emulated(src, src_n, dst, dst_n);
+        if (st) {
+            set_error("atl_inflate_probe: the device decoder's host emulation returned status %d", st);
+            rc = ATL_E_INVALID;
+        }
+        done = true;
+    } else if (which != 1) {
         done = h5::fast_inflate_zlib(src, src_n, dst, dst_n) == 0;
         if (!done && which == 0) {
             set_error("atl_inflate_probe: the fast decoder declined the stream");

@@ -292,10 +292,13 @@ int scratch_reserve(atl_ctx *ctx, size_t bytes, void **out);
 int copy_stream_of(atl_ctx *ctx, hipStream_t *out);
 // Every device allocation of the library goes through these two.  Normally hipMalloc / hipFree.  With
 // $ATLITE_HIP_FENCE=1 (a debugging mode, tools/hang_hunt.sh) each block is its own virtual-memory mapping whose LAST
-// byte is the last mapped byte before an unmapped guard range (8-byte granularity), with another guard range in
+// byte is the last mapped byte before an unmapped guard range (8-byte granularity; $ATLITE_HIP_FENCE_SLACK bytes may
+// stay mapped behind it), with another guard range in
 // front, and a freed block's addresses are never handed out again: an access one element past either end, or after
 // the free, is a page fault on the spot instead of a silent read of a neighbouring allocation.  dev_free does not
 // order anything: callers synchronise first, as they had to for hipFree's sake.
+// atl_ingest.hip: settle the context's device-inflate reads (no-op when there are none)
+int ingest_finish(atl_ctx *ctx);
 hipError_t dev_malloc(void **out, size_t bytes);
 hipError_t dev_free(void *p);
 bool fence_mode();

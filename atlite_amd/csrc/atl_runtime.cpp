@@ -76,7 +76,13 @@ hipError_t dev_malloc(void **out, size_t bytes) {
     size_t gran = 0;
     if ((e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum)) != hipSuccess) return e;
     if (gran == 0) return hipErrorNotSupported;
-    const size_t want = align_up(bytes ? bytes : 8, 8), mapped = align_up(want, gran);
+    // $ATLITE_HIP_FENCE_SLACK bytes (default 0) stay mapped behind the block: 8 lets the vectorised kernels run on cubes with
+    // an odd cell count (their documented 8-byte over-read of the last pair, vec_ok) while anything further still faults
+    static const size_t slack = [] {
+        const char *e = getenv("ATLITE_HIP_FENCE_SLACK");
+        return e ? size_t(std::max(0, atoi(e))) / 8 * 8 : size_t(0);
+    }();
+    const size_t want = align_up(bytes ? bytes : 8, 8) + slack, mapped = align_up(want, gran);
     FenceBlock b{};
     b.mapped = mapped;
     b.device = dev;
@@ -494,7 +500,9 @@ int atl_event_record(atl_ctx *ctx, atl_event *ev, int which_stream) {
     ATL_REQUIRE(ctx && ev, "atl_event_record: bad argument");
     hipStream_t st = ctx->stream;
     if (which_stream == 1) {
-        int rc = copy_stream_of(ctx, &st);
+        int rc = ingest_finish(ctx);  // reads whose chunks the device inflated: their verdicts first
+        if (rc) return rc;
+        rc = copy_stream_of(ctx, &st);
         if (rc) return rc;
     }
     ATL_HIP_TRY(hipEventRecord(ev->ev, st));

@@ -242,6 +242,7 @@ class SlotPool:
         self.base = ctx.empty((max(self.T * self.ld, 1),))
         if self.Sp > self.S:  # the padding is never read as data; keep it free of stray NaN patterns
             check(ctx.lib.atl_memset(ctx.handle, self.base.ptr, 0, self.base.nbytes))
+            ctx.copy_after_compute()  # the cubes are filled on the copy stream: behind the memset
 
     def view(self, name):
         v = self.names.index(name)
@@ -486,6 +487,7 @@ class Context:
         base = self.empty((max(T * ld, 1),), dtype)
         if ld > S:
             check(self.lib.atl_memset(self.handle, base.ptr, 0, base.nbytes))
+            self.copy_after_compute()
         return DeviceArray(self, base.ptr, (T, S), dtype, owner=base, ld=ld) if ld > S else base.reshape(T, S)
 
     def _stride(self, S, *arrays):
@@ -538,6 +540,17 @@ class Context:
             self._copy_ev = ev
         check(self.lib.atl_event_record(self.handle, ev, 1))
         check(self.lib.atl_stream_wait_event(self.handle, 0, ev))
+
+    def copy_after_compute(self):
+        """Make the copy stream wait for everything enqueued on the compute stream so far (a block zeroed on the compute
+        stream that the copy stream is about to fill)."""
+        ev = self.__dict__.get("_compute_ev")
+        if ev is None:
+            ev = C.c_void_p()
+            check(self.lib.atl_event_create(self.handle, C.byref(ev)))
+            self._compute_ev = ev
+        check(self.lib.atl_event_record(self.handle, ev, 0))
+        check(self.lib.atl_stream_wait_event(self.handle, 1, ev))
 
     def name(self):
         buf = C.create_string_buffer(256)
@@ -861,9 +874,10 @@ class Context:
                 for ev in pair:
                     self.lib.atl_event_destroy(ev)
             self.__dict__.pop("_pool_st", None)
-        ev = self.__dict__.pop("_copy_ev", None)
-        if ev is not None:
-            self.lib.atl_event_destroy(ev)
+        for key in ("_copy_ev", "_compute_ev"):
+            ev = self.__dict__.pop(key, None)
+            if ev is not None:
+                self.lib.atl_event_destroy(ev)
         if getattr(self, "handle", None):
             self.lib.atl_destroy(self.handle)
             self.handle = None

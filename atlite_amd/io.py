@@ -205,7 +205,13 @@ class FileArray:
         stride = int(ld) if pitched else row
         step = max(1, block_bytes // (row * 8))
         if self.var.layout == "chunked":
-            step = max(self.var.chunks[0], step // self.var.chunks[0] * self.var.chunks[0])
+            ct = self.var.chunks[0]
+            if self.var.deflate is not None and os.environ.get("ATLITE_HIP_INFLATE", "") in ("", "device"):
+                # the chunks' zlib streams are inflated on the device, one wavefront per stream (atl_nc_read_slab): a call should
+                # carry thousands of them - up to 1.5 GiB of on-disk dtype per call (staging: two slots of that)
+                es = np.dtype(self.var.dtype).itemsize if self.var.dtype else 8
+                step = max(step, int(os.environ.get("ATLITE_HIP_INFLATE_BLOCK", 3 << 29)) // max(row * es, 1))
+            step = max(ct, step // ct * ct)
         check(ctx.lib.atl_set_slot_stride(ctx.handle, stride if pitched else 0))  # where atl_nc_read_slab puts the rows
         try:
             for t0 in range(0, self.shape[0], step):

@@ -465,12 +465,23 @@ int atl_nc_att_double(atl_nc *f, const char *var, const char *att, double *out, 
 /* rows [start0, start0 + count0) along the first dimension, CF-decoded to fp64 on the host
  * (coordinates, static fields, tests); out holds count0 * prod(shape[1:]) doubles */
 int atl_nc_read_host(atl_nc *f, const char *name, int64_t start0, int64_t count0, double *out);
-/* same rows as an fp64 (count0, prod(shape[1:])) block at d_out, asynchronously: returns after the
- * host inflate; the copy + device decode are enqueued on the copy stream (order against the
- * compute stream with atl_event_record(ev, 1) / atl_stream_wait_event(ctx, 0, ev)).
+/* same rows as an fp64 (count0, prod(shape[1:])) block at d_out, asynchronously; the result is visible in the order of
+ * the context's COPY stream (order against the compute stream with atl_event_record(ev, 1) /
+ * atl_stream_wait_event(ctx, 0, ev)).  Two ways through the zlib streams of a chunked, deflated variable
+ * (atlite/data.py:246-248 writes cutouts with zlib + shuffle):
+ *  - on the DEVICE, one wavefront per chunk stream (k_inflate; round 5), when the rows asked for span at least
+ *    $ATLITE_HIP_INFLATE_MIN_CHUNKS chunks (default 512; $ATLITE_HIP_INFLATE=device: always): the host threads only
+ *    pread the COMPRESSED bytes into page-locked staging, PCIe carries those, un-shuffle + widening + CF decoding follow
+ *    on the device as before.  Every stream's Adler-32 is checked on the device; a stream the device decoder declines
+ *    is decoded by the host decoders before anyone can observe the copy stream (atl_event_record(ev, 1), the slot's next
+ *    use, atl_nc_close): a corrupt stream is reported THERE, with the host decoders' message;
+ *  - on host threads ($ATLITE_HIP_INFLATE=host, =zlib, or few chunks): returns after the inflate, DMA + decode enqueued.
  * n_threads <= 0: $ATLITE_HIP_IO_THREADS, else min(2 x usable CPUs (cgroup quota aware), 128). */
 int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, int64_t count0,
                      double *d_out, int n_threads);
+/* chunks of this context's atl_nc_read_slab calls so far: inflated on the device / on host threads / declined by the device
+ * decoder and decoded again on the host (settles pending reads first) */
+int atl_nc_ingest_stats(atl_ctx *ctx, int64_t *device_chunks, int64_t *host_chunks, int64_t *redone);
 /* host array of a narrower dtype (what xarray hands over for a float32 cutout) -> fp64 on the
  * device through the same staging + decode kernel; halves the PCIe bytes of atl_upload_async */
 int atl_upload_convert_async(atl_ctx *ctx, double *d_dst, const void *h_src, int dtype, int64_t n);

@@ -17,6 +17,22 @@ pytestmark = pytest.mark.gpu
 NC = os.path.join(os.path.dirname(__file__), "golden", "nc")
 
 
+@pytest.fixture(autouse=True, params=["host", "device"])
+def inflate_mode(request, monkeypatch):
+    """Every test of this file runs twice: the chunks' zlib streams inflated on host threads, and on the device (one
+    wavefront per stream, atl_nc_read_slab; forced here - by default only reads of >= 512 chunks take it)."""
+    monkeypatch.setenv("ATLITE_HIP_INFLATE", request.param)
+    return request.param
+
+
+def ingest_stats(ctx):
+    import ctypes as C
+
+    v = [C.c_int64() for _ in range(3)]
+    check(ctx.lib.atl_nc_ingest_stats(ctx.handle, *[C.byref(x) for x in v]))
+    return tuple(int(x.value) for x in v)  # device chunks, host chunks, redone on the host
+
+
 def close(a, b, s=1e-12):
     np.testing.assert_allclose(a, b, rtol=1e-10, atol=s * np.nanmax(np.abs(b)), equal_nan=True)
 
@@ -24,6 +40,7 @@ def close(a, b, s=1e-12):
 def slab(ctx, f, name, t0, n):
     var = f.variables[name]
     out = ctx.zeros((max(n, 1),) + var.shape[1:])
+    ctx.copy_after_compute()  # zeroed on the compute stream, filled on the copy stream
     f.read_slab(ctx, name, t0, n, out.ptr)
     ctx.copy_barrier()
     ctx.sync()
@@ -215,3 +232,112 @@ def test_read_slab_random_files(ctx, tmp_path, seed):
             n = int(rng.integers(1, n0 - t0 + 1))
             got = slab(ctx, f, v, t0, n)
             assert np.array_equal(got, exp[v][t0:t0 + n], equal_nan=True), (v, t0, n, T, Y, X, ct, cy, cx, libver)
+
+
+def test_device_inflate_is_the_path_that_ran(ctx, inflate_mode):
+    """The counters of atl_nc_ingest_stats: in device mode the deflated chunks of a read are inflated by k_inflate (and none
+    had to be decoded again on the host), in host mode none is."""
+    f = io.NcFile(f"{NC}/cutout_nc4.nc")
+    exp = np.load(f"{NC}/cutout_nc4.npz")
+    d0, h0, r0 = ingest_stats(ctx)
+    got = slab(ctx, f, "temperature", 0, exp["temperature"].shape[0])
+    assert np.array_equal(got, exp["temperature"], equal_nan=True)
+    d1, h1, r1 = ingest_stats(ctx)
+    if inflate_mode == "device" and f.variables["temperature"].deflate is not None:
+        assert d1 > d0 and h1 == h0 and r1 == r0
+    else:
+        assert d1 == d0 and h1 > h0
+
+
+def test_device_inflate_many_chunks(ctx, tmp_path, monkeypatch):
+    """A cutout of a few thousand chunk streams (written by h5py when the conda interpreter is there): the device decoder's
+    output == the host decoders' == h5py's, no stream declined, through FileArray.to_device (one big read per variable)
+    and through ragged row ranges."""
+    import subprocess
+
+    conda = "/opt/conda/bin/python3.9"
+    make = os.path.join(os.path.dirname(__file__), "golden", "make_nc_fixtures.py")
+    try:
+        ok = subprocess.run([conda, "-c", "import h5py"], capture_output=True, timeout=120).returncode == 0
+    except Exception:
+        ok = False
+    if not ok:
+        pytest.skip("needs the conda interpreter with h5py")
+    path = tmp_path / "many.nc"
+    T, Y, X = 120, 96, 80
+    r = subprocess.run([conda, make, "--cutout", str(path), str(T), str(Y), str(X), "8", "24", "20", "f4", "5"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    f = io.NcFile(path)
+    names = [n for n, v in f.variables.items() if v.ndim == 3]
+    assert len(names) >= 7 and f.variables[names[0]].n_chunks == 15 * 4 * 4
+    host = {}
+    monkeypatch.setenv("ATLITE_HIP_INFLATE", "host")
+    for n in names:
+        host[n] = slab(ctx, f, n, 0, T)
+        assert np.array_equal(host[n], f.read(n), equal_nan=True)
+    monkeypatch.setenv("ATLITE_HIP_INFLATE", "device")
+    d0, _, r0 = ingest_stats(ctx)
+    for n in names:
+        assert np.array_equal(slab(ctx, f, n, 0, T), host[n], equal_nan=True), n
+        assert np.array_equal(slab(ctx, f, n, 13, 77), host[n][13:90], equal_nan=True), n
+        dev = io.FileArray(f, n).to_device(ctx)
+        ctx.sync()
+        assert np.array_equal(dev.numpy().reshape(T, Y, X), host[n], equal_nan=True), n
+    d1, _, r1 = ingest_stats(ctx)
+    assert d1 - d0 >= len(names) * 240 * 2 and r1 == r0
+    # the default policy: a read of >= 512 chunks goes to the device, a small one stays on the host threads
+    monkeypatch.delenv("ATLITE_HIP_INFLATE")
+    monkeypatch.setenv("ATLITE_HIP_INFLATE_MIN_CHUNKS", "200")
+    d1, h1, _ = ingest_stats(ctx)
+    assert np.array_equal(slab(ctx, f, names[0], 0, T), host[names[0]], equal_nan=True)  # 240 chunks
+    assert np.array_equal(slab(ctx, f, names[0], 0, 8), host[names[0]][:8], equal_nan=True)  # 16 chunks
+    d2, h2, _ = ingest_stats(ctx)
+    assert d2 - d1 == 240 and h2 - h1 == 16
+
+
+def test_corrupt_streams_get_the_host_decoders_verdict(ctx, tmp_path, monkeypatch):
+    """Bytes of a cutout file overwritten at random: whatever the host path says about a variable - an error, or data -
+    the device path says as well (streams the device decoder declines are decoded again by the host decoders before the
+    copy stream can be observed)."""
+    import shutil
+
+    src = f"{NC}/cutout_nc4.nc"
+    raw = bytearray(open(src, "rb").read())
+    rng = np.random.default_rng(11)
+    names = ["temperature", "influx_direct", "runoff", "albedo"]
+    n_err = n_diff = 0
+    for case in range(12):
+        b = bytearray(raw)
+        for pos in rng.integers(len(b) // 3, len(b), size=int(rng.integers(1, 6))):
+            b[int(pos)] ^= 1 << int(rng.integers(8))
+        path = tmp_path / f"c{case}.nc"
+        open(path, "wb").write(bytes(b))
+        verdicts = {}
+        for mode in ("host", "device"):
+            monkeypatch.setenv("ATLITE_HIP_INFLATE", mode)
+            try:
+                f = io.NcFile(path)
+            except Exception as e:  # the container itself no longer parses: nothing to compare
+                verdicts[mode] = ("open", type(e).__name__)
+                continue
+            out = {}
+            for n in names:
+                try:
+                    out[n] = slab(ctx, f, n, 0, f.variables[n].shape[0])
+                except Exception as e:
+                    out[n] = type(e).__name__
+            f.close()
+            verdicts[mode] = out
+        h, d = verdicts["host"], verdicts["device"]
+        if isinstance(h, tuple) or isinstance(d, tuple):
+            assert h == d
+            continue
+        for n in names:
+            if isinstance(h[n], str) or isinstance(d[n], str):
+                assert h[n] == d[n], (case, n, h[n] if isinstance(h[n], str) else "data", d[n] if isinstance(d[n], str) else "data")
+                n_err += 1
+            else:
+                assert np.array_equal(h[n], d[n], equal_nan=True), (case, n)
+                n_diff += 1
+    assert n_diff > 0

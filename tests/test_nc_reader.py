@@ -246,6 +246,8 @@ def test_fast_inflate_matches_zlib():
                     comp = co.compress(d) + co.flush()
                     rc, out = _inflate(comp, len(d), 0)
                     assert rc == 0 and out == d, (len(d), level, strat, mem)
+                    rc, out = _inflate(comp, len(d), 3)  # the device decoder's serial half on the host (atl_inflate_dev.h)
+                    assert rc == 0 and out == d, ("device decoder emulation", len(d), level, strat, mem)
                     n += 1
     assert n == len(data) * 32
     # wrong expected size, truncated and corrupted streams

@@ -65,6 +65,8 @@ def main():
         assert rc == 0 and out == d, ("valid stream", k, len(d), level, strat, rc)
         rc, out = inflate(comp, len(d), 2)
         assert rc == 0 and out == d, ("valid stream, product path", k)
+        rc, out = inflate(comp, len(d), 3)  # the device decoder's serial half (atl_inflate_dev.h) on the host
+        assert rc == 0 and out == d, ("valid stream, device decoder emulation", k, len(d), level, strat, rc)
         valid += 1
         for _ in range(3):
             b = bytearray(comp)
@@ -93,6 +95,8 @@ def main():
                 assert out == z
                 agree_ok += 1
             inflate(b, want, 0)  # the fast decoder alone: any verdict
+            rc3, out3 = inflate(b, want, 3)  # the device decoder's emulation: may refuse, must never accept what zlib rejects
+            assert rc3 != 0 or (ok and out3 == z), ("device decoder accepted a stream zlib rejects", k, how)
             corrupt += 1
     print(f"{valid} valid streams decoded identically, {corrupt} corrupted streams ({agree_ok} still valid) with zlib's verdict, no crash")
 
