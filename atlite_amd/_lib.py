@@ -233,6 +233,7 @@ SIGNATURES = {
     "atl_nc_read_host": (_i, [_vp, C.c_char_p, _i64, _i64, _vp]),
     "atl_nc_read_slab": (_i, [_vp, _vp, C.c_char_p, _i64, _i64, _vp, _i]),
     "atl_nc_ingest_stats": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "atl_nc_ingest_times": (_i, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "atl_upload_convert_async": (_i, [_vp, _vp, _vp, _i, _i64]),
     "atl_upload_convert_2d_async": (_i, [_vp, _vp, _i64, _vp, _i, _i64, _i64]),
     "atl_inflate_probe": (_i, [_vp, _sz, _vp, _sz, _i, C.POINTER(_i64)]),

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void k_adler(const uint8_t *__restrict__ raw, 
     }
 }
 
-// ---- per-context staging: two slots, each {pinned host, device raw, descriptor buffers, event} -------------
+// ---- per-context staging: kSlots slots, each {pinned host, device raw, descriptor buffers, event, stream} -------------
 // a read whose chunks were inflated on the device and whose verdicts (InfResult) have not been looked at yet
 struct Pending {
     bool active = false;
@@ -408,15 +408,21 @@ struct Slot {
     hipEvent_t ev = nullptr;
     hipEvent_t ev_fork[2] = {nullptr, nullptr};
     hipStream_t st = nullptr;  // device path: the slot's own stream (two reads in flight overlap)
+    hipEvent_t ev_t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // device path: stage boundaries (timing)
     bool pending = false;
     Pending job;
 };
 
+constexpr unsigned kSlots = 4;  // reads in flight: host-side staging of one overlaps DMA + device work of the others
+
 struct IngestState {
-    Slot slot[2];
+    Slot slot[kSlots];
     unsigned calls = 0;
     atl_ctx *ctx = nullptr;
     int64_t n_device_chunks = 0, n_host_chunks = 0, n_redone = 0;
+    // device path, accumulated: host gather of the compressed bytes (wall clock) | H2D | k_inflate | k_adler | k_unpack (events)
+    double ms[5] = {0, 0, 0, 0, 0};
+    int64_t comp_bytes = 0, raw_bytes = 0;
 };
 
 // live states, so that closing a file can settle the reads that still refer to it
@@ -437,6 +443,8 @@ void ingest_free(void *p) {
             (void)hipEventDestroy(sl.ev);
         }
         for (hipEvent_t e : sl.ev_fork)
+            if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : sl.ev_t)
             if (e) (void)hipEventDestroy(e);
         if (sl.st) {
             (void)hipStreamSynchronize(sl.st);
@@ -464,7 +472,7 @@ IngestState *state_of(atl_ctx *ctx) {
 int slot_acquire(atl_ctx *ctx, size_t bytes, Slot **out, size_t raw_bytes = 0) {
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     IngestState *st = state_of(ctx);
-    Slot &sl = st->slot[st->calls++ & 1];
+    Slot &sl = st->slot[st->calls++ % kSlots];
     if (!sl.ev) ATL_HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
     int rc = finish_slot(ctx, st, sl);  // the previous user of this slot has left its stream; its verdicts are in
     if (rc) return rc;
@@ -696,7 +704,7 @@ bool device_inflate_wanted(size_t n_streams) {
     const char *e = getenv("ATLITE_HIP_INFLATE");
     if (e && strcmp(e, "device") == 0) return n_streams > 0;
     if (e && *e) return false;  // "host", "zlib"
-    size_t min_chunks = 512;    // below that the host threads finish first: a stream is one wave, tens of MB/s
+    size_t min_chunks = 192;    // below that the host threads finish first: a stream is one wave, tens of MB/s (up to kSlots reads overlap)
     if (const char *m = getenv("ATLITE_HIP_INFLATE_MIN_CHUNKS")) min_chunks = size_t(std::max(1, atoi(m)));
     return n_streams >= min_chunks;
 }
@@ -726,14 +734,21 @@ int submit_device(atl_ctx *ctx, Slot *sl, size_t h2d_bytes, double *d_out) {
     ATL_HIP_TRY(hipEventRecord(sl->ev_fork[0], cs));
     ATL_HIP_TRY(hipStreamWaitEvent(sl->st, sl->ev_fork[0], 0));
     const size_t n = job.inf.size(), n_desc = (job.off_res - job.off_unp) / sizeof(UnpackDesc);
+    for (hipEvent_t &e : sl->ev_t)
+        if (!e) ATL_HIP_TRY(hipEventCreate(&e));
+    ATL_HIP_TRY(hipEventRecord(sl->ev_t[0], sl->st));
     ATL_HIP_TRY(hipMemcpyAsync(sl->d, sl->h, h2d_bytes, hipMemcpyHostToDevice, sl->st));
+    ATL_HIP_TRY(hipEventRecord(sl->ev_t[1], sl->st));
     const InfDesc *d_inf = reinterpret_cast<const InfDesc *>(sl->d + job.off_inf);
     InfResult *d_res = reinterpret_cast<InfResult *>(sl->d + job.off_res);
     if (n) {
         hipLaunchKernelGGL(k_inflate, dim3(unsigned(n)), dim3(64), 0, sl->st, sl->d, d_inf, sl->d_raw, d_res);
-        hipLaunchKernelGGL(k_adler, dim3(unsigned(n)), dim3(256), 0, sl->st, sl->d_raw, d_inf, d_res);
     }
+    ATL_HIP_TRY(hipEventRecord(sl->ev_t[2], sl->st));
+    if (n) hipLaunchKernelGGL(k_adler, dim3(unsigned(n)), dim3(256), 0, sl->st, sl->d_raw, d_inf, d_res);
+    ATL_HIP_TRY(hipEventRecord(sl->ev_t[3], sl->st));
     launch_unpack(sl->st, sl->d_raw, reinterpret_cast<const UnpackDesc *>(sl->d + job.off_unp), n_desc, job.p, job.max_elems, d_out);
+    ATL_HIP_TRY(hipEventRecord(sl->ev_t[4], sl->st));
     ATL_HIP_TRY(hipGetLastError());
     if (n) ATL_HIP_TRY(hipMemcpyAsync(sl->h + job.off_res, d_res, n * sizeof(InfResult), hipMemcpyDeviceToHost, sl->st));
     ATL_HIP_TRY(hipEventRecord(sl->ev, sl->st));
@@ -751,6 +766,15 @@ int finish_slot(atl_ctx *ctx, IngestState *st, Slot &sl) {
     Pending &job = sl.job;
     if (!job.active) return ATL_OK;
     job.active = false;
+    for (int k = 0; k < 4; ++k) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, sl.ev_t[k], sl.ev_t[k + 1]) == hipSuccess) st->ms[k + 1] += double(t);
+    }
+    (void)hipGetLastError();
+    for (const InfDesc &q : job.inf) {
+        st->comp_bytes += q.src_n;
+        st->raw_bytes += q.dst_n;
+    }
     const InfResult *res = reinterpret_cast<const InfResult *>(sl.h + job.off_res);
     std::vector<size_t> bad;
     for (size_t i = 0; i < job.inf.size(); ++i)
@@ -813,6 +837,17 @@ int atl_nc_ingest_stats(atl_ctx *ctx, int64_t *device_chunks, int64_t *host_chun
     if (device_chunks) *device_chunks = st ? st->n_device_chunks : 0;
     if (host_chunks) *host_chunks = st ? st->n_host_chunks : 0;
     if (redone) *redone = st ? st->n_redone : 0;
+    return ATL_OK;
+}
+
+int atl_nc_ingest_times(atl_ctx *ctx, double *ms5, int64_t *compressed_bytes, int64_t *inflated_bytes) {
+    ATL_REQUIRE(ctx && ms5, "atl_nc_ingest_times: bad argument");
+    int rc = ingest_finish(ctx);
+    if (rc) return rc;
+    const IngestState *st = static_cast<const IngestState *>(ctx->ingest);
+    for (int k = 0; k < 5; ++k) ms5[k] = st ? st->ms[k] : 0.0;
+    if (compressed_bytes) *compressed_bytes = st ? st->comp_bytes : 0;
+    if (inflated_bytes) *inflated_bytes = st ? st->raw_bytes : 0;
     return ATL_OK;
 }
 
@@ -1131,6 +1166,7 @@ int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, 
             if (rc) return rc;
             const int fd = f->file.fd();
             const uint8_t *base = f->file.base();
+            const auto t_gather = std::chrono::steady_clock::now();
             rc = parallel_for(inf.size(), pick_threads(n_threads, inf.size()), [&](size_t i) -> int {
                 const h5::Chunk &c = d->chunks[lin[i]];
                 uint8_t *dst = sl->h + inf[i].src_off;
@@ -1146,6 +1182,7 @@ int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, 
                 return ATL_OK;
             });
             if (rc) return rc;
+            state_of(ctx)->ms[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_gather).count();
             if (!inf.empty()) memcpy(sl->h + off_inf, inf.data(), inf.size() * sizeof(InfDesc));
             memcpy(sl->h + off_unp, sel.desc.data(), sel.desc.size() * sizeof(UnpackDesc));
             Pending &job = sl->job;

@@ -470,7 +470,7 @@ int atl_nc_read_host(atl_nc *f, const char *name, int64_t start0, int64_t count0
  * atl_stream_wait_event(ctx, 0, ev)).  Two ways through the zlib streams of a chunked, deflated variable
  * (atlite/data.py:246-248 writes cutouts with zlib + shuffle):
  *  - on the DEVICE, one wavefront per chunk stream (k_inflate; round 5), when the rows asked for span at least
- *    $ATLITE_HIP_INFLATE_MIN_CHUNKS chunks (default 512; $ATLITE_HIP_INFLATE=device: always): the host threads only
+ *    $ATLITE_HIP_INFLATE_MIN_CHUNKS chunks (default 192; $ATLITE_HIP_INFLATE=device: always): the host threads only
  *    pread the COMPRESSED bytes into page-locked staging, PCIe carries those, un-shuffle + widening + CF decoding follow
  *    on the device as before.  Every stream's Adler-32 is checked on the device; a stream the device decoder declines
  *    is decoded by the host decoders before anyone can observe the copy stream (atl_event_record(ev, 1), the slot's next
@@ -482,6 +482,9 @@ int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, 
 /* chunks of this context's atl_nc_read_slab calls so far: inflated on the device / on host threads / declined by the device
  * decoder and decoded again on the host (settles pending reads first) */
 int atl_nc_ingest_stats(atl_ctx *ctx, int64_t *device_chunks, int64_t *host_chunks, int64_t *redone);
+/* device-inflate reads so far, accumulated: ms5 = {host gather of the compressed bytes (wall clock), H2D, k_inflate, k_adler,
+ * k_unpack (HIP events on the slot streams; two reads overlap, so the sum can exceed the wall time)}, bytes in / out of k_inflate */
+int atl_nc_ingest_times(atl_ctx *ctx, double *ms5, int64_t *compressed_bytes, int64_t *inflated_bytes);
 /* host array of a narrower dtype (what xarray hands over for a float32 cutout) -> fp64 on the
  * device through the same staging + decode kernel; halves the PCIe bytes of atl_upload_async */
 int atl_upload_convert_async(atl_ctx *ctx, double *d_dst, const void *h_src, int dtype, int64_t n);

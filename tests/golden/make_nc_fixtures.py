@@ -131,7 +131,32 @@ def write_case(path, T=23, Y=7, X=9, chunks=(10, 4, 5), libver=("earliest", "v10
     return exp
 
 
-def write_cutout(path, T=48, Y=9, X=12, chunks=(20, 5, 7), dtype="f4", seed=7, gzip=6, start_hours=990552):
+def _write_chunks_direct(v, a, chunks, level, threads):
+    """Same bytes libhdf5's own pipeline would store (shuffle, then zlib at `level`; edge chunks padded with the fill value
+    0), produced on `threads` threads - zlib releases the GIL - and handed over with write_direct_chunk."""
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    es = a.dtype.itemsize
+    origins = [(t, y, x) for t in range(0, a.shape[0], chunks[0]) for y in range(0, a.shape[1], chunks[1])
+               for x in range(0, a.shape[2], chunks[2])]
+
+    def pack(o):
+        part = a[o[0]:o[0] + chunks[0], o[1]:o[1] + chunks[1], o[2]:o[2] + chunks[2]]
+        if part.shape == tuple(chunks):
+            blk = np.ascontiguousarray(part)
+        else:
+            blk = np.zeros(chunks, dtype=a.dtype)
+            blk[:part.shape[0], :part.shape[1], :part.shape[2]] = part
+        shuffled = blk.view(np.uint8).reshape(-1, es).T.copy() if es > 1 else blk.view(np.uint8)
+        return zlib.compress(shuffled.tobytes(), level)
+
+    with ThreadPoolExecutor(threads) as ex:
+        for o, payload in zip(origins, ex.map(pack, origins)):
+            v.id.write_direct_chunk(o, payload)
+
+
+def write_cutout(path, T=48, Y=9, X=12, chunks=(20, 5, 7), dtype="f4", seed=7, gzip=6, start_hours=990552, threads=1):
     """An ERA5-shaped cutout with every input of pv / wind / heat_demand / runoff (random but in range)."""
     rng = np.random.default_rng(seed)
     with h5py.File(path, "w", libver=("earliest", "v108"), track_order=True) as f:
@@ -158,8 +183,13 @@ def write_cutout(path, T=48, Y=9, X=12, chunks=(20, 5, 7), dtype="f4", seed=7, g
         }
         for n, a in fields.items():
             a = np.round(a * 4096) / 4096  # keeps the deflated fixture small
-            v = f.create_dataset(n, data=a.astype(dtype), chunks=chunks, compression="gzip", compression_opts=gzip,
-                                 shuffle=True, track_order=True)
+            if threads > 1:  # big bench files: the chunks are shuffled + deflated on a thread pool and written as they are
+                v = f.create_dataset(n, shape=a.shape, dtype=dtype, chunks=chunks, compression="gzip", compression_opts=gzip,
+                                     shuffle=True, track_order=True)
+                _write_chunks_direct(v, a.astype(dtype), chunks, gzip, threads)
+            else:
+                v = f.create_dataset(n, data=a.astype(dtype), chunks=chunks, compression="gzip", compression_opts=gzip,
+                                     shuffle=True, track_order=True)
             for i, s in enumerate((t, y, x)):
                 v.dims[i].attach_scale(s)
             v.attrs["units"] = np.string_("unit of " + n)
@@ -200,7 +230,8 @@ def main(out):
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--cutout":  # --cutout path T Y X ct cy cx dtype seed
         a = sys.argv[2:]
-        write_cutout(a[0], int(a[1]), int(a[2]), int(a[3]), (int(a[4]), int(a[5]), int(a[6])), a[7], int(a[8]), gzip=1)
+        write_cutout(a[0], int(a[1]), int(a[2]), int(a[3]), (int(a[4]), int(a[5]), int(a[6])), a[7], int(a[8]), gzip=1,
+                     threads=int(a[9]) if len(a) > 9 else 1)
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "--case":  # --case path T Y X ct cy cx libver track seed [unlimited axes, e.g. 0 or 01]
         a = sys.argv[2:]

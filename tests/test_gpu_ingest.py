@@ -20,7 +20,7 @@ NC = os.path.join(os.path.dirname(__file__), "golden", "nc")
 @pytest.fixture(autouse=True, params=["host", "device"])
 def inflate_mode(request, monkeypatch):
     """Every test of this file runs twice: the chunks' zlib streams inflated on host threads, and on the device (one
-    wavefront per stream, atl_nc_read_slab; forced here - by default only reads of >= 512 chunks take it)."""
+    wavefront per stream, atl_nc_read_slab; forced here - by default only reads of >= 192 chunks take it)."""
     monkeypatch.setenv("ATLITE_HIP_INFLATE", request.param)
     return request.param
 
@@ -64,7 +64,7 @@ def test_read_slab_matches_h5py(ctx, name):
 
 
 def test_read_slab_many_calls_reuse_staging(ctx):
-    """Back-to-back calls alternate between the two staging slots without waiting for the GPU."""
+    """Back-to-back calls rotate through the staging slots without waiting for the GPU."""
     f = io.NcFile(f"{NC}/cutout_nc4.nc")
     exp = np.load(f"{NC}/cutout_nc4.npz")
     names = ["runoff", "albedo", "temperature", "roughness", "u16cube", "soil_temperature", "influx_direct"]
@@ -286,7 +286,7 @@ def test_device_inflate_many_chunks(ctx, tmp_path, monkeypatch):
         assert np.array_equal(dev.numpy().reshape(T, Y, X), host[n], equal_nan=True), n
     d1, _, r1 = ingest_stats(ctx)
     assert d1 - d0 >= len(names) * 240 * 2 and r1 == r0
-    # the default policy: a read of >= 512 chunks goes to the device, a small one stays on the host threads
+    # the default policy: a read of many chunks (default >= 192) goes to the device, a small one stays on the host threads
     monkeypatch.delenv("ATLITE_HIP_INFLATE")
     monkeypatch.setenv("ATLITE_HIP_INFLATE_MIN_CHUNKS", "200")
     d1, h1, _ = ingest_stats(ctx)

@@ -35,18 +35,21 @@ def main():
     ap.add_argument("--dtype", default="f4")
     ap.add_argument("--shapes", type=int, default=100)
     ap.add_argument("--keep", default=None, help="write the file here and keep it")
+    ap.add_argument("--threads", type=int, default=0, help="threads that deflate the chunks while the file is written (0: CPUs)")
+    ap.add_argument("--quick", action="store_true", help="only the from-file legs (device / host inflate) and the stage split")
     a = ap.parse_args()
     ct, cy, cx = (int(v) for v in a.chunks.split(","))
     tmp = tempfile.mkdtemp(prefix="atl_ingest_", dir="/tmp")
     path = a.keep or os.path.join(tmp, "cutout.nc")
     t0 = time.perf_counter()
-    subprocess.run([CONDA, os.path.join(ROOT, "tests/golden/make_nc_fixtures.py"), "--cutout", path, str(a.T), str(a.Y),
-                    str(a.X), str(ct), str(cy), str(cx), a.dtype, "11"], check=True)
+    if not (a.keep and os.path.exists(path)):  # --keep: an existing file is reused
+        subprocess.run([CONDA, os.path.join(ROOT, "tests/golden/make_nc_fixtures.py"), "--cutout", path, str(a.T), str(a.Y),
+                        str(a.X), str(ct), str(cy), str(cx), a.dtype, "11", str(a.threads or len(os.sched_getaffinity(0)))], check=True)
     print(f"wrote {path}: {os.path.getsize(path) / 1e6:.1f} MB on disk in {time.perf_counter() - t0:.1f} s "
           f"(T={a.T} {a.Y}x{a.X}, chunks {a.chunks}, {a.dtype}, 11 cubes)", flush=True)
 
     import atlite_amd as aa
-    from atlite_amd import gis, io
+    from atlite_amd import _lib, gis, io
     from atlite_amd.device import default_context
 
     ctx = default_context()
@@ -74,11 +77,38 @@ def main():
               f"{7 * cells * 8 / best / 1e9:7.2f} GB/s fp64-equivalent  {disk / best / 1e6:8.1f} MB/s of file", flush=True)
         return r
 
-    ref = leg("pv from FILE (inflate on host threads, decode on GPU)", lambda: cf.pv(**kw).values)
+    import ctypes as C
+
+    def times():
+        ms = (C.c_double * 5)()
+        cb, rb = C.c_int64(), C.c_int64()
+        _lib.check(ctx.lib.atl_nc_ingest_times(ctx.handle, ms, C.byref(cb), C.byref(rb)))
+        st = [C.c_int64() for _ in range(3)]
+        _lib.check(ctx.lib.atl_nc_ingest_stats(ctx.handle, *[C.byref(x) for x in st]))
+        return np.array(list(ms)), cb.value, rb.value, [x.value for x in st]
+
+    os.environ["ATLITE_HIP_INFLATE"] = "device"
+    ref = leg("pv from FILE (inflate on the DEVICE, one wave per chunk)", lambda: cf.pv(**kw).values, n=4)
+    m0, c0, r0, s0 = times()
+    cf.pv(**kw).values
+    m1, c1, r1, s1 = times()
+    dm = m1 - m0
+    print(f"  one warm call, stage split (two reads in flight overlap): gather {dm[0]:.1f} ms | H2D {dm[1]:.1f} ms "
+          f"({(c1 - c0) / max(dm[1], 1e-9) / 1e6:.1f} GB/s) | k_inflate {dm[2]:.1f} ms ({(r1 - r0) / max(dm[2], 1e-9) / 1e6:.1f} GB/s "
+          f"of output, {s1[0] - s0[0]} streams, {s1[2] - s0[2]} redone on the host) | k_adler {dm[3]:.1f} ms | k_unpack {dm[4]:.1f} ms", flush=True)
+    os.environ["ATLITE_HIP_INFLATE"] = "host"
+    ref_h = leg("pv from FILE (inflate on host threads, decode on GPU)", lambda: cf.pv(**kw).values)
+    assert np.array_equal(ref, ref_h), "device-inflate and host-inflate results differ"
+    print("device-inflate result == host-inflate result: bit-identical", flush=True)
+    if a.quick:
+        if not a.keep:
+            os.remove(path)
+        return
     for nt in (1, 16, 32, 64, 128):
         os.environ["ATLITE_HIP_IO_THREADS"] = str(nt)
         leg(f"  same, ATLITE_HIP_IO_THREADS={nt}", lambda: cf.pv(**kw).values, n=2)
     os.environ.pop("ATLITE_HIP_IO_THREADS")
+    os.environ.pop("ATLITE_HIP_INFLATE")
 
     f = cf.data.file
     t0 = time.perf_counter()
