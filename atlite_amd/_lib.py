@@ -42,7 +42,7 @@ class PvInputs(C.Structure):
             "d_sin_lat",
             "d_cos_lat",
         )
-    ] + [("X", C.c_int64)] + [(n, C.c_void_p) for n in ("d_influx", "d_outflux", "d_humidity")]
+    ] + [("X", C.c_int64)] + [(n, C.c_void_p) for n in ("d_influx", "d_outflux", "d_humidity", "d_day_map")] + [("day_map_ld", C.c_int64)]
 
 
 class PvParams(C.Structure):
@@ -233,6 +233,7 @@ SIGNATURES = {
     "atl_nc_read_host": (_i, [_vp, C.c_char_p, _i64, _i64, _vp]),
     "atl_nc_read_slab": (_i, [_vp, _vp, C.c_char_p, _i64, _i64, _vp, _i]),
     "atl_nc_ingest_stats": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "atl_pv_day_map": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64]),
     "atl_nc_ingest_times": (_i, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "atl_upload_convert_async": (_i, [_vp, _vp, _vp, _i, _i64]),
     "atl_upload_convert_2d_async": (_i, [_vp, _vp, _i64, _vp, _i, _i64, _i64]),

@@ -591,6 +591,9 @@ struct PvConvT {
     // a cell below the altitude cut-off converts to +0.0 whatever the other cubes hold (pv_cell: capped; a NaN
     // altitude is NOT capped)
     static constexpr bool kNightPipe = SKIP;
+    // stored angles: the early-out's votes can come from a day map built once per (plan, altitude cube, cut-off):
+    // atl_pv_day_map -> in.d_day_map (pv() with its defaults and Hay-Davies, either orientation kind)
+    static constexpr bool kDayMap = SKIP && !SP && (TAIL == kTailHuld || TAIL == kTailHuldHayDavies) && TRACK == ATL_TRACK_NONE && HEAD == 0;
     // register budget of the fused kernels: the night kernel with stored angles and one orientation for the grid
     // fits 4 waves per SIMD
 #ifndef ATL_SP_NIGHT_WAVES

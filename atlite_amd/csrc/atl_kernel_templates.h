@@ -273,6 +273,12 @@ template <class Conv, class = void>
 struct conv_stage_values : std::false_type {};
 template <class Conv>
 struct conv_stage_values<Conv, std::void_t<decltype(Conv::kStageValues)>> : std::integral_constant<bool, Conv::kStageValues> {};
+// converters whose early-out can read a precomputed DAY MAP instead of loading and voting on the keys (Conv::kDayMap;
+// the map pointer travels in conv.in.d_day_map: k_day_map / k_fused_segred_night<..., MAP = true>)
+template <class Conv, class = void>
+struct conv_day_map : std::false_type {};
+template <class Conv>
+struct conv_day_map<Conv, std::void_t<decltype(Conv::kDayMap)>> : std::integral_constant<bool, Conv::kDayMap> {};
 template <class Conv, class = void>
 struct conv_night_pipe : std::false_type {};
 template <class Conv>
@@ -889,7 +895,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
 // LDS and a loop instead of eight unrolled slots the kernel needs < 128 VGPRs: 4 waves per SIMD, for which
 // the LDS budget (160 KiB / 16 waves) leaves kRowCacheNight = 2 weight rows per wave.  Converters opt in with
 // kNightPipe and provide key_load / key_is_zero / rest_load / compute_keyed.
-template <class Conv, bool VEC, bool DENSE>
+#ifndef ATL_DAYMAP_PIPE
+#define ATL_DAYMAP_PIPE 1
+#endif
+template <class Conv, bool VEC, bool DENSE, bool MAP = false>
 __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 2 : min_waves<Conv>()) void k_fused_segred_night(Conv conv, PlanDev plan, int64_t slot0,
                                                       int64_t n_slots, int64_t S, int32_t chunk_slots,
                                                       int64_t n_units, double *__restrict__ partials,
@@ -933,6 +942,67 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 2 : min_waves<Conv>())
     const int64_t send = min(min(sbeg + int64_t(chunk_slots), slot0 + n_slots), uc.slots);
     if (sbeg >= send) return;
     partials -= slot0;
+    if constexpr (MAP) {
+        // The day bits of this tile were computed once for the (plan, altitude cube, cut-off) - k_day_map, the same vote - :
+        // a batch reads one byte through the scalar cache instead of eight altitude pairs per lane; a dark slot reads
+        // NOTHING, a day slot issues all of its streams at once (no key-then-rest dependency).
+        static_assert(!DENSE, "day map: sparse tiles");
+        const uint8_t *mrow = conv.in.d_day_map + int64_t(seg) * conv.in.day_map_ld;
+        for (int64_t sb = sbeg; sb < send; sb += kBatch) {
+            const int64_t rel = sb - slot0;  // the map is indexed by the call's own slots
+            unsigned day = ((unsigned(mrow[rel >> 3]) | (unsigned(mrow[(rel >> 3) + 1]) << 8)) >> (rel & 7)) & 0xFFu;
+            day = __builtin_amdgcn_readfirstlane(day);
+            if (send - sb < kBatch) day &= (1u << int(send - sb)) - 1u;
+#pragma unroll
+            for (int i = 0; i < kBatch; ++i) *reinterpret_cast<double2 *>(vl + vrow_pair<false>(i, lane)) = double2{0.0, 0.0};
+            bool finite = true;
+            unsigned m = day;
+            // two register sets: the next day slot's seven streams are in flight while this one is converted (the keys'
+            // 16 registers are gone, so both sets fit the 128 of four waves per SIMD)
+            typename Conv::Carry carry{};
+#if !ATL_DAYMAP_PIPE  // experiment (tools/build_variant.sh): one register set, a day slot's loads wait for the previous conversion
+            while (m) {
+                const int p1s = __builtin_ctz(m);
+                m &= m - 1;
+                typename Conv::Raw A1 = {};
+                if (covered) A1 = conv.template load<VEC>(sb + p1s, p1s, s0c, s1c, cell, carry);
+                double2 r = conv.compute(A1, v0, v1, cell, lds);
+                r.x = covered ? r.x : 0.0;
+                r.y = covered ? r.y : 0.0;
+                finite = finite && (__builtin_fabs(r.x) < __builtin_inf()) && (__builtin_fabs(r.y) < __builtin_inf());
+                *reinterpret_cast<double2 *>(vl + vrow_pair<false>(p1s, lane)) = r;
+            }
+#endif
+            typename Conv::Raw A = {};
+            int p = -1;
+            if (m) {
+                p = __builtin_ctz(m);
+                m &= m - 1;
+                if (covered) A = conv.template load<VEC>(sb + p, p, s0c, s1c, cell, carry);
+            }
+            while (p >= 0) {
+                typename Conv::Raw B = {};
+                int q = -1;
+                if (m) {
+                    q = __builtin_ctz(m);
+                    m &= m - 1;
+                    if (covered) B = conv.template load<VEC>(sb + q, q, s0c, s1c, cell, carry);
+                }
+                double2 r = conv.compute(A, v0, v1, cell, lds);
+                r.x = covered ? r.x : 0.0;
+                r.y = covered ? r.y : 0.0;
+                finite = finite && (__builtin_fabs(r.x) < __builtin_inf()) && (__builtin_fabs(r.y) < __builtin_inf());
+                *reinterpret_cast<double2 *>(vl + vrow_pair<false>(p, lane)) = r;
+                A = B;
+                p = q;
+            }
+            double2 v[kBatch];
+#pragma unroll
+            for (int i = 0; i < kBatch; ++i) v[i] = *reinterpret_cast<const double2 *>(vl + vrow_pair<false>(i, lane));
+            reduce_batch<kRowCacheNight>(v, finite, plan, p0, p1, wlds, present, lane, sb, send, partials, ldp);
+        }
+        return;
+    }
     double2 key[kBatch];
 #pragma unroll
     for (int i = 0; i < kBatch; ++i) key[i] = covered ? conv.template key_load<VEC>(min(sbeg + i, send - 1), s0c, s1c, cell) : double2{0.0, 0.0};
@@ -981,6 +1051,40 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 2 : min_waves<Conv>())
             else
                 reduce_batch<kRowCacheNight>(v, finite, plan, p0, p1, wlds, present, lane, sb, send, partials, ldp);
         }
+    }
+}
+
+// The early-out's votes, once: bit (t & 7) of map[tile * ld + (t >> 3)] = in slot t some covered cell of the tile has a key
+// that does not convert to +0.0 - literally the test k_fused_segred_night makes on the keys it loads (same converter
+// functions, same lanes, same coverage mask).  One wave per (tile, run of 64 slots); bytes past the last slot's are 0.
+template <class Conv, bool VEC>
+__global__ __launch_bounds__(256) void k_day_map(Conv conv, PlanDev plan, int64_t n_slots, int64_t S, int64_t n_units,
+                                                 uint8_t *__restrict__ map, int64_t ld) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    conv.block_init(lds);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    const int64_t unit = int64_t(blockIdx.x) * 4 + wave;
+    if (unit >= n_units) return;
+    const int32_t seg = int32_t(unit % plan.n_segs);
+    const int64_t run = unit / plan.n_segs;
+    const UnitCells uc = unit_cells(plan, seg, lane, S, n_slots);
+    const typename Conv::Cell cell = conv.cell_setup(uc.c0, uc.v0, uc.v1, lds);
+    const bool covered = (plan.seg_mask[seg] >> lane) & 1u;
+    const int64_t sbeg = run * 64, send = min(sbeg + 64, n_slots);
+    for (int64_t sb = sbeg; sb < send; sb += kBatch) {
+        double2 key[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i)
+            key[i] = covered ? conv.template key_load<VEC>(min(sb + i, send - 1), uc.ld0, uc.ld1, cell) : double2{0.0, 0.0};
+        unsigned day = 0;
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+            const bool d = (sb + i < send) && !__all(conv.key_is_zero(key[i], min(sb + i, send - 1), cell) || !covered);
+            day |= d ? 1u << i : 0u;
+        }
+        if (lane == 0) map[int64_t(seg) * ld + (sb >> 3)] = uint8_t(day);
     }
 }
 
@@ -1355,7 +1459,15 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
             const size_t lds_base = conv_lds + size_t(kWavesPerBlock) * (dense ? kRowCacheDense + kDenseSlots : stage ? kRowCacheNight + kBatch : kRowCache) * kSegCells * sizeof(double);
             if constexpr (conv_night_pipe<Conv>::value) {
                 const size_t lds_night = conv_lds + size_t(kWavesPerBlock) * (kRowCacheNight + kBatch) * kSegCells * sizeof(double);
-                if (!vec) {
+                bool mapped = false;
+                if constexpr (conv_day_map<Conv>::value) {
+                    if (conv.in.d_day_map && vec && !dense && !aligned && w0 == 0 && wn == n_slots) {
+                        launch(k_fused_segred_night<Conv, true, false, true>, lds_night);
+                        mapped = true;
+                    }
+                }
+                if (mapped) {
+                } else if (!vec) {
                     if constexpr (kScalarToo) launch(k_fused_segred_night<Conv, false, false>, lds_night);
                 } else if constexpr (conv_dense_ok<Conv>::value)
                     dense ? launch(k_fused_segred_night<Conv, true, true>, lds_night) : launch(k_fused_segred_night<Conv, true, false>, lds_night);

@@ -119,6 +119,37 @@ int atl_pv_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p
     return rc == kNeedScalar ? pvx_convert(ctx, in, p, T, S, time_agg, d_out) : rc;
 }
 
+int atl_pv_day_map(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S, const atl_agg *agg,
+                   uint8_t *d_map, int64_t ld) {
+    ATL_REQUIRE(ctx && in && p && agg && d_map, "atl_pv_day_map: a NULL argument");
+    ATL_REQUIRE(agg->ctx == ctx, "atl_pv_day_map: aggregation plan belongs to another context");
+    ATL_REQUIRE(in->d_solar_altitude, "atl_pv_day_map: needs the stored solar altitude");
+    ATL_REQUIRE(agg->dev.shift_classes == 0, "atl_pv_day_map: not for line-aligned plans");
+    ATL_REQUIRE(agg->dev.n_cells == S, "atl_pv_day_map: matrix has %lld columns but the cutout has %lld cells",
+                (long long)agg->dev.n_cells, (long long)S);
+    ATL_REQUIRE(T >= 0 && ld >= T / 8 + 2, "atl_pv_day_map: ld %lld is too small for %lld time steps", (long long)ld, (long long)T);
+    ATL_HIP_TRY(hipSetDevice(ctx->device));
+    const PlanDev &plan = agg->dev;
+    if (plan.n_segs == 0) return ATL_OK;
+    ATL_HIP_TRY(hipMemsetAsync(d_map, 0, size_t(plan.n_segs) * size_t(ld), ctx->stream));
+    if (T == 0) return ATL_OK;
+    PvConvT<false, false, true> c;  // the keys of every stored-angle early-out converter: altitude against the cut-off
+    const int64_t stride = slot_stride_of(ctx, S);
+    ATL_REQUIRE(stride >= S, "atl_pv_day_map: slot stride %lld is smaller than the %lld cells of a slot", (long long)stride, (long long)S);
+    c.in = *in;
+    c.S = stride;
+    c.k = pv_const_of(p);
+    c.cell_slope = c.cell_azimuth = nullptr;
+    const bool vec = vec_ok(T, S, stride, {in->d_solar_altitude});
+    const int64_t n_units = ((T + 63) / 64) * int64_t(plan.n_segs);
+    const dim3 grid(unsigned((n_units + 3) / 4));
+    if (vec)
+        hipLaunchKernelGGL((k_day_map<PvConvT<false, false, true>, true>), grid, dim3(256), 0, ctx->stream, c, plan, T, S, n_units, d_map, ld);
+    else
+        hipLaunchKernelGGL((k_day_map<PvConvT<false, false, true>, false>), grid, dim3(256), 0, ctx->stream, c, plan, T, S, n_units, d_map, ld);
+    return check_launch("atl_pv_day_map");
+}
+
 int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T,
                              int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out) {
     ATL_REQUIRE(ctx && in && p, "atl_pv_convert_aggregate: ctx/inputs/params is NULL");

@@ -219,6 +219,20 @@ class DeviceArray:
         return f"DeviceArray(shape={self.shape}{pitch}, dtype={self.dtype}, device={self.ctx.device})"
 
 
+def root_block(a):
+    """The allocation a DeviceArray view ultimately points into (views keep their parent alive in ``_owner``)."""
+    while isinstance(a._owner, DeviceArray):
+        a = a._owner
+    return a
+
+
+def mark_static(a):
+    """The library filled this block from host or file data and nobody else holds a pointer to write through: what is
+    derived from its CONTENTS (the early-out's day maps, ``Context.pv``) may be kept with it."""
+    root_block(a)._static = True
+    return a
+
+
 def interleave_enabled():
     """``ATLITE_HIP_INTERLEAVE=0``: every device copy in an allocation of its own (the layout before round 3)."""
     return os.environ.get("ATLITE_HIP_INTERLEAVE", "1") != "0"
@@ -721,6 +735,10 @@ class Context:
             pp.orientation_per_time = 1 if per_time else 0
         self._stride(S, *[v for v in inputs.values() if v is not None], *([ds, da] if pp.orientation_per_time else []))
         try:
+            if plan is not None and pp.night_skip and solar_tables is None:
+                dm = self._day_map(inputs.get("solar_altitude"), pin, pp, T, S, plan, options)
+                if dm is not None:
+                    pin.d_day_map, pin.day_map_ld = dm[0].ptr, dm[1]
             res, optr, ld = self._out(plan, T, S, time_agg, out)
             if plan is None:
                 check(self.lib.atl_pv_convert(self.handle, C.byref(pin), C.byref(pp), T, S, _TIME_CODES[time_agg], optr))
@@ -732,6 +750,31 @@ class Context:
         if keep:
             self.sync()  # temporaries uploaded for this call must outlive the kernels
         return res
+
+    def _day_map(self, alt, pin, pp, T, S, plan, options):
+        """(map, ld) of the early-out's day bits for (plan, altitude cube, cut-off) - ``atl_pv_day_map`` - or None.  Built on
+        first use and kept WITH THE CUBE'S ALLOCATION, so it lives exactly as long as the device copy it describes; only for
+        cubes the library filled itself (``mark_static``: a caller's own device array may be rewritten between calls) unless
+        ``options["day_map"]`` says the caller vouches for it.  ``ATLITE_HIP_DAY_MAP=0`` switches the maps off."""
+        want = options.get("day_map")
+        if alt is None or want is False or plan.aligned or T == 0 or os.environ.get("ATLITE_HIP_DAY_MAP", "1") == "0":
+            return None
+        root = root_block(alt)
+        if not (want or getattr(root, "_static", False)):
+            return None
+        maps = root.__dict__.setdefault("_day_maps", {})
+        key = (alt.ptr, alt.ld, T, S, id(plan), float(pp.altitude_threshold))
+        hit = maps.get(key)
+        if hit is not None and hit[0] is plan:
+            return hit[1], hit[2]
+        ld = (T // 8 + 2 + 3) // 4 * 4
+        n_tiles = plan.info()["n_segments"]
+        dmap = self.empty((max(n_tiles, 1) * ld,), np.uint8)
+        check(self.lib.atl_pv_day_map(self.handle, C.byref(pin), C.byref(pp), T, S, plan.handle, dmap.ptr, ld))
+        while len(maps) >= 4:  # a handful of plans per cutout
+            maps.pop(next(iter(maps)))
+        maps[key] = (plan, dmap, ld)
+        return dmap, ld
 
     def wind(self, wnd, aux, V, POWn, to_height, from_height, method, T, S, plan=None, time_agg=None, out=None):
         """V / POWn: the power curve (POW / P); V = None: no power curve - the extrapolated wind speed itself."""

@@ -235,12 +235,16 @@ class Dataset:
     (atlite/aggregate.py:21-35).
     """
 
-    def __init__(self, data_vars, coords, attrs=None, chunked=False, repack=None):
+    def __init__(self, data_vars, coords, attrs=None, chunked=False, repack=None, static=False):
         # repack: copy (time, y, x) variables the CALLER holds on the device into the library's padded, slot-interleaved
         # layout on first use when the cell count is not a multiple of 16 (contiguous cubes off the 128-byte line grid run
         # the fused kernels 15-35 % slower: one extra line per 1-KiB wave load).  Costs one device-to-device copy and the
         # cubes' size in HBM again; pays off from the second conversion on.  Default: $ATLITE_HIP_REPACK == "1".
         self.repack = (os.environ.get("ATLITE_HIP_REPACK", "0") == "1") if repack is None else bool(repack)
+        # static: the caller promises not to rewrite the DEVICE arrays it hands in while this dataset is in use (a cutout's
+        # data never changes, atlite/cutout.py:151-153), so what is derived from their contents - the night early-out's day
+        # maps - may be cached with them.  The library's own copies of host / file data always are.
+        self.static = bool(static)
         self.coords = {}
         for k, v in coords.items():
             self.coords[k] = pd.DatetimeIndex(v) if k == "time" else np.asarray(v, dtype=np.float64)
@@ -490,14 +494,19 @@ class Dataset:
         from ._lib import check
 
         T, S = view.shape
+        from .device import root_block
+
+        root_block(view).__dict__.pop("_day_maps", None)  # what was derived from the block's old contents
         if resident is not None:
             r = resident.reshape(T, S)
             check(ctx.lib.atl_copy_2d(ctx.handle, view.ptr, (view.ld or S) * 8, r.ptr, (r.ld or S) * 8, S * 8, T, 2, 0))
             ctx.sync()  # the old copy may be freed as soon as the cache lets go of it
             return view
+        from .device import mark_static
+
         x = self._vars[name].data
         if getattr(x, "is_file_array", False):
-            return x.to_device(ctx, out=view)
+            return mark_static(x.to_device(ctx, out=view))
         if _is_device(x) or (type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)):
             r = ctx.asdevice(x).reshape(T, S)  # the caller's own device cube (repack): copied on the device
             check(ctx.lib.atl_copy_2d(ctx.handle, view.ptr, (view.ld or S) * 8, r.ptr, (r.ld or S) * 8, S * 8, T, 2, 0))
@@ -505,7 +514,7 @@ class Dataset:
             return view
         if type(x).__module__.startswith("torch") and hasattr(x, "data_ptr"):
             x = x.numpy()
-        return ctx.upload(np.asarray(x).reshape(T, -1), out=view)
+        return mark_static(ctx.upload(np.asarray(x).reshape(T, -1), out=view))
 
     def _caller_layout(self):
         """True when a (time, y, x) variable already lives on a device in the caller's own (contiguous) layout, which every
@@ -532,14 +541,20 @@ class Dataset:
         if ld is not None and (_is_device(x) or (type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False))):
             d = ctx.asdevice(x)  # repack: a padded copy of the caller's device cube
             return ctx._relayout(d.reshape(d.shape[0], -1), ld)
-        if ld is None or _is_device(x):
-            return ctx.asdevice(x)
+        from .device import mark_static
+
+        if _is_device(x) or (type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)):
+            d = ctx.asdevice(x)  # the caller's own device memory, as it lies
+            return mark_static(d) if self.static and _is_device(x) else d
+        if ld is None:
+            return mark_static(ctx.asdevice(x))
         T = x.shape[0]
+
         if getattr(x, "is_file_array", False):  # inflate + decode straight into the padded rows
-            return x.to_device(ctx, ld=ld)
+            return mark_static(x.to_device(ctx, ld=ld))
         if type(x).__module__.startswith("torch") and hasattr(x, "data_ptr"):
             x = x.numpy()
-        return ctx.upload(np.asarray(x).reshape(T, -1), ld=ld)
+        return mark_static(ctx.upload(np.asarray(x).reshape(T, -1), ld=ld))
 
     def __repr__(self):
         return f"<Dataset {self.sizes} vars={list(self._vars)} chunked={self.chunked}>"

@@ -157,7 +157,7 @@ PEAK_GBPS = 8000.0  # HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 # profile entry is only quoted for a leg when it was measured on THIS kernel
 KERNELS = {
     "headline": "k_fused_segred<PvConvT<false, false, false, 0, 0, 0>, true, false>",
-    "night_skip": "k_fused_segred_night<PvConvT<false, false, true, 0, 0, 0>, true, false>",
+    "night_skip": "k_fused_segred_night<PvConvT<false, false, true, 0, 0, 0>, true, false, true>",
     "star_polygons": "k_fused_segred<PvConvT<false, false, false, 0, 0, 0>, true, false>",
     "star_night_skip": "k_fused_segred_night<PvConvT<false, false, true, 0, 0, 0>, true, false>",
     "c3_series": "k_cells_series_flat<WindConvT<1, -1>>",
@@ -995,8 +995,23 @@ def main():
         # (1) the Python API's default: night early-out (bit-identical output, fewer bytes read)
         if not a.night_skip and want("night_skip"):
             ref_out = step(pp_main).clone()
+            dts_v, kk_v = timed(pv_params(True), ks, kw_)  # the tile's altitudes loaded and voted on (first call; a caller's own cubes)
+            same_v = bool(torch.equal(step(pv_params(True)), ref_out))
+            # ... and with the day map of (plan, altitude cube, cut-off), built once and kept with the cube: the API's steady state
+            ld_m = (T_loc // 8 + 2 + 3) // 4 * 4
+            dmap = ctx.empty((max(plan_info["n_segments"], 1) * ld_m,), np.uint8)
+            _lib.check(ctx.lib.atl_set_slot_stride(ctx.handle, 0 if ld == S else ld))
+            ctx.sync()
+            ctx.timer_start()
+            _lib.check(ctx.lib.atl_pv_day_map(ctx.handle, C.byref(pin), C.byref(pv_params(True)), T_loc, S, plan.handle, dmap.ptr, ld_m))
+            map_ms = ctx.timer_stop()
+            _lib.check(ctx.lib.atl_set_slot_stride(ctx.handle, 0))
+            for q in pins:
+                q.d_day_map, q.day_map_ld = dmap.ptr, ld_m
             dts, kk = timed(pv_params(True), ks, kw_)
-            same = bool(torch.equal(step(pv_params(True)), ref_out))
+            same = bool(torch.equal(step(pv_params(True)), ref_out)) and same_v
+            for q in pins:
+                q.d_day_map, q.day_map_ld = None, 0
             # algorithmic bytes of the early-out: the altitude cube in full + the six other cubes where a cell is up
             # (the fewest bytes any per-cell early-out could read; the kernel decides per 128-cell tile and slot)
             try:
@@ -1007,7 +1022,11 @@ def main():
                 n_day, night_bytes = None, None
                 print(f"[bench] day-cell count skipped: {e!r}", file=sys.stderr)
             result["night_skip"] = {"ms_per_step": dts / ks * 1e3, "value": T_total * S / (dts / ks), "bit_identical": same,
-                                    "day_cell_steps": n_day,
+                                    "day_cell_steps": n_day, "day_map": True, "day_map_build_ms": map_ms,
+                                    "day_cell_bytes": 56 * n_day if n_day else None,
+                                    "voting_kernel": {"ms_per_step": dts_v / ks * 1e3, "kernel_ms": float(np.mean(kk_v)) if len(kk_v) else None,
+                                                      "note": "no day map: the tile's altitudes loaded and voted on (round 4's kernel; first call, "
+                                                              "or cubes the caller may rewrite)"},
                                     "roofline": roofline_of("night_skip", night_bytes or algo_bytes, kk,
                                                             {"note": "algorithmic bytes = 8 B x every cell-step (altitude) + 48 B x the "
                                                                      "cell-steps above the 1 degree cut-off; the kernel skips per tile and "
@@ -1033,7 +1052,7 @@ def main():
         if want("api"):
             from atlite_amd import Cutout, Dataset
 
-            cut = Cutout(Dataset(dict(inputs), dict(time=synthetic.time_index(T_loc), y=y, x=x)))
+            cut = Cutout(Dataset(dict(inputs), dict(time=synthetic.time_index(T_loc), y=y, x=x), static=True))
             kw = dict(panel="CSi", orientation={"slope": 30.0, "azimuth": 180.0}, aggregate_time=None)
 
             def call(**k):

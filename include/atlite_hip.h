@@ -222,6 +222,13 @@ typedef struct {
     const double *d_influx;         /* (T,S) or NULL (then influx_direct/diffuse are used) */
     const double *d_outflux;        /* (T,S), used iff d_albedo == NULL                    */
     const double *d_humidity;       /* (T,S), "enhanced" clearsky model only               */
+    /* night early-out with a DAY MAP (atl_pv_day_map; round 5): bit (t & 7) of d_day_map[tile * day_map_ld + (t >> 3)] =
+     * in time step t some cell of the plan's tile that carries a weight is above the altitude cut-off - what the early-out
+     * kernel otherwise finds out by loading the tile's altitudes and voting.  Belongs to ONE (aggregation plan,
+     * d_solar_altitude contents, altitude_threshold, T, slot stride); NULL = vote.  Read by atl_pv_convert_aggregate with
+     * night_skip = 1 and stored angles; ignored everywhere else. */
+    const uint8_t *d_day_map;
+    int64_t day_map_ld;
 } atl_pv_inputs;
 
 #define ATL_TRACK_NONE 0              /* pv/orientation.py:113-117 */
@@ -276,6 +283,13 @@ int atl_pv_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p
 int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p,
                              int64_t T, int64_t S, const atl_agg *agg, int time_agg,
                              double *d_out, int64_t ld_out);
+
+/* The day map of (plan, in->d_solar_altitude, p->altitude_threshold) for T time steps: d_map is n_tiles x ld bytes
+ * (n_tiles: atl_agg_info's n_segments; ld >= T / 8 + 2), every byte written.  The altitude cube is read once (8 B per
+ * cell-step); cutout data does not change, so callers keep the map with the device copy of the cube
+ * (atlite/pv/irradiation.py:251-252 and solar_position.py:54-60: the cut-off the map encodes). */
+int atl_pv_day_map(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S,
+                   const atl_agg *agg, uint8_t *d_map, int64_t ld);
 
 /* ---- wind ----------------------------------------------------------------------------
  * Replaces convert_wind (convert.py:634-662) = extrapolate_wind_speed (wind.py:76-112)
