@@ -279,6 +279,14 @@ SIGNATURES = {
     ),
 }
 
+# the twins that take the slot stride as their second argument (include/atlite_hip.h: "the slot stride as an ARGUMENT")
+for _name in ("atl_agg_create", "atl_spmm_csr", "atl_pv_convert", "atl_pv_convert_aggregate", "atl_pv_day_map", "atl_wind_convert",
+              "atl_wind_convert_aggregate", "atl_heat_demand_convert", "atl_heat_demand_convert_aggregate", "atl_thermo_convert",
+              "atl_thermo_convert_aggregate", "atl_runoff_convert", "atl_runoff_convert_aggregate", "atl_nc_read_slab"):
+    _res, _args = SIGNATURES[_name]
+    SIGNATURES[_name + "_ld"] = (_res, [_args[0], _i64] + list(_args[1:]))
+del _name, _res, _args
+
 _lib = None
 
 

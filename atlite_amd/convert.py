@@ -271,6 +271,12 @@ class _PvSpec(_Spec):
     def time_vars(self):
         return tuple(dict.fromkeys(self.vars))
 
+    @property
+    def aligned_ok(self):
+        """Line-aligned plans re-address the cubes by slot; the in-kernel solar position (per-time tables) and an
+        orientation that follows the sun (the general kernel) index by the time step itself: not worth building the plan."""
+        return self.solar_tables is None and not self.per_time
+
     def prepare(self, ctx, ds):
         """Upload the per-call constant tables once (per-cell orientation, solar position tables)."""
         S = len(ds.coords["y"]) * len(ds.coords["x"])
@@ -834,9 +840,8 @@ def convert_and_aggregate(
             # line-aligned plan (atl_agg_create_aligned); conversions it does not cover answer with an error -> ordinary plan
             try:
                 out = _execute(ctx, spec, ds, ctx.plan(matrix, row_len=X, aligned=True), on_device_time)
-            except ValueError as e:  # (ATL_E_INVALID)
-                if "line-aligned plan" not in str(e):
-                    raise
+            except NotImplementedError:  # ATL_E_UNSUPPORTED: this converter / these cubes cannot be re-addressed
+                out = None
         if out is None:
             plan = ctx.plan(matrix, row_len=X, ld=getattr(ds, "_slot_stride", lambda: None)())
             out = _execute(ctx, spec, ds, plan, on_device_time)  # the plan stays in ctx's cache
@@ -1067,6 +1072,12 @@ def runoff(cutout, smooth=None, lower_threshold_quantile=None, normalize_using_y
     """
     Runoff (optionally height-weighted) aggregated to shapes, with the reference's post-processing of the small
     (shapes x time) result (convert.py:1037-1084) - on the device, before the result is downloaded.
+
+    One deliberate deviation, in ``smooth``: a +-inf value in the series counts as MISSING in the rolling mean (what
+    pandas' rolling does), where the reference's ``rolling(time=w, min_periods=1).mean()`` - xarray -> bottleneck
+    ``move_mean`` - keeps the inf in the window's running sum: inf while it is inside, NaN for the rest of the row once
+    it has left (inf - inf).  Runoff is finite; NaN is skipped in both.  The running sums restart every 256 steps with
+    compensated additions, so finite results can differ from bottleneck's in the last bits (rtol 1e-10 holds).
     """
     post = _RunoffPost(smooth, lower_threshold_quantile, normalize_using_yearly)
     if post:
@@ -1091,12 +1102,19 @@ def runoff(cutout, smooth=None, lower_threshold_quantile=None, normalize_using_y
                                                {d: result.coords[d].values for d in result.dims},
                                                dict(result.attrs), result.name)
     ax = la.get_axis_num("time")  # (a result without a time axis cannot be smoothed: the reference raises as well)
-    dim = la.dims[1 - ax]
-    if post.dim_coords is None or len(post.dim_coords) != la.shape[1 - ax]:
-        post.dim_coords = la.coords.get(dim, np.arange(la.shape[1 - ax]))
+    # any rank: a per-cell (time, y, x) cube (no shapes) is smoothed along time per cell and thresholded on the quantile of
+    # ALL its values, as the reference's rolling(time=...) / values.ravel() do (convert.py:1046-1062); time goes last, the
+    # other axes are the rows of the device routines
+    vals = np.moveaxis(np.asarray(la.values, dtype=np.float64), ax, -1)
+    lead, T_ = vals.shape[:-1], vals.shape[-1]
+    if post.norm is not None:
+        if la.ndim != 2:
+            raise ValueError("normalize_using_yearly needs a (shapes x time) result: pass shapes or a matrix")
+        dim = la.dims[1 - ax]
+        if post.dim_coords is None or len(post.dim_coords) != la.shape[1 - ax]:
+            post.dim_coords = la.coords.get(dim, np.arange(la.shape[1 - ax]))
     ctx = default_context()
-    vals = np.ascontiguousarray(np.moveaxis(np.asarray(la.values, dtype=np.float64), ax, 1))
-    out = post(ctx, ctx.upload(vals), la.coords["time"]).numpy()
-    la = LabeledArray(np.moveaxis(out, 1, ax), la.dims, la.coords, la.attrs, la.name)
+    out = post(ctx, ctx.upload(np.ascontiguousarray(vals.reshape(-1, T_))), la.coords["time"]).numpy()
+    la = LabeledArray(np.moveaxis(out.reshape(lead + (T_,)), -1, ax), la.dims, la.coords, la.attrs, la.name)
     out = _finish(la) if is_xr or labeled.xr is not None else la
     return (out, cap) if cap is not None else out

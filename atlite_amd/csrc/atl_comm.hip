@@ -207,6 +207,7 @@ struct atl_comm {
     int64_t tickets = 0;
     void *buf = nullptr;                 // send / receive staging of the asynchronous collectives
     size_t buf_bytes = 0;
+    bool aborted = false;                // atl_comm_abort ran: only atl_comm_destroy is left
 };
 
 namespace {
@@ -296,6 +297,7 @@ int gather_place(atl_comm *comm, const double *d_local, int64_t N, const RankOff
 int check_gather_args(const char *what, atl_comm *comm, const double *d_local, int64_t N, const int64_t *h_lens,
                       double *d_out, int64_t ld_out, RankOffsets *ro, int64_t *Tmax) {
     ATL_REQUIRE(comm && h_lens && d_out, "%s: bad argument", what);
+    ATL_REQUIRE(!comm->aborted, "%s: the communicator was aborted", what);
     ATL_REQUIRE(N >= 0 && N < 65536, "%s: bad shape", what);
     int rc = fill_offsets(what, comm->n_ranks, h_lens, ro, Tmax);
     if (rc) return rc;
@@ -507,8 +509,14 @@ int atl_comm_abort(atl_comm *comm) {
         comm->group->aborted = true;
         comm->group->cv.notify_all();
     }
-    // RCCL: a rank that never enqueues its collective leaves the others blocked on the device; ncclCommAbort frees
-    // this rank's side, destroying the communicator after an error is the caller's recourse
+    // RCCL: a rank that never enqueues its collective leaves the others blocked on the device; ncclCommAbort ends this
+    // rank's outstanding operations and frees its side of the communicator (atl_comm_destroy then finds nothing to destroy)
+    comm->aborted = true;
+    if (comm->comm && g_rccl.CommAbort) {
+        (void)hipSetDevice(comm->ctx->device);
+        (void)g_rccl.CommAbort(comm->comm);
+        comm->comm = nullptr;
+    }
     return ATL_OK;
 }
 
@@ -640,6 +648,7 @@ int atl_gather_place_v_host(const double *h_gathered, int n_ranks, int64_t N, co
 
 int atl_allreduce_sum(atl_comm *comm, double *d_buf, int64_t n) {
     ATL_REQUIRE(comm && (n == 0 || d_buf) && n >= 0, "atl_allreduce_sum: bad argument");
+    ATL_REQUIRE(!comm->aborted, "atl_allreduce_sum: the communicator was aborted");
     if (n == 0) return ATL_OK;
     atl_ctx *ctx = comm->ctx;
     ATL_HIP_TRY(hipSetDevice(ctx->device));

@@ -1369,10 +1369,18 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
     ATL_REQUIRE(agg->dev.n_cells == S, "%s: matrix has %lld columns but the cutout has %lld cells", what,
                 (long long)agg->dev.n_cells, (long long)S);
     if (aligned) {
-        ATL_REQUIRE(conv_shift_ok<Conv>::value, "%s: this conversion cannot run on a line-aligned plan (atl_agg_create_aligned)", what);
+        // refusals of a line-aligned plan are ATL_E_UNSUPPORTED, not ATL_E_INVALID: the caller (the gateway) takes the
+        // ordinary plan instead - told apart by the code, not by the wording
+        if (!conv_shift_ok<Conv>::value) {
+            set_error("%s: this conversion cannot run on a line-aligned plan (atl_agg_create_aligned)", what);
+            return ATL_E_UNSUPPORTED;
+        }
         ATL_REQUIRE(slot_stride_of(ctx, S) == S, "%s: a line-aligned plan is for contiguous cubes (slot stride %lld, %lld cells)", what,
                     (long long)slot_stride_of(ctx, S), (long long)S);
-        ATL_REQUIRE(vec, "%s: a line-aligned plan needs the vectorised kernels (8-byte aligned cubes that do not end on a page boundary)", what);
+        if (!vec) {
+            set_error("%s: a line-aligned plan needs the vectorised kernels (8-byte aligned cubes that do not end on a page boundary)", what);
+            return ATL_E_UNSUPPORTED;
+        }
         if constexpr (conv_shift_ok<Conv>::value) {
             if (conv.S != agg->dev.shift_classes * S) {  // the converter's slot stride: p slots of the contiguous cubes
                 Conv strided = conv;

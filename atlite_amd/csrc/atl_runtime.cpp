@@ -1451,3 +1451,95 @@ int atl_agg_info(const atl_agg *agg, int64_t *n_rows, int64_t *n_cells, int64_t 
 }
 
 }  // extern "C"
+
+
+// ---- the conversion calls with the slot stride as an ARGUMENT (round 5) ------------------------------------------------
+// atl_set_slot_stride makes the stride context state that a conversion call reads: two calls whose coupling a forgotten
+// reset breaks silently.  These entry points take it with the call (ld_cells: cells between the slots of the call's (T, S)
+// input cubes, 0 = contiguous) and leave the context's own setting as they found it.  The Python layer calls only these.
+namespace {
+struct StrideScope {
+    atl_ctx *c;
+    int64_t old;
+    StrideScope(atl_ctx *ctx, int64_t ld) : c(ctx), old(ctx->slot_stride) { c->slot_stride = ld; }
+    ~StrideScope() { c->slot_stride = old; }
+};
+}  // namespace
+#define ATL_LD_GUARD(name)                                                                      \
+    ATL_REQUIRE(ctx && ld_cells >= 0, name ": ctx is NULL or the slot stride is negative");    \
+    StrideScope stride_scope(ctx, ld_cells)
+
+extern "C" {
+
+int atl_spmm_csr_ld(atl_ctx *ctx, int64_t ld_cells, const atl_agg *agg, const double *d_dense, int64_t T, int64_t S, int time_agg,
+                    double *d_out, int64_t ld_out) {
+    ATL_LD_GUARD("atl_spmm_csr_ld");
+    return atl_spmm_csr(ctx, agg, d_dense, T, S, time_agg, d_out, ld_out);
+}
+int atl_pv_convert_ld(atl_ctx *ctx, int64_t ld_cells, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S,
+                      int time_agg, double *d_out) {
+    ATL_LD_GUARD("atl_pv_convert_ld");
+    return atl_pv_convert(ctx, in, p, T, S, time_agg, d_out);
+}
+int atl_pv_convert_aggregate_ld(atl_ctx *ctx, int64_t ld_cells, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T,
+                                int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out) {
+    ATL_LD_GUARD("atl_pv_convert_aggregate_ld");
+    return atl_pv_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);
+}
+int atl_pv_day_map_ld(atl_ctx *ctx, int64_t ld_cells, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S,
+                      const atl_agg *agg, uint8_t *d_map, int64_t ld) {
+    ATL_LD_GUARD("atl_pv_day_map_ld");
+    return atl_pv_day_map(ctx, in, p, T, S, agg, d_map, ld);
+}
+int atl_wind_convert_ld(atl_ctx *ctx, int64_t ld_cells, const atl_wind_inputs *in, const atl_wind_params *p, int64_t T, int64_t S,
+                        int time_agg, double *d_out) {
+    ATL_LD_GUARD("atl_wind_convert_ld");
+    return atl_wind_convert(ctx, in, p, T, S, time_agg, d_out);
+}
+int atl_wind_convert_aggregate_ld(atl_ctx *ctx, int64_t ld_cells, const atl_wind_inputs *in, const atl_wind_params *p, int64_t T,
+                                  int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out) {
+    ATL_LD_GUARD("atl_wind_convert_aggregate_ld");
+    return atl_wind_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);
+}
+int atl_heat_demand_convert_ld(atl_ctx *ctx, int64_t ld_cells, const double *d_temperature, const atl_heat_params *p, int64_t T,
+                               int64_t S, int time_agg, double *d_out) {
+    ATL_LD_GUARD("atl_heat_demand_convert_ld");
+    return atl_heat_demand_convert(ctx, d_temperature, p, T, S, time_agg, d_out);
+}
+int atl_heat_demand_convert_aggregate_ld(atl_ctx *ctx, int64_t ld_cells, const double *d_temperature, const atl_heat_params *p,
+                                         int64_t T, int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out) {
+    ATL_LD_GUARD("atl_heat_demand_convert_aggregate_ld");
+    return atl_heat_demand_convert_aggregate(ctx, d_temperature, p, T, S, agg, time_agg, d_out, ld_out);
+}
+int atl_thermo_convert_ld(atl_ctx *ctx, int64_t ld_cells, const double *d_var, const atl_thermo_params *p, int64_t T, int64_t S,
+                          int time_agg, double *d_out) {
+    ATL_LD_GUARD("atl_thermo_convert_ld");
+    return atl_thermo_convert(ctx, d_var, p, T, S, time_agg, d_out);
+}
+int atl_thermo_convert_aggregate_ld(atl_ctx *ctx, int64_t ld_cells, const double *d_var, const atl_thermo_params *p, int64_t T,
+                                    int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out) {
+    ATL_LD_GUARD("atl_thermo_convert_aggregate_ld");
+    return atl_thermo_convert_aggregate(ctx, d_var, p, T, S, agg, time_agg, d_out, ld_out);
+}
+int atl_runoff_convert_ld(atl_ctx *ctx, int64_t ld_cells, const double *d_runoff, const double *d_height, int64_t T, int64_t S,
+                          int time_agg, double *d_out) {
+    ATL_LD_GUARD("atl_runoff_convert_ld");
+    return atl_runoff_convert(ctx, d_runoff, d_height, T, S, time_agg, d_out);
+}
+int atl_runoff_convert_aggregate_ld(atl_ctx *ctx, int64_t ld_cells, const double *d_runoff, const double *d_height, int64_t T,
+                                    int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out) {
+    ATL_LD_GUARD("atl_runoff_convert_aggregate_ld");
+    return atl_runoff_convert_aggregate(ctx, d_runoff, d_height, T, S, agg, time_agg, d_out, ld_out);
+}
+int atl_agg_create_ld(atl_ctx *ctx, int64_t ld_cells, int64_t n_rows, int64_t n_cells, int64_t row_len, const int64_t *h_indptr,
+                      const int32_t *h_indices, const double *h_data, atl_agg **out) {
+    ATL_LD_GUARD("atl_agg_create_ld");
+    return atl_agg_create(ctx, n_rows, n_cells, row_len, h_indptr, h_indices, h_data, out);
+}
+int atl_nc_read_slab_ld(atl_ctx *ctx, int64_t ld_cells, atl_nc *f, const char *name, int64_t start0, int64_t count0, double *d_out,
+                        int n_threads) {
+    ATL_LD_GUARD("atl_nc_read_slab_ld");
+    return atl_nc_read_slab(ctx, f, name, start0, count0, d_out, n_threads);
+}
+
+}  // extern "C"

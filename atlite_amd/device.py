@@ -288,11 +288,11 @@ class AggPlan:
                                                  data.ctypes.data if data.size else None, C.byref(h)))
             self.handle = h
             return
-        check(ctx.lib.atl_set_slot_stride(ctx.handle, int(ld) if ld and int(ld) != m.shape[1] else 0))
-        try:  # the stride is call-scoped: a rejected matrix must not leave it set
+        if True:  # the slot stride of the cubes the plan will meet travels with the call (atl_agg_create_ld)
             check(
-                ctx.lib.atl_agg_create(
+                ctx.lib.atl_agg_create_ld(
                     ctx.handle,
+                    int(ld) if ld and int(ld) != m.shape[1] else 0,
                     m.shape[0],
                     m.shape[1],
                     int(row_len) if row_len and m.shape[1] % int(row_len) == 0 else 0,
@@ -302,8 +302,6 @@ class AggPlan:
                     C.byref(h),
                 )
             )
-        finally:
-            ctx.lib.atl_set_slot_stride(ctx.handle, 0)
         self.handle = h
 
     def info(self):
@@ -505,16 +503,16 @@ class Context:
         return DeviceArray(self, base.ptr, (T, S), dtype, owner=base, ld=ld) if ld > S else base.reshape(T, S)
 
     def _stride(self, S, *arrays):
-        """Tell the context how far apart the slots of this call's (T, S) input cubes are: every 2-d input must have
-        the same layout (all contiguous, or all padded to the same ``ld``)."""
+        """How far apart the slots of this call's (T, S) input cubes are - the ``ld_cells`` argument of the C-ABI's ``*_ld``
+        entry points (0 = contiguous): every 2-d input must have the same layout (all contiguous, or all padded to the same
+        ``ld``)."""
         lds = {(a.ld if a.ld is not None else int(S)) for a in arrays
                if isinstance(a, DeviceArray) and a.ndim == 2 and a.shape[1] == int(S)}
         if len(lds) > 1:
             raise ValueError(f"the input cubes of one call mix slot strides {sorted(lds)}: upload them the same way "
                              "(Dataset.device pads every cube of a dataset alike; ATLITE_HIP_PITCH=0 switches padding off)")
         ld = lds.pop() if lds else int(S)
-        check(self.lib.atl_set_slot_stride(self.handle, 0 if ld == int(S) else ld))
-        return ld
+        return 0 if ld == int(S) else ld  # what the *_ld entry points take: 0 = contiguous
 
     def _relayout(self, a, ld):
         """Device copy of the (T, S) block ``a`` with slots ``ld`` elements apart (None: contiguous)."""
@@ -523,11 +521,6 @@ class Context:
         es = a.dtype.itemsize
         check(self.lib.atl_copy_2d(self.handle, out.ptr, (ld or S) * es, a.ptr, (a.ld or S) * es, S * es, T, 2, 0))
         return out
-
-    def _unstride(self):
-        """The stride is call-scoped: outside a conversion call the context reads contiguous cubes (the slab pipeline's
-        buffers, atl_nc_read_slab into them)."""
-        check(self.lib.atl_set_slot_stride(self.handle, 0))
 
     def asdevice(self, x, dtype=np.float64):
         """DeviceArray as is; torch CUDA tensor zero-copy; anything else is uploaded."""
@@ -652,12 +645,9 @@ class Context:
 
     def spmm(self, plan, dense, time_agg=None, out=None):
         T, S = dense.shape
-        self._stride(S, dense)
-        try:
-            res, optr, ld = self._out(plan, T, S, time_agg, out)
-            check(self.lib.atl_spmm_csr(self.handle, plan.handle, dense.ptr, T, S, _TIME_CODES[time_agg], optr, ld))
-        finally:
-            self._unstride()
+        ldc = self._stride(S, dense)
+        res, optr, ld = self._out(plan, T, S, time_agg, out)
+        check(self.lib.atl_spmm_csr_ld(self.handle, ldc, plan.handle, dense.ptr, T, S, _TIME_CODES[time_agg], optr, ld))
         return res
 
     def pv(self, inputs: dict, params: dict, T, S, plan=None, time_agg=None, solar_tables=None, options=None,
@@ -733,25 +723,22 @@ class Context:
                 raise ValueError(f"orientation arrays must have shape {shape}, got {tuple(ds.shape)} / {tuple(da.shape)}")
             pp.d_cell_slope, pp.d_cell_azimuth = ds.ptr, da.ptr
             pp.orientation_per_time = 1 if per_time else 0
-        self._stride(S, *[v for v in inputs.values() if v is not None], *([ds, da] if pp.orientation_per_time else []))
-        try:
-            if plan is not None and pp.night_skip and solar_tables is None:
-                dm = self._day_map(inputs.get("solar_altitude"), pin, pp, T, S, plan, options)
-                if dm is not None:
-                    pin.d_day_map, pin.day_map_ld = dm[0].ptr, dm[1]
-            res, optr, ld = self._out(plan, T, S, time_agg, out)
-            if plan is None:
-                check(self.lib.atl_pv_convert(self.handle, C.byref(pin), C.byref(pp), T, S, _TIME_CODES[time_agg], optr))
-            else:
-                check(self.lib.atl_pv_convert_aggregate(self.handle, C.byref(pin), C.byref(pp), T, S, plan.handle,
-                                                        _TIME_CODES[time_agg], optr, ld))
-        finally:
-            self._unstride()
+        ldc = self._stride(S, *[v for v in inputs.values() if v is not None], *([ds, da] if pp.orientation_per_time else []))
+        if plan is not None and pp.night_skip and solar_tables is None:
+            dm = self._day_map(inputs.get("solar_altitude"), pin, pp, T, S, plan, options, ldc)
+            if dm is not None:
+                pin.d_day_map, pin.day_map_ld = dm[0].ptr, dm[1]
+        res, optr, ld = self._out(plan, T, S, time_agg, out)
+        if plan is None:
+            check(self.lib.atl_pv_convert_ld(self.handle, ldc, C.byref(pin), C.byref(pp), T, S, _TIME_CODES[time_agg], optr))
+        else:
+            check(self.lib.atl_pv_convert_aggregate_ld(self.handle, ldc, C.byref(pin), C.byref(pp), T, S, plan.handle,
+                                                       _TIME_CODES[time_agg], optr, ld))
         if keep:
             self.sync()  # temporaries uploaded for this call must outlive the kernels
         return res
 
-    def _day_map(self, alt, pin, pp, T, S, plan, options):
+    def _day_map(self, alt, pin, pp, T, S, plan, options, ldc):
         """(map, ld) of the early-out's day bits for (plan, altitude cube, cut-off) - ``atl_pv_day_map`` - or None.  Built on
         first use and kept WITH THE CUBE'S ALLOCATION, so it lives exactly as long as the device copy it describes; only for
         cubes the library filled itself (``mark_static``: a caller's own device array may be rewritten between calls) unless
@@ -770,7 +757,7 @@ class Context:
         ld = (T // 8 + 2 + 3) // 4 * 4
         n_tiles = plan.info()["n_segments"]
         dmap = self.empty((max(n_tiles, 1) * ld,), np.uint8)
-        check(self.lib.atl_pv_day_map(self.handle, C.byref(pin), C.byref(pp), T, S, plan.handle, dmap.ptr, ld))
+        check(self.lib.atl_pv_day_map_ld(self.handle, ldc, C.byref(pin), C.byref(pp), T, S, plan.handle, dmap.ptr, ld))
         while len(maps) >= 4:  # a handful of plans per cutout
             maps.pop(next(iter(maps)))
         maps[key] = (plan, dmap, ld)
@@ -791,32 +778,26 @@ class Context:
             V.ctypes.data_as(_lib.c_double_p),
             POWn.ctypes.data_as(_lib.c_double_p),
         )
-        self._stride(S, wnd, aux)
-        try:
-            res, optr, ld = self._out(plan, T, S, time_agg, out)
-            if plan is None:
-                check(self.lib.atl_wind_convert(self.handle, C.byref(win), C.byref(wp), T, S, _TIME_CODES[time_agg], optr))
-            else:
-                check(self.lib.atl_wind_convert_aggregate(self.handle, C.byref(win), C.byref(wp), T, S, plan.handle,
-                                                          _TIME_CODES[time_agg], optr, ld))
-        finally:
-            self._unstride()
+        ldc = self._stride(S, wnd, aux)
+        res, optr, ld = self._out(plan, T, S, time_agg, out)
+        if plan is None:
+            check(self.lib.atl_wind_convert_ld(self.handle, ldc, C.byref(win), C.byref(wp), T, S, _TIME_CODES[time_agg], optr))
+        else:
+            check(self.lib.atl_wind_convert_aggregate_ld(self.handle, ldc, C.byref(win), C.byref(wp), T, S, plan.handle,
+                                                         _TIME_CODES[time_agg], optr, ld))
         return res
 
     def thermo(self, var, T, S, offset=-273.15, fillna0=False, cop=None, plan=None, time_agg=None, out=None):
         """temperature family (var + offset [, fillna 0]) and, with cop=(sink_T, c0, c1, c2), the COP."""
         tp = _lib.ThermoParams(float(offset), 1 if fillna0 else 0, 0 if cop is None else 1,
                                *(map(float, cop) if cop is not None else (0.0, 0.0, 0.0, 0.0)))
-        self._stride(S, var)
-        try:
-            res, optr, ld = self._out(plan, T, S, time_agg, out)
-            if plan is None:
-                check(self.lib.atl_thermo_convert(self.handle, var.ptr, C.byref(tp), T, S, _TIME_CODES[time_agg], optr))
-            else:
-                check(self.lib.atl_thermo_convert_aggregate(self.handle, var.ptr, C.byref(tp), T, S, plan.handle,
-                                                            _TIME_CODES[time_agg], optr, ld))
-        finally:
-            self._unstride()
+        ldc = self._stride(S, var)
+        res, optr, ld = self._out(plan, T, S, time_agg, out)
+        if plan is None:
+            check(self.lib.atl_thermo_convert_ld(self.handle, ldc, var.ptr, C.byref(tp), T, S, _TIME_CODES[time_agg], optr))
+        else:
+            check(self.lib.atl_thermo_convert_aggregate_ld(self.handle, ldc, var.ptr, C.byref(tp), T, S, plan.handle,
+                                                           _TIME_CODES[time_agg], optr, ld))
         return res
 
     def heat_demand(self, temperature, day_ptr, threshold_K, a, constant, T, S, plan=None, time_agg=None,
@@ -830,33 +811,27 @@ class Context:
             assert D >= 0 and day_ptr[0] >= 0 and day_ptr[-1] <= T and np.all(np.diff(day_ptr) >= 0)
             d_ptr, fresh = self.upload(day_ptr, np.int64), True
         hp = _lib.HeatParams(float(threshold_K), float(a), float(constant), D, d_ptr.ptr, 1 if cooling else 0)
-        self._stride(S, temperature)
-        try:
-            res, optr, ld = self._out(plan, D, S, time_agg, out)
-            if plan is None:
-                check(self.lib.atl_heat_demand_convert(self.handle, temperature.ptr, C.byref(hp), T, S,
-                                                       _TIME_CODES[time_agg], optr))
-            else:
-                check(self.lib.atl_heat_demand_convert_aggregate(self.handle, temperature.ptr, C.byref(hp), T, S,
-                                                                 plan.handle, _TIME_CODES[time_agg], optr, ld))
-        finally:
-            self._unstride()
+        ldc = self._stride(S, temperature)
+        res, optr, ld = self._out(plan, D, S, time_agg, out)
+        if plan is None:
+            check(self.lib.atl_heat_demand_convert_ld(self.handle, ldc, temperature.ptr, C.byref(hp), T, S,
+                                                      _TIME_CODES[time_agg], optr))
+        else:
+            check(self.lib.atl_heat_demand_convert_aggregate_ld(self.handle, ldc, temperature.ptr, C.byref(hp), T, S,
+                                                                plan.handle, _TIME_CODES[time_agg], optr, ld))
         if fresh:
             self.sync()  # d_ptr must outlive the kernels
         return res
 
     def runoff(self, runoff, height, T, S, plan=None, time_agg=None, out=None):
-        self._stride(S, runoff)
-        try:
-            res, optr, ld = self._out(plan, T, S, time_agg, out)
-            hptr = height.ptr if height is not None else None
-            if plan is None:
-                check(self.lib.atl_runoff_convert(self.handle, runoff.ptr, hptr, T, S, _TIME_CODES[time_agg], optr))
-            else:
-                check(self.lib.atl_runoff_convert_aggregate(self.handle, runoff.ptr, hptr, T, S, plan.handle,
-                                                            _TIME_CODES[time_agg], optr, ld))
-        finally:
-            self._unstride()
+        ldc = self._stride(S, runoff)
+        res, optr, ld = self._out(plan, T, S, time_agg, out)
+        hptr = height.ptr if height is not None else None
+        if plan is None:
+            check(self.lib.atl_runoff_convert_ld(self.handle, ldc, runoff.ptr, hptr, T, S, _TIME_CODES[time_agg], optr))
+        else:
+            check(self.lib.atl_runoff_convert_aggregate_ld(self.handle, ldc, runoff.ptr, hptr, T, S, plan.handle,
+                                                           _TIME_CODES[time_agg], optr, ld))
         return res
 
     # -- post-processing of a small (rows x time) result on the device (runoff: convert.py:1046-1082) ------------

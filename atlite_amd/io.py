@@ -120,10 +120,11 @@ class NcFile:
         check(self.lib.atl_nc_read_host(self.handle, name.encode(), int(start), int(count), out.ctypes.data))
         return out
 
-    def read_slab(self, ctx, name, start, count, dptr, n_threads=0):
-        """Rows -> fp64 block at device pointer ``dptr``; enqueued on the context's COPY stream."""
-        check(self.lib.atl_nc_read_slab(ctx.handle, self.handle, name.encode(), int(start), int(count), int(dptr),
-                                        int(n_threads)))
+    def read_slab(self, ctx, name, start, count, dptr, n_threads=0, ld=0):
+        """Rows -> fp64 block at device pointer ``dptr`` (``ld``: cells between its slots, 0 = contiguous); visible in the
+        order of the context's COPY stream."""
+        check(self.lib.atl_nc_read_slab_ld(ctx.handle, int(ld or 0), self.handle, name.encode(), int(start), int(count), int(dptr),
+                                           int(n_threads)))
 
     def close(self):
         if getattr(self, "handle", None):
@@ -186,8 +187,8 @@ class FileArray:
                 return self.file.read(self.name, self.row0 + start, max(stop - start, 0))
         return np.asarray(self)[key]
 
-    def read_slab(self, ctx, t0, t1, dptr):
-        self.file.read_slab(ctx, self.name, self.row0 + t0, t1 - t0, dptr)
+    def read_slab(self, ctx, t0, t1, dptr, ld=0):
+        self.file.read_slab(ctx, self.name, self.row0 + t0, t1 - t0, dptr, ld=ld)
 
     def to_device(self, ctx, block_bytes=256 << 20, ld=None, out=None):
         """Whole variable as a DeviceArray (rows in blocks so that the pinned staging stays bounded); ``ld``: a
@@ -212,13 +213,9 @@ class FileArray:
                 es = np.dtype(self.var.dtype).itemsize if self.var.dtype else 8
                 step = max(step, int(os.environ.get("ATLITE_HIP_INFLATE_BLOCK", 3 << 29)) // max(row * es, 1))
             step = max(ct, step // ct * ct)
-        check(ctx.lib.atl_set_slot_stride(ctx.handle, stride if pitched else 0))  # where atl_nc_read_slab puts the rows
-        try:
-            for t0 in range(0, self.shape[0], step):
-                t1 = min(self.shape[0], t0 + step)
-                self.read_slab(ctx, t0, t1, out.ptr + t0 * stride * 8)
-        finally:
-            check(ctx.lib.atl_set_slot_stride(ctx.handle, 0))
+        for t0 in range(0, self.shape[0], step):
+            t1 = min(self.shape[0], t0 + step)
+            self.read_slab(ctx, t0, t1, out.ptr + t0 * stride * 8, ld=stride if pitched else 0)  # where the rows go
         ctx.copy_barrier()
         return out
 

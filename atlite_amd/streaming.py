@@ -154,11 +154,7 @@ def run(ctx, spec, ds, plan, time_agg):
                 check(lib.atl_stream_wait_event(ctx.handle, COPY, ev_done[b]))
             for n, a in host.items():
                 if _is_file(a):
-                    check(lib.atl_set_slot_stride(ctx.handle, ld or 0))  # where atl_nc_read_slab puts the rows
-                    try:
-                        a.read_slab(ctx, t0, t1, bufs[b][n].ptr)
-                    finally:
-                        check(lib.atl_set_slot_stride(ctx.handle, 0))
+                    a.read_slab(ctx, t0, t1, bufs[b][n].ptr, ld=ld or 0)  # where atl_nc_read_slab puts the rows
                     continue
                 blk = a[t0:t1]
                 if a.dtype == np.float64 and ld:

@@ -720,9 +720,9 @@ def main():
     full3 = full.view(N, parts, T_loc) if equal else None
 
     def cabi_pv(pin_, pp, T_, out_ptr, ld_out):
-        """The timed call.  The slot stride is call-scoped context state (the Python wrappers reset it after every op)."""
-        _lib.check(ctx.lib.atl_set_slot_stride(ctx.handle, 0 if ld == S else ld))
-        _lib.check(ctx.lib.atl_pv_convert_aggregate(ctx.handle, C.byref(pin_), C.byref(pp), T_, S, plan.handle, 0, out_ptr, ld_out))
+        """The timed call: ONE entry of the C ABI, the cubes' slot stride an argument of it."""
+        _lib.check(ctx.lib.atl_pv_convert_aggregate_ld(ctx.handle, 0 if ld == S else ld, C.byref(pin_), C.byref(pp), T_, S, plan.handle, 0,
+                                                       out_ptr, ld_out))
 
     graphs = {}  # --graph: (params identity, piece, output pointer) -> hipGraph of the piece's launches
 
@@ -1000,12 +1000,11 @@ def main():
             # ... and with the day map of (plan, altitude cube, cut-off), built once and kept with the cube: the API's steady state
             ld_m = (T_loc // 8 + 2 + 3) // 4 * 4
             dmap = ctx.empty((max(plan_info["n_segments"], 1) * ld_m,), np.uint8)
-            _lib.check(ctx.lib.atl_set_slot_stride(ctx.handle, 0 if ld == S else ld))
             ctx.sync()
             ctx.timer_start()
-            _lib.check(ctx.lib.atl_pv_day_map(ctx.handle, C.byref(pin), C.byref(pv_params(True)), T_loc, S, plan.handle, dmap.ptr, ld_m))
+            _lib.check(ctx.lib.atl_pv_day_map_ld(ctx.handle, 0 if ld == S else ld, C.byref(pin), C.byref(pv_params(True)), T_loc, S,
+                                                 plan.handle, dmap.ptr, ld_m))
             map_ms = ctx.timer_stop()
-            _lib.check(ctx.lib.atl_set_slot_stride(ctx.handle, 0))
             for q in pins:
                 q.d_day_map, q.day_map_ld = dmap.ptr, ld_m
             dts, kk = timed(pv_params(True), ks, kw_)

@@ -182,6 +182,16 @@ int atl_agg_check_host_aligned(int64_t n_rows, int64_t n_cells, int64_t row_len,
 int atl_agg_info(const atl_agg *agg, int64_t *n_rows, int64_t *n_cells, int64_t *n_segments,
                  int64_t *n_partial_rows, int32_t *tile_w, int32_t *tile_h);
 
+/* ---- the slot stride as an ARGUMENT (round 5) -----------------------------------------------------------------------
+ * Every entry point that reads the context's slot stride (atl_set_slot_stride) has a twin that takes it with the call -
+ * ld_cells: cells between the slots of the call's (T, S) input cubes (for atl_nc_read_slab: of the OUTPUT block), 0 =
+ * contiguous - and leaves the context's own setting untouched: one call instead of set / call / reset.  Declared here, the
+ * originals' documentation applies. */
+int atl_agg_create_ld(atl_ctx *ctx, int64_t ld_cells, int64_t n_rows, int64_t n_cells, int64_t row_len, const int64_t *h_indptr,
+                      const int32_t *h_indices, const double *h_data, atl_agg **out);
+int atl_spmm_csr_ld(atl_ctx *ctx, int64_t ld_cells, const atl_agg *agg, const double *d_dense, int64_t T, int64_t S, int time_agg,
+                    double *d_out, int64_t ld_out);
+
 /* ---- generic aggregation: out = M . D^T ----------------------------------------------
  * Replaces aggregate_matrix(da, matrix, index) (aggregate.py:16-35) for an arbitrary
  * already-converted cube D (T x S).  time_agg NONE: d_out is (N x T) row-major with row
@@ -370,6 +380,30 @@ int atl_runoff_convert_aggregate(atl_ctx *ctx, const double *d_runoff, const dou
                                  int64_t T, int64_t S, const atl_agg *agg, int time_agg,
                                  double *d_out, int64_t ld_out);
 
+/* ... and the twins of the conversions above with the slot stride as an argument (see atl_spmm_csr_ld) */
+int atl_pv_convert_ld(atl_ctx *ctx, int64_t ld_cells, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S,
+                      int time_agg, double *d_out);
+int atl_pv_convert_aggregate_ld(atl_ctx *ctx, int64_t ld_cells, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T,
+                                int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out);
+int atl_pv_day_map_ld(atl_ctx *ctx, int64_t ld_cells, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S,
+                      const atl_agg *agg, uint8_t *d_map, int64_t ld);
+int atl_wind_convert_ld(atl_ctx *ctx, int64_t ld_cells, const atl_wind_inputs *in, const atl_wind_params *p, int64_t T, int64_t S,
+                        int time_agg, double *d_out);
+int atl_wind_convert_aggregate_ld(atl_ctx *ctx, int64_t ld_cells, const atl_wind_inputs *in, const atl_wind_params *p, int64_t T,
+                                  int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out);
+int atl_heat_demand_convert_ld(atl_ctx *ctx, int64_t ld_cells, const double *d_temperature, const atl_heat_params *p, int64_t T,
+                               int64_t S, int time_agg, double *d_out);
+int atl_heat_demand_convert_aggregate_ld(atl_ctx *ctx, int64_t ld_cells, const double *d_temperature, const atl_heat_params *p,
+                                         int64_t T, int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out);
+int atl_thermo_convert_ld(atl_ctx *ctx, int64_t ld_cells, const double *d_var, const atl_thermo_params *p, int64_t T, int64_t S,
+                          int time_agg, double *d_out);
+int atl_thermo_convert_aggregate_ld(atl_ctx *ctx, int64_t ld_cells, const double *d_var, const atl_thermo_params *p, int64_t T,
+                                    int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out);
+int atl_runoff_convert_ld(atl_ctx *ctx, int64_t ld_cells, const double *d_runoff, const double *d_height, int64_t T, int64_t S,
+                          int time_agg, double *d_out);
+int atl_runoff_convert_aggregate_ld(atl_ctx *ctx, int64_t ld_cells, const double *d_runoff, const double *d_height, int64_t T,
+                                    int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out);
+
 /* ---- runoff post-processing on the (rows x time) result, on the device (atlite/convert.py:1046-1082) -------------
  * The result of atl_runoff_convert_aggregate is a few MB that the reference then smooths, thresholds and rescales
  * with xarray / pandas on the host; here it stays in HBM until it is final.  d: rows x T, row stride ld (time
@@ -495,6 +529,9 @@ int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, 
                      double *d_out, int n_threads);
 /* chunks of this context's atl_nc_read_slab calls so far: inflated on the device / on host threads / declined by the device
  * decoder and decoded again on the host (settles pending reads first) */
+/* atl_nc_read_slab with the OUTPUT block's slot stride as an argument (see atl_spmm_csr_ld) */
+int atl_nc_read_slab_ld(atl_ctx *ctx, int64_t ld_cells, atl_nc *f, const char *name, int64_t start0, int64_t count0, double *d_out,
+                        int n_threads);
 int atl_nc_ingest_stats(atl_ctx *ctx, int64_t *device_chunks, int64_t *host_chunks, int64_t *redone);
 /* device-inflate reads so far, accumulated: ms5 = {host gather of the compressed bytes (wall clock), H2D, k_inflate, k_adler,
  * k_unpack (HIP events on the slot streams; two reads overlap, so the sum can exceed the wall time)}, bytes in / out of k_inflate */

@@ -145,13 +145,15 @@ def test_small_device_blocks_are_recycled_and_results_arrive_in_pinned_memory(ct
     h[0, 0] = -1.0  # an ordinary writeable array
     del d
     e = ctx.empty((200, 100))  # the same number of bytes: the block that was just released
-    assert e.ptr == ptr
     e2 = ctx.empty((200, 100))
-    assert e2.ptr != ptr
-    tiny = ctx.upload(np.ones(5))
-    assert tiny.numpy().base is None
     import os
 
+    if ctx._pool_state()["on"]:  # (off under ATLITE_HIP_RECYCLE=0 and the fenced allocator)
+        assert e.ptr == ptr and e2.ptr != ptr
+    else:
+        assert e.ptr != ptr
+    tiny = ctx.upload(np.ones(5))
+    assert tiny.numpy().base is None
     os.environ["ATLITE_HIP_PINNED_RESULTS"] = "0"
     try:
         assert ctx.upload(a).numpy().base is None
