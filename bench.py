@@ -107,6 +107,9 @@ def parse():
     ap.add_argument("--debug-rccl-self", action="store_true",
                     help="testing only (one GPU, one process): open a 1-rank RCCL process group and route the step "
                          "through the collective branch (async all-gather on the group's stream, placement copy)")
+    ap.add_argument("--preflight-fail", default="", choices=["", "lib", "torch", "all"],
+                    help="testing only: pretend this rung of the collective ladder (lib -> torch.distributed -> none) failed "
+                         "its preflight")
     ap.add_argument("--debug-gloo-one-gpu", action="store_true",
                     help="testing only: all ranks share GPU 0 and the collective runs over gloo on host copies")
     return ap.parse_args()
@@ -608,6 +611,110 @@ def main():
         T_total = T
     T_loc, off = edges[my + 1] - edges[my], edges[my]
     shard_lens = [edges[r + 1] - edges[r] for r in range(parts)]
+    # ---- the collective, decided BEFORE any cube is generated: a preflight that forms the communicator and pushes 128 bytes per
+    # rank through it, and a ladder lib (atl_comm_* over RCCL) -> torch.distributed (RCCL) -> no collective at all, so that
+    # a line with n_gpus = N is printed whatever the node's RCCL does.  Every rung is agreed on by all
+    # ranks over the gloo control group; every wait has a time-out (atl_comm_init: $ATLITE_HIP_COMM_TIMEOUT_S; here: 90 s).
+    equal = len(set(shard_lens)) == 1
+    collective = parts > 1 or (a.debug_rccl_self and world == 1)
+    simulate = bool(a.preflight_fail)  # --preflight-fail: walk the ladder with pretended failures (also on one GPU, over gloo)
+    use_lib = collective and a.collective == "lib" and (not (a.emulate_shard or a.debug_gloo_one_gpu) or (simulate and not a.emulate_shard))
+    comm = None
+    lib_error = None
+    preflight = {"ladder": []}
+    collective_failed = False
+
+    def all_ranks_ok(ok):
+        if world == 1:
+            return bool(ok)
+        okf = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        return int(okf.item()) == 1
+
+    def with_timeout(fn, seconds=float(os.environ.get("ATLITE_BENCH_PREFLIGHT_TIMEOUT", 90))):
+        """fn() on a helper thread; (result, None) or (None, error text) - a call that never returns is given up on."""
+        import threading
+
+        box = {}
+
+        def run():
+            try:
+                box["r"] = fn()
+            except Exception as e:  # noqa: BLE001
+                box["e"] = repr(e)
+
+        th = threading.Thread(target=run, daemon=True)
+        th.start()
+        th.join(seconds)
+        if th.is_alive():
+            return None, f"no answer within {seconds:.0f} s"
+        return box.get("r"), box.get("e")
+
+    def tiny_gather(how):
+        """16 doubles per rank through the collective `how`; True iff every rank's block arrived where it belongs."""
+        n = max(world, 1)
+        src = torch.full((1, 16), float(rank + 1), dtype=torch.float64, device=dev)
+        dst = torch.zeros((1, 16 * n), dtype=torch.float64, device=dev)
+        if how == "lib":
+            h_lens = (C.c_int64 * n)(*([16] * n))
+            torch.cuda.synchronize()
+            _lib.check(ctx.lib.atl_allgather_time_v(comm.handle, src.data_ptr(), 1, h_lens, dst.data_ptr(), 16 * n))
+            ctx.sync()
+        else:
+            dist.all_gather_into_tensor(dst.view(-1), src.view(-1))
+        torch.cuda.synchronize()
+        want = torch.arange(1, n + 1, dtype=torch.float64, device=dev).repeat_interleave(16).view(1, -1)
+        return bool(torch.equal(dst, want))
+
+    if use_lib:
+        # the library's own communicator (C ABI atl_comm_*): rank 0 draws the unique id, the control group ships it
+        try:
+            uid = D.RcclComm.unique_id() if rank == 0 else None
+        except Exception as e:  # noqa: BLE001
+            uid, lib_error = None, repr(e)
+        if world > 1:
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            uid = box[0]
+        if uid is not None and a.preflight_fail not in ("lib", "all"):
+            try:
+                comm = D.RcclComm(ctx, max(world, 1), rank, uid)
+            except Exception as e:  # noqa: BLE001
+                lib_error = repr(e)
+        elif uid is not None:
+            lib_error = "--preflight-fail"
+        ok = comm is not None
+        if all_ranks_ok(ok):
+            good, err = with_timeout(lambda: tiny_gather("lib"))
+            ok = bool(good) and err is None
+            lib_error = err or (None if ok else "the test all-gather returned wrong data")
+        if not all_ranks_ok(ok):  # every rank or none: a rank without a communicator would leave the others inside the collective
+            if comm is not None:
+                try:
+                    comm.abort()
+                    comm.close()
+                except Exception:  # noqa: BLE001
+                    pass
+            comm = None
+        preflight["ladder"].append({"rung": "lib (atl_comm_init + atl_allgather_time_v)", "ok": comm is not None, "error": lib_error})
+        if comm is None:
+            use_lib = False
+            if rank == 0:
+                print(f"[bench] the library's RCCL communicator is not available ({lib_error}); trying torch.distributed",
+                      file=sys.stderr)
+    if collective and world > 1 and not use_lib and (not (a.emulate_shard or a.debug_gloo_one_gpu) or (simulate and not a.emulate_shard)):
+        good, err = (None, "--preflight-fail") if a.preflight_fail in ("torch", "all") else with_timeout(lambda: tiny_gather("torch"))
+        ok = all_ranks_ok(bool(good) and err is None)
+        preflight["ladder"].append({"rung": "torch.distributed all_gather_into_tensor (RCCL)", "ok": ok,
+                                    "error": err or (None if good else "wrong data")})
+        if not ok:
+            # last rung: every rank converts + aggregates its shard, nobody gathers; the line says so
+            collective, collective_failed = False, True
+            if rank == 0:
+                print(f"[bench] no working collective on this node ({err}); timing the ranks' own steps WITHOUT a gather "
+                      "(multi_gpu.collective_failed = true)", file=sys.stderr)
+    if world > 1 and rank == 0:
+        print(f"[bench] preflight: {json.dumps(preflight)}", file=sys.stderr)
     inputs, x, y, tables = generate_pv(ctx, synthetic, solar, _lib, T_loc, Y, X, off, cfg["stored_angles"],
                                        interleaved=a.layout == "interleaved")
     ld = next(iter(inputs.values())).ld or S  # cells between the slots of a cube (S: one allocation per cube)
@@ -645,38 +752,6 @@ def main():
     # auto: two sub-launches per step (the first one's all-gather overlaps the second) once a rank's shard is big
     # enough to pay for the extra launch - measured on a 1/8 shard of C2 (4.4e7 cell-steps): 0.417 ms with one
     # launch, 0.450 ms with two, against an all-gather of 7 MB that takes less than the difference
-    equal = len(set(shard_lens)) == 1
-    collective = parts > 1 or (a.debug_rccl_self and world == 1)
-    use_lib = collective and a.collective == "lib" and not (a.emulate_shard or a.debug_gloo_one_gpu)
-    comm = None
-    lib_error = None
-    if use_lib:
-        # the library's own communicator (C ABI atl_comm_*): rank 0 draws the unique id, the control group ships it
-        try:
-            uid = D.RcclComm.unique_id() if rank == 0 else None
-        except Exception as e:  # noqa: BLE001
-            uid, lib_error = None, repr(e)
-        if world > 1:
-            box = [uid]
-            dist.broadcast_object_list(box, src=0)
-            uid = box[0]
-        if uid is not None:
-            try:
-                comm = D.RcclComm(ctx, max(world, 1), rank, uid)
-            except Exception as e:  # noqa: BLE001
-                lib_error = repr(e)
-        if world > 1:  # every rank or none: a rank without a communicator would leave the others inside the collective
-            okf = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
-            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
-            if int(okf.item()) == 0:
-                if comm is not None:
-                    comm.close()
-                comm = None
-        if comm is None:
-            use_lib = False
-            if rank == 0:
-                print(f"[bench] the library's RCCL communicator is not available ({lib_error}); gathering with "
-                      "torch.distributed instead", file=sys.stderr)
     # RCCL path: the all-gather and the placement copy of a step run behind the NEXT step's kernel - a second set of
     # (piece, gather) buffers by step parity, the placement on a side stream, buffer reuse ordered by events; the timed
     # region ends with a device-wide synchronize, so every step's result is in place when the clock stops.  One
@@ -864,7 +939,7 @@ def main():
             dist.all_gather(lst_i, mine_i)
             info = {"ranks_seen": [int(v[0]) for v in lst_i], "rank_of": [int(v[1]) for v in lst_i],
                     "device_of_rank": [int(v[2]) for v in lst_i], "local_rank": [int(v[3]) for v in lst_i]}
-        if a.debug_gloo_one_gpu:
+        if a.debug_gloo_one_gpu or collective_failed:
             return per_rank, None, info
         reps = 10
         fence()
@@ -893,7 +968,7 @@ def main():
         comm_info = {"ranks_seen": [comm.info()["n_ranks"]], "device_of_rank": [comm.info()["device"]]}
 
     # the reassembled result holds every rank's block in place
-    if world > 1:
+    if world > 1 and not collective_failed:
         res = step(pp_main)
         fence()
         own = torch.empty((N, T_loc), dtype=torch.float64, device=dev)
@@ -949,7 +1024,10 @@ def main():
             "gather_ms": gather_ms,  # serial all-gather + placement of one step's result (max over ranks), untimed region
             "result_bytes": int(N * sum(shard_lens) * 8),
             "collective": ("library: atl_comm_init + atl_allgather_time_v" + ("_async (communicator's own stream)" if overlap else "")) if use_lib
+                          else "NONE: no collective worked on this node; every rank timed its own shard, nothing was gathered" if collective_failed
                           else ("torch.distributed all_gather_into_tensor" + (f" (the library's communicator failed: {lib_error})" if lib_error else "")),
+            "collective_failed": bool(collective_failed),
+            "preflight": preflight["ladder"],
             "transport": "gloo on host copies (debug, all ranks on GPU 0)" if a.debug_gloo_one_gpu else "RCCL over xGMI",
         }
         if comm_info:

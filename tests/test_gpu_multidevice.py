@@ -180,6 +180,34 @@ def test_bench_collective_branch_over_rccl_on_one_rank(mode):
 
 
 
+def test_bench_prints_its_line_when_no_collective_works():
+    """bench.py --gpus N decides on its collective BEFORE a cube is generated: a preflight forms the communicator and sends
+    16 doubles per rank through it, and a ladder - the library's communicator, torch.distributed, no collective - is walked
+    by all ranks together.  Here every rung is told to fail (two ranks on this one GPU, control plane over gloo): the run
+    still ends with ONE line for n_gpus = 2, flagged collective_failed, with the ladder in it."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--debug-gloo-one-gpu", "--preflight-fail", "all",
+                        "--steps", "2", "--warmup", "1", "--T", "960", "--no-cpu-baseline", "--no-extras"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    mg = j["multi_gpu"]
+    assert j["n_gpus"] == 2 and mg["collective_failed"] is True and mg["collective"].startswith("NONE")
+    assert [x["ok"] for x in mg["preflight"]] == [False, False] and len(mg["per_rank_kernel_ms"]) == 2
+    assert j["value"] > 0 and j["ms_per_step"] > 0
+
+
 # ---- the N-rank collective code on ONE GPU: the in-process transport (atl_comm_init_local) ----------------------
 def _local_ranks(n):
     """n Contexts on device 0 + their communicators of one local group (each built on its own thread: the rendezvous
