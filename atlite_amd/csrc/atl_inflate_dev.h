@@ -25,8 +25,11 @@
 
 namespace atl { namespace dinf {
 
-constexpr int kLitBits = 10, kLitCap = 2048;   // primary table + sub-tables (zlib's bound for a 10-bit root: 1332)
-constexpr int kOffBits = 8, kOffCap = 1024;
+// primary table + sub-tables.  zlib's "enough" bounds for this two-level layout: 1332 entries for 286 symbols behind a
+// 10-bit root; distances: 592 behind a 6-bit root, less behind 8 bits.  A code that needs more (none can, for valid streams)
+// fails build_table and the stream goes to the host decoders.  Small tables = more streams resident per CU (LDS).
+constexpr int kLitBits = 10, kLitCap = 1344;
+constexpr int kOffBits = 8, kOffCap = 640;
 constexpr int kPreBits = 7, kPreCap = 128;
 constexpr int kQueue = 64;                      // records per batch: one per lane
 constexpr int kMaxMatch = 258;
@@ -104,6 +107,10 @@ struct HostMem {
     static inline void st32(uint32_t *p, uint32_t v) { *p = v; }
     static inline void st8(uint8_t *p, uint32_t v) { *p = uint8_t(v); }
     static inline uint32_t src(const uint32_t *w, uint32_t i) { return w[i]; }
+    // "this value is the same in every lane" (device: keeps the decoder's state in scalar registers)
+    static inline uint32_t uni(uint32_t v) { return v; }
+    static inline uint64_t uni(uint64_t v) { return v; }
+    static inline int uni(int v) { return v; }
 };
 
 // LDS areas of one stream's decoder (device: carved out of the workgroup's shared memory; host: a struct on the heap)
@@ -199,7 +206,6 @@ struct Bits {
     uint64_t buf;
     int cnt;
     uint32_t ahead;
-    uint64_t taken;  // bits handed to the buffer so far
 
     ATL_HD inline uint32_t word(uint32_t i) const { return i < n_words ? M::src(w, i) : 0u; }
     ATL_HD inline void start(typename M::src_t words, uint32_t n, uint64_t bit_pos) {
@@ -209,7 +215,6 @@ struct Bits {
         buf = 0;
         cnt = 0;
         ahead = word(wpos);
-        taken = uint64_t(wpos) * 32;
         refill();
         drop(int(bit_pos & 31));
     }
@@ -217,7 +222,6 @@ struct Bits {
         if (cnt <= 32) {
             buf |= uint64_t(ahead) << cnt;
             cnt += 32;
-            taken += 32;
             ++wpos;
             ahead = word(wpos);
         }
@@ -232,7 +236,14 @@ struct Bits {
         drop(n);
         return v;
     }
-    ATL_HD inline uint64_t consumed() const { return taken - uint64_t(cnt); }  // bits of the stream used so far
+    // bits of the stream used so far: the words before `ahead` (index wpos) have gone into the buffer, cnt of them are left
+    ATL_HD inline uint64_t consumed() const { return uint64_t(wpos) * 32 - uint64_t(cnt); }
+    ATL_HD inline void uniform() {  // every field is wave-uniform by construction; say so (M::uni)
+        wpos = M::uni(wpos);
+        buf = M::uni(buf);
+        cnt = M::uni(cnt);
+        ahead = M::uni(ahead);
+    }
 };
 
 // ---- block header -------------------------------------------------------------------------------------------------------
@@ -340,7 +351,10 @@ ATL_HD inline int decode_batch(const Areas<M> &A, Bits<M> &b, uint64_t &out_pos,
         uint32_t e = M::ld32(A.lit + b.peek(kLitBits));
         if (e_kind(e) == kSub) {
             b.drop(kLitBits);
-            e = M::ld32(A.lit + ((e_value(e) + b.peek(int(e_extra(e)))) & uint32_t(kLitCap - 1)));
+            {
+                const uint32_t ix = e_value(e) + b.peek(int(e_extra(e)));
+                e = M::ld32(A.lit + (ix < uint32_t(kLitCap) ? ix : uint32_t(kLitCap - 1)));
+            }
         }
         const int l = int(e_len(e));
         if (!l) {
@@ -372,7 +386,10 @@ ATL_HD inline int decode_batch(const Areas<M> &A, Bits<M> &b, uint64_t &out_pos,
         uint32_t o = M::ld32(A.off + b.peek(kOffBits));
         if (e_kind(o) == kSub) {
             b.drop(kOffBits);
-            o = M::ld32(A.off + ((e_value(o) + b.peek(int(e_extra(o)))) & uint32_t(kOffCap - 1)));
+            {
+                const uint32_t ix = e_value(o) + b.peek(int(e_extra(o)));
+                o = M::ld32(A.off + (ix < uint32_t(kOffCap) ? ix : uint32_t(kOffCap - 1)));
+            }
         }
         const int lo = int(e_len(o));
         if (!lo || e_kind(o) != kBase) {

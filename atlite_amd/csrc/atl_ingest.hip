@@ -242,27 +242,32 @@ struct WaveMem {
     // every lane reads the same LDS word; the value continues in an SGPR
     static __device__ __forceinline__ uint32_t ld32(u32p p) { return __builtin_amdgcn_readfirstlane(*p); }
     static __device__ __forceinline__ uint32_t ld8(u8p p) { return __builtin_amdgcn_readfirstlane(uint32_t(*p)); }
-    static __device__ __forceinline__ void st32(u32p p, uint32_t v) {
-        if (threadIdx.x == 0) *p = v;
-    }
-    static __device__ __forceinline__ void st8(u8p p, uint32_t v) {
-        if (threadIdx.x == 0) *p = uint8_t(v);
-    }
+    // every lane stores the same value to the same address.  (Guarding the store with `lane == 0` puts a lane-dependent branch
+    // into every loop of the decoder, after which the compiler treats the loops' whole state as divergent - VGPRs and
+    // exec-mask branches instead of SGPRs and scalar branches: measured 0.8 MB/s per stream.)
+    static __device__ __forceinline__ void st32(u32p p, uint32_t v) { *p = v; }
+    static __device__ __forceinline__ void st8(u8p p, uint32_t v) { *p = uint8_t(v); }
     static __device__ __forceinline__ uint32_t src(src_t w, uint32_t i) { return w[__builtin_amdgcn_readfirstlane(i)]; }
+    static __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+    static __device__ __forceinline__ int uni(int v) { return int(__builtin_amdgcn_readfirstlane(uint32_t(v))); }
+    static __device__ __forceinline__ uint64_t uni(uint64_t v) {
+        return uint64_t(__builtin_amdgcn_readfirstlane(uint32_t(v))) | (uint64_t(__builtin_amdgcn_readfirstlane(uint32_t(v >> 32))) << 32);
+    }
 };
 
 // The parallel half: lane i owns record i of a batch.  Output bytes of the batch are assembled in the LDS staging area
 // (sources inside the batch are LDS reads, sources before it are this wave's own earlier output in HBM) and flushed.
 struct WaveSink {
     uint32_t rec = 0, pos = 0;  // this lane's record of the current batch
-    WaveMem::u8p stage;         // [kStage (+ slack)]
+    WaveMem::u8p stage;         // [kStage + 3], word aligned
     const uint8_t *src8;        // the stream's bytes (stored blocks)
     uint8_t *dst;               // the chunk's output
     __device__ __forceinline__ void put(int i, uint32_t r, uint64_t p) {
-        if (int(threadIdx.x) == i) {
-            rec = r;
-            pos = uint32_t(p);
-        }
+        // selects, not a branch: a lane-dependent branch inside the symbol loop makes the compiler treat the loop's whole
+        // state as divergent (VGPRs + exec-mask branches instead of SGPRs + scalar branches)
+        const bool mine = int(threadIdx.x) == i;
+        rec = mine ? r : rec;
+        pos = mine ? uint32_t(p) : pos;
     }
     __device__ __forceinline__ void tables_ready() { __syncthreads(); }
     __device__ void stored(uint64_t byte_pos, uint32_t len, uint64_t out_pos) {
@@ -272,6 +277,8 @@ struct WaveSink {
     __device__ void resolve(int n, uint64_t bstart, uint64_t bend) {
         const uint32_t lane = threadIdx.x;
         const uint32_t bs = uint32_t(bstart), total = uint32_t(bend - bstart);
+        // the staging area starts (bs & 3) bytes in, so that its aligned words are the output's aligned words (the flush)
+        WaveMem::u8p st = stage + (bs & 3u);
         const bool active = int(lane) < n;
         const bool lit = (rec & dinf::kLitFlag) != 0;
         const uint32_t len = rec & 0x1FFu, dist = (rec & 0x7FFFFFFFu) >> 9;
@@ -279,10 +286,10 @@ struct WaveSink {
         bool coop = false;  // matches that wait for the ordered pass: sources inside the batch, or long
         if (active) {
             if (lit) {
-                stage[rel] = uint8_t(rec);
+                st[rel] = uint8_t(rec);
             } else if (pos - dist + len <= bs && len <= 16) {  // short, its whole source precedes the batch: on its own
                 const uint8_t *sp = dst + (pos - dist);
-                for (uint32_t j = 0; j < len; ++j) stage[rel + j] = sp[j];
+                for (uint32_t j = 0; j < len; ++j) st[rel + j] = sp[j];
             } else {
                 coop = true;
             }
@@ -297,11 +304,19 @@ struct WaveSink {
             for (uint32_t j = lane; j < L; j += 64) {
                 const uint32_t k = D >= L ? j : j % D;  // an overlapping match repeats its first D bytes
                 const uint32_t sp = p - D + k;
-                stage[R + j] = sp >= bs ? stage[sp - bs] : dst[sp];
+                st[R + j] = sp >= bs ? st[sp - bs] : dst[sp];
             }
             __syncthreads();
         }
-        for (uint32_t k = lane; k < total; k += 64) dst[bs + k] = stage[k];
+        // flush: the unaligned head and tail byte by byte, the words in between as words
+        const uint32_t head = min((4u - (bs & 3u)) & 3u, total), words = (total - head) >> 2, tail0 = head + 4u * words;
+        if (lane < head) dst[bs + lane] = st[lane];
+        if (lane >= 32 && lane - 32 < total - tail0) dst[bs + tail0 + (lane - 32)] = st[tail0 + (lane - 32)];
+        {
+            const __attribute__((address_space(3))) uint32_t *sw = (const __attribute__((address_space(3))) uint32_t *)(st + head);
+            uint32_t *dw = reinterpret_cast<uint32_t *>(dst + bs + head);
+            for (uint32_t k = lane; k < words; k += 64) dw[k] = sw[k];
+        }
         __threadfence_block();  // later batches read these bytes back
         __syncthreads();
     }
@@ -396,7 +411,7 @@ struct Pending {
     UnpackParams p{};
     double *d_out = nullptr;
     int64_t chunk_bytes = 0, max_elems = 0;
-    size_t off_inf = 0, off_unp = 0, off_res = 0;
+    size_t off_inf = 0, off_unp = 0, off_res = 0, n_desc = 0;
 };
 
 struct Slot {
@@ -733,7 +748,7 @@ int submit_device(atl_ctx *ctx, Slot *sl, size_t h2d_bytes, double *d_out) {
     if (!sl->ev_fork[0]) ATL_HIP_TRY(hipEventCreateWithFlags(&sl->ev_fork[0], hipEventDisableTiming));
     ATL_HIP_TRY(hipEventRecord(sl->ev_fork[0], cs));
     ATL_HIP_TRY(hipStreamWaitEvent(sl->st, sl->ev_fork[0], 0));
-    const size_t n = job.inf.size(), n_desc = (job.off_res - job.off_unp) / sizeof(UnpackDesc);
+    const size_t n = job.inf.size(), n_desc = job.n_desc;
     for (hipEvent_t &e : sl->ev_t)
         if (!e) ATL_HIP_TRY(hipEventCreate(&e));
     ATL_HIP_TRY(hipEventRecord(sl->ev_t[0], sl->st));
@@ -754,7 +769,9 @@ int submit_device(atl_ctx *ctx, Slot *sl, size_t h2d_bytes, double *d_out) {
     ATL_HIP_TRY(hipEventRecord(sl->ev, sl->st));
     sl->pending = true;
     job.active = true;
-    ATL_HIP_TRY(hipStreamWaitEvent(cs, sl->ev, 0));
+    // (no hipStreamWaitEvent(cs, sl->ev) here: the NEXT read forks from the copy stream, so that join would put the slots'
+    //  streams one behind the other.  Whoever observes the copy stream goes through ingest_finish, which waits for every
+    //  pending slot on the host first.)
     return ATL_OK;
 }
 
@@ -1198,6 +1215,7 @@ int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, 
             job.off_inf = off_inf;
             job.off_unp = off_unp;
             job.off_res = off_res;
+            job.n_desc = sel.desc.size();
             return submit_device(ctx, sl, off_unp + sel.desc.size() * sizeof(UnpackDesc), d_out);
         }
         for (UnpackDesc &ds : sel.desc) ds.shuffled = 0;

@@ -206,6 +206,12 @@ def roofline_of(leg, algo_bytes, k_ms, extra=None):
             us = ent.get("avg_us_timed") or ent["avg_us"]  # the launches after the leg's warm-up, when the record says which
             r["profile_kernel_ms"] = us * 1e-3
             r["frac_from_profile"] = algo_bytes / (us * 1e-6) / 1e9 / PEAK_GBPS
+            import socket
+
+            # the same build runs +-4 % from box to box: say whether the record and this line come from the same one
+            r["profile_box"], r["this_box"] = ent.get("box"), socket.gethostname()
+            r["profile_is_this_box"] = ent.get("box") == socket.gethostname()
+            r["frac_vs_profile"] = r["frac"] / r["frac_from_profile"]
             r["profile_source"] = (f"{src} (rocprofv3 --kernel-trace --stats, avg of the {ent.get('timed_launches', ent.get('calls'))} "
                                    f"launches of this leg after its warm-up, not this run; all {ent.get('calls')} launches: {ent['avg_us'] * 1e-3:.3f} ms)")
         tr = ent.get("hbm_bytes_per_launch")

@@ -73,7 +73,10 @@ def main():
     env = dict(os.environ, TMPDIR="/tmp")
     latest_f = out / "bench_profile_latest.json"
     latest = json.loads(latest_f.read_text()) if latest_f.exists() else {"note": __doc__.strip().split("\n\n")[0], "legs": {}}
-    tag = os.environ.get("ATL_PROFILE_TAG", "r04")
+    tag = os.environ.get("ATL_PROFILE_TAG", "r05")
+    import socket
+
+    box = socket.gethostname()  # which box the record was measured on: bench.py quotes it beside a line from another one
     for g in groups:
         args, legs = GROUPS[g]
         lines, per_pass = [], {}
@@ -163,7 +166,7 @@ def main():
                 w, n_timed = SLICES[leg]
             timed = seq[w:w + n_timed] if len(seq) > w else seq
             e = dict(kernel=k, **st, warmup_launches=w if len(seq) > w else 0, timed_launches=len(timed),
-                     avg_us_timed=sum(timed) / len(timed), source=f"profiles/{tag}_bench_{g}.txt")
+                     avg_us_timed=sum(timed) / len(timed), source=f"profiles/{tag}_bench_{g}.txt", box=box)
             if leg in SLICES and k in pmc_seq and len(pmc_seq[k].get("FETCH_SIZE", [])) >= w + n_timed:
                 # the counters of THIS leg's launches only (the kernel's other launches in the pass read other cubes)
                 f = pmc_seq[k]["FETCH_SIZE"][w:w + n_timed]
