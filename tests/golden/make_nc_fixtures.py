@@ -131,7 +131,7 @@ def write_case(path, T=23, Y=7, X=9, chunks=(10, 4, 5), libver=("earliest", "v10
     return exp
 
 
-def _write_chunks_direct(v, a, chunks, level, threads):
+def _write_chunks_direct(v, a, chunks, level, threads, t0=0):
     """Same bytes libhdf5's own pipeline would store (shuffle, then zlib at `level`; edge chunks padded with the fill value
     0), produced on `threads` threads - zlib releases the GIL - and handed over with write_direct_chunk."""
     import zlib
@@ -153,7 +153,7 @@ def _write_chunks_direct(v, a, chunks, level, threads):
 
     with ThreadPoolExecutor(threads) as ex:
         for o, payload in zip(origins, ex.map(pack, origins)):
-            v.id.write_direct_chunk(o, payload)
+            v.id.write_direct_chunk((o[0] + t0, o[1], o[2]), payload)
 
 
 def write_cutout(path, T=48, Y=9, X=12, chunks=(20, 5, 7), dtype="f4", seed=7, gzip=6, start_hours=990552, threads=1):
@@ -171,28 +171,43 @@ def write_cutout(path, T=48, Y=9, X=12, chunks=(20, 5, 7), dtype="f4", seed=7, g
             d.make_scale(n)
         f.create_dataset("lon", data=x[...], track_order=True).dims[0].attach_scale(x)
         f.create_dataset("lat", data=y[...], track_order=True).dims[0].attach_scale(y)
-        u = lambda: rng.random((T, Y, X))
-        alt = (u() - 0.35) * 1.6
-        toa = 1361.0 * np.maximum(np.sin(alt), 0.0)
-        kt, fd = 0.2 + 0.55 * u(), 0.3 + 0.5 * u()
-        fields = {
-            "influx_toa": toa, "influx_direct": toa * kt * fd, "influx_diffuse": toa * kt * (1 - fd),
-            "albedo": 0.05 + 0.3 * u(), "temperature": 268.0 + 30.0 * u(), "solar_altitude": alt,
-            "solar_azimuth": 2 * np.pi * u(), "wnd100m": 25.0 * u() ** 2, "roughness": 0.001 + 1.5 * u() ** 3,
-            "runoff": 1e-4 * u(), "soil temperature": 270.0 + 20.0 * u(),
-        }
-        for n, a in fields.items():
-            a = np.round(a * 4096) / 4096  # keeps the deflated fixture small
-            if threads > 1:  # big bench files: the chunks are shuffled + deflated on a thread pool and written as they are
-                v = f.create_dataset(n, shape=a.shape, dtype=dtype, chunks=chunks, compression="gzip", compression_opts=gzip,
-                                     shuffle=True, track_order=True)
-                _write_chunks_direct(v, a.astype(dtype), chunks, gzip, threads)
-            else:
-                v = f.create_dataset(n, data=a.astype(dtype), chunks=chunks, compression="gzip", compression_opts=gzip,
-                                     shuffle=True, track_order=True)
+        def make_fields(rng, Tb):
+            u = lambda: rng.random((Tb, Y, X))
+            alt = (u() - 0.35) * 1.6
+            toa = 1361.0 * np.maximum(np.sin(alt), 0.0)
+            kt, fd = 0.2 + 0.55 * u(), 0.3 + 0.5 * u()
+            return {
+                "influx_toa": toa, "influx_direct": toa * kt * fd, "influx_diffuse": toa * kt * (1 - fd),
+                "albedo": 0.05 + 0.3 * u(), "temperature": 268.0 + 30.0 * u(), "solar_altitude": alt,
+                "solar_azimuth": 2 * np.pi * u(), "wnd100m": 25.0 * u() ** 2, "roughness": 0.001 + 1.5 * u() ** 3,
+                "runoff": 1e-4 * u(), "soil temperature": 270.0 + 20.0 * u(),
+            }
+
+        def finish(v, n):
             for i, s in enumerate((t, y, x)):
                 v.dims[i].attach_scale(s)
             v.attrs["units"] = np.string_("unit of " + n)
+
+        if threads > 1:
+            # big bench files: generated and written in blocks of whole chunk rows (memory stays bounded: a year of 200 x 200
+            # would be 30 GB of float64 fields at once), the chunks shuffled + deflated on a thread pool and written as they are
+            tb = max(chunks[0], (720 // chunks[0]) * chunks[0])
+            dsets = {}
+            for t0 in range(0, T, tb):
+                blk = make_fields(np.random.default_rng([seed, t0]), min(tb, T - t0))
+                for n, a in blk.items():
+                    if n not in dsets:
+                        dsets[n] = f.create_dataset(n, shape=(T, Y, X), dtype=dtype, chunks=chunks, compression="gzip",
+                                                    compression_opts=gzip, shuffle=True, track_order=True)
+                    _write_chunks_direct(dsets[n], (np.round(a * 4096) / 4096).astype(dtype), chunks, gzip, threads, t0)
+            for n, v in dsets.items():
+                finish(v, n)
+        else:
+            for n, a in make_fields(rng, T).items():
+                a = np.round(a * 4096) / 4096  # keeps the deflated fixture small
+                v = f.create_dataset(n, data=a.astype(dtype), chunks=chunks, compression="gzip", compression_opts=gzip,
+                                     shuffle=True, track_order=True)
+                finish(v, n)
         h = f.create_dataset("height", data=(2000.0 * rng.random((Y, X))).astype(dtype), track_order=True)
         h.dims[0].attach_scale(y)
         h.dims[1].attach_scale(x)

@@ -9,13 +9,13 @@ export TMPDIR=/tmp
 echo "== 1. ingest tests"; date +%T
 timeout 420 python -X faulthandler -m pytest tests/test_gpu_ingest.py -x -q > $OUT/ingest_tests.log 2>&1
 echo "rc=$? $(tail -1 $OUT/ingest_tests.log)"; grep -E "^(FAILED|ERROR)|Error|assert " $OUT/ingest_tests.log | head -10
-echo "== 2. from-file bench, T=1440 and T=8760"; date +%T
+echo "== 2. from-file bench, T=1440 and T=4380"; date +%T
 timeout 300 python tools/bench_ingest.py --T 1440 --quick --keep /tmp/c1440.nc > $OUT/ingest_1440.log 2>&1
 cut -c1-250 $OUT/ingest_1440.log
 date +%T
-timeout 480 python tools/bench_ingest.py --T 8760 --quick --keep /tmp/c8760.nc > $OUT/ingest_8760.log 2>&1
-cut -c1-250 $OUT/ingest_8760.log
-rm -f /tmp/c8760.nc
+timeout 480 python tools/bench_ingest.py --T 4380 --quick --keep /tmp/c4380.nc > $OUT/ingest_4380.log 2>&1
+cut -c1-250 $OUT/ingest_4380.log
+rm -f /tmp/c4380.nc
 echo "== 3. tests: day map, aligned refusals, post, parity, bench ladder"; date +%T
 timeout 600 python -X faulthandler -m pytest tests/test_gpu_day_map.py tests/test_gpu_aligned_plans.py tests/test_gpu_post.py \
   tests/test_gpu_multidevice.py::test_bench_prints_its_line_when_no_collective_works tests/test_gpu_parity.py -x -q > $OUT/tests.log 2>&1
