@@ -232,6 +232,8 @@ SIGNATURES = {
     "atl_nc_att_double": (_i, [_vp, C.c_char_p, C.c_char_p, _vp, _i64, C.POINTER(_i64)]),
     "atl_nc_read_host": (_i, [_vp, C.c_char_p, _i64, _i64, _vp]),
     "atl_nc_read_slab": (_i, [_vp, _vp, C.c_char_p, _i64, _i64, _vp, _i]),
+    "atl_nc_read_slabs": (_i, [_vp, _vp, _i, C.POINTER(C.c_char_p), _i64, _i64, C.POINTER(_vp), _i]),
+    "atl_nc_read_slabs_ld": (_i, [_vp, _i64, _vp, _i, C.POINTER(C.c_char_p), _i64, _i64, C.POINTER(_vp), _i]),
     "atl_nc_ingest_stats": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "atl_pv_day_map": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64]),
     "atl_nc_ingest_times": (_i, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64)]),

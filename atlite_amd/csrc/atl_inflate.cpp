@@ -474,13 +474,8 @@ namespace {
 struct HostSink {
     const uint8_t *src;
     uint8_t *dst;
-    uint32_t rec[dinf::kQueue];
-    uint64_t pos[dinf::kQueue];
+    const uint32_t *rec, *pos;  // the decoder's queue (Areas::qrec / qpos)
     uint64_t max_batch = 0;
-    void put(int i, uint32_t r, uint64_t p) {
-        rec[i] = r;
-        pos[i] = p;
-    }
     void tables_ready() {}
     void stored(uint64_t byte_pos, uint32_t len, uint64_t out_pos) { memcpy(dst + out_pos, src + byte_pos, len); }
     void resolve(int n, uint64_t bstart, uint64_t bend) {
@@ -503,12 +498,15 @@ int device_inflate_emulated(const uint8_t *src, uint64_t src_n, uint8_t *dst, ui
     if (src_n) memcpy(words.data(), src, size_t(src_n));
     std::vector<uint32_t> lit(kLitCap), off(kOffCap), codes(320), cnt(16), nxt(16);
     std::vector<uint8_t> sub_bits(size_t(1) << kLitBits), lens(512);
-    Areas<HostMem> A{lit.data(), off.data(), codes.data(), cnt.data(), nxt.data(), sub_bits.data(), lens.data()};
+    std::vector<uint32_t> qrec(kQueue), qpos(kQueue + 1), wbuf(16);
+    Areas<HostMem> A{lit.data(), off.data(), codes.data(), cnt.data(), nxt.data(), sub_bits.data(), lens.data(), qrec.data(), qpos.data(), wbuf.data()};
     HostSink sink{};
     sink.src = reinterpret_cast<const uint8_t *>(words.data());
     sink.dst = dst;
+    sink.rec = qrec.data();
+    sink.pos = qpos.data();
     uint32_t want = 0;
-    const int st = inflate_stream<HostMem, HostSink>(A, words.data(), uint32_t((src_n + 3) / 4), src_n, dst_n, sink, &want);
+    const int st = inflate_stream<HostMem, HostWave, HostWindow<HostMem>, HostSink>(A, words.data(), uint32_t((src_n + 3) / 4), src_n, dst_n, sink, &want);
     if (st) return st;
     if (sink.max_batch > uint64_t(kStage)) return 100;  // the staging area of the device would have overflowed
     return adler32_of(dst, dst_n) == want ? kOk : kAdler;

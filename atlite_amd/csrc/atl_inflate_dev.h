@@ -6,12 +6,16 @@
 // PCIe carries the COMPRESSED bytes.
 //
 // Split of a wave's work (k_inflate, atl_ingest.hip):
-//   * serial, wave-uniform (this header): bit reader, block headers, canonical Huffman tables in LDS, symbol decode into a
-//     batch of up to 64 (literal | length, distance) records.  Every lane executes the same instructions on the same
-//     values, so the compiler keeps the state in SGPRs and reads the input through the scalar cache; LDS reads come back
-//     through v_readfirstlane.
-//   * parallel (atl_ingest.hip): the batch is resolved into an LDS staging area by all 64 lanes (lane i owns record i)
-//     and flushed to HBM.
+//   * wave-uniform (this header): bit reader, block headers, canonical Huffman tables in LDS.  Every lane executes the same
+//     instructions on the same values, so the compiler keeps the state in SGPRs and reads the input through the scalar
+//     cache; LDS reads come back through v_readfirstlane.
+//   * symbols, 64 bit offsets at a time (decode_batch_wide): lane k decodes - speculatively - the symbol that would start
+//     k bits into the window (its table lookups are one LDS gather for the whole wave); a short uniform loop then follows
+//     the chain of real symbol starts (offset += that lane's code length) and queues the selected lanes' records.  A
+//     scalar decoder pays ~800 cycles per symbol on this machine (one wave issues an instruction every ~4 cycles, a taken
+//     branch costs ~16); the window pays the lookups once per ~7 symbols.
+//   * parallel (atl_ingest.hip): a batch of up to 64 queued records is resolved into an LDS staging area by all 64 lanes
+//     (lane i owns record i) and flushed to HBM.
 // The serial half is plain C++ over a memory policy M (HostMem: ordinary pointers; the device's WaveMem: LDS pointers,
 // readfirstlane loads, lane-0 stores), so the CPU suite runs exactly this code against zlib
 // (atl_inflate_probe(which = 3), tools/fuzz_inflate.py) without a GPU.  Untrusted input: every table index, every
@@ -107,10 +111,44 @@ struct HostMem {
     static inline void st32(uint32_t *p, uint32_t v) { *p = v; }
     static inline void st8(uint8_t *p, uint32_t v) { *p = uint8_t(v); }
     static inline uint32_t src(const uint32_t *w, uint32_t i) { return w[i]; }
+    static inline uint32_t ldv32(const uint32_t *p) { return *p; }       // a load / store whose address differs from lane to lane
+    static inline void stv32(uint32_t *p, uint32_t v) { *p = v; }
+    static inline uint32_t ldv8(const uint8_t *p) { return *p; }
+    static inline void stv8(uint8_t *p, uint32_t v) { *p = uint8_t(v); }
     // "this value is the same in every lane" (device: keeps the decoder's state in scalar registers)
     static inline uint32_t uni(uint32_t v) { return v; }
     static inline uint64_t uni(uint64_t v) { return v; }
     static inline int uni(int v) { return v; }
+};
+
+// the wave as the host sees it: every per-lane variable is an array of 64, every per-lane step a loop
+struct HostWave {
+    template <class T>
+    struct Var {
+        T v[64];
+        T &operator()(int k) { return v[k]; }
+    };
+    template <class F>
+    static inline void each(F &&f) {
+        for (int k = 0; k < 64; ++k) f(k);
+    }
+    static inline uint32_t readlane(Var<uint32_t> &x, int lane) { return x.v[lane]; }
+    static inline uint64_t ballot(Var<uint32_t> &x) {
+        uint64_t m = 0;
+        for (int k = 0; k < 64; ++k) m |= uint64_t(x.v[k] != 0) << k;
+        return m;
+    }
+    static inline void sync() {}
+    // x(k) <- sum of x over the lanes below k; returns the sum over all lanes
+    static inline uint32_t excl_scan(Var<uint32_t> &x) {
+        uint32_t acc = 0;
+        for (int k = 0; k < 64; ++k) {
+            const uint32_t v = x.v[k];
+            x.v[k] = acc;
+            acc += v;
+        }
+        return acc;
+    }
 };
 
 // LDS areas of one stream's decoder (device: carved out of the workgroup's shared memory; host: a struct on the heap)
@@ -123,74 +161,139 @@ struct Areas {
     typename M::u32p nxt;      // [16]   next code per length
     typename M::u8p sub_bits;  // [1 << kLitBits] widest long code behind a primary slot
     typename M::u8p lens;      // [286 + 30 + 138] code lengths of the block
+    typename M::u32p qrec;     // [kQueue] records of the current batch: literal = kLitFlag | byte, match = length | distance << 9
+    typename M::u32p qpos;     // [kQueue + 1] ... and where in the output each begins (+ a slot nobody reads)
+    typename M::u32p wbuf;     // [16] the stream's words under the current window
 };
 
 // canonical Huffman decode table, single lookup + one sub-table level.  Returns false for an invalid code.
-template <class M>
+// Built by the whole wave (round 5; the serial version cost a fifth of a stream's time): lane k owns the symbols k, k + 64, ...
+// - their rank among the symbols of equal length comes from ballots, their table entries are written by the lane itself -
+// and a 64th of the primary slots when the sub-tables are laid out.  Only what needs an order is serial: the 15 first codes,
+// and the widest long code behind a primary slot (a loop over the long codes, few).
+template <class M, class W>
 ATL_HD inline bool build_table(const Areas<M> &A, typename M::u8p lens, int n, int table_bits, int cap, TableKind what,
                                typename M::u32p table) {
-    for (int l = 0; l < 16; ++l) M::st32(A.cnt + l, 0);
-    for (int i = 0; i < n; ++i) {
-        const uint32_t l = M::ld8(lens + i) & 15u;
-        M::st32(A.cnt + l, M::ld32(A.cnt + l) + 1);
-    }
-    if (int(M::ld32(A.cnt + 0)) == n) return false;  // no codes at all
-    int left = 1, used = 0;
-    uint32_t code = 0, prev_count = 0;
-    uint32_t count1 = 0;
-    for (int l = 1; l <= 15; ++l) {
-        const uint32_t c = M::ld32(A.cnt + l);
-        if (l == 1) count1 = c;
-        left = (left << 1) - int(c);
-        if (left < 0) return false;  // over-subscribed
-        used += int(c);
-        code = (code + prev_count) << 1;  // unused symbols (length 0) take no code space: prev_count starts at 0
-        M::st32(A.nxt + l, code);
-        prev_count = c;
-    }
-    if (left > 0 && !(used == 1 && count1 == 1)) return false;  // incomplete (zlib allows a single 1-bit code)
     const uint32_t tsize = 1u << table_bits;
-    for (uint32_t i = 0; i < tsize; ++i) {
-        M::st32(table + i, 0);  // len 0 = invalid
-        M::st8(A.sub_bits + i, 0);
+    const int n_chunks = (n + 63) / 64;
+    for (int l = 0; l < 16; ++l) M::st32(A.cnt + l, 0);
+    W::each([&](int k) {
+        for (uint32_t i = uint32_t(k); i < tsize; i += 64u) {
+            M::stv32(table + i, 0);  // len 0 = invalid
+            M::stv8(A.sub_bits + i, 0);
+        }
+    });
+    W::sync();
+    // rank of every symbol among the symbols of its length (symbol order), the counts per length on the way
+    for (int c = 0; c < n_chunks; ++c) {
+        typename W::template Var<uint32_t> len, rank, is;
+        W::each([&](int k) {
+            const int i = 64 * c + k;
+            len(k) = i < n ? (M::ldv8(lens + i) & 15u) : 0u;
+            rank(k) = 0;
+        });
+        for (uint32_t l = 1; l <= 15; ++l) {
+            W::each([&](int k) { is(k) = len(k) == l ? 1u : 0u; });
+            const uint64_t m = W::ballot(is);
+            if (!m) continue;
+            const uint32_t base = M::ld32(A.cnt + l);
+            W::each([&](int k) {
+                if (len(k) == l) rank(k) = base + uint32_t(__builtin_popcountll(m & ((uint64_t(1) << k) - 1u)));
+            });
+            M::st32(A.cnt + l, base + uint32_t(__builtin_popcountll(m)));
+        }
+        W::each([&](int k) {
+            const int i = 64 * c + k;
+            if (i < n) M::stv32(A.codes + i, rank(k));
+        });
     }
-    bool any_long = false;
-    for (int s = 0; s < n; ++s) {
-        const int l = int(M::ld8(lens + s) & 15u);
-        if (!l) continue;
-        const uint32_t c = M::ld32(A.nxt + l);
-        M::st32(A.nxt + l, c + 1);
-        const uint32_t r = bit_reverse(c, l);
-        M::st32(A.codes + s, r);
-        if (l <= table_bits) {
-            const uint32_t e = entry_for(what, s, uint32_t(l));
-            for (uint32_t i = r; i < tsize; i += 1u << l) M::st32(table + i, e);
-        } else {
-            const uint32_t p = r & (tsize - 1);
-            if (uint32_t(l - table_bits) > M::ld8(A.sub_bits + p)) M::st8(A.sub_bits + p, uint32_t(l - table_bits));
-            any_long = true;
+    W::sync();
+    // the code space: complete, not over-subscribed (zlib allows a single 1-bit code); first code of every length
+    int left = 1, used = 0;
+    uint32_t code = 0, prev_count = 0, count1 = 0;
+    for (int l = 1; l <= 15; ++l) {
+        const uint32_t cl = M::ld32(A.cnt + l);
+        if (l == 1) count1 = cl;
+        left = (left << 1) - int(cl);
+        if (left < 0) return false;
+        used += int(cl);
+        code = (code + prev_count) << 1;
+        M::st32(A.nxt + l, code);
+        prev_count = cl;
+    }
+    if (used == 0) return false;  // no codes at all
+    if (left > 0 && !(used == 1 && count1 == 1)) return false;
+    W::sync();
+    // codes; the entries of the short ones
+    uint64_t any_long = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        typename W::template Var<uint32_t> lng;
+        W::each([&](int k) {
+            const int i = 64 * c + k;
+            lng(k) = 0;
+            const uint32_t l = i < n ? (M::ldv8(lens + i) & 15u) : 0u;
+            if (l) {
+                const uint32_t r = bit_reverse(M::ldv32(A.nxt + l) + M::ldv32(A.codes + i), int(l));
+                M::stv32(A.codes + i, r);
+                if (l <= uint32_t(table_bits)) {
+                    const uint32_t e = entry_for(what, i, l);
+                    for (uint32_t j = r; j < tsize; j += 1u << l) M::stv32(table + j, e);
+                } else {
+                    lng(k) = 1;
+                }
+            }
+        });
+        const uint64_t m = W::ballot(lng);
+        any_long |= m;
+        // the widest long code behind each primary slot: several codes share a slot, so one after the other
+        for (uint64_t t = m; t; t &= t - 1) {
+            const int i = 64 * c + __builtin_ctzll(t);
+            const uint32_t l = M::ld8(lens + i) & 15u, pslot = M::ld32(A.codes + i) & (tsize - 1);
+            if (l - uint32_t(table_bits) > M::ld8(A.sub_bits + pslot)) M::st8(A.sub_bits + pslot, l - uint32_t(table_bits));
         }
     }
-    if (!any_long) return true;
-    uint32_t pos = tsize;
-    for (uint32_t p = 0; p < tsize; ++p) {
-        const uint32_t sb = M::ld8(A.sub_bits + p);
-        if (!sb) continue;
-        if (pos + (1u << sb) > uint32_t(cap)) return false;
-        M::st32(table + p, mk(uint32_t(table_bits), sb, kSub, pos));
-        for (uint32_t i = 0; i < (1u << sb); ++i) M::st32(table + pos + i, 0);
-        pos += 1u << sb;
+    if (!any_long) {
+        W::sync();
+        return true;
     }
-    for (int s = 0; s < n; ++s) {
-        const int l = int(M::ld8(lens + s) & 15u);
-        if (l <= table_bits) continue;
-        const uint32_t r = M::ld32(A.codes + s);
-        const uint32_t p = r & (tsize - 1);
-        const uint32_t link = M::ld32(table + p);
-        const uint32_t start = e_value(link), sb = e_extra(link);
-        const uint32_t e = entry_for(what, s, uint32_t(l - table_bits));
-        for (uint32_t i = r >> table_bits; i < (1u << sb); i += 1u << (l - table_bits)) M::st32(table + start + i, e);
+    W::sync();
+    // sub-tables: lane k lays out the ones behind its run of primary slots, one after the other from where the lanes below end
+    const uint32_t per = tsize / 64u;  // primary slots per lane (16, 4 or 2)
+    typename W::template Var<uint32_t> room;
+    W::each([&](int k) {
+        uint32_t sum = 0;
+        for (uint32_t q = 0; q < per; ++q) {
+            const uint32_t sb = M::ldv8(A.sub_bits + uint32_t(k) * per + q);
+            sum += sb ? 1u << sb : 0u;
+        }
+        room(k) = sum;
+    });
+    const uint32_t total = W::excl_scan(room);
+    if (tsize + total > uint32_t(cap)) return false;
+    W::each([&](int k) {
+        uint32_t pos = tsize + room(k);
+        for (uint32_t q = 0; q < per; ++q) {
+            const uint32_t pslot = uint32_t(k) * per + q, sb = M::ldv8(A.sub_bits + pslot);
+            if (!sb) continue;
+            M::stv32(table + pslot, mk(uint32_t(table_bits), sb, kSub, pos));
+            for (uint32_t j = 0; j < (1u << sb); ++j) M::stv32(table + pos + j, 0);
+            pos += 1u << sb;
+        }
+    });
+    W::sync();
+    // the long codes' entries in their sub-tables (disjoint: every lane for itself)
+    for (int c = 0; c < n_chunks; ++c) {
+        W::each([&](int k) {
+            const int i = 64 * c + k;
+            const uint32_t l = i < n ? (M::ldv8(lens + i) & 15u) : 0u;
+            if (l > uint32_t(table_bits)) {
+                const uint32_t r = M::ldv32(A.codes + i), link = M::ldv32(table + (r & (tsize - 1)));
+                const uint32_t start = e_value(link), sb = e_extra(link), e = entry_for(what, i, l - uint32_t(table_bits));
+                for (uint32_t j = r >> table_bits; j < (1u << sb); j += 1u << (l - uint32_t(table_bits))) M::stv32(table + start + j, e);
+            }
+        });
     }
+    W::sync();
     return true;
 }
 
@@ -248,7 +351,7 @@ struct Bits {
 
 // ---- block header -------------------------------------------------------------------------------------------------------
 // type 2: code lengths -> both tables.  type 1: the fixed code's tables.  Returns a Status.
-template <class M>
+template <class M, class W>
 ATL_HD inline int dynamic_tables(const Areas<M> &A, Bits<M> &b) {
     b.refill();
     const int hlit = int(b.take(5)) + 257;
@@ -274,7 +377,7 @@ ATL_HD inline int dynamic_tables(const Areas<M> &A, Bits<M> &b) {
         M::st8(A.lens + o, v);
     }
     typename M::u32p pre = A.off;  // the offset table's space: it is rebuilt after the lengths have been read
-    if (!build_table<M>(A, A.lens, 19, kPreBits, kPreCap, kPrecodeTable, pre)) return kBadCode;
+    if (!build_table<M, W>(A, A.lens, 19, kPreBits, kPreCap, kPrecodeTable, pre)) return kBadCode;
     // the code lengths of both alphabets as one run-length coded sequence (kept past the precode's 19 bytes)
     typename M::u8p lens = A.lens + 32;
     const int total = hlit + hdist;
@@ -312,105 +415,194 @@ ATL_HD inline int dynamic_tables(const Areas<M> &A, Bits<M> &b) {
         i += rep;
     }
     if (M::ld8(lens + 256) == 0) return kBadCode;  // no end-of-block code
-    if (!build_table<M>(A, lens, hlit, kLitBits, kLitCap, kLitlenTable, A.lit)) return kBadCode;
+    if (!build_table<M, W>(A, lens, hlit, kLitBits, kLitCap, kLitlenTable, A.lit)) return kBadCode;
     bool any_off = false;
     for (int k = 0; k < hdist; ++k) any_off = any_off || M::ld8(lens + hlit + k) != 0;
     if (any_off) {
-        if (!build_table<M>(A, lens + hlit, hdist, kOffBits, kOffCap, kOffsetTable, A.off)) return kBadCode;
+        if (!build_table<M, W>(A, lens + hlit, hdist, kOffBits, kOffCap, kOffsetTable, A.off)) return kBadCode;
     } else {  // a block of literals only may carry an empty offset code
         for (int k = 0; k < (1 << kOffBits); ++k) M::st32(A.off + k, 0);
     }
     return kOk;
 }
 
-template <class M>
+template <class M, class W>
 ATL_HD inline int fixed_tables(const Areas<M> &A) {
     typename M::u8p lens = A.lens + 32;
     for (int i = 0; i < 288; ++i) M::st8(lens + i, i < 144 ? 8u : i < 256 ? 9u : i < 280 ? 7u : 8u);
     for (int i = 0; i < 32; ++i) M::st8(lens + 288 + i, 5u);
-    if (!build_table<M>(A, lens, 288, kLitBits, kLitCap, kLitlenTable, A.lit)) return kBadCode;
-    if (!build_table<M>(A, lens + 288, 32, kOffBits, kOffCap, kOffsetTable, A.off)) return kBadCode;
+    if (!build_table<M, W>(A, lens, 288, kLitBits, kLitCap, kLitlenTable, A.lit)) return kBadCode;
+    if (!build_table<M, W>(A, lens + 288, 32, kOffBits, kOffCap, kOffsetTable, A.off)) return kBadCode;
     return kOk;
 }
 
 // ---- one batch of symbols ---------------------------------------------------------------------------------------------------
-// Records: literal = 0x80000000 | byte; match = length (9 bits) | distance << 9.  `Sink::put(i, record, pos)` stores
-// record i of the batch (device: lane i keeps it in registers; host: arrays).  Decoding stops at the end of the block
-// (*eob), after kQueue records, or when fewer than kMaxMatch bytes of the staging area would be left.
+// Records: literal = kLitFlag | byte; match = length (9 bits) | distance << 9.
 constexpr uint32_t kLitFlag = 0x80000000u;
 
-template <class M, class Sink>
-ATL_HD inline int decode_batch(const Areas<M> &A, Bits<M> &b, uint64_t &out_pos, uint64_t out_n, Sink &sink, int &n_out,
-                               bool &eob) {
-    const uint64_t bstart = out_pos;
-    int n = 0;
-    eob = false;
-    int status = kOk;
-    while (n < kQueue && out_pos - bstart <= uint64_t(kStage - kMaxMatch)) {
-        b.refill();
-        uint32_t e = M::ld32(A.lit + b.peek(kLitBits));
-        if (e_kind(e) == kSub) {
-            b.drop(kLitBits);
-            {
-                const uint32_t ix = e_value(e) + b.peek(int(e_extra(e)));
-                e = M::ld32(A.lit + (ix < uint32_t(kLitCap) ? ix : uint32_t(kLitCap - 1)));
-            }
-        }
-        const int l = int(e_len(e));
-        if (!l) {
-            status = kBadSymbol;
-            break;
-        }
-        b.drop(l);
-        const uint32_t kind = e_kind(e);
-        if (kind == kLiteral) {
-            if (out_pos >= out_n) {
-                status = kOutputFull;
-                break;
-            }
-            sink.put(n, kLitFlag | e_value(e), out_pos);
-            ++n;
-            ++out_pos;
-            continue;
-        }
-        if (kind == kEnd) {
-            eob = true;
-            break;
-        }
-        if (kind != kBase) {  // a sub-table link inside a sub-table: never built
-            status = kBadSymbol;
-            break;
-        }
-        const uint32_t length = e_value(e) + b.take(int(e_extra(e)));
-        b.refill();
-        uint32_t o = M::ld32(A.off + b.peek(kOffBits));
-        if (e_kind(o) == kSub) {
-            b.drop(kOffBits);
-            {
-                const uint32_t ix = e_value(o) + b.peek(int(e_extra(o)));
-                o = M::ld32(A.off + (ix < uint32_t(kOffCap) ? ix : uint32_t(kOffCap - 1)));
-            }
-        }
-        const int lo = int(e_len(o));
-        if (!lo || e_kind(o) != kBase) {
-            status = kBadSymbol;
-            break;
-        }
-        b.drop(lo);
-        const uint32_t dist = e_value(o) + b.take(int(e_extra(o)));
-        if (uint64_t(dist) > out_pos || dist == 0) {
-            status = kBadDistance;
-            break;
-        }
-        if (out_n - out_pos < uint64_t(length)) {
-            status = kOutputFull;
-            break;
-        }
-        sink.put(n, length | (dist << 9), out_pos);
-        ++n;
-        out_pos += length;
+// what a lane finds at its bit offset: info = bits the whole symbol takes (7) | output bytes << 7 (9) | kind << 16
+// (0 no code there, 1 literal, 3 match - bit 16 = "a symbol with output" -, 2 end of block); rec = the record
+struct LaneSym {
+    uint32_t info, rec;
+};
+
+// bits [sh, sh + 32) of the 64-bit value hi:lo, sh < 32 (one v_alignbit_b32 on the device)
+ATL_HD inline uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh) { return uint32_t(((uint64_t(hi) << 32) | lo) >> sh); }
+ATL_HD inline uint32_t low32(uint32_t v, uint32_t n) { return v & ((1u << n) - 1u); }  // n <= 16
+
+// the symbol that starts at bit 0 of the 64 stream bits bhi:blo (a symbol takes at most 15 + 5 + 15 + 13 = 48): the literal /
+// length code and its extra bits lie in blo (<= 20 bits), the distance code and its extra bits in the 28 bits behind them
+template <class M>
+ATL_HD inline LaneSym decode_at(const Areas<M> &A, uint32_t blo, uint32_t bhi) {
+    const LaneSym none{0u, 0u};
+    uint32_t e = M::ldv32(A.lit + low32(blo, kLitBits));
+    uint32_t used = 0;
+    if (e_kind(e) == kSub) {
+        used = kLitBits;
+        const uint32_t ix = e_value(e) + low32(blo >> kLitBits, e_extra(e));
+        e = M::ldv32(A.lit + (ix < uint32_t(kLitCap) ? ix : uint32_t(kLitCap - 1)));
     }
-    n_out = n;
+    const uint32_t l = e_len(e), kind = e_kind(e);
+    if (!l) return none;
+    used += l;
+    if (kind == kLiteral) return LaneSym{used | (1u << 7) | (1u << 16), kLitFlag | e_value(e)};
+    if (kind == kEnd) return LaneSym{used | (2u << 16), 0u};
+    if (kind != kBase) return none;  // a sub-table link inside a sub-table: never built
+    const uint32_t x = e_extra(e), length = e_value(e) + low32(blo >> used, x);
+    used += x;                                    // <= 20
+    const uint32_t b2 = funnel(bhi, blo, used);  // the 32 bits behind the length: distance code (<= 15) + extra (<= 13)
+    uint32_t o = M::ldv32(A.off + low32(b2, kOffBits));
+    uint32_t used2 = 0;
+    if (e_kind(o) == kSub) {
+        used2 = kOffBits;
+        const uint32_t ix = e_value(o) + low32(b2 >> kOffBits, e_extra(o));
+        o = M::ldv32(A.off + (ix < uint32_t(kOffCap) ? ix : uint32_t(kOffCap - 1)));
+    }
+    const uint32_t lo = e_len(o);
+    if (!lo || e_kind(o) != kBase) return none;
+    used2 += lo;
+    const uint32_t ox = e_extra(o), dist = e_value(o) + low32(b2 >> used2, ox);
+    used2 += ox;
+    return LaneSym{(used + used2) | (length << 7) | (3u << 16), length | (dist << 9)};
+}
+
+// where the window's words come from.  load(): the words under bit `bitpos` ... + 111 + 48 into A.wbuf, returns the bit
+// offset of `bitpos` inside A.wbuf[0].  (The device's loader keeps one window's worth of words in flight: atl_ingest.hip.)
+template <class M>
+struct HostWindow {
+    inline void reset() {}
+    inline uint32_t load(const Areas<M> &A, typename M::src_t w, uint32_t n_words, uint64_t bitpos) {
+        const uint32_t w0 = uint32_t(bitpos >> 5);
+        for (uint32_t j = 0; j < 6; ++j) M::st32(A.wbuf + j, w0 + j < n_words ? M::src(w, w0 + j) : 0u);
+        return uint32_t(bitpos & 31);
+    }
+};
+
+// Up to kQueue records -> A.qrec / A.qpos, window by window.  `bitpos`: where in the stream the next symbol starts (in / out).
+// Stops at the end of the block (*eob), when kQueue records are queued or the staging area (kStage output bytes) is full.
+#if defined(ATL_INF_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define ATL_INF_TICK(win, i, t0) ((win).ticks[i] += __builtin_readcyclecounter() - (t0), (t0) = __builtin_readcyclecounter())
+#define ATL_INF_T0() __builtin_readcyclecounter()
+#else
+#define ATL_INF_TICK(win, i, t0) ((void)0)
+#define ATL_INF_T0() 0ull
+#endif
+template <class M, class W, class Win>
+ATL_HD inline int decode_batch_wide(const Areas<M> &A, Win &win, typename M::src_t w, uint32_t n_words, uint64_t &bitpos,
+                                    uint64_t src_bits, uint64_t &out_pos, uint64_t out_n, int &n_out, bool &eob) {
+    const uint32_t bstart = uint32_t(out_pos);  // (chunks are < 2^31 bytes: 32-bit positions inside a batch)
+    uint32_t n = 0, rel_out = 0;                // records queued, output bytes of the batch so far
+    int status = kOk;
+    uint32_t stop = 0;  // 1 no code at a symbol start, 2 end of block, 3 queue / staging area full
+    eob = false;
+    for (;;) {
+        unsigned long long tk = ATL_INF_T0();
+        (void)tk;
+        const uint32_t o = win.load(A, w, n_words, bitpos);
+        W::sync();
+        ATL_INF_TICK(win, 0, tk);
+        typename W::template Var<uint32_t> info, rec;
+        W::each([&](int k) {
+            const uint32_t at = o + uint32_t(k), ix = at >> 5, sh = at & 31u;
+            const uint32_t w0 = M::ldv32(A.wbuf + ix), w1 = M::ldv32(A.wbuf + ix + 1), w2 = M::ldv32(A.wbuf + ix + 2);
+            const LaneSym sy = decode_at<M>(A, funnel(w1, w0, sh), funnel(w2, w1, sh));
+            info(k) = sy.info;
+            rec(k) = sy.rec;
+        });
+        // The chain of real symbol starts - offset 0, then each symbol's own length further - is the one serial step, and a
+        // scalar loop pays ~6 cycles per instruction: it only collects the mask of starts.  A lane without a code, or with the
+        // end-of-block code, ends the chain (jump 64); what fits into the queue and the staging area is decided in parallel
+        // afterwards, on prefix sums over the selected lanes.
+        ATL_INF_TICK(win, 1, tk);
+        typename W::template Var<uint32_t> jump;
+        W::each([&](int k) { jump(k) = ((info(k) >> 16) & 1u) ? (info(k) & 127u) : 64u; });
+        uint32_t s = 0;
+        uint64_t sel = 0;
+        do {
+            sel |= uint64_t(1) << s;
+            s += W::readlane(jump, int(s));
+        } while (s < 64u);
+        ATL_INF_TICK(win, 2, tk);
+        // output bytes before each selected symbol (exclusive prefix sum), its rank among the selected lanes, does it still fit
+        typename W::template Var<uint32_t> cum, miss;
+        W::each([&](int k) { cum(k) = (((sel >> k) & 1u) && ((info(k) >> 16) & 1u)) ? ((info(k) >> 7) & 511u) : 0u; });
+        uint32_t rel_add = W::excl_scan(cum);  // output bytes of the window's symbols (all of them, unless the batch ends inside)
+        typename W::template Var<uint32_t> rank;
+        W::each([&](int k) {
+            const bool selected = (sel >> k) & 1u, sym = (info(k) >> 16) & 1u;
+            const uint32_t olen = (info(k) >> 7) & 511u;
+            rank(k) = uint32_t(__builtin_popcountll(sel & ((uint64_t(1) << k) - 1u)));
+            const bool fits = sym && n + rank(k) < uint32_t(kQueue) && rel_out + cum(k) + olen <= uint32_t(kStage);
+            miss(k) = (selected && !fits) ? 1u : 0u;
+        });
+        const uint64_t missing = W::ballot(miss);  // the first of these ends the batch: end of block, no code, or no room
+        uint64_t keep = sel;
+        uint32_t consumed = s;
+        stop = 0u;
+        if (missing) {
+            const int c = __builtin_ctzll(missing);
+            const uint32_t inf = W::readlane(info, c);
+            keep = sel & ((uint64_t(1) << c) - 1u);
+            consumed = uint32_t(c);
+            rel_add = W::readlane(cum, c);
+            if ((inf >> 16) & 1u) {
+                stop = 3u;  // a symbol that does not fit any more: it opens the next batch
+            } else if ((inf >> 16) == 2u) {
+                stop = 2u;
+                consumed += inf & 127u;
+            } else {
+                stop = 1u;
+            }
+        }
+        // the kept lanes' records into the queue, in lane (= symbol) order; a distance must not reach before the output
+        typename W::template Var<uint32_t> bad;
+        W::each([&](int k) {
+            bad(k) = 0;
+            if ((keep >> k) & 1u) {
+                const uint32_t q = n + rank(k);  // (the lanes below a kept lane are all kept)
+                const uint32_t r = rec(k), p = bstart + rel_out + cum(k);
+                M::stv32(A.qrec + q, r);
+                M::stv32(A.qpos + q, p);
+                if (!(r & kLitFlag)) {
+                    const uint32_t dist = (r & 0x7FFFFFFFu) >> 9;
+                    if (dist == 0 || dist > p) bad(k) = 1;
+                }
+            }
+        });
+        n += uint32_t(__builtin_popcountll(keep));
+        rel_out += rel_add;
+        bitpos += consumed;
+        ATL_INF_TICK(win, 3, tk);
+        if (W::ballot(bad) != 0) status = kBadDistance;
+        else if (stop == 1u) status = kBadSymbol;
+        else if (uint64_t(bstart) + rel_out > out_n) status = kOutputFull;
+        else if (bitpos > src_bits) status = kInputOverrun;
+        if (status != kOk || stop != 0u) break;
+    }
+    W::sync();
+    eob = stop == 2u;
+    out_pos = uint64_t(bstart) + rel_out;
+    n_out = int(n);
     return status;
 }
 
@@ -421,18 +613,20 @@ ATL_HD inline bool zlib_header_ok(uint32_t first_word) {
 }
 
 // ---- a whole stream ---------------------------------------------------------------------------------------------------------
-// Sink: put(i, record, pos) (decode_batch), resolve(n, batch_start, batch_end): records 0 .. n-1 -> output bytes
+// Sink: resolve(n, batch_start, batch_end): the queued records 0 .. n-1 (A.qrec / A.qpos) -> output bytes
 // [batch_start, batch_end), stored(src_byte, len, out_pos): len input bytes -> output, tables_ready(): the tables written
 // by build_table are about to be read.  *adler_want = the stream's trailer (checked by the caller: k_adler on the device).
-template <class M, class Sink>
+template <class M, class W, class Win, class Sink>
 ATL_HD inline int inflate_stream(const Areas<M> &A, typename M::src_t w, uint32_t n_words, uint64_t src_n, uint64_t out_n, Sink &sink,
                                  uint32_t *adler_want) {
     if (src_n < 6 || n_words == 0) return kBadHeader;
     if (!zlib_header_ok(M::src(w, 0))) return kBadHeader;
     Bits<M> b;
     b.start(w, n_words, 16);
+    Win win;
     uint64_t out_pos = 0;
     const uint64_t src_bits = src_n * 8;
+    if (out_n >= (uint64_t(1) << 31)) return kOutputFull;  // 32-bit positions inside a batch
     bool final_block = false;
     while (!final_block) {
         b.refill();
@@ -456,26 +650,34 @@ ATL_HD inline int inflate_stream(const Areas<M> &A, typename M::src_t w, uint32_
         }
         int st;
         if (type == 1) {
-            st = fixed_tables<M>(A);
+            st = fixed_tables<M, W>(A);
         } else if (type == 2) {
             if (b.consumed() + 14 > src_bits) return kInputOverrun;
-            st = dynamic_tables<M>(A, b);
+            st = dynamic_tables<M, W>(A, b);
         } else {
             return kBadBlock;
         }
         if (st) return st;
         if (b.consumed() > src_bits) return kInputOverrun;
         sink.tables_ready();
+        uint64_t bitpos = b.consumed();
         bool eob = false;
+        win.reset();
         while (!eob) {
             int n = 0;
             const uint64_t bstart = out_pos;
-            st = decode_batch<M, Sink>(A, b, out_pos, out_n, sink, n, eob);
+            st = decode_batch_wide<M, W, Win>(A, win, w, n_words, bitpos, src_bits, out_pos, out_n, n, eob);
             if (st) return st;
-            if (b.consumed() > src_bits) return kInputOverrun;
+            if (bitpos > src_bits) return kInputOverrun;
             sink.resolve(n, bstart, out_pos);
         }
+        b.start(w, n_words, bitpos);
     }
+#if defined(ATL_INF_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        printf("[decode 0] windows %u | cycles: window words %llu, lookups %llu, chain %llu, queue %llu\n", win.windows, win.ticks[0],
+               win.ticks[1], win.ticks[2], win.ticks[3]);
+#endif
     if (out_pos != out_n) return kShort;
     b.drop(int((8 - (b.consumed() & 7)) & 7));  // trailer: Adler-32 of the output, big-endian
     uint32_t want = 0;

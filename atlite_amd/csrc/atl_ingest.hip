@@ -248,6 +248,10 @@ struct WaveMem {
     static __device__ __forceinline__ void st32(u32p p, uint32_t v) { *p = v; }
     static __device__ __forceinline__ void st8(u8p p, uint32_t v) { *p = uint8_t(v); }
     static __device__ __forceinline__ uint32_t src(src_t w, uint32_t i) { return w[__builtin_amdgcn_readfirstlane(i)]; }
+    static __device__ __forceinline__ uint32_t ldv32(u32p p) { return *p; }  // per-lane addresses: an LDS gather / scatter
+    static __device__ __forceinline__ void stv32(u32p p, uint32_t v) { *p = v; }
+    static __device__ __forceinline__ uint32_t ldv8(u8p p) { return *p; }
+    static __device__ __forceinline__ void stv8(u8p p, uint32_t v) { *p = uint8_t(v); }
     static __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
     static __device__ __forceinline__ int uni(int v) { return int(__builtin_amdgcn_readfirstlane(uint32_t(v))); }
     static __device__ __forceinline__ uint64_t uni(uint64_t v) {
@@ -255,21 +259,93 @@ struct WaveMem {
     }
 };
 
+// the wavefront as decode_batch_wide sees it: a per-lane variable is a register, a per-lane step runs once
+struct DevWave {
+    template <class T>
+    struct Var {
+        T v;
+        __device__ __forceinline__ T &operator()(int) { return v; }
+    };
+    template <class F>
+    static __device__ __forceinline__ void each(F &&f) {
+        f(int(threadIdx.x));
+    }
+    static __device__ __forceinline__ uint32_t readlane(Var<uint32_t> &x, int lane) { return __builtin_amdgcn_readlane(x.v, lane); }
+    static __device__ __forceinline__ uint64_t ballot(Var<uint32_t> &x) { return __ballot(x.v != 0); }
+    // x <- sum of x over the lanes below; returns the wave's total.  Four DPP row shifts scan the rows of 16, the rows'
+    // totals come over as scalars
+    static __device__ __forceinline__ uint32_t excl_scan(Var<uint32_t> &x) {
+        const uint32_t v0 = x.v;
+        uint32_t v = v0;
+        v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xF, 0xF, false));  // row_shr:1
+        v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xF, 0xF, false));  // row_shr:2
+        v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xF, 0xF, false));  // row_shr:4
+        v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xF, 0xF, false));  // row_shr:8
+        const uint32_t r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47),
+                       r3 = __builtin_amdgcn_readlane(v, 63);
+        const uint32_t row = threadIdx.x >> 4;
+        const uint32_t before = row == 0 ? 0u : row == 1 ? r0 : row == 2 ? r0 + r1 : r0 + r1 + r2;
+        x.v = v + before - v0;
+        return r0 + r1 + r2 + r3;
+    }
+    // one wavefront per workgroup: its LDS operations execute in order, so lanes see each other's LDS writes without a barrier;
+    // what is needed is that the COMPILER keeps the order (a __syncthreads would also wait for every load and store in flight -
+    // the window prefetch among them)
+    static __device__ __forceinline__ void sync() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
+// The words under decode_batch_wide's window, one window ahead: lanes 0 .. 11 hold the twelve words from the PREVIOUS
+// window's first word on (the next window starts at most 111 bits later, and reaches at most 63 + 48 bits beyond its start:
+// eight words in), loaded while the previous window was decoded; the load for the next window is issued before this one's
+// words are needed.  One exposed memory latency per deflate block instead of one per window.
+struct DevWindow {
+    uint32_t cur = 0, cw0 = 0;
+    bool primed = false;
+#ifdef ATL_INF_PROFILE
+    unsigned long long ticks[4] = {0, 0, 0, 0};
+    unsigned windows = 0;
+#endif
+    __device__ __forceinline__ void reset() { primed = false; }
+    __device__ __forceinline__ uint32_t load(const dinf::Areas<WaveMem> &A, WaveMem::src_t w, uint32_t n_words, uint64_t bitpos) {
+        const uint32_t lane = threadIdx.x, nw0 = uint32_t(bitpos >> 5);
+        const uint32_t *gw = (const uint32_t *)w;
+#ifdef ATL_INF_PROFILE
+        ++windows;
+#endif
+        const bool mine = lane < 12u && nw0 + lane < n_words;
+        if (!primed) {
+            cur = mine ? gw[nw0 + lane] : 0u;
+            cw0 = nw0;
+            primed = true;
+        }
+        const uint32_t pre = mine ? gw[nw0 + lane] : 0u;
+        if (lane < 12u) A.wbuf[lane] = cur;
+        const uint32_t rel = uint32_t(bitpos - uint64_t(cw0) * 32u);
+        cur = pre;
+        cw0 = nw0;
+        return rel;
+    }
+};
+
 // The parallel half: lane i owns record i of a batch.  Output bytes of the batch are assembled in the LDS staging area
 // (sources inside the batch are LDS reads, sources before it are this wave's own earlier output in HBM) and flushed.
+#ifdef ATL_INF_PROFILE
+#define ATL_PROF(x) x
+#else
+#define ATL_PROF(x)
+#endif
 struct WaveSink {
-    uint32_t rec = 0, pos = 0;  // this lane's record of the current batch
+    WaveMem::u32p qrec, qpos;   // the batch's records (decode_batch_wide)
+    ATL_PROF(unsigned long long t_p1 = 0; unsigned long long t_coop = 0; unsigned long long t_flush = 0; unsigned long long t_fence = 0;
+             unsigned long long t_res0 = 0; unsigned long long t_res_total = 0; unsigned n_batches = 0; unsigned n_syms = 0; unsigned n_coop = 0;
+             unsigned n_far = 0; unsigned n_short = 0; unsigned n_lit = 0;)
     WaveMem::u8p stage;         // [kStage + 3], word aligned
     const uint8_t *src8;        // the stream's bytes (stored blocks)
     uint8_t *dst;               // the chunk's output
-    __device__ __forceinline__ void put(int i, uint32_t r, uint64_t p) {
-        // selects, not a branch: a lane-dependent branch inside the symbol loop makes the compiler treat the loop's whole
-        // state as divergent (VGPRs + exec-mask branches instead of SGPRs + scalar branches)
-        const bool mine = int(threadIdx.x) == i;
-        rec = mine ? r : rec;
-        pos = mine ? uint32_t(p) : pos;
-    }
-    __device__ __forceinline__ void tables_ready() { __syncthreads(); }
+    __device__ __forceinline__ void tables_ready() { DevWave::sync(); }
     __device__ void stored(uint64_t byte_pos, uint32_t len, uint64_t out_pos) {
         for (uint32_t j = threadIdx.x; j < len; j += 64) dst[out_pos + j] = src8[byte_pos + j];
         __threadfence_block();
@@ -277,9 +353,11 @@ struct WaveSink {
     __device__ void resolve(int n, uint64_t bstart, uint64_t bend) {
         const uint32_t lane = threadIdx.x;
         const uint32_t bs = uint32_t(bstart), total = uint32_t(bend - bstart);
+        ATL_PROF(const unsigned long long c0 = __builtin_readcyclecounter(); ++n_batches; n_syms += unsigned(n);)
         // the staging area starts (bs & 3) bytes in, so that its aligned words are the output's aligned words (the flush)
         WaveMem::u8p st = stage + (bs & 3u);
         const bool active = int(lane) < n;
+        const uint32_t rec = active ? qrec[lane] : 0u, pos = active ? qpos[lane] : 0u;  // this lane's record
         const bool lit = (rec & dinf::kLitFlag) != 0;
         const uint32_t len = rec & 0x1FFu, dist = (rec & 0x7FFFFFFFu) >> 9;
         const uint32_t rel = pos - bs;
@@ -295,19 +373,23 @@ struct WaveSink {
             }
         }
         uint64_t todo = __ballot(coop);
-        __syncthreads();
+        DevWave::sync();
+        ATL_PROF(const unsigned long long c1 = __builtin_readcyclecounter(); t_p1 += c1 - c0; n_coop += unsigned(__popcll(todo));
+                 n_lit += unsigned(__popcll(__ballot(active && lit))); n_short += unsigned(__popcll(__ballot(active && !lit && !coop)));)
         while (todo) {  // in symbol order; every source byte of a match precedes the match
             const int i = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
             const uint32_t r = __builtin_amdgcn_readlane(rec, i), p = __builtin_amdgcn_readlane(pos, i);
             const uint32_t L = r & 0x1FFu, D = (r & 0x7FFFFFFFu) >> 9, R = p - bs;
+            ATL_PROF(if (p - D < bs) ++n_far;)
             for (uint32_t j = lane; j < L; j += 64) {
                 const uint32_t k = D >= L ? j : j % D;  // an overlapping match repeats its first D bytes
                 const uint32_t sp = p - D + k;
                 st[R + j] = sp >= bs ? st[sp - bs] : dst[sp];
             }
-            __syncthreads();
+            DevWave::sync();
         }
+        ATL_PROF(const unsigned long long c2 = __builtin_readcyclecounter(); t_coop += c2 - c1;)
         // flush: the unaligned head and tail byte by byte, the words in between as words
         const uint32_t head = min((4u - (bs & 3u)) & 3u, total), words = (total - head) >> 2, tail0 = head + 4u * words;
         if (lane < head) dst[bs + lane] = st[lane];
@@ -317,8 +399,10 @@ struct WaveSink {
             uint32_t *dw = reinterpret_cast<uint32_t *>(dst + bs + head);
             for (uint32_t k = lane; k < words; k += 64) dw[k] = sw[k];
         }
+        ATL_PROF(const unsigned long long c3 = __builtin_readcyclecounter(); t_flush += c3 - c2;)
         __threadfence_block();  // later batches read these bytes back
-        __syncthreads();
+        DevWave::sync();
+        ATL_PROF(const unsigned long long c4 = __builtin_readcyclecounter(); t_fence += c4 - c3; t_res_total += c4 - c0;)
     }
 };
 
@@ -330,8 +414,10 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
     __shared__ uint32_t s_tmp[320 + 256];  // codes | sub_bits while a table is built; the staging area while symbols are decoded
     __shared__ uint32_t s_cnt[32];
     __shared__ uint32_t s_lens[128];
+    __shared__ uint32_t s_q[2 * kQueue + 1 + 16];  // records | positions (+ 1) | window words
     static_assert(sizeof(s_tmp) >= size_t(kStage), "staging area");
     const InfDesc d = desc[blockIdx.x];
+    ATL_PROF(const unsigned long long t_start = __builtin_readcyclecounter();)
     Areas<WaveMem> A;
     A.lit = (WaveMem::u32p)s_lit;
     A.off = (WaveMem::u32p)s_off;
@@ -340,17 +426,28 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
     A.cnt = (WaveMem::u32p)s_cnt;
     A.nxt = (WaveMem::u32p)(s_cnt + 16);
     A.lens = (WaveMem::u8p)s_lens;
+    A.qrec = (WaveMem::u32p)s_q;
+    A.qpos = (WaveMem::u32p)(s_q + kQueue);
+    A.wbuf = (WaveMem::u32p)(s_q + 2 * kQueue + 1);
     WaveSink sink;
+    sink.qrec = A.qrec;
+    sink.qpos = A.qpos;
     sink.stage = (WaveMem::u8p)s_tmp;
     sink.src8 = comp + d.src_off;
     sink.dst = raw + d.dst_off;
     uint32_t want = 0;
-    const int st = inflate_stream<WaveMem, WaveSink>(A, (WaveMem::src_t)(comp + d.src_off), uint32_t((d.src_n + 3) / 4),
+    const int st = inflate_stream<WaveMem, DevWave, DevWindow, WaveSink>(A, (WaveMem::src_t)(comp + d.src_off), uint32_t((d.src_n + 3) / 4),
                                                      uint64_t(d.src_n), uint64_t(d.dst_n), sink, &want);
     if (threadIdx.x == 0) {
         res[blockIdx.x].status = st;
         res[blockIdx.x].adler_want = want;
     }
+    ATL_PROF(if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) {
+        const unsigned long long total = __builtin_readcyclecounter() - t_start;
+        printf("[k_inflate %u/%u] out %lld B in %lld B: cycles total %llu | resolve %llu (p1 %llu coop %llu flush %llu fence %llu) | batches %u syms %u lit %u short %u coop %u (far %u)\n",
+               blockIdx.x, gridDim.x, (long long)d.dst_n, (long long)d.src_n, total, sink.t_res_total, sink.t_p1, sink.t_coop, sink.t_flush, sink.t_fence,
+               sink.n_batches, sink.n_syms, sink.n_lit, sink.n_short, sink.n_coop, sink.n_far);
+    })
 }
 
 // Adler-32 of every inflated chunk against its stream's trailer: s1 = 1 + sum b_i, s2 = n + sum (n - i) b_i (mod 65521);
@@ -401,17 +498,23 @@ __global__ __launch_bounds__(256) void k_adler(const uint8_t *__restrict__ raw, 
 
 // ---- per-context staging: kSlots slots, each {pinned host, device raw, descriptor buffers, event, stream} -------------
 // a read whose chunks were inflated on the device and whose verdicts (InfResult) have not been looked at yet
-struct Pending {
-    bool active = false;
-    atl_nc *nc = nullptr;
+struct Part {  // one variable of a read
     const Dataset *ds = nullptr;
-    std::vector<size_t> lin;         // stream -> linear chunk index
-    std::vector<uint32_t> desc_of;   // stream -> index of its UnpackDesc
-    std::vector<InfDesc> inf;
     UnpackParams p{};
     double *d_out = nullptr;
     int64_t chunk_bytes = 0, max_elems = 0;
-    size_t off_inf = 0, off_unp = 0, off_res = 0, n_desc = 0;
+    size_t desc0 = 0, n_desc = 0;  // its UnpackDesc run
+};
+
+struct Pending {
+    bool active = false;
+    atl_nc *nc = nullptr;
+    std::vector<Part> parts;
+    std::vector<uint32_t> part_of;   // stream -> part
+    std::vector<size_t> lin;         // stream -> linear chunk index (in its variable)
+    std::vector<uint32_t> desc_of;   // stream -> index of its UnpackDesc (global)
+    std::vector<InfDesc> inf;
+    size_t off_inf = 0, off_unp = 0, off_res = 0;
 };
 
 struct Slot {
@@ -445,6 +548,8 @@ std::mutex g_states_m;
 std::vector<IngestState *> g_states;
 
 int finish_slot(atl_ctx *ctx, IngestState *st, Slot &sl);
+int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *names, int64_t start0, int64_t count0, double *const *d_outs,
+                      int n_threads, bool *done);
 
 void ingest_free(void *p) {
     IngestState *s = static_cast<IngestState *>(p);
@@ -719,7 +824,8 @@ bool device_inflate_wanted(size_t n_streams) {
     const char *e = getenv("ATLITE_HIP_INFLATE");
     if (e && strcmp(e, "device") == 0) return n_streams > 0;
     if (e && *e) return false;  // "host", "zlib"
-    size_t min_chunks = 192;    // below that the host threads finish first: a stream is one wave, tens of MB/s (up to kSlots reads overlap)
+    size_t min_chunks = 1024;   // below that the host threads finish first: a stream is one wavefront at ~10 MB/s, so a read costs
+                                // ~0.1 s however few streams it has; 16 host threads inflate ~1000 chunks of 1 MB in that time
     if (const char *m = getenv("ATLITE_HIP_INFLATE_MIN_CHUNKS")) min_chunks = size_t(std::max(1, atoi(m)));
     return n_streams >= min_chunks;
 }
@@ -736,7 +842,7 @@ void launch_unpack(hipStream_t st, const uint8_t *raw, const UnpackDesc *d_desc,
 // Everything of a device-inflate read is enqueued on the slot's stream; the copy stream waits for it.  The verdicts come
 // back with the last copy and are read by finish_slot: at the slot's next use, when the copy stream is observed
 // (atl_event_record on it), when the file is closed, when the context goes.
-int submit_device(atl_ctx *ctx, Slot *sl, size_t h2d_bytes, double *d_out) {
+int submit_device(atl_ctx *ctx, Slot *sl, size_t h2d_bytes) {
     hipStream_t cs;
     int rc = copy_stream_of(ctx, &cs);
     if (rc) return rc;
@@ -748,7 +854,7 @@ int submit_device(atl_ctx *ctx, Slot *sl, size_t h2d_bytes, double *d_out) {
     if (!sl->ev_fork[0]) ATL_HIP_TRY(hipEventCreateWithFlags(&sl->ev_fork[0], hipEventDisableTiming));
     ATL_HIP_TRY(hipEventRecord(sl->ev_fork[0], cs));
     ATL_HIP_TRY(hipStreamWaitEvent(sl->st, sl->ev_fork[0], 0));
-    const size_t n = job.inf.size(), n_desc = job.n_desc;
+    const size_t n = job.inf.size();
     for (hipEvent_t &e : sl->ev_t)
         if (!e) ATL_HIP_TRY(hipEventCreate(&e));
     ATL_HIP_TRY(hipEventRecord(sl->ev_t[0], sl->st));
@@ -756,13 +862,12 @@ int submit_device(atl_ctx *ctx, Slot *sl, size_t h2d_bytes, double *d_out) {
     ATL_HIP_TRY(hipEventRecord(sl->ev_t[1], sl->st));
     const InfDesc *d_inf = reinterpret_cast<const InfDesc *>(sl->d + job.off_inf);
     InfResult *d_res = reinterpret_cast<InfResult *>(sl->d + job.off_res);
-    if (n) {
-        hipLaunchKernelGGL(k_inflate, dim3(unsigned(n)), dim3(64), 0, sl->st, sl->d, d_inf, sl->d_raw, d_res);
-    }
+    if (n) hipLaunchKernelGGL(k_inflate, dim3(unsigned(n)), dim3(64), 0, sl->st, sl->d, d_inf, sl->d_raw, d_res);
     ATL_HIP_TRY(hipEventRecord(sl->ev_t[2], sl->st));
     if (n) hipLaunchKernelGGL(k_adler, dim3(unsigned(n)), dim3(256), 0, sl->st, sl->d_raw, d_inf, d_res);
     ATL_HIP_TRY(hipEventRecord(sl->ev_t[3], sl->st));
-    launch_unpack(sl->st, sl->d_raw, reinterpret_cast<const UnpackDesc *>(sl->d + job.off_unp), n_desc, job.p, job.max_elems, d_out);
+    const UnpackDesc *d_unp = reinterpret_cast<const UnpackDesc *>(sl->d + job.off_unp);
+    for (const Part &pt : job.parts) launch_unpack(sl->st, sl->d_raw, d_unp + pt.desc0, pt.n_desc, pt.p, pt.max_elems, pt.d_out);
     ATL_HIP_TRY(hipEventRecord(sl->ev_t[4], sl->st));
     ATL_HIP_TRY(hipGetLastError());
     if (n) ATL_HIP_TRY(hipMemcpyAsync(sl->h + job.off_res, d_res, n * sizeof(InfResult), hipMemcpyDeviceToHost, sl->st));
@@ -801,15 +906,17 @@ int finish_slot(atl_ctx *ctx, IngestState *st, Slot &sl) {
     // streams the device decoder did not accept (corrupt, or a shape of code it declines): the host decoders decide, the chunk
     // is decoded again from their output; a stream they reject too is the caller's error, as on the host path
     ATL_HIP_TRY(hipSetDevice(ctx->device));
-    std::vector<uint8_t> tmp(size_t(job.chunk_bytes));
+    std::vector<uint8_t> tmp;
     const UnpackDesc *d_unp = reinterpret_cast<const UnpackDesc *>(sl.d + job.off_unp);
     for (size_t i : bad) {
+        const Part &pt = job.parts[job.part_of[i]];
+        tmp.resize(size_t(pt.chunk_bytes));
         bool shuffled = false;
-        const h5::Chunk &c = job.ds->chunks[job.lin[i]];
-        const int e = h5::chunk_inflate(*job.ds, c, job.nc->file.base(), -1, tmp.data(), uint64_t(job.chunk_bytes), &shuffled);
+        const h5::Chunk &c = pt.ds->chunks[job.lin[i]];
+        const int e = h5::chunk_inflate(*pt.ds, c, job.nc->file.base(), -1, tmp.data(), uint64_t(pt.chunk_bytes), &shuffled);
         if (e) return e;
-        ATL_HIP_TRY(hipMemcpy(sl.d_raw + job.inf[i].dst_off, tmp.data(), size_t(job.chunk_bytes), hipMemcpyHostToDevice));
-        launch_unpack(sl.st, sl.d_raw, d_unp + job.desc_of[i], 1, job.p, job.max_elems, job.d_out);
+        ATL_HIP_TRY(hipMemcpy(sl.d_raw + job.inf[i].dst_off, tmp.data(), size_t(pt.chunk_bytes), hipMemcpyHostToDevice));
+        launch_unpack(sl.st, sl.d_raw, d_unp + job.desc_of[i], 1, pt.p, pt.max_elems, pt.d_out);
         ATL_HIP_TRY(hipGetLastError());
         ++st->n_redone;
     }
@@ -825,6 +932,135 @@ int copy_text(const std::string &s, char *buf, int64_t buflen, int64_t *needed) 
         buf[n] = '\0';
     }
     return ATL_OK;
+}
+
+}  // namespace
+
+namespace {
+
+// geometry + decoding + the (rows x cells) block's row stride of one variable of a read
+int part_setup(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, int64_t count0, const char *who, const Dataset **d_out,
+               Geometry *g, UnpackParams *p) {
+    const Dataset *d;
+    int rc = lookup(f, name, &d, who);
+    if (rc) return rc;
+    rc = geometry_of(*d, g, who);
+    if (rc) return rc;
+    ATL_REQUIRE(start0 >= 0 && count0 >= 0 && start0 + count0 <= g->shape[0], "%s: rows [%lld, %lld) outside '%s' (%lld rows)", who,
+                (long long)start0, (long long)(start0 + count0), name, (long long)g->shape[0]);
+    *p = UnpackParams{};
+    p->shape1 = g->shape[1];
+    p->shape2 = g->shape[2];
+    p->ld = g->shape[1] * g->shape[2];
+    if (ctx->slot_stride > 0 && d->shape.size() == 3) {
+        ATL_REQUIRE(ctx->slot_stride >= p->ld, "%s: slot stride %lld is smaller than a row of %lld cells", who,
+                    (long long)ctx->slot_stride, (long long)p->ld);
+        p->ld = ctx->slot_stride;
+    }
+    p->r0 = start0;
+    p->r1 = start0 + count0;
+    p->dec = decode_of(f->file, *d);
+    *d_out = d;
+    return ATL_OK;
+}
+
+// The device-inflate path for the rows [start0, start0 + count0) of n_vars variables at once: ONE k_inflate launch over every
+// chunk stream of the group (the machine holds ~3600 streams at a time; launches from different HIP streams are not a way to
+// get there - the runtime multiplexes its streams onto four hardware queues and a queue runs its kernels one after the other).
+// *done = false: not every stored chunk is a plain zlib stream, or too few of them - the caller reads variable by variable.
+int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *names, int64_t start0, int64_t count0, double *const *d_outs,
+                      int n_threads, bool *done) {
+    *done = false;
+    if (count0 == 0) return ATL_OK;
+    std::vector<Part> parts;
+    std::vector<UnpackDesc> descs;
+    std::vector<InfDesc> inf;
+    std::vector<size_t> lin;
+    std::vector<uint32_t> part_of, desc_of;
+    size_t raw_off = 0, comp_off = 0;
+    for (int v = 0; v < n_vars; ++v) {
+        const Dataset *d;
+        Geometry g;
+        Part pt;
+        int rc = part_setup(ctx, f, names[v], start0, count0, "atl_nc_read_slabs", &d, &g, &pt.p);
+        if (rc) return rc;
+        if (g.row_elems == 0) continue;
+        ATL_REQUIRE(d_outs[v], "atl_nc_read_slabs: d_out of '%s' is NULL", names[v]);
+        if (d->layout != 2) return ATL_OK;  // compact / contiguous: the host path
+        const int64_t chunk_bytes = g.chunk_elems * pt.p.dec.esize;
+        if (chunk_bytes > (int64_t(64) << 20)) return ATL_OK;
+        Selection sel;
+        select_chunks(g, pt.p.r0, pt.p.r1, chunk_bytes, &sel);
+        pt.ds = d;
+        pt.d_out = d_outs[v];
+        pt.chunk_bytes = chunk_bytes;
+        pt.max_elems = g.chunk_elems;
+        pt.desc0 = descs.size();
+        pt.n_desc = sel.desc.size();
+        for (size_t i = 0; i < sel.lin.size(); ++i) {
+            const h5::Chunk &c = d->chunks[sel.lin[i]];
+            UnpackDesc ds = sel.desc[i];
+            ds.src_off = int64_t(raw_off);  // where the chunk's inflated bytes go in the slot's raw buffer
+            raw_off += align_up(size_t(chunk_bytes), 16);
+            if (c.size == 0) {
+                ds.missing = 1;
+            } else {
+                uint64_t pay = 0;
+                bool defl = false, shuf = false;
+                if (h5::chunk_filters(*d, c, &pay, &defl, &shuf) != ATL_OK || !defl || pay < 6 || c.addr > f->file.size() ||
+                    c.size > f->file.size() - c.addr)
+                    return ATL_OK;
+                ds.shuffled = shuf;
+                inf.push_back(InfDesc{int64_t(comp_off), int64_t(pay), ds.src_off, chunk_bytes});
+                comp_off += align_up(size_t(pay) + 8, 16);
+                lin.push_back(sel.lin[i]);
+                part_of.push_back(uint32_t(parts.size()));
+                desc_of.push_back(uint32_t(descs.size()));
+            }
+            descs.push_back(ds);
+        }
+        parts.push_back(pt);
+    }
+    if (parts.empty() || !device_inflate_wanted(inf.size())) return ATL_OK;
+    // staging: streams (16-byte aligned, whole words) | InfDesc[] | UnpackDesc[] ; behind them, device -> host: InfResult[]
+    const size_t off_inf = align_up(comp_off, 256), off_unp = align_up(off_inf + inf.size() * sizeof(InfDesc), 256);
+    const size_t off_res = align_up(off_unp + descs.size() * sizeof(UnpackDesc), 256);
+    Slot *sl = nullptr;
+    int rc = slot_acquire(ctx, off_res + inf.size() * sizeof(InfResult) + 256, &sl, raw_off + 256);
+    if (rc) return rc;
+    const int fd = f->file.fd();
+    const uint8_t *base = f->file.base();
+    const auto t_gather = std::chrono::steady_clock::now();
+    rc = parallel_for(inf.size(), pick_threads(n_threads, inf.size()), [&](size_t i) -> int {
+        const h5::Chunk &c = parts[part_of[i]].ds->chunks[lin[i]];
+        uint8_t *dst = sl->h + inf[i].src_off;
+        const uint64_t n = uint64_t(inf[i].src_n);
+        uint64_t got = 0;
+        while (fd >= 0 && got < n) {  // straight into the pinned staging (a mapping's page faults contend across threads)
+            const ssize_t r = pread(fd, dst + got, size_t(n - got), off_t(c.addr + got));
+            if (r <= 0) break;
+            got += uint64_t(r);
+        }
+        if (got < n) memcpy(dst + got, base + c.addr + got, size_t(n - got));
+        memset(dst + n, 0, size_t(align_up(size_t(n) + 8, 16) - n));  // the bit reader's look-ahead words
+        return ATL_OK;
+    });
+    if (rc) return rc;
+    state_of(ctx)->ms[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_gather).count();
+    if (!inf.empty()) memcpy(sl->h + off_inf, inf.data(), inf.size() * sizeof(InfDesc));
+    memcpy(sl->h + off_unp, descs.data(), descs.size() * sizeof(UnpackDesc));
+    Pending &job = sl->job;
+    job.nc = f;
+    job.parts = std::move(parts);
+    job.part_of = std::move(part_of);
+    job.lin = std::move(lin);
+    job.desc_of = std::move(desc_of);
+    job.inf = std::move(inf);
+    job.off_inf = off_inf;
+    job.off_unp = off_unp;
+    job.off_res = off_res;
+    *done = true;
+    return submit_device(ctx, sl, off_unp + descs.size() * sizeof(UnpackDesc));
 }
 
 }  // namespace
@@ -1144,79 +1380,13 @@ int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, 
         select_chunks(g, r0, r1, chunk_bytes, &sel);
         payload = sel.desc.size() * align_up(size_t(chunk_bytes), 16);
         max_elems = g.chunk_elems;
-        // ---- chunks inflated on the device: every stored chunk of the selection is a zlib stream -----------------------
-        size_t n_streams = 0;
-        bool all_deflate = chunk_bytes <= (int64_t(64) << 20);
-        std::vector<uint64_t> pay(sel.lin.size(), 0);
-        for (size_t i = 0; i < sel.lin.size() && all_deflate; ++i) {
-            const h5::Chunk &c = d->chunks[sel.lin[i]];
-            if (c.size == 0) continue;
-            bool defl = false, shuf = false;
-            if (h5::chunk_filters(*d, c, &pay[i], &defl, &shuf) != ATL_OK || !defl || pay[i] < 6 || c.addr > f->file.size() ||
-                c.size > f->file.size() - c.addr) {
-                all_deflate = false;
-                break;
-            }
-            sel.desc[i].shuffled = shuf;
-            ++n_streams;
-        }
-        if (all_deflate && device_inflate_wanted(n_streams)) {
-            // staging: streams (16-byte aligned, whole words) | InfDesc[] | UnpackDesc[] ; behind them, device -> host: InfResult[]
-            std::vector<InfDesc> inf;
-            std::vector<size_t> lin;
-            std::vector<uint32_t> desc_of;
-            inf.reserve(n_streams);
-            size_t off = 0;
-            for (size_t i = 0; i < sel.lin.size(); ++i) {
-                if (d->chunks[sel.lin[i]].size == 0) {
-                    sel.desc[i].missing = 1;
-                    continue;
-                }
-                inf.push_back(InfDesc{int64_t(off), int64_t(pay[i]), sel.desc[i].src_off, chunk_bytes});
-                lin.push_back(sel.lin[i]);
-                desc_of.push_back(uint32_t(i));
-                off += align_up(size_t(pay[i]) + 8, 16);
-            }
-            const size_t off_inf = align_up(off, 256), off_unp = align_up(off_inf + inf.size() * sizeof(InfDesc), 256);
-            const size_t off_res = align_up(off_unp + sel.desc.size() * sizeof(UnpackDesc), 256);
-            rc = slot_acquire(ctx, off_res + inf.size() * sizeof(InfResult) + 256, &sl, payload + 256);
-            if (rc) return rc;
-            const int fd = f->file.fd();
-            const uint8_t *base = f->file.base();
-            const auto t_gather = std::chrono::steady_clock::now();
-            rc = parallel_for(inf.size(), pick_threads(n_threads, inf.size()), [&](size_t i) -> int {
-                const h5::Chunk &c = d->chunks[lin[i]];
-                uint8_t *dst = sl->h + inf[i].src_off;
-                const uint64_t n = uint64_t(inf[i].src_n);
-                uint64_t got = 0;
-                while (fd >= 0 && got < n) {  // straight into the pinned staging (a mapping's page faults contend across threads)
-                    const ssize_t r = pread(fd, dst + got, size_t(n - got), off_t(c.addr + got));
-                    if (r <= 0) break;
-                    got += uint64_t(r);
-                }
-                if (got < n) memcpy(dst + got, base + c.addr + got, size_t(n - got));
-                memset(dst + n, 0, size_t(align_up(size_t(n) + 8, 16) - n));  // the bit reader's look-ahead words
-                return ATL_OK;
-            });
-            if (rc) return rc;
-            state_of(ctx)->ms[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_gather).count();
-            if (!inf.empty()) memcpy(sl->h + off_inf, inf.data(), inf.size() * sizeof(InfDesc));
-            memcpy(sl->h + off_unp, sel.desc.data(), sel.desc.size() * sizeof(UnpackDesc));
-            Pending &job = sl->job;
-            job.nc = f;
-            job.ds = d;
-            job.lin = std::move(lin);
-            job.desc_of = std::move(desc_of);
-            job.inf = std::move(inf);
-            job.p = p;
-            job.d_out = d_out;
-            job.chunk_bytes = chunk_bytes;
-            job.max_elems = max_elems;
-            job.off_inf = off_inf;
-            job.off_unp = off_unp;
-            job.off_res = off_res;
-            job.n_desc = sel.desc.size();
-            return submit_device(ctx, sl, off_unp + sel.desc.size() * sizeof(UnpackDesc), d_out);
+        // ---- chunks inflated on the device: every stored chunk of the selection is a zlib stream (read_group_device) ------------
+        {
+            const char *one[1] = {name};
+            double *outs[1] = {d_out};
+            bool done = false;
+            rc = read_group_device(ctx, f, 1, one, start0, count0, outs, n_threads, &done);
+            if (rc || done) return rc;
         }
         for (UnpackDesc &ds : sel.desc) ds.shuffled = 0;
         rc = slot_acquire(ctx, align_up(payload, 256) + sel.desc.size() * sizeof(UnpackDesc), &sl);
@@ -1237,6 +1407,20 @@ int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, 
         if (rc) return rc;
     }
     return submit(ctx, sl, payload, sel.desc, p, max_elems, d_out);
+}
+
+int atl_nc_read_slabs(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *names, int64_t start0, int64_t count0, double *const *d_outs,
+                      int n_threads) {
+    ATL_REQUIRE(ctx && f && n_vars >= 0 && (n_vars == 0 || (names && d_outs)), "atl_nc_read_slabs: bad argument");
+    if (n_vars == 0) return ATL_OK;
+    bool done = false;
+    int rc = n_vars > 1 ? read_group_device(ctx, f, n_vars, names, start0, count0, d_outs, n_threads, &done) : ATL_OK;
+    if (rc || done) return rc;
+    for (int v = 0; v < n_vars; ++v) {  // variable by variable (each decides for itself: device or host threads)
+        rc = atl_nc_read_slab(ctx, f, names[v], start0, count0, d_outs[v], n_threads);
+        if (rc) return rc;
+    }
+    return ATL_OK;
 }
 
 int atl_inflate_probe(const void *h_src, size_t src_n, void *h_dst, size_t dst_n, int which, int64_t *ns) {

@@ -132,58 +132,10 @@ __global__ __launch_bounds__(256) void k_cells_series_flat(Conv conv, int64_t S,
     st2<true>(out, slot * S + c0, v0, v1, r);
 }
 
-// The same walk by a PERSISTENT grid (round 5, $ATLITE_HIP_SERIES_PERSIST=1): n_CU x 8 blocks take the (slot, chunk) units b,
-// b + G, b + 2 G, ... - the grid as a whole still sweeps every stream front to back - and build the converter's LDS tables
-// (the wind law's 93 divisions + logarithms) ONCE per block instead of once per 512 cells; the next unit's loads are issued
-// before the current one is converted.
-template <class Conv>
-__global__ __launch_bounds__(256) void k_cells_series_flat_persist(Conv conv, int64_t S, uint32_t n_chunks, uint64_t n_units,
-                                                                   double *__restrict__ out, int32_t shift) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    conv.block_init(lds);
-    __syncthreads();
-    typename Conv::Carry carry = carry_init<typename Conv::Carry>();
-    auto place = [&](uint64_t b, int64_t &slot, int64_t &c0, bool &v0, bool &v1, int64_t &s0c, int64_t &s1c) {
-        const uint64_t slot_u = b / n_chunks;
-        slot = int64_t(slot_u);
-        const int64_t o = shift ? (slot * conv.S) & 15 : 0;
-        c0 = int64_t(b - slot_u * n_chunks) * 512 + int64_t(threadIdx.x) * 2 - o;
-        v0 = c0 >= 0 && c0 < S;
-        v1 = c0 + 1 >= 0 && c0 + 1 < S;
-        s0c = (v0 || v1) ? c0 : 0;
-        s1c = v1 ? c0 + 1 : (S > 1 ? 1 : 0);
-    };
-    uint64_t b = blockIdx.x;
-    if (b >= n_units) return;
-    int64_t slot, c0, s0c, s1c;
-    bool v0, v1;
-    place(b, slot, c0, v0, v1, s0c, s1c);
-    typename Conv::Cell cell = conv.cell_setup(c0, v0, v1, lds);
-    typename Conv::Raw raw = conv.template load<true>(slot, 0, s0c, s1c, cell, carry);
-    for (;;) {
-        const uint64_t bn = b + gridDim.x;
-        int64_t slot_n = 0, c0n = 0, s0n = 0, s1n = 0;
-        bool v0n = false, v1n = false;
-        typename Conv::Raw raw_n = raw;
-        typename Conv::Cell cell_n = cell;
-        if (bn < n_units) {
-            place(bn, slot_n, c0n, v0n, v1n, s0n, s1n);
-            cell_n = conv.cell_setup(c0n, v0n, v1n, lds);
-            raw_n = conv.template load<true>(slot_n, 0, s0n, s1n, cell_n, carry);
-        }
-        const double2 r = conv.compute(raw, v0, v1, cell, lds);
-        st2<true>(out, slot * S + c0, v0, v1, r);
-        if (bn >= n_units) break;
-        b = bn;
-        slot = slot_n;
-        c0 = c0n;
-        v0 = v0n;
-        v1 = v1n;
-        raw = raw_n;
-        cell = cell_n;
-    }
-}
-
+// (Round 5 tried the same walk with a PERSISTENT grid - n_CU x 8 or 16 blocks taking units b, b + G, ..., the converter's LDS
+//  tables built once per block, the next unit's loads in flight during the conversion: 7.0 / 6.8 ms against this kernel's
+//  5.6 ms on C3, gpurun_out/r05_d.  One short-lived block per unit lets the hardware's dispatcher keep the sweep tight;
+//  removed again.)
 // ---------------------------------------------------------------------------------------
 // kernel 2: per-cell time reduction.  psum/pcnt[chunk, cell] then k_chunk_reduce.
 // ---------------------------------------------------------------------------------------
@@ -948,7 +900,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
 // the LDS budget (160 KiB / 16 waves) leaves kRowCacheNight = 2 weight rows per wave.  Converters opt in with
 // kNightPipe and provide key_load / key_is_zero / rest_load / compute_keyed.
 #ifndef ATL_DAYMAP_PIPE
-#define ATL_DAYMAP_PIPE 1
+#define ATL_DAYMAP_PIPE 0  // measured on C2 (gpurun_out/r05_d): one register set 1.919 ms, two (next day slot's loads in flight) 1.984 ms
 #endif
 template <class Conv, bool VEC, bool DENSE, bool MAP = false>
 __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 2 : min_waves<Conv>()) void k_fused_segred_night(Conv conv, PlanDev plan, int64_t slot0,
@@ -1009,8 +961,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 2 : min_waves<Conv>())
             for (int i = 0; i < kBatch; ++i) *reinterpret_cast<double2 *>(vl + vrow_pair<false>(i, lane)) = double2{0.0, 0.0};
             bool finite = true;
             unsigned m = day;
-            // two register sets: the next day slot's seven streams are in flight while this one is converted (the keys'
-            // 16 registers are gone, so both sets fit the 128 of four waves per SIMD)
+            // (ATL_DAYMAP_PIPE = 1: two register sets, the next day slot's seven streams in flight while this one is converted -
+            //  fits the 128 registers of four waves per SIMD now that the keys' 16 are gone, and is 3 % SLOWER on C2)
             typename Conv::Carry carry{};
 #if !ATL_DAYMAP_PIPE  // experiment (tools/build_variant.sh): one register set, a day slot's loads wait for the previous conversion
             while (m) {
@@ -1342,16 +1294,7 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
             if constexpr (conv_flat_series<Conv>::value) {  // flat order: see k_cells_series_flat
                 const int32_t shift = slot_stride_of(ctx, S) % 16 != 0 && !getenv("ATLITE_HIP_SERIES_NO_SHIFT");
                 const unsigned gxs = shift ? unsigned((S + 15 + 511) / 512) : gx_cells;
-                static const int persist = [] {
-                    const char *e = getenv("ATLITE_HIP_SERIES_PERSIST");
-                    return e ? atoi(e) : 0;
-                }();
-                const uint64_t n_units = uint64_t(gxs) * uint64_t(n_slots);
-                if (persist > 0 && n_units > uint64_t(ctx->n_cu) * uint64_t(persist))
-                    hipLaunchKernelGGL((k_cells_series_flat_persist<Conv>), dim3(unsigned(ctx->n_cu * persist)), dim3(256), lds_bytes, ctx->stream,
-                                       conv, S, uint32_t(gxs), n_units, d_out, shift);
-                else
-                    hipLaunchKernelGGL((k_cells_series_flat<Conv>), dim3(unsigned(int64_t(gxs) * n_slots)), dim3(256), lds_bytes, ctx->stream, conv, S,
+                hipLaunchKernelGGL((k_cells_series_flat<Conv>), dim3(unsigned(int64_t(gxs) * n_slots)), dim3(256), lds_bytes, ctx->stream, conv, S,
                                        uint32_t(gxs), d_out, shift);
             }
         } else if (vec) {  // (else: the early-out converters do not instantiate the plain series kernel)

@@ -1536,6 +1536,11 @@ int atl_agg_create_ld(atl_ctx *ctx, int64_t ld_cells, int64_t n_rows, int64_t n_
     ATL_LD_GUARD("atl_agg_create_ld");
     return atl_agg_create(ctx, n_rows, n_cells, row_len, h_indptr, h_indices, h_data, out);
 }
+int atl_nc_read_slabs_ld(atl_ctx *ctx, int64_t ld_cells, atl_nc *f, int n_vars, const char *const *names, int64_t start0, int64_t count0,
+                         double *const *d_outs, int n_threads) {
+    ATL_LD_GUARD("atl_nc_read_slabs_ld");
+    return atl_nc_read_slabs(ctx, f, n_vars, names, start0, count0, d_outs, n_threads);
+}
 int atl_nc_read_slab_ld(atl_ctx *ctx, int64_t ld_cells, atl_nc *f, const char *name, int64_t start0, int64_t count0, double *d_out,
                         int n_threads) {
     ATL_LD_GUARD("atl_nc_read_slab_ld");

@@ -126,6 +126,15 @@ class NcFile:
         check(self.lib.atl_nc_read_slab_ld(ctx.handle, int(ld or 0), self.handle, name.encode(), int(start), int(count), int(dptr),
                                            int(n_threads)))
 
+    def read_slabs(self, ctx, names, start, count, dptrs, n_threads=0, ld=0):
+        """The same rows of several variables -> fp64 blocks at the device pointers ``dptrs``: one call, and - when their chunks
+        are zlib streams - ONE device launch that inflates all of them (``atl_nc_read_slabs``)."""
+        n = len(names)
+        c_names = (C.c_char_p * n)(*[s.encode() for s in names])
+        c_outs = (C.c_void_p * n)(*[int(p) for p in dptrs])
+        check(self.lib.atl_nc_read_slabs_ld(ctx.handle, int(ld or 0), self.handle, n, c_names, int(start), int(count), c_outs,
+                                            int(n_threads)))
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.atl_nc_close(self.handle)

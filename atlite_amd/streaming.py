@@ -152,9 +152,16 @@ def run(ctx, spec, ds, plan, time_agg):
             b = i % 2
             if i >= 2:
                 check(lib.atl_stream_wait_event(ctx.handle, COPY, ev_done[b]))
+            # the file-backed variables of the slab in ONE read per file (atl_nc_read_slabs: one device launch inflates the chunk
+            # streams of all of them)
+            by_file = {}
             for n, a in host.items():
                 if _is_file(a):
-                    a.read_slab(ctx, t0, t1, bufs[b][n].ptr, ld=ld or 0)  # where atl_nc_read_slab puts the rows
+                    by_file.setdefault((id(a.file), a.row0), (a.file, a.row0, []))[2].append(n)
+            for fobj, row0, names in by_file.values():
+                fobj.read_slabs(ctx, [host[n].name for n in names], row0 + t0, t1 - t0, [bufs[b][n].ptr for n in names], ld=ld or 0)
+            for n, a in host.items():
+                if _is_file(a):
                     continue
                 blk = a[t0:t1]
                 if a.dtype == np.float64 and ld:

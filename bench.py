@@ -103,7 +103,7 @@ def parse():
                          "(atl_capture_begin / atl_graph_launch)")
     ap.add_argument("--legs", default="all",
                     help="comma-separated subset of the N = 1 legs: headline,night_skip,star_polygons,api,separate_cubes,"
-                         "cpu,c3_series,c3_cf_map,c3_aggregated,c5_heat,c5_runoff,odd_caller,c4_full_sp (default: all)")
+                         "from_file,cpu,c3_series,c3_cf_map,c3_aggregated,c5_heat,c5_runoff,odd_caller,c4_full_sp (default: all)")
     ap.add_argument("--debug-rccl-self", action="store_true",
                     help="testing only (one GPU, one process): open a 1-rank RCCL process group and route the step "
                          "through the collective branch (async all-gather on the group's stream, placement copy)")
@@ -544,6 +544,83 @@ def self_launch(a):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
     return subprocess.run(cmd, env=env).returncode
+
+
+def from_file_leg(ctx, _lib, gis, M, Y, X, T=1440, chunks=(24, 100, 100)):
+    """pv from a cutout file, device inflate vs host inflate: seconds, cell-steps/s, GB/s of file and fp64-equivalent GB/s."""
+    import subprocess
+    import tempfile
+
+    import atlite_amd as aa
+
+    conda = "/opt/conda/bin/python3.9"
+    if not os.path.exists(conda):
+        return {"skipped": "no conda interpreter with h5py to write the file"}
+    tmp = tempfile.mkdtemp(prefix="atl_bench_", dir="/tmp")
+    path = os.path.join(tmp, "cutout.nc")
+    t0 = time.perf_counter()
+    subprocess.run([conda, str(ROOT / "tests" / "golden" / "make_nc_fixtures.py"), "--cutout", path, str(T), str(Y), str(X),
+                    *[str(c) for c in chunks], "f4", "11", str(max(2, len(os.sched_getaffinity(0))))], check=True, timeout=300)
+    t_write = time.perf_counter() - t0
+    names = ["influx_direct", "influx_diffuse", "influx_toa", "albedo", "temperature", "solar_altitude", "solar_azimuth"]
+    out = {"file": f"NetCDF-4, {T}x{Y}x{X} float32, chunks {chunks}, shuffle + zlib level 1, 11 cubes (7 read); written in {t_write:.1f} s",
+           "call": "Cutout(path).pv(panel='CSi', orientation={slope:30,azimuth:180}, matrix=M, aggregate_time=None).values"}
+    try:
+        cf = aa.Cutout(path)
+        if M is None:
+            M = gis.compute_indicatormatrix(cf.coords["x"], cf.coords["y"], gis.random_tessellation(100, cf.bounds, seed=0))
+        kw = dict(panel="CSi", orientation={"slope": 30.0, "azimuth": 180.0}, matrix=M, aggregate_time=None)
+        disk = sum(cf.data.file.variables[v].stored_bytes for v in names)
+        cells = T * Y * X
+        dctx = default_context_of()
+
+        def times():
+            ms = (C.c_double * 5)()
+            cb, rb = C.c_int64(), C.c_int64()
+            _lib.check(dctx.lib.atl_nc_ingest_times(dctx.handle, ms, C.byref(cb), C.byref(rb)))
+            st = [C.c_int64() for _ in range(3)]
+            _lib.check(dctx.lib.atl_nc_ingest_stats(dctx.handle, *[C.byref(x) for x in st]))
+            return np.array(list(ms)), cb.value, rb.value, [x.value for x in st]
+
+        def leg(mode, n):
+            os.environ["ATLITE_HIP_INFLATE"] = mode
+            ts, r = [], None
+            for _ in range(n):
+                t0 = time.perf_counter()
+                r = cf.pv(**kw).values
+                ts.append(time.perf_counter() - t0)
+            best = min(ts)
+            return r, {"first_s": ts[0], "best_s": best, "value": cells / best, "unit": "cell-timesteps/s",
+                       "file_GBps": disk / best / 1e9, "fp64_equivalent_GBps": 7 * cells * 8 / best / 1e9}
+
+        try:
+            r_dev, out["device_inflate"] = leg("device", 4)
+            m0, c0, r0, s0 = times()
+            cf.pv(**kw)
+            m1, c1, r1, s1 = times()
+            dm = m1 - m0
+            out["device_inflate"]["one_warm_call"] = {
+                "host_gather_ms": dm[0], "h2d_ms": dm[1], "k_inflate_ms": dm[2], "k_adler_ms": dm[3], "k_unpack_ms": dm[4],
+                "streams": s1[0] - s0[0], "redone_on_host": s1[2] - s0[2], "compressed_bytes": c1 - c0, "inflated_bytes": r1 - r0,
+                "note": "HIP-event times on the staging slots' own streams; up to four reads are in flight, so the sum exceeds the wall time"}
+            r_host, out["host_inflate"] = leg("host", 3)
+            out["bit_identical"] = bool(np.array_equal(np.asarray(r_dev), np.asarray(r_host)))
+            out["stored_bytes"] = int(disk)
+        finally:
+            os.environ.pop("ATLITE_HIP_INFLATE", None)
+    finally:
+        try:
+            os.remove(path)
+            os.rmdir(tmp)
+        except OSError:
+            pass
+    return out
+
+
+def default_context_of():
+    from atlite_amd.device import default_context
+
+    return default_context()
 
 
 def main():
@@ -1158,6 +1235,16 @@ def main():
                                     "equals_timed_result": same}
             dctx.set_profiling(False)
             del cut, r0
+
+        # (3b) from a cutout FILE: NetCDF-4, fp32, zlib + shuffle - what atlite writes (atlite/data.py:246-248) -
+        # opened with the library's own reader; the chunks' zlib streams are inflated on the device (one wavefront per stream),
+        # PCIe carries the compressed bytes.  A month and a half of the C2 grid (the file is written here, with h5py under the
+        # image's conda interpreter: ~7 s), the timed call is Cutout(path).pv(matrix=M) end to end.
+        if want("from_file"):
+            try:
+                result["from_file"] = from_file_leg(ctx, _lib, gis, M if (Y, X) == (200, 200) else None, Y, X)
+            except Exception as e:  # noqa: BLE001 - a side leg must not cost the run its line
+                result["from_file"] = {"skipped": repr(e)}
 
         # (4) the same cubes in an allocation each (the layout a caller's own device arrays have, and the library's before
         # round 3): same kernel, same bytes, bit-identical result - the memory system alone makes the difference

@@ -518,7 +518,7 @@ int atl_nc_read_host(atl_nc *f, const char *name, int64_t start0, int64_t count0
  * atl_stream_wait_event(ctx, 0, ev)).  Two ways through the zlib streams of a chunked, deflated variable
  * (atlite/data.py:246-248 writes cutouts with zlib + shuffle):
  *  - on the DEVICE, one wavefront per chunk stream (k_inflate; round 5), when the rows asked for span at least
- *    $ATLITE_HIP_INFLATE_MIN_CHUNKS chunks (default 192; $ATLITE_HIP_INFLATE=device: always): the host threads only
+ *    $ATLITE_HIP_INFLATE_MIN_CHUNKS chunks (default 1024; $ATLITE_HIP_INFLATE=device: always): the host threads only
  *    pread the COMPRESSED bytes into page-locked staging, PCIe carries those, un-shuffle + widening + CF decoding follow
  *    on the device as before.  Every stream's Adler-32 is checked on the device; a stream the device decoder declines
  *    is decoded by the host decoders before anyone can observe the copy stream (atl_event_record(ev, 1), the slot's next
@@ -529,6 +529,14 @@ int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, 
                      double *d_out, int n_threads);
 /* chunks of this context's atl_nc_read_slab calls so far: inflated on the device / on host threads / declined by the device
  * decoder and decoded again on the host (settles pending reads first) */
+/* The same rows of n_vars variables at once (what one conversion reads: a slab of the pv inputs): when every stored chunk
+ * of the group is a plain zlib stream, ALL of them are inflated by ONE k_inflate launch - the device holds ~3600 streams at
+ * a time, a single variable's rows rarely bring that many, and launches from different HIP streams do not add up (the
+ * runtime multiplexes them onto four hardware queues).  Otherwise exactly n_vars atl_nc_read_slab calls. */
+int atl_nc_read_slabs(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *names, int64_t start0, int64_t count0,
+                      double *const *d_outs, int n_threads);
+int atl_nc_read_slabs_ld(atl_ctx *ctx, int64_t ld_cells, atl_nc *f, int n_vars, const char *const *names, int64_t start0,
+                         int64_t count0, double *const *d_outs, int n_threads);
 /* atl_nc_read_slab with the OUTPUT block's slot stride as an argument (see atl_spmm_csr_ld) */
 int atl_nc_read_slab_ld(atl_ctx *ctx, int64_t ld_cells, atl_nc *f, const char *name, int64_t start0, int64_t count0, double *d_out,
                         int n_threads);

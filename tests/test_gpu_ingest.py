@@ -20,7 +20,7 @@ NC = os.path.join(os.path.dirname(__file__), "golden", "nc")
 @pytest.fixture(autouse=True, params=["host", "device"])
 def inflate_mode(request, monkeypatch):
     """Every test of this file runs twice: the chunks' zlib streams inflated on host threads, and on the device (one
-    wavefront per stream, atl_nc_read_slab; forced here - by default only reads of >= 192 chunks take it)."""
+    wavefront per stream, atl_nc_read_slab; forced here - by default only reads of >= 1024 chunks take it)."""
     monkeypatch.setenv("ATLITE_HIP_INFLATE", request.param)
     return request.param
 
@@ -284,9 +284,17 @@ def test_device_inflate_many_chunks(ctx, tmp_path, monkeypatch):
         dev = io.FileArray(f, n).to_device(ctx)
         ctx.sync()
         assert np.array_equal(dev.numpy().reshape(T, Y, X), host[n], equal_nan=True), n
+    # ... and all of them in one read (atl_nc_read_slabs: one launch over every variable's streams)
+    outs = [ctx.zeros((T, Y, X)) for _ in names]
+    ctx.copy_after_compute()
+    f.read_slabs(ctx, names, 5, 100, [o.ptr for o in outs])
+    ctx.copy_barrier()
+    ctx.sync()
+    for n, o in zip(names, outs):
+        assert np.array_equal(o.numpy()[:100], host[n][5:105], equal_nan=True), n
     d1, _, r1 = ingest_stats(ctx)
     assert d1 - d0 >= len(names) * 240 * 2 and r1 == r0
-    # the default policy: a read of many chunks (default >= 192) goes to the device, a small one stays on the host threads
+    # the default policy: a read of many chunks (default >= 1024) goes to the device, a small one stays on the host threads
     monkeypatch.delenv("ATLITE_HIP_INFLATE")
     monkeypatch.setenv("ATLITE_HIP_INFLATE_MIN_CHUNKS", "200")
     d1, h1, _ = ingest_stats(ctx)
