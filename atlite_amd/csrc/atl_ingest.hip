@@ -592,7 +592,20 @@ IngestState *state_of(atl_ctx *ctx) {
 int slot_acquire(atl_ctx *ctx, size_t bytes, Slot **out, size_t raw_bytes = 0) {
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     IngestState *st = state_of(ctx);
-    Slot &sl = st->slot[st->calls++ % kSlots];
+    // the next slot in turn - unless another one is idle and already holds buffers of this size (a read of a whole slab stages
+    // a GB: page-locking that again for every slot of the rotation would cost more than the read)
+    unsigned pick = st->calls % kSlots;
+    for (unsigned k = 0; k < kSlots; ++k) {
+        Slot &c = st->slot[(st->calls + k) % kSlots];
+        const bool idle = !c.pending || hipEventQuery(c.ev) == hipSuccess;
+        if (idle && c.bytes >= bytes && c.raw_bytes >= raw_bytes) {
+            pick = (st->calls + k) % kSlots;
+            break;
+        }
+    }
+    (void)hipGetLastError();  // (hipEventQuery's "not ready" is not an error)
+    ++st->calls;
+    Slot &sl = st->slot[pick];
     if (!sl.ev) ATL_HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
     int rc = finish_slot(ctx, st, sl);  // the previous user of this slot has left its stream; its verdicts are in
     if (rc) return rc;
@@ -1414,7 +1427,28 @@ int atl_nc_read_slabs(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     ATL_REQUIRE(ctx && f && n_vars >= 0 && (n_vars == 0 || (names && d_outs)), "atl_nc_read_slabs: bad argument");
     if (n_vars == 0) return ATL_OK;
     bool done = false;
-    int rc = n_vars > 1 ? read_group_device(ctx, f, n_vars, names, start0, count0, d_outs, n_threads, &done) : ATL_OK;
+    int rc = ATL_OK;
+    if (n_vars > 1) {
+        // a big group in two halves, each a device job of its own: the second half's pread + DMA run while the first half's
+        // streams are inflated (the kernels themselves queue up behind each other)
+        int64_t chunks = 0;
+        for (int v = 0; v < n_vars; ++v) {
+            const Dataset *d = f->file.find(names[v]);
+            if (d && d->layout == 2 && !d->chunk.empty() && d->chunk[0] > 0) {
+                int64_t per_row = 1;
+                for (size_t k = 1; k < d->grid.size(); ++k) per_row *= int64_t(d->grid[k]);
+                chunks += (count0 / int64_t(d->chunk[0]) + 1) * per_row;
+            }
+        }
+        const int half = (chunks >= 7168 && n_vars >= 4) ? n_vars / 2 : n_vars;  // (twice what the device holds at a time)
+        rc = read_group_device(ctx, f, half, names, start0, count0, d_outs, n_threads, &done);
+        if (!rc && done && half < n_vars) {
+            bool done2 = false;
+            rc = read_group_device(ctx, f, n_vars - half, names + half, start0, count0, d_outs + half, n_threads, &done2);
+            if (!rc && !done2)
+                for (int v = half; v < n_vars && !rc; ++v) rc = atl_nc_read_slab(ctx, f, names[v], start0, count0, d_outs[v], n_threads);
+        }
+    }
     if (rc || done) return rc;
     for (int v = 0; v < n_vars; ++v) {  // variable by variable (each decides for itself: device or host threads)
         rc = atl_nc_read_slab(ctx, f, names[v], start0, count0, d_outs[v], n_threads);

@@ -886,6 +886,7 @@ class Context:
     def close(self):
         for p in self.__dict__.pop("_plan_cache", {}).values():
             p.close()
+        self.__dict__.pop("_slab_cache", None)  # (streaming.run's slab buffers)
         if getattr(self, "handle", None):
             self.trim()
             for pair in self.__dict__.get("_pool_st", {}).get("events", []):

@@ -120,7 +120,7 @@ def run(ctx, spec, ds, plan, time_agg):
     steps = int(os.environ.get("ATLITE_HIP_SLAB_STEPS", 0)) or max(8, min(T, slab_bytes // max(S * 8, 1)) // 8 * 8)
     # file sources: whole chunks per slab, so that no chunk is inflated twice
     tchunk = max([a.var.chunks[0] for a in host.values() if _is_file(a) and a.var.layout == "chunked"], default=0)
-    if tchunk and not os.environ.get("ATLITE_HIP_SLAB_STEPS"):
+    if tchunk and not os.environ.get("ATLITE_HIP_SLAB_STEPS") and steps < T:
         steps = max(tchunk, steps // tchunk * tchunk)
     edges = spec.slab_edges(T, steps)
     n_slots = spec.n_slots(ds)
@@ -132,8 +132,22 @@ def run(ctx, spec, ds, plan, time_agg):
     from .device import pitch_for
 
     ld = pitch_for(S)
-    bufs = [{n: (ctx.empty_pitched((max(max_len, 1), S), ld) if ld else ctx.empty((max(max_len, 1), S))) for n in host}
-            for _ in range(2)]
+    import time as _time
+
+    _t0 = _time.perf_counter()
+    _dbg = os.environ.get("ATLITE_HIP_STREAM_TIMING") == "1"
+    # two sets of slab buffers (one is filled while the other is converted); a single slab needs one.  Fresh device memory
+    # costs ~30 ms per GB to map (a year of the C2 grid: 0.6 s for two sets, twice the read itself), so the sets of the last
+    # call stay with the context - up to $ATLITE_HIP_SLAB_CACHE bytes (default 48 GiB of the 288) - for the next one
+    n_sets = 2 if len(edges) > 1 else 1
+    key = (max(max_len, 1), S, ld, tuple(host))
+    cache = ctx.__dict__.setdefault("_slab_cache", {})
+    bufs = cache.pop(key, [])[:n_sets]
+    while len(bufs) < n_sets:
+        bufs.append({n: (ctx.empty_pitched((max(max_len, 1), S), ld) if ld else ctx.empty((max(max_len, 1), S))) for n in host})
+    if _dbg:
+        ctx.sync()
+        print(f"[streaming] {len(edges)} slab(s) of <= {max_len} steps, buffers allocated in {(_time.perf_counter() - _t0) * 1e3:.1f} ms", flush=True)
     ev_ready, ev_done = [], []
     for _ in range(2):
         for lst in (ev_ready, ev_done):
@@ -149,8 +163,9 @@ def run(ctx, spec, ds, plan, time_agg):
     pinned = _Pinned(lib, [a for a in host.values() if not _is_file(a)], getattr(ds, "pinned_ranges", lambda: [])())
     try:
         for i, (t0, t1) in enumerate(edges):
-            b = i % 2
-            if i >= 2:
+            b = i % len(bufs)
+            _t1 = _time.perf_counter()
+            if i >= len(bufs):
                 check(lib.atl_stream_wait_event(ctx.handle, COPY, ev_done[b]))
             # the file-backed variables of the slab in ONE read per file (atl_nc_read_slabs: one device launch inflates the chunk
             # streams of all of them)
@@ -174,8 +189,11 @@ def run(ctx, spec, ds, plan, time_agg):
                 else:
                     check(lib.atl_upload_convert_async(ctx.handle, bufs[b][n].ptr, blk.ctypes.data,
                                                        NC_CODES[a.dtype.name], blk.size))
+            _t2 = _time.perf_counter()
             check(lib.atl_event_record(ctx.handle, ev_ready[b], COPY))
             check(lib.atl_stream_wait_event(ctx.handle, COMPUTE, ev_ready[b]))
+            if _dbg:
+                print(f"[streaming] slab {i}: reads enqueued in {(_t2 - _t1) * 1e3:.1f} ms, copy stream observed after {(_time.perf_counter() - _t2) * 1e3:.1f} ms more", flush=True)
             view = _SlabView(ds, bufs[b], static, t0, t1)
             sub = spec.for_slab(t0, t1)
             s0, s1 = spec.out_slots(t0, t1)
@@ -187,8 +205,16 @@ def run(ctx, spec, ds, plan, time_agg):
                 host_acc += sub.run(ctx, view, None, "sum").numpy()  # (S,) per slab: tiny
             check(lib.atl_event_record(ctx.handle, ev_done[b], COMPUTE))
         ctx.sync()
+        if _dbg:
+            print(f"[streaming] all slabs done {(_time.perf_counter() - _t0) * 1e3:.1f} ms after the start", flush=True)
     finally:
         ctx.sync()
+        cap = int(os.environ.get("ATLITE_HIP_SLAB_CACHE", 48 << 30))
+        size = sum(a.nbytes for b_ in bufs for a in b_.values())
+        if size <= cap:
+            for k_ in list(cache):  # one shape at a time: a different cutout replaces it
+                del cache[k_]
+            cache[key] = bufs
         pinned.release()
         for h in ev_ready + ev_done:
             lib.atl_event_destroy(h)

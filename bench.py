@@ -546,7 +546,7 @@ def self_launch(a):
     return subprocess.run(cmd, env=env).returncode
 
 
-def from_file_leg(ctx, _lib, gis, M, Y, X, T=1440, chunks=(24, 100, 100)):
+def from_file_leg(ctx, _lib, gis, M, Y, X, T=2920, chunks=(24, 100, 100)):
     """pv from a cutout file, device inflate vs host inflate: seconds, cell-steps/s, GB/s of file and fp64-equivalent GB/s."""
     import subprocess
     import tempfile
