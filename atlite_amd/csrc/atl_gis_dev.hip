@@ -242,7 +242,7 @@ static int indicator_integral(atl_ctx *ctx, int64_t n_shapes, const int64_t *h_s
         auto up = [&](void **d, const void *h, size_t bytes) -> hipError_t {
             hipError_t e = dev_malloc(d, std::max<size_t>(bytes, 8));
             if (e != hipSuccess) return e;
-            return bytes ? hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
+            return (bytes && h2d(ctx, ctx->stream, *d, h, bytes) != ATL_OK) ? hipErrorUnknown : hipSuccess;
         };
         hipError_t e = up((void **)&d_edges, bedges.data(), bedges.size() * sizeof(Edge));
         if (e == hipSuccess) e = up((void **)&d_ptr, bucket_ptr.data(), bucket_ptr.size() * sizeof(int64_t));
@@ -261,7 +261,7 @@ static int indicator_integral(atl_ctx *ctx, int64_t n_shapes, const int64_t *h_s
                 e = hipGetLastError();
             }
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(cand.data(), d_cand, size_t(n_cand) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && d2h(ctx, ctx->stream, cand.data(), d_cand, size_t(n_cand) * sizeof(double)) != ATL_OK) e = hipErrorUnknown;
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         for (void *p : {(void *)d_edges, (void *)d_ptr, (void *)d_out_off, (void *)d_col, (void *)d_row0, (void *)d_nrows, (void *)d_cand})
             if (p) (void)dev_free(p);

@@ -928,7 +928,10 @@ int finish_slot(atl_ctx *ctx, IngestState *st, Slot &sl) {
         const h5::Chunk &c = pt.ds->chunks[job.lin[i]];
         const int e = h5::chunk_inflate(*pt.ds, c, job.nc->file.base(), -1, tmp.data(), uint64_t(pt.chunk_bytes), &shuffled);
         if (e) return e;
-        ATL_HIP_TRY(hipMemcpy(sl.d_raw + job.inf[i].dst_off, tmp.data(), size_t(pt.chunk_bytes), hipMemcpyHostToDevice));
+        {
+            const int rc = h2d(ctx, sl.st, sl.d_raw + job.inf[i].dst_off, tmp.data(), size_t(pt.chunk_bytes));
+            if (rc) return rc;
+        }
         launch_unpack(sl.st, sl.d_raw, d_unp + job.desc_of[i], 1, pt.p, pt.max_elems, pt.d_out);
         ATL_HIP_TRY(hipGetLastError());
         ++st->n_redone;

@@ -267,6 +267,13 @@ struct atl_ctx {
     // file / narrow-dtype ingest (atl_ingest.hip): staging buffers, created on first use
     void *ingest = nullptr;
     void (*ingest_free)(void *) = nullptr;
+    // two page-locked bounce buffers (created on first use): every transfer between device memory and host memory that is
+    // NOT page-locked goes through them (atl::h2d / atl::d2h), so the runtime never has to pin a caller's heap or stack
+    // pages on the fly
+    uint8_t *bounce[2] = {nullptr, nullptr};
+    hipEvent_t bounce_ev[2] = {nullptr, nullptr};
+    bool bounce_busy[2] = {false, false};
+    int bounce_next = 0;
 };
 
 struct atl_event {
@@ -299,6 +306,18 @@ int copy_stream_of(atl_ctx *ctx, hipStream_t *out);
 // order anything: callers synchronise first, as they had to for hipFree's sake.
 // atl_ingest.hip: settle the context's device-inflate reads (no-op when there are none)
 int ingest_finish(atl_ctx *ctx);
+// Transfers between device memory and ARBITRARY host memory (a caller's NumPy array, a std::vector, a stack variable).  The
+// HIP runtime serves such a copy by pinning the host pages on the fly and letting a copy engine or a blit kernel touch them;
+// three unexplained "Memory access fault by GPU ... on address <a host heap address>" aborts of the test suite (rounds 3-5, one
+// in ~15 whole-suite runs, always in a process that had run for a minute and freed many small arrays) ended when the library
+// stopped doing that: host memory that is not page-locked (hipHostMalloc / hipHostRegister) is copied through the context's
+// own page-locked bounce buffers, 4 MiB at a time, double-buffered.  h2d returns once the source has been read (the device
+// side completes in stream order); d2h returns with the data in place.
+int h2d(atl_ctx *ctx, hipStream_t st, void *d_dst, const void *h_src, size_t bytes);
+int d2h(atl_ctx *ctx, hipStream_t st, void *h_dst, const void *d_src, size_t bytes);
+int h2d_2d(atl_ctx *ctx, hipStream_t st, void *d_dst, size_t dst_pitch, const void *h_src, size_t src_pitch, size_t width, size_t height);
+int d2h_2d(atl_ctx *ctx, hipStream_t st, void *h_dst, size_t dst_pitch, const void *d_src, size_t src_pitch, size_t width, size_t height);
+bool host_is_pinned(const void *p);
 hipError_t dev_malloc(void **out, size_t bytes);
 hipError_t dev_free(void *p);
 bool fence_mode();

@@ -280,8 +280,7 @@ int atl_order_statistic(atl_ctx *ctx, const double *d_in, int64_t rows, int64_t 
     hipLaunchKernelGGL(k_sel_count, dim3(grid), dim3(256), 0, ctx->stream, d_in, rows, T, ld, st);
     if ((rc = launched("atl_order_statistic"))) return rc;
     SelState h{};
-    ATL_HIP_TRY(hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-    ATL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if ((rc = d2h(ctx, ctx->stream, &h, st, sizeof(h)))) return rc;
     *h_n = int64_t(h.n);
     if (h.n == 0) return ATL_OK;
     // numpy's "linear" method: virtual index q (n - 1); the order statistics floor(.) and floor(.) + 1 bracket it
@@ -290,7 +289,7 @@ int atl_order_statistic(atl_ctx *ctx, const double *d_in, int64_t rows, int64_t 
     lo = std::min<int64_t>(std::max<int64_t>(lo, 0), int64_t(h.n) - 1);
     h.rank = (unsigned long long)lo;
     h.next = ~0ull;
-    ATL_HIP_TRY(hipMemcpyAsync(st, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = h2d(ctx, ctx->stream, st, &h, sizeof(h)))) return rc;
     for (int p = 0; p < kSelPasses; ++p) {
         const int hi = 64 - p * kSelBits;
         const int shift = std::max(hi - kSelBits, 0), bits = hi - shift;
@@ -301,9 +300,8 @@ int atl_order_statistic(atl_ctx *ctx, const double *d_in, int64_t rows, int64_t 
     hipLaunchKernelGGL(k_sel_values, dim3(1), dim3(1), 0, ctx->stream, st, vals);
     if ((rc = launched("atl_order_statistic"))) return rc;
     double pair[2];
-    ATL_HIP_TRY(hipMemcpyAsync(pair, vals, sizeof(pair), hipMemcpyDeviceToHost, ctx->stream));
-    ATL_HIP_TRY(hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-    ATL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if ((rc = d2h(ctx, ctx->stream, pair, vals, sizeof(pair)))) return rc;
+    if ((rc = d2h(ctx, ctx->stream, &h, st, sizeof(h)))) return rc;
     h_pair[0] = pair[0];
     // the order statistic after x_(lo): x_(lo) itself when it is repeated beyond rank lo, else the smallest value above
     h_pair[1] = (int64_t(h.n_le) > lo + 1) ? pair[0] : pair[1];

@@ -175,8 +175,11 @@ static int to_device(atl_agg *a, const std::vector<T> &v, const T **out) {
     size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
     ATL_HIP_TRY(dev_malloc(&d, bytes));
     a->allocs.push_back(d);
-    if (!v.empty())
-        ATL_HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (!v.empty()) {
+        int rc = atl::h2d(a->ctx, a->ctx->stream, d, v.data(), v.size() * sizeof(T));
+        if (rc) return rc;
+        ATL_HIP_TRY(hipStreamSynchronize(a->ctx->stream));
+    }
     *out = static_cast<const T *>(d);
     return ATL_OK;
 }
@@ -193,6 +196,140 @@ int copy_stream_of(atl_ctx *ctx, hipStream_t *out) {
 }  // namespace atl
 
 namespace atl {
+// ---- host <-> device through the context's page-locked bounce buffers (atl_internal.h) -----------------------------------
+constexpr size_t kBounce = size_t(4) << 20;
+
+bool host_is_pinned(const void *p) {
+    hipPointerAttribute_t attr;
+    const bool pinned = hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();  // "not a registered pointer" is an answer, not an error
+    return pinned;
+}
+
+static int bounce_slot(atl_ctx *ctx, int *slot) {
+    const int s = ctx->bounce_next;
+    ctx->bounce_next ^= 1;
+    if (!ctx->bounce[s]) {
+        ATL_HIP_TRY(hipSetDevice(ctx->device));
+        ATL_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->bounce[s]), kBounce, hipHostMallocDefault));
+        ATL_HIP_TRY(hipEventCreateWithFlags(&ctx->bounce_ev[s], hipEventDisableTiming));
+    }
+    if (ctx->bounce_busy[s]) {  // the transfer that last used this buffer has left it
+        ATL_HIP_TRY(hipEventSynchronize(ctx->bounce_ev[s]));
+        ctx->bounce_busy[s] = false;
+    }
+    *slot = s;
+    return ATL_OK;
+}
+
+int h2d(atl_ctx *ctx, hipStream_t st, void *d_dst, const void *h_src, size_t bytes) {
+    if (!bytes) return ATL_OK;
+    if (host_is_pinned(h_src)) {
+        ATL_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
+        return ATL_OK;
+    }
+    for (size_t off = 0; off < bytes; off += kBounce) {
+        const size_t n = std::min(kBounce, bytes - off);
+        int s;
+        int rc = bounce_slot(ctx, &s);
+        if (rc) return rc;
+        memcpy(ctx->bounce[s], static_cast<const uint8_t *>(h_src) + off, n);
+        ATL_HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(d_dst) + off, ctx->bounce[s], n, hipMemcpyHostToDevice, st));
+        ATL_HIP_TRY(hipEventRecord(ctx->bounce_ev[s], st));
+        ctx->bounce_busy[s] = true;
+    }
+    return ATL_OK;
+}
+
+int d2h(atl_ctx *ctx, hipStream_t st, void *h_dst, const void *d_src, size_t bytes) {
+    if (!bytes) return ATL_OK;
+    if (host_is_pinned(h_dst)) {
+        ATL_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+        ATL_HIP_TRY(hipStreamSynchronize(st));
+        return ATL_OK;
+    }
+    // slice i + 1 travels while slice i is copied out of its buffer
+    int cur = -1;
+    size_t cur_off = 0, cur_n = 0;
+    for (size_t off = 0; off < bytes || cur >= 0; off += kBounce) {
+        int nxt = -1;
+        size_t nxt_n = 0;
+        if (off < bytes) {
+            nxt_n = std::min(kBounce, bytes - off);
+            int rc = bounce_slot(ctx, &nxt);
+            if (rc) return rc;
+            ATL_HIP_TRY(hipMemcpyAsync(ctx->bounce[nxt], static_cast<const uint8_t *>(d_src) + off, nxt_n, hipMemcpyDeviceToHost, st));
+            ATL_HIP_TRY(hipEventRecord(ctx->bounce_ev[nxt], st));
+            ctx->bounce_busy[nxt] = true;
+        }
+        if (cur >= 0) {
+            ATL_HIP_TRY(hipEventSynchronize(ctx->bounce_ev[cur]));
+            ctx->bounce_busy[cur] = false;
+            memcpy(static_cast<uint8_t *>(h_dst) + cur_off, ctx->bounce[cur], cur_n);
+        }
+        cur = nxt;
+        cur_off = off;
+        cur_n = nxt_n;
+    }
+    return ATL_OK;
+}
+
+int h2d_2d(atl_ctx *ctx, hipStream_t st, void *d_dst, size_t dst_pitch, const void *h_src, size_t src_pitch, size_t width, size_t height) {
+    if (!width || !height) return ATL_OK;
+    if (host_is_pinned(h_src)) {
+        ATL_HIP_TRY(hipMemcpy2DAsync(d_dst, dst_pitch, h_src, src_pitch, width, height, hipMemcpyHostToDevice, st));
+        return ATL_OK;
+    }
+    if (width > kBounce) {  // rows longer than a buffer: row by row
+        for (size_t r = 0; r < height; ++r) {
+            int rc = h2d(ctx, st, static_cast<uint8_t *>(d_dst) + r * dst_pitch, static_cast<const uint8_t *>(h_src) + r * src_pitch, width);
+            if (rc) return rc;
+        }
+        return ATL_OK;
+    }
+    const size_t rows_per = std::max<size_t>(1, kBounce / width);
+    for (size_t r0 = 0; r0 < height; r0 += rows_per) {
+        const size_t nr = std::min(rows_per, height - r0);
+        int s;
+        int rc = bounce_slot(ctx, &s);
+        if (rc) return rc;
+        for (size_t r = 0; r < nr; ++r) memcpy(ctx->bounce[s] + r * width, static_cast<const uint8_t *>(h_src) + (r0 + r) * src_pitch, width);
+        ATL_HIP_TRY(hipMemcpy2DAsync(static_cast<uint8_t *>(d_dst) + r0 * dst_pitch, dst_pitch, ctx->bounce[s], width, width, nr,
+                                     hipMemcpyHostToDevice, st));
+        ATL_HIP_TRY(hipEventRecord(ctx->bounce_ev[s], st));
+        ctx->bounce_busy[s] = true;
+    }
+    return ATL_OK;
+}
+
+int d2h_2d(atl_ctx *ctx, hipStream_t st, void *h_dst, size_t dst_pitch, const void *d_src, size_t src_pitch, size_t width, size_t height) {
+    if (!width || !height) return ATL_OK;
+    if (host_is_pinned(h_dst)) {
+        ATL_HIP_TRY(hipMemcpy2DAsync(h_dst, dst_pitch, d_src, src_pitch, width, height, hipMemcpyDeviceToHost, st));
+        ATL_HIP_TRY(hipStreamSynchronize(st));
+        return ATL_OK;
+    }
+    if (width > kBounce) {
+        for (size_t r = 0; r < height; ++r) {
+            int rc = d2h(ctx, st, static_cast<uint8_t *>(h_dst) + r * dst_pitch, static_cast<const uint8_t *>(d_src) + r * src_pitch, width);
+            if (rc) return rc;
+        }
+        return ATL_OK;
+    }
+    const size_t rows_per = std::max<size_t>(1, kBounce / width);
+    for (size_t r0 = 0; r0 < height; r0 += rows_per) {
+        const size_t nr = std::min(rows_per, height - r0);
+        int s;
+        int rc = bounce_slot(ctx, &s);
+        if (rc) return rc;
+        ATL_HIP_TRY(hipMemcpy2DAsync(ctx->bounce[s], width, static_cast<const uint8_t *>(d_src) + r0 * src_pitch, src_pitch, width, nr,
+                                     hipMemcpyDeviceToHost, st));
+        ATL_HIP_TRY(hipStreamSynchronize(st));
+        for (size_t r = 0; r < nr; ++r) memcpy(static_cast<uint8_t *>(h_dst) + (r0 + r) * dst_pitch, ctx->bounce[s] + r * width, width);
+    }
+    return ATL_OK;
+}
+
 // grid layout of a plan: (Y, X) cells in tiles of (2 << w2_log2) x (64 >> w2_log2) cells
 struct Layout {
     int64_t X, Y;
@@ -349,6 +486,13 @@ int atl_destroy(atl_ctx *ctx) {
     for (hipEvent_t e : ctx->ev_ring) (void)hipEventDestroy(e);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     if (ctx->ingest && ctx->ingest_free) ctx->ingest_free(ctx->ingest);
+    for (int b = 0; b < 2; ++b) {
+        if (ctx->bounce_ev[b]) {
+            if (ctx->bounce_busy[b]) (void)hipEventSynchronize(ctx->bounce_ev[b]);
+            (void)hipEventDestroy(ctx->bounce_ev[b]);
+        }
+        if (ctx->bounce[b]) (void)hipHostFree(ctx->bounce[b]);
+    }
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -389,7 +533,8 @@ int atl_free(atl_ctx *ctx, void *d_ptr) {
 int atl_upload(atl_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
     ATL_REQUIRE(ctx && (bytes == 0 || (d_dst && h_src)), "atl_upload: bad argument");
     if (!bytes) return ATL_OK;
-    ATL_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    int rc = h2d(ctx, ctx->stream, d_dst, h_src, bytes);
+    if (rc) return rc;
     ATL_HIP_TRY(hipStreamSynchronize(ctx->stream));
     return ATL_OK;
 }
@@ -397,9 +542,7 @@ int atl_upload(atl_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
 int atl_download(atl_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     ATL_REQUIRE(ctx && (bytes == 0 || (h_dst && d_src)), "atl_download: bad argument");
     if (!bytes) return ATL_OK;
-    ATL_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    ATL_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return ATL_OK;
+    return d2h(ctx, ctx->stream, h_dst, d_src, bytes);
 }
 
 int atl_set_slot_stride(atl_ctx *ctx, int64_t ld_cells) {
@@ -421,7 +564,14 @@ int atl_copy_2d(atl_ctx *ctx, void *dst, size_t dst_pitch, const void *src, size
         int rc = copy_stream_of(ctx, &st);
         if (rc) return rc;
     }
-    ATL_HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width, height, k, st));
+    if (kind == 0) {  // (asynchronous or not: the host rows have been read when this returns)
+        int rc = h2d_2d(ctx, st, dst, dst_pitch, src, src_pitch, width, height);
+        if (rc) return rc;
+    } else if (kind == 1) {
+        return d2h_2d(ctx, st, dst, dst_pitch, src, src_pitch, width, height);  // the data is in place on return
+    } else {
+        ATL_HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width, height, k, st));
+    }
     if (!async_on_copy_stream) ATL_HIP_TRY(hipStreamSynchronize(st));
     return ATL_OK;
 }
@@ -470,8 +620,7 @@ int atl_upload_async(atl_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
     hipStream_t cs;
     int rc = copy_stream_of(ctx, &cs);
     if (rc) return rc;
-    ATL_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, cs));
-    return ATL_OK;
+    return h2d(ctx, cs, d_dst, h_src, bytes);  // page-locked sources (atl_host_register, Dataset.pin) go as they lie
 }
 
 int atl_event_create(atl_ctx *ctx, atl_event **out) {
