@@ -457,7 +457,8 @@ class Context:
             return DeviceArray(self, ptr, shape, dtype)
         p = C.c_void_p()
         rc = self.lib.atl_alloc(self.handle, nbytes, C.byref(p))
-        if rc == _lib.ATL_E_NOMEM and self.__dict__.get("_pool_st", {}).get("held"):
+        if rc == _lib.ATL_E_NOMEM and (self.__dict__.get("_pool_st", {}).get("held") or self.__dict__.get("_slab_cache")):
+            self.__dict__.pop("_slab_cache", None)  # what the context only keeps for the NEXT call's sake goes first
             self.trim()
             rc = self.lib.atl_alloc(self.handle, nbytes, C.byref(p))
         check(rc)

@@ -740,12 +740,12 @@ def main():
         dst = torch.zeros((1, 16 * n), dtype=torch.float64, device=dev)
         if how == "lib":
             h_lens = (C.c_int64 * n)(*([16] * n))
-            torch.cuda.synchronize()
+            torch.cuda.synchronize(dev)  # (this runs on a helper thread: torch's "current device" there is not ours)
             _lib.check(ctx.lib.atl_allgather_time_v(comm.handle, src.data_ptr(), 1, h_lens, dst.data_ptr(), 16 * n))
             ctx.sync()
         else:
             dist.all_gather_into_tensor(dst.view(-1), src.view(-1))
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(dev)
         want = torch.arange(1, n + 1, dtype=torch.float64, device=dev).repeat_interleave(16).view(1, -1)
         return bool(torch.equal(dst, want))
 
