@@ -189,6 +189,20 @@ def profile_entry(leg):
     return ent
 
 
+def lines_touched(covered, slot_cells, line_cells=16):
+    """How many 128-byte lines of one time slot of one cube hold at least one cell some shape covers - what the memory system
+    fetches for a plan whose shapes leave cells out (the kernel's lanes load only weighted cells, the hardware whole lines).
+    `covered`: bool per cell; `slot_cells`: cells between the slots of a cube.  None when the slots do not start on a line
+    (then the count differs from slot to slot)."""
+    covered = np.asarray(covered, dtype=bool).ravel()
+    if slot_cells % line_cells:
+        return None
+    pad = (-covered.size) % line_cells
+    if pad:
+        covered = np.concatenate([covered, np.zeros(pad, bool)])
+    return int(covered.reshape(-1, line_cells).any(axis=1).sum())
+
+
 def roofline_of(leg, algo_bytes, k_ms, extra=None):
     """The roofline object of a leg: achieved = algorithmic bytes / HIP-event kernel time of this run; from the committed
     profile of the same leg: the counter traffic per launch and the fraction its average duration gives.  Nothing above
@@ -1198,15 +1212,25 @@ def main():
             plan_main, plan = plan, ctx.plan(M_s, row_len=X, ld=None if ld == S else ld)
             dts, kk = timed(pp_main, ks, kw_)
             info_s = plan.info()
-            covered = int((np.asarray((M_s != 0).sum(0)).ravel() > 0).sum())
+            cov_mask = np.asarray((M_s != 0).sum(0)).ravel() > 0
+            covered = int(cov_mask.sum())
+            n_lines = lines_touched(cov_mask, ld)
+            line_bytes = None if n_lines is None else n_lines * 16 * bpc * T_loc
             result["star_polygons"] = {
                 "ms_per_step": dts / ks * 1e3, "value": T_total * S / (dts / ks),
                 "partial_rows": info_s["n_partial_rows"], "cell_tile": f"{info_s['tile_w']}x{info_s['tile_h']}",
                 "covered_cells": covered, "max_shapes_per_cell": int(np.asarray((M_s != 0).sum(0)).max()),
                 "roofline": roofline_of("star_polygons", bpc * T_loc * covered, kk,
                                         {"note": "algorithmic bytes = 56 B x the cells some shape covers; whole "
-                                                                          "128-byte lines are fetched along the ragged edges (traffic)"}),
+                                                                          "128-byte lines are fetched along the ragged edges (traffic): "
+                                                                          "line_bytes = the 128-byte lines that hold a covered cell, counted "
+                                                                          "on the host from the indicator matrix",
+                                         "lines_128B_per_slot": n_lines, "line_bytes": line_bytes,
+                                         "frac_on_line_bytes": None if not line_bytes else line_bytes / (float(np.mean(kk)) * 1e-3) / 1e9 / PEAK_GBPS}),
             }
+            tr_s = result["star_polygons"]["roofline"].get("traffic")
+            if tr_s and line_bytes:
+                result["star_polygons"]["roofline"]["traffic_over_line_bytes"] = tr_s / line_bytes
             plan = plan_main
         # (3) what a user of the drop-in API waits for: cutout.pv(...) on a device-resident Dataset
         if want("api"):

@@ -1011,3 +1011,30 @@ def test_device_block_recycling_is_ordered_by_events(monkeypatch):
     del x
     assert ctx2.lib.freed == [px] and not [e for e in ctx2.lib.log if e[0] == "record"]
     ctx2.close()
+
+
+def test_bench_counts_the_lines_a_ragged_plan_touches():
+    """bench.py's star-polygon leg prices the kernel on the 128-byte lines that hold a covered cell (what the memory system
+    fetches when lanes skip unweighted cells), next to the covered cells' own bytes."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+
+    cov = np.zeros(64, bool)
+    assert bench.lines_touched(cov, 64) == 0
+    cov[[0, 15, 16, 47]] = True  # lines 0, 1, 2
+    assert bench.lines_touched(cov, 64) == 3
+    assert bench.lines_touched(np.ones(40, bool), 48) == 3  # 40 cells in slots of 48: the last line is half used
+    assert bench.lines_touched(np.ones(17, bool), 17) is None  # slots that do not start on a line: no single count
+    # BASELINE's star polygons on C2's grid: the figure DESIGN.md quotes (2160 lines of 2500, 23758 cells of 40000)
+    from atlite_amd import gis
+
+    X = Y = 200
+    x, y = -25 + (70 / X) * np.arange(X), 30 + (42 / Y) * np.arange(Y)
+    dx, dy = x[1] - x[0], y[1] - y[0]
+    polys = gis.random_star_polygons(100, (x[0] - dx / 2, y[0] - dy / 2, x[-1] + dx / 2, y[-1] + dy / 2), seed=42)
+    M = gis.compute_indicatormatrix(x, y, polys)
+    mask = np.asarray((M != 0).sum(0)).ravel() > 0
+    assert int(mask.sum()) == 23758 and bench.lines_touched(mask, X * Y) == 2160
