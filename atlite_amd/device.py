@@ -288,20 +288,11 @@ class AggPlan:
                                                  data.ctypes.data if data.size else None, C.byref(h)))
             self.handle = h
             return
-        if True:  # the slot stride of the cubes the plan will meet travels with the call (atl_agg_create_ld)
-            check(
-                ctx.lib.atl_agg_create_ld(
-                    ctx.handle,
-                    int(ld) if ld and int(ld) != m.shape[1] else 0,
-                    m.shape[0],
-                    m.shape[1],
-                    int(row_len) if row_len and m.shape[1] % int(row_len) == 0 else 0,
-                    indptr.ctypes.data,
-                    indices.ctypes.data if indices.size else None,
-                    data.ctypes.data if data.size else None,
-                    C.byref(h),
-                )
-            )
+        # the slot stride of the cubes the plan will meet travels with the call (atl_agg_create_ld)
+        check(ctx.lib.atl_agg_create_ld(ctx.handle, int(ld) if ld and int(ld) != m.shape[1] else 0, m.shape[0], m.shape[1],
+                                        int(row_len) if row_len and m.shape[1] % int(row_len) == 0 else 0, indptr.ctypes.data,
+                                        indices.ctypes.data if indices.size else None,
+                                        data.ctypes.data if data.size else None, C.byref(h)))
         self.handle = h
 
     def info(self):
