@@ -283,8 +283,8 @@ struct DevWave {
         v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xF, 0xF, false));  // row_shr:8
         const uint32_t r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47),
                        r3 = __builtin_amdgcn_readlane(v, 63);
-        const uint32_t row = threadIdx.x >> 4;
-        const uint32_t before = row == 0 ? 0u : row == 1 ? r0 : row == 2 ? r0 + r1 : r0 + r1 + r2;
+        const uint32_t row = threadIdx.x >> 4;  // (three selects of scalars: a chain of ?: compiled to exec-mask branches)
+        const uint32_t before = (row > 0u ? r0 : 0u) + (row > 1u ? r1 : 0u) + (row > 2u ? r2 : 0u);
         x.v = v + before - v0;
         return r0 + r1 + r2 + r3;
     }
@@ -321,10 +321,15 @@ struct DevWindow {
             cw0 = nw0;
             primed = true;
         }
-        const uint32_t pre = mine ? gw[nw0 + lane] : 0u;
-        if (lane < 12u) A.wbuf[lane] = cur;
+        // the words of THIS window into LDS first - the one place that waits for the load issued a window ago - and only then
+        // the load for the next window: issued before the store, the compiler's conservative wait (the priming load above
+        // may or may not be outstanding) drained the new load as well, one exposed memory latency per window
+        // (every lane stores - lanes 12 .. 63 into the four spare words behind the twelve: a store under a lane condition
+        //  sits in a branch, and the wait for `cur` inside a branch does not count for the code behind it)
+        A.wbuf[lane < 12u ? lane : 12u + (lane & 3u)] = cur;
         const uint32_t rel = uint32_t(bitpos - uint64_t(cw0) * 32u);
-        cur = pre;
+        __builtin_amdgcn_wave_barrier();
+        cur = mine ? gw[nw0 + lane] : 0u;
         cw0 = nw0;
         return rel;
     }
@@ -346,11 +351,11 @@ struct WaveSink {
     const uint8_t *src8;        // the stream's bytes (stored blocks)
     uint8_t *dst;               // the chunk's output
     __device__ __forceinline__ void tables_ready() { DevWave::sync(); }
-    __device__ void stored(uint64_t byte_pos, uint32_t len, uint64_t out_pos) {
+    __device__ __forceinline__ void stored(uint64_t byte_pos, uint32_t len, uint64_t out_pos) {
         for (uint32_t j = threadIdx.x; j < len; j += 64) dst[out_pos + j] = src8[byte_pos + j];
         __threadfence_block();
     }
-    __device__ void resolve(int n, uint64_t bstart, uint64_t bend) {
+    __device__ __forceinline__ void resolve(int n, uint64_t bstart, uint64_t bend) {
         const uint32_t lane = threadIdx.x;
         const uint32_t bs = uint32_t(bstart), total = uint32_t(bend - bstart);
         ATL_PROF(const unsigned long long c0 = __builtin_readcyclecounter(); ++n_batches; n_syms += unsigned(n);)
@@ -366,8 +371,17 @@ struct WaveSink {
             if (lit) {
                 st[rel] = uint8_t(rec);
             } else if (pos - dist + len <= bs && len <= 16) {  // short, its whole source precedes the batch: on its own
+                // eight source bytes per round trip to memory (a byte loop waits for every load; bytes past the match are
+                // read and dropped: they lie inside the raw buffer, which ends with 256 bytes of slack)
                 const uint8_t *sp = dst + (pos - dist);
-                for (uint32_t j = 0; j < len; ++j) st[rel + j] = sp[j];
+                for (uint32_t j0 = 0; j0 < len; j0 += 8) {
+                    uint8_t b[8];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j) b[j] = sp[j0 + j];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j)
+                        if (j0 + j < len) st[rel + j0 + j] = b[j];
+                }
             } else {
                 coop = true;
             }
