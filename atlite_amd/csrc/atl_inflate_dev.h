@@ -139,6 +139,17 @@ struct HostWave {
         return m;
     }
     static inline void sync() {}
+    // the mask of the lanes 0, jump(0), jump(0) + jump(that lane), ... below 64; *end = the first position >= 64
+    static inline uint64_t chain(Var<uint32_t> &jump, uint32_t *end) {
+        uint32_t s = 0;
+        uint64_t sel = 0;
+        do {
+            sel |= uint64_t(1) << s;
+            s += jump.v[s];
+        } while (s < 64u);
+        *end = s;
+        return sel;
+    }
     // x(k) <- sum of x over the lanes below k; returns the sum over all lanes
     static inline uint32_t excl_scan(Var<uint32_t> &x) {
         uint32_t acc = 0;
@@ -537,11 +548,7 @@ ATL_HD inline int decode_batch_wide(const Areas<M> &A, Win &win, typename M::src
         typename W::template Var<uint32_t> jump;
         W::each([&](int k) { jump(k) = ((info(k) >> 16) & 1u) ? (info(k) & 127u) : 64u; });
         uint32_t s = 0;
-        uint64_t sel = 0;
-        do {
-            sel |= uint64_t(1) << s;
-            s += W::readlane(jump, int(s));
-        } while (s < 64u);
+        const uint64_t sel = W::chain(jump, &s);
         ATL_INF_TICK(win, 2, tk);
         // output bytes before each selected symbol (exclusive prefix sum), its rank among the selected lanes, does it still fit
         typename W::template Var<uint32_t> cum, miss;

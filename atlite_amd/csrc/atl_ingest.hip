@@ -272,6 +272,24 @@ struct DevWave {
     }
     static __device__ __forceinline__ uint32_t readlane(Var<uint32_t> &x, int lane) { return __builtin_amdgcn_readlane(x.v, lane); }
     static __device__ __forceinline__ uint64_t ballot(Var<uint32_t> &x) { return __ballot(x.v != 0); }
+    // The chain of symbol starts (HostWave::chain), four scalar instructions per hop instead of the six the compiler makes of
+    // the C loop (shift + or for the mask, compare + branch for the end): the position is kept as s - 64 (mod 2^32) - the lane
+    // select of v_readlane and the bit index of s_bitset1 use the low six bits, which are those of s - and the add's carry-out
+    // is "s >= 64".  A lone wave pays ~10 cycles per dependent instruction and a window has ~8 hops.
+    static __device__ __forceinline__ uint64_t chain(Var<uint32_t> &jump, uint32_t *end) {
+        uint64_t sel = 0;
+        uint32_t s = 0xFFFFFFC0u, j;
+        asm volatile(".Latl_chain_%=:\n\t"
+                     "s_bitset1_b64 %0, %1\n\t"
+                     "v_readlane_b32 %2, %3, %1\n\t"
+                     "s_add_u32 %1, %1, %2\n\t"
+                     "s_cbranch_scc0 .Latl_chain_%="
+                     : "+s"(sel), "+s"(s), "=&s"(j)
+                     : "v"(jump.v)
+                     : "scc");
+        *end = s + 64u;
+        return sel;
+    }
     // x <- sum of x over the lanes below; returns the wave's total.  Four DPP row shifts scan the rows of 16, the rows'
     // totals come over as scalars
     static __device__ __forceinline__ uint32_t excl_scan(Var<uint32_t> &x) {
