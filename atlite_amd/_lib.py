@@ -127,6 +127,7 @@ class SynthSolar(C.Structure):
         ("X", C.c_int64),
         ("Y", C.c_int64),
         ("seed", C.c_uint64),
+        ("ld_cells", C.c_int64),
     ]
 
 
@@ -259,7 +260,6 @@ SIGNATURES = {
     "atl_order_statistic": (_i, [_vp, _vp, _i64, _i64, _i64, _d, c_int64_p, c_double_p, c_int64_p, c_int64_p]),
     "atl_zero_below": (_i, [_vp, _vp, _i64, _i64, _i64, _d]),
     "atl_normalize_rows": (_i, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
-    "atl_set_slot_stride": (_i, [_vp, _i64]),
     "atl_copy_2d": (_i, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_size_t, _i, _i]),
     "atl_comm_group_create": (_i, [_i, C.POINTER(_vp)]),
     "atl_comm_group_destroy": (_i, [_vp]),

@@ -496,10 +496,11 @@ int device_inflate_emulated(const uint8_t *src, uint64_t src_n, uint8_t *dst, ui
     using namespace dinf;
     std::vector<uint32_t> words(size_t(src_n / 4 + 3), 0u);
     if (src_n) memcpy(words.data(), src, size_t(src_n));
-    std::vector<uint32_t> lit(kLitCap), off(kOffCap), codes(320), cnt(16), nxt(16);
-    std::vector<uint8_t> sub_bits(size_t(1) << kLitBits), lens(512);
-    std::vector<uint32_t> qrec(kQueue), qpos(kQueue + 1), wbuf(16);
-    Areas<HostMem> A{lit.data(), off.data(), codes.data(), cnt.data(), nxt.data(), sub_bits.data(), lens.data(), qrec.data(), qpos.data(), wbuf.data()};
+    std::vector<uint16_t> lit(kLitCap), off(kOffCap), codes(320);
+    std::vector<uint32_t> cnt(16), nxt(16);
+    std::vector<uint8_t> lens(32 + 320);
+    std::vector<uint32_t> qrec(kQueue), qpos(kQueue + 1), wbuf(16), sym(64);
+    Areas<HostMem> A{lit.data(), off.data(), codes.data(), cnt.data(), nxt.data(), lens.data(), qrec.data(), qpos.data(), wbuf.data(), sym.data()};
     HostSink sink{};
     sink.src = reinterpret_cast<const uint8_t *>(words.data());
     sink.dst = dst;

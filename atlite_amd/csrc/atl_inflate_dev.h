@@ -29,15 +29,19 @@
 
 namespace atl { namespace dinf {
 
-// primary table + sub-tables.  zlib's "enough" bounds for this two-level layout: 1332 entries for 286 symbols behind a
-// 10-bit root; distances: 592 behind a 6-bit root, less behind 8 bits.  A code that needs more (none can, for valid streams)
-// fails build_table and the stream goes to the host decoders.  Small tables = more streams resident per CU (LDS).
-constexpr int kLitBits = 10, kLitCap = 1344;
+// primary table + sub-tables.  zlib's "enough" bounds for this two-level layout: 852 entries for 286 symbols behind a
+// 9-bit root; distances: 592 behind a 6-bit root, less behind 8 bits.  A code that needs more (none can, for valid streams)
+// fails build_table and the stream goes to the host decoders.  Small tables = more streams resident per CU: with 16-bit
+// entries (round 6) a stream owns 4.7 kB of LDS instead of 11.4 and 32 of them share a CU (8 waves per SIMD) instead of 14 -
+// a lone wave issues an instruction every ~10 cycles, so residency is throughput.  (The root's width costs nothing here:
+// every lane of the window looks up a speculative bit offset, so some lane lands in a sub-table on nearly every window
+// whatever the root.)
+constexpr int kLitBits = 9, kLitCap = 864;
 constexpr int kOffBits = 8, kOffCap = 640;
 constexpr int kPreBits = 7, kPreCap = 128;
 constexpr int kQueue = 64;                      // records per batch: one per lane
 constexpr int kMaxMatch = 258;
-constexpr int kStage = 2048;                    // output bytes staged per batch (a batch ends once fewer than kMaxMatch are free)
+constexpr int kStage = 1024;                    // output bytes staged per batch (a batch ends once fewer than kMaxMatch are free)
 
 enum Status : int {
     kOk = 0,
@@ -53,15 +57,18 @@ enum Status : int {
     kNotRun = 15,
 };
 
-// table entry: len (6) | extra (4) << 6 | kind (2) << 10 | value << 16
+// table entry, 16 bits: kind (2) | len (4) << 2 | value << 8 - the value is the literal's byte or the INDEX of the length /
+// distance symbol (its base and extra-bit count are computed from it: len_base ... off_extra below) - or, for the link to a
+// sub-table, kind | sub-table bits (3) << 2 | first entry (11) << 5.  0 = no code.
 enum : uint32_t { kBase = 0, kLiteral = 1, kEnd = 2, kSub = 3 };
-ATL_HD inline uint32_t mk(uint32_t len, uint32_t extra, uint32_t kind, uint32_t value) {
-    return len | (extra << 6) | (kind << 10) | (value << 16);
-}
-ATL_HD inline uint32_t e_len(uint32_t e) { return e & 0x3F; }
-ATL_HD inline uint32_t e_extra(uint32_t e) { return (e >> 6) & 0xF; }
-ATL_HD inline uint32_t e_kind(uint32_t e) { return (e >> 10) & 0x3; }
-ATL_HD inline uint32_t e_value(uint32_t e) { return e >> 16; }
+ATL_HD inline uint32_t mk(uint32_t len, uint32_t kind, uint32_t value) { return kind | (len << 2) | (value << 8); }
+ATL_HD inline uint32_t mk_sub(uint32_t bits, uint32_t start) { return uint32_t(kSub) | (bits << 2) | (start << 5); }
+ATL_HD inline uint32_t e_kind(uint32_t e) { return e & 0x3; }
+ATL_HD inline uint32_t e_len(uint32_t e) { return (e >> 2) & 0xF; }
+ATL_HD inline uint32_t e_value(uint32_t e) { return e >> 8; }
+ATL_HD inline uint32_t sub_bits_of(uint32_t e) { return e_kind(e) == kSub ? (e >> 2) & 0x7u : 0u; }  // 0 for anything but a link
+ATL_HD inline uint32_t sub_start(uint32_t e) { return e >> 5; }
+static_assert(15 - kLitBits <= 7 && 15 - kOffBits <= 7 && kLitCap <= 2048 && kOffCap <= 2048, "sub-table links: 3 + 11 bits");
 
 // base values and extra-bit counts of the length / distance symbols, computed (no constant tables to place in device memory)
 ATL_HD inline uint32_t len_extra(int s) {  // s = symbol - 257, 0..28
@@ -94,25 +101,30 @@ ATL_HD inline uint32_t bit_reverse(uint32_t code, int len) {
 enum TableKind { kLitlenTable, kOffsetTable, kPrecodeTable };
 
 ATL_HD inline uint32_t entry_for(TableKind what, int sym, uint32_t len) {
-    if (what == kPrecodeTable) return mk(len, 0, kLiteral, uint32_t(sym));
-    if (what == kOffsetTable) return sym < 30 ? mk(len, off_extra(sym), kBase, off_base(sym)) : 0u;
-    if (sym < 256) return mk(len, 0, kLiteral, uint32_t(sym));
-    if (sym == 256) return mk(len, 0, kEnd, 0);
-    return sym < 286 ? mk(len, len_extra(sym - 257), kBase, len_base(sym - 257)) : 0u;
+    if (what == kPrecodeTable) return mk(len, kLiteral, uint32_t(sym));
+    if (what == kOffsetTable) return sym < 30 ? mk(len, kBase, uint32_t(sym)) : 0u;
+    if (sym < 256) return mk(len, kLiteral, uint32_t(sym));
+    if (sym == 256) return mk(len, kEnd, 0);
+    return sym < 286 ? mk(len, kBase, uint32_t(sym - 257)) : 0u;
 }
 
 // ---- memory policies ---------------------------------------------------------------------------------------------
 struct HostMem {
     typedef uint32_t *u32p;
+    typedef uint16_t *u16p;
     typedef uint8_t *u8p;
     typedef const uint32_t *src_t;
     static inline uint32_t ld32(const uint32_t *p) { return *p; }
     static inline uint32_t ld8(const uint8_t *p) { return *p; }
     static inline void st32(uint32_t *p, uint32_t v) { *p = v; }
     static inline void st8(uint8_t *p, uint32_t v) { *p = uint8_t(v); }
+    static inline uint32_t ld16(const uint16_t *p) { return *p; }
+    static inline void st16(uint16_t *p, uint32_t v) { *p = uint16_t(v); }
     static inline uint32_t src(const uint32_t *w, uint32_t i) { return w[i]; }
     static inline uint32_t ldv32(const uint32_t *p) { return *p; }       // a load / store whose address differs from lane to lane
     static inline void stv32(uint32_t *p, uint32_t v) { *p = v; }
+    static inline uint32_t ldv16(const uint16_t *p) { return *p; }
+    static inline void stv16(uint16_t *p, uint32_t v) { *p = uint16_t(v); }
     static inline uint32_t ldv8(const uint8_t *p) { return *p; }
     static inline void stv8(uint8_t *p, uint32_t v) { *p = uint8_t(v); }
     // "this value is the same in every lane" (device: keeps the decoder's state in scalar registers)
@@ -139,6 +151,9 @@ struct HostWave {
         return m;
     }
     static inline void sync() {}
+    // is lane k in the (wave-uniform) mask; how many lanes of the mask lie below lane k
+    static inline bool in(uint64_t mask, int k) { return (mask >> k) & 1u; }
+    static inline uint32_t below(uint64_t mask, int k) { return uint32_t(__builtin_popcountll(mask & ((uint64_t(1) << k) - 1u))); }
     // the mask of the lanes 0, jump(0), jump(0) + jump(that lane), ... below 64; *end = the first position >= 64
     static inline uint64_t chain(Var<uint32_t> &jump, uint32_t *end) {
         uint32_t s = 0;
@@ -165,17 +180,31 @@ struct HostWave {
 // LDS areas of one stream's decoder (device: carved out of the workgroup's shared memory; host: a struct on the heap)
 template <class M>
 struct Areas {
-    typename M::u32p lit;      // [kLitCap]
-    typename M::u32p off;      // [kOffCap]  (its first kPreCap entries double as the precode table while a header is parsed)
-    typename M::u32p codes;    // [320]  bit-reversed code of every symbol (table construction)
+    typename M::u16p lit;      // [kLitCap]
+    typename M::u16p off;      // [kOffCap]  (its first kPreCap entries double as the precode table while a header is parsed)
+    typename M::u16p codes;    // [320]  bit-reversed code of every symbol (table construction; shares the staging area's space)
     typename M::u32p cnt;      // [16]   codes per length
     typename M::u32p nxt;      // [16]   next code per length
-    typename M::u8p sub_bits;  // [1 << kLitBits] widest long code behind a primary slot
-    typename M::u8p lens;      // [286 + 30 + 138] code lengths of the block
+    typename M::u8p lens;      // [32 + 320] code lengths of the block (table construction; shares the staging area's space)
     typename M::u32p qrec;     // [kQueue] records of the current batch: literal = kLitFlag | byte, match = length | distance << 9
     typename M::u32p qpos;     // [kQueue + 1] ... and where in the output each begins (+ a slot nobody reads)
     typename M::u32p wbuf;     // [16] the stream's words under the current window
+    typename M::u32p sym;      // [64] base | extra bits << 16 of the length symbols (0 .. 28) and, from 32 on, the distance symbols (0 .. 29)
 };
+
+// the 64 entries of Areas::sym, one per lane (init_sym): a table entry carries the symbol's INDEX (16-bit entries), its base
+// value and extra-bit count are one more LDS gather - the arithmetic (len_base ... off_extra) was ~20 vector instructions of
+// the ~150 a 64-bit window costs, and at 8 waves per SIMD the decoder is bound by the vector ALU's issue rate
+ATL_HD inline uint32_t sym_entry(int k) {
+    if (k < 29) return len_base(k) | (len_extra(k) << 16);
+    if (k >= 32 && k < 62) return off_base(k - 32) | (off_extra(k - 32) << 16);
+    return 0u;
+}
+template <class M, class W>
+ATL_HD inline void init_sym(const Areas<M> &A) {
+    W::each([&](int k) { M::stv32(A.sym + k, sym_entry(k)); });
+    W::sync();
+}
 
 // canonical Huffman decode table, single lookup + one sub-table level.  Returns false for an invalid code.
 // Built by the whole wave (round 5; the serial version cost a fifth of a stream's time): lane k owns the symbols k, k + 64, ...
@@ -184,15 +213,12 @@ struct Areas {
 // and the widest long code behind a primary slot (a loop over the long codes, few).
 template <class M, class W>
 ATL_HD inline bool build_table(const Areas<M> &A, typename M::u8p lens, int n, int table_bits, int cap, TableKind what,
-                               typename M::u32p table) {
+                               typename M::u16p table) {
     const uint32_t tsize = 1u << table_bits;
     const int n_chunks = (n + 63) / 64;
     for (int l = 0; l < 16; ++l) M::st32(A.cnt + l, 0);
     W::each([&](int k) {
-        for (uint32_t i = uint32_t(k); i < tsize; i += 64u) {
-            M::stv32(table + i, 0);  // len 0 = invalid
-            M::stv8(A.sub_bits + i, 0);
-        }
+        for (uint32_t i = uint32_t(k); i < tsize; i += 64u) M::stv16(table + i, 0);  // 0 = no code
     });
     W::sync();
     // rank of every symbol among the symbols of its length (symbol order), the counts per length on the way
@@ -209,13 +235,13 @@ ATL_HD inline bool build_table(const Areas<M> &A, typename M::u8p lens, int n, i
             if (!m) continue;
             const uint32_t base = M::ld32(A.cnt + l);
             W::each([&](int k) {
-                if (len(k) == l) rank(k) = base + uint32_t(__builtin_popcountll(m & ((uint64_t(1) << k) - 1u)));
+                if (len(k) == l) rank(k) = base + W::below(m, k);
             });
             M::st32(A.cnt + l, base + uint32_t(__builtin_popcountll(m)));
         }
         W::each([&](int k) {
             const int i = 64 * c + k;
-            if (i < n) M::stv32(A.codes + i, rank(k));
+            if (i < n) M::stv16(A.codes + i, rank(k));
         });
     }
     W::sync();
@@ -244,11 +270,11 @@ ATL_HD inline bool build_table(const Areas<M> &A, typename M::u8p lens, int n, i
             lng(k) = 0;
             const uint32_t l = i < n ? (M::ldv8(lens + i) & 15u) : 0u;
             if (l) {
-                const uint32_t r = bit_reverse(M::ldv32(A.nxt + l) + M::ldv32(A.codes + i), int(l));
-                M::stv32(A.codes + i, r);
+                const uint32_t r = bit_reverse(M::ldv32(A.nxt + l) + M::ldv16(A.codes + i), int(l));
+                M::stv16(A.codes + i, r);
                 if (l <= uint32_t(table_bits)) {
                     const uint32_t e = entry_for(what, i, l);
-                    for (uint32_t j = r; j < tsize; j += 1u << l) M::stv32(table + j, e);
+                    for (uint32_t j = r; j < tsize; j += 1u << l) M::stv16(table + j, e);
                 } else {
                     lng(k) = 1;
                 }
@@ -256,11 +282,12 @@ ATL_HD inline bool build_table(const Areas<M> &A, typename M::u8p lens, int n, i
         });
         const uint64_t m = W::ballot(lng);
         any_long |= m;
-        // the widest long code behind each primary slot: several codes share a slot, so one after the other
+        // the widest long code behind each primary slot, kept in the slot itself as a link without a start (a prefix code: no
+        // short code's entry lies there): several codes share a slot, so one after the other
         for (uint64_t t = m; t; t &= t - 1) {
             const int i = 64 * c + __builtin_ctzll(t);
-            const uint32_t l = M::ld8(lens + i) & 15u, pslot = M::ld32(A.codes + i) & (tsize - 1);
-            if (l - uint32_t(table_bits) > M::ld8(A.sub_bits + pslot)) M::st8(A.sub_bits + pslot, l - uint32_t(table_bits));
+            const uint32_t l = M::ld8(lens + i) & 15u, pslot = M::ld16(A.codes + i) & (tsize - 1);
+            if (l - uint32_t(table_bits) > sub_bits_of(M::ld16(table + pslot))) M::st16(table + pslot, mk_sub(l - uint32_t(table_bits), 0));
         }
     }
     if (!any_long) {
@@ -269,12 +296,12 @@ ATL_HD inline bool build_table(const Areas<M> &A, typename M::u8p lens, int n, i
     }
     W::sync();
     // sub-tables: lane k lays out the ones behind its run of primary slots, one after the other from where the lanes below end
-    const uint32_t per = tsize / 64u;  // primary slots per lane (16, 4 or 2)
+    const uint32_t per = tsize / 64u;  // primary slots per lane (8, 4 or 2)
     typename W::template Var<uint32_t> room;
     W::each([&](int k) {
         uint32_t sum = 0;
         for (uint32_t q = 0; q < per; ++q) {
-            const uint32_t sb = M::ldv8(A.sub_bits + uint32_t(k) * per + q);
+            const uint32_t sb = sub_bits_of(M::ldv16(table + uint32_t(k) * per + q));
             sum += sb ? 1u << sb : 0u;
         }
         room(k) = sum;
@@ -284,10 +311,10 @@ ATL_HD inline bool build_table(const Areas<M> &A, typename M::u8p lens, int n, i
     W::each([&](int k) {
         uint32_t pos = tsize + room(k);
         for (uint32_t q = 0; q < per; ++q) {
-            const uint32_t pslot = uint32_t(k) * per + q, sb = M::ldv8(A.sub_bits + pslot);
+            const uint32_t pslot = uint32_t(k) * per + q, sb = sub_bits_of(M::ldv16(table + pslot));
             if (!sb) continue;
-            M::stv32(table + pslot, mk(uint32_t(table_bits), sb, kSub, pos));
-            for (uint32_t j = 0; j < (1u << sb); ++j) M::stv32(table + pos + j, 0);
+            M::stv16(table + pslot, mk_sub(sb, pos));
+            for (uint32_t j = 0; j < (1u << sb); ++j) M::stv16(table + pos + j, 0);
             pos += 1u << sb;
         }
     });
@@ -298,9 +325,9 @@ ATL_HD inline bool build_table(const Areas<M> &A, typename M::u8p lens, int n, i
             const int i = 64 * c + k;
             const uint32_t l = i < n ? (M::ldv8(lens + i) & 15u) : 0u;
             if (l > uint32_t(table_bits)) {
-                const uint32_t r = M::ldv32(A.codes + i), link = M::ldv32(table + (r & (tsize - 1)));
-                const uint32_t start = e_value(link), sb = e_extra(link), e = entry_for(what, i, l - uint32_t(table_bits));
-                for (uint32_t j = r >> table_bits; j < (1u << sb); j += 1u << (l - uint32_t(table_bits))) M::stv32(table + start + j, e);
+                const uint32_t r = M::ldv16(A.codes + i), link = M::ldv16(table + (r & (tsize - 1)));
+                const uint32_t start = sub_start(link), sb = sub_bits_of(link), e = entry_for(what, i, l - uint32_t(table_bits));
+                for (uint32_t j = r >> table_bits; j < (1u << sb); j += 1u << (l - uint32_t(table_bits))) M::stv16(table + start + j, e);
             }
         });
     }
@@ -387,7 +414,7 @@ ATL_HD inline int dynamic_tables(const Areas<M> &A, Bits<M> &b) {
         }
         M::st8(A.lens + o, v);
     }
-    typename M::u32p pre = A.off;  // the offset table's space: it is rebuilt after the lengths have been read
+    typename M::u16p pre = A.off;  // the offset table's space: it is rebuilt after the lengths have been read
     if (!build_table<M, W>(A, A.lens, 19, kPreBits, kPreCap, kPrecodeTable, pre)) return kBadCode;
     // the code lengths of both alphabets as one run-length coded sequence (kept past the precode's 19 bytes)
     typename M::u8p lens = A.lens + 32;
@@ -396,7 +423,7 @@ ATL_HD inline int dynamic_tables(const Areas<M> &A, Bits<M> &b) {
     uint32_t last = 0;
     while (i < total) {
         b.refill();
-        const uint32_t e = M::ld32(pre + b.peek(kPreBits));
+        const uint32_t e = M::ld16(pre + b.peek(kPreBits));
         const int l = int(e_len(e));
         if (!l) return kBadCode;
         b.drop(l);
@@ -432,7 +459,7 @@ ATL_HD inline int dynamic_tables(const Areas<M> &A, Bits<M> &b) {
     if (any_off) {
         if (!build_table<M, W>(A, lens + hlit, hdist, kOffBits, kOffCap, kOffsetTable, A.off)) return kBadCode;
     } else {  // a block of literals only may carry an empty offset code
-        for (int k = 0; k < (1 << kOffBits); ++k) M::st32(A.off + k, 0);
+        for (int k = 0; k < (1 << kOffBits); ++k) M::st16(A.off + k, 0);
     }
     return kOk;
 }
@@ -457,8 +484,15 @@ struct LaneSym {
     uint32_t info, rec;
 };
 
-// bits [sh, sh + 32) of the 64-bit value hi:lo, sh < 32 (one v_alignbit_b32 on the device)
-ATL_HD inline uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh) { return uint32_t(((uint64_t(hi) << 32) | lo) >> sh); }
+// bits [sh, sh + 32) of the 64-bit value hi:lo, sh < 32: one full-rate v_alignbit_b32 on the device (left to itself the
+// compiler merged the window's three funnels into 64-bit shifts, which the vector ALU runs at a fraction of the rate)
+ATL_HD inline uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return uint32_t(((uint64_t(hi) << 32) | lo) >> sh);
+#endif
+}
 ATL_HD inline uint32_t low32(uint32_t v, uint32_t n) { return v & ((1u << n) - 1u); }  // n <= 16
 
 // the symbol that starts at bit 0 of the 64 stream bits bhi:blo (a symbol takes at most 15 + 5 + 15 + 13 = 48): the literal /
@@ -466,33 +500,34 @@ ATL_HD inline uint32_t low32(uint32_t v, uint32_t n) { return v & ((1u << n) - 1
 template <class M>
 ATL_HD inline LaneSym decode_at(const Areas<M> &A, uint32_t blo, uint32_t bhi) {
     const LaneSym none{0u, 0u};
-    uint32_t e = M::ldv32(A.lit + low32(blo, kLitBits));
+    uint32_t e = M::ldv16(A.lit + low32(blo, kLitBits));
     uint32_t used = 0;
     if (e_kind(e) == kSub) {
         used = kLitBits;
-        const uint32_t ix = e_value(e) + low32(blo >> kLitBits, e_extra(e));
-        e = M::ldv32(A.lit + (ix < uint32_t(kLitCap) ? ix : uint32_t(kLitCap - 1)));
+        const uint32_t ix = sub_start(e) + low32(blo >> kLitBits, sub_bits_of(e));
+        e = M::ldv16(A.lit + (ix < uint32_t(kLitCap) ? ix : uint32_t(kLitCap - 1)));
     }
     const uint32_t l = e_len(e), kind = e_kind(e);
-    if (!l) return none;
+    if (!l || kind == kSub) return none;  // (a sub-table link inside a sub-table: never built)
     used += l;
     if (kind == kLiteral) return LaneSym{used | (1u << 7) | (1u << 16), kLitFlag | e_value(e)};
     if (kind == kEnd) return LaneSym{used | (2u << 16), 0u};
-    if (kind != kBase) return none;  // a sub-table link inside a sub-table: never built
-    const uint32_t x = e_extra(e), length = e_value(e) + low32(blo >> used, x);
+    const uint32_t lt = M::ldv32(A.sym + (e_value(e) & 31u));  // index of the length symbol, 0..28
+    const uint32_t x = lt >> 16, length = (lt & 0xFFFFu) + low32(blo >> used, x);
     used += x;                                    // <= 20
     const uint32_t b2 = funnel(bhi, blo, used);  // the 32 bits behind the length: distance code (<= 15) + extra (<= 13)
-    uint32_t o = M::ldv32(A.off + low32(b2, kOffBits));
+    uint32_t o = M::ldv16(A.off + low32(b2, kOffBits));
     uint32_t used2 = 0;
     if (e_kind(o) == kSub) {
         used2 = kOffBits;
-        const uint32_t ix = e_value(o) + low32(b2 >> kOffBits, e_extra(o));
-        o = M::ldv32(A.off + (ix < uint32_t(kOffCap) ? ix : uint32_t(kOffCap - 1)));
+        const uint32_t ix = sub_start(o) + low32(b2 >> kOffBits, sub_bits_of(o));
+        o = M::ldv16(A.off + (ix < uint32_t(kOffCap) ? ix : uint32_t(kOffCap - 1)));
     }
     const uint32_t lo = e_len(o);
     if (!lo || e_kind(o) != kBase) return none;
     used2 += lo;
-    const uint32_t ox = e_extra(o), dist = e_value(o) + low32(b2 >> used2, ox);
+    const uint32_t ot = M::ldv32(A.sym + 32 + (e_value(o) & 31u));  // the distance symbol, 0..29
+    const uint32_t ox = ot >> 16, dist = (ot & 0xFFFFu) + low32(b2 >> used2, ox);
     used2 += ox;
     return LaneSym{(used + used2) | (length << 7) | (3u << 16), length | (dist << 9)};
 }
@@ -552,13 +587,13 @@ ATL_HD inline int decode_batch_wide(const Areas<M> &A, Win &win, typename M::src
         ATL_INF_TICK(win, 2, tk);
         // output bytes before each selected symbol (exclusive prefix sum), its rank among the selected lanes, does it still fit
         typename W::template Var<uint32_t> cum, miss;
-        W::each([&](int k) { cum(k) = (((sel >> k) & 1u) && ((info(k) >> 16) & 1u)) ? ((info(k) >> 7) & 511u) : 0u; });
+        W::each([&](int k) { cum(k) = (W::in(sel, k) && ((info(k) >> 16) & 1u)) ? ((info(k) >> 7) & 511u) : 0u; });
         uint32_t rel_add = W::excl_scan(cum);  // output bytes of the window's symbols (all of them, unless the batch ends inside)
         typename W::template Var<uint32_t> rank;
         W::each([&](int k) {
-            const bool selected = (sel >> k) & 1u, sym = (info(k) >> 16) & 1u;
+            const bool selected = W::in(sel, k), sym = (info(k) >> 16) & 1u;
             const uint32_t olen = (info(k) >> 7) & 511u;
-            rank(k) = uint32_t(__builtin_popcountll(sel & ((uint64_t(1) << k) - 1u)));
+            rank(k) = W::below(sel, k);
             const bool fits = sym && n + rank(k) < uint32_t(kQueue) && rel_out + cum(k) + olen <= uint32_t(kStage);
             miss(k) = (selected && !fits) ? 1u : 0u;
         });
@@ -585,7 +620,7 @@ ATL_HD inline int decode_batch_wide(const Areas<M> &A, Win &win, typename M::src
         typename W::template Var<uint32_t> bad;
         W::each([&](int k) {
             bad(k) = 0;
-            if ((keep >> k) & 1u) {
+            if (W::in(keep, k)) {
                 const uint32_t q = n + rank(k);  // (the lanes below a kept lane are all kept)
                 const uint32_t r = rec(k), p = bstart + rel_out + cum(k);
                 M::stv32(A.qrec + q, r);
@@ -628,6 +663,7 @@ ATL_HD inline int inflate_stream(const Areas<M> &A, typename M::src_t w, uint32_
                                  uint32_t *adler_want) {
     if (src_n < 6 || n_words == 0) return kBadHeader;
     if (!zlib_header_ok(M::src(w, 0))) return kBadHeader;
+    init_sym<M, W>(A);
     Bits<M> b;
     b.start(w, n_words, 16);
     Win win;

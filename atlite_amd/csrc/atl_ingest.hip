@@ -186,12 +186,34 @@ struct UnpackParams {
     Decode dec;
 };
 
+// one element of a chunk: raw little- or big-endian bytes (byte-shuffled or not) -> CF-decoded double
+__device__ __forceinline__ double unpack_value(const uint8_t *__restrict__ src, int64_t n, int64_t e, int shuffled, const Decode &dec) {
+    const int es = dec.esize;
+    uint64_t b = 0;
+    if (shuffled) {
+        // byte k of element e sits at k*n + e: es coalesced byte streams
+        for (int k = 0; k < es; ++k) {
+            const int dstk = dec.big_endian ? es - 1 - k : k;
+            b |= uint64_t(src[int64_t(k) * n + e]) << (8 * dstk);
+        }
+    } else if (es == 4 && !dec.big_endian) {
+        b = reinterpret_cast<const uint32_t *>(src)[e];
+    } else if (es == 8 && !dec.big_endian) {
+        b = reinterpret_cast<const uint64_t *>(src)[e];
+    } else {
+        for (int k = 0; k < es; ++k) {
+            const int dstk = dec.big_endian ? es - 1 - k : k;
+            b |= uint64_t(src[e * es + k]) << (8 * dstk);
+        }
+    }
+    return cf_decode(bits_to_double(b, dec.dtype), dec);
+}
+
 __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ raw, const UnpackDesc *__restrict__ desc,
                                                 UnpackParams p, double *__restrict__ out) {
     const UnpackDesc d = desc[blockIdx.y];
     const int64_t n = d.dim[0] * d.dim[1] * d.dim[2];
     const int64_t plane = d.dim[1] * d.dim[2];
-    const int es = p.dec.esize;
     const uint8_t *src = raw + d.src_off;
     for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += int64_t(gridDim.x) * blockDim.x) {
         const int64_t ct = e / plane, rem = e - ct * plane;
@@ -202,41 +224,96 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ raw,
         if (d.missing) {
             v = p.dec.has_fill ? cf_decode(p.dec.fill, p.dec) : __builtin_nan("");
         } else {
-            uint64_t b = 0;
-            if (d.shuffled) {
-                // byte k of element e sits at k*n + e: es coalesced byte streams
-                for (int k = 0; k < es; ++k) {
-                    const int dstk = p.dec.big_endian ? es - 1 - k : k;
-                    b |= uint64_t(src[int64_t(k) * n + e]) << (8 * dstk);
-                }
-            } else if (es == 4 && !p.dec.big_endian) {
-                b = reinterpret_cast<const uint32_t *>(src)[e];
-            } else if (es == 8 && !p.dec.big_endian) {
-                b = reinterpret_cast<const uint64_t *>(src)[e];
-            } else {
-                for (int k = 0; k < es; ++k) {
-                    const int dstk = p.dec.big_endian ? es - 1 - k : k;
-                    b |= uint64_t(src[e * es + k]) << (8 * dstk);
-                }
-            }
-            v = cf_decode(bits_to_double(b, p.dec.dtype), p.dec);
+            v = unpack_value(src, n, e, d.shuffled, p.dec);
         }
         out[(t - p.r0) * p.ld + y * p.shape2 + x] = v;
     }
 }
 
+// The same by ONE wavefront, row by row of the chunk (no per-element division): what a k_inflate wave does with the chunk it has
+// just inflated (round 6) - the chunk's bytes are still in the L2, and a separate k_unpack pass over a year of C2 was 19-27 ms
+// at the end of a read that nothing could overlap with.
+__device__ __forceinline__ void wave_unpack(const uint8_t *__restrict__ raw, const UnpackDesc &d, const UnpackParams &p, double *__restrict__ out) {
+    const uint32_t lane = threadIdx.x;
+    const int64_t n = d.dim[0] * d.dim[1] * d.dim[2];
+    const uint8_t *src = raw + d.src_off;
+    const uint32_t rows = uint32_t(d.dim[0] * d.dim[1]), dim1 = uint32_t(d.dim[1]), dim2 = uint32_t(d.dim[2]);
+    uint32_t ct = 0, cy = 0;
+    for (uint32_t r = 0; r < rows; ++r) {
+        const int64_t t = d.org[0] + ct, y = d.org[1] + cy;
+        if (t >= p.r0 && t < p.r1 && y < p.shape1) {
+            double *orow = out + (t - p.r0) * p.ld + y * p.shape2 + d.org[2];
+            const int64_t e0 = int64_t(r) * dim2;
+            for (uint32_t cx = lane; cx < dim2; cx += 64)
+                if (d.org[2] + cx < p.shape2) orow[cx] = unpack_value(src, n, e0 + cx, d.shuffled, p.dec);
+        }
+        if (++cy == dim1) {
+            cy = 0;
+            ++ct;
+        }
+    }
+}
+
+// Adler-32 of n bytes at p (16-byte aligned) by one wavefront: s1 = 1 + sum b_i, s2 = n + sum (n - i) b_i (mod 65521)
+// (chunks <= 64 MiB: the weighted sum stays below 2^60)
+__device__ __forceinline__ uint32_t wave_adler(const uint8_t *__restrict__ p, uint64_t n) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t n16 = n / 16;
+    unsigned long long s1 = 0, s2 = 0;
+    for (uint64_t i = lane; i < n16; i += 64) {
+        const uint4 v = reinterpret_cast<const uint4 *>(p)[i];
+        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+        uint32_t sum = 0, wsum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t b = (wds[q] >> (8 * k)) & 0xFFu;
+                sum += b;
+                wsum += uint32_t(4 * q + k) * b;
+            }
+        s1 += sum;
+        s2 += (n - i * 16) * sum - wsum;
+    }
+    for (uint64_t i = n16 * 16 + lane; i < n; i += 64) {
+        s1 += p[i];
+        s2 += (n - i) * p[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    const uint32_t a = uint32_t((1 + s1) % 65521ull), b = uint32_t((n % 65521ull + s2 % 65521ull) % 65521ull);
+    return (b << 16) | a;
+}
+
 // ---- DEFLATE on the device: one wave per chunk stream (serial half: atl_inflate_dev.h) ---------------------------
 struct InfDesc {
-    int64_t src_off, src_n;  // zlib stream inside the compressed buffer (src_off 16-byte aligned, padded to whole words)
+    int64_t src_off, src_n;  // zlib stream inside the compressed buffer (src_off 128-byte aligned: no cache line holds two streams)
     int64_t dst_off, dst_n;  // inflated chunk inside the raw buffer (16-byte aligned)
+    uint32_t part, desc;     // the stream's variable (FedPart) and its chunk (UnpackDesc): the wave unpacks what it inflated
+    uint32_t batch;          // fed launches: the stream's bytes are on the device once flags[batch * kFlagPitch] != 0; kNoWait: they are
+    uint32_t pad;
+};
+constexpr uint32_t kNoWait = 0xFFFFFFFFu;
+constexpr uint32_t kFlagPitch = 32;   // words between the batches' arrival flags (a 128-byte line each: polled by different waves)
+constexpr uint32_t kFlagReady = 1u, kFlagAbort = 2u;
+
+struct FedPart {  // one variable of a read, as the device sees it
+    UnpackParams p;
+    double *out;
 };
 struct InfResult {
     int32_t status;       // dinf::Status
     uint32_t adler_want;  // the stream's trailer; k_adler compares
 };
 
+#ifndef ATL_INFLATE_WAVES
+#define ATL_INFLATE_WAVES 8  // resident streams per SIMD the register allocation aims at (LDS allows 8)
+#endif
 struct WaveMem {
     typedef __attribute__((address_space(3))) uint32_t *u32p;
+    typedef __attribute__((address_space(3))) uint16_t *u16p;
     typedef __attribute__((address_space(3))) uint8_t *u8p;
     typedef __attribute__((address_space(4))) const uint32_t *src_t;  // read-only for the kernel's lifetime: scalar loads
     // every lane reads the same LDS word; the value continues in an SGPR
@@ -247,11 +324,15 @@ struct WaveMem {
     // exec-mask branches instead of SGPRs and scalar branches: measured 0.8 MB/s per stream.)
     static __device__ __forceinline__ void st32(u32p p, uint32_t v) { *p = v; }
     static __device__ __forceinline__ void st8(u8p p, uint32_t v) { *p = uint8_t(v); }
+    static __device__ __forceinline__ uint32_t ld16(u16p p) { return __builtin_amdgcn_readfirstlane(uint32_t(*p)); }
+    static __device__ __forceinline__ void st16(u16p p, uint32_t v) { *p = uint16_t(v); }
     static __device__ __forceinline__ uint32_t src(src_t w, uint32_t i) { return w[__builtin_amdgcn_readfirstlane(i)]; }
     static __device__ __forceinline__ uint32_t ldv32(u32p p) { return *p; }  // per-lane addresses: an LDS gather / scatter
     static __device__ __forceinline__ void stv32(u32p p, uint32_t v) { *p = v; }
     static __device__ __forceinline__ uint32_t ldv8(u8p p) { return *p; }
     static __device__ __forceinline__ void stv8(u8p p, uint32_t v) { *p = uint8_t(v); }
+    static __device__ __forceinline__ uint32_t ldv16(u16p p) { return *p; }
+    static __device__ __forceinline__ void stv16(u16p p, uint32_t v) { *p = uint16_t(v); }
     static __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
     static __device__ __forceinline__ int uni(int v) { return int(__builtin_amdgcn_readfirstlane(uint32_t(v))); }
     static __device__ __forceinline__ uint64_t uni(uint64_t v) {
@@ -272,6 +353,12 @@ struct DevWave {
     }
     static __device__ __forceinline__ uint32_t readlane(Var<uint32_t> &x, int lane) { return __builtin_amdgcn_readlane(x.v, lane); }
     static __device__ __forceinline__ uint64_t ballot(Var<uint32_t> &x) { return __ballot(x.v != 0); }
+    // a wave-uniform 64-bit value AS the lane mask (one operand of a v_cndmask instead of two ands and a 64-bit compare per
+    // use); the lanes of it below this one: v_mbcnt_lo / _hi
+    static __device__ __forceinline__ bool in(uint64_t mask, int) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+    static __device__ __forceinline__ uint32_t below(uint64_t mask, int) {
+        return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+    }
     // The chain of symbol starts (HostWave::chain), four scalar instructions per hop instead of the six the compiler makes of
     // the C loop (shift + or for the mask, compare + branch for the end): the position is kept as s - 64 (mod 2^32) - the lane
     // select of v_readlane and the bit index of s_bitset1 use the low six bits, which are those of s - and the add's carry-out
@@ -438,29 +525,70 @@ struct WaveSink {
     }
 };
 
-__global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp, const InfDesc *__restrict__ desc,
-                                                uint8_t *__restrict__ raw, InfResult *__restrict__ res) {
+// FED launches (round 6).  The kernel is launched BEFORE the compressed bytes are on the device: the host preads them batch by
+// batch into a small page-locked ring, each batch is one DMA, and when the DMA's event has completed the host sets the batch's
+// arrival flag; a wave waits for its stream's flag (s_sleep between polls, backing off) before it starts.  pread, DMA, inflate,
+// checksum and unpack of one read overlap INSIDE one launch - launches from different HIP streams do not (rocprofv3: they run one
+// or two at a time, and a launch costs a stream's ~100 ms whatever it holds).
+// What can reach a running kernel whose waiting waves fill every wave slot was measured (tools/probes/feed_probe.hip,
+// profiles/r06_ingest.txt): bulk DMAs do (the copy engines need no compute unit: 64 MiB in 10 ms), 4-byte DMAs do NOT (the
+// runtime copies small transfers with a blit kernel, which finds no free slot until the waves time out - a first version that
+// set the flags that way stalled for the whole time-out as soon as a read had more streams than the device holds), a CPU store
+// to page-locked host memory that the waves poll across PCIe does, at once.  Hence: flags in the slot's page-locked block, set
+// by the CPU.  A wave still gives up after a time-out ($ATLITE_HIP_INGEST_TIMEOUT_MS, default 20 s; status kNotRun: the host
+// decoders take the stream), so a stalled host can never hang the device.
+__device__ __forceinline__ bool wait_for_batch(const uint32_t *__restrict__ flags, uint32_t batch, unsigned long long timeout_ticks) {
+    const uint32_t *f = flags + size_t(batch) * kFlagPitch;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t naps = 1;  // s_sleep(127) ~ 3.4 us each; the gap between polls grows by an eighth per poll up to ~0.9 ms: a wave that
+                        // waits 100 ms for a late batch crosses PCIe ~140 times, the 8192 of them together < 1 GB/s
+    for (;;) {
+        const uint32_t v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        if (v == kFlagReady) break;
+        if (v == kFlagAbort || __builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) return false;  // (100 MHz ticks)
+        for (uint32_t k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(127);
+        naps = min(naps + (naps >> 3) + 1u, 256u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // the DMA's bytes, not an older image of the staging buffer, from here on
+    __builtin_amdgcn_s_dcache_inv();               // ... through the scalar cache too (the bit reader's s_load)
+    return true;
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ATL_INFLATE_WAVES, ATL_INFLATE_WAVES))) void k_inflate(
+    const uint8_t *__restrict__ comp, const InfDesc *__restrict__ desc, uint8_t *__restrict__ raw, InfResult *__restrict__ res,
+    const uint32_t *__restrict__ flags, const FedPart *__restrict__ parts, const UnpackDesc *__restrict__ unp, unsigned long long timeout_ticks) {
     using namespace dinf;
-    __shared__ uint32_t s_lit[kLitCap];
-    __shared__ uint32_t s_off[kOffCap];
-    __shared__ uint32_t s_tmp[320 + 256];  // codes | sub_bits while a table is built; the staging area while symbols are decoded
+    // 4.7 kB per stream: 32 streams share a CU's 160 KiB (8 waves per SIMD - the register budget of that is 64 VGPRs, which
+    // amdgpu_waves_per_eu above asks the compiler for)
+    __shared__ uint16_t s_lit[kLitCap];
+    __shared__ uint16_t s_off[kOffCap];
+    constexpr int kTmpWords = (kStage + 4 > 640 + 352 ? kStage + 4 : 640 + 352) / 4 + 1;
+    __shared__ uint32_t s_tmp[kTmpWords];  // codes | code lengths while a table is built; the staging area while symbols are decoded
     __shared__ uint32_t s_cnt[32];
-    __shared__ uint32_t s_lens[128];
     __shared__ uint32_t s_q[2 * kQueue + 1 + 16];  // records | positions (+ 1) | window words
-    static_assert(sizeof(s_tmp) >= size_t(kStage), "staging area");
+    __shared__ uint32_t s_sym[64];                 // base | extra bits of the length and distance symbols
+    static_assert(sizeof(s_tmp) >= size_t(kStage) + 4, "staging area");
+    static_assert(sizeof(s_lit) + sizeof(s_off) + sizeof(s_tmp) + sizeof(s_cnt) + sizeof(s_q) + sizeof(s_sym) <= 5120, "32 streams per CU");
     const InfDesc d = desc[blockIdx.x];
+    if (d.batch != kNoWait && !wait_for_batch(flags, d.batch, timeout_ticks)) {
+        if (threadIdx.x == 0) {
+            res[blockIdx.x].status = kNotRun;
+            res[blockIdx.x].adler_want = 0;
+        }
+        return;
+    }
     ATL_PROF(const unsigned long long t_start = __builtin_readcyclecounter();)
     Areas<WaveMem> A;
-    A.lit = (WaveMem::u32p)s_lit;
-    A.off = (WaveMem::u32p)s_off;
-    A.codes = (WaveMem::u32p)s_tmp;
-    A.sub_bits = (WaveMem::u8p)(s_tmp + 320);
+    A.lit = (WaveMem::u16p)s_lit;
+    A.off = (WaveMem::u16p)s_off;
+    A.codes = (WaveMem::u16p)s_tmp;
     A.cnt = (WaveMem::u32p)s_cnt;
     A.nxt = (WaveMem::u32p)(s_cnt + 16);
-    A.lens = (WaveMem::u8p)s_lens;
+    A.lens = (WaveMem::u8p)(s_tmp + 160);  // behind the 320 codes
     A.qrec = (WaveMem::u32p)s_q;
     A.qpos = (WaveMem::u32p)(s_q + kQueue);
     A.wbuf = (WaveMem::u32p)(s_q + 2 * kQueue + 1);
+    A.sym = (WaveMem::u32p)s_sym;
     WaveSink sink;
     sink.qrec = A.qrec;
     sink.qpos = A.qpos;
@@ -468,8 +596,15 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
     sink.src8 = comp + d.src_off;
     sink.dst = raw + d.dst_off;
     uint32_t want = 0;
-    const int st = inflate_stream<WaveMem, DevWave, DevWindow, WaveSink>(A, (WaveMem::src_t)(comp + d.src_off), uint32_t((d.src_n + 3) / 4),
-                                                     uint64_t(d.src_n), uint64_t(d.dst_n), sink, &want);
+    int st = inflate_stream<WaveMem, DevWave, DevWindow, WaveSink>(A, (WaveMem::src_t)(comp + d.src_off), uint32_t((d.src_n + 3) / 4),
+                                                               uint64_t(d.src_n), uint64_t(d.dst_n), sink, &want);
+    // the chunk's Adler-32 and, if it is the stream's, the chunk's elements into the block the conversion kernels read (un-shuffle,
+    // widen, CF-decode, scatter) - by the wave that has just written the bytes: they are in its XCD's L2
+    if (st == kOk) {
+        __threadfence_block();
+        if (wave_adler(raw + d.dst_off, uint64_t(d.dst_n)) != want) st = kAdler;
+    }
+    if (st == kOk && parts) wave_unpack(raw, unp[d.desc], parts[d.part].p, parts[d.part].out);
     if (threadIdx.x == 0) {
         res[blockIdx.x].status = st;
         res[blockIdx.x].adler_want = want;
@@ -480,52 +615,6 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
                blockIdx.x, gridDim.x, (long long)d.dst_n, (long long)d.src_n, total, sink.t_res_total, sink.t_p1, sink.t_coop, sink.t_flush, sink.t_fence,
                sink.n_batches, sink.n_syms, sink.n_lit, sink.n_short, sink.n_coop, sink.n_far);
     })
-}
-
-// Adler-32 of every inflated chunk against its stream's trailer: s1 = 1 + sum b_i, s2 = n + sum (n - i) b_i (mod 65521);
-// one block per chunk (chunks <= 64 MiB: the weighted sum stays below 2^60)
-__global__ __launch_bounds__(256) void k_adler(const uint8_t *__restrict__ raw, const InfDesc *__restrict__ desc,
-                                               InfResult *__restrict__ res) {
-    __shared__ unsigned long long r1[256], r2[256];
-    const InfDesc d = desc[blockIdx.x];
-    const uint32_t want = res[blockIdx.x].adler_want;
-    if (res[blockIdx.x].status != dinf::kOk) return;  // the same for the whole block
-    const uint8_t *p = raw + d.dst_off;
-    const uint64_t n = uint64_t(d.dst_n), n16 = n / 16;
-    unsigned long long s1 = 0, s2 = 0;
-    for (uint64_t i = threadIdx.x; i < n16; i += 256) {
-        const uint4 v = reinterpret_cast<const uint4 *>(p)[i];
-        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
-        uint32_t sum = 0, wsum = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t b = (wds[q] >> (8 * k)) & 0xFFu;
-                sum += b;
-                wsum += uint32_t(4 * q + k) * b;
-            }
-        s1 += sum;
-        s2 += (n - i * 16) * sum - wsum;
-    }
-    for (uint64_t i = n16 * 16 + threadIdx.x; i < n; i += 256) {
-        s1 += p[i];
-        s2 += (n - i) * p[i];
-    }
-    r1[threadIdx.x] = s1;
-    r2[threadIdx.x] = s2;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if (int(threadIdx.x) < w) {
-            r1[threadIdx.x] += r1[threadIdx.x + w];
-            r2[threadIdx.x] += r2[threadIdx.x + w];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const uint32_t a = uint32_t((1 + r1[0]) % 65521ull), b = uint32_t((n % 65521ull + r2[0] % 65521ull) % 65521ull);
-        if (((b << 16) | a) != want) res[blockIdx.x].status = dinf::kAdler;
-    }
 }
 
 // ---- per-context staging: kSlots slots, each {pinned host, device raw, descriptor buffers, event, stream} -------------
@@ -540,48 +629,93 @@ struct Part {  // one variable of a read
 
 struct Pending {
     bool active = false;
+    bool aborted = false;  // the read call itself failed (and said so): nothing of this job is decoded again
     atl_nc *nc = nullptr;
     std::vector<Part> parts;
     std::vector<uint32_t> part_of;   // stream -> part
     std::vector<size_t> lin;         // stream -> linear chunk index (in its variable)
     std::vector<uint32_t> desc_of;   // stream -> index of its UnpackDesc (global)
     std::vector<InfDesc> inf;
-    size_t off_inf = 0, off_unp = 0, off_res = 0;
+    size_t off_unp = 0;              // device: the UnpackDesc array inside sl.d
+    size_t off_res = 0;              // host: the InfResult array inside sl.h
+    size_t off_flag = 0;             // host: the batches' arrival flags inside sl.h
 };
 
 struct Slot {
-    uint8_t *h = nullptr;
-    uint8_t *d = nullptr;
-    size_t bytes = 0;
+    uint8_t *h = nullptr;   // page-locked: host path - inflated chunks + descriptors; device path - descriptors + verdicts
+    uint8_t *d = nullptr;   // device: the image of h (host path); compressed streams + descriptors + arrival flags (device path)
+    size_t bytes = 0, d_bytes = 0;
     uint8_t *d_raw = nullptr;  // device path: the inflated chunks
     size_t raw_bytes = 0;
     hipEvent_t ev = nullptr;
     hipEvent_t ev_fork[2] = {nullptr, nullptr};
-    hipStream_t st = nullptr;  // device path: the slot's own stream (two reads in flight overlap)
+    hipStream_t st = nullptr;    // device path: the slot's kernel stream (two reads in flight overlap)
+    hipStream_t st_c = nullptr;  // ... and its copy stream: the batches' DMAs run beside the kernel that waits for them
     hipEvent_t ev_t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // device path: stage boundaries (timing)
+    hipEvent_t ev_c[2] = {nullptr, nullptr};                             // ... first / last DMA on st_c
+    hipEvent_t ev_meta = nullptr;
+    std::vector<hipEvent_t> ev_batch;  // device path: "this batch's DMA has completed" (then the CPU sets its arrival flag)
     bool pending = false;
+    bool joined = true;  // device path: the copy stream has been made to wait for this slot's stream (ingest_join)
     Pending job;
 };
 
-constexpr unsigned kSlots = 4;  // reads in flight: host-side staging of one overlaps DMA + device work of the others
+constexpr unsigned kSlots = 4;     // reads in flight: host-side staging of one overlaps DMA + device work of the others
+constexpr unsigned kFedSlots = 2;  // ... of them used by device-path jobs (each may hold GBs of compressed + inflated chunks)
+constexpr unsigned kRing = 3;      // page-locked buffers the batches of a device-path job rotate through
+
+struct Ring {
+    uint8_t *h = nullptr;
+    size_t bytes = 0;
+    hipEvent_t ev = nullptr;
+    bool busy = false;
+};
 
 struct IngestState {
     Slot slot[kSlots];
-    unsigned calls = 0;
+    unsigned calls = 0, fed_calls = 0;
+    Ring ring[kRing];
+    unsigned ring_next = 0;
     atl_ctx *ctx = nullptr;
     int64_t n_device_chunks = 0, n_host_chunks = 0, n_redone = 0;
-    // device path, accumulated: host gather of the compressed bytes (wall clock) | H2D | k_inflate | k_adler | k_unpack (events)
+    // device path, accumulated: host gather of the compressed bytes (wall clock) | H2D (first to last DMA) | k_inflate (incl. its
+    // waits for the DMAs) | - (the Adler-32 is part of k_inflate since round 6) | k_unpack of never-written chunks (events)
     double ms[5] = {0, 0, 0, 0, 0};
     int64_t comp_bytes = 0, raw_bytes = 0;
+    // the verdict of a device-inflate read that failed while nobody was listening (atl_nc_close, a slot's reuse by an
+    // unrelated call): kept until a caller that propagates it has seen it - ingest_finish, i.e. whoever observes the copy stream
+    int sticky_rc = ATL_OK;
+    std::string sticky_msg;
 };
+
+// remember the calling thread's error as the state's verdict (the first one wins); returns rc
+int keep_verdict(IngestState *st, int rc) {
+    if (rc && !st->sticky_rc) {
+        st->sticky_rc = rc;
+        st->sticky_msg = atl_last_error();
+    }
+    return rc;
+}
+
+// hand the kept verdict to a caller that returns it to its own caller: reported once
+int take_verdict(IngestState *st) {
+    const int rc = st->sticky_rc;
+    if (rc) {
+        set_error("%s", st->sticky_msg.c_str());
+        st->sticky_rc = ATL_OK;
+        st->sticky_msg.clear();
+    }
+    return rc;
+}
 
 // live states, so that closing a file can settle the reads that still refer to it
 std::mutex g_states_m;
 std::vector<IngestState *> g_states;
 
 int finish_slot(atl_ctx *ctx, IngestState *st, Slot &sl);
-int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *names, int64_t start0, int64_t count0, double *const *d_outs,
-                      int n_threads, bool *done);
+int read_rows_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *names, int64_t start0, int64_t count0, double *const *d_outs,
+                     int n_threads, bool *done);
+int read_slab_one(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, int64_t count0, double *d_out, int n_threads, bool try_device);
 
 void ingest_free(void *p) {
     IngestState *s = static_cast<IngestState *>(p);
@@ -594,17 +728,26 @@ void ingest_free(void *p) {
             if (sl.pending) (void)hipEventSynchronize(sl.ev);
             (void)hipEventDestroy(sl.ev);
         }
+        for (hipStream_t q : {sl.st, sl.st_c})
+            if (q) {
+                (void)hipStreamSynchronize(q);
+                (void)hipStreamDestroy(q);
+            }
         for (hipEvent_t e : sl.ev_fork)
             if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : sl.ev_t)
             if (e) (void)hipEventDestroy(e);
-        if (sl.st) {
-            (void)hipStreamSynchronize(sl.st);
-            (void)hipStreamDestroy(sl.st);
-        }
+        for (hipEvent_t e : sl.ev_c)
+            if (e) (void)hipEventDestroy(e);
+        if (sl.ev_meta) (void)hipEventDestroy(sl.ev_meta);
+        for (hipEvent_t e : sl.ev_batch) (void)hipEventDestroy(e);
         if (sl.h) (void)hipHostFree(sl.h);
         if (sl.d) (void)dev_free(sl.d);
         if (sl.d_raw) (void)dev_free(sl.d_raw);
+    }
+    for (Ring &r : s->ring) {
+        if (r.ev) (void)hipEventDestroy(r.ev);
+        if (r.h) (void)hipHostFree(r.h);
     }
     delete s;
 }
@@ -621,36 +764,46 @@ IngestState *state_of(atl_ctx *ctx) {
     return static_cast<IngestState *>(ctx->ingest);
 }
 
-int slot_acquire(atl_ctx *ctx, size_t bytes, Slot **out, size_t raw_bytes = 0) {
+// A staging slot with at least h_bytes of page-locked memory, d_bytes of device memory and raw_bytes for inflated chunks.
+// fed: a device-path job (rotates over the first kFedSlots slots only).
+int slot_acquire(atl_ctx *ctx, size_t h_bytes, size_t d_bytes, size_t raw_bytes, bool fed, Slot **out) {
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     IngestState *st = state_of(ctx);
     // the next slot in turn - unless another one is idle and already holds buffers of this size (a read of a whole slab stages
     // a GB: page-locking that again for every slot of the rotation would cost more than the read)
-    unsigned pick = st->calls % kSlots;
-    for (unsigned k = 0; k < kSlots; ++k) {
-        Slot &c = st->slot[(st->calls + k) % kSlots];
+    const unsigned n_rot = fed ? kFedSlots : kSlots;
+    unsigned &calls = fed ? st->fed_calls : st->calls;
+    unsigned pick = calls % n_rot;
+    for (unsigned k = 0; k < n_rot; ++k) {
+        Slot &c = st->slot[(calls + k) % n_rot];
         const bool idle = !c.pending || hipEventQuery(c.ev) == hipSuccess;
-        if (idle && c.bytes >= bytes && c.raw_bytes >= raw_bytes) {
-            pick = (st->calls + k) % kSlots;
+        if (idle && c.bytes >= h_bytes && c.d_bytes >= d_bytes && c.raw_bytes >= raw_bytes) {
+            pick = (calls + k) % n_rot;
             break;
         }
     }
     (void)hipGetLastError();  // (hipEventQuery's "not ready" is not an error)
-    ++st->calls;
+    ++calls;
     Slot &sl = st->slot[pick];
     if (!sl.ev) ATL_HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
-    int rc = finish_slot(ctx, st, sl);  // the previous user of this slot has left its stream; its verdicts are in
+    (void)finish_slot(ctx, st, sl);  // the previous user of this slot has left its stream; its verdicts are in
+    int rc = take_verdict(st);        // (a failed read - this slot's or one settled unobserved - ends the call that finds it)
     if (rc) return rc;
-    if (sl.bytes < bytes) {
+    if (sl.bytes < h_bytes) {
         if (sl.h) (void)hipHostFree(sl.h);
-        if (sl.d) (void)dev_free(sl.d);
         sl.h = nullptr;
-        sl.d = nullptr;
         sl.bytes = 0;
-        const size_t want = align_up(bytes + bytes / 4, size_t(1) << 20);
+        const size_t want = align_up(h_bytes + h_bytes / 4, size_t(1) << 20);
         ATL_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sl.h), want, hipHostMallocDefault));
-        ATL_HIP_TRY(dev_malloc(reinterpret_cast<void **>(&sl.d), want));
         sl.bytes = want;
+    }
+    if (sl.d_bytes < d_bytes) {
+        if (sl.d) (void)dev_free(sl.d);
+        sl.d = nullptr;
+        sl.d_bytes = 0;
+        const size_t want = align_up(d_bytes + d_bytes / 4, size_t(1) << 20);
+        ATL_HIP_TRY(dev_malloc(reinterpret_cast<void **>(&sl.d), want));
+        sl.d_bytes = want;
     }
     if (sl.raw_bytes < raw_bytes) {
         if (sl.d_raw) (void)dev_free(sl.d_raw);
@@ -664,11 +817,48 @@ int slot_acquire(atl_ctx *ctx, size_t bytes, Slot **out, size_t raw_bytes = 0) {
     return ATL_OK;
 }
 
+// Every ring buffer at least `bytes` long.  BEFORE a fed launch: hipHostFree / hipHostMalloc wait for the device, and a device
+// that runs a kernel waiting for these very buffers' contents never gets there (measured: the read stalled for the waves' whole
+// time-out the first time a job needed a longer ring than its predecessor).
+int ring_reserve(atl_ctx *ctx, size_t bytes) {
+    IngestState *st = state_of(ctx);
+    for (Ring &r : st->ring) {
+        if (!r.ev) ATL_HIP_TRY(hipEventCreateWithFlags(&r.ev, hipEventDisableTiming));
+        if (r.bytes >= bytes) continue;
+        if (r.busy) {
+            ATL_HIP_TRY(hipEventSynchronize(r.ev));
+            r.busy = false;
+        }
+        if (r.h) (void)hipHostFree(r.h);
+        r.h = nullptr;
+        r.bytes = 0;
+        const size_t want = align_up(bytes, size_t(1) << 20);
+        ATL_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&r.h), want, hipHostMallocDefault));
+        r.bytes = want;
+    }
+    return ATL_OK;
+}
+
+// the next page-locked ring buffer (ring_reserve has sized it), free of its last DMA
+int ring_acquire(atl_ctx *ctx, size_t bytes, Ring **out) {
+    IngestState *st = state_of(ctx);
+    Ring &r = st->ring[st->ring_next++ % kRing];
+    ATL_REQUIRE(r.h && r.bytes >= bytes, "ring_acquire: the ring was not reserved");
+    if (r.busy) {
+        ATL_HIP_TRY(hipEventSynchronize(r.ev));
+        r.busy = false;
+    }
+    *out = &r;
+    return ATL_OK;
+}
+
 // stage `payload` bytes (in sl->h, or in the caller's pinned buffer h_payload) + descriptors, copy, decode
 int submit(atl_ctx *ctx, Slot *sl, size_t payload, const std::vector<UnpackDesc> &descs, const UnpackParams &p,
            int64_t max_chunk_elems, double *d_out, const void *h_payload = nullptr) {
     hipStream_t cs;
     int rc = copy_stream_of(ctx, &cs);
+    if (rc) return rc;
+    rc = ingest_join(ctx, cs);  // behind the device-inflate reads in flight (they may write the same block)
     if (rc) return rc;
     const size_t desc_off = align_up(payload, 256);
     memcpy(sl->h + desc_off, descs.data(), descs.size() * sizeof(UnpackDesc));
@@ -884,60 +1074,23 @@ void launch_unpack(hipStream_t st, const uint8_t *raw, const UnpackDesc *d_desc,
     }
 }
 
-// Everything of a device-inflate read is enqueued on the slot's stream; the copy stream waits for it.  The verdicts come
-// back with the last copy and are read by finish_slot: at the slot's next use, when the copy stream is observed
-// (atl_event_record on it), when the file is closed, when the context goes.
-int submit_device(atl_ctx *ctx, Slot *sl, size_t h2d_bytes) {
-    hipStream_t cs;
-    int rc = copy_stream_of(ctx, &cs);
-    if (rc) return rc;
-    Pending &job = sl->job;
-    if (!sl->st) ATL_HIP_TRY(hipStreamCreateWithFlags(&sl->st, hipStreamNonBlocking));
-    // behind whatever the copy stream holds (an earlier read into the same block; what the caller ordered the copy stream
-    // after: Context.copy_after_compute).  NOT behind the compute stream: a slab pipeline reads the next slab while the
-    // previous one is converted
-    if (!sl->ev_fork[0]) ATL_HIP_TRY(hipEventCreateWithFlags(&sl->ev_fork[0], hipEventDisableTiming));
-    ATL_HIP_TRY(hipEventRecord(sl->ev_fork[0], cs));
-    ATL_HIP_TRY(hipStreamWaitEvent(sl->st, sl->ev_fork[0], 0));
-    const size_t n = job.inf.size();
-    for (hipEvent_t &e : sl->ev_t)
-        if (!e) ATL_HIP_TRY(hipEventCreate(&e));
-    ATL_HIP_TRY(hipEventRecord(sl->ev_t[0], sl->st));
-    ATL_HIP_TRY(hipMemcpyAsync(sl->d, sl->h, h2d_bytes, hipMemcpyHostToDevice, sl->st));
-    ATL_HIP_TRY(hipEventRecord(sl->ev_t[1], sl->st));
-    const InfDesc *d_inf = reinterpret_cast<const InfDesc *>(sl->d + job.off_inf);
-    InfResult *d_res = reinterpret_cast<InfResult *>(sl->d + job.off_res);
-    if (n) hipLaunchKernelGGL(k_inflate, dim3(unsigned(n)), dim3(64), 0, sl->st, sl->d, d_inf, sl->d_raw, d_res);
-    ATL_HIP_TRY(hipEventRecord(sl->ev_t[2], sl->st));
-    if (n) hipLaunchKernelGGL(k_adler, dim3(unsigned(n)), dim3(256), 0, sl->st, sl->d_raw, d_inf, d_res);
-    ATL_HIP_TRY(hipEventRecord(sl->ev_t[3], sl->st));
-    const UnpackDesc *d_unp = reinterpret_cast<const UnpackDesc *>(sl->d + job.off_unp);
-    for (const Part &pt : job.parts) launch_unpack(sl->st, sl->d_raw, d_unp + pt.desc0, pt.n_desc, pt.p, pt.max_elems, pt.d_out);
-    ATL_HIP_TRY(hipEventRecord(sl->ev_t[4], sl->st));
-    ATL_HIP_TRY(hipGetLastError());
-    if (n) ATL_HIP_TRY(hipMemcpyAsync(sl->h + job.off_res, d_res, n * sizeof(InfResult), hipMemcpyDeviceToHost, sl->st));
-    ATL_HIP_TRY(hipEventRecord(sl->ev, sl->st));
-    sl->pending = true;
-    job.active = true;
-    // (no hipStreamWaitEvent(cs, sl->ev) here: the NEXT read forks from the copy stream, so that join would put the slots'
-    //  streams one behind the other.  Whoever observes the copy stream goes through ingest_finish, which waits for every
-    //  pending slot on the host first.)
-    return ATL_OK;
-}
-
-int finish_slot(atl_ctx *ctx, IngestState *st, Slot &sl) {
+static int finish_slot_impl(atl_ctx *ctx, IngestState *st, Slot &sl) {
     if (sl.pending) {
-        ATL_HIP_TRY(hipEventSynchronize(sl.ev));
         sl.pending = false;
+        ATL_HIP_TRY(hipEventSynchronize(sl.ev));
     }
+    sl.joined = true;
     Pending &job = sl.job;
     if (!job.active) return ATL_OK;
     job.active = false;
-    for (int k = 0; k < 4; ++k) {
+    {
         float t = 0.f;
-        if (hipEventElapsedTime(&t, sl.ev_t[k], sl.ev_t[k + 1]) == hipSuccess) st->ms[k + 1] += double(t);
+        if (hipEventElapsedTime(&t, sl.ev_c[0], sl.ev_c[1]) == hipSuccess) st->ms[1] += double(t);
+        if (hipEventElapsedTime(&t, sl.ev_t[1], sl.ev_t[2]) == hipSuccess) st->ms[2] += double(t);
+        if (hipEventElapsedTime(&t, sl.ev_t[2], sl.ev_t[3]) == hipSuccess) st->ms[4] += double(t);
     }
     (void)hipGetLastError();
+    if (job.aborted) return ATL_OK;  // the read call failed and reported it: nothing to decode again
     for (const InfDesc &q : job.inf) {
         st->comp_bytes += q.src_n;
         st->raw_bytes += q.dst_n;
@@ -948,8 +1101,24 @@ int finish_slot(atl_ctx *ctx, IngestState *st, Slot &sl) {
         if (res[i].status != dinf::kOk) bad.push_back(i);
     st->n_device_chunks += int64_t(job.inf.size() - bad.size());
     if (bad.empty()) return ATL_OK;
-    // streams the device decoder did not accept (corrupt, or a shape of code it declines): the host decoders decide, the chunk
-    // is decoded again from their output; a stream they reject too is the caller's error, as on the host path
+    if (getenv("ATLITE_HIP_INGEST_DEBUG")) {  // which verdicts, of which variables
+        int hist[16] = {0};
+        for (size_t i : bad) ++hist[res[i].status & 15];
+        fprintf(stderr, "[atlite-hip ingest] %zu of %zu streams go back to the host decoders; status histogram:", bad.size(), job.inf.size());
+        for (int k = 0; k < 16; ++k)
+            if (hist[k]) fprintf(stderr, " %d x status %d", hist[k], k);
+        float t_k = -1.f, t_c = -1.f;
+        (void)hipEventElapsedTime(&t_k, sl.ev_t[1], sl.ev_t[2]);
+        (void)hipEventElapsedTime(&t_c, sl.ev_c[0], sl.ev_c[1]);
+        (void)hipGetLastError();
+        const uint32_t *hf = reinterpret_cast<const uint32_t *>(sl.h + job.off_flag);
+        fprintf(stderr, "; first: stream %zu of '%s' (%lld -> %lld bytes, batch %u, its flag now %u); kernel span %.1f ms, DMA span %.1f ms\n", bad[0],
+                job.parts[job.part_of[bad[0]]].ds->name.c_str(), (long long)job.inf[bad[0]].src_n, (long long)job.inf[bad[0]].dst_n,
+                job.inf[bad[0]].batch, job.inf[bad[0]].batch == kNoWait ? 0u : hf[size_t(job.inf[bad[0]].batch) * kFlagPitch], t_k, t_c);
+    }
+    // streams the device decoder did not accept (corrupt, a shape of code it declines, or bytes that never arrived): the host
+    // decoders decide, the chunk is decoded again from their output; a stream they reject too is the caller's error, as on the
+    // host path
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     std::vector<uint8_t> tmp;
     const UnpackDesc *d_unp = reinterpret_cast<const UnpackDesc *>(sl.d + job.off_unp);
@@ -971,6 +1140,10 @@ int finish_slot(atl_ctx *ctx, IngestState *st, Slot &sl) {
     ATL_HIP_TRY(hipStreamSynchronize(sl.st));
     return ATL_OK;
 }
+
+// Settle a slot.  A failure is KEPT in the state (keep_verdict) as well as returned: callers that cannot report it - atl_nc_close,
+// a context being recycled - drop the return value, and the next caller that observes the copy stream gets it (take_verdict).
+int finish_slot(atl_ctx *ctx, IngestState *st, Slot &sl) { return keep_verdict(st, finish_slot_impl(ctx, st, sl)); }
 
 int copy_text(const std::string &s, char *buf, int64_t buflen, int64_t *needed) {
     if (needed) *needed = int64_t(s.size()) + 1;
@@ -1012,16 +1185,31 @@ int part_setup(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, int64_
     return ATL_OK;
 }
 
-// The device-inflate path for the rows [start0, start0 + count0) of n_vars variables at once: ONE k_inflate launch over every
-// chunk stream of the group (the machine holds ~3600 streams at a time; launches from different HIP streams are not a way to
-// get there - the runtime multiplexes its streams onto four hardware queues and a queue runs its kernels one after the other).
-// *done = false: not every stored chunk is a plain zlib stream, or too few of them - the caller reads variable by variable.
-int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *names, int64_t start0, int64_t count0, double *const *d_outs,
-                      int n_threads, bool *done) {
+// Streams per ... : the DMA batches of a job.  A batch is a run of consecutive streams of ~128 MiB of compressed bytes
+// ($ATLITE_HIP_INGEST_BATCH): pread into one ring buffer by the host threads, one DMA, one flag.
+struct Batch {
+    size_t first = 0, count = 0;   // streams
+    size_t off = 0, bytes = 0;     // inside the job's compressed area
+};
+
+bool fed_mode() {
+    const char *e = getenv("ATLITE_HIP_INGEST_FED");
+    return !(e && strcmp(e, "0") == 0);
+}
+
+// One JOB of the device-inflate path: the rows [start0, start0 + count0) of n_vars variables, every chunk stream of them in ONE
+// k_inflate launch on a staging slot's own stream.  The launch is FED (k_inflate's comment): it is enqueued first, then the
+// compressed bytes follow batch by batch - pread by the host threads into a page-locked ring, DMA'd on the slot's copy stream,
+// each batch's arrival flag behind it - so that pread, DMA, inflate, checksum and unpack of the job overlap.  The rows land in
+// blocks that begin at row `base_row` (the whole read's first row).  *done = false (nothing enqueued): not every stored chunk
+// is a plain zlib stream - the caller reads these rows variable by variable.
+int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *names, int64_t start0, int64_t count0, int64_t base_row,
+                      double *const *d_outs, int n_threads, bool *done) {
     *done = false;
     if (count0 == 0) return ATL_OK;
     std::vector<Part> parts;
-    std::vector<UnpackDesc> descs;
+    std::vector<UnpackDesc> descs, missing;
+    std::vector<uint32_t> missing_part;
     std::vector<InfDesc> inf;
     std::vector<size_t> lin;
     std::vector<uint32_t> part_of, desc_of;
@@ -1040,7 +1228,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
         Selection sel;
         select_chunks(g, pt.p.r0, pt.p.r1, chunk_bytes, &sel);
         pt.ds = d;
-        pt.d_out = d_outs[v];
+        pt.d_out = d_outs[v] + (start0 - base_row) * pt.p.ld;
         pt.chunk_bytes = chunk_bytes;
         pt.max_elems = g.chunk_elems;
         pt.desc0 = descs.size();
@@ -1049,18 +1237,28 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
             const h5::Chunk &c = d->chunks[sel.lin[i]];
             UnpackDesc ds = sel.desc[i];
             ds.src_off = int64_t(raw_off);  // where the chunk's inflated bytes go in the slot's raw buffer
-            raw_off += align_up(size_t(chunk_bytes), 16);
             if (c.size == 0) {
                 ds.missing = 1;
+                missing.push_back(ds);
+                missing_part.push_back(uint32_t(parts.size()));
             } else {
+                raw_off += align_up(size_t(chunk_bytes), 16);
                 uint64_t pay = 0;
                 bool defl = false, shuf = false;
                 if (h5::chunk_filters(*d, c, &pay, &defl, &shuf) != ATL_OK || !defl || pay < 6 || c.addr > f->file.size() ||
                     c.size > f->file.size() - c.addr)
                     return ATL_OK;
                 ds.shuffled = shuf;
-                inf.push_back(InfDesc{int64_t(comp_off), int64_t(pay), ds.src_off, chunk_bytes});
-                comp_off += align_up(size_t(pay) + 8, 16);
+                InfDesc q{};
+                q.src_off = int64_t(comp_off);
+                q.src_n = int64_t(pay);
+                q.dst_off = ds.src_off;
+                q.dst_n = chunk_bytes;
+                q.part = uint32_t(parts.size());
+                q.desc = uint32_t(descs.size());
+                q.batch = kNoWait;
+                inf.push_back(q);
+                comp_off += align_up(size_t(pay) + 8, 128);  // (+ the bit reader's look-ahead words; a 128-byte line of its own)
                 lin.push_back(sel.lin[i]);
                 part_of.push_back(uint32_t(parts.size()));
                 desc_of.push_back(uint32_t(descs.size()));
@@ -1069,34 +1267,114 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
         }
         parts.push_back(pt);
     }
-    if (parts.empty() || !device_inflate_wanted(inf.size())) return ATL_OK;
-    // staging: streams (16-byte aligned, whole words) | InfDesc[] | UnpackDesc[] ; behind them, device -> host: InfResult[]
-    const size_t off_inf = align_up(comp_off, 256), off_unp = align_up(off_inf + inf.size() * sizeof(InfDesc), 256);
-    const size_t off_res = align_up(off_unp + descs.size() * sizeof(UnpackDesc), 256);
-    Slot *sl = nullptr;
-    int rc = slot_acquire(ctx, off_res + inf.size() * sizeof(InfResult) + 256, &sl, raw_off + 256);
-    if (rc) return rc;
-    const int fd = f->file.fd();
-    const uint8_t *base = f->file.base();
-    const auto t_gather = std::chrono::steady_clock::now();
-    rc = parallel_for(inf.size(), pick_threads(n_threads, inf.size()), [&](size_t i) -> int {
-        const h5::Chunk &c = parts[part_of[i]].ds->chunks[lin[i]];
-        uint8_t *dst = sl->h + inf[i].src_off;
-        const uint64_t n = uint64_t(inf[i].src_n);
-        uint64_t got = 0;
-        while (fd >= 0 && got < n) {  // straight into the pinned staging (a mapping's page faults contend across threads)
-            const ssize_t r = pread(fd, dst + got, size_t(n - got), off_t(c.addr + got));
-            if (r <= 0) break;
-            got += uint64_t(r);
+    if (parts.empty() || inf.empty()) return ATL_OK;
+    const bool fed = fed_mode();
+    // batches of consecutive streams
+    size_t batch_bytes = size_t(128) << 20;
+    if (const char *e = getenv("ATLITE_HIP_INGEST_BATCH")) batch_bytes = size_t(std::max(1, atoi(e))) << 20;
+    std::vector<Batch> batches;
+    for (size_t i = 0; i < inf.size(); ++i) {
+        const size_t len = align_up(size_t(inf[i].src_n) + 8, 128);
+        if (batches.empty() || batches.back().bytes + len > batch_bytes) {
+            Batch nb;
+            nb.first = i;
+            nb.off = size_t(inf[i].src_off);
+            batches.push_back(nb);
         }
-        if (got < n) memcpy(dst + got, base + c.addr + got, size_t(n - got));
-        memset(dst + n, 0, size_t(align_up(size_t(n) + 8, 16) - n));  // the bit reader's look-ahead words
-        return ATL_OK;
-    });
+        batches.back().count += 1;
+        batches.back().bytes += len;
+        if (fed) inf[i].batch = uint32_t(batches.size() - 1);
+    }
+    size_t ring_bytes = 0;
+    for (const Batch &b : batches) ring_bytes = std::max(ring_bytes, b.bytes);
+    // device: streams | InfDesc[] | UnpackDesc[] (the chunks', then the never-written ones') | FedPart[] | flags | InfResult[]
+    // page-locked: the same from InfDesc[] on (off_meta = 0 there)
+    const size_t n = inf.size(), nd = descs.size(), nm = missing.size(), np = parts.size(), nb = batches.size();
+    const size_t m_inf = 0, m_unp = align_up(m_inf + n * sizeof(InfDesc), 256), m_mis = m_unp + nd * sizeof(UnpackDesc),
+                 m_part = align_up(m_mis + nm * sizeof(UnpackDesc), 256), m_flag = align_up(m_part + np * sizeof(FedPart), 256),
+                 m_res = align_up(m_flag + nb * kFlagPitch * sizeof(uint32_t), 256), m_end = m_res + n * sizeof(InfResult);
+    const size_t off_meta = align_up(comp_off, 256);
+    Slot *sl = nullptr;
+    int rc = slot_acquire(ctx, m_end + 256, off_meta + m_end + 256, raw_off + 256, true, &sl);
     if (rc) return rc;
-    state_of(ctx)->ms[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_gather).count();
-    if (!inf.empty()) memcpy(sl->h + off_inf, inf.data(), inf.size() * sizeof(InfDesc));
-    memcpy(sl->h + off_unp, descs.data(), descs.size() * sizeof(UnpackDesc));
+    rc = ring_reserve(ctx, ring_bytes);  // (every allocation of the job happens before its kernel is launched)
+    if (rc) return rc;
+    IngestState *state = state_of(ctx);
+    memcpy(sl->h + m_inf, inf.data(), n * sizeof(InfDesc));
+    memcpy(sl->h + m_unp, descs.data(), nd * sizeof(UnpackDesc));
+    if (nm) memcpy(sl->h + m_mis, missing.data(), nm * sizeof(UnpackDesc));
+    {
+        FedPart *fp = reinterpret_cast<FedPart *>(sl->h + m_part);
+        for (size_t k = 0; k < np; ++k) {
+            fp[k].p = parts[k].p;
+            fp[k].out = parts[k].d_out;
+        }
+    }
+    memset(sl->h + m_flag, 0, nb * kFlagPitch * sizeof(uint32_t));
+    {  // verdicts: "not run" until the device says otherwise (a launch that never happens must not read as success)
+        InfResult *r = reinterpret_cast<InfResult *>(sl->h + m_res);
+        for (size_t k = 0; k < n; ++k) r[k] = InfResult{int32_t(dinf::kNotRun), 0u};
+    }
+    // ---- streams and events of the slot ------------------------------------------------------------------------------------
+    hipStream_t cs;
+    rc = copy_stream_of(ctx, &cs);
+    if (rc) return rc;
+    if (!sl->st) ATL_HIP_TRY(hipStreamCreateWithFlags(&sl->st, hipStreamNonBlocking));
+    if (!sl->st_c) {  // a priority of its own = a hardware queue of its own (k_inflate's comment)
+        int least = 0, greatest = 0;
+        ATL_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        ATL_HIP_TRY(hipStreamCreateWithPriority(&sl->st_c, hipStreamNonBlocking, greatest));
+    }
+    if (!sl->ev_fork[0]) ATL_HIP_TRY(hipEventCreateWithFlags(&sl->ev_fork[0], hipEventDisableTiming));
+    if (!sl->ev_meta) ATL_HIP_TRY(hipEventCreateWithFlags(&sl->ev_meta, hipEventDisableTiming));
+    for (hipEvent_t &e : sl->ev_t)
+        if (!e) ATL_HIP_TRY(hipEventCreate(&e));
+    for (hipEvent_t &e : sl->ev_c)
+        if (!e) ATL_HIP_TRY(hipEventCreate(&e));
+    while (sl->ev_batch.size() < nb) {
+        hipEvent_t e = nullptr;
+        ATL_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        sl->ev_batch.push_back(e);
+    }
+    // behind whatever the copy stream holds (an earlier read into the same block; what the caller ordered the copy stream
+    // after: Context.copy_after_compute).  NOT behind the compute stream: a slab pipeline reads the next slab while the
+    // previous one is converted
+    ATL_HIP_TRY(hipEventRecord(sl->ev_fork[0], cs));
+    ATL_HIP_TRY(hipStreamWaitEvent(sl->st, sl->ev_fork[0], 0));
+    uint8_t *d_meta = sl->d + off_meta;
+    const InfDesc *d_inf = reinterpret_cast<const InfDesc *>(d_meta + m_inf);
+    const UnpackDesc *d_unp = reinterpret_cast<const UnpackDesc *>(d_meta + m_unp);
+    const UnpackDesc *d_mis = reinterpret_cast<const UnpackDesc *>(d_meta + m_mis);
+    const FedPart *d_part = reinterpret_cast<const FedPart *>(d_meta + m_part);
+    uint32_t *h_flag = reinterpret_cast<uint32_t *>(sl->h + m_flag);  // page-locked: the CPU stores, the waves poll (k_inflate's comment)
+    InfResult *d_res = reinterpret_cast<InfResult *>(d_meta + m_res);
+    ATL_HIP_TRY(hipEventRecord(sl->ev_t[0], sl->st));
+    ATL_HIP_TRY(hipMemcpyAsync(d_meta, sl->h, m_end, hipMemcpyHostToDevice, sl->st));  // descriptors, cleared flags, "not run"
+    ATL_HIP_TRY(hipEventRecord(sl->ev_meta, sl->st));
+    ATL_HIP_TRY(hipEventRecord(sl->ev_t[1], sl->st));
+    ATL_HIP_TRY(hipStreamWaitEvent(sl->st_c, sl->ev_meta, 0));  // (a flag must not land before the flags are cleared)
+    auto launch = [&]() -> int {
+        unsigned long long ticks = 2000000000ull;  // 20 s of the 100 MHz clock
+        if (const char *e = getenv("ATLITE_HIP_INGEST_TIMEOUT_MS")) ticks = (unsigned long long)(std::max(1, atoi(e))) * 100000ull;
+        // ($ATLITE_HIP_INGEST_LDS_PAD: bytes of dynamic LDS the launch asks for and never touches - an experiment knob that caps
+        //  the streams per CU below the 32 the kernel's own 5 kB allow)
+        unsigned pad = 0u;
+        if (const char *e = getenv("ATLITE_HIP_INGEST_LDS_PAD")) pad = unsigned(std::max(0, atoi(e)));
+        hipLaunchKernelGGL(k_inflate, dim3(unsigned(n)), dim3(64), pad, sl->st, sl->d, d_inf, sl->d_raw, d_res, h_flag, d_part, d_unp, ticks);
+        ATL_HIP_TRY(hipGetLastError());
+        ATL_HIP_TRY(hipEventRecord(sl->ev_t[2], sl->st));
+        for (size_t k = 0; k < nm;) {  // never-written chunks: fill value / NaN (runs of one variable)
+            size_t e = k;
+            while (e < nm && missing_part[e] == missing_part[k]) ++e;
+            const Part &pt = sl->job.parts[missing_part[k]];  // (the job owns the parts by the time this runs)
+            launch_unpack(sl->st, sl->d_raw, d_mis + k, e - k, pt.p, pt.max_elems, pt.d_out);
+            k = e;
+        }
+        ATL_HIP_TRY(hipGetLastError());
+        ATL_HIP_TRY(hipEventRecord(sl->ev_t[3], sl->st));
+        return ATL_OK;
+    };
+    // the job is the slot's from here on: whatever happens below, the slot must be settled before it is used again
     Pending &job = sl->job;
     job.nc = f;
     job.parts = std::move(parts);
@@ -1104,11 +1382,165 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     job.lin = std::move(lin);
     job.desc_of = std::move(desc_of);
     job.inf = std::move(inf);
-    job.off_inf = off_inf;
-    job.off_unp = off_unp;
-    job.off_res = off_res;
+    job.off_unp = off_meta + m_unp;
+    job.off_res = m_res;
+    job.off_flag = m_flag;
+    job.aborted = false;
+    if (fed) {
+        rc = launch();
+        if (rc) return rc;
+    }
+    // ---- the batches ----------------------------------------------------------------------------------------------------------
+    const int fd = f->file.fd();
+    const uint8_t *base = f->file.base();
+    const int nt = pick_threads(n_threads, batches.empty() ? 1 : batches[0].count);
+    double gather_ms = 0;
+    ATL_HIP_TRY(hipEventRecord(sl->ev_c[0], sl->st_c));
+    size_t fed_batches = 0, flagged = 0;
+    // arrival flags of the batches whose DMA has completed (wait: of every batch enqueued so far)
+    auto set_flags = [&](bool wait) -> int {
+        while (fed && flagged < fed_batches) {
+            const hipError_t q = wait ? hipEventSynchronize(sl->ev_batch[flagged]) : hipEventQuery(sl->ev_batch[flagged]);
+            if (q == hipErrorNotReady) {
+                (void)hipGetLastError();
+                break;
+            }
+            if (q != hipSuccess) {
+                set_error("atl_nc_read_slabs: waiting for the DMA of a batch of chunk streams failed: %s", hipGetErrorString(q));
+                return ATL_E_HIP;
+            }
+            __atomic_store_n(h_flag + flagged * kFlagPitch, kFlagReady, __ATOMIC_RELEASE);
+            ++flagged;
+        }
+        return ATL_OK;
+    };
+    for (size_t b = 0; b < nb && !rc; ++b) {
+        const Batch &bt = batches[b];
+        Ring *ring = nullptr;
+        rc = ring_acquire(ctx, ring_bytes, &ring);
+        if (!rc) rc = set_flags(false);
+        if (rc) break;
+        const auto t_gather = std::chrono::steady_clock::now();
+        rc = parallel_for(bt.count, nt, [&](size_t k) -> int {
+            const size_t i = bt.first + k;
+            const h5::Chunk &c = job.parts[job.part_of[i]].ds->chunks[job.lin[i]];
+            uint8_t *dst = ring->h + (size_t(job.inf[i].src_off) - bt.off);
+            const uint64_t want = uint64_t(job.inf[i].src_n);
+            uint64_t got = 0;
+            while (fd >= 0 && got < want) {  // straight into the pinned ring (a mapping's page faults contend across threads)
+                const ssize_t r = pread(fd, dst + got, size_t(want - got), off_t(c.addr + got));
+                if (r <= 0) break;
+                got += uint64_t(r);
+            }
+            if (got < want) memcpy(dst + got, base + c.addr + got, size_t(want - got));
+            memset(dst + want, 0, size_t(align_up(size_t(want) + 8, 128) - want));  // the bit reader's look-ahead words
+            return ATL_OK;
+        });
+        gather_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_gather).count();
+        if (rc) break;
+        hipError_t e = hipMemcpyAsync(sl->d + bt.off, ring->h, bt.bytes, hipMemcpyHostToDevice, sl->st_c);
+        if (e == hipSuccess) e = hipEventRecord(sl->ev_batch[b], sl->st_c);
+        if (e == hipSuccess) e = hipEventRecord(ring->ev, sl->st_c);
+        if (e != hipSuccess) {
+            set_error("atl_nc_read_slabs: DMA of a batch of chunk streams failed: %s", hipGetErrorString(e));
+            rc = ATL_E_HIP;
+            break;
+        }
+        ring->busy = true;
+        fed_batches = b + 1;
+        rc = set_flags(false);
+    }
+    if (!rc) rc = set_flags(true);  // the call returns when its last DMA has landed; the kernel goes on by itself
+    state->ms[0] += gather_ms;
+    if (rc && fed) {  // waves that wait for the batches that will not come: let them go (status kNotRun), then report
+        for (size_t b = flagged; b < nb; ++b) __atomic_store_n(h_flag + b * kFlagPitch, kFlagAbort, __ATOMIC_RELEASE);
+        job.aborted = true;
+    }
+    (void)hipEventRecord(sl->ev_c[1], sl->st_c);
+    if (!rc && !fed) {  // the unfed order (A/B, $ATLITE_HIP_INGEST_FED=0): every byte first, then the launch
+        ATL_HIP_TRY(hipStreamWaitEvent(sl->st, sl->ev_c[1], 0));
+        rc = launch();
+    }
+    if (fed || !rc) {
+        // the verdicts come back behind the kernel AND the last DMA (an aborted job's kernel may end before its flags' DMAs)
+        (void)hipStreamWaitEvent(sl->st, sl->ev_c[1], 0);
+        (void)hipMemcpyAsync(sl->h + m_res, d_res, n * sizeof(InfResult), hipMemcpyDeviceToHost, sl->st);
+    }
+    (void)hipEventRecord(sl->ev, sl->st);
+    sl->pending = true;
+    sl->joined = false;
+    job.active = true;
+    if (rc) {
+        job.aborted = true;
+        return rc;
+    }
     *done = true;
-    return submit_device(ctx, sl, off_unp + descs.size() * sizeof(UnpackDesc));
+    // (no hipStreamWaitEvent(cs, sl->ev) here: the NEXT read forks from the copy stream, so that join would put the slots'
+    //  streams one behind the other.  Whoever observes the copy stream goes through ingest_finish, which waits for every
+    //  pending slot on the host first; the library's other copy-stream calls join lazily: ingest_join.)
+    return ATL_OK;
+}
+
+// cells between the rows of variable `name`'s output block (what part_setup computes)
+int64_t row_stride_of(atl_ctx *ctx, atl_nc *f, const char *name) {
+    const Dataset *d = f->file.find(name);
+    if (!d) return 0;
+    int64_t ld = 1;
+    for (size_t k = 1; k < d->shape.size(); ++k) ld *= int64_t(d->shape[k]);
+    if (ctx->slot_stride > 0 && d->shape.size() == 3) ld = std::max<int64_t>(ld, ctx->slot_stride);
+    return ld;
+}
+
+// The device-inflate path of a read: normally ONE job (read_group_device); rows whose chunks inflate to more than
+// $ATLITE_HIP_INGEST_JOB_GB (default 12 GiB: the staging slots keep their buffers) are cut into jobs of whole chunk rows, one
+// after the other on alternating slots.  *done = false (nothing enqueued): the device path does not apply - the caller reads
+// variable by variable.
+int read_rows_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *names, int64_t start0, int64_t count0, double *const *d_outs,
+                     int n_threads, bool *done) {
+    *done = false;
+    if (count0 <= 0 || n_vars <= 0) return ATL_OK;
+    // streams and inflated bytes of the whole read, and the coarsest time chunking among the variables (jobs are cut on its
+    // boundaries: no chunk of that variable is inflated twice)
+    int64_t streams = 0, tchunk = 1;
+    double raw_bytes = 0;
+    for (int v = 0; v < n_vars; ++v) {
+        const Dataset *d = f->file.find(names[v]);
+        if (!d) return ATL_OK;  // (the per-variable path words the error)
+        if (d->layout != 2 || d->chunk.empty() || d->chunk[0] == 0) return ATL_OK;
+        const int64_t c0 = int64_t(d->chunk[0]);
+        int64_t per_row = 1;
+        double chunk_bytes = double(d->type.size);
+        for (size_t k = 1; k < d->grid.size(); ++k) per_row *= int64_t(d->grid[k]);
+        for (size_t k = 0; k < d->chunk.size(); ++k) chunk_bytes *= double(d->chunk[k]);
+        const int64_t rows = (start0 + count0 - 1) / c0 - start0 / c0 + 1;
+        streams += rows * per_row;
+        raw_bytes += double(rows * per_row) * chunk_bytes;
+        tchunk = std::max(tchunk, c0);
+    }
+    if (!device_inflate_wanted(size_t(streams))) return ATL_OK;
+    double job_bytes = 12.0 * double(size_t(1) << 30);
+    if (const char *e = getenv("ATLITE_HIP_INGEST_JOB_GB")) job_bytes = std::max(0.001, atof(e)) * double(size_t(1) << 30);
+    const int64_t first_row = start0 / tchunk, last_row = (start0 + count0 - 1) / tchunk, chunk_rows = last_row - first_row + 1;
+    const int64_t n_jobs = std::max<int64_t>(1, std::min<int64_t>(chunk_rows, int64_t(raw_bytes / job_bytes) + 1));
+    const int64_t rows_per_job = (chunk_rows + n_jobs - 1) / n_jobs;
+    for (int64_t j = 0; j < n_jobs; ++j) {
+        const int64_t a = std::max(start0, (first_row + j * rows_per_job) * tchunk);
+        const int64_t b = std::min(start0 + count0, (first_row + (j + 1) * rows_per_job) * tchunk);
+        if (b <= a) continue;
+        bool job_done = false;
+        int rc = read_group_device(ctx, f, n_vars, names, a, b - a, start0, d_outs, n_threads, &job_done);
+        if (rc) return rc;
+        if (!job_done) {
+            if (!*done) return ATL_OK;  // nothing enqueued yet: the whole read takes the other path
+            // these rows hold a chunk that is not a plain zlib stream: variable by variable on the host threads
+            for (int v = 0; v < n_vars; ++v) {
+                rc = read_slab_one(ctx, f, names[v], a, b - a, d_outs[v] + (a - start0) * row_stride_of(ctx, f, names[v]), n_threads, false);
+                if (rc) return rc;
+            }
+        }
+        *done = true;
+    }
+    return ATL_OK;
 }
 
 }  // namespace
@@ -1119,11 +1551,22 @@ namespace atl {
 int ingest_finish(atl_ctx *ctx) {
     if (!ctx || !ctx->ingest) return ATL_OK;
     IngestState *st = static_cast<IngestState *>(ctx->ingest);
-    for (Slot &sl : st->slot) {
-        if (!sl.job.active) continue;
-        const int rc = finish_slot(ctx, st, sl);
-        if (rc) return rc;
-    }
+    for (Slot &sl : st->slot)
+        if (sl.job.active) (void)finish_slot(ctx, st, sl);  // (every slot is settled, whatever the others' verdicts)
+    return take_verdict(st);
+}
+
+// Make the copy stream wait for every device-inflate read still in flight (their kernels run on the slots' own streams, forked
+// from the copy stream): whatever is enqueued on the copy stream next is ordered behind them, as include/atlite_hip.h promises
+// for atl_nc_read_slab.  No host wait, no verdicts looked at.
+int ingest_join(atl_ctx *ctx, hipStream_t cs) {
+    if (!ctx || !ctx->ingest) return ATL_OK;
+    IngestState *st = static_cast<IngestState *>(ctx->ingest);
+    for (Slot &sl : st->slot)
+        if (sl.job.active && sl.pending && !sl.joined) {
+            ATL_HIP_TRY(hipStreamWaitEvent(cs, sl.ev, 0));
+            sl.joined = true;
+        }
     return ATL_OK;
 }
 }  // namespace atl
@@ -1170,7 +1613,7 @@ int atl_nc_close(atl_nc *f) {
         std::lock_guard<std::mutex> lk(g_states_m);
         for (IngestState *st : g_states)
             for (Slot &sl : st->slot)
-                if (sl.job.active && sl.job.nc == f) (void)finish_slot(st->ctx, st, sl);
+                if (sl.job.active && sl.job.nc == f) (void)finish_slot(st->ctx, st, sl);  // (a failure stays with the state: keep_verdict)
     }
     delete f;
     return ATL_OK;
@@ -1360,6 +1803,13 @@ int atl_nc_read_host(atl_nc *f, const char *name, int64_t start0, int64_t count0
 
 int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, int64_t count0, double *d_out,
                      int n_threads) {
+    return read_slab_one(ctx, f, name, start0, count0, d_out, n_threads, true);
+}
+
+}  // extern "C"
+
+namespace {
+int read_slab_one(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, int64_t count0, double *d_out, int n_threads, bool try_device) {
     ATL_REQUIRE(ctx, "atl_nc_read_slab: ctx is NULL");
     const Dataset *d;
     int rc = lookup(f, name, &d, "atl_nc_read_slab");
@@ -1378,7 +1828,7 @@ int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, 
     UnpackParams p{};
     p.shape1 = g.shape[1];
     p.shape2 = g.shape[2];
-    // rows of the output block: contiguous unless the context asks for padded slots (atl_set_slot_stride) and the
+    // rows of the output block: contiguous unless the call asks for padded slots (ld_cells) and the
     // variable has rows to pad (a (time, y, x) cube)
     p.ld = g.shape[1] * g.shape[2];
     if (ctx->slot_stride > 0 && d->shape.size() == 3) {
@@ -1410,7 +1860,10 @@ int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, 
         sel.desc.push_back(ds);
         payload = written ? size_t(count0 * row_bytes) : 16;
         max_elems = count0 * g.row_elems;
-        rc = slot_acquire(ctx, align_up(payload, 256) + sizeof(UnpackDesc), &sl);
+        {
+            const size_t need = align_up(payload, 256) + sizeof(UnpackDesc);
+            rc = slot_acquire(ctx, need, need, 0, false, &sl);
+        }
         if (rc) return rc;
         if (written) {
             const uint8_t *src = (d->layout == 0 ? d->compact : f->file.base() + d->contiguous_addr) + r0 * row_bytes;
@@ -1428,16 +1881,19 @@ int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, 
         select_chunks(g, r0, r1, chunk_bytes, &sel);
         payload = sel.desc.size() * align_up(size_t(chunk_bytes), 16);
         max_elems = g.chunk_elems;
-        // ---- chunks inflated on the device: every stored chunk of the selection is a zlib stream (read_group_device) ------------
-        {
+        // ---- chunks inflated on the device: every stored chunk of the selection is a zlib stream (read_rows_device) ------------
+        if (try_device) {
             const char *one[1] = {name};
             double *outs[1] = {d_out};
             bool done = false;
-            rc = read_group_device(ctx, f, 1, one, start0, count0, outs, n_threads, &done);
+            rc = read_rows_device(ctx, f, 1, one, start0, count0, outs, n_threads, &done);
             if (rc || done) return rc;
         }
         for (UnpackDesc &ds : sel.desc) ds.shuffled = 0;
-        rc = slot_acquire(ctx, align_up(payload, 256) + sel.desc.size() * sizeof(UnpackDesc), &sl);
+        {
+            const size_t need = align_up(payload, 256) + sel.desc.size() * sizeof(UnpackDesc);
+            rc = slot_acquire(ctx, need, need, 0, false, &sl);
+        }
         if (rc) return rc;
         state_of(ctx)->n_host_chunks += int64_t(sel.lin.size());
         rc = parallel_for(sel.lin.size(), pick_threads(n_threads, sel.lin.size()), [&](size_t i) -> int {
@@ -1456,34 +1912,16 @@ int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, 
     }
     return submit(ctx, sl, payload, sel.desc, p, max_elems, d_out);
 }
+}  // namespace
+
+extern "C" {
 
 int atl_nc_read_slabs(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *names, int64_t start0, int64_t count0, double *const *d_outs,
                       int n_threads) {
     ATL_REQUIRE(ctx && f && n_vars >= 0 && (n_vars == 0 || (names && d_outs)), "atl_nc_read_slabs: bad argument");
     if (n_vars == 0) return ATL_OK;
     bool done = false;
-    int rc = ATL_OK;
-    if (n_vars > 1) {
-        // a big group in two halves, each a device job of its own: the second half's pread + DMA run while the first half's
-        // streams are inflated (the kernels themselves queue up behind each other)
-        int64_t chunks = 0;
-        for (int v = 0; v < n_vars; ++v) {
-            const Dataset *d = f->file.find(names[v]);
-            if (d && d->layout == 2 && !d->chunk.empty() && d->chunk[0] > 0) {
-                int64_t per_row = 1;
-                for (size_t k = 1; k < d->grid.size(); ++k) per_row *= int64_t(d->grid[k]);
-                chunks += (count0 / int64_t(d->chunk[0]) + 1) * per_row;
-            }
-        }
-        const int half = (chunks >= 7168 && n_vars >= 4) ? n_vars / 2 : n_vars;  // (twice what the device holds at a time)
-        rc = read_group_device(ctx, f, half, names, start0, count0, d_outs, n_threads, &done);
-        if (!rc && done && half < n_vars) {
-            bool done2 = false;
-            rc = read_group_device(ctx, f, n_vars - half, names + half, start0, count0, d_outs + half, n_threads, &done2);
-            if (!rc && !done2)
-                for (int v = half; v < n_vars && !rc; ++v) rc = atl_nc_read_slab(ctx, f, names[v], start0, count0, d_outs[v], n_threads);
-        }
-    }
+    int rc = read_rows_device(ctx, f, n_vars, names, start0, count0, d_outs, n_threads, &done);  // all variables, pipelined jobs
     if (rc || done) return rc;
     for (int v = 0; v < n_vars; ++v) {  // variable by variable (each decides for itself: device or host threads)
         rc = atl_nc_read_slab(ctx, f, names[v], start0, count0, d_outs[v], n_threads);
@@ -1540,7 +1978,8 @@ int atl_upload_convert_2d_async(atl_ctx *ctx, double *d_dst, int64_t ld_cells, c
     ATL_REQUIRE(es > 0, "atl_upload_convert_async: unknown dtype code %d", dtype);
     const size_t payload = size_t(n) * es;
     Slot *sl = nullptr;
-    int rc = slot_acquire(ctx, align_up(payload, 256) + sizeof(UnpackDesc), &sl);
+    const size_t need_bytes = align_up(payload, 256) + sizeof(UnpackDesc);
+    int rc = slot_acquire(ctx, need_bytes, need_bytes, 0, false, &sl);
     if (rc) return rc;
     // page-locked source (atl_host_register / Dataset.pin): DMA straight from it; pageable: gather
     // through the pinned staging on host threads (a pageable hipMemcpyAsync would serialise the stream)

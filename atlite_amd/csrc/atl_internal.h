@@ -259,7 +259,7 @@ struct atl_ctx {
     int64_t ring_count = 0;           // launches bracketed since profiling was enabled
     bool profiling = false;
     int n_cu = 256;
-    // slots of the INPUT cubes of the next conversion calls are this many cells apart (atl_set_slot_stride); 0 = the
+    // slots of the INPUT cubes of the next conversion calls are this many cells apart (the ld_cells argument of the *_ld entry points, set for the duration of a call: StrideScope); 0 = the
     // cubes are contiguous (T, S).  The library's own device copies of a cutout pad every slot to a 128-byte line.
     int64_t slot_stride = 0;
     // atl_capture_begin .. atl_capture_end: the calls in between are recorded into a hipGraph, not executed
@@ -306,6 +306,8 @@ int copy_stream_of(atl_ctx *ctx, hipStream_t *out);
 // order anything: callers synchronise first, as they had to for hipFree's sake.
 // atl_ingest.hip: settle the context's device-inflate reads (no-op when there are none)
 int ingest_finish(atl_ctx *ctx);
+// atl_ingest.hip: order the copy stream `cs` behind the device-inflate reads in flight (device-side wait, no verdicts read)
+int ingest_join(atl_ctx *ctx, hipStream_t cs);
 // Transfers between device memory and ARBITRARY host memory (a caller's NumPy array, a std::vector, a stack variable).  The
 // HIP runtime serves such a copy by pinning the host pages on the fly and letting a copy engine or a blit kernel touch them;
 // three unexplained "Memory access fault by GPU ... on address <a host heap address>" aborts of the test suite (rounds 3-5, one

@@ -1231,7 +1231,7 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
               int time_agg, double *d_out, const char *what, int64_t row_len = 0) {
     ATL_REQUIRE(time_agg >= ATL_TIME_NONE && time_agg <= ATL_TIME_SUM_COUNT, "%s: bad time_agg %d", what, time_agg);
     ATL_REQUIRE(d_out, "%s: d_out is NULL", what);
-    ATL_REQUIRE(slot_stride_of(ctx, S) >= S, "%s: slot stride %lld is smaller than the %lld cells of a slot (atl_set_slot_stride)", what,
+    ATL_REQUIRE(slot_stride_of(ctx, S) >= S, "%s: slot stride %lld is smaller than the %lld cells of a slot", what,
                 (long long)slot_stride_of(ctx, S), (long long)S);
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     if (S == 0 || (n_slots == 0 && time_agg == ATL_TIME_NONE)) return ATL_OK;
@@ -1379,8 +1379,11 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
             set_error("%s: this conversion cannot run on a line-aligned plan (atl_agg_create_aligned)", what);
             return ATL_E_UNSUPPORTED;
         }
-        ATL_REQUIRE(slot_stride_of(ctx, S) == S, "%s: a line-aligned plan is for contiguous cubes (slot stride %lld, %lld cells)", what,
-                    (long long)slot_stride_of(ctx, S), (long long)S);
+        if (slot_stride_of(ctx, S) != S) {
+            set_error("%s: a line-aligned plan is for contiguous cubes (slot stride %lld, %lld cells)", what,
+                      (long long)slot_stride_of(ctx, S), (long long)S);
+            return ATL_E_UNSUPPORTED;
+        }
         if (!vec) {
             set_error("%s: a line-aligned plan needs the vectorised kernels (8-byte aligned cubes that do not end on a page boundary)", what);
             return ATL_E_UNSUPPORTED;
@@ -1397,7 +1400,7 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
     ATL_REQUIRE(d_out, "%s: d_out is NULL", what);
     ATL_REQUIRE(time_agg != ATL_TIME_NONE || ld_out >= n_slots, "%s: ld_out %lld < %lld", what,
                 (long long)ld_out, (long long)n_slots);
-    ATL_REQUIRE(slot_stride_of(ctx, S) >= S, "%s: slot stride %lld is smaller than the %lld cells of a slot (atl_set_slot_stride)", what,
+    ATL_REQUIRE(slot_stride_of(ctx, S) >= S, "%s: slot stride %lld is smaller than the %lld cells of a slot", what,
                 (long long)slot_stride_of(ctx, S), (long long)S);
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     const PlanDev &plan = agg->dev;
@@ -1517,7 +1520,7 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
 //  * with an ODD cell count the lane that owns a slot's last cell reads 8 bytes past it: the next slot's first cell or,
 //    in the last slot, 8 bytes past the cube.  Those bytes share the last element's 4 KiB page unless the cube ENDS on
 //    a page boundary - then, and only then, the launch takes the unvectorised instantiation (stores never overrun: st2).
-// (ld = cells between slots, atl_set_slot_stride.)
+// (ld = cells between slots: the ld_cells argument of the *_ld entry points.)
 bool vec_ok(int64_t T, int64_t S, int64_t ld, std::initializer_list<const void *> ptrs) {
     if (no_vec()) return false;
     for (const void *p : ptrs) {

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_synth_pv(atl_synth_solar s, int64_t T, 
     const int64_t n = T * S;
     for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) {
         const int64_t t = i / S, c = i % S;
-        const int64_t o = t * ld + c;  // slots ld cells apart (atl_set_slot_stride); the hash stays on the logical index
+        const int64_t o = t * ld + c;  // slots ld cells apart (ld_cells); the hash stays on the logical index
         const int64_t y = c / s.X, x = c % s.X;
         const double lat = s.d_lat_rad[y];
         const double sl = sin(lat), cl = cos(lat);
@@ -404,7 +404,7 @@ int atl_synth_pv_inputs(atl_ctx *ctx, const atl_synth_solar *s, int64_t T, int64
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     if (T * S == 0) return ATL_OK;
     const unsigned grid = unsigned(std::min<int64_t>((T * S + 255) / 256, int64_t(ctx->n_cu) * 32));
-    hipLaunchKernelGGL(k_synth_pv, dim3(grid), dim3(256), 0, ctx->stream, *s, T, S, slot_stride_of(ctx, S), d_influx_direct,
+    hipLaunchKernelGGL(k_synth_pv, dim3(grid), dim3(256), 0, ctx->stream, *s, T, S, s->ld_cells > 0 ? s->ld_cells : S, d_influx_direct,
                        d_influx_diffuse, d_influx_toa, d_albedo, d_temperature, d_solar_altitude,
                        d_solar_azimuth);
     return check_launch("atl_synth_pv_inputs");

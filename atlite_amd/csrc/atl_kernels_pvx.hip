@@ -65,7 +65,7 @@ int make_pvx(const atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p
     ATL_REQUIRE((p->d_cell_slope == nullptr) == (p->d_cell_azimuth == nullptr),
                 "atl_pv: d_cell_slope and d_cell_azimuth must be given together");
     const int64_t ld = slot_stride_of(ctx, S);
-    ATL_REQUIRE(ld >= S, "atl_pv: slot stride %lld is smaller than the %lld cells of a slot (atl_set_slot_stride)", (long long)ld, (long long)S);
+    ATL_REQUIRE(ld >= S, "atl_pv: slot stride %lld is smaller than the %lld cells of a slot", (long long)ld, (long long)S);
     c->in = *in;
     c->S = ld;  // the converter's S is what separates the slots of its cubes
     c->k = pv_const_of(p);

@@ -127,6 +127,9 @@ hipError_t dev_free(void *p) {
         b = it->second;
         g_fence.erase(it);
     }
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != b.device) (void)hipSetDevice(b.device);  // the block's device, not whichever the calling thread last used
     hipError_t e = hipDeviceSynchronize();  // what hipFree does implicitly
     size_t gran = 0;
     hipMemAllocationProp prop{};
@@ -136,6 +139,7 @@ hipError_t dev_free(void *p) {
     (void)hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
     hipError_t e2 = hipMemUnmap(b.va + gran, b.mapped);
     hipError_t e3 = hipMemRelease(b.handle);
+    if (cur >= 0 && cur != b.device) (void)hipSetDevice(cur);
     // the reservation stays: the addresses are never reused
     return e != hipSuccess ? e : e2 != hipSuccess ? e2 : e3;
 }
@@ -206,6 +210,12 @@ bool host_is_pinned(const void *p) {
     return pinned;
 }
 
+// the whole range [p, p + bytes): a view that runs past a registered array (first byte page-locked, last byte not) must take
+// the bounce buffers, or the runtime pins its tail on the fly - the very thing they exist to avoid
+static bool host_range_is_pinned(const void *p, size_t bytes) {
+    return host_is_pinned(p) && (bytes <= 1 || host_is_pinned(static_cast<const uint8_t *>(p) + bytes - 1));
+}
+
 static int bounce_slot(atl_ctx *ctx, int *slot) {
     const int s = ctx->bounce_next;
     ctx->bounce_next ^= 1;
@@ -224,7 +234,7 @@ static int bounce_slot(atl_ctx *ctx, int *slot) {
 
 int h2d(atl_ctx *ctx, hipStream_t st, void *d_dst, const void *h_src, size_t bytes) {
     if (!bytes) return ATL_OK;
-    if (host_is_pinned(h_src)) {
+    if (host_range_is_pinned(h_src, bytes)) {
         ATL_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
         return ATL_OK;
     }
@@ -243,7 +253,7 @@ int h2d(atl_ctx *ctx, hipStream_t st, void *d_dst, const void *h_src, size_t byt
 
 int d2h(atl_ctx *ctx, hipStream_t st, void *h_dst, const void *d_src, size_t bytes) {
     if (!bytes) return ATL_OK;
-    if (host_is_pinned(h_dst)) {
+    if (host_range_is_pinned(h_dst, bytes)) {
         ATL_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
         ATL_HIP_TRY(hipStreamSynchronize(st));
         return ATL_OK;
@@ -276,7 +286,7 @@ int d2h(atl_ctx *ctx, hipStream_t st, void *h_dst, const void *d_src, size_t byt
 
 int h2d_2d(atl_ctx *ctx, hipStream_t st, void *d_dst, size_t dst_pitch, const void *h_src, size_t src_pitch, size_t width, size_t height) {
     if (!width || !height) return ATL_OK;
-    if (host_is_pinned(h_src)) {
+    if (host_range_is_pinned(h_src, (height - 1) * src_pitch + width)) {
         ATL_HIP_TRY(hipMemcpy2DAsync(d_dst, dst_pitch, h_src, src_pitch, width, height, hipMemcpyHostToDevice, st));
         return ATL_OK;
     }
@@ -304,7 +314,7 @@ int h2d_2d(atl_ctx *ctx, hipStream_t st, void *d_dst, size_t dst_pitch, const vo
 
 int d2h_2d(atl_ctx *ctx, hipStream_t st, void *h_dst, size_t dst_pitch, const void *d_src, size_t src_pitch, size_t width, size_t height) {
     if (!width || !height) return ATL_OK;
-    if (host_is_pinned(h_dst)) {
+    if (host_range_is_pinned(h_dst, (height - 1) * dst_pitch + width)) {
         ATL_HIP_TRY(hipMemcpy2DAsync(h_dst, dst_pitch, d_src, src_pitch, width, height, hipMemcpyDeviceToHost, st));
         ATL_HIP_TRY(hipStreamSynchronize(st));
         return ATL_OK;
@@ -545,11 +555,6 @@ int atl_download(atl_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     return d2h(ctx, ctx->stream, h_dst, d_src, bytes);
 }
 
-int atl_set_slot_stride(atl_ctx *ctx, int64_t ld_cells) {
-    ATL_REQUIRE(ctx && ld_cells >= 0, "atl_set_slot_stride: bad argument");
-    ctx->slot_stride = ld_cells;
-    return ATL_OK;
-}
 
 int atl_copy_2d(atl_ctx *ctx, void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width, size_t height,
                 int kind, int async_on_copy_stream) {
@@ -562,6 +567,8 @@ int atl_copy_2d(atl_ctx *ctx, void *dst, size_t dst_pitch, const void *src, size
     hipStream_t st = ctx->stream;
     if (async_on_copy_stream) {
         int rc = copy_stream_of(ctx, &st);
+        if (rc) return rc;
+        rc = ingest_join(ctx, st);
         if (rc) return rc;
     }
     if (kind == 0) {  // (asynchronous or not: the host rows have been read when this returns)
@@ -620,6 +627,8 @@ int atl_upload_async(atl_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
     hipStream_t cs;
     int rc = copy_stream_of(ctx, &cs);
     if (rc) return rc;
+    rc = ingest_join(ctx, cs);
+    if (rc) return rc;
     return h2d(ctx, cs, d_dst, h_src, bytes);  // page-locked sources (atl_host_register, Dataset.pin) go as they lie
 }
 
@@ -647,11 +656,17 @@ int atl_event_destroy(atl_event *ev) {
 
 int atl_event_record(atl_ctx *ctx, atl_event *ev, int which_stream) {
     ATL_REQUIRE(ctx && ev, "atl_event_record: bad argument");
+    ATL_REQUIRE(which_stream >= 0 && which_stream <= 2, "atl_event_record: which_stream must be 0, 1 or 2");
     hipStream_t st = ctx->stream;
     if (which_stream == 1) {
         int rc = ingest_finish(ctx);  // reads whose chunks the device inflated: their verdicts first
         if (rc) return rc;
         rc = copy_stream_of(ctx, &st);
+        if (rc) return rc;
+    } else if (which_stream == 2) {  // the copy stream as a fence only: behind the reads in flight, their verdicts left for an observer
+        int rc = copy_stream_of(ctx, &st);
+        if (rc) return rc;
+        rc = ingest_join(ctx, st);
         if (rc) return rc;
     }
     ATL_HIP_TRY(hipEventRecord(ev->ev, st));
@@ -903,7 +918,7 @@ static int build_plan(int64_t n_rows, int64_t n_cells, int64_t row_len, int64_t 
             // neighbour: +16 / w of the traffic.  Measured (201 x 200, f = 1/2): 16x8 4.65 ms, 32x4 4.02, 64x2 3.72,
             // flat 3.63; (189 x 157, odd S): 16x8 4.43, flat 3.01.  Wide tiles win there.
             static const double row_eff[7] = {0, 0, 0, 1.0, 1.0, 1.05, 1.0};
-            const int64_t stride = slot_stride > 0 ? slot_stride : n_cells;  // cells between slots (atl_set_slot_stride)
+            const int64_t stride = slot_stride > 0 ? slot_stride : n_cells;  // cells between slots (ld_cells)
             int64_t g = stride % 16;  // phases are the multiples of gcd(stride % 16, 16)
             for (int64_t b = 16; b != 0;) {
                 const int64_t r = g % b;
@@ -1603,9 +1618,9 @@ int atl_agg_info(const atl_agg *agg, int64_t *n_rows, int64_t *n_cells, int64_t 
 
 
 // ---- the conversion calls with the slot stride as an ARGUMENT (round 5) ------------------------------------------------
-// atl_set_slot_stride makes the stride context state that a conversion call reads: two calls whose coupling a forgotten
-// reset breaks silently.  These entry points take it with the call (ld_cells: cells between the slots of the call's (T, S)
-// input cubes, 0 = contiguous) and leave the context's own setting as they found it.  The Python layer calls only these.
+// Rounds 3-5 exported a setter that made the stride context state a conversion call read: two calls whose coupling a forgotten
+// reset broke silently (removed in round 6).  These entry points take it with the call (ld_cells: cells between the slots of
+// the call's (T, S) input cubes, 0 = contiguous); inside the library it is still carried by the context for the call's duration.
 namespace {
 struct StrideScope {
     atl_ctx *c;

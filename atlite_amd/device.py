@@ -243,7 +243,7 @@ class SlotPool:
     One allocation that holds the ``n`` (T, S) cubes a conversion reads slot-interleaved: cube ``v`` of time step ``t``
     starts ``(t * n + v) * Sp`` cells in, so the variables of one time step lie side by side (``Sp``: cells of a slot
     rounded up to a 128-byte line, ``pitch_for``).  The kernels address cube v, slot t as ``ptr_v + t * ld`` and never
-    see the difference (``ld = n * Sp``, ``atl_set_slot_stride``); the memory system does: with seven separate
+    see the difference (``ld = n * Sp``, the ``ld_cells`` argument of the ``atl_*_ld`` calls); the memory system does: with seven separate
     allocations the fused pv kernel streams at 6.2-6.3 TB/s, with this layout at 6.6-6.8.
     """
 
@@ -360,7 +360,9 @@ class Context:
             check(self.lib.atl_event_create(self.handle, C.byref(pair[0])))
             check(self.lib.atl_event_create(self.handle, C.byref(pair[1])))
         check(self.lib.atl_event_record(self.handle, pair[0], 0))
-        check(self.lib.atl_event_record(self.handle, pair[1], 1))
+        # (2: the copy stream as a fence - ordered behind the device-inflate reads in flight, WITHOUT settling them: a failed
+        #  read's verdict must reach whoever observes the copy stream, not be swallowed by a block being recycled)
+        check(self.lib.atl_event_record(self.handle, pair[1], 2))
         return pair
 
     def _recycle(self, ptr, nbytes):

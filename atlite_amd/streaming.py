@@ -112,11 +112,11 @@ def run(ctx, spec, ds, plan, time_agg):
     # slab = 128 MiB of fp64 per variable (DMA sources), 512 MiB for file sources: one read call inflates
     # a slab's chunks in parallel, so a bigger slab keeps more host threads busy
     from_file = any(_is_file(a) for a in host.values())
-    # ... and 2 GiB when the chunks are zlib streams that the DEVICE inflates (one wavefront per stream: a read should carry
-    # a thousand of them, several reads are in flight)
+    # ... and 4 GiB when the chunks are zlib streams that the DEVICE inflates (one wavefront per stream, the device holds 8192 of
+    # them; a read is ONE launch that its own DMAs feed, so a year of the C2 grid is best read as one slab)
     on_device = from_file and os.environ.get("ATLITE_HIP_INFLATE", "") in ("", "device") and any(
         _is_file(a) and a.var.deflate is not None for a in host.values())
-    slab_bytes = int(os.environ.get("ATLITE_HIP_SLAB_BYTES", (2 << 30) if on_device else (512 << 20) if from_file else (128 << 20)))
+    slab_bytes = int(os.environ.get("ATLITE_HIP_SLAB_BYTES", (4 << 30) if on_device else (512 << 20) if from_file else (128 << 20)))
     steps = int(os.environ.get("ATLITE_HIP_SLAB_STEPS", 0)) or max(8, min(T, slab_bytes // max(S * 8, 1)) // 8 * 8)
     # file sources: whole chunks per slab, so that no chunk is inflated twice
     tchunk = max([a.var.chunks[0] for a in host.values() if _is_file(a) and a.var.layout == "chunked"], default=0)

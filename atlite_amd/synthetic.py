@@ -59,12 +59,8 @@ def pv_inputs(ctx, T, Y, X, start="2013-01-01", offset_hours=0, seed=42, interle
         out = {k: ctx.empty((T, S)) for k in PV_VARS}
     # the hash is indexed by the GLOBAL linear index so time shards of one cutout are consistent
     s = _lib.SynthSolar(tabs["sin_dec"].ptr, tabs["cos_dec"].ptr, tabs["h"].ptr, tabs["lat"].ptr,
-                        tabs["tseason"].ptr, X, Y, int(seed) + 1000003 * int(offset_hours))
-    check(ctx.lib.atl_set_slot_stride(ctx.handle, 0 if ld == S else ld))
-    try:
-        check(ctx.lib.atl_synth_pv_inputs(ctx.handle, C.byref(s), T, S, *[out[k].ptr for k in PV_VARS]))
-    finally:
-        check(ctx.lib.atl_set_slot_stride(ctx.handle, 0))
+                        tabs["tseason"].ptr, X, Y, int(seed) + 1000003 * int(offset_hours), 0 if ld == S else ld)
+    check(ctx.lib.atl_synth_pv_inputs(ctx.handle, C.byref(s), T, S, *[out[k].ptr for k in PV_VARS]))
     ctx.sync()
     return out, dict(x=x, y=y, time=t)
 

@@ -101,6 +101,11 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="replay a rank's launches of one step (slot stride, fused kernel, k_combine) as ONE hipGraph "
                          "(atl_capture_begin / atl_graph_launch)")
+    ap.add_argument("--workloads", default=None,
+                    help="N > 1 (or --debug-gloo-one-gpu): comma-separated subset of the extra multi-GPU workloads c4,c5 run after the "
+                         "C2 line (default: both when N > 1; 'none' to skip) - BASELINE configs[3] (pv 8760x800x800, 500 shapes, in-kernel "
+                         "solar position, time-sharded) and configs[4] (heat demand + runoff 35040x400x400, 50 shapes, day-aligned shards)")
+    ap.add_argument("--workload-steps", type=int, default=5)
     ap.add_argument("--legs", default="all",
                     help="comma-separated subset of the N = 1 legs: headline,night_skip,star_polygons,api,separate_cubes,"
                          "from_file,cpu,c3_series,c3_cf_map,c3_aggregated,c5_heat,c5_runoff,odd_caller,c4_full_sp (default: all)")
@@ -282,7 +287,6 @@ def generate_pv(ctx, synthetic, solar, _lib, T_loc, Y, X, off, stored_angles, in
         big, ld = {k: ctx.empty((T_loc, S)) for k in five}, S
     g = max(1, min(GEN_STEPS * S // ld, T_loc))  # the scratch shares the cubes' slot stride: the same bytes either way
     alt, az = ctx.empty((g * ld,)), ctx.empty((g * ld,))
-    _lib.check(ctx.lib.atl_set_slot_stride(ctx.handle, 0 if ld == S else ld))
     for a in range(0, T_loc, g):
         n = min(g, T_loc - a)
         t = synthetic.time_index(n, "2013-01-01", off + a)
@@ -290,11 +294,10 @@ def generate_pv(ctx, synthetic, solar, _lib, T_loc, Y, X, off, stored_angles, in
         doy, hour = np.asarray(t.dayofyear, float), np.asarray(t.hour, float)
         tseason = 283.15 + 12.0 * np.sin(2 * np.pi * (doy - 110.0) / 365.0) + 5.0 * np.sin(2 * np.pi * (hour - 9.0) / 24.0)
         tabs = [ctx.upload(v) for v in (np.sin(dec), np.cos(dec), h, np.radians(y), tseason)]
-        s = _lib.SynthSolar(*[v.ptr for v in tabs], X, Y, 42 + 1000003 * (off + a))
+        s = _lib.SynthSolar(*[v.ptr for v in tabs], X, Y, 42 + 1000003 * (off + a), 0 if ld == S else ld)
         ptrs = [big[k].ptr + a * ld * 8 for k in five] + [alt.ptr, az.ptr]
         _lib.check(ctx.lib.atl_synth_pv_inputs(ctx.handle, C.byref(s), n, S, *ptrs))
         ctx.sync()
-    _lib.check(ctx.lib.atl_set_slot_stride(ctx.handle, 0))
     del alt, az
     t = synthetic.time_index(T_loc, "2013-01-01", off)
     h, dec = solar.hour_angle(t, x, "-30min")
@@ -533,6 +536,240 @@ def config_legs(ctx, legs, reps, check=True):
     return out
 
 
+def sharded_workload(name, ctx, a, rank, world, dev, torch, dist, comm, mode, barrier, fence, D, _lib, gis, synthetic, solar, parts=None):
+    """One of BASELINE.json's 8-GPU configurations as a `world`-rank run: every rank converts + aggregates its own time shard,
+    ONE ragged all-gather per result reassembles (shapes x time) on every rank.
+      c4  configs[3]: pv CSi 8760 x 800 x 800, 500 shapes, in-kernel solar position (5 cubes, 40 B per cell-step)
+      c5  configs[4]: heat demand (daily means; shards on calendar days) + runoff, 35040 x 400 x 400, 50 shapes (8 B + 8 B)
+    mode: "lib" (atl_allgather_time_v[_async] on the library's communicator), "torch" (torch.distributed, padded blocks),
+    "gloo-debug" (host copies, all ranks on one GPU) or "none" (no collective on this node: the ranks' own steps).
+    Returns ms per step with the gather behind the next step's kernel and with the gather finished inside the step, the kernel
+    ms of every rank, the gather alone, and the parity of THIS rank's block against the oracle on a sample."""
+    from oracle import atlite_oracle as orc
+
+    # parts: shards of the time axis (= world; --emulate-shard N on one GPU: N, of which this process runs rank 0's, no collective)
+    parts = world if parts is None else parts
+    assert parts == world or (world == 1 and mode == "none")
+    steps, warm = max(2, a.workload_steps), 2
+    if name == "c4":
+        T, Y, X, N = 8760, 800, 800, 500
+        bpc, align = 40, 1
+    elif name == "c5":
+        T, Y, X, N = 35040, 400, 400, 50
+        bpc, align = 16, 24
+    else:
+        raise ValueError(f"unknown workload {name!r}")
+    if os.environ.get("ATL_BENCH_WORKLOAD_SCALE"):  # testing: a fraction of the time axis (whole days)
+        T = max(48 * parts, int(T * float(os.environ["ATL_BENCH_WORKLOAD_SCALE"])) // 24 * 24)
+    S = Y * X
+    edges = D.time_partition(T, parts, align=align)
+    lens = [edges[r + 1] - edges[r] for r in range(parts)]
+    T_loc, off = lens[rank], edges[rank]
+    x, y = synthetic.grid_coords(Y, X)
+    dx, dy = x[1] - x[0], y[1] - y[0]
+    polys = gis.random_tessellation(N, (x[0] - dx / 2, y[0] - dy / 2, x[-1] + dx / 2, y[-1] + dy / 2), seed=42)
+    M = gis.compute_indicatormatrix(x, y, polys, ctx=ctx)
+
+    def rows(dev_arr, sel):
+        return np.stack([dev_arr.slab(int(t), int(t) + 1).numpy()[0] for t in sel])
+
+    def close(got, ref, atol=None):
+        scale = float(np.nanmax(np.abs(ref))) if np.size(ref) else 0.0
+        atol = 1e-12 * scale if atol is None else atol
+        err = np.abs(got - ref) - atol
+        rel = float(np.nanmax(err / np.maximum(np.abs(ref), 1e-300))) if np.size(ref) else 0.0
+        return {"ok": bool(np.allclose(got, ref, rtol=1e-10, atol=atol, equal_nan=True)), "checked_values": int(np.size(ref)),
+                "max_rel_err_beyond_atol": max(rel, 0.0), "rtol": 1e-10}
+
+    # ---- the rank's shard: cubes, plan, and the launches of one step as (result name, slots, launch(out_ptr, ld_out)) ----------
+    if name == "c4":
+        big, _x, _y, tables = generate_pv(ctx, synthetic, solar, _lib, T_loc, Y, X, off, False, interleaved=True)
+        ld = next(iter(big.values())).ld
+        plan = ctx.plan(M, row_len=X, ld=ld)
+        params, tabs = dict(CSI, **ORI), dict(tables)
+        outs = [("pv", lens, lambda ptr, ldo: ctx.pv(big, params, T_loc, S, plan=plan, solar_tables=tabs, options=dict(night_skip=False),
+                                                     out=(ptr, ldo)))]
+
+        def parity(block):
+            sel = np.unique(np.clip(np.concatenate([np.arange(0, 8), np.arange(T_loc // 2, T_loc // 2 + 8)]), 0, T_loc - 1))
+            host = {k: rows(v, sel) for k, v in big.items()}
+            al, az = orc.solar_position(synthetic.time_index(T_loc, "2013-01-01", off)[sel], x, y, "-30min")
+            host["solar_altitude"], host["solar_azimuth"] = al.reshape(len(sel), S), az.reshape(len(sel), S)
+            ref = np.concatenate([orc.aggregate_matrix(orc.convert_pv({k: v[i:i + 8] for k, v in host.items()}, CSI, ORI), M)
+                                  for i in range(0, len(sel), 8)], axis=1)
+            return close(block["pv"][:, sel], ref)
+    else:
+        d = synthetic.heat_runoff_inputs(ctx, T_loc, Y, X)
+        plan = ctx.plan(M, row_len=X)
+        day_ptr = np.arange(0, T_loc + 1, 24)
+        if day_ptr[-1] != T_loc:
+            day_ptr = np.append(day_ptr, T_loc)
+        day_lens = [-(-l // 24) for l in lens]  # every shard starts on a day boundary (time_partition(align=24))
+        outs = [("heat_demand", day_lens, lambda ptr, ldo: ctx.heat_demand(d["temperature"], day_ptr, 288.15, 1.0, 0.0, T_loc, S, plan=plan,
+                                                                          out=(ptr, ldo))),
+                ("runoff", lens, lambda ptr, ldo: ctx.runoff(d["runoff"], d["height"], T_loc, S, plan=plan, out=(ptr, ldo)))]
+
+        def parity(block):
+            days = np.unique(np.concatenate([[0, 1, len(day_ptr) - 2], np.random.default_rng(2).integers(0, len(day_ptr) - 1, 5)]))
+            ref = []
+            for dd in days:
+                blk = d["temperature"].slab(int(day_ptr[dd]), int(day_ptr[dd + 1])).numpy()
+                ref.append(orc.aggregate_matrix(orc.convert_heat_demand(blk, np.array([0, blk.shape[0]]), threshold=15.0, a=1.0, constant=0.0), M)[:, 0])
+            p1 = close(block["heat_demand"][:, days], np.stack(ref, axis=1), atol=1e-9)
+            sel = np.unique(np.concatenate([np.arange(0, 12), [T_loc // 2, T_loc - 1]]))
+            p2 = close(block["runoff"][:, sel], orc.aggregate_matrix(orc.convert_runoff(rows(d["runoff"], sel), d["height"].numpy()[None, :]), M))
+            return {"ok": p1["ok"] and p2["ok"], "heat_demand": p1, "runoff": p2}
+
+    # ---- buffers: per result two pieces (step parity) and the gathered (N x sum of slots) --------------------------------------
+    side = torch.cuda.Stream(device=dev) if mode == "torch" else None
+    bufs = []
+    for rname, slens, fn in outs:
+        mine, tot, mx = slens[rank], sum(slens), max(slens)
+        b = dict(name=rname, lens=slens, fn=fn, mine=mine, total=tot, start=sum(slens[:rank]),
+                 piece=[torch.empty((N, max(mine, 1)), dtype=torch.float64, device=dev) for _ in range(2)],
+                 full=torch.empty((N, tot), dtype=torch.float64, device=dev), ticket=[None, None])
+        if mode in ("torch", "gloo-debug"):  # equal-sized blocks for all_gather_into_tensor: shards padded to the longest
+            b["pad"] = [torch.zeros((N, mx), dtype=torch.float64, device=dev) for _ in range(2)]
+            b["gb"] = [torch.empty((world, N, mx), dtype=torch.float64, device=dev) for _ in range(2)]
+        bufs.append(b)
+
+    def gather(b, par, overlap):
+        if mode == "none":
+            b["full"][:, b["start"]:b["start"] + b["mine"]].copy_(b["piece"][par][:, :b["mine"]])
+            return
+        if mode == "lib":
+            if overlap:
+                b["ticket"][par] = comm.gather_time_v_async(b["piece"][par].data_ptr(), N, b["lens"], b["full"].data_ptr(), b["total"])
+            else:
+                h_lens = (C.c_int64 * world)(*b["lens"])
+                _lib.check(ctx.lib.atl_allgather_time_v(comm.handle, b["piece"][par].data_ptr(), N, h_lens, b["full"].data_ptr(), b["total"]))
+            return
+        pad, gb = b["pad"][par], b["gb"][par]
+        pad[:, :b["mine"]].copy_(b["piece"][par][:, :b["mine"]])
+
+        def place():
+            o = 0
+            for r in range(world):
+                b["full"][:, o:o + b["lens"][r]].copy_(gb[r, :, :b["lens"][r]])
+                o += b["lens"][r]
+
+        if mode == "gloo-debug":
+            torch.cuda.current_stream().synchronize()
+            host = torch.empty(gb.shape, dtype=torch.float64)
+            dist.all_gather_into_tensor(host.view(-1), pad.cpu().view(-1))
+            gb.copy_(host)
+            place()
+            return
+        w = dist.all_gather_into_tensor(gb.view(-1), pad.view(-1), async_op=True)
+        if overlap:
+            with torch.cuda.stream(side):
+                w.wait()
+                place()
+                ev = torch.cuda.Event()
+                ev.record(side)
+                b["ticket"][par] = ev
+        else:
+            w.wait()
+            place()
+
+    step_no = [0]
+
+    def step(overlap):
+        par = step_no[0] & 1
+        step_no[0] += 1
+        for b in bufs:
+            t = b["ticket"][par]
+            if t is not None:  # the gather that last read this piece (two steps back)
+                if mode == "lib":
+                    comm.wait(t)
+                else:
+                    torch.cuda.current_stream().wait_event(t)
+                b["ticket"][par] = None
+            b["fn"](b["piece"][par].data_ptr(), b["piece"][par].stride(0))
+            gather(b, par, overlap)
+
+    def timed(overlap):
+        n_k = len(bufs)
+        ctx.set_profiling(max(2, (steps + warm) * n_k))
+        for _ in range(warm):
+            step(overlap)
+        fence()
+        ctx.set_profiling(max(2, steps * n_k))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(overlap)
+        fence()
+        dt = time.perf_counter() - t0
+        k = np.asarray(ctx.kernel_times(), float)
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        k_step = float(k.reshape(-1, n_k).sum(axis=1).mean()) if k.size and k.size % n_k == 0 else (float(k.sum()) / steps if k.size else None)
+        return dt / steps * 1e3, k_step
+
+    can_overlap = mode in ("lib", "torch")
+    ms_ov, k_ov = timed(True) if can_overlap else (None, None)
+    ms_sync, k_sync = timed(False)
+    ms_step = ms_ov if ms_ov is not None else ms_sync
+    k_ms = k_ov if k_ov is not None else k_sync
+    # the gather alone (every result of one step), nothing to hide behind
+    gather_ms = None
+    if mode != "none":
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            for b in bufs:
+                gather(b, 0, False)
+        fence()
+        tg = torch.tensor([(time.perf_counter() - t0) / 5 * 1e3], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        gather_ms = float(tg.item())
+    per_rank = [k_ms]
+    if world > 1:
+        mine_t = torch.tensor([k_ms or 0.0], dtype=torch.float64)
+        lst = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(lst, mine_t)
+        per_rank = [float(v.item()) for v in lst]
+    # ---- checks: this rank's block in place and equal to the oracle on a sample; all ranks hold the same gathered result --------
+    step(False)
+    fence()
+    block, placed_ok, agree = {}, True, True
+    for b in bufs:
+        own = b["piece"][(step_no[0] - 1) & 1][:, :b["mine"]]
+        placed_ok = placed_ok and bool(torch.equal(b["full"][:, b["start"]:b["start"] + b["mine"]], own))
+        block[b["name"]] = own.cpu().numpy()
+        if world > 1 and mode != "none":
+            chk = torch.stack([b["full"].sum(), b["full"].abs().sum()]).cpu()
+            lst = [torch.zeros_like(chk) for _ in range(world)]
+            dist.all_gather(lst, chk)
+            agree = agree and all(torch.equal(v, chk) for v in lst)
+    par = parity(block) if not a.no_parity else None
+    if world > 1 and par is not None:  # every rank checks its own shard; the line carries rank 0's record and the AND over ranks
+        okf = torch.tensor([1 if par["ok"] else 0], dtype=torch.int32)
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        par["ok_on_every_rank"] = bool(int(okf.item()) == 1)
+    cells = (T if parts == world else T_loc) * S  # (an emulated shard: this rank's own cell-steps)
+    info = plan.info()
+    return {
+        "workload": (f"configs[3]: pv CSi slope 30 az 180, {T}x{Y}x{X} fp64, {N} tessellation shapes, in-kernel solar position (5 cubes, 40 B per "
+                     f"cell-step)" if name == "c4" else
+                     f"configs[4]: heat demand (threshold 15, daily means) + runoff x height, {T}x{Y}x{X} fp64, {N} tessellation shapes "
+                     f"(8 B + 8 B per cell-step), shards on calendar days") + f"; time-sharded x{parts}, {info['tile_w']}x{info['tile_h']} tiles, "
+                    f"{info['n_partial_rows']} partial rows",
+        "value": cells / (ms_step * 1e-3), "unit": "cell-timesteps/s", "scaling": "strong", "n_gpus": world, "shards": parts, "steps": steps,
+        "ms_per_step": ms_step, "ms_per_step_gather_overlapped": ms_ov, "ms_per_step_gather_inside_the_step": ms_sync,
+        "time_steps_per_gpu": lens, "per_rank_kernel_ms": per_rank, "gather_ms": gather_ms,
+        "result_bytes": int(sum(N * b["total"] * 8 for b in bufs)), "collective": mode,
+        "ranks_seen": (comm.info()["n_ranks"] if comm is not None else None),
+        "algorithmic_bytes_per_rank": int(bpc * T_loc * S),
+        "frac_of_hbm_peak_rank_kernel": (bpc * T_loc * S / (k_ms * 1e-3) / 1e9 / PEAK_GBPS) if k_ms else None,
+        "own_block_in_place": placed_ok, "ranks_agree_on_the_result": agree, "parity": par,
+    }
+
+
+
 def self_launch(a):
     """``python bench.py --gpus N`` without an external launcher: re-run this very command line under
     ``python -m torch.distributed.run`` (one rank per GPU, rendezvous on 127.0.0.1) and hand its exit code back.
@@ -560,8 +797,9 @@ def self_launch(a):
     return subprocess.run(cmd, env=env).returncode
 
 
-def from_file_leg(ctx, _lib, gis, M, Y, X, T=2920, chunks=(24, 100, 100)):
-    """pv from a cutout file, device inflate vs host inflate: seconds, cell-steps/s, GB/s of file and fp64-equivalent GB/s."""
+def from_file_leg(ctx, _lib, gis, M, Y, X, T=8760, chunks=(24, 100, 100), host_calls=1, device_calls=4):
+    """pv from a cutout file, device inflate vs host inflate: seconds, cell-steps/s, GB/s of file and fp64-equivalent GB/s.
+    Default: a whole year of the C2 grid (10 220 chunk streams of 960 kB: more than the 8 192 the device holds at a time)."""
     import subprocess
     import tempfile
 
@@ -574,10 +812,10 @@ def from_file_leg(ctx, _lib, gis, M, Y, X, T=2920, chunks=(24, 100, 100)):
     path = os.path.join(tmp, "cutout.nc")
     t0 = time.perf_counter()
     subprocess.run([conda, str(ROOT / "tests" / "golden" / "make_nc_fixtures.py"), "--cutout", path, str(T), str(Y), str(X),
-                    *[str(c) for c in chunks], "f4", "11", str(max(2, len(os.sched_getaffinity(0))))], check=True, timeout=300)
+                    *[str(c) for c in chunks], "f4", "11", str(max(2, len(os.sched_getaffinity(0)))), "pv"], check=True, timeout=400)
     t_write = time.perf_counter() - t0
     names = ["influx_direct", "influx_diffuse", "influx_toa", "albedo", "temperature", "solar_altitude", "solar_azimuth"]
-    out = {"file": f"NetCDF-4, {T}x{Y}x{X} float32, chunks {chunks}, shuffle + zlib level 1, 11 cubes (7 read); written in {t_write:.1f} s",
+    out = {"file": f"NetCDF-4, {T}x{Y}x{X} float32, chunks {tuple(chunks)}, shuffle + zlib level 1, the 7 pv cubes; written in {t_write:.1f} s",
            "call": "Cutout(path).pv(panel='CSi', orientation={slope:30,azimuth:180}, matrix=M, aggregate_time=None).values"}
     try:
         cf = aa.Cutout(path)
@@ -585,6 +823,7 @@ def from_file_leg(ctx, _lib, gis, M, Y, X, T=2920, chunks=(24, 100, 100)):
             M = gis.compute_indicatormatrix(cf.coords["x"], cf.coords["y"], gis.random_tessellation(100, cf.bounds, seed=0))
         kw = dict(panel="CSi", orientation={"slope": 30.0, "azimuth": 180.0}, matrix=M, aggregate_time=None)
         disk = sum(cf.data.file.variables[v].stored_bytes for v in names)
+        out["chunk_streams"] = int(sum(cf.data.file.variables[v].n_chunks for v in names))
         cells = T * Y * X
         dctx = default_context_of()
 
@@ -604,20 +843,28 @@ def from_file_leg(ctx, _lib, gis, M, Y, X, T=2920, chunks=(24, 100, 100)):
                 r = cf.pv(**kw).values
                 ts.append(time.perf_counter() - t0)
             best = min(ts)
-            return r, {"first_s": ts[0], "best_s": best, "value": cells / best, "unit": "cell-timesteps/s",
+            return r, {"first_s": ts[0], "best_s": best, "calls": n, "value": cells / best, "unit": "cell-timesteps/s",
                        "file_GBps": disk / best / 1e9, "fp64_equivalent_GBps": 7 * cells * 8 / best / 1e9}
 
         try:
-            r_dev, out["device_inflate"] = leg("device", 4)
-            m0, c0, r0, s0 = times()
-            cf.pv(**kw)
-            m1, c1, r1, s1 = times()
-            dm = m1 - m0
-            out["device_inflate"]["one_warm_call"] = {
-                "host_gather_ms": dm[0], "h2d_ms": dm[1], "k_inflate_ms": dm[2], "k_adler_ms": dm[3], "k_unpack_ms": dm[4],
-                "streams": s1[0] - s0[0], "redone_on_host": s1[2] - s0[2], "compressed_bytes": c1 - c0, "inflated_bytes": r1 - r0,
-                "note": "HIP-event times on the staging slots' own streams; up to four reads are in flight, so the sum exceeds the wall time"}
-            r_host, out["host_inflate"] = leg("host", 3)
+            st0 = times()[3]
+            r_dev, out["device_inflate"] = leg("", device_calls)  # the library's own choice (device from 1024 streams on)
+            st1 = times()[3]
+            out["device_inflate"]["chunks_inflated_on_the_device"] = st1[0] - st0[0]
+            out["device_inflate"]["chunks_inflated_on_host_threads"] = st1[1] - st0[1]
+            if st1[0] - st0[0] > 0:
+                m0, c0, r0, s0 = times()
+                cf.pv(**kw)
+                m1, c1, r1, s1 = times()
+                dm = m1 - m0
+                out["device_inflate"]["one_warm_call"] = {
+                    "host_gather_ms": dm[0], "h2d_ms": dm[1], "k_inflate_ms": dm[2], "unpack_of_unwritten_chunks_ms": dm[4],
+                    "streams": s1[0] - s0[0], "redone_on_host": s1[2] - s0[2], "compressed_bytes": c1 - c0, "inflated_bytes": r1 - r0,
+                    "note": "ONE fed launch: the kernel starts first, the compressed bytes follow in DMA batches (h2d_ms: first to last "
+                            "DMA), each wave waits for its stream's batch, then inflates, checks the Adler-32 and unpacks its chunk "
+                            "(k_inflate_ms spans all of that, waits included); host_gather_ms is the preads' wall time inside the same "
+                            "window - the three overlap"}
+            r_host, out["host_inflate"] = leg("host", host_calls)
             out["bit_identical"] = bool(np.array_equal(np.asarray(r_dev), np.asarray(r_host)))
             out["stored_bytes"] = int(disk)
         finally:
@@ -1269,6 +1516,12 @@ def main():
                 result["from_file"] = from_file_leg(ctx, _lib, gis, M if (Y, X) == (200, 200) else None, Y, X)
             except Exception as e:  # noqa: BLE001 - a side leg must not cost the run its line
                 result["from_file"] = {"skipped": repr(e)}
+            try:  # the same grid chunked (time = 100, y, x) - atlite's own chunks={"time": 100} written through: 16 MB streams, few
+                # of them (a third of a year: 210); a zlib stream is sequential, so these stay on the host threads
+                result["from_file_large_chunks"] = from_file_leg(ctx, _lib, gis, M if (Y, X) == (200, 200) else None, Y, X, T=3000,
+                                                                 chunks=(100, Y, X), device_calls=2)
+            except Exception as e:  # noqa: BLE001
+                result["from_file_large_chunks"] = {"skipped": repr(e)}
 
         # (4) the same cubes in an allocation each (the layout a caller's own device arrays have, and the library's before
         # round 3): same kernel, same bytes, bit-identical result - the memory system alone makes the difference
@@ -1350,6 +1603,28 @@ def main():
             result["configs"] = config_legs(ctx, cfg_legs, max(3, min(a.steps, 6)), check=not a.no_parity)
         except Exception as e:  # noqa: BLE001 - never a reason to lose the headline line
             result["configs"] = {"error": repr(e)[:400]}
+
+    # ---- N > 1: the two configurations BASELINE.json names for 8 GPUs, in the same run and the same JSON line ----
+    wl = a.workloads if a.workloads is not None else ("c4,c5" if world > 1 else "none")
+    wl = [w.strip() for w in wl.split(",") if w.strip() and w.strip() != "none"]
+    if wl:
+        # drop the C2 cubes and buffers (the closures above share these cells: rebinding the names releases the memory)
+        inputs = plan = full = full3 = piece = pin = pins = gbuf = tables = piece2 = gbuf2 = placed = None  # noqa: F841
+        import gc
+
+        gc.collect()
+        mode = "none" if (collective_failed or world == 1) else "gloo-debug" if a.debug_gloo_one_gpu else "lib" if use_lib else "torch"
+        result["workloads"] = {}
+        for name in wl:
+            try:  # each workload on its own: one failure must not cost the others' numbers, nor the C2 line
+                result["workloads"][name] = sharded_workload(
+                    name, ctx, a, rank, world, dev, torch, dist, comm if use_lib else None, mode, barrier, fence, D, _lib, gis, synthetic, solar,
+                    parts=parts)
+            except Exception as e:  # noqa: BLE001
+                import traceback
+
+                result["workloads"][name] = {"error": repr(e)[:300], "where": traceback.format_exc()[-600:]}
+            gc.collect()
 
     if rank == 0:
         print(json.dumps(result))

@@ -35,7 +35,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define ATL_VERSION 100 /* 0.1.0 */
+#define ATL_VERSION 102 /* 0.1.2: atl_set_slot_stride removed, atl_event_record(..., 2), atl_synth_solar.ld_cells */
 
 #define ATL_OK 0
 #define ATL_E_INVALID (-1)     /* bad argument (maps to ValueError) */
@@ -71,14 +71,14 @@ int atl_upload(atl_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /*
 int atl_download(atl_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* blocking */
 int atl_memset(atl_ctx *ctx, void *d_dst, int byte_value, size_t bytes);
 /* Pitched cubes.  The kernels stream whole 128-byte lines and own them by position, so a (T, S) cube is read fastest when
- * every slot starts on a line: S % 16 == 0, or slots PADDED to a multiple of 16 cells.  atl_set_slot_stride(ctx, ld) tells
- * the context that the (T, S) INPUT cubes of the following calls (conversions, atl_spmm_csr, atl_agg_create's tile
- * choice, atl_nc_read_slab's output) have their slots ld cells apart (ld >= S; 0 = contiguous again); per-cell static
- * arrays, tables and every result stay contiguous.  atl_copy_2d moves pitched blocks (kind 0 host -> device, 1 device ->
- * host, 2 device -> device; blocking on the compute stream, or enqueued on the copy stream).  The Python layer pads its
- * own device copies of a cutout this way (atlite_amd.labeled.Dataset.device); the reference has no counterpart - numpy
- * arrays are contiguous (atlite/convert.py:198). */
-int atl_set_slot_stride(atl_ctx *ctx, int64_t ld_cells);
+ * every slot starts on a line: S % 16 == 0, or slots PADDED to a multiple of 16 cells.  The slot stride of a call's (T, S)
+ * INPUT cubes (conversions, atl_spmm_csr, atl_agg_create's tile choice, atl_nc_read_slab's output) is an ARGUMENT of the
+ * call: the *_ld entry points below (ld_cells >= S; 0 = contiguous); the entry points without it take contiguous cubes.
+ * (Rounds 3-5 exported atl_set_slot_stride, which made the stride mutable context state between two calls; removed in
+ * round 6, ATL_VERSION 102.)  Per-cell static arrays, tables and every result stay contiguous.  atl_copy_2d moves pitched
+ * blocks (kind 0 host -> device, 1 device -> host, 2 device -> device; blocking on the compute stream, or enqueued on the
+ * copy stream).  The Python layer pads its own device copies of a cutout this way (atlite_amd.labeled.Dataset.device); the
+ * reference has no counterpart - numpy arrays are contiguous (atlite/convert.py:198). */
 int atl_copy_2d(atl_ctx *ctx, void *dst, size_t dst_pitch_bytes, const void *src, size_t src_pitch_bytes,
                 size_t width_bytes, size_t height, int kind, int async_on_copy_stream);
 
@@ -100,6 +100,12 @@ int atl_host_unregister(void *h_ptr);
 int atl_upload_async(atl_ctx *ctx, void *d_dst, const void *h_src, size_t bytes); /* copy stream */
 int atl_event_create(atl_ctx *ctx, atl_event **out);
 int atl_event_destroy(atl_event *ev);
+/* which_stream 0: the compute stream.  1: the copy stream, OBSERVED - reads whose chunks the device inflates
+ * (atl_nc_read_slab) are settled first, on the host: streams the device decoder declined are decoded again by the host
+ * decoders, and the verdict of a read that failed (a corrupt chunk) is returned HERE, once, with the host decoders' message
+ * (it is kept by the context until a call that can return it comes along: closing the file or reusing a staging slot does
+ * not lose it).  2: the copy stream as a fence only - the event is ordered behind those reads on the device, nobody waits and
+ * no verdict is consumed (block recycling uses it). */
 int atl_event_record(atl_ctx *ctx, atl_event *ev, int which_stream);
 int atl_stream_wait_event(atl_ctx *ctx, int which_stream, atl_event *ev);
 int atl_event_synchronize(atl_event *ev);
@@ -183,10 +189,9 @@ int atl_agg_info(const atl_agg *agg, int64_t *n_rows, int64_t *n_cells, int64_t 
                  int64_t *n_partial_rows, int32_t *tile_w, int32_t *tile_h);
 
 /* ---- the slot stride as an ARGUMENT (round 5) -----------------------------------------------------------------------
- * Every entry point that reads the context's slot stride (atl_set_slot_stride) has a twin that takes it with the call -
+ * Every entry point whose (T, S) cubes may have padded slots has a twin that takes the stride with the call -
  * ld_cells: cells between the slots of the call's (T, S) input cubes (for atl_nc_read_slab: of the OUTPUT block), 0 =
- * contiguous - and leaves the context's own setting untouched: one call instead of set / call / reset.  Declared here, the
- * originals' documentation applies. */
+ * contiguous.  Declared here, the originals' documentation applies. */
 int atl_agg_create_ld(atl_ctx *ctx, int64_t ld_cells, int64_t n_rows, int64_t n_cells, int64_t row_len, const int64_t *h_indptr,
                       const int32_t *h_indices, const double *h_data, atl_agg **out);
 int atl_spmm_csr_ld(atl_ctx *ctx, int64_t ld_cells, const atl_agg *agg, const double *d_dense, int64_t T, int64_t S, int time_agg,
@@ -232,7 +237,10 @@ typedef struct {
     const double *d_influx;         /* (T,S) or NULL (then influx_direct/diffuse are used) */
     const double *d_outflux;        /* (T,S), used iff d_albedo == NULL                    */
     const double *d_humidity;       /* (T,S), "enhanced" clearsky model only               */
-    /* night early-out with a DAY MAP (atl_pv_day_map; round 5): bit (t & 7) of d_day_map[tile * day_map_ld + (t >> 3)] =
+    /* (Zero-initialise the struct - memset or = {0} - before filling it in: fields are added at its END from one ATL_VERSION to
+     *  the next and 0 / NULL always means "not used", so a caller built against an older header keeps working only if the
+     *  bytes it does not know about are zero.  d_day_map / day_map_ld came with ATL_VERSION 101.)
+     * night early-out with a DAY MAP (atl_pv_day_map; round 5): bit (t & 7) of d_day_map[tile * day_map_ld + (t >> 3)] =
      * in time step t some cell of the plan's tile that carries a weight is above the altitude cut-off - what the early-out
      * kernel otherwise finds out by loading the tile's altitudes and voting.  Belongs to ONE (aggregation plan,
      * d_solar_altitude contents, altitude_threshold, T, slot stride); NULL = vote.  Read by atl_pv_convert_aggregate with
@@ -515,7 +523,9 @@ int atl_nc_att_double(atl_nc *f, const char *var, const char *att, double *out, 
 int atl_nc_read_host(atl_nc *f, const char *name, int64_t start0, int64_t count0, double *out);
 /* same rows as an fp64 (count0, prod(shape[1:])) block at d_out, asynchronously; the result is visible in the order of
  * the context's COPY stream (order against the compute stream with atl_event_record(ev, 1) /
- * atl_stream_wait_event(ctx, 0, ev)).  Two ways through the zlib streams of a chunked, deflated variable
+ * atl_stream_wait_event(ctx, 0, ev); the library's own copy-stream calls - atl_upload_async, atl_copy_2d(..., 1),
+ * atl_upload_convert_async, later reads - are ordered behind a read whose chunks the device inflates on its staging
+ * slot's stream: they make the copy stream wait for that slot first).  Two ways through the zlib streams of a chunked, deflated variable
  * (atlite/data.py:246-248 writes cutouts with zlib + shuffle):
  *  - on the DEVICE, one wavefront per chunk stream (k_inflate; round 5), when the rows asked for span at least
  *    $ATLITE_HIP_INFLATE_MIN_CHUNKS chunks (default 1024; $ATLITE_HIP_INFLATE=device: always): the host threads only
@@ -530,9 +540,11 @@ int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, 
 /* chunks of this context's atl_nc_read_slab calls so far: inflated on the device / on host threads / declined by the device
  * decoder and decoded again on the host (settles pending reads first) */
 /* The same rows of n_vars variables at once (what one conversion reads: a slab of the pv inputs): when every stored chunk
- * of the group is a plain zlib stream, ALL of them are inflated by ONE k_inflate launch - the device holds ~3600 streams at
- * a time, a single variable's rows rarely bring that many, and launches from different HIP streams do not add up (the
- * runtime multiplexes them onto four hardware queues).  Otherwise exactly n_vars atl_nc_read_slab calls. */
+ * of the group is a plain zlib stream, the rows are cut into JOBS of ~2048 streams across all the variables
+ * ($ATLITE_HIP_INGEST_JOB), each one k_inflate launch on its own staging slot and stream - the device holds 8192 streams
+ * at a time (round 6: 4.7 kB of LDS and 64 VGPRs per stream), a single variable's rows rarely bring that many - and the
+ * jobs are pipelined: pread + DMA of job k+1 run while job k is inflated and job k-1 unpacked.  Otherwise exactly n_vars
+ * atl_nc_read_slab calls. */
 int atl_nc_read_slabs(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *names, int64_t start0, int64_t count0,
                       double *const *d_outs, int n_threads);
 int atl_nc_read_slabs_ld(atl_ctx *ctx, int64_t ld_cells, atl_nc *f, int n_vars, const char *const *names, int64_t start0,
@@ -547,7 +559,7 @@ int atl_nc_ingest_times(atl_ctx *ctx, double *ms5, int64_t *compressed_bytes, in
 /* host array of a narrower dtype (what xarray hands over for a float32 cutout) -> fp64 on the
  * device through the same staging + decode kernel; halves the PCIe bytes of atl_upload_async */
 int atl_upload_convert_async(atl_ctx *ctx, double *d_dst, const void *h_src, int dtype, int64_t n);
-/* the same for a (rows, cols) host block into device rows ld_cells doubles apart (padded slots, atl_set_slot_stride) */
+/* the same for a (rows, cols) host block into device rows ld_cells doubles apart (padded slots) */
 int atl_upload_convert_2d_async(atl_ctx *ctx, double *d_dst, int64_t ld_cells, const void *h_src, int dtype,
                                 int64_t rows, int64_t cols);
 
@@ -667,6 +679,7 @@ typedef struct {
     const double *d_tseason; /* (T) seasonal+diurnal temperature term, K */
     int64_t X, Y;
     uint64_t seed;
+    int64_t ld_cells; /* cells between the slots of the OUTPUT cubes (>= S), 0 = contiguous */
 } atl_synth_solar;
 int atl_synth_pv_inputs(atl_ctx *ctx, const atl_synth_solar *s, int64_t T, int64_t S,
                         double *d_influx_direct, double *d_influx_diffuse, double *d_influx_toa,

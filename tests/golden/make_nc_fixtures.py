@@ -156,8 +156,12 @@ def _write_chunks_direct(v, a, chunks, level, threads, t0=0):
             v.id.write_direct_chunk((o[0] + t0, o[1], o[2]), payload)
 
 
-def write_cutout(path, T=48, Y=9, X=12, chunks=(20, 5, 7), dtype="f4", seed=7, gzip=6, start_hours=990552, threads=1):
-    """An ERA5-shaped cutout with every input of pv / wind / heat_demand / runoff (random but in range)."""
+PV_VARS = ("influx_toa", "influx_direct", "influx_diffuse", "albedo", "temperature", "solar_altitude", "solar_azimuth")
+
+
+def write_cutout(path, T=48, Y=9, X=12, chunks=(20, 5, 7), dtype="f4", seed=7, gzip=6, start_hours=990552, threads=1, only=None):
+    """An ERA5-shaped cutout with every input of pv / wind / heat_demand / runoff (random but in range).  ``only``: write just
+    these cubes (the bench's year-long file holds the seven pv inputs; the random draws stay those of the full set)."""
     rng = np.random.default_rng(seed)
     with h5py.File(path, "w", libver=("earliest", "v108"), track_order=True) as f:
         f.attrs["module"] = np.string_("era5")
@@ -196,6 +200,8 @@ def write_cutout(path, T=48, Y=9, X=12, chunks=(20, 5, 7), dtype="f4", seed=7, g
             for t0 in range(0, T, tb):
                 blk = make_fields(np.random.default_rng([seed, t0]), min(tb, T - t0))
                 for n, a in blk.items():
+                    if only is not None and n not in only:
+                        continue
                     if n not in dsets:
                         dsets[n] = f.create_dataset(n, shape=(T, Y, X), dtype=dtype, chunks=chunks, compression="gzip",
                                                     compression_opts=gzip, shuffle=True, track_order=True)
@@ -204,6 +210,8 @@ def write_cutout(path, T=48, Y=9, X=12, chunks=(20, 5, 7), dtype="f4", seed=7, g
                 finish(v, n)
         else:
             for n, a in make_fields(rng, T).items():
+                if only is not None and n not in only:
+                    continue
                 a = np.round(a * 4096) / 4096  # keeps the deflated fixture small
                 v = f.create_dataset(n, data=a.astype(dtype), chunks=chunks, compression="gzip", compression_opts=gzip,
                                      shuffle=True, track_order=True)
@@ -243,10 +251,10 @@ def main(out):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--cutout":  # --cutout path T Y X ct cy cx dtype seed
+    if len(sys.argv) > 2 and sys.argv[1] == "--cutout":  # --cutout path T Y X ct cy cx dtype seed [threads ["pv"]]
         a = sys.argv[2:]
         write_cutout(a[0], int(a[1]), int(a[2]), int(a[3]), (int(a[4]), int(a[5]), int(a[6])), a[7], int(a[8]), gzip=1,
-                     threads=int(a[9]) if len(a) > 9 else 1)
+                     threads=int(a[9]) if len(a) > 9 else 1, only=PV_VARS if len(a) > 10 and a[10] == "pv" else None)
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "--case":  # --case path T Y X ct cy cx libver track seed [unlimited axes, e.g. 0 or 01]
         a = sys.argv[2:]

@@ -1,7 +1,7 @@
 """
 GPU: the slot-interleaved residency of the library's own device copies (device.SlotPool, Dataset.device_group) - the cubes
 one conversion reads lie in ONE allocation, the variables of a time step side by side; the kernels see nothing but a slot
-stride (atl_set_slot_stride) and stream 5-9 % faster from it.  Same bits as with an allocation per cube
+stride (the ld_cells argument) and stream 5-9 % faster from it.  Same bits as with an allocation per cube
 (ATLITE_HIP_INTERLEAVE=0); a replaced variable returns to its slot; a call that needs another set of cubes regroups on the
 device; file-backed variables are inflated straight into their slots.
 Reference: the variables a conversion reads, atlite/convert.py:529-562 (pv), :597-610 (wind).

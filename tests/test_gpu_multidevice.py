@@ -208,6 +208,59 @@ def test_bench_prints_its_line_when_no_collective_works():
     assert j["value"] > 0 and j["ms_per_step"] > 0
 
 
+def _bench_line(args, scale="0.02", timeout=1200):
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, ATL_BENCH_WORKLOAD_SCALE=scale)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(root / "bench.py"), *args], capture_output=True, text=True, env=env, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_multi_gpu_line_carries_the_three_workloads():
+    """bench.py --gpus N (N > 1) prints ONE line that covers what BASELINE.json asks of 8 GPUs: C2 strong scaling (the line's
+    own value), configs[3] (pv 8760x800x800, in-kernel solar position) and configs[4] (heat demand + runoff 35040x400x400,
+    shards on calendar days) - each with per-rank kernel ms, the gather alone, the step with the gather inside it, the own block
+    in place, all ranks agreeing on the gathered result and an ORACLE parity sample of every rank's own shard.  Two ranks on
+    this one GPU, the collective over gloo on host copies, a fiftieth of the time axes."""
+    j = _bench_line(["--gpus", "2", "--debug-gloo-one-gpu", "--steps", "2", "--warmup", "1", "--T", "960", "--no-cpu-baseline",
+                     "--no-extras", "--workload-steps", "2"])
+    assert j["n_gpus"] == 2 and j["value"] > 0
+    w = j["workloads"]
+    assert set(w) == {"c4", "c5"}, w
+    for name in ("c4", "c5"):
+        e = w[name]
+        assert "error" not in e, e
+        assert e["n_gpus"] == 2 and e["shards"] == 2 and e["collective"] == "gloo-debug"
+        assert e["own_block_in_place"] and e["ranks_agree_on_the_result"], e
+        assert e["parity"]["ok"] and e["parity"]["ok_on_every_rank"], e["parity"]
+        assert len(e["per_rank_kernel_ms"]) == 2 and all(v > 0 for v in e["per_rank_kernel_ms"])
+        assert e["gather_ms"] > 0 and e["ms_per_step"] > 0 and e["value"] > 0
+    assert all(v % 24 == 0 for v in w["c5"]["time_steps_per_gpu"]), w["c5"]["time_steps_per_gpu"]  # calendar days stay whole
+    assert w["c5"]["parity"]["heat_demand"]["ok"] and w["c5"]["parity"]["runoff"]["ok"]
+
+
+def test_bench_workloads_on_an_emulated_shard():
+    """--emulate-shard 8 --workloads c4,c5 on one GPU: rank 0's shard of the 8-way split of both configurations (no collective),
+    the figures the scaling rehearsal (profiles/r06_scale_rehearsal.json) predicts the 8-GPU speed-up from."""
+    j = _bench_line(["--emulate-shard", "8", "--workloads", "c4,c5", "--steps", "2", "--warmup", "1", "--T", "960", "--no-cpu-baseline",
+                     "--no-extras", "--workload-steps", "2"], scale="0.05")
+    for name in ("c4", "c5"):
+        e = j["workloads"][name]
+        assert "error" not in e, e
+        assert e["shards"] == 8 and e["n_gpus"] == 1 and e["collective"] == "none"
+        assert e["parity"]["ok"] and e["own_block_in_place"], e
+
+
 # ---- the N-rank collective code on ONE GPU: the in-process transport (atl_comm_init_local) ----------------------
 def _local_ranks(n):
     """n Contexts on device 0 + their communicators of one local group (each built on its own thread: the rendezvous

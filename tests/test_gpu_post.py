@@ -132,6 +132,34 @@ def test_runoff_chain_at_config5_result_size(ctx, chunked):
     close(got2, ref2)
 
 
+@pytest.mark.parametrize("chunked", [False, True])
+def test_per_cell_runoff_is_smoothed_and_thresholded_without_shapes(ctx, chunked):
+    """Cutout.runoff(smooth=..., lower_threshold_quantile=...) WITHOUT shapes or a matrix: the result is the per-cell
+    (time, y, x) cube, and the reference's post-processing handles any rank - rolling(time=w, min_periods=1).mean() runs along
+    time for every cell, the threshold is the quantile of ALL the cube's values (atlite/convert.py:1046-1062).  The cube
+    reaches the host first; the same device routines then run on an upload, every cell a row."""
+    T, Y, X = 400, 5, 7
+    rng = np.random.default_rng(21)
+    t = pd.date_range("2013-03-01", periods=T, freq="h")
+    ro = rng.gamma(0.3, 1e-4, size=(T, Y, X))
+    ro[rng.random((T, Y, X)) < 0.02] = np.nan
+    height = rng.uniform(0.0, 2000.0, size=(Y, X))
+    c = Cutout(Dataset({"runoff": ro, "height": height}, dict(time=t, y=np.arange(Y, dtype=float), x=np.arange(X, dtype=float)),
+                       chunked=chunked))
+    cube = orc.convert_runoff(ro, height[None])  # (T, Y, X)
+    rows = cube.reshape(T, Y * X).T               # every cell a row, time last: what runoff_postprocess restates
+    for kw in (dict(smooth=24), dict(smooth=True, lower_threshold_quantile=0.3), dict(lower_threshold_quantile=True)):
+        r = c.runoff(aggregate_time=None, **kw)
+        assert r.dims == ("time", "y", "x") and r.shape == (T, Y, X), (r.dims, r.shape)
+        ref = orc.runoff_postprocess(rows, t, None, **kw).T.reshape(T, Y, X)
+        close(np.asarray(r.values), ref)
+        if "lower_threshold_quantile" in kw:
+            assert (np.asarray(r.values) == 0.0).any()
+    # the yearly normalisation needs rows with labels: refused for a per-cell cube, with a message that says what to pass
+    with pytest.raises(ValueError, match="shapes or a matrix"):
+        c.runoff(aggregate_time=None, normalize_using_yearly=pd.DataFrame({"a": [1.0]}, index=["2013"]))
+
+
 def test_small_device_blocks_are_recycled_and_results_arrive_in_pinned_memory(ctx):
     """Context.empty / DeviceArray.free recycle small blocks by size (hipMalloc + hipFree cost more than a warm result
     download); DeviceArray.numpy() hands back page-locked memory for results of 64 KiB .. 1 GiB - same values either way."""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """
 Padded slots against contiguous cubes on grids whose cell count is not a multiple of 16 (real-world ERA5 cutouts): the same
-synthetic pv cubes once as (T, S) contiguous and once with every slot padded to a 128-byte line (atl_set_slot_stride, what
+synthetic pv cubes once as (T, S) contiguous and once with every slot padded to a 128-byte line (ld_cells, what
 Dataset.device() does for the library's own device copies), pv convert + aggregate and the per-cell capacity-factor map.
 usage: tools/bench_pitch.py [Y X]...
 """
