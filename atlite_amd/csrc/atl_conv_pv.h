@@ -267,9 +267,6 @@ ATL_HD __forceinline__ double pv_cell(double dir, double dif, double toa, double
     const double influx = direct + diffuse;
     // irradiation.py:251-252 (NaN compares false: a NaN altitude is not capped)
     const bool capped = (alt < k.alt_thr) || (influx <= 0.01);
-#ifdef ATL_ABLATE_NOMATH  // experiment: keep the 7 streams, drop the physics
-    return influx + alb + tmp + alt + az;
-#endif
     if (capped) return 0.0;  // G = 0 -> G_ = 0, eff -> 0 : 0*0*inv
     double sa, ca;
     lean_sincos(alt, &sa, &ca);
@@ -307,11 +304,7 @@ ATL_HD __forceinline__ PvPlain pv_tail_plain(double direct, double diffuse, doub
                                                  const PvOri &o, const PvConst &k, double toa = 1.0) {
     const double inf = __builtin_inf();
     const double cosinc = __builtin_fmax(o.ss * ca * cosd + o.cs * sa, 0.0);
-#ifdef ATL_ABLATE_NODIV  // experiment: what the division costs
-    const double kk = cosinc * sa;
-#else
     const double kk = fast_div(cosinc, sa);
-#endif
     const double direct_t = kk * direct;
     double diffuse_t;
     if constexpr (HD) {
@@ -332,11 +325,7 @@ ATL_HD __forceinline__ PvPlain pv_tail_plain(double direct, double diffuse, doub
     const double T_ = (k.c_amb * tmp + k.c_irr * G) - k.r_tmod;
     const double G_ = G * k.inv_r_irr;
     const bool pos = G_ > 0.0;
-#ifdef ATL_ABLATE_NOLOG  // experiment: what the logarithm costs
-    const double l = G_ - 1.0;
-#else
     const double l = log_core(pos ? G_ : 1.0);
-#endif
     const double l2 = l * l;
     double eff = 1.0 + k.k1 * l + k.k2 * l2 + T_ * (k.k3 + k.k4 * l + k.k5 * l2) + k.k6 * (T_ * T_);
     eff = pos ? __builtin_fmax(eff, 0.0) : 0.0;
@@ -738,11 +727,6 @@ struct PvConvT {
                 const bool dark0 = !v0 || (q.sd * c.sl0 + q.cd * c.cl0 * q.b.x) < k.sin_alt_thr - 1e-9;
                 const bool dark1 = !v1 || (q.sd * c.sl1 + q.cd * c.cl1 * q.b.y) < k.sin_alt_thr - 1e-9;
                 r.x = r.y = 0.0;
-#ifdef ATL_ABLATE_SPMATH  // experiment: the kernel's floor with every load and the reduction, no physics
-                r.x = q.dir.x + q.dif.x + q.toa.x + q.alb.x + q.tmp.x + q.a.x + q.b.x;
-                r.y = q.dir.y + q.dif.y + q.toa.y + q.alb.y + q.tmp.y + q.a.y + q.b.y;
-                if (false)
-#endif
                 if (!(dark0 && dark1 && tame)) {
                     const PvPlain p0 = pv_cell_sp_plain(q.dir.x, q.dif.x, q.toa.x, q.alb.x, q.tmp.x, q.sd, q.cd, c.sl0, c.cl0, q.a.x, q.b.x, o0, a0, k);
                     const PvPlain p1 = pv_cell_sp_plain(q.dir.y, q.dif.y, q.toa.y, q.alb.y, q.tmp.y, q.sd, q.cd, c.sl1, c.cl1, q.a.y, q.b.y, o1, a1, k);
@@ -891,16 +875,7 @@ ATL_HD double pvx_cell(double dir, double dif, double infl, double toa, double a
                            double rh, double alt, double az, double slope, double sazim, const PvConst &k,
                            const PvxOpt &o_) {
     const double nan = __builtin_nan("");
-#ifdef ATL_PVX_FIXED  // experiment: how many registers do the run-time switches cost?
-    PvxOpt o = o_;
-    o.panel = ATL_PVX_PANEL;
-    o.has_influx = ATL_PVX_INFLUX;
-    o.has_albedo = 1 - ATL_PVX_INFLUX;
-    o.irradiation = ATL_IRR_TOTAL;
-    o.clearsky = ATL_CLEARSKY_SIMPLE;
-#else
     const PvxOpt &o = o_;
-#endif
     double sa, ca;
     lean_sincos(alt, &sa, &ca);
     // ---- direct / diffuse horizontal (irradiation.py:202-208, 13-73) ------------------------
@@ -1061,11 +1036,7 @@ struct PvxConvT {
             r.osl = ld2<VEC>(cell_slope, off, c0, c1);
             r.oaz = ld2<VEC>(cell_azimuth, off, c0, c1);
         }
-#ifdef ATL_PVX_NO_SP
-        if (true) {
-#else
         if (in.d_solar_altitude) {
-#endif
             r.alt = ld2<VEC>(in.d_solar_altitude, off, c0, c1);
             r.az = ld2<VEC>(in.d_solar_azimuth, off, c0, c1);
         } else {
@@ -1086,9 +1057,6 @@ struct PvxConvT {
             az1 = q.oaz.y;
         }
         r.x = v0 ? pvx_cell<TRACK, TRIGON>(q.dir.x, q.dif.x, q.inf.x, q.toa.x, q.alb.x, q.ouf.x, q.tmp.x, q.hum.x, q.alt.x, q.az.x, sl0, az0, k, o) : 0.0;
-#if defined(ATL_PVX_SCHED_BARRIER) && defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_sched_barrier(0);  // do not interleave the two cells: halves the live temporaries
-#endif
         r.y = v1 ? pvx_cell<TRACK, TRIGON>(q.dir.y, q.dif.y, q.inf.y, q.toa.y, q.alb.y, q.ouf.y, q.tmp.y, q.hum.y, q.alt.y, q.az.y, sl1, az1, k, o) : 0.0;
         return r;
     }

@@ -100,13 +100,9 @@ struct WindConvT {
             // routine, so z0 == from gives den == 0 exactly (-> rare path -> the literal formula).
             const double *ltab = lds + tab_doubles;
             const bool zok = z >= 0x1.0p-1022 && z < __builtin_inf();
-#ifdef ATL_ABLATE_WIND_NOLOG
-            const double lz = z;
-#else
             // no substitute for a bad z: log_core_tab builds its mantissa (and with it the table index) from
             // the fraction bits alone, so any bit pattern reads inside the table; the value is discarded (rare)
             const double lz = log_core_tab(z, ltab);
-#endif
             const double den = c.lf - lz;
             // |den| < 1500 always.  Both logs carry ~1e-15 of absolute error: below 2^-20 the difference would
             // lose the 1e-10 the result must keep, so roughness within 1e-6 (relative) of the source height
@@ -175,13 +171,8 @@ struct WindConvT {
                 h0 = hub_speed_literal(v.x, z.x);
                 h1 = hub_speed_literal(v.y, z.y);
             }
-#ifdef ATL_ABLATE_WIND_NOINTERP
-            r.x = h0;
-            r.y = h1;
-#else
             r.x = interp(h0, lds);
             r.y = interp(h1, lds);
-#endif
         }
         r.x = v0 ? r.x : 0.0;
         r.y = v1 ? r.y : 0.0;

@@ -739,27 +739,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
     constexpr int kWaveLds = (ROWS + (STAGE ? kBatch : 0)) * kSegCells;
     double *wlds = lds + conv_lds_doubles + wave * kWaveLds;
     [[maybe_unused]] double *vstage = wlds + ROWS * kSegCells + 2 * lane;  // STAGE: this lane's 16 bytes of the wave's value rows
-#ifndef ATL_XCD_MAP
     // Linear order: consecutive blocks (= consecutive XCDs, block b runs on XCD b % 8) take consecutive
-    // tile groups of the same time chunk, so the chip as a whole streams contiguous memory.
+    // tile groups of the same time chunk, so the chip as a whole streams contiguous memory.  (An XCD-affine order - a group of
+    // tiles always on the same XCD, its weights in one L2 - was measured in round 2 and removed in round 6: no gain, C2 3.44 vs
+    // 3.41 ms; the weights are register-cached per chunk and < 1 % of the traffic.)
     const int64_t unit = int64_t(blockIdx.x) * kWavesPerBlock + wave;
     if (unit >= n_units) return;
     const int32_t seg = int32_t(unit % plan.n_segs);
     const int64_t chunk = unit / plan.n_segs;
-#else
-    // XCD-affine order (-DATL_XCD_MAP; measured: no gain - C2 3.44 vs 3.41 ms, C4 shard 6.12 vs
-    // 6.13 ms, runoff 0.97 vs 0.97 ms): a group of 4 tiles always lands on the same XCD for every time
-    // chunk, so its weights sit in one XCD's L2 instead of eight.  There is no reuse to win - the
-    // weights are register-cached per 64-slot chunk and make up < 1 % of the traffic.
-    const int64_t n_groups = (int64_t(plan.n_segs) + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int64_t per_xcd = (n_groups + 7) / 8;
-    const int64_t j = int64_t(blockIdx.x) >> 3;
-    const int64_t group = int64_t(blockIdx.x & 7) + 8 * (j % per_xcd);
-    const int64_t chunk = j / per_xcd;
-    const int64_t seg64 = group * kWavesPerBlock + wave;
-    if (group >= n_groups || seg64 >= plan.n_segs || chunk * chunk_slots >= n_slots) return;
-    const int32_t seg = int32_t(seg64);
-#endif
     // tile coordinates -> the lane's two adjacent cells (atl_internal.h: tile_lane_cells; unit_cells above)
     const UnitCells uc = unit_cells(plan, seg, lane, S, n_real);
     const int64_t c0 = uc.c0;
@@ -876,14 +863,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
                 for (int i = 0; i < kBatch; ++i) v[i] = *reinterpret_cast<const double2 *>(vstage + i * kSegCells);
             }
         }
-#ifdef ATL_ABLATE_NOREDUCE  // experiment: conversion only, one dummy store per batch
-        {
-            double acc = 0.0;
-            for (int i = 0; i < kBatch; ++i) acc += v[i].x + v[i].y;
-            if (acc == 1.2345e300) partials[sb] = acc;
-            continue;
-        }
-#endif
         reduce_batch<ROWS>(v, finite, plan, p0, p1, wlds, present, lane, sb, send, partials, ldp);  // (sparse tile)
     }
 }
@@ -899,9 +878,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE && min_waves<Conv>() > 2
 // LDS and a loop instead of eight unrolled slots the kernel needs < 128 VGPRs: 4 waves per SIMD, for which
 // the LDS budget (160 KiB / 16 waves) leaves kRowCacheNight = 2 weight rows per wave.  Converters opt in with
 // kNightPipe and provide key_load / key_is_zero / rest_load / compute_keyed.
-#ifndef ATL_DAYMAP_PIPE
-#define ATL_DAYMAP_PIPE 0  // measured on C2 (gpurun_out/r05_d): one register set 1.919 ms, two (next day slot's loads in flight) 1.984 ms
-#endif
 template <class Conv, bool VEC, bool DENSE, bool MAP = false>
 __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 2 : min_waves<Conv>()) void k_fused_segred_night(Conv conv, PlanDev plan, int64_t slot0,
                                                       int64_t n_slots, int64_t S, int32_t chunk_slots,
@@ -961,10 +937,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 2 : min_waves<Conv>())
             for (int i = 0; i < kBatch; ++i) *reinterpret_cast<double2 *>(vl + vrow_pair<false>(i, lane)) = double2{0.0, 0.0};
             bool finite = true;
             unsigned m = day;
-            // (ATL_DAYMAP_PIPE = 1: two register sets, the next day slot's seven streams in flight while this one is converted -
-            //  fits the 128 registers of four waves per SIMD now that the keys' 16 are gone, and is 3 % SLOWER on C2)
+            // (one register set: a day slot's loads wait for the previous conversion.  A second set - the next day slot's seven
+            //  streams in flight during the conversion - fits the 128 registers and was 3 % SLOWER on C2, 1.984 vs 1.919 ms
+            //  (round 5, gpurun_out/r05_d): the kernel is issue-bound; removed in round 6)
             typename Conv::Carry carry{};
-#if !ATL_DAYMAP_PIPE  // experiment (tools/build_variant.sh): one register set, a day slot's loads wait for the previous conversion
             while (m) {
                 const int p1s = __builtin_ctz(m);
                 m &= m - 1;
@@ -975,30 +951,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 2 : min_waves<Conv>())
                 r.y = covered ? r.y : 0.0;
                 finite = finite && (__builtin_fabs(r.x) < __builtin_inf()) && (__builtin_fabs(r.y) < __builtin_inf());
                 *reinterpret_cast<double2 *>(vl + vrow_pair<false>(p1s, lane)) = r;
-            }
-#endif
-            typename Conv::Raw A = {};
-            int p = -1;
-            if (m) {
-                p = __builtin_ctz(m);
-                m &= m - 1;
-                if (covered) A = conv.template load<VEC>(sb + p, p, s0c, s1c, cell, carry);
-            }
-            while (p >= 0) {
-                typename Conv::Raw B = {};
-                int q = -1;
-                if (m) {
-                    q = __builtin_ctz(m);
-                    m &= m - 1;
-                    if (covered) B = conv.template load<VEC>(sb + q, q, s0c, s1c, cell, carry);
-                }
-                double2 r = conv.compute(A, v0, v1, cell, lds);
-                r.x = covered ? r.x : 0.0;
-                r.y = covered ? r.y : 0.0;
-                finite = finite && (__builtin_fabs(r.x) < __builtin_inf()) && (__builtin_fabs(r.y) < __builtin_inf());
-                *reinterpret_cast<double2 *>(vl + vrow_pair<false>(p, lane)) = r;
-                A = B;
-                p = q;
             }
             double2 v[kBatch];
 #pragma unroll
@@ -1207,20 +1159,12 @@ int32_t pick_chunk_slots(const atl_ctx *ctx, int64_t n_slots, int64_t n_segs, in
     return int32_t(chunk);
 }
 
-// per-cell series of the converters marked kFlatSeries go through k_cells_series_flat ($ATLITE_HIP_SERIES_FLAT=0: the
-// slot-walking kernel, for A/B runs)
-inline bool flat_series() {
-    const char *e = getenv("ATLITE_HIP_SERIES_FLAT");
-    return !(e && e[0] == '0');
-}
-
 constexpr size_t kCellsNightLds = 4 * kBatch * kSegCells * sizeof(double);  // k_cells_night: key rows of the block's four waves
 
 // slots per block of the per-cell kernels that walk a slot range: as long as possible while the grid still fills the chip
 // (16 blocks per CU), whole batches
 inline int64_t slot_chunk_len(const atl_ctx *ctx, int64_t n_slots, unsigned gx) {
-    int64_t per_cu = 16;
-    if (const char *e = getenv("ATLITE_HIP_CELL_BLOCKS_PER_CU")) per_cu = std::max<int64_t>(1, atoll(e));  // experiments
+    const int64_t per_cu = 16;
     const int64_t n_chunks = std::max<int64_t>(1, std::min<int64_t>((n_slots + 15) / 16, (int64_t(ctx->n_cu) * per_cu + gx - 1) / gx));
     const int64_t len = std::max<int64_t>(1, (n_slots + n_chunks - 1) / n_chunks);
     return (len + kBatch - 1) / kBatch * kBatch;
@@ -1259,7 +1203,7 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
         if constexpr (conv_night_pipe<Conv>::value) {  // long slot ranges: the keys are fetched one batch ahead
             const int64_t len = slot_chunk_len(ctx, n_slots, gx_cells);
             const dim3 gridn(gx, unsigned((n_slots + len - 1) / len));
-            if (conv_flat_night<Conv>::value && vec && (int64_t(gx) + int64_t(gx_cells)) * n_slots < (int64_t(1) << 30) && flat_series()) {
+            if (conv_flat_night<Conv>::value && vec && (int64_t(gx) + int64_t(gx_cells)) * n_slots < (int64_t(1) << 30)) {
                 if constexpr (conv_flat_night<Conv>::value)
                 {
                     // slots off the line grid (a caller's contiguous cubes, S % 16 != 0): one block lives for one slot, so its
@@ -1277,10 +1221,6 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
                             gxf = unsigned((int64_t(fntx) * ((fY + 7) / 8) + 3) / 4);
                         }
                     }
-                    if (getenv("ATLITE_HIP_SERIES_FLAT_STRIPS")) {  // experiment: 128-cell strips instead of 16 x 8 tiles
-                        fX = 0;
-                        gxf = shift ? unsigned((S + 15 + 511) / 512) : gx_cells;
-                    }
                     hipLaunchKernelGGL((k_cells_series_flat_night<Conv>), dim3(unsigned(int64_t(gxf) * n_slots)), dim3(256), lds_bytes, ctx->stream, conv,
                                        S, uint32_t(gxf), d_out, fX, fY, fntx, shift);
                 }
@@ -1290,7 +1230,7 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
             else if constexpr (kScalarToo)
                 hipLaunchKernelGGL((k_cells_night<Conv, false, true>), gridn, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
                                    len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)), tX, tY, ntx, 1);
-        } else if (conv_flat_series<Conv>::value && vec && int64_t(gx_cells) * n_slots < (int64_t(1) << 30) && flat_series()) {
+        } else if (conv_flat_series<Conv>::value && vec && int64_t(gx_cells) * n_slots < (int64_t(1) << 30)) {
             if constexpr (conv_flat_series<Conv>::value) {  // flat order: see k_cells_series_flat
                 const int32_t shift = slot_stride_of(ctx, S) % 16 != 0 && !getenv("ATLITE_HIP_SERIES_NO_SHIFT");
                 const unsigned gxs = shift ? unsigned((S + 15 + 511) / 512) : gx_cells;
@@ -1445,12 +1385,7 @@ int run_fused(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
             const int32_t chunk_slots = pick_chunk_slots(ctx, wn, plan.n_segs, min_chunk);
             const int64_t n_chunks = (wn + chunk_slots - 1) / chunk_slots;
             const int64_t n_units = n_chunks * plan.n_segs;
-#ifndef ATL_XCD_MAP
             const dim3 grid(unsigned((n_units + kWavesPerBlock - 1) / kWavesPerBlock));
-#else
-            const int64_t n_groups = (int64_t(plan.n_segs) + kWavesPerBlock - 1) / kWavesPerBlock;
-            const dim3 grid(unsigned(8 * ((n_groups + 7) / 8) * n_chunks));
-#endif
             // dynamic LDS: the converter's tables, then kRowCache weight rows per wave
             const size_t conv_lds = align_up(lds_bytes, 16);
             const int32_t conv_lds_doubles = int32_t(conv_lds / sizeof(double));

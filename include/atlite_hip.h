@@ -529,10 +529,13 @@ int atl_nc_read_host(atl_nc *f, const char *name, int64_t start0, int64_t count0
  * (atlite/data.py:246-248 writes cutouts with zlib + shuffle):
  *  - on the DEVICE, one wavefront per chunk stream (k_inflate; round 5), when the rows asked for span at least
  *    $ATLITE_HIP_INFLATE_MIN_CHUNKS chunks (default 1024; $ATLITE_HIP_INFLATE=device: always): the host threads only
- *    pread the COMPRESSED bytes into page-locked staging, PCIe carries those, un-shuffle + widening + CF decoding follow
- *    on the device as before.  Every stream's Adler-32 is checked on the device; a stream the device decoder declines
- *    is decoded by the host decoders before anyone can observe the copy stream (atl_event_record(ev, 1), the slot's next
- *    use, atl_nc_close): a corrupt stream is reported THERE, with the host decoders' message;
+ *    pread the COMPRESSED bytes, batch by batch, into a page-locked ring, PCIe carries those INTO A RUNNING KERNEL (round 6:
+ *    the launch comes first, every wave waits for its stream's batch - flags in page-locked memory that the CPU sets when a
+ *    batch's DMA has completed; the call returns when the last DMA has landed), and the wave that inflated a chunk checks its
+ *    Adler-32 and un-shuffles / widens / CF-decodes it into place.  A stream the device decoder declines (or whose bytes did
+ *    not arrive within $ATLITE_HIP_INGEST_TIMEOUT_MS, default 20 s) is decoded by the host decoders before anyone can
+ *    observe the copy stream (atl_event_record(ev, 1), the slot's next use, atl_nc_close): a corrupt stream is reported
+ *    THERE, with the host decoders' message;
  *  - on host threads ($ATLITE_HIP_INFLATE=host, =zlib, or few chunks): returns after the inflate, DMA + decode enqueued.
  * n_threads <= 0: $ATLITE_HIP_IO_THREADS, else min(2 x usable CPUs (cgroup quota aware), 128). */
 int atl_nc_read_slab(atl_ctx *ctx, atl_nc *f, const char *name, int64_t start0, int64_t count0,
@@ -553,8 +556,10 @@ int atl_nc_read_slabs_ld(atl_ctx *ctx, int64_t ld_cells, atl_nc *f, int n_vars, 
 int atl_nc_read_slab_ld(atl_ctx *ctx, int64_t ld_cells, atl_nc *f, const char *name, int64_t start0, int64_t count0, double *d_out,
                         int n_threads);
 int atl_nc_ingest_stats(atl_ctx *ctx, int64_t *device_chunks, int64_t *host_chunks, int64_t *redone);
-/* device-inflate reads so far, accumulated: ms5 = {host gather of the compressed bytes (wall clock), H2D, k_inflate, k_adler,
- * k_unpack (HIP events on the slot streams; two reads overlap, so the sum can exceed the wall time)}, bytes in / out of k_inflate */
+/* device-inflate reads so far, accumulated: ms5 = {preads of the compressed bytes (wall clock), DMAs first to last, k_inflate
+ * including its waits for the DMAs and its fused Adler-32 + unpack, 0 (round 5's separate checksum pass), k_unpack of
+ * never-written chunks} - HIP events on the slot's streams; the first three overlap inside ONE fed launch (round 6), so their
+ * sum exceeds the wall time - and the bytes in / out of k_inflate */
 int atl_nc_ingest_times(atl_ctx *ctx, double *ms5, int64_t *compressed_bytes, int64_t *inflated_bytes);
 /* host array of a narrower dtype (what xarray hands over for a float32 cutout) -> fp64 on the
  * device through the same staging + decode kernel; halves the PCIe bytes of atl_upload_async */

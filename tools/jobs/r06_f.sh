@@ -31,3 +31,35 @@ for i in (1,2,3,4):
     for k, a, n in con.execute("select name, avg(duration), count(*) from kernels where name like '%k_inflate%' group by name"):
         print("pass", i, "k_inflate avg_us=%.1f n=%d" % (a / 1e3, n))
 PY
+# ---- the overlap, seen by rocprofv3: one fed read of a C2 year, kernel + memory-copy trace (no counters)
+unset ATLITE_HIP_INGEST_FED
+F=/tmp/c8760.nc
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --memory-copy-trace -d $OUT/trace -o run -- python $REPO/tools/bench_ingest.py --T 8760 --quick --no-host --keep $F > $OUT/trace.log 2>&1)
+rm -f $F
+grep "DEVICE\|stage split" $OUT/trace.log | cut -c1-300
+python - <<PY
+import sqlite3, glob
+fs = glob.glob("$OUT/trace/**/*.db", recursive=True)
+print(fs)
+if fs:
+    db = sqlite3.connect(fs[0])
+    tabs = [r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")]
+    print([t for t in tabs if 'copy' in t.lower() or 'kernel' in t.lower()][:20])
+    ks = db.execute("select name, start, end from kernels where name like '%k_inflate%' order by start").fetchall()
+    print("k_inflate launches:", len(ks))
+    if ks:
+        name, s0, e0 = ks[-1]
+        print("last k_inflate: %.1f ms" % ((e0 - s0) / 1e6))
+        try:
+            cps = db.execute("select start, end, size, name from memory_copies where start >= ? and start <= ? order by start", (s0 - 5_000_000, e0)).fetchall()
+        except Exception as ex:
+            print("memory_copies view:", ex); cps = []
+        big = [c for c in cps if c[2] and c[2] > (1 << 20)]
+        print("DMAs of > 1 MiB inside the launch: %d, first starts %.1f ms after the kernel, last ends at %.1f ms (kernel ends at %.1f)" % (
+            len(big), (big[0][0] - s0) / 1e6 if big else -1, (big[-1][1] - s0) / 1e6 if big else -1, (e0 - s0) / 1e6))
+        for c in big[:3] + big[-3:]:
+            print("   DMA %.1f .. %.1f ms, %.1f MB, %.1f GB/s  %s" % ((c[0] - s0) / 1e6, (c[1] - s0) / 1e6, c[2] / 1e6, c[2] / max(c[1] - c[0], 1), c[3]))
+        others = db.execute("select name, start, end from kernels where start >= ? and start <= ? and name not like '%k_inflate%' order by start", (s0, e0 + 10_000_000)).fetchall()
+        for n, s, e in others[:8]:
+            print("   kernel %-60s %.1f .. %.1f ms" % (n[:60], (s - s0) / 1e6, (e - s0) / 1e6))
+PY

@@ -19,8 +19,19 @@ inputs, _ = synthetic.pv_inputs(ctx, T, Y, X)
 x, y = synthetic.grid_coords(Y, X)
 dx, dy = x[1] - x[0], y[1] - y[0]
 polys = gis.random_tessellation(N, (x[0] - dx / 2, y[0] - dy / 2, x[-1] + dx / 2, y[-1] + dy / 2), seed=42)
-cut = Cutout(Dataset(dict(inputs), dict(time=synthetic.time_index(T), y=y, x=x)))
 kw = dict(panel="CSi", orientation={"slope": 30.0, "azimuth": 180.0}, shapes=polys, aggregate_time=None)
+# ---- the COLD call (what bench.py's api_e2e_ms.cold times): a fresh Cutout over device-resident data, first pv() with shapes ----
+for rep in range(2):
+    cut = Cutout(Dataset(dict(inputs), dict(time=synthetic.time_index(T), y=y, x=x), static=True))
+    pr = cProfile.Profile()
+    t0 = time.perf_counter()
+    pr.enable()
+    r = cut.pv(**kw)
+    pr.disable()
+    print("cold call %d: %.2f ms" % (rep, (time.perf_counter() - t0) * 1e3))
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(32)
+    del cut
+cut = Cutout(Dataset(dict(inputs), dict(time=synthetic.time_index(T), y=y, x=x), static=True))
 for _ in range(3):
     r = cut.pv(**kw)
 t0 = time.perf_counter()
