@@ -62,14 +62,6 @@ __global__ __launch_bounds__(256) void k_cells_series(Conv conv, int64_t n_slots
         typename Conv::Raw raw[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) raw[g] = conv.template load<VEC>(min(sg + g, s1 - 1), g, s0c, s1c, cell, carry);
-#ifdef ATL_SERIES_BATCH_STORES  // experiment: convert the whole group, then its stores back to back
-        double2 r[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) r[g] = conv.compute(raw[g], v0, v1, cell, lds);
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-            if (sg + g < s1) st2<VEC>(out, (sg + g) * S + c0, v0, v1, r[g]);
-#else
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             // lanes without a cell loaded a real cell's data (safe indices) and are masked by the store; the converter is
@@ -78,7 +70,6 @@ __global__ __launch_bounds__(256) void k_cells_series(Conv conv, int64_t n_slots
             const double2 r = conv.compute(raw[g], v0, v1, cell, lds);
             if (sg + g < s1) st2<VEC>(out, (sg + g) * S + c0, v0, v1, r);
         }
-#endif
     }
 }
 
@@ -101,6 +92,9 @@ struct conv_early_load : std::false_type {};
 template <class Conv>
 struct conv_early_load<Conv, std::void_t<decltype(Conv::kEarlyLoad)>> : std::integral_constant<bool, Conv::kEarlyLoad> {};
 
+// (Round 6 tried blocks of 2 / 4 / 8 x 512 cells - all loads of a block issued before its LDS tables are built, the tables paid for
+//  once per 2-8 x 12 KiB of traffic: C3 wind series 5.58 ms with 512 cells per block, 5.66 / 5.91 / 5.70 ms with 1024 / 2048 / 4096
+//  on one box (gpurun_out/r06_m).  The order in which the chip sweeps the cubes matters more than the table build; removed.)
 template <class Conv>
 __global__ __launch_bounds__(256) void k_cells_series_flat(Conv conv, int64_t S, uint32_t n_chunks, double *__restrict__ out, int32_t shift) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -117,8 +111,14 @@ __global__ __launch_bounds__(256) void k_cells_series_flat(Conv conv, int64_t S,
     typename Conv::Raw raw;
     typename Conv::Cell cell;
     if constexpr (conv_early_load<Conv>::value) {
+#ifdef ATL_FLAT_SETPRIO  // experiment: the waves that still have to issue their loads win arbitration over those building tables
+        __builtin_amdgcn_s_setprio(3);
+#endif
         cell = conv.cell_early(c0, v0, v1);
         raw = conv.template load<true>(slot, 0, s0c, s1c, cell, carry);
+#ifdef ATL_FLAT_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         conv.block_init(lds);
         __syncthreads();
         conv.cell_finish(cell, lds);
@@ -924,15 +924,27 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 2 : min_waves<Conv>())
     partials -= slot0;
     if constexpr (MAP) {
         // The day bits of this tile were computed once for the (plan, altitude cube, cut-off) - k_day_map, the same vote - :
-        // a batch reads one byte through the scalar cache instead of eight altitude pairs per lane; a dark slot reads
+        // a batch reads eight bytes through the scalar cache instead of eight altitude pairs per lane; a dark slot reads
         // NOTHING, a day slot issues all of its streams at once (no key-then-rest dependency).
+        // LINE-granular since round 6: a slot's byte has one bit per 128-byte line of the tile (lanes 8 j .. 8 j + 7 = the 16
+        // consecutive cells of one line of every cube, whatever the tile's shape) - the lanes of a line without a cell above the
+        // cut-off do not load: in the slots in which the terminator crosses a tile only its lit lines are fetched (round 5
+        // fetched the whole tile: 1.09 x the day cells' bytes).  A dark lane's cells convert to +0.0 (irradiation.py:251-252),
+        // which is what it contributes without having loaded anything: the same bits.
         static_assert(!DENSE, "day map: sparse tiles");
         const uint8_t *mrow = conv.in.d_day_map + int64_t(seg) * conv.in.day_map_ld;
+        const unsigned my_line = unsigned(lane) >> 3;
         for (int64_t sb = sbeg; sb < send; sb += kBatch) {
-            const int64_t rel = sb - slot0;  // the map is indexed by the call's own slots
-            unsigned day = ((unsigned(mrow[rel >> 3]) | (unsigned(mrow[(rel >> 3) + 1]) << 8)) >> (rel & 7)) & 0xFFu;
-            day = __builtin_amdgcn_readfirstlane(day);
-            if (send - sb < kBatch) day &= (1u << int(send - sb)) - 1u;
+            const int64_t rel = sb - slot0;  // the map is indexed by the call's own slots (a multiple of kBatch: run_fused)
+            const uint2 w2 = *reinterpret_cast<const uint2 *>(mrow + rel);
+            uint64_t lines = uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(w2.x)))) |
+                             (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(w2.y)))) << 32);
+            if (send - sb < kBatch) lines &= (uint64_t(1) << (8 * int(send - sb))) - 1u;
+            // slot i is a day slot iff its byte is not zero: fold every byte onto its lowest bit, gather the eight bits
+            uint64_t f = lines | (lines >> 4);
+            f |= f >> 2;
+            f |= f >> 1;
+            const unsigned day = unsigned(((f & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
 #pragma unroll
             for (int i = 0; i < kBatch; ++i) *reinterpret_cast<double2 *>(vl + vrow_pair<false>(i, lane)) = double2{0.0, 0.0};
             bool finite = true;
@@ -944,11 +956,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 2 : min_waves<Conv>())
             while (m) {
                 const int p1s = __builtin_ctz(m);
                 m &= m - 1;
+                const bool lit = covered && ((unsigned(lines >> (8 * p1s)) >> my_line) & 1u);
                 typename Conv::Raw A1 = {};
-                if (covered) A1 = conv.template load<VEC>(sb + p1s, p1s, s0c, s1c, cell, carry);
+                if (lit) A1 = conv.template load<VEC>(sb + p1s, p1s, s0c, s1c, cell, carry);
                 double2 r = conv.compute(A1, v0, v1, cell, lds);
-                r.x = covered ? r.x : 0.0;
-                r.y = covered ? r.y : 0.0;
+                r.x = lit ? r.x : 0.0;
+                r.y = lit ? r.y : 0.0;
                 finite = finite && (__builtin_fabs(r.x) < __builtin_inf()) && (__builtin_fabs(r.y) < __builtin_inf());
                 *reinterpret_cast<double2 *>(vl + vrow_pair<false>(p1s, lane)) = r;
             }
@@ -1010,9 +1023,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 2 : min_waves<Conv>())
     }
 }
 
-// The early-out's votes, once: bit (t & 7) of map[tile * ld + (t >> 3)] = in slot t some covered cell of the tile has a key
-// that does not convert to +0.0 - literally the test k_fused_segred_night makes on the keys it loads (same converter
-// functions, same lanes, same coverage mask).  One wave per (tile, run of 64 slots); bytes past the last slot's are 0.
+// The early-out's votes, once: map[tile * ld + t] = one bit per 128-byte line of the tile (bit j: lanes 8 j .. 8 j + 7), set iff in
+// slot t some covered cell of that line has a key that does not convert to +0.0 - literally the test k_fused_segred_night
+// makes on the keys it loads (same converter functions, same lanes, same coverage mask); the slot is a day slot of the tile
+// iff the byte is not zero.  One wave per (tile, run of 64 slots); bytes past the last slot's are 0.
 template <class Conv, bool VEC>
 __global__ __launch_bounds__(256) void k_day_map(Conv conv, PlanDev plan, int64_t n_slots, int64_t S, int64_t n_units,
                                                  uint8_t *__restrict__ map, int64_t ld) {
@@ -1034,13 +1048,17 @@ __global__ __launch_bounds__(256) void k_day_map(Conv conv, PlanDev plan, int64_
 #pragma unroll
         for (int i = 0; i < kBatch; ++i)
             key[i] = covered ? conv.template key_load<VEC>(min(sb + i, send - 1), uc.ld0, uc.ld1, cell) : double2{0.0, 0.0};
-        unsigned day = 0;
+        uint64_t lines = 0;
 #pragma unroll
         for (int i = 0; i < kBatch; ++i) {
-            const bool d = (sb + i < send) && !__all(conv.key_is_zero(key[i], min(sb + i, send - 1), cell) || !covered);
-            day |= d ? 1u << i : 0u;
+            const bool up = (sb + i < send) && covered && !conv.key_is_zero(key[i], min(sb + i, send - 1), cell);
+            uint64_t f = __ballot(up);  // lane bits -> one bit per group of eight lanes
+            f |= f >> 4;
+            f |= f >> 2;
+            f |= f >> 1;
+            lines |= (((f & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56) << (8 * i);
         }
-        if (lane == 0) map[int64_t(seg) * ld + (sb >> 3)] = uint8_t(day);
+        if (lane == 0) *reinterpret_cast<uint64_t *>(map + int64_t(seg) * ld + sb) = lines;  // (ld and sb are multiples of 8)
     }
 }
 

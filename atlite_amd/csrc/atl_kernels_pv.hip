@@ -127,7 +127,9 @@ int atl_pv_day_map(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p
     ATL_REQUIRE(agg->dev.shift_classes == 0, "atl_pv_day_map: not for line-aligned plans");
     ATL_REQUIRE(agg->dev.n_cells == S, "atl_pv_day_map: matrix has %lld columns but the cutout has %lld cells",
                 (long long)agg->dev.n_cells, (long long)S);
-    ATL_REQUIRE(T >= 0 && ld >= T / 8 + 2, "atl_pv_day_map: ld %lld is too small for %lld time steps", (long long)ld, (long long)T);
+    ATL_REQUIRE(T >= 0 && ld >= (T + 7) / 8 * 8 && ld % 8 == 0 && (reinterpret_cast<uintptr_t>(d_map) & 7u) == 0,
+                "atl_pv_day_map: ld %lld must be a multiple of 8 of at least %lld time steps rounded up to 8, the map 8-byte aligned",
+                (long long)ld, (long long)T);
     ATL_HIP_TRY(hipSetDevice(ctx->device));
     const PlanDev &plan = agg->dev;
     if (plan.n_segs == 0) return ATL_OK;

@@ -748,7 +748,7 @@ class Context:
         hit = maps.get(key)
         if hit is not None and hit[0] is plan:
             return hit[1], hit[2]
-        ld = (T // 8 + 2 + 3) // 4 * 4
+        ld = (T + 7) // 8 * 8  # one byte per (tile, time step): a bit per 128-byte line of the tile (round 6)
         n_tiles = plan.info()["n_segments"]
         dmap = self.empty((max(n_tiles, 1) * ld,), np.uint8)
         check(self.lib.atl_pv_day_map_ld(self.handle, ldc, C.byref(pin), C.byref(pp), T, S, plan.handle, dmap.ptr, ld))

@@ -108,7 +108,7 @@ def parse():
     ap.add_argument("--workload-steps", type=int, default=5)
     ap.add_argument("--legs", default="all",
                     help="comma-separated subset of the N = 1 legs: headline,night_skip,star_polygons,api,separate_cubes,"
-                         "from_file,cpu,c3_series,c3_cf_map,c3_aggregated,c5_heat,c5_runoff,odd_caller,c4_full_sp (default: all)")
+                         "from_file,cpu,c3_series,c3_cf_map,c3_aggregated,c5_heat,c5_runoff,odd_caller,c2_sp,c4_full_sp (default: all)")
     ap.add_argument("--debug-rccl-self", action="store_true",
                     help="testing only (one GPU, one process): open a 1-rank RCCL process group and route the step "
                          "through the collective branch (async all-gather on the group's stream, placement copy)")
@@ -175,6 +175,7 @@ KERNELS = {
     "c5_runoff": "k_fused_segred<RunoffConv, true, false>",
     "odd_caller": "k_fused_segred<PvConvT<false, false, false, 0, 0, 0>, true, false>",
     "c4_full_sp": "k_fused_segred<PvConvT<true, false, false, 0, 0, 0>, true, false>",
+    "c2_sp": "k_fused_segred<PvConvT<true, false, false, 0, 0, 0>, true, false>",
     "c4_headline": "k_fused_segred<PvConvT<true, false, false, 0, 0, 0>, true, false>",
 }
 
@@ -508,6 +509,30 @@ def config_legs(ctx, legs, reps, check=True):
         gc.collect()
 
     # ---- configs[3] on one GPU: the whole 8760 x 800 x 800 cutout, in-kernel solar position ------------------------------
+    # (c2_sp: the same kernel on the C2 grid - 8760 x 200 x 200, 100 shapes - where it is bound by the vector ALU, not by HBM)
+    for leg_sp, (T, Y, X, N) in (("c2_sp", (8760, 200, 200, 100)),):
+        if leg_sp not in legs:
+            continue
+        S = Y * X
+        big, x, y, tables = generate_pv(ctx, synthetic, solar, _lib, T, Y, X, 0, False, interleaved=True)
+        ld = next(iter(big.values())).ld
+        M = matrix_of(Y, X, N)
+        plan = ctx.plan(M, row_len=X, ld=ld)
+        info = plan.info()
+        tabs = dict(tables)
+        params = dict(CSI, **ORI)
+        ms, res = run(lambda: ctx.pv(big, params, T, S, plan=plan, solar_tables=tabs, options=dict(night_skip=False)))
+        par = None
+        if check:
+            sel = np.unique(np.clip(np.concatenate([np.arange(0, 48), np.arange(4000, 4048), [T - 1]]), 0, T - 1))
+            host = {k: rows(v, sel) for k, v in big.items()}
+            al, az = orc.solar_position(synthetic.time_index(T)[sel], x, y, "-30min")
+            host["solar_altitude"], host["solar_azimuth"] = al.reshape(len(sel), S), az.reshape(len(sel), S)
+            par = close(res.numpy()[:, sel], orc.aggregate_matrix(orc.convert_pv(host, CSI, ORI), M))
+        record(leg_sp, f"pv CSi, {T}x{Y}x{X}, {N} tessellation shapes ({info['tile_w']}x{info['tile_h']} tiles, {info['n_partial_rows']} partial rows), "
+                       f"IN-KERNEL solar position, 5 cubes slot-interleaved = 40 B per cell-step", 40 * T * S, T * S, ms, par)
+        del big, res, plan, tabs, tables
+        gc.collect()
     if "c4_full_sp" in legs:
         T, Y, X, N = 8760, 800, 800, 500
         S = Y * X
@@ -1420,7 +1445,7 @@ def main():
             dts_v, kk_v = timed(pv_params(True), ks, kw_)  # the tile's altitudes loaded and voted on (first call; a caller's own cubes)
             same_v = bool(torch.equal(step(pv_params(True)), ref_out))
             # ... and with the day map of (plan, altitude cube, cut-off), built once and kept with the cube: the API's steady state
-            ld_m = (T_loc // 8 + 2 + 3) // 4 * 4
+            ld_m = (T_loc + 7) // 8 * 8  # one byte per (tile, time step)
             dmap = ctx.empty((max(plan_info["n_segments"], 1) * ld_m,), np.uint8)
             ctx.sync()
             ctx.timer_start()
@@ -1593,7 +1618,7 @@ def main():
                 result["cpu_baseline"]["dask_array"] = {"skipped": repr(e)[:200]}
 
     # ---- the other BASELINE.json configurations at N = 1, at their own sizes (after the C2 legs: their cubes go first) ----
-    cfg_legs = [l for l in ("c3_series", "c3_cf_map", "c3_aggregated", "c5_heat", "c5_runoff", "odd_caller", "c4_full_sp") if want(l)]
+    cfg_legs = [l for l in ("c3_series", "c3_cf_map", "c3_aggregated", "c5_heat", "c5_runoff", "odd_caller", "c2_sp", "c4_full_sp") if want(l)]
     if extras and cfg_legs:
         del inputs, plan, full, full3, piece, pin, pins
         import gc

@@ -240,11 +240,14 @@ typedef struct {
     /* (Zero-initialise the struct - memset or = {0} - before filling it in: fields are added at its END from one ATL_VERSION to
      *  the next and 0 / NULL always means "not used", so a caller built against an older header keeps working only if the
      *  bytes it does not know about are zero.  d_day_map / day_map_ld came with ATL_VERSION 101.)
-     * night early-out with a DAY MAP (atl_pv_day_map; round 5): bit (t & 7) of d_day_map[tile * day_map_ld + (t >> 3)] =
-     * in time step t some cell of the plan's tile that carries a weight is above the altitude cut-off - what the early-out
-     * kernel otherwise finds out by loading the tile's altitudes and voting.  Belongs to ONE (aggregation plan,
-     * d_solar_altitude contents, altitude_threshold, T, slot stride); NULL = vote.  Read by atl_pv_convert_aggregate with
-     * night_skip = 1 and stored angles; ignored everywhere else. */
+     * night early-out with a DAY MAP (atl_pv_day_map; round 5, line-granular since round 6): d_day_map[tile * day_map_ld + t]
+     * holds one bit per 128-byte line of the plan's tile (bit j = lanes 8 j .. 8 j + 7 of the tile's wave = 16 consecutive cells),
+     * set iff in time step t some cell of that line that carries a weight is above the altitude cut-off - what the early-out
+     * kernel otherwise finds out by loading the tile's altitudes and voting; a zero byte = the whole tile is dark, nothing of
+     * that (tile, step) is read, and in a step in which the terminator crosses the tile only its lit lines are.  Belongs to
+     * ONE (aggregation plan, d_solar_altitude contents, altitude_threshold, T, slot stride); NULL = vote.  day_map_ld: a
+     * multiple of 8, >= T rounded up to 8; the map 8-byte aligned.  Read by atl_pv_convert_aggregate with night_skip = 1 and
+     * stored angles; ignored everywhere else. */
     const uint8_t *d_day_map;
     int64_t day_map_ld;
 } atl_pv_inputs;

@@ -49,8 +49,9 @@ def test_day_map_gives_the_voting_kernels_bits(ctx, T, Y, X):
 
 
 def test_day_map_bits_are_the_votes(ctx):
-    """The map itself, against NumPy: bit t of tile s = some covered cell of the tile has an altitude that is not below the
-    cut-off (NaN counts as day), for a cut-off other than the default as well."""
+    """The map itself, against NumPy: byte t of tile s is non-zero iff some covered cell of the tile has an altitude that is not
+    below the cut-off (NaN counts as day), for a cut-off other than the default as well.  (Its bits are the tile's 128-byte
+    lines: test_line_bits_follow_the_terminator.)"""
     T, Y, X = 77, 24, 40
     S = Y * X
     ds = H.pv_dataset(T, Y, X, seed=3)
@@ -68,7 +69,7 @@ def test_day_map_bits_are_the_votes(ctx):
         day_any = np.zeros(T, bool)
         for s in range(bits.shape[0]):
             for t in range(T):
-                if bits[s, t >> 3] >> (t & 7) & 1:
+                if bits[s, t]:
                     day_any[t] = True
         alt = ds["solar_altitude"]
         # over ALL tiles: no day of a covered cell is missed; a step in which every cell of the grid is dark has no bit (the vote
@@ -76,7 +77,37 @@ def test_day_map_bits_are_the_votes(ctx):
         covered_day = (~(alt < thr) & covered[None, :]).any(axis=1)
         any_day = (~(alt < thr)).any(axis=1)
         assert (day_any | ~covered_day).all() and (~day_any | any_day).all() and day_any.any() and not day_any.all()
-        assert not bits[:, (T + 7) // 8:].any()  # nothing behind the last time step
+        assert not bits[:, T:].any()  # nothing behind the last time step
+
+
+def test_line_bits_follow_the_terminator(ctx):
+    """Line granularity (round 6): a grid of ONE 16 x 8 tile row band whose altitude is a step function of x - west half up, east
+    half down - must light exactly the lines (16 consecutive cells) that hold a cell of the west half, in every covered tile;
+    the result stays bit-identical to the kernel without the early-out while the dark lines hold NaN / inf in every other cube
+    (they are not read: were they, NaN would reach the shapes' sums through 0 * NaN)."""
+    T, Y, X = 24, 8, 64
+    S = Y * X
+    ds = H.pv_dataset(T, Y, X, seed=5)
+    alt = np.full((T, Y, X), -0.5)
+    alt[:, :, :24] = 0.6  # the first line and a half of every row is up
+    ds["solar_altitude"] = alt.reshape(T, S)
+    M = H.blob_matrix(3, Y, X, seed=1, overlap=True)
+    import scipy.sparse as sp
+
+    M = sp.csr_matrix(np.ones((1, S)))  # every cell covered: the coverage mask plays no part here
+    plan = ctx.plan(M, row_len=X)
+    dev = up(ctx, ds)
+    full = ctx.pv(dev, PV_PARAMS, T, S, plan=plan, options=dict(night_skip=False)).numpy()
+    mapped = ctx.pv(dev, PV_PARAMS, T, S, plan=plan, options=dict(night_skip=True, day_map=True)).numpy()
+    np.testing.assert_array_equal(mapped, full)
+    _, dmap, ld = next(iter(root_block(dev["solar_altitude"])._day_maps.values()))
+    bits = dmap.numpy().reshape(-1, ld)[:, :T]
+    assert (bits == bits[:, :1]).all()  # the same every step
+    # every 128-byte line (16 consecutive cells; X is a multiple of 16) belongs to exactly one tile: the lit lines over all tiles
+    # are the two westernmost lines of each of the Y rows, and no tile is lit as a whole
+    lit = sum(bin(int(b)).count("1") for b in bits[:, 0])
+    assert lit == 2 * Y, (lit, [bin(int(b)) for b in bits[:, 0]])
+    assert all(int(b) != 0xFF for b in bits[:, 0])
 
 
 def test_day_map_follows_the_dataset(ctx):

@@ -34,6 +34,7 @@ GROUPS = {
     "configs": (["--legs", "c3_series,c3_cf_map,c3_aggregated,c5_heat,c5_runoff"],
                 ["c3_series", "c3_cf_map", "c3_aggregated", "c5_heat", "c5_runoff"]),
     "c4": (["--legs", "c4_full_sp"], ["c4_full_sp"]),
+    "c2sp": (["--legs", "c2_sp"], ["c2_sp"]),
     # the same kernel NAME as the headline: this leg's launches are told apart by their place in the pass (SLICES)
     "odd": (["--legs", "odd_caller"], ["odd_caller"]),
 }
@@ -73,7 +74,7 @@ def main():
     env = dict(os.environ, TMPDIR="/tmp")
     latest_f = out / "bench_profile_latest.json"
     latest = json.loads(latest_f.read_text()) if latest_f.exists() else {"note": __doc__.strip().split("\n\n")[0], "legs": {}}
-    tag = os.environ.get("ATL_PROFILE_TAG", "r05")
+    tag = os.environ.get("ATL_PROFILE_TAG", "r06")
     import socket
 
     box = socket.gethostname()  # which box the record was measured on: bench.py quotes it beside a line from another one
