@@ -13,7 +13,7 @@
 #include "atl_internal.h"
 #include "atl_math.h"
 
-// tuning knobs of the fused kernel (A/B-tested with tools/build_variant.sh + tools/ab_bench.sh)
+// tuning knobs of the fused kernel (A/B-tested with variants built by tools/build_variant.sh, loaded through $ATLITE_HIP_LIB)
 #ifndef ATL_FUSED_WAVES
 #define ATL_FUSED_WAVES 3  // waves per SIMD the register allocation must allow (<= 168 VGPRs)
 #endif

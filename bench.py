@@ -161,7 +161,7 @@ def cpu_baseline(inputs_host, M, n_threads):
 
 PEAK_GBPS = 8000.0  # HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 
-# the dominant kernel of every leg, as rocprofv3 names it (tools/rocpd_summary.py strips the anonymous namespace): a
+# the dominant kernel of every leg, as rocprofv3 names it (tools/profile_bench.py strips the anonymous namespace): a
 # profile entry is only quoted for a leg when it was measured on THIS kernel
 KERNELS = {
     "headline": "k_fused_segred<PvConvT<false, false, false, 0, 0, 0>, true, false>",
