@@ -96,10 +96,11 @@ struct conv_early_load<Conv, std::void_t<decltype(Conv::kEarlyLoad)>> : std::int
 //  once per 2-8 x 12 KiB of traffic: C3 wind series 5.58 ms with 512 cells per block, 5.66 / 5.91 / 5.70 ms with 1024 / 2048 / 4096
 //  on one box (gpurun_out/r06_m).  The order in which the chip sweeps the cubes matters more than the table build; removed.)
 template <class Conv>
-__global__ __launch_bounds__(256) void k_cells_series_flat(Conv conv, int64_t S, uint32_t n_chunks, double *__restrict__ out, int32_t shift) {
+__global__ __launch_bounds__(256) void k_cells_series_flat(Conv conv, int64_t S, uint32_t n_chunks, double *__restrict__ out, int32_t shift,
+                                                           int64_t slot0) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const uint32_t slot_u = blockIdx.x / n_chunks;  // blocks in (slot, chunk) order: every stream advances front to back
-    const int64_t slot = slot_u;
+    const int64_t slot = slot0 + slot_u;            // (slot0: the first slot of this launch's range)
     // slots that do not start on a 128-byte line (the converter's slot stride conv.S is not a multiple of 16 cells: a
     // caller's contiguous cubes on an odd grid): the chunks of THIS slot start o cells early, on its line grid - every
     // lane's 16 bytes aligned, every wave's KiB eight whole lines (slot 0 has o = 0: nothing is read before the cube)
@@ -401,14 +402,14 @@ struct conv_flat_night<Conv, std::void_t<decltype(Conv::kFlatNightSeries)>> : st
 
 template <class Conv>
 __global__ __launch_bounds__(256) void k_cells_series_flat_night(Conv conv, int64_t S, uint32_t n_chunks, double *__restrict__ out, int64_t X,
-                                                                 int64_t Y, int32_t ntx, int32_t shift) {
+                                                                 int64_t Y, int32_t ntx, int32_t shift, int64_t slot0) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     conv.block_init(lds);
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
     const uint32_t slot_u = blockIdx.x / n_chunks;
-    const int64_t slot = slot_u;
+    const int64_t slot = slot0 + slot_u;
     const int64_t chunk = blockIdx.x - slot_u * n_chunks;
     const int64_t o = shift ? (slot * conv.S) & 15 : 0;  // this slot's offset inside its 128-byte line (see k_cells_series_flat)
     int64_t c0 = (chunk * 256 + threadIdx.x) * 2 - o;
@@ -1218,12 +1219,18 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
     if (time_agg == ATL_TIME_NONE) {
         const dim3 grid(gx, unsigned((n_slots + kSeriesSlots - 1) / kSeriesSlots));
         KernelBracket kb(ctx);
+        // the flat kernels' grids are (chunks of a slot) x (slots) blocks in ONE dimension: a launch carries at most 2^30 blocks,
+        // longer series go in consecutive slot ranges (slot0) - the converters they serve have no slot-walking vectorised
+        // instantiation since round 6 (47 kernels less)
+        const auto flat_ranges = [&](unsigned gxf, auto &&launch) {
+            const int64_t per = std::max<int64_t>(1, ((int64_t(1) << 30) - 1) / std::max(1u, gxf));
+            for (int64_t a0 = 0; a0 < n_slots; a0 += per) launch(a0, std::min(per, n_slots - a0));
+        };
         if constexpr (conv_night_pipe<Conv>::value) {  // long slot ranges: the keys are fetched one batch ahead
             const int64_t len = slot_chunk_len(ctx, n_slots, gx_cells);
             const dim3 gridn(gx, unsigned((n_slots + len - 1) / len));
-            if (conv_flat_night<Conv>::value && vec && (int64_t(gx) + int64_t(gx_cells)) * n_slots < (int64_t(1) << 30)) {
-                if constexpr (conv_flat_night<Conv>::value)
-                {
+            if constexpr (conv_flat_night<Conv>::value) {
+                if (vec) {
                     // slots off the line grid (a caller's contiguous cubes, S % 16 != 0): one block lives for one slot, so its
                     // tiles / strips can sit on THAT slot's line grid (o = (slot * stride) % 16 cells; ATLITE_HIP_SERIES_NO_SHIFT: as before)
                     const int32_t shift = slot_stride_of(ctx, S) % 16 != 0 && !getenv("ATLITE_HIP_SERIES_NO_SHIFT");
@@ -1239,23 +1246,33 @@ int run_cells(atl_ctx *ctx, const Conv &conv, bool vec, size_t lds_bytes, int64_
                             gxf = unsigned((int64_t(fntx) * ((fY + 7) / 8) + 3) / 4);
                         }
                     }
-                    hipLaunchKernelGGL((k_cells_series_flat_night<Conv>), dim3(unsigned(int64_t(gxf) * n_slots)), dim3(256), lds_bytes, ctx->stream, conv,
-                                       S, uint32_t(gxf), d_out, fX, fY, fntx, shift);
+                    flat_ranges(gxf, [&](int64_t a0, int64_t nb) {
+                        hipLaunchKernelGGL((k_cells_series_flat_night<Conv>), dim3(unsigned(int64_t(gxf) * nb)), dim3(256), lds_bytes, ctx->stream, conv,
+                                           S, uint32_t(gxf), d_out, fX, fY, fntx, shift, a0);
+                    });
+                } else if constexpr (kScalarToo) {
+                    hipLaunchKernelGGL((k_cells_night<Conv, false, true>), gridn, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
+                                       len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)), tX, tY, ntx, 1);
                 }
-            } else if (vec)
+            } else if (vec) {
                 hipLaunchKernelGGL((k_cells_night<Conv, true, true>), gridn, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
                                    len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)), tX, tY, ntx, 1);
-            else if constexpr (kScalarToo)
+            } else if constexpr (kScalarToo) {
                 hipLaunchKernelGGL((k_cells_night<Conv, false, true>), gridn, dim3(256), lds_bytes + kCellsNightLds, ctx->stream, conv, n_slots, S,
                                    len, d_out, static_cast<double *>(nullptr), int32_t(lds_bytes / sizeof(double)), tX, tY, ntx, 1);
-        } else if (conv_flat_series<Conv>::value && vec && int64_t(gx_cells) * n_slots < (int64_t(1) << 30)) {
-            if constexpr (conv_flat_series<Conv>::value) {  // flat order: see k_cells_series_flat
+            }
+        } else if constexpr (conv_flat_series<Conv>::value) {  // flat order: see k_cells_series_flat
+            if (vec) {
                 const int32_t shift = slot_stride_of(ctx, S) % 16 != 0 && !getenv("ATLITE_HIP_SERIES_NO_SHIFT");
                 const unsigned gxs = shift ? unsigned((S + 15 + 511) / 512) : gx_cells;
-                hipLaunchKernelGGL((k_cells_series_flat<Conv>), dim3(unsigned(int64_t(gxs) * n_slots)), dim3(256), lds_bytes, ctx->stream, conv, S,
-                                       uint32_t(gxs), d_out, shift);
+                flat_ranges(gxs, [&](int64_t a0, int64_t nb) {
+                    hipLaunchKernelGGL((k_cells_series_flat<Conv>), dim3(unsigned(int64_t(gxs) * nb)), dim3(256), lds_bytes, ctx->stream, conv, S,
+                                       uint32_t(gxs), d_out, shift, a0);
+                });
+            } else if constexpr (kScalarToo) {
+                hipLaunchKernelGGL((k_cells_series<Conv, false>), grid, dim3(256), lds_bytes, ctx->stream, conv, n_slots, S, d_out);
             }
-        } else if (vec) {  // (else: the early-out converters do not instantiate the plain series kernel)
+        } else if (vec) {  // (the early-out converters do not instantiate the plain series kernel)
             hipLaunchKernelGGL((k_cells_series<Conv, true>), grid, dim3(256), lds_bytes, ctx->stream, conv,
                                n_slots, S, d_out);
         } else if constexpr (kScalarToo) {

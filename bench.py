@@ -180,6 +180,18 @@ KERNELS = {
 }
 
 
+def box_id():
+    """Which machine this is: the host name alone is the same on every box of the pool (a container's), so the kernel's boot id
+    goes with it - two runs share it exactly when they ran on the same boot of the same box."""
+    import socket
+
+    try:
+        boot = open("/proc/sys/kernel/random/boot_id").read().strip()[:8]
+    except OSError:
+        boot = "?"
+    return f"{socket.gethostname()}-{boot}"
+
+
 def profile_entry(leg):
     """The committed rocprofv3 record of a leg (profiles/bench_profile_latest.json, written by tools/profile_bench.sh
     from --kernel-trace --stats and separate --pmc FETCH_SIZE / WRITE_SIZE passes over THIS file's ``--legs <leg>``
@@ -229,8 +241,8 @@ def roofline_of(leg, algo_bytes, k_ms, extra=None):
             import socket
 
             # the same build runs +-4 % from box to box: say whether the record and this line come from the same one
-            r["profile_box"], r["this_box"] = ent.get("box"), socket.gethostname()
-            r["profile_is_this_box"] = ent.get("box") == socket.gethostname()
+            r["profile_box"], r["this_box"] = ent.get("box"), box_id()
+            r["profile_is_this_box"] = ent.get("box") == box_id()
             r["frac_vs_profile"] = r["frac"] / r["frac_from_profile"]
             r["profile_source"] = (f"{src} (rocprofv3 --kernel-trace --stats, avg of the {ent.get('timed_launches', ent.get('calls'))} "
                                    f"launches of this leg after its warm-up, not this run; all {ent.get('calls')} launches: {ent['avg_us'] * 1e-3:.3f} ms)")
@@ -401,7 +413,11 @@ def config_legs(ctx, legs, reps, check=True):
         args = (wnd, z0, V, POW / P, hub, 100.0, "logarithmic", T, S)
         lay = "the two cubes slot-interleaved in one allocation" if inter else "one allocation per cube"
         if "c3_series" in c3:
-            ms, ser = run(lambda: ctx.wind(*args))
+            # the 11 GB result is allocated ONCE and written by every launch (as the headline's result is): a fresh allocation per
+            # call made this leg bimodal from process to process - 5.3 / 5.6 / 6.0-6.2 ms with one library on one box, by where the
+            # driver happened to place the new block (tools/probes/series_placement.py: 5.25-5.30 ms on a buffer that stays)
+            ser = ctx.empty((T, S))
+            ms, _none = run(lambda: ctx.wind(*args, out=(ser.ptr, S)))
             par = None
             if check:
                 sel = np.unique(np.concatenate([np.arange(0, 6), [T // 2, T - 1]]))

@@ -77,7 +77,9 @@ def main():
     tag = os.environ.get("ATL_PROFILE_TAG", "r06")
     import socket
 
-    box = socket.gethostname()  # which box the record was measured on: bench.py quotes it beside a line from another one
+    from bench import box_id
+
+    box = box_id()  # which box (host name + boot id) the record was measured on: bench.py quotes it beside a line from another one
     for g in groups:
         args, legs = GROUPS[g]
         lines, per_pass = [], {}
