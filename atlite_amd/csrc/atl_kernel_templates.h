@@ -112,14 +112,10 @@ __global__ __launch_bounds__(256) void k_cells_series_flat(Conv conv, int64_t S,
     typename Conv::Raw raw;
     typename Conv::Cell cell;
     if constexpr (conv_early_load<Conv>::value) {
-#ifdef ATL_FLAT_SETPRIO  // experiment: the waves that still have to issue their loads win arbitration over those building tables
-        __builtin_amdgcn_s_setprio(3);
-#endif
+        // (s_setprio 3 around these two lines - the waves that still have to issue their loads win arbitration over those building
+        //  tables - changed nothing measurable: round 6, gpurun_out/r06_final1)
         cell = conv.cell_early(c0, v0, v1);
         raw = conv.template load<true>(slot, 0, s0c, s1c, cell, carry);
-#ifdef ATL_FLAT_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         conv.block_init(lds);
         __syncthreads();
         conv.cell_finish(cell, lds);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6, one box for everything DESIGN.md tabulates: the GPU suite, rocprofv3 over every bench leg (stats + FETCH_SIZE + WRITE_SIZE + SQ
-# passes, tools/profile_bench.py), the pv variants, the plain bench line, the per-cell series with s_setprio (variants/lib_prio.so)
+# passes, tools/profile_bench.py), the pv variants, the plain bench line
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/${1:-r06_final}
 mkdir -p $OUT
@@ -23,17 +23,4 @@ date +%T
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 800 $OUT/bench.json; echo
 date +%T
-V=$REPO/atlite_amd/lib/variants
-for i in 1 2; do
-  for L in prio base; do
-    if [ $L = prio ]; then export ATLITE_HIP_LIB=$V/lib_prio.so; else unset ATLITE_HIP_LIB; fi
-    timeout 300 python bench.py --legs c3_series --no-cpu-baseline --steps 6 > $OUT/c3_$L$i.json 2> $OUT/c3_$L$i.err
-    python - <<PY
-import json
-j = json.loads(open("$OUT/c3_$L$i.json").read().strip().splitlines()[-1]); c = j["configs"]["c3_series"]
-print("$L$i c3_series %.4f ms median %.4f frac %.3f" % (c["ms"], c["ms_median"], c["frac"]))
-PY
-  done
-done
-unset ATLITE_HIP_LIB
 date +%T
