@@ -1395,7 +1395,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     ATL_HIP_TRY(hipStreamWaitEvent(sl->st_c, sl->ev_meta, 0));  // (a flag must not land before the flags are cleared)
     auto launch = [&]() -> int {
         unsigned long long ticks = 2000000000ull;  // 20 s of the 100 MHz clock
-        if (const char *e = getenv("ATLITE_HIP_INGEST_TIMEOUT_MS")) ticks = (unsigned long long)(std::max(1, atoi(e))) * 100000ull;
+        if (const char *e = getenv("ATLITE_HIP_INGEST_TIMEOUT_MS")) ticks = (unsigned long long)(std::max(1e-5, atof(e)) * 100000.0);  // (fractions allowed: tests)
         // ($ATLITE_HIP_INGEST_LDS_PAD: bytes of dynamic LDS the launch asks for and never touches - an experiment knob that caps
         //  the streams per CU below the 32 the kernel's own 5 kB allow)
         unsigned pad = 0u;

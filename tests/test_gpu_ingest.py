@@ -304,6 +304,67 @@ def test_device_inflate_many_chunks(ctx, tmp_path, monkeypatch):
     assert d2 - d1 == 240 and h2 - h1 == 16
 
 
+def test_fed_launch_knobs_and_fallbacks_give_the_same_bytes(ctx, tmp_path, monkeypatch, inflate_mode):
+    """The fed k_inflate launch (round 6: the kernel starts before its data, DMA batches and CPU-set arrival flags feed it) under
+    every way it can be made to run: small DMA batches (many flags), several jobs per read, the unfed order, and a time-out so
+    short that waves give up before their batch lands - those streams come back as "not run" and the host decoders take them
+    (ingest_stats counts them) - always the bytes h5py wrote."""
+    import subprocess
+
+    if inflate_mode != "device":
+        pytest.skip("device path only")
+    conda = "/opt/conda/bin/python3.9"
+    make = os.path.join(os.path.dirname(__file__), "golden", "make_nc_fixtures.py")
+    try:
+        ok = subprocess.run([conda, "-c", "import h5py"], capture_output=True, timeout=120).returncode == 0
+    except Exception:
+        ok = False
+    if not ok:
+        pytest.skip("needs the conda interpreter with h5py")
+    path = tmp_path / "fed.nc"
+    T, Y, X = 96, 96, 80
+    r = subprocess.run([conda, make, "--cutout", str(path), str(T), str(Y), str(X), "8", "24", "20", "f4", "9", "4", "pv"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    f = io.NcFile(path)
+    names = [n for n, v in f.variables.items() if v.ndim == 3]
+    assert len(names) == 7
+    monkeypatch.setenv("ATLITE_HIP_INFLATE", "host")
+    want = {n: slab(ctx, f, n, 0, T) for n in names}
+    monkeypatch.setenv("ATLITE_HIP_INFLATE", "device")
+
+    def all_at_once(t0=3, n=90):
+        outs = [ctx.zeros((T, Y, X)) for _ in names]
+        ctx.copy_after_compute()
+        f.read_slabs(ctx, names, t0, n, [o.ptr for o in outs])
+        ctx.copy_barrier()
+        ctx.sync()
+        for nm, o in zip(names, outs):
+            assert np.array_equal(o.numpy()[:n], want[nm][t0:t0 + n], equal_nan=True), nm
+
+    for env in ({"ATLITE_HIP_INGEST_BATCH": "1"},                                   # 1 MiB batches: a dozen flags per read
+                {"ATLITE_HIP_INGEST_JOB_GB": "0.004"},                              # ~4 MB of inflated chunks per job: several jobs
+                {"ATLITE_HIP_INGEST_FED": "0"},                                     # every byte first, then the launch
+                {"ATLITE_HIP_INGEST_BATCH": "1", "ATLITE_HIP_INGEST_JOB_GB": "0.004"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        d0, _, r0 = ingest_stats(ctx)
+        all_at_once()
+        d1, _, r1 = ingest_stats(ctx)
+        assert d1 > d0 and r1 == r0, env
+        for k in env:
+            monkeypatch.delenv(k)
+    # waves that give up: a time-out of one microsecond - a wave that finds its batch's flag unset leaves at once
+    monkeypatch.setenv("ATLITE_HIP_INGEST_TIMEOUT_MS", "0.001")
+    monkeypatch.setenv("ATLITE_HIP_INGEST_BATCH", "1")
+    d0, _, r0 = ingest_stats(ctx)
+    for _ in range(3):
+        all_at_once()
+    d1, _, r1 = ingest_stats(ctx)
+    assert (d1 - d0) + (r1 - r0) >= 3 * 7 * 12 * 16  # every stream was settled one way or the other ...
+    assert r1 > r0                                    # ... and some by the host decoders: the fallback ran
+
+
 def test_corrupt_streams_get_the_host_decoders_verdict(ctx, tmp_path, monkeypatch):
     """Bytes of a cutout file overwritten at random: whatever the host path says about a variable - an error, or data -
     the device path says as well (streams the device decoder declines are decoded again by the host decoders before the
