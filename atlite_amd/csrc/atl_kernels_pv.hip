@@ -22,6 +22,10 @@ int pvt_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, i
                 double *d_out);
 int pvt_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S,
                           const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out);
+// atl_kernels_pvkt.hip
+bool pvkt_takes(const atl_pv_inputs *in, const atl_pv_params *p);
+int pvkt_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S,
+                           const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out);
 // atl_kernels_pvk.hip
 int pvk_convert(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S, int time_agg,
                 double *d_out);
@@ -155,6 +159,7 @@ int atl_pv_day_map(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p
 int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T,
                              int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out) {
     ATL_REQUIRE(ctx && in && p, "atl_pv_convert_aggregate: ctx/inputs/params is NULL");
+    if (pvkt_takes(in, p)) return pvkt_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);
     if (pv_needs_general(in, p)) return pvx_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);
     if (pv_influx_fast(in, p)) return pvi_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);
     if (pv_other_tail(in, p)) return pvt_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);

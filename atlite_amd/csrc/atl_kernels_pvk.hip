@@ -1,5 +1,5 @@
 // The fast pv kernel family behind a tracker: pv(tracking="horizontal" | "tilted_horizontal" | "vertical" | "dual") with
-// the Huld panel, the simple trigon model (Hay-Davies behind a tracker: the general kernel), one orientation for the grid
+// the Huld panel, the simple trigon model (Hay-Davies, irradiation() and the bofinger panel behind a tracker: atl_kernels_pvkt.hip), one orientation for the grid
 // or one per cell, stored solar angles, with and without the night early-out.  Vectorised launches only: odd cell counts / row lengths and unaligned cubes take the
 // general kernel (atl_kernels_pvx.hip), whose tracker is a run-time switch.  Same PvConvT
 // template as atl_kernels_pv.hip; a translation unit of its own so that the kernel files compile in parallel.

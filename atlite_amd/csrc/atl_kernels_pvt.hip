@@ -1,7 +1,7 @@
 // The fast pv kernel family's tails other than the Huld panel: the bofinger panel (pv(panel="KANENA")), the solar
 // thermal collector (solar_thermal()) and the plain tilted irradiation (irradiation()), each after the simple or the
 // Hay-Davies ("other") trigon model, fixed panel, stored solar angles, with and without the night early-out.  (Behind a
-// tracker these panels take the general kernel: rarely combined, and 96 kernels for it.)  Vectorised launches only:
+// tracker: the fused kernels of atl_kernels_pvkt.hip for the common combinations, else the general kernel.)  Vectorised launches only:
 // odd cell counts / row lengths and unaligned cubes take the general kernel too (atl_kernels_pvx.hip).  Same PvConvT
 // template as atl_kernels_pv.hip; a translation unit of its own so that the kernel files compile in parallel.
 // Reference arithmetic: atlite/convert.py:550-574, 748-767; atlite/pv/irradiation.py:76-145, 214-255;

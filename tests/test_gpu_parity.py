@@ -361,7 +361,11 @@ def test_pv_night_skip_per_cell_kernels_on_grid_tiles(ctx, Y, X):
     dict(panel_model="none", trigon_model="other", irradiation="diffuse"),
     dict(panel_model="solar_thermal", c0=0.8, c1=3.0, t_store_K=353.15),
     dict(panel_model="solar_thermal", c0=0.8, c1=3.0, t_store_K=353.15, trigon_model="other"),
-    dict(panel="KANENA"), dict(panel="KANENA", trigon_model="other")])
+    dict(panel="KANENA"), dict(panel="KANENA", trigon_model="other"),
+    # trackers x tails that are fused fast-family kernels since round 6 (atl_kernels_pvkt.hip; the general kernel before)
+    dict(tracking="horizontal", trigon_model="other"), dict(tracking="vertical", trigon_model="other"),
+    dict(panel="KANENA", tracking="horizontal"), dict(panel="KANENA", tracking="dual"),
+    dict(panel_model="none", tracking="tilted_horizontal"), dict(panel_model="none", tracking="vertical")])
 def test_pv_night_skip_other_tails_and_trackers(ctx, opts):
     """The night early-out for the family's other members - trackers with the Huld panel, and the bofinger /
     solar thermal / irradiation tails after either trigon model with a fixed panel: the same bits as without it (fused,
@@ -398,6 +402,13 @@ def test_pv_night_skip_other_tails_and_trackers(ctx, opts):
     got = ctx.pv(dev, scal, T, Y * X, options=dict(opts, night_skip=True)).numpy()
     ref = np.asarray(ref).reshape(T, -1)
     np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-12 * np.nanmax(np.abs(ref[np.isfinite(ref)])), equal_nan=True)
+    # ... and the FUSED kernels (convert + aggregate: for trackers x tails another instantiation than the per-cell one) against
+    # the oracle's aggregate of the same cube
+    with np.errstate(invalid="ignore"):
+        refa = orc.aggregate_matrix(ref, M)
+    for ns in (False, True):
+        agg = ctx.pv(dev, scal, T, Y * X, plan=plan, options=dict(opts, night_skip=ns)).numpy()
+        np.testing.assert_allclose(agg, refa, rtol=1e-10, atol=1e-12 * np.nanmax(np.abs(refa[np.isfinite(refa)])), equal_nan=True)
 
 
 def test_pv_influx_outflux_dataset_fast_family(ctx):

@@ -76,15 +76,15 @@ for name, nbytes, fn in (
     ("solar_thermal() - fast family, collector tail", 56,
      lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="solar_thermal", c0=0.8, c1=3.0, t_store_K=353.15))),
     ("pv(trigon_model='other') - fast family, Hay-Davies tail", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(trigon_model="other"))),
-    ("tracking='horizontal' + Hay-Davies - general kernel since round 3 (fast family in r02)", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="horizontal", trigon_model="other"))),
+    ("tracking='horizontal' + Hay-Davies - fast family again since round 6 (general kernel in r03-r05: 4.87 ms)", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="horizontal", trigon_model="other"))),
     ("tracking='tilted_horizontal', per-cell orientation - fast family (r02)", 56, lambda: ctx.pv(inputs, percell, T, S, plan=plan, options=dict(tracking="tilted_horizontal"))),
     ("pv(panel='KANENA') bofinger - fast family (r02)", 56, lambda: ctx.pv(inputs, kanena, T, S, plan=plan, options=dict(night_skip=False))),
     ("bofinger + Hay-Davies - fast family (r02; was the general kernel)", 56, lambda: ctx.pv(inputs, kanena, T, S, plan=plan, options=dict(trigon_model="other"))),
     ("irradiation(trigon_model='other') - fast family (r02) (48 B/cell: temperature is not read)", 48, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none", trigon_model="other"))),
     ("solar_thermal(trigon_model='other') - fast family (r02)", 56,
      lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="solar_thermal", c0=0.8, c1=3.0, t_store_K=353.15, trigon_model="other"))),
-    ("bofinger + tracking='horizontal' - general kernel since round 3 (fast family in r02)", 56, lambda: ctx.pv(inputs, kanena, T, S, plan=plan, options=dict(tracking="horizontal"))),
-    ("irradiation(tracking='dual') - general kernel since round 3 (fast family in r02)", 48, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none", tracking="dual"))),
+    ("bofinger + tracking='horizontal' - fast family again since round 6 (general kernel in r03-r05: 5.45 ms)", 56, lambda: ctx.pv(inputs, kanena, T, S, plan=plan, options=dict(tracking="horizontal"))),
+    ("irradiation(tracking='dual') - fast family again since round 6 (general kernel in r03-r05: 3.62 ms)", 48, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none", tracking="dual"))),
     ("bofinger + tracking='tilted_horizontal' + Hay-Davies, per-cell orientation - general kernel since round 3", 56,
      lambda: ctx.pv(inputs, dict(kanena, slope=percell["slope"], azimuth=percell["azimuth"]), T, S, plan=plan, options=dict(tracking="tilted_horizontal", trigon_model="other"))),
     ("pv(tracking='horizontal') + night early-out (r02)", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="horizontal", night_skip=True))),
