@@ -1353,6 +1353,7 @@ def main():
         comm_info = {"ranks_seen": [comm.info()["n_ranks"]], "device_of_rank": [comm.info()["device"]]}
 
     # the reassembled result holds every rank's block in place
+    multi_parity = None
     if world > 1 and not collective_failed:
         res = step(pp_main)
         fence()
@@ -1364,6 +1365,24 @@ def main():
         lst = [torch.zeros_like(chk) for _ in range(world)]
         dist.all_gather(lst, chk)
         assert all(torch.equal(v, chk) for v in lst), "ranks disagree on the gathered result"
+        if not a.no_parity:
+            # ... and an ORACLE sample of every rank's own shard (round 6: until then the multi-rank path checked placement and
+            # agreement only): two dozen steps around the shard's first morning and its middle
+            from oracle import atlite_oracle as orc
+
+            sel = np.unique(np.clip(np.concatenate([np.arange(0, 12), np.arange(T_loc // 2, T_loc // 2 + 12)]), 0, T_loc - 1))
+            host = {k: np.stack([v.slab(int(t), int(t) + 1).numpy()[0] for t in sel]) for k, v in inputs.items()}
+            if tables is not None:
+                al, az = orc.solar_position(synthetic.time_index(T_loc, "2013-01-01", off)[sel], x, y, "-30min")
+                host["solar_altitude"], host["solar_azimuth"] = al.reshape(len(sel), S), az.reshape(len(sel), S)
+            ref = orc.aggregate_matrix(orc.convert_pv(host, CSI, ORI), M)
+            got = own.cpu().numpy()[:, sel]
+            scale = np.abs(ref).max()
+            err = float((np.abs(got - ref) / np.maximum(np.abs(ref), 1e-12 * scale)).max())
+            okf = torch.tensor([1 if err <= 1e-10 else 0], dtype=torch.int32)
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            multi_parity = {"checked_steps_per_rank": int(len(sel)), "max_rel_err_rank0": err, "rtol": 1e-10,
+                            "ok_on_every_rank": bool(int(okf.item()) == 1)}
 
     shapes_word = ("a 100-cell Voronoi TESSELLATION (every cell covered: all 56 B/cell-step are read; BASELINE's overlapping "
                    "star polygons: star_polygons below)") if a.shape_kind == "tessellation" else "overlapping star-convex polygons"
@@ -1417,6 +1436,8 @@ def main():
         }
         if comm_info:
             result["multi_gpu"].update(comm_info)
+        if multi_parity is not None:
+            result["multi_gpu"]["parity"] = multi_parity
     if a.emulate_shard:
         # what one rank of an N-way strong-scaling run spends per step besides the collective
         result["emulated_shard"] = {

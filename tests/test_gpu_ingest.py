@@ -365,6 +365,59 @@ def test_fed_launch_knobs_and_fallbacks_give_the_same_bytes(ctx, tmp_path, monke
     assert r1 > r0                                    # ... and some by the host decoders: the fallback ran
 
 
+def test_a_failed_read_keeps_its_verdict_until_somebody_listens(ctx, tmp_path, monkeypatch, inflate_mode):
+    """A device-inflate read of a corrupt chunk whose verdict nobody collects at first - the file is closed (which settles the
+    read and must not swallow the failure), blocks are allocated and recycled (their fences do not consume it either) - reports
+    the host decoders' error to the next caller that observes the copy stream, once; the context works on afterwards."""
+    if inflate_mode != "device":
+        pytest.skip("device path only")
+    src = f"{NC}/cutout_nc4.nc"
+    exp = np.load(f"{NC}/cutout_nc4.npz")
+    good = io.NcFile(src)
+    var = good.variables["temperature"]
+    if var.deflate is None:
+        pytest.skip("fixture variable is not deflated")
+    # the last bytes of the file belong to some chunk's zlib stream only by luck; find one of 'temperature' by trial: flip bytes
+    # until the HOST path fails on this variable (the host decoders' verdict is what must come back)
+    raw = bytearray(open(src, "rb").read())
+    rng = np.random.default_rng(3)
+    path = None
+    for attempt in range(200):
+        b = bytearray(raw)
+        for pos in rng.integers(len(b) // 3, len(b), size=3):
+            b[int(pos)] ^= 0xFF
+        cand = tmp_path / f"bad{attempt}.nc"
+        open(cand, "wb").write(bytes(b))
+        monkeypatch.setenv("ATLITE_HIP_INFLATE", "host")
+        try:
+            f = io.NcFile(cand)
+            slab(ctx, f, "temperature", 0, exp["temperature"].shape[0])
+            f.close()
+        except ValueError:
+            path = cand
+            break
+        except Exception:
+            continue
+    assert path is not None, "no corruption of the fixture made the host path fail"
+    monkeypatch.setenv("ATLITE_HIP_INFLATE", "device")
+    f = io.NcFile(path)
+    T = exp["temperature"].shape[0]
+    out = ctx.zeros((T,) + var.shape[1:])
+    ctx.copy_after_compute()
+    f.read_slab(ctx, "temperature", 0, T, out.ptr)  # enqueued; nobody has looked at the copy stream yet
+    f.close()                                       # settles the read: the failure must survive this
+    junk = [ctx.empty((1000,)) for _ in range(4)]    # pooled blocks: allocated, released, recycled behind fence events
+    del junk
+    again = ctx.empty((1000,))
+    with pytest.raises(ValueError):
+        ctx.copy_barrier()                          # the first observer gets the host decoders' error ...
+    ctx.copy_barrier()                              # ... once
+    ctx.sync()
+    g = io.NcFile(src)
+    assert np.array_equal(slab(ctx, g, "temperature", 0, T), exp["temperature"], equal_nan=True)
+    del again
+
+
 def test_corrupt_streams_get_the_host_decoders_verdict(ctx, tmp_path, monkeypatch):
     """Bytes of a cutout file overwritten at random: whatever the host path says about a variable - an error, or data -
     the device path says as well (streams the device decoder declines are decoded again by the host decoders before the

@@ -235,6 +235,7 @@ def test_bench_multi_gpu_line_carries_the_three_workloads():
     j = _bench_line(["--gpus", "2", "--debug-gloo-one-gpu", "--steps", "2", "--warmup", "1", "--T", "960", "--no-cpu-baseline",
                      "--no-extras", "--workload-steps", "2"])
     assert j["n_gpus"] == 2 and j["value"] > 0
+    assert j["multi_gpu"]["parity"]["ok_on_every_rank"] and j["multi_gpu"]["parity"]["max_rel_err_rank0"] < 1e-10  # C2 itself
     w = j["workloads"]
     assert set(w) == {"c4", "c5"}, w
     for name in ("c4", "c5"):

@@ -24,3 +24,4 @@ for k in ("night_skip", "star_polygons", "api_e2e_ms", "from_file", "from_file_l
 for k, v in (j.get("configs") or {}).items():
     if isinstance(v, dict): print(k, v.get("ms"), v.get("frac"), (v.get("parity") or {}).get("ok"))
 PY
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
