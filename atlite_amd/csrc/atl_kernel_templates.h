@@ -538,14 +538,10 @@ __device__ __forceinline__ void reduce_batch(const double2 (&v)[kBatch], bool fi
         // (an all-finite batch needs no guards here either: a zero weight times a finite value is a zero - the same
         // shortcut the cached rows take; 16 selects less per row and batch, which the early-out kernels with their two
         // cached rows feel)
-#ifdef ATL_GUARD_UNCACHED_ROWS  // experiment: round 3's behaviour
-        reduce_row<true>(v, wz, a0, a1, lane, sb, send, partials + int64_t(p) * ldp);
-#else
         if (all_finite)
             reduce_row<false>(v, wz, true, true, lane, sb, send, partials + int64_t(p) * ldp);
         else
             reduce_row<true>(v, wz, a0, a1, lane, sb, send, partials + int64_t(p) * ldp);
-#endif
     }
 }
 
@@ -942,6 +938,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, DENSE ? 2 : min_waves<Conv>())
             f |= f >> 2;
             f |= f >> 1;
             const unsigned day = unsigned(((f & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
+            // (round 6 tried writing the zeros of a batch that is dark for the whole tile - a third of the batches - straight to the
+            //  partial rows, without value rows or a reduction: no gain, 1.919 vs 1.920 ms on one box, gpurun_out/r06_r; removed)
 #pragma unroll
             for (int i = 0; i < kBatch; ++i) *reinterpret_cast<double2 *>(vl + vrow_pair<false>(i, lane)) = double2{0.0, 0.0};
             bool finite = true;
