@@ -535,6 +535,9 @@ struct WaveSink {
         DevWave::sync();
         ATL_PROF(const unsigned long long c1 = __builtin_readcyclecounter(); t_p1 += c1 - c0; n_coop += unsigned(__popcll(todo));
                  n_lit += unsigned(__popcll(__ballot(active && lit))); n_short += unsigned(__popcll(__ballot(active && !lit && !coop)));)
+        // (tried, round 6: short in-batch matches copied by their own lanes, all whose source bytes are written at once - a bitmap of
+        //  owed bytes in LDS, 2.9 rounds per batch instead of 9.8 ordered copies; a round's five dependent LDS trips cost what
+        //  it saved: profiles/r06_ingest.txt)
         while (todo) {  // in symbol order; every source byte of a match precedes the match
             const int i = __ffsll((long long)todo) - 1;
             todo &= todo - 1;

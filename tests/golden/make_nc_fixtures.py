@@ -221,6 +221,57 @@ def write_cutout(path, T=48, Y=9, X=12, chunks=(20, 5, 7), dtype="f4", seed=7, g
         h.dims[1].attach_scale(x)
 
 
+def write_payloads(path, seed=0, T=64, Y=128, X=128, ct=8):
+    """uint8 variables whose chunk streams exercise a DEFLATE decoder beyond weather fields: no matches at all, short close
+    matches, runs (matches that overlap themselves), long periods (maximum-length matches), sparse bytes in zeros, far
+    matches of a dictionary, byte planes of smooth integers; zlib levels 1 / 6 / 9.  Expected values beside it (.npz)."""
+    rng = np.random.default_rng(seed)
+    n = T * Y * X
+
+    def runs():
+        ln = rng.geometric(1.0 / rng.choice([3, 20, 400]), size=n // 2 + 1)
+        return np.repeat(rng.integers(0, 256, ln.size, dtype=np.uint8), ln)[:n]
+
+    def periodic():
+        out = np.empty(n, np.uint8)
+        i = 0
+        while i < n:
+            period = int(rng.choice([1, 2, 3, 5, 17, 100, 257, 300, 4000]))
+            m = min(int(rng.integers(period, 40 * period + 600)), n - i)
+            out[i:i + m] = np.resize(rng.integers(0, 256, period, dtype=np.uint8), m)
+            i += m
+        return out
+
+    def sparse():
+        out = np.zeros(n, np.uint8)
+        idx = rng.integers(0, n, n // 700)
+        out[idx] = rng.integers(1, 256, idx.size, dtype=np.uint8)
+        return out
+
+    def words():
+        vocab = [rng.integers(97, 123, int(k), dtype=np.uint8) for k in rng.integers(2, 14, 900)]
+        pick = rng.zipf(1.3, size=n // 4) % len(vocab)
+        return np.concatenate([vocab[i] for i in pick])[:n] if n else np.zeros(0, np.uint8)
+
+    def planes():
+        v = (np.cumsum(rng.standard_normal(n // 4 + 1)) * 50).astype("<i4")
+        return np.ascontiguousarray(v.view(np.uint8).reshape(-1, 4).T).reshape(-1)[:n]
+
+    kinds = {"noise": lambda: rng.integers(0, 256, n, dtype=np.uint8), "few": lambda: rng.integers(0, 4, n, dtype=np.uint8),
+             "runs": runs, "periodic": periodic, "sparse": sparse, "words": words, "planes": planes}
+    exp = {}
+    with h5py.File(path, "w", libver=("earliest", "v108")) as f:
+        t, y, x = _scales(f, T, Y, X, True)
+        for k, (name, make) in enumerate(kinds.items()):
+            a = make()
+            a = np.resize(a, n).reshape(T, Y, X)
+            for level in ((1, 6, 9) if name in ("runs", "periodic", "words") else ((1, 6, 9)[k % 3],)):
+                v = f.create_dataset(f"{name}_{level}", data=a, chunks=(ct, Y, X), compression="gzip", compression_opts=level)
+                _attach(v, (t, y, x))
+                exp[f"{name}_{level}"] = a
+    np.savez_compressed(os.path.splitext(path)[0] + ".npz", **exp)
+
+
 def main(out):
     os.makedirs(out, exist_ok=True)
     # 1. what netCDF-C produces: v108 (1.8) bounds, creation order tracked
@@ -261,5 +312,8 @@ if __name__ == "__main__":
         lv = a[7] if a[7] in ("earliest", "latest") else ("earliest", "v108")
         unl = tuple(int(c) for c in a[10]) if len(a) > 10 else ()
         write_case(a[0], int(a[1]), int(a[2]), int(a[3]), (int(a[4]), int(a[5]), int(a[6])), lv, a[8] == "1", int(a[9]), unlimited=unl)
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[1] == "--payloads":  # --payloads path seed
+        write_payloads(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 0)
         sys.exit(0)
     main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "nc"))

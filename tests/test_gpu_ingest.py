@@ -234,6 +234,40 @@ def test_read_slab_random_files(ctx, tmp_path, seed):
             assert np.array_equal(got, exp[v][t0:t0 + n], equal_nan=True), (v, t0, n, T, Y, X, ct, cy, cx, libver)
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_inflate_payload_statistics(ctx, tmp_path, seed, inflate_mode):
+    """Chunk streams that are NOT weather fields (tests/golden/make_nc_fixtures.py --payloads: noise, four-letter bytes,
+    runs - matches that overlap themselves -, long periods - maximum-length matches -, sparse bytes in zeros, a Zipf
+    dictionary - far matches -, byte planes; zlib 1 / 6 / 9): what was written comes back, and in device mode every
+    stream was inflated by k_inflate, none redone on the host."""
+    import subprocess
+
+    conda = "/opt/conda/bin/python3.9"
+    make = os.path.join(os.path.dirname(__file__), "golden", "make_nc_fixtures.py")
+    try:
+        ok = subprocess.run([conda, "-c", "import h5py"], capture_output=True, timeout=120).returncode == 0
+    except Exception:
+        ok = False
+    if not ok:
+        pytest.skip("needs the conda interpreter with h5py")
+    path = tmp_path / "payloads.nc"
+    r = subprocess.run([conda, make, "--payloads", str(path), str(40 + seed)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    f = io.NcFile(path)
+    exp = np.load(tmp_path / "payloads.npz")
+    d0, h0, r0 = ingest_stats(ctx)
+    n_streams = 0
+    for v in exp.files:
+        assert np.array_equal(slab(ctx, f, v, 0, exp[v].shape[0]), exp[v]), v
+        assert np.array_equal(slab(ctx, f, v, 5, 30), exp[v][5:35]), v
+        n_streams += f.variables[v].n_chunks + 5
+    d1, h1, r1 = ingest_stats(ctx)
+    if inflate_mode == "device":
+        assert (d1 - d0, h1 - h0, r1 - r0) == (n_streams, 0, 0)
+    else:
+        assert (d1 - d0, h1 - h0) == (0, n_streams)
+
+
 def test_device_inflate_is_the_path_that_ran(ctx, inflate_mode):
     """The counters of atl_nc_ingest_stats: in device mode the deflated chunks of a read are inflated by k_inflate (and none
     had to be decoded again on the host), in host mode none is."""
