@@ -14,6 +14,7 @@ struct PvConst {
     // inverter efficiency / capacity
     double bA, bB, bC, bD, bfrac, bDf_ta, bTstd, bthr, bscale;
     int tracking;  // ATL_TRACK_*: read by the instantiations whose tracker is a run-time switch (kTrackAny)
+    int alb_cube;  // influx head: the dataset has an albedo variable (irradiation.py:129-130) - it rides where the outflux would
 };
 // TRACK template value of the converters that choose their tracker at run time (a wave-uniform switch over
 // panel_geom's closed forms): the rarely used tracker x panel / trigon / orientation combinations share ONE
@@ -254,7 +255,7 @@ ATL_HD __forceinline__ double pv_cell_influx(double infl, double outf, double to
     reindl_split<ENH>(infl, toa, sa, tmp, rh, &direct, &diffuse);
     const double influx = direct + diffuse;
     if ((alt < k.alt_thr) || (influx <= 0.01)) return 0.0;
-    const double alb = albedo_from_outflux(outf, influx);
+    const double alb = k.alb_cube ? outf : albedo_from_outflux(outf, influx);
     return pv_tail<TAIL>(direct, diffuse, influx, toa, alb, tmp, sa, ca, lean_cos(o.saz - az), o, k);
 }
 
@@ -416,7 +417,10 @@ ATL_HD __forceinline__ PvPlain pv_cell_influx_plain(double infl, double outf, do
     const double direct = influx_c - diffuse;
     const double influx = direct + diffuse;
     const bool capped = (alt < k.alt_thr) || (influx <= 0.01);
-    const double alb = __builtin_fmin(fast_div(outf, capped ? 1.0 : influx), 1.0);
+    // an albedo variable is used as it is; else outflux / influx, at most 1 (a select, not a branch: the pair's two
+    // evaluations stay one block of straight-line code)
+    const double alb_derived = __builtin_fmin(fast_div(outf, capped ? 1.0 : influx), 1.0);
+    const double alb = k.alb_cube ? outf : alb_derived;
     const double cosd = cos_core(o.saz - az);
     return pv_tail_plain<HD>(direct, diffuse, influx, alb, tmp, sa, ca, cosd, plain, capped, o, k, toa);
 }
@@ -480,7 +484,8 @@ ATL_HD __forceinline__ double pv_cell_sp(double dir, double dif, double toa, dou
 // TRACK: a tracker (pv(tracking=...)) with the Huld panel, either trigon model, scalar or per-cell orientation
 // and stored solar angles - the ways trackers are used with pv(); other mixes stay general.
 // HEAD: 1 / 2 = influx / outflux dataset (Reindl split with the "simple" / the "enhanced" clearsky model + albedo from
-// outflux; stored angles, Huld panel after either trigon model, fixed panel): influx rides in Raw::dir, outflux in Raw::alb,
+// outflux - or the dataset's albedo variable, a run-time switch: PvConst::alb_cube; stored angles, Huld panel after
+// either trigon model, fixed panel): influx rides in Raw::dir, outflux (albedo) in Raw::alb,
 // the diffuse slot carries the relative humidity of the enhanced model or is not loaded (48 / 56 B/cell).
 template <bool SP, bool PC = false, bool SKIP = false, int TAIL = kTailHuld, int TRACK = ATL_TRACK_NONE, int HEAD = 0>
 struct PvConvT {
@@ -829,7 +834,7 @@ inline PvConst pv_const_of(const atl_pv_params *p) {
               p->k_3,        p->k_4,          p->k_5,    p->k_6,                 p->inverter_efficiency,
               p->altitude_threshold, sin(p->altitude_threshold),
               p->st_c0, p->st_c1, p->st_t_store_K, p->irradiation,
-              0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0};
+              0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0};
     if (p->panel_model == ATL_PANEL_BOFINGER) {  // the uniform sub-expressions of pvx_cell's bofinger branch, same order
         const double fraction = (p->bof_NOCT - p->bof_Tamb) / p->bof_Intc;
         const double capacity = (p->bof_A + p->bof_B * 1000.0 + p->bof_C * log(1000.0)) * 1e3;

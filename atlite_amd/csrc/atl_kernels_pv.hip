@@ -24,6 +24,13 @@ int pvt_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_pa
                           const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out);
 // atl_kernels_pvkt.hip
 bool pvkt_takes(const atl_pv_inputs *in, const atl_pv_params *p);
+// atl_kernels_pvka.hip, atl_kernels_pvkc.hip
+bool pvka_takes(const atl_pv_inputs *in, const atl_pv_params *p);
+int pvka_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S,
+                           const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out);
+bool pvkc_takes(const atl_pv_inputs *in, const atl_pv_params *p);
+int pvkc_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S,
+                           const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out);
 int pvkt_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p, int64_t T, int64_t S,
                            const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out);
 // atl_kernels_pvk.hip
@@ -38,10 +45,10 @@ namespace {
 #include "atl_conv_pv.h"
 #include "atl_pv_make.h"
 
-// influx / outflux datasets the fast family takes (atl_kernels_pvi.hip): total influx + outflux, either clearsky model,
-// stored solar angles, the Huld panel on a fixed mount after either trigon model
+// influx datasets the fast family takes (atl_kernels_pvi.hip): total influx + outflux or an albedo variable, either
+// clearsky model, stored solar angles, the Huld panel on a fixed mount after either trigon model
 bool pv_influx_fast(const atl_pv_inputs *in, const atl_pv_params *p) {
-    return in->d_influx && in->d_outflux && !in->d_albedo && !in->d_influx_direct && !in->d_influx_diffuse &&
+    return in->d_influx && (in->d_outflux || in->d_albedo) && !in->d_influx_direct && !in->d_influx_diffuse &&
            in->d_solar_altitude && in->d_solar_azimuth && in->d_temperature &&
            (p->clearsky_model == ATL_CLEARSKY_SIMPLE || (p->clearsky_model == ATL_CLEARSKY_ENHANCED && in->d_humidity)) &&
            p->panel_model == ATL_PANEL_HULD && p->tracking == ATL_TRACK_NONE &&
@@ -160,6 +167,8 @@ int atl_pv_convert_aggregate(atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv
                              int64_t S, const atl_agg *agg, int time_agg, double *d_out, int64_t ld_out) {
     ATL_REQUIRE(ctx && in && p, "atl_pv_convert_aggregate: ctx/inputs/params is NULL");
     if (pvkt_takes(in, p)) return pvkt_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);
+    if (pvka_takes(in, p)) return pvka_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);
+    if (pvkc_takes(in, p)) return pvkc_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);
     if (pv_needs_general(in, p)) return pvx_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);
     if (pv_influx_fast(in, p)) return pvi_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);
     if (pv_other_tail(in, p)) return pvt_convert_aggregate(ctx, in, p, T, S, agg, time_agg, d_out, ld_out);

@@ -2,8 +2,8 @@
 // (Huld panel after Hay-Davies), irradiation(tracking=...) (the plain tilted irradiation, simple trigon model) and
 // pv(panel="KANENA", tracking=...) (bofinger panel, simple trigon model) - FUSED (convert + aggregate) kernels only, one
 // orientation for the grid, stored solar angles, with and without the night early-out: 24 kernels.  Until round 6 these
-// combinations ran in the general kernel (atl_kernels_pvx.hip) at 0.40-0.58 of the HBM peak; per-cell results, per-cell
-// orientations, the remaining tail x trigon combinations and launches that cannot be vectorised still do.
+// combinations ran in the general kernel (atl_kernels_pvx.hip) at 0.40-0.58 of the HBM peak; per-cell results and launches
+// that cannot be vectorised still do (per-cell orientations: atl_kernels_pvkc.hip; Hay-Davies before the other tails: atl_kernels_pvka.hip).
 // Reference arithmetic: atlite/pv/orientation.py:104-196 (closed forms: panel_geom in atl_conv_pv.h),
 // atlite/pv/irradiation.py:76-145, 214-255; atlite/pv/solar_panel_model.py:22-74; atlite/convert.py:748-767.
 #include "atl_kernel_templates.h"
@@ -53,7 +53,8 @@ bool pvkt_takes(const atl_pv_inputs *in, const atl_pv_params *p) {
         !in->d_solar_altitude || !in->d_solar_azimuth || p->d_cell_slope || p->orientation_per_time)
         return false;
     if (p->panel_model == ATL_PANEL_HULD) return p->trigon_model == ATL_TRIGON_OTHER && p->irradiation == ATL_IRR_TOTAL;
-    if (p->panel_model == ATL_PANEL_NONE) return p->trigon_model == ATL_TRIGON_SIMPLE && p->irradiation == ATL_IRR_TOTAL;
+    if (p->panel_model == ATL_PANEL_NONE)  // (which component the tail returns is a run-time switch: PvConst::irr)
+        return p->trigon_model == ATL_TRIGON_SIMPLE && p->irradiation >= ATL_IRR_TOTAL && p->irradiation <= ATL_IRR_GROUND;
     if (p->panel_model == ATL_PANEL_BOFINGER) return p->trigon_model == ATL_TRIGON_SIMPLE && p->irradiation == ATL_IRR_TOTAL;
     return false;
 }

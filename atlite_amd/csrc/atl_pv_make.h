@@ -8,7 +8,8 @@ int make_pv(const atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p,
     ATL_REQUIRE(in && p, "atl_pv: inputs/params is NULL");
     ATL_REQUIRE(T >= 0 && S >= 0, "atl_pv: negative shape");
     if (in->d_influx) {  // the influx / outflux head (pv_influx_fast)
-        ATL_REQUIRE(in->d_outflux && in->d_influx_toa, "atl_pv: an influx dataset needs outflux and influx_toa here");
+        ATL_REQUIRE((in->d_outflux || in->d_albedo) && in->d_influx_toa,
+                    "atl_pv: an influx dataset needs albedo or outflux (irradiation.py:128-139) and influx_toa here");
         ATL_REQUIRE(p->clearsky_model == ATL_CLEARSKY_SIMPLE || p->clearsky_model == ATL_CLEARSKY_ENHANCED,
                     "`clearsky model` must be chosen from 'simple' and 'enhanced'");
         ATL_REQUIRE(p->clearsky_model == ATL_CLEARSKY_SIMPLE || in->d_humidity,
@@ -36,6 +37,10 @@ int make_pv(const atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p,
     c->in = *in;
     c->S = ld;  // the converter's S is what separates the slots of its cubes
     c->k = pv_const_of(p);
+    if (in->d_influx && in->d_albedo) {  // "albedo" wins over "outflux" (irradiation.py:129-131): it takes the outflux's stream
+        c->k.alb_cube = 1;
+        c->in.d_outflux = in->d_albedo;
+    }
     c->o.ss = sin(p->slope);
     c->o.cs = cos(p->slope);
     c->o.hp = (1.0 + c->o.cs) / 2.0;
@@ -53,7 +58,7 @@ int make_pv(const atl_ctx *ctx, const atl_pv_inputs *in, const atl_pv_params *p,
     c->cell_slope = p->d_cell_slope;
     c->cell_azimuth = p->d_cell_azimuth;
     *vec = vec_ok(T, S, ld, {in->d_influx_direct, in->d_influx_diffuse, in->d_influx_toa, in->d_albedo,
-                      in->d_temperature, in->d_solar_altitude, in->d_solar_azimuth, in->d_influx, in->d_outflux,
+                      in->d_temperature, in->d_solar_altitude, in->d_solar_azimuth, in->d_influx, in->d_influx ? c->in.d_outflux : in->d_outflux,
                       in->d_influx && p->clearsky_model == ATL_CLEARSKY_ENHANCED ? in->d_humidity : nullptr});
     return ATL_OK;
 }

@@ -1350,9 +1350,15 @@ int atl_pv_probe_host(const atl_pv_params *p, int family, int64_t n, const doubl
             return int(ATL_OK);
         });
     }
-    // the fast family's influx / outflux head (pv_influx_fast, atl_kernels_pvi.hip): Reindl split (either clearsky model) +
-    // albedo from outflux, then the Huld panel after either trigon model
-    if (family == 0 && infl && outf && !dir && !dif && !alb) {
+    // the fast family's influx head (pv_influx_fast, atl_kernels_pvi.hip): Reindl split (either clearsky model) +
+    // albedo from outflux or the albedo variable, then the Huld panel after either trigon model
+    if (family == 0 && infl && (outf || alb) && !dir && !dif) {
+        PvConst kk = k;
+        const double *second = outf;
+        if (alb) {  // the dataset's albedo variable wins (irradiation.py:129-131)
+            kk.alb_cube = 1;
+            second = alb;
+        }
         ATL_REQUIRE(tmp && p->tracking == ATL_TRACK_NONE && (p->trigon_model == ATL_TRIGON_SIMPLE || p->trigon_model == ATL_TRIGON_OTHER) &&
                         (p->clearsky_model == ATL_CLEARSKY_SIMPLE || (p->clearsky_model == ATL_CLEARSKY_ENHANCED && hum)) &&
                         p->panel_model == ATL_PANEL_HULD && p->irradiation == ATL_IRR_TOTAL,
@@ -1362,12 +1368,12 @@ int atl_pv_probe_host(const atl_pv_params *p, int family, int64_t n, const doubl
             const double rh = at(hum, i);
             if (hd) {
                 const PvOri o = PvConvT<false, true, false, kTailHuldHayDavies>::make_ori(slope[i], pazim[i]);
-                h_out[i] = enh ? pv_cell_influx_auto<kTailHuldHayDavies, true>(infl[i], outf[i], toa[i], tmp[i], rh, alt[i], az[i], o, k)
-                               : pv_cell_influx_auto<kTailHuldHayDavies, false>(infl[i], outf[i], toa[i], tmp[i], rh, alt[i], az[i], o, k);
+                h_out[i] = enh ? pv_cell_influx_auto<kTailHuldHayDavies, true>(infl[i], second[i], toa[i], tmp[i], rh, alt[i], az[i], o, kk)
+                               : pv_cell_influx_auto<kTailHuldHayDavies, false>(infl[i], second[i], toa[i], tmp[i], rh, alt[i], az[i], o, kk);
             } else {
                 const PvOri o = PvConvT<false, true, false, kTailHuld>::make_ori(slope[i], pazim[i]);
-                h_out[i] = enh ? pv_cell_influx_auto<kTailHuld, true>(infl[i], outf[i], toa[i], tmp[i], rh, alt[i], az[i], o, k)
-                               : pv_cell_influx_auto<kTailHuld, false>(infl[i], outf[i], toa[i], tmp[i], rh, alt[i], az[i], o, k);
+                h_out[i] = enh ? pv_cell_influx_auto<kTailHuld, true>(infl[i], second[i], toa[i], tmp[i], rh, alt[i], az[i], o, kk)
+                               : pv_cell_influx_auto<kTailHuld, false>(infl[i], second[i], toa[i], tmp[i], rh, alt[i], az[i], o, kk);
             }
         }
         return ATL_OK;

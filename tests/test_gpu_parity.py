@@ -365,7 +365,13 @@ def test_pv_night_skip_per_cell_kernels_on_grid_tiles(ctx, Y, X):
     # trackers x tails that are fused fast-family kernels since round 6 (atl_kernels_pvkt.hip; the general kernel before)
     dict(tracking="horizontal", trigon_model="other"), dict(tracking="vertical", trigon_model="other"),
     dict(panel="KANENA", tracking="horizontal"), dict(panel="KANENA", tracking="dual"),
-    dict(panel_model="none", tracking="tilted_horizontal"), dict(panel_model="none", tracking="vertical")])
+    dict(panel_model="none", tracking="tilted_horizontal"), dict(panel_model="none", tracking="vertical"),
+    dict(panel_model="none", tracking="dual", irradiation="ground"),
+    # ... and the rest behind a run-time tracker switch (atl_kernels_pvka.hip: per-cell orientations, Hay-Davies before the
+    # irradiation / bofinger tails)
+    dict(panel="KANENA", tracking="tilted_horizontal", trigon_model="other"),
+    dict(panel_model="none", tracking="horizontal", trigon_model="other", irradiation="direct"),
+    dict(panel_model="none", tracking="vertical", trigon_model="other")])
 def test_pv_night_skip_other_tails_and_trackers(ctx, opts):
     """The night early-out for the family's other members - trackers with the Huld panel, and the bofinger /
     solar thermal / irradiation tails after either trigon model with a fixed panel: the same bits as without it (fused,
@@ -409,6 +415,19 @@ def test_pv_night_skip_other_tails_and_trackers(ctx, opts):
     for ns in (False, True):
         agg = ctx.pv(dev, scal, T, Y * X, plan=plan, options=dict(opts, night_skip=ns)).numpy()
         np.testing.assert_allclose(agg, refa, rtol=1e-10, atol=1e-12 * np.nanmax(np.abs(refa[np.isfinite(refa)])), equal_nan=True)
+    # ... with one orientation per cell (trackers x Hay-Davies / bofinger / irradiation: fused kernels of their own)
+    ori_pc = dict(slope=np.repeat(lo["slope"], X)[None, :], azimuth=np.repeat(lo["azimuth"], X)[None, :])
+    with np.errstate(all="ignore"):
+        if opts.get("panel_model") == "none":
+            refpc = orc.convert_irradiation(ds, ori_pc, trk, opts.get("irradiation", "total"), tm, "simple")
+        elif opts.get("panel_model") == "solar_thermal":
+            refpc = orc.convert_solar_thermal(ds, ori_pc, tm, "simple", 0.8, 3.0, 80.0)
+        else:
+            refpc = orc.convert_pv_general(ds, panel, ori_pc, trk, tm, "simple")
+        refpa = orc.aggregate_matrix(np.asarray(refpc).reshape(T, -1), M)
+    percell = dict(panel, slope=np.repeat(lo["slope"], X), azimuth=np.repeat(lo["azimuth"], X))
+    agg = ctx.pv(dev, percell, T, Y * X, plan=plan, options=dict(opts, night_skip=True)).numpy()
+    np.testing.assert_allclose(agg, refpa, rtol=1e-10, atol=1e-12 * np.nanmax(np.abs(refpa[np.isfinite(refpa)])), equal_nan=True)
 
 
 def test_pv_influx_outflux_dataset_fast_family(ctx):
@@ -456,6 +475,51 @@ def test_pv_influx_outflux_dataset_fast_family(ctx):
                                    clearsky_model="simple")
     got = ctx.pv(dev, pc, T, S, options=dict(clearsky_model="simple")).numpy()
     np.testing.assert_allclose(got, refpc, rtol=1e-10, atol=1e-12 * np.nanmax(np.abs(refpc)), equal_nan=True)
+
+
+@pytest.mark.parametrize("both", [False, True])
+def test_pv_influx_dataset_with_an_albedo_variable(ctx, both):
+    """Total influx and an `albedo` variable (irradiation.py:128-131: "albedo" is used as it is and wins over "outflux"):
+    the fast family's influx head with the albedo riding in the outflux's stream (round 6; the general kernel before) -
+    either trigon model, either clearsky model, scalar and per-cell orientation, per cell and aggregated, early-out on /
+    off with the same bits, against the oracle; hostile albedos (NaN, > 1, negative) stay what they are."""
+    T, Y, X, N = 50, 9, 20, 6
+    S = Y * X
+    ds = H.pv_dataset(T, Y, X, seed=77)
+    infl = ds["influx_direct"] + ds["influx_diffuse"]
+    alb = ds["albedo"].copy()
+    day = np.argwhere(infl > 50.0)
+    for n, (t, c) in enumerate(day[:: max(1, len(day) // 6)][:6]):
+        alb[t, c] = (np.nan, 3.0, -0.5, 0.0, 1.0, 1e300)[n]
+    d = {k: ds[k] for k in ("influx_toa", "temperature", "solar_altitude", "solar_azimuth")}
+    d["influx"], d["albedo"] = infl, alb
+    d["humidity"] = np.random.default_rng(3).random((T, S))
+    if both:
+        d["outflux"] = 0.5 * infl  # ignored: albedo wins
+    dev = {k: ctx.upload(v) for k, v in d.items()}
+    M = H.blob_matrix(N, Y, X, seed=78)
+    plan = ctx.plan(M, row_len=X)
+    _, ygrid = H.grid(Y, X)
+    lo = orc.orientation_latitude_optimal(np.radians(ygrid))
+    pc = dict(H.CSI, slope=np.repeat(lo["slope"], X), azimuth=np.repeat(lo["azimuth"], X))
+    ori_pc = dict(slope=np.repeat(lo["slope"], X)[None, :], azimuth=np.repeat(lo["azimuth"], X)[None, :])
+    ori = dict(slope=np.radians(30.0), azimuth=np.radians(180.0))
+    for tm in ("simple", "other"):
+        for cs in ("simple", "enhanced"):
+            opts = dict(clearsky_model=cs, trigon_model=tm)
+            with np.errstate(all="ignore"):
+                ref = orc.convert_pv_general(d, H.CSI, ori, None, tm, cs)
+                refpc = orc.convert_pv_general(d, H.CSI, ori_pc, None, tm, cs)
+                refa = orc.aggregate_matrix(ref, M)
+            tol = dict(rtol=1e-10, equal_nan=True)
+            got = ctx.pv(dev, PV_PARAMS, T, S, options=opts).numpy()
+            np.testing.assert_allclose(got, ref, atol=1e-12 * np.nanmax(np.abs(ref)), **tol)
+            got = ctx.pv(dev, pc, T, S, options=opts).numpy()
+            np.testing.assert_allclose(got, refpc, atol=1e-12 * np.nanmax(np.abs(refpc)), **tol)
+            a = ctx.pv(dev, PV_PARAMS, T, S, plan=plan, options=dict(opts, night_skip=False)).numpy()
+            b = ctx.pv(dev, PV_PARAMS, T, S, plan=plan, options=dict(opts, night_skip=True)).numpy()
+            np.testing.assert_array_equal(a, b)
+            np.testing.assert_allclose(a, refa, atol=1e-12 * np.nanmax(np.abs(refa[np.isfinite(refa)])), **tol)
 
 
 @pytest.mark.parametrize("R", [16, 17, 28, 40, 48, 70])

@@ -127,7 +127,7 @@ def test_host_pv_math_against_oracle(seed):
         # the fast family wherever the dispatcher would use it
         model = pp.panel_model
         fast_ok = flavour == "split"  # (solar_thermal has no tracker in the reference's API either)
-        if flavour == "sarah":  # influx / outflux dataset: the Huld panel on a fixed mount, either trigon / clearsky model
+        if flavour in ("sarah", "influx"):  # total influx with outflux or an albedo variable: the Huld panel on a fixed mount, either trigon / clearsky model
             fast_ok = what == "pv" and trk is None and model == _lib.PANEL["huld"]
         if fast_ok:
             got = probe(pp, 0, ds, ori["slope"], ori["azimuth"])

@@ -85,12 +85,12 @@ for name, nbytes, fn in (
      lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="solar_thermal", c0=0.8, c1=3.0, t_store_K=353.15, trigon_model="other"))),
     ("bofinger + tracking='horizontal' - fast family again since round 6 (general kernel in r03-r05: 5.45 ms)", 56, lambda: ctx.pv(inputs, kanena, T, S, plan=plan, options=dict(tracking="horizontal"))),
     ("irradiation(tracking='dual') - fast family again since round 6 (general kernel in r03-r05: 3.62 ms)", 48, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none", tracking="dual"))),
-    ("bofinger + tracking='tilted_horizontal' + Hay-Davies, per-cell orientation - general kernel since round 3", 56,
+    ("bofinger + tracking='tilted_horizontal' + Hay-Davies, per-cell orientation - run-time tracker family since round 6 (general kernel in r03-r05: 6.09 ms)", 56,
      lambda: ctx.pv(inputs, dict(kanena, slope=percell["slope"], azimuth=percell["azimuth"]), T, S, plan=plan, options=dict(tracking="tilted_horizontal", trigon_model="other"))),
     ("pv(tracking='horizontal') + night early-out (r02)", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="horizontal", night_skip=True))),
     ("pv(tracking='tilted_horizontal') + night early-out (r02)", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="tilted_horizontal", night_skip=True))),
     ("pv(tracking='dual') + night early-out (r02)", 48, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="dual", night_skip=True))),
-    ("tracking='horizontal' + Hay-Davies, per-cell orientation + night early-out - general kernel since round 3 (reads every byte)", 56, lambda: ctx.pv(inputs, percell, T, S, plan=plan, options=dict(tracking="horizontal", trigon_model="other", night_skip=True))),
+    ("tracking='horizontal' + Hay-Davies, per-cell orientation + night early-out - run-time tracker family since round 6 (general kernel in r03-r05: 4.93 ms)", 56, lambda: ctx.pv(inputs, percell, T, S, plan=plan, options=dict(tracking="horizontal", trigon_model="other", night_skip=True))),
     ("pv(trigon_model='other') + night early-out (r02)", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(trigon_model="other", night_skip=True))),
     ("pv(panel='KANENA') + night early-out (r02)", 56, lambda: ctx.pv(inputs, kanena, T, S, plan=plan, options=dict(night_skip=True))),
     ("irradiation() + night early-out (r02)", 48, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none", night_skip=True))),
@@ -104,7 +104,7 @@ for name, nbytes, fn in (
     ("influx / outflux dataset, enhanced clearsky model + Hay-Davies - fast family head (r04)", 56,
      lambda: ctx.pv(dict(influx_ds, humidity=inputs["albedo"]), scal, T, S, plan=plan, options=dict(clearsky_model="enhanced", trigon_model="other"))),
     ("influx / outflux dataset + Hay-Davies + night early-out (r04)", 48, lambda: ctx.pv(influx_ds, scal, T, S, plan=plan, options=dict(trigon_model="other", night_skip=True))),
-    ("general kernel: influx dataset with an albedo cube + Hay-Davies (what is left for it)", 48,
+    ("influx dataset with an albedo variable + Hay-Davies - fast family head since round 6 (the general kernel before: 5.04 ms)", 48,
      lambda: ctx.pv(dict(influx=inputs["influx_direct"], influx_toa=inputs["influx_toa"], albedo=inputs["albedo"], temperature=inputs["temperature"],
                          solar_altitude=inputs["solar_altitude"], solar_azimuth=inputs["solar_azimuth"]), scal, T, S, plan=plan, options=dict(trigon_model="other"))),
     ("per-cell series out (no matrix), no early-out", 64, lambda: ctx.pv(inputs, scal, T, S, options=dict(night_skip=False))),
