@@ -85,12 +85,16 @@ for name, nbytes, fn in (
      lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="solar_thermal", c0=0.8, c1=3.0, t_store_K=353.15, trigon_model="other"))),
     ("bofinger + tracking='horizontal' - fast family again since round 6 (general kernel in r03-r05: 5.45 ms)", 56, lambda: ctx.pv(inputs, kanena, T, S, plan=plan, options=dict(tracking="horizontal"))),
     ("irradiation(tracking='dual') - fast family again since round 6 (general kernel in r03-r05: 3.62 ms)", 48, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none", tracking="dual"))),
-    ("bofinger + tracking='tilted_horizontal' + Hay-Davies, per-cell orientation - run-time tracker family since round 6 (general kernel in r03-r05: 6.09 ms)", 56,
+    ("bofinger + tracking='tilted_horizontal' + Hay-Davies, per-cell orientation - fast family since round 6, atl_kernels_pvka.hip (general kernel in r03-r05: 6.09 ms)", 56,
      lambda: ctx.pv(inputs, dict(kanena, slope=percell["slope"], azimuth=percell["azimuth"]), T, S, plan=plan, options=dict(tracking="tilted_horizontal", trigon_model="other"))),
+    ("irradiation(tracking='horizontal', trigon_model='other') - fast family since round 6, atl_kernels_pvka.hip (48 B/cell)", 48,
+     lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none", tracking="horizontal", trigon_model="other", night_skip=False))),
+    ("bofinger + tracking='vertical', per-cell orientation - fast family since round 6, atl_kernels_pvkc.hip (48 B/cell: azimuth not read)", 48,
+     lambda: ctx.pv(inputs, dict(kanena, slope=percell["slope"], azimuth=percell["azimuth"]), T, S, plan=plan, options=dict(tracking="vertical", night_skip=False))),
     ("pv(tracking='horizontal') + night early-out (r02)", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="horizontal", night_skip=True))),
     ("pv(tracking='tilted_horizontal') + night early-out (r02)", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="tilted_horizontal", night_skip=True))),
     ("pv(tracking='dual') + night early-out (r02)", 48, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(tracking="dual", night_skip=True))),
-    ("tracking='horizontal' + Hay-Davies, per-cell orientation + night early-out - run-time tracker family since round 6 (general kernel in r03-r05: 4.93 ms)", 56, lambda: ctx.pv(inputs, percell, T, S, plan=plan, options=dict(tracking="horizontal", trigon_model="other", night_skip=True))),
+    ("tracking='horizontal' + Hay-Davies, per-cell orientation + night early-out - fast family since round 6, atl_kernels_pvkc.hip (general kernel in r03-r05: 4.93 ms)", 56, lambda: ctx.pv(inputs, percell, T, S, plan=plan, options=dict(tracking="horizontal", trigon_model="other", night_skip=True))),
     ("pv(trigon_model='other') + night early-out (r02)", 56, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(trigon_model="other", night_skip=True))),
     ("pv(panel='KANENA') + night early-out (r02)", 56, lambda: ctx.pv(inputs, kanena, T, S, plan=plan, options=dict(night_skip=True))),
     ("irradiation() + night early-out (r02)", 48, lambda: ctx.pv(inputs, scal, T, S, plan=plan, options=dict(panel_model="none", night_skip=True))),
