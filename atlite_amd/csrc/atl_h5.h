@@ -153,5 +153,7 @@ int fast_inflate_zlib(const uint8_t *src, uint64_t src_n, uint8_t *dst, uint64_t
 // The serial half of the DEVICE decoder (atl_inflate_dev.h) executed on the host: a test entry (atl_inflate_probe which = 3).
 // 0 = exactly dst_n bytes and the Adler-32 matches, else the decoder's dinf::Status.
 int device_inflate_emulated(const uint8_t *src, uint64_t src_n, uint8_t *dst, uint64_t dst_n);
+// ... its segment scheme (a stream's blocks decoded side by side: atl_inflate_dev.h): finder, count, chain, decode, resolve
+int device_inflate_split_emulated(const uint8_t *src, uint64_t src_n, uint8_t *dst, uint64_t dst_n, int *n_segments);
 
 }}  // namespace atl::h5

@@ -7,6 +7,7 @@
 // with a bounds-checked tail loop - and is ~2-3x faster.  Safety net: every stream's Adler-32 is
 // verified; on ANY failure (format error, checksum mismatch, size mismatch) the caller falls back to
 // zlib's own inflate, so the fast path can only ever make things faster, never different.
+#include <algorithm>
 #include <immintrin.h>
 
 #include <cstdint>
@@ -510,6 +511,134 @@ int device_inflate_emulated(const uint8_t *src, uint64_t src_n, uint8_t *dst, ui
     const int st = inflate_stream<HostMem, HostWave, HostWindow<HostMem>, HostSink>(A, words.data(), uint32_t((src_n + 3) / 4), src_n, dst_n, sink, &want);
     if (st) return st;
     if (sink.max_batch > uint64_t(kStage)) return 100;  // the staging area of the device would have overflowed
+    return adler32_of(dst, dst_n) == want ? kOk : kAdler;
+}
+
+// ---- the segment scheme (atl_inflate_dev.h, "SEGMENTS") on the host: finder, count pass, chain, decode pass with markers,
+// resolve - the same templates and tests the kernels run, the parallel parts as loops.  *n_segments: how many segments the
+// stream's chain had (1 = the finder found nothing to split at).  CPU tests hold it against zlib.
+namespace {
+struct VecSplits {
+    const std::vector<uint64_t> *v;
+    bool is_split(uint64_t bit) const { return std::binary_search(v->begin(), v->end(), bit); }
+};
+struct CountSinkH {
+    void tables_ready() {}
+    void stored(uint64_t, uint32_t, uint64_t) {}
+    void resolve(int, uint64_t, uint64_t) {}
+};
+struct MarkSinkH {
+    const uint8_t *src;
+    uint8_t *val, *mark;
+    const uint32_t *rec, *pos;
+    uint64_t seg0 = 0, max_batch = 0;
+    void tables_ready() {}
+    void stored(uint64_t byte_pos, uint32_t len, uint64_t out_pos) {
+        memcpy(val + out_pos, src + byte_pos, len);
+        memset(mark + out_pos, 0, len);
+    }
+    void resolve(int n, uint64_t bstart, uint64_t bend) {
+        if (bend - bstart > max_batch) max_batch = bend - bstart;
+        for (int i = 0; i < n; ++i) {
+            if (rec[i] & dinf::kLitFlag) {
+                val[pos[i]] = uint8_t(rec[i]);
+                mark[pos[i]] = 0;
+                continue;
+            }
+            const uint32_t len = rec[i] & 0x1FF, dist = (rec[i] & 0x7FFFFFFF) >> 9;
+            for (uint32_t j = 0; j < len; ++j) {
+                const int64_t sp = int64_t(pos[i]) + j - int64_t(dist);
+                if (sp < int64_t(seg0)) {  // before this segment: a marker
+                    const uint32_t back = uint32_t(int64_t(seg0) - sp);
+                    val[pos[i] + j] = uint8_t(dinf::marker_lo(back));
+                    mark[pos[i] + j] = uint8_t(dinf::marker_hi(back));
+                } else {
+                    val[pos[i] + j] = val[sp];
+                    mark[pos[i] + j] = mark[sp];
+                }
+            }
+        }
+    }
+};
+}  // namespace
+
+int device_inflate_split_emulated(const uint8_t *src, uint64_t src_n, uint8_t *dst, uint64_t dst_n, int *n_segments) {
+    using namespace dinf;
+    if (n_segments) *n_segments = 0;
+    std::vector<uint32_t> words(size_t(src_n / 4 + 4), 0u);
+    if (src_n) memcpy(words.data(), src, size_t(src_n));
+    const uint32_t n_words = uint32_t((src_n + 3) / 4);
+    if (src_n < 6 || !zlib_header_ok(words[0])) return kBadHeader;
+    std::vector<uint16_t> lit(kLitCap), off(kOffCap), codes(320);
+    std::vector<uint32_t> cnt(16), nxt(16);
+    std::vector<uint8_t> lens(32 + 320);
+    std::vector<uint32_t> qrec(kQueue), qpos(kQueue + 1), wbuf(16), sym(64);
+    Areas<HostMem> A{lit.data(), off.data(), codes.data(), cnt.data(), nxt.data(), lens.data(), qrec.data(), qpos.data(), wbuf.data(), sym.data()};
+    // 1. find
+    const uint64_t src_bits = src_n * 8;
+    std::vector<uint64_t> cands;
+    uint8_t tab[128];
+    for (uint64_t p = 17; p + 74 < src_bits; ++p) {
+        if (!find_l1(bits64_at(words.data(), n_words, p), bits64_at(words.data(), n_words, p + 64))) continue;
+        if (header_l2(words.data(), n_words, p, src_bits, tab)) cands.push_back(p);
+    }
+    // 2. count, from the stream's first block and from every candidate
+    std::vector<uint64_t> starts;
+    starts.push_back(16);
+    starts.insert(starts.end(), cands.begin(), cands.end());
+    const VecSplits splits{&cands};
+    std::vector<SegOut> res(starts.size());
+    std::vector<int> status(starts.size());
+    for (size_t t = 0; t < starts.size(); ++t) {
+        CountSinkH sink;
+        status[t] = inflate_segment<HostMem, HostWave, HostWindow<HostMem>, CountSinkH, VecSplits>(
+            A, words.data(), n_words, src_n, starts[t], 0, t == 0 ? 0u : kSegSlack, dst_n, splits, sink, &res[t]);
+    }
+    // the chain
+    std::vector<size_t> chain;
+    std::vector<uint64_t> seg0;
+    uint64_t at = 0;
+    uint32_t want = 0;
+    for (size_t t = 0;;) {
+        if (status[t]) return status[t];
+        chain.push_back(t);
+        seg0.push_back(at);
+        at += res[t].out_end;
+        if (at > dst_n) return kOutputFull;
+        if (res[t].is_final) {
+            want = res[t].adler;
+            break;
+        }
+        const auto it = std::lower_bound(starts.begin() + 1, starts.end(), res[t].end_bit);
+        if (it == starts.end() || *it != res[t].end_bit) return 101;  // a segment stops only where another one starts
+        t = size_t(it - starts.begin());
+    }
+    if (at != dst_n) return kShort;
+    if (n_segments) *n_segments = int(chain.size());
+    // 3. decode with markers
+    std::vector<uint8_t> mark(size_t(dst_n) + 1, 0);
+    for (size_t c = 0; c < chain.size(); ++c) {
+        MarkSinkH sink{};
+        sink.src = reinterpret_cast<const uint8_t *>(words.data());
+        sink.val = dst;
+        sink.mark = mark.data();
+        sink.rec = qrec.data();
+        sink.pos = qpos.data();
+        sink.seg0 = seg0[c];
+        SegOut o{};
+        const uint32_t slack = uint32_t(std::min<uint64_t>(kSegSlack, seg0[c]));
+        const int st = inflate_segment<HostMem, HostWave, HostWindow<HostMem>, MarkSinkH, VecSplits>(
+            A, words.data(), n_words, src_n, starts[chain[c]], seg0[c], slack, dst_n, splits, sink, &o);
+        if (st) return st;
+        if (sink.max_batch > uint64_t(kStage)) return 100;
+        if (o.out_end != seg0[c] + res[chain[c]].out_end || o.end_bit != res[chain[c]].end_bit) return 102;  // both passes agree
+    }
+    // 4. resolve, segment after segment
+    for (size_t c = 1; c < chain.size(); ++c) {
+        const uint64_t end = c + 1 < chain.size() ? seg0[c + 1] : dst_n;
+        for (uint64_t i = seg0[c]; i < end; ++i)
+            if (mark[i] & 0x80u) dst[i] = dst[seg0[c] - marker_back(dst[i], mark[i])];
+    }
     return adler32_of(dst, dst_n) == want ? kOk : kAdler;
 }
 

@@ -553,9 +553,12 @@ struct HostWindow {
 #define ATL_INF_TICK(win, i, t0) ((void)0)
 #define ATL_INF_T0() 0ull
 #endif
-template <class M, class W, class Win>
+// SEG (segments of a stream decoded side by side, inflate_segment below): a distance may reach `slack` bytes before `seg0`, the
+// position the segment's output starts at - whether it stays inside the chunk is known once the segments before it are.
+template <class M, class W, class Win, bool SEG = false>
 ATL_HD inline int decode_batch_wide(const Areas<M> &A, Win &win, typename M::src_t w, uint32_t n_words, uint64_t &bitpos,
-                                    uint64_t src_bits, uint64_t &out_pos, uint64_t out_n, int &n_out, bool &eob) {
+                                    uint64_t src_bits, uint64_t &out_pos, uint64_t out_n, int &n_out, bool &eob, uint32_t seg0 = 0,
+                                    uint32_t slack = 0) {
     const uint32_t bstart = uint32_t(out_pos);  // (chunks are < 2^31 bytes: 32-bit positions inside a batch)
     uint32_t n = 0, rel_out = 0;                // records queued, output bytes of the batch so far
     int status = kOk;
@@ -627,7 +630,11 @@ ATL_HD inline int decode_batch_wide(const Areas<M> &A, Win &win, typename M::src
                 M::stv32(A.qpos + q, p);
                 if (!(r & kLitFlag)) {
                     const uint32_t dist = (r & 0x7FFFFFFFu) >> 9;
-                    if (dist == 0 || dist > p) bad(k) = 1;
+                    if constexpr (SEG) {
+                        if (dist == 0 || dist > p - seg0 + slack) bad(k) = 1;
+                    } else {
+                        if (dist == 0 || dist > p) bad(k) = 1;
+                    }
                 }
             }
         });
@@ -731,6 +738,253 @@ ATL_HD inline int inflate_stream(const Areas<M> &A, typename M::src_t w, uint32_
     if (b.consumed() > src_bits) return kInputOverrun;
     *adler_want = want;
     return kOk;
+}
+
+// ---- SEGMENTS: one stream decoded by many waves (round 6) ----------------------------------------------------------------
+// A zlib stream of an atlite cutout is long - atlite writes (time = 100, y, x) chunks, 16 MB each for a 200 x 200 grid
+// (atlite/cutout.py:143, atlite/data.py:70-71, 139: zlib level 9 + shuffle) - and one wave inflates ~10 MB/s whatever the
+// device does besides; a year of such a cutout is a few hundred streams.  But a stream is a chain of DEFLATE BLOCKS (zlib
+// closes one every 16 383 symbols), and a block can be decoded without its predecessors except for what its matches copy from
+// the 32 KiB before it.  So (pugz / rapidgzip's scheme, restated for wavefronts):
+//   1. find: every bit offset of the compressed bytes is tested for a dynamic-Huffman block header that inflate would accept
+//      (find_l1 / header_l2 below: BTYPE, HLIT / HDIST ranges, a complete precode, then the code lengths decoded and both codes
+//      complete) - candidates, a few per 64 KiB, some of them false;
+//   2. count: a wave per candidate decodes from there, without output, until it stands at the NEXT candidate at a block
+//      boundary or at the end of the stream (inflate_segment): where it ends and how many bytes it makes.  The host follows the
+//      chain from the stream's first block: the candidates on it are real, their segments' output positions are prefix sums;
+//   3. decode: a wave per segment on the chain decodes again, this time writing - a byte it would copy from before its own
+//      start is written as a MARKER (how far before the start: 15 bits across the value plane and a second, "mark" plane;
+//      copies of markers copy markers);
+//   4. resolve: segment after segment of a stream, all bytes of a segment at once, markers are replaced by the bytes they
+//      point at (final by then); Adler-32 over the whole chunk.
+// Nothing here trusts the finder: a false candidate costs a wave's time, a missed one only makes its predecessor's segment
+// longer, a chain that does not close sends the stream to the host decoders like any other declined stream.
+constexpr uint32_t kSegSlack = 32768;  // how far before its start a segment's matches may reach (DEFLATE's window)
+ATL_HD inline uint32_t marker_lo(uint32_t back) { return (back - 1u) & 0xFFu; }            // back = 1 .. 32768 bytes before the start
+ATL_HD inline uint32_t marker_hi(uint32_t back) { return 0x80u | ((back - 1u) >> 8); }
+ATL_HD inline uint32_t marker_back(uint32_t lo, uint32_t hi) { return (((hi & 0x7Fu) << 8) | lo) + 1u; }
+
+struct SegOut {
+    uint64_t end_bit;   // where the segment stopped: a split point at a block boundary, or behind the stream's trailer
+    uint64_t out_end;   // output position behind its last byte
+    uint32_t is_final;  // it decoded the stream's final block (adler = the trailer)
+    uint32_t adler;
+};
+
+// Splits: bool is_split(uint64_t bit) - is a segment known to start at this block boundary?
+// start_bit: a block header (the stream's first: 16); seg0: where its output begins (count pass: 0); slack: kSegSlack, or
+// what lies before seg0 if that is less (the stream's first segment: 0).
+template <class M, class W, class Win, class Sink, class Splits>
+ATL_HD inline int inflate_segment(const Areas<M> &A, typename M::src_t w, uint32_t n_words, uint64_t src_n, uint64_t start_bit,
+                                  uint64_t seg0, uint32_t slack, uint64_t out_n, const Splits &splits, Sink &sink, SegOut *r) {
+    if (src_n < 6 || n_words == 0) return kBadHeader;
+    if (out_n >= (uint64_t(1) << 31)) return kOutputFull;  // 32-bit positions inside a batch
+    init_sym<M, W>(A);
+    Bits<M> b;
+    b.start(w, n_words, start_bit);
+    Win win;
+    uint64_t out_pos = seg0;
+    const uint64_t src_bits = src_n * 8;
+    r->is_final = 0;
+    r->adler = 0;
+    for (;;) {
+        const uint64_t hp = b.consumed();
+        if (hp != start_bit && splits.is_split(hp)) {  // somebody else's block
+            r->end_bit = hp;
+            break;
+        }
+        b.refill();
+        if (hp + 3 > src_bits) return kInputOverrun;
+        const bool final_block = b.take(1) != 0;
+        const uint32_t type = b.take(2);
+        if (type == 0) {  // stored: skip to the byte boundary, LEN, ~LEN, the bytes
+            b.drop(int((8 - (b.consumed() & 7)) & 7));
+            b.refill();
+            const uint32_t len = b.take(16);
+            b.refill();
+            const uint32_t nlen = b.take(16);
+            if ((len ^ nlen) != 0xFFFFu) return kBadBlock;
+            const uint64_t byte_pos = b.consumed() >> 3;
+            if (byte_pos + len > src_n) return kInputOverrun;
+            if (out_n - out_pos < len) return kOutputFull;
+            sink.stored(byte_pos, len, out_pos);
+            out_pos += len;
+            b.start(w, n_words, (byte_pos + len) * 8);
+        } else {
+            int st;
+            if (type == 1) {
+                st = fixed_tables<M, W>(A);
+            } else if (type == 2) {
+                if (b.consumed() + 14 > src_bits) return kInputOverrun;
+                st = dynamic_tables<M, W>(A, b);
+            } else {
+                return kBadBlock;
+            }
+            if (st) return st;
+            if (b.consumed() > src_bits) return kInputOverrun;
+            sink.tables_ready();
+            uint64_t bitpos = b.consumed();
+            bool eob = false;
+            win.reset();
+            while (!eob) {
+                int n = 0;
+                const uint64_t bstart = out_pos;
+                st = decode_batch_wide<M, W, Win, true>(A, win, w, n_words, bitpos, src_bits, out_pos, out_n, n, eob, uint32_t(seg0), slack);
+                if (st) return st;
+                if (bitpos > src_bits) return kInputOverrun;
+                sink.resolve(n, bstart, out_pos);
+            }
+            b.start(w, n_words, bitpos);
+        }
+        if (final_block) {
+            b.drop(int((8 - (b.consumed() & 7)) & 7));  // trailer: Adler-32 of the output, big-endian
+            uint32_t want = 0;
+            for (int k = 0; k < 4; ++k) {
+                b.refill();
+                want = (want << 8) | b.take(8);
+            }
+            if (b.consumed() > src_bits) return kInputOverrun;
+            r->is_final = 1;
+            r->adler = want;
+            r->end_bit = b.consumed();
+            break;
+        }
+    }
+    r->out_end = out_pos;
+    return kOk;
+}
+
+// ---- the block finder's tests (one lane = one bit offset; plain loads, no wave-uniform state) ------------------------------
+// the 64 bits of a word buffer from bit p on (words past the end read as zero)
+ATL_HD inline uint64_t bits64_at(const uint32_t *w, uint32_t n_words, uint64_t p) {
+    const uint32_t i = uint32_t(p >> 5), sh = uint32_t(p & 31);
+    const uint32_t a = i < n_words ? w[i] : 0u, b = i + 1 < n_words ? w[i + 1] : 0u, c = i + 2 < n_words ? w[i + 2] : 0u;
+    return uint64_t(funnel(b, a, sh)) | (uint64_t(funnel(c, b, sh)) << 32);
+}
+
+// the weight 128 >> len of a precode length (0 for "no code"): complete means the weights add up to 128
+ATL_HD inline uint32_t precode_weight(uint32_t len) { return len ? 128u >> len : 0u; }
+
+// L0 + L1: at the 74 bits x (0 .. 63), y (64 ..): BFINAL = 0, BTYPE = dynamic, HLIT <= 29, HDIST <= 29 and a COMPLETE precode
+// (zlib's inflate refuses an incomplete one).  (The device tests 64 offsets' L0 with a handful of mask operations and takes
+// the weights from a table of four lengths at a time: k_find_blocks; this is the reference form.)
+ATL_HD inline bool find_l1(uint64_t x, uint64_t y) {
+    if ((x & 7u) != 4u) return false;  // BFINAL 0, BTYPE 2 (bits 1, 2 = 0, 1)
+    if (((x >> 3) & 31u) > 29u || ((x >> 8) & 31u) > 29u) return false;
+    const uint32_t hclen = uint32_t((x >> 13) & 15u) + 4u;
+    const uint64_t f = (x >> 17) | (y << 47);
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < hclen; ++i) sum += precode_weight(uint32_t(f >> (3 * i)) & 7u);
+    return sum == 128u;
+}
+
+// L2: the code lengths behind a header that passed L1, decoded with its precode: no bad repeat, an end-of-block code, a complete
+// literal / length code, a complete (or absent, or single) distance code - what dynamic_tables + build_table accept, minus the
+// single-code literal alphabet no compressor emits.  tab: 128 bytes of the caller's (per-lane LDS on the device).
+template <class Tab>
+ATL_HD inline bool header_l2(const uint32_t *w, uint32_t n_words, uint64_t p, uint64_t src_bits, Tab tab) {
+    uint64_t pos = p;
+    uint64_t buf = bits64_at(w, n_words, pos);
+    const uint32_t hlit = uint32_t((buf >> 3) & 31u) + 257u, hdist = uint32_t((buf >> 8) & 31u) + 1u, hclen = uint32_t((buf >> 13) & 15u) + 4u;
+    pos += 17;
+    // precode lengths by symbol, 3 bits each (transmission order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15)
+    uint64_t L = 0;
+    {
+        const uint64_t f = bits64_at(w, n_words, pos);
+        for (uint32_t i = 0; i < hclen; ++i) {
+            uint32_t o;
+            if (i < 3) {
+                o = 16 + i;
+            } else if (i == 3) {
+                o = 0;
+            } else {
+                const uint32_t k = i - 4, step = (k + 1) >> 1;
+                o = (k & 1) ? 8 - step : 8 + step;
+            }
+            L |= ((f >> (3 * i)) & 7u) << (3 * o);
+        }
+        pos += 3 * hclen;
+    }
+    // canonical codes -> 7-bit lookup: symbol | length << 5
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t s2 = 0; s2 < 19; ++s2) {
+        const uint32_t l = uint32_t(L >> (3 * s2)) & 7u;
+#pragma unroll
+        for (uint32_t q = 1; q < 8; ++q) cnt[q] += l == q ? 1u : 0u;
+    }
+    uint32_t nxt[8];
+    {
+        uint32_t code = 0;
+        nxt[0] = 0;
+#pragma unroll
+        for (uint32_t q = 1; q < 8; ++q) {
+            code = (code + (q > 1 ? cnt[q - 1] : 0u)) << 1;
+            nxt[q] = code;
+        }
+    }
+    for (uint32_t j = 0; j < 128; ++j) tab[j] = 0;
+    for (uint32_t s2 = 0; s2 < 19; ++s2) {
+        const uint32_t l = uint32_t(L >> (3 * s2)) & 7u;
+        if (!l) continue;
+        uint32_t code = 0;
+#pragma unroll
+        for (uint32_t q = 1; q < 8; ++q)
+            if (l == q) {
+                code = nxt[q];
+                nxt[q] = code + 1u;
+            }
+        const uint32_t rv = bit_reverse(code, int(l));
+        for (uint32_t j = rv; j < 128u; j += 1u << l) tab[j] = uint8_t(s2 | (l << 5));
+    }
+    // the code lengths: only their weights are kept (units of 2^-15), and whether symbol 256 has a code
+    const uint32_t total = hlit + hdist;
+    uint32_t i = 0, last = 0, w_lit = 0, w_dist = 0, n_dist = 0;
+    bool eob = false;
+    auto add = [&](uint32_t n, uint32_t v) {  // n lengths v from index i on
+        if (v) {
+            const uint32_t in_lit = i < hlit ? (n < hlit - i ? n : hlit - i) : 0u, in_dist = n - in_lit;
+            w_lit += in_lit << (15u - v);
+            w_dist += in_dist << (15u - v);
+            n_dist += in_dist;
+            if (i <= 256u && i + n > 256u) eob = true;
+        }
+        i += n;
+    };
+    while (i < total) {
+        if (pos + 14 > src_bits) return false;
+        buf = bits64_at(w, n_words, pos);
+        const uint32_t e = tab[uint32_t(buf) & 127u];
+        const uint32_t l = e >> 5, sym = e & 31u;
+        if (!l) return false;
+        pos += l;
+        buf >>= l;
+        if (sym < 16u) {
+            add(1, sym);
+            last = sym;
+            continue;
+        }
+        uint32_t rep, v;
+        if (sym == 16u) {
+            if (i == 0) return false;
+            rep = 3u + (uint32_t(buf) & 3u);
+            pos += 2;
+            v = last;
+        } else if (sym == 17u) {
+            rep = 3u + (uint32_t(buf) & 7u);
+            pos += 3;
+            v = 0;
+        } else {
+            rep = 11u + (uint32_t(buf) & 127u);
+            pos += 7;
+            v = 0;
+        }
+        if (i + rep > total) return false;
+        add(rep, v);
+        last = v;
+    }
+    if (pos > src_bits || !eob) return false;
+    if (w_lit != (1u << 15)) return false;
+    return w_dist == (1u << 15) || n_dist == 0 || (n_dist == 1 && w_dist == (1u << 14));
 }
 
 }}  // namespace atl::dinf

@@ -1974,7 +1974,7 @@ int atl_nc_read_slabs(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
 }
 
 int atl_inflate_probe(const void *h_src, size_t src_n, void *h_dst, size_t dst_n, int which, int64_t *ns) {
-    ATL_REQUIRE(h_src && (h_dst || dst_n == 0) && which >= 0 && which <= 3, "atl_inflate_probe: bad argument");
+    ATL_REQUIRE(h_src && (h_dst || dst_n == 0) && which >= 0 && which <= 4, "atl_inflate_probe: bad argument");
     const auto t0 = std::chrono::steady_clock::now();
     int rc = ATL_OK;
     const uint8_t *src = static_cast<const uint8_t *>(h_src);
@@ -1987,6 +1987,15 @@ int atl_inflate_probe(const void *h_src, size_t src_n, void *h_dst, size_t dst_n
             rc = ATL_E_INVALID;
         }
         done = true;
+    } else if (which == 4) {  // ... and its segment scheme (*ns = the number of segments of the stream's chain instead of a time)
+        int n_seg = 0;
+        const int st = h5::device_inflate_split_emulated(src, src_n, dst, dst_n, &n_seg);
+        if (st) {
+            set_error("atl_inflate_probe: the segment decoder's host emulation returned status %d", st);
+            rc = ATL_E_INVALID;
+        }
+        if (ns) *ns = n_seg;
+        return rc;
     } else if (which != 1) {
         done = h5::fast_inflate_zlib(src, src_n, dst, dst_n) == 0;
         if (!done && which == 0) {

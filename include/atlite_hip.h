@@ -664,7 +664,10 @@ int atl_wind_interp_host(const double *h_V, const double *h_F, int n_knots, cons
                          double *h_out);
 /* zlib-wrapped DEFLATE stream -> exactly dst_n bytes on the host.  which = 0: the library's fast
  * decoder alone (ATL_E_UNSUPPORTED if it declines the stream), 1: zlib alone, 2: the product
- * combination (fast, zlib on any doubt).  *ns = wall time of the decode.  Host only. */
+ * combination (fast, zlib on any doubt), 3: the device decoder's serial half run on the host, 4: its
+ * segment scheme (a stream's DEFLATE blocks decoded side by side: block finder, count pass, chain,
+ * decode pass with markers, resolve) run on the host - *ns = the number of segments then.
+ * *ns = wall time of the decode otherwise.  Host only. */
 int atl_inflate_probe(const void *h_src, size_t src_n, void *h_dst, size_t dst_n, int which, int64_t *ns);
 
 /* ---- synthetic ERA5-shaped inputs (bench/test tooling) ----------
