@@ -660,6 +660,348 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ATL_INFLATE_
     })
 }
 
+// ---- SEGMENTS: a stream's DEFLATE blocks decoded side by side (the scheme: atl_inflate_dev.h) ------------------------------------
+// k_find_blocks: block headers; k_segments<true>: where a segment ends and how much it makes; k_segments<false>: its bytes, markers
+// for what it would copy from before its start; k_resolve: markers -> bytes, segment after segment, and the chunk's Adler-32.
+// The host follows the chains between the passes (read_group_device: launch_split).
+struct FindSpan {
+    uint32_t stream, first_bit, n_bits, pad;  // bit offsets [first_bit, first_bit + n_bits) of the stream's bytes
+};
+constexpr uint32_t kSpanBits = 64u * 1024u * 8u;  // compressed bytes one workgroup searches
+constexpr uint32_t kSpanSlots = 7;                // headers kept per span (zlib closes a block every 16 383 symbols: one to three per 64 KiB)
+constexpr uint32_t kSpanWords = kSpanSlots + 1;   // count | bit offsets
+constexpr uint32_t kFindQueue = 1280;
+
+__global__ __launch_bounds__(256) void k_find_blocks(const uint8_t *__restrict__ comp, const InfDesc *__restrict__ desc,
+                                                     const FindSpan *__restrict__ spans, uint32_t *__restrict__ out) {
+    using namespace dinf;
+    __shared__ uint16_t s_w4[4096];          // the weights of four precode lengths (3 bits each) added up
+    __shared__ uint32_t s_q[kFindQueue];     // offsets that passed L1
+    __shared__ uint32_t s_nq;
+    __shared__ uint8_t s_tab[256 * 132];     // header_l2's lookup table, one per lane (132: the lanes' tables in different banks)
+    const uint32_t tid = threadIdx.x;
+    const FindSpan sp = spans[blockIdx.x];
+    const InfDesc d = desc[sp.stream];
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(comp + d.src_off);
+    const uint32_t n_words = uint32_t((d.src_n + 3) / 4);
+    const uint64_t src_bits = uint64_t(d.src_n) * 8;
+    for (uint32_t i = tid; i < 4096u; i += 256u)
+        s_w4[i] = uint16_t(precode_weight(i & 7u) + precode_weight((i >> 3) & 7u) + precode_weight((i >> 6) & 7u) + precode_weight((i >> 9) & 7u));
+    if (tid == 0) s_nq = 0;
+    __syncthreads();
+    const uint32_t n_win = (sp.n_bits + 63u) / 64u;
+    for (uint32_t w0 = 0; w0 < n_win; w0 += 256u) {
+        const uint32_t wi = w0 + tid;
+        if (wi < n_win) {
+            const uint64_t B = uint64_t(sp.first_bit) + 64ull * wi;
+            const uint64_t x0 = bits64_at(w, n_words, B), x1 = bits64_at(w, n_words, B + 64), x2 = bits64_at(w, n_words, B + 128);
+            auto v = [&](int k) { return (x0 >> k) | (x1 << (64 - k)); };  // the bits k further on, for all 64 offsets at once
+            // BFINAL 0, BTYPE 10b, HLIT and HDIST not 30 / 31 (their upper four bits not all set)
+            uint64_t m = ~x0 & ~v(1) & v(2) & ~(v(4) & v(5) & v(6) & v(7)) & ~(v(9) & v(10) & v(11) & v(12));
+            const uint32_t rem = sp.n_bits - 64u * wi;
+            if (rem < 64u) m &= (uint64_t(1) << rem) - 1u;
+            while (m) {
+                const uint32_t o = uint32_t(__builtin_ctzll(m));
+                m &= m - 1;
+                const uint64_t X = o ? (x0 >> o) | (x1 << (64u - o)) : x0, Y = o ? (x1 >> o) | (x2 << (64u - o)) : x1;
+                const uint32_t hclen = uint32_t((X >> 13) & 15u) + 4u;
+                const uint64_t f = ((X >> 17) | (Y << 47)) & ((uint64_t(1) << (3u * hclen)) - 1u);
+                const uint32_t sum = uint32_t(s_w4[f & 4095u]) + s_w4[(f >> 12) & 4095u] + s_w4[(f >> 24) & 4095u] + s_w4[(f >> 36) & 4095u] +
+                                     s_w4[(f >> 48) & 4095u];
+                if (sum == 128u) {  // a complete precode
+                    const uint32_t q = atomicAdd(&s_nq, 1u);
+                    if (q < kFindQueue) s_q[q] = uint32_t(B) + o;
+                }
+            }
+        }
+        __syncthreads();
+        const bool last = w0 + 256u >= n_win;
+        for (;;) {  // L2 on full sets of lanes
+            const uint32_t nq = min(s_nq, kFindQueue);
+            if (nq == 0u || (nq < 256u && !last)) break;
+            const uint32_t take = min(nq, 256u), base = nq - take;
+            bool ok = false;
+            uint32_t bit = 0;
+            if (tid < take) {
+                bit = s_q[base + tid];
+                ok = header_l2(w, n_words, uint64_t(bit), src_bits, (WaveMem::u8p)(s_tab + tid * 132u));
+            }
+            __syncthreads();
+            if (tid == 0) s_nq = base;
+            if (ok) {
+                const uint32_t slot = atomicAdd(out + size_t(blockIdx.x) * kSpanWords, 1u);
+                if (slot < kSpanSlots) out[size_t(blockIdx.x) * kSpanWords + 1u + slot] = bit;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+struct SegTask {
+    uint32_t stream, start_bit, slack, cand0, n_cand, pad;  // cands[cand0 .. cand0 + n_cand): the stream's split points, ascending
+    uint64_t seg0;                                          // where the segment's output starts in the chunk (count pass: 0)
+};
+struct SegRes {
+    dinf::SegOut o;
+    int32_t status;
+    uint32_t pad;
+};
+struct DevSplits {
+    const uint32_t *c;
+    uint32_t n;
+    __device__ __forceinline__ bool is_split(uint64_t bit) const {
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const uint32_t v = __builtin_amdgcn_readfirstlane(c[mid]);
+            if (uint64_t(v) < bit) lo = mid + 1; else hi = mid;
+        }
+        return lo < n && uint64_t(__builtin_amdgcn_readfirstlane(c[lo])) == bit;
+    }
+};
+struct CountSink {
+    __device__ __forceinline__ void tables_ready() { DevWave::sync(); }
+    __device__ __forceinline__ void stored(uint64_t, uint32_t, uint64_t) {}
+    __device__ __forceinline__ void resolve(int, uint64_t, uint64_t) {}
+};
+// WaveSink with the second plane: a byte whose source lies before the segment's start is a marker (atl_inflate_dev.h)
+struct MarkSink {
+    WaveMem::u32p qrec, qpos;
+    WaveMem::u8p stage, stage_hi;  // [kStage + 3] each, word aligned
+    const uint8_t *src8;
+    uint8_t *dst, *mk;             // the chunk's value and mark planes
+    uint32_t seg0;
+    __device__ __forceinline__ void tables_ready() { DevWave::sync(); }
+    __device__ __forceinline__ void stored(uint64_t byte_pos, uint32_t len, uint64_t out_pos) {
+        for (uint32_t j = threadIdx.x; j < len; j += 64) {
+            dst[out_pos + j] = src8[byte_pos + j];
+            mk[out_pos + j] = 0;
+        }
+        __threadfence_block();
+    }
+    // the two planes of the byte at output position s (before the batch)
+    __device__ __forceinline__ void fetch(uint32_t s, uint32_t &lo, uint32_t &hi) const {
+        const bool before = s < seg0;
+        const uint32_t a = before ? seg0 : s;
+        lo = dst[a];
+        hi = mk[a];
+        if (before) {
+            lo = dinf::marker_lo(seg0 - s);
+            hi = dinf::marker_hi(seg0 - s);
+        }
+    }
+    __device__ __forceinline__ void resolve(int n, uint64_t bstart, uint64_t bend) {
+        const uint32_t lane = threadIdx.x;
+        const uint32_t bs = uint32_t(bstart), total = uint32_t(bend - bstart);
+        WaveMem::u8p st = stage + (bs & 3u), sh = stage_hi + (bs & 3u);
+        const bool active = int(lane) < n;
+        const uint32_t rec = active ? qrec[lane] : 0u, pos = active ? qpos[lane] : 0u;
+        const bool lit = (rec & dinf::kLitFlag) != 0;
+        const uint32_t len = rec & 0x1FFu, dist = (rec & 0x7FFFFFFFu) >> 9;
+        const uint32_t rel = pos - bs;
+        bool coop = false;
+        if (active) {
+            if (lit) {
+                st[rel] = uint8_t(rec);
+                sh[rel] = 0;
+            } else if (pos - dist + len <= bs && len <= 16) {  // (dist <= pos: the slack of a segment never exceeds its seg0)
+                const uint32_t sp0 = pos - dist;
+                for (uint32_t j0 = 0; j0 < len; j0 += 8) {
+                    uint32_t lo[8], hi[8];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j) fetch(sp0 + j0 + j, lo[j], hi[j]);
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j)
+                        if (j0 + j < len) {
+                            st[rel + j0 + j] = uint8_t(lo[j]);
+                            sh[rel + j0 + j] = uint8_t(hi[j]);
+                        }
+                }
+            } else {
+                coop = true;
+            }
+        }
+        uint64_t todo = __ballot(coop);
+        DevWave::sync();
+        while (todo) {  // in symbol order; every source byte of a match precedes the match
+            const int i = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t r = __builtin_amdgcn_readlane(rec, i), p = __builtin_amdgcn_readlane(pos, i);
+            const uint32_t L = r & 0x1FFu, D = (r & 0x7FFFFFFFu) >> 9, R = p - bs;
+            for (uint32_t j = lane; j < L; j += 64) {
+                const uint32_t k = D >= L ? j : j % D;
+                const uint32_t sp = p - D + k;
+                uint32_t lo, hi;
+                if (sp >= bs) {
+                    lo = st[sp - bs];
+                    hi = sh[sp - bs];
+                } else {
+                    fetch(sp, lo, hi);
+                }
+                st[R + j] = uint8_t(lo);
+                sh[R + j] = uint8_t(hi);
+            }
+            DevWave::sync();
+        }
+        const uint32_t head = min((4u - (bs & 3u)) & 3u, total), words = (total - head) >> 2, tail0 = head + 4u * words;
+        if (lane < head) {
+            dst[bs + lane] = st[lane];
+            mk[bs + lane] = sh[lane];
+        }
+        if (lane >= 32 && lane - 32 < total - tail0) {
+            dst[bs + tail0 + (lane - 32)] = st[tail0 + (lane - 32)];
+            mk[bs + tail0 + (lane - 32)] = sh[tail0 + (lane - 32)];
+        }
+        {
+            const __attribute__((address_space(3))) uint32_t *sw = (const __attribute__((address_space(3))) uint32_t *)(st + head);
+            const __attribute__((address_space(3))) uint32_t *sw2 = (const __attribute__((address_space(3))) uint32_t *)(sh + head);
+            uint32_t *dw = reinterpret_cast<uint32_t *>(dst + bs + head), *dw2 = reinterpret_cast<uint32_t *>(mk + bs + head);
+            for (uint32_t k = lane; k < words; k += 64) {
+                dw[k] = sw[k];
+                dw2[k] = sw2[k];
+            }
+        }
+        __threadfence_block();
+        DevWave::sync();
+    }
+};
+
+template <bool COUNT>
+__global__ __launch_bounds__(64) void k_segments(const uint8_t *__restrict__ comp, const InfDesc *__restrict__ desc,
+                                                 const SegTask *__restrict__ tasks, const uint32_t *__restrict__ cands,
+                                                 uint8_t *__restrict__ raw, uint8_t *__restrict__ mark, SegRes *__restrict__ res) {
+    using namespace dinf;
+    __shared__ uint16_t s_lit[kLitCap];
+    __shared__ uint16_t s_off[kOffCap];
+    constexpr int kTmpWords = (kStage + 4 > 640 + 352 ? kStage + 4 : 640 + 352) / 4 + 1;
+    __shared__ uint32_t s_tmp[kTmpWords];
+    __shared__ uint32_t s_hi[COUNT ? 1 : kTmpWords];  // the mark plane's staging area
+    __shared__ uint32_t s_cnt[32];
+    __shared__ uint32_t s_q[2 * kQueue + 1 + 16];
+    __shared__ uint32_t s_sym[64];
+    const SegTask t = tasks[blockIdx.x];
+    const InfDesc d = desc[t.stream];
+    Areas<WaveMem> A;
+    A.lit = (WaveMem::u16p)s_lit;
+    A.off = (WaveMem::u16p)s_off;
+    A.codes = (WaveMem::u16p)s_tmp;
+    A.cnt = (WaveMem::u32p)s_cnt;
+    A.nxt = (WaveMem::u32p)(s_cnt + 16);
+    A.lens = (WaveMem::u8p)(s_tmp + 160);
+    A.qrec = (WaveMem::u32p)s_q;
+    A.qpos = (WaveMem::u32p)(s_q + kQueue);
+    A.wbuf = (WaveMem::u32p)(s_q + 2 * kQueue + 1);
+    A.sym = (WaveMem::u32p)s_sym;
+    const DevSplits splits{cands + t.cand0, t.n_cand};
+    SegOut o{};
+    int st;
+    const WaveMem::src_t w = (WaveMem::src_t)(comp + d.src_off);
+    const uint32_t n_words = uint32_t((d.src_n + 3) / 4);
+    if constexpr (COUNT) {
+        CountSink sink;
+        st = inflate_segment<WaveMem, DevWave, DevWindow, CountSink, DevSplits>(A, w, n_words, uint64_t(d.src_n), uint64_t(t.start_bit), 0, t.slack,
+                                                                               uint64_t(d.dst_n), splits, sink, &o);
+    } else {
+        MarkSink sink;
+        sink.qrec = A.qrec;
+        sink.qpos = A.qpos;
+        sink.stage = (WaveMem::u8p)s_tmp;
+        sink.stage_hi = (WaveMem::u8p)s_hi;
+        sink.src8 = comp + d.src_off;
+        sink.dst = raw + d.dst_off;
+        sink.mk = mark + d.dst_off;
+        sink.seg0 = uint32_t(t.seg0);
+        st = inflate_segment<WaveMem, DevWave, DevWindow, MarkSink, DevSplits>(A, w, n_words, uint64_t(d.src_n), uint64_t(t.start_bit), t.seg0, t.slack,
+                                                                              uint64_t(d.dst_n), splits, sink, &o);
+    }
+    if (threadIdx.x == 0) {
+        res[blockIdx.x].o = o;
+        res[blockIdx.x].status = st;
+    }
+}
+
+struct ResDesc {
+    uint32_t stream, bound0, n_seg, adler_want;  // bounds[bound0 .. bound0 + n_seg]: where the stream's segments begin (and the chunk's end)
+};
+// one workgroup per stream: markers -> bytes, then the Adler-32 of the chunk
+__global__ __launch_bounds__(1024) void k_resolve(const InfDesc *__restrict__ desc, const ResDesc *__restrict__ rds, const uint32_t *__restrict__ bounds,
+                                                  uint8_t *__restrict__ raw, const uint8_t *__restrict__ mark, InfResult *__restrict__ res) {
+    const ResDesc rd = rds[blockIdx.x];
+    const InfDesc d = desc[rd.stream];
+    uint8_t *base = raw + d.dst_off;
+    const uint8_t *mb = mark + d.dst_off;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    __shared__ int s_bad;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    for (uint32_t c = 1; c < rd.n_seg; ++c) {
+        const uint32_t s0 = bounds[rd.bound0 + c], s1 = bounds[rd.bound0 + c + 1];
+        // whole words where no byte is a marker are skipped
+        const uint32_t a0 = min((s0 + 3u) & ~3u, s1), a1 = max(s1 & ~3u, a0);
+        auto one = [&](uint32_t i) {
+            const uint32_t m = mb[i];
+            if (m & 0x80u) {
+                const uint32_t back = dinf::marker_back(base[i], m);
+                if (back > s0) s_bad = 1; else base[i] = base[s0 - back];
+            }
+        };
+        for (uint32_t i = s0 + tid; i < a0; i += nt) one(i);
+        for (uint32_t i = a1 + tid; i < s1; i += nt) one(i);
+        for (uint32_t k = a0 / 4u + tid; k < a1 / 4u; k += nt) {
+            const uint32_t m4 = reinterpret_cast<const uint32_t *>(mb)[k];
+            if (m4 & 0x80808080u) {
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) one(4u * k + j);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    // Adler-32 (wave_adler's sums, the whole workgroup)
+    const uint64_t n = uint64_t(d.dst_n), n16 = n / 16;
+    unsigned long long s1 = 0, s2 = 0;
+    for (uint64_t i = tid; i < n16; i += nt) {
+        const uint4 v = reinterpret_cast<const uint4 *>(base)[i];
+        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+        uint32_t sum = 0, wsum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t b = (wds[q] >> (8 * k)) & 0xFFu;
+                sum += b;
+                wsum += uint32_t(4 * q + k) * b;
+            }
+        s1 += sum;
+        s2 += (n - i * 16) * sum - wsum;
+    }
+    for (uint64_t i = n16 * 16 + tid; i < n; i += nt) {
+        s1 += base[i];
+        s2 += (n - i) * base[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    __shared__ unsigned long long r1[16], r2[16];
+    if ((tid & 63u) == 0) {
+        r1[tid >> 6] = s1;
+        r2[tid >> 6] = s2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long t1 = 0, t2 = 0;
+        for (uint32_t k = 0; k < nt / 64u; ++k) {
+            t1 += r1[k];
+            t2 += r2[k];
+        }
+        const uint32_t a = uint32_t((1 + t1) % 65521ull), b = uint32_t((n % 65521ull + t2 % 65521ull) % 65521ull);
+        const uint32_t got = (b << 16) | a;
+        res[rd.stream].status = s_bad ? int32_t(dinf::kBadDistance) : got == rd.adler_want ? int32_t(dinf::kOk) : int32_t(dinf::kAdler);
+        res[rd.stream].adler_want = rd.adler_want;
+    }
+}
+
 // ---- per-context staging: kSlots slots, each {pinned host, device raw, descriptor buffers, event, stream} -------------
 // a read whose chunks were inflated on the device and whose verdicts (InfResult) have not been looked at yet
 struct Part {  // one variable of a read
@@ -722,7 +1064,7 @@ struct IngestState {
     atl_ctx *ctx = nullptr;
     int64_t n_device_chunks = 0, n_host_chunks = 0, n_redone = 0;
     // device path, accumulated: host gather of the compressed bytes (wall clock) | H2D (first to last DMA) | k_inflate (incl. its
-    // waits for the DMAs) | - (the Adler-32 is part of k_inflate since round 6) | k_unpack of never-written chunks (events)
+    // waits for the DMAs) | segments decoded side by side (a count; launch_split) | k_unpack of never-written chunks (events)
     double ms[5] = {0, 0, 0, 0, 0};
     int64_t comp_bytes = 0, raw_bytes = 0;
     // the verdict of a device-inflate read that failed while nobody was listening (atl_nc_close, a slot's reuse by an
@@ -1235,6 +1577,17 @@ struct Batch {
     size_t off = 0, bytes = 0;     // inside the job's compressed area
 };
 
+// Streams whose blocks are worth decoding side by side: fewer streams than the device has wave slots for whole-stream decoding
+// to fill it, and long ones.  $ATLITE_HIP_INFLATE_SPLIT = 1 / 0 forces / forbids it.
+bool split_wanted(const std::vector<InfDesc> &inf) {
+    const char *e = getenv("ATLITE_HIP_INFLATE_SPLIT");
+    if (e && *e) return strcmp(e, "0") != 0;
+    if (inf.empty() || inf.size() >= 4096) return false;
+    size_t bytes = 0;
+    for (const InfDesc &q : inf) bytes += size_t(q.src_n);
+    return bytes / inf.size() >= (size_t(1) << 20);
+}
+
 bool fed_mode() {
     const char *e = getenv("ATLITE_HIP_INGEST_FED");
     return !(e && strcmp(e, "0") == 0);
@@ -1311,7 +1664,9 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
         parts.push_back(pt);
     }
     if (parts.empty() || inf.empty()) return ATL_OK;
-    const bool fed = fed_mode();
+    // few, long streams (atlite's own cutouts: (time = 100, y, x) chunks): their blocks are decoded side by side (launch_split below)
+    const bool split = split_wanted(inf);
+    const bool fed = fed_mode() && !split;
     // batches of consecutive streams
     size_t batch_bytes = size_t(128) << 20;
     if (const char *e = getenv("ATLITE_HIP_INGEST_BATCH")) batch_bytes = size_t(std::max(1, atoi(e))) << 20;
@@ -1337,8 +1692,22 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
                  m_part = align_up(m_mis + nm * sizeof(UnpackDesc), 256), m_flag = align_up(m_part + np * sizeof(FedPart), 256),
                  m_res = align_up(m_flag + nb * kFlagPitch * sizeof(uint32_t), 256), m_end = m_res + n * sizeof(InfResult);
     const size_t off_meta = align_up(comp_off, 256);
+    // split jobs: spans of the finder | its slots | the streams' split points | segment tasks | their results | segment bounds | ResDesc[]
+    // (behind the rest, same offsets on both sides), and the mark plane behind the inflated chunks
+    size_t n_spans = 0;
+    if (split)
+        for (const InfDesc &q : inf) {
+            const uint64_t bits = uint64_t(q.src_n) * 8;
+            if (bits > 17 + 128) n_spans += size_t((bits - 17 + kSpanBits - 1) / kSpanBits);
+        }
+    const size_t t_max = split ? n + n_spans * kSpanSlots : 0;
+    const size_t s_span = align_up(m_end, 256), s_out = align_up(s_span + n_spans * sizeof(FindSpan), 256),
+                 s_cand = align_up(s_out + n_spans * kSpanWords * sizeof(uint32_t), 256), s_task = align_up(s_cand + t_max * sizeof(uint32_t), 256),
+                 s_res = align_up(s_task + t_max * sizeof(SegTask), 256), s_bound = align_up(s_res + t_max * sizeof(SegRes), 256),
+                 s_rd = align_up(s_bound + (t_max + n) * sizeof(uint32_t), 256), s_end = split ? s_rd + n * sizeof(ResDesc) : m_end;
+    const size_t mark_off = align_up(raw_off + 256, 256);
     Slot *sl = nullptr;
-    int rc = slot_acquire(ctx, m_end + 256, off_meta + m_end + 256, raw_off + 256, true, &sl);
+    int rc = slot_acquire(ctx, s_end + 256, off_meta + s_end + 256, split ? 2 * mark_off : raw_off + 256, true, &sl);
     if (rc) return rc;
     rc = ring_reserve(ctx, ring_bytes);  // (every allocation of the job happens before its kernel is launched)
     if (rc) return rc;
@@ -1429,6 +1798,157 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     job.off_res = m_res;
     job.off_flag = m_flag;
     job.aborted = false;
+    // The split order: every byte is on the device; find the block headers, count, follow the chains (host), decode, resolve,
+    // unpack.  Synchronous: the host reads the device's lists between the passes.  A stream whose chain does not close keeps
+    // its "not run" verdict and goes to the host decoders with the other declined streams (finish_slot).
+    auto launch_split = [&]() -> int {
+        using dinf::SegOut;
+        hipStream_t q = sl->st;
+        const std::vector<InfDesc> &jn = job.inf;
+        uint8_t *d_mark = sl->d_raw + mark_off;
+        const bool dbg = getenv("ATLITE_HIP_INGEST_DEBUG") != nullptr;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+        const auto t_begin = now();
+        FindSpan *h_span = reinterpret_cast<FindSpan *>(sl->h + s_span);
+        std::vector<size_t> span0(n + 1, 0);  // the streams' spans
+        {
+            size_t k = 0;
+            for (size_t i = 0; i < n; ++i) {
+                span0[i] = k;
+                const uint64_t bits = uint64_t(jn[i].src_n) * 8;
+                if (bits > 17 + 128)
+                    for (uint64_t b = 17; b < bits; b += kSpanBits) h_span[k++] = FindSpan{uint32_t(i), uint32_t(b), uint32_t(std::min<uint64_t>(kSpanBits, bits - b)), 0u};
+            }
+            span0[n] = k;
+            ATL_REQUIRE(k == n_spans, "atl_nc_read_slabs: span count");
+        }
+        uint32_t *h_out = reinterpret_cast<uint32_t *>(sl->h + s_out);
+        if (n_spans) {
+            ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_span, h_span, n_spans * sizeof(FindSpan), hipMemcpyHostToDevice, q));
+            ATL_HIP_TRY(hipMemsetAsync(d_meta + s_out, 0, n_spans * kSpanWords * sizeof(uint32_t), q));
+            hipLaunchKernelGGL(k_find_blocks, dim3(unsigned(n_spans)), dim3(256), 0, q, sl->d, d_inf, reinterpret_cast<const FindSpan *>(d_meta + s_span),
+                               reinterpret_cast<uint32_t *>(d_meta + s_out));
+            ATL_HIP_TRY(hipGetLastError());
+            ATL_HIP_TRY(hipMemcpyAsync(h_out, d_meta + s_out, n_spans * kSpanWords * sizeof(uint32_t), hipMemcpyDeviceToHost, q));
+        }
+        ATL_HIP_TRY(hipStreamSynchronize(q));
+        const double ms_find = ms_since(t_begin);
+        const auto t_count = now();
+        // the streams' split points (ascending) and one task per start
+        uint32_t *h_cand = reinterpret_cast<uint32_t *>(sl->h + s_cand);
+        SegTask *h_task = reinterpret_cast<SegTask *>(sl->h + s_task);
+        std::vector<size_t> task0(n + 1, 0), cand0(n + 1, 0);
+        size_t nc = 0, ntask = 0;
+        for (size_t i = 0; i < n; ++i) {
+            cand0[i] = nc;
+            task0[i] = ntask;
+            for (size_t k = span0[i]; k < span0[i + 1]; ++k) {
+                const uint32_t cnt = std::min(h_out[k * kSpanWords], kSpanSlots);
+                uint32_t *c = h_out + k * kSpanWords + 1;
+                std::sort(c, c + cnt);
+                for (uint32_t j = 0; j < cnt; ++j) h_cand[nc++] = c[j];
+            }
+            const uint32_t ncs = uint32_t(nc - cand0[i]);
+            h_task[ntask++] = SegTask{uint32_t(i), 16u, 0u, uint32_t(cand0[i]), ncs, 0u, 0u};
+            for (uint32_t j = 0; j < ncs; ++j) h_task[ntask++] = SegTask{uint32_t(i), h_cand[cand0[i] + j], dinf::kSegSlack, uint32_t(cand0[i]), ncs, 0u, 0u};
+        }
+        cand0[n] = nc;
+        task0[n] = ntask;
+        SegRes *h_res = reinterpret_cast<SegRes *>(sl->h + s_res);
+        const SegTask *d_task = reinterpret_cast<const SegTask *>(d_meta + s_task);
+        const uint32_t *d_cand = reinterpret_cast<const uint32_t *>(d_meta + s_cand);
+        SegRes *d_sres = reinterpret_cast<SegRes *>(d_meta + s_res);
+        if (nc) ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_cand, h_cand, nc * sizeof(uint32_t), hipMemcpyHostToDevice, q));
+        ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_task, h_task, ntask * sizeof(SegTask), hipMemcpyHostToDevice, q));
+        hipLaunchKernelGGL((k_segments<true>), dim3(unsigned(ntask)), dim3(64), 0, q, sl->d, d_inf, d_task, d_cand, sl->d_raw, d_mark, d_sres);
+        ATL_HIP_TRY(hipGetLastError());
+        ATL_HIP_TRY(hipMemcpyAsync(h_res, d_sres, ntask * sizeof(SegRes), hipMemcpyDeviceToHost, q));
+        ATL_HIP_TRY(hipStreamSynchronize(q));
+        const double ms_count = ms_since(t_count);
+        const auto t_chain = now();
+        // the chains: from the stream's first block, every segment ends where the next one starts; output positions on the way
+        std::vector<SegTask> run;
+        std::vector<uint32_t> bounds;
+        std::vector<ResDesc> rds;
+        size_t n_seg_total = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const size_t r0 = run.size(), b0 = bounds.size();
+            uint64_t at = 0;
+            bool ok = true;
+            uint32_t want = 0;
+            for (size_t t = task0[i];;) {
+                const SegRes &r = h_res[t];
+                if (r.status != dinf::kOk || r.o.out_end == 0 || at + r.o.out_end > uint64_t(jn[i].dst_n) || run.size() - r0 > size_t(task0[i + 1] - task0[i])) {
+                    ok = false;
+                    break;
+                }
+                SegTask tk = h_task[t];
+                tk.seg0 = at;
+                tk.slack = uint32_t(std::min<uint64_t>(dinf::kSegSlack, at));
+                run.push_back(tk);
+                bounds.push_back(uint32_t(at));
+                at += r.o.out_end;
+                if (r.o.is_final) {
+                    want = r.o.adler;
+                    break;
+                }
+                const uint32_t *c = h_cand + cand0[i], *ce = h_cand + cand0[i + 1];
+                const uint32_t *it = std::lower_bound(c, ce, uint32_t(r.o.end_bit));
+                if (it == ce || *it != uint32_t(r.o.end_bit)) {
+                    ok = false;
+                    break;
+                }
+                t = task0[i] + 1 + size_t(it - c);
+            }
+            if (!ok || at != uint64_t(jn[i].dst_n)) {  // the host decoders take the stream
+                run.resize(r0);
+                bounds.resize(b0);
+                continue;
+            }
+            bounds.push_back(uint32_t(at));
+            rds.push_back(ResDesc{uint32_t(i), uint32_t(b0), uint32_t(run.size() - r0), want});
+            n_seg_total += run.size() - r0;
+        }
+        state->ms[3] += double(n_seg_total);  // (a count: atl_nc_ingest_times)
+        const double ms_chain = ms_since(t_chain);
+        if (dbg)
+            fprintf(stderr, "[atlite-hip ingest] split: %zu streams, %zu spans, %zu candidate headers, %zu of %zu streams chained into %zu segments; "
+                    "find %.1f ms, count pass %.1f ms, chains (host) %.1f ms\n", n, n_spans, nc, rds.size(), n, n_seg_total, ms_find, ms_count, ms_chain);
+        if (!run.empty()) {
+            ATL_REQUIRE(run.size() <= t_max && bounds.size() <= t_max + n, "atl_nc_read_slabs: segment lists");
+            memcpy(sl->h + s_task, run.data(), run.size() * sizeof(SegTask));
+            memcpy(sl->h + s_bound, bounds.data(), bounds.size() * sizeof(uint32_t));
+            memcpy(sl->h + s_rd, rds.data(), rds.size() * sizeof(ResDesc));
+            ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_task, sl->h + s_task, run.size() * sizeof(SegTask), hipMemcpyHostToDevice, q));
+            ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_bound, sl->h + s_bound, bounds.size() * sizeof(uint32_t), hipMemcpyHostToDevice, q));
+            ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_rd, sl->h + s_rd, rds.size() * sizeof(ResDesc), hipMemcpyHostToDevice, q));
+            hipLaunchKernelGGL((k_segments<false>), dim3(unsigned(run.size())), dim3(64), 0, q, sl->d, d_inf, d_task, d_cand, sl->d_raw, d_mark, d_sres);
+            ATL_HIP_TRY(hipGetLastError());
+            const auto t_dec = now();
+            if (dbg) {  // the decode pass must end where the count pass did
+                ATL_HIP_TRY(hipMemcpyAsync(h_res, d_sres, run.size() * sizeof(SegRes), hipMemcpyDeviceToHost, q));
+                ATL_HIP_TRY(hipStreamSynchronize(q));
+                size_t bad = 0;
+                for (size_t t = 0; t < run.size(); ++t) bad += h_res[t].status != dinf::kOk;
+                fprintf(stderr, "[atlite-hip ingest] split: decode pass %.1f ms, %zu of %zu segments with a status\n", ms_since(t_dec), bad, run.size());
+            }
+            const auto t_res = now();
+            hipLaunchKernelGGL(k_resolve, dim3(unsigned(rds.size())), dim3(1024), 0, q, d_inf, reinterpret_cast<const ResDesc *>(d_meta + s_rd),
+                               reinterpret_cast<const uint32_t *>(d_meta + s_bound), sl->d_raw, d_mark, d_res);
+            ATL_HIP_TRY(hipGetLastError());
+            if (dbg) {
+                ATL_HIP_TRY(hipStreamSynchronize(q));
+                fprintf(stderr, "[atlite-hip ingest] split: resolve + Adler-32 %.1f ms\n", ms_since(t_res));
+            }
+        }
+        ATL_HIP_TRY(hipEventRecord(sl->ev_t[2], q));
+        for (const Part &pt : job.parts)  // (a stream the host decoders take is unpacked again behind them)
+            if (pt.n_desc) launch_unpack(q, sl->d_raw, d_unp + pt.desc0, pt.n_desc, pt.p, pt.max_elems, pt.d_out);
+        ATL_HIP_TRY(hipGetLastError());
+        ATL_HIP_TRY(hipEventRecord(sl->ev_t[3], q));
+        return ATL_OK;
+    };
     if (fed) {
         rc = launch();
         if (rc) return rc;
@@ -1502,7 +2022,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     (void)hipEventRecord(sl->ev_c[1], sl->st_c);
     if (!rc && !fed) {  // the unfed order (A/B, $ATLITE_HIP_INGEST_FED=0): every byte first, then the launch
         ATL_HIP_TRY(hipStreamWaitEvent(sl->st, sl->ev_c[1], 0));
-        rc = launch();
+        rc = split ? launch_split() : launch();
     }
     if (fed || !rc) {
         // the verdicts come back behind the kernel AND the last DMA (an aborted job's kernel may end before its flags' DMAs)

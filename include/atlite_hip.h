@@ -560,8 +560,10 @@ int atl_nc_read_slab_ld(atl_ctx *ctx, int64_t ld_cells, atl_nc *f, const char *n
                         int n_threads);
 int atl_nc_ingest_stats(atl_ctx *ctx, int64_t *device_chunks, int64_t *host_chunks, int64_t *redone);
 /* device-inflate reads so far, accumulated: ms5 = {preads of the compressed bytes (wall clock), DMAs first to last, k_inflate
- * including its waits for the DMAs and its fused Adler-32 + unpack, 0 (round 5's separate checksum pass), k_unpack of
- * never-written chunks} - HIP events on the slot's streams; the first three overlap inside ONE fed launch (round 6), so their
+ * including its waits for the DMAs and its fused Adler-32 + unpack, the NUMBER of stream segments decoded side by side (a count
+ * in round 5's checksum-pass slot: reads of few, long streams - atlite's own (time = 100, y, x) chunks - are decoded block by
+ * block, $ATLITE_HIP_INFLATE_SPLIT; 0 while streams are decoded whole), k_unpack of never-written chunks} - HIP events on the
+ * slot's streams; the first three overlap inside ONE fed launch (round 6), so their
  * sum exceeds the wall time - and the bytes in / out of k_inflate */
 int atl_nc_ingest_times(atl_ctx *ctx, double *ms5, int64_t *compressed_bytes, int64_t *inflated_bytes);
 /* host array of a narrower dtype (what xarray hands over for a float32 cutout) -> fp64 on the

@@ -313,7 +313,8 @@ if __name__ == "__main__":
         unl = tuple(int(c) for c in a[10]) if len(a) > 10 else ()
         write_case(a[0], int(a[1]), int(a[2]), int(a[3]), (int(a[4]), int(a[5]), int(a[6])), lv, a[8] == "1", int(a[9]), unlimited=unl)
         sys.exit(0)
-    if len(sys.argv) > 2 and sys.argv[1] == "--payloads":  # --payloads path seed
-        write_payloads(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 0)
+    if len(sys.argv) > 2 and sys.argv[1] == "--payloads":  # --payloads path seed [T Y X ct]
+        a = sys.argv[2:]
+        write_payloads(a[0], int(a[1]) if len(a) > 1 else 0, *[int(v) for v in a[2:6]])
         sys.exit(0)
     main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "nc"))

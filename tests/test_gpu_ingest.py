@@ -268,6 +268,71 @@ def test_inflate_payload_statistics(ctx, tmp_path, seed, inflate_mode):
         assert (d1 - d0, h1 - h0) == (0, n_streams)
 
 
+def ingest_segments(ctx):
+    import ctypes as C
+
+    ms = (C.c_double * 5)()
+    a, b = C.c_int64(), C.c_int64()
+    check(ctx.lib.atl_nc_ingest_times(ctx.handle, ms, C.byref(a), C.byref(b)))
+    return int(ms[3])  # the count of stream segments decoded side by side
+
+
+def test_long_streams_are_decoded_block_by_block(ctx, tmp_path, monkeypatch, inflate_mode):
+    """Few, long chunk streams - atlite's own cutouts have (time = 100, y, x) chunks, 16 MB each for a 200 x 200 grid - are
+    split at their DEFLATE block headers and the blocks decoded side by side (block finder, count pass, chain, decode pass with
+    markers for what a block copies from its predecessors, resolve): 1 MiB chunks of seven payload kinds x zlib levels, forced
+    ($ATLITE_HIP_INFLATE_SPLIT=1) and by the default policy; the bytes are what was written, no stream goes back to the host, and
+    the compressible kinds really are decoded in several segments each."""
+    import subprocess
+
+    if inflate_mode != "device":
+        pytest.skip("the device decoder's scheme")
+    conda = "/opt/conda/bin/python3.9"
+    make = os.path.join(os.path.dirname(__file__), "golden", "make_nc_fixtures.py")
+    try:
+        ok = subprocess.run([conda, "-c", "import h5py"], capture_output=True, timeout=120).returncode == 0
+    except Exception:
+        ok = False
+    if not ok:
+        pytest.skip("needs the conda interpreter with h5py")
+    path = tmp_path / "long.nc"
+    T, Y, X, ct = 64, 256, 256, 16
+    r = subprocess.run([conda, make, "--payloads", str(path), "7", str(T), str(Y), str(X), str(ct)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    f = io.NcFile(path)
+    exp = np.load(tmp_path / "long.npz")
+    for forced in ("1", None):
+        if forced:
+            monkeypatch.setenv("ATLITE_HIP_INFLATE_SPLIT", forced)
+        else:
+            monkeypatch.delenv("ATLITE_HIP_INFLATE_SPLIT")
+        for v in exp.files:
+            d0, h0, r0 = ingest_stats(ctx)
+            s0 = ingest_segments(ctx)
+            got = slab(ctx, f, v, 0, T)
+            assert np.array_equal(got, exp[v]), v
+            assert np.array_equal(slab(ctx, f, v, 10, 30), exp[v][10:40]), v
+            d1, h1, r1 = ingest_stats(ctx)
+            n_streams = T // ct + 3
+            assert (d1 - d0, h1 - h0, r1 - r0) == (n_streams, 0, 0), v
+            segs = ingest_segments(ctx) - s0
+            if forced:
+                assert segs >= n_streams, (v, segs)
+                if v.split("_")[0] in ("few", "words", "planes", "periodic"):
+                    assert segs >= 2 * n_streams, (v, segs)  # a 1 MiB chunk of these is several blocks
+    # the emulation on the host (atl_inflate_probe(which = 4)) agrees about a stream written the same way
+    import zlib
+
+    raw = exp["planes_1"][:ct].astype(np.uint8).tobytes()
+    comp = np.frombuffer(zlib.compress(raw, 1), np.uint8)
+    out = np.zeros(len(raw), np.uint8)
+    import ctypes as C
+
+    nseg = C.c_int64()
+    check(ctx.lib.atl_inflate_probe(comp.ctypes.data, comp.size, out.ctypes.data, out.size, 4, C.byref(nseg)))
+    assert out.tobytes() == raw and nseg.value >= 3
+
+
 def test_device_inflate_is_the_path_that_ran(ctx, inflate_mode):
     """The counters of atl_nc_ingest_stats: in device mode the deflated chunks of a read are inflated by k_inflate (and none
     had to be decoded again on the host), in host mode none is."""
