@@ -323,7 +323,7 @@ def test_long_streams_are_decoded_block_by_block(ctx, tmp_path, monkeypatch, inf
     # the emulation on the host (atl_inflate_probe(which = 4)) agrees about a stream written the same way
     import zlib
 
-    raw = exp["planes_1"][:ct].astype(np.uint8).tobytes()
+    raw = exp["words_1"][:ct].astype(np.uint8).tobytes()
     comp = np.frombuffer(zlib.compress(raw, 1), np.uint8)
     out = np.zeros(len(raw), np.uint8)
     import ctypes as C

@@ -274,6 +274,64 @@ def test_fast_inflate_matches_zlib():
         _inflate(b, len(d), 0)  # the fast decoder alone: any verdict, no crash
 
 
+def test_segment_scheme_matches_zlib():
+    """Long streams are decoded block by block on the device (atl_inflate_dev.h, "SEGMENTS"): its host emulation
+    (atl_inflate_probe(which = 4): the same finder tests, count / decode passes, markers and resolve as the kernels) against
+    zlib on streams of many blocks - every payload kind x level, with small windows and memLevels (other block sizes), with
+    stored and fixed blocks in between - and on corrupted ones (any error, never a wrong accept, no crash)."""
+    import ctypes as C
+    import zlib
+
+    lib = _lib.load()
+
+    def run(comp, n):
+        dst = np.zeros(max(n, 1), np.uint8)
+        src = np.frombuffer(comp, np.uint8)
+        nseg = C.c_int64()
+        rc = lib.atl_inflate_probe(src.ctypes.data, len(comp), dst.ctypes.data, n, 4, C.byref(nseg))
+        return rc, dst[:n].tobytes(), int(nseg.value)
+
+    rng = np.random.default_rng(5)
+    n = 600000
+    vocab = [rng.integers(97, 123, int(k), dtype=np.uint8) for k in rng.integers(2, 14, 500)]
+    f = (np.cumsum(rng.standard_normal(n // 4)) * 50).astype("<f4")
+    data = {
+        "planes": np.ascontiguousarray(f.view(np.uint8).reshape(-1, 4).T).tobytes(),
+        "words": np.concatenate([vocab[i] for i in rng.zipf(1.3, size=n // 5) % len(vocab)])[:n].tobytes(),
+        "few": rng.integers(0, 4, n, dtype=np.uint8).tobytes(),
+        "runs": np.repeat(rng.integers(0, 256, n // 10, dtype=np.uint8), rng.geometric(0.1, n // 10))[:n].tobytes(),
+        "mixed": rng.integers(0, 256, 150000, dtype=np.uint8).tobytes() + bytes(100000) + rng.integers(0, 3, 200000, dtype=np.uint8).tobytes() + b"ab" * 9,
+    }
+    split = 0
+    for name, d in data.items():
+        for level, wbits, mem in ((1, 15, 8), (6, 15, 8), (9, 15, 9), (6, 9, 1), (4, 12, 4)):
+            co = zlib.compressobj(level, zlib.DEFLATED, wbits, mem)
+            comp = co.compress(d[: len(d) // 2]) + co.flush(zlib.Z_FULL_FLUSH) + co.compress(d[len(d) // 2:]) + co.flush()
+            rc, out, nseg = run(comp, len(d))
+            assert rc == 0 and out == d, (name, level, wbits, mem)
+            split += nseg > 2
+    assert split >= 15  # most of them really are decoded in several segments
+    comp = zlib.compress(data["words"], 6)
+    d = data["words"]
+    accepted = 0
+    for k in range(60):
+        b = bytearray(comp)
+        for pos in rng.integers(0, len(b), size=int(rng.integers(1, 4))):
+            b[int(pos)] ^= 1 << int(rng.integers(8))
+        if k % 6 == 0:
+            b = b[: int(rng.integers(2, len(b)))]
+        b = bytes(b)
+        try:
+            z = zlib.decompress(b)
+            ok = len(z) == len(d)
+        except Exception:
+            ok = False
+        rc, out, _ = run(b, len(d))
+        assert rc != 0 or (ok and out == z), k
+        accepted += rc == 0
+    assert accepted <= 3
+
+
 def test_isel_time_is_lazy():
     """A rank's time shard of a file-backed cutout: coordinates sliced, variables still on disk."""
     ds = io.open_cutout(f"{NC}/cutout_small_f32.nc")

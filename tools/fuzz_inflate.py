@@ -30,7 +30,7 @@ def inflate(comp, n, which):
 
 def payload(rng):
     kind = int(rng.integers(7))
-    n = int(rng.integers(0, 60000)) if rng.random() < 0.9 else int(rng.integers(60000, 400000))
+    n = int(rng.integers(0, 60000)) if rng.random() < 0.85 else int(rng.integers(60000, 1500000))
     if kind == 0:
         return rng.integers(0, 256, n, dtype=np.uint8).tobytes()
     if kind == 1:
@@ -67,6 +67,8 @@ def main():
         assert rc == 0 and out == d, ("valid stream, product path", k)
         rc, out = inflate(comp, len(d), 3)  # the device decoder's serial half (atl_inflate_dev.h) on the host
         assert rc == 0 and out == d, ("valid stream, device decoder emulation", k, len(d), level, strat, rc)
+        rc, out = inflate(comp, len(d), 4)  # ... and its segment scheme (block finder, count, chain, decode with markers, resolve)
+        assert rc == 0 and out == d, ("valid stream, segment scheme emulation", k, len(d), level, strat, rc)
         valid += 1
         for _ in range(3):
             b = bytearray(comp)
@@ -97,6 +99,8 @@ def main():
             inflate(b, want, 0)  # the fast decoder alone: any verdict
             rc3, out3 = inflate(b, want, 3)  # the device decoder's emulation: may refuse, must never accept what zlib rejects
             assert rc3 != 0 or (ok and out3 == z), ("device decoder accepted a stream zlib rejects", k, how)
+            rc4, out4 = inflate(b, want, 4)
+            assert rc4 != 0 or (ok and out4 == z), ("segment scheme accepted a stream zlib rejects", k, how)
             corrupt += 1
     print(f"{valid} valid streams decoded identically, {corrupt} corrupted streams ({agree_ok} still valid) with zlib's verdict, no crash")
 
