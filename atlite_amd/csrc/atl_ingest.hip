@@ -738,7 +738,8 @@ __global__ __launch_bounds__(256) void k_find_blocks(const uint8_t *__restrict__
 }
 
 struct SegTask {
-    uint32_t stream, start_bit, slack, cand0, n_cand, pad;  // cands[cand0 .. cand0 + n_cand): the stream's split points, ascending
+    uint32_t stream, start_bit, slack, cand0, n_cand;  // cands[cand0 .. cand0 + n_cand): the stream's split points, ascending
+    uint32_t res_ix;                                    // where its result goes (tasks are launched longest first)
     uint64_t seg0;                                          // where the segment's output starts in the chunk (count pass: 0)
 };
 struct SegRes {
@@ -915,8 +916,8 @@ __global__ __launch_bounds__(64) void k_segments(const uint8_t *__restrict__ com
                                                                               uint64_t(d.dst_n), splits, sink, &o);
     }
     if (threadIdx.x == 0) {
-        res[blockIdx.x].o = o;
-        res[blockIdx.x].status = st;
+        res[t.res_ix].o = o;
+        res[t.res_ix].status = st;
     }
 }
 
@@ -936,7 +937,8 @@ __global__ __launch_bounds__(1024) void k_resolve(const InfDesc *__restrict__ de
     __syncthreads();
     for (uint32_t c = 1; c < rd.n_seg; ++c) {
         const uint32_t s0 = bounds[rd.bound0 + c], s1 = bounds[rd.bound0 + c + 1];
-        // whole words where no byte is a marker are skipped
+        // whole words where no byte is a marker are skipped; the four source bytes of a word with markers are loaded together
+        // (they lie before s0: final), the word is stored once
         const uint32_t a0 = min((s0 + 3u) & ~3u, s1), a1 = max(s1 & ~3u, a0);
         auto one = [&](uint32_t i) {
             const uint32_t m = mb[i];
@@ -947,12 +949,36 @@ __global__ __launch_bounds__(1024) void k_resolve(const InfDesc *__restrict__ de
         };
         for (uint32_t i = s0 + tid; i < a0; i += nt) one(i);
         for (uint32_t i = a1 + tid; i < s1; i += nt) one(i);
-        for (uint32_t k = a0 / 4u + tid; k < a1 / 4u; k += nt) {
-            const uint32_t m4 = reinterpret_cast<const uint32_t *>(mb)[k];
-            if (m4 & 0x80808080u) {
+        const uint32_t *mw = reinterpret_cast<const uint32_t *>(mb);
+        uint32_t *bw = reinterpret_cast<uint32_t *>(base);
+        auto word = [&](uint32_t k, uint32_t m4) {
+            const uint32_t v4 = bw[k];
+            uint32_t src[4], b[4];
 #pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) one(4u * k + j);
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t m = (m4 >> (8u * j)) & 0xFFu, back = dinf::marker_back((v4 >> (8u * j)) & 0xFFu, m);
+                const bool is = (m & 0x80u) != 0u;
+                if (is && back > s0) s_bad = 1;
+                src[j] = (is && back <= s0) ? s0 - back : 0u;
             }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) b[j] = base[src[j]];
+            uint32_t nv = v4;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j)
+                if ((m4 >> (8u * j)) & 0x80u) nv = (nv & ~(0xFFu << (8u * j))) | (b[j] << (8u * j));
+            bw[k] = nv;
+        };
+        uint32_t k = a0 / 4u + tid;
+        const uint32_t k_end = a1 / 4u;
+        for (; k + nt < k_end; k += 2u * nt) {  // two words per step: eight source loads in flight
+            const uint32_t ma = mw[k], mb2 = mw[k + nt];
+            if (ma & 0x80808080u) word(k, ma);
+            if (mb2 & 0x80808080u) word(k + nt, mb2);
+        }
+        if (k < k_end) {
+            const uint32_t ma = mw[k];
+            if (ma & 0x80808080u) word(k, ma);
         }
         __threadfence_block();
         __syncthreads();
@@ -1440,14 +1466,25 @@ int lookup(atl_nc *f, const char *name, const Dataset **out, const char *who) {
 }
 
 // ---- device inflate: submit, and the settling of its verdicts ---------------------------------------------------------
-bool device_inflate_wanted(size_t n_streams) {
+// $ATLITE_HIP_INFLATE_SPLIT: 1 / 0 forces / forbids decoding a stream's blocks side by side (launch_split); unset: for few, long streams
+int split_env() {
+    const char *e = getenv("ATLITE_HIP_INFLATE_SPLIT");
+    return (e && *e) ? (strcmp(e, "0") != 0 ? 1 : 0) : -1;
+}
+constexpr size_t kSplitMaxStreams = 4096;             // from there on whole-stream waves fill the device
+constexpr double kSplitMinBytes = double(2u << 20);   // mean inflated bytes per stream from which a stream is "long"
+
+bool device_inflate_wanted(size_t n_streams, double raw_bytes) {
     const char *e = getenv("ATLITE_HIP_INFLATE");
     if (e && strcmp(e, "device") == 0) return n_streams > 0;
     if (e && *e) return false;  // "host", "zlib"
     size_t min_chunks = 1024;   // below that the host threads finish first: a stream is one wavefront at ~10 MB/s, so a read costs
                                 // ~0.1 s however few streams it has; 16 host threads inflate ~1000 chunks of 1 MB in that time
     if (const char *m = getenv("ATLITE_HIP_INFLATE_MIN_CHUNKS")) min_chunks = size_t(std::max(1, atoi(m)));
-    return n_streams >= min_chunks;
+    if (n_streams >= min_chunks) return true;
+    // few but LONG streams (atlite's own cutouts: (time = 100, y, x) chunks): their blocks are decoded side by side, 3 - 4 x the
+    // host threads' rate from a few hundred MB on (the scheme's passes cost ~10 ms before the first byte)
+    return split_env() != 0 && n_streams > 0 && raw_bytes / double(n_streams) >= kSplitMinBytes && raw_bytes >= double(256u << 20);
 }
 
 void launch_unpack(hipStream_t st, const uint8_t *raw, const UnpackDesc *d_desc, size_t n_desc, const UnpackParams &p,
@@ -1578,14 +1615,14 @@ struct Batch {
 };
 
 // Streams whose blocks are worth decoding side by side: fewer streams than the device has wave slots for whole-stream decoding
-// to fill it, and long ones.  $ATLITE_HIP_INFLATE_SPLIT = 1 / 0 forces / forbids it.
+// to fill it, and long ones.
 bool split_wanted(const std::vector<InfDesc> &inf) {
-    const char *e = getenv("ATLITE_HIP_INFLATE_SPLIT");
-    if (e && *e) return strcmp(e, "0") != 0;
-    if (inf.empty() || inf.size() >= 4096) return false;
-    size_t bytes = 0;
-    for (const InfDesc &q : inf) bytes += size_t(q.src_n);
-    return bytes / inf.size() >= (size_t(1) << 20);
+    const int e = split_env();
+    if (e >= 0) return e != 0;
+    if (inf.empty() || inf.size() >= kSplitMaxStreams) return false;
+    double bytes = 0;
+    for (const InfDesc &q : inf) bytes += double(q.dst_n);
+    return bytes / double(inf.size()) >= kSplitMinBytes;
 }
 
 bool fed_mode() {
@@ -1798,150 +1835,206 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     job.off_res = m_res;
     job.off_flag = m_flag;
     job.aborted = false;
-    // The split order: every byte is on the device; find the block headers, count, follow the chains (host), decode, resolve,
-    // unpack.  Synchronous: the host reads the device's lists between the passes.  A stream whose chain does not close keeps
-    // its "not run" verdict and goes to the host decoders with the other declined streams (finish_slot).
-    auto launch_split = [&]() -> int {
-        using dinf::SegOut;
+    // split jobs: the finder's spans (64 KiB of a stream each) go up with the descriptors; a batch's spans are searched as soon as
+    // its DMA has landed, while the next batch is read and copied
+    std::vector<size_t> span0;  // the streams' spans
+    if (split) {
+        span0.assign(n + 1, 0);
+        FindSpan *h_span = reinterpret_cast<FindSpan *>(sl->h + s_span);
+        size_t k = 0;
+        for (size_t i = 0; i < n; ++i) {
+            span0[i] = k;
+            const uint64_t bits = uint64_t(job.inf[i].src_n) * 8;
+            if (bits > 17 + 128)
+                for (uint64_t b = 17; b < bits; b += kSpanBits)
+                    h_span[k++] = FindSpan{uint32_t(i), uint32_t(b), uint32_t(std::min<uint64_t>(kSpanBits, bits - b)), 0u};
+        }
+        span0[n] = k;
+        ATL_REQUIRE(k == n_spans, "atl_nc_read_slabs: span count");
+        if (n_spans) {
+            ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_span, h_span, n_spans * sizeof(FindSpan), hipMemcpyHostToDevice, sl->st));
+            ATL_HIP_TRY(hipMemsetAsync(d_meta + s_out, 0, n_spans * kSpanWords * sizeof(uint32_t), sl->st));
+        }
+    }
+    auto find_batch = [&](size_t b) -> int {  // (on the kernel stream, behind batch b's DMA)
+        const size_t k0 = span0[batches[b].first], k1 = span0[batches[b].first + batches[b].count];
+        if (k1 == k0) return ATL_OK;
+        ATL_HIP_TRY(hipStreamWaitEvent(sl->st, sl->ev_batch[b], 0));
+        hipLaunchKernelGGL(k_find_blocks, dim3(unsigned(k1 - k0)), dim3(256), 0, sl->st, sl->d, d_inf, reinterpret_cast<const FindSpan *>(d_meta + s_span) + k0,
+                           reinterpret_cast<uint32_t *>(d_meta + s_out) + k0 * kSpanWords);
+        ATL_HIP_TRY(hipGetLastError());
+        return ATL_OK;
+    };
+    // The split order: a batch's block headers are found as soon as its bytes are on the device (find_batch, behind the DMAs);
+    // when everything has arrived the segments are counted, the chains followed (host), the segments decoded and resolved
+    // (split_stage over all streams).  The host reads the device's lists between the passes, so the stage blocks the calling
+    // thread.  (split_stage takes a range of streams: a stage per batch, overlapping the next batch's DMA, was measured -
+    // T = 2000 of 16 MB chunks 0.190 s in 256 MiB batches, 0.158 in 512 MiB, 0.132 s as ONE stage: a launch lasts as long as its
+    // longest segment, a lone wave makes ~10 MB/s, and every batch has a long segment or two.)  A stream whose chain does not
+    // close keeps its "not run" verdict and goes to the host decoders with the other declined streams (finish_slot).
+    size_t so_cand = 0, so_task = 0, so_bound = 0, so_rd = 0;  // what the stages so far have used of the lists
+    const bool dbg = getenv("ATLITE_HIP_INGEST_DEBUG") != nullptr;
+    auto split_stage = [&](size_t i0, size_t i1) -> int {  // streams [i0, i1): their finder has been enqueued
         hipStream_t q = sl->st;
         const std::vector<InfDesc> &jn = job.inf;
         uint8_t *d_mark = sl->d_raw + mark_off;
-        const bool dbg = getenv("ATLITE_HIP_INGEST_DEBUG") != nullptr;
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
         const auto t_begin = now();
-        FindSpan *h_span = reinterpret_cast<FindSpan *>(sl->h + s_span);
-        std::vector<size_t> span0(n + 1, 0);  // the streams' spans
-        {
-            size_t k = 0;
-            for (size_t i = 0; i < n; ++i) {
-                span0[i] = k;
-                const uint64_t bits = uint64_t(jn[i].src_n) * 8;
-                if (bits > 17 + 128)
-                    for (uint64_t b = 17; b < bits; b += kSpanBits) h_span[k++] = FindSpan{uint32_t(i), uint32_t(b), uint32_t(std::min<uint64_t>(kSpanBits, bits - b)), 0u};
-            }
-            span0[n] = k;
-            ATL_REQUIRE(k == n_spans, "atl_nc_read_slabs: span count");
-        }
         uint32_t *h_out = reinterpret_cast<uint32_t *>(sl->h + s_out);
-        if (n_spans) {
-            ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_span, h_span, n_spans * sizeof(FindSpan), hipMemcpyHostToDevice, q));
-            ATL_HIP_TRY(hipMemsetAsync(d_meta + s_out, 0, n_spans * kSpanWords * sizeof(uint32_t), q));
-            hipLaunchKernelGGL(k_find_blocks, dim3(unsigned(n_spans)), dim3(256), 0, q, sl->d, d_inf, reinterpret_cast<const FindSpan *>(d_meta + s_span),
-                               reinterpret_cast<uint32_t *>(d_meta + s_out));
-            ATL_HIP_TRY(hipGetLastError());
-            ATL_HIP_TRY(hipMemcpyAsync(h_out, d_meta + s_out, n_spans * kSpanWords * sizeof(uint32_t), hipMemcpyDeviceToHost, q));
-        }
+        const size_t k0 = span0[i0], k1 = span0[i1];
+        if (k1 > k0)
+            ATL_HIP_TRY(hipMemcpyAsync(h_out + k0 * kSpanWords, d_meta + s_out + k0 * kSpanWords * sizeof(uint32_t), (k1 - k0) * kSpanWords * sizeof(uint32_t),
+                                       hipMemcpyDeviceToHost, q));
         ATL_HIP_TRY(hipStreamSynchronize(q));
         const double ms_find = ms_since(t_begin);
         const auto t_count = now();
         // the streams' split points (ascending) and one task per start
         uint32_t *h_cand = reinterpret_cast<uint32_t *>(sl->h + s_cand);
         SegTask *h_task = reinterpret_cast<SegTask *>(sl->h + s_task);
-        std::vector<size_t> task0(n + 1, 0), cand0(n + 1, 0);
-        size_t nc = 0, ntask = 0;
-        for (size_t i = 0; i < n; ++i) {
-            cand0[i] = nc;
-            task0[i] = ntask;
+        const size_t ni = i1 - i0, c_base = so_cand, t_base = so_task;
+        std::vector<size_t> task0(ni + 1, 0), cand0(ni + 1, 0);
+        size_t nc = c_base, ntask = t_base;
+        for (size_t i = i0; i < i1; ++i) {
+            cand0[i - i0] = nc;
+            task0[i - i0] = ntask;
             for (size_t k = span0[i]; k < span0[i + 1]; ++k) {
                 const uint32_t cnt = std::min(h_out[k * kSpanWords], kSpanSlots);
                 uint32_t *c = h_out + k * kSpanWords + 1;
                 std::sort(c, c + cnt);
                 for (uint32_t j = 0; j < cnt; ++j) h_cand[nc++] = c[j];
             }
-            const uint32_t ncs = uint32_t(nc - cand0[i]);
-            h_task[ntask++] = SegTask{uint32_t(i), 16u, 0u, uint32_t(cand0[i]), ncs, 0u, 0u};
-            for (uint32_t j = 0; j < ncs; ++j) h_task[ntask++] = SegTask{uint32_t(i), h_cand[cand0[i] + j], dinf::kSegSlack, uint32_t(cand0[i]), ncs, 0u, 0u};
+            const uint32_t ncs = uint32_t(nc - cand0[i - i0]), c0 = uint32_t(cand0[i - i0]);
+            h_task[ntask] = SegTask{uint32_t(i), 16u, 0u, c0, ncs, uint32_t(ntask - t_base), 0u};
+            ++ntask;
+            for (uint32_t j = 0; j < ncs; ++j) {
+                h_task[ntask] = SegTask{uint32_t(i), h_cand[c0 + j], dinf::kSegSlack, c0, ncs, uint32_t(ntask - t_base), 0u};
+                ++ntask;
+            }
         }
-        cand0[n] = nc;
-        task0[n] = ntask;
+        cand0[ni] = nc;
+        task0[ni] = ntask;
+        ATL_REQUIRE(ntask <= t_max && nc <= t_max, "atl_nc_read_slabs: segment lists");
+        const size_t n_count = ntask - t_base;
         SegRes *h_res = reinterpret_cast<SegRes *>(sl->h + s_res);
         const SegTask *d_task = reinterpret_cast<const SegTask *>(d_meta + s_task);
         const uint32_t *d_cand = reinterpret_cast<const uint32_t *>(d_meta + s_cand);
         SegRes *d_sres = reinterpret_cast<SegRes *>(d_meta + s_res);
-        if (nc) ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_cand, h_cand, nc * sizeof(uint32_t), hipMemcpyHostToDevice, q));
-        ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_task, h_task, ntask * sizeof(SegTask), hipMemcpyHostToDevice, q));
-        hipLaunchKernelGGL((k_segments<true>), dim3(unsigned(ntask)), dim3(64), 0, q, sl->d, d_inf, d_task, d_cand, sl->d_raw, d_mark, d_sres);
+        if (nc > c_base)
+            ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_cand + c_base * sizeof(uint32_t), h_cand + c_base, (nc - c_base) * sizeof(uint32_t), hipMemcpyHostToDevice, q));
+        // longest first (a launch is as long as its last wave): the compressed bits up to the next split point stand for the work.
+        // The sorted copy is what goes up (in the decode tasks' place: page-locked, free until the chains are known)
+        SegTask *h_sorted = reinterpret_cast<SegTask *>(sl->h + s_res) + t_base;  // (SegRes is not smaller than SegTask; results land behind the sync)
+        {
+            std::vector<std::pair<uint64_t, uint32_t>> order(n_count);
+            for (size_t t = 0; t < n_count; ++t) {
+                const SegTask &tk = h_task[t_base + t];
+                const bool last_of_stream = t + 1 == n_count || h_task[t_base + t + 1].stream != tk.stream;
+                const uint64_t end = last_of_stream ? uint64_t(jn[tk.stream].src_n) * 8 : uint64_t(h_task[t_base + t + 1].start_bit);
+                order[t] = {end - tk.start_bit, uint32_t(t)};
+            }
+            std::sort(order.begin(), order.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+            for (size_t t = 0; t < n_count; ++t) h_sorted[t] = h_task[t_base + order[t].second];
+        }
+        ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_task + t_base * sizeof(SegTask), h_sorted, n_count * sizeof(SegTask), hipMemcpyHostToDevice, q));
+        hipLaunchKernelGGL((k_segments<true>), dim3(unsigned(n_count)), dim3(64), 0, q, sl->d, d_inf, d_task + t_base, d_cand, sl->d_raw, d_mark, d_sres + t_base);
         ATL_HIP_TRY(hipGetLastError());
-        ATL_HIP_TRY(hipMemcpyAsync(h_res, d_sres, ntask * sizeof(SegRes), hipMemcpyDeviceToHost, q));
+        ATL_HIP_TRY(hipMemcpyAsync(h_res + t_base, d_sres + t_base, n_count * sizeof(SegRes), hipMemcpyDeviceToHost, q));
         ATL_HIP_TRY(hipStreamSynchronize(q));
         const double ms_count = ms_since(t_count);
         const auto t_chain = now();
         // the chains: from the stream's first block, every segment ends where the next one starts; output positions on the way
         std::vector<SegTask> run;
+        std::vector<uint64_t> run_len;
         std::vector<uint32_t> bounds;
         std::vector<ResDesc> rds;
-        size_t n_seg_total = 0;
-        for (size_t i = 0; i < n; ++i) {
-            const size_t r0 = run.size(), b0 = bounds.size();
+        for (size_t i = i0; i < i1; ++i) {
+            const size_t r0 = run.size(), b0 = bounds.size(), li = i - i0;
             uint64_t at = 0;
             bool ok = true;
             uint32_t want = 0;
-            for (size_t t = task0[i];;) {
+            for (size_t t = task0[li];;) {
                 const SegRes &r = h_res[t];
-                if (r.status != dinf::kOk || r.o.out_end == 0 || at + r.o.out_end > uint64_t(jn[i].dst_n) || run.size() - r0 > size_t(task0[i + 1] - task0[i])) {
+                if (r.status != dinf::kOk || r.o.out_end == 0 || at + r.o.out_end > uint64_t(jn[i].dst_n) || run.size() - r0 > size_t(task0[li + 1] - task0[li])) {
                     ok = false;
                     break;
                 }
                 SegTask tk = h_task[t];
                 tk.seg0 = at;
                 tk.slack = uint32_t(std::min<uint64_t>(dinf::kSegSlack, at));
+                tk.res_ix = uint32_t(run.size());
                 run.push_back(tk);
+                run_len.push_back(r.o.out_end);
                 bounds.push_back(uint32_t(at));
                 at += r.o.out_end;
                 if (r.o.is_final) {
                     want = r.o.adler;
                     break;
                 }
-                const uint32_t *c = h_cand + cand0[i], *ce = h_cand + cand0[i + 1];
+                const uint32_t *c = h_cand + cand0[li], *ce = h_cand + cand0[li + 1];
                 const uint32_t *it = std::lower_bound(c, ce, uint32_t(r.o.end_bit));
                 if (it == ce || *it != uint32_t(r.o.end_bit)) {
                     ok = false;
                     break;
                 }
-                t = task0[i] + 1 + size_t(it - c);
+                t = task0[li] + 1 + size_t(it - c);
             }
             if (!ok || at != uint64_t(jn[i].dst_n)) {  // the host decoders take the stream
                 run.resize(r0);
+                run_len.resize(r0);
                 bounds.resize(b0);
                 continue;
             }
             bounds.push_back(uint32_t(at));
-            rds.push_back(ResDesc{uint32_t(i), uint32_t(b0), uint32_t(run.size() - r0), want});
-            n_seg_total += run.size() - r0;
+            rds.push_back(ResDesc{uint32_t(i), uint32_t(so_bound + b0), uint32_t(run.size() - r0), want});
         }
-        state->ms[3] += double(n_seg_total);  // (a count: atl_nc_ingest_times)
+        state->ms[3] += double(run.size());  // (a count: atl_nc_ingest_times)
         const double ms_chain = ms_since(t_chain);
         if (dbg)
-            fprintf(stderr, "[atlite-hip ingest] split: %zu streams, %zu spans, %zu candidate headers, %zu of %zu streams chained into %zu segments; "
-                    "find %.1f ms, count pass %.1f ms, chains (host) %.1f ms\n", n, n_spans, nc, rds.size(), n, n_seg_total, ms_find, ms_count, ms_chain);
+            fprintf(stderr, "[atlite-hip ingest] split: streams %zu .. %zu, %zu spans, %zu candidate headers, %zu streams chained into %zu segments; "
+                    "find (wait) %.1f ms, count pass %.1f ms, chains (host) %.1f ms\n", i0, i1, k1 - k0, nc - c_base, rds.size(), run.size(), ms_find, ms_count,
+                    ms_chain);
         if (!run.empty()) {
-            ATL_REQUIRE(run.size() <= t_max && bounds.size() <= t_max + n, "atl_nc_read_slabs: segment lists");
-            memcpy(sl->h + s_task, run.data(), run.size() * sizeof(SegTask));
-            memcpy(sl->h + s_bound, bounds.data(), bounds.size() * sizeof(uint32_t));
-            memcpy(sl->h + s_rd, rds.data(), rds.size() * sizeof(ResDesc));
-            ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_task, sl->h + s_task, run.size() * sizeof(SegTask), hipMemcpyHostToDevice, q));
-            ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_bound, sl->h + s_bound, bounds.size() * sizeof(uint32_t), hipMemcpyHostToDevice, q));
-            ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_rd, sl->h + s_rd, rds.size() * sizeof(ResDesc), hipMemcpyHostToDevice, q));
-            hipLaunchKernelGGL((k_segments<false>), dim3(unsigned(run.size())), dim3(64), 0, q, sl->d, d_inf, d_task, d_cand, sl->d_raw, d_mark, d_sres);
+            // the decode pass's tasks take the place of the count pass's (which nobody reads again)
+            ATL_REQUIRE(run.size() <= n_count && so_bound + bounds.size() <= t_max + n && so_rd + rds.size() <= n, "atl_nc_read_slabs: segment lists");
+            {  // longest first, as the count pass (res_ix: results in chain order; a stream dropped above leaves a gap in the numbering)
+                std::vector<uint32_t> order(run.size());
+                for (size_t t = 0; t < run.size(); ++t) {
+                    order[t] = uint32_t(t);
+                    run[t].res_ix = uint32_t(t);
+                }
+                std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return run_len[a] > run_len[b]; });
+                for (size_t t = 0; t < run.size(); ++t) h_task[t_base + t] = run[order[t]];
+            }
+            uint32_t *h_bound = reinterpret_cast<uint32_t *>(sl->h + s_bound);
+            ResDesc *h_rd = reinterpret_cast<ResDesc *>(sl->h + s_rd);
+            memcpy(h_bound + so_bound, bounds.data(), bounds.size() * sizeof(uint32_t));
+            memcpy(h_rd + so_rd, rds.data(), rds.size() * sizeof(ResDesc));
+            ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_task + t_base * sizeof(SegTask), h_task + t_base, run.size() * sizeof(SegTask), hipMemcpyHostToDevice, q));
+            ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_bound + so_bound * sizeof(uint32_t), h_bound + so_bound, bounds.size() * sizeof(uint32_t), hipMemcpyHostToDevice, q));
+            ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_rd + so_rd * sizeof(ResDesc), h_rd + so_rd, rds.size() * sizeof(ResDesc), hipMemcpyHostToDevice, q));
+            hipLaunchKernelGGL((k_segments<false>), dim3(unsigned(run.size())), dim3(64), 0, q, sl->d, d_inf, d_task + t_base, d_cand, sl->d_raw, d_mark, d_sres + t_base);
             ATL_HIP_TRY(hipGetLastError());
             const auto t_dec = now();
             if (dbg) {  // the decode pass must end where the count pass did
-                ATL_HIP_TRY(hipMemcpyAsync(h_res, d_sres, run.size() * sizeof(SegRes), hipMemcpyDeviceToHost, q));
+                ATL_HIP_TRY(hipMemcpyAsync(h_res + t_base, d_sres + t_base, run.size() * sizeof(SegRes), hipMemcpyDeviceToHost, q));
                 ATL_HIP_TRY(hipStreamSynchronize(q));
                 size_t bad = 0;
-                for (size_t t = 0; t < run.size(); ++t) bad += h_res[t].status != dinf::kOk;
+                for (size_t t = 0; t < run.size(); ++t) bad += h_res[t_base + t].status != dinf::kOk;
                 fprintf(stderr, "[atlite-hip ingest] split: decode pass %.1f ms, %zu of %zu segments with a status\n", ms_since(t_dec), bad, run.size());
             }
-            const auto t_res = now();
-            hipLaunchKernelGGL(k_resolve, dim3(unsigned(rds.size())), dim3(1024), 0, q, d_inf, reinterpret_cast<const ResDesc *>(d_meta + s_rd),
+            hipLaunchKernelGGL(k_resolve, dim3(unsigned(rds.size())), dim3(1024), 0, q, d_inf, reinterpret_cast<const ResDesc *>(d_meta + s_rd) + so_rd,
                                reinterpret_cast<const uint32_t *>(d_meta + s_bound), sl->d_raw, d_mark, d_res);
             ATL_HIP_TRY(hipGetLastError());
-            if (dbg) {
-                ATL_HIP_TRY(hipStreamSynchronize(q));
-                fprintf(stderr, "[atlite-hip ingest] split: resolve + Adler-32 %.1f ms\n", ms_since(t_res));
-            }
         }
+        so_cand = nc;
+        so_task = ntask;
+        so_bound += bounds.size();
+        so_rd += rds.size();
+        return ATL_OK;
+    };
+    auto split_finish = [&]() -> int {
+        hipStream_t q = sl->st;
         ATL_HIP_TRY(hipEventRecord(sl->ev_t[2], q));
         for (const Part &pt : job.parts)  // (a stream the host decoders take is unpacked again behind them)
             if (pt.n_desc) launch_unpack(q, sl->d_raw, d_unp + pt.desc0, pt.n_desc, pt.p, pt.max_elems, pt.d_out);
@@ -2012,6 +2105,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
         ring->busy = true;
         fed_batches = b + 1;
         rc = set_flags(false);
+        if (!rc && split) rc = find_batch(b);
     }
     if (!rc) rc = set_flags(true);  // the call returns when its last DMA has landed; the kernel goes on by itself
     state->ms[0] += gather_ms;
@@ -2022,7 +2116,12 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     (void)hipEventRecord(sl->ev_c[1], sl->st_c);
     if (!rc && !fed) {  // the unfed order (A/B, $ATLITE_HIP_INGEST_FED=0): every byte first, then the launch
         ATL_HIP_TRY(hipStreamWaitEvent(sl->st, sl->ev_c[1], 0));
-        rc = split ? launch_split() : launch();
+        if (split) {
+            rc = split_stage(0, n);
+            if (!rc) rc = split_finish();
+        } else {
+            rc = launch();
+        }
     }
     if (fed || !rc) {
         // the verdicts come back behind the kernel AND the last DMA (an aborted job's kernel may end before its flags' DMAs)
@@ -2080,7 +2179,7 @@ int read_rows_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *nam
         raw_bytes += double(rows * per_row) * chunk_bytes;
         tchunk = std::max(tchunk, c0);
     }
-    if (!device_inflate_wanted(size_t(streams))) return ATL_OK;
+    if (!device_inflate_wanted(size_t(streams), raw_bytes)) return ATL_OK;
     double job_bytes = 12.0 * double(size_t(1) << 30);
     if (const char *e = getenv("ATLITE_HIP_INGEST_JOB_GB")) job_bytes = std::max(0.001, atof(e)) * double(size_t(1) << 30);
     const int64_t first_row = start0 / tchunk, last_row = (start0 + count0 - 1) / tchunk, chunk_rows = last_row - first_row + 1;

@@ -900,11 +900,14 @@ def from_file_leg(ctx, _lib, gis, M, Y, X, T=8760, chunks=(24, 100, 100), host_c
                 dm = m1 - m0
                 out["device_inflate"]["one_warm_call"] = {
                     "host_gather_ms": dm[0], "h2d_ms": dm[1], "k_inflate_ms": dm[2], "unpack_of_unwritten_chunks_ms": dm[4],
+                    "segments_decoded_side_by_side": int(dm[3]),
                     "streams": s1[0] - s0[0], "redone_on_host": s1[2] - s0[2], "compressed_bytes": c1 - c0, "inflated_bytes": r1 - r0,
-                    "note": "ONE fed launch: the kernel starts first, the compressed bytes follow in DMA batches (h2d_ms: first to last "
-                            "DMA), each wave waits for its stream's batch, then inflates, checks the Adler-32 and unpacks its chunk "
-                            "(k_inflate_ms spans all of that, waits included); host_gather_ms is the preads' wall time inside the same "
-                            "window - the three overlap"}
+                    "note": "many streams - ONE fed launch: the kernel starts first, the compressed bytes follow in DMA batches (h2d_ms: "
+                            "first to last DMA), each wave waits for its stream's batch, then inflates, checks the Adler-32 and unpacks "
+                            "its chunk (k_inflate_ms spans all of that, waits included); host_gather_ms is the preads' wall time inside "
+                            "the same window - the three overlap.  Few long streams (segments_decoded_side_by_side > 0): their DEFLATE "
+                            "blocks are found (behind the DMAs), counted, decoded and resolved by a wave per block; k_inflate_ms spans "
+                            "those passes and starts when the last DMA has landed"}
             r_host, out["host_inflate"] = leg("host", host_calls)
             out["bit_identical"] = bool(np.array_equal(np.asarray(r_dev), np.asarray(r_host)))
             out["stored_bytes"] = int(disk)
@@ -1579,7 +1582,8 @@ def main():
             except Exception as e:  # noqa: BLE001 - a side leg must not cost the run its line
                 result["from_file"] = {"skipped": repr(e)}
             try:  # the same grid chunked (time = 100, y, x) - atlite's own chunks={"time": 100} written through: 16 MB streams, few
-                # of them (a third of a year: 210); a zlib stream is sequential, so these stay on the host threads
+                # of them (a third of a year: 210).  A zlib stream is sequential - until round 6 these stayed on the host threads -
+                # but its DEFLATE blocks are not: they are decoded side by side, a wave per block (atl_inflate_dev.h, "SEGMENTS")
                 result["from_file_large_chunks"] = from_file_leg(ctx, _lib, gis, M if (Y, X) == (200, 200) else None, Y, X, T=3000,
                                                                  chunks=(100, Y, X), device_calls=2)
             except Exception as e:  # noqa: BLE001
