@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--keep", default=None, help="write the file here and keep it")
     ap.add_argument("--threads", type=int, default=0, help="threads that deflate the chunks while the file is written (0: CPUs)")
     ap.add_argument("--no-host", action="store_true", help="skip the host-inflate leg (A/B runs of the device decoder)")
+    ap.add_argument("--default-policy", action="store_true", help="let the library choose host / device inflate (default: device forced)")
     ap.add_argument("--quick", action="store_true", help="only the from-file legs (device / host inflate) and the stage split")
     a = ap.parse_args()
     ct, cy, cx = (int(v) for v in a.chunks.split(","))
@@ -88,7 +89,10 @@ def main():
         _lib.check(ctx.lib.atl_nc_ingest_stats(ctx.handle, *[C.byref(x) for x in st]))
         return np.array(list(ms)), cb.value, rb.value, [x.value for x in st]
 
-    os.environ["ATLITE_HIP_INFLATE"] = "device"
+    if a.default_policy:
+        os.environ.pop("ATLITE_HIP_INFLATE", None)
+    else:
+        os.environ["ATLITE_HIP_INFLATE"] = "device"
     ref = leg("pv from FILE (inflate on the DEVICE, one wave per chunk stream)", lambda: cf.pv(**kw).values, n=4)
     m0, c0, r0, s0 = times()
     cf.pv(**kw).values
@@ -97,7 +101,7 @@ def main():
     print(f"  one warm call, the stages of its ONE fed launch (they overlap): preads {dm[0]:.1f} ms | DMAs, first to last {dm[1]:.1f} ms "
           f"({(c1 - c0) / max(dm[1], 1e-9) / 1e6:.1f} GB/s) | k_inflate incl. its waits, Adler-32 and unpack {dm[2]:.1f} ms "
           f"({(r1 - r0) / max(dm[2], 1e-9) / 1e6:.1f} GB/s of output, {s1[0] - s0[0]} streams, {s1[2] - s0[2]} redone on the host) | "
-          f"unpack of never-written chunks {dm[4]:.1f} ms", flush=True)
+          f"unpack of never-written chunks {dm[4]:.1f} ms | segments decoded side by side {int(dm[3])}", flush=True)
     if a.no_host:
         import hashlib
         print("result sha1", hashlib.sha1(np.ascontiguousarray(ref).tobytes()).hexdigest(), flush=True)
