@@ -54,6 +54,7 @@ enum Status : int {
     kShort = 7,        // stream ended before the chunk was full
     kInputOverrun = 8, // consumed more bits than the stream has
     kAdler = 9,        // Adler-32 mismatch (set by the checksum kernel)
+    kPoolFull = 10,    // segments decoded in one pass: the pool of output pages ran out (the stream goes to the host decoders)
     kNotRun = 15,
 };
 
@@ -763,6 +764,9 @@ constexpr uint32_t kSegSlack = 32768;  // how far before its start a segment's m
 ATL_HD inline uint32_t marker_lo(uint32_t back) { return (back - 1u) & 0xFFu; }            // back = 1 .. 32768 bytes before the start
 ATL_HD inline uint32_t marker_hi(uint32_t back) { return 0x80u | ((back - 1u) >> 8); }
 ATL_HD inline uint32_t marker_back(uint32_t lo, uint32_t hi) { return (((hi & 0x7Fu) << 8) | lo) + 1u; }
+// ... and as ONE 16-bit unit per output byte (the single-pass variant's pool): a byte, or 0x8000 | (back - 1)
+ATL_HD inline uint32_t marker16(uint32_t back) { return 0x8000u | (back - 1u); }
+ATL_HD inline uint32_t marker16_back(uint32_t v) { return (v & 0x7FFFu) + 1u; }
 
 struct SegOut {
     uint64_t end_bit;   // where the segment stopped: a split point at a block boundary, or behind the stream's trailer

@@ -924,6 +924,276 @@ __global__ __launch_bounds__(64) void k_segments(const uint8_t *__restrict__ com
 struct ResDesc {
     uint32_t stream, bound0, n_seg, adler_want;  // bounds[bound0 .. bound0 + n_seg]: where the stream's segments begin (and the chunk's end)
 };
+// ---- ... in ONE decode pass (no count pass): a segment's output goes into regions of a pool - 8 Ki, 16 Ki, 32 Ki ... 16-bit units, taken
+// from a bump allocator as the segment grows - as one unit per byte (the byte, or a marker); when the chains are known k_gather copies
+// the segments to their places in the chunk, markers resolved on the way.
+constexpr uint32_t kRegionLog = 13;              // first region: 8192 units (bytes of output); region r holds 8192 << r
+constexpr uint32_t kMaxRegions = 14;             // 8192 * (2^14 - 1) > 64 MiB, the largest chunk the device path takes
+struct PoolRef {
+    uint16_t *pool;          // 16-bit units
+    uint32_t *next;          // bump allocator, in units of 8192
+    uint32_t cap;            // ... its end
+    uint32_t *regs;          // [tasks][kMaxRegions] the regions' bases (units of 8192): k_gather reads them
+};
+// position inside a segment -> (region, offset): region r begins at 8192 * (2^r - 1)
+__device__ __forceinline__ uint32_t region_of(uint32_t pos) { return 31u - uint32_t(__builtin_clz((pos >> kRegionLog) + 1u)); }
+__device__ __forceinline__ uint32_t region_off(uint32_t pos, uint32_t r) { return pos - (((1u << r) - 1u) << kRegionLog); }
+
+struct PoolSink {
+    WaveMem::u32p qrec, qpos;
+    WaveMem::u16p stage;   // [kStage + 4] units, word aligned
+    WaveMem::u32p reg;     // [kMaxRegions] bases of this segment's regions
+    const uint8_t *src8;
+    uint16_t *pool;
+    uint32_t *next, *regs_out;
+    uint32_t cap, n_reg = 0, alloc_end = 0;
+    bool full = false;
+    __device__ __forceinline__ void tables_ready() { DevWave::sync(); }
+    __device__ __forceinline__ size_t at(uint32_t pos) const {
+        const uint32_t r = region_of(pos);
+        return (size_t(reg[r]) << kRegionLog) + region_off(pos, r);
+    }
+    // regions up to output position `end` (wave-uniform); false: the pool is exhausted
+    __device__ __forceinline__ bool ensure(uint32_t end) {
+        while (alloc_end < end && !full) {
+            uint32_t base = 0;
+            if (threadIdx.x == 0) base = atomicAdd(next, 1u << n_reg);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (n_reg >= kMaxRegions || base > cap || (1u << n_reg) > cap - base) {
+                full = true;
+                break;
+            }
+            if (threadIdx.x == 0) {
+                reg[n_reg] = base;
+                regs_out[n_reg] = base;
+            }
+            alloc_end += 1u << (kRegionLog + n_reg);
+            ++n_reg;
+            DevWave::sync();
+        }
+        return !full;
+    }
+    __device__ __forceinline__ void stored(uint64_t byte_pos, uint32_t len, uint64_t out_pos) {
+        if (!ensure(uint32_t(out_pos) + len)) return;
+        for (uint32_t j = threadIdx.x; j < len; j += 64) pool[at(uint32_t(out_pos) + j)] = src8[byte_pos + j];
+        __threadfence_block();
+    }
+    // the unit of output position s (relative to the segment's start; negative: before it - a marker)
+    __device__ __forceinline__ uint32_t fetch(int32_t s) const {
+        const bool before = s < 0;
+        const uint32_t v = pool[at(before ? 0u : uint32_t(s))];
+        return before ? dinf::marker16(uint32_t(-s)) : v;
+    }
+    __device__ __forceinline__ void resolve(int n, uint64_t bstart, uint64_t bend) {
+        const uint32_t lane = threadIdx.x;
+        const uint32_t bs = uint32_t(bstart), total = uint32_t(bend - bstart);
+        if (!ensure(uint32_t(bend))) return;  // (the segment's status says so at its end: k_segments_pool)
+        WaveMem::u16p st = stage + (bs & 1u);  // the staging area's aligned words are the pool's
+        const bool active = int(lane) < n;
+        const uint32_t rec = active ? qrec[lane] : 0u, pos = active ? qpos[lane] : 0u;
+        const bool lit = (rec & dinf::kLitFlag) != 0;
+        const uint32_t len = rec & 0x1FFu, dist = (rec & 0x7FFFFFFFu) >> 9;
+        const uint32_t rel = pos - bs;
+        bool coop = false;
+        if (active) {
+            if (lit) {
+                st[rel] = uint16_t(rec & 0xFFu);
+            } else if (int32_t(pos) - int32_t(dist) + int32_t(len) <= int32_t(bs) && len <= 16) {
+                const int32_t sp0 = int32_t(pos) - int32_t(dist);
+                for (uint32_t j0 = 0; j0 < len; j0 += 8) {
+                    uint32_t v[8];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j) v[j] = fetch(sp0 + int32_t(min(j0 + j, len - 1u)));  // (nothing behind the match is read: it may not be allocated)
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j)
+                        if (j0 + j < len) st[rel + j0 + j] = uint16_t(v[j]);
+                }
+            } else {
+                coop = true;
+            }
+        }
+        uint64_t todo = __ballot(coop);
+        DevWave::sync();
+        while (todo) {  // in symbol order; every source byte of a match precedes the match
+            const int i = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t r = __builtin_amdgcn_readlane(rec, i), p = __builtin_amdgcn_readlane(pos, i);
+            const uint32_t L = r & 0x1FFu, D = (r & 0x7FFFFFFFu) >> 9, R = p - bs;
+            for (uint32_t j = lane; j < L; j += 64) {
+                const uint32_t k = D >= L ? j : j % D;
+                const int32_t sp = int32_t(p) - int32_t(D) + int32_t(k);
+                st[R + j] = uint16_t(sp >= int32_t(bs) ? uint32_t(st[uint32_t(sp) - bs]) : fetch(sp));
+            }
+            DevWave::sync();
+        }
+        // flush: an odd first unit and an odd last one on their own, the pairs in between as words
+        const uint32_t head = min(bs & 1u, total), words = (total - head) >> 1, tail0 = head + 2u * words;
+        if (lane == 0 && head) pool[at(bs)] = st[0];
+        if (lane == 32 && tail0 < total) pool[at(bs + tail0)] = st[tail0];
+        {
+            const __attribute__((address_space(3))) uint32_t *sw = (const __attribute__((address_space(3))) uint32_t *)(st + head);
+            for (uint32_t k = lane; k < words; k += 64) *reinterpret_cast<uint32_t *>(pool + at(bs + head + 2u * k)) = sw[k];
+        }
+        __threadfence_block();
+        DevWave::sync();
+    }
+};
+
+__global__ __launch_bounds__(64) void k_segments_pool(const uint8_t *__restrict__ comp, const InfDesc *__restrict__ desc,
+                                                      const SegTask *__restrict__ tasks, const uint32_t *__restrict__ cands, PoolRef pr,
+                                                      SegRes *__restrict__ res) {
+    using namespace dinf;
+    __shared__ uint16_t s_lit[kLitCap];
+    __shared__ uint16_t s_off[kOffCap];
+    constexpr int kTmpWords = (2 * (kStage + 4) > 640 + 352 ? 2 * (kStage + 4) : 640 + 352) / 4 + 1;
+    __shared__ uint32_t s_tmp[kTmpWords];  // codes | code lengths while a table is built; the staging area (16-bit units) while symbols are decoded
+    __shared__ uint32_t s_cnt[32];
+    __shared__ uint32_t s_q[2 * kQueue + 1 + 16];
+    __shared__ uint32_t s_sym[64];
+    __shared__ uint32_t s_reg[kMaxRegions + 2];
+    const SegTask t = tasks[blockIdx.x];
+    const InfDesc d = desc[t.stream];
+    Areas<WaveMem> A;
+    A.lit = (WaveMem::u16p)s_lit;
+    A.off = (WaveMem::u16p)s_off;
+    A.codes = (WaveMem::u16p)s_tmp;
+    A.cnt = (WaveMem::u32p)s_cnt;
+    A.nxt = (WaveMem::u32p)(s_cnt + 16);
+    A.lens = (WaveMem::u8p)(s_tmp + 160);
+    A.qrec = (WaveMem::u32p)s_q;
+    A.qpos = (WaveMem::u32p)(s_q + kQueue);
+    A.wbuf = (WaveMem::u32p)(s_q + 2 * kQueue + 1);
+    A.sym = (WaveMem::u32p)s_sym;
+    const DevSplits splits{cands + t.cand0, t.n_cand};
+    SegOut o{};
+    PoolSink sink;
+    sink.qrec = A.qrec;
+    sink.qpos = A.qpos;
+    sink.stage = (WaveMem::u16p)s_tmp;
+    sink.reg = (WaveMem::u32p)s_reg;
+    sink.src8 = comp + d.src_off;
+    sink.pool = pr.pool;
+    sink.next = pr.next;
+    sink.cap = pr.cap;
+    sink.regs_out = pr.regs + size_t(t.res_ix) * kMaxRegions;
+    int st = inflate_segment<WaveMem, DevWave, DevWindow, PoolSink, DevSplits>(A, (WaveMem::src_t)(comp + d.src_off), uint32_t((d.src_n + 3) / 4),
+                                                                              uint64_t(d.src_n), uint64_t(t.start_bit), 0, t.slack, uint64_t(d.dst_n), splits,
+                                                                              sink, &o);
+    if (st == kOk && sink.full) st = kPoolFull;
+    if (threadIdx.x == 0) {
+        res[t.res_ix].o = o;
+        res[t.res_ix].status = st;
+    }
+}
+
+struct GatherSeg {
+    uint32_t task;   // whose regions (PoolRef::regs)
+    uint32_t start;  // where the segment's bytes go in the chunk
+};
+// one workgroup per stream: segment after segment, pool units -> bytes of the chunk (markers: the byte `back` before the segment's
+// start, final by then), then the chunk's Adler-32.  segs[bound0 .. bound0 + n_seg) and one more entry whose start is the chunk's end.
+__global__ __launch_bounds__(1024) void k_gather(const InfDesc *__restrict__ desc, const ResDesc *__restrict__ rds, const GatherSeg *__restrict__ segs,
+                                                 PoolRef pr, uint8_t *__restrict__ raw, InfResult *__restrict__ res) {
+    const ResDesc rd = rds[blockIdx.x];
+    const InfDesc d = desc[rd.stream];
+    uint8_t *base = raw + d.dst_off;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    __shared__ int s_bad;
+    __shared__ uint32_t s_reg[kMaxRegions];
+    if (tid == 0) s_bad = 0;
+    for (uint32_t c = 0; c < rd.n_seg; ++c) {
+        const GatherSeg g = segs[rd.bound0 + c];
+        const uint32_t s0 = g.start, len = segs[rd.bound0 + c + 1].start - s0;
+        __syncthreads();  // (the previous segment's bytes are written, its regions no longer read)
+        if (tid < kMaxRegions) s_reg[tid] = pr.regs[size_t(g.task) * kMaxRegions + tid];
+        __syncthreads();
+        auto unit = [&](uint32_t i) -> uint32_t {
+            const uint32_t r = region_of(i);
+            return pr.pool[(size_t(s_reg[r]) << kRegionLog) + region_off(i, r)];
+        };
+        auto byte_of = [&](uint32_t v) -> uint32_t {
+            if (!(v & 0x8000u)) return v & 0xFFu;
+            const uint32_t back = dinf::marker16_back(v);
+            if (back > s0) {
+                s_bad = 1;
+                return 0u;
+            }
+            return base[s0 - back];
+        };
+        // four bytes per thread where the chunk's words allow: the head up to a word boundary and the tail byte by byte
+        const uint32_t h = min((4u - (s0 & 3u)) & 3u, len), nw = (len - h) >> 2, t0 = h + 4u * nw;
+        if (tid < h) base[s0 + tid] = uint8_t(byte_of(unit(tid)));
+        if (tid >= 32 && tid - 32 < len - t0) base[s0 + t0 + (tid - 32)] = uint8_t(byte_of(unit(t0 + (tid - 32))));
+        for (uint32_t k = tid; k < nw; k += nt) {
+            const uint32_t i = h + 4u * k;
+            uint32_t v[4];
+            if ((i & 1u) == 0u) {  // two aligned pairs (a pair never straddles regions: they begin at multiples of 8192)
+                auto pair = [&](uint32_t p) -> uint32_t {
+                    const uint32_t r = region_of(p);
+                    return *reinterpret_cast<const uint32_t *>(pr.pool + (size_t(s_reg[r]) << kRegionLog) + region_off(p, r));
+                };
+                const uint32_t a = pair(i), b = pair(i + 2u);
+                v[0] = a & 0xFFFFu;
+                v[1] = a >> 16;
+                v[2] = b & 0xFFFFu;
+                v[3] = b >> 16;
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) v[j] = unit(i + j);
+            }
+            uint32_t w = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) w |= byte_of(v[j]) << (8u * j);
+            *reinterpret_cast<uint32_t *>(base + s0 + i) = w;
+        }
+        __threadfence_block();
+    }
+    __syncthreads();
+    // Adler-32 (wave_adler's sums, the whole workgroup)
+    const uint64_t n = uint64_t(d.dst_n), n16 = n / 16;
+    unsigned long long s1 = 0, s2 = 0;
+    for (uint64_t i = tid; i < n16; i += nt) {
+        const uint4 v = reinterpret_cast<const uint4 *>(base)[i];
+        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+        uint32_t sum = 0, wsum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t b = (wds[q] >> (8 * k)) & 0xFFu;
+                sum += b;
+                wsum += uint32_t(4 * q + k) * b;
+            }
+        s1 += sum;
+        s2 += (n - i * 16) * sum - wsum;
+    }
+    for (uint64_t i = n16 * 16 + tid; i < n; i += nt) {
+        s1 += base[i];
+        s2 += (n - i) * base[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    __shared__ unsigned long long r1[16], r2[16];
+    if ((tid & 63u) == 0) {
+        r1[tid >> 6] = s1;
+        r2[tid >> 6] = s2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long t1 = 0, t2 = 0;
+        for (uint32_t k = 0; k < nt / 64u; ++k) {
+            t1 += r1[k];
+            t2 += r2[k];
+        }
+        const uint32_t a = uint32_t((1 + t1) % 65521ull), b = uint32_t((n % 65521ull + t2 % 65521ull) % 65521ull);
+        const uint32_t got = (b << 16) | a;
+        res[rd.stream].status = s_bad ? int32_t(dinf::kBadDistance) : got == rd.adler_want ? int32_t(dinf::kOk) : int32_t(dinf::kAdler);
+        res[rd.stream].adler_want = rd.adler_want;
+    }
+}
+
 // one workgroup per stream: markers -> bytes, then the Adler-32 of the chunk
 __global__ __launch_bounds__(1024) void k_resolve(const InfDesc *__restrict__ desc, const ResDesc *__restrict__ rds, const uint32_t *__restrict__ bounds,
                                                   uint8_t *__restrict__ raw, const uint8_t *__restrict__ mark, InfResult *__restrict__ res) {
@@ -1058,6 +1328,8 @@ struct Slot {
     size_t bytes = 0, d_bytes = 0;
     uint8_t *d_raw = nullptr;  // device path: the inflated chunks
     size_t raw_bytes = 0;
+    uint8_t *d_pool = nullptr;  // segments decoded in one pass: the pool of output regions + its lists (k_segments_pool)
+    size_t pool_bytes = 0;
     hipEvent_t ev = nullptr;
     hipEvent_t ev_fork[2] = {nullptr, nullptr};
     hipStream_t st = nullptr;    // device path: the slot's kernel stream (two reads in flight overlap)
@@ -1155,6 +1427,7 @@ void ingest_free(void *p) {
         if (sl.h) (void)hipHostFree(sl.h);
         if (sl.d) (void)dev_free(sl.d);
         if (sl.d_raw) (void)dev_free(sl.d_raw);
+        if (sl.d_pool) (void)dev_free(sl.d_pool);
     }
     for (Ring &r : s->ring) {
         if (r.ev) (void)hipEventDestroy(r.ev);
@@ -1744,7 +2017,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
                  s_rd = align_up(s_bound + (t_max + n) * sizeof(uint32_t), 256), s_end = split ? s_rd + n * sizeof(ResDesc) : m_end;
     const size_t mark_off = align_up(raw_off + 256, 256);
     Slot *sl = nullptr;
-    int rc = slot_acquire(ctx, s_end + 256, off_meta + s_end + 256, split ? 2 * mark_off : raw_off + 256, true, &sl);
+    int rc = slot_acquire(ctx, s_end + 256, off_meta + s_end + 256, raw_off + 256, true, &sl);  // (count + decode: the mark plane is added when needed)
     if (rc) return rc;
     rc = ring_reserve(ctx, ring_bytes);  // (every allocation of the job happens before its kernel is launched)
     if (rc) return rc;
@@ -1877,7 +2150,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     auto split_stage = [&](size_t i0, size_t i1) -> int {  // streams [i0, i1): their finder has been enqueued
         hipStream_t q = sl->st;
         const std::vector<InfDesc> &jn = job.inf;
-        uint8_t *d_mark = sl->d_raw + mark_off;
+        uint8_t *d_mark = nullptr;
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
         const auto t_begin = now();
@@ -1937,7 +2210,57 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
             for (size_t t = 0; t < n_count; ++t) h_sorted[t] = h_task[t_base + order[t].second];
         }
         ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_task + t_base * sizeof(SegTask), h_sorted, n_count * sizeof(SegTask), hipMemcpyHostToDevice, q));
-        hipLaunchKernelGGL((k_segments<true>), dim3(unsigned(n_count)), dim3(64), 0, q, sl->d, d_inf, d_task + t_base, d_cand, sl->d_raw, d_mark, d_sres + t_base);
+        // ONE decode pass into a pool of output regions (default), or count + decode ($ATLITE_HIP_SPLIT_PASSES=2; also when the pool
+        // cannot be had): the pool holds a 16-bit unit per output byte, a segment wastes less than it makes + one first region
+        bool one_pass = true;
+        if (const char *e = getenv("ATLITE_HIP_SPLIT_PASSES")) one_pass = atoi(e) != 2;
+        PoolRef pr{};
+        size_t off_gseg = 0, off_rd = 0;
+        if (one_pass) {
+            double out_bytes = 0;
+            for (size_t i = i0; i < i1; ++i) out_bytes += double(jn[i].dst_n);
+            const size_t cap_regions = size_t((1.75 * out_bytes + 8192.0 * double(n_count)) / 8192.0) + 1024;
+            const size_t b_pool = cap_regions * 8192 * sizeof(uint16_t), off_regs = align_up(b_pool, 256),
+                         off_next = align_up(off_regs + n_count * kMaxRegions * sizeof(uint32_t), 256);
+            off_gseg = off_next + 256;
+            off_rd = align_up(off_gseg + (n_count + ni + 1) * sizeof(GatherSeg), 256);
+            const size_t need = off_rd + (ni + 1) * sizeof(ResDesc) + 256;
+            if (cap_regions >= (size_t(1) << 32)) one_pass = false;
+            if (one_pass && sl->pool_bytes < need) {
+                if (sl->d_pool) (void)dev_free(sl->d_pool);
+                sl->d_pool = nullptr;
+                sl->pool_bytes = 0;
+                if (dev_malloc(reinterpret_cast<void **>(&sl->d_pool), need) == hipSuccess) {
+                    sl->pool_bytes = need;
+                } else {
+                    (void)hipGetLastError();
+                    sl->d_pool = nullptr;
+                    one_pass = false;  // no room for the pool: count + decode
+                }
+            }
+            if (one_pass) {
+                pr.pool = reinterpret_cast<uint16_t *>(sl->d_pool);
+                pr.regs = reinterpret_cast<uint32_t *>(sl->d_pool + off_regs);
+                pr.next = reinterpret_cast<uint32_t *>(sl->d_pool + off_next);
+                pr.cap = uint32_t(cap_regions);
+                ATL_HIP_TRY(hipMemsetAsync(pr.next, 0, 256, q));
+            }
+        }
+        if (!one_pass) {  // the mark plane behind the inflated chunks (nothing has been written there yet)
+            if (sl->raw_bytes < 2 * mark_off) {
+                ATL_HIP_TRY(hipStreamSynchronize(q));
+                if (sl->d_raw) (void)dev_free(sl->d_raw);
+                sl->d_raw = nullptr;
+                sl->raw_bytes = 0;
+                ATL_HIP_TRY(dev_malloc(reinterpret_cast<void **>(&sl->d_raw), 2 * mark_off));
+                sl->raw_bytes = 2 * mark_off;
+            }
+            d_mark = sl->d_raw + mark_off;
+        }
+        if (one_pass)
+            hipLaunchKernelGGL(k_segments_pool, dim3(unsigned(n_count)), dim3(64), 0, q, sl->d, d_inf, d_task + t_base, d_cand, pr, d_sres + t_base);
+        else
+            hipLaunchKernelGGL((k_segments<true>), dim3(unsigned(n_count)), dim3(64), 0, q, sl->d, d_inf, d_task + t_base, d_cand, sl->d_raw, d_mark, d_sres + t_base);
         ATL_HIP_TRY(hipGetLastError());
         ATL_HIP_TRY(hipMemcpyAsync(h_res + t_base, d_sres + t_base, n_count * sizeof(SegRes), hipMemcpyDeviceToHost, q));
         ATL_HIP_TRY(hipStreamSynchronize(q));
@@ -1962,7 +2285,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
                 SegTask tk = h_task[t];
                 tk.seg0 = at;
                 tk.slack = uint32_t(std::min<uint64_t>(dinf::kSegSlack, at));
-                tk.res_ix = uint32_t(run.size());
+                tk.res_ix = uint32_t(t - t_base);  // (one pass: whose regions; count + decode: renumbered below)
                 run.push_back(tk);
                 run_len.push_back(r.o.out_end);
                 bounds.push_back(uint32_t(at));
@@ -1994,7 +2317,36 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
             fprintf(stderr, "[atlite-hip ingest] split: streams %zu .. %zu, %zu spans, %zu candidate headers, %zu streams chained into %zu segments; "
                     "find (wait) %.1f ms, count pass %.1f ms, chains (host) %.1f ms\n", i0, i1, k1 - k0, nc - c_base, rds.size(), run.size(), ms_find, ms_count,
                     ms_chain);
-        if (!run.empty()) {
+        if (one_pass && !run.empty()) {  // the segments' units -> the chunks' bytes
+            std::vector<GatherSeg> gs;
+            gs.reserve(run.size() + rds.size());
+            for (ResDesc &rd : rds) {  // (rd.bound0 indexes `bounds`: so_bound + b0, n_seg + 1 entries per stream)
+                const size_t b0 = rd.bound0 - so_bound, g0 = gs.size();
+                // the stream's tasks lie in `run` in the same order as its bounds: find them by walking both
+                for (uint32_t c = 0; c < rd.n_seg; ++c) gs.push_back(GatherSeg{0u, bounds[b0 + c]});
+                gs.push_back(GatherSeg{0u, bounds[b0 + rd.n_seg]});
+                rd.bound0 = uint32_t(g0);
+            }
+            {  // tasks: `run` holds the chained segments stream after stream, in the order of `rds`
+                size_t g = 0, t = 0;
+                for (const ResDesc &rd : rds) {
+                    for (uint32_t c = 0; c < rd.n_seg; ++c) gs[g++].task = run[t++].res_ix;
+                    ++g;
+                }
+            }
+            ATL_HIP_TRY(hipMemcpyAsync(sl->d_pool + off_gseg, gs.data(), gs.size() * sizeof(GatherSeg), hipMemcpyHostToDevice, q));
+            ATL_HIP_TRY(hipMemcpyAsync(sl->d_pool + off_rd, rds.data(), rds.size() * sizeof(ResDesc), hipMemcpyHostToDevice, q));
+            ATL_HIP_TRY(hipStreamSynchronize(q));  // (the lists are on the stack)
+            hipLaunchKernelGGL(k_gather, dim3(unsigned(rds.size())), dim3(1024), 0, q, d_inf, reinterpret_cast<const ResDesc *>(sl->d_pool + off_rd),
+                               reinterpret_cast<const GatherSeg *>(sl->d_pool + off_gseg), pr, sl->d_raw, d_res);
+            ATL_HIP_TRY(hipGetLastError());
+            if (dbg) {
+                uint32_t used = 0;
+                ATL_HIP_TRY(hipMemcpyAsync(&used, pr.next, sizeof used, hipMemcpyDeviceToHost, q));
+                ATL_HIP_TRY(hipStreamSynchronize(q));
+                fprintf(stderr, "[atlite-hip ingest] split: one decode pass; the pool: %u of %u regions of 16 KiB used\n", used, pr.cap);
+            }
+        } else if (!run.empty()) {
             // the decode pass's tasks take the place of the count pass's (which nobody reads again)
             ATL_REQUIRE(run.size() <= n_count && so_bound + bounds.size() <= t_max + n && so_rd + rds.size() <= n, "atl_nc_read_slabs: segment lists");
             {  // longest first, as the count pass (res_ix: results in chain order; a stream dropped above leaves a gap in the numbering)

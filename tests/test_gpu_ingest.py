@@ -279,8 +279,9 @@ def ingest_segments(ctx):
 
 def test_long_streams_are_decoded_block_by_block(ctx, tmp_path, monkeypatch, inflate_mode):
     """Few, long chunk streams - atlite's own cutouts have (time = 100, y, x) chunks, 16 MB each for a 200 x 200 grid - are
-    split at their DEFLATE block headers and the blocks decoded side by side (block finder, count pass, chain, decode pass with
-    markers for what a block copies from its predecessors, resolve): 1 MiB chunks of seven payload kinds x zlib levels, forced
+    split at their DEFLATE block headers and the blocks decoded side by side (block finder, one decode pass into a pool of output
+    regions with markers for what a block copies from its predecessors - or a count pass and a decode pass -, the chains followed
+    on the host, gather / resolve): 1 MiB chunks of seven payload kinds x zlib levels, forced
     ($ATLITE_HIP_INFLATE_SPLIT=1) and by the default policy; the bytes are what was written, no stream goes back to the host, and
     the compressible kinds really are decoded in several segments each."""
     import subprocess
@@ -301,11 +302,16 @@ def test_long_streams_are_decoded_block_by_block(ctx, tmp_path, monkeypatch, inf
     assert r.returncode == 0, r.stderr
     f = io.NcFile(path)
     exp = np.load(tmp_path / "long.npz")
-    for forced in ("1", None):
+    # forced, in ONE decode pass into a pool of output regions (the default) and as count + decode passes; then the default policy
+    for forced, passes in (("1", None), ("1", "2"), (None, None)):
         if forced:
             monkeypatch.setenv("ATLITE_HIP_INFLATE_SPLIT", forced)
         else:
             monkeypatch.delenv("ATLITE_HIP_INFLATE_SPLIT")
+        if passes:
+            monkeypatch.setenv("ATLITE_HIP_SPLIT_PASSES", passes)
+        else:
+            monkeypatch.delenv("ATLITE_HIP_SPLIT_PASSES", raising=False)
         for v in exp.files:
             d0, h0, r0 = ingest_stats(ctx)
             s0 = ingest_segments(ctx)
