@@ -8,6 +8,8 @@
 // verified; on ANY failure (format error, checksum mismatch, size mismatch) the caller falls back to
 // zlib's own inflate, so the fast path can only ever make things faster, never different.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <immintrin.h>
 
 #include <cstdint>
@@ -634,11 +636,18 @@ int device_inflate_split_emulated(const uint8_t *src, uint64_t src_n, uint8_t *d
         if (o.out_end != seg0[c] + res[chain[c]].out_end || o.end_bit != res[chain[c]].end_bit) return 102;  // both passes agree
     }
     // 4. resolve, segment after segment
+    uint64_t n_markers = 0;
     for (size_t c = 1; c < chain.size(); ++c) {
         const uint64_t end = c + 1 < chain.size() ? seg0[c + 1] : dst_n;
         for (uint64_t i = seg0[c]; i < end; ++i)
-            if (mark[i] & 0x80u) dst[i] = dst[seg0[c] - marker_back(dst[i], mark[i])];
+            if (mark[i] & 0x80u) {
+                dst[i] = dst[seg0[c] - marker_back(dst[i], mark[i])];
+                ++n_markers;
+            }
     }
+    if (getenv("ATLITE_HIP_INGEST_DEBUG"))
+        fprintf(stderr, "[atlite-hip inflate] segment scheme (host emulation): %zu segments, %llu of %llu bytes were markers\n", chain.size(),
+                (unsigned long long)n_markers, (unsigned long long)dst_n);
     return adler32_of(dst, dst_n) == want ? kOk : kAdler;
 }
 

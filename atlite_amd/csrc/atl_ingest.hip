@@ -928,7 +928,7 @@ struct ResDesc {
 // from a bump allocator as the segment grows - as one unit per byte (the byte, or a marker); when the chains are known k_gather copies
 // the segments to their places in the chunk, markers resolved on the way.
 constexpr uint32_t kRegionLog = 13;              // first region: 8192 units (bytes of output); region r holds 8192 << r
-constexpr uint32_t kMaxRegions = 14;             // 8192 * (2^14 - 1) > 64 MiB, the largest chunk the device path takes
+constexpr uint32_t kMaxRegions = 14;             // 8192 * (2^14 - 1) = 134 MB: the longest segment (beyond: the stream goes to the host decoders)
 struct PoolRef {
     uint16_t *pool;          // 16-bit units
     uint32_t *next;          // bump allocator, in units of 8192
@@ -1171,6 +1171,8 @@ __global__ __launch_bounds__(1024) void k_gather(const InfDesc *__restrict__ des
         s1 += base[i];
         s2 += (n - i) * base[i];
     }
+    s1 %= 65521ull;  // (chunks up to 1 GiB: a thread's weighted sum stays below 2^60, the workgroup's would not)
+    s2 %= 65521ull;
     for (int o = 32; o > 0; o >>= 1) {
         s1 += __shfl_xor(s1, o);
         s2 += __shfl_xor(s2, o);
@@ -1275,6 +1277,8 @@ __global__ __launch_bounds__(1024) void k_resolve(const InfDesc *__restrict__ de
         s1 += base[i];
         s2 += (n - i) * base[i];
     }
+    s1 %= 65521ull;  // (chunks up to 1 GiB: a thread's weighted sum stays below 2^60, the workgroup's would not)
+    s2 %= 65521ull;
     for (int o = 32; o > 0; o >>= 1) {
         s1 += __shfl_xor(s1, o);
         s2 += __shfl_xor(s2, o);
@@ -1920,6 +1924,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     std::vector<size_t> lin;
     std::vector<uint32_t> part_of, desc_of;
     size_t raw_off = 0, comp_off = 0;
+    bool big_chunks = false;
     for (int v = 0; v < n_vars; ++v) {
         const Dataset *d;
         Geometry g;
@@ -1930,7 +1935,10 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
         ATL_REQUIRE(d_outs[v], "atl_nc_read_slabs: d_out of '%s' is NULL", names[v]);
         if (d->layout != 2) return ATL_OK;  // compact / contiguous: the host path
         const int64_t chunk_bytes = g.chunk_elems * pt.p.dec.esize;
-        if (chunk_bytes > (int64_t(64) << 20)) return ATL_OK;
+        // whole-stream waves: chunks up to 64 MiB (wave_adler's sums); decoded block by block (split): up to 1 GiB - an 800 x 800
+        // grid in atlite's (100, y, x) chunks is 256 MB a chunk
+        if (chunk_bytes > (int64_t(1) << 30)) return ATL_OK;
+        if (chunk_bytes > (int64_t(64) << 20)) big_chunks = true;
         Selection sel;
         select_chunks(g, pt.p.r0, pt.p.r1, chunk_bytes, &sel);
         pt.ds = d;
@@ -1976,6 +1984,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     if (parts.empty() || inf.empty()) return ATL_OK;
     // few, long streams (atlite's own cutouts: (time = 100, y, x) chunks): their blocks are decoded side by side (launch_split below)
     const bool split = split_wanted(inf);
+    if (big_chunks && !split) return ATL_OK;  // (the host path)
     const bool fed = fed_mode() && !split;
     // batches of consecutive streams
     size_t batch_bytes = size_t(128) << 20;
@@ -2401,7 +2410,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     // ---- the batches ----------------------------------------------------------------------------------------------------------
     const int fd = f->file.fd();
     const uint8_t *base = f->file.base();
-    const int nt = pick_threads(n_threads, batches.empty() ? 1 : batches[0].count);
+    const size_t nt_max = size_t(pick_threads(n_threads, size_t(1) << 20));
     double gather_ms = 0;
     ATL_HIP_TRY(hipEventRecord(sl->ev_c[0], sl->st_c));
     size_t fed_batches = 0, flagged = 0;
@@ -2429,19 +2438,33 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
         if (!rc) rc = set_flags(false);
         if (rc) break;
         const auto t_gather = std::chrono::steady_clock::now();
-        rc = parallel_for(bt.count, nt, [&](size_t k) -> int {
-            const size_t i = bt.first + k;
+        // pieces of at most 8 MiB, so that a batch of one or two long streams still keeps every thread reading
+        struct Piece {
+            size_t stream;
+            uint64_t off, len;
+        };
+        std::vector<Piece> pieces;
+        for (size_t k = 0; k < bt.count; ++k) {
+            const uint64_t want = uint64_t(job.inf[bt.first + k].src_n);
+            for (uint64_t o = 0; o < want || o == 0; o += uint64_t(8) << 20) {
+                pieces.push_back(Piece{bt.first + k, o, std::min<uint64_t>(uint64_t(8) << 20, want - o)});
+                if (want == 0) break;
+            }
+        }
+        rc = parallel_for(pieces.size(), int(std::max<size_t>(1, std::min(nt_max, pieces.size()))), [&](size_t k) -> int {
+            const Piece &pc = pieces[k];
+            const size_t i = pc.stream;
             const h5::Chunk &c = job.parts[job.part_of[i]].ds->chunks[job.lin[i]];
             uint8_t *dst = ring->h + (size_t(job.inf[i].src_off) - bt.off);
-            const uint64_t want = uint64_t(job.inf[i].src_n);
-            uint64_t got = 0;
-            while (fd >= 0 && got < want) {  // straight into the pinned ring (a mapping's page faults contend across threads)
-                const ssize_t r = pread(fd, dst + got, size_t(want - got), off_t(c.addr + got));
+            const uint64_t want = uint64_t(job.inf[i].src_n), end = pc.off + pc.len;
+            uint64_t got = pc.off;
+            while (fd >= 0 && got < end) {  // straight into the pinned ring (a mapping's page faults contend across threads)
+                const ssize_t r = pread(fd, dst + got, size_t(end - got), off_t(c.addr + got));
                 if (r <= 0) break;
                 got += uint64_t(r);
             }
-            if (got < want) memcpy(dst + got, base + c.addr + got, size_t(want - got));
-            memset(dst + want, 0, size_t(align_up(size_t(want) + 8, 128) - want));  // the bit reader's look-ahead words
+            if (got < end) memcpy(dst + got, base + c.addr + got, size_t(end - got));
+            if (end == want) memset(dst + want, 0, size_t(align_up(size_t(want) + 8, 128) - want));  // the bit reader's look-ahead words
             return ATL_OK;
         });
         gather_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_gather).count();
