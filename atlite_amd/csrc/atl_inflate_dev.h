@@ -782,6 +782,7 @@ template <class M, class W, class Win, class Sink, class Splits>
 ATL_HD inline int inflate_segment(const Areas<M> &A, typename M::src_t w, uint32_t n_words, uint64_t src_n, uint64_t start_bit,
                                   uint64_t seg0, uint32_t slack, uint64_t out_n, const Splits &splits, Sink &sink, SegOut *r) {
     if (src_n < 6 || n_words == 0) return kBadHeader;
+    if (start_bit == 16 && !zlib_header_ok(M::src(w, 0))) return kBadHeader;  // (the stream's first segment vouches for the wrapper)
     if (out_n >= (uint64_t(1) << 31)) return kOutputFull;  // 32-bit positions inside a batch
     init_sym<M, W>(A);
     Bits<M> b;

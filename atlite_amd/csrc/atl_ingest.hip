@@ -1779,6 +1779,11 @@ static int finish_slot_impl(atl_ctx *ctx, IngestState *st, Slot &sl) {
         ATL_HIP_TRY(hipEventSynchronize(sl.ev));
     }
     sl.joined = true;
+    if (sl.d_pool && sl.pool_bytes > (size_t(4) << 30)) {  // a year's pool of segment regions is tens of GB: not kept between reads
+        (void)dev_free(sl.d_pool);
+        sl.d_pool = nullptr;
+        sl.pool_bytes = 0;
+    }
     Pending &job = sl.job;
     if (!job.active) return ATL_OK;
     job.active = false;
