@@ -304,7 +304,7 @@ def main(out):
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--cutout":  # --cutout path T Y X ct cy cx dtype seed [threads ["pv"]]
         a = sys.argv[2:]
-        write_cutout(a[0], int(a[1]), int(a[2]), int(a[3]), (int(a[4]), int(a[5]), int(a[6])), a[7], int(a[8]), gzip=1,
+        write_cutout(a[0], int(a[1]), int(a[2]), int(a[3]), (int(a[4]), int(a[5]), int(a[6])), a[7], int(a[8]), gzip=int(os.environ.get("ATL_FIXTURE_GZIP", "1")),
                      threads=int(a[9]) if len(a) > 9 else 1, only=PV_VARS if len(a) > 10 and a[10] == "pv" else None)
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "--case":  # --case path T Y X ct cy cx libver track seed [unlimited axes, e.g. 0 or 01]
