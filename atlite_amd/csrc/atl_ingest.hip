@@ -1337,6 +1337,8 @@ struct Slot {
     hipEvent_t ev = nullptr;
     hipEvent_t ev_fork[2] = {nullptr, nullptr};
     hipStream_t st = nullptr;    // device path: the slot's kernel stream (two reads in flight overlap)
+    hipStream_t st2 = nullptr;   // ... segments decoded block by block: the decode kernels' stream (beside the finder's, behind the DMAs)
+    hipEvent_t ev_st2 = nullptr;
     hipStream_t st_c = nullptr;  // ... and its copy stream: the batches' DMAs run beside the kernel that waits for them
     hipEvent_t ev_t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // device path: stage boundaries (timing)
     hipEvent_t ev_c[2] = {nullptr, nullptr};                             // ... first / last DMA on st_c
@@ -1415,7 +1417,8 @@ void ingest_free(void *p) {
             if (sl.pending) (void)hipEventSynchronize(sl.ev);
             (void)hipEventDestroy(sl.ev);
         }
-        for (hipStream_t q : {sl.st, sl.st_c})
+        if (sl.ev_st2) (void)hipEventDestroy(sl.ev_st2);
+        for (hipStream_t q : {sl.st, sl.st_c, sl.st2})
             if (q) {
                 (void)hipStreamSynchronize(q);
                 (void)hipStreamDestroy(q);
@@ -2408,8 +2411,197 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
         ATL_HIP_TRY(hipEventRecord(sl->ev_t[3], q));
         return ATL_OK;
     };
+    // ---- ... the one-pass variant as stages on a second stream: op_launch (tasks from the finder's lists, the kernel, its results on
+    // the way back) for a range of streams, then the chains of all stages are followed and ONE k_gather places them (op_finish).
+    // The pool of output regions is reserved for the whole job up front (op_prepare; no room: the single stage above, count +
+    // decode).  ONE stage, when the last batch has landed, is what runs: launching the first half's segments when half of the
+    // batches were on the device - to decode inside the DMAs - was measured (T = 2000: 0.118-0.121 s against 0.096-0.101): the
+    // decode kernel fills every CU, the remaining batches' copies and finder kernels stall until it ends (DMAs first to last 72 ms
+    // instead of 21), and the kernel itself runs slower beside them.
+    struct OpStage {
+        size_t i0, i1, t_base, n_task;
+        std::vector<size_t> task0, cand0;
+    };
+    std::vector<OpStage> op_stages;
+    bool op_ready = false;
+    PoolRef op_pr{};
+    size_t op_gseg = 0, op_rd = 0;
+    auto op_prepare = [&]() -> int {
+        if (!split) return ATL_OK;
+        if (const char *e = getenv("ATLITE_HIP_SPLIT_PASSES"))
+            if (atoi(e) == 2) return ATL_OK;
+        double out_bytes = 0;
+        for (const InfDesc &q : job.inf) out_bytes += double(q.dst_n);
+        // 1.75 x the output (a segment's last region is at most half used) + a first region for every task there may be
+        const size_t cap_regions = size_t((1.75 * out_bytes) / 8192.0) + (n + 4 * n_spans) + 1024;
+        if (cap_regions >= (size_t(1) << 32)) return ATL_OK;
+        const size_t b_pool = cap_regions * 8192 * sizeof(uint16_t), off_regs = align_up(b_pool, 256),
+                     off_next = align_up(off_regs + t_max * kMaxRegions * sizeof(uint32_t), 256);
+        op_gseg = off_next + 256;
+        op_rd = align_up(op_gseg + (t_max + n + 1) * sizeof(GatherSeg), 256);
+        const size_t need = op_rd + (n + 1) * sizeof(ResDesc) + 256;
+        if (sl->pool_bytes < need) {
+            if (sl->d_pool) (void)dev_free(sl->d_pool);
+            sl->d_pool = nullptr;
+            sl->pool_bytes = 0;
+            if (dev_malloc(reinterpret_cast<void **>(&sl->d_pool), need) != hipSuccess) {
+                (void)hipGetLastError();
+                sl->d_pool = nullptr;
+                return ATL_OK;  // (no room: count + decode at the end)
+            }
+            sl->pool_bytes = need;
+        }
+        if (!sl->st2) ATL_HIP_TRY(hipStreamCreateWithFlags(&sl->st2, hipStreamNonBlocking));
+        if (!sl->ev_st2) ATL_HIP_TRY(hipEventCreateWithFlags(&sl->ev_st2, hipEventDisableTiming));
+        op_pr.pool = reinterpret_cast<uint16_t *>(sl->d_pool);
+        op_pr.regs = reinterpret_cast<uint32_t *>(sl->d_pool + off_regs);
+        op_pr.next = reinterpret_cast<uint32_t *>(sl->d_pool + off_next);
+        op_pr.cap = uint32_t(cap_regions);
+        ATL_HIP_TRY(hipStreamWaitEvent(sl->st2, sl->ev_meta, 0));  // (the descriptors)
+        ATL_HIP_TRY(hipMemsetAsync(op_pr.next, 0, 256, sl->st2));
+        op_ready = true;
+        return ATL_OK;
+    };
+    auto op_launch = [&](size_t i0, size_t i1) -> int {  // streams [i0, i1): their bytes are on the device, their finder enqueued
+        if (i1 <= i0) return ATL_OK;
+        const std::vector<InfDesc> &jn = job.inf;
+        uint32_t *h_out = reinterpret_cast<uint32_t *>(sl->h + s_out);
+        const size_t k0 = span0[i0], k1 = span0[i1];
+        if (k1 > k0)
+            ATL_HIP_TRY(hipMemcpyAsync(h_out + k0 * kSpanWords, d_meta + s_out + k0 * kSpanWords * sizeof(uint32_t), (k1 - k0) * kSpanWords * sizeof(uint32_t),
+                                       hipMemcpyDeviceToHost, sl->st));
+        ATL_HIP_TRY(hipStreamSynchronize(sl->st));  // the finder's lists
+        uint32_t *h_cand = reinterpret_cast<uint32_t *>(sl->h + s_cand);
+        SegTask *h_task = reinterpret_cast<SegTask *>(sl->h + s_task);
+        OpStage stg;
+        stg.i0 = i0;
+        stg.i1 = i1;
+        stg.t_base = so_task;
+        const size_t ni = i1 - i0, c_base = so_cand, t_base = so_task;
+        stg.task0.assign(ni + 1, 0);
+        stg.cand0.assign(ni + 1, 0);
+        size_t nc = c_base, ntask = t_base;
+        for (size_t i = i0; i < i1; ++i) {
+            stg.cand0[i - i0] = nc;
+            stg.task0[i - i0] = ntask;
+            for (size_t k = span0[i]; k < span0[i + 1]; ++k) {
+                const uint32_t cnt = std::min(h_out[k * kSpanWords], kSpanSlots);
+                uint32_t *c = h_out + k * kSpanWords + 1;
+                std::sort(c, c + cnt);
+                for (uint32_t j = 0; j < cnt; ++j) h_cand[nc++] = c[j];
+            }
+            const uint32_t ncs = uint32_t(nc - stg.cand0[i - i0]), c0 = uint32_t(stg.cand0[i - i0]);
+            h_task[ntask] = SegTask{uint32_t(i), 16u, 0u, c0, ncs, uint32_t(ntask), 0u};
+            ++ntask;
+            for (uint32_t j = 0; j < ncs; ++j) {
+                h_task[ntask] = SegTask{uint32_t(i), h_cand[c0 + j], dinf::kSegSlack, c0, ncs, uint32_t(ntask), 0u};
+                ++ntask;
+            }
+        }
+        stg.cand0[ni] = nc;
+        stg.task0[ni] = ntask;
+        ATL_REQUIRE(ntask <= t_max && nc <= t_max, "atl_nc_read_slabs: segment lists");
+        const size_t n_count = ntask - t_base;
+        stg.n_task = n_count;
+        SegTask *h_sorted = reinterpret_cast<SegTask *>(sl->h + s_res) + t_base;  // (the results' page-locked place: they land behind the kernel)
+        {  // longest first: the compressed bits up to the next split point stand for the work
+            std::vector<std::pair<uint64_t, uint32_t>> order(n_count);
+            for (size_t t = 0; t < n_count; ++t) {
+                const SegTask &tk = h_task[t_base + t];
+                const bool last_of_stream = t + 1 == n_count || h_task[t_base + t + 1].stream != tk.stream;
+                const uint64_t end = last_of_stream ? uint64_t(jn[tk.stream].src_n) * 8 : uint64_t(h_task[t_base + t + 1].start_bit);
+                order[t] = {end - tk.start_bit, uint32_t(t)};
+            }
+            std::sort(order.begin(), order.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+            for (size_t t = 0; t < n_count; ++t) h_sorted[t] = h_task[t_base + order[t].second];
+        }
+        hipStream_t q2 = sl->st2;
+        const SegTask *d_task = reinterpret_cast<const SegTask *>(d_meta + s_task);
+        SegRes *d_sres = reinterpret_cast<SegRes *>(d_meta + s_res);
+        if (nc > c_base)
+            ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_cand + c_base * sizeof(uint32_t), h_cand + c_base, (nc - c_base) * sizeof(uint32_t), hipMemcpyHostToDevice, q2));
+        ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_task + t_base * sizeof(SegTask), h_sorted, n_count * sizeof(SegTask), hipMemcpyHostToDevice, q2));
+        hipLaunchKernelGGL(k_segments_pool, dim3(unsigned(n_count)), dim3(64), 0, q2, sl->d, d_inf, d_task + t_base,
+                           reinterpret_cast<const uint32_t *>(d_meta + s_cand), op_pr, d_sres);
+        ATL_HIP_TRY(hipGetLastError());
+        ATL_HIP_TRY(hipMemcpyAsync(reinterpret_cast<SegRes *>(sl->h + s_res) + t_base, d_sres + t_base, n_count * sizeof(SegRes), hipMemcpyDeviceToHost, q2));
+        so_cand = nc;
+        so_task = ntask;
+        op_stages.push_back(std::move(stg));
+        return ATL_OK;
+    };
+    auto op_finish = [&]() -> int {
+        hipStream_t q2 = sl->st2;
+        ATL_HIP_TRY(hipStreamSynchronize(q2));  // every stage's results
+        const std::vector<InfDesc> &jn = job.inf;
+        const SegRes *h_res = reinterpret_cast<const SegRes *>(sl->h + s_res);
+        const uint32_t *h_cand = reinterpret_cast<const uint32_t *>(sl->h + s_cand);
+        std::vector<GatherSeg> gs;
+        std::vector<ResDesc> rds;
+        size_t n_seg_total = 0, n_tasks = 0;
+        for (const OpStage &stg : op_stages) {
+            n_tasks += stg.n_task;
+            for (size_t i = stg.i0; i < stg.i1; ++i) {
+                const size_t li = i - stg.i0, g0 = gs.size();
+                uint64_t at = 0;
+                bool ok = true;
+                uint32_t want = 0;
+                for (size_t t = stg.task0[li];;) {
+                    const SegRes &r = h_res[t];
+                    if (r.status != dinf::kOk || r.o.out_end == 0 || at + r.o.out_end > uint64_t(jn[i].dst_n) ||
+                        gs.size() - g0 > size_t(stg.task0[li + 1] - stg.task0[li])) {
+                        ok = false;
+                        break;
+                    }
+                    gs.push_back(GatherSeg{uint32_t(t), uint32_t(at)});
+                    at += r.o.out_end;
+                    if (r.o.is_final) {
+                        want = r.o.adler;
+                        break;
+                    }
+                    const uint32_t *c = h_cand + stg.cand0[li], *ce = h_cand + stg.cand0[li + 1];
+                    const uint32_t *it = std::lower_bound(c, ce, uint32_t(r.o.end_bit));
+                    if (it == ce || *it != uint32_t(r.o.end_bit)) {
+                        ok = false;
+                        break;
+                    }
+                    t = stg.task0[li] + 1 + size_t(it - c);
+                }
+                if (!ok || at != uint64_t(jn[i].dst_n)) {  // the host decoders take the stream
+                    gs.resize(g0);
+                    continue;
+                }
+                rds.push_back(ResDesc{uint32_t(i), uint32_t(g0), uint32_t(gs.size() - g0), want});
+                n_seg_total += gs.size() - g0;
+                gs.push_back(GatherSeg{0u, uint32_t(at)});
+            }
+        }
+        state->ms[3] += double(n_seg_total);  // (a count: atl_nc_ingest_times)
+        if (dbg) {
+            uint32_t used = 0;
+            ATL_HIP_TRY(hipMemcpy(&used, op_pr.next, sizeof used, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[atlite-hip ingest] split, one pass in %zu stage(s): %zu streams, %zu spans, %zu tasks, %zu streams chained into %zu segments; "
+                    "the pool: %u of %u regions of 16 KiB used\n", op_stages.size(), n, n_spans, n_tasks, rds.size(), n_seg_total, used, op_pr.cap);
+        }
+        if (!rds.empty()) {
+            ATL_REQUIRE(gs.size() <= t_max + n + 1 && rds.size() <= n, "atl_nc_read_slabs: segment lists");
+            ATL_HIP_TRY(hipMemcpyAsync(sl->d_pool + op_gseg, gs.data(), gs.size() * sizeof(GatherSeg), hipMemcpyHostToDevice, q2));
+            ATL_HIP_TRY(hipMemcpyAsync(sl->d_pool + op_rd, rds.data(), rds.size() * sizeof(ResDesc), hipMemcpyHostToDevice, q2));
+            ATL_HIP_TRY(hipStreamSynchronize(q2));  // (the lists are on the stack)
+            hipLaunchKernelGGL(k_gather, dim3(unsigned(rds.size())), dim3(1024), 0, q2, d_inf, reinterpret_cast<const ResDesc *>(sl->d_pool + op_rd),
+                               reinterpret_cast<const GatherSeg *>(sl->d_pool + op_gseg), op_pr, sl->d_raw, d_res);
+            ATL_HIP_TRY(hipGetLastError());
+        }
+        ATL_HIP_TRY(hipEventRecord(sl->ev_st2, q2));
+        ATL_HIP_TRY(hipStreamWaitEvent(sl->st, sl->ev_st2, 0));  // the slot's stream goes on behind the gather: unpack, verdicts
+        return split_finish();
+    };
     if (fed) {
         rc = launch();
+        if (rc) return rc;
+    }
+    if (split) {
+        rc = op_prepare();
         if (rc) return rc;
     }
     // ---- the batches ----------------------------------------------------------------------------------------------------------
@@ -2496,7 +2688,11 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     (void)hipEventRecord(sl->ev_c[1], sl->st_c);
     if (!rc && !fed) {  // the unfed order (A/B, $ATLITE_HIP_INGEST_FED=0): every byte first, then the launch
         ATL_HIP_TRY(hipStreamWaitEvent(sl->st, sl->ev_c[1], 0));
-        if (split) {
+        if (split && op_ready) {
+            rc = op_launch(op_stages.empty() ? 0 : op_stages.back().i1, n);
+            if (!rc) rc = op_finish();
+            if (rc) (void)hipStreamSynchronize(sl->st2);
+        } else if (split) {
             rc = split_stage(0, n);
             if (!rc) rc = split_finish();
         } else {
@@ -2513,6 +2709,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     sl->joined = false;
     job.active = true;
     if (rc) {
+        if (split && sl->st2) (void)hipStreamSynchronize(sl->st2);  // (an early stage's kernel may still be reading the slot)
         job.aborted = true;
         return rc;
     }
