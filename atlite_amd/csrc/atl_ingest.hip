@@ -2155,9 +2155,9 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
         ATL_HIP_TRY(hipGetLastError());
         return ATL_OK;
     };
-    // The split order: a batch's block headers are found as soon as its bytes are on the device (find_batch, behind the DMAs);
-    // when everything has arrived the segments are counted, the chains followed (host), the segments decoded and resolved
-    // (split_stage over all streams).  The host reads the device's lists between the passes, so the stage blocks the calling
+    // The split order, COUNT + DECODE variant ($ATLITE_HIP_SPLIT_PASSES=2, or no room for the one-pass variant's pool - op_* below):
+    // a batch's block headers are found as soon as its bytes are on the device (find_batch, behind the DMAs); when everything has
+    // arrived the segments are counted, the chains followed (host), the segments decoded and resolved (split_stage over all streams).  The host reads the device's lists between the passes, so the stage blocks the calling
     // thread.  (split_stage takes a range of streams: a stage per batch, overlapping the next batch's DMA, was measured -
     // T = 2000 of 16 MB chunks 0.190 s in 256 MiB batches, 0.158 in 512 MiB, 0.132 s as ONE stage: a launch lasts as long as its
     // longest segment, a lone wave makes ~10 MB/s, and every batch has a long segment or two.)  A stream whose chain does not
@@ -2227,43 +2227,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
             for (size_t t = 0; t < n_count; ++t) h_sorted[t] = h_task[t_base + order[t].second];
         }
         ATL_HIP_TRY(hipMemcpyAsync(d_meta + s_task + t_base * sizeof(SegTask), h_sorted, n_count * sizeof(SegTask), hipMemcpyHostToDevice, q));
-        // ONE decode pass into a pool of output regions (default), or count + decode ($ATLITE_HIP_SPLIT_PASSES=2; also when the pool
-        // cannot be had): the pool holds a 16-bit unit per output byte, a segment wastes less than it makes + one first region
-        bool one_pass = true;
-        if (const char *e = getenv("ATLITE_HIP_SPLIT_PASSES")) one_pass = atoi(e) != 2;
-        PoolRef pr{};
-        size_t off_gseg = 0, off_rd = 0;
-        if (one_pass) {
-            double out_bytes = 0;
-            for (size_t i = i0; i < i1; ++i) out_bytes += double(jn[i].dst_n);
-            const size_t cap_regions = size_t((1.75 * out_bytes + 8192.0 * double(n_count)) / 8192.0) + 1024;
-            const size_t b_pool = cap_regions * 8192 * sizeof(uint16_t), off_regs = align_up(b_pool, 256),
-                         off_next = align_up(off_regs + n_count * kMaxRegions * sizeof(uint32_t), 256);
-            off_gseg = off_next + 256;
-            off_rd = align_up(off_gseg + (n_count + ni + 1) * sizeof(GatherSeg), 256);
-            const size_t need = off_rd + (ni + 1) * sizeof(ResDesc) + 256;
-            if (cap_regions >= (size_t(1) << 32)) one_pass = false;
-            if (one_pass && sl->pool_bytes < need) {
-                if (sl->d_pool) (void)dev_free(sl->d_pool);
-                sl->d_pool = nullptr;
-                sl->pool_bytes = 0;
-                if (dev_malloc(reinterpret_cast<void **>(&sl->d_pool), need) == hipSuccess) {
-                    sl->pool_bytes = need;
-                } else {
-                    (void)hipGetLastError();
-                    sl->d_pool = nullptr;
-                    one_pass = false;  // no room for the pool: count + decode
-                }
-            }
-            if (one_pass) {
-                pr.pool = reinterpret_cast<uint16_t *>(sl->d_pool);
-                pr.regs = reinterpret_cast<uint32_t *>(sl->d_pool + off_regs);
-                pr.next = reinterpret_cast<uint32_t *>(sl->d_pool + off_next);
-                pr.cap = uint32_t(cap_regions);
-                ATL_HIP_TRY(hipMemsetAsync(pr.next, 0, 256, q));
-            }
-        }
-        if (!one_pass) {  // the mark plane behind the inflated chunks (nothing has been written there yet)
+        {  // the mark plane behind the inflated chunks (nothing has been written there yet)
             if (sl->raw_bytes < 2 * mark_off) {
                 ATL_HIP_TRY(hipStreamSynchronize(q));
                 if (sl->d_raw) (void)dev_free(sl->d_raw);
@@ -2274,10 +2238,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
             }
             d_mark = sl->d_raw + mark_off;
         }
-        if (one_pass)
-            hipLaunchKernelGGL(k_segments_pool, dim3(unsigned(n_count)), dim3(64), 0, q, sl->d, d_inf, d_task + t_base, d_cand, pr, d_sres + t_base);
-        else
-            hipLaunchKernelGGL((k_segments<true>), dim3(unsigned(n_count)), dim3(64), 0, q, sl->d, d_inf, d_task + t_base, d_cand, sl->d_raw, d_mark, d_sres + t_base);
+        hipLaunchKernelGGL((k_segments<true>), dim3(unsigned(n_count)), dim3(64), 0, q, sl->d, d_inf, d_task + t_base, d_cand, sl->d_raw, d_mark, d_sres + t_base);
         ATL_HIP_TRY(hipGetLastError());
         ATL_HIP_TRY(hipMemcpyAsync(h_res + t_base, d_sres + t_base, n_count * sizeof(SegRes), hipMemcpyDeviceToHost, q));
         ATL_HIP_TRY(hipStreamSynchronize(q));
@@ -2302,7 +2263,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
                 SegTask tk = h_task[t];
                 tk.seg0 = at;
                 tk.slack = uint32_t(std::min<uint64_t>(dinf::kSegSlack, at));
-                tk.res_ix = uint32_t(t - t_base);  // (one pass: whose regions; count + decode: renumbered below)
+                tk.res_ix = uint32_t(run.size());
                 run.push_back(tk);
                 run_len.push_back(r.o.out_end);
                 bounds.push_back(uint32_t(at));
@@ -2334,36 +2295,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
             fprintf(stderr, "[atlite-hip ingest] split: streams %zu .. %zu, %zu spans, %zu candidate headers, %zu streams chained into %zu segments; "
                     "find (wait) %.1f ms, count pass %.1f ms, chains (host) %.1f ms\n", i0, i1, k1 - k0, nc - c_base, rds.size(), run.size(), ms_find, ms_count,
                     ms_chain);
-        if (one_pass && !run.empty()) {  // the segments' units -> the chunks' bytes
-            std::vector<GatherSeg> gs;
-            gs.reserve(run.size() + rds.size());
-            for (ResDesc &rd : rds) {  // (rd.bound0 indexes `bounds`: so_bound + b0, n_seg + 1 entries per stream)
-                const size_t b0 = rd.bound0 - so_bound, g0 = gs.size();
-                // the stream's tasks lie in `run` in the same order as its bounds: find them by walking both
-                for (uint32_t c = 0; c < rd.n_seg; ++c) gs.push_back(GatherSeg{0u, bounds[b0 + c]});
-                gs.push_back(GatherSeg{0u, bounds[b0 + rd.n_seg]});
-                rd.bound0 = uint32_t(g0);
-            }
-            {  // tasks: `run` holds the chained segments stream after stream, in the order of `rds`
-                size_t g = 0, t = 0;
-                for (const ResDesc &rd : rds) {
-                    for (uint32_t c = 0; c < rd.n_seg; ++c) gs[g++].task = run[t++].res_ix;
-                    ++g;
-                }
-            }
-            ATL_HIP_TRY(hipMemcpyAsync(sl->d_pool + off_gseg, gs.data(), gs.size() * sizeof(GatherSeg), hipMemcpyHostToDevice, q));
-            ATL_HIP_TRY(hipMemcpyAsync(sl->d_pool + off_rd, rds.data(), rds.size() * sizeof(ResDesc), hipMemcpyHostToDevice, q));
-            ATL_HIP_TRY(hipStreamSynchronize(q));  // (the lists are on the stack)
-            hipLaunchKernelGGL(k_gather, dim3(unsigned(rds.size())), dim3(1024), 0, q, d_inf, reinterpret_cast<const ResDesc *>(sl->d_pool + off_rd),
-                               reinterpret_cast<const GatherSeg *>(sl->d_pool + off_gseg), pr, sl->d_raw, d_res);
-            ATL_HIP_TRY(hipGetLastError());
-            if (dbg) {
-                uint32_t used = 0;
-                ATL_HIP_TRY(hipMemcpyAsync(&used, pr.next, sizeof used, hipMemcpyDeviceToHost, q));
-                ATL_HIP_TRY(hipStreamSynchronize(q));
-                fprintf(stderr, "[atlite-hip ingest] split: one decode pass; the pool: %u of %u regions of 16 KiB used\n", used, pr.cap);
-            }
-        } else if (!run.empty()) {
+        if (!run.empty()) {
             // the decode pass's tasks take the place of the count pass's (which nobody reads again)
             ATL_REQUIRE(run.size() <= n_count && so_bound + bounds.size() <= t_max + n && so_rd + rds.size() <= n, "atl_nc_read_slabs: segment lists");
             {  // longest first, as the count pass (res_ix: results in chain order; a stream dropped above leaves a gap in the numbering)
