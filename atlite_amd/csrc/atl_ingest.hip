@@ -2346,16 +2346,19 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     // ---- ... the one-pass variant as stages on a second stream: op_launch (tasks from the finder's lists, the kernel, its results on
     // the way back) for a range of streams, then the chains of all stages are followed and ONE k_gather places them (op_finish).
     // The pool of output regions is reserved for the whole job up front (op_prepare; no room: the single stage above, count +
-    // decode).  ONE stage, when the last batch has landed, is what runs: launching the first half's segments when half of the
-    // batches were on the device - to decode inside the DMAs - was measured (T = 2000: 0.118-0.121 s against 0.096-0.101): the
-    // decode kernel fills every CU, the remaining batches' copies and finder kernels stall until it ends (DMAs first to last 72 ms
-    // instead of 21), and the kernel itself runs slower beside them.
+    // decode).  ONE stage, when the last batch has landed, is what runs.  Launching the first half's segments when half of the
+    // batches are on the device - to decode inside the DMAs - is $ATLITE_HIP_SPLIT_EARLY and was measured twice (T = 2000):
+    // with the results' copy queued behind the early kernel 0.118-0.121 s against 0.096-0.101 - that copy sits at the head of a
+    // copy engine's queue until the kernel ends, and the later batches' DMAs wait behind it (first to last 72 ms instead of 21);
+    // with the results fetched at the end 0.107-0.108 s against 0.096-0.102: the DMAs run on, but two launches have two tails, the
+    // finder's workgroups (46 kB of LDS) wait for the decode kernel's CUs, and the kernel is slower beside them.
     struct OpStage {
         size_t i0, i1, t_base, n_task;
         std::vector<size_t> task0, cand0;
     };
     std::vector<OpStage> op_stages;
     bool op_ready = false;
+    const bool op_early = getenv("ATLITE_HIP_SPLIT_EARLY") != nullptr;
     PoolRef op_pr{};
     size_t op_gseg = 0, op_rd = 0;
     auto op_prepare = [&]() -> int {
@@ -2456,7 +2459,8 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
         hipLaunchKernelGGL(k_segments_pool, dim3(unsigned(n_count)), dim3(64), 0, q2, sl->d, d_inf, d_task + t_base,
                            reinterpret_cast<const uint32_t *>(d_meta + s_cand), op_pr, d_sres);
         ATL_HIP_TRY(hipGetLastError());
-        ATL_HIP_TRY(hipMemcpyAsync(reinterpret_cast<SegRes *>(sl->h + s_res) + t_base, d_sres + t_base, n_count * sizeof(SegRes), hipMemcpyDeviceToHost, q2));
+        // (its results are fetched in op_finish: a copy queued behind the kernel would sit at the head of a copy engine's queue
+        //  and hold up the batches' DMAs that are issued after it)
         so_cand = nc;
         so_task = ntask;
         op_stages.push_back(std::move(stg));
@@ -2464,6 +2468,9 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     };
     auto op_finish = [&]() -> int {
         hipStream_t q2 = sl->st2;
+        for (const OpStage &stg : op_stages)
+            ATL_HIP_TRY(hipMemcpyAsync(reinterpret_cast<SegRes *>(sl->h + s_res) + stg.t_base, reinterpret_cast<SegRes *>(d_meta + s_res) + stg.t_base,
+                                       stg.n_task * sizeof(SegRes), hipMemcpyDeviceToHost, q2));
         ATL_HIP_TRY(hipStreamSynchronize(q2));  // every stage's results
         const std::vector<InfDesc> &jn = job.inf;
         const SegRes *h_res = reinterpret_cast<const SegRes *>(sl->h + s_res);
@@ -2609,7 +2616,10 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
         ring->busy = true;
         fed_batches = b + 1;
         rc = set_flags(false);
-        if (!rc && split) rc = find_batch(b);
+        if (!rc && split) {
+            if (op_ready && op_early && nb >= 4 && b == nb / 2) rc = op_launch(0, batches[b].first);  // (an experiment: op_launch's comment)
+            if (!rc) rc = find_batch(b);
+        }
     }
     if (!rc) rc = set_flags(true);  // the call returns when its last DMA has landed; the kernel goes on by itself
     state->ms[0] += gather_ms;
