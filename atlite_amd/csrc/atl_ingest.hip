@@ -1323,6 +1323,7 @@ struct Pending {
     std::vector<InfDesc> inf;
     size_t off_unp = 0;              // device: the UnpackDesc array inside sl.d
     size_t off_res = 0;              // host: the InfResult array inside sl.h
+    size_t off_res_dev = 0;          // ... and inside sl.d (fetched when the slot is settled: finish_slot)
     size_t off_flag = 0;             // host: the batches' arrival flags inside sl.h
 };
 
@@ -1802,6 +1803,8 @@ static int finish_slot_impl(atl_ctx *ctx, IngestState *st, Slot &sl) {
         st->comp_bytes += q.src_n;
         st->raw_bytes += q.dst_n;
     }
+    ATL_HIP_TRY(hipSetDevice(ctx->device));
+    ATL_HIP_TRY(hipMemcpy(sl.h + job.off_res, sl.d + job.off_res_dev, job.inf.size() * sizeof(InfResult), hipMemcpyDeviceToHost));  // (the kernels are done: sl.ev)
     const InfResult *res = reinterpret_cast<const InfResult *>(sl.h + job.off_res);
     std::vector<size_t> bad;
     for (size_t i = 0; i < job.inf.size(); ++i)
@@ -2123,6 +2126,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     job.inf = std::move(inf);
     job.off_unp = off_meta + m_unp;
     job.off_res = m_res;
+    job.off_res_dev = off_meta + m_res;
     job.off_flag = m_flag;
     job.aborted = false;
     // split jobs: the finder's spans (64 KiB of a stream each) go up with the descriptors; a batch's spans are searched as soon as
@@ -2642,9 +2646,11 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
         }
     }
     if (fed || !rc) {
-        // the verdicts come back behind the kernel AND the last DMA (an aborted job's kernel may end before its flags' DMAs)
+        // the slot's event comes behind the kernel AND the last DMA (an aborted job's kernel may end before its flags' DMAs).  The
+        // verdicts are fetched when the slot is settled (finish_slot), not queued here: a copy that waits for a kernel sits at the
+        // head of a copy engine's queue and holds up every copy issued after it - the next job's or the next read's DMAs
+        // (measured on the segment scheme's stages: profiles/r06_ingest.txt)
         (void)hipStreamWaitEvent(sl->st, sl->ev_c[1], 0);
-        (void)hipMemcpyAsync(sl->h + m_res, d_res, n * sizeof(InfResult), hipMemcpyDeviceToHost, sl->st);
     }
     (void)hipEventRecord(sl->ev, sl->st);
     sl->pending = true;
