@@ -1124,9 +1124,9 @@ __global__ __launch_bounds__(1024) void k_gather(const InfDesc *__restrict__ des
         const uint32_t h = min((4u - (s0 & 3u)) & 3u, len), nw = (len - h) >> 2, t0 = h + 4u * nw;
         if (tid < h) base[s0 + tid] = uint8_t(byte_of(unit(tid)));
         if (tid >= 32 && tid - 32 < len - t0) base[s0 + t0 + (tid - 32)] = uint8_t(byte_of(unit(t0 + (tid - 32))));
-        for (uint32_t k = tid; k < nw; k += nt) {
-            const uint32_t i = h + 4u * k;
-            uint32_t v[4];
+        // the four units of a word: loaded together, then the markers' source bytes together (they lie before s0: final), one store;
+        // two words per step
+        auto units4 = [&](uint32_t i, uint32_t *v) {
             if ((i & 1u) == 0u) {  // two aligned pairs (a pair never straddles regions: they begin at multiples of 8192)
                 auto pair = [&](uint32_t p) -> uint32_t {
                     const uint32_t r = region_of(p);
@@ -1141,10 +1141,46 @@ __global__ __launch_bounds__(1024) void k_gather(const InfDesc *__restrict__ des
 #pragma unroll
                 for (uint32_t j = 0; j < 4; ++j) v[j] = unit(i + j);
             }
+        };
+        auto sources4 = [&](const uint32_t *v, uint32_t *src) {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t back = dinf::marker16_back(v[j]);
+                const bool is = (v[j] & 0x8000u) != 0u;
+                if (is && back > s0) s_bad = 1;
+                src[j] = (is && back <= s0) ? s0 - back : 0u;
+            }
+        };
+        auto word_of = [&](const uint32_t *v, const uint32_t *b) -> uint32_t {
             uint32_t w = 0;
 #pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) w |= byte_of(v[j]) << (8u * j);
-            *reinterpret_cast<uint32_t *>(base + s0 + i) = w;
+            for (uint32_t j = 0; j < 4; ++j) w |= (((v[j] & 0x8000u) ? b[j] : v[j]) & 0xFFu) << (8u * j);
+            return w;
+        };
+        uint32_t k = tid;
+        for (; k + nt < nw; k += 2u * nt) {
+            const uint32_t ia = h + 4u * k, ib = h + 4u * (k + nt);
+            uint32_t va[4], vb[4], sa[4], sb[4], ba[4], bb[4];
+            units4(ia, va);
+            units4(ib, vb);
+            sources4(va, sa);
+            sources4(vb, sb);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                ba[j] = base[sa[j]];
+                bb[j] = base[sb[j]];
+            }
+            *reinterpret_cast<uint32_t *>(base + s0 + ia) = word_of(va, ba);
+            *reinterpret_cast<uint32_t *>(base + s0 + ib) = word_of(vb, bb);
+        }
+        if (k < nw) {
+            const uint32_t ia = h + 4u * k;
+            uint32_t va[4], sa[4], ba[4];
+            units4(ia, va);
+            sources4(va, sa);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) ba[j] = base[sa[j]];
+            *reinterpret_cast<uint32_t *>(base + s0 + ia) = word_of(va, ba);
         }
         __threadfence_block();
     }
