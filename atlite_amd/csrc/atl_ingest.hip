@@ -1001,9 +1001,19 @@ struct PoolSink {
             } else if (int32_t(pos) - int32_t(dist) + int32_t(len) <= int32_t(bs) && len <= 16) {
                 const int32_t sp0 = int32_t(pos) - int32_t(dist);
                 for (uint32_t j0 = 0; j0 < len; j0 += 8) {
+                    // eight units per round trip; nothing behind the match is read (it may not be allocated).  Nearly always the
+                    // eight lie in one region: one translation (it is a tenth of this kernel's vector instructions otherwise)
                     uint32_t v[8];
+                    const uint32_t last = min(7u, len - 1u - j0);
+                    const int32_t sa = sp0 + int32_t(j0), sb = sa + int32_t(last);
+                    if (sa >= 0 && region_of(uint32_t(sa)) == region_of(uint32_t(sb))) {
+                        const uint16_t *q = pool + at(uint32_t(sa));
 #pragma unroll
-                    for (uint32_t j = 0; j < 8; ++j) v[j] = fetch(sp0 + int32_t(min(j0 + j, len - 1u)));  // (nothing behind the match is read: it may not be allocated)
+                        for (uint32_t j = 0; j < 8; ++j) v[j] = q[min(j, last)];
+                    } else {
+#pragma unroll
+                        for (uint32_t j = 0; j < 8; ++j) v[j] = fetch(sa + int32_t(min(j, last)));
+                    }
 #pragma unroll
                     for (uint32_t j = 0; j < 8; ++j)
                         if (j0 + j < len) st[rel + j0 + j] = uint16_t(v[j]);
@@ -2557,6 +2567,15 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
         }
         state->ms[3] += double(n_seg_total);  // (a count: atl_nc_ingest_times)
         if (dbg) {
+            uint64_t longest = 0, n_long = 0;  // a launch lasts at least as long as its longest segment (a lone wave: ~10 MB/s)
+            for (const OpStage &stg : op_stages)
+                for (size_t t = stg.t_base; t < stg.t_base + stg.n_task; ++t)
+                    if (h_res[t].status == dinf::kOk) {
+                        longest = std::max<uint64_t>(longest, h_res[t].o.out_end);
+                        n_long += h_res[t].o.out_end > (256u << 10);
+                    }
+            fprintf(stderr, "[atlite-hip ingest] split: the longest segment makes %llu bytes, %llu segments make more than 256 KiB\n", (unsigned long long)longest,
+                    (unsigned long long)n_long);
             uint32_t used = 0;
             ATL_HIP_TRY(hipMemcpy(&used, op_pr.next, sizeof used, hipMemcpyDeviceToHost));
             fprintf(stderr, "[atlite-hip ingest] split, one pass in %zu stage(s): %zu streams, %zu spans, %zu tasks, %zu streams chained into %zu segments; "
