@@ -41,7 +41,10 @@ constexpr int kOffBits = 8, kOffCap = 640;
 constexpr int kPreBits = 7, kPreCap = 128;
 constexpr int kQueue = 64;                      // records per batch: one per lane
 constexpr int kMaxMatch = 258;
-constexpr int kStage = 1024;                    // output bytes staged per batch (a batch ends once fewer than kMaxMatch are free)
+#ifndef ATL_STAGE
+#define ATL_STAGE 1024
+#endif
+constexpr int kStage = ATL_STAGE;               // output bytes staged per batch (a batch ends once fewer than kMaxMatch are free)
 
 enum Status : int {
     kOk = 0,
@@ -556,7 +559,7 @@ struct HostWindow {
 #endif
 // SEG (segments of a stream decoded side by side, inflate_segment below): a distance may reach `slack` bytes before `seg0`, the
 // position the segment's output starts at - whether it stays inside the chunk is known once the segments before it are.
-template <class M, class W, class Win, bool SEG = false>
+template <class M, class W, class Win, bool SEG = false, int STAGE = kStage>
 ATL_HD inline int decode_batch_wide(const Areas<M> &A, Win &win, typename M::src_t w, uint32_t n_words, uint64_t &bitpos,
                                     uint64_t src_bits, uint64_t &out_pos, uint64_t out_n, int &n_out, bool &eob, uint32_t seg0 = 0,
                                     uint32_t slack = 0) {
@@ -598,7 +601,7 @@ ATL_HD inline int decode_batch_wide(const Areas<M> &A, Win &win, typename M::src
             const bool selected = W::in(sel, k), sym = (info(k) >> 16) & 1u;
             const uint32_t olen = (info(k) >> 7) & 511u;
             rank(k) = W::below(sel, k);
-            const bool fits = sym && n + rank(k) < uint32_t(kQueue) && rel_out + cum(k) + olen <= uint32_t(kStage);
+            const bool fits = sym && n + rank(k) < uint32_t(kQueue) && rel_out + cum(k) + olen <= uint32_t(STAGE);
             miss(k) = (selected && !fits) ? 1u : 0u;
         });
         const uint64_t missing = W::ballot(miss);  // the first of these ends the batch: end of block, no code, or no room
@@ -778,7 +781,7 @@ struct SegOut {
 // Splits: bool is_split(uint64_t bit) - is a segment known to start at this block boundary?
 // start_bit: a block header (the stream's first: 16); seg0: where its output begins (count pass: 0); slack: kSegSlack, or
 // what lies before seg0 if that is less (the stream's first segment: 0).
-template <class M, class W, class Win, class Sink, class Splits>
+template <class M, class W, class Win, class Sink, class Splits, int STAGE = kStage>
 ATL_HD inline int inflate_segment(const Areas<M> &A, typename M::src_t w, uint32_t n_words, uint64_t src_n, uint64_t start_bit,
                                   uint64_t seg0, uint32_t slack, uint64_t out_n, const Splits &splits, Sink &sink, SegOut *r) {
     if (src_n < 6 || n_words == 0) return kBadHeader;
@@ -834,7 +837,7 @@ ATL_HD inline int inflate_segment(const Areas<M> &A, typename M::src_t w, uint32
             while (!eob) {
                 int n = 0;
                 const uint64_t bstart = out_pos;
-                st = decode_batch_wide<M, W, Win, true>(A, win, w, n_words, bitpos, src_bits, out_pos, out_n, n, eob, uint32_t(seg0), slack);
+                st = decode_batch_wide<M, W, Win, true, STAGE>(A, win, w, n_words, bitpos, src_bits, out_pos, out_n, n, eob, uint32_t(seg0), slack);
                 if (st) return st;
                 if (bitpos > src_bits) return kInputOverrun;
                 sink.resolve(n, bstart, out_pos);

@@ -611,7 +611,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ATL_INFLATE_
     __shared__ uint32_t s_q[2 * kQueue + 1 + 16];  // records | positions (+ 1) | window words
     __shared__ uint32_t s_sym[64];                 // base | extra bits of the length and distance symbols
     static_assert(sizeof(s_tmp) >= size_t(kStage) + 4, "staging area");
-    static_assert(sizeof(s_lit) + sizeof(s_off) + sizeof(s_tmp) + sizeof(s_cnt) + sizeof(s_q) + sizeof(s_sym) <= 5120, "32 streams per CU");
+    static_assert(ATL_STAGE != 1024 || sizeof(s_lit) + sizeof(s_off) + sizeof(s_tmp) + sizeof(s_cnt) + sizeof(s_q) + sizeof(s_sym) <= 5120, "32 streams per CU");
     const InfDesc d = desc[blockIdx.x];
     if (d.batch != kNoWait && !wait_for_batch(flags, d.batch, timeout_ticks)) {
         if (threadIdx.x == 0) {
@@ -927,6 +927,11 @@ struct ResDesc {
 // ---- ... in ONE decode pass (no count pass): a segment's output goes into regions of a pool - 8 Ki, 16 Ki, 32 Ki ... 16-bit units, taken
 // from a bump allocator as the segment grows - as one unit per byte (the byte, or a marker); when the chains are known k_gather copies
 // the segments to their places in the chunk, markers resolved on the way.
+#ifndef ATL_POOL_STAGE
+#define ATL_POOL_STAGE 1536  // (measured, T = 2000 of 16 MB streams: 496 units 0.118 s, 1024 0.093-0.104, 1536 0.090, 2048 0.090-0.091, 4096 0.102: byte planes
+                             //  with runs make long matches, a batch ends when the stage is full; beyond 2048 the LDS costs too many waves)
+#endif
+constexpr int kPoolStage = ATL_POOL_STAGE;        // output bytes staged per batch (16-bit units: twice the LDS of k_inflate's)
 constexpr uint32_t kRegionLog = 13;              // first region: 8192 units (bytes of output); region r holds 8192 << r
 constexpr uint32_t kMaxRegions = 14;             // 8192 * (2^14 - 1) = 134 MB: the longest segment (beyond: the stream goes to the host decoders)
 struct PoolRef {
@@ -941,7 +946,7 @@ __device__ __forceinline__ uint32_t region_off(uint32_t pos, uint32_t r) { retur
 
 struct PoolSink {
     WaveMem::u32p qrec, qpos;
-    WaveMem::u16p stage;   // [kStage + 4] units, word aligned
+    WaveMem::u16p stage;   // [kPoolStage + 4] units, word aligned
     WaveMem::u32p reg;     // [kMaxRegions] bases of this segment's regions
     const uint8_t *src8;
     uint16_t *pool;
@@ -1049,13 +1054,16 @@ struct PoolSink {
     }
 };
 
+#ifdef ATL_POOL_WAVES
+__attribute__((amdgpu_waves_per_eu(ATL_POOL_WAVES, ATL_POOL_WAVES)))
+#endif
 __global__ __launch_bounds__(64) void k_segments_pool(const uint8_t *__restrict__ comp, const InfDesc *__restrict__ desc,
                                                       const SegTask *__restrict__ tasks, const uint32_t *__restrict__ cands, PoolRef pr,
                                                       SegRes *__restrict__ res) {
     using namespace dinf;
     __shared__ uint16_t s_lit[kLitCap];
     __shared__ uint16_t s_off[kOffCap];
-    constexpr int kTmpWords = (2 * (kStage + 4) > 640 + 352 ? 2 * (kStage + 4) : 640 + 352) / 4 + 1;
+    constexpr int kTmpWords = (2 * (kPoolStage + 4) > 640 + 352 ? 2 * (kPoolStage + 4) : 640 + 352) / 4 + 1;
     __shared__ uint32_t s_tmp[kTmpWords];  // codes | code lengths while a table is built; the staging area (16-bit units) while symbols are decoded
     __shared__ uint32_t s_cnt[32];
     __shared__ uint32_t s_q[2 * kQueue + 1 + 16];
@@ -1086,7 +1094,7 @@ __global__ __launch_bounds__(64) void k_segments_pool(const uint8_t *__restrict_
     sink.next = pr.next;
     sink.cap = pr.cap;
     sink.regs_out = pr.regs + size_t(t.res_ix) * kMaxRegions;
-    int st = inflate_segment<WaveMem, DevWave, DevWindow, PoolSink, DevSplits>(A, (WaveMem::src_t)(comp + d.src_off), uint32_t((d.src_n + 3) / 4),
+    int st = inflate_segment<WaveMem, DevWave, DevWindow, PoolSink, DevSplits, kPoolStage>(A, (WaveMem::src_t)(comp + d.src_off), uint32_t((d.src_n + 3) / 4),
                                                                               uint64_t(d.src_n), uint64_t(t.start_bit), 0, t.slack, uint64_t(d.dst_n), splits,
                                                                               sink, &o);
     if (st == kOk && sink.full) st = kPoolFull;
