@@ -1837,10 +1837,19 @@ static int finish_slot_impl(atl_ctx *ctx, IngestState *st, Slot &sl) {
         ATL_HIP_TRY(hipEventSynchronize(sl.ev));
     }
     sl.joined = true;
-    if (sl.d_pool && sl.pool_bytes > (size_t(4) << 30)) {  // a year's pool of segment regions is tens of GB: not kept between reads
-        (void)dev_free(sl.d_pool);
-        sl.d_pool = nullptr;
-        sl.pool_bytes = 0;
+    if (sl.d_pool) {
+        // the segment scheme's pool of a year-sized read is tens of GB: kept for the next read (allocating and freeing 40 GB costs
+        // ~30 ms of a 0.35 s call) unless it is more than a quarter of the device's memory
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+            (void)hipGetLastError();
+            total_b = 0;
+        }
+        if (sl.pool_bytes > total_b / 4) {
+            (void)dev_free(sl.d_pool);
+            sl.d_pool = nullptr;
+            sl.pool_bytes = 0;
+        }
     }
     Pending &job = sl.job;
     if (!job.active) return ATL_OK;
