@@ -1156,6 +1156,9 @@ int check_launch(const char *what) {
 // chunk of output slots walked by one wave of the fused kernel
 int32_t pick_chunk_slots(const atl_ctx *ctx, int64_t n_slots, int64_t n_segs, int64_t min_chunk) {
     // aim for >= ~16 waves per CU worth of units, chunks a multiple of kBatch in [8, 64]
+    // (longer chunks - fewer re-reads of a tile's weight rows, 4-5 % of the one-cube converters' traffic - are slower for every
+    //  converter: 128 / 256 / 512 slots, C5 heat demand 0.853 -> 0.971 / 1.003 / 1.006 ms, runoff 0.858 -> 0.961 / 0.902 / 0.994, C2 pv 3.11 -> 3.20 /
+    //  3.28 / 3.40: tools/jobs/r06_chunk.sh)
     int64_t chunk = 64;
     if (const char *e = getenv("ATLITE_HIP_CHUNK")) {  // experiments: any multiple of kBatch
         const int64_t v = atoll(e);
