@@ -2161,11 +2161,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     auto launch = [&]() -> int {
         unsigned long long ticks = 2000000000ull;  // 20 s of the 100 MHz clock
         if (const char *e = getenv("ATLITE_HIP_INGEST_TIMEOUT_MS")) ticks = (unsigned long long)(std::max(1e-5, atof(e)) * 100000.0);  // (fractions allowed: tests)
-        // ($ATLITE_HIP_INGEST_LDS_PAD: bytes of dynamic LDS the launch asks for and never touches - an experiment knob that caps
-        //  the streams per CU below the 32 the kernel's own 5 kB allow)
-        unsigned pad = 0u;
-        if (const char *e = getenv("ATLITE_HIP_INGEST_LDS_PAD")) pad = unsigned(std::max(0, atoi(e)));
-        hipLaunchKernelGGL(k_inflate, dim3(unsigned(n)), dim3(64), pad, sl->st, sl->d, d_inf, sl->d_raw, d_res, h_flag, d_part, d_unp, ticks);
+        hipLaunchKernelGGL(k_inflate, dim3(unsigned(n)), dim3(64), 0, sl->st, sl->d, d_inf, sl->d_raw, d_res, h_flag, d_part, d_unp, ticks);
         ATL_HIP_TRY(hipGetLastError());
         ATL_HIP_TRY(hipEventRecord(sl->ev_t[2], sl->st));
         for (size_t k = 0; k < nm;) {  // never-written chunks: fill value / NaN (runs of one variable)
@@ -2414,7 +2410,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     // the way back) for a range of streams, then the chains of all stages are followed and ONE k_gather places them (op_finish).
     // The pool of output regions is reserved for the whole job up front (op_prepare; no room: the single stage above, count +
     // decode).  ONE stage, when the last batch has landed, is what runs.  Launching the first half's segments when half of the
-    // batches are on the device - to decode inside the DMAs - is $ATLITE_HIP_SPLIT_EARLY and was measured twice (T = 2000):
+    // batches are on the device - to decode inside the DMAs - was measured twice (T = 2000; the knob is gone, tools/jobs/r06_early.sh):
     // with the results' copy queued behind the early kernel 0.118-0.121 s against 0.096-0.101 - that copy sits at the head of a
     // copy engine's queue until the kernel ends, and the later batches' DMAs wait behind it (first to last 72 ms instead of 21);
     // with the results fetched at the end 0.107-0.108 s against 0.096-0.102: the DMAs run on, but two launches have two tails, the
@@ -2425,7 +2421,6 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     };
     std::vector<OpStage> op_stages;
     bool op_ready = false;
-    const bool op_early = getenv("ATLITE_HIP_SPLIT_EARLY") != nullptr;
     PoolRef op_pr{};
     size_t op_gseg = 0, op_rd = 0;
     auto op_prepare = [&]() -> int {
@@ -2692,10 +2687,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
         ring->busy = true;
         fed_batches = b + 1;
         rc = set_flags(false);
-        if (!rc && split) {
-            if (op_ready && op_early && nb >= 4 && b == nb / 2) rc = op_launch(0, batches[b].first);  // (an experiment: op_launch's comment)
-            if (!rc) rc = find_batch(b);
-        }
+        if (!rc && split) rc = find_batch(b);
     }
     if (!rc) rc = set_flags(true);  // the call returns when its last DMA has landed; the kernel goes on by itself
     state->ms[0] += gather_ms;
