@@ -2430,7 +2430,9 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
         double out_bytes = 0;
         for (const InfDesc &q : job.inf) out_bytes += double(q.dst_n);
         // 1.75 x the output (a segment's last region is at most half used) + a first region for every task there may be
-        const size_t cap_regions = size_t((1.75 * out_bytes) / 8192.0) + (n + 4 * n_spans) + 1024;
+        size_t cap_regions = size_t((1.75 * out_bytes) / 8192.0) + (n + 4 * n_spans) + 1024;
+        if (const char *e = getenv("ATLITE_HIP_SPLIT_POOL_PERCENT"))  // tests: a pool that runs out (its streams go to the host decoders)
+            cap_regions = std::max<size_t>(16, cap_regions * size_t(std::max(1, atoi(e))) / 100);
         if (cap_regions >= (size_t(1) << 32)) return ATL_OK;
         const size_t b_pool = cap_regions * 8192 * sizeof(uint16_t), off_regs = align_up(b_pool, 256),
                      off_next = align_up(off_regs + t_max * kMaxRegions * sizeof(uint32_t), 256);

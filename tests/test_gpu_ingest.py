@@ -326,6 +326,17 @@ def test_long_streams_are_decoded_block_by_block(ctx, tmp_path, monkeypatch, inf
                 assert segs >= n_streams, (v, segs)
                 if v.split("_")[0] in ("few", "words", "planes", "periodic"):
                     assert segs >= 2 * n_streams, (v, segs)  # a 1 MiB chunk of these is several blocks
+    # a pool of output regions that runs out: the segments that found no room fail, their streams are decoded again by the host
+    # decoders - the same bytes
+    monkeypatch.setenv("ATLITE_HIP_INFLATE_SPLIT", "1")
+    monkeypatch.delenv("ATLITE_HIP_SPLIT_PASSES", raising=False)
+    monkeypatch.setenv("ATLITE_HIP_SPLIT_POOL_PERCENT", "20")
+    d0, h0, r0 = ingest_stats(ctx)
+    for v in ("words_6", "few_6", "periodic_9"):
+        assert np.array_equal(slab(ctx, f, v, 0, T), exp[v]), v
+    d1, h1, r1 = ingest_stats(ctx)
+    assert r1 > r0 and (d1 - d0) + (r1 - r0) == 3 * (T // ct)
+    monkeypatch.delenv("ATLITE_HIP_SPLIT_POOL_PERCENT")
     # the emulation on the host (atl_inflate_probe(which = 4)) agrees about a stream written the same way
     import zlib
 
