@@ -2416,7 +2416,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     // with the results fetched at the end 0.107-0.108 s against 0.096-0.102: the DMAs run on, but two launches have two tails, the
     // finder's workgroups (46 kB of LDS) wait for the decode kernel's CUs, and the kernel is slower beside them.
     struct OpStage {
-        size_t i0, i1, t_base, n_task;
+        size_t i0, i1, t_base, n_task, n_headers = 0;
         std::vector<size_t> task0, cand0;
     };
     std::vector<OpStage> op_stages;
@@ -2480,14 +2480,24 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
         stg.task0.assign(ni + 1, 0);
         stg.cand0.assign(ni + 1, 0);
         size_t nc = c_base, ntask = t_base;
+        // Not every header has to start a segment: a few segments per wave slot fill the device, and every segment costs k_gather
+        // a step of its stream's sequence (and the pool a first region).  Every `stride`-th header of a stream is kept, so that
+        // the read has ~4 segments per slot - but no segment is made longer than eight blocks (a lone wave makes ~10 MB/s).
+        size_t n_headers = 0;
+        for (size_t k = k0; k < k1; ++k) n_headers += std::min(h_out[k * kSpanWords], kSpanSlots);
+        const size_t want_segments = size_t(ctx->n_cu) * 22 * 4;
+        const size_t stride = std::max<size_t>(1, std::min<size_t>(8, n_headers / std::max<size_t>(1, want_segments)));
+        stg.n_headers = n_headers;
         for (size_t i = i0; i < i1; ++i) {
             stg.cand0[i - i0] = nc;
             stg.task0[i - i0] = ntask;
+            size_t seen = 0;
             for (size_t k = span0[i]; k < span0[i + 1]; ++k) {
                 const uint32_t cnt = std::min(h_out[k * kSpanWords], kSpanSlots);
                 uint32_t *c = h_out + k * kSpanWords + 1;
                 std::sort(c, c + cnt);
-                for (uint32_t j = 0; j < cnt; ++j) h_cand[nc++] = c[j];
+                for (uint32_t j = 0; j < cnt; ++j)
+                    if (++seen % stride == 0) h_cand[nc++] = c[j];
             }
             const uint32_t ncs = uint32_t(nc - stg.cand0[i - i0]), c0 = uint32_t(stg.cand0[i - i0]);
             h_task[ntask] = SegTask{uint32_t(i), 16u, 0u, c0, ncs, uint32_t(ntask), 0u};
@@ -2541,9 +2551,10 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
         const uint32_t *h_cand = reinterpret_cast<const uint32_t *>(sl->h + s_cand);
         std::vector<GatherSeg> gs;
         std::vector<ResDesc> rds;
-        size_t n_seg_total = 0, n_tasks = 0;
+        size_t n_seg_total = 0, n_tasks = 0, n_headers = 0;
         for (const OpStage &stg : op_stages) {
             n_tasks += stg.n_task;
+            n_headers += stg.n_headers;
             for (size_t i = stg.i0; i < stg.i1; ++i) {
                 const size_t li = i - stg.i0, g0 = gs.size();
                 uint64_t at = 0;
@@ -2592,8 +2603,9 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
                     (unsigned long long)n_long);
             uint32_t used = 0;
             ATL_HIP_TRY(hipMemcpy(&used, op_pr.next, sizeof used, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[atlite-hip ingest] split, one pass in %zu stage(s): %zu streams, %zu spans, %zu tasks, %zu streams chained into %zu segments; "
-                    "the pool: %u of %u regions of 16 KiB used\n", op_stages.size(), n, n_spans, n_tasks, rds.size(), n_seg_total, used, op_pr.cap);
+            fprintf(stderr, "[atlite-hip ingest] split, one pass in %zu stage(s): %zu streams, %zu spans, %zu block headers, %zu tasks, %zu streams chained into "
+                    "%zu segments; the pool: %u of %u regions of 16 KiB used\n", op_stages.size(), n, n_spans, n_headers, n_tasks, rds.size(), n_seg_total, used,
+                    op_pr.cap);
         }
         if (!rds.empty()) {
             ATL_REQUIRE(gs.size() <= t_max + n + 1 && rds.size() <= n, "atl_nc_read_slabs: segment lists");
