@@ -1110,8 +1110,9 @@ struct GatherSeg {
 };
 // one workgroup per stream: segment after segment, pool units -> bytes of the chunk (markers: the byte `back` before the segment's
 // start, final by then), then the chunk's Adler-32.  segs[bound0 .. bound0 + n_seg) and one more entry whose start is the chunk's end.
+// adler_here = 0: chunks too long for one workgroup's Adler-32 (256 MB: 40 ms) - k_adler_parts / k_adler_final follow
 __global__ __launch_bounds__(1024) void k_gather(const InfDesc *__restrict__ desc, const ResDesc *__restrict__ rds, const GatherSeg *__restrict__ segs,
-                                                 PoolRef pr, uint8_t *__restrict__ raw, InfResult *__restrict__ res) {
+                                                 PoolRef pr, uint8_t *__restrict__ raw, InfResult *__restrict__ res, int adler_here) {
     const ResDesc rd = rds[blockIdx.x];
     const InfDesc d = desc[rd.stream];
     uint8_t *base = raw + d.dst_off;
@@ -1203,6 +1204,13 @@ __global__ __launch_bounds__(1024) void k_gather(const InfDesc *__restrict__ des
         __threadfence_block();
     }
     __syncthreads();
+    if (!adler_here) {
+        if (tid == 0) {
+            res[rd.stream].status = s_bad ? int32_t(dinf::kBadDistance) : int32_t(dinf::kOk);  // (k_adler_final has the last word)
+            res[rd.stream].adler_want = rd.adler_want;
+        }
+        return;
+    }
     // Adler-32 (wave_adler's sums, the whole workgroup)
     const uint64_t n = uint64_t(d.dst_n), n16 = n / 16;
     unsigned long long s1 = 0, s2 = 0;
@@ -1354,6 +1362,64 @@ __global__ __launch_bounds__(1024) void k_resolve(const InfDesc *__restrict__ de
         res[rd.stream].status = s_bad ? int32_t(dinf::kBadDistance) : got == rd.adler_want ? int32_t(dinf::kOk) : int32_t(dinf::kAdler);
         res[rd.stream].adler_want = rd.adler_want;
     }
+}
+
+// Adler-32 of long chunks by many workgroups: partial sums of 4 MiB pieces (weights n - i: the chunk's own), added up per stream
+constexpr uint64_t kAdlerPiece = uint64_t(4) << 20;
+__global__ __launch_bounds__(256) void k_adler_parts(const InfDesc *__restrict__ desc, const ResDesc *__restrict__ rds, const uint8_t *__restrict__ raw,
+                                                     unsigned long long *__restrict__ acc) {
+    const ResDesc rd = rds[blockIdx.y];
+    const InfDesc d = desc[rd.stream];
+    const uint64_t n = uint64_t(d.dst_n), p0 = uint64_t(blockIdx.x) * kAdlerPiece;
+    if (p0 >= n) return;
+    const uint64_t p1 = min(n, p0 + kAdlerPiece);
+    const uint8_t *base = raw + d.dst_off;
+    const uint32_t tid = threadIdx.x;
+    unsigned long long s1 = 0, s2 = 0;
+    for (uint64_t i = p0 / 16 + tid; i < p1 / 16; i += 256) {  // (pieces begin at multiples of 16; the last one's tail below)
+        const uint4 v = reinterpret_cast<const uint4 *>(base)[i];
+        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+        uint32_t sum = 0, wsum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t b = (wds[q] >> (8 * k)) & 0xFFu;
+                sum += b;
+                wsum += uint32_t(4 * q + k) * b;
+            }
+        s1 += sum;
+        s2 += (n - i * 16) * sum - wsum;
+    }
+    for (uint64_t i = (p1 / 16) * 16 + tid; i < p1; i += 256) {
+        s1 += base[i];
+        s2 += (n - i) * base[i];
+    }
+    s1 %= 65521ull;
+    s2 %= 65521ull;
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    __shared__ unsigned long long r1[4], r2[4];
+    if ((tid & 63u) == 0) {
+        r1[tid >> 6] = s1;
+        r2[tid >> 6] = s2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(acc + 2 * size_t(blockIdx.y), (r1[0] + r1[1] + r1[2] + r1[3]) % 65521ull);
+        atomicAdd(acc + 2 * size_t(blockIdx.y) + 1, (r2[0] + r2[1] + r2[2] + r2[3]) % 65521ull);
+    }
+}
+__global__ void k_adler_final(const InfDesc *__restrict__ desc, const ResDesc *__restrict__ rds, uint32_t n_rd, const unsigned long long *__restrict__ acc,
+                              InfResult *__restrict__ res) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_rd) return;
+    const ResDesc rd = rds[k];
+    const uint64_t n = uint64_t(desc[rd.stream].dst_n);
+    const uint32_t a = uint32_t((1 + acc[2 * size_t(k)]) % 65521ull), b = uint32_t((n % 65521ull + acc[2 * size_t(k) + 1] % 65521ull) % 65521ull);
+    if (res[rd.stream].status == int32_t(dinf::kOk) && ((b << 16) | a) != rd.adler_want) res[rd.stream].status = int32_t(dinf::kAdler);
 }
 
 // ---- per-context staging: kSlots slots, each {pinned host, device raw, descriptor buffers, event, stream} -------------
@@ -2422,7 +2488,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     std::vector<OpStage> op_stages;
     bool op_ready = false;
     PoolRef op_pr{};
-    size_t op_gseg = 0, op_rd = 0;
+    size_t op_gseg = 0, op_rd = 0, op_acc = 0;
     auto op_prepare = [&]() -> int {
         if (!split) return ATL_OK;
         if (const char *e = getenv("ATLITE_HIP_SPLIT_PASSES"))
@@ -2438,7 +2504,8 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
                      off_next = align_up(off_regs + t_max * kMaxRegions * sizeof(uint32_t), 256);
         op_gseg = off_next + 256;
         op_rd = align_up(op_gseg + (t_max + n + 1) * sizeof(GatherSeg), 256);
-        const size_t need = op_rd + (n + 1) * sizeof(ResDesc) + 256;
+        op_acc = align_up(op_rd + (n + 1) * sizeof(ResDesc), 256);
+        const size_t need = op_acc + 2 * (n + 1) * sizeof(unsigned long long) + 256;
         if (sl->pool_bytes < need) {
             if (sl->d_pool) (void)dev_free(sl->d_pool);
             sl->d_pool = nullptr;
@@ -2480,12 +2547,12 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
         stg.task0.assign(ni + 1, 0);
         stg.cand0.assign(ni + 1, 0);
         size_t nc = c_base, ntask = t_base;
-        // Not every header has to start a segment: a few segments per wave slot fill the device, and every segment costs k_gather
-        // a step of its stream's sequence (and the pool a first region).  Every `stride`-th header of a stream is kept, so that
-        // the read has ~4 segments per slot - but no segment is made longer than eight blocks (a lone wave makes ~10 MB/s).
+        // Not every header has to start a segment: some segments per wave slot fill the device evenly, and every segment costs
+        // k_gather a step of its stream's sequence (and the pool a first region).  Every `stride`-th header of a stream is kept, so
+        // that the read has ~16 segments per slot (4: long segments, an uneven last round) - never longer than eight blocks.
         size_t n_headers = 0;
         for (size_t k = k0; k < k1; ++k) n_headers += std::min(h_out[k * kSpanWords], kSpanSlots);
-        const size_t want_segments = size_t(ctx->n_cu) * 22 * 4;
+        const size_t want_segments = size_t(ctx->n_cu) * 22 * 16;  // (measured 4 / 8 / 16 / all: profiles/r06_ingest.txt)
         const size_t stride = std::max<size_t>(1, std::min<size_t>(8, n_headers / std::max<size_t>(1, want_segments)));
         stg.n_headers = n_headers;
         for (size_t i = i0; i < i1; ++i) {
@@ -2612,9 +2679,22 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
             ATL_HIP_TRY(hipMemcpyAsync(sl->d_pool + op_gseg, gs.data(), gs.size() * sizeof(GatherSeg), hipMemcpyHostToDevice, q2));
             ATL_HIP_TRY(hipMemcpyAsync(sl->d_pool + op_rd, rds.data(), rds.size() * sizeof(ResDesc), hipMemcpyHostToDevice, q2));
             ATL_HIP_TRY(hipStreamSynchronize(q2));  // (the lists are on the stack)
-            hipLaunchKernelGGL(k_gather, dim3(unsigned(rds.size())), dim3(1024), 0, q2, d_inf, reinterpret_cast<const ResDesc *>(sl->d_pool + op_rd),
-                               reinterpret_cast<const GatherSeg *>(sl->d_pool + op_gseg), op_pr, sl->d_raw, d_res);
+            // chunks beyond 32 MiB: their Adler-32 by many workgroups behind the gather (one workgroup needs 40 ms for 256 MB)
+            uint64_t longest_chunk = 0;
+            for (const ResDesc &rd : rds) longest_chunk = std::max<uint64_t>(longest_chunk, uint64_t(jn[rd.stream].dst_n));
+            const bool adler_here = longest_chunk <= (uint64_t(32) << 20);
+            const ResDesc *d_rds = reinterpret_cast<const ResDesc *>(sl->d_pool + op_rd);
+            hipLaunchKernelGGL(k_gather, dim3(unsigned(rds.size())), dim3(1024), 0, q2, d_inf, d_rds, reinterpret_cast<const GatherSeg *>(sl->d_pool + op_gseg),
+                               op_pr, sl->d_raw, d_res, adler_here ? 1 : 0);
             ATL_HIP_TRY(hipGetLastError());
+            if (!adler_here) {
+                unsigned long long *d_acc = reinterpret_cast<unsigned long long *>(sl->d_pool + op_acc);
+                ATL_HIP_TRY(hipMemsetAsync(d_acc, 0, 2 * rds.size() * sizeof(unsigned long long), q2));
+                hipLaunchKernelGGL(k_adler_parts, dim3(unsigned((longest_chunk + kAdlerPiece - 1) / kAdlerPiece), unsigned(rds.size())), dim3(256), 0, q2, d_inf,
+                                   d_rds, sl->d_raw, d_acc);
+                hipLaunchKernelGGL(k_adler_final, dim3(unsigned((rds.size() + 255) / 256)), dim3(256), 0, q2, d_inf, d_rds, uint32_t(rds.size()), d_acc, d_res);
+                ATL_HIP_TRY(hipGetLastError());
+            }
         }
         ATL_HIP_TRY(hipEventRecord(sl->ev_st2, q2));
         ATL_HIP_TRY(hipStreamWaitEvent(sl->st, sl->ev_st2, 0));  // the slot's stream goes on behind the gather: unpack, verdicts
