@@ -1105,103 +1105,121 @@ __global__ __launch_bounds__(64) void k_segments_pool(const uint8_t *__restrict_
 }
 
 struct GatherSeg {
-    uint32_t task;   // whose regions (PoolRef::regs)
-    uint32_t start;  // where the segment's bytes go in the chunk
+    uint32_t task;    // whose regions (PoolRef::regs); kNoTask: the entry behind a stream's last segment (its start = the chunk's end)
+    uint32_t start;   // where the segment's bytes go in the chunk
+    uint32_t stream;  // (k_gather_rest)
+    uint32_t pad;
 };
-// one workgroup per stream: segment after segment, pool units -> bytes of the chunk (markers: the byte `back` before the segment's
-// start, final by then), then the chunk's Adler-32.  segs[bound0 .. bound0 + n_seg) and one more entry whose start is the chunk's end.
-// adler_here = 0: chunks too long for one workgroup's Adler-32 (256 MB: 40 ms) - k_adler_parts / k_adler_final follow
+constexpr uint32_t kNoTask = 0xFFFFFFFFu;
+constexpr uint32_t kWindow = 32768;  // DEFLATE's: a marker points at most this far before its segment's start
+
+// Bytes [lo, hi) of a segment that starts at s0 of the chunk at `base`: pool units -> bytes, a marker -> the byte `back` before s0
+// (final by then).  By all nt threads of the caller; s_reg: the segment's region bases (LDS), *bad: a marker that points before the chunk.
+__device__ __forceinline__ void gather_range(uint8_t *__restrict__ base, uint32_t s0, uint32_t lo, uint32_t hi, const uint32_t *s_reg, const PoolRef &pr,
+                                             uint32_t tid, uint32_t nt, int *bad) {
+    auto unit = [&](uint32_t i) -> uint32_t {
+        const uint32_t r = region_of(i);
+        return pr.pool[(size_t(s_reg[r]) << kRegionLog) + region_off(i, r)];
+    };
+    auto byte_of = [&](uint32_t v) -> uint32_t {
+        if (!(v & 0x8000u)) return v & 0xFFu;
+        const uint32_t back = dinf::marker16_back(v);
+        if (back > s0) {
+            *bad = 1;
+            return 0u;
+        }
+        return base[s0 - back];
+    };
+    // four bytes per thread where the chunk's words allow: the head up to a word boundary and the tail byte by byte
+    const uint32_t len = hi - lo;
+    const uint32_t h = lo + min((4u - ((s0 + lo) & 3u)) & 3u, len), nw = (hi - h) >> 2, t0 = h + 4u * nw;
+    if (lo + tid < h) base[s0 + lo + tid] = uint8_t(byte_of(unit(lo + tid)));
+    if (tid >= 32 && t0 + (tid - 32) < hi) base[s0 + t0 + (tid - 32)] = uint8_t(byte_of(unit(t0 + (tid - 32))));
+    // the four units of a word: loaded together, then the markers' source bytes together (they lie before s0: final), one store
+    auto units4 = [&](uint32_t i, uint32_t *v) {
+        if ((i & 1u) == 0u) {  // two aligned pairs (a pair never straddles regions: they begin at multiples of 8192)
+            auto pair = [&](uint32_t p) -> uint32_t {
+                const uint32_t r = region_of(p);
+                return *reinterpret_cast<const uint32_t *>(pr.pool + (size_t(s_reg[r]) << kRegionLog) + region_off(p, r));
+            };
+            const uint32_t a = pair(i), b = pair(i + 2u);
+            v[0] = a & 0xFFFFu;
+            v[1] = a >> 16;
+            v[2] = b & 0xFFFFu;
+            v[3] = b >> 16;
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) v[j] = unit(i + j);
+        }
+    };
+    auto sources4 = [&](const uint32_t *v, uint32_t *src) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t back = dinf::marker16_back(v[j]);
+            const bool is = (v[j] & 0x8000u) != 0u;
+            if (is && back > s0) *bad = 1;
+            src[j] = (is && back <= s0) ? s0 - back : 0u;
+        }
+    };
+    auto word_of = [&](const uint32_t *v, const uint32_t *b) -> uint32_t {
+        uint32_t w = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) w |= (((v[j] & 0x8000u) ? b[j] : v[j]) & 0xFFu) << (8u * j);
+        return w;
+    };
+    uint32_t k = tid;
+    constexpr uint32_t Q = 4;  // words per step: their unit loads, then their source loads, in flight together (8: 128 VGPRs, the sequence 52 -> 61 ms)
+    for (; k + (Q - 1u) * nt < nw; k += Q * nt) {
+        uint32_t v[Q][4], sx[Q][4], bx[Q][4];
+#pragma unroll
+        for (uint32_t q = 0; q < Q; ++q) units4(h + 4u * (k + q * nt), v[q]);
+#pragma unroll
+        for (uint32_t q = 0; q < Q; ++q) sources4(v[q], sx[q]);
+#pragma unroll
+        for (uint32_t q = 0; q < Q; ++q)
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) bx[q][j] = base[sx[q][j]];
+#pragma unroll
+        for (uint32_t q = 0; q < Q; ++q) *reinterpret_cast<uint32_t *>(base + s0 + h + 4u * (k + q * nt)) = word_of(v[q], bx[q]);
+    }
+    for (; k < nw; k += nt) {
+        const uint32_t ia = h + 4u * k;
+        uint32_t va[4], sa[4], ba[4];
+        units4(ia, va);
+        sources4(va, sa);
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) ba[j] = base[sa[j]];
+        *reinterpret_cast<uint32_t *>(base + s0 + ia) = word_of(va, ba);
+    }
+}
+
+// One workgroup per stream, segment after segment: a segment's markers point into the kWindow bytes before its start, which must be
+// final - but only a segment's LAST kWindow bytes are anybody's window.  So the sequence places just those (tails = 1: a third of the
+// bytes of 100 KB segments, and the step is what a long stream's gather costs); k_gather_rest places what lies before them, all segments at
+// once, when the sequence is through.  Then the chunk's Adler-32: here, or (adler_here = 0: chunks too long for one workgroup, 256 MB: 40 ms)
+// by k_adler_parts / k_adler_final.  segs[bound0 .. bound0 + n_seg) and one more entry whose start is the chunk's end.
 __global__ __launch_bounds__(1024) void k_gather(const InfDesc *__restrict__ desc, const ResDesc *__restrict__ rds, const GatherSeg *__restrict__ segs,
-                                                 PoolRef pr, uint8_t *__restrict__ raw, InfResult *__restrict__ res, int adler_here) {
+                                                 PoolRef pr, uint8_t *__restrict__ raw, InfResult *__restrict__ res, int adler_here, int tails) {
     const ResDesc rd = rds[blockIdx.x];
     const InfDesc d = desc[rd.stream];
     uint8_t *base = raw + d.dst_off;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     __shared__ int s_bad;
-    __shared__ uint32_t s_reg[kMaxRegions];
+    __shared__ uint32_t s_reg[2][kMaxRegions];  // this segment's regions | the next one's, fetched while this one is placed
     if (tid == 0) s_bad = 0;
+    GatherSeg g = segs[rd.bound0], g1 = segs[rd.bound0 + 1];
+    if (tid < kMaxRegions) s_reg[0][tid] = pr.regs[size_t(g.task) * kMaxRegions + tid];
     for (uint32_t c = 0; c < rd.n_seg; ++c) {
-        const GatherSeg g = segs[rd.bound0 + c];
-        const uint32_t s0 = g.start, len = segs[rd.bound0 + c + 1].start - s0;
-        __syncthreads();  // (the previous segment's bytes are written, its regions no longer read)
-        if (tid < kMaxRegions) s_reg[tid] = pr.regs[size_t(g.task) * kMaxRegions + tid];
-        __syncthreads();
-        auto unit = [&](uint32_t i) -> uint32_t {
-            const uint32_t r = region_of(i);
-            return pr.pool[(size_t(s_reg[r]) << kRegionLog) + region_off(i, r)];
-        };
-        auto byte_of = [&](uint32_t v) -> uint32_t {
-            if (!(v & 0x8000u)) return v & 0xFFu;
-            const uint32_t back = dinf::marker16_back(v);
-            if (back > s0) {
-                s_bad = 1;
-                return 0u;
-            }
-            return base[s0 - back];
-        };
-        // four bytes per thread where the chunk's words allow: the head up to a word boundary and the tail byte by byte
-        const uint32_t h = min((4u - (s0 & 3u)) & 3u, len), nw = (len - h) >> 2, t0 = h + 4u * nw;
-        if (tid < h) base[s0 + tid] = uint8_t(byte_of(unit(tid)));
-        if (tid >= 32 && tid - 32 < len - t0) base[s0 + t0 + (tid - 32)] = uint8_t(byte_of(unit(t0 + (tid - 32))));
-        // the four units of a word: loaded together, then the markers' source bytes together (they lie before s0: final), one store;
-        // two words per step
-        auto units4 = [&](uint32_t i, uint32_t *v) {
-            if ((i & 1u) == 0u) {  // two aligned pairs (a pair never straddles regions: they begin at multiples of 8192)
-                auto pair = [&](uint32_t p) -> uint32_t {
-                    const uint32_t r = region_of(p);
-                    return *reinterpret_cast<const uint32_t *>(pr.pool + (size_t(s_reg[r]) << kRegionLog) + region_off(p, r));
-                };
-                const uint32_t a = pair(i), b = pair(i + 2u);
-                v[0] = a & 0xFFFFu;
-                v[1] = a >> 16;
-                v[2] = b & 0xFFFFu;
-                v[3] = b >> 16;
-            } else {
-#pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) v[j] = unit(i + j);
-            }
-        };
-        auto sources4 = [&](const uint32_t *v, uint32_t *src) {
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) {
-                const uint32_t back = dinf::marker16_back(v[j]);
-                const bool is = (v[j] & 0x8000u) != 0u;
-                if (is && back > s0) s_bad = 1;
-                src[j] = (is && back <= s0) ? s0 - back : 0u;
-            }
-        };
-        auto word_of = [&](const uint32_t *v, const uint32_t *b) -> uint32_t {
-            uint32_t w = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) w |= (((v[j] & 0x8000u) ? b[j] : v[j]) & 0xFFu) << (8u * j);
-            return w;
-        };
-        uint32_t k = tid;
-        for (; k + nt < nw; k += 2u * nt) {
-            const uint32_t ia = h + 4u * k, ib = h + 4u * (k + nt);
-            uint32_t va[4], vb[4], sa[4], sb[4], ba[4], bb[4];
-            units4(ia, va);
-            units4(ib, vb);
-            sources4(va, sa);
-            sources4(vb, sb);
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) {
-                ba[j] = base[sa[j]];
-                bb[j] = base[sb[j]];
-            }
-            *reinterpret_cast<uint32_t *>(base + s0 + ia) = word_of(va, ba);
-            *reinterpret_cast<uint32_t *>(base + s0 + ib) = word_of(vb, bb);
-        }
-        if (k < nw) {
-            const uint32_t ia = h + 4u * k;
-            uint32_t va[4], sa[4], ba[4];
-            units4(ia, va);
-            sources4(va, sa);
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) ba[j] = base[sa[j]];
-            *reinterpret_cast<uint32_t *>(base + s0 + ia) = word_of(va, ba);
-        }
+        const uint32_t s0 = g.start, len = g1.start - s0;
+        __syncthreads();  // (the previous segment's bytes are written; this one's regions are in)
+        const GatherSeg g2 = segs[rd.bound0 + min(c + 2u, rd.n_seg)];
+        uint32_t next_reg = 0;
+        if (tid < kMaxRegions && g1.task != kNoTask) next_reg = pr.regs[size_t(g1.task) * kMaxRegions + tid];
+        gather_range(base, s0, (tails && len > kWindow) ? len - kWindow : 0u, len, s_reg[c & 1u], pr, tid, nt, &s_bad);
+        if (tid < kMaxRegions) s_reg[(c + 1u) & 1u][tid] = next_reg;
         __threadfence_block();
+        g = g1;
+        g1 = g2;
     }
     __syncthreads();
     if (!adler_here) {
@@ -1362,6 +1380,27 @@ __global__ __launch_bounds__(1024) void k_resolve(const InfDesc *__restrict__ de
         res[rd.stream].status = s_bad ? int32_t(dinf::kBadDistance) : got == rd.adler_want ? int32_t(dinf::kOk) : int32_t(dinf::kAdler);
         res[rd.stream].adler_want = rd.adler_want;
     }
+}
+
+// ... what lies before a segment's last kWindow bytes: pieces of at most kRestPiece bytes, a workgroup each, all at once (every window is
+// final).  (A workgroup per SEGMENT took 54 ms for a read whose longest segments - blocks of 258-byte matches - make tens of MB.)
+struct GatherPiece {
+    uint32_t seg, lo, hi, pad;  // bytes [lo, hi) of segment segs[seg]
+};
+constexpr uint32_t kRestPiece = 256u << 10;
+__global__ __launch_bounds__(256) void k_gather_rest(const InfDesc *__restrict__ desc, const GatherSeg *__restrict__ segs, const GatherPiece *__restrict__ pieces,
+                                                     PoolRef pr, uint8_t *__restrict__ raw, InfResult *__restrict__ res) {
+    const GatherPiece pc = pieces[blockIdx.x];
+    const GatherSeg g = segs[pc.seg];
+    __shared__ int s_bad;
+    __shared__ uint32_t s_reg[kMaxRegions];
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_bad = 0;
+    if (tid < kMaxRegions) s_reg[tid] = pr.regs[size_t(g.task) * kMaxRegions + tid];
+    __syncthreads();
+    gather_range(raw + desc[g.stream].dst_off, g.start, pc.lo, pc.hi, s_reg, pr, tid, 256u, &s_bad);
+    __syncthreads();
+    if (tid == 0 && s_bad) res[g.stream].status = int32_t(dinf::kBadDistance);
 }
 
 // Adler-32 of long chunks by many workgroups: partial sums of 4 MiB pieces (weights n - i: the chunk's own), added up per stream
@@ -2488,7 +2527,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
     std::vector<OpStage> op_stages;
     bool op_ready = false;
     PoolRef op_pr{};
-    size_t op_gseg = 0, op_rd = 0, op_acc = 0;
+    size_t op_gseg = 0, op_rd = 0, op_acc = 0, op_piece = 0, op_piece_cap = 0;
     auto op_prepare = [&]() -> int {
         if (!split) return ATL_OK;
         if (const char *e = getenv("ATLITE_HIP_SPLIT_PASSES"))
@@ -2505,7 +2544,9 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
         op_gseg = off_next + 256;
         op_rd = align_up(op_gseg + (t_max + n + 1) * sizeof(GatherSeg), 256);
         op_acc = align_up(op_rd + (n + 1) * sizeof(ResDesc), 256);
-        const size_t need = op_acc + 2 * (n + 1) * sizeof(unsigned long long) + 256;
+        op_piece = align_up(op_acc + 2 * (n + 1) * sizeof(unsigned long long), 256);
+        op_piece_cap = t_max + n + size_t(out_bytes / double(kRestPiece)) + 16;
+        const size_t need = op_piece + op_piece_cap * sizeof(GatherPiece) + 256;
         if (sl->pool_bytes < need) {
             if (sl->d_pool) (void)dev_free(sl->d_pool);
             sl->d_pool = nullptr;
@@ -2634,7 +2675,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
                         ok = false;
                         break;
                     }
-                    gs.push_back(GatherSeg{uint32_t(t), uint32_t(at)});
+                    gs.push_back(GatherSeg{uint32_t(t), uint32_t(at), uint32_t(i), 0u});
                     at += r.o.out_end;
                     if (r.o.is_final) {
                         want = r.o.adler;
@@ -2654,7 +2695,7 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
                 }
                 rds.push_back(ResDesc{uint32_t(i), uint32_t(g0), uint32_t(gs.size() - g0), want});
                 n_seg_total += gs.size() - g0;
-                gs.push_back(GatherSeg{0u, uint32_t(at)});
+                gs.push_back(GatherSeg{kNoTask, uint32_t(at), uint32_t(i), 0u});
             }
         }
         state->ms[3] += double(n_seg_total);  // (a count: atl_nc_ingest_times)
@@ -2676,17 +2717,33 @@ int read_group_device(atl_ctx *ctx, atl_nc *f, int n_vars, const char *const *na
         }
         if (!rds.empty()) {
             ATL_REQUIRE(gs.size() <= t_max + n + 1 && rds.size() <= n, "atl_nc_read_slabs: segment lists");
-            ATL_HIP_TRY(hipMemcpyAsync(sl->d_pool + op_gseg, gs.data(), gs.size() * sizeof(GatherSeg), hipMemcpyHostToDevice, q2));
-            ATL_HIP_TRY(hipMemcpyAsync(sl->d_pool + op_rd, rds.data(), rds.size() * sizeof(ResDesc), hipMemcpyHostToDevice, q2));
-            ATL_HIP_TRY(hipStreamSynchronize(q2));  // (the lists are on the stack)
-            // chunks beyond 32 MiB: their Adler-32 by many workgroups behind the gather (one workgroup needs 40 ms for 256 MB)
+            // long streams (chunks beyond 4 MiB): the sequence places the segments' last 32 KiB only, the rest follows at once, in pieces
             uint64_t longest_chunk = 0;
             for (const ResDesc &rd : rds) longest_chunk = std::max<uint64_t>(longest_chunk, uint64_t(jn[rd.stream].dst_n));
-            const bool adler_here = longest_chunk <= (uint64_t(32) << 20);
+            const bool tails = longest_chunk > (uint64_t(4) << 20);
+            std::vector<GatherPiece> pcs;
+            if (tails)
+                for (size_t g = 0; g + 1 < gs.size(); ++g) {
+                    if (gs[g].task == kNoTask) continue;
+                    const uint32_t len = gs[g + 1].start - gs[g].start;
+                    if (len <= kWindow) continue;
+                    for (uint32_t lo = 0; lo < len - kWindow; lo += kRestPiece) pcs.push_back(GatherPiece{uint32_t(g), lo, std::min(lo + kRestPiece, len - kWindow), 0u});
+                }
+            ATL_REQUIRE(pcs.size() <= op_piece_cap, "atl_nc_read_slabs: piece list");
+            ATL_HIP_TRY(hipMemcpyAsync(sl->d_pool + op_gseg, gs.data(), gs.size() * sizeof(GatherSeg), hipMemcpyHostToDevice, q2));
+            ATL_HIP_TRY(hipMemcpyAsync(sl->d_pool + op_rd, rds.data(), rds.size() * sizeof(ResDesc), hipMemcpyHostToDevice, q2));
+            if (!pcs.empty()) ATL_HIP_TRY(hipMemcpyAsync(sl->d_pool + op_piece, pcs.data(), pcs.size() * sizeof(GatherPiece), hipMemcpyHostToDevice, q2));
+            ATL_HIP_TRY(hipStreamSynchronize(q2));  // (the lists are on the stack)
             const ResDesc *d_rds = reinterpret_cast<const ResDesc *>(sl->d_pool + op_rd);
-            hipLaunchKernelGGL(k_gather, dim3(unsigned(rds.size())), dim3(1024), 0, q2, d_inf, d_rds, reinterpret_cast<const GatherSeg *>(sl->d_pool + op_gseg),
-                               op_pr, sl->d_raw, d_res, adler_here ? 1 : 0);
+            const GatherSeg *d_gs = reinterpret_cast<const GatherSeg *>(sl->d_pool + op_gseg);
+            const bool adler_here = !tails;  // (long chunks: the Adler-32 by many workgroups behind the gather)
+            hipLaunchKernelGGL(k_gather, dim3(unsigned(rds.size())), dim3(1024), 0, q2, d_inf, d_rds, d_gs, op_pr, sl->d_raw, d_res, adler_here ? 1 : 0, tails ? 1 : 0);
             ATL_HIP_TRY(hipGetLastError());
+            if (tails && !pcs.empty()) {
+                hipLaunchKernelGGL(k_gather_rest, dim3(unsigned(pcs.size())), dim3(256), 0, q2, d_inf, d_gs,
+                                   reinterpret_cast<const GatherPiece *>(sl->d_pool + op_piece), op_pr, sl->d_raw, d_res);
+                ATL_HIP_TRY(hipGetLastError());
+            }
             if (!adler_here) {
                 unsigned long long *d_acc = reinterpret_cast<unsigned long long *>(sl->d_pool + op_acc);
                 ATL_HIP_TRY(hipMemsetAsync(d_acc, 0, 2 * rds.size() * sizeof(unsigned long long), q2));
