@@ -119,6 +119,23 @@ def _memory_twin(path):
 
 @pytest.mark.parametrize("fname,steps", [("cutout_small_f32", None), ("cutout_small_f32", "7"), ("cutout_small_f64", "9")])
 def test_conversions_from_file(monkeypatch, fname, steps):
+    _conversions_from_file(monkeypatch, fname, steps)
+
+
+@pytest.mark.parametrize("passes", [None, "2"])
+def test_conversions_from_file_block_by_block(monkeypatch, inflate_mode, passes):
+    """The same conversions with every device read decoded block by block (the scheme of long chunk streams forced on these small
+    ones: one decode pass into the pool of regions, and count + decode): pv, wind, runoff, heat demand, temperatures from the file
+    == from memory."""
+    if inflate_mode != "device":
+        pytest.skip("the device decoder's scheme")
+    monkeypatch.setenv("ATLITE_HIP_INFLATE_SPLIT", "1")
+    if passes:
+        monkeypatch.setenv("ATLITE_HIP_SPLIT_PASSES", passes)
+    _conversions_from_file(monkeypatch, "cutout_small_f32", "7")
+
+
+def _conversions_from_file(monkeypatch, fname, steps):
     if steps:
         monkeypatch.setenv("ATLITE_HIP_SLAB_STEPS", steps)  # slabs that do NOT line up with the chunks
     cf, cm, data = _memory_twin(f"{NC}/{fname}.nc")
